@@ -1,0 +1,154 @@
+/* nrs.h -- C ABI of the MI355X-native NR-SLAM hot path (libnrs_hip.so).
+ *
+ * The reference (endomapper/NR-SLAM) has no FFI; its seam is a handful of C++ free functions and
+ * two classes.  Each entry point below replaces the *body* of one of them; the C++
+ * shim in nr-slam_amd/host/ keeps the reference signatures, flattens Frame/Map/KeyFrame into the
+ * plain arrays declared here and calls through.
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative nrs_status; nothing throws across the ABI;
+ *     nrs_last_error(ctx) gives a human-readable message for the last failure on that context.
+ *   - host pointers are caller-owned and only read/written during the call; the context owns all
+ *     device memory and one HIP stream; a context is NOT thread-safe (the reference calls these
+ *     functions from its single main thread, modules/SLAM/system.cc:113-132).
+ *   - poses are double[7] = {qx,qy,qz,qw,tx,ty,tz} of T_camera_world, i.e. what the reference
+ *     hands to g2o::SE3Quat (modules/optimization/g2o_optimization.cc:68-71,165-168,907-910).
+ *   - camera model: 0 = PinHole (fx fy cx cy), 1 = KannalaBrandt8 (fx fy cx cy k0 k1 k2 k3)
+ *     (modules/calibration/pin_hole.cc:22-25, kannala_brandt_8.cc:25-32).
+ *   - LandmarkStatus values are the reference's (modules/utilities/landmark_status.h:23-30).
+ *   - there is no CPU fallback: every compute entry point fails with NRS_ERR_NO_DEVICE when no
+ *     HIP device is usable.
+ */
+#ifndef NRS_H
+#define NRS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRS_VERSION 100
+
+typedef enum {
+    NRS_OK = 0,
+    NRS_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, index out of range) */
+    NRS_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime error at context creation    */
+    NRS_ERR_HIP = -3,         /* HIP runtime error during the call (message in nrs_last_error)    */
+    NRS_ERR_ALLOC = -4,       /* host or device allocation failed                                 */
+    NRS_ERR_STATE = -5,       /* call sequence error (e.g. optimize before upload)                */
+    NRS_ERR_NUMERIC = -6      /* non-finite values reached the solver                             */
+} nrs_status;
+
+typedef enum { NRS_CAM_PINHOLE = 0, NRS_CAM_KB8 = 1 } nrs_camera_model;
+
+/* LandmarkStatus (modules/utilities/landmark_status.h:23-30) */
+enum { NRS_TRACKED_WITH_3D = 0, NRS_TRACKED = 1, NRS_JUST_TRIANGULATED = 2, NRS_BAD = 3,
+       NRS_OUT_IMAGE_BOUNDARIES = 4, NRS_BAD_FEATURE = 5 };
+
+/* RegularizationGraph::Status (modules/map/regularization_graph.h:42-47) */
+enum { NRS_GRAPH_VERIFIED = 0, NRS_GRAPH_NEIGHBOR = 1, NRS_GRAPH_NEUTRAL = 2, NRS_GRAPH_BAD = 3 };
+
+typedef struct nrs_ctx nrs_ctx;
+
+typedef struct {
+    int32_t model;            /* nrs_camera_model */
+    float params[8];
+} nrs_camera;
+
+typedef struct {
+    int32_t device;           /* HIP device ordinal; -1 = current device                         */
+    double pcg_rtol;          /* relative residual ||b-Ax||/||b|| at which the inner solve stops;
+                                 0 = default 1e-10 (SURVEY.md 7.2 hard part 1)                    */
+    int32_t pcg_max_iters;    /* 0 = default 2000                                                */
+    int32_t pcg_batch;        /* PCG iterations enqueued between host checks; 0 = default 16      */
+    int32_t profile;          /* 1 = time the linearise and SpMV kernels with HIP events on the
+                                 context stream (serialises launches; for bench roofline only)    */
+} nrs_options;
+
+/* One Levenberg-Marquardt trial as executed by g2o
+ * (third_party/g2o/g2o/core/optimization_algorithm_levenberg.cpp:94-145). */
+typedef struct {
+    int32_t round;            /* outer round of the entry point (inlier rounds), 0 for BA         */
+    int32_t iter;             /* LM iteration inside optimize()                                  */
+    int32_t trial;            /* qmax at the time of the trial                                   */
+    int32_t accepted;
+    int32_t solver_ok;        /* 0 = linear solve reported "not positive definite"               */
+    int32_t inner_iters;      /* PCG iterations of this trial (0 for dense 6x6 solves)           */
+    double lambda;
+    double chi2;              /* currentChi                                                      */
+    double chi2_new;          /* tempChi                                                         */
+    double rho;
+} nrs_lm_trial;
+
+typedef struct {
+    nrs_lm_trial* trials;     /* caller-allocated, may be NULL                                   */
+    int32_t capacity;
+    int32_t count;            /* out: trials executed (may exceed capacity; extra are dropped)   */
+    int32_t iterations;       /* out: LM iterations executed (cjIterations)                      */
+} nrs_lm_trace;
+
+/* Kernel timing accumulated while nrs_options.profile = 1 */
+typedef struct {
+    double linearize_ms;  int64_t linearize_launches;
+    double spmv_ms;       int64_t spmv_launches;
+    double vec_ms;        int64_t vec_launches;
+    double update_ms;     int64_t update_launches;
+} nrs_profile;
+
+int nrs_create(nrs_ctx** out, const nrs_options* opt);
+void nrs_destroy(nrs_ctx* ctx);
+const char* nrs_last_error(const nrs_ctx* ctx);
+int nrs_device_name(const nrs_ctx* ctx, char* buf, int32_t buf_len);
+int nrs_get_profile(const nrs_ctx* ctx, nrs_profile* out);
+int nrs_reset_profile(nrs_ctx* ctx);
+void* nrs_stream(nrs_ctx* ctx);                 /* hipStream_t the context launches on */
+
+/* ---- a1: CameraPoseOptimization (modules/optimization/g2o_optimization.cc:50-146) ------------
+ * 3 rounds x optimize(10), restart from the seed each round, chi2 > 5.99 edges to level 1 between
+ * rounds, Huber kernel dropped for round 3.  uv: n x 2 keypoints, X: n x 3 landmark positions of
+ * the TRACKED_WITH_3D observations in frame index order.  pose_qt in: frame pose, out: refined.
+ * inlier (may be NULL): final classification of every edge. */
+int nrs_pose_only_solve(nrs_ctx* ctx, const nrs_camera* cam, int32_t n, const float* uv,
+                        const float* X, double pose_qt[7], uint8_t* inlier, nrs_lm_trace* trace);
+
+/* ---- a3: LocalDeformableBundleAdjustment (g2o_optimization.cc:880-1161) ----------------------
+ * Host-side edge construction of OPT:927-1137 from flattened keyframes and the ordered
+ * neighbour lists that RegularizationGraph::GetEdges returns (a19).  kf_rowptr[n_kf+1] delimits,
+ * oldest keyframe first, the map-point index of every TRACKED_WITH_3D observation in keyframe
+ * index order (kf_pt).  Landmark l = position in that concatenation.  Two-call pattern: pass
+ * sp_ij = NULL to obtain the counts, then call again with buffers of that size. */
+int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const int32_t* kf_pt,
+                        int32_t n_points, const int32_t* nbr_rowptr, const int32_t* nbr_col,
+                        const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status,
+                        int32_t* n_spring, int32_t* sp_ij, float* sp_d0,
+                        int32_t* n_damper, int32_t* dm_idx, float* dm_w);
+
+/* One-shot: upload, optimize(iters), download.  lm_kf[l] = keyframe (pose index) of landmark l,
+ * must be non-decreasing.  sp_ij: n_spring x 2 landmark indices; dm_idx: n_damper x 4
+ * (1c,2c,1n,2n).  scale = Map::GetMapScale().  The reference calls optimize(5). */
+int nrs_dba_solve(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, double* poses_qt,
+                  int32_t n_lm, float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                  int32_t n_spring, const int32_t* sp_ij, const float* sp_d0,
+                  int32_t n_damper, const int32_t* dm_idx, const float* dm_w,
+                  float scale, int32_t iters, nrs_lm_trace* trace);
+
+/* Device-resident form of the same solve (used by bench.py so that the timed region starts with
+ * the inputs already in HBM): upload once, then any number of {reset, optimize}. */
+int nrs_dba_upload(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                   int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                   int32_t n_spring, const int32_t* sp_ij, const float* sp_d0,
+                   int32_t n_damper, const int32_t* dm_idx, const float* dm_w, float scale);
+int nrs_dba_reset(nrs_ctx* ctx);                                  /* estimates <- uploaded values */
+int nrs_dba_optimize(nrs_ctx* ctx, int32_t iters, nrs_lm_trace* trace);
+int nrs_dba_download(nrs_ctx* ctx, double* poses_qt, double* lm_xyz /* n_lm x 3, fp64 */);
+/* Debug/parity taps on the resident problem (host buffers, fp64): per-edge residuals at the
+ * current estimate and the assembled gradient b = -J^T W r in solver order (poses then landmarks). */
+int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_spring /* n_spring */,
+                      double* r_damper /* n_damper x 3 */);
+int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRS_H */

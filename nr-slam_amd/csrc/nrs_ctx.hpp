@@ -1,0 +1,77 @@
+// Context shared by the C-ABI entry points: one HIP stream, growable device buffers, last-error text.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/nrs.h"
+
+namespace nrs {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DbaProblem;   // nrs_engine.hip
+
+}  // namespace nrs
+
+struct nrs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    nrs_options opt;
+    char err[512];
+    nrs_profile prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scratch for a1
+    nrs::DevBuf po_uv, po_X, po_err, po_level, po_out, po_trace;
+    // resident BA problem
+    nrs::DbaProblem* dba = nullptr;
+
+    int fail(int code, const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, sizeof(err), fmt, ap);
+        va_end(ap);
+        return code;
+    }
+    int ensure(nrs::DevBuf& b, size_t bytes) {
+        if (bytes <= b.cap && b.p) return NRS_OK;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        b.cap = want;
+        return NRS_OK;
+    }
+    void release(nrs::DevBuf& b) {
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+};
+
+#define NRS_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return (ctx)->fail(NRS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                               __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define NRS_TRY(expr)                \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != NRS_OK) return rc__; \
+    } while (0)
+
+namespace nrs {
+void dba_free(nrs_ctx* ctx);
+}

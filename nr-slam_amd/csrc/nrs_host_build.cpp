@@ -1,0 +1,106 @@
+// Host-side problem construction for the deformable BA (plain C++, no device code).
+//
+// Restates the edge-construction loops of the reference LocalDeformableBundleAdjustment
+// (modules/optimization/g2o_optimization.cc:927-1137) on flat arrays: one landmark per
+// (keyframe, map point), springs between graph neighbours inside a keyframe, dampers between a
+// pair of neighbours in two consecutive keyframes.  The order of the emitted edges is the
+// reference's insertion order, the counting rule (`n_regularizers > 10`, duplicates count) and the
+// de-duplication keys (SpatialPoint / TemporalPoint, OPT:816-878) are kept, so the output is
+// index-for-index what g2o would have been given.
+#include <climits>
+#include <cstddef>
+#include <cstdint>
+#include <unordered_set>
+#include <vector>
+#include "../../include/nrs.h"
+
+namespace {
+constexpr int kRegularizersPerPoint = 10;      // OPT:958
+
+inline uint64_t pair_key(int32_t a, int32_t b) {
+    const uint32_t lo = (uint32_t)(a < b ? a : b), hi = (uint32_t)(a < b ? b : a);
+    return ((uint64_t)lo << 32) | hi;
+}
+}  // namespace
+
+extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const int32_t* kf_pt,
+                                   int32_t n_points, const int32_t* nbr_rowptr, const int32_t* nbr_col,
+                                   const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status,
+                                   int32_t* n_spring, int32_t* sp_ij, float* sp_d0,
+                                   int32_t* n_damper, int32_t* dm_idx, float* dm_w) {
+    if (n_kf < 0 || n_points < 0 || !kf_rowptr || !nbr_rowptr || !n_spring || !n_damper) return NRS_ERR_INVALID;
+    if (n_kf > 0 && kf_rowptr[n_kf] > 0 && !kf_pt) return NRS_ERR_INVALID;
+    if (n_points > 0 && nbr_rowptr[n_points] > 0 && (!nbr_col || !nbr_w || !nbr_d0 || !nbr_status)) return NRS_ERR_INVALID;
+    const bool fill = sp_ij != nullptr;
+    if (fill && (!sp_d0 || !dm_idx || !dm_w)) return NRS_ERR_INVALID;
+    const int32_t cap_s = *n_spring, cap_d = *n_damper;
+    for (int32_t i = 0; i < kf_rowptr[n_kf]; ++i)
+        if (kf_pt[i] < 0 || kf_pt[i] >= n_points) return NRS_ERR_INVALID;
+
+    // inserted_landmarks[kf][mappoint] -> landmark index (OPT:927-952), two rolling rows suffice
+    std::vector<int32_t> cur(n_points, -1), nxt(n_points, -1);
+    auto load = [&](std::vector<int32_t>& row, int k) {
+        for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) row[kf_pt[i]] = i;
+    };
+    auto clear = [&](std::vector<int32_t>& row, int k) {
+        for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) row[kf_pt[i]] = -1;
+    };
+    int64_t ns = 0, nd = 0;
+    std::unordered_set<uint64_t> spring_seen, damper_seen;
+    if (n_kf > 0) load(cur, 0);
+    for (int k = 0; k < n_kf; ++k) {
+        const bool has_next = k + 1 < n_kf;
+        if (has_next) load(nxt, k + 1);
+        spring_seen.clear();          // keys carry the keyframe id: a per-keyframe set is equivalent
+        damper_seen.clear();
+        spring_seen.reserve((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        damper_seen.reserve((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        for (int32_t l = kf_rowptr[k]; l < kf_rowptr[k + 1]; ++l) {
+            const int32_t p = kf_pt[l];
+            const int32_t lo = nbr_rowptr[p], hi = nbr_rowptr[p + 1];
+            int n_reg = 0;
+            for (int32_t e = lo; e < hi; ++e) {                                     // OPT:1033-1074
+                if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
+                const int32_t o = nbr_col[e];
+                if (o < 0 || o >= n_points) return NRS_ERR_INVALID;
+                if (cur[o] < 0) continue;
+                if (!spring_seen.insert(pair_key(p, o)).second) { ++n_reg; continue; }
+                if (fill) {
+                    if (ns >= cap_s) return NRS_ERR_INVALID;
+                    sp_ij[2 * ns] = l;
+                    sp_ij[2 * ns + 1] = cur[o];
+                    sp_d0[ns] = nbr_d0[e];
+                }
+                ++ns;
+                ++n_reg;
+            }
+            if (has_next) {                                                          // OPT:1076-1136
+                if (nxt[p] < 0) continue;
+                const int32_t ln = nxt[p];
+                n_reg = 0;
+                for (int32_t e = lo; e < hi; ++e) {
+                    if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
+                    const int32_t o = nbr_col[e];
+                    if (cur[o] < 0 || nxt[o] < 0) continue;
+                    if (!damper_seen.insert(pair_key(p, o)).second) { ++n_reg; continue; }
+                    if (fill) {
+                        if (nd >= cap_d) return NRS_ERR_INVALID;
+                        dm_idx[4 * nd] = l;
+                        dm_idx[4 * nd + 1] = cur[o];
+                        dm_idx[4 * nd + 2] = ln;
+                        dm_idx[4 * nd + 3] = nxt[o];
+                        dm_w[nd] = nbr_w[e];
+                    }
+                    ++nd;
+                    ++n_reg;
+                }
+            }
+        }
+        clear(cur, k);
+        if (has_next) cur.swap(nxt);
+    }
+    if (ns > INT32_MAX || nd > INT32_MAX) return NRS_ERR_INVALID;
+    *n_spring = (int32_t)ns;
+    *n_damper = (int32_t)nd;
+    return NRS_OK;
+}

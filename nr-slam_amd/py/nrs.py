@@ -1,0 +1,231 @@
+"""ctypes binding of libnrs_hip.so (include/nrs.h) for the tests and bench.py.
+
+Thin by design: every function maps 1:1 onto a C-ABI entry point, takes/returns NumPy arrays and
+raises NrsError (with nrs_last_error) on a non-zero status.  There is no fallback: if the
+shared library is missing the import fails; if no HIP device is usable nrs_create fails.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libnrs_hip.so")
+
+OK = 0
+STATUS_NAMES = {0: "NRS_OK", -1: "NRS_ERR_INVALID", -2: "NRS_ERR_NO_DEVICE", -3: "NRS_ERR_HIP",
+                -4: "NRS_ERR_ALLOC", -5: "NRS_ERR_STATE", -6: "NRS_ERR_NUMERIC"}
+
+# every symbol include/nrs.h declares (tests check that the library exports all of them)
+SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
+           "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
+           "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient"]
+
+
+class NrsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("model", C.c_int32), ("params", C.c_float * 8)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
+                ("pcg_batch", C.c_int32), ("profile", C.c_int32)]
+
+
+class LmTrial(C.Structure):
+    _fields_ = [("round", C.c_int32), ("iter", C.c_int32), ("trial", C.c_int32),
+                ("accepted", C.c_int32), ("solver_ok", C.c_int32), ("inner_iters", C.c_int32),
+                ("lam", C.c_double), ("chi2", C.c_double), ("chi2_new", C.c_double),
+                ("rho", C.c_double)]
+
+
+class LmTrace(C.Structure):
+    _fields_ = [("trials", C.POINTER(LmTrial)), ("capacity", C.c_int32), ("count", C.c_int32),
+                ("iterations", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("linearize_ms", C.c_double), ("linearize_launches", C.c_int64),
+                ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64),
+                ("vec_ms", C.c_double), ("vec_launches", C.c_int64),
+                ("update_ms", C.c_double), ("update_launches", C.c_int64)]
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError("libnrs_hip.so not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C nr-slam_amd`): %s" % path)
+    lib = C.CDLL(path)
+    lib.nrs_last_error.restype = C.c_char_p
+    lib.nrs_stream.restype = C.c_void_p
+    lib.nrs_destroy.restype = None
+    return lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, np.int32)
+
+
+def make_camera(model, params):
+    cam = Camera()
+    cam.model = int(model)
+    prm = np.zeros(8, np.float32)
+    prm[:len(params)] = np.asarray(params, np.float32)
+    for i in range(8):
+        cam.params[i] = float(prm[i])
+    return cam
+
+
+class Trace:
+    def __init__(self, capacity=512):
+        self.buf = (LmTrial * capacity)()
+        self.c = LmTrace(C.cast(self.buf, C.POINTER(LmTrial)), capacity, 0, 0)
+
+    @property
+    def trials(self):
+        n = min(self.c.count, self.c.capacity)
+        return [dict(round=t.round, iter=t.iter, trial=t.trial, accepted=bool(t.accepted),
+                     ok=bool(t.solver_ok), inner=t.inner_iters, lam=t.lam, chi=t.chi2,
+                     chi_new=t.chi2_new, rho=t.rho) for t in self.buf[:n]]
+
+    @property
+    def iterations(self):
+        return self.c.iterations
+
+
+def dba_build_edges(kf_points, graph, lib=None):
+    """Host-side (no GPU) edge construction, reference g2o_optimization.cc:927-1137."""
+    lib = lib or load_library()
+    n_kf = len(kf_points)
+    kf_rowptr = np.zeros(n_kf + 1, np.int32)
+    kf_rowptr[1:] = np.cumsum([len(k) for k in kf_points])
+    kf_pt = _i32(np.concatenate(kf_points)) if n_kf else np.zeros(0, np.int32)
+    n_points = len(graph["rowptr"]) - 1
+    rp, col, w, d0, st = (_i32(graph["rowptr"]), _i32(graph["col"]), _f32(graph["w"]),
+                          _f32(graph["d0"]), _i32(graph["status"]))
+    ns, nd = C.c_int32(0), C.c_int32(0)
+    args = [C.c_int32(n_kf), _p(kf_rowptr, C.c_int32), _p(kf_pt, C.c_int32), C.c_int32(n_points),
+            _p(rp, C.c_int32), _p(col, C.c_int32), _p(w, C.c_float), _p(d0, C.c_float), _p(st, C.c_int32)]
+    rc = lib.nrs_dba_build_edges(*args, C.byref(ns), None, None, C.byref(nd), None, None)
+    if rc != OK:
+        raise NrsError(rc, "nrs_dba_build_edges (count)")
+    sp_ij = np.zeros((ns.value, 2), np.int32)
+    sp_d0 = np.zeros(ns.value, np.float32)
+    dm_idx = np.zeros((nd.value, 4), np.int32)
+    dm_w = np.zeros(nd.value, np.float32)
+    rc = lib.nrs_dba_build_edges(*args, C.byref(ns), _p(sp_ij, C.c_int32), _p(sp_d0, C.c_float),
+                                 C.byref(nd), _p(dm_idx, C.c_int32), _p(dm_w, C.c_float))
+    if rc != OK:
+        raise NrsError(rc, "nrs_dba_build_edges (fill)")
+    return dict(sp_ij=sp_ij, sp_d0=sp_d0, dm_idx=dm_idx, dm_w=dm_w)
+
+
+class Context:
+    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0):
+        self.lib = load_library()
+        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile)
+        self.h = C.c_void_p()
+        rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
+        if rc != OK:
+            raise NrsError(rc, "nrs_create failed (no usable HIP device?)")
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise NrsError(rc, self.lib.nrs_last_error(self.h).decode())
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self.lib.nrs_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def profile(self):
+        p = Profile()
+        self._chk(self.lib.nrs_get_profile(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def reset_profile(self):
+        self._chk(self.lib.nrs_reset_profile(self.h))
+
+    # ---- a1
+    def pose_only_solve(self, cam, uv, X, pose_q, pose_t, trace=None):
+        uv, X = _f32(uv).reshape(-1, 2), _f32(X).reshape(-1, 3)
+        n = len(uv)
+        qt = np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)])
+        inl = np.zeros(n, np.uint8)
+        self._chk(self.lib.nrs_pose_only_solve(self.h, C.byref(cam), C.c_int32(n), _p(uv, C.c_float),
+                                               _p(X, C.c_float), _p(qt, C.c_double), _p(inl, C.c_uint8),
+                                               C.byref(trace.c) if trace else None))
+        return qt[:4].copy(), qt[4:].copy(), inl.astype(bool)
+
+    # ---- a3
+    def _dba_args(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):
+        self._keep = (np.ascontiguousarray(poses_qt, np.float64).reshape(-1, 7), _f32(lm_xyz).reshape(-1, 3),
+                      _i32(lm_kf), _f32(lm_uv).reshape(-1, 2), _i32(edges["sp_ij"]).reshape(-1, 2),
+                      _f32(edges["sp_d0"]), _i32(edges["dm_idx"]).reshape(-1, 4), _f32(edges["dm_w"]))
+        pq, xyz, kf, uv, sp, d0, dm, dw = self._keep
+        return [self.h, C.byref(cam), C.c_int32(len(pq)), _p(pq, C.c_double), C.c_int32(len(xyz)),
+                _p(xyz, C.c_float), _p(kf, C.c_int32), _p(uv, C.c_float), C.c_int32(len(sp)),
+                _p(sp, C.c_int32), _p(d0, C.c_float), C.c_int32(len(dm)), _p(dm, C.c_int32),
+                _p(dw, C.c_float), C.c_float(scale)]
+
+    def dba_solve(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale, iters=5, trace=None):
+        args = self._dba_args(cam, np.array(poses_qt, np.float64), np.array(lm_xyz, np.float32),
+                              lm_kf, lm_uv, edges, scale)
+        self._chk(self.lib.nrs_dba_solve(*args, C.c_int32(iters), C.byref(trace.c) if trace else None))
+        return self._keep[0].copy(), self._keep[1].copy()
+
+    def dba_upload(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):
+        args = self._dba_args(cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale)
+        self._n_kf, self._n_lm = len(self._keep[0]), len(self._keep[1])
+        self._n_sp, self._n_dm = len(self._keep[4]), len(self._keep[6])
+        self._chk(self.lib.nrs_dba_upload(*args))
+
+    def dba_reset(self):
+        self._chk(self.lib.nrs_dba_reset(self.h))
+
+    def dba_optimize(self, iters=5, trace=None):
+        self._chk(self.lib.nrs_dba_optimize(self.h, C.c_int32(iters), C.byref(trace.c) if trace else None))
+
+    def dba_download(self):
+        pq = np.zeros((self._n_kf, 7), np.float64)
+        xyz = np.zeros((self._n_lm, 3), np.float64)
+        self._chk(self.lib.nrs_dba_download(self.h, _p(pq, C.c_double), _p(xyz, C.c_double)))
+        return pq, xyz
+
+    def dba_residuals(self):
+        rr = np.zeros((self._n_lm, 2), np.float64)
+        rs = np.zeros(self._n_sp, np.float64)
+        rd = np.zeros((self._n_dm, 3), np.float64)
+        self._chk(self.lib.nrs_dba_residuals(self.h, _p(rr, C.c_double), _p(rs, C.c_double), _p(rd, C.c_double)))
+        return rr, rs, rd
+
+    def dba_gradient(self):
+        n = 6 * self._n_kf + 3 * self._n_lm
+        b = np.zeros(n, np.float64)
+        d = np.zeros(n, np.float64)
+        self._chk(self.lib.nrs_dba_gradient(self.h, _p(b, C.c_double), _p(d, C.c_double)))
+        return b, d

@@ -1,0 +1,241 @@
+"""Seeded synthetic problems for the NR-SLAM hot path (BASELINE.json configs).
+
+The build's own generator: scene layout follows the recipe of SURVEY.md 8(d) -- a smooth
+endoscopic-like surface, an arc of keyframe poses looking at its centroid, a low-frequency
+per-keyframe deformation field, noisy observations with a few gross outliers, and a
+deformation graph whose edges carry {weight, first_distance, status} exactly like
+RegularizationGraph::Edge (reference modules/map/regularization_graph.h:49-59).
+
+Everything the C-ABI consumes is produced here as flat arrays; nothing in this file depends on
+the oracle.
+"""
+import numpy as np
+from scipy.spatial import cKDTree
+
+F32 = np.float32
+
+PINHOLE, KB8 = 0, 1
+HAMLYN_PINHOLE = np.array([766.380279, 766.380279, 304.8638076782227, 258.3343734741211, 0, 0, 0, 0], F32)
+ENDOMAPPER_KB8 = np.array([358.6052, 358.7408, 367.6783, 276.3991,
+                           -0.1389272, -0.001239606, 0.0009125824, -4.071615e-05], F32)
+
+GRAPH_NEUTRAL, GRAPH_BAD = 2, 3
+
+CONFIGS = {
+    # name: (n_points, n_keyframes, seed, camera)
+    "C2": (5000, 20, 1, PINHOLE),
+    "C3": (10000, 50, 2, PINHOLE),
+    "C4": (50000, 200, 3, PINHOLE),
+    "C5": (100000, 200, 4, KB8),
+}
+
+
+def _project(model, prm, p):
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    if model == PINHOLE:
+        return np.stack([prm[0] * x / z + prm[2], prm[1] * y / z + prm[3]], 1)
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan2(r, z)
+    psi = np.arctan2(y, x)
+    rd = th + prm[4] * th ** 3 + prm[5] * th ** 5 + prm[6] * th ** 7 + prm[7] * th ** 9
+    return np.stack([prm[0] * rd * np.cos(psi) + prm[2], prm[1] * rd * np.sin(psi) + prm[3]], 1)
+
+
+def _look_at(C, target):
+    z = target - C
+    z /= np.linalg.norm(z)
+    x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z])            # rows = camera axes in world  => p_cam = R (X - C)
+    return R, -R @ C
+
+
+def _R_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[3] = (R[k, j] - R[j, k]) / s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _small_rot(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def surface_points(n, rng, model):
+    """Rest shape in mm."""
+    if model == PINHOLE:
+        x = rng.uniform(-22, 22, n)
+        y = rng.uniform(-17, 17, n)
+        z = 60 + 8 * np.sin(x / 15) * np.cos(y / 12)
+        nrm = np.stack([-(8 / 15) * np.cos(x / 15) * np.cos(y / 12),
+                        (8 / 12) * np.sin(x / 15) * np.sin(y / 12), np.ones(n)], 1)
+    else:
+        # colon-like tube of radius 15 mm around the optical axis, theta in ~10..80 deg
+        ang = rng.uniform(0, 2 * np.pi, n)
+        z = rng.uniform(3.0, 80.0, n)
+        rad = 15 + 1.5 * np.sin(3 * ang) * np.cos(z / 9)
+        x, y = rad * np.cos(ang), rad * np.sin(ang)
+        nrm = np.stack([-np.cos(ang), -np.sin(ang), np.zeros(n)], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.stack([x, y, z], 1), nrm
+
+
+def build_graph(X, sigma, knn=16):
+    """Symmetric deformation graph over points X (fp32, map units) in the ordered-CSR wire form
+    that RegularizationGraph::GetEdges would return per point: rows sorted by (status asc,
+    weight desc), cut at min_weight (reference regularization_graph.cc:61-87).  Candidate edges
+    = union of k-nearest-neighbour pairs (the reference starts from all pairs; pairs below
+    min_weight can never be returned by GetEdges because weights only decrease)."""
+    X = np.asarray(X, F32)
+    n = len(X)
+    sigma = F32(sigma)
+    min_w = np.exp(-(F32(float(sigma) * 1.5) ** 2) / (F32(2) * sigma * sigma)).astype(F32)
+    k = min(knn + 1, n)
+    tree = cKDTree(X.astype(np.float64))
+    _, nn = tree.query(X.astype(np.float64), k=k)
+    src = np.repeat(np.arange(n), k - 1)
+    dst = nn[:, 1:].ravel()
+    a, b = np.minimum(src, dst), np.maximum(src, dst)
+    keep = a != b
+    pairs = np.unique(np.stack([a[keep], b[keep]], 1), axis=0)
+    rel = X[pairs[:, 1]] - X[pairs[:, 0]]
+    d = np.sqrt((rel[:, 0] * rel[:, 0] + rel[:, 1] * rel[:, 1] + rel[:, 2] * rel[:, 2]).astype(F32)).astype(F32)
+    w = np.exp(-(d * d) / (F32(2) * sigma * sigma)).astype(F32)
+    ok = w >= min_w
+    pairs, d, w = pairs[ok], d[ok], w[ok]
+    row = np.concatenate([pairs[:, 0], pairs[:, 1]])
+    col = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    ww = np.concatenate([w, w])
+    dd = np.concatenate([d, d])
+    order = np.lexsort((col, -ww.astype(np.float64), row))     # status all NEUTRAL
+    row, col, ww, dd = row[order], col[order], ww[order], dd[order]
+    rowptr = np.zeros(n + 1, np.int32)
+    np.add.at(rowptr, row + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return dict(rowptr=rowptr, col=col.astype(np.int32), w=ww.astype(F32), d0=dd.astype(F32),
+                status=np.full(len(col), GRAPH_NEUTRAL, np.int32), min_w=float(min_w),
+                sigma=float(sigma), max_d=dd.astype(F32).copy(), min_d=dd.astype(F32).copy())
+
+
+def make_scene(n_points, n_kf, seed, model=PINHOLE, dropout=0.05, outlier_frac=0.02,
+               img_wh=(640, 480), knn=16):
+    """Full synthetic sequence: rest shape, per-keyframe truth, observations, graph.
+    Positions are in *map units* (mm * scale, scale = 3/median depth: reference
+    tracking.cc:156-157)."""
+    rng = np.random.default_rng(seed)
+    prm = HAMLYN_PINHOLE if model == PINHOLE else ENDOMAPPER_KB8
+    if model == KB8:
+        img_wh = (736, 552)
+    Xmm, nrm = surface_points(n_points, rng, model)
+    centroid = Xmm.mean(0)
+    if model == PINHOLE:
+        depth0 = Xmm[:, 2]
+    else:
+        depth0 = Xmm[:, 2]
+    scale = F32(3.0) / F32(np.median(depth0))
+    sigma = F32(3.0) * F32(np.std(depth0.astype(F32))) * scale      # tracking.cc:159-160,200
+    poses_R, poses_t = [], []
+    phis = np.linspace(-1.0, 1.0, n_kf) if n_kf > 1 else np.array([0.0])
+    for phi in phis:
+        if model == PINHOLE:
+            C = np.array([6.0 * phi, 2.0 * np.sin(np.pi * phi), 0.0])
+            R, t = _look_at(C, centroid)
+        else:
+            C = np.array([1.5 * phi, 1.0 * np.sin(np.pi * phi), 2.0 * phi])
+            R = _small_rot(np.array([0.03 * phi, -0.04 * phi, 0.02 * phi]))
+            t = -R @ C
+        poses_R.append(R)
+        poses_t.append(t)
+    # per-keyframe true positions (mm): low-frequency deformation along the normal
+    obs = []
+    Xk_true = []
+    A = 1.5
+    for k in range(n_kf):
+        amp = A * np.sin(2 * np.pi * k / 20.0) * (0.6 + 0.4 * np.sin(Xmm[:, 0] / 11.0 + 0.3) * np.cos(Xmm[:, 1] / 9.0))
+        Xk = Xmm + (amp + rng.normal(0, 0.05, n_points))[:, None] * nrm
+        Xk_true.append(Xk)
+        pc = Xk @ poses_R[k].T + poses_t[k]
+        uv = _project(model, prm.astype(np.float64), pc)
+        vis = (pc[:, 2] > 1.0) & (uv[:, 0] > 12) & (uv[:, 0] < img_wh[0] - 12) & (uv[:, 1] > 12) & (uv[:, 1] < img_wh[1] - 12)
+        vis &= rng.uniform(size=n_points) > dropout
+        uv = uv + rng.normal(0, 0.5, uv.shape)
+        out = rng.uniform(size=n_points) < outlier_frac
+        uv[out] = np.stack([rng.uniform(12, img_wh[0] - 12, out.sum()), rng.uniform(12, img_wh[1] - 12, out.sum())], 1)
+        obs.append((np.where(vis)[0].astype(np.int32), uv[vis].astype(F32)))
+    s = float(scale)
+    X0 = (Xmm * s).astype(F32)
+    graph = build_graph(X0, sigma, knn)
+    return dict(model=model, prm=prm, scale=float(scale), sigma=float(sigma), X0=X0,
+                Xk_true=[(x * s) for x in Xk_true], poses_R=poses_R,
+                poses_t=[t * s for t in poses_t], obs=obs, graph=graph, rng=rng, img_wh=img_wh)
+
+
+def make_dba_problem(name_or_n, n_kf=None, seed=None, model=PINHOLE, pose_noise=(0.002, 0.01),
+                     lm_noise=0.004, **kw):
+    """Flat input of nrs_dba_* for one windowed deformable BA (reference
+    LocalDeformableBundleAdjustment, g2o_optimization.cc:880-1161), with the window cap lifted
+    to n_kf keyframes.  Edge lists are NOT built here: the product's host builder
+    (nrs_dba_build_edges) and the oracle's dba_build both derive them from (kf_points, graph)."""
+    if isinstance(name_or_n, str):
+        n_points, n_kf, seed, model = CONFIGS[name_or_n]
+    else:
+        n_points = name_or_n
+    sc = make_scene(n_points, n_kf, seed, model, **kw)
+    rng = sc["rng"]
+    poses_q, poses_t = [], []
+    for k in range(n_kf):
+        dR = _small_rot(rng.normal(0, pose_noise[0], 3))
+        R = dR @ sc["poses_R"][k]
+        t = dR @ sc["poses_t"][k] + rng.normal(0, pose_noise[1], 3)
+        q = _R_to_quat(R).astype(F32).astype(np.float64)          # boundary hands over SE3f
+        poses_q.append(q)
+        poses_t.append(t.astype(F32).astype(np.float64))
+    kf_points = [o[0] for o in sc["obs"]]
+    lm_uv = np.concatenate([o[1] for o in sc["obs"]]).astype(F32)
+    lm_xyz = np.concatenate([sc["Xk_true"][k][kf_points[k]] + rng.normal(0, lm_noise, (len(kf_points[k]), 3))
+                             for k in range(n_kf)]).astype(F32)
+    lm_kf = np.concatenate([np.full(len(kf_points[k]), k, np.int32) for k in range(n_kf)])
+    lm_pt = np.concatenate(kf_points).astype(np.int32)
+    return dict(model=sc["model"], prm=sc["prm"], scale=sc["scale"], n_kf=n_kf, n_points=n_points,
+                poses_q=np.array(poses_q), poses_t=np.array(poses_t), kf_points=kf_points,
+                lm_xyz=lm_xyz, lm_kf=lm_kf, lm_pt=lm_pt, lm_uv=lm_uv, graph=sc["graph"], scene=sc)
+
+
+def make_tracking_problem(n_points, seed, model=PINHOLE, frame=3, lost_frac=0.03, **kw):
+    """One tracked frame for nrs_pose_only_solve / nrs_track_deform_solve (reference
+    CameraPoseOptimization / CameraPoseAndDeformationOptimization, g2o_optimization.cc:50-557):
+    previous positions X0 (= last estimate), current observations, pose seed = previous pose."""
+    sc = make_scene(n_points, frame + 1, seed, model, **kw)
+    rng = sc["rng"]
+    idx, uv = sc["obs"][frame]
+    prev = sc["Xk_true"][frame - 1] + rng.normal(0, 0.002, (n_points, 3))
+    R = _small_rot(rng.normal(0, 0.003, 3)) @ sc["poses_R"][frame - 1]
+    t = sc["poses_t"][frame - 1] + rng.normal(0, 0.01, 3)
+    status = np.full(n_points, 3, np.int32)             # BAD unless observed
+    status[idx] = 0                                     # TRACKED_WITH_3D
+    lost = idx[rng.uniform(size=len(idx)) < lost_frac]
+    status[lost] = 1                                    # TRACKED (no 3D this frame) -> "lost" neighbours
+    uv_full = np.zeros((n_points, 2), F32)
+    uv_full[idx] = uv
+    return dict(model=sc["model"], prm=sc["prm"], scale=sc["scale"], n_points=n_points,
+                status=status, uv=uv_full, X_prev=prev.astype(F32),
+                pose_q=_R_to_quat(R).astype(F32).astype(np.float64),
+                pose_t=t.astype(F32).astype(np.float64), graph=sc["graph"], scene=sc)

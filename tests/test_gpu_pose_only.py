@@ -1,0 +1,79 @@
+"""GPU parity: a1 CameraPoseOptimization (reference g2o_optimization.cc:50-146) through the C ABI
+against the oracle on identical seeded inputs.
+
+Tolerances: final rotation 1e-6 (quaternion components), translation 1e-5 map
+units, per-trial chi2 1e-6 relative, identical accept/reject sequence while consecutive chi2
+values are separated by more than the fp32-projection noise floor, identical inlier mask."""
+import numpy as np
+import pytest
+
+import nrs
+import nrs_oracle as O
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n, seed, model=S.PINHOLE):
+    tp = S.make_tracking_problem(n, seed, model)
+    m = tp["status"] == 0
+    return tp, tp["uv"][m], tp["X_prev"][m]
+
+
+def _compare(ctx, tp, uv, X):
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    tr = nrs.Trace(1024)
+    q, t, inl = ctx.pose_only_solve(cam, uv, X, tp["pose_q"], tp["pose_t"], tr)
+    otr = []
+    q2, t2, inl2 = O.pose_only_solve(tp["model"], tp["prm"], uv, X, tp["pose_q"], tp["pose_t"], otr)
+    return (q, t, inl, tr.trials), (q2, t2, inl2, [dict(r, round=i) for i, rnd in enumerate(otr) for r in rnd])
+
+
+@pytest.mark.parametrize("n,seed", [(60, 1), (500, 2), (5000, 3)])
+def test_pose_only_matches_oracle_pinhole(ctx, n, seed):
+    tp, uv, X = _problem(n, seed)
+    (q, t, inl, tr), (q2, t2, inl2, otr) = _compare(ctx, tp, uv, X)
+    assert np.allclose(q, q2, atol=1e-6, rtol=0)
+    assert np.allclose(t, t2, atol=1e-5, rtol=0)
+    assert np.array_equal(inl, inl2)
+    # the first trials of every round are far above the fp32 noise floor: they must agree exactly
+    for rnd in range(3):
+        a = [x for x in tr if x["round"] == rnd][:3]
+        b = [x for x in otr if x["round"] == rnd][:3]
+        assert [x["accepted"] for x in a] == [x["accepted"] for x in b]
+        for x, y in zip(a, b):
+            assert abs(x["chi"] - y["chi"]) <= 1e-6 * abs(y["chi"])
+            assert abs(x["lam"] - y["lam"]) <= 1e-6 * abs(y["lam"])
+
+
+def test_pose_only_kb8(ctx):
+    tp, uv, X = _problem(800, 4, S.KB8)
+    (q, t, inl, tr), (q2, t2, inl2, otr) = _compare(ctx, tp, uv, X)
+    # device atan2f/sinf/cosf differ from the host libm in the last ulp: tolerance-level parity
+    assert np.allclose(q, q2, atol=5e-6, rtol=0)
+    assert np.allclose(t, t2, atol=5e-5, rtol=0)
+    assert np.mean(inl == inl2) > 0.995
+
+
+def test_pose_only_edge_cases(ctx):
+    tp, uv, X = _problem(200, 6)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    # empty input: nothing to optimise, pose returned unchanged (g2o: optimize() on an empty graph)
+    q, t, inl = ctx.pose_only_solve(cam, uv[:0], X[:0], tp["pose_q"], tp["pose_t"])
+    assert np.allclose(q, O.quat_normalize(tp["pose_q"])) and np.allclose(t, tp["pose_t"]) and len(inl) == 0
+    # all observations gross outliers -> every edge ends at level 1
+    uv_bad = uv + 300.0
+    q, t, inl = ctx.pose_only_solve(cam, uv_bad, X, tp["pose_q"], tp["pose_t"])
+    q2, t2, inl2 = O.pose_only_solve(tp["model"], tp["prm"], uv_bad, X, tp["pose_q"], tp["pose_t"])
+    assert np.array_equal(inl, inl2)
+    # bad arguments are reported, not crashed on
+    with pytest.raises(nrs.NrsError):
+        ctx.pose_only_solve(nrs.make_camera(7, tp["prm"]), uv, X, tp["pose_q"], tp["pose_t"])
+
+
+def test_pose_only_deterministic(ctx):
+    tp, uv, X = _problem(3000, 8)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    a = ctx.pose_only_solve(cam, uv, X, tp["pose_q"], tp["pose_t"])
+    b = ctx.pose_only_solve(cam, uv, X, tp["pose_q"], tp["pose_t"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -1,0 +1,87 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/nrs.h, the host
+edge builder reproduces the oracle's restatement of OPT:927-1137 index for index, and compute
+entry points refuse to run without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nrs_oracle as O
+import nrs_synth as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_header_symbols(lib_built):
+    nrs = lib_built
+    lib = nrs.load_library()
+    hdr = open(os.path.join(ROOT, "include", "nrs.h")).read()
+    declared = set(re.findall(r"\b(nrs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nrs.SYMBOLS), declared ^ set(nrs.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_no_cpu_fallback(lib_built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    nrs = lib_built
+    with pytest.raises(nrs.NrsError) as ei:
+        nrs.Context()
+    assert ei.value.code == -2            # NRS_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("n,k,seed,bad", [(150, 3, 1, 0.0), (400, 5, 2, 0.1), (400, 2, 3, 0.3), (50, 1, 4, 0.0)])
+def test_edge_builder_matches_oracle(lib_built, n, k, seed, bad):
+    nrs = lib_built
+    p = S.make_dba_problem(n, k, seed, dropout=0.15)
+    g = dict(p["graph"])
+    st = g["status"].copy()
+    rng = np.random.default_rng(seed)
+    st[rng.uniform(size=len(st)) < bad] = S.GRAPH_BAD
+    g["status"] = st
+    eo = O.dba_build(p["kf_points"], g["rowptr"], g["col"], g["w"], g["d0"], g["status"])
+    e = nrs.dba_build_edges(p["kf_points"], g)
+    for key in ("sp_ij", "sp_d0", "dm_idx", "dm_w"):
+        assert np.array_equal(e[key], eo[key]), key          # integer/index work: bit-exact
+    assert np.array_equal(eo["lm_kf"], p["lm_kf"]) and np.array_equal(eo["lm_pt"], p["lm_pt"])
+    if k == 1:
+        assert len(e["dm_idx"]) == 0
+
+
+def test_edge_builder_rejects_bad_input(lib_built):
+    nrs = lib_built
+    p = S.make_dba_problem(60, 2, 5)
+    g = dict(p["graph"])
+    g["col"] = g["col"].copy()
+    g["col"][0] = 10 ** 6
+    with pytest.raises(nrs.NrsError):
+        nrs.dba_build_edges(p["kf_points"], g)
+
+
+def test_graph_wire_format():
+    """The synthetic graph is in the ordered form GetEdges returns (regularization_graph.cc:61-87):
+    symmetric, rows sorted by weight descending, cut at min_weight, no float ties."""
+    sc = S.make_scene(800, 2, 9)
+    g = sc["graph"]
+    rp, col, w = g["rowptr"], g["col"], g["w"]
+    assert abs(g["min_w"] - float(O.min_weight(g["sigma"]))) < 1e-7
+    pairs = set()
+    for i in range(len(rp) - 1):
+        ww = w[rp[i]:rp[i + 1]]
+        assert np.all(np.diff(ww) < 0), "ties or wrong order in row %d" % i
+        assert np.all(ww >= g["min_w"])
+        for c in col[rp[i]:rp[i + 1]]:
+            pairs.add((i, int(c)))
+    assert all((b, a) in pairs for a, b in pairs)
+    # weights are the reference's fp32 InterpolationWeight of the rest distance
+    assert np.array_equal(w, O.interpolation_weight(g["d0"], g["sigma"]))
+    # get_edges on an unordered copy of a row reproduces the stored order
+    i = 17
+    sl = slice(rp[i], rp[i + 1])
+    perm = np.argsort(col[sl])
+    pos = O.get_edges(col[sl][perm], w[sl][perm], g["status"][sl][perm], g["min_w"])
+    assert np.array_equal(col[sl][perm][pos], col[sl])
