@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- deformable-BA LM iterations/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch = one reference-shaped
+LocalDeformableBundleAdjustment solve, optimize(5) (reference g2o_optimization.cc:1141-1143), on
+BASELINE.json configs[1]: 5k map points x 20 keyframes (pinhole), every point a deformation-graph
+node (parity mode).  Inputs are uploaded to HBM once, outside the timed
+region; each timed step is {reset estimates (device-to-device), optimize(5)}.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves its own,
+independent BA window of the same size (weak scaling, no data-path collective -- DESIGN.md
+"Multi-GPU"); ranks are bracketed by a barrier and the slowest rank's time is used.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd", "py"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def unique_blocks(n_lm, sp_ij, dm_idx):
+    """Number of distinct off-diagonal 3x3 landmark blocks of H_ll (upper triangle, as g2o stores
+    it: block_solver.hpp:108-266)."""
+    d = dm_idx.astype(np.int64)
+    pairs = [sp_ij.astype(np.int64)]
+    for a, b in ((0, 1), (2, 3), (0, 2), (1, 3), (0, 3), (1, 2)):
+        pairs.append(d[:, [a, b]])
+    p = np.concatenate(pairs)
+    lo, hi = np.minimum(p[:, 0], p[:, 1]), np.maximum(p[:, 0], p[:, 1])
+    return int(len(np.unique(lo * n_lm + hi)))
+
+
+def algorithmic_bytes(n_lm, n_sp, n_dm, n_blocks):
+    """SURVEY.md 8(d) per-unit figures (fp32 storage of inputs and H blocks, each input once,
+    each distinct output once) x the units one launch processes."""
+    lin = 136 * n_lm + 48 * n_sp + 24 * n_dm              # fused linearise+assemble, BA form
+    spmv = 40 * (n_blocks + n_lm) + 76 * n_lm             # BSR SpMV: 3x3 blocks (off-diag + diag), 6x3 H_pl
+    return lin, spmv
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (kind "port": NumPy/SciPy restatement of the reference, oracle/nrs_oracle.py)
+    timed on this host, 1 core, on a bounded sample: the same generator at the reference's own
+    window size (5 keyframes, g2o_optimization.cc:894) with 400 points -- C2 itself (275k unknowns,
+    full sparse Cholesky per trial) does not finish in minutes on a CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nrs
+    import nrs_oracle as O
+    import nrs_synth as S
+    p = S.make_dba_problem(400, 5, 1)
+    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    t0 = time.perf_counter()
+    iters = 0
+    runs = 0
+    while True:
+        _, _, _, nit = O.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"],
+                                   p["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], 5)
+        iters += nit
+        runs += 1
+        if time.perf_counter() - t0 > seconds_budget or runs >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port",
+                sample="optimize(5) on 400 points x 5 keyframes (%d landmarks, %d springs, %d dampers), %d runs, %.1f s"
+                       % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]), runs, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    import nrs
+    import nrs_synth as S
+
+    n_points, n_kf, seed, model = S.CONFIGS[args.workload]
+    p = S.make_dba_problem(n_points, n_kf, seed + 1000 * rank, model)
+    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx = nrs.Context(device=local_rank)          # fails loudly without a HIP device
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.dba_reset()
+        ctx.dba_optimize(5)
+    barrier()
+    t0 = time.perf_counter()
+    lm_iters = 0
+    trials = 0
+    inner = 0
+    for _ in range(args.steps):
+        ctx.dba_reset()
+        tr = nrs.Trace(64)
+        ctx.dba_optimize(5, tr)              # returns after the last host read-back: stream is idle
+        lm_iters += tr.iterations
+        trials += tr.c.count
+        inner += sum(t["inner"] for t in tr.trials)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        it = torch.tensor([float(lm_iters)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        lm_iters_all = float(it.item())
+    else:
+        lm_iters_all = float(lm_iters)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernels: HIP events on the context's own stream ----------
+        pctx = nrs.Context(device=local_rank, profile=1)
+        pctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        pctx.dba_optimize(5)
+        pctx.reset_profile()
+        pctx.dba_reset()
+        pctx.dba_optimize(5)
+        prof = pctx.profile()
+        pctx.close()
+        n_lm, n_sp, n_dm = len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"])
+        nblk = unique_blocks(n_lm, e["sp_ij"], e["dm_idx"])
+        lin_b, spmv_b = algorithmic_bytes(n_lm, n_sp, n_dm, nblk)
+        spmv_us = 1e3 * prof["spmv_ms"] / max(1, prof["spmv_launches"])
+        lin_us = 1e3 * prof["linearize_ms"] / max(1, prof["linearize_launches"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC pass, see profiles/README.md
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.workload, {})
+        spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
+        lin_gbs = lin_b / (lin_us * 1e-6) / 1e9
+        out = {
+            "metric": "deformable-BA LM iters/sec", "value": lm_iters_all / dt, "unit": "LM iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (fp32 projection, as the reference)", "data": "synthetic",
+            "config": {"workload": "%s: %d map points x %d keyframes, %s, every point a graph node; "
+                                   "optimize(5) per step" % (args.workload, n_points, n_kf,
+                                                             "pinhole" if model == 0 else "KannalaBrandt8"),
+                       "landmarks": n_lm, "springs": n_sp, "dampers": n_dm,
+                       "lm_trials_per_step": trials / args.steps, "pcg_iters_per_step": inner / args.steps,
+                       "parallelism": "independent BA window per GPU" if world > 1 else "1 GPU"},
+            "roofline": {"kernel": "k_spmv (PCG operator apply, dominant: see profiles/)", "bound": "hbm",
+                         "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("k_spmv"), "avg_us": spmv_us,
+                         "algorithmic_bytes": spmv_b, "launches": prof["spmv_launches"]},
+            "roofline_linearize": {"kernel": "k_reproj<true> + k_reg<true> (residual/Jacobian + assemble)", "bound": "hbm",
+                                   "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"),
+                                   "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

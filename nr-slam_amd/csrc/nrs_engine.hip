@@ -80,6 +80,7 @@ struct DbaDev {
     double* scal;                    // misc device scalars (see enum)
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
     int n_regblk;                    // workgroups of the T-lane kernels
+    int n_vecblk;                    // workgroups of the one-thread-per-row kernels
 };
 
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4 /* gamma_old, alpha_old */, SC_SLOT1 = 6, SC_N = 16 };
@@ -347,9 +348,11 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
 // =====================================================================================
 template <bool LIN>
 __global__ __launch_bounds__(BLK) void k_finalize(DbaDev P) {
-    __shared__ double lds[4 * 2];
+    __shared__ double lds[4 * 3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double chi = 0, md = 0;
+    double chi = 0, md = 0, sc = 0;
+    if (!LIN)
+        for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
     for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
     for (int b = tid; b < P.n_regblk; b += BLK) {
         chi += P.part_reg[2 * (size_t)b];
@@ -370,16 +373,15 @@ __global__ __launch_bounds__(BLK) void k_finalize(DbaDev P) {
         }
     }
     double c = wave_sum(chi);
+    sc = wave_sum(sc);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
-    if (lane == 0) { lds[wave * 2] = c; lds[wave * 2 + 1] = md; }
+    if (lane == 0) { lds[wave * 3] = c; lds[wave * 3 + 1] = md; lds[wave * 3 + 2] = sc; }
     __syncthreads();
     if (tid == 0) {
-        P.scal[SC_CHI] = lds[0] + lds[2] + lds[4] + lds[6];
-        if (LIN) P.scal[SC_MAXDIAG] = fmax(fmax(lds[1], lds[3]), fmax(lds[5], lds[7]));
-        double sc = 0;
-        for (int b = 0; b < P.n_regblk; ++b) sc += P.part_apply[b];
-        if (!LIN) P.scal[SC_SCALE] = sc;
+        P.scal[SC_CHI] = lds[0] + lds[3] + lds[6] + lds[9];
+        if (LIN) P.scal[SC_MAXDIAG] = fmax(fmax(lds[1], lds[4]), fmax(lds[7], lds[10]));
+        if (!LIN) P.scal[SC_SCALE] = lds[2] + lds[5] + lds[8] + lds[11];
     }
 }
 
@@ -795,7 +797,7 @@ static int dba_upload_impl(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, cons
     c->dba = pb;
     DbaDev& d = pb->d;
     memset(&d, 0, sizeof(d));
-    int T = 4;
+    int T = 2;                       // lanes per row; 2 measured best on C2 (profiles/README.md)
     if (const char* e = getenv("NRS_SELL_T")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) T = v;
@@ -835,14 +837,47 @@ static int dba_upload_impl(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, cons
     d.n_rows = d.n_groups * ROW_ALIGN;
     const int rows_per_regblk = BLK / T;
     d.n_regblk = d.n_rows / rows_per_regblk;
+    d.n_vecblk = d.n_rows / BLK;
+    // Inside a keyframe the rows are ordered along a Morton curve of the initial positions, so
+    // that the graph neighbours of one workgroup's rows share cache lines (private row order:
+    // the C ABI keeps the caller's landmark order).
     pb->lm_row.resize(n_lm);
     std::vector<int> row_lm(d.n_rows, -1);
-    for (int k = 0; k < n_kf; ++k)
-        for (int l = pb->kf_ptr[k]; l < pb->kf_ptr[k + 1]; ++l) {
-            const int row = kf_grp_ptr[k] * ROW_ALIGN + (l - pb->kf_ptr[k]);
-            pb->lm_row[l] = row;
-            row_lm[row] = l;
+    {
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int l = 0; l < n_lm; ++l)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], lm_xyz[3 * l + a]); hi[a] = std::max(hi[a], lm_xyz[3 * l + a]); }
+        auto spread = [](uint64_t v) {            // 21 bits -> every third bit
+            v &= 0x1fffff;
+            v = (v | v << 32) & 0x1f00000000ffffULL;
+            v = (v | v << 16) & 0x1f0000ff0000ffULL;
+            v = (v | v << 8) & 0x100f00f00f00f00fULL;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+            v = (v | v << 2) & 0x1249249249249249ULL;
+            return v;
+        };
+        const bool morton = getenv("NRS_NO_MORTON") == nullptr;
+        std::vector<std::pair<uint64_t, int>> keys;
+        for (int k = 0; k < n_kf; ++k) {
+            keys.clear();
+            for (int l = pb->kf_ptr[k]; l < pb->kf_ptr[k + 1]; ++l) {
+                uint64_t code = 0;
+                if (morton)
+                    for (int a = 0; a < 3; ++a) {
+                        const float ext = hi[a] - lo[a];
+                        const double f = ext > 0 ? (lm_xyz[3 * l + a] - lo[a]) / ext : 0.0;
+                        code |= spread((uint64_t)(f * 2097151.0)) << a;
+                    }
+                keys.emplace_back(code, l);
+            }
+            std::stable_sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size(); ++i) {
+                const int row = kf_grp_ptr[k] * ROW_ALIGN + (int)i;
+                pb->lm_row[keys[i].second] = row;
+                row_lm[row] = keys[i].second;
+            }
         }
+    }
     // ---- incidence lists
     std::vector<std::vector<Inc>> rs(d.n_rows), rd(d.n_rows);
     for (int e = 0; e < n_sp; ++e) {
@@ -982,10 +1017,10 @@ static void launch_reg(nrs_ctx* c, const DbaDev& d, const double* xl) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
         case 1: hipLaunchKernelGGL((k_reg<1, LIN>), g, b, 0, c->stream, d, xl); break;
-        case 2: hipLaunchKernelGGL((k_reg<2, LIN>), g, b, 0, c->stream, d, xl); break;
         case 8: hipLaunchKernelGGL((k_reg<8, LIN>), g, b, 0, c->stream, d, xl); break;
         case 16: hipLaunchKernelGGL((k_reg<16, LIN>), g, b, 0, c->stream, d, xl); break;
-        default: hipLaunchKernelGGL((k_reg<4, LIN>), g, b, 0, c->stream, d, xl); break;
+        case 4: hipLaunchKernelGGL((k_reg<4, LIN>), g, b, 0, c->stream, d, xl); break;
+        default: hipLaunchKernelGGL((k_reg<2, LIN>), g, b, 0, c->stream, d, xl); break;
     }
 }
 
@@ -993,10 +1028,10 @@ static void launch_spmv(nrs_ctx* c, const DbaDev& d, double lam) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
         case 1: hipLaunchKernelGGL((k_spmv<1>), g, b, 0, c->stream, d, lam); break;
-        case 2: hipLaunchKernelGGL((k_spmv<2>), g, b, 0, c->stream, d, lam); break;
         case 8: hipLaunchKernelGGL((k_spmv<8>), g, b, 0, c->stream, d, lam); break;
         case 16: hipLaunchKernelGGL((k_spmv<16>), g, b, 0, c->stream, d, lam); break;
-        default: hipLaunchKernelGGL((k_spmv<4>), g, b, 0, c->stream, d, lam); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4>), g, b, 0, c->stream, d, lam); break;
+        default: hipLaunchKernelGGL((k_spmv<2>), g, b, 0, c->stream, d, lam); break;
     }
 }
 
