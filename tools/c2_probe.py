@@ -1,6 +1,6 @@
 """Scratch probe: time the resident C2 solve and print the LM/PCG trace."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd/py"))
 import numpy as np, nrs, nrs_synth as S
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"
