@@ -57,7 +57,7 @@ def cpu_baseline(seconds_budget=20.0):
     import nrs_oracle as O
     import nrs_synth as S
     p = S.make_dba_problem(400, 5, 1)
-    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     t0 = time.perf_counter()
     iters = 0
     runs = 0
@@ -97,7 +97,7 @@ def main():
 
     n_points, n_kf, seed, model = S.CONFIGS[args.workload]
     p = S.make_dba_problem(n_points, n_kf, seed + 1000 * rank, model)
-    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     ctx = nrs.Context(device=local_rank)          # fails loudly without a HIP device

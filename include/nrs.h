@@ -148,6 +148,50 @@ int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_s
                       double* r_damper /* n_damper x 3 */);
 int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
 
+/* ---- a19 / a20: RegularizationGraph (modules/map/regularization_graph.{h,cc}) ------------------
+ * Flat form of the graph: undirected edges carry the fields of RegularizationGraph::Edge
+ * (regularization_graph.h:49-59); the raw CSR lists, per map point, its neighbours in ascending
+ * index order (= the btree_map ID order GetEdges starts from) together with the undirected edge id.
+ * Weights are (float)exp((double)arg) of the float argument -(d*d)/(2*sigma*sigma)
+ * (utilities/geometry_toolbox.cc:26-28; see DESIGN.md "weights"). */
+typedef struct {
+    int32_t n_points;
+    const int32_t* rowptr;    /* n_points+1 */
+    const int32_t* col;       /* nnz = 2 * n_edges, ascending inside a row */
+    const int32_t* eid;       /* nnz -> undirected edge */
+    int32_t n_edges;
+    float* e_w;               /* in/out: weight                */
+    const float* e_d0;        /*         first_distance        */
+    float* e_max;             /* in/out: max_distance          */
+    float* e_min;             /* in/out: min_distance          */
+    int32_t* e_status;        /* in/out: NRS_GRAPH_*           */
+    float sigma;              /* options_.weight_sigma         */
+    float stretch_th;         /* options_.streching_th (1.1)   */
+} nrs_graph;
+
+/* RegularizationGraph::GetEdges for every point (regularization_graph.cc:61-87): neighbours sorted
+ * by (status asc, weight desc, index asc) and cut at the first weight below min_weight =
+ * InterpolationWeight(1.5 sigma, sigma).  o_col / o_eid need room for nnz entries. */
+int nrs_graph_select_neighbours(nrs_ctx* ctx, const nrs_graph* g, int32_t* o_rowptr, int32_t* o_col,
+                                int32_t* o_eid);
+
+/* RegularizationGraph::UpdateVertex for the listed points (regularization_graph.cc:89-146): every
+ * edge of such a point is refreshed from pos (n_points x 3 last world positions); good_count[i] =
+ * connections of ids[i] that pass the stretch test. */
+int nrs_graph_update(nrs_ctx* ctx, nrs_graph* g, const float* pos, int32_t n_ids, const int32_t* ids,
+                     int32_t* good_count);
+
+/* ---- a2: CameraPoseAndDeformationOptimization (g2o_optimization.cc:148-557) ------------------
+ * Frame side: n_f landmarks in frame index order with their map-point index (f_map, -1 = none),
+ * LandmarkStatus (in/out), keypoint (f_uv) and position (f_pos, in/out).  Map side: the graph
+ * (updated in place, OPT:458-474) and MapPoint::GetLastWorldPosition of every map point (map_pos,
+ * in/out).  pose_qt in: frame pose; out: refined pose.  Outputs: Frame::SetDeformationMaginitud
+ * value, and the re-located lost map points (lost needs room for n_points entries). */
+int nrs_track_deform_solve(nrs_ctx* ctx, const nrs_camera* cam, nrs_graph* g, float* map_pos,
+                           int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                           float* f_pos, double pose_qt[7], float scale, float* deform_median,
+                           int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
+
 #ifdef __cplusplus
 }
 #endif

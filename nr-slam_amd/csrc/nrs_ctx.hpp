@@ -16,7 +16,8 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct DbaProblem;   // nrs_engine.hip
+struct Engine;       // nrs_engine.hip
+struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 
 }  // namespace nrs
 
@@ -30,8 +31,10 @@ struct nrs_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for a1
     nrs::DevBuf po_uv, po_X, po_err, po_level, po_out, po_trace;
-    // resident BA problem
-    nrs::DbaProblem* dba = nullptr;
+    // resident BA problem (a3) and per-call tracking problems (a2): one reusable arena each
+    nrs::Engine* dba = nullptr;
+    nrs::Arena arena_dba, arena_trk;
+    std::vector<int32_t> dba_lm_kf;
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;

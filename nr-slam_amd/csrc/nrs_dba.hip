@@ -1,0 +1,124 @@
+// a3: LocalDeformableBundleAdjustment C-ABI entry points (reference
+// modules/optimization/g2o_optimization.cc:880-1161) on top of the graph LM engine.
+#include "nrs_engine.hpp"
+
+namespace nrs {
+
+void dba_free(nrs_ctx* c) {
+    if (c->dba) engine_destroy(c, c->dba);
+    c->dba = nullptr;
+}
+
+// constants of OPT:958-973 (float arithmetic, widened to double like g2o does)
+void ba_constants(EngineSpec& s, float scale) {
+    const float th2 = sqrtf(5.99f), th3 = sqrtf(0.584f);
+    const float sigma_rep = 0.5f, sigma_pos = 0.1f;
+    const float sigma_spatial = (float)(0.1 * (double)scale);
+    s.info_reproj = (double)(1.0f / (sigma_rep * sigma_rep));
+    s.delta_reproj = (double)th2;
+    s.info_pos = (double)(1.0f / (sigma_pos * sigma_pos));
+    s.info_spatial = (double)(1.0f / (sigma_spatial * sigma_spatial));
+    s.delta_spatial = (double)th3;
+    s.k_spring = (double)1.1f;
+}
+
+}  // namespace nrs
+
+using namespace nrs;
+
+extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                              int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                              int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                              int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!cam || n_kf <= 0 || n_lm <= 0 || !poses_qt || !lm_xyz || !lm_kf || !lm_uv || n_sp < 0 || n_dm < 0 ||
+        (n_sp > 0 && (!sp_ij || !sp_d0)) || (n_dm > 0 && (!dm_idx || !dm_w)))
+        return c->fail(NRS_ERR_INVALID, "nrs_dba_upload: bad argument");
+    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    for (int64_t i = 0; i < 4 * (int64_t)n_dm; ++i)
+        if (dm_idx[i] < 0) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+    dba_free(c);
+    EngineSpec s;
+    s.K = n_kf;
+    s.M = n_lm;
+    std::vector<Pose> poses(n_kf);
+    for (int k = 0; k < n_kf; ++k) {
+        for (int i = 0; i < 4; ++i) poses[k].q[i] = poses_qt[7 * k + i];
+        for (int i = 0; i < 3; ++i) poses[k].t[i] = poses_qt[7 * k + 4 + i];
+        quat_normalize(poses[k].q);                                  // SE3Quat ctor (se3quat.h:56-58)
+    }
+    std::vector<double> x(3 * (size_t)n_lm);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (double)lm_xyz[i];  // OPT:943 cast<double>
+    std::vector<uint8_t> rflag(n_lm, RF_OBS | RF_REPROJ_ACTIVE);
+    s.poses = poses.data();
+    s.x = x.data();
+    s.lm_pose = lm_kf;
+    s.uv = lm_uv;
+    s.rflag = rflag.data();
+    s.n_sp = n_sp; s.sp_ij = sp_ij; s.sp_d0 = sp_d0;
+    s.n_dm = n_dm; s.dm_idx = dm_idx; s.dm_w = dm_w;
+    s.cam.model = cam->model;
+    for (int i = 0; i < 8; ++i) s.cam.p[i] = cam->params[i];
+    ba_constants(s, scale);
+    s.delta_pos = 0.0;                  // no robust kernel on the BA springs (OPT:1057-1071)
+    s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
+    return engine_create(c, s, &c->arena_dba, &c->dba);
+}
+
+extern "C" int nrs_dba_reset(nrs_ctx* c) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    return engine_reset(c, c->dba);
+}
+
+extern "C" int nrs_dba_optimize(nrs_ctx* c, int32_t iters, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if (trace) { trace->count = 0; trace->iterations = 0; }
+    return engine_optimize(c, c->dba, iters, 0, trace);
+}
+
+static int download(nrs_ctx* c, int n_kf, double* poses_qt, double* xyz) {
+    std::vector<Pose> poses(n_kf);
+    NRS_TRY(engine_download(c, c->dba, poses.data(), xyz));
+    if (poses_qt)
+        for (int k = 0; k < n_kf; ++k) {
+            for (int i = 0; i < 4; ++i) poses_qt[7 * k + i] = poses[k].q[i];
+            for (int i = 0; i < 3; ++i) poses_qt[7 * k + 4 + i] = poses[k].t[i];
+        }
+    return NRS_OK;
+}
+
+extern "C" int nrs_dba_download(nrs_ctx* c, double* poses_qt, double* lm_xyz) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    return download(c, engine_num_poses(c->dba), poses_qt, lm_xyz);
+}
+
+extern "C" int nrs_dba_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, double* poses_qt,
+                             int32_t n_lm, float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                             int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                             int32_t n_dm, const int32_t* dm_idx, const float* dm_w,
+                             float scale, int32_t iters, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    NRS_TRY(nrs_dba_upload(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale));
+    NRS_TRY(nrs_dba_optimize(c, iters, trace));
+    std::vector<double> xyz((size_t)n_lm * 3);
+    NRS_TRY(download(c, n_kf, poses_qt, xyz.data()));
+    for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
+    return NRS_OK;
+}
+
+extern "C" int nrs_dba_residuals(nrs_ctx* c, double* r_reproj, double* r_spring, double* r_damper) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if (!r_reproj || !r_spring || !r_damper) return c->fail(NRS_ERR_INVALID, "null output");
+    return engine_residuals(c, c->dba, r_reproj, r_spring, r_damper);
+}
+
+extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if (!b || !diag) return c->fail(NRS_ERR_INVALID, "null output");
+    return engine_gradient(c, c->dba, b, diag);
+}

@@ -1,24 +1,30 @@
-// a3: LocalDeformableBundleAdjustment on MI355X
-// (reference modules/optimization/g2o_optimization.cc:880-1161 + the g2o machinery it drives:
-//  third_party/g2o/g2o/core/{optimization_algorithm_levenberg.cpp:57-174, block_solver.hpp:495-562,
-//  base_fixed_sized_edge.hpp:49-133, robust_kernel_impl.cpp:60-74}).
+// Graph Levenberg-Marquardt engine for MI355X: the numerical core behind
+//   a2 CameraPoseAndDeformationOptimization (reference g2o_optimization.cc:148-557) and
+//   a3 LocalDeformableBundleAdjustment       (reference g2o_optimization.cc:880-1161),
+// i.e. the g2o machinery those functions drive (third_party/g2o/g2o/core/
+// optimization_algorithm_levenberg.cpp:57-174, block_solver.hpp:495-562,
+// base_fixed_sized_edge.hpp:49-133, robust_kernel_impl.cpp:60-74, sparse_optimizer.cpp:203-285).
 //
 // Design (MI355X-first, not a translation of g2o's pointer graph):
-//   * unknowns: K pose blocks (6) then one 3-dof block per landmark ROW.  Landmarks are laid out
-//     keyframe-major and every keyframe is padded to a multiple of ROW_ALIGN rows, so a workgroup
-//     never straddles two keyframes and the per-pose reductions are plain block reductions.
+//   * unknowns: K pose blocks (6) then one 3-dof block per landmark ROW.  Rows are laid out
+//     pose-major and every pose's rows are padded to a multiple of ROW_ALIGN, so a workgroup
+//     never straddles two poses and the per-pose reductions are plain block reductions.  Inside
+//     a pose the rows follow a Morton curve of the initial positions: graph neighbours share
+//     cache lines.
 //   * every edge is owned by the rows it touches ("incidence lists", sliced-ELL layout: a wave64
 //     serves 64/T rows with T lanes per row; element (row r, lane t, step j) of a slice lives at
 //     base + j*64 + r*T + t so all loads of a wave are one contiguous 64-element run).  Nothing
 //     is scattered: no atomics, no assembly maps, bit-reproducible sums.
-//   * H is never assembled.  The damped normal equations (H + lambda I) x = b are solved by a
-//     block-Jacobi preconditioned conjugate gradient (single-reduction Chronopoulos-Gear form:
-//     2 launches per iteration) whose operator is applied from per-incidence factors:
+//   * H is never assembled.  (H + lambda I) x = b is solved by a block-Jacobi preconditioned
+//     conjugate gradient (single-reduction Chronopoulos-Gear form: 2 launches per iteration)
+//     whose operator is applied from per-incidence factors:
 //         spring  : q g g^T is rank one          -> store g~ = sqrt(q) g      (24 B)
 //         damper  : all 16 blocks are +-s I3      -> store s                   (8 B)
-//         reproj  : H_pl (6x3), H_ll in the row's 3x3 diagonal block, H_pp reduced per keyframe
+//         reproj  : H_pl (6x3), H_ll in the row's 3x3 diagonal block, H_pp reduced per pose
 //     The reference factorises the same matrix with a sparse Cholesky (no Schur: H_ll is not
 //     block diagonal); PCG to 1e-10 relative residual reproduces its iterates.
+//   * g2o levels / fixed vertices are byte masks: inactive edges store zero factors, fixed rows
+//     are identity rows whose columns vanish because their PCG vectors stay zero.
 //   * LM control flow (lambda schedule, accept/reject, <=10 trials) runs on the host exactly as in
 //     g2o; per trial the host reads back two scalars.  PCG convergence is detected on device; the
 //     host only polls a flag once per batch of iterations.
@@ -28,34 +34,38 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
-#include "nrs_ctx.hpp"
-#include "nrs_device.hpp"
+#include "nrs_engine.hpp"
 
 namespace nrs {
 
-constexpr int ROW_ALIGN = 256;       // keyframe row padding; also rows per k_reproj workgroup
+constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj workgroup
 constexpr int BLK = 256;             // threads per workgroup everywhere
 constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel
 
-struct Sell {                        // sliced-ELL incidence storage (device pointers)
-    int* slice_ptr;                  // n_slices+1, element offsets (multiples of 64)
-    int nnz;                         // total padded elements
-};
+// incidence meta bits
+constexpr int SM_COUNT = 1 << 30;    // spring: this incidence adds the edge's rho to chi2
+constexpr int SM_ACTIVE = 1 << 29;   // spring: edge is at level 0
+constexpr int DM_COUNT = 1 << 2;     // damper: bits 0-1 role
+constexpr int DM_ACTIVE = 1 << 3;
+constexpr int DM_UNARY = 1 << 4;     // damper: the other vertex is a value, not a variable
 
-struct DbaDev {
-    int K, M, n_rows, n_groups;      // poses, landmarks, padded rows, ROW_ALIGN groups
+struct Dev {
+    int K, M, n_rows, n_groups;      // poses, vertices, padded rows, ROW_ALIGN groups
     int T;                           // lanes per row
-    int n_sp, n_dm;
+    int n_sp, n_dm, n_un;
+    int n_regblk, n_vecblk;
     Cam cam;
     double info_reproj, delta_reproj, info_pos, delta_pos, info_spatial, delta_spatial, k_spring;
-    int spring_form;                 // 0 = BA Jacobian as written (position_regularizer.cc:51-60)
+    int spring_form;
     // rows
-    int* grp_kf;                     // n_groups -> pose index
-    int* kf_grp_ptr;                 // K+1 -> group ranges
-    int* row_lm;                     // n_rows -> landmark index or -1 (padding)
+    int* grp_pose;                   // n_groups -> pose index
+    int* pose_grp_ptr;               // K+1 -> group ranges
+    uint8_t* rflag;                  // n_rows
+    uint8_t* pose_fixed;             // K
     float* uv;                       // n_rows x 2
-    // incidences
-    Sell ss, sd;
+    double* X0;                      // n_rows x 3 or null
+    // incidences (sliced ELL)
+    int* ss_ptr; int ss_nnz; int* sd_ptr; int sd_nnz;
     int* s_other; float* s_d0; int* s_meta;
     int* d_o0; int* d_o1; int* d_o2; float* d_w; int* d_meta;
     // state (two copies: current / trial, swapped on accept)
@@ -76,25 +86,30 @@ struct DbaDev {
     double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
     double* part_reg;                // n_regblk x 2    (chi, maxdiag)
     double* part_spmv;               // n_regblk x NPART
-    double* part_apply;              // n_regblk x 1
-    double* scal;                    // misc device scalars (see enum)
+    double* part_apply;              // n_vecblk
+    double* scal;
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
-    int n_regblk;                    // workgroups of the T-lane kernels
-    int n_vecblk;                    // workgroups of the one-thread-per-row kernels
 };
 
-enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4 /* gamma_old, alpha_old */, SC_SLOT1 = 6, SC_N = 16 };
+enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
 
-struct DbaProblem {
-    DbaDev d;
-    std::vector<void*> allocs;
-    std::vector<int> kf_ptr;         // K+1 landmark ranges
-    std::vector<int> lm_row;         // landmark -> row
-    int cur = 0;                     // which state copy is current
-    double* h_scal = nullptr;        // pinned host mirror
+struct Engine {
+    Dev d;
+    Arena* arena = nullptr;
+    int cur = 0;
+    double* h_scal = nullptr;        // pinned host mirrors
     int* h_flags = nullptr;
-    std::vector<int> sp_ij, dm_idx;  // host copies for the residual tap
-    std::vector<float> sp_d0, dm_w;
+    std::vector<int> vrow;           // vertex -> row
+    // host copies needed to rewrite masks and to run the edge taps
+    std::vector<int> sp_ij, dm_idx, un_ij;
+    std::vector<float> sp_d0, dm_w, un_w;
+    std::vector<int> sp_pos, dm_pos, un_pos;     // SELL positions of every incidence (2 / 4 / 1 per edge)
+    std::vector<int> h_s_meta, h_d_meta;
+    std::vector<uint8_t> h_rflag, h_pose_fixed;
+    // device copies for the taps
+    int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
+    float *t_d0 = nullptr, *t_w = nullptr;
+    double* t_out = nullptr;
 };
 
 // =====================================================================================
@@ -118,7 +133,7 @@ __device__ inline void block_sum(double* v, double* lds /* 4*N */, int lane, int
     __syncthreads();
 }
 
-// same reduction, totals written to out[0..N) by the first N threads (avoids dynamic register indexing)
+// same reduction, totals written to out[0..N) by the first N threads
 template <int N>
 __device__ inline void block_sum_store(const double* v, double* lds /* 4*N */, int tid, double* out) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -146,32 +161,41 @@ __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double la
     return det > 0;
 }
 
+__device__ inline double damper_sign(int role) { return (role == 0 || role == 3) ? -1.0 : 1.0; }
+
 // =====================================================================================
-// linearisation, part 1: reprojection edges.  One thread per row, one keyframe per workgroup.
-//   ReprojectionError::computeError / linearizeOplus (reference reprojection_error.cc:32-64),
+// linearisation, part 1: reprojection edges.  One thread per row, one pose per workgroup.
+//   ReprojectionError / ReprojectionErrorWithDeformation computeError + linearizeOplus
+//   (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68),
 //   quadratic form with Huber weight (base_fixed_sized_edge.hpp:49-63, base_edge.h:158-164).
 // =====================================================================================
 template <bool LIN>
-__global__ __launch_bounds__(BLK) void k_reproj(DbaDev P, const Pose* __restrict__ poses,
+__global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ poses,
                                                 const double* __restrict__ xl) {
     __shared__ double lds[4 * 28];
     const int g = xcd_tile(blockIdx.x, P.n_groups);
     if (g >= P.n_groups) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = g * ROW_ALIGN + tid;
-    const int kf = P.grp_kf[g];
-    const Pose T = poses[kf];
+    const int kf = P.grp_pose[g];
+    const Pose Tcw = poses[kf];
+    const bool pfix = P.pose_fixed[kf] != 0;
     double R[9];
-    quat_to_R(T.q, R);
+    quat_to_R(Tcw.q, R);
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0;
-    const bool valid = P.row_lm[row] >= 0;
-    if (valid) {
-        const double x0 = xl[3 * row], x1 = xl[3 * row + 1], x2 = xl[3 * row + 2];
-        const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + T.t[0];
-        const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + T.t[1];
-        const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + T.t[2];
+    const int rf = P.rflag[row];
+    const bool rfix = (rf & RF_FIXED) != 0;
+    // an edge whose vertices are all fixed is not part of the optimisation (sparse_optimizer.cpp:236)
+    const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
+    bool wrote = false;
+    if (active) {
+        double x0 = xl[3 * row], x1 = xl[3 * row + 1], x2 = xl[3 * row + 2];
+        if (P.X0) { x0 += P.X0[3 * row]; x1 += P.X0[3 * row + 1]; x2 += P.X0[3 * row + 2]; }
+        const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + Tcw.t[0];
+        const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + Tcw.t[1];
+        const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + Tcw.t[2];
         float u, v;
         project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
         const double r0 = (double)P.uv[2 * row] - (double)u, r1 = (double)P.uv[2 * row + 1] - (double)v;
@@ -182,17 +206,18 @@ __global__ __launch_bounds__(BLK) void k_reproj(DbaDev P, const Pose* __restrict
             float Jf[6];
             projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
             const double w = rho1 * P.info_reproj;
+            const double pm = pfix ? 0.0 : 1.0, lm = rfix ? 0.0 : 1.0;
             double Jp[2][6], Jl[2][3];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
-                Jp[rr][0] = -j1 * pz + j2 * py;
-                Jp[rr][1] = j0 * pz - j2 * px;
-                Jp[rr][2] = -j0 * py + j1 * px;
-                Jp[rr][3] = j0; Jp[rr][4] = j1; Jp[rr][5] = j2;
-                Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
-                Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
-                Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+                Jp[rr][0] = pm * (-j1 * pz + j2 * py);
+                Jp[rr][1] = pm * (j0 * pz - j2 * px);
+                Jp[rr][2] = pm * (-j0 * py + j1 * px);
+                Jp[rr][3] = pm * j0; Jp[rr][4] = pm * j1; Jp[rr][5] = pm * j2;
+                Jl[rr][0] = lm * (j0 * R[0] + j1 * R[3] + j2 * R[6]);
+                Jl[rr][1] = lm * (j0 * R[1] + j1 * R[4] + j2 * R[7]);
+                Jl[rr][2] = lm * (j0 * R[2] + j1 * R[5] + j2 * R[8]);
             }
             int k = 0;
 #pragma unroll
@@ -217,8 +242,10 @@ __global__ __launch_bounds__(BLK) void k_reproj(DbaDev P, const Pose* __restrict
             P.bl[3 * row] = -w * (Jl[0][0] * r0 + Jl[1][0] * r1);
             P.bl[3 * row + 1] = -w * (Jl[0][1] * r0 + Jl[1][1] * r1);
             P.bl[3 * row + 2] = -w * (Jl[0][2] * r0 + Jl[1][2] * r1);
+            wrote = true;
         }
-    } else if (LIN) {
+    }
+    if (LIN && !wrote) {
 #pragma unroll
         for (int c = 0; c < 18; ++c) P.Hpl[(size_t)c * P.n_rows + row] = 0;
 #pragma unroll
@@ -237,10 +264,13 @@ __global__ __launch_bounds__(BLK) void k_reproj(DbaDev P, const Pose* __restrict
 // =====================================================================================
 // linearisation, part 2: springs and dampers from the incidence lists (T lanes per row).
 //   PositionRegularizer (position_regularizer.cc:32-61, Jacobian as written),
-//   SpatialRegularizer  (spatial_regularizer.cc:32-59).
+//   PositionRegularizerWithDeformation (position_regularizer_with_deformation.cc:31-57),
+//   SpatialRegularizer (spatial_regularizer.cc:32-59), SpatialRegularizerWithDeformation
+//   (spatial_regularizer_with_deformation.cc:36-49), SpatialRegularizerFixed
+//   (spatial_regularizer_fixed.cc:32-43).
 // =====================================================================================
 template <int T, bool LIN>
-__global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict__ xl) {
+__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl) {
     __shared__ double lds[4 * 2];
     constexpr int R = 64 / T;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
@@ -249,30 +279,41 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
+    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     const double xo0 = xl[3 * row], xo1 = xl[3 * row + 1], xo2 = xl[3 * row + 2];
+    double xs0 = xo0, xs1 = xo1, xs2 = xo2;                 // spring position = X0 + x
+    if (P.X0) { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
     double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
     // ---- springs
     {
-        const int beg = P.ss.slice_ptr[slice], end = P.ss.slice_ptr[slice + 1];
+        const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
+        const size_t nz = (size_t)P.ss_nnz;
         for (int idx = beg + lane; idx < end; idx += 64) {
             const int o = P.s_other[idx];
             if (o < 0) continue;
+            const int meta = P.s_meta[idx];
+            if (!(meta & SM_ACTIVE)) {
+                if (LIN) { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+                continue;
+            }
             const double d0 = (double)P.s_d0[idx];
-            const double v0 = xo0 - xl[3 * o], v1 = xo1 - xl[3 * o + 1], v2 = xo2 - xl[3 * o + 2];
+            double y0 = xl[3 * o], y1 = xl[3 * o + 1], y2 = xl[3 * o + 2];
+            if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
+            const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
             const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
             const double r = P.k_spring * (d - d0) / d0;
             double rho0, rho1;
             huber(P.info_pos * r * r, P.delta_pos, rho0, rho1);
-            if (P.s_meta[idx] >> 30) chi += rho0;
+            if (meta & SM_COUNT) chi += rho0;
             if (LIN) {
                 const double cg = P.spring_form == 0 ? (P.k_spring / d0) * (1.0 / sqrt(d)) * 2.0
-                                                     : P.k_spring / (d0 * d);
-                const double q = rho1 * P.info_pos;
+                                                     : (P.k_spring / (2 * d0 * d)) * 2.0;
+                const double q = rfix ? 0.0 : rho1 * P.info_pos;
                 const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
                 const double sq = sqrt(q);
                 P.s_g[idx] = sq * g0;
-                P.s_g[(size_t)P.ss.nnz + idx] = sq * g1;
-                P.s_g[2 * (size_t)P.ss.nnz + idx] = sq * g2;
+                P.s_g[nz + idx] = sq * g1;
+                P.s_g[2 * nz + idx] = sq * g2;
                 D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
                 D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
                 const double qr = q * r;
@@ -282,19 +323,22 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
     }
     // ---- dampers: r = w((x1n - x1c) - (x2n - x2c)), roles (1c,2c,1n,2n), signs (-,+,+,-)
     {
-        const int beg = P.sd.slice_ptr[slice], end = P.sd.slice_ptr[slice + 1];
+        const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
         for (int idx = beg + lane; idx < end; idx += 64) {
             const int meta = P.d_meta[idx];
             if (meta < 0) continue;
+            if (!(meta & DM_ACTIVE)) {
+                if (LIN) P.d_s[idx] = 0;
+                continue;
+            }
             const int role = meta & 3;
             const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
             const double w = (double)P.d_w[idx];
-            const double sgn_own = (role == 0 || role == 3) ? -1.0 : 1.0;
+            const double sgn_own = damper_sign(role);
             double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int ro = k + (k >= role ? 1 : 0);          // role of the k-th other vertex
-                const double sg = (ro == 0 || ro == 3) ? -1.0 : 1.0;
+                const double sg = damper_sign(k + (k >= role ? 1 : 0));   // role of the k-th other vertex
                 if (o[k] >= 0) {
                     s0 += sg * xl[3 * o[k]]; s1 += sg * xl[3 * o[k] + 1]; s2 += sg * xl[3 * o[k] + 2];
                 }
@@ -302,12 +346,13 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
             const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
             double rho0, rho1;
             huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho0, rho1);
-            if ((meta >> 2) & 1) chi += rho0;
+            if (meta & DM_COUNT) chi += rho0;
             if (LIN) {
-                const double s = rho1 * P.info_spatial * w * w;
+                const double fx = rfix ? 0.0 : 1.0;
+                const double s = fx * rho1 * P.info_spatial * w * w;
                 P.d_s[idx] = s;
                 D[0] += s; D[3] += s; D[5] += s;
-                const double c = sgn_own * rho1 * P.info_spatial * w;
+                const double c = fx * sgn_own * rho1 * P.info_spatial * w;
                 bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
             }
         }
@@ -330,7 +375,6 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
             part[1] = fmax(fabs(dd[0]), fmax(fabs(dd[3]), fabs(dd[5])));
         }
     }
-    // chi: sum; maxdiag: max  (max via wave butterflies)
     double c = wave_sum(part[0]);
     double m = part[1];
 #pragma unroll
@@ -344,10 +388,10 @@ __global__ __launch_bounds__(BLK) void k_reg(DbaDev P, const double* __restrict_
 }
 
 // =====================================================================================
-// finalize: fixed-order sums of the partials.  LIN: H_pp, b_p, chi2, max diag.  else chi2 only.
+// finalize: fixed-order sums of the partials.  LIN: H_pp, b_p, chi2, max diag.  else chi2, scale.
 // =====================================================================================
 template <bool LIN>
-__global__ __launch_bounds__(BLK) void k_finalize(DbaDev P) {
+__global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
     __shared__ double lds[4 * 3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double chi = 0, md = 0, sc = 0;
@@ -362,7 +406,7 @@ __global__ __launch_bounds__(BLK) void k_finalize(DbaDev P) {
         for (int i = tid; i < P.K * 27; i += BLK) {
             const int k = i / 27, c = i % 27;
             double s = 0;
-            for (int g = P.kf_grp_ptr[k]; g < P.kf_grp_ptr[k + 1]; ++g) s += P.part_lin[(size_t)g * 32 + c];
+            for (int g = P.pose_grp_ptr[k]; g < P.pose_grp_ptr[k + 1]; ++g) s += P.part_lin[(size_t)g * 32 + c];
             if (c < 21) {
                 P.Hpp[k * 21 + c] = s;
                 // diagonal entries of the packed upper triangle: 0,6,11,15,18,20
@@ -428,7 +472,7 @@ __device__ inline bool inv6_spd(const double* Hu, double lam, double* Ainv /*36*
     return ok;
 }
 
-__global__ __launch_bounds__(BLK) void k_trial_setup(DbaDev P, double lam) {
+__global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i < P.n_rows) {
         double Di[6];
@@ -464,7 +508,7 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(DbaDev P, double lam) {
 //   [0] r.u  [1] w.u  [2] u_l.(H_pl^T u_p)  [3..8] H_pl u_l (pose rows)
 // =====================================================================================
 template <int T>
-__global__ __launch_bounds__(BLK) void k_spmv(DbaDev P, double lam) {
+__global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     __shared__ double lds[4 * 9];
     if (P.flags[0]) return;
     constexpr int R = 64 / T;
@@ -474,13 +518,14 @@ __global__ __launch_bounds__(BLK) void k_spmv(DbaDev P, double lam) {
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
+    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     const double* __restrict__ u = P.uv3;
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double ul0 = 0, ul1 = 0, ul2 = 0;
     if (t == 0) {
         ul0 = u[3 * row]; ul1 = u[3 * row + 1]; ul2 = u[3 * row + 2];
-        const int kf = P.grp_kf[row / ROW_ALIGN];
+        const int kf = P.grp_pose[row / ROW_ALIGN];
         const double* D = P.D + 6 * (size_t)row;
         a0 = (D[0] + lam) * ul0 + D[1] * ul1 + D[2] * ul2;
         a1 = D[1] * ul0 + (D[3] + lam) * ul1 + D[4] * ul2;
@@ -498,9 +543,9 @@ __global__ __launch_bounds__(BLK) void k_spmv(DbaDev P, double lam) {
         a0 += h0; a1 += h1; a2 += h2;
         part[2] = ul0 * h0 + ul1 * h1 + ul2 * h2;
     }
-    {
-        const int beg = P.ss.slice_ptr[slice], end = P.ss.slice_ptr[slice + 1];
-        const size_t nz = (size_t)P.ss.nnz;
+    if (!rfix) {
+        const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
+        const size_t nz = (size_t)P.ss_nnz;
         for (int idx = beg + lane; idx < end; idx += 64) {
             const int o = P.s_other[idx];
             if (o < 0) continue;
@@ -509,21 +554,20 @@ __global__ __launch_bounds__(BLK) void k_spmv(DbaDev P, double lam) {
             a0 -= g0 * dot; a1 -= g1 * dot; a2 -= g2 * dot;
         }
     }
-    {
-        const int beg = P.sd.slice_ptr[slice], end = P.sd.slice_ptr[slice + 1];
+    if (!rfix) {
+        const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
         for (int idx = beg + lane; idx < end; idx += 64) {
             const int meta = P.d_meta[idx];
-            if (meta < 0) continue;
+            if (meta < 0 || (meta & DM_UNARY)) continue;          // padding, or value-only other vertex
             const int role = meta & 3;
             const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
             double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int ro = k + (k >= role ? 1 : 0);
-                const double sg = (ro == 0 || ro == 3) ? -1.0 : 1.0;
+                const double sg = damper_sign(k + (k >= role ? 1 : 0));
                 if (o[k] >= 0) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
             }
-            const double c = ((role == 0 || role == 3) ? -1.0 : 1.0) * P.d_s[idx];
+            const double c = damper_sign(role) * P.d_s[idx];
             a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     }
@@ -541,11 +585,12 @@ __global__ __launch_bounds__(BLK) void k_spmv(DbaDev P, double lam) {
 // from the partials in a fixed order, then updates its rows:
 //   gamma = r.u, delta = w.u, beta = gamma/gamma_old, alpha = gamma/(delta - beta*gamma/alpha_old)
 //   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = M^-1 r
-// Workgroups >= n_vecblk own the pose rows (w_p = (H_pp + lambda) u_p + sum_l H_pl u_l).
+// Workgroups >= n_vec8 own the pose rows (w_p = (H_pp + lambda) u_p + sum_l H_pl u_l).
 // =====================================================================================
-__global__ __launch_bounds__(BLK) void k_pcg_update(DbaDev P, double lam, int it, double tol2, int n_vecblk) {
+__global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2) {
     __shared__ double lds[4 * 3];
     if (P.flags[0]) return;
+    const int n_vecblk = P.n_vecblk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v[3] = {0, 0, 0};
     for (int b = tid; b < P.n_regblk; b += BLK) {
@@ -630,7 +675,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(DbaDev P, double lam, int it
                 w += P.Hpp[21 * k + pk] * P.up[6 * k + c];
             }
             const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
-            for (int g = P.kf_grp_ptr[k] * rb; g < P.kf_grp_ptr[k + 1] * rb; ++g) w += P.part_spmv[(size_t)g * NPART + 3 + a];
+            for (int g = P.pose_grp_ptr[k] * rb; g < P.pose_grp_ptr[k + 1] * rb; ++g) w += P.part_spmv[(size_t)g * NPART + 3 + a];
             const double p = ua + beta * P.pp[i];
             const double s = w + beta * P.sp[i];
             P.pp[i] = p;
@@ -653,7 +698,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(DbaDev P, double lam, int it
 // trial state = state (+) x ;  partial of computeScale: sum_j x_j (lambda x_j + b_j)
 // (levenberg.cpp:167-174; LandmarkVertex::oplusImpl landmark_vertex.cc:40-43)
 // =====================================================================================
-__global__ __launch_bounds__(BLK) void k_apply(DbaDev P, double lam, const Pose* __restrict__ pose_in,
+__global__ __launch_bounds__(BLK) void k_apply(Dev P, double lam, const Pose* __restrict__ pose_in,
                                                const double* __restrict__ xl_in, Pose* pose_out, double* xl_out) {
     __shared__ double lds[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -669,88 +714,86 @@ __global__ __launch_bounds__(BLK) void k_apply(DbaDev P, double lam, const Pose*
         }
     }
     if (i < P.K) {
-        Pose T = pose_in[i];
-        double upd[6];
-        for (int a = 0; a < 6; ++a) {
-            upd[a] = P.xp[6 * i + a];
-            sc[0] += upd[a] * (lam * upd[a] + P.bp[6 * i + a]);
+        Pose Tcw = pose_in[i];
+        if (!P.pose_fixed[i]) {
+            double upd[6];
+            for (int a = 0; a < 6; ++a) {
+                upd[a] = P.xp[6 * i + a];
+                sc[0] += upd[a] * (lam * upd[a] + P.bp[6 * i + a]);
+            }
+            pose_oplus(Tcw, upd);
         }
-        pose_oplus(T, upd);
-        pose_out[i] = T;
+        pose_out[i] = Tcw;
     }
     block_sum<1>(sc, lds, lane, wave);
     if (tid == 0) P.part_apply[blockIdx.x] = sc[0];
 }
 
 // =====================================================================================
-// debug / parity taps (edge-parallel, not on the timed path)
+// edge taps (edge-parallel, not on the timed path): residuals of every edge at a given state
 // =====================================================================================
-__global__ void k_tap_residuals(DbaDev P, const Pose* poses, const double* xl, const int* lm_row,
+__global__ void k_tap_residuals(Dev P, const Pose* poses, const double* xl, const int* vrow,
                                 const int* sp_ij, const float* sp_d0, const int* dm_idx, const float* dm_w,
                                 double* r_reproj, double* r_spring, double* r_damper) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.M) {
-        const int row = lm_row[i];
-        const Pose T = poses[P.grp_kf[row / ROW_ALIGN]];
-        double R[9];
-        quat_to_R(T.q, R);
-        const double x0 = xl[3 * row], x1 = xl[3 * row + 1], x2 = xl[3 * row + 2];
-        const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + T.t[0];
-        const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + T.t[1];
-        const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + T.t[2];
-        float u, v;
-        project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
-        r_reproj[2 * i] = (double)P.uv[2 * row] - (double)u;
-        r_reproj[2 * i + 1] = (double)P.uv[2 * row + 1] - (double)v;
+        const int row = vrow[i];
+        r_reproj[2 * i] = r_reproj[2 * i + 1] = 0;
+        if (P.rflag[row] & RF_OBS) {
+            const Pose Tcw = poses[P.grp_pose[row / ROW_ALIGN]];
+            double R[9];
+            quat_to_R(Tcw.q, R);
+            double x0 = xl[3 * row], x1 = xl[3 * row + 1], x2 = xl[3 * row + 2];
+            if (P.X0) { x0 += P.X0[3 * row]; x1 += P.X0[3 * row + 1]; x2 += P.X0[3 * row + 2]; }
+            const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + Tcw.t[0];
+            const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + Tcw.t[1];
+            const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + Tcw.t[2];
+            float u, v;
+            project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+            r_reproj[2 * i] = (double)P.uv[2 * row] - (double)u;
+            r_reproj[2 * i + 1] = (double)P.uv[2 * row + 1] - (double)v;
+        }
     }
     if (i < P.n_sp) {
-        const int a = lm_row[sp_ij[2 * i]], b = lm_row[sp_ij[2 * i + 1]];
-        const double v0 = xl[3 * a] - xl[3 * b], v1 = xl[3 * a + 1] - xl[3 * b + 1], v2 = xl[3 * a + 2] - xl[3 * b + 2];
-        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2), d0 = (double)sp_d0[i];
+        const int a = vrow[sp_ij[2 * i]], b = vrow[sp_ij[2 * i + 1]];
+        double v[3];
+        for (int k = 0; k < 3; ++k) {
+            v[k] = xl[3 * a + k] - xl[3 * b + k];
+            if (P.X0) v[k] = (xl[3 * a + k] + P.X0[3 * a + k]) - (xl[3 * b + k] + P.X0[3 * b + k]);
+        }
+        const double d = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), d0 = (double)sp_d0[i];
         r_spring[i] = P.k_spring * (d - d0) / d0;
     }
     if (i < P.n_dm) {
-        const int a = lm_row[dm_idx[4 * i]], b = lm_row[dm_idx[4 * i + 1]], c = lm_row[dm_idx[4 * i + 2]], d = lm_row[dm_idx[4 * i + 3]];
         const double w = (double)dm_w[i];
-        for (int k = 0; k < 3; ++k)
-            r_damper[3 * i + k] = w * ((xl[3 * c + k] - xl[3 * a + k]) - (xl[3 * d + k] - xl[3 * b + k]));
+        for (int k = 0; k < 3; ++k) {
+            double s = 0;
+            for (int role = 0; role < 4; ++role) {
+                const int v = dm_idx[4 * i + role];
+                if (v >= 0) s += damper_sign(role) * xl[3 * vrow[v] + k];
+            }
+            r_damper[3 * i + k] = w * s;
+        }
     }
 }
 
 // =====================================================================================
 // host side
 // =====================================================================================
-static int dev_alloc(nrs_ctx* c, DbaProblem* pb, void** p, size_t bytes) {
-    *p = nullptr;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    pb->allocs.push_back(*p);
-    return NRS_OK;
+int engine_num_poses(const Engine* e) { return e->d.K; }
+
+void arena_release(Arena* a) {
+    if (a->base) (void)hipFree(a->base);
+    a->base = nullptr;
+    a->cap = a->off = 0;
 }
 
-template <class Tp>
-static int dev_upload(nrs_ctx* c, DbaProblem* pb, Tp** dst, const std::vector<Tp>& src) {
-    NRS_TRY(dev_alloc(c, pb, (void**)dst, sizeof(Tp) * src.size()));
-    if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(*dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice, c->stream));
-    return NRS_OK;
-}
+struct Inc { int other[3]; float w; int meta; int edge; int slot; };
 
-void dba_free(nrs_ctx* c) {
-    if (!c->dba) return;
-    (void)hipStreamSynchronize(c->stream);
-    for (void* p : c->dba->allocs) (void)hipFree(p);
-    if (c->dba->h_scal) (void)hipHostFree(c->dba->h_scal);
-    if (c->dba->h_flags) (void)hipHostFree(c->dba->h_flags);
-    delete c->dba;
-    c->dba = nullptr;
-}
-
-struct Inc { int other[3]; float w; int meta; };
-
-// pack per-row incidence lists into the sliced-ELL layout described at the top of the file
+// pack per-row incidence lists into the sliced-ELL layout described at the top of the file;
+// pos[] receives the packed position of every incidence (indexed by Inc::slot)
 static void sell_pack(const std::vector<std::vector<Inc>>& rows, int T, std::vector<int>& slice_ptr,
-                      std::vector<Inc>& out) {
+                      std::vector<Inc>& out, std::vector<int>& pos) {
     const int R = 64 / T;
     const int n_slices = (int)rows.size() / R;
     slice_ptr.assign(n_slices + 1, 0);
@@ -763,90 +806,173 @@ static void sell_pack(const std::vector<std::vector<Inc>>& rows, int T, std::vec
     pad.other[0] = pad.other[1] = pad.other[2] = -1;
     pad.w = 0;
     pad.meta = -1;
+    pad.edge = -1;
+    pad.slot = -1;
     out.assign((size_t)slice_ptr[n_slices], pad);
     for (int s = 0; s < n_slices; ++s)
         for (int r = 0; r < R; ++r) {
             const auto& L = rows[(size_t)s * R + r];
             for (size_t e = 0; e < L.size(); ++e) {
                 const int j = (int)e / T, t = (int)e % T;
-                out[(size_t)slice_ptr[s] + (size_t)j * 64 + r * T + t] = L[e];
+                const size_t p = (size_t)slice_ptr[s] + (size_t)j * 64 + r * T + t;
+                out[p] = L[e];
+                if (L[e].slot >= 0) pos[L[e].slot] = (int)p;
             }
         }
 }
 
-static int dba_upload_impl(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
-                           int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
-                           int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
-                           int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale) {
-    if (!cam || n_kf <= 0 || n_lm <= 0 || !poses_qt || !lm_xyz || !lm_kf || !lm_uv || n_sp < 0 || n_dm < 0 ||
-        (n_sp > 0 && (!sp_ij || !sp_d0)) || (n_dm > 0 && (!dm_idx || !dm_w)))
-        return c->fail(NRS_ERR_INVALID, "nrs_dba_upload: bad argument");
-    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
-    for (int i = 0; i < n_lm; ++i) {
-        if (lm_kf[i] < 0 || lm_kf[i] >= n_kf || (i > 0 && lm_kf[i] < lm_kf[i - 1]))
-            return c->fail(NRS_ERR_INVALID, "lm_kf must be non-decreasing and in [0, n_kf)");
+struct ArenaPlan {                   // two passes: size, then carve
+    Arena* a;
+    bool dry;
+    size_t off = 0;
+    template <class Tp> Tp* get(size_t n) {
+        const size_t bytes = ((n * sizeof(Tp) + 255) / 256) * 256 + 256;
+        Tp* p = dry ? nullptr : reinterpret_cast<Tp*>(a->base + off);
+        off += bytes;
+        return p;
     }
-    for (int64_t i = 0; i < 2 * (int64_t)n_sp; ++i)
-        if (sp_ij[i] < 0 || sp_ij[i] >= n_lm) return c->fail(NRS_ERR_INVALID, "spring index out of range");
-    for (int64_t i = 0; i < 4 * (int64_t)n_dm; ++i)
-        if (dm_idx[i] < 0 || dm_idx[i] >= n_lm) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+};
+
+static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, Engine* e) {
+    const size_t nr = (size_t)d.n_rows, K = (size_t)d.K;
+    d.grp_pose = A.get<int>(d.n_groups);
+    d.pose_grp_ptr = A.get<int>(K + 1);
+    d.rflag = A.get<uint8_t>(nr);
+    d.pose_fixed = A.get<uint8_t>(K);
+    d.uv = A.get<float>(2 * nr);
+    double* X0 = A.get<double>(has_X0 ? 3 * nr : 1);
+    d.X0 = has_X0 ? X0 : nullptr;
+    d.ss_ptr = A.get<int>(n_slices + 1);
+    d.sd_ptr = A.get<int>(n_slices + 1);
+    d.s_other = A.get<int>(nnz_s); d.s_d0 = A.get<float>(nnz_s); d.s_meta = A.get<int>(nnz_s);
+    d.d_o0 = A.get<int>(nnz_d); d.d_o1 = A.get<int>(nnz_d); d.d_o2 = A.get<int>(nnz_d);
+    d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(nnz_d);
+    for (int s = 0; s < 2; ++s) { d.pose[s] = A.get<Pose>(K); d.xl[s] = A.get<double>(3 * nr); }
+    d.pose_init = A.get<Pose>(K);
+    d.xl_init = A.get<double>(3 * nr);
+    d.D = A.get<double>(6 * nr);
+    d.Hpl = A.get<double>(18 * nr);
+    d.s_g = A.get<double>(3 * nnz_s);
+    d.d_s = A.get<double>(nnz_d);
+    d.Hpp = A.get<double>(21 * K);
+    d.bp = A.get<double>(6 * K);
+    d.bl = A.get<double>(3 * nr);
+    d.Dinv = A.get<double>(6 * nr);
+    d.Hppinv = A.get<double>(36 * K);
+    double** pv[] = {&d.xp, &d.rp, &d.up, &d.pp, &d.sp, &d.wp};
+    for (auto p : pv) *p = A.get<double>(6 * K);
+    double** rvv[] = {&d.xv, &d.rv, &d.uv3, &d.pv, &d.sv, &d.wv};
+    for (auto p : rvv) *p = A.get<double>(3 * nr);
+    d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
+    d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
+    d.part_spmv = A.get<double>(NPART * (size_t)d.n_regblk);
+    d.part_apply = A.get<double>((size_t)d.n_vecblk);
+    d.scal = A.get<double>(SC_N);
+    d.flags = A.get<int>(8);
+    e->t_vrow = A.get<int>(d.M);
+    e->t_sp = A.get<int>(2 * (size_t)d.n_sp);
+    e->t_dm = A.get<int>(4 * (size_t)d.n_dm);
+    e->t_d0 = A.get<float>(d.n_sp);
+    e->t_w = A.get<float>(d.n_dm);
+    e->t_out = A.get<double>(2 * (size_t)d.M + (size_t)d.n_sp + 3 * (size_t)d.n_dm);
+}
+
+template <class Tp>
+static int h2d(nrs_ctx* c, Tp* dst, const std::vector<Tp>& src) {
+    if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice, c->stream));
+    return NRS_OK;
+}
+
+// per-edge masks -> per-incidence meta words and per-row flags (host), then upload
+static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uint8_t* dm_active) {
+    Dev& d = e->d;
+    auto vfixed = [&](int v) { return (e->h_rflag[e->vrow[v]] & RF_FIXED) != 0; };
+    for (int s = 0; s < d.n_sp; ++s) {
+        const int i = e->sp_ij[2 * s], j = e->sp_ij[2 * s + 1];
+        const bool act = (!sp_active || sp_active[s]) && !(vfixed(i) && vfixed(j));
+        const int m = act ? SM_ACTIVE : 0;
+        e->h_s_meta[e->sp_pos[2 * s]] = m | (act ? SM_COUNT : 0);
+        e->h_s_meta[e->sp_pos[2 * s + 1]] = m;
+    }
+    for (int s = 0; s < d.n_dm; ++s) {
+        bool allfix = true;
+        int first = -1;
+        for (int r = 0; r < 4; ++r) {
+            const int v = e->dm_idx[4 * s + r];
+            if (v >= 0) { if (first < 0) first = r; allfix = allfix && vfixed(v); }
+        }
+        const bool act = (!dm_active || dm_active[s]) && !allfix;
+        for (int r = 0; r < 4; ++r) {
+            const int p = e->dm_pos[4 * s + r];
+            if (p < 0) continue;
+            e->h_d_meta[p] = r | (act ? DM_ACTIVE : 0) | ((act && r == first) ? DM_COUNT : 0);
+        }
+    }
+    for (int s = 0; s < d.n_un; ++s) {
+        const bool act = !vfixed(e->un_ij[2 * s]);
+        e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
+    }
+    NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
+    NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
+    NRS_TRY(h2d(c, d.rflag, e->h_rflag));
+    NRS_TRY(h2d(c, d.pose_fixed, e->h_pose_fixed));
+    return NRS_OK;
+}
+
+int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
+    *out = nullptr;
+    if (s.K <= 0 || s.M <= 0 || !s.poses || !s.x || !s.lm_pose || !s.uv || !s.rflag || s.n_sp < 0 || s.n_dm < 0 || s.n_un < 0)
+        return c->fail(NRS_ERR_INVALID, "engine: bad specification");
+    for (int i = 0; i < s.M; ++i)
+        if (s.lm_pose[i] < 0 || s.lm_pose[i] >= s.K || (i > 0 && s.lm_pose[i] < s.lm_pose[i - 1]))
+            return c->fail(NRS_ERR_INVALID, "vertex pose index must be non-decreasing and in [0, n_poses)");
+    for (int64_t i = 0; i < 2 * (int64_t)s.n_sp; ++i)
+        if (s.sp_ij[i] < 0 || s.sp_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "spring index out of range");
+    for (int64_t i = 0; i < 4 * (int64_t)s.n_dm; ++i)
+        if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+    for (int64_t i = 0; i < 2 * (int64_t)s.n_un; ++i)
+        if (s.un_ij[i] < 0 || s.un_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "unary damper index out of range");
     NRS_HIP(c, hipSetDevice(c->device));
-    dba_free(c);
-    DbaProblem* pb = new (std::nothrow) DbaProblem();
-    if (!pb) return c->fail(NRS_ERR_ALLOC, "out of host memory");
-    c->dba = pb;
-    DbaDev& d = pb->d;
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    struct Guard { nrs_ctx* c; Engine* e; bool keep = false; ~Guard() { if (!keep) engine_destroy(c, e); } } guard{c, e};
+    e->arena = arena;
+    Dev& d = e->d;
     memset(&d, 0, sizeof(d));
     int T = 2;                       // lanes per row; 2 measured best on C2 (profiles/README.md)
-    if (const char* e = getenv("NRS_SELL_T")) {
-        const int v = atoi(e);
+    if (const char* ev = getenv("NRS_SELL_T")) {
+        const int v = atoi(ev);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) T = v;
     }
     d.T = T;
-    d.K = n_kf;
-    d.M = n_lm;
-    d.n_sp = n_sp;
-    d.n_dm = n_dm;
-    d.cam.model = cam->model;
-    for (int i = 0; i < 8; ++i) d.cam.p[i] = cam->params[i];
-    // constants: reference g2o_optimization.cc:958-973 (float arithmetic, widened)
-    const float th2 = sqrtf(5.99f), th3 = sqrtf(0.584f);
-    const float sigma_rep = 0.5f, sigma_pos = 0.1f;
-    const float sigma_spatial = (float)(0.1 * (double)scale);
-    d.info_reproj = (double)(1.0f / (sigma_rep * sigma_rep));
-    d.delta_reproj = (double)th2;
-    d.info_pos = (double)(1.0f / (sigma_pos * sigma_pos));
-    d.delta_pos = 0.0;                                   // no robust kernel on the BA springs (OPT:1057-1071)
-    d.info_spatial = (double)(1.0f / (sigma_spatial * sigma_spatial));
-    d.delta_spatial = (double)th3;
-    d.k_spring = (double)1.1f;
-    d.spring_form = 0;
+    d.K = s.K; d.M = s.M; d.n_sp = s.n_sp; d.n_dm = s.n_dm; d.n_un = s.n_un;
+    d.cam = s.cam;
+    d.info_reproj = s.info_reproj; d.delta_reproj = s.delta_reproj;
+    d.info_pos = s.info_pos; d.delta_pos = s.delta_pos;
+    d.info_spatial = s.info_spatial; d.delta_spatial = s.delta_spatial;
+    d.k_spring = s.k_spring; d.spring_form = s.spring_form;
 
-    // ---- row layout: keyframe-major, each keyframe padded to ROW_ALIGN rows
-    pb->kf_ptr.assign(n_kf + 1, 0);
-    for (int i = 0; i < n_lm; ++i) pb->kf_ptr[lm_kf[i] + 1]++;
-    for (int k = 0; k < n_kf; ++k) pb->kf_ptr[k + 1] += pb->kf_ptr[k];
-    std::vector<int> kf_grp_ptr(n_kf + 1, 0), grp_kf;
-    for (int k = 0; k < n_kf; ++k) {
-        const int n = pb->kf_ptr[k + 1] - pb->kf_ptr[k];
+    // ---- row layout: pose-major, each pose padded to ROW_ALIGN rows, Morton order inside
+    std::vector<int> pose_ptr(s.K + 1, 0);
+    for (int i = 0; i < s.M; ++i) pose_ptr[s.lm_pose[i] + 1]++;
+    for (int k = 0; k < s.K; ++k) pose_ptr[k + 1] += pose_ptr[k];
+    std::vector<int> pose_grp_ptr(s.K + 1, 0), grp_pose;
+    for (int k = 0; k < s.K; ++k) {
+        const int n = pose_ptr[k + 1] - pose_ptr[k];
         const int ng = std::max(1, (n + ROW_ALIGN - 1) / ROW_ALIGN);
-        kf_grp_ptr[k + 1] = kf_grp_ptr[k] + ng;
-        for (int g = 0; g < ng; ++g) grp_kf.push_back(k);
+        pose_grp_ptr[k + 1] = pose_grp_ptr[k] + ng;
+        for (int g = 0; g < ng; ++g) grp_pose.push_back(k);
     }
-    d.n_groups = kf_grp_ptr[n_kf];
+    d.n_groups = pose_grp_ptr[s.K];
     d.n_rows = d.n_groups * ROW_ALIGN;
-    const int rows_per_regblk = BLK / T;
-    d.n_regblk = d.n_rows / rows_per_regblk;
+    d.n_regblk = d.n_rows / (BLK / T);
     d.n_vecblk = d.n_rows / BLK;
-    // Inside a keyframe the rows are ordered along a Morton curve of the initial positions, so
-    // that the graph neighbours of one workgroup's rows share cache lines (private row order:
-    // the C ABI keeps the caller's landmark order).
-    pb->lm_row.resize(n_lm);
-    std::vector<int> row_lm(d.n_rows, -1);
+    e->vrow.resize(s.M);
     {
-        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-        for (int l = 0; l < n_lm; ++l)
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], lm_xyz[3 * l + a]); hi[a] = std::max(hi[a], lm_xyz[3 * l + a]); }
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        auto pos = [&](int v, int a) { return s.x[3 * (size_t)v + a] + (s.X0 ? s.X0[3 * (size_t)v + a] : 0.0); };
+        for (int v = 0; v < s.M; ++v)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos(v, a)); hi[a] = std::max(hi[a], pos(v, a)); }
         auto spread = [](uint64_t v) {            // 21 bits -> every third bit
             v &= 0x1fffff;
             v = (v | v << 32) & 0x1f00000000ffffULL;
@@ -858,135 +984,167 @@ static int dba_upload_impl(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, cons
         };
         const bool morton = getenv("NRS_NO_MORTON") == nullptr;
         std::vector<std::pair<uint64_t, int>> keys;
-        for (int k = 0; k < n_kf; ++k) {
+        for (int k = 0; k < s.K; ++k) {
             keys.clear();
-            for (int l = pb->kf_ptr[k]; l < pb->kf_ptr[k + 1]; ++l) {
+            for (int v = pose_ptr[k]; v < pose_ptr[k + 1]; ++v) {
                 uint64_t code = 0;
                 if (morton)
                     for (int a = 0; a < 3; ++a) {
-                        const float ext = hi[a] - lo[a];
-                        const double f = ext > 0 ? (lm_xyz[3 * l + a] - lo[a]) / ext : 0.0;
+                        const double ext = hi[a] - lo[a];
+                        const double f = ext > 0 ? (pos(v, a) - lo[a]) / ext : 0.0;
                         code |= spread((uint64_t)(f * 2097151.0)) << a;
                     }
-                keys.emplace_back(code, l);
+                keys.emplace_back(code, v);
             }
             std::stable_sort(keys.begin(), keys.end());
-            for (size_t i = 0; i < keys.size(); ++i) {
-                const int row = kf_grp_ptr[k] * ROW_ALIGN + (int)i;
-                pb->lm_row[keys[i].second] = row;
-                row_lm[row] = keys[i].second;
-            }
+            for (size_t i = 0; i < keys.size(); ++i) e->vrow[keys[i].second] = pose_grp_ptr[k] * ROW_ALIGN + (int)i;
         }
     }
     // ---- incidence lists
     std::vector<std::vector<Inc>> rs(d.n_rows), rd(d.n_rows);
-    for (int e = 0; e < n_sp; ++e) {
-        const int a = pb->lm_row[sp_ij[2 * e]], b = pb->lm_row[sp_ij[2 * e + 1]];
+    e->sp_pos.assign(2 * (size_t)s.n_sp, -1);
+    e->dm_pos.assign(4 * (size_t)s.n_dm, -1);
+    e->un_pos.assign((size_t)s.n_un, -1);
+    for (int q = 0; q < s.n_sp; ++q) {
+        const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
         Inc i1;
-        i1.other[0] = b; i1.other[1] = i1.other[2] = -1; i1.w = sp_d0[e]; i1.meta = (e & 0x3fffffff) | (1 << 30);
+        i1.other[0] = b; i1.other[1] = i1.other[2] = -1; i1.w = s.sp_d0[q]; i1.meta = 0; i1.edge = q; i1.slot = 2 * q;
         rs[a].push_back(i1);
         Inc i2 = i1;
-        i2.other[0] = a; i2.meta = (e & 0x3fffffff);
+        i2.other[0] = a; i2.slot = 2 * q + 1;
         rs[b].push_back(i2);
     }
-    for (int e = 0; e < n_dm; ++e) {
+    for (int q = 0; q < s.n_dm; ++q) {
         int r4[4];
-        for (int k = 0; k < 4; ++k) r4[k] = pb->lm_row[dm_idx[4 * e + k]];
+        for (int k = 0; k < 4; ++k) r4[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
         for (int role = 0; role < 4; ++role) {
+            if (r4[role] < 0) continue;
             Inc in;
-            int q = 0;
+            int z = 0;
             for (int k = 0; k < 4; ++k)
-                if (k != role) in.other[q++] = r4[k];
-            in.w = dm_w[e];
-            in.meta = role | ((role == 0 ? 1 : 0) << 2);
+                if (k != role) in.other[z++] = r4[k];
+            in.w = s.dm_w[q]; in.meta = role; in.edge = q; in.slot = 4 * q + role;
             rd[r4[role]].push_back(in);
         }
     }
-    std::vector<int> ss_ptr, sd_ptr;
+    const int dm_slots = 4 * s.n_dm;
+    for (int q = 0; q < s.n_un; ++q) {           // own role 2 (1n, +), value-only other in role 3 (2n, -)
+        Inc in;
+        in.other[0] = in.other[1] = -1;
+        in.other[2] = e->vrow[s.un_ij[2 * q + 1]];
+        in.w = s.un_w[q]; in.meta = 2; in.edge = q; in.slot = dm_slots + q;
+        rd[e->vrow[s.un_ij[2 * q]]].push_back(in);
+    }
+    std::vector<int> ss_ptr, sd_ptr, dpos((size_t)dm_slots + s.n_un, -1);
     std::vector<Inc> ss, sd;
-    sell_pack(rs, T, ss_ptr, ss);
-    sell_pack(rd, T, sd_ptr, sd);
-    d.ss.nnz = (int)ss.size();
-    d.sd.nnz = (int)sd.size();
-    std::vector<int> s_other(ss.size()), s_meta(ss.size()), d_o0(sd.size()), d_o1(sd.size()), d_o2(sd.size()), d_meta(sd.size());
-    std::vector<float> s_d0(ss.size()), d_w(sd.size());
-    for (size_t i = 0; i < ss.size(); ++i) { s_other[i] = ss[i].other[0]; s_d0[i] = ss[i].w; s_meta[i] = ss[i].meta < 0 ? 0 : ss[i].meta; }
-    for (size_t i = 0; i < sd.size(); ++i) { d_o0[i] = sd[i].other[0]; d_o1[i] = sd[i].other[1]; d_o2[i] = sd[i].other[2]; d_w[i] = sd[i].w; d_meta[i] = sd[i].meta; }
+    sell_pack(rs, T, ss_ptr, ss, e->sp_pos);
+    sell_pack(rd, T, sd_ptr, sd, dpos);
+    std::copy(dpos.begin(), dpos.begin() + dm_slots, e->dm_pos.begin());
+    std::copy(dpos.begin() + dm_slots, dpos.end(), e->un_pos.begin());
+    d.ss_nnz = (int)ss.size();
+    d.sd_nnz = (int)sd.size();
 
-    // ---- uploads
-    NRS_TRY(dev_upload(c, pb, &d.grp_kf, grp_kf));
-    NRS_TRY(dev_upload(c, pb, &d.kf_grp_ptr, kf_grp_ptr));
-    NRS_TRY(dev_upload(c, pb, &d.row_lm, row_lm));
+    // ---- device memory: one arena allocation, reused across calls when large enough
+    ArenaPlan dry{arena, true};
+    {
+        Dev tmp = d;
+        Engine te;
+        carve(dry, tmp, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, &te);
+    }
+    if (dry.off > arena->cap) {
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        arena_release(arena);
+        const size_t want = dry.off + dry.off / 8;
+        hipError_t he = hipMalloc((void**)&arena->base, want);
+        if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
+        arena->cap = want;
+    }
+    ArenaPlan real{arena, false};
+    carve(real, d, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, e);
+
+    // ---- host mirrors + uploads
+    e->sp_ij.assign(s.sp_ij, s.sp_ij + 2 * (size_t)s.n_sp);
+    e->sp_d0.assign(s.sp_d0, s.sp_d0 + (size_t)s.n_sp);
+    e->dm_idx.assign(s.dm_idx, s.dm_idx + 4 * (size_t)s.n_dm);
+    e->dm_w.assign(s.dm_w, s.dm_w + (size_t)s.n_dm);
+    e->un_ij.assign(s.un_ij, s.un_ij + 2 * (size_t)s.n_un);
+    e->un_w.assign(s.un_w, s.un_w + (size_t)s.n_un);
+    e->h_rflag.assign(d.n_rows, 0);
+    for (int v = 0; v < s.M; ++v) e->h_rflag[e->vrow[v]] = s.rflag[v];
+    e->h_pose_fixed.assign(s.K, 0);
+    if (s.pose_fixed) e->h_pose_fixed.assign(s.pose_fixed, s.pose_fixed + s.K);
     std::vector<float> uv((size_t)d.n_rows * 2, 0.f);
-    std::vector<double> xl((size_t)d.n_rows * 3, 0.0);
-    for (int l = 0; l < n_lm; ++l) {
-        const int row = pb->lm_row[l];
-        uv[2 * (size_t)row] = lm_uv[2 * l];
-        uv[2 * (size_t)row + 1] = lm_uv[2 * l + 1];
-        for (int k = 0; k < 3; ++k) xl[3 * (size_t)row + k] = (double)lm_xyz[3 * l + k];   // OPT:943 cast<double>
+    std::vector<double> xl((size_t)d.n_rows * 3, 0.0), X0;
+    if (s.X0) X0.assign((size_t)d.n_rows * 3, 0.0);
+    for (int v = 0; v < s.M; ++v) {
+        const size_t row = (size_t)e->vrow[v];
+        uv[2 * row] = s.uv[2 * v];
+        uv[2 * row + 1] = s.uv[2 * v + 1];
+        for (int k = 0; k < 3; ++k) {
+            xl[3 * row + k] = s.x[3 * (size_t)v + k];
+            if (s.X0) X0[3 * row + k] = s.X0[3 * (size_t)v + k];
+        }
     }
-    NRS_TRY(dev_upload(c, pb, &d.uv, uv));
-    NRS_TRY(dev_upload(c, pb, &d.xl_init, xl));
-    std::vector<Pose> poses(n_kf);
-    for (int k = 0; k < n_kf; ++k) {
-        for (int i = 0; i < 4; ++i) poses[k].q[i] = poses_qt[7 * k + i];
-        for (int i = 0; i < 3; ++i) poses[k].t[i] = poses_qt[7 * k + 4 + i];
-        quat_normalize(poses[k].q);
-    }
-    NRS_TRY(dev_upload(c, pb, &d.pose_init, poses));
-    NRS_TRY(dev_upload(c, pb, &d.ss.slice_ptr, ss_ptr));
-    NRS_TRY(dev_upload(c, pb, &d.sd.slice_ptr, sd_ptr));
-    NRS_TRY(dev_upload(c, pb, &d.s_other, s_other));
-    NRS_TRY(dev_upload(c, pb, &d.s_d0, s_d0));
-    NRS_TRY(dev_upload(c, pb, &d.s_meta, s_meta));
-    NRS_TRY(dev_upload(c, pb, &d.d_o0, d_o0));
-    NRS_TRY(dev_upload(c, pb, &d.d_o1, d_o1));
-    NRS_TRY(dev_upload(c, pb, &d.d_o2, d_o2));
-    NRS_TRY(dev_upload(c, pb, &d.d_w, d_w));
-    NRS_TRY(dev_upload(c, pb, &d.d_meta, d_meta));
-    const size_t nr = (size_t)d.n_rows, K = (size_t)n_kf;
-    for (int s = 0; s < 2; ++s) {
-        NRS_TRY(dev_alloc(c, pb, (void**)&d.pose[s], sizeof(Pose) * K));
-        NRS_TRY(dev_alloc(c, pb, (void**)&d.xl[s], sizeof(double) * 3 * nr));
-    }
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.D, sizeof(double) * 6 * nr));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.Hpl, sizeof(double) * 18 * nr));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.s_g, sizeof(double) * 3 * ss.size()));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.d_s, sizeof(double) * sd.size()));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.Hpp, sizeof(double) * 21 * K));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.bp, sizeof(double) * 6 * K));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.bl, sizeof(double) * 3 * nr));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.Dinv, sizeof(double) * 6 * nr));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.Hppinv, sizeof(double) * 36 * K));
-    double** pv[] = {&d.xp, &d.rp, &d.up, &d.pp, &d.sp, &d.wp};
-    for (auto p : pv) NRS_TRY(dev_alloc(c, pb, (void**)p, sizeof(double) * 6 * K));
-    double** rvv[] = {&d.xv, &d.rv, &d.uv3, &d.pv, &d.sv, &d.wv};
-    for (auto p : rvv) NRS_TRY(dev_alloc(c, pb, (void**)p, sizeof(double) * 3 * nr));
-    const int n_vecblk = (d.n_rows + BLK - 1) / BLK;
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.part_lin, sizeof(double) * 32 * (size_t)d.n_groups));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.part_reg, sizeof(double) * 2 * (size_t)d.n_regblk));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.part_spmv, sizeof(double) * NPART * (size_t)d.n_regblk));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.part_apply, sizeof(double) * (size_t)std::max(d.n_regblk, n_vecblk)));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.scal, sizeof(double) * SC_N));
-    NRS_TRY(dev_alloc(c, pb, (void**)&d.flags, sizeof(int) * 8));
-    NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)std::max(d.n_regblk, n_vecblk), c->stream));
+    std::vector<int> s_other(ss.size()), d_o0(sd.size()), d_o1(sd.size()), d_o2(sd.size());
+    std::vector<float> s_d0(ss.size()), d_w(sd.size());
+    e->h_s_meta.assign(ss.size(), 0);
+    e->h_d_meta.assign(sd.size(), -1);
+    for (size_t i = 0; i < ss.size(); ++i) { s_other[i] = ss[i].other[0]; s_d0[i] = ss[i].w; }
+    for (size_t i = 0; i < sd.size(); ++i) { d_o0[i] = sd[i].other[0]; d_o1[i] = sd[i].other[1]; d_o2[i] = sd[i].other[2]; d_w[i] = sd[i].w; }
+    std::vector<Pose> poses(s.poses, s.poses + s.K);
+    NRS_TRY(h2d(c, d.grp_pose, grp_pose));
+    NRS_TRY(h2d(c, d.pose_grp_ptr, pose_grp_ptr));
+    NRS_TRY(h2d(c, d.uv, uv));
+    NRS_TRY(h2d(c, d.xl_init, xl));
+    if (s.X0) NRS_TRY(h2d(c, d.X0, X0));
+    NRS_TRY(h2d(c, d.pose_init, poses));
+    NRS_TRY(h2d(c, d.ss_ptr, ss_ptr));
+    NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
+    NRS_TRY(h2d(c, d.s_other, s_other));
+    NRS_TRY(h2d(c, d.s_d0, s_d0));
+    NRS_TRY(h2d(c, d.d_o0, d_o0));
+    NRS_TRY(h2d(c, d.d_o1, d_o1));
+    NRS_TRY(h2d(c, d.d_o2, d_o2));
+    NRS_TRY(h2d(c, d.d_w, d_w));
+    NRS_TRY(push_masks(c, e, s.sp_active, s.dm_active));
+    NRS_TRY(h2d(c, e->t_vrow, e->vrow));
+    NRS_TRY(h2d(c, e->t_sp, e->sp_ij));
+    NRS_TRY(h2d(c, e->t_dm, e->dm_idx));
+    NRS_TRY(h2d(c, e->t_d0, e->sp_d0));
+    NRS_TRY(h2d(c, e->t_w, e->dm_w));
+    NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
-    NRS_HIP(c, hipHostMalloc((void**)&pb->h_scal, sizeof(double) * SC_N));
-    NRS_HIP(c, hipHostMalloc((void**)&pb->h_flags, sizeof(int) * 8));
-    pb->sp_ij.assign(sp_ij, sp_ij + 2 * (size_t)n_sp);
-    pb->sp_d0.assign(sp_d0, sp_d0 + (size_t)n_sp);
-    pb->dm_idx.assign(dm_idx, dm_idx + 4 * (size_t)n_dm);
-    pb->dm_w.assign(dm_w, dm_w + (size_t)n_dm);
+    NRS_HIP(c, hipHostMalloc((void**)&e->h_scal, sizeof(double) * SC_N));
+    NRS_HIP(c, hipHostMalloc((void**)&e->h_flags, sizeof(int) * 8));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
+    NRS_TRY(engine_reset(c, e));
+    guard.keep = true;
+    *out = e;
+    return NRS_OK;
+}
+
+void engine_destroy(nrs_ctx* c, Engine* e) {
+    if (!e) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (e->h_scal) (void)hipHostFree(e->h_scal);
+    if (e->h_flags) (void)hipHostFree(e->h_flags);
+    delete e;
+}
+
+int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8_t* pose_fixed,
+                        const uint8_t* sp_active, const uint8_t* dm_active) {
+    if (rflag)
+        for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
+    if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
+    NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
 
-static int dba_reset_impl(nrs_ctx* c) {
-    DbaProblem* pb = c->dba;
-    if (!pb) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
-    DbaDev& d = pb->d;
-    pb->cur = 0;
+int engine_reset(nrs_ctx* c, Engine* e) {
+    Dev& d = e->d;
+    e->cur = 0;
     NRS_HIP(c, hipMemcpyAsync(d.pose[0], d.pose_init, sizeof(Pose) * d.K, hipMemcpyDeviceToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(d.xl[0], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(d.xl[1], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
@@ -1013,32 +1171,32 @@ struct Timer {                       // HIP-event timing of one launch when prof
 };
 
 template <bool LIN>
-static void launch_reg(nrs_ctx* c, const DbaDev& d, const double* xl) {
+static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
         case 1: hipLaunchKernelGGL((k_reg<1, LIN>), g, b, 0, c->stream, d, xl); break;
+        case 4: hipLaunchKernelGGL((k_reg<4, LIN>), g, b, 0, c->stream, d, xl); break;
         case 8: hipLaunchKernelGGL((k_reg<8, LIN>), g, b, 0, c->stream, d, xl); break;
         case 16: hipLaunchKernelGGL((k_reg<16, LIN>), g, b, 0, c->stream, d, xl); break;
-        case 4: hipLaunchKernelGGL((k_reg<4, LIN>), g, b, 0, c->stream, d, xl); break;
         default: hipLaunchKernelGGL((k_reg<2, LIN>), g, b, 0, c->stream, d, xl); break;
     }
 }
 
-static void launch_spmv(nrs_ctx* c, const DbaDev& d, double lam) {
+static void launch_spmv(nrs_ctx* c, const Dev& d, double lam) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
         case 1: hipLaunchKernelGGL((k_spmv<1>), g, b, 0, c->stream, d, lam); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4>), g, b, 0, c->stream, d, lam); break;
         case 8: hipLaunchKernelGGL((k_spmv<8>), g, b, 0, c->stream, d, lam); break;
         case 16: hipLaunchKernelGGL((k_spmv<16>), g, b, 0, c->stream, d, lam); break;
-        case 4: hipLaunchKernelGGL((k_spmv<4>), g, b, 0, c->stream, d, lam); break;
         default: hipLaunchKernelGGL((k_spmv<2>), g, b, 0, c->stream, d, lam); break;
     }
 }
 
 // errors (+ linearisation) at a given state; leaves chi2 (and max diag) in scal[]
 template <bool LIN>
-static int evaluate(nrs_ctx* c, DbaProblem* pb, int which) {
-    const DbaDev& d = pb->d;
+static int evaluate(nrs_ctx* c, Engine* e, int which) {
+    const Dev& d = e->d;
     const dim3 gg(((d.n_groups + 7) / 8) * 8), b(BLK);
     if (LIN) {
         Timer t(c, &c->prof.linearize_ms, &c->prof.linearize_launches);
@@ -1053,21 +1211,20 @@ static int evaluate(nrs_ctx* c, DbaProblem* pb, int which) {
     return NRS_OK;
 }
 
-static int read_scalars(nrs_ctx* c, DbaProblem* pb) {
-    NRS_HIP(c, hipMemcpyAsync(pb->h_scal, pb->d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(pb->h_flags, pb->d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+static int read_scalars(nrs_ctx* c, Engine* e) {
+    NRS_HIP(c, hipMemcpyAsync(e->h_scal, e->d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(e->h_flags, e->d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
 
 // (H + lam I) x = b by block-Jacobi PCG; returns iterations, ok=false on non-finite values
-static int pcg_solve(nrs_ctx* c, DbaProblem* pb, double lam, int* iters, bool* ok) {
-    const DbaDev& d = pb->d;
-    const int n_vecblk = (d.n_rows + BLK - 1) / BLK;
+static int pcg_solve(nrs_ctx* c, Engine* e, double lam, int* iters, bool* ok) {
+    const Dev& d = e->d;
     const int n_poseblk = (d.K + 41) / 42;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
-    hipLaunchKernelGGL(k_trial_setup, dim3(n_vecblk), dim3(BLK), 0, c->stream, d, lam);
+    hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
     int it = 0;
     while (true) {
         const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
@@ -1078,68 +1235,64 @@ static int pcg_solve(nrs_ctx* c, DbaProblem* pb, double lam, int* iters, bool* o
             }
             {
                 Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-                hipLaunchKernelGGL(k_pcg_update, dim3(((n_vecblk + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2, n_vecblk);
+                hipLaunchKernelGGL(k_pcg_update, dim3(((d.n_vecblk + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2);
             }
         }
         NRS_HIP(c, hipGetLastError());
-        NRS_HIP(c, hipMemcpyAsync(pb->h_flags, d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(e->h_flags, d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
-        if (pb->h_flags[0] || it >= c->opt.pcg_max_iters) break;
+        if (e->h_flags[0] || it >= c->opt.pcg_max_iters) break;
     }
-    *iters = pb->h_flags[1];
-    *ok = pb->h_flags[2] == 0;
+    *iters = e->h_flags[1];
+    *ok = e->h_flags[2] == 0;
     return NRS_OK;
 }
 
-// g2o SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve on the resident problem
-static int dba_optimize_impl(nrs_ctx* c, int iters, nrs_lm_trace* trace) {
-    DbaProblem* pb = c->dba;
-    if (!pb) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+// g2o SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve on the resident problem.
+// trace->count / iterations are accumulated (the drivers reset them once per entry point).
+int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* trace) {
     if (iters < 0) return c->fail(NRS_ERR_INVALID, "iters < 0");
     NRS_HIP(c, hipSetDevice(c->device));
-    DbaDev& d = pb->d;
-    const int n_vecblk = (d.n_rows + BLK - 1) / BLK;
+    Dev& d = e->d;
     double lam = -1, ni = 2;
-    int ntr = 0, done = 0;
-    if (trace) { trace->count = 0; trace->iterations = 0; }
     for (int it = 0; it < iters; ++it) {
-        NRS_TRY(evaluate<true>(c, pb, pb->cur));
-        NRS_TRY(read_scalars(c, pb));
-        double chi = pb->h_scal[SC_CHI];
-        if (it == 0) { lam = 1e-5 * pb->h_scal[SC_MAXDIAG]; ni = 2; }
+        NRS_TRY(evaluate<true>(c, e, e->cur));
+        NRS_TRY(read_scalars(c, e));
+        double chi = e->h_scal[SC_CHI];
+        if (it == 0) { lam = 1e-5 * e->h_scal[SC_MAXDIAG]; ni = 2; }
         if (!std::isfinite(chi) || !std::isfinite(lam)) return c->fail(NRS_ERR_NUMERIC, "non-finite chi2/lambda at LM iteration %d", it);
         double rho = 0;
         int qmax = 0;
         do {
             int inner = 0;
             bool ok = true;
-            NRS_TRY(pcg_solve(c, pb, lam, &inner, &ok));
-            const int trial = 1 - pb->cur;
+            NRS_TRY(pcg_solve(c, e, lam, &inner, &ok));
+            const int trial = 1 - e->cur;
             {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
-                hipLaunchKernelGGL(k_apply, dim3(n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[pb->cur], d.xl[pb->cur], d.pose[trial], d.xl[trial]);
+                hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
             }
-            NRS_TRY(evaluate<false>(c, pb, trial));
-            NRS_TRY(read_scalars(c, pb));
-            const double temp = ok ? pb->h_scal[SC_CHI] : 1.7976931348623157e308;
-            const double scale = pb->h_scal[SC_SCALE] + 1e-3;
+            NRS_TRY(evaluate<false>(c, e, trial));
+            NRS_TRY(read_scalars(c, e));
+            const double temp = ok ? e->h_scal[SC_CHI] : 1.7976931348623157e308;
+            const double scale = e->h_scal[SC_SCALE] + 1e-3;
             rho = (chi - temp) / scale;
             const bool accepted = rho > 0 && std::isfinite(temp);
             if (trace) {
-                if (trace->trials && ntr < trace->capacity) {
-                    nrs_lm_trial& T = trace->trials[ntr];
-                    T.round = 0; T.iter = it; T.trial = qmax; T.accepted = accepted; T.solver_ok = ok;
-                    T.inner_iters = inner; T.lambda = lam; T.chi2 = chi; T.chi2_new = temp; T.rho = rho;
+                if (trace->trials && trace->count < trace->capacity) {
+                    nrs_lm_trial& Tr = trace->trials[trace->count];
+                    Tr.round = round; Tr.iter = it; Tr.trial = qmax; Tr.accepted = accepted; Tr.solver_ok = ok;
+                    Tr.inner_iters = inner; Tr.lambda = lam; Tr.chi2 = chi; Tr.chi2_new = temp; Tr.rho = rho;
                 }
+                trace->count++;
             }
-            ++ntr;
             if (accepted) {
                 double alpha = 1.0 - std::pow(2 * rho - 1, 3);
                 alpha = std::min(alpha, 2.0 / 3.0);
                 lam *= std::max(1.0 / 3.0, alpha);
                 ni = 2;
                 chi = temp;
-                pb->cur = trial;                       // discardTop: the trial state becomes current
+                e->cur = trial;                        // discardTop: the trial state becomes current
             } else {
                 lam *= ni;
                 ni *= 2;                               // pop: current state untouched
@@ -1147,116 +1300,57 @@ static int dba_optimize_impl(nrs_ctx* c, int iters, nrs_lm_trace* trace) {
             }
             ++qmax;
         } while (rho < 0 && qmax < 10);
-        ++done;
+        if (trace) trace->iterations++;
         if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;
     }
-    if (trace) { trace->count = ntr; trace->iterations = done; }
     return NRS_OK;
 }
 
-static int dba_download_impl(nrs_ctx* c, double* poses_qt, double* lm_xyz) {
-    DbaProblem* pb = c->dba;
-    if (!pb) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
-    DbaDev& d = pb->d;
-    std::vector<Pose> poses(d.K);
+int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x) {
+    Dev& d = e->d;
     std::vector<double> xl((size_t)d.n_rows * 3);
-    NRS_HIP(c, hipMemcpyAsync(poses.data(), d.pose[pb->cur], sizeof(Pose) * d.K, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(xl.data(), d.xl[pb->cur], sizeof(double) * xl.size(), hipMemcpyDeviceToHost, c->stream));
+    if (poses) NRS_HIP(c, hipMemcpyAsync(poses, d.pose[e->cur], sizeof(Pose) * d.K, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(xl.data(), d.xl[e->cur], sizeof(double) * xl.size(), hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
-    if (poses_qt)
-        for (int k = 0; k < d.K; ++k) {
-            for (int i = 0; i < 4; ++i) poses_qt[7 * k + i] = poses[k].q[i];
-            for (int i = 0; i < 3; ++i) poses_qt[7 * k + 4 + i] = poses[k].t[i];
-        }
-    if (lm_xyz)
-        for (int l = 0; l < d.M; ++l)
-            for (int k = 0; k < 3; ++k) lm_xyz[3 * (size_t)l + k] = xl[3 * (size_t)pb->lm_row[l] + k];
+    if (x)
+        for (int v = 0; v < d.M; ++v)
+            for (int k = 0; k < 3; ++k) x[3 * (size_t)v + k] = xl[3 * (size_t)e->vrow[v] + k];
     return NRS_OK;
 }
 
-}  // namespace nrs
-
-using namespace nrs;
-
-extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
-                              int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
-                              int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
-                              int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale) {
-    if (!c) return NRS_ERR_INVALID;
-    int rc = dba_upload_impl(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale);
-    if (rc != NRS_OK) { dba_free(c); return rc; }
-    return dba_reset_impl(c);
-}
-
-extern "C" int nrs_dba_reset(nrs_ctx* c) { return c ? dba_reset_impl(c) : NRS_ERR_INVALID; }
-
-extern "C" int nrs_dba_optimize(nrs_ctx* c, int32_t iters, nrs_lm_trace* trace) {
-    return c ? dba_optimize_impl(c, iters, trace) : NRS_ERR_INVALID;
-}
-
-extern "C" int nrs_dba_download(nrs_ctx* c, double* poses_qt, double* lm_xyz) {
-    return c ? dba_download_impl(c, poses_qt, lm_xyz) : NRS_ERR_INVALID;
-}
-
-extern "C" int nrs_dba_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, double* poses_qt,
-                             int32_t n_lm, float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
-                             int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
-                             int32_t n_dm, const int32_t* dm_idx, const float* dm_w,
-                             float scale, int32_t iters, nrs_lm_trace* trace) {
-    if (!c) return NRS_ERR_INVALID;
-    NRS_TRY(nrs_dba_upload(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale));
-    NRS_TRY(dba_optimize_impl(c, iters, trace));
-    std::vector<double> xyz((size_t)n_lm * 3);
-    NRS_TRY(dba_download_impl(c, poses_qt, xyz.data()));
-    for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
-    return NRS_OK;
-}
-
-extern "C" int nrs_dba_residuals(nrs_ctx* c, double* r_reproj, double* r_spring, double* r_damper) {
-    if (!c) return NRS_ERR_INVALID;
-    DbaProblem* pb = c->dba;
-    if (!pb) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
-    if (!r_reproj || !r_spring || !r_damper) return c->fail(NRS_ERR_INVALID, "null output");
-    DbaDev& d = pb->d;
-    int *lm_row, *sp, *dm;
-    float *d0, *w;
-    double *rr, *rs, *rd;
-    std::vector<void*> tmp;
-    auto al = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) tmp.push_back(*p); return e; };
-    NRS_HIP(c, al((void**)&lm_row, sizeof(int) * d.M));
-    NRS_HIP(c, al((void**)&sp, sizeof(int) * 2 * (size_t)d.n_sp));
-    NRS_HIP(c, al((void**)&dm, sizeof(int) * 4 * (size_t)d.n_dm));
-    NRS_HIP(c, al((void**)&d0, sizeof(float) * (size_t)d.n_sp));
-    NRS_HIP(c, al((void**)&w, sizeof(float) * (size_t)d.n_dm));
-    NRS_HIP(c, al((void**)&rr, sizeof(double) * 2 * (size_t)d.M));
-    NRS_HIP(c, al((void**)&rs, sizeof(double) * (size_t)d.n_sp));
-    NRS_HIP(c, al((void**)&rd, sizeof(double) * 3 * (size_t)d.n_dm));
-    NRS_HIP(c, hipMemcpy(lm_row, pb->lm_row.data(), sizeof(int) * d.M, hipMemcpyHostToDevice));
-    if (d.n_sp) {
-        NRS_HIP(c, hipMemcpy(sp, pb->sp_ij.data(), sizeof(int) * 2 * (size_t)d.n_sp, hipMemcpyHostToDevice));
-        NRS_HIP(c, hipMemcpy(d0, pb->sp_d0.data(), sizeof(float) * (size_t)d.n_sp, hipMemcpyHostToDevice));
-    }
-    if (d.n_dm) {
-        NRS_HIP(c, hipMemcpy(dm, pb->dm_idx.data(), sizeof(int) * 4 * (size_t)d.n_dm, hipMemcpyHostToDevice));
-        NRS_HIP(c, hipMemcpy(w, pb->dm_w.data(), sizeof(float) * (size_t)d.n_dm, hipMemcpyHostToDevice));
-    }
+int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper) {
+    Dev& d = e->d;
+    double* rr = e->t_out;
+    double* rs = rr + 2 * (size_t)d.M;
+    double* rd = rs + (size_t)d.n_sp;
     const int n = std::max(d.M, std::max(d.n_sp, d.n_dm));
-    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[pb->cur], d.xl[pb->cur], lm_row, sp, d0, dm, w, rr, rs, rd);
+    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], d.xl[e->cur],
+                       e->t_vrow, e->t_sp, e->t_d0, e->t_dm, e->t_w, rr, rs, rd);
+    NRS_HIP(c, hipGetLastError());
+    if (r_reproj) NRS_HIP(c, hipMemcpyAsync(r_reproj, rr, sizeof(double) * 2 * (size_t)d.M, hipMemcpyDeviceToHost, c->stream));
+    if (r_spring && d.n_sp) NRS_HIP(c, hipMemcpyAsync(r_spring, rs, sizeof(double) * (size_t)d.n_sp, hipMemcpyDeviceToHost, c->stream));
+    if (r_damper && d.n_dm) NRS_HIP(c, hipMemcpyAsync(r_damper, rd, sizeof(double) * 3 * (size_t)d.n_dm, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
-    NRS_HIP(c, hipMemcpy(r_reproj, rr, sizeof(double) * 2 * (size_t)d.M, hipMemcpyDeviceToHost));
-    if (d.n_sp) NRS_HIP(c, hipMemcpy(r_spring, rs, sizeof(double) * (size_t)d.n_sp, hipMemcpyDeviceToHost));
-    if (d.n_dm) NRS_HIP(c, hipMemcpy(r_damper, rd, sizeof(double) * 3 * (size_t)d.n_dm, hipMemcpyDeviceToHost));
-    for (void* p : tmp) (void)hipFree(p);
     return NRS_OK;
 }
 
-extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
-    if (!c) return NRS_ERR_INVALID;
-    DbaProblem* pb = c->dba;
-    if (!pb) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
-    if (!b || !diag) return c->fail(NRS_ERR_INVALID, "null output");
-    DbaDev& d = pb->d;
-    NRS_TRY(evaluate<true>(c, pb, pb->cur));
+int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj, double* spring, double* damper) {
+    Dev& d = e->d;
+    std::vector<double> rr(2 * (size_t)d.M), rs((size_t)d.n_sp), rd(3 * (size_t)d.n_dm);
+    NRS_TRY(engine_residuals(c, e, rr.data(), rs.data(), rd.data()));
+    if (reproj)
+        for (int i = 0; i < d.M; ++i) reproj[i] = d.info_reproj * (rr[2 * i] * rr[2 * i] + rr[2 * i + 1] * rr[2 * i + 1]);
+    if (spring)
+        for (int i = 0; i < d.n_sp; ++i) spring[i] = d.info_pos * rs[i] * rs[i];
+    if (damper)
+        for (int i = 0; i < d.n_dm; ++i)
+            damper[i] = d.info_spatial * (rd[3 * i] * rd[3 * i] + rd[3 * i + 1] * rd[3 * i + 1] + rd[3 * i + 2] * rd[3 * i + 2]);
+    return NRS_OK;
+}
+
+int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag) {
+    Dev& d = e->d;
+    NRS_TRY(evaluate<true>(c, e, e->cur));
     std::vector<double> bp(6 * (size_t)d.K), Hpp(21 * (size_t)d.K), bl(3 * (size_t)d.n_rows), D(6 * (size_t)d.n_rows);
     NRS_HIP(c, hipMemcpyAsync(bp.data(), d.bp, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipMemcpyAsync(Hpp.data(), d.Hpp, sizeof(double) * Hpp.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1267,12 +1361,14 @@ extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
     for (int k = 0; k < d.K; ++k)
         for (int a = 0; a < 6; ++a) { b[6 * k + a] = bp[6 * k + a]; diag[6 * k + a] = Hpp[21 * k + dg[a]]; }
     static const int d3[3] = {0, 3, 5};
-    for (int l = 0; l < d.M; ++l) {
-        const size_t row = (size_t)pb->lm_row[l];
+    for (int v = 0; v < d.M; ++v) {
+        const size_t row = (size_t)e->vrow[v];
         for (int a = 0; a < 3; ++a) {
-            b[6 * (size_t)d.K + 3 * (size_t)l + a] = bl[3 * row + a];
-            diag[6 * (size_t)d.K + 3 * (size_t)l + a] = D[6 * row + d3[a]];
+            b[6 * (size_t)d.K + 3 * (size_t)v + a] = bl[3 * row + a];
+            diag[6 * (size_t)d.K + 3 * (size_t)v + a] = D[6 * row + d3[a]];
         }
     }
     return NRS_OK;
 }
+
+}  // namespace nrs

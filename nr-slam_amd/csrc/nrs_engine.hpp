@@ -1,0 +1,64 @@
+// Host-side interface of the graph Levenberg-Marquardt engine (nrs_engine.hip).
+//
+// The engine solves the reference's g2o problems on the GPU for one fixed vertex layout:
+// K pose vertices (6 dof, VertexSE3Expmap) followed by M landmark / deformation vertices (3 dof,
+// LandmarkVertex), with the reference's edge types:
+//   * one optional reprojection edge per landmark vertex (ReprojectionError /
+//     ReprojectionErrorWithDeformation), point = X0 + x
+//   * springs   (PositionRegularizer / PositionRegularizerWithDeformation)  on (i, j)
+//   * dampers   (SpatialRegularizer 4 vertices (1c,2c,1n,2n); the 2-vertex
+//                SpatialRegularizerWithDeformation is the same edge with 1c = 2c = -1)
+//   * unary dampers (SpatialRegularizerFixed): Jacobian on i only, j read as a value
+// Levels and fixed flags are plain byte masks that the drivers rewrite between rounds.
+#pragma once
+#include "nrs_ctx.hpp"
+#include "nrs_device.hpp"
+
+namespace nrs {
+
+enum : uint8_t { RF_OBS = 1, RF_REPROJ_ACTIVE = 2, RF_FIXED = 4 };
+
+struct EngineSpec {
+    int K = 0, M = 0;
+    const Pose* poses = nullptr;          // K, already normalised
+    const uint8_t* pose_fixed = nullptr;  // K or null (none fixed)
+    const double* x = nullptr;            // M x 3 initial estimates
+    const double* X0 = nullptr;           // M x 3 constant offset (tracking form) or null
+    const int* lm_pose = nullptr;         // M, non-decreasing pose index of each vertex
+    const float* uv = nullptr;            // M x 2
+    const uint8_t* rflag = nullptr;       // M, RF_* bits
+    int n_sp = 0;
+    const int* sp_ij = nullptr;           // n_sp x 2
+    const float* sp_d0 = nullptr;
+    const uint8_t* sp_active = nullptr;   // level == 0, null = all
+    int n_dm = 0;
+    const int* dm_idx = nullptr;          // n_dm x 4 (1c,2c,1n,2n), -1 = absent vertex
+    const float* dm_w = nullptr;
+    const uint8_t* dm_active = nullptr;
+    int n_un = 0;
+    const int* un_ij = nullptr;           // n_un x 2: (vertex, value-only vertex)
+    const float* un_w = nullptr;
+    Cam cam;
+    double info_reproj = 0, delta_reproj = 0, info_pos = 0, delta_pos = 0, info_spatial = 0, delta_spatial = 0;
+    double k_spring = 0;
+    int spring_form = 0;                  // 0: BA Jacobian as written, 1: tracking form
+};
+
+struct Engine;
+
+int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out);
+void engine_destroy(nrs_ctx* c, Engine* e);
+int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8_t* pose_fixed,
+                        const uint8_t* sp_active, const uint8_t* dm_active);
+int engine_reset(nrs_ctx* c, Engine* e);                                   // estimates <- initial values
+int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* trace);
+int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x);      // caller vertex order
+// fresh computeError() at the current estimate: chi2 = r^T Omega r of every edge
+int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring /*n_sp*/, double* damper /*n_dm*/);
+int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
+int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);       // solver order, caller vertex order
+void arena_release(Arena* a);
+int engine_num_poses(const Engine* e);
+void ba_constants(EngineSpec& s, float scale);            // thresholds / informations of OPT:195-210,958-973
+
+}  // namespace nrs

@@ -1,0 +1,444 @@
+// a2: CameraPoseAndDeformationOptimization (reference modules/optimization/g2o_optimization.cc:148-557)
+// and the RegularizationGraph operations it embeds:
+//   a19 GetEdges      (reference modules/map/regularization_graph.cc:61-87)
+//   a20 UpdateVertex  (reference modules/map/regularization_graph.cc:89-146)
+//
+// Division of labour: every floating-point pass over points or edges (residuals, Jacobians, the
+// normal equations, the PCG solves, edge re-weighting, neighbour ranking) is a HIP kernel; the host
+// runs the reference's bookkeeping between them (which edges exist, levels between the two inlier
+// rounds, the IQR test, statuses), because those are data-dependent container walks whose order is
+// part of the reference's semantics (SURVEY.md 8a "container-order dependencies").
+#include <algorithm>
+#include <cmath>
+#include <set>
+#include "nrs_engine.hpp"
+
+namespace nrs {
+
+// ---------------------------------------------------------------------------------------------
+// InterpolationWeight (utilities/geometry_toolbox.cc:26-28): float argument, exp evaluated in
+// double and rounded to float -- the value a correctly rounded expf returns (include/nrs.h).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline float interpolation_weight(float d, float sigma) {
+#pragma clang fp contract(off)
+    const float arg = -(d * d) / (2.0f * sigma * sigma);
+    return (float)exp((double)arg);
+}
+
+// a19, step 1: rank of every directed entry inside its row under (status asc, weight desc, index asc)
+__global__ void k_graph_rank(int n, const int* __restrict__ rowptr, const int* __restrict__ eid,
+                             const float* __restrict__ e_w, const int* __restrict__ e_status, int* rank) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int lo = rowptr[p], hi = rowptr[p + 1];
+    for (int a = lo; a < hi; ++a) {
+        const int sa = e_status[eid[a]];
+        const float wa = e_w[eid[a]];
+        int r = 0;
+        for (int b = lo; b < hi; ++b) {
+            const int sb = e_status[eid[b]];
+            const float wb = e_w[eid[b]];
+            const bool before = (sb != sa) ? (sb < sa) : ((wb != wa) ? (wb > wa) : (b < a));
+            r += before ? 1 : 0;
+        }
+        rank[a] = r;
+    }
+}
+
+// a19, step 2: cut position = rank of the first entry (in sorted order) whose weight < min_weight
+__global__ void k_graph_cut(int n, const int* __restrict__ rowptr, const int* __restrict__ eid,
+                            const float* __restrict__ e_w, const int* __restrict__ rank, float min_w, int* count) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int lo = rowptr[p], hi = rowptr[p + 1];
+    int cut = hi - lo;
+    for (int a = lo; a < hi; ++a)
+        if (e_w[eid[a]] < min_w) cut = min(cut, rank[a]);
+    count[p] = cut;
+}
+
+// a19, step 3: scatter the kept entries to their sorted position
+__global__ void k_graph_scatter(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                const int* __restrict__ eid, const int* __restrict__ rank,
+                                const int* __restrict__ o_rowptr, int* o_col, int* o_eid) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int lo = rowptr[p], hi = rowptr[p + 1];
+    const int base = o_rowptr[p], cnt = o_rowptr[p + 1] - base;
+    for (int a = lo; a < hi; ++a)
+        if (rank[a] < cnt) { o_col[base + rank[a]] = col[a]; o_eid[base + rank[a]] = eid[a]; }
+}
+
+// a20: UpdateVertex for a list of points.  Two points sharing an edge compute the same values
+// (the positions are final), so concurrent updates of one edge are idempotent.
+__global__ void k_graph_update(int n_ids, const int* __restrict__ ids, const int* __restrict__ rowptr,
+                               const int* __restrict__ col, const int* __restrict__ eid, const float* __restrict__ pos,
+                               float* e_w, float* e_max, float* e_min, int* e_status, float sigma, float stretch_th,
+                               int* good) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ids) return;
+    const int p = ids[i];
+    const float px = pos[3 * p], py = pos[3 * p + 1], pz = pos[3 * p + 2];
+    int n_good = 0;
+    for (int a = rowptr[p]; a < rowptr[p + 1]; ++a) {
+        const int o = col[a], e = eid[a];
+        const float dx = px - pos[3 * o], dy = py - pos[3 * o + 1], dz = pz - pos[3 * o + 2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        float mx = e_max[e], mn = e_min[e];
+        if (d > mx) mx = d;
+        if (d < mn) mn = d;
+        e_max[e] = mx;
+        e_min[e] = mn;
+        e_w[e] = interpolation_weight(mx, sigma);
+        if (fabsf((mx - mn) / mn) > stretch_th) e_status[e] = NRS_GRAPH_BAD;
+        else ++n_good;
+    }
+    good[i] = n_good;
+}
+
+struct GraphDevice {            // device mirror of an nrs_graph for the duration of one call
+    nrs_ctx* c;
+    std::vector<void*> allocs;
+    int *rowptr = nullptr, *col = nullptr, *eid = nullptr, *status = nullptr, *rank = nullptr, *count = nullptr;
+    int *o_rowptr = nullptr, *o_col = nullptr, *o_eid = nullptr, *ids = nullptr, *good = nullptr;
+    float *w = nullptr, *mx = nullptr, *mn = nullptr, *pos = nullptr;
+    int n = 0, nnz = 0, ne = 0;
+    ~GraphDevice() { for (void* p : allocs) (void)hipFree(p); }
+    template <class Tp> int alloc(Tp** p, size_t n_) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(16, n_ * sizeof(Tp)));
+        if (e != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc failed: %s", hipGetErrorString(e));
+        allocs.push_back(*p);
+        return NRS_OK;
+    }
+};
+
+static int graph_validate(nrs_ctx* c, const nrs_graph* g) {
+    if (!g || g->n_points < 0 || g->n_edges < 0 || !g->rowptr) return c->fail(NRS_ERR_INVALID, "graph: null/negative");
+    const int nnz = g->rowptr[g->n_points];
+    if (nnz > 0 && (!g->col || !g->eid || !g->e_w || !g->e_d0 || !g->e_max || !g->e_min || !g->e_status))
+        return c->fail(NRS_ERR_INVALID, "graph: null arrays");
+    if (!(g->sigma > 0)) return c->fail(NRS_ERR_INVALID, "graph: sigma must be positive");
+    for (int p = 0; p < g->n_points; ++p) {
+        if (g->rowptr[p + 1] < g->rowptr[p]) return c->fail(NRS_ERR_INVALID, "graph: rowptr not monotone");
+        for (int a = g->rowptr[p]; a < g->rowptr[p + 1]; ++a) {
+            if (g->col[a] < 0 || g->col[a] >= g->n_points || g->eid[a] < 0 || g->eid[a] >= g->n_edges)
+                return c->fail(NRS_ERR_INVALID, "graph: index out of range");
+            if (a > g->rowptr[p] && g->col[a] <= g->col[a - 1]) return c->fail(NRS_ERR_INVALID, "graph: row not in ascending index order");
+        }
+    }
+    return NRS_OK;
+}
+
+static int graph_upload(nrs_ctx* c, GraphDevice& G, const nrs_graph* g) {
+    G.c = c;
+    G.n = g->n_points;
+    G.nnz = g->rowptr[g->n_points];
+    G.ne = g->n_edges;
+    NRS_TRY(G.alloc(&G.rowptr, G.n + 1)); NRS_TRY(G.alloc(&G.col, G.nnz)); NRS_TRY(G.alloc(&G.eid, G.nnz));
+    NRS_TRY(G.alloc(&G.status, G.ne)); NRS_TRY(G.alloc(&G.w, G.ne)); NRS_TRY(G.alloc(&G.mx, G.ne)); NRS_TRY(G.alloc(&G.mn, G.ne));
+    NRS_TRY(G.alloc(&G.rank, G.nnz)); NRS_TRY(G.alloc(&G.count, G.n + 1));
+    NRS_TRY(G.alloc(&G.o_rowptr, G.n + 1)); NRS_TRY(G.alloc(&G.o_col, G.nnz)); NRS_TRY(G.alloc(&G.o_eid, G.nnz));
+    NRS_TRY(G.alloc(&G.ids, G.n)); NRS_TRY(G.alloc(&G.good, G.n)); NRS_TRY(G.alloc(&G.pos, 3 * (size_t)G.n));
+    NRS_HIP(c, hipMemcpyAsync(G.rowptr, g->rowptr, sizeof(int) * (G.n + 1), hipMemcpyHostToDevice, c->stream));
+    if (G.nnz) {
+        NRS_HIP(c, hipMemcpyAsync(G.col, g->col, sizeof(int) * G.nnz, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(G.eid, g->eid, sizeof(int) * G.nnz, hipMemcpyHostToDevice, c->stream));
+    }
+    if (G.ne) {
+        NRS_HIP(c, hipMemcpyAsync(G.status, g->e_status, sizeof(int) * G.ne, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(G.w, g->e_w, sizeof(float) * G.ne, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(G.mx, g->e_max, sizeof(float) * G.ne, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(G.mn, g->e_min, sizeof(float) * G.ne, hipMemcpyHostToDevice, c->stream));
+    }
+    return NRS_OK;
+}
+
+// GetEdges for all points on the device copy; result on the host
+static int graph_select(nrs_ctx* c, GraphDevice& G, float sigma, std::vector<int>& o_rowptr, std::vector<int>& o_col,
+                        std::vector<int>& o_eid) {
+    const float min_w = interpolation_weight((float)((double)sigma * 1.5), sigma);   // regularization_graph.cc:30
+    const dim3 b(256), g((G.n + 255) / 256);
+    o_rowptr.assign(G.n + 1, 0);
+    if (G.n == 0) return NRS_OK;
+    hipLaunchKernelGGL(k_graph_rank, g, b, 0, c->stream, G.n, G.rowptr, G.eid, G.w, G.status, G.rank);
+    hipLaunchKernelGGL(k_graph_cut, g, b, 0, c->stream, G.n, G.rowptr, G.eid, G.w, G.rank, min_w, G.count);
+    NRS_HIP(c, hipGetLastError());
+    std::vector<int> cnt(G.n);
+    NRS_HIP(c, hipMemcpyAsync(cnt.data(), G.count, sizeof(int) * G.n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < G.n; ++p) o_rowptr[p + 1] = o_rowptr[p] + cnt[p];
+    NRS_HIP(c, hipMemcpyAsync(G.o_rowptr, o_rowptr.data(), sizeof(int) * (G.n + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_graph_scatter, g, b, 0, c->stream, G.n, G.rowptr, G.col, G.eid, G.rank, G.o_rowptr, G.o_col, G.o_eid);
+    NRS_HIP(c, hipGetLastError());
+    const int tot = o_rowptr[G.n];
+    o_col.resize(tot);
+    o_eid.resize(tot);
+    if (tot) {
+        NRS_HIP(c, hipMemcpyAsync(o_col.data(), G.o_col, sizeof(int) * tot, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(o_eid.data(), G.o_eid, sizeof(int) * tot, hipMemcpyDeviceToHost, c->stream));
+    }
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+
+static int graph_update(nrs_ctx* c, GraphDevice& G, nrs_graph* g, const float* pos, int n_ids, const int* ids,
+                        int* good) {
+    if (n_ids == 0) return NRS_OK;
+    NRS_HIP(c, hipMemcpyAsync(G.pos, pos, sizeof(float) * 3 * (size_t)G.n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(G.ids, ids, sizeof(int) * n_ids, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_graph_update, dim3((n_ids + 255) / 256), dim3(256), 0, c->stream, n_ids, G.ids, G.rowptr, G.col,
+                       G.eid, G.pos, G.w, G.mx, G.mn, G.status, g->sigma, g->stretch_th, G.good);
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipMemcpyAsync(good, G.good, sizeof(int) * n_ids, hipMemcpyDeviceToHost, c->stream));
+    if (G.ne) {
+        NRS_HIP(c, hipMemcpyAsync(g->e_w, G.w, sizeof(float) * G.ne, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(g->e_max, G.mx, sizeof(float) * G.ne, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(g->e_min, G.mn, sizeof(float) * G.ne, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(g->e_status, G.status, sizeof(int) * G.ne, hipMemcpyDeviceToHost, c->stream));
+    }
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+
+}  // namespace nrs
+
+using namespace nrs;
+
+extern "C" int nrs_graph_select_neighbours(nrs_ctx* c, const nrs_graph* g, int32_t* o_rowptr, int32_t* o_col,
+                                           int32_t* o_eid) {
+    if (!c) return NRS_ERR_INVALID;
+    NRS_TRY(graph_validate(c, g));
+    if (!o_rowptr || (g->rowptr[g->n_points] > 0 && (!o_col || !o_eid))) return c->fail(NRS_ERR_INVALID, "null output");
+    NRS_HIP(c, hipSetDevice(c->device));
+    GraphDevice G;
+    NRS_TRY(graph_upload(c, G, g));
+    std::vector<int> rp, oc, oe;
+    NRS_TRY(graph_select(c, G, g->sigma, rp, oc, oe));
+    std::copy(rp.begin(), rp.end(), o_rowptr);
+    std::copy(oc.begin(), oc.end(), o_col);
+    std::copy(oe.begin(), oe.end(), o_eid);
+    return NRS_OK;
+}
+
+extern "C" int nrs_graph_update(nrs_ctx* c, nrs_graph* g, const float* pos, int32_t n_ids, const int32_t* ids,
+                                int32_t* good_count) {
+    if (!c) return NRS_ERR_INVALID;
+    NRS_TRY(graph_validate(c, g));
+    if (n_ids < 0 || (n_ids > 0 && (!ids || !good_count || !pos))) return c->fail(NRS_ERR_INVALID, "nrs_graph_update: bad argument");
+    for (int i = 0; i < n_ids; ++i)
+        if (ids[i] < 0 || ids[i] >= g->n_points) return c->fail(NRS_ERR_INVALID, "point index out of range");
+    NRS_HIP(c, hipSetDevice(c->device));
+    GraphDevice G;
+    NRS_TRY(graph_upload(c, G, g));
+    return graph_update(c, G, g, pos, n_ids, ids, good_count);
+}
+
+extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_graph* g, float* map_pos,
+                                      int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                                      float* f_pos, double pose_qt[7], float scale, float* deform_median,
+                                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!cam || !map_pos || n_f < 0 || !pose_qt || !n_lost || (n_f > 0 && (!f_map || !f_status || !f_uv || !f_pos)))
+        return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve: bad argument");
+    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    NRS_TRY(graph_validate(c, g));
+    NRS_HIP(c, hipSetDevice(c->device));
+    if (trace) { trace->count = 0; trace->iterations = 0; }
+    *n_lost = 0;
+    if (deform_median) *deform_median = 0.f;
+    const int n_map = g->n_points;
+    std::vector<int> map_to_frame(n_map, -1);
+    for (int i = 0; i < n_f; ++i) {
+        if (f_map[i] >= n_map) return c->fail(NRS_ERR_INVALID, "f_map out of range");
+        if (f_map[i] >= 0) map_to_frame[f_map[i]] = i;
+    }
+    // points in the optimisation: TRACKED_WITH_3D in frame index order (OPT:174-192)
+    std::vector<int> opt_f, ids;
+    for (int i = 0; i < n_f; ++i)
+        if (f_status[i] == NRS_TRACKED_WITH_3D && f_map[i] >= 0) { opt_f.push_back(i); ids.push_back(f_map[i]); }
+    const int N = (int)opt_f.size();
+    if (N == 0) return NRS_OK;                       // nothing to optimise (g2o: empty graph)
+    std::vector<int> id_to_idx(n_map, -1);
+    for (int i = 0; i < N; ++i) id_to_idx[ids[i]] = i;
+
+    GraphDevice G;
+    NRS_TRY(graph_upload(c, G, g));
+    std::vector<int> orp, ocol, oeid;
+    NRS_TRY(graph_select(c, G, g->sigma, orp, ocol, oeid));
+
+    // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
+    std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
+    std::vector<int> dm_idx, sp_ij;
+    std::vector<float> dm_w, sp_d0;
+    std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
+    for (int idx = 0; idx < N; ++idx) {
+        const int p = ids[idx];
+        int n_reg = 0;
+        for (int a = orp[p]; a < orp[p + 1]; ++a) {
+            const int e = oeid[a], other = ocol[a];
+            if (n_reg > 10 || g->e_status[e] == NRS_GRAPH_BAD) break;
+            const int fo = map_to_frame[other];
+            if (fo < 0 || f_status[fo] != NRS_TRACKED_WITH_3D) {
+                if (fo >= 0 && f_status[fo] != NRS_JUST_TRIANGULATED) lost_set.insert(other);
+                continue;
+            }
+            const int io = id_to_idx[other];
+            bool dup = false;
+            for (auto& pr : reg[idx]) dup = dup || pr.first == io;
+            if (dup) continue;
+            const int k = (int)dm_w.size();
+            dm_idx.insert(dm_idx.end(), {-1, -1, idx, io});      // r = w (delta_idx - delta_io)
+            dm_w.push_back(g->e_w[e]);
+            sp_ij.insert(sp_ij.end(), {idx, io});
+            sp_d0.push_back(g->e_d0[e]);
+            reg[idx].push_back({io, k});
+            reg[io].push_back({idx, k});
+            ++n_reg;
+        }
+    }
+    const int E = (int)dm_w.size();
+
+    // ---- engine for the two inlier rounds
+    EngineSpec s;
+    Pose seed;
+    for (int i = 0; i < 4; ++i) seed.q[i] = pose_qt[i];
+    for (int i = 0; i < 3; ++i) seed.t[i] = pose_qt[4 + i];
+    quat_normalize(seed.q);
+    std::vector<double> X0(3 * (size_t)N), zeros(3 * (size_t)N, 0.0);
+    std::vector<float> uv(2 * (size_t)N);
+    std::vector<int> lm_pose(N, 0);
+    for (int i = 0; i < N; ++i) {
+        for (int k = 0; k < 3; ++k) X0[3 * (size_t)i + k] = (double)f_pos[3 * (size_t)opt_f[i] + k];
+        uv[2 * (size_t)i] = f_uv[2 * (size_t)opt_f[i]];
+        uv[2 * (size_t)i + 1] = f_uv[2 * (size_t)opt_f[i] + 1];
+    }
+    std::vector<uint8_t> rflag(N, RF_OBS | RF_REPROJ_ACTIVE), dm_active(E, 1);
+    s.K = 1; s.M = N;
+    s.poses = &seed;
+    s.x = zeros.data(); s.X0 = X0.data();
+    s.lm_pose = lm_pose.data(); s.uv = uv.data(); s.rflag = rflag.data();
+    s.n_sp = E; s.sp_ij = sp_ij.data(); s.sp_d0 = sp_d0.data();
+    s.n_dm = E; s.dm_idx = dm_idx.data(); s.dm_w = dm_w.data(); s.dm_active = dm_active.data();
+    s.cam.model = cam->model;
+    for (int i = 0; i < 8; ++i) s.cam.p[i] = cam->params[i];
+    ba_constants(s, scale);
+    s.delta_pos = s.delta_spatial;                                // Huber sqrt(0.584) on the springs (OPT:324-326)
+    s.spring_form = 1;
+    Engine* eng = nullptr;
+    NRS_TRY(engine_create(c, s, &c->arena_trk, &eng));
+    struct EG { nrs_ctx* c; Engine* e; ~EG() { engine_destroy(c, e); } } eg{c, eng};
+
+    const float th2_sq = 5.99f, th3_sq = 0.584f;
+    std::vector<char> inl(N, 1);
+    std::vector<double> chi_r(N), chi_d(E);
+    for (int rnd = 0; rnd < 2; ++rnd) {                          // OPT:338-395
+        NRS_TRY(engine_reset(c, eng));
+        NRS_TRY(engine_optimize(c, eng, 10, rnd, trace));
+        NRS_TRY(engine_edge_chi2(c, eng, chi_r.data(), nullptr, chi_d.data()));
+        for (int idx = 0; idx < N; ++idx) {
+            const bool out = (float)chi_r[idx] > th2_sq;
+            inl[idx] = !out;
+            rflag[idx] = RF_OBS | (out ? 0 : RF_REPROJ_ACTIVE);
+            for (auto& pr : reg[idx]) dm_active[pr.second] = out ? 0 : 1;
+            for (auto& pr : reg[idx]) dm_active[pr.second] = chi_d[pr.second] > (double)th3_sq ? 0 : 1;
+        }
+        NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
+    }
+    Pose pose_out;
+    std::vector<double> delta(3 * (size_t)N);
+    NRS_TRY(engine_download(c, eng, &pose_out, delta.data()));
+    for (int i = 0; i < 4; ++i) pose_qt[i] = pose_out.q[i];
+    for (int i = 0; i < 3; ++i) pose_qt[4 + i] = pose_out.t[i];
+
+    // ---- OPT:401-455: deformation statistics, status / position updates
+    std::vector<float> mag(N), dfl(3 * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        const float d0 = (float)delta[3 * (size_t)i], d1 = (float)delta[3 * (size_t)i + 1], d2 = (float)delta[3 * (size_t)i + 2];
+        dfl[3 * (size_t)i] = d0; dfl[3 * (size_t)i + 1] = d1; dfl[3 * (size_t)i + 2] = d2;
+        mag[i] = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    std::vector<float> srt = mag;
+    std::sort(srt.begin(), srt.end());
+    const float q1 = srt[(int)(N * 0.25f)], q3 = srt[(int)(N * 0.75f)];
+    const float th = 1.5f * (q3 - q1);
+    for (int idx = 0; idx < N; ++idx) {
+        const int fi = opt_f[idx];
+        if ((float)chi_r[idx] > th2_sq) { inl[idx] = 0; f_status[fi] = NRS_TRACKED; }
+        if (mag[idx] >= q3 + th) { f_status[fi] = NRS_TRACKED; continue; }
+        rflag[idx] |= RF_FIXED;
+        for (int k = 0; k < 3; ++k) {
+            const float cur = dfl[3 * (size_t)idx + k] + f_pos[3 * (size_t)fi + k];
+            f_pos[3 * (size_t)fi + k] = cur;
+            map_pos[3 * (size_t)ids[idx] + k] = cur;
+        }
+    }
+    if (deform_median) {
+        std::vector<float> m2 = mag;
+        std::nth_element(m2.begin(), m2.begin() + N / 2, m2.end());
+        *deform_median = m2[N / 2];
+    }
+    // ---- graph update OPT:457-474
+    {
+        std::vector<int> upd_ids, upd_idx;
+        for (int idx = 0; idx < N; ++idx)
+            if (inl[idx]) { upd_ids.push_back(ids[idx]); upd_idx.push_back(idx); }
+        std::vector<int> good(upd_ids.size());
+        NRS_TRY(graph_update(c, G, g, map_pos, (int)upd_ids.size(), upd_ids.data(), good.data()));
+        for (size_t i = 0; i < upd_ids.size(); ++i)
+            if (good[i] < 10 * 0.5) f_status[opt_f[upd_idx[i]]] = NRS_BAD;
+    }
+    if (lost_set.empty()) return NRS_OK;
+
+    // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
+    NRS_TRY(graph_select(c, G, g->sigma, orp, ocol, oeid));       // GetEdges sees the updated graph
+    std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
+    const int L = (int)lost_ids.size();
+    std::vector<int> un_ij;
+    std::vector<float> un_w;
+    for (int li = 0; li < L; ++li) {
+        const int p = lost_ids[li];
+        int n_reg = 0;
+        for (int a = orp[p]; a < orp[p + 1]; ++a) {
+            if (n_reg > 10) break;
+            const int io = id_to_idx[ocol[a]];
+            if (io < 0) continue;
+            un_ij.insert(un_ij.end(), {N + li, io});
+            un_w.push_back(g->e_w[oeid[a]]);
+            ++n_reg;
+        }
+    }
+    const int M2 = N + L;
+    std::vector<double> x2(3 * (size_t)M2, 0.0), X02(3 * (size_t)M2, 0.0);
+    std::copy(delta.begin(), delta.end(), x2.begin());
+    std::copy(X0.begin(), X0.end(), X02.begin());
+    std::vector<float> uv2(2 * (size_t)M2, 0.f);
+    std::copy(uv.begin(), uv.end(), uv2.begin());
+    std::vector<int> lm_pose2(M2, 0);
+    std::vector<uint8_t> rflag2(M2, 0);
+    std::copy(rflag.begin(), rflag.end(), rflag2.begin());
+    const uint8_t pose_fixed = 1;
+    EngineSpec s2 = s;
+    s2.M = M2;
+    s2.poses = &pose_out;
+    s2.pose_fixed = &pose_fixed;
+    s2.x = x2.data(); s2.X0 = X02.data();
+    s2.lm_pose = lm_pose2.data(); s2.uv = uv2.data(); s2.rflag = rflag2.data();
+    s2.dm_active = dm_active.data();
+    s2.n_un = (int)un_w.size(); s2.un_ij = un_ij.data(); s2.un_w = un_w.data();
+    engine_destroy(c, eng);
+    eg.e = nullptr;
+    Engine* eng2 = nullptr;
+    NRS_TRY(engine_create(c, s2, &c->arena_trk, &eng2));
+    eg.e = eng2;
+    NRS_TRY(engine_optimize(c, eng2, 10, 2, trace));
+    std::vector<double> x_out(3 * (size_t)M2);
+    NRS_TRY(engine_download(c, eng2, nullptr, x_out.data()));
+    for (int li = 0; li < L; ++li) {
+        for (int k = 0; k < 3; ++k)
+            map_pos[3 * (size_t)lost_ids[li] + k] = (float)x_out[3 * (size_t)(N + li) + k] + map_pos[3 * (size_t)lost_ids[li] + k];
+        if (lost) lost[li] = lost_ids[li];
+    }
+    *n_lost = L;
+    return NRS_OK;
+}

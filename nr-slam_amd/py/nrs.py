@@ -19,7 +19,8 @@ STATUS_NAMES = {0: "NRS_OK", -1: "NRS_ERR_INVALID", -2: "NRS_ERR_NO_DEVICE", -3:
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient"]
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient",
+           "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve"]
 
 
 class NrsError(RuntimeError):
@@ -47,6 +48,13 @@ class LmTrial(C.Structure):
 class LmTrace(C.Structure):
     _fields_ = [("trials", C.POINTER(LmTrial)), ("capacity", C.c_int32), ("count", C.c_int32),
                 ("iterations", C.c_int32)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("rowptr", C.POINTER(C.c_int32)), ("col", C.POINTER(C.c_int32)),
+                ("eid", C.POINTER(C.c_int32)), ("n_edges", C.c_int32), ("e_w", C.POINTER(C.c_float)),
+                ("e_d0", C.POINTER(C.c_float)), ("e_max", C.POINTER(C.c_float)), ("e_min", C.POINTER(C.c_float)),
+                ("e_status", C.POINTER(C.c_int32)), ("sigma", C.c_float), ("stretch_th", C.c_float)]
 
 
 class Profile(C.Structure):
@@ -87,6 +95,25 @@ def make_camera(model, params):
     for i in range(8):
         cam.params[i] = float(prm[i])
     return cam
+
+
+class GraphArrays:
+    """Owns contiguous copies of a flat graph dict (nrs_synth.build_graph) and the nrs_graph view."""
+
+    def __init__(self, g):
+        self.rowptr, self.col, self.eid = _i32(g["rowptr"]).copy(), _i32(g["col"]).copy(), _i32(g["eid"]).copy()
+        self.e_w, self.e_d0 = _f32(g["e_w"]).copy(), _f32(g["e_d0"]).copy()
+        self.e_max, self.e_min = _f32(g["e_max"]).copy(), _f32(g["e_min"]).copy()
+        self.e_status = _i32(g["e_status"]).copy()
+        self.c = Graph(len(self.rowptr) - 1, _p(self.rowptr, C.c_int32), _p(self.col, C.c_int32),
+                       _p(self.eid, C.c_int32), len(self.e_w), _p(self.e_w, C.c_float), _p(self.e_d0, C.c_float),
+                       _p(self.e_max, C.c_float), _p(self.e_min, C.c_float), _p(self.e_status, C.c_int32),
+                       float(g["sigma"]), float(g["stretch_th"]))
+
+    def as_dict(self, g):
+        out = dict(g)
+        out.update(e_w=self.e_w.copy(), e_max=self.e_max.copy(), e_min=self.e_min.copy(), e_status=self.e_status.copy())
+        return out
 
 
 class Trace:
@@ -180,6 +207,41 @@ class Context:
                                                _p(X, C.c_float), _p(qt, C.c_double), _p(inl, C.c_uint8),
                                                C.byref(trace.c) if trace else None))
         return qt[:4].copy(), qt[4:].copy(), inl.astype(bool)
+
+    # ---- a19 / a20
+    def graph_select_neighbours(self, g):
+        ga = GraphArrays(g)
+        n, nnz = len(ga.rowptr) - 1, len(ga.col)
+        rp, oc, oe = np.zeros(n + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz, np.int32)
+        self._chk(self.lib.nrs_graph_select_neighbours(self.h, C.byref(ga.c), _p(rp, C.c_int32), _p(oc, C.c_int32),
+                                                       _p(oe, C.c_int32)))
+        return rp, oc[:rp[-1]].copy(), oe[:rp[-1]].copy()
+
+    def graph_update(self, g, pos, ids):
+        ga = GraphArrays(g)
+        pos = _f32(pos).reshape(-1, 3)
+        ids = _i32(ids)
+        good = np.zeros(len(ids), np.int32)
+        self._chk(self.lib.nrs_graph_update(self.h, C.byref(ga.c), _p(pos, C.c_float), C.c_int32(len(ids)),
+                                            _p(ids, C.c_int32), _p(good, C.c_int32)))
+        return ga.as_dict(g), good
+
+    # ---- a2
+    def track_deform_solve(self, cam, g, map_pos, f_map, f_status, f_uv, f_pos, pose_q, pose_t, scale, trace=None):
+        ga = GraphArrays(g)
+        map_pos = _f32(map_pos).reshape(-1, 3).copy()
+        f_map, f_status = _i32(f_map), _i32(f_status).copy()
+        f_uv, f_pos = _f32(f_uv).reshape(-1, 2), _f32(f_pos).reshape(-1, 3).copy()
+        qt = np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)])
+        med = C.c_float(0)
+        n_lost = C.c_int32(0)
+        lost = np.zeros(len(map_pos), np.int32)
+        self._chk(self.lib.nrs_track_deform_solve(
+            self.h, C.byref(cam), C.byref(ga.c), _p(map_pos, C.c_float), C.c_int32(len(f_map)), _p(f_map, C.c_int32),
+            _p(f_status, C.c_int32), _p(f_uv, C.c_float), _p(f_pos, C.c_float), _p(qt, C.c_double), C.c_float(scale),
+            C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
+        return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
+                    graph=ga.as_dict(g), median=float(med.value), lost=lost[:n_lost.value].tolist())
 
     # ---- a3
     def _dba_args(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):

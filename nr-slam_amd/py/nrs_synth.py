@@ -98,16 +98,28 @@ def surface_points(n, rng, model):
     return np.stack([x, y, z], 1), nrm
 
 
-def build_graph(X, sigma, knn=16):
-    """Symmetric deformation graph over points X (fp32, map units) in the ordered-CSR wire form
-    that RegularizationGraph::GetEdges would return per point: rows sorted by (status asc,
-    weight desc), cut at min_weight (reference regularization_graph.cc:61-87).  Candidate edges
-    = union of k-nearest-neighbour pairs (the reference starts from all pairs; pairs below
-    min_weight can never be returned by GetEdges because weights only decrease)."""
+def _weight(d, sigma):
+    """InterpolationWeight (reference geometry_toolbox.cc:26-28): float argument, exp in double,
+    result rounded to float (include/nrs.h nrs_graph)."""
+    d = np.asarray(d, F32)
+    sigma = F32(sigma)
+    arg = (-(d * d) / (F32(2) * sigma * sigma)).astype(F32)
+    return np.exp(arg.astype(np.float64)).astype(F32)
+
+
+def build_graph(X, sigma, knn=16, stretch_th=1.1):
+    """Deformation graph over points X (fp32, map units) in the flat wire form of
+    RegularizationGraph (reference regularization_graph.h:49-59,79,89):
+      * undirected edges e: e_i < e_j, first_distance d0, max/min distance, weight, status
+      * raw CSR per point, neighbours in ascending index order (= btree_map ID order), each
+        directed entry naming its undirected edge (eid).
+    Candidate edges = union of k-nearest-neighbour pairs whose initial weight reaches min_weight
+    (the reference starts from all pairs, map.cc:148-166; pairs below min_weight can never be
+    returned by GetEdges because weights only decrease, regularization_graph.cc:113)."""
     X = np.asarray(X, F32)
     n = len(X)
     sigma = F32(sigma)
-    min_w = np.exp(-(F32(float(sigma) * 1.5) ** 2) / (F32(2) * sigma * sigma)).astype(F32)
+    min_w = _weight(F32(float(sigma) * 1.5), sigma)
     k = min(knn + 1, n)
     tree = cKDTree(X.astype(np.float64))
     _, nn = tree.query(X.astype(np.float64), k=k)
@@ -118,21 +130,54 @@ def build_graph(X, sigma, knn=16):
     pairs = np.unique(np.stack([a[keep], b[keep]], 1), axis=0)
     rel = X[pairs[:, 1]] - X[pairs[:, 0]]
     d = np.sqrt((rel[:, 0] * rel[:, 0] + rel[:, 1] * rel[:, 1] + rel[:, 2] * rel[:, 2]).astype(F32)).astype(F32)
-    w = np.exp(-(d * d) / (F32(2) * sigma * sigma)).astype(F32)
+    w = _weight(d, sigma)
     ok = w >= min_w
     pairs, d, w = pairs[ok], d[ok], w[ok]
+    ne = len(pairs)
     row = np.concatenate([pairs[:, 0], pairs[:, 1]])
     col = np.concatenate([pairs[:, 1], pairs[:, 0]])
-    ww = np.concatenate([w, w])
-    dd = np.concatenate([d, d])
-    order = np.lexsort((col, -ww.astype(np.float64), row))     # status all NEUTRAL
-    row, col, ww, dd = row[order], col[order], ww[order], dd[order]
-    rowptr = np.zeros(n + 1, np.int32)
+    eid = np.concatenate([np.arange(ne), np.arange(ne)])
+    order = np.lexsort((col, row))
+    row, col, eid = row[order], col[order], eid[order]
+    rowptr = np.zeros(n + 1, np.int64)
     np.add.at(rowptr, row + 1, 1)
     rowptr = np.cumsum(rowptr).astype(np.int32)
-    return dict(rowptr=rowptr, col=col.astype(np.int32), w=ww.astype(F32), d0=dd.astype(F32),
-                status=np.full(len(col), GRAPH_NEUTRAL, np.int32), min_w=float(min_w),
-                sigma=float(sigma), max_d=dd.astype(F32).copy(), min_d=dd.astype(F32).copy())
+    g = dict(n=n, rowptr=rowptr, col=col.astype(np.int32), eid=eid.astype(np.int32),
+             e_ij=pairs.astype(np.int32), e_d0=d.copy(), e_w=w.copy(), e_max=d.copy(), e_min=d.copy(),
+             e_status=np.full(ne, GRAPH_NEUTRAL, np.int32), min_w=float(min_w), sigma=float(sigma),
+             stretch_th=float(stretch_th))
+    g.update(ordered_neighbours(g))
+    return g
+
+
+def ordered_neighbours(g):
+    """NumPy twin of GetEdges (reference regularization_graph.cc:61-87) on the flat graph: per
+    point, neighbours sorted by (status asc, weight desc, index asc) and cut at the first weight
+    below min_weight.  Used to build inputs; the product's version is nrs_graph_select_neighbours."""
+    rowptr, col, eid = g["rowptr"], g["col"], g["eid"]
+    n = len(rowptr) - 1
+    row = np.repeat(np.arange(n), np.diff(rowptr))
+    w = g["e_w"][eid]
+    st = g["e_status"][eid]
+    order = np.lexsort((col, -w.astype(np.float64), st, row))
+    r2, c2, e2, w2 = row[order], col[order], eid[order], w[order]
+    low = w2 < np.float32(g["min_w"])
+    # cut every row at its first low-weight entry
+    pos = np.arange(len(r2)) - rowptr[r2]
+    first_low = np.full(n, np.iinfo(np.int64).max)
+    np.minimum.at(first_low, r2[low], pos[low])
+    keep = pos < first_low[r2]
+    r2, c2, e2 = r2[keep], c2[keep], e2[keep]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, r2 + 1, 1)
+    return dict(o_rowptr=np.cumsum(rp).astype(np.int32), o_col=c2.astype(np.int32), o_eid=e2.astype(np.int32))
+
+
+def ordered_view(g):
+    """Ordered neighbour lists with per-entry weight / first_distance / status (input of
+    nrs_dba_build_edges and of the oracle's dba_build)."""
+    e = g["o_eid"]
+    return dict(rowptr=g["o_rowptr"], col=g["o_col"], w=g["e_w"][e], d0=g["e_d0"][e], status=g["e_status"][e])
 
 
 def make_scene(n_points, n_kf, seed, model=PINHOLE, dropout=0.05, outlier_frac=0.02,
@@ -216,7 +261,8 @@ def make_dba_problem(name_or_n, n_kf=None, seed=None, model=PINHOLE, pose_noise=
     lm_pt = np.concatenate(kf_points).astype(np.int32)
     return dict(model=sc["model"], prm=sc["prm"], scale=sc["scale"], n_kf=n_kf, n_points=n_points,
                 poses_q=np.array(poses_q), poses_t=np.array(poses_t), kf_points=kf_points,
-                lm_xyz=lm_xyz, lm_kf=lm_kf, lm_pt=lm_pt, lm_uv=lm_uv, graph=sc["graph"], scene=sc)
+                lm_xyz=lm_xyz, lm_kf=lm_kf, lm_pt=lm_pt, lm_uv=lm_uv, graph=sc["graph"],
+                nbr=ordered_view(sc["graph"]), scene=sc)
 
 
 def make_tracking_problem(n_points, seed, model=PINHOLE, frame=3, lost_frac=0.03, **kw):

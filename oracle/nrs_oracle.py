@@ -670,9 +670,13 @@ GRAPH_NEUTRAL = 2
 
 
 def interpolation_weight(d, sigma):
+    """InterpolationWeight (geometry_toolbox.cc:26-28): float argument, exp evaluated in double and
+    rounded to float (what a correctly rounded expf returns; libm expf implementations differ in
+    the last ulp, so the build fixes this definition on both sides -- DESIGN.md "weights")."""
     d = np.asarray(d, F32)
     sigma = F32(sigma)
-    return np.exp(-(d * d) / (F32(2) * sigma * sigma)).astype(F32)
+    arg = (-(d * d) / (F32(2) * sigma * sigma)).astype(F32)
+    return np.exp(arg.astype(np.float64)).astype(F32)
 
 
 def min_weight(sigma):
@@ -807,3 +811,170 @@ def dba_solve(cam_model, cam_prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij,
     G.initialize(0)
     n_it = lm_optimize(G, iters, trace, solver)
     return G.pose_q.copy(), G.pose_t.copy(), G.pts.copy(), n_it
+
+
+# ----------------------------------------------------------------------------
+# flat RegularizationGraph helpers (regularization_graph.cc:61-146)
+# ----------------------------------------------------------------------------
+def graph_get_edges(g, p):
+    """GetEdges(p) on the flat graph: list of (other, eid) in reference order."""
+    sl = slice(g["rowptr"][p], g["rowptr"][p + 1])
+    e = g["eid"][sl]
+    pos = get_edges(g["col"][sl], g["e_w"][e], g["e_status"][e], F32(g["min_w"]))
+    return [(int(g["col"][sl][k]), int(e[k])) for k in pos]
+
+
+def graph_update_vertex_flat(g, p, map_pos):
+    """UpdateVertex(p): every edge of p is refreshed from the last world positions
+    (regularization_graph.cc:89-146).  Returns the number of good connections."""
+    sl = slice(g["rowptr"][p], g["rowptr"][p + 1])
+    e = g["eid"][sl]
+    if len(e) == 0:
+        return 0
+    mx, mn, w, st, good = graph_update_vertex(map_pos[p], map_pos[g["col"][sl]], g["e_max"][e], g["e_min"][e],
+                                              g["e_status"][e], g["sigma"], g["stretch_th"])
+    g["e_max"][e], g["e_min"][e], g["e_w"][e], g["e_status"][e] = mx, mn, w, st
+    return good
+
+
+# ----------------------------------------------------------------------------
+# a2: CameraPoseAndDeformationOptimization (g2o_optimization.cc:148-557)
+# ----------------------------------------------------------------------------
+TRACKED_WITH_3D, TRACKED, JUST_TRIANGULATED, BAD = 0, 1, 2, 3
+
+
+def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv, f_pos, pose_q, pose_t,
+                       scale, trace=None, solver=solve_spd):
+    """Flat restatement.  graph / map_pos / f_status / f_pos are copied, the updated copies are
+    returned.  f_map[i] = map-point index of frame landmark i (-1: none)."""
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+    map_pos = np.array(map_pos, F32)
+    f_status = np.array(f_status, np.int32)
+    f_pos = np.array(f_pos, F32)
+    f_map = np.asarray(f_map, np.int64)
+    f_uv = np.asarray(f_uv, F32)
+    n_map = len(map_pos)
+    map_to_frame = -np.ones(n_map, np.int64)
+    map_to_frame[f_map[f_map >= 0]] = np.where(f_map >= 0)[0]
+    opt_f = np.where((f_status == TRACKED_WITH_3D) & (f_map >= 0))[0]       # frame order (frame.cc:83-119)
+    N = len(opt_f)
+    ids = f_map[opt_f]
+    id_to_idx = -np.ones(n_map, np.int64)
+    id_to_idx[ids] = np.arange(N)
+    X0 = f_pos[opt_f].astype(np.float64)
+    q0 = quat_normalize(np.asarray(pose_q, np.float64))
+    t0 = np.asarray(pose_t, np.float64).copy()
+    info_sp = info_spatial(scale)
+
+    # ---- edge construction OPT:224-337
+    reg = [dict() for _ in range(N)]               # spatial_regularizers[idx][idx_other] = edge index
+    dm_i, dm_j, dm_w, sp_d0 = [], [], [], []
+    lost = set()
+    for idx in range(N):
+        n_reg = 0
+        for other, e in graph_get_edges(g, int(ids[idx])):
+            if n_reg > REGULARIZERS_PER_POINT or g["e_status"][e] == GRAPH_BAD:
+                break
+            fo = map_to_frame[other]
+            if fo < 0 or f_status[fo] != TRACKED_WITH_3D:
+                if fo >= 0 and f_status[fo] != JUST_TRIANGULATED:
+                    lost.add(other)
+                continue
+            io = int(id_to_idx[other])
+            if io in reg[idx]:
+                continue
+            k = len(dm_i)
+            dm_i.append(idx); dm_j.append(io); dm_w.append(g["e_w"][e]); sp_d0.append(g["e_d0"][e])
+            reg[idx][io] = k
+            reg[io][idx] = k
+            n_reg += 1
+    E = len(dm_i)
+    G = Graph(cam_model, cam_prm, [q0], [t0], np.zeros((N, 3)))
+    rep = ReprojEdges('deform', f_uv[opt_f], np.zeros(N, np.int64), np.arange(N), X0, float(INFO_REPROJ), TH2)
+    dmp = DamperDeformEdges(dm_i, dm_j, np.asarray(dm_w, F32).astype(np.float64), info_sp, TH3)
+    spr = SpringDeformEdges(dm_i, dm_j, np.asarray(sp_d0, F32).astype(np.float64),
+                            X0[np.asarray(dm_i, np.int64)] if E else np.zeros((0, 3)),
+                            X0[np.asarray(dm_j, np.int64)] if E else np.zeros((0, 3)),
+                            float(INFO_POSITION), TH3)
+    G.groups += [rep, dmp, spr]
+    inl = np.ones(N, bool)
+    for rnd in range(2):                                                   # OPT:338-395
+        G.pose_q[0], G.pose_t[0] = q0.copy(), t0.copy()
+        G.pts[:] = 0
+        if G.initialize(0):
+            tr = None if trace is None else []
+            lm_optimize(G, 10, tr, solver)
+            if trace is not None:
+                trace.append(tr)
+        rep.err[:] = rep.residual(G, np.arange(N))
+        chi = rep.chi2().astype(F32)
+        for idx in range(N):
+            out = bool(chi[idx] > TH2_SQ)
+            inl[idx] = not out
+            rep.level[idx] = 1 if out else 0
+            for io, k in reg[idx].items():
+                dmp.level[k] = 1 if out else 0
+            for io, k in reg[idx].items():
+                dmp.err[k] = dmp.residual(G, np.array([k]))[0]
+                dmp.level[k] = 1 if dmp.chi2()[k] > float(TH3_SQ) else 0
+    pose_q_out, pose_t_out = G.pose_q[0].copy(), G.pose_t[0].copy()
+    # ---- OPT:401-455
+    delta = G.pts[:N].astype(F32)
+    mag = np.sqrt((delta[:, 0] * delta[:, 0] + delta[:, 1] * delta[:, 1] + delta[:, 2] * delta[:, 2]).astype(F32)).astype(F32)
+    srt = np.sort(mag)
+    q1 = srt[int(F32(N) * F32(0.25))]
+    q3 = srt[int(F32(N) * F32(0.75))]
+    th = F32(1.5) * (q3 - q1)
+    rep.err[:] = rep.residual(G, np.arange(N))
+    chi = rep.chi2().astype(F32)
+    for idx in range(N):
+        fi = opt_f[idx]
+        if chi[idx] > TH2_SQ:
+            inl[idx] = False
+            f_status[fi] = TRACKED
+        if mag[idx] >= q3 + th:
+            f_status[fi] = TRACKED
+            continue
+        G.pt_fixed[idx] = True
+        cur = delta[idx] + f_pos[fi]
+        f_pos[fi] = cur
+        map_pos[ids[idx]] = cur
+    median = float(np.partition(mag.copy(), N // 2)[N // 2])
+    # ---- graph update OPT:457-474
+    for idx in range(N):
+        if not inl[idx]:
+            continue
+        good = graph_update_vertex_flat(g, int(ids[idx]), map_pos)
+        if good < REGULARIZERS_PER_POINT * 0.5:
+            f_status[opt_f[idx]] = BAD
+    res = dict(pose_q=pose_q_out, pose_t=pose_t_out, f_pos=f_pos, f_status=f_status, map_pos=map_pos, graph=g,
+               median=median, inliers=inl, delta=G.pts[:N].copy(), lost=[], n_edges=E)
+    if not lost:
+        return res
+    # ---- stage 2 OPT:476-553
+    lost_sorted = sorted(lost)
+    L = len(lost_sorted)
+    G.pts = np.vstack([G.pts, np.zeros((L, 3))])
+    G.M = N + L
+    G.pt_fixed = np.concatenate([G.pt_fixed, np.zeros(L, bool)])
+    ui, uj, uw = [], [], []
+    for li, lid in enumerate(lost_sorted):
+        n_reg = 0
+        for other, e in graph_get_edges(g, lid):
+            if n_reg > 10:
+                break
+            if id_to_idx[other] < 0:
+                continue
+            ui.append(N + li); uj.append(int(id_to_idx[other])); uw.append(g["e_w"][e])
+            n_reg += 1
+    G.groups.append(DamperFixedEdges(ui, uj, np.asarray(uw, F32).astype(np.float64), info_sp, TH3))
+    G.pose_fixed[0] = True
+    if G.initialize(0):
+        tr = None if trace is None else []
+        lm_optimize(G, 10, tr, solver)
+        if trace is not None:
+            trace.append(tr)
+    for li, lid in enumerate(lost_sorted):
+        map_pos[lid] = G.pts[N + li].astype(F32) + map_pos[lid]
+    res.update(lost=lost_sorted, lost_delta=G.pts[N:].copy(), delta_final=G.pts[:N].copy(), map_pos=map_pos)
+    return res

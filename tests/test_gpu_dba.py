@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def _setup(n, k, seed, model=S.PINHOLE):
     p = S.make_dba_problem(n, k, seed, model)
-    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     return p, e, cam, qt
@@ -107,7 +107,7 @@ def test_full_size_c2_properties(ctx):
     in seconds at this size, so check size-independent properties: chi2 strictly decreases over
     accepted trials, every inner solve converges, and the resident path is reproducible."""
     p = S.make_dba_problem("C2")
-    e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])

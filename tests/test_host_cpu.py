@@ -38,7 +38,7 @@ def test_no_cpu_fallback(lib_built):
 def test_edge_builder_matches_oracle(lib_built, n, k, seed, bad):
     nrs = lib_built
     p = S.make_dba_problem(n, k, seed, dropout=0.15)
-    g = dict(p["graph"])
+    g = dict(p["nbr"])
     st = g["status"].copy()
     rng = np.random.default_rng(seed)
     st[rng.uniform(size=len(st)) < bad] = S.GRAPH_BAD
@@ -55,7 +55,7 @@ def test_edge_builder_matches_oracle(lib_built, n, k, seed, bad):
 def test_edge_builder_rejects_bad_input(lib_built):
     nrs = lib_built
     p = S.make_dba_problem(60, 2, 5)
-    g = dict(p["graph"])
+    g = dict(p["nbr"])
     g["col"] = g["col"].copy()
     g["col"][0] = 10 ** 6
     with pytest.raises(nrs.NrsError):
@@ -66,22 +66,28 @@ def test_graph_wire_format():
     """The synthetic graph is in the ordered form GetEdges returns (regularization_graph.cc:61-87):
     symmetric, rows sorted by weight descending, cut at min_weight, no float ties."""
     sc = S.make_scene(800, 2, 9)
-    g = sc["graph"]
+    G = sc["graph"]
+    g = S.ordered_view(G)
     rp, col, w = g["rowptr"], g["col"], g["w"]
-    assert abs(g["min_w"] - float(O.min_weight(g["sigma"]))) < 1e-7
+    assert abs(G["min_w"] - float(O.min_weight(G["sigma"]))) < 1e-7
     pairs = set()
     for i in range(len(rp) - 1):
         ww = w[rp[i]:rp[i + 1]]
         assert np.all(np.diff(ww) < 0), "ties or wrong order in row %d" % i
-        assert np.all(ww >= g["min_w"])
+        assert np.all(ww >= G["min_w"])
         for c in col[rp[i]:rp[i + 1]]:
             pairs.add((i, int(c)))
     assert all((b, a) in pairs for a, b in pairs)
     # weights are the reference's fp32 InterpolationWeight of the rest distance
-    assert np.array_equal(w, O.interpolation_weight(g["d0"], g["sigma"]))
-    # get_edges on an unordered copy of a row reproduces the stored order
-    i = 17
-    sl = slice(rp[i], rp[i + 1])
-    perm = np.argsort(col[sl])
-    pos = O.get_edges(col[sl][perm], w[sl][perm], g["status"][sl][perm], g["min_w"])
-    assert np.array_equal(col[sl][perm][pos], col[sl])
+    assert np.array_equal(G["e_w"], O.interpolation_weight(G["e_d0"], G["sigma"]))
+    # the oracle's GetEdges on the raw (index-ordered) row reproduces the ordered row, also after
+    # some edges went BAD / lost weight
+    rng = np.random.default_rng(3)
+    G["e_status"][rng.uniform(size=len(G["e_status"])) < 0.2] = S.GRAPH_BAD
+    G["e_w"][rng.uniform(size=len(G["e_w"])) < 0.2] *= np.float32(0.4)
+    G.update(S.ordered_neighbours(G))
+    for i in (0, 17, 399, 799):
+        sl = slice(G["rowptr"][i], G["rowptr"][i + 1])
+        e = G["eid"][sl]
+        pos = O.get_edges(G["col"][sl], G["e_w"][e], G["e_status"][e], G["min_w"])
+        assert np.array_equal(G["col"][sl][pos], G["o_col"][G["o_rowptr"][i]:G["o_rowptr"][i + 1]])

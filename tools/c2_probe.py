@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd/py"))
 import numpy as np, nrs, nrs_synth as S
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"
 p = S.make_dba_problem(name)
-e = nrs.dba_build_edges(p["kf_points"], p["graph"])
+e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
 cam = nrs.make_camera(p["model"], p["prm"])
 qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
 ctx = nrs.Context()
