@@ -192,6 +192,45 @@ int nrs_track_deform_solve(nrs_ctx* ctx, const nrs_camera* cam, nrs_graph* g, fl
                            float* f_pos, double pose_qt[7], float scale, float* deform_median,
                            int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
 
+/* ---- a21-a23: LucasKanadeTracker (modules/matching/lucas_kanade_tracker.{h,cc}) ----------------
+ * The context holds what the reference's tracker object holds: the reference points and, per point
+ * and pyramid level, the cached 21x21 template (intensity x32 as int16, Scharr derivative as
+ * 2 x int16, the two window means, a "filled" flag) -- members Iref_/Idref_/vMeanI_/vMeanI2_/prevPts_
+ * (lucas_kanade_tracker.h:76-91).  Images are 8-bit single channel, row stride in bytes.
+ * The pyramid is built on the device the way cv::buildOpticalFlowPyramid(img, pyr, Size(21,21),
+ * maxLevel) builds it (LK:50,184; DESIGN.md "pyramid"). */
+typedef struct {
+    int32_t win_size;            /* 21 (the only size the reference uses, SLAM/system.cc:78)        */
+    int32_t max_level;           /* 4                                                              */
+    int32_t max_iters;           /* 10                                                             */
+    float epsilon;               /* 1e-4, on |delta|^2                                             */
+    float min_eig_threshold;     /* 1e-4                                                           */
+} nrs_klt_config;
+
+int nrs_klt_configure(nrs_ctx* ctx, const nrs_klt_config* cfg);     /* defaults = the values above */
+int nrs_klt_clear(nrs_ctx* ctx);                                    /* LucasKanadeTracker::clear   */
+int nrs_klt_num_points(nrs_ctx* ctx);
+
+/* LucasKanadeTracker::SetReferenceImage (LK:47-168).  mask: NULL or w x h bytes, 0 = masked. */
+int nrs_klt_set_reference(nrs_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                          const uint8_t* mask, int32_t n, const float* xy);
+
+/* LucasKanadeTracker::Track (LK:170-596).  xy in: initial guess (used when use_initial_flow),
+ * out: tracked positions; status in/out: LandmarkStatus, only usable points are tracked and they
+ * may become OUT_IMAGE_BOUNDARIES / BAD_FEATURE / BAD; n_good = points that pass the SSIM gate;
+ * ssim (may be NULL): SSIM of every point that reached the gate. */
+int nrs_klt_track(nrs_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t n,
+                  float* xy, int32_t* status, int32_t use_initial_flow, float min_ssim, int32_t* n_good,
+                  float* ssim);
+
+/* GetPhotometricInformationOfPoint / InsertPhotometricInformation (LK:598-620).  Buffers hold
+ * (max_level+1) levels: gray (levels x 441), grad (levels x 441 x 2), mean (levels x 2: meanI,
+ * meanI2), valid (levels). */
+int nrs_klt_get_template(nrs_ctx* ctx, int32_t idx, float xy[2], int16_t* gray, int16_t* grad,
+                         float* mean, uint8_t* valid);
+int nrs_klt_insert_template(nrs_ctx* ctx, const float xy[2], const int16_t* gray, const int16_t* grad,
+                            const float* mean, const uint8_t* valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ struct DevBuf {
 };
 
 struct Engine;       // nrs_engine.hip
+struct KltState;     // nrs_klt.hip
 struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 
 }  // namespace nrs
@@ -34,7 +35,7 @@ struct nrs_ctx {
     // resident BA problem (a3) and per-call tracking problems (a2): one reusable arena each
     nrs::Engine* dba = nullptr;
     nrs::Arena arena_dba, arena_trk;
-    std::vector<int32_t> dba_lm_kf;
+    nrs::KltState* klt = nullptr;
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;
@@ -77,4 +78,5 @@ struct nrs_ctx {
 
 namespace nrs {
 void dba_free(nrs_ctx* ctx);
+void klt_free(nrs_ctx* ctx);
 }

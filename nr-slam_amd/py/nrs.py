@@ -20,7 +20,9 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
            "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient",
-           "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve"]
+           "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
+           "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
+           "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template"]
 
 
 class NrsError(RuntimeError):
@@ -55,6 +57,11 @@ class Graph(C.Structure):
                 ("eid", C.POINTER(C.c_int32)), ("n_edges", C.c_int32), ("e_w", C.POINTER(C.c_float)),
                 ("e_d0", C.POINTER(C.c_float)), ("e_max", C.POINTER(C.c_float)), ("e_min", C.POINTER(C.c_float)),
                 ("e_status", C.POINTER(C.c_int32)), ("sigma", C.c_float), ("stretch_th", C.c_float)]
+
+
+class KltConfig(C.Structure):
+    _fields_ = [("win_size", C.c_int32), ("max_level", C.c_int32), ("max_iters", C.c_int32),
+                ("epsilon", C.c_float), ("min_eig_threshold", C.c_float)]
 
 
 class Profile(C.Structure):
@@ -242,6 +249,51 @@ class Context:
             C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     graph=ga.as_dict(g), median=float(med.value), lost=lost[:n_lost.value].tolist())
+
+    # ---- a21-a23
+    def klt_configure(self, win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4):
+        cfg = KltConfig(win, max_level, max_iters, epsilon, min_eig)
+        self._klt_levels = max_level + 1
+        self._chk(self.lib.nrs_klt_configure(self.h, C.byref(cfg)))
+
+    def klt_clear(self):
+        self._chk(self.lib.nrs_klt_clear(self.h))
+
+    def klt_num_points(self):
+        return self.lib.nrs_klt_num_points(self.h)
+
+    def klt_set_reference(self, img, xy, mask=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        xy = _f32(xy).reshape(-1, 2)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._chk(self.lib.nrs_klt_set_reference(self.h, _p(img, C.c_uint8), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]),
+                                                 C.c_int32(img.strides[0]), _p(m, C.c_uint8), C.c_int32(len(xy)), _p(xy, C.c_float)))
+
+    def klt_track(self, img, xy, status, initial_flow=True, min_ssim=0.7):
+        img = np.ascontiguousarray(img, np.uint8)
+        xy = _f32(xy).reshape(-1, 2).copy()
+        st = _i32(status).copy()
+        good = C.c_int32(0)
+        ssim = np.full(len(xy), np.nan, np.float32)
+        self._chk(self.lib.nrs_klt_track(self.h, _p(img, C.c_uint8), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]),
+                                         C.c_int32(img.strides[0]), C.c_int32(len(xy)), _p(xy, C.c_float), _p(st, C.c_int32),
+                                         C.c_int32(1 if initial_flow else 0), C.c_float(min_ssim), C.byref(good), _p(ssim, C.c_float)))
+        return xy, st, good.value, ssim
+
+    def klt_get_template(self, idx):
+        L = getattr(self, "_klt_levels", 5)
+        xy = np.zeros(2, np.float32)
+        gray, grad = np.zeros((L, 21, 21), np.int16), np.zeros((L, 21, 21, 2), np.int16)
+        mean, valid = np.zeros((L, 2), np.float32), np.zeros(L, np.uint8)
+        self._chk(self.lib.nrs_klt_get_template(self.h, C.c_int32(idx), _p(xy, C.c_float), _p(gray, C.c_int16),
+                                                _p(grad, C.c_int16), _p(mean, C.c_float), _p(valid, C.c_uint8)))
+        return dict(xy=xy, gray=gray, grad=grad, mean=mean, valid=valid)
+
+    def klt_insert_template(self, t):
+        xy, gray, grad = _f32(t["xy"]), np.ascontiguousarray(t["gray"], np.int16), np.ascontiguousarray(t["grad"], np.int16)
+        mean, valid = _f32(t["mean"]), np.ascontiguousarray(t["valid"], np.uint8)
+        self._chk(self.lib.nrs_klt_insert_template(self.h, _p(xy, C.c_float), _p(gray, C.c_int16), _p(grad, C.c_int16),
+                                                   _p(mean, C.c_float), _p(valid, C.c_uint8)))
 
     # ---- a3
     def _dba_args(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):

@@ -285,3 +285,58 @@ def make_tracking_problem(n_points, seed, model=PINHOLE, frame=3, lost_frac=0.03
                 status=status, uv=uv_full, X_prev=prev.astype(F32),
                 pose_q=_R_to_quat(R).astype(F32).astype(np.float64),
                 pose_t=t.astype(F32).astype(np.float64), graph=sc["graph"], scene=sc)
+
+
+def make_lk_sequence(n_points=500, seed=5, wh=(640, 480), flow_px=6.0):
+    """Synthetic LK pair (SURVEY.md 8d "LK"): band-limited noise texture, second frame = smooth warp
+    (<= flow_px) with gain 0.8-1.2 and bias +-10; points at high-gradient locations."""
+    rng = np.random.default_rng(seed)
+    w, h = wh
+    tex = np.zeros((h + 64, w + 64), np.float64)
+    for sc, amp in ((4, 28.0), (8, 36.0), (16, 30.0), (32, 22.0)):
+        gh, gw = (h + 64) // sc + 3, (w + 64) // sc + 3
+        g = rng.normal(0, 1, (gh, gw))
+        yy = np.arange(h + 64) / sc
+        xx = np.arange(w + 64) / sc
+        y0, x0 = np.floor(yy).astype(int), np.floor(xx).astype(int)
+        fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+        fy, fx = fy * fy * (3 - 2 * fy), fx * fx * (3 - 2 * fx)
+        tex += amp * ((g[np.ix_(y0, x0)] * (1 - fx) + g[np.ix_(y0, x0 + 1)] * fx) * (1 - fy)
+                      + (g[np.ix_(y0 + 1, x0)] * (1 - fx) + g[np.ix_(y0 + 1, x0 + 1)] * fx) * fy)
+    tex = 120 + tex
+
+    def render(flow_fn, gain, bias):
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+        dx, dy = flow_fn(xs, ys)
+        sx, sy = xs - dx + 32, ys - dy + 32                 # backward warp
+        x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+        fx, fy = sx - x0, sy - y0
+        x0 = np.clip(x0, 0, w + 62)
+        y0 = np.clip(y0, 0, h + 62)
+        v = (tex[y0, x0] * (1 - fx) + tex[y0, x0 + 1] * fx) * (1 - fy) + (tex[y0 + 1, x0] * (1 - fx) + tex[y0 + 1, x0 + 1] * fx) * fy
+        return np.clip(np.rint(gain * v + bias), 0, 255).astype(np.uint8)
+
+    zero = lambda xs, ys: (np.zeros_like(xs), np.zeros_like(ys))
+    ax, ay = rng.uniform(0.5, 1.0) * flow_px, rng.uniform(0.5, 1.0) * flow_px
+    flow = lambda xs, ys: (ax * np.sin(xs / 90.0 + 0.3) * np.cos(ys / 70.0), ay * np.cos(xs / 80.0) * np.sin(ys / 60.0 + 0.5))
+    im0 = render(zero, 1.0, 0.0)
+    im1 = render(flow, rng.uniform(0.8, 1.2), rng.uniform(-10, 10))
+    # corners: strongest gradient-energy responses on a coarse grid, away from the border
+    g = im0.astype(np.float64)
+    gx = np.zeros_like(g); gy = np.zeros_like(g)
+    gx[:, 1:-1] = g[:, 2:] - g[:, :-2]
+    gy[1:-1, :] = g[2:, :] - g[:-2, :]
+    e = gx * gx + gy * gy
+    pts = []
+    cell = max(8, int(np.sqrt(w * h / max(1, n_points)) * 0.9))
+    for y in range(30, h - 30 - cell, cell):
+        for x in range(30, w - 30 - cell, cell):
+            blk = e[y:y + cell, x:x + cell]
+            k = np.unravel_index(np.argmax(blk), blk.shape)
+            pts.append((x + k[1] + rng.uniform(-0.4, 0.4), y + k[0] + rng.uniform(-0.4, 0.4)))
+    pts = np.array(pts, F32)
+    if len(pts) > n_points:
+        pts = pts[rng.choice(len(pts), n_points, replace=False)]
+    fx, fy = flow(pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64))
+    truth = pts + np.stack([fx, fy], 1).astype(F32)
+    return dict(im0=im0, im1=im1, pts=pts, truth=truth)

@@ -1,0 +1,120 @@
+"""GPU parity: a21-a23 LucasKanadeTracker (reference modules/matching/lucas_kanade_tracker.cc) through
+the C ABI against the oracle (oracle/lk_oracle.py), given this build's own restatement of the
+OpenCV pyramid (parity unpinned at the pyramid boundary).
+
+Bars: templates (int16 windows), status codes and n_good: exact; means and tracked positions:
+exact as well (same fixed-point sampling, same sequential float32 sums, no FMA contraction) -- the
+tests allow 1e-3 px / 1e-6 relative as the stated tolerance but assert bit-equality where it holds."""
+import numpy as np
+import pytest
+
+import lk_oracle as LK
+import nrs
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, n, seed, **kw):
+    sq = S.make_lk_sequence(n, seed, **kw)
+    ctx.klt_configure()
+    ctx.klt_set_reference(sq["im0"], sq["pts"])
+    lk = LK.LucasKanadeOracle()
+    lk.set_reference(sq["im0"], sq["pts"])
+    return sq, lk
+
+
+def test_templates_match_oracle(ctx):
+    sq, lk = _setup(ctx, 60, 3)
+    assert ctx.klt_num_points() == len(sq["pts"])
+    for i in (0, 7, len(sq["pts"]) - 1):
+        t = ctx.klt_get_template(i)
+        for level in range(5):
+            assert bool(t["valid"][level]) == (lk.Iref[level][i] is not None)
+            if lk.Iref[level][i] is not None:
+                assert np.array_equal(t["gray"][level], lk.Iref[level][i])           # pyramid + sampling: bit-exact
+                assert np.array_equal(t["grad"][level], lk.Idref[level][i])
+                assert t["mean"][level, 0] == lk.meanI[level][i] and t["mean"][level, 1] == lk.meanI2[level][i]
+            else:
+                assert t["mean"][level, 0] == -1 and t["mean"][level, 1] == -1
+
+
+@pytest.mark.parametrize("n,seed,flow", [(80, 5, 6.0), (150, 6, 3.0), (150, 7, 12.0)])
+def test_track_matches_oracle(ctx, n, seed, flow):
+    sq, lk = _setup(ctx, n, seed, flow_px=flow)
+    st = np.zeros(len(sq["pts"]), np.int32)
+    st[::17] = 3                                        # BAD points are skipped and left untouched
+    guess = sq["pts"] + np.float32(0.7)
+    xy, st2, good, ssim = ctx.klt_track(sq["im1"], guess, st)
+    oxy, ost, ogood, ossim = lk.track(sq["im1"], guess.copy(), st)
+    assert np.array_equal(st2, ost)                     # status codes: exact
+    assert good == ogood
+    ok = np.isin(ost, (0, 1, 2))
+    assert np.allclose(xy[ok], oxy[ok], atol=1e-3, rtol=0)
+    assert np.array_equal(xy, oxy)                      # and in fact bit-identical
+    assert np.allclose(ssim[ok], ossim[ok], atol=1e-5)
+    assert np.array_equal(xy[st == 3], guess[st == 3])
+    # sanity: the tracker found the synthetic flow
+    err = np.linalg.norm(xy[ost == 0] - sq["truth"][ost == 0], axis=1)
+    assert np.median(err) < 0.5
+
+
+def test_track_without_initial_flow_and_failures(ctx):
+    sq, lk = _setup(ctx, 120, 9, flow_px=25.0)          # large flow: drift cap / SSIM failures appear
+    st = np.zeros(len(sq["pts"]), np.int32)
+    xy, st2, good, _ = ctx.klt_track(sq["im1"], sq["pts"], st, initial_flow=False, min_ssim=0.9)
+    oxy, ost, ogood, _ = lk.track(sq["im1"], sq["pts"].copy(), st, initial_flow=False, min_ssim=0.9)
+    assert np.array_equal(st2, ost) and good == ogood
+    assert np.array_equal(xy, oxy)
+    assert len(set(ost.tolist())) > 1                   # more than one status code is exercised
+
+
+def test_border_points_and_mask(ctx):
+    sq = S.make_lk_sequence(40, 11)
+    h, w = sq["im0"].shape
+    pts = np.concatenate([sq["pts"], np.array([[2.0, 3.0], [w - 3.0, h - 2.0], [w + 40.0, 10.0], [15.5, 15.5]], np.float32)])
+    mask = np.full((h, w), 255, np.uint8)
+    mask[200:260, 300:380] = 0
+    ctx.klt_configure()
+    ctx.klt_set_reference(sq["im0"], pts, mask)
+    lk = LK.LucasKanadeOracle()
+    lk.set_reference(sq["im0"], pts, mask)
+    for i in range(len(pts)):
+        t = ctx.klt_get_template(i)
+        assert [bool(v) for v in t["valid"]] == [lk.Iref[l][i] is not None for l in range(5)], i
+    st = np.zeros(len(pts), np.int32)
+    xy, st2, good, _ = ctx.klt_track(sq["im1"], pts, st)
+    oxy, ost, ogood, _ = lk.track(sq["im1"], pts.copy(), st)
+    assert np.array_equal(st2, ost) and good == ogood
+    assert (ost == 4).sum() >= 2                        # OUT_IMAGE_BOUNDARIES
+
+
+def test_photometric_round_trip_and_clear(ctx):
+    sq, lk = _setup(ctx, 30, 13)
+    t = ctx.klt_get_template(4)
+    n0 = ctx.klt_num_points()
+    ctx.klt_insert_template(t)                          # PointReuse re-inserts stored templates (tracking.cc:473-503)
+    assert ctx.klt_num_points() == n0 + 1
+    t2 = ctx.klt_get_template(n0)
+    for k in ("xy", "gray", "grad", "mean", "valid"):
+        assert np.array_equal(t[k], t2[k])
+    pts = np.concatenate([sq["pts"], sq["pts"][4:5]])
+    xy, st, good, _ = ctx.klt_track(sq["im1"], pts, np.zeros(n0 + 1, np.int32))
+    assert np.array_equal(xy[4], xy[n0]) and st[4] == st[n0]
+    ctx.klt_clear()
+    assert ctx.klt_num_points() == 0
+    with pytest.raises(nrs.NrsError):
+        ctx.klt_track(sq["im1"], pts, np.zeros(n0 + 1, np.int32))
+
+
+def test_full_size_properties(ctx):
+    """5k points on 640x480 (the size of BASELINE configs): tracking a frame against itself is the
+    identity (size-independent property), and every point keeps its status."""
+    sq = S.make_lk_sequence(5000, 21)
+    ctx.klt_configure()
+    ctx.klt_set_reference(sq["im0"], sq["pts"])
+    st = np.zeros(len(sq["pts"]), np.int32)
+    xy, st2, good, ssim = ctx.klt_track(sq["im0"], sq["pts"], st)
+    assert good == len(sq["pts"]) and np.all(st2 == 0)
+    assert np.max(np.abs(xy - sq["pts"])) < 0.05
+    assert np.nanmin(ssim) > 0.99
