@@ -68,6 +68,10 @@ struct Dev {
     int* ss_ptr; int ss_nnz; int* sd_ptr; int sd_nnz;
     int* s_other; float* s_d0; int* s_meta;
     int* d_o0; int* d_o1; int* d_o2; float* d_w; int* d_meta;
+    // LDS staging: neighbour ids above are LOCAL to the workgroup's tile: [0, tile_rows) = own rows,
+    // tile_rows + i = halo_rows[halo_ptr[b] + i]
+    int use_lds, tile_rows, max_halo;
+    int* halo_ptr; int* halo_rows;
     // state (two copies: current / trial, swapped on accept)
     Pose* pose[2]; double* xl[2];
     Pose* pose_init; double* xl_init;
@@ -159,6 +163,21 @@ __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double la
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (a * g - c * c) * id; o[4] = (b * c - a * f) * id; o[5] = (a * e - b * b) * id;
     return det > 0;
+}
+
+// stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0)
+__device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __restrict__ v, const double* __restrict__ add,
+                                  double* lds) {
+    const int row0 = b * P.tile_rows;
+    for (int i = tid; i < 3 * P.tile_rows; i += BLK) lds[i] = v[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    for (int i = tid; i < hn; i += BLK) {
+        const size_t r = (size_t)P.halo_rows[hb + i];
+        double* d = lds + 3 * (size_t)(P.tile_rows + i);
+        d[0] = v[3 * r] + (add ? add[3 * r] : 0.0);
+        d[1] = v[3 * r + 1] + (add ? add[3 * r + 1] : 0.0);
+        d[2] = v[3 * r + 2] + (add ? add[3 * r + 2] : 0.0);
+    }
 }
 
 __device__ inline double damper_sign(int role) { return (role == 0 || role == 3) ? -1.0 : 1.0; }
@@ -269,9 +288,10 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
 //   (spatial_regularizer_with_deformation.cc:36-49), SpatialRegularizerFixed
 //   (spatial_regularizer_fixed.cc:32-43).
 // =====================================================================================
-template <int T, bool LIN>
-__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl) {
+template <int T, bool LIN, bool LDS>
+__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g) {
     __shared__ double lds[4 * 2];
+    extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
     if (b >= P.n_regblk) return;
@@ -280,9 +300,29 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
-    const double xo0 = xl[3 * row], xo1 = xl[3 * row + 1], xo2 = xl[3 * row + 2];
+    // xl: estimates (dampers act on them), xp: X0 + estimates (springs); with LDS staging both are
+    // tile-local arrays indexed by the local neighbour ids
+    const double* xl = xl_g;
+    const double* xp = nullptr;
+    int self = row;
+    if (LDS) {
+        double* lx = dyn;
+        stage_rows(P, b, tid, xl_g, nullptr, lx);
+        xl = lx;
+        if (P.X0) {
+            double* lp = dyn + 3 * (size_t)(P.tile_rows + P.max_halo);
+            stage_rows(P, b, tid, xl_g, P.X0, lp);
+            xp = lp;
+        }
+        __syncthreads();
+        self = row - b * P.tile_rows;
+    }
+    const double xo0 = xl[3 * self], xo1 = xl[3 * self + 1], xo2 = xl[3 * self + 2];
     double xs0 = xo0, xs1 = xo1, xs2 = xo2;                 // spring position = X0 + x
-    if (P.X0) { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
+    if (P.X0) {
+        if (LDS) { xs0 = xp[3 * self]; xs1 = xp[3 * self + 1]; xs2 = xp[3 * self + 2]; }
+        else { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
+    }
     double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
     // ---- springs
     {
@@ -297,8 +337,12 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                 continue;
             }
             const double d0 = (double)P.s_d0[idx];
-            double y0 = xl[3 * o], y1 = xl[3 * o + 1], y2 = xl[3 * o + 2];
-            if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
+            double y0, y1, y2;
+            if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
+            else {
+                y0 = xl[3 * o]; y1 = xl[3 * o + 1]; y2 = xl[3 * o + 2];
+                if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
+            }
             const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
             const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
             const double r = P.k_spring * (d - d0) / d0;
@@ -507,9 +551,10 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
 // plus the per-block partials the update kernel needs:
 //   [0] r.u  [1] w.u  [2] u_l.(H_pl^T u_p)  [3..8] H_pl u_l (pose rows)
 // =====================================================================================
-template <int T>
+template <int T, bool LDS>
 __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     __shared__ double lds[4 * 9];
+    extern __shared__ double dyn[];
     if (P.flags[0]) return;
     constexpr int R = 64 / T;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
@@ -519,12 +564,19 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
-    const double* __restrict__ u = P.uv3;
+    const double* u = P.uv3;
+    int self = row;
+    if (LDS) {
+        stage_rows(P, b, tid, P.uv3, nullptr, dyn);
+        __syncthreads();
+        u = dyn;
+        self = row - b * P.tile_rows;
+    }
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double ul0 = 0, ul1 = 0, ul2 = 0;
     if (t == 0) {
-        ul0 = u[3 * row]; ul1 = u[3 * row + 1]; ul2 = u[3 * row + 2];
+        ul0 = u[3 * self]; ul1 = u[3 * self + 1]; ul2 = u[3 * self + 2];
         const int kf = P.grp_pose[row / ROW_ALIGN];
         const double* D = P.D + 6 * (size_t)row;
         a0 = (D[0] + lam) * ul0 + D[1] * ul1 + D[2] * ul2;
@@ -833,7 +885,7 @@ struct ArenaPlan {                   // two passes: size, then carve
     }
 };
 
-static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, Engine* e) {
+static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, size_t n_halo, Engine* e) {
     const size_t nr = (size_t)d.n_rows, K = (size_t)d.K;
     d.grp_pose = A.get<int>(d.n_groups);
     d.pose_grp_ptr = A.get<int>(K + 1);
@@ -844,6 +896,8 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.X0 = has_X0 ? X0 : nullptr;
     d.ss_ptr = A.get<int>(n_slices + 1);
     d.sd_ptr = A.get<int>(n_slices + 1);
+    d.halo_ptr = A.get<int>((size_t)d.n_regblk + 1);
+    d.halo_rows = A.get<int>(n_halo);
     d.s_other = A.get<int>(nnz_s); d.s_d0 = A.get<float>(nnz_s); d.s_meta = A.get<int>(nnz_s);
     d.d_o0 = A.get<int>(nnz_d); d.d_o1 = A.get<int>(nnz_d); d.d_o2 = A.get<int>(nnz_d);
     d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(nnz_d);
@@ -1043,13 +1097,69 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::copy(dpos.begin() + dm_slots, dpos.end(), e->un_pos.begin());
     d.ss_nnz = (int)ss.size();
     d.sd_nnz = (int)sd.size();
+    // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
+    // outside the tile; neighbour ids become tile-local
+    d.tile_rows = BLK / T;
+    std::vector<int> halo_ptr(d.n_regblk + 1, 0), halo_rows;
+    {
+        const int Rw = 64 / T;
+        std::vector<int> ext;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int row0 = b * d.tile_rows, row1 = row0 + d.tile_rows;
+            ext.clear();
+            auto visit = [&](std::vector<Inc>& arr, const std::vector<int>& ptr, int nother, bool collect) {
+                for (int sl = b * 4; sl < b * 4 + 4; ++sl)
+                    for (int p = ptr[sl]; p < ptr[sl + 1]; ++p) {
+                        Inc& in = arr[p];
+                        if (in.meta < 0 && in.slot < 0) continue;
+                        for (int k = 0; k < nother; ++k) {
+                            const int o = in.other[k];
+                            if (o < 0) continue;
+                            if (collect) { if (o < row0 || o >= row1) ext.push_back(o); }
+                            else if (o >= row0 && o < row1) in.other[k] = o - row0;
+                            else in.other[k] = d.tile_rows + (int)(std::lower_bound(ext.begin(), ext.end(), o) - ext.begin());
+                        }
+                    }
+            };
+            visit(ss, ss_ptr, 1, true);
+            visit(sd, sd_ptr, 3, true);
+            std::sort(ext.begin(), ext.end());
+            ext.erase(std::unique(ext.begin(), ext.end()), ext.end());
+            visit(ss, ss_ptr, 1, false);
+            visit(sd, sd_ptr, 3, false);
+            halo_rows.insert(halo_rows.end(), ext.begin(), ext.end());
+            halo_ptr[b + 1] = (int)halo_rows.size();
+            d.max_halo = std::max(d.max_halo, (int)ext.size());
+        }
+        (void)Rw;
+    }
+    d.use_lds = 1;
+    const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
+    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024) {
+        // irregular graph (or A/B switch): fall back to global gathers with global row ids
+        d.use_lds = 0;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int row0 = b * d.tile_rows;
+            auto undo = [&](std::vector<Inc>& arr, const std::vector<int>& ptr, int nother) {
+                for (int sl = b * 4; sl < b * 4 + 4; ++sl)
+                    for (int p = ptr[sl]; p < ptr[sl + 1]; ++p)
+                        for (int k = 0; k < nother; ++k) {
+                            int& o = arr[p].other[k];
+                            if (o < 0) continue;
+                            o = o < d.tile_rows ? row0 + o : halo_rows[halo_ptr[b] + (o - d.tile_rows)];
+                        }
+            };
+            undo(ss, ss_ptr, 1);
+            undo(sd, sd_ptr, 3);
+        }
+    }
 
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
     {
         Dev tmp = d;
         Engine te;
-        carve(dry, tmp, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, &te);
+        carve(dry, tmp, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, halo_rows.size(), &te);
     }
     if (dry.off > arena->cap) {
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -1060,7 +1170,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         arena->cap = want;
     }
     ArenaPlan real{arena, false};
-    carve(real, d, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, e);
+    carve(real, d, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, halo_rows.size(), e);
 
     // ---- host mirrors + uploads
     e->sp_ij.assign(s.sp_ij, s.sp_ij + 2 * (size_t)s.n_sp);
@@ -1100,6 +1210,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.pose_init, poses));
     NRS_TRY(h2d(c, d.ss_ptr, ss_ptr));
     NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
+    NRS_TRY(h2d(c, d.halo_ptr, halo_ptr));
+    NRS_TRY(h2d(c, d.halo_rows, halo_rows));
     NRS_TRY(h2d(c, d.s_other, s_other));
     NRS_TRY(h2d(c, d.s_d0, s_d0));
     NRS_TRY(h2d(c, d.d_o0, d_o0));
@@ -1170,27 +1282,41 @@ struct Timer {                       // HIP-event timing of one launch when prof
     }
 };
 
-template <bool LIN>
-static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
+template <bool LIN, bool LDS>
+static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
-        case 1: hipLaunchKernelGGL((k_reg<1, LIN>), g, b, 0, c->stream, d, xl); break;
-        case 4: hipLaunchKernelGGL((k_reg<4, LIN>), g, b, 0, c->stream, d, xl); break;
-        case 8: hipLaunchKernelGGL((k_reg<8, LIN>), g, b, 0, c->stream, d, xl); break;
-        case 16: hipLaunchKernelGGL((k_reg<16, LIN>), g, b, 0, c->stream, d, xl); break;
-        default: hipLaunchKernelGGL((k_reg<2, LIN>), g, b, 0, c->stream, d, xl); break;
+        case 1: hipLaunchKernelGGL((k_reg<1, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+        case 4: hipLaunchKernelGGL((k_reg<4, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+        case 8: hipLaunchKernelGGL((k_reg<8, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+        case 16: hipLaunchKernelGGL((k_reg<16, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+        default: hipLaunchKernelGGL((k_reg<2, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+    }
+}
+
+template <bool LIN>
+static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
+    const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (d.X0 ? 2 : 1);
+    if (d.use_lds) launch_reg2<LIN, true>(c, d, xl, shm);
+    else launch_reg2<LIN, false>(c, d, xl, 0);
+}
+
+template <bool LDS>
+static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm) {
+    const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
+    switch (d.T) {
+        case 1: hipLaunchKernelGGL((k_spmv<1, LDS>), g, b, shm, c->stream, d, lam); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4, LDS>), g, b, shm, c->stream, d, lam); break;
+        case 8: hipLaunchKernelGGL((k_spmv<8, LDS>), g, b, shm, c->stream, d, lam); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, LDS>), g, b, shm, c->stream, d, lam); break;
+        default: hipLaunchKernelGGL((k_spmv<2, LDS>), g, b, shm, c->stream, d, lam); break;
     }
 }
 
 static void launch_spmv(nrs_ctx* c, const Dev& d, double lam) {
-    const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
-    switch (d.T) {
-        case 1: hipLaunchKernelGGL((k_spmv<1>), g, b, 0, c->stream, d, lam); break;
-        case 4: hipLaunchKernelGGL((k_spmv<4>), g, b, 0, c->stream, d, lam); break;
-        case 8: hipLaunchKernelGGL((k_spmv<8>), g, b, 0, c->stream, d, lam); break;
-        case 16: hipLaunchKernelGGL((k_spmv<16>), g, b, 0, c->stream, d, lam); break;
-        default: hipLaunchKernelGGL((k_spmv<2>), g, b, 0, c->stream, d, lam); break;
-    }
+    const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
+    if (d.use_lds) launch_spmv2<true>(c, d, lam, shm);
+    else launch_spmv2<false>(c, d, lam, 0);
 }
 
 // errors (+ linearisation) at a given state; leaves chi2 (and max diag) in scal[]
