@@ -74,6 +74,51 @@ def cpu_baseline(seconds_budget=20.0):
                        % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]), runs, dt))
 
 
+def reduce_over_ranks(dist, dt, units, device=None):
+    """Whole-job figures from per-rank ones: elapsed = MAX over ranks, units = SUM over ranks.
+    Works with any torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests)."""
+    if dist is None:
+        return float(dt), float(units)
+    import torch
+    t = torch.tensor([float(dt)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    u = torch.tensor([float(units)], dtype=torch.float64, device=device)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def tracked_fps(ctx, n_points=5000, frames=5):
+    """Secondary figure of BASELINE.json's metric: tracked frames/s = klt_track + pose-only solve +
+    pose-and-deformation solve (with its graph update) on one 640x480 frame with n_points map
+    points (SURVEY.md 8d unit definition; reference tracking.cc:291-330 minus image decode).  The
+    three calls take host buffers (a frame arrives from the host), so this is PCIe-inclusive."""
+    import nrs
+    import nrs_synth as S
+    sq = S.make_lk_sequence(n_points, 5)
+    tp = S.make_tracking_problem(n_points, 3)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    m = tp["status"] == 0
+    fm = np.arange(n_points, dtype=np.int32)
+    ctx.klt_configure()
+    ctx.klt_set_reference(sq["im0"], sq["pts"])
+    st = np.zeros(len(sq["pts"]), np.int32)
+    parts = np.zeros(3)
+    for f in range(frames + 1):
+        t0 = time.perf_counter()
+        ctx.klt_track(sq["im1"], sq["pts"], st)
+        t1 = time.perf_counter()
+        ctx.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
+        t2 = time.perf_counter()
+        ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
+                               tp["pose_q"], tp["pose_t"], tp["scale"])
+        t3 = time.perf_counter()
+        if f > 0:
+            parts += (t1 - t0, t2 - t1, t3 - t2)
+    parts /= frames
+    return dict(value=1.0 / parts.sum(), unit="frames/s", points=int(m.sum()), klt_points=len(sq["pts"]),
+                ms_klt_track=1e3 * parts[0], ms_pose_only=1e3 * parts[1], ms_pose_and_deformation=1e3 * parts[2])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,15 +170,7 @@ def main():
         inner += sum(t["inner"] for t in tr.trials)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        it = torch.tensor([float(lm_iters)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        lm_iters_all = float(it.item())
-    else:
-        lm_iters_all = float(lm_iters)
+    dt, lm_iters_all = reduce_over_ranks(dist, dt, lm_iters, "cuda" if dist is not None else None)
 
     out = None
     if rank == 0:
@@ -177,6 +214,8 @@ def main():
                                    "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"),
                                    "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]},
         }
+        if world == 1:
+            out["tracked_fps"] = tracked_fps(ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     ctx.close()

@@ -8,6 +8,7 @@
 // loads that stay in L1/L2: 20 B/point), reduce with wave butterflies + LDS, and lane 0 runs
 // the LM control flow, the Cholesky of H+lambda*I and the SE(3) retraction.  No host round trips,
 // no inter-workgroup hand-offs; latency per trial is a few microseconds.
+#include <cstdlib>
 #include "nrs_ctx.hpp"
 #include "nrs_device.hpp"
 
@@ -303,6 +304,7 @@ extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     c->opt.device = -1;
     if (opt) c->opt = *opt;
     if (c->opt.pcg_rtol <= 0) c->opt.pcg_rtol = 1e-10;
+    if (const char* e = getenv("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
     if (c->opt.pcg_max_iters <= 0) c->opt.pcg_max_iters = 2000;
     if (c->opt.pcg_batch <= 0) c->opt.pcg_batch = 16;
     c->err[0] = 0;
