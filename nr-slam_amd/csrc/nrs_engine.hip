@@ -49,6 +49,13 @@ constexpr int DM_COUNT = 1 << 2;     // damper: bits 0-1 role
 constexpr int DM_ACTIVE = 1 << 3;
 constexpr int DM_UNARY = 1 << 4;     // damper: the other vertex is a value, not a variable
 
+// packed incidence records of the LDS-staged path: one 16-byte load per damper incidence, two per
+// spring incidence; neighbour ids are tile-local (own rows, then halo)
+struct __attribute__((aligned(16))) SpringRec { double g0, g1, g2; uint16_t other, meta; float d0; };   // 32 B
+struct __attribute__((aligned(16))) DamperRec { uint16_t o0, o1, o2, meta; double s; };                  // 16 B
+constexpr uint16_t REC_NONE = 0xFFFF;
+constexpr uint16_t SR_ACTIVE = 1, SR_COUNT = 2;
+
 struct Dev {
     int K, M, n_rows, n_groups;      // poses, vertices, padded rows, ROW_ALIGN groups
     int T;                           // lanes per row
@@ -72,6 +79,7 @@ struct Dev {
     // tile_rows + i = halo_rows[halo_ptr[b] + i]
     int use_lds, tile_rows, max_halo;
     int* halo_ptr; int* halo_rows;
+    SpringRec* s_rec; DamperRec* d_rec;
     // state (two copies: current / trial, swapped on accept)
     Pose* pose[2]; double* xl[2];
     Pose* pose_init; double* xl_init;
@@ -109,6 +117,8 @@ struct Engine {
     std::vector<float> sp_d0, dm_w, un_w;
     std::vector<int> sp_pos, dm_pos, un_pos;     // SELL positions of every incidence (2 / 4 / 1 per edge)
     std::vector<int> h_s_meta, h_d_meta;
+    std::vector<SpringRec> h_s_rec;
+    std::vector<DamperRec> h_d_rec;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
     // device copies for the taps
     int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
@@ -329,14 +339,27 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
         const size_t nz = (size_t)P.ss_nnz;
         for (int idx = beg + lane; idx < end; idx += 64) {
-            const int o = P.s_other[idx];
-            if (o < 0) continue;
-            const int meta = P.s_meta[idx];
+            int o, meta;
+            double d0;
+            if (LDS) {
+                const SpringRec* rc = P.s_rec + idx;
+                o = rc->other;
+                if (o == REC_NONE) continue;
+                meta = ((rc->meta & SR_ACTIVE) ? SM_ACTIVE : 0) | ((rc->meta & SR_COUNT) ? SM_COUNT : 0);
+                d0 = (double)rc->d0;
+            } else {
+                o = P.s_other[idx];
+                if (o < 0) continue;
+                meta = P.s_meta[idx];
+                d0 = (double)P.s_d0[idx];
+            }
             if (!(meta & SM_ACTIVE)) {
-                if (LIN) { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+                if (LIN) {
+                    if (LDS) { P.s_rec[idx].g0 = 0; P.s_rec[idx].g1 = 0; P.s_rec[idx].g2 = 0; }
+                    else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+                }
                 continue;
             }
-            const double d0 = (double)P.s_d0[idx];
             double y0, y1, y2;
             if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
             else {
@@ -355,9 +378,8 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                 const double q = rfix ? 0.0 : rho1 * P.info_pos;
                 const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
                 const double sq = sqrt(q);
-                P.s_g[idx] = sq * g0;
-                P.s_g[nz + idx] = sq * g1;
-                P.s_g[2 * nz + idx] = sq * g2;
+                if (LDS) { P.s_rec[idx].g0 = sq * g0; P.s_rec[idx].g1 = sq * g1; P.s_rec[idx].g2 = sq * g2; }
+                else { P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
                 D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
                 D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
                 const double qr = q * r;
@@ -369,14 +391,24 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     {
         const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
         for (int idx = beg + lane; idx < end; idx += 64) {
-            const int meta = P.d_meta[idx];
-            if (meta < 0) continue;
+            int meta, o[3];
+            if (LDS) {
+                const DamperRec* rc = P.d_rec + idx;
+                if (rc->meta == REC_NONE) continue;
+                meta = rc->meta;
+                o[0] = rc->o0 == REC_NONE ? -1 : rc->o0;
+                o[1] = rc->o1 == REC_NONE ? -1 : rc->o1;
+                o[2] = rc->o2 == REC_NONE ? -1 : rc->o2;
+            } else {
+                meta = P.d_meta[idx];
+                if (meta < 0) continue;
+                o[0] = P.d_o0[idx]; o[1] = P.d_o1[idx]; o[2] = P.d_o2[idx];
+            }
             if (!(meta & DM_ACTIVE)) {
-                if (LIN) P.d_s[idx] = 0;
+                if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
                 continue;
             }
             const int role = meta & 3;
-            const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
             const double w = (double)P.d_w[idx];
             const double sgn_own = damper_sign(role);
             double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             if (LIN) {
                 const double fx = rfix ? 0.0 : 1.0;
                 const double s = fx * rho1 * P.info_spatial * w * w;
-                P.d_s[idx] = s;
+                if (LDS) P.d_rec[idx].s = s; else P.d_s[idx] = s;
                 D[0] += s; D[3] += s; D[5] += s;
                 const double c = fx * sgn_own * rho1 * P.info_spatial * w;
                 bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
@@ -574,17 +606,19 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     }
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double ul0 = 0, ul1 = 0, ul2 = 0;
-    if (t == 0) {
-        ul0 = u[3 * self]; ul1 = u[3 * self + 1]; ul2 = u[3 * self + 2];
+    const double ul0 = u[3 * self], ul1 = u[3 * self + 1], ul2 = u[3 * self + 2];
+    {
+        // row part: the T lanes of a row share the 6 pose components of H_pl
         const int kf = P.grp_pose[row / ROW_ALIGN];
-        const double* D = P.D + 6 * (size_t)row;
-        a0 = (D[0] + lam) * ul0 + D[1] * ul1 + D[2] * ul2;
-        a1 = D[1] * ul0 + (D[3] + lam) * ul1 + D[4] * ul2;
-        a2 = D[2] * ul0 + D[4] * ul1 + (D[5] + lam) * ul2;
+        if (t == 0) {
+            const double* D = P.D + 6 * (size_t)row;
+            a0 = (D[0] + lam) * ul0 + D[1] * ul1 + D[2] * ul2;
+            a1 = D[1] * ul0 + (D[3] + lam) * ul1 + D[4] * ul2;
+            a2 = D[2] * ul0 + D[4] * ul1 + (D[5] + lam) * ul2;
+        }
         double h0 = 0, h1 = 0, h2 = 0;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
+        for (int p = t; p < 6; p += T) {
             const double upk = P.up[6 * kf + p];
             const double e0 = P.Hpl[(size_t)(p * 3) * P.n_rows + row];
             const double e1 = P.Hpl[(size_t)(p * 3 + 1) * P.n_rows + row];
@@ -597,30 +631,85 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     }
     if (!rfix) {
         const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
-        const size_t nz = (size_t)P.ss_nnz;
-        for (int idx = beg + lane; idx < end; idx += 64) {
-            const int o = P.s_other[idx];
-            if (o < 0) continue;
-            const double g0 = P.s_g[idx], g1 = P.s_g[nz + idx], g2 = P.s_g[2 * nz + idx];
-            const double dot = g0 * u[3 * o] + g1 * u[3 * o + 1] + g2 * u[3 * o + 2];
-            a0 -= g0 * dot; a1 -= g1 * dot; a2 -= g2 * dot;
+        if (LDS) {
+            // records are streamed 4 steps ahead: with ~3 waves per SIMD the loop is bound by the
+            // latency of its own record loads unless several are in flight
+            constexpr int U = 4;
+            for (int idx = beg + lane; idx < end; idx += 64 * U) {
+                double2 ga[U];
+                double g2[U];
+                int o[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int j = idx + 64 * q;
+                    o[q] = REC_NONE;
+                    if (j < end) {
+                        const SpringRec* rc = P.s_rec + j;
+                        ga[q] = *reinterpret_cast<const double2*>(rc);
+                        g2[q] = rc->g2;
+                        o[q] = rc->other;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    if (o[q] == REC_NONE) continue;
+                    const double dot = ga[q].x * u[3 * o[q]] + ga[q].y * u[3 * o[q] + 1] + g2[q] * u[3 * o[q] + 2];
+                    a0 -= ga[q].x * dot; a1 -= ga[q].y * dot; a2 -= g2[q] * dot;
+                }
+            }
+        } else {
+            const size_t nz = (size_t)P.ss_nnz;
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int o = P.s_other[idx];
+                if (o < 0) continue;
+                const double g0 = P.s_g[idx], g1 = P.s_g[nz + idx], g2 = P.s_g[2 * nz + idx];
+                const double dot = g0 * u[3 * o] + g1 * u[3 * o + 1] + g2 * u[3 * o + 2];
+                a0 -= g0 * dot; a1 -= g1 * dot; a2 -= g2 * dot;
+            }
         }
     }
     if (!rfix) {
         const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
-        for (int idx = beg + lane; idx < end; idx += 64) {
-            const int meta = P.d_meta[idx];
-            if (meta < 0 || (meta & DM_UNARY)) continue;          // padding, or value-only other vertex
-            const int role = meta & 3;
-            const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
-            double s0 = 0, s1 = 0, s2 = 0;
+        if (LDS) {
+            constexpr int U = 4;
+            for (int idx = beg + lane; idx < end; idx += 64 * U) {
+                DamperRec rc[U];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double sg = damper_sign(k + (k >= role ? 1 : 0));
-                if (o[k] >= 0) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
+                for (int q = 0; q < U; ++q) {
+                    const int j = idx + 64 * q;
+                    rc[q].meta = REC_NONE;
+                    if (j < end) rc[q] = P.d_rec[j];
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    if (rc[q].meta == REC_NONE || (rc[q].meta & DM_UNARY)) continue;   // padding / value-only other
+                    const int role = rc[q].meta & 3;
+                    const uint16_t o[3] = {rc[q].o0, rc[q].o1, rc[q].o2};
+                    double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double sg = damper_sign(k + (k >= role ? 1 : 0));
+                        if (o[k] != REC_NONE) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
+                    }
+                    const double c = damper_sign(role) * rc[q].s;
+                    a0 += c * s0; a1 += c * s1; a2 += c * s2;
+                }
             }
-            const double c = damper_sign(role) * P.d_s[idx];
-            a0 += c * s0; a1 += c * s1; a2 += c * s2;
+        } else {
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int meta = P.d_meta[idx];
+                if (meta < 0 || (meta & DM_UNARY)) continue;
+                const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
+                const int role = meta & 3;
+                double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double sg = damper_sign(k + (k >= role ? 1 : 0));
+                    if (o[k] >= 0) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
+                }
+                const double c = damper_sign(role) * P.d_s[idx];
+                a0 += c * s0; a1 += c * s1; a2 += c * s2;
+            }
         }
     }
     a0 = sub_sum(a0, T); a1 = sub_sum(a1, T); a2 = sub_sum(a2, T);
@@ -687,61 +776,96 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         if (it == 0) P.scal[SC_GAMMA0] = gamma;
         P.flags[1] = it + 1;
     }
-    const int n_vec8 = ((n_vecblk + 7) >> 3) << 3;
+    // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
+    // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
+    const int n_vec2 = (n_vecblk + 1) >> 1;
+    const int n_vec8 = ((n_vec2 + 7) >> 3) << 3;
     if ((int)blockIdx.x < n_vec8) {
-        const int i = xcd_tile(blockIdx.x, n_vecblk) * BLK + tid;
-        if (i < P.n_rows) {
-            double r[3], uu[3];
-            const double* Di = P.Dinv + 6 * (size_t)i;
+        const int pair = xcd_tile(blockIdx.x, n_vec2) * BLK + tid;
+        if (2 * pair < P.n_rows) {
+            const size_t o = 6 * (size_t)pair;
+            double uu[6], pp[6], ww[6], ss[6], rr[6], xx[6];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int j = 3 * i + k;
-                const double p = P.uv3[j] + beta * P.pv[j];
-                const double s = P.wv[j] + beta * P.sv[j];
-                P.pv[j] = p;
-                P.sv[j] = s;
-                P.xv[j] += alpha * p;
-                r[k] = P.rv[j] - alpha * s;
-                P.rv[j] = r[k];
+                const double2 a = *reinterpret_cast<const double2*>(P.uv3 + o + 2 * k);
+                const double2 b = *reinterpret_cast<const double2*>(P.pv + o + 2 * k);
+                const double2 c = *reinterpret_cast<const double2*>(P.wv + o + 2 * k);
+                const double2 d = *reinterpret_cast<const double2*>(P.sv + o + 2 * k);
+                const double2 e = *reinterpret_cast<const double2*>(P.rv + o + 2 * k);
+                const double2 f = *reinterpret_cast<const double2*>(P.xv + o + 2 * k);
+                uu[2 * k] = a.x; uu[2 * k + 1] = a.y; pp[2 * k] = b.x; pp[2 * k + 1] = b.y;
+                ww[2 * k] = c.x; ww[2 * k + 1] = c.y; ss[2 * k] = d.x; ss[2 * k + 1] = d.y;
+                rr[2 * k] = e.x; rr[2 * k + 1] = e.y; xx[2 * k] = f.x; xx[2 * k + 1] = f.y;
             }
-            uu[0] = Di[0] * r[0] + Di[1] * r[1] + Di[2] * r[2];
-            uu[1] = Di[1] * r[0] + Di[3] * r[1] + Di[4] * r[2];
-            uu[2] = Di[2] * r[0] + Di[4] * r[1] + Di[5] * r[2];
-            P.uv3[3 * i] = uu[0]; P.uv3[3 * i + 1] = uu[1]; P.uv3[3 * i + 2] = uu[2];
+            double Di[12];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double2 a = *reinterpret_cast<const double2*>(P.Dinv + 2 * o + 2 * k);
+                Di[2 * k] = a.x; Di[2 * k + 1] = a.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                pp[k] = uu[k] + beta * pp[k];
+                ss[k] = ww[k] + beta * ss[k];
+                xx[k] += alpha * pp[k];
+                rr[k] -= alpha * ss[k];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double* Dh = Di + 6 * h;
+                const double r0 = rr[3 * h], r1 = rr[3 * h + 1], r2 = rr[3 * h + 2];
+                uu[3 * h] = Dh[0] * r0 + Dh[1] * r1 + Dh[2] * r2;
+                uu[3 * h + 1] = Dh[1] * r0 + Dh[3] * r1 + Dh[4] * r2;
+                uu[3 * h + 2] = Dh[2] * r0 + Dh[4] * r1 + Dh[5] * r2;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<double2*>(P.pv + o + 2 * k) = make_double2(pp[2 * k], pp[2 * k + 1]);
+                *reinterpret_cast<double2*>(P.sv + o + 2 * k) = make_double2(ss[2 * k], ss[2 * k + 1]);
+                *reinterpret_cast<double2*>(P.xv + o + 2 * k) = make_double2(xx[2 * k], xx[2 * k + 1]);
+                *reinterpret_cast<double2*>(P.rv + o + 2 * k) = make_double2(rr[2 * k], rr[2 * k + 1]);
+                *reinterpret_cast<double2*>(P.uv3 + o + 2 * k) = make_double2(uu[2 * k], uu[2 * k + 1]);
+            }
         }
     } else {
-        // pose workgroups: 42 poses per workgroup, 6 lanes per pose
-        __shared__ double s_r[42 * 6];
-        const int pb = blockIdx.x - n_vec8;
-        const int kl = tid / 6, a = tid % 6;
-        const int k = pb * 42 + kl;
-        const bool act = kl < 42 && k < P.K;
-        double rnew = 0;
-        if (act) {
+        // pose workgroups: one wave per pose; its 64 lanes split the pose's SpMV partials
+        const int k = (blockIdx.x - n_vec8) * 4 + wave;
+        if (k < P.K) {
+            const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
+            const int g0 = P.pose_grp_ptr[k] * rb, g1 = P.pose_grp_ptr[k + 1] * rb;
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int g = g0 + lane; g < g1; g += 64) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
+            // lanes 0..5 own one pose component each
+            const int a = lane < 6 ? lane : 0;
+            double hw = acc[0];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) hw = (a == q) ? acc[q] : hw;
             const int i = 6 * k + a;
             const double ua = P.up[i];
-            double w = lam * ua;
+            double w = lam * ua + hw;
             for (int c = 0; c < 6; ++c) {
                 const int lo = a < c ? a : c, hi = a < c ? c : a;
                 const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
                 w += P.Hpp[21 * k + pk] * P.up[6 * k + c];
             }
-            const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
-            for (int g = P.pose_grp_ptr[k] * rb; g < P.pose_grp_ptr[k + 1] * rb; ++g) w += P.part_spmv[(size_t)g * NPART + 3 + a];
             const double p = ua + beta * P.pp[i];
-            const double s = w + beta * P.sp[i];
-            P.pp[i] = p;
-            P.sp[i] = s;
-            P.xp[i] += alpha * p;
-            rnew = P.rp[i] - alpha * s;
-            P.rp[i] = rnew;
-            s_r[kl * 6 + a] = rnew;
-        }
-        __syncthreads();
-        if (act) {
-            double s = 0;
-            for (int c = 0; c < 6; ++c) s += P.Hppinv[36 * k + a * 6 + c] * s_r[kl * 6 + c];
-            P.up[6 * k + a] = s;
+            const double sN = w + beta * P.sp[i];
+            const double rnew = P.rp[i] - alpha * sN;
+            double unew = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) unew += P.Hppinv[36 * k + a * 6 + c] * __shfl(rnew, c, 64);
+            if (lane < 6) {
+                P.pp[i] = p;
+                P.sp[i] = sN;
+                P.xp[i] += alpha * p;
+                P.rp[i] = rnew;
+                P.up[i] = unew;
+            }
         }
     }
 }
@@ -898,16 +1022,19 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.sd_ptr = A.get<int>(n_slices + 1);
     d.halo_ptr = A.get<int>((size_t)d.n_regblk + 1);
     d.halo_rows = A.get<int>(n_halo);
-    d.s_other = A.get<int>(nnz_s); d.s_d0 = A.get<float>(nnz_s); d.s_meta = A.get<int>(nnz_s);
-    d.d_o0 = A.get<int>(nnz_d); d.d_o1 = A.get<int>(nnz_d); d.d_o2 = A.get<int>(nnz_d);
-    d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(nnz_d);
+    d.s_rec = A.get<SpringRec>(d.use_lds ? nnz_s : 1);
+    d.d_rec = A.get<DamperRec>(d.use_lds ? nnz_d : 1);
+    const size_t us = d.use_lds ? 1 : nnz_s, ud = d.use_lds ? 1 : nnz_d;     // unpacked arrays: fallback path only
+    d.s_other = A.get<int>(us); d.s_d0 = A.get<float>(us); d.s_meta = A.get<int>(us);
+    d.d_o0 = A.get<int>(ud); d.d_o1 = A.get<int>(ud); d.d_o2 = A.get<int>(ud);
+    d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(ud);
     for (int s = 0; s < 2; ++s) { d.pose[s] = A.get<Pose>(K); d.xl[s] = A.get<double>(3 * nr); }
     d.pose_init = A.get<Pose>(K);
     d.xl_init = A.get<double>(3 * nr);
     d.D = A.get<double>(6 * nr);
     d.Hpl = A.get<double>(18 * nr);
-    d.s_g = A.get<double>(3 * nnz_s);
-    d.d_s = A.get<double>(nnz_d);
+    d.s_g = A.get<double>(3 * us);
+    d.d_s = A.get<double>(ud);
     d.Hpp = A.get<double>(21 * K);
     d.bp = A.get<double>(6 * K);
     d.bl = A.get<double>(3 * nr);
@@ -966,8 +1093,19 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
         const bool act = !vfixed(e->un_ij[2 * s]);
         e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
     }
-    NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
-    NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
+    if (d.use_lds) {
+        for (size_t i = 0; i < e->h_s_rec.size(); ++i) {
+            const int m = e->h_s_meta[i];
+            e->h_s_rec[i].meta = (uint16_t)(((m & SM_ACTIVE) ? SR_ACTIVE : 0) | ((m & SM_COUNT) ? SR_COUNT : 0));
+        }
+        for (size_t i = 0; i < e->h_d_rec.size(); ++i)
+            e->h_d_rec[i].meta = e->h_d_meta[i] < 0 ? REC_NONE : (uint16_t)e->h_d_meta[i];
+        NRS_TRY(h2d(c, d.s_rec, e->h_s_rec));
+        NRS_TRY(h2d(c, d.d_rec, e->h_d_rec));
+    } else {
+        NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
+        NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
+    }
     NRS_TRY(h2d(c, d.rflag, e->h_rflag));
     NRS_TRY(h2d(c, d.pose_fixed, e->h_pose_fixed));
     return NRS_OK;
@@ -1135,7 +1273,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     d.use_lds = 1;
     const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
-    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024) {
+    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) {
         // irregular graph (or A/B switch): fall back to global gathers with global row ids
         d.use_lds = 0;
         for (int b = 0; b < d.n_regblk; ++b) {
@@ -1201,6 +1339,21 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->h_d_meta.assign(sd.size(), -1);
     for (size_t i = 0; i < ss.size(); ++i) { s_other[i] = ss[i].other[0]; s_d0[i] = ss[i].w; }
     for (size_t i = 0; i < sd.size(); ++i) { d_o0[i] = sd[i].other[0]; d_o1[i] = sd[i].other[1]; d_o2[i] = sd[i].other[2]; d_w[i] = sd[i].w; }
+    if (d.use_lds) {
+        auto u16 = [](int v) { return v < 0 ? REC_NONE : (uint16_t)v; };
+        e->h_s_rec.resize(ss.size());
+        for (size_t i = 0; i < ss.size(); ++i) {
+            SpringRec& r = e->h_s_rec[i];
+            r.g0 = r.g1 = r.g2 = 0;
+            r.other = u16(ss[i].other[0]); r.meta = 0; r.d0 = ss[i].w;
+        }
+        e->h_d_rec.resize(sd.size());
+        for (size_t i = 0; i < sd.size(); ++i) {
+            DamperRec& r = e->h_d_rec[i];
+            r.o0 = u16(sd[i].other[0]); r.o1 = u16(sd[i].other[1]); r.o2 = u16(sd[i].other[2]);
+            r.meta = REC_NONE; r.s = 0;
+        }
+    }
     std::vector<Pose> poses(s.poses, s.poses + s.K);
     NRS_TRY(h2d(c, d.grp_pose, grp_pose));
     NRS_TRY(h2d(c, d.pose_grp_ptr, pose_grp_ptr));
@@ -1212,11 +1365,13 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
     NRS_TRY(h2d(c, d.halo_ptr, halo_ptr));
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
-    NRS_TRY(h2d(c, d.s_other, s_other));
-    NRS_TRY(h2d(c, d.s_d0, s_d0));
-    NRS_TRY(h2d(c, d.d_o0, d_o0));
-    NRS_TRY(h2d(c, d.d_o1, d_o1));
-    NRS_TRY(h2d(c, d.d_o2, d_o2));
+    if (!d.use_lds) {
+        NRS_TRY(h2d(c, d.s_other, s_other));
+        NRS_TRY(h2d(c, d.s_d0, s_d0));
+        NRS_TRY(h2d(c, d.d_o0, d_o0));
+        NRS_TRY(h2d(c, d.d_o1, d_o1));
+        NRS_TRY(h2d(c, d.d_o2, d_o2));
+    }
     NRS_TRY(h2d(c, d.d_w, d_w));
     NRS_TRY(push_masks(c, e, s.sp_active, s.dm_active));
     NRS_TRY(h2d(c, e->t_vrow, e->vrow));
@@ -1347,7 +1502,7 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 // (H + lam I) x = b by block-Jacobi PCG; returns iterations, ok=false on non-finite values
 static int pcg_solve(nrs_ctx* c, Engine* e, double lam, int* iters, bool* ok) {
     const Dev& d = e->d;
-    const int n_poseblk = (d.K + 41) / 42;
+    const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
@@ -1361,7 +1516,7 @@ static int pcg_solve(nrs_ctx* c, Engine* e, double lam, int* iters, bool* ok) {
             }
             {
                 Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-                hipLaunchKernelGGL(k_pcg_update, dim3(((d.n_vecblk + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2);
+                hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2);
             }
         }
         NRS_HIP(c, hipGetLastError());
