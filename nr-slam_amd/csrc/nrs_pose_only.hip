@@ -14,7 +14,7 @@
 
 namespace nrs {
 
-constexpr int PO_THREADS = 1024;
+constexpr int PO_THREADS = 512;
 constexpr int PO_WAVES = PO_THREADS / 64;
 constexpr int PO_NACC = 28;          // 21 upper H + 6 b + chi2
 
@@ -38,37 +38,56 @@ struct PoseOnlyArgs {
 
 __device__ inline bool chol6_solve(const double* Hu /*21 upper, row-major packed*/, double lam,
                                    const double* b, double* x) {
-    double A[6][6];
-    int k = 0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { A[i][j] = Hu[k]; A[j][i] = Hu[k]; ++k; }
+    // fully unrolled so that A, L, y live in registers (dynamic indexing would put them in scratch
+    // and every access of the serial LM lane would be a memory round trip)
+    double A[6][6], L[6][6], y[6], xx[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { A[i][j] = Hu[k]; A[j][i] = Hu[k]; ++k; }
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) A[i][i] += lam;
-    double L[6][6];
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = 0; j < 6; ++j) L[i][j] = 0;
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = A[j][j];
+#pragma unroll
         for (int k2 = 0; k2 < j; ++k2) d -= L[j][k2] * L[j][k2];
-        if (!(d > 0.0)) return false;            // also catches NaN
+        if (!(d > 0.0)) ok = false;              // also catches NaN
         const double l = sqrt(d);
         L[j][j] = l;
+#pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = A[i][j];
+#pragma unroll
             for (int k2 = 0; k2 < j; ++k2) s -= L[i][k2] * L[j][k2];
             L[i][j] = s / l;
         }
     }
-    double y[6];
+    if (!ok) return false;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
+#pragma unroll
         for (int k2 = 0; k2 < i; ++k2) s -= L[i][k2] * y[k2];
         y[i] = s / L[i][i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
-        for (int k2 = i + 1; k2 < 6; ++k2) s -= L[k2][i] * x[k2];
-        x[i] = s / L[i][i];
+#pragma unroll
+        for (int k2 = i + 1; k2 < 6; ++k2) s -= L[k2][i] * xx[k2];
+        xx[i] = s / L[i][i];
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = xx[i];
     return true;
 }
 
