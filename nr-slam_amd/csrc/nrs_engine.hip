@@ -728,7 +728,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
 //   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = M^-1 r
 // Workgroups >= n_vec8 own the pose rows (w_p = (H_pp + lambda) u_p + sum_l H_pl u_l).
 // =====================================================================================
-__global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2) {
+__global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2) {
     __shared__ double lds[4 * 3];
     if (P.flags[0]) return;
     const int n_vecblk = P.n_vecblk;
@@ -775,6 +775,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         nslot[1] = alpha;
         if (it == 0) P.scal[SC_GAMMA0] = gamma;
         P.flags[1] = it + 1;
+        if (gamma <= peek_tol2 * gamma0) P.flags[3] = 1;       // "peek" milestone reached (early trial rejection)
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
@@ -1131,7 +1132,15 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->arena = arena;
     Dev& d = e->d;
     memset(&d, 0, sizeof(d));
-    int T = 2;                       // lanes per row; 2 measured best on C2 (profiles/README.md)
+    // lanes per row: 2 measured best on C2 (92k rows), 8 on single-frame problems (4.5k rows), where
+    // the kernels are bound by per-lane latency chains rather than by traffic (profiles/README.md)
+    int n_pad_rows = 0;
+    {
+        std::vector<int> cnt(s.K, 0);
+        for (int i = 0; i < s.M; ++i) cnt[s.lm_pose[i]]++;
+        for (int k = 0; k < s.K; ++k) n_pad_rows += std::max(1, (cnt[k] + ROW_ALIGN - 1) / ROW_ALIGN) * ROW_ALIGN;
+    }
+    int T = n_pad_rows >= 32768 ? 2 : 8;
     if (const char* ev = getenv("NRS_SELL_T")) {
         const int v = atoi(ev);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) T = v;
@@ -1499,14 +1508,23 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
     return NRS_OK;
 }
 
-// (H + lam I) x = b by block-Jacobi PCG; returns iterations, ok=false on non-finite values
-static int pcg_solve(nrs_ctx* c, Engine* e, double lam, int* iters, bool* ok) {
+// (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
+// convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
+constexpr double PEEK_RTOL = 1e-4;
+
+static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
+    const Dev& d = e->d;
+    NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
+    hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
+    *it = 0;
+    return NRS_OK;
+}
+
+static int pcg_advance(nrs_ctx* c, Engine* e, double lam, bool stop_at_peek, int* it_io, bool* done) {
     const Dev& d = e->d;
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
-    NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
-    hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
-    int it = 0;
+    int it = *it_io;
     while (true) {
         const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
         for (; it < stop; ++it) {
@@ -1516,16 +1534,17 @@ static int pcg_solve(nrs_ctx* c, Engine* e, double lam, int* iters, bool* ok) {
             }
             {
                 Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-                hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2);
+                hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
+                                   d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
             }
         }
         NRS_HIP(c, hipGetLastError());
         NRS_HIP(c, hipMemcpyAsync(e->h_flags, d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
-        if (e->h_flags[0] || it >= c->opt.pcg_max_iters) break;
+        if (e->h_flags[0] || it >= c->opt.pcg_max_iters) { *done = true; break; }
+        if (stop_at_peek && e->h_flags[3]) { *done = false; break; }
     }
-    *iters = e->h_flags[1];
-    *ok = e->h_flags[2] == 0;
+    *it_io = it;
     return NRS_OK;
 }
 
@@ -1545,25 +1564,47 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
         double rho = 0;
         int qmax = 0;
         do {
-            int inner = 0;
-            bool ok = true;
-            NRS_TRY(pcg_solve(c, e, lam, &inner, &ok));
+            int pit = 0;
+            bool done = false, early = false;
             const int trial = 1 - e->cur;
-            {
-                Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
-                hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+            double temp = 0, scale = 0;
+            bool ok = true;
+            NRS_TRY(pcg_begin(c, e, lam, &pit));
+            if (!c->opt.exact_trials) {
+                // peek: a trial that is clearly going to be rejected is not solved any further --
+                // its step is discarded, so the iterate sequence is the reference's either way
+                NRS_TRY(pcg_advance(c, e, lam, true, &pit, &done));
+                if (!done) {
+                    hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                    NRS_TRY(evaluate<false>(c, e, trial));
+                    NRS_TRY(read_scalars(c, e));
+                    temp = e->h_scal[SC_CHI];
+                    scale = e->h_scal[SC_SCALE] + 1e-3;
+                    const double rho_peek = (chi - temp) / scale;
+                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < -0.5;
+                }
             }
-            NRS_TRY(evaluate<false>(c, e, trial));
-            NRS_TRY(read_scalars(c, e));
-            const double temp = ok ? e->h_scal[SC_CHI] : 1.7976931348623157e308;
-            const double scale = e->h_scal[SC_SCALE] + 1e-3;
+            if (!early) {
+                if (!done) NRS_TRY(pcg_advance(c, e, lam, false, &pit, &done));
+                ok = e->h_flags[2] == 0;
+                {
+                    Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
+                    hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                }
+                NRS_TRY(evaluate<false>(c, e, trial));
+                NRS_TRY(read_scalars(c, e));
+                temp = ok ? e->h_scal[SC_CHI] : 1.7976931348623157e308;
+                scale = e->h_scal[SC_SCALE] + 1e-3;
+            }
+            const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
-            const bool accepted = rho > 0 && std::isfinite(temp);
+            const bool accepted = !early && rho > 0 && std::isfinite(temp);
             if (trace) {
                 if (trace->trials && trace->count < trace->capacity) {
                     nrs_lm_trial& Tr = trace->trials[trace->count];
                     Tr.round = round; Tr.iter = it; Tr.trial = qmax; Tr.accepted = accepted; Tr.solver_ok = ok;
-                    Tr.inner_iters = inner; Tr.lambda = lam; Tr.chi2 = chi; Tr.chi2_new = temp; Tr.rho = rho;
+                    Tr.inner_iters = inner; Tr.early_rejected = early; Tr.reserved = 0;
+                    Tr.lambda = lam; Tr.chi2 = chi; Tr.chi2_new = temp; Tr.rho = rho;
                 }
                 trace->count++;
             }

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
                     if (ntrials < a.trace_cap) {
                         nrs_lm_trial& T = a.trace[ntrials];
                         T.round = round; T.iter = it; T.trial = qmax; T.accepted = accepted; T.solver_ok = ok;
-                        T.inner_iters = 0; T.lambda = lam; T.chi2 = chi; T.chi2_new = tempChi; T.rho = rho;
+                        T.inner_iters = 0; T.early_rejected = 0; T.reserved = 0; T.lambda = lam; T.chi2 = chi; T.chi2_new = tempChi; T.rho = rho;
                     }
                     ++ntrials;
                     bool lam_bad = false;

@@ -37,12 +37,13 @@ class Camera(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
-                ("pcg_batch", C.c_int32), ("profile", C.c_int32)]
+                ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32)]
 
 
 class LmTrial(C.Structure):
     _fields_ = [("round", C.c_int32), ("iter", C.c_int32), ("trial", C.c_int32),
                 ("accepted", C.c_int32), ("solver_ok", C.c_int32), ("inner_iters", C.c_int32),
+                ("early_rejected", C.c_int32), ("reserved", C.c_int32),
                 ("lam", C.c_double), ("chi2", C.c_double), ("chi2_new", C.c_double),
                 ("rho", C.c_double)]
 
@@ -132,7 +133,7 @@ class Trace:
     def trials(self):
         n = min(self.c.count, self.c.capacity)
         return [dict(round=t.round, iter=t.iter, trial=t.trial, accepted=bool(t.accepted),
-                     ok=bool(t.solver_ok), inner=t.inner_iters, lam=t.lam, chi=t.chi2,
+                     ok=bool(t.solver_ok), inner=t.inner_iters, early=bool(t.early_rejected), lam=t.lam, chi=t.chi2,
                      chi_new=t.chi2_new, rho=t.rho) for t in self.buf[:n]]
 
     @property
@@ -168,9 +169,9 @@ def dba_build_edges(kf_points, graph, lib=None):
 
 
 class Context:
-    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0):
+    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0):
         self.lib = load_library()
-        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile)
+        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials)
         self.h = C.c_void_p()
         rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
         if rc != OK:

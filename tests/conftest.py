@@ -30,3 +30,12 @@ def ctx():
     c = nrs.Context()
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_exact():
+    """Context with nrs_options.exact_trials = 1: every LM trial is solved to pcg_rtol."""
+    import nrs
+    c = nrs.Context(exact_trials=1)
+    yield c
+    c.close()
