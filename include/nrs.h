@@ -61,7 +61,7 @@ typedef struct {
     double pcg_rtol;          /* relative residual ||b-Ax||/||b|| at which the inner solve stops;
                                  0 = default 1e-10 (SURVEY.md 7.2 hard part 1)                    */
     int32_t pcg_max_iters;    /* 0 = default 2000                                                */
-    int32_t pcg_batch;        /* PCG iterations enqueued between host checks; 0 = default 16      */
+    int32_t pcg_batch;        /* PCG iterations enqueued between host checks; 0 = default 8       */
     int32_t profile;          /* 1 = time the linearise and SpMV kernels with HIP events on the
                                  context stream (serialises launches; for bench roofline only)    */
     int32_t exact_trials;     /* 0 (default): an LM trial whose gain ratio is already < -0.5 when the

@@ -34,6 +34,7 @@ struct PoseOnlyArgs {
     nrs_lm_trial* trace;
     int trace_cap;
     int* counters;      // [0] trials, [1] iterations
+    int cache_pts;      // 1: uv/X of all points are cached in LDS (n * 20 B of dynamic LDS)
 };
 
 __device__ inline bool chol6_solve(const double* Hu /*21 upper, row-major packed*/, double lam,
@@ -125,6 +126,17 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
         s_t[0] = cur.t[0]; s_t[1] = cur.t[1]; s_t[2] = cur.t[2];
         s_phase = PH_EVAL;
     }
+    // the points are constant over all ~40 passes: keep them in LDS when they fit (the passes are
+    // otherwise a chain of dependent L2 round trips per point)
+    extern __shared__ float s_pts[];
+    const float* pX = a.X;
+    const float* pU = a.uv;
+    if (a.cache_pts) {
+        for (int i = tid; i < 3 * a.n; i += PO_THREADS) s_pts[i] = a.X[i];
+        for (int i = tid; i < 2 * a.n; i += PO_THREADS) s_pts[3 * a.n + i] = a.uv[i];
+        pX = s_pts;
+        pU = s_pts + 3 * a.n;
+    }
     for (int i = tid; i < a.n; i += PO_THREADS) a.level[i] = 0;
     __syncthreads();
 
@@ -143,14 +155,14 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
             for (int i = tid; i < a.n; i += PO_THREADS) {
                 if (a.level[i] != 0) continue;
                 ++nact;
-                const double X0 = a.X[3 * i], X1 = a.X[3 * i + 1], X2 = a.X[3 * i + 2];
+                const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
                 const double px = R0 * X0 + R1 * X1 + R2 * X2 + t0;
                 const double py = R3 * X0 + R4 * X1 + R5 * X2 + t1;
                 const double pz = R6 * X0 + R7 * X1 + R8 * X2 + t2;
                 float u, v, Jf[6];
                 project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
                 projection_jacobian_f32(a.cam, (float)px, (float)py, (float)pz, Jf);
-                const double r0 = (double)a.uv[2 * i] - (double)u, r1 = (double)a.uv[2 * i + 1] - (double)v;
+                const double r0 = (double)pU[2 * i] - (double)u, r1 = (double)pU[2 * i + 1] - (double)v;
                 a.err[2 * i] = r0;
                 a.err[2 * i + 1] = r1;
                 double rho0, rho1;
@@ -268,14 +280,14 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
             for (int i = tid; i < a.n; i += PO_THREADS) {
                 double r0, r1;
                 if (a.level[i] != 0) {
-                    const double X0 = a.X[3 * i], X1 = a.X[3 * i + 1], X2 = a.X[3 * i + 2];
+                    const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
                     const double px = R0 * X0 + R1 * X1 + R2 * X2 + t0;
                     const double py = R3 * X0 + R4 * X1 + R5 * X2 + t1;
                     const double pz = R6 * X0 + R7 * X1 + R8 * X2 + t2;
                     float u, v;
                     project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
-                    r0 = (double)a.uv[2 * i] - (double)u;
-                    r1 = (double)a.uv[2 * i + 1] - (double)v;
+                    r0 = (double)pU[2 * i] - (double)u;
+                    r1 = (double)pU[2 * i + 1] - (double)v;
                     a.err[2 * i] = r0;
                     a.err[2 * i + 1] = r1;
                 } else {
@@ -325,7 +337,7 @@ extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     if (c->opt.pcg_rtol <= 0) c->opt.pcg_rtol = 1e-10;
     if (const char* e = getenv("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
     if (c->opt.pcg_max_iters <= 0) c->opt.pcg_max_iters = 2000;
-    if (c->opt.pcg_batch <= 0) c->opt.pcg_batch = 16;
+    if (c->opt.pcg_batch <= 0) c->opt.pcg_batch = 8;
     c->err[0] = 0;
     memset(&c->prof, 0, sizeof(c->prof));
     int dev = c->opt.device;
@@ -420,7 +432,11 @@ extern "C" int nrs_pose_only_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n,
     a.counters = reinterpret_cast<int*>(c->po_out.as<char>() + sizeof(Pose));
     a.trace = c->po_trace.as<nrs_lm_trial>();
     a.trace_cap = cap;
-    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(PO_THREADS), 0, c->stream, a);
+    const size_t shm = (size_t)n * 20;
+    a.cache_pts = shm <= 140 * 1024 ? 1 : 0;                 // 160 KiB of LDS per CU on gfx950
+    if (a.cache_pts && shm > 48 * 1024)
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pose_only_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(PO_THREADS), a.cache_pts ? shm : 0, c->stream, a);
     NRS_HIP(c, hipGetLastError());
     Pose out;
     int counters[2] = {0, 0};
