@@ -36,6 +36,8 @@ struct nrs_ctx {
     nrs::Engine* dba = nullptr;
     nrs::Arena arena_dba, arena_trk;
     nrs::KltState* klt = nullptr;
+    double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
+    int* pin_flags = nullptr;
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;

@@ -31,6 +31,7 @@
 //   * XCD-aware launch order: logical tile = (blockIdx % 8) * ceil(nb/8) + blockIdx / 8, so each
 //     XCD's L2 serves one contiguous run of rows (neighbour gathers stay inside it).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -965,39 +966,6 @@ void arena_release(Arena* a) {
     a->cap = a->off = 0;
 }
 
-struct Inc { int other[3]; float w; int meta; int edge; int slot; };
-
-// pack per-row incidence lists into the sliced-ELL layout described at the top of the file;
-// pos[] receives the packed position of every incidence (indexed by Inc::slot)
-static void sell_pack(const std::vector<std::vector<Inc>>& rows, int T, std::vector<int>& slice_ptr,
-                      std::vector<Inc>& out, std::vector<int>& pos) {
-    const int R = 64 / T;
-    const int n_slices = (int)rows.size() / R;
-    slice_ptr.assign(n_slices + 1, 0);
-    for (int s = 0; s < n_slices; ++s) {
-        int width = 0;
-        for (int r = 0; r < R; ++r) width = std::max(width, ((int)rows[(size_t)s * R + r].size() + T - 1) / T);
-        slice_ptr[s + 1] = slice_ptr[s] + width * 64;
-    }
-    Inc pad;
-    pad.other[0] = pad.other[1] = pad.other[2] = -1;
-    pad.w = 0;
-    pad.meta = -1;
-    pad.edge = -1;
-    pad.slot = -1;
-    out.assign((size_t)slice_ptr[n_slices], pad);
-    for (int s = 0; s < n_slices; ++s)
-        for (int r = 0; r < R; ++r) {
-            const auto& L = rows[(size_t)s * R + r];
-            for (size_t e = 0; e < L.size(); ++e) {
-                const int j = (int)e / T, t = (int)e % T;
-                const size_t p = (size_t)slice_ptr[s] + (size_t)j * 64 + r * T + t;
-                out[p] = L[e];
-                if (L[e].slot >= 0) pos[L[e].slot] = (int)p;
-            }
-        }
-}
-
 struct ArenaPlan {                   // two passes: size, then carve
     Arena* a;
     bool dry;
@@ -1125,6 +1093,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
     for (int64_t i = 0; i < 2 * (int64_t)s.n_un; ++i)
         if (s.un_ij[i] < 0 || s.un_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "unary damper index out of range");
+    const bool tm = getenv("NRS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!tm) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nrs] engine_create %-18s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     NRS_HIP(c, hipSetDevice(c->device));
     Engine* e = new (std::nothrow) Engine();
     if (!e) return c->fail(NRS_ERR_ALLOC, "out of host memory");
@@ -1201,112 +1177,108 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             for (size_t i = 0; i < keys.size(); ++i) e->vrow[keys[i].second] = pose_grp_ptr[k] * ROW_ALIGN + (int)i;
         }
     }
-    // ---- incidence lists
-    std::vector<std::vector<Inc>> rs(d.n_rows), rd(d.n_rows);
+    mark("row layout");
+    // ---- incidence lists -> sliced ELL, built with two counting passes (no per-row containers)
+    const int Rw = 64 / T;
+    const int n_slices = d.n_rows / Rw;
+    const int dm_slots = 4 * s.n_dm;
     e->sp_pos.assign(2 * (size_t)s.n_sp, -1);
     e->dm_pos.assign(4 * (size_t)s.n_dm, -1);
     e->un_pos.assign((size_t)s.n_un, -1);
+    std::vector<int> cnt_s(d.n_rows, 0), cnt_d(d.n_rows, 0);
+    for (int q = 0; q < s.n_sp; ++q) { cnt_s[e->vrow[s.sp_ij[2 * q]]]++; cnt_s[e->vrow[s.sp_ij[2 * q + 1]]]++; }
+    for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)
+        if (s.dm_idx[q] >= 0) cnt_d[e->vrow[s.dm_idx[q]]]++;
+    for (int q = 0; q < s.n_un; ++q) cnt_d[e->vrow[s.un_ij[2 * q]]]++;
+    std::vector<int> ss_ptr(n_slices + 1, 0), sd_ptr(n_slices + 1, 0);
+    for (int sl = 0; sl < n_slices; ++sl) {
+        int ws = 0, wd = 0;
+        for (int r = 0; r < Rw; ++r) {
+            ws = std::max(ws, (cnt_s[sl * Rw + r] + T - 1) / T);
+            wd = std::max(wd, (cnt_d[sl * Rw + r] + T - 1) / T);
+        }
+        ss_ptr[sl + 1] = ss_ptr[sl] + ws * 64;
+        sd_ptr[sl + 1] = sd_ptr[sl] + wd * 64;
+    }
+    const size_t nnz_s = (size_t)ss_ptr[n_slices], nnz_d = (size_t)sd_ptr[n_slices];
+    d.ss_nnz = (int)nnz_s;
+    d.sd_nnz = (int)nnz_d;
+    // packed position of the k-th incidence of a row
+    auto pos_of = [&](const std::vector<int>& ptr, int row, int k) {
+        const int sl = row / Rw, r = row - sl * Rw;
+        return (size_t)ptr[sl] + (size_t)(k / T) * 64 + (size_t)r * T + (size_t)(k % T);
+    };
+    std::vector<int> S_other(nnz_s, -1), D_o(3 * nnz_d, -1), D_role(nnz_d, -1);
+    std::vector<float> S_d0(nnz_s, 0.f), D_w(nnz_d, 0.f);
+    std::fill(cnt_s.begin(), cnt_s.end(), 0);
+    std::fill(cnt_d.begin(), cnt_d.end(), 0);
     for (int q = 0; q < s.n_sp; ++q) {
         const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
-        Inc i1;
-        i1.other[0] = b; i1.other[1] = i1.other[2] = -1; i1.w = s.sp_d0[q]; i1.meta = 0; i1.edge = q; i1.slot = 2 * q;
-        rs[a].push_back(i1);
-        Inc i2 = i1;
-        i2.other[0] = a; i2.slot = 2 * q + 1;
-        rs[b].push_back(i2);
+        const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++), pb = pos_of(ss_ptr, b, cnt_s[b]++);
+        S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
+        S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
     }
     for (int q = 0; q < s.n_dm; ++q) {
         int r4[4];
         for (int k = 0; k < 4; ++k) r4[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
         for (int role = 0; role < 4; ++role) {
             if (r4[role] < 0) continue;
-            Inc in;
+            const size_t pz = pos_of(sd_ptr, r4[role], cnt_d[r4[role]]++);
             int z = 0;
             for (int k = 0; k < 4; ++k)
-                if (k != role) in.other[z++] = r4[k];
-            in.w = s.dm_w[q]; in.meta = role; in.edge = q; in.slot = 4 * q + role;
-            rd[r4[role]].push_back(in);
+                if (k != role) D_o[3 * pz + z++] = r4[k];
+            D_w[pz] = s.dm_w[q];
+            D_role[pz] = role;
+            e->dm_pos[4 * (size_t)q + role] = (int)pz;
         }
     }
-    const int dm_slots = 4 * s.n_dm;
     for (int q = 0; q < s.n_un; ++q) {           // own role 2 (1n, +), value-only other in role 3 (2n, -)
-        Inc in;
-        in.other[0] = in.other[1] = -1;
-        in.other[2] = e->vrow[s.un_ij[2 * q + 1]];
-        in.w = s.un_w[q]; in.meta = 2; in.edge = q; in.slot = dm_slots + q;
-        rd[e->vrow[s.un_ij[2 * q]]].push_back(in);
+        const int row = e->vrow[s.un_ij[2 * q]];
+        const size_t pz = pos_of(sd_ptr, row, cnt_d[row]++);
+        D_o[3 * pz + 2] = e->vrow[s.un_ij[2 * q + 1]];
+        D_w[pz] = s.un_w[q];
+        D_role[pz] = 2;
+        e->un_pos[q] = (int)pz;
     }
-    std::vector<int> ss_ptr, sd_ptr, dpos((size_t)dm_slots + s.n_un, -1);
-    std::vector<Inc> ss, sd;
-    sell_pack(rs, T, ss_ptr, ss, e->sp_pos);
-    sell_pack(rd, T, sd_ptr, sd, dpos);
-    std::copy(dpos.begin(), dpos.begin() + dm_slots, e->dm_pos.begin());
-    std::copy(dpos.begin() + dm_slots, dpos.end(), e->un_pos.begin());
-    d.ss_nnz = (int)ss.size();
-    d.sd_nnz = (int)sd.size();
+    (void)dm_slots;
+    mark("sell pack");
     // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
     // outside the tile; neighbour ids become tile-local
     d.tile_rows = BLK / T;
     std::vector<int> halo_ptr(d.n_regblk + 1, 0), halo_rows;
+    std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
     {
-        const int Rw = 64 / T;
-        std::vector<int> ext;
+        std::vector<int> stamp(d.n_rows, -1), local(d.n_rows, 0), ext;
         for (int b = 0; b < d.n_regblk; ++b) {
             const int row0 = b * d.tile_rows, row1 = row0 + d.tile_rows;
             ext.clear();
-            auto visit = [&](std::vector<Inc>& arr, const std::vector<int>& ptr, int nother, bool collect) {
-                for (int sl = b * 4; sl < b * 4 + 4; ++sl)
-                    for (int p = ptr[sl]; p < ptr[sl + 1]; ++p) {
-                        Inc& in = arr[p];
-                        if (in.meta < 0 && in.slot < 0) continue;
-                        for (int k = 0; k < nother; ++k) {
-                            const int o = in.other[k];
-                            if (o < 0) continue;
-                            if (collect) { if (o < row0 || o >= row1) ext.push_back(o); }
-                            else if (o >= row0 && o < row1) in.other[k] = o - row0;
-                            else in.other[k] = d.tile_rows + (int)(std::lower_bound(ext.begin(), ext.end(), o) - ext.begin());
-                        }
-                    }
+            const size_t s0 = (size_t)ss_ptr[b * 4], s1 = (size_t)ss_ptr[b * 4 + 4];
+            const size_t d0 = (size_t)sd_ptr[b * 4], d1 = (size_t)sd_ptr[b * 4 + 4];
+            auto see = [&](int o) {
+                if (o >= 0 && (o < row0 || o >= row1) && stamp[o] != b) { stamp[o] = b; ext.push_back(o); }
             };
-            visit(ss, ss_ptr, 1, true);
-            visit(sd, sd_ptr, 3, true);
+            for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
+            for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
             std::sort(ext.begin(), ext.end());
-            ext.erase(std::unique(ext.begin(), ext.end()), ext.end());
-            visit(ss, ss_ptr, 1, false);
-            visit(sd, sd_ptr, 3, false);
+            for (size_t i = 0; i < ext.size(); ++i) local[ext[i]] = d.tile_rows + (int)i;
+            auto loc = [&](int o) { return o < 0 ? -1 : (o >= row0 && o < row1) ? o - row0 : local[o]; };
+            for (size_t p2 = s0; p2 < s1; ++p2) L_s[p2] = loc(S_other[p2]);
+            for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) L_d[p2] = loc(D_o[p2]);
             halo_rows.insert(halo_rows.end(), ext.begin(), ext.end());
             halo_ptr[b + 1] = (int)halo_rows.size();
             d.max_halo = std::max(d.max_halo, (int)ext.size());
         }
-        (void)Rw;
     }
     d.use_lds = 1;
     const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
-    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) {
-        // irregular graph (or A/B switch): fall back to global gathers with global row ids
-        d.use_lds = 0;
-        for (int b = 0; b < d.n_regblk; ++b) {
-            const int row0 = b * d.tile_rows;
-            auto undo = [&](std::vector<Inc>& arr, const std::vector<int>& ptr, int nother) {
-                for (int sl = b * 4; sl < b * 4 + 4; ++sl)
-                    for (int p = ptr[sl]; p < ptr[sl + 1]; ++p)
-                        for (int k = 0; k < nother; ++k) {
-                            int& o = arr[p].other[k];
-                            if (o < 0) continue;
-                            o = o < d.tile_rows ? row0 + o : halo_rows[halo_ptr[b] + (o - d.tile_rows)];
-                        }
-            };
-            undo(ss, ss_ptr, 1);
-            undo(sd, sd_ptr, 3);
-        }
-    }
-
+    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    mark("halo");
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
     {
         Dev tmp = d;
         Engine te;
-        carve(dry, tmp, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, halo_rows.size(), &te);
+        carve(dry, tmp, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), &te);
     }
     if (dry.off > arena->cap) {
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -1317,8 +1289,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         arena->cap = want;
     }
     ArenaPlan real{arena, false};
-    carve(real, d, s.X0 != nullptr, ss.size(), sd.size(), ss_ptr.size() - 1, halo_rows.size(), e);
+    carve(real, d, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), e);
 
+    mark("arena");
     // ---- host mirrors + uploads
     e->sp_ij.assign(s.sp_ij, s.sp_ij + 2 * (size_t)s.n_sp);
     e->sp_d0.assign(s.sp_d0, s.sp_d0 + (size_t)s.n_sp);
@@ -1342,27 +1315,33 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             if (s.X0) X0[3 * row + k] = s.X0[3 * (size_t)v + k];
         }
     }
-    std::vector<int> s_other(ss.size()), d_o0(sd.size()), d_o1(sd.size()), d_o2(sd.size());
-    std::vector<float> s_d0(ss.size()), d_w(sd.size());
-    e->h_s_meta.assign(ss.size(), 0);
-    e->h_d_meta.assign(sd.size(), -1);
-    for (size_t i = 0; i < ss.size(); ++i) { s_other[i] = ss[i].other[0]; s_d0[i] = ss[i].w; }
-    for (size_t i = 0; i < sd.size(); ++i) { d_o0[i] = sd[i].other[0]; d_o1[i] = sd[i].other[1]; d_o2[i] = sd[i].other[2]; d_w[i] = sd[i].w; }
+    e->h_s_meta.assign(nnz_s, 0);
+    e->h_d_meta.assign(nnz_d, -1);
+    for (size_t i = 0; i < nnz_d; ++i)
+        if (D_role[i] >= 0) e->h_d_meta[i] = D_role[i];
+    std::vector<int> d_o0, d_o1, d_o2;
     if (d.use_lds) {
         auto u16 = [](int v) { return v < 0 ? REC_NONE : (uint16_t)v; };
-        e->h_s_rec.resize(ss.size());
-        for (size_t i = 0; i < ss.size(); ++i) {
+        e->h_s_rec.resize(nnz_s);
+        for (size_t i = 0; i < nnz_s; ++i) {
             SpringRec& r = e->h_s_rec[i];
             r.g0 = r.g1 = r.g2 = 0;
-            r.other = u16(ss[i].other[0]); r.meta = 0; r.d0 = ss[i].w;
+            r.other = u16(L_s[i]); r.meta = 0; r.d0 = S_d0[i];
         }
-        e->h_d_rec.resize(sd.size());
-        for (size_t i = 0; i < sd.size(); ++i) {
+        e->h_d_rec.resize(nnz_d);
+        for (size_t i = 0; i < nnz_d; ++i) {
             DamperRec& r = e->h_d_rec[i];
-            r.o0 = u16(sd[i].other[0]); r.o1 = u16(sd[i].other[1]); r.o2 = u16(sd[i].other[2]);
+            r.o0 = u16(L_d[3 * i]); r.o1 = u16(L_d[3 * i + 1]); r.o2 = u16(L_d[3 * i + 2]);
             r.meta = REC_NONE; r.s = 0;
         }
+    } else {
+        d_o0.resize(nnz_d); d_o1.resize(nnz_d); d_o2.resize(nnz_d);
+        for (size_t i = 0; i < nnz_d; ++i) { d_o0[i] = D_o[3 * i]; d_o1[i] = D_o[3 * i + 1]; d_o2[i] = D_o[3 * i + 2]; }
     }
+    const std::vector<int>& s_other = S_other;
+    const std::vector<float>& s_d0 = S_d0;
+    const std::vector<float>& d_w = D_w;
+    mark("host mirrors");
     std::vector<Pose> poses(s.poses, s.poses + s.K);
     NRS_TRY(h2d(c, d.grp_pose, grp_pose));
     NRS_TRY(h2d(c, d.pose_grp_ptr, pose_grp_ptr));
@@ -1391,9 +1370,13 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
-    NRS_HIP(c, hipHostMalloc((void**)&e->h_scal, sizeof(double) * SC_N));
-    NRS_HIP(c, hipHostMalloc((void**)&e->h_flags, sizeof(int) * 8));
+    mark("uploads enqueued");
+    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N));      // pinned mirrors live in
+    if (!c->pin_flags) NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8));         // the context (reused)
+    e->h_scal = c->pin_scal;
+    e->h_flags = c->pin_flags;
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
+    mark("pinned+sync");
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
     *out = e;
@@ -1403,8 +1386,6 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
 void engine_destroy(nrs_ctx* c, Engine* e) {
     if (!e) return;
     (void)hipStreamSynchronize(c->stream);
-    if (e->h_scal) (void)hipHostFree(e->h_scal);
-    if (e->h_flags) (void)hipHostFree(e->h_flags);
     delete e;
 }
 
