@@ -1,0 +1,120 @@
+"""Edge cases of the engine through the C ABI (empty / ragged inputs, degenerate graphs), each
+checked against the oracle where the oracle defines the answer."""
+import numpy as np
+import pytest
+
+import nrs
+import nrs_oracle as O
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _ba(ctx, p, e, iters=5):
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    tr = nrs.Trace()
+    pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], iters, tr)
+    otr = []
+    oq, ot, opts, nit = O.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"], p["lm_uv"],
+                                    e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], iters, otr)
+    assert [t["accepted"] for t in tr.trials] == [t["accepted"] for t in otr]
+    assert np.allclose(pq[:, :4], oq, atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
+    assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
+    return tr
+
+
+def test_ba_without_regularisers(ctx):
+    """no springs, no dampers: plain reprojection BA (every landmark sees one pose)."""
+    p = S.make_dba_problem(80, 3, 71)
+    e = dict(sp_ij=np.zeros((0, 2), np.int32), sp_d0=np.zeros(0, np.float32),
+             dm_idx=np.zeros((0, 4), np.int32), dm_w=np.zeros(0, np.float32))
+    _ba(ctx, p, e)
+
+
+def test_ba_single_keyframe_and_ragged_keyframes(ctx):
+    p = S.make_dba_problem(70, 1, 72)                       # one keyframe: springs only
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    assert len(e["dm_idx"]) == 0 and len(e["sp_ij"]) > 0
+    _ba(ctx, p, e)
+    p = S.make_dba_problem(300, 4, 73)                      # very different keyframe sizes
+    keep = np.ones(len(p["lm_kf"]), bool)
+    idx1 = np.where(p["lm_kf"] == 1)[0]
+    keep[idx1[7:]] = False                                  # keyframe 1 keeps 7 observations
+    idx3 = np.where(p["lm_kf"] == 3)[0]
+    keep[idx3[::2]] = False
+    for k in ("lm_xyz", "lm_kf", "lm_pt", "lm_uv"):
+        p[k] = p[k][keep]
+    p["kf_points"] = [p["lm_pt"][p["lm_kf"] == k] for k in range(4)]
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    sizes = [len(k) for k in p["kf_points"]]
+    assert sizes[1] == 7 and max(sizes) > 10 * min(sizes)
+    _ba(ctx, p, e)
+
+
+def test_ba_more_rows_than_one_group(ctx):
+    """a keyframe with more than ROW_ALIGN (256) landmarks spans several row groups."""
+    p = S.make_dba_problem(700, 2, 74, dropout=0.0)
+    assert min(len(k) for k in p["kf_points"]) > 512
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    _ba(ctx, p, e)
+
+
+def test_ba_zero_iterations_and_reupload(ctx):
+    p = S.make_dba_problem(60, 3, 75)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    tr = nrs.Trace()
+    ctx.dba_optimize(0, tr)
+    pq, xyz = ctx.dba_download()
+    assert tr.iterations == 0 and len(tr.trials) == 0
+    assert np.allclose(xyz, p["lm_xyz"].astype(np.float64)) and np.allclose(pq[:, 4:], p["poses_t"])
+    # a larger problem after a smaller one re-uses / grows the arena
+    p2 = S.make_dba_problem(400, 4, 76)
+    e2 = nrs.dba_build_edges(p2["kf_points"], p2["nbr"])
+    _ba(ctx, p2, e2)
+    _ba(ctx, p, e)
+
+
+def test_calls_before_upload_fail(lib_built):
+    c = nrs.Context()
+    with pytest.raises(nrs.NrsError) as ei:
+        c.dba_optimize(5)
+    assert ei.value.code == -5
+    with pytest.raises(nrs.NrsError):
+        c.dba_reset()
+    c.close()
+
+
+def test_track_all_neighbours_bad_and_isolated_points(ctx):
+    """every graph edge BAD: no regularisers at all, points only see their reprojection edge."""
+    tp = S.make_tracking_problem(200, 77)
+    g = dict(tp["graph"])
+    g["e_status"] = np.full_like(g["e_status"], S.GRAPH_BAD)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    fm = np.arange(200, dtype=np.int32)
+    r = ctx.track_deform_solve(cam, g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"])
+    o = O.track_deform_solve(tp["model"], tp["prm"], g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"])
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0) and np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == o["lost"]
+    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-4, rtol=0)
+
+
+def test_track_frame_with_unmapped_slots(ctx):
+    """frame slots without a map point (f_map = -1) and map points that are not in the frame."""
+    tp = S.make_tracking_problem(260, 78)
+    n = 260
+    rng = np.random.default_rng(1)
+    in_frame = np.sort(rng.choice(n, 200, replace=False))
+    f_map = np.concatenate([in_frame, -np.ones(15, np.int64)]).astype(np.int32)
+    st = np.concatenate([tp["status"][in_frame], np.full(15, 1, np.int32)])
+    uv = np.concatenate([tp["uv"][in_frame], np.zeros((15, 2), np.float32)])
+    pos = np.concatenate([tp["X_prev"][in_frame], np.zeros((15, 3), np.float32)])
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    r = ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], f_map, st, uv, pos, tp["pose_q"], tp["pose_t"], tp["scale"])
+    o = O.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], f_map, st, uv, pos, tp["pose_q"], tp["pose_t"], tp["scale"])
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == o["lost"]
+    assert np.allclose(r["map_pos"], o["map_pos"], atol=1e-4, rtol=0)
