@@ -47,7 +47,7 @@ def algorithmic_bytes(n_lm, n_sp, n_dm, n_blocks):
     return lin, spmv
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=20.0, ctx=None):
     """The oracle (kind "port": NumPy/SciPy restatement of the reference, oracle/nrs_oracle.py)
     timed on this host, 1 core, on a bounded sample: the same generator at the reference's own
     window size (5 keyframes, g2o_optimization.cc:894) with 400 points -- C2 itself (275k unknowns,
@@ -69,9 +69,24 @@ def cpu_baseline(seconds_budget=20.0):
         if time.perf_counter() - t0 > seconds_budget or runs >= 3:
             break
     dt = time.perf_counter() - t0
-    return dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port",
-                sample="optimize(5) on 400 points x 5 keyframes (%d landmarks, %d springs, %d dampers), %d runs, %.1f s"
-                       % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]), runs, dt))
+    out = dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port",
+               sample="optimize(5) on 400 points x 5 keyframes (%d landmarks, %d springs, %d dampers), %d runs, %.1f s"
+                      % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]), runs, dt))
+    if ctx is not None:
+        # the GPU path on the very same sample (resident, like `value`), for a like-for-like ratio
+        cam = nrs.make_camera(p["model"], p["prm"])
+        qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+        ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        g_it, reps = 0, 20
+        ctx.dba_optimize(5)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.dba_reset()
+            tr = nrs.Trace(64)
+            ctx.dba_optimize(5, tr)
+            g_it += tr.iterations
+        out["gpu_same_sample"] = g_it / (time.perf_counter() - t1)
+    return out
 
 
 def reduce_over_ranks(dist, dt, units, device=None):
@@ -198,10 +213,11 @@ def main():
             "metric": "deformable-BA LM iters/sec", "value": lm_iters_all / dt, "unit": "LM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 (fp32 projection, as the reference)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d map points x %d keyframes, %s, every point a graph node; "
                                    "optimize(5) per step" % (args.workload, n_points, n_kf,
                                                              "pinhole" if model == 0 else "KannalaBrandt8"),
+                       "arithmetic": "fp64 state / normal equations / PCG, fp32 projection and projection Jacobian (as the reference)",
                        "landmarks": n_lm, "springs": n_sp, "dampers": n_dm,
                        "lm_trials_per_step": trials / args.steps, "pcg_iters_per_step": inner / args.steps,
                        "parallelism": "independent BA window per GPU" if world > 1 else "1 GPU"},
@@ -217,7 +233,7 @@ def main():
         if world == 1:
             out["tracked_fps"] = tracked_fps(ctx)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(ctx=ctx)
     ctx.close()
     if dist is not None:
         dist.barrier()

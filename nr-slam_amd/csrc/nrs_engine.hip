@@ -1491,7 +1491,7 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
-constexpr double PEEK_RTOL = 1e-4;
+constexpr double PEEK_RTOL = 1e-3;
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
