@@ -95,6 +95,9 @@ struct Dev {
     // PCG vectors: pose part [6K] and row part [3 n_rows]
     double *xp, *rp, *up, *pp, *sp, *wp;
     double *xv, *rv, *uv3, *pv, *sv, *wv;
+    // second halves of the ping-pong pairs used by the fused small-problem iteration
+    double *rp2, *sp2, *up2, *rv2, *sv2, *wv2, *part_spmv2;
+    int fused;
     // partials / scalars
     double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
     double* part_reg;                // n_regblk x 2    (chi, maxdiag)
@@ -873,6 +876,316 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
 }
 
 // =====================================================================================
+// Fused PCG iteration for small problems (single-frame tracking, short BA windows): ONE launch per
+// iteration.  F(it) = [vector update of iteration it-1] followed by [operator apply of iteration
+// it].  Every workgroup re-derives the scalars from the previous launch's partials, updates its own
+// rows, and RECOMPUTES the updated u of its halo rows from (r, s, w, M^-1) instead of waiting for
+// their owners -- so there is no inter-workgroup hand-off inside a launch.  r, s, w, the pose
+// vectors and the partials are ping-pong pairs (read half (it+1)&1, write half it&1): owners write
+// the new values while neighbours still read the old ones.  Same arithmetic, in the same order, as
+// k_pcg_update + k_spmv.
+// =====================================================================================
+template <int T>
+__global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, double tol2, double peek_tol2) {
+    __shared__ double lds[4 * 9];
+    __shared__ double s_up[6];
+    extern __shared__ double dyn[];
+    if (P.flags[0]) return;
+    constexpr int R = 64 / T;
+    constexpr int U = 4;
+    const int b = xcd_tile(blockIdx.x, P.n_regblk);
+    if (b >= P.n_regblk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // read half / write half of the ping-pong pairs.  Launch 0 only applies the operator: the state
+    // written by k_trial_setup lives in half 0 and stays there.
+    const int hin = it == 0 ? 0 : ((it + 1) & 1), hout = it & 1;
+    const double* r_in = hin ? P.rv2 : P.rv;    double* r_out = hout ? P.rv2 : P.rv;
+    const double* s_in = hin ? P.sv2 : P.sv;    double* s_out = hout ? P.sv2 : P.sv;
+    const double* w_in = hin ? P.wv2 : P.wv;    double* w_out = hout ? P.wv2 : P.wv;
+    const double* rp_in = hin ? P.rp2 : P.rp;   double* rp_out = hout ? P.rp2 : P.rp;
+    const double* sp_in = hin ? P.sp2 : P.sp;   double* sp_out = hout ? P.sp2 : P.sp;
+    const double* up_in = hin ? P.up2 : P.up;   double* up_out = hout ? P.up2 : P.up;
+    const double* part_in = hin ? P.part_spmv2 : P.part_spmv;
+    double* part_out = hout ? P.part_spmv2 : P.part_spmv;
+    const int slice = b * 4 + wave;
+    const int row = slice * R + lane / T;
+    const int t = lane % T;
+    const int row0 = b * P.tile_rows;
+    const int kf = P.grp_pose[row0 / ROW_ALIGN];                   // a tile never straddles two poses
+    const int self = row - row0;
+    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
+    double* lu = dyn;
+
+    // ================= phase 1: every global load this launch needs is requested up front (the
+    // launch is a chain of dependent round trips otherwise: partials -> vectors -> records)
+    double v[3] = {0, 0, 0};
+    if (it > 0) {
+        for (int q = tid; q < P.n_regblk; q += BLK) {
+            v[0] += part_in[(size_t)q * NPART];
+            v[1] += part_in[(size_t)q * NPART + 1];
+            v[2] += part_in[(size_t)q * NPART + 2];
+        }
+        for (int i = tid; i < 6 * P.K; i += BLK) {
+            const int k = i / 6, a = i % 6;
+            const double ua = up_in[i];
+            v[0] += rp_in[i] * ua;
+            double sacc = lam * ua;
+            for (int c = 0; c < 6; ++c) {
+                const int lo = a < c ? a : c, hi = a < c ? c : a;
+                const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+                sacc += P.Hpp[21 * k + pk] * up_in[6 * k + c];
+            }
+            v[1] += ua * sacc;
+        }
+    }
+    // own row (one thread per row) and first halo row of this thread
+    const bool own = tid < P.tile_rows;
+    const size_t orow = (size_t)(row0 + (own ? tid : 0));
+    double o_u[3], o_p[3], o_w[3], o_s[3], o_r[3], o_x[3], o_D[6];
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    const bool hh = tid < hn;
+    const size_t hrow = hh ? (size_t)P.halo_rows[hb + tid] : 0;
+    double h_w[3], h_s[3], h_r[3], h_D[6];
+    if (it > 0) {
+        if (own) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o_u[k] = P.uv3[3 * orow + k]; o_p[k] = P.pv[3 * orow + k]; o_w[k] = w_in[3 * orow + k];
+                o_s[k] = s_in[3 * orow + k]; o_r[k] = r_in[3 * orow + k]; o_x[k] = P.xv[3 * orow + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o_D[k] = P.Dinv[6 * orow + k];
+        }
+        if (hh) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { h_w[k] = w_in[3 * hrow + k]; h_s[k] = s_in[3 * hrow + k]; h_r[k] = r_in[3 * hrow + k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) h_D[k] = P.Dinv[6 * hrow + k];
+        }
+    } else {
+        stage_rows(P, b, tid, P.uv3, nullptr, lu);
+    }
+    // row blocks and first record chunks
+    double Dr[6] = {0, 0, 0, 0, 0, 0};
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Dr[k] = P.D[6 * (size_t)row + k];
+    }
+    constexpr int NPC = (6 + T - 1) / T;                          // pose components per lane
+    double e_[NPC][3];
+    {
+        int np = 0;
+#pragma unroll
+        for (int p = t; p < 6; p += T) {
+            e_[np][0] = P.Hpl[(size_t)(p * 3) * P.n_rows + row];
+            e_[np][1] = P.Hpl[(size_t)(p * 3 + 1) * P.n_rows + row];
+            e_[np][2] = P.Hpl[(size_t)(p * 3 + 2) * P.n_rows + row];
+            ++np;
+        }
+    }
+    const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
+    const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
+    double2 ga[U];
+    double g2[U];
+    int so[U];
+    DamperRec dr[U];
+    auto load_springs = [&](int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            so[q] = REC_NONE;
+            if (j < send) {
+                const SpringRec* rc = P.s_rec + j;
+                ga[q] = *reinterpret_cast<const double2*>(rc);
+                g2[q] = rc->g2;
+                so[q] = rc->other;
+            }
+        }
+    };
+    auto load_dampers = [&](int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            dr[q].meta = REC_NONE;
+            if (j < dend) dr[q] = P.d_rec[j];
+        }
+    };
+    load_springs(sbeg + lane);
+    load_dampers(dbeg + lane);
+
+    // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
+    double alpha = 0, beta = 0;
+    if (it > 0) {
+        block_sum<3>(v, lds, lane, wave);
+        const double gamma = v[0], delta = v[1] + v[2];
+        const int ip = it - 1;                                     // PCG iteration these scalars belong to
+        const double* slot = P.scal + ((ip & 1) ? SC_SLOT1 : SC_SLOT0);
+        double* nslot = P.scal + ((ip & 1) ? SC_SLOT0 : SC_SLOT1);
+        const double gamma0 = ip == 0 ? gamma : P.scal[SC_GAMMA0];
+        const bool bad = !isfinite(gamma) || !isfinite(delta);
+        const bool conv = (gamma <= tol2 * gamma0) || bad || gamma == 0.0;
+        if (conv) {
+            if (blockIdx.x == 0 && tid == 0) {
+                if (bad) P.flags[2] = 1;
+                P.flags[1] = ip;
+                __threadfence();
+                P.flags[0] = 1;
+            }
+            return;
+        }
+        beta = ip == 0 ? 0.0 : gamma / slot[0];
+        alpha = ip == 0 ? gamma / delta : gamma / (delta - beta * gamma / slot[1]);
+        if (blockIdx.x == 0 && tid == 0) {
+            nslot[0] = gamma;
+            nslot[1] = alpha;
+            if (ip == 0) P.scal[SC_GAMMA0] = gamma;
+            P.flags[1] = ip + 1;
+            if (gamma <= peek_tol2 * gamma0) P.flags[3] = 1;
+        }
+    }
+    // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
+    // it, the first workgroup of the pose also stores the pose part of the state)
+    if (wave == 0) {
+        const int a = lane < 6 ? lane : 0;
+        const int i = 6 * kf + a;
+        double unew = up_in[i];
+        if (it > 0) {
+            const int rb = ROW_ALIGN / (BLK / P.T);
+            const int g0 = P.pose_grp_ptr[kf] * rb, g1 = P.pose_grp_ptr[kf + 1] * rb;
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int g = g0 + lane; g < g1; g += 64) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[c] += part_in[(size_t)g * NPART + 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
+            double hw = acc[0];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) hw = (a == q) ? acc[q] : hw;
+            const double ua = up_in[i];
+            double w = lam * ua + hw;
+            for (int c = 0; c < 6; ++c) {
+                const int lo = a < c ? a : c, hi = a < c ? c : a;
+                const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+                w += P.Hpp[21 * kf + pk] * up_in[6 * kf + c];
+            }
+            const double sN = w + beta * sp_in[i];
+            const double rnew = rp_in[i] - alpha * sN;
+            unew = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) unew += P.Hppinv[36 * kf + a * 6 + c] * __shfl(rnew, c, 64);
+            if (lane < 6 && b == P.pose_grp_ptr[kf] * rb) {
+                const double p = ua + beta * P.pp[i];
+                P.pp[i] = p;
+                P.xp[i] += alpha * p;
+                sp_out[i] = sN;
+                rp_out[i] = rnew;
+                up_out[i] = unew;
+            }
+        }
+        if (lane < 6) s_up[lane] = unew;
+    }
+    // ================= phase 4: u of the tile (own rows: full update, stored; halo rows:
+    // recomputed from r, s, w, M^-1, LDS only)
+    double dot_ru = 0;                                             // r.u of this thread's own row (after the update)
+    if (it > 0) {
+        if (own) {
+            double rn[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double p = o_u[k] + beta * o_p[k];
+                const double sN = o_w[k] + beta * o_s[k];
+                P.pv[3 * orow + k] = p;
+                s_out[3 * orow + k] = sN;
+                P.xv[3 * orow + k] = o_x[k] + alpha * p;
+                rn[k] = o_r[k] - alpha * sN;
+                r_out[3 * orow + k] = rn[k];
+            }
+            const double u0 = o_D[0] * rn[0] + o_D[1] * rn[1] + o_D[2] * rn[2];
+            const double u1 = o_D[1] * rn[0] + o_D[3] * rn[1] + o_D[4] * rn[2];
+            const double u2 = o_D[2] * rn[0] + o_D[4] * rn[1] + o_D[5] * rn[2];
+            P.uv3[3 * orow] = u0; P.uv3[3 * orow + 1] = u1; P.uv3[3 * orow + 2] = u2;
+            lu[3 * tid] = u0; lu[3 * tid + 1] = u1; lu[3 * tid + 2] = u2;
+            dot_ru = rn[0] * u0 + rn[1] * u1 + rn[2] * u2;
+        }
+        for (int i = tid; i < hn; i += BLK) {
+            if (i != tid) {                                        // beyond the prefetched one (large halos only)
+                const size_t r2 = (size_t)P.halo_rows[hb + i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { h_w[k] = w_in[3 * r2 + k]; h_s[k] = s_in[3 * r2 + k]; h_r[k] = r_in[3 * r2 + k]; }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) h_D[k] = P.Dinv[6 * r2 + k];
+            }
+            double rn[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rn[k] = h_r[k] - alpha * (h_w[k] + beta * h_s[k]);
+            double* dst = lu + 3 * (size_t)(P.tile_rows + i);
+            dst[0] = h_D[0] * rn[0] + h_D[1] * rn[1] + h_D[2] * rn[2];
+            dst[1] = h_D[1] * rn[0] + h_D[3] * rn[1] + h_D[4] * rn[2];
+            dst[2] = h_D[2] * rn[0] + h_D[4] * rn[1] + h_D[5] * rn[2];
+        }
+    }
+    __syncthreads();
+    // ================= phase 5: operator apply on the staged u (k_spmv, LDS path)
+    const double* u = lu;
+    double a0 = 0, a1 = 0, a2 = 0;
+    double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double ul0 = u[3 * self], ul1 = u[3 * self + 1], ul2 = u[3 * self + 2];
+    {
+        if (t == 0) {
+            a0 = (Dr[0] + lam) * ul0 + Dr[1] * ul1 + Dr[2] * ul2;
+            a1 = Dr[1] * ul0 + (Dr[3] + lam) * ul1 + Dr[4] * ul2;
+            a2 = Dr[2] * ul0 + Dr[4] * ul1 + (Dr[5] + lam) * ul2;
+        }
+        double h0 = 0, h1 = 0, h2 = 0;
+        int q = 0;
+#pragma unroll
+        for (int p = t; p < 6; p += T) {
+            const double upk = s_up[p];
+            h0 += e_[q][0] * upk; h1 += e_[q][1] * upk; h2 += e_[q][2] * upk;
+            part[3 + p] = e_[q][0] * ul0 + e_[q][1] * ul1 + e_[q][2] * ul2;
+            ++q;
+        }
+        a0 += h0; a1 += h1; a2 += h2;
+        part[2] = ul0 * h0 + ul1 * h1 + ul2 * h2;
+    }
+    for (int idx = sbeg + lane; idx < send; idx += 64 * U) {
+        if (idx != sbeg + lane) load_springs(idx);
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (so[q] == REC_NONE) continue;
+            const double dot = ga[q].x * u[3 * so[q]] + ga[q].y * u[3 * so[q] + 1] + g2[q] * u[3 * so[q] + 2];
+            a0 -= ga[q].x * dot; a1 -= ga[q].y * dot; a2 -= g2[q] * dot;
+        }
+    }
+    for (int idx = dbeg + lane; idx < dend; idx += 64 * U) {
+        if (idx != dbeg + lane) load_dampers(idx);
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (dr[q].meta == REC_NONE || (dr[q].meta & DM_UNARY)) continue;
+            const int role = dr[q].meta & 3;
+            const uint16_t o[3] = {dr[q].o0, dr[q].o1, dr[q].o2};
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double sg = damper_sign(k + (k >= role ? 1 : 0));
+                if (o[k] != REC_NONE) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
+            }
+            const double c = damper_sign(role) * dr[q].s;
+            a0 += c * s0; a1 += c * s1; a2 += c * s2;
+        }
+    }
+    a0 = sub_sum(a0, T); a1 = sub_sum(a1, T); a2 = sub_sum(a2, T);
+    if (t == 0) {
+        w_out[3 * row] = a0; w_out[3 * row + 1] = a1; w_out[3 * row + 2] = a2;
+        if (it == 0) part[0] = r_out[3 * row] * ul0 + r_out[3 * row + 1] * ul1 + r_out[3 * row + 2] * ul2;
+        part[1] = a0 * ul0 + a1 * ul1 + a2 * ul2;
+    }
+    part[0] += dot_ru;
+    block_sum_store<9>(part, lds, tid, part_out + (size_t)b * NPART);
+}
+
+// =====================================================================================
 // trial state = state (+) x ;  partial of computeScale: sum_j x_j (lambda x_j + b_j)
 // (levenberg.cpp:167-174; LandmarkVertex::oplusImpl landmark_vertex.cc:40-43)
 // =====================================================================================
@@ -1013,6 +1326,9 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     for (auto p : pv) *p = A.get<double>(6 * K);
     double** rvv[] = {&d.xv, &d.rv, &d.uv3, &d.pv, &d.sv, &d.wv};
     for (auto p : rvv) *p = A.get<double>(3 * nr);
+    d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
+    d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
+    d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
     d.part_spmv = A.get<double>(NPART * (size_t)d.n_regblk);
@@ -1272,6 +1588,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.use_lds = 1;
     const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
     if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
+    d.fused = (d.use_lds && d.n_rows < 32768 && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     mark("halo");
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
@@ -1509,6 +1827,18 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, bool stop_at_peek, int
     while (true) {
         const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
         for (; it < stop; ++it) {
+            if (d.fused) {
+                const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
+                const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
+                switch (d.T) {
+                    case 1: hipLaunchKernelGGL((k_pcg_fused<1>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                    case 2: hipLaunchKernelGGL((k_pcg_fused<2>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                    case 4: hipLaunchKernelGGL((k_pcg_fused<4>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                    case 16: hipLaunchKernelGGL((k_pcg_fused<16>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                    default: hipLaunchKernelGGL((k_pcg_fused<8>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                }
+                continue;
+            }
             {
                 Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
                 launch_spmv(c, d, lam);
