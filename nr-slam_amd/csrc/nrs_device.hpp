@@ -174,10 +174,40 @@ __device__ inline void huber(double e, double delta, double& rho0, double& rho1)
     }
 }
 
-// ---- wave64 / block reductions (fp64).  Butterfly so that every lane holds the total.
+// ---- wave64 reductions (fp64) on DPP cross-lane moves.  hipcc lowers __shfl_xor to ds_bpermute
+// (an LDS-pipe round trip per 32-bit half and step: 12 per double); the DPP forms below are plain
+// VALU moves.  Fixed combination order => bit-reproducible.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// sum over the 64 lanes; every lane receives the total
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_mov<DPP_QUAD_1032>(v);
+    v += dpp_mov<DPP_QUAD_2301>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);                   // every lane of a 16-lane row holds the row sum
+    v += dpp_mov<DPP_ROW_BCAST15, 0xa>(v);             // rows 1 and 3 += rows 0 and 2
+    v += dpp_mov<DPP_ROW_BCAST31, 0xc>(v);             // rows 2 and 3 += lane 31 (rows 0+1): lane 63 = total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over aligned groups of T lanes (T = 1, 2, 4, 8, 16); every lane of a group receives its sum
+template <int T>
+__device__ inline double group_sum(double v) {
+    if (T >= 2) v += dpp_mov<DPP_QUAD_1032>(v);
+    if (T >= 4) v += dpp_mov<DPP_QUAD_2301>(v);
+    if (T >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    if (T >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
 }
 

@@ -164,10 +164,8 @@ __device__ inline void block_sum_store(const double* v, double* lds /* 4*N */, i
     if (tid < N) out[tid] = lds[tid] + lds[N + tid] + lds[2 * N + tid] + lds[3 * N + tid];
 }
 
-__device__ inline double sub_sum(double v, int T) {      // reduce over the T lanes of a row
-    for (int off = 1; off < T; off <<= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+template <int T>
+__device__ inline double sub_sum_t(double v) { return group_sum<T>(v); }   // reduce over the T lanes of a row
 
 __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double lam, double* o) {
     const double a = d[0] + lam, b = d[1], c = d[2], e = d[3] + lam, f = d[4], g = d[5] + lam;
@@ -442,9 +440,9 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     part[1] = 0;
     if (LIN) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) D[k] = sub_sum(D[k], T);
+        for (int k = 0; k < 6; ++k) D[k] = sub_sum_t<T>(D[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bb[k] = sub_sum(bb[k], T);
+        for (int k = 0; k < 3; ++k) bb[k] = sub_sum_t<T>(bb[k]);
         if (t == 0) {
             double* Dr = P.D + 6 * (size_t)row;
             double dd[6];
@@ -716,7 +714,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
             }
         }
     }
-    a0 = sub_sum(a0, T); a1 = sub_sum(a1, T); a2 = sub_sum(a2, T);
+    a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         P.wv[3 * row] = a0; P.wv[3 * row + 1] = a1; P.wv[3 * row + 2] = a2;
         part[0] = P.rv[3 * row] * ul0 + P.rv[3 * row + 1] * ul1 + P.rv[3 * row + 2] * ul2;
@@ -1175,7 +1173,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     }
-    a0 = sub_sum(a0, T); a1 = sub_sum(a1, T); a2 = sub_sum(a2, T);
+    a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         w_out[3 * row] = a0; w_out[3 * row + 1] = a1; w_out[3 * row + 2] = a2;
         if (it == 0) part[0] = r_out[3 * row] * ul0 + r_out[3 * row + 1] * ul1 + r_out[3 * row + 2] * ul2;
