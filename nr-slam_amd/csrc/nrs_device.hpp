@@ -57,6 +57,8 @@ __host__ __device__ inline void quat_rotate(const double* q, const double* v, do
 }
 
 __host__ __device__ inline void R_to_quat(const double* R, double* q) {
+    // Eigen's matrix -> quaternion conversion; the three "largest diagonal" cases are spelled out
+    // so that no array is indexed dynamically (dynamic indices put q/R in scratch memory on the GPU)
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
@@ -65,17 +67,27 @@ __host__ __device__ inline void R_to_quat(const double* R, double* q) {
         q[0] = (R[7] - R[5]) * t;
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-        q[i] = 0.5 * t;
+    } else if (!(R[4] > R[0]) && !(R[8] > R[0])) {                 // i = 0, j = 1, k = 2
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t;
         t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[3] = (R[7] - R[5]) * t;
+        q[1] = (R[3] + R[1]) * t;
+        q[2] = (R[6] + R[2]) * t;
+    } else if ((R[4] > R[0]) && !(R[8] > R[4])) {                  // i = 1, j = 2, k = 0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t;
+        q[2] = (R[7] + R[5]) * t;
+        q[0] = (R[1] + R[3]) * t;
+    } else {                                                        // i = 2, j = 0, k = 1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t;
+        q[0] = (R[2] + R[6]) * t;
+        q[1] = (R[5] + R[7]) * t;
     }
 }
 

@@ -337,101 +337,127 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     }
     double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
     // ---- springs
+    const size_t nz = (size_t)P.ss_nnz;
+    auto spring = [&](int idx, int o, int meta, double d0) {
+        if (!(meta & SM_ACTIVE)) {
+            if (LIN) {
+                if (LDS) { P.s_rec[idx].g0 = 0; P.s_rec[idx].g1 = 0; P.s_rec[idx].g2 = 0; }
+                else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+            }
+            return;
+        }
+        double y0, y1, y2;
+        if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
+        else {
+            y0 = xl[3 * o]; y1 = xl[3 * o + 1]; y2 = xl[3 * o + 2];
+            if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
+        }
+        const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
+        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        const double r = P.k_spring * (d - d0) / d0;
+        double rho0, rho1;
+        huber(P.info_pos * r * r, P.delta_pos, rho0, rho1);
+        if (meta & SM_COUNT) chi += rho0;
+        if (LIN) {
+            const double cg = P.spring_form == 0 ? (P.k_spring / d0) * (1.0 / sqrt(d)) * 2.0
+                                                 : (P.k_spring / (2 * d0 * d)) * 2.0;
+            const double q = rfix ? 0.0 : rho1 * P.info_pos;
+            const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
+            const double sq = sqrt(q);
+            if (LDS) { P.s_rec[idx].g0 = sq * g0; P.s_rec[idx].g1 = sq * g1; P.s_rec[idx].g2 = sq * g2; }
+            else { P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
+            D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
+            D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
+            const double qr = q * r;
+            bb[0] -= qr * g0; bb[1] -= qr * g1; bb[2] -= qr * g2;
+        }
+    };
     {
         const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
-        const size_t nz = (size_t)P.ss_nnz;
-        for (int idx = beg + lane; idx < end; idx += 64) {
-            int o, meta;
-            double d0;
-            if (LDS) {
-                const SpringRec* rc = P.s_rec + idx;
-                o = rc->other;
-                if (o == REC_NONE) continue;
-                meta = ((rc->meta & SR_ACTIVE) ? SM_ACTIVE : 0) | ((rc->meta & SR_COUNT) ? SM_COUNT : 0);
-                d0 = (double)rc->d0;
-            } else {
-                o = P.s_other[idx];
-                if (o < 0) continue;
-                meta = P.s_meta[idx];
-                d0 = (double)P.s_d0[idx];
-            }
-            if (!(meta & SM_ACTIVE)) {
-                if (LIN) {
-                    if (LDS) { P.s_rec[idx].g0 = 0; P.s_rec[idx].g1 = 0; P.s_rec[idx].g2 = 0; }
-                    else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+        if (LDS) {
+            constexpr int U = 4;                                   // record headers are streamed 4 steps ahead
+            for (int idx = beg + lane; idx < end; idx += 64 * U) {
+                uint2 hdr[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int j = idx + 64 * q;
+                    hdr[q] = make_uint2(0xFFFFu, 0u);
+                    if (j < end) hdr[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 24);
                 }
-                continue;
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int o = (int)(hdr[q].x & 0xFFFFu), m16 = (int)(hdr[q].x >> 16);
+                    if (o == REC_NONE) continue;
+                    const int meta = ((m16 & SR_ACTIVE) ? SM_ACTIVE : 0) | ((m16 & SR_COUNT) ? SM_COUNT : 0);
+                    spring(idx + 64 * q, o, meta, (double)__uint_as_float(hdr[q].y));
+                }
             }
-            double y0, y1, y2;
-            if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
-            else {
-                y0 = xl[3 * o]; y1 = xl[3 * o + 1]; y2 = xl[3 * o + 2];
-                if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
-            }
-            const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
-            const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-            const double r = P.k_spring * (d - d0) / d0;
-            double rho0, rho1;
-            huber(P.info_pos * r * r, P.delta_pos, rho0, rho1);
-            if (meta & SM_COUNT) chi += rho0;
-            if (LIN) {
-                const double cg = P.spring_form == 0 ? (P.k_spring / d0) * (1.0 / sqrt(d)) * 2.0
-                                                     : (P.k_spring / (2 * d0 * d)) * 2.0;
-                const double q = rfix ? 0.0 : rho1 * P.info_pos;
-                const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
-                const double sq = sqrt(q);
-                if (LDS) { P.s_rec[idx].g0 = sq * g0; P.s_rec[idx].g1 = sq * g1; P.s_rec[idx].g2 = sq * g2; }
-                else { P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
-                D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
-                D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
-                const double qr = q * r;
-                bb[0] -= qr * g0; bb[1] -= qr * g1; bb[2] -= qr * g2;
+        } else {
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int o = P.s_other[idx];
+                if (o < 0) continue;
+                spring(idx, o, P.s_meta[idx], (double)P.s_d0[idx]);
             }
         }
     }
     // ---- dampers: r = w((x1n - x1c) - (x2n - x2c)), roles (1c,2c,1n,2n), signs (-,+,+,-)
+    auto damper = [&](int idx, int meta, const int* o, double w) {
+        if (!(meta & DM_ACTIVE)) {
+            if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
+            return;
+        }
+        const int role = meta & 3;
+        const double sgn_own = damper_sign(role);
+        double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double sg = damper_sign(k + (k >= role ? 1 : 0));   // role of the k-th other vertex
+            if (o[k] >= 0) {
+                s0 += sg * xl[3 * o[k]]; s1 += sg * xl[3 * o[k] + 1]; s2 += sg * xl[3 * o[k] + 2];
+            }
+        }
+        const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
+        double rho0, rho1;
+        huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho0, rho1);
+        if (meta & DM_COUNT) chi += rho0;
+        if (LIN) {
+            const double fx = rfix ? 0.0 : 1.0;
+            const double sfac = fx * rho1 * P.info_spatial * w * w;
+            if (LDS) P.d_rec[idx].s = sfac; else P.d_s[idx] = sfac;
+            D[0] += sfac; D[3] += sfac; D[5] += sfac;
+            const double c = fx * sgn_own * rho1 * P.info_spatial * w;
+            bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
+        }
+    };
     {
         const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
-        for (int idx = beg + lane; idx < end; idx += 64) {
-            int meta, o[3];
-            if (LDS) {
-                const DamperRec* rc = P.d_rec + idx;
-                if (rc->meta == REC_NONE) continue;
-                meta = rc->meta;
-                o[0] = rc->o0 == REC_NONE ? -1 : rc->o0;
-                o[1] = rc->o1 == REC_NONE ? -1 : rc->o1;
-                o[2] = rc->o2 == REC_NONE ? -1 : rc->o2;
-            } else {
-                meta = P.d_meta[idx];
-                if (meta < 0) continue;
-                o[0] = P.d_o0[idx]; o[1] = P.d_o1[idx]; o[2] = P.d_o2[idx];
-            }
-            if (!(meta & DM_ACTIVE)) {
-                if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
-                continue;
-            }
-            const int role = meta & 3;
-            const double w = (double)P.d_w[idx];
-            const double sgn_own = damper_sign(role);
-            double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
+        if (LDS) {
+            constexpr int U = 4;
+            for (int idx = beg + lane; idx < end; idx += 64 * U) {
+                uint2 hdr[U];
+                float ww[U];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double sg = damper_sign(k + (k >= role ? 1 : 0));   // role of the k-th other vertex
-                if (o[k] >= 0) {
-                    s0 += sg * xl[3 * o[k]]; s1 += sg * xl[3 * o[k] + 1]; s2 += sg * xl[3 * o[k] + 2];
+                for (int q = 0; q < U; ++q) {
+                    const int j = idx + 64 * q;
+                    hdr[q] = make_uint2(0u, 0xFFFF0000u);
+                    ww[q] = 0.f;
+                    if (j < end) { hdr[q] = *reinterpret_cast<const uint2*>(P.d_rec + j); ww[q] = P.d_w[j]; }
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int m16 = (int)(hdr[q].y >> 16);
+                    if (m16 == REC_NONE) continue;
+                    const int r0 = (int)(hdr[q].x & 0xFFFFu), r1 = (int)(hdr[q].x >> 16), r2 = (int)(hdr[q].y & 0xFFFFu);
+                    const int o[3] = {r0 == REC_NONE ? -1 : r0, r1 == REC_NONE ? -1 : r1, r2 == REC_NONE ? -1 : r2};
+                    damper(idx + 64 * q, m16, o, (double)ww[q]);
                 }
             }
-            const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
-            double rho0, rho1;
-            huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho0, rho1);
-            if (meta & DM_COUNT) chi += rho0;
-            if (LIN) {
-                const double fx = rfix ? 0.0 : 1.0;
-                const double s = fx * rho1 * P.info_spatial * w * w;
-                if (LDS) P.d_rec[idx].s = s; else P.d_s[idx] = s;
-                D[0] += s; D[3] += s; D[5] += s;
-                const double c = fx * sgn_own * rho1 * P.info_spatial * w;
-                bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
+        } else {
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int meta = P.d_meta[idx];
+                if (meta < 0) continue;
+                const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
+                damper(idx, meta, o, (double)P.d_w[idx]);
             }
         }
     }
