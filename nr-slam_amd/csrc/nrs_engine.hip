@@ -98,6 +98,10 @@ struct Dev {
     // second halves of the ping-pong pairs used by the fused small-problem iteration
     double *rp2, *sp2, *up2, *rv2, *sv2, *wv2, *part_spmv2;
     int fused;
+    // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
+    // being re-summed by every workgroup of the update kernel (which is O(workgroups^2) reads)
+    int hier;
+    double* red;                     // [0..2] r.u, w.u, cross ; [3 + 6k + a] pose sums
     // partials / scalars
     double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
     double* part_reg;                // n_regblk x 2    (chi, maxdiag)
@@ -750,6 +754,40 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
 }
 
 // =====================================================================================
+// large problems only: fixed-order reduction of the SpMV partials.  Workgroup 0: the three dot
+// partials over all workgroups; workgroup 1 + k: the six pose sums of pose k.
+// =====================================================================================
+__global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
+    __shared__ double lds[4 * 6];
+    if (P.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0) {
+        double v[3] = {0, 0, 0};
+        for (int b = tid; b < P.n_regblk; b += BLK) {
+            v[0] += P.part_spmv[(size_t)b * NPART];
+            v[1] += P.part_spmv[(size_t)b * NPART + 1];
+            v[2] += P.part_spmv[(size_t)b * NPART + 2];
+        }
+        block_sum<3>(v, lds, lane, wave);
+        if (tid == 0) { P.red[0] = v[0]; P.red[1] = v[1]; P.red[2] = v[2]; }
+    } else {
+        const int k = blockIdx.x - 1;
+        const int rb = ROW_ALIGN / (BLK / P.T);
+        const int g0 = P.pose_grp_ptr[k] * rb, g1 = P.pose_grp_ptr[k + 1] * rb;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int g = g0 + tid; g < g1; g += BLK) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
+        }
+        block_sum<6>(acc, lds, lane, wave);
+        if (tid == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) P.red[3 + 6 * k + a] = acc[a];
+        }
+    }
+}
+
+// =====================================================================================
 // PCG kernel 2 (Chronopoulos-Gear single-reduction CG): every workgroup re-derives the scalars
 // from the partials in a fixed order, then updates its rows:
 //   gamma = r.u, delta = w.u, beta = gamma/gamma_old, alpha = gamma/(delta - beta*gamma/alpha_old)
@@ -762,10 +800,14 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     const int n_vecblk = P.n_vecblk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v[3] = {0, 0, 0};
-    for (int b = tid; b < P.n_regblk; b += BLK) {
-        v[0] += P.part_spmv[(size_t)b * NPART];
-        v[1] += P.part_spmv[(size_t)b * NPART + 1];
-        v[2] += P.part_spmv[(size_t)b * NPART + 2];
+    if (P.hier) {
+        if (tid == 0) { v[0] = P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
+    } else {
+        for (int b = tid; b < P.n_regblk; b += BLK) {
+            v[0] += P.part_spmv[(size_t)b * NPART];
+            v[1] += P.part_spmv[(size_t)b * NPART + 1];
+            v[2] += P.part_spmv[(size_t)b * NPART + 2];
+        }
     }
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
     for (int i = tid; i < 6 * P.K; i += BLK) {
@@ -863,12 +905,17 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
             const int g0 = P.pose_grp_ptr[k] * rb, g1 = P.pose_grp_ptr[k + 1] * rb;
             double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (int g = g0 + lane; g < g1; g += 64) {
+            if (P.hier) {
 #pragma unroll
-                for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
+                for (int a = 0; a < 6; ++a) acc[a] = P.red[3 + 6 * k + a];
+            } else {
+                for (int g = g0 + lane; g < g1; g += 64) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
             }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
             // lanes 0..5 own one pose component each
             const int a = lane < 6 ? lane : 0;
             double hw = acc[0];
@@ -1353,6 +1400,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
     d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
     d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
+    d.red = A.get<double>(3 + 6 * K);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
     d.part_spmv = A.get<double>(NPART * (size_t)d.n_regblk);
@@ -1614,6 +1662,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     d.fused = (d.use_lds && d.n_rows < 32768 && !getenv("NRS_NO_FUSED")) ? 1 : 0;
+    d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     mark("halo");
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
@@ -1867,6 +1916,7 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, bool stop_at_peek, int
                 Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
                 launch_spmv(c, d, lam);
             }
+            if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
             {
                 Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
                 hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
