@@ -138,6 +138,35 @@ def test_full_size_c2_properties(ctx):
     assert np.linalg.norm(b1) < 0.5 * np.linalg.norm(b0)
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_full_size_c2_matches_oracle_golden(ctx, ctx_exact, exact):
+    """BASELINE configs[1] at full size against tests/golden/dba_C2_trace.npz: the oracle's LM on the
+    complete problem (linear solves by NumPy PCG to 1e-12, tests/golden/make_c2_golden.py, 391 s on
+    one core).  Same tolerances as the small cases."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dba_C2_trace.npz"))
+    c = ctx_exact if exact else ctx
+    p = S.make_dba_problem("C2")
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    assert len(p["lm_kf"]) == int(g["n_lm"])
+    c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    tr = nrs.Trace()
+    c.dba_optimize(5, tr)
+    pq, xyz = c.dba_download()
+    t = tr.trials
+    assert tr.iterations == int(g["out_iters"])
+    assert [x["accepted"] for x in t] == g["out_accepted"].tolist()
+    for x, chi, chi_new, lam in zip(t, g["out_chi"], g["out_chi_new"], g["out_lam"]):
+        assert abs(x["lam"] - lam) <= 1e-6 * lam and abs(x["chi"] - chi) <= 1e-6 * chi
+        if not x["early"]:
+            assert abs(x["chi_new"] - chi_new) <= 1e-6 * chi_new
+    assert np.allclose(pq[:, :4], g["out_q"], atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], g["out_t"], atol=1e-5, rtol=0)
+    assert np.allclose(xyz[g["sel"]], g["out_pts_sel"], atol=1e-4, rtol=0)
+    assert np.allclose(xyz.sum(0), g["out_pts_sum"], atol=1e-4 * np.sqrt(len(xyz)), rtol=0)
+
+
 def test_bad_arguments(ctx):
     p, e, cam, qt = _setup(60, 3, 61)
     bad = dict(e)
