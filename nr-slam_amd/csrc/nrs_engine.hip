@@ -1882,7 +1882,8 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
-constexpr double PEEK_RTOL = 1e-3;
+constexpr double PEEK_RTOL = 1e-2;      // inner-solve accuracy at which a trial is first evaluated
+constexpr double PEEK_RHO = -2.0;       // gain ratio below which it is rejected there (accept needs rho > 0)
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
@@ -1966,7 +1967,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     temp = e->h_scal[SC_CHI];
                     scale = e->h_scal[SC_SCALE] + 1e-3;
                     const double rho_peek = (chi - temp) / scale;
-                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < -0.5;
+                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO;
                 }
             }
             if (!early) {
