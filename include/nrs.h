@@ -65,8 +65,8 @@ typedef struct {
     int32_t profile;          /* 1 = time the linearise and SpMV kernels with HIP events on the
                                  context stream (serialises launches; for bench roofline only)    */
     int32_t exact_trials;     /* 0 (default): an LM trial whose gain ratio is already < -2 when the
-                                 inner solve has reached 1e-2 is rejected there (its step would be
-                                 discarded anyway; accepted steps are always solved to pcg_rtol, so
+                                 inner solve has reached 1e-2 (or < -0.5 at 1e-3) is rejected there (its
+                                 step would be discarded anyway; accepted steps are always solved to pcg_rtol, so
                                  the iterates are unchanged).  1: every trial is solved to pcg_rtol. */
 } nrs_options;
 
@@ -79,7 +79,7 @@ typedef struct {
     int32_t accepted;
     int32_t solver_ok;        /* 0 = linear solve reported "not positive definite"               */
     int32_t inner_iters;      /* PCG iterations of this trial (0 for dense 6x6 solves)           */
-    int32_t early_rejected;   /* 1 = rejected at the 1e-2 peek (chi2_new / rho are the peek values) */
+    int32_t early_rejected;   /* 1 = rejected at a peek (chi2_new / rho are the peek values) */
     int32_t reserved;
     double lambda;
     double chi2;              /* currentChi                                                      */

@@ -845,7 +845,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         nslot[1] = alpha;
         if (it == 0) P.scal[SC_GAMMA0] = gamma;
         P.flags[1] = it + 1;
-        if (gamma <= peek_tol2 * gamma0) P.flags[3] = 1;       // "peek" milestone reached (early trial rejection)
+        // "peek" milestones for early trial rejection: level 1 at peek_tol, level 2 at peek_tol/10
+        if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1);
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
@@ -1111,7 +1112,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             nslot[1] = alpha;
             if (ip == 0) P.scal[SC_GAMMA0] = gamma;
             P.flags[1] = ip + 1;
-            if (gamma <= peek_tol2 * gamma0) P.flags[3] = 1;
+            if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1);
         }
     }
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
@@ -1884,6 +1885,7 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
 constexpr double PEEK_RTOL = 1e-2;      // inner-solve accuracy at which a trial is first evaluated
 constexpr double PEEK_RHO = -2.0;       // gain ratio below which it is rejected there (accept needs rho > 0)
+constexpr double PEEK_RHO2 = -0.5;      // ... and at the second look, at PEEK_RTOL / 10
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
@@ -1893,44 +1895,50 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     return NRS_OK;
 }
 
-static int pcg_advance(nrs_ctx* c, Engine* e, double lam, bool stop_at_peek, int* it_io, bool* done) {
+// enqueue one batch of PCG iterations (no host synchronisation)
+static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io) {
     const Dev& d = e->d;
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     int it = *it_io;
-    while (true) {
-        const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
-        for (; it < stop; ++it) {
-            if (d.fused) {
-                const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
-                const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
-                switch (d.T) {
-                    case 1: hipLaunchKernelGGL((k_pcg_fused<1>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                    case 2: hipLaunchKernelGGL((k_pcg_fused<2>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                    case 4: hipLaunchKernelGGL((k_pcg_fused<4>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                    case 16: hipLaunchKernelGGL((k_pcg_fused<16>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                    default: hipLaunchKernelGGL((k_pcg_fused<8>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                }
-                continue;
+    const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
+    for (; it < stop; ++it) {
+        if (d.fused) {
+            const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
+            const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
+            switch (d.T) {
+                case 1: hipLaunchKernelGGL((k_pcg_fused<1>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                case 2: hipLaunchKernelGGL((k_pcg_fused<2>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                case 4: hipLaunchKernelGGL((k_pcg_fused<4>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                case 16: hipLaunchKernelGGL((k_pcg_fused<16>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                default: hipLaunchKernelGGL((k_pcg_fused<8>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
             }
-            {
-                Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
-                launch_spmv(c, d, lam);
-            }
-            if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
-            {
-                Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-                hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
-                                   d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-            }
+            continue;
         }
+        {
+            Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
+            launch_spmv(c, d, lam);
+        }
+        if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
+        {
+            Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
+            hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
+                               d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+        }
+    }
+    *it_io = it;
+}
+
+static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* it_io, bool* done) {
+    const Dev& d = e->d;
+    while (true) {
+        pcg_enqueue_batch(c, e, lam, it_io);
         NRS_HIP(c, hipGetLastError());
         NRS_HIP(c, hipMemcpyAsync(e->h_flags, d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
-        if (e->h_flags[0] || it >= c->opt.pcg_max_iters) { *done = true; break; }
-        if (stop_at_peek && e->h_flags[3]) { *done = false; break; }
+        if (e->h_flags[0] || *it_io >= c->opt.pcg_max_iters) { *done = true; break; }
+        if (stop_level && e->h_flags[3] >= stop_level) { *done = false; break; }
     }
-    *it_io = it;
     return NRS_OK;
 }
 
@@ -1941,6 +1949,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     NRS_HIP(c, hipSetDevice(c->device));
     Dev& d = e->d;
     double lam = -1, ni = 2;
+    bool speculate = true;
     for (int it = 0; it < iters; ++it) {
         NRS_TRY(evaluate<true>(c, e, e->cur));
         NRS_TRY(read_scalars(c, e));
@@ -1956,32 +1965,44 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             double temp = 0, scale = 0;
             bool ok = true;
             NRS_TRY(pcg_begin(c, e, lam, &pit));
-            if (!c->opt.exact_trials) {
-                // peek: a trial that is clearly going to be rejected is not solved any further --
-                // its step is discarded, so the iterate sequence is the reference's either way
-                NRS_TRY(pcg_advance(c, e, lam, true, &pit, &done));
-                if (!done) {
-                    hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
-                    NRS_TRY(evaluate<false>(c, e, trial));
-                    NRS_TRY(read_scalars(c, e));
-                    temp = e->h_scal[SC_CHI];
-                    scale = e->h_scal[SC_SCALE] + 1e-3;
-                    const double rho_peek = (chi - temp) / scale;
-                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO;
-                }
-            }
-            if (!early) {
-                if (!done) NRS_TRY(pcg_advance(c, e, lam, false, &pit, &done));
-                ok = e->h_flags[2] == 0;
-                {
-                    Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
-                    hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
-                }
+            auto eval_trial = [&]() -> int {
+                Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
+                hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
                 NRS_TRY(evaluate<false>(c, e, trial));
-                NRS_TRY(read_scalars(c, e));
-                temp = ok ? e->h_scal[SC_CHI] : 1.7976931348623157e308;
-                scale = e->h_scal[SC_SCALE] + 1e-3;
+                return read_scalars(c, e);                 // one synchronisation: chi2, scale and the PCG flags
+            };
+            const bool peeking = !c->opt.exact_trials;
+            // The first batch of PCG iterations and a speculative evaluation of its result go out
+            // together: most trials are decided by it (converged, or clearly rejected at the peek).
+            // (only while the previous trial was decided inside its first batch -- long solves skip it)
+            int seen = 0;                                  // peek levels already evaluated
+            if (speculate) {
+                pcg_enqueue_batch(c, e, lam, &pit);
+                NRS_TRY(eval_trial());
+                done = e->h_flags[0] != 0 || pit >= c->opt.pcg_max_iters;
+            } else {
+                NRS_TRY(pcg_advance(c, e, lam, peeking ? 1 : 0, &pit, &done));
+                NRS_TRY(eval_trial());
             }
+            while (true) {
+                temp = e->h_scal[SC_CHI];
+                scale = e->h_scal[SC_SCALE] + 1e-3;
+                if (done) break;
+                const int lvl = e->h_flags[3];
+                if (peeking && lvl > seen) {
+                    // peek: a trial that is clearly going to be rejected is not solved any further --
+                    // its step is discarded, so the iterate sequence is the reference's either way
+                    const double rho_peek = (chi - temp) / scale;
+                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < (lvl >= 2 ? PEEK_RHO2 : PEEK_RHO);
+                    if (early) break;
+                    seen = lvl;
+                }
+                NRS_TRY(pcg_advance(c, e, lam, peeking && seen < 2 ? seen + 1 : 0, &pit, &done));
+                NRS_TRY(eval_trial());
+            }
+            ok = e->h_flags[2] == 0;
+            if (!early && !ok) temp = 1.7976931348623157e308;
+            speculate = pit <= c->opt.pcg_batch;
             const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
             const bool accepted = !early && rho > 0 && std::isfinite(temp);

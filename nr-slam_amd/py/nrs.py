@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libnrs_hip.so")
+LIB_PATH = os.environ.get("NRS_LIB") or os.path.join(os.path.dirname(_HERE), "libnrs_hip.so")
 
 OK = 0
 STATUS_NAMES = {0: "NRS_OK", -1: "NRS_ERR_INVALID", -2: "NRS_ERR_NO_DEVICE", -3: "NRS_ERR_HIP",
