@@ -98,6 +98,8 @@ struct Dev {
     // second halves of the ping-pong pairs used by the fused small-problem iteration
     double *rp2, *sp2, *up2, *rv2, *sv2, *wv2, *part_spmv2;
     int fused;
+    int* tile_desc;                  // fused path: 8 ints per tile {pose, first tile of pose, end tile of pose, halo begin, halo count, 0,0,0}
+    int* halo_fix;                   // fused path: BLK ints per tile = the first BLK halo rows (fixed stride: no pointer chase)
     // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
     // being re-summed by every workgroup of the update kernel (which is O(workgroups^2) reads)
     int hier;
@@ -117,6 +119,7 @@ struct Engine {
     Dev d;
     Arena* arena = nullptr;
     int cur = 0;
+    int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes the next first batch)
     double* h_scal = nullptr;        // pinned host mirrors
     int* h_flags = nullptr;
     std::vector<int> vrow;           // vertex -> row
@@ -619,7 +622,6 @@ template <int T, bool LDS>
 __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
-    if (P.flags[0]) return;
     constexpr int R = 64 / T;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
     if (b >= P.n_regblk) return;
@@ -962,7 +964,6 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     __shared__ double lds[4 * 9];
     __shared__ double s_up[6];
     extern __shared__ double dyn[];
-    if (P.flags[0]) return;
     constexpr int R = 64 / T;
     constexpr int U = 4;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
@@ -983,7 +984,17 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const int row0 = b * P.tile_rows;
-    const int kf = P.grp_pose[row0 / ROW_ALIGN];                   // a tile never straddles two poses
+    // The launch is a chain of dependent memory round trips unless everything is requested at once:
+    // level 1 = whatever is addressed by the tile index alone (tile descriptor, flags, scalars, all
+    // partials, own rows, fixed-stride halo list, slice pointers), level 2 = what those address
+    // (records, halo rows, the pose's partials and vectors).  Nothing is loaded after that.
+    const int4 td = *reinterpret_cast<const int4*>(P.tile_desc + 8 * (size_t)b);
+    const int kf = td.x, pg0 = td.y, pg1 = td.z, hb = td.w;       // a tile never straddles two poses
+    const int hn = P.tile_desc[8 * (size_t)b + 4];
+    const int done_flag = P.flags[0];
+    const int ipq = it > 0 ? it - 1 : 0;                           // PCG iteration whose scalars this launch finishes
+    const double sc_gamma0 = P.scal[SC_GAMMA0];
+    const double sc_slot0 = P.scal[(ipq & 1) ? SC_SLOT1 : SC_SLOT0], sc_slot1 = P.scal[((ipq & 1) ? SC_SLOT1 : SC_SLOT0) + 1];
     const int self = row - row0;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     double* lu = dyn;
@@ -1014,9 +1025,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const bool own = tid < P.tile_rows;
     const size_t orow = (size_t)(row0 + (own ? tid : 0));
     double o_u[3], o_p[3], o_w[3], o_s[3], o_r[3], o_x[3], o_D[6];
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
     const bool hh = tid < hn;
-    const size_t hrow = hh ? (size_t)P.halo_rows[hb + tid] : 0;
+    const size_t hrow = (size_t)P.halo_fix[(size_t)b * BLK + tid];
     double h_w[3], h_s[3], h_r[3], h_D[6];
     if (it > 0) {
         if (own) {
@@ -1036,6 +1046,29 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         }
     } else {
         stage_rows(P, b, tid, P.uv3, nullptr, lu);
+    }
+    // wave 0: everything the pose-vector update of this tile's pose needs
+    const int pa = lane < 6 ? lane : 0;
+    double q_up[6], q_H[6], q_Hi[6], q_sp = 0, q_rp = 0, q_pp = 0, q_xp = 0, q_acc[6] = {0, 0, 0, 0, 0, 0};
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) q_up[c] = up_in[6 * kf + c];
+        if (it > 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int lo = pa < c ? pa : c, hi = pa < c ? c : pa;
+                const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+                q_H[c] = P.Hpp[21 * kf + pk];
+                q_Hi[c] = P.Hppinv[36 * kf + pa * 6 + c];
+            }
+            q_sp = sp_in[6 * kf + pa];
+            q_rp = rp_in[6 * kf + pa];
+            if (b == pg0) { q_pp = P.pp[6 * kf + pa]; q_xp = P.xp[6 * kf + pa]; }
+            if (pg0 + lane < pg1) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) q_acc[c] += part_in[(size_t)(pg0 + lane) * NPART + 3 + c];
+            }
+        }
     }
     // row blocks and first record chunks
     double Dr[6] = {0, 0, 0, 0, 0, 0};
@@ -1085,15 +1118,15 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     load_springs(sbeg + lane);
     load_dampers(dbeg + lane);
 
+    if (done_flag) return;
     // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
     double alpha = 0, beta = 0;
     if (it > 0) {
         block_sum<3>(v, lds, lane, wave);
         const double gamma = v[0], delta = v[1] + v[2];
         const int ip = it - 1;                                     // PCG iteration these scalars belong to
-        const double* slot = P.scal + ((ip & 1) ? SC_SLOT1 : SC_SLOT0);
         double* nslot = P.scal + ((ip & 1) ? SC_SLOT0 : SC_SLOT1);
-        const double gamma0 = ip == 0 ? gamma : P.scal[SC_GAMMA0];
+        const double gamma0 = ip == 0 ? gamma : sc_gamma0;
         const bool bad = !isfinite(gamma) || !isfinite(delta);
         const bool conv = (gamma <= tol2 * gamma0) || bad || gamma == 0.0;
         if (conv) {
@@ -1105,8 +1138,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             }
             return;
         }
-        beta = ip == 0 ? 0.0 : gamma / slot[0];
-        alpha = ip == 0 ? gamma / delta : gamma / (delta - beta * gamma / slot[1]);
+        beta = ip == 0 ? 0.0 : gamma / sc_slot0;
+        alpha = ip == 0 ? gamma / delta : gamma / (delta - beta * gamma / sc_slot1);
         if (blockIdx.x == 0 && tid == 0) {
             nslot[0] = gamma;
             nslot[1] = alpha;
@@ -1118,14 +1151,17 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
     // it, the first workgroup of the pose also stores the pose part of the state)
     if (wave == 0) {
-        const int a = lane < 6 ? lane : 0;
+        const int a = pa;
         const int i = 6 * kf + a;
-        double unew = up_in[i];
+        double ua = q_up[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) ua = (a == q) ? q_up[q] : ua;
+        double unew = ua;
         if (it > 0) {
-            const int rb = ROW_ALIGN / (BLK / P.T);
-            const int g0 = P.pose_grp_ptr[kf] * rb, g1 = P.pose_grp_ptr[kf + 1] * rb;
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (int g = g0 + lane; g < g1; g += 64) {
+            double acc[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[c] = q_acc[c];
+            for (int g = pg0 + lane + 64; g < pg1; g += 64) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) acc[c] += part_in[(size_t)g * NPART + 3 + c];
             }
@@ -1134,22 +1170,18 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             double hw = acc[0];
 #pragma unroll
             for (int q = 1; q < 6; ++q) hw = (a == q) ? acc[q] : hw;
-            const double ua = up_in[i];
             double w = lam * ua + hw;
-            for (int c = 0; c < 6; ++c) {
-                const int lo = a < c ? a : c, hi = a < c ? c : a;
-                const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
-                w += P.Hpp[21 * kf + pk] * up_in[6 * kf + c];
-            }
-            const double sN = w + beta * sp_in[i];
-            const double rnew = rp_in[i] - alpha * sN;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) w += q_H[c] * q_up[c];
+            const double sN = w + beta * q_sp;
+            const double rnew = q_rp - alpha * sN;
             unew = 0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) unew += P.Hppinv[36 * kf + a * 6 + c] * __shfl(rnew, c, 64);
-            if (lane < 6 && b == P.pose_grp_ptr[kf] * rb) {
-                const double p = ua + beta * P.pp[i];
+            for (int c = 0; c < 6; ++c) unew += q_Hi[c] * __shfl(rnew, c, 64);
+            if (lane < 6 && b == pg0) {
+                const double p = ua + beta * q_pp;
                 P.pp[i] = p;
-                P.xp[i] += alpha * p;
+                P.xp[i] = q_xp + alpha * p;
                 sp_out[i] = sN;
                 rp_out[i] = rnew;
                 up_out[i] = unew;
@@ -1401,6 +1433,8 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
     d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
     d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
+    d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
+    d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
     d.red = A.get<double>(3 + 6 * K);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
@@ -1662,7 +1696,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
     if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
-    d.fused = (d.use_lds && d.n_rows < 32768 && !getenv("NRS_NO_FUSED")) ? 1 : 0;
+    const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
+    d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     mark("halo");
     // ---- device memory: one arena allocation, reused across calls when large enough
@@ -1745,6 +1780,19 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
     NRS_TRY(h2d(c, d.halo_ptr, halo_ptr));
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
+    if (d.fused) {
+        std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
+        const int rb = ROW_ALIGN / d.tile_rows;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int kf = grp_pose[(size_t)b * d.tile_rows / ROW_ALIGN];
+            int* td = &tile_desc[8 * (size_t)b];
+            td[0] = kf; td[1] = pose_grp_ptr[kf] * rb; td[2] = pose_grp_ptr[kf + 1] * rb;
+            td[3] = halo_ptr[b]; td[4] = halo_ptr[b + 1] - halo_ptr[b];
+            for (int i = 0; i < td[4] && i < BLK; ++i) halo_fix[(size_t)b * BLK + i] = halo_rows[td[3] + i];
+        }
+        NRS_TRY(h2d(c, d.tile_desc, tile_desc));
+        NRS_TRY(h2d(c, d.halo_fix, halo_fix));
+    }
     if (!d.use_lds) {
         NRS_TRY(h2d(c, d.s_other, s_other));
         NRS_TRY(h2d(c, d.s_d0, s_d0));
@@ -1896,12 +1944,12 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
 }
 
 // enqueue one batch of PCG iterations (no host synchronisation)
-static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io) {
+static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int count = 0) {
     const Dev& d = e->d;
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     int it = *it_io;
-    const int stop = std::min(it + c->opt.pcg_batch, c->opt.pcg_max_iters);
+    const int stop = std::min(it + (count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
     for (; it < stop; ++it) {
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
@@ -1977,7 +2025,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             // (only while the previous trial was decided inside its first batch -- long solves skip it)
             int seen = 0;                                  // peek levels already evaluated
             if (speculate) {
-                pcg_enqueue_batch(c, e, lam, &pit);
+                // sized by the previous trial: one launch more than it needed detects convergence
+                // without a tail of no-op launches
+                const int first = e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch ? e->pred_iters + 1 : 0;
+                pcg_enqueue_batch(c, e, lam, &pit, first);
                 NRS_TRY(eval_trial());
                 done = e->h_flags[0] != 0 || pit >= c->opt.pcg_max_iters;
             } else {
@@ -2002,7 +2053,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             ok = e->h_flags[2] == 0;
             if (!early && !ok) temp = 1.7976931348623157e308;
-            speculate = pit <= c->opt.pcg_batch;
+            speculate = pit <= 2 * c->opt.pcg_batch;
+            if (!early) e->pred_iters = e->h_flags[1];
             const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
             const bool accepted = !early && rho > 0 && std::isfinite(temp);
