@@ -798,9 +798,39 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
 // =====================================================================================
 __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2) {
     __shared__ double lds[4 * 3];
-    if (P.flags[0]) return;
     const int n_vecblk = P.n_vecblk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Everything this launch reads is requested before the first dependent use (flag, scalars,
+    // partials, the two rows of this thread): otherwise the launch is a chain of four round trips.
+    const int done_flag = P.flags[0];
+    const double sc_gamma0 = P.scal[SC_GAMMA0];
+    const double sc_slot0 = P.scal[(it & 1) ? SC_SLOT1 : SC_SLOT0], sc_slot1 = P.scal[((it & 1) ? SC_SLOT1 : SC_SLOT0) + 1];
+    const int n_vec2 = (n_vecblk + 1) >> 1;
+    const int n_vec8 = ((n_vec2 + 7) >> 3) << 3;
+    const bool row_wg = (int)blockIdx.x < n_vec8;
+    const int pair = row_wg ? xcd_tile(blockIdx.x, n_vec2) * BLK + tid : 0;
+    const bool has_rows = row_wg && 2 * pair < P.n_rows;
+    const size_t o = 6 * (size_t)pair;
+    double uu[6], pp[6], ww[6], ss[6], rr[6], xx[6], Di[12];
+    if (has_rows) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double2 a = *reinterpret_cast<const double2*>(P.uv3 + o + 2 * k);
+            const double2 b = *reinterpret_cast<const double2*>(P.pv + o + 2 * k);
+            const double2 c = *reinterpret_cast<const double2*>(P.wv + o + 2 * k);
+            const double2 d = *reinterpret_cast<const double2*>(P.sv + o + 2 * k);
+            const double2 e = *reinterpret_cast<const double2*>(P.rv + o + 2 * k);
+            const double2 f = *reinterpret_cast<const double2*>(P.xv + o + 2 * k);
+            uu[2 * k] = a.x; uu[2 * k + 1] = a.y; pp[2 * k] = b.x; pp[2 * k + 1] = b.y;
+            ww[2 * k] = c.x; ww[2 * k + 1] = c.y; ss[2 * k] = d.x; ss[2 * k + 1] = d.y;
+            rr[2 * k] = e.x; rr[2 * k + 1] = e.y; xx[2 * k] = f.x; xx[2 * k + 1] = f.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double2 a = *reinterpret_cast<const double2*>(P.Dinv + 2 * o + 2 * k);
+            Di[2 * k] = a.x; Di[2 * k + 1] = a.y;
+        }
+    }
     double v[3] = {0, 0, 0};
     if (P.hier) {
         if (tid == 0) { v[0] = P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
@@ -824,11 +854,11 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         }
         v[1] += ua * s;
     }
+    if (done_flag) return;
     block_sum<3>(v, lds, lane, wave);
     const double gamma = v[0], delta = v[1] + v[2];
-    const double* slot = P.scal + ((it & 1) ? SC_SLOT1 : SC_SLOT0);
     double* nslot = P.scal + ((it & 1) ? SC_SLOT0 : SC_SLOT1);
-    const double gamma0 = it == 0 ? gamma : P.scal[SC_GAMMA0];
+    const double gamma0 = it == 0 ? gamma : sc_gamma0;
     const bool bad = !isfinite(gamma) || !isfinite(delta);
     const bool conv = (gamma <= tol2 * gamma0) || bad || gamma == 0.0;
     if (conv) {
@@ -840,8 +870,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         }
         return;
     }
-    const double beta = it == 0 ? 0.0 : gamma / slot[0];
-    const double alpha = it == 0 ? gamma / delta : gamma / (delta - beta * gamma / slot[1]);
+    const double beta = it == 0 ? 0.0 : gamma / sc_slot0;
+    const double alpha = it == 0 ? gamma / delta : gamma / (delta - beta * gamma / sc_slot1);
     if (blockIdx.x == 0 && tid == 0) {
         nslot[0] = gamma;
         nslot[1] = alpha;
@@ -852,31 +882,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
-    const int n_vec2 = (n_vecblk + 1) >> 1;
-    const int n_vec8 = ((n_vec2 + 7) >> 3) << 3;
-    if ((int)blockIdx.x < n_vec8) {
-        const int pair = xcd_tile(blockIdx.x, n_vec2) * BLK + tid;
-        if (2 * pair < P.n_rows) {
-            const size_t o = 6 * (size_t)pair;
-            double uu[6], pp[6], ww[6], ss[6], rr[6], xx[6];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double2 a = *reinterpret_cast<const double2*>(P.uv3 + o + 2 * k);
-                const double2 b = *reinterpret_cast<const double2*>(P.pv + o + 2 * k);
-                const double2 c = *reinterpret_cast<const double2*>(P.wv + o + 2 * k);
-                const double2 d = *reinterpret_cast<const double2*>(P.sv + o + 2 * k);
-                const double2 e = *reinterpret_cast<const double2*>(P.rv + o + 2 * k);
-                const double2 f = *reinterpret_cast<const double2*>(P.xv + o + 2 * k);
-                uu[2 * k] = a.x; uu[2 * k + 1] = a.y; pp[2 * k] = b.x; pp[2 * k + 1] = b.y;
-                ww[2 * k] = c.x; ww[2 * k + 1] = c.y; ss[2 * k] = d.x; ss[2 * k + 1] = d.y;
-                rr[2 * k] = e.x; rr[2 * k + 1] = e.y; xx[2 * k] = f.x; xx[2 * k + 1] = f.y;
-            }
-            double Di[12];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const double2 a = *reinterpret_cast<const double2*>(P.Dinv + 2 * o + 2 * k);
-                Di[2 * k] = a.x; Di[2 * k + 1] = a.y;
-            }
+    if (row_wg) {
+        if (has_rows) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 pp[k] = uu[k] + beta * pp[k];
