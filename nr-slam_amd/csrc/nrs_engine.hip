@@ -50,9 +50,12 @@ constexpr int DM_COUNT = 1 << 2;     // damper: bits 0-1 role
 constexpr int DM_ACTIVE = 1 << 3;
 constexpr int DM_UNARY = 1 << 4;     // damper: the other vertex is a value, not a variable
 
-// packed incidence records of the LDS-staged path: one 16-byte load per damper incidence, two per
-// spring incidence; neighbour ids are tile-local (own rows, then halo)
-struct __attribute__((aligned(16))) SpringRec { double g0, g1, g2; uint16_t other, meta; float d0; };   // 32 B
+// packed incidence records of the LDS-staged path: one 16-byte load per incidence; neighbour ids
+// are tile-local (own rows, then halo).  The operator is applied in factored form: a spring block is
+// qc * v v^T with v = x_i - x_j re-formed from the staged linearisation point (qc = rho' Omega cg^2),
+// a reprojection block is J^T w J with J rebuilt from the fp32 projection Jacobian kept per row.
+struct __attribute__((aligned(16))) SpringRec { double qc; uint16_t other, meta; float d0; };   // 16 B
+struct __attribute__((aligned(16))) RowRec { float J[6]; double w; };                           // 32 B
 struct __attribute__((aligned(16))) DamperRec { uint16_t o0, o1, o2, meta; double s; };                  // 16 B
 constexpr uint16_t REC_NONE = 0xFFFF;
 constexpr uint16_t SR_ACTIVE = 1, SR_COUNT = 2;
@@ -81,12 +84,14 @@ struct Dev {
     int use_lds, tile_rows, max_halo;
     int* halo_ptr; int* halo_rows;
     SpringRec* s_rec; DamperRec* d_rec;
+    RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
+    Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
     // state (two copies: current / trial, swapped on accept)
     Pose* pose[2]; double* xl[2];
     Pose* pose_init; double* xl_init;
     // linearisation
     double* D;                       // n_rows x 6   (xx xy xz yy yz zz)
-    double* Hpl;                     // 18 x n_rows  (component-major)
+    double* Hpl;                     // 18 x n_rows  (component-major; gather fallback path only)
     double* s_g;                     // 3 x nnz_s
     double* d_s;                     // nnz_d
     double* Hpp;                     // K x 21
@@ -199,6 +204,60 @@ __device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __
     }
 }
 
+// u and the (spring) positions of the linearisation point, one pass over the halo list
+__device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* __restrict__ u, const double* __restrict__ x,
+                                   const double* __restrict__ add, double* lu, double* lx) {
+    const int row0 = b * P.tile_rows;
+    for (int i = tid; i < 3 * P.tile_rows; i += BLK) {
+        lu[i] = u[3 * (size_t)row0 + i];
+        lx[i] = x[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
+    }
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    for (int i = tid; i < hn; i += BLK) {
+        const size_t r = (size_t)P.halo_rows[hb + i];
+        double* d = lu + 3 * (size_t)(P.tile_rows + i);
+        double* e = lx + 3 * (size_t)(P.tile_rows + i);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d[k] = u[3 * r + k]; e[k] = x[3 * r + k] + (add ? add[3 * r + k] : 0.0); }
+    }
+}
+
+// reprojection block of one row in factored form (same expressions as k_reproj):
+//   a += J_l^T w (J_l u_l + J_p u_p) ; pose partial = J_p^T w J_l u_l ; cross = u_l . H_lp u_p
+__device__ inline void row_factored(const RowRec& rc, const Pose& Tcw, const double* xs, const double* ul, const double* up,
+                                    double pm, double& a0, double& a1, double& a2, double* part /*9*/) {
+    double R[9];
+    quat_to_R(Tcw.q, R);
+    const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
+    const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
+    const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
+    double tl[2], tp[2], Jl[2][3], Jp[2][6];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+        Jp[rr][0] = pm * (-j1 * pz + j2 * py);
+        Jp[rr][1] = pm * (j0 * pz - j2 * px);
+        Jp[rr][2] = pm * (-j0 * py + j1 * px);
+        Jp[rr][3] = pm * j0; Jp[rr][4] = pm * j1; Jp[rr][5] = pm * j2;
+        Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+        Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+        Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+        tl[rr] = Jl[rr][0] * ul[0] + Jl[rr][1] * ul[1] + Jl[rr][2] * ul[2];
+        double s = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) s += Jp[rr][p] * up[p];
+        tp[rr] = s;
+    }
+    const double w = rc.w;
+    const double c0 = w * (tl[0] + tp[0]), c1 = w * (tl[1] + tp[1]);
+    a0 += Jl[0][0] * c0 + Jl[1][0] * c1;
+    a1 += Jl[0][1] * c0 + Jl[1][1] * c1;
+    a2 += Jl[0][2] * c0 + Jl[1][2] * c1;
+    part[2] = w * (tl[0] * tp[0] + tl[1] * tp[1]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) part[3 + p] = w * (Jp[0][p] * tl[0] + Jp[1][p] * tl[1]);
+}
+
 __device__ inline double damper_sign(int role) { return (role == 0 || role == 3) ? -1.0 : 1.0; }
 
 // =====================================================================================
@@ -264,12 +323,21 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
                 for (int q = p; q < 6; ++q) { acc[k] = w * (Jp[0][p] * Jp[0][q] + Jp[1][p] * Jp[1][q]); ++k; }
 #pragma unroll
             for (int p = 0; p < 6; ++p) acc[21 + p] = -w * (Jp[0][p] * r0 + Jp[1][p] * r1);
-            // H_pl (6x3), component-major so that a wave writes 18 contiguous runs
+            if (P.use_lds) {
+                // factored form: the PCG kernels rebuild J_l, J_p from these 32 bytes
+                RowRec rc;
 #pragma unroll
-            for (int p = 0; p < 6; ++p)
+                for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
+                rc.w = lm * w;
+                P.rowrec[row] = rc;
+            } else {
+                // H_pl (6x3), component-major so that a wave writes 18 contiguous runs
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    P.Hpl[(size_t)(p * 3 + c) * P.n_rows + row] = w * (Jp[0][p] * Jl[0][c] + Jp[1][p] * Jl[1][c]);
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        P.Hpl[(size_t)(p * 3 + c) * P.n_rows + row] = w * (Jp[0][p] * Jl[0][c] + Jp[1][p] * Jl[1][c]);
+            }
             double* D = P.D + 6 * (size_t)row;
             D[0] = w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]);
             D[1] = w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]);
@@ -284,8 +352,16 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
         }
     }
     if (LIN && !wrote) {
+        if (P.use_lds) {
+            RowRec rc;
 #pragma unroll
-        for (int c = 0; c < 18; ++c) P.Hpl[(size_t)c * P.n_rows + row] = 0;
+            for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
+            rc.w = 0;
+            P.rowrec[row] = rc;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 18; ++c) P.Hpl[(size_t)c * P.n_rows + row] = 0;
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) P.D[6 * (size_t)row + c] = 0;
         P.bl[3 * row] = P.bl[3 * row + 1] = P.bl[3 * row + 2] = 0;
@@ -348,7 +424,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     auto spring = [&](int idx, int o, int meta, double d0) {
         if (!(meta & SM_ACTIVE)) {
             if (LIN) {
-                if (LDS) { P.s_rec[idx].g0 = 0; P.s_rec[idx].g1 = 0; P.s_rec[idx].g2 = 0; }
+                if (LDS) P.s_rec[idx].qc = 0;
                 else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
             }
             return;
@@ -370,9 +446,8 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                                                  : (P.k_spring / (2 * d0 * d)) * 2.0;
             const double q = rfix ? 0.0 : rho1 * P.info_pos;
             const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
-            const double sq = sqrt(q);
-            if (LDS) { P.s_rec[idx].g0 = sq * g0; P.s_rec[idx].g1 = sq * g1; P.s_rec[idx].g2 = sq * g2; }
-            else { P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
+            if (LDS) P.s_rec[idx].qc = q * cg * cg;
+            else { const double sq = sqrt(q); P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
             D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
             D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
             const double qr = q * r;
@@ -389,7 +464,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                 for (int q = 0; q < U; ++q) {
                     const int j = idx + 64 * q;
                     hdr[q] = make_uint2(0xFFFFu, 0u);
-                    if (j < end) hdr[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 24);
+                    if (j < end) hdr[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 8);
                 }
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
@@ -620,8 +695,8 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
 // =====================================================================================
 template <int T, bool LDS>
 __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
+    static_assert(!LDS, "gather fallback only: the LDS-staged path is k_spmv_f");
     __shared__ double lds[4 * 9];
-    extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     const int b = xcd_tile(blockIdx.x, P.n_regblk);
     if (b >= P.n_regblk) return;
@@ -631,13 +706,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     const double* u = P.uv3;
-    int self = row;
-    if (LDS) {
-        stage_rows(P, b, tid, P.uv3, nullptr, dyn);
-        __syncthreads();
-        u = dyn;
-        self = row - b * P.tile_rows;
-    }
+    const int self = row;
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double ul0 = u[3 * self], ul1 = u[3 * self + 1], ul2 = u[3 * self + 2];
@@ -665,85 +734,30 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
     }
     if (!rfix) {
         const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
-        if (LDS) {
-            // records are streamed 4 steps ahead: with ~3 waves per SIMD the loop is bound by the
-            // latency of its own record loads unless several are in flight
-            constexpr int U = 4;
-            for (int idx = beg + lane; idx < end; idx += 64 * U) {
-                double2 ga[U];
-                double g2[U];
-                int o[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int j = idx + 64 * q;
-                    o[q] = REC_NONE;
-                    if (j < end) {
-                        const SpringRec* rc = P.s_rec + j;
-                        ga[q] = *reinterpret_cast<const double2*>(rc);
-                        g2[q] = rc->g2;
-                        o[q] = rc->other;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    if (o[q] == REC_NONE) continue;
-                    const double dot = ga[q].x * u[3 * o[q]] + ga[q].y * u[3 * o[q] + 1] + g2[q] * u[3 * o[q] + 2];
-                    a0 -= ga[q].x * dot; a1 -= ga[q].y * dot; a2 -= g2[q] * dot;
-                }
-            }
-        } else {
-            const size_t nz = (size_t)P.ss_nnz;
-            for (int idx = beg + lane; idx < end; idx += 64) {
-                const int o = P.s_other[idx];
-                if (o < 0) continue;
-                const double g0 = P.s_g[idx], g1 = P.s_g[nz + idx], g2 = P.s_g[2 * nz + idx];
-                const double dot = g0 * u[3 * o] + g1 * u[3 * o + 1] + g2 * u[3 * o + 2];
-                a0 -= g0 * dot; a1 -= g1 * dot; a2 -= g2 * dot;
-            }
+        const size_t nz = (size_t)P.ss_nnz;
+        for (int idx = beg + lane; idx < end; idx += 64) {
+            const int o = P.s_other[idx];
+            if (o < 0) continue;
+            const double g0 = P.s_g[idx], g1 = P.s_g[nz + idx], g2 = P.s_g[2 * nz + idx];
+            const double dot = g0 * u[3 * o] + g1 * u[3 * o + 1] + g2 * u[3 * o + 2];
+            a0 -= g0 * dot; a1 -= g1 * dot; a2 -= g2 * dot;
         }
     }
     if (!rfix) {
         const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
-        if (LDS) {
-            constexpr int U = 4;
-            for (int idx = beg + lane; idx < end; idx += 64 * U) {
-                DamperRec rc[U];
+        for (int idx = beg + lane; idx < end; idx += 64) {
+            const int meta = P.d_meta[idx];
+            if (meta < 0 || (meta & DM_UNARY)) continue;
+            const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
+            const int role = meta & 3;
+            double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int j = idx + 64 * q;
-                    rc[q].meta = REC_NONE;
-                    if (j < end) rc[q] = P.d_rec[j];
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    if (rc[q].meta == REC_NONE || (rc[q].meta & DM_UNARY)) continue;   // padding / value-only other
-                    const int role = rc[q].meta & 3;
-                    const uint16_t o[3] = {rc[q].o0, rc[q].o1, rc[q].o2};
-                    double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const double sg = damper_sign(k + (k >= role ? 1 : 0));
-                        if (o[k] != REC_NONE) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
-                    }
-                    const double c = damper_sign(role) * rc[q].s;
-                    a0 += c * s0; a1 += c * s1; a2 += c * s2;
-                }
+            for (int k = 0; k < 3; ++k) {
+                const double sg = damper_sign(k + (k >= role ? 1 : 0));
+                if (o[k] >= 0) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
             }
-        } else {
-            for (int idx = beg + lane; idx < end; idx += 64) {
-                const int meta = P.d_meta[idx];
-                if (meta < 0 || (meta & DM_UNARY)) continue;
-                const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
-                const int role = meta & 3;
-                double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double sg = damper_sign(k + (k >= role ? 1 : 0));
-                    if (o[k] >= 0) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
-                }
-                const double c = damper_sign(role) * P.d_s[idx];
-                a0 += c * s0; a1 += c * s1; a2 += c * s2;
-            }
+            const double c = damper_sign(role) * P.d_s[idx];
+            a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     }
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
@@ -751,6 +765,132 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
         P.wv[3 * row] = a0; P.wv[3 * row + 1] = a1; P.wv[3 * row + 2] = a2;
         part[0] = P.rv[3 * row] * ul0 + P.rv[3 * row + 1] * ul1 + P.rv[3 * row + 2] * ul2;
         part[1] = a0 * ul0 + a1 * ul1 + a2 * ul2;
+    }
+    block_sum_store<9>(part, lds, tid, P.part_spmv + (size_t)b * NPART);
+}
+
+// =====================================================================================
+// PCG kernel 1, LDS-staged path: the same operator in factored form.  The tile's u and the positions
+// of the linearisation point are staged (own rows + halo); per incidence the kernel reads ONE
+// 16-byte record: spring  a_i += qc (v . (u_i - u_j)) v,  v = x_i - x_j;
+//                 damper  a_i += sg_i s (sum_k sg_k u_k)  (all four vertices, the own one included);
+// per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
+// =====================================================================================
+template <int T>
+__global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
+    __shared__ double lds[4 * 9];
+    extern __shared__ double dyn[];
+    constexpr int R = 64 / T;
+    constexpr int U = 4;
+    const int b = xcd_tile(blockIdx.x, P.n_regblk);
+    if (b >= P.n_regblk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = b * 4 + wave;
+    const int row = slice * R + lane / T;
+    const int t = lane % T;
+    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
+    const int kf = P.grp_pose[row / ROW_ALIGN];
+    const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
+    const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
+    double* lu = dyn;
+    double* lx = dyn + 3 * (size_t)(P.tile_rows + P.max_halo + 1);
+    // row ZROW of both arrays is zero: padding records and absent damper vertices point at it, so the
+    // incidence loops are branch-free and the LDS reads of a whole chunk can be in flight together
+    const int ZROW = P.tile_rows + P.max_halo;
+    if (tid < 3) { lu[3 * ZROW + tid] = 0; lx[3 * ZROW + tid] = 0; }
+    stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
+    // row factors and the first record chunks are requested while the staging loads are in flight
+    RowRec rc;
+    rc.w = 0;
+    double rv0 = 0, rv1 = 0, rv2 = 0;
+    if (t == 0) {
+        rc = P.rowrec[row];
+        rv0 = P.rv[3 * row]; rv1 = P.rv[3 * row + 1]; rv2 = P.rv[3 * row + 2];
+    }
+    // records are double-buffered: chunk k+1 is requested before chunk k is consumed (with ~3 waves
+    // per SIMD the loops are bound by the latency of their own loads otherwise)
+    SpringRec srA[U], srB[U];
+    DamperRec drA[U], drB[U];
+    auto load_springs = [&](SpringRec* sr, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            sr[q].other = REC_NONE; sr[q].qc = 0;
+            if (j < send) sr[q] = P.s_rec[j];
+        }
+    };
+    auto load_dampers = [&](DamperRec* dr, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            dr[q].meta = 0; dr[q].s = 0; dr[q].o0 = dr[q].o1 = dr[q].o2 = REC_NONE;
+            if (j < dend) dr[q] = P.d_rec[j];
+        }
+    };
+    load_springs(srA, sbeg + lane);
+    load_dampers(drA, dbeg + lane);
+    __syncthreads();
+    const int self = row - b * P.tile_rows;
+    const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
+    const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
+    double a0 = 0, a1 = 0, a2 = 0;
+    double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto do_springs = [&](const SpringRec* sr) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int o = sr[q].other == REC_NONE ? ZROW : (int)sr[q].other;     // padding: qc = 0
+            const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
+            const double dot = sr[q].qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
+            a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
+        }
+    };
+    auto do_dampers = [&](const DamperRec* dr) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            // padding records carry s = 0; a unary damper (the other vertex is a value) and absent
+            // vertices read the zero row, which leaves the diagonal term s u_i
+            const int meta = dr[q].meta == REC_NONE ? 0 : (int)dr[q].meta;
+            const double sv = dr[q].meta == REC_NONE ? 0.0 : dr[q].s;
+            const bool un = (meta & DM_UNARY) != 0;
+            const int role = meta & 3;
+            const int o0 = (un || dr[q].o0 == REC_NONE) ? ZROW : (int)dr[q].o0;
+            const int o1 = (un || dr[q].o1 == REC_NONE) ? ZROW : (int)dr[q].o1;
+            const int o2 = (un || dr[q].o2 == REC_NONE) ? ZROW : (int)dr[q].o2;
+            const double so = damper_sign(role);
+            const double g0 = damper_sign(role == 0 ? 1 : 0), g1 = damper_sign(role <= 1 ? 2 : 1), g2 = damper_sign(role <= 2 ? 3 : 2);
+            const double s0 = so * ul[0] + g0 * lu[3 * o0] + g1 * lu[3 * o1] + g2 * lu[3 * o2];
+            const double s1 = so * ul[1] + g0 * lu[3 * o0 + 1] + g1 * lu[3 * o1 + 1] + g2 * lu[3 * o2 + 1];
+            const double s2 = so * ul[2] + g0 * lu[3 * o0 + 2] + g1 * lu[3 * o1 + 2] + g2 * lu[3 * o2 + 2];
+            const double c = so * sv;
+            a0 += c * s0; a1 += c * s1; a2 += c * s2;
+        }
+    };
+    if (t == 0) {
+        a0 = lam * ul[0]; a1 = lam * ul[1]; a2 = lam * ul[2];
+        if (rc.w != 0.0) {
+            double up[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) up[p] = P.up[6 * kf + p];
+            row_factored(rc, P.lin_pose[kf], xs, ul, up, P.pose_fixed[kf] ? 0.0 : 1.0, a0, a1, a2, part);
+        }
+    }
+    for (int base = sbeg; base < send; base += 128 * U) {          // wave-uniform trip count
+        load_springs(srB, base + 64 * U + lane);
+        do_springs(srA);
+        load_springs(srA, base + 128 * U + lane);
+        do_springs(srB);
+    }
+    for (int base = dbeg; base < dend; base += 128 * U) {
+        load_dampers(drB, base + 64 * U + lane);
+        do_dampers(drA);
+        load_dampers(drA, base + 128 * U + lane);
+        do_dampers(drB);
+    }
+    a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
+    if (t == 0) {
+        P.wv[3 * row] = a0; P.wv[3 * row + 1] = a1; P.wv[3 * row + 2] = a2;
+        part[0] = rv0 * ul[0] + rv1 * ul[1] + rv2 * ul[2];
+        part[1] = a0 * ul[0] + a1 * ul[1] + a2 * ul[2];
     }
     block_sum_store<9>(part, lds, tid, P.part_spmv + (size_t)b * NPART);
 }
@@ -1005,6 +1145,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const int self = row - row0;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     double* lu = dyn;
+    double* lx = dyn + 3 * (size_t)(P.tile_rows + P.max_halo);     // positions of the linearisation point
 
     // ================= phase 1: every global load this launch needs is requested up front (the
     // launch is a chain of dependent round trips otherwise: partials -> vectors -> records)
@@ -1035,6 +1176,15 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const bool hh = tid < hn;
     const size_t hrow = (size_t)P.halo_fix[(size_t)b * BLK + tid];
     double h_w[3], h_s[3], h_r[3], h_D[6];
+    double x_own[3] = {0, 0, 0}, x_h[3] = {0, 0, 0};
+    if (own) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x_own[k] = P.lin_xl[3 * orow + k] + (P.X0 ? P.X0[3 * orow + k] : 0.0);
+    }
+    if (hh) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x_h[k] = P.lin_xl[3 * hrow + k] + (P.X0 ? P.X0[3 * hrow + k] : 0.0);
+    }
     if (it > 0) {
         if (own) {
 #pragma unroll
@@ -1077,41 +1227,22 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             }
         }
     }
-    // row blocks and first record chunks
-    double Dr[6] = {0, 0, 0, 0, 0, 0};
-    if (t == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Dr[k] = P.D[6 * (size_t)row + k];
-    }
-    constexpr int NPC = (6 + T - 1) / T;                          // pose components per lane
-    double e_[NPC][3];
-    {
-        int np = 0;
-#pragma unroll
-        for (int p = t; p < 6; p += T) {
-            e_[np][0] = P.Hpl[(size_t)(p * 3) * P.n_rows + row];
-            e_[np][1] = P.Hpl[(size_t)(p * 3 + 1) * P.n_rows + row];
-            e_[np][2] = P.Hpl[(size_t)(p * 3 + 2) * P.n_rows + row];
-            ++np;
-        }
-    }
+    // row factors, the tile's pose at the linearisation point, first record chunks
+    RowRec rc;
+    rc.w = 0;
+    if (t == 0) rc = P.rowrec[row];
+    const Pose Tlin = P.lin_pose[kf];
+    const double pmask = P.pose_fixed[kf] ? 0.0 : 1.0;
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
-    double2 ga[U];
-    double g2[U];
-    int so[U];
+    SpringRec sr[U];
     DamperRec dr[U];
     auto load_springs = [&](int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
-            so[q] = REC_NONE;
-            if (j < send) {
-                const SpringRec* rc = P.s_rec + j;
-                ga[q] = *reinterpret_cast<const double2*>(rc);
-                g2[q] = rc->g2;
-                so[q] = rc->other;
-            }
+            sr[q].other = REC_NONE;
+            if (j < send) sr[q] = P.s_rec[j];
         }
     };
     auto load_dampers = [&](int idx) {
@@ -1236,61 +1367,69 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             dst[2] = h_D[2] * rn[0] + h_D[4] * rn[1] + h_D[5] * rn[2];
         }
     }
+    if (own) { lx[3 * tid] = x_own[0]; lx[3 * tid + 1] = x_own[1]; lx[3 * tid + 2] = x_own[2]; }
+    for (int i = tid; i < hn; i += BLK) {
+        if (i != tid) {
+            const size_t r2 = (size_t)P.halo_rows[hb + i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x_h[k] = P.lin_xl[3 * r2 + k] + (P.X0 ? P.X0[3 * r2 + k] : 0.0);
+        }
+        double* dst = lx + 3 * (size_t)(P.tile_rows + i);
+        dst[0] = x_h[0]; dst[1] = x_h[1]; dst[2] = x_h[2];
+    }
     __syncthreads();
-    // ================= phase 5: operator apply on the staged u (k_spmv, LDS path)
-    const double* u = lu;
+    // ================= phase 5: operator apply on the staged u (k_spmv_f)
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double ul0 = u[3 * self], ul1 = u[3 * self + 1], ul2 = u[3 * self + 2];
-    {
-        if (t == 0) {
-            a0 = (Dr[0] + lam) * ul0 + Dr[1] * ul1 + Dr[2] * ul2;
-            a1 = Dr[1] * ul0 + (Dr[3] + lam) * ul1 + Dr[4] * ul2;
-            a2 = Dr[2] * ul0 + Dr[4] * ul1 + (Dr[5] + lam) * ul2;
-        }
-        double h0 = 0, h1 = 0, h2 = 0;
-        int q = 0;
+    const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
+    const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
+    if (t == 0) {
+        a0 = lam * ul[0]; a1 = lam * ul[1]; a2 = lam * ul[2];
+        if (rc.w != 0.0) {
+            double up[6];
 #pragma unroll
-        for (int p = t; p < 6; p += T) {
-            const double upk = s_up[p];
-            h0 += e_[q][0] * upk; h1 += e_[q][1] * upk; h2 += e_[q][2] * upk;
-            part[3 + p] = e_[q][0] * ul0 + e_[q][1] * ul1 + e_[q][2] * ul2;
-            ++q;
+            for (int p = 0; p < 6; ++p) up[p] = s_up[p];
+            row_factored(rc, Tlin, xs, ul, up, pmask, a0, a1, a2, part);
         }
-        a0 += h0; a1 += h1; a2 += h2;
-        part[2] = ul0 * h0 + ul1 * h1 + ul2 * h2;
     }
     for (int idx = sbeg + lane; idx < send; idx += 64 * U) {
         if (idx != sbeg + lane) load_springs(idx);
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            if (so[q] == REC_NONE) continue;
-            const double dot = ga[q].x * u[3 * so[q]] + ga[q].y * u[3 * so[q] + 1] + g2[q] * u[3 * so[q] + 2];
-            a0 -= ga[q].x * dot; a1 -= ga[q].y * dot; a2 -= g2[q] * dot;
+            const int o = sr[q].other;
+            if (o == REC_NONE) continue;
+            const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
+            const double dot = sr[q].qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
+            a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
         }
     }
     for (int idx = dbeg + lane; idx < dend; idx += 64 * U) {
         if (idx != dbeg + lane) load_dampers(idx);
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            if (dr[q].meta == REC_NONE || (dr[q].meta & DM_UNARY)) continue;
+            if (dr[q].meta == REC_NONE) continue;
+            if (dr[q].meta & DM_UNARY) {
+                a0 += dr[q].s * ul[0]; a1 += dr[q].s * ul[1]; a2 += dr[q].s * ul[2];
+                continue;
+            }
             const int role = dr[q].meta & 3;
             const uint16_t o[3] = {dr[q].o0, dr[q].o1, dr[q].o2};
-            double s0 = 0, s1 = 0, s2 = 0;
+            const double so = damper_sign(role);
+            double s0 = so * ul[0], s1 = so * ul[1], s2 = so * ul[2];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double sg = damper_sign(k + (k >= role ? 1 : 0));
-                if (o[k] != REC_NONE) { s0 += sg * u[3 * o[k]]; s1 += sg * u[3 * o[k] + 1]; s2 += sg * u[3 * o[k] + 2]; }
+                if (o[k] != REC_NONE) { s0 += sg * lu[3 * o[k]]; s1 += sg * lu[3 * o[k] + 1]; s2 += sg * lu[3 * o[k] + 2]; }
             }
-            const double c = damper_sign(role) * dr[q].s;
+            const double c = so * dr[q].s;
             a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     }
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         w_out[3 * row] = a0; w_out[3 * row + 1] = a1; w_out[3 * row + 2] = a2;
-        if (it == 0) part[0] = r_out[3 * row] * ul0 + r_out[3 * row + 1] * ul1 + r_out[3 * row + 2] * ul2;
-        part[1] = a0 * ul0 + a1 * ul1 + a2 * ul2;
+        if (it == 0) part[0] = r_out[3 * row] * ul[0] + r_out[3 * row + 1] * ul[1] + r_out[3 * row + 2] * ul[2];
+        part[1] = a0 * ul[0] + a1 * ul[1] + a2 * ul[2];
     }
     part[0] += dot_ru;
     block_sum_store<9>(part, lds, tid, part_out + (size_t)b * NPART);
@@ -1425,7 +1564,8 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.pose_init = A.get<Pose>(K);
     d.xl_init = A.get<double>(3 * nr);
     d.D = A.get<double>(6 * nr);
-    d.Hpl = A.get<double>(18 * nr);
+    d.Hpl = A.get<double>(d.use_lds ? 1 : 18 * nr);
+    d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
     d.s_g = A.get<double>(3 * us);
     d.d_s = A.get<double>(ud);
     d.Hpp = A.get<double>(21 * K);
@@ -1700,7 +1840,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         }
     }
     d.use_lds = 1;
-    const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (s.X0 ? 2 : 1);
+    const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * 2;      // u + positions
     if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
@@ -1759,7 +1899,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         e->h_s_rec.resize(nnz_s);
         for (size_t i = 0; i < nnz_s; ++i) {
             SpringRec& r = e->h_s_rec[i];
-            r.g0 = r.g1 = r.g2 = 0;
+            r.qc = 0;
             r.other = u16(L_s[i]); r.meta = 0; r.d0 = S_d0[i];
         }
         e->h_d_rec.resize(nnz_d);
@@ -1906,14 +2046,22 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm) {
 }
 
 static void launch_spmv(nrs_ctx* c, const Dev& d, double lam) {
-    const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
-    if (d.use_lds) launch_spmv2<true>(c, d, lam, shm);
-    else launch_spmv2<false>(c, d, lam, 0);
+    if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0); return; }
+    const size_t shm = sizeof(double) * 6 * (size_t)(d.tile_rows + d.max_halo + 1);
+    const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
+    switch (d.T) {
+        case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam); break;
+        case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam); break;
+        case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam); break;
+        case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam); break;
+        default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam); break;
+    }
 }
 
 // errors (+ linearisation) at a given state; leaves chi2 (and max diag) in scal[]
 template <bool LIN>
 static int evaluate(nrs_ctx* c, Engine* e, int which) {
+    if (LIN) { e->d.lin_pose = e->d.pose[which]; e->d.lin_xl = e->d.xl[which]; }   // the PCG kernels re-form factors from it
     const Dev& d = e->d;
     const dim3 gg(((d.n_groups + 7) / 8) * 8), b(BLK);
     if (LIN) {
@@ -1960,7 +2108,7 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
     for (; it < stop; ++it) {
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
-            const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo);
+            const size_t shm = sizeof(double) * 6 * (size_t)(d.tile_rows + d.max_halo);
             switch (d.T) {
                 case 1: hipLaunchKernelGGL((k_pcg_fused<1>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
                 case 2: hipLaunchKernelGGL((k_pcg_fused<2>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
