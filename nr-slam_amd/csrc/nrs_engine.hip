@@ -115,6 +115,7 @@ struct Dev {
     double* part_spmv;               // n_regblk x NPART
     double* part_apply;              // n_vecblk
     double* scal;
+    double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
 };
 
@@ -588,20 +589,8 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
         chi += P.part_reg[2 * (size_t)b];
         md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
     }
-    if (LIN) {
-        for (int i = tid; i < P.K * 27; i += BLK) {
-            const int k = i / 27, c = i % 27;
-            double s = 0;
-            for (int g = P.pose_grp_ptr[k]; g < P.pose_grp_ptr[k + 1]; ++g) s += P.part_lin[(size_t)g * 32 + c];
-            if (c < 21) {
-                P.Hpp[k * 21 + c] = s;
-                // diagonal entries of the packed upper triangle: 0,6,11,15,18,20
-                if (c == 0 || c == 6 || c == 11 || c == 15 || c == 18 || c == 20) md = fmax(md, fabs(s));
-            } else {
-                P.bp[k * 6 + (c - 21)] = s;
-            }
-        }
-    }
+    if (LIN)
+        for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp|
     double c = wave_sum(chi);
     sc = wave_sum(sc);
 #pragma unroll
@@ -612,7 +601,45 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
         P.scal[SC_CHI] = lds[0] + lds[3] + lds[6] + lds[9];
         if (LIN) P.scal[SC_MAXDIAG] = fmax(fmax(lds[1], lds[4]), fmax(lds[7], lds[10]));
         if (!LIN) P.scal[SC_SCALE] = lds[2] + lds[5] + lds[8] + lds[11];
+        // the host reads these after a stream synchronisation: written straight into mapped host memory
+        P.h_scal[SC_CHI] = P.scal[SC_CHI];
+        if (LIN) P.h_scal[SC_MAXDIAG] = P.scal[SC_MAXDIAG];
+        if (!LIN) P.h_scal[SC_SCALE] = P.scal[SC_SCALE];
     }
+    if (tid < 8) P.h_flags[tid] = P.flags[tid];
+}
+
+// H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the k_reproj partials
+// (8 lanes per component, then the 8 in order); red[3 + k] = max |diagonal| for the LM lambda_0
+__global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
+    __shared__ double lds[8][32];
+    __shared__ double mdl[32];
+    const int k = blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
+    double s = 0;
+    if (c < 27)
+        for (int g = P.pose_grp_ptr[k] + gl; g < P.pose_grp_ptr[k + 1]; g += 8) s += P.part_lin[(size_t)g * 32 + c];
+    lds[gl][c] = s;
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0;
+        if (c < 27) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += lds[q][c];
+            if (c < 21) P.Hpp[k * 21 + c] = t; else P.bp[k * 6 + (c - 21)] = t;
+        }
+        // diagonal entries of the packed upper triangle: 0,6,11,15,18,20
+        mdl[c] = (c == 0 || c == 6 || c == 11 || c == 15 || c == 18 || c == 20) ? fabs(t) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0;
+        for (int q = 0; q < 21; ++q) m = fmax(m, mdl[q]);
+        P.red[3 + k] = m;
+    }
+}
+
+__global__ void k_publish(Dev P) {
+    if (threadIdx.x < 8) P.h_flags[threadIdx.x] = P.flags[threadIdx.x];
 }
 
 // =====================================================================================
@@ -809,8 +836,8 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
     }
     // records are double-buffered: chunk k+1 is requested before chunk k is consumed (with ~3 waves
     // per SIMD the loops are bound by the latency of their own loads otherwise)
-    SpringRec srA[U], srB[U];
-    DamperRec drA[U], drB[U];
+    SpringRec srA[U];
+    DamperRec drA[U];
     auto load_springs = [&](SpringRec* sr, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -874,17 +901,13 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
             row_factored(rc, P.lin_pose[kf], xs, ul, up, P.pose_fixed[kf] ? 0.0 : 1.0, a0, a1, a2, part);
         }
     }
-    for (int base = sbeg; base < send; base += 128 * U) {          // wave-uniform trip count
-        load_springs(srB, base + 64 * U + lane);
+    for (int base = sbeg; base < send; base += 64 * U) {           // wave-uniform trip count
+        if (base != sbeg) load_springs(srA, base + lane);
         do_springs(srA);
-        load_springs(srA, base + 128 * U + lane);
-        do_springs(srB);
     }
-    for (int base = dbeg; base < dend; base += 128 * U) {
-        load_dampers(drB, base + 64 * U + lane);
+    for (int base = dbeg; base < dend; base += 64 * U) {
+        if (base != dbeg) load_dampers(drA, base + lane);
         do_dampers(drA);
-        load_dampers(drA, base + 128 * U + lane);
-        do_dampers(drB);
     }
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
@@ -1958,10 +1981,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     mark("uploads enqueued");
-    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N));      // pinned mirrors live in
-    if (!c->pin_flags) NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8));         // the context (reused)
+    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N, hipHostMallocMapped));      // pinned mirrors live in
+    if (!c->pin_flags) NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped));         // the context (reused)
     e->h_scal = c->pin_scal;
     e->h_flags = c->pin_flags;
+    e->d.h_scal = c->pin_scal;          // hipHostMalloc memory is mapped: same pointer on the device
+    e->d.h_flags = c->pin_flags;
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
     NRS_TRY(engine_reset(c, e));
@@ -2072,14 +2097,14 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
         launch_reg<LIN>(c, d, d.xl[which]);
     }
+    if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.K), b, 0, c->stream, d);
     hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d);
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
 
 static int read_scalars(nrs_ctx* c, Engine* e) {
-    NRS_HIP(c, hipMemcpyAsync(e->h_scal, e->d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(e->h_flags, e->d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+    // k_finalize (always the last kernel enqueued before this) has written both mirrors
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
@@ -2137,7 +2162,7 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* i
     while (true) {
         pcg_enqueue_batch(c, e, lam, it_io);
         NRS_HIP(c, hipGetLastError());
-        NRS_HIP(c, hipMemcpyAsync(e->h_flags, d.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d);
         NRS_HIP(c, hipStreamSynchronize(c->stream));
         if (e->h_flags[0] || *it_io >= c->opt.pcg_max_iters) { *done = true; break; }
         if (stop_level && e->h_flags[3] >= stop_level) { *done = false; break; }
