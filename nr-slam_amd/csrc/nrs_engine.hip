@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         if (it == 0) P.scal[SC_GAMMA0] = gamma;
         P.flags[1] = it + 1;
         // "peek" milestones for early trial rejection: level 1 at peek_tol, level 2 at peek_tol/10
-        if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1);
+        if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             nslot[1] = alpha;
             if (ip == 0) P.scal[SC_GAMMA0] = gamma;
             P.flags[1] = ip + 1;
-            if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1);
+            if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
         }
     }
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
@@ -2112,8 +2112,12 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
 constexpr double PEEK_RTOL = 1e-2;      // inner-solve accuracy at which a trial is first evaluated
-constexpr double PEEK_RHO = -2.0;       // gain ratio below which it is rejected there (accept needs rho > 0)
-constexpr double PEEK_RHO2 = -0.5;      // ... and at the second look, at PEEK_RTOL / 10
+// Gain ratio below which a trial is rejected at the looks taken when the inner solve reaches 1e-2,
+// 1e-3, 1e-4 (acceptance needs rho > 0).  The gain ratio of the partially converged step is within
+// ~1e-2 / 4e-3 / 2e-3 of the final one at those milestones (second order in the PCG error; measured
+// on the a2 and BA problems, profiles/README.md), so the thresholds keep a >10x margin.
+constexpr int PEEK_LEVELS = 3;
+constexpr double PEEK_RHO_LVL[5] = {0, -0.25, -0.1, -0.03, -0.03};
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
@@ -2160,7 +2164,11 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
 static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* it_io, bool* done) {
     const Dev& d = e->d;
     while (true) {
-        pcg_enqueue_batch(c, e, lam, it_io);
+        // Once no peek is pending, batches are sized by the previous trial's iteration count (half of
+        // what it predicts is left): fewer host round trips; launches past convergence are no-ops.
+        int count = 0;
+        if (stop_level == 0 && e->pred_iters > *it_io) count = std::min(std::max((e->pred_iters - *it_io) / 2, c->opt.pcg_batch), 8 * c->opt.pcg_batch);
+        pcg_enqueue_batch(c, e, lam, it_io, count);
         NRS_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d);
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -2178,6 +2186,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     Dev& d = e->d;
     double lam = -1, ni = 2;
     bool speculate = true;
+    const bool peek_debug = getenv("NRS_PEEK_DEBUG") != nullptr;
+    const int peek_levels = peek_debug ? 4 : PEEK_LEVELS;
     for (int it = 0; it < iters; ++it) {
         NRS_TRY(evaluate<true>(c, e, e->cur));
         NRS_TRY(read_scalars(c, e));
@@ -2224,11 +2234,12 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     // peek: a trial that is clearly going to be rejected is not solved any further --
                     // its step is discarded, so the iterate sequence is the reference's either way
                     const double rho_peek = (chi - temp) / scale;
-                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < (lvl >= 2 ? PEEK_RHO2 : PEEK_RHO);
+                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl];
+                    if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f\n", it, qmax, lvl, pit, rho_peek); early = false; }
                     if (early) break;
                     seen = lvl;
                 }
-                NRS_TRY(pcg_advance(c, e, lam, peeking && seen < 2 ? seen + 1 : 0, &pit, &done));
+                NRS_TRY(pcg_advance(c, e, lam, peeking && seen < peek_levels ? seen + 1 : 0, &pit, &done));
                 NRS_TRY(eval_trial());
             }
             ok = e->h_flags[2] == 0;
@@ -2237,6 +2248,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             if (!early) e->pred_iters = e->h_flags[1];
             const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
+            if (peek_debug) fprintf(stderr, "[peek] it %d trial %d FINAL pit %d rho %.4f\n", it, qmax, pit, rho);
             const bool accepted = !early && rho > 0 && std::isfinite(temp);
             if (trace) {
                 if (trace->trials && trace->count < trace->capacity) {

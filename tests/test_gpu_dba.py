@@ -51,7 +51,7 @@ def test_residuals_and_gradient(ctx, model):
 @pytest.mark.parametrize("n,k,seed", [(120, 3, 31), (300, 4, 32), (600, 6, 33)])
 def test_solve_matches_oracle(ctx, ctx_exact, n, k, seed, exact):
     """exact=True: every trial solved to pcg_rtol, every chi2 compared.  exact=False (default
-    options): clearly-rejected trials stop at a peek (1e-2: rho < -2, 1e-3: rho < -0.5); their chi2_new is then only an
+    options): rejected trials stop at a peek (1e-2: rho < -0.25, 1e-3: rho < -0.1, 1e-4: rho < -0.03); their chi2_new is then only an
     approximation, but decisions, lambdas and all accepted iterates must be unchanged."""
     ctx = ctx_exact if exact else ctx
     p, e, cam, qt = _setup(n, k, seed)
@@ -67,7 +67,7 @@ def test_solve_matches_oracle(ctx, ctx_exact, n, k, seed, exact):
         assert abs(a["lam"] - b["lam"]) <= 1e-6 * b["lam"]
         assert abs(a["chi"] - b["chi"]) <= 1e-6 * b["chi"]
         if a["early"]:
-            assert not exact and not a["accepted"] and not b["accepted"] and b["rho"] < -0.25
+            assert not exact and not a["accepted"] and not b["accepted"] and b["rho"] < -0.02
         else:
             assert abs(a["chi_new"] - b["chi_new"]) <= 1e-6 * b["chi_new"]
     if exact:
