@@ -82,7 +82,11 @@ struct Dev {
     // LDS staging: neighbour ids above are LOCAL to the workgroup's tile: [0, tile_rows) = own rows,
     // tile_rows + i = halo_rows[halo_ptr[b] + i]
     int use_lds, tile_rows, max_halo;
-    int* halo_ptr; int* halo_rows;
+    int max_halo_s;                  // halo lists start with the spring (same-keyframe) neighbours: at most this many
+    // tiles come in two classes so that a few tiles with very large halos do not set the LDS size
+    // (= occupancy) of all: tile_list = class-0 tiles, then class-1 tiles; caps per class
+    int* tile_list; int n_tiles_cls[2]; int cap_h[2], cap_s[2];
+    int* halo_ptr; int* halo_rows; int* halo_ns;   // halo_ns[b] = number of spring-halo rows of tile b
     SpringRec* s_rec; DamperRec* d_rec;
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
     Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
@@ -213,13 +217,17 @@ __device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* _
         lu[i] = u[3 * (size_t)row0 + i];
         lx[i] = x[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
     }
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
     for (int i = tid; i < hn; i += BLK) {
         const size_t r = (size_t)P.halo_rows[hb + i];
         double* d = lu + 3 * (size_t)(P.tile_rows + i);
-        double* e = lx + 3 * (size_t)(P.tile_rows + i);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { d[k] = u[3 * r + k]; e[k] = x[3 * r + k] + (add ? add[3 * r + k] : 0.0); }
+        for (int k = 0; k < 3; ++k) d[k] = u[3 * r + k];
+        if (i < ns) {                                              // positions: spring neighbours only
+            double* e = lx + 3 * (size_t)(P.tile_rows + i);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e[k] = x[3 * r + k] + (add ? add[3 * r + k] : 0.0);
+        }
     }
 }
 
@@ -385,12 +393,13 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
 //   (spatial_regularizer_fixed.cc:32-43).
 // =====================================================================================
 template <int T, bool LIN, bool LDS>
-__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g) {
+__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double lds[4 * 2];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
-    const int b = xcd_tile(blockIdx.x, P.n_regblk);
-    if (b >= P.n_regblk) return;
+    int b = xcd_tile(blockIdx.x, LDS ? P.n_tiles_cls[cls] : P.n_regblk);
+    if (b >= (LDS ? P.n_tiles_cls[cls] : P.n_regblk)) return;
+    if (LDS) b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         stage_rows(P, b, tid, xl_g, nullptr, lx);
         xl = lx;
         if (P.X0) {
-            double* lp = dyn + 3 * (size_t)(P.tile_rows + P.max_halo);
+            double* lp = dyn + 3 * (size_t)(P.tile_rows + P.cap_h[cls]);
             stage_rows(P, b, tid, xl_g, P.X0, lp);
             xp = lp;
         }
@@ -804,13 +813,14 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
 template <int T>
-__global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
+__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     constexpr int U = 4;
-    const int b = xcd_tile(blockIdx.x, P.n_regblk);
-    if (b >= P.n_regblk) return;
+    const int bi = xcd_tile(blockIdx.x, P.n_tiles_cls[cls]);
+    if (bi >= P.n_tiles_cls[cls]) return;
+    const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + bi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
@@ -820,11 +830,11 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
     double* lu = dyn;
-    double* lx = dyn + 3 * (size_t)(P.tile_rows + P.max_halo + 1);
+    double* lx = dyn + 3 * (size_t)(P.tile_rows + P.cap_h[cls] + 1);
     // row ZROW of both arrays is zero: padding records and absent damper vertices point at it, so the
     // incidence loops are branch-free and the LDS reads of a whole chunk can be in flight together
-    const int ZROW = P.tile_rows + P.max_halo;
-    if (tid < 3) { lu[3 * ZROW + tid] = 0; lx[3 * ZROW + tid] = 0; }
+    const int ZROW = P.tile_rows + P.cap_h[cls], ZROWX = P.tile_rows + P.cap_s[cls];
+    if (tid < 3) { lu[3 * ZROW + tid] = 0; lx[3 * ZROWX + tid] = 0; }
     stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
     // row factors and the first record chunks are requested while the staging loads are in flight
     RowRec rc;
@@ -861,12 +871,12 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
     const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
     double a0 = 0, a1 = 0, a2 = 0;
-    double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto do_springs = [&](const SpringRec* sr) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             const int o = sr[q].other == REC_NONE ? ZROW : (int)sr[q].other;     // padding: qc = 0
-            const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
+            const int ox = sr[q].other == REC_NONE ? ZROWX : (int)sr[q].other;
+            const double v0 = xs[0] - lx[3 * ox], v1 = xs[1] - lx[3 * ox + 1], v2 = xs[2] - lx[3 * ox + 2];
             const double dot = sr[q].qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
             a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
         }
@@ -892,15 +902,6 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
             a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     };
-    if (t == 0) {
-        a0 = lam * ul[0]; a1 = lam * ul[1]; a2 = lam * ul[2];
-        if (rc.w != 0.0) {
-            double up[6];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) up[p] = P.up[6 * kf + p];
-            row_factored(rc, P.lin_pose[kf], xs, ul, up, P.pose_fixed[kf] ? 0.0 : 1.0, a0, a1, a2, part);
-        }
-    }
     for (int base = sbeg; base < send; base += 64 * U) {           // wave-uniform trip count
         if (base != sbeg) load_springs(srA, base + lane);
         do_springs(srA);
@@ -908,6 +909,17 @@ __global__ __launch_bounds__(BLK, 3) void k_spmv_f(Dev P, double lam) {
     for (int base = dbeg; base < dend; base += 64 * U) {
         if (base != dbeg) load_dampers(drA, base + lane);
         do_dampers(drA);
+    }
+    // the row's own terms come last: their temporaries then never coexist with the record registers
+    double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (t == 0) {
+        a0 += lam * ul[0]; a1 += lam * ul[1]; a2 += lam * ul[2];
+        if (rc.w != 0.0) {
+            double up[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) up[p] = P.up[6 * kf + p];
+            row_factored(rc, P.lin_pose[kf], xs, ul, up, P.pose_fixed[kf] ? 0.0 : 1.0, a0, a1, a2, part);
+        }
     }
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
@@ -1577,6 +1589,8 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.sd_ptr = A.get<int>(n_slices + 1);
     d.halo_ptr = A.get<int>((size_t)d.n_regblk + 1);
     d.halo_rows = A.get<int>(n_halo);
+    d.halo_ns = A.get<int>((size_t)d.n_regblk);
+    d.tile_list = A.get<int>((size_t)d.n_regblk);
     d.s_rec = A.get<SpringRec>(d.use_lds ? nnz_s : 1);
     d.d_rec = A.get<DamperRec>(d.use_lds ? nnz_d : 1);
     const size_t us = d.use_lds ? 1 : nnz_s, ud = d.use_lds ? 1 : nnz_d;     // unpacked arrays: fallback path only
@@ -1838,7 +1852,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
     // outside the tile; neighbour ids become tile-local
     d.tile_rows = BLK / T;
-    std::vector<int> halo_ptr(d.n_regblk + 1, 0), halo_rows;
+    std::vector<int> halo_ptr(d.n_regblk + 1, 0), halo_rows, halo_ns(d.n_regblk, 0);
+    d.max_halo_s = 0;
     std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
     {
         std::vector<int> stamp(d.n_rows, -1), local(d.n_rows, 0), ext;
@@ -1850,9 +1865,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             auto see = [&](int o) {
                 if (o >= 0 && (o < row0 || o >= row1) && stamp[o] != b) { stamp[o] = b; ext.push_back(o); }
             };
+            // spring neighbours first (the SpMV stages positions for them only), then damper-only rows
             for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
+            const size_t ns = ext.size();
             for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
-            std::sort(ext.begin(), ext.end());
+            std::sort(ext.begin(), ext.begin() + ns);
+            std::sort(ext.begin() + ns, ext.end());
+            halo_ns[b] = (int)ns;
+            d.max_halo_s = std::max(d.max_halo_s, (int)ns);
             for (size_t i = 0; i < ext.size(); ++i) local[ext[i]] = d.tile_rows + (int)i;
             auto loc = [&](int o) { return o < 0 ? -1 : (o >= row0 && o < row1) ? o - row0 : local[o]; };
             for (size_t p2 = s0; p2 < s1; ++p2) L_s[p2] = loc(S_other[p2]);
@@ -1862,14 +1882,48 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             d.max_halo = std::max(d.max_halo, (int)ext.size());
         }
     }
+    // ---- tile classes: if a few tiles have much larger halos than the rest they get their own
+    // launch (class 1) with their own LDS size, and the bulk (class 0) keeps its occupancy
+    std::vector<int> tile_list(d.n_regblk);
+    {
+        std::vector<int> hs(d.n_regblk);
+        for (int b = 0; b < d.n_regblk; ++b) hs[b] = halo_ptr[b + 1] - halo_ptr[b];
+        std::vector<int> sorted = hs;
+        std::sort(sorted.begin(), sorted.end());
+        int cut = d.max_halo;
+        if (d.n_regblk >= 1024) {                                  // small problems are latency-bound: one launch
+            // (the second launch has to fill the chip by itself: >= 4 workgroups per CU, or be needed
+            // for the bulk to fit the LDS budget at all)
+            const int p97 = sorted[(size_t)(0.97 * (d.n_regblk - 1))];
+            const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
+            if (4 * d.max_halo > 5 * p97 && (d.n_regblk - (int)(0.97 * d.n_regblk) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
+        }
+        int n0 = 0;
+        for (int b = 0; b < d.n_regblk; ++b) if (hs[b] <= cut) tile_list[n0++] = b;
+        int n1 = n0;
+        for (int b = 0; b < d.n_regblk; ++b) if (hs[b] > cut) tile_list[n1++] = b;
+        d.n_tiles_cls[0] = n0; d.n_tiles_cls[1] = d.n_regblk - n0;
+        d.cap_h[0] = d.cap_h[1] = d.cap_s[0] = d.cap_s[1] = 0;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int cls = hs[b] <= cut ? 0 : 1;
+            d.cap_h[cls] = std::max(d.cap_h[cls], hs[b]);
+            d.cap_s[cls] = std::max(d.cap_s[cls], halo_ns[b]);
+        }
+    }
     d.use_lds = 1;
-    const size_t lds_need = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * 2;      // u + positions
-    if (getenv("NRS_NO_LDS") || lds_need > 60 * 1024 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    size_t lds_need = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+        if (!d.n_tiles_cls[cls]) continue;
+        lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (s.X0 ? 2 : 1));                          // linearise
+        lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2));                    // operator: u + positions
+    }
+    if (getenv("NRS_NO_LDS") || lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     mark("halo");
+    if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
     {
@@ -1950,6 +2004,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
     NRS_TRY(h2d(c, d.halo_ptr, halo_ptr));
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
+    NRS_TRY(h2d(c, d.halo_ns, halo_ns));
+    NRS_TRY(h2d(c, d.tile_list, tile_list));
     if (d.fused) {
         std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
         const int rb = ROW_ALIGN / d.tile_rows;
@@ -2040,22 +2096,25 @@ struct Timer {                       // HIP-event timing of one launch when prof
 };
 
 template <bool LIN, bool LDS>
-static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm) {
-    const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
+static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, int n, int cls) {
+    const dim3 g(((n + 7) / 8) * 8), b(BLK);
     switch (d.T) {
-        case 1: hipLaunchKernelGGL((k_reg<1, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
-        case 4: hipLaunchKernelGGL((k_reg<4, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
-        case 8: hipLaunchKernelGGL((k_reg<8, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
-        case 16: hipLaunchKernelGGL((k_reg<16, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
-        default: hipLaunchKernelGGL((k_reg<2, LIN, LDS>), g, b, shm, c->stream, d, xl); break;
+        case 1: hipLaunchKernelGGL((k_reg<1, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
+        case 4: hipLaunchKernelGGL((k_reg<4, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
+        case 8: hipLaunchKernelGGL((k_reg<8, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
+        case 16: hipLaunchKernelGGL((k_reg<16, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
+        default: hipLaunchKernelGGL((k_reg<2, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
     }
 }
 
 template <bool LIN>
 static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
-    const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.max_halo) * (d.X0 ? 2 : 1);
-    if (d.use_lds) launch_reg2<LIN, true>(c, d, xl, shm);
-    else launch_reg2<LIN, false>(c, d, xl, 0);
+    if (!d.use_lds) { launch_reg2<LIN, false>(c, d, xl, 0, d.n_regblk, 0); return; }
+    for (int cls = 0; cls < 2; ++cls) {
+        if (d.n_tiles_cls[cls] == 0) continue;
+        const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
+        launch_reg2<LIN, true>(c, d, xl, shm, d.n_tiles_cls[cls], cls);
+    }
 }
 
 template <bool LDS>
@@ -2072,14 +2131,18 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm) {
 
 static void launch_spmv(nrs_ctx* c, const Dev& d, double lam) {
     if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0); return; }
-    const size_t shm = sizeof(double) * 6 * (size_t)(d.tile_rows + d.max_halo + 1);
-    const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
-    switch (d.T) {
-        case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam); break;
-        case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam); break;
-        case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam); break;
-        case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam); break;
-        default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam); break;
+    for (int cls = 0; cls < 2; ++cls) {
+        const int n = d.n_tiles_cls[cls];
+        if (n == 0) continue;
+        const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
+        const dim3 g(((n + 7) / 8) * 8), b(BLK);
+        switch (d.T) {
+            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls); break;
+            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls); break;
+            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls); break;
+            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls); break;
+            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls); break;
+        }
     }
 }
 
