@@ -1898,6 +1898,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
             if (4 * d.max_halo > 5 * p97 && (d.n_regblk - (int)(0.97 * d.n_regblk) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
         }
+        if (getenv("NRS_TILE_CUT_PCT")) {                          // test switch: force a split at a percentile
+            const double pct = atof(getenv("NRS_TILE_CUT_PCT")) / 100.0;
+            cut = sorted[(size_t)(pct * (d.n_regblk - 1))];
+        }
         int n0 = 0;
         for (int b = 0; b < d.n_regblk; ++b) if (hs[b] <= cut) tile_list[n0++] = b;
         int n1 = n0;

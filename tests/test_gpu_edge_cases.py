@@ -118,3 +118,23 @@ def test_track_frame_with_unmapped_slots(ctx):
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
     assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == o["lost"]
     assert np.allclose(r["map_pos"], o["map_pos"], atol=1e-4, rtol=0)
+
+
+def test_ba_two_tile_classes_bit_identical(ctx, monkeypatch):
+    """Tiles with outlier halos run in their own launch (own LDS size).  Forcing the split at the
+    median halo size must not change a single bit: per-tile arithmetic and the order of the partial
+    sums are the same, only the launch a tile runs in differs."""
+    p = S.make_dba_problem(1500, 8, 75)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    monkeypatch.setenv("NRS_FUSED_MAX_ROWS", "0")             # the two-kernel PCG path (as for large windows)
+    res = []
+    for cut in (None, "50"):
+        if cut:
+            monkeypatch.setenv("NRS_TILE_CUT_PCT", cut)
+        tr = nrs.Trace()
+        pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 3, tr)
+        res.append((pq, xyz, [(t["accepted"], t["inner"], t["chi"], t["chi_new"]) for t in tr.trials]))
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
