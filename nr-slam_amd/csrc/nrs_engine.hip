@@ -817,7 +817,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
-    constexpr int U = 4;
+    constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
     const int bi = xcd_tile(blockIdx.x, P.n_tiles_cls[cls]);
     if (bi >= P.n_tiles_cls[cls]) return;
     const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + bi];
@@ -846,8 +846,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
     }
     // records are double-buffered: chunk k+1 is requested before chunk k is consumed (with ~3 waves
     // per SIMD the loops are bound by the latency of their own loads otherwise)
-    SpringRec srA[U];
-    DamperRec drA[U];
+    SpringRec srA[U], srB[U];
+    DamperRec drA[U], drB[U];
     auto load_springs = [&](SpringRec* sr, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -902,13 +902,17 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
             a0 += c * s0; a1 += c * s1; a2 += c * s2;
         }
     };
-    for (int base = sbeg; base < send; base += 64 * U) {           // wave-uniform trip count
-        if (base != sbeg) load_springs(srA, base + lane);
+    for (int base = sbeg; base < send; base += 128 * U) {          // wave-uniform trip count
+        load_springs(srB, base + 64 * U + lane);
         do_springs(srA);
+        load_springs(srA, base + 128 * U + lane);
+        do_springs(srB);
     }
-    for (int base = dbeg; base < dend; base += 64 * U) {
-        if (base != dbeg) load_dampers(drA, base + lane);
+    for (int base = dbeg; base < dend; base += 128 * U) {
+        load_dampers(drB, base + 64 * U + lane);
         do_dampers(drA);
+        load_dampers(drA, base + 128 * U + lane);
+        do_dampers(drB);
     }
     // the row's own terms come last: their temporaries then never coexist with the record registers
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
