@@ -405,6 +405,31 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
+    // record headers are double-buffered in two-record chunks; the first chunk of both streams is
+    // requested before the tile is staged
+    constexpr int U = 2;
+    const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
+    const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
+    uint2 shA[U], shB[U], dhA[U], dhB[U];
+    float dwA[U], dwB[U];
+    auto load_sh = [&](uint2* h, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0xFFFFu, 0u);
+            if (j < s_end) h[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 8);
+        }
+    };
+    auto load_dh = [&](uint2* h, float* w, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0u, 0xFFFF0000u);
+            w[q] = 0.f;
+            if (j < d_end) { h[q] = *reinterpret_cast<const uint2*>(P.d_rec + j); w[q] = P.d_w[j]; }
+        }
+    };
+    if (LDS) { load_sh(shA, s_beg + lane); load_dh(dhA, dwA, d_beg + lane); }
     // xl: estimates (dampers act on them), xp: X0 + estimates (springs); with LDS staging both are
     // tile-local arrays indexed by the local neighbour ids
     const double* xl = xl_g;
@@ -467,15 +492,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     {
         const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
         if (LDS) {
-            constexpr int U = 4;                                   // record headers are streamed 4 steps ahead
-            for (int idx = beg + lane; idx < end; idx += 64 * U) {
-                uint2 hdr[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int j = idx + 64 * q;
-                    hdr[q] = make_uint2(0xFFFFu, 0u);
-                    if (j < end) hdr[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 8);
-                }
+            auto do_sh = [&](const uint2* hdr, int idx) {
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
                     const int o = (int)(hdr[q].x & 0xFFFFu), m16 = (int)(hdr[q].x >> 16);
@@ -483,6 +500,12 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                     const int meta = ((m16 & SR_ACTIVE) ? SM_ACTIVE : 0) | ((m16 & SR_COUNT) ? SM_COUNT : 0);
                     spring(idx + 64 * q, o, meta, (double)__uint_as_float(hdr[q].y));
                 }
+            };
+            for (int base = beg; base < end; base += 128 * U) {    // wave-uniform trip count
+                load_sh(shB, base + 64 * U + lane);
+                do_sh(shA, base + lane);
+                load_sh(shA, base + 128 * U + lane);
+                do_sh(shB, base + 64 * U + lane);
             }
         } else {
             for (int idx = beg + lane; idx < end; idx += 64) {
@@ -524,17 +547,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     {
         const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
         if (LDS) {
-            constexpr int U = 4;
-            for (int idx = beg + lane; idx < end; idx += 64 * U) {
-                uint2 hdr[U];
-                float ww[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int j = idx + 64 * q;
-                    hdr[q] = make_uint2(0u, 0xFFFF0000u);
-                    ww[q] = 0.f;
-                    if (j < end) { hdr[q] = *reinterpret_cast<const uint2*>(P.d_rec + j); ww[q] = P.d_w[j]; }
-                }
+            auto do_dh = [&](const uint2* hdr, const float* ww, int idx) {
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
                     const int m16 = (int)(hdr[q].y >> 16);
@@ -543,6 +556,12 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                     const int o[3] = {r0 == REC_NONE ? -1 : r0, r1 == REC_NONE ? -1 : r1, r2 == REC_NONE ? -1 : r2};
                     damper(idx + 64 * q, m16, o, (double)ww[q]);
                 }
+            };
+            for (int base = beg; base < end; base += 128 * U) {
+                load_dh(dhB, dwB, base + 64 * U + lane);
+                do_dh(dhA, dwA, base + lane);
+                load_dh(dhA, dwA, base + 128 * U + lane);
+                do_dh(dhB, dwB, base + 64 * U + lane);
             }
         } else {
             for (int idx = beg + lane; idx < end; idx += 64) {
