@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <thread>
 #include "nrs_engine.hpp"
 
 namespace nrs {
@@ -1879,31 +1880,49 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.max_halo_s = 0;
     std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
     {
-        std::vector<int> stamp(d.n_rows, -1), local(d.n_rows, 0), ext;
-        for (int b = 0; b < d.n_regblk; ++b) {
-            const int row0 = b * d.tile_rows, row1 = row0 + d.tile_rows;
-            ext.clear();
-            const size_t s0 = (size_t)ss_ptr[b * 4], s1 = (size_t)ss_ptr[b * 4 + 4];
-            const size_t d0 = (size_t)sd_ptr[b * 4], d1 = (size_t)sd_ptr[b * 4 + 4];
-            auto see = [&](int o) {
-                if (o >= 0 && (o < row0 || o >= row1) && stamp[o] != b) { stamp[o] = b; ext.push_back(o); }
-            };
-            // spring neighbours first (the SpMV stages positions for them only), then damper-only rows
-            for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
-            const size_t ns = ext.size();
-            for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
-            std::sort(ext.begin(), ext.begin() + ns);
-            std::sort(ext.begin() + ns, ext.end());
-            halo_ns[b] = (int)ns;
-            d.max_halo_s = std::max(d.max_halo_s, (int)ns);
-            for (size_t i = 0; i < ext.size(); ++i) local[ext[i]] = d.tile_rows + (int)i;
-            auto loc = [&](int o) { return o < 0 ? -1 : (o >= row0 && o < row1) ? o - row0 : local[o]; };
-            for (size_t p2 = s0; p2 < s1; ++p2) L_s[p2] = loc(S_other[p2]);
-            for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) L_d[p2] = loc(D_o[p2]);
-            halo_rows.insert(halo_rows.end(), ext.begin(), ext.end());
-            halo_ptr[b + 1] = (int)halo_rows.size();
-            d.max_halo = std::max(d.max_halo, (int)ext.size());
+        // tiles are independent: a few host threads each take a contiguous range of tiles
+        const int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 128}));
+        std::vector<std::vector<int>> part(nt);
+        std::vector<int> cnt(d.n_regblk, 0);
+        auto work = [&](int ti) {
+            const int b0 = (int)((int64_t)d.n_regblk * ti / nt), b1 = (int)((int64_t)d.n_regblk * (ti + 1) / nt);
+            std::vector<int> stamp(d.n_rows, -1), local(d.n_rows, 0), ext;
+            for (int b = b0; b < b1; ++b) {
+                const int row0 = b * d.tile_rows, row1 = row0 + d.tile_rows;
+                ext.clear();
+                const size_t s0 = (size_t)ss_ptr[b * 4], s1 = (size_t)ss_ptr[b * 4 + 4];
+                const size_t d0 = (size_t)sd_ptr[b * 4], d1 = (size_t)sd_ptr[b * 4 + 4];
+                auto see = [&](int o) {
+                    if (o >= 0 && (o < row0 || o >= row1) && stamp[o] != b) { stamp[o] = b; ext.push_back(o); }
+                };
+                // spring neighbours first (the SpMV stages positions for them only), then damper-only rows
+                for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
+                const size_t ns = ext.size();
+                for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
+                std::sort(ext.begin(), ext.begin() + ns);
+                std::sort(ext.begin() + ns, ext.end());
+                halo_ns[b] = (int)ns;
+                for (size_t i = 0; i < ext.size(); ++i) local[ext[i]] = d.tile_rows + (int)i;
+                auto loc = [&](int o) { return o < 0 ? -1 : (o >= row0 && o < row1) ? o - row0 : local[o]; };
+                for (size_t p2 = s0; p2 < s1; ++p2) L_s[p2] = loc(S_other[p2]);
+                for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) L_d[p2] = loc(D_o[p2]);
+                part[ti].insert(part[ti].end(), ext.begin(), ext.end());
+                cnt[b] = (int)ext.size();
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int ti = 0; ti < nt; ++ti) th.emplace_back(work, ti);
+            for (auto& t : th) t.join();
         }
+        for (int b = 0; b < d.n_regblk; ++b) {
+            halo_ptr[b + 1] = halo_ptr[b] + cnt[b];
+            d.max_halo = std::max(d.max_halo, cnt[b]);
+            d.max_halo_s = std::max(d.max_halo_s, halo_ns[b]);
+        }
+        halo_rows.reserve((size_t)halo_ptr[d.n_regblk]);
+        for (int ti = 0; ti < nt; ++ti) halo_rows.insert(halo_rows.end(), part[ti].begin(), part[ti].end());
     }
     // ---- tile classes: if a few tiles have much larger halos than the rest they get their own
     // launch (class 1) with their own LDS size, and the bulk (class 0) keeps its occupancy
