@@ -195,13 +195,35 @@ __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double la
     return det > 0;
 }
 
-// stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0)
+// stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0).
+// The halo is a gather through an index list: all indices of a thread are requested first, then all
+// rows, so that a thread has its 2-4 gathers in flight together instead of one dependent pair at a time.
+constexpr int STAGE_K = 4;
 __device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __restrict__ v, const double* __restrict__ add,
                                   double* lds) {
     const int row0 = b * P.tile_rows;
-    for (int i = tid; i < 3 * P.tile_rows; i += BLK) lds[i] = v[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
     const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
-    for (int i = tid; i < hn; i += BLK) {
+    int idx[STAGE_K];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
+    for (int i = tid; i < 3 * P.tile_rows; i += BLK) lds[i] = v[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
+    double val[STAGE_K][3];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            const size_t r = (size_t)idx[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) val[k][c] = v[3 * r + c] + (add ? add[3 * r + c] : 0.0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            double* d = lds + 3 * (size_t)(P.tile_rows + tid + k * BLK);
+            d[0] = val[k][0]; d[1] = val[k][1]; d[2] = val[k][2];
+        }
+    }
+    for (int i = tid + STAGE_K * BLK; i < hn; i += BLK) {         // very large halos
         const size_t r = (size_t)P.halo_rows[hb + i];
         double* d = lds + 3 * (size_t)(P.tile_rows + i);
         d[0] = v[3 * r] + (add ? add[3 * r] : 0.0);
@@ -214,17 +236,45 @@ __device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __
 __device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* __restrict__ u, const double* __restrict__ x,
                                    const double* __restrict__ add, double* lu, double* lx) {
     const int row0 = b * P.tile_rows;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
+    int idx[STAGE_K];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
     for (int i = tid; i < 3 * P.tile_rows; i += BLK) {
         lu[i] = u[3 * (size_t)row0 + i];
         lx[i] = x[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
     }
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
-    for (int i = tid; i < hn; i += BLK) {
+    double uu[STAGE_K][3], xx[STAGE_K][3];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            const size_t r = (size_t)idx[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) uu[k][c] = u[3 * r + c];
+            if (tid + k * BLK < ns) {                              // positions: spring neighbours only
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xx[k][c] = x[3 * r + c] + (add ? add[3 * r + c] : 0.0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        const int i = tid + k * BLK;
+        if (idx[k] >= 0) {
+            double* d = lu + 3 * (size_t)(P.tile_rows + i);
+            d[0] = uu[k][0]; d[1] = uu[k][1]; d[2] = uu[k][2];
+            if (i < ns) {
+                double* e = lx + 3 * (size_t)(P.tile_rows + i);
+                e[0] = xx[k][0]; e[1] = xx[k][1]; e[2] = xx[k][2];
+            }
+        }
+    }
+    for (int i = tid + STAGE_K * BLK; i < hn; i += BLK) {         // very large halos
         const size_t r = (size_t)P.halo_rows[hb + i];
         double* d = lu + 3 * (size_t)(P.tile_rows + i);
 #pragma unroll
         for (int k = 0; k < 3; ++k) d[k] = u[3 * r + k];
-        if (i < ns) {                                              // positions: spring neighbours only
+        if (i < ns) {
             double* e = lx + 3 * (size_t)(P.tile_rows + i);
 #pragma unroll
             for (int k = 0; k < 3; ++k) e[k] = x[3 * r + k] + (add ? add[3 * r + k] : 0.0);
