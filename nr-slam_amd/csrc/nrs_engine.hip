@@ -800,7 +800,7 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
 //   [0] r.u  [1] w.u  [2] u_l.(H_pl^T u_p)  [3..8] H_pl u_l (pose rows)
 // =====================================================================================
 template <int T, bool LDS>
-__global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
+__global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
     static_assert(!LDS, "gather fallback only: the LDS-staged path is k_spmv_f");
     __shared__ double lds[4 * 9];
     constexpr int R = 64 / T;
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
         double h0 = 0, h1 = 0, h2 = 0;
 #pragma unroll
         for (int p = t; p < 6; p += T) {
-            const double upk = P.up[6 * kf + p];
+            const double upk = ((it & 1) ? P.up2 : P.up)[6 * kf + p];
             const double e0 = P.Hpl[(size_t)(p * 3) * P.n_rows + row];
             const double e1 = P.Hpl[(size_t)(p * 3 + 1) * P.n_rows + row];
             const double e2 = P.Hpl[(size_t)(p * 3 + 2) * P.n_rows + row];
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam) {
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
 template <int T>
-__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
+__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls) {
         if (rc.w != 0.0) {
             double up[6];
 #pragma unroll
-            for (int p = 0; p < 6; ++p) up[p] = P.up[6 * kf + p];
+            for (int p = 0; p < 6; ++p) up[p] = ((it & 1) ? P.up2 : P.up)[6 * kf + p];
             row_factored(rc, P.lin_pose[kf], xs, ul, up, P.pose_fixed[kf] ? 0.0 : 1.0, a0, a1, a2, part);
         }
     }
@@ -1049,6 +1049,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     __shared__ double lds[4 * 3];
     const int n_vecblk = P.n_vecblk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // u_p and r_p are read by every workgroup (for the scalars) and rewritten by the pose workgroups
+    // of the same launch: they are a ping-pong pair (read half it&1, write the other)
+    const double* up_in = (it & 1) ? P.up2 : P.up;   double* up_out = (it & 1) ? P.up : P.up2;
+    const double* rp_in = (it & 1) ? P.rp2 : P.rp;   double* rp_out = (it & 1) ? P.rp : P.rp2;
     // Everything this launch reads is requested before the first dependent use (flag, scalars,
     // partials, the two rows of this thread): otherwise the launch is a chain of four round trips.
     const int done_flag = P.flags[0];
@@ -1080,6 +1084,32 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             Di[2 * k] = a.x; Di[2 * k + 1] = a.y;
         }
     }
+    // pose workgroups (one wave per pose): their inputs are requested up front as well
+    const int pk_pose = row_wg ? P.K : (int)(blockIdx.x - n_vec8) * 4 + wave;
+    const bool has_pose = pk_pose < P.K;
+    const int pa = lane < 6 ? lane : 0;
+    double q_up[6], q_H[6], q_Hi[6], q_pp = 0, q_sp = 0, q_rp = 0, q_xp = 0, q_acc[6] = {0, 0, 0, 0, 0, 0};
+    int pg0 = 0, pg1 = 0;
+    if (has_pose) {
+        const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
+        pg0 = P.pose_grp_ptr[pk_pose] * rb; pg1 = P.pose_grp_ptr[pk_pose + 1] * rb;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int lo = pa < c ? pa : c, hi = pa < c ? c : pa;
+            const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+            q_up[c] = up_in[6 * pk_pose + c];
+            q_H[c] = P.Hpp[21 * pk_pose + pk];
+            q_Hi[c] = P.Hppinv[36 * pk_pose + pa * 6 + c];
+        }
+        q_pp = P.pp[6 * pk_pose + pa]; q_sp = P.sp[6 * pk_pose + pa]; q_rp = rp_in[6 * pk_pose + pa]; q_xp = P.xp[6 * pk_pose + pa];
+        if (P.hier) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q_acc[a] = P.red[3 + 6 * pk_pose + a];
+        } else if (pg0 + lane < pg1) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) q_acc[a] += P.part_spmv[(size_t)(pg0 + lane) * NPART + 3 + a];
+        }
+    }
     double v[3] = {0, 0, 0};
     if (P.hier) {
         if (tid == 0) { v[0] = P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
@@ -1093,13 +1123,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
     for (int i = tid; i < 6 * P.K; i += BLK) {
         const int k = i / 6, a = i % 6;
-        const double ua = P.up[i];
-        v[0] += P.rp[i] * ua;
+        const double ua = up_in[i];
+        v[0] += rp_in[i] * ua;
         double s = lam * ua;
         for (int c = 0; c < 6; ++c) {
             const int lo = a < c ? a : c, hi = a < c ? c : a;
             const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);     // packed upper index
-            s += P.Hpp[21 * k + pk] * P.up[6 * k + c];
+            s += P.Hpp[21 * k + pk] * up_in[6 * k + c];
         }
         v[1] += ua * s;
     }
@@ -1159,16 +1189,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         }
     } else {
         // pose workgroups: one wave per pose; its 64 lanes split the pose's SpMV partials
-        const int k = (blockIdx.x - n_vec8) * 4 + wave;
-        if (k < P.K) {
-            const int rb = ROW_ALIGN / (BLK / P.T);       // reg-blocks per row group
-            const int g0 = P.pose_grp_ptr[k] * rb, g1 = P.pose_grp_ptr[k + 1] * rb;
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            if (P.hier) {
+        if (has_pose) {
+            const int k = pk_pose;
+            double acc[6];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) acc[a] = P.red[3 + 6 * k + a];
-            } else {
-                for (int g = g0 + lane; g < g1; g += 64) {
+            for (int a = 0; a < 6; ++a) acc[a] = q_acc[a];
+            if (!P.hier) {
+                for (int g = pg0 + lane + 64; g < pg1; g += 64) {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
                 }
@@ -1176,30 +1203,26 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
                 for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
             }
             // lanes 0..5 own one pose component each
-            const int a = lane < 6 ? lane : 0;
-            double hw = acc[0];
+            const int a = pa;
+            double hw = acc[0], ua = q_up[0];
 #pragma unroll
-            for (int q = 1; q < 6; ++q) hw = (a == q) ? acc[q] : hw;
+            for (int q = 1; q < 6; ++q) { hw = (a == q) ? acc[q] : hw; ua = (a == q) ? q_up[q] : ua; }
             const int i = 6 * k + a;
-            const double ua = P.up[i];
             double w = lam * ua + hw;
-            for (int c = 0; c < 6; ++c) {
-                const int lo = a < c ? a : c, hi = a < c ? c : a;
-                const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
-                w += P.Hpp[21 * k + pk] * P.up[6 * k + c];
-            }
-            const double p = ua + beta * P.pp[i];
-            const double sN = w + beta * P.sp[i];
-            const double rnew = P.rp[i] - alpha * sN;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) w += q_H[c] * q_up[c];
+            const double p = ua + beta * q_pp;
+            const double sN = w + beta * q_sp;
+            const double rnew = q_rp - alpha * sN;
             double unew = 0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) unew += P.Hppinv[36 * k + a * 6 + c] * __shfl(rnew, c, 64);
+            for (int c = 0; c < 6; ++c) unew += q_Hi[c] * __shfl(rnew, c, 64);
             if (lane < 6) {
                 P.pp[i] = p;
                 P.sp[i] = sN;
-                P.xp[i] += alpha * p;
-                P.rp[i] = rnew;
-                P.up[i] = unew;
+                P.xp[i] = q_xp + alpha * p;
+                rp_out[i] = rnew;
+                up_out[i] = unew;
             }
         }
     }
@@ -2214,30 +2237,30 @@ static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
 }
 
 template <bool LDS>
-static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm) {
+static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int it) {
     const dim3 g(((d.n_regblk + 7) / 8) * 8), b(BLK);
     switch (d.T) {
-        case 1: hipLaunchKernelGGL((k_spmv<1, LDS>), g, b, shm, c->stream, d, lam); break;
-        case 4: hipLaunchKernelGGL((k_spmv<4, LDS>), g, b, shm, c->stream, d, lam); break;
-        case 8: hipLaunchKernelGGL((k_spmv<8, LDS>), g, b, shm, c->stream, d, lam); break;
-        case 16: hipLaunchKernelGGL((k_spmv<16, LDS>), g, b, shm, c->stream, d, lam); break;
-        default: hipLaunchKernelGGL((k_spmv<2, LDS>), g, b, shm, c->stream, d, lam); break;
+        case 1: hipLaunchKernelGGL((k_spmv<1, LDS>), g, b, shm, c->stream, d, lam, it); break;
+        case 4: hipLaunchKernelGGL((k_spmv<4, LDS>), g, b, shm, c->stream, d, lam, it); break;
+        case 8: hipLaunchKernelGGL((k_spmv<8, LDS>), g, b, shm, c->stream, d, lam, it); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, LDS>), g, b, shm, c->stream, d, lam, it); break;
+        default: hipLaunchKernelGGL((k_spmv<2, LDS>), g, b, shm, c->stream, d, lam, it); break;
     }
 }
 
-static void launch_spmv(nrs_ctx* c, const Dev& d, double lam) {
-    if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0); return; }
+static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it) {
+    if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0, it); return; }
     for (int cls = 0; cls < 2; ++cls) {
         const int n = d.n_tiles_cls[cls];
         if (n == 0) continue;
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         const dim3 g(((n + 7) / 8) * 8), b(BLK);
         switch (d.T) {
-            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls); break;
-            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls); break;
-            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls); break;
-            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls); break;
-            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls); break;
+            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls, it); break;
+            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls, it); break;
+            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls, it); break;
+            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls, it); break;
+            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls, it); break;
         }
     }
 }
@@ -2308,7 +2331,7 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
         }
         {
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
-            launch_spmv(c, d, lam);
+            launch_spmv(c, d, lam, it);
         }
         if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
         {
