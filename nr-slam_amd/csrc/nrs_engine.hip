@@ -2299,6 +2299,7 @@ constexpr double PEEK_RTOL = 1e-2;      // inner-solve accuracy at which a trial
 // ~1e-2 / 4e-3 / 2e-3 of the final one at those milestones (second order in the PCG error; measured
 // on the a2 and BA problems, profiles/README.md), so the thresholds keep a >10x margin.
 constexpr int PEEK_LEVELS = 3;
+constexpr double PEEK_MIN_REL_INCREASE = 1e-5;
 constexpr double PEEK_RHO_LVL[5] = {0, -0.25, -0.1, -0.03, -0.03};
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
@@ -2416,7 +2417,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     // peek: a trial that is clearly going to be rejected is not solved any further --
                     // its step is discarded, so the iterate sequence is the reference's either way
                     const double rho_peek = (chi - temp) / scale;
-                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl];
+                    // ... and only when the chi2 increase is well above the noise floor of the fp32
+                    // projection (relative 1e-7 per evaluation): near convergence the gain ratio of a
+                    // tiny step is noise over the 1e-3 regulariser of its denominator, at any accuracy
+                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl] && (temp - chi) > PEEK_MIN_REL_INCREASE * chi;
                     if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f\n", it, qmax, lvl, pit, rho_peek); early = false; }
                     if (early) break;
                     seen = lvl;
