@@ -140,12 +140,15 @@ __device__ inline void project_f32(const Cam& c, float x, float y, float z, floa
         v = c.p[1] * y / z + c.p[3];
     } else {
         const float r2 = x * x + y * y;
-        const float th = atan2f(sqrtf(r2), z);
-        const float psi = atan2f(y, x);
+        // atan2f / cosf / sinf are DEFINED here (and in the oracle) as the double-precision function
+        // rounded to float: the value a correctly rounded float routine returns.  libm, ocml and
+        // NumPy float routines differ in the last ulp, which flips inlier decisions once in a while.
+        const float th = (float)atan2((double)sqrtf(r2), (double)z);
+        const float psi = (float)atan2((double)y, (double)x);
         const float th2 = th * th, th3 = th * th2, th5 = th3 * th2, th7 = th5 * th2, th9 = th7 * th2;
         const float r = th + c.p[4] * th3 + c.p[5] * th5 + c.p[6] * th7 + c.p[7] * th9;
-        u = c.p[0] * r * cosf(psi) + c.p[2];
-        v = c.p[1] * r * sinf(psi) + c.p[3];
+        u = c.p[0] * r * (float)cos((double)psi) + c.p[2];
+        v = c.p[1] * r * (float)sin((double)psi) + c.p[3];
     }
 }
 
@@ -161,7 +164,7 @@ __device__ inline void projection_jacobian_f32(const Cam& c, float x, float y, f
         const float r2 = x2 + y2;
         const float r = sqrtf(r2);
         const float r3 = r2 * r;
-        const float th = atan2f(r, z);
+        const float th = (float)atan2((double)r, (double)z);
         const float th2 = th * th, th3 = th2 * th, th4 = th2 * th2, th5 = th4 * th;
         const float th6 = th2 * th4, th7 = th6 * th, th8 = th4 * th4, th9 = th8 * th;
         const float f = th + th3 * k0 + th5 * k1 + th7 * k2 + th9 * k3;

@@ -63,16 +63,18 @@ def project_f32(model, prm, p):
     else:
         k0, k1, k2, k3 = prm[4], prm[5], prm[6], prm[7]
         r2 = x * x + y * y
-        th = np.arctan2(np.sqrt(r2), z).astype(F32)
-        psi = np.arctan2(y, x).astype(F32)
+        # atan2f / cosf / sinf are defined as the double function rounded to float (the value a
+        # correctly rounded float routine returns); same definition on the device
+        th = np.arctan2(np.sqrt(r2).astype(np.float64), z.astype(np.float64)).astype(F32)
+        psi = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(F32)
         th2 = th * th
         th3 = th * th2
         th5 = th3 * th2
         th7 = th5 * th2
         th9 = th7 * th2
         r = th + k0 * th3 + k1 * th5 + k2 * th7 + k3 * th9
-        u = fx * r * np.cos(psi).astype(F32) + cx
-        v = fy * r * np.sin(psi).astype(F32) + cy
+        u = fx * r * np.cos(psi.astype(np.float64)).astype(F32) + cx
+        v = fy * r * np.sin(psi.astype(np.float64)).astype(F32) + cy
     return np.stack([u, v], axis=1).astype(F32)
 
 
@@ -94,7 +96,7 @@ def projection_jacobian_f32(model, prm, p):
         r2 = x2 + y2
         r = np.sqrt(r2).astype(F32)
         r3 = r2 * r
-        th = np.arctan2(r, z).astype(F32)
+        th = np.arctan2(r.astype(np.float64), z.astype(np.float64)).astype(F32)
         th2 = th * th
         th3 = th2 * th
         th4 = th2 * th2

@@ -109,10 +109,10 @@ def test_track_deform_matches_oracle(ctx, n, seed):
 
 def test_track_deform_kb8(ctx):
     tp, r, o, tr, otr = _track_compare(ctx, 400, 21, S.KB8)
-    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-5, rtol=0)
-    assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-4, rtol=0)
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
+    assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
     assert np.mean(r["f_status"] == o["f_status"]) > 0.99
-    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-3, rtol=0)
+    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-4, rtol=0)
 
 
 def test_track_deform_no_lost_points(ctx):
