@@ -41,24 +41,25 @@ def aggregates(Ad, size):
 def two_level(A, Mj, Z):
     Ac = (Z.T @ A @ Z).toarray(); Aci = np.linalg.inv(Ac)
     return lambda r: Mj(r) + Z @ (Aci @ (Z.T @ r))
-for ci in [0, 1, 2, 3, 4, 8]:
-    A, b = caps[ci]; n = A.shape[0]; nb = (n - 6) // 3
-    Mj, D, Ad = block_jacobi(A)
-    base = pcg(A, b, Mj)
-    res = [base]
-    for size in (16, 32, 64):
-        agg, na = aggregates(Ad, size)
-        # 3-dof piecewise constant + pose identity
-        rows = np.arange(n - 6) + 6; cols = 6 + 3 * agg[(rows - 6) // 3] + (rows - 6) % 3
-        Z = sp.csr_matrix((np.ones(n - 6), (rows, cols)), shape=(n, 6 + 3 * na))
-        Z = Z + sp.csr_matrix((np.ones(6), (np.arange(6), np.arange(6))), shape=(n, 6 + 3 * na))
-        r3 = pcg(A, b, two_level(A, Mj, Z))
-        # depth-only: weakest eigenvector of the diagonal block
-        w, V = np.linalg.eigh(D); e = V[:, :, 0]       # smallest eigenvalue
-        # orient consistently
-        e *= np.sign(e @ e[0])[:, None] + (e @ e[0] == 0)[:, None]
-        Z1 = sp.csr_matrix((e.ravel(), (rows, 6 + agg[(rows - 6) // 3])), shape=(n, 6 + na))
-        Z1 = Z1 + sp.csr_matrix((np.ones(6), (np.arange(6), np.arange(6))), shape=(n, 6 + na))
-        r1 = pcg(A, b, two_level(A, Mj, Z1))
-        res.append((size, na, r3, r1))
-    print("system", ci, "n", n, "block-jacobi", base, "| (size, n_agg, 3dof, depth-only):", res[1:], flush=True)
+if __name__ == "__main__":
+  for ci in [0, 1, 2, 3, 4, 8]:
+      A, b = caps[ci]; n = A.shape[0]; nb = (n - 6) // 3
+      Mj, D, Ad = block_jacobi(A)
+      base = pcg(A, b, Mj)
+      res = [base]
+      for size in (16, 32, 64):
+          agg, na = aggregates(Ad, size)
+          # 3-dof piecewise constant + pose identity
+          rows = np.arange(n - 6) + 6; cols = 6 + 3 * agg[(rows - 6) // 3] + (rows - 6) % 3
+          Z = sp.csr_matrix((np.ones(n - 6), (rows, cols)), shape=(n, 6 + 3 * na))
+          Z = Z + sp.csr_matrix((np.ones(6), (np.arange(6), np.arange(6))), shape=(n, 6 + 3 * na))
+          r3 = pcg(A, b, two_level(A, Mj, Z))
+          # depth-only: weakest eigenvector of the diagonal block
+          w, V = np.linalg.eigh(D); e = V[:, :, 0]       # smallest eigenvalue
+          # orient consistently
+          e *= np.sign(e @ e[0])[:, None] + (e @ e[0] == 0)[:, None]
+          Z1 = sp.csr_matrix((e.ravel(), (rows, 6 + agg[(rows - 6) // 3])), shape=(n, 6 + na))
+          Z1 = Z1 + sp.csr_matrix((np.ones(6), (np.arange(6), np.arange(6))), shape=(n, 6 + na))
+          r1 = pcg(A, b, two_level(A, Mj, Z1))
+          res.append((size, na, r3, r1))
+      print("system", ci, "n", n, "block-jacobi", base, "| (size, n_agg, 3dof, depth-only):", res[1:], flush=True)
