@@ -42,7 +42,9 @@ namespace nrs {
 
 constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj workgroup
 constexpr int BLK = 256;             // threads per workgroup everywhere
-constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel
+constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel: [0..2] dots, [3..8] pose sums
+constexpr int CO_MAX = 84;           // largest coarse system of the two-level preconditioner (fits one workgroup's LDS)
+constexpr int CO_TG = 8;             // row groups a tile's incidences may reach (own group included)
 
 // incidence meta bits
 constexpr int SM_COUNT = 1 << 30;    // spring: this incidence adds the edge's rho to chi2
@@ -108,6 +110,19 @@ struct Dev {
     // second halves of the ping-pong pairs used by the fused small-problem iteration
     double *rp2, *sp2, *up2, *rv2, *sv2, *wv2, *part_spmv2;
     int fused;
+    // two-level preconditioner of the fused path (single pose): coarse unknowns = one translation per
+    // 256-row group + the pose; M^-1 = block-Jacobi + Z (Z^T H Z + lambda Z^T Z)^-1 Z^T
+    int coarse, co_n;                // enabled, number of coarse unknowns (3 n_groups + 6)
+    int* co_tg;                      // n_regblk x CO_TG target groups of a tile (-1 padded)
+    double* co_ct;                   // n_regblk x CO_TG x 6: sum of H_ij over i in tile, j in target group
+    double* co_cp;                   // n_regblk x 18: sum of H_lp over the tile's rows (3x6)
+    double* co_tb;                   // n_regblk x 4: sum of b (3) and number of free rows
+    double* part_ts; double* part_ts2;   // 9 x n_regblk (component-major, ping-pong): tile sums of r, s, w
+    double* co_bt;                   // n_regblk x 6: sum of H_ij over i, j in the tile (tile-level diagonal block)
+    double* co_c0;                   // co_n x co_n: Z^T H Z ; co_nn: Z^T Z diagonal ; co_bc: Z^T b
+    double* co_nn; double* co_bc;
+    double* co_inv;                  // co_n x co_n: (C0 + lambda N)^-1 of the current trial
+    double* co_y0;                   // co_n: its product with Z^T b (start vector of the trial)
     int* tile_desc;                  // fused path: 8 ints per tile {pose, first tile of pose, end tile of pose, halo begin, halo count, 0,0,0}
     int* halo_fix;                   // fused path: BLK ints per tile = the first BLK halo rows (fixed stride: no pointer chase)
     // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
@@ -193,6 +208,17 @@ __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double la
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (a * g - c * c) * id; o[4] = (b * c - a * f) * id; o[5] = (a * e - b * b) * id;
     return det > 0;
+}
+
+// tile-level coarse correction: y = (B_t + lambda n_t I)^-1 rc, zero when the block is not positive
+__device__ inline void tile_level(const double* Bt /*6*/, double nfree, double lam, const double* rc, double* y) {
+    double Bi[6];
+    y[0] = y[1] = y[2] = 0;
+    if (nfree > 0 && inv3_sym(Bt, lam * nfree, Bi) && Bi[0] > 0) {
+        y[0] = Bi[0] * rc[0] + Bi[1] * rc[1] + Bi[2] * rc[2];
+        y[1] = Bi[1] * rc[0] + Bi[3] * rc[1] + Bi[4] * rc[2];
+        y[2] = Bi[2] * rc[0] + Bi[4] * rc[1] + Bi[5] * rc[2];
+    }
 }
 
 // stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0).
@@ -722,6 +748,279 @@ __global__ void k_publish(Dev P) {
 }
 
 // =====================================================================================
+// Two-level preconditioner of the fused path (one pose, <= CO_MAX coarse unknowns).
+//   k_coarse_tile   (per linearisation, one workgroup per tile): the tile's rows of Z^T H Z, i.e.
+//                   sum of H_ij over i in the tile and j in each row group its incidences reach,
+//                   its part of the landmark-pose coupling, sum of b, number of free rows;
+//   k_coarse_reduce (one workgroup): C0 = Z^T H Z, N = Z^T Z, bc = Z^T b in fixed summation order;
+//   k_coarse_invert (per trial, one workgroup): (C0 + lambda N)^-1 by in-place Gauss-Jordan in LDS.
+// Coarse unknown 3g+c = translation c of every free row of group g; 3G+a = pose component a.
+// =====================================================================================
+template <int T>
+__global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
+    __shared__ double lds[4 * 9];
+    extern __shared__ double dyn[];
+    constexpr int R = 64 / T;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = b * 4 + wave;
+    const int row = slice * R + lane / T;
+    const int t = lane % T;
+    const int row0 = b * P.tile_rows;
+    const int own_grp = row0 / ROW_ALIGN;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    double* lx = dyn;                                                      // positions, tile + halo
+    unsigned char* lfix = reinterpret_cast<unsigned char*>(dyn + 3 * (size_t)(P.tile_rows + P.max_halo));
+    unsigned short* lgrp = reinterpret_cast<unsigned short*>(lfix + P.tile_rows + P.max_halo + 8);
+    stage_rows(P, b, tid, P.lin_xl, P.X0, lx);
+    for (int i = tid; i < P.tile_rows + hn; i += BLK) {
+        const int r = i < P.tile_rows ? row0 + i : P.halo_rows[hb + i - P.tile_rows];
+        lfix[i] = (P.rflag[r] & RF_FIXED) ? 1 : 0;
+        lgrp[i] = (unsigned short)(r / ROW_ALIGN);
+    }
+    __syncthreads();
+    const int self = row - row0;
+    const bool rfix = lfix[self] != 0;
+    const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
+    const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
+    const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
+    for (int slot = 0; slot < CO_TG; ++slot) {
+        const int hg = P.co_tg[b * CO_TG + slot];
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (hg >= 0) {
+            if (t == 0 && !rfix && hg == own_grp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[k] = P.D[6 * (size_t)row + k];
+            }
+            for (int idx = sbeg + lane; idx < send; idx += 64) {
+                const SpringRec rc = P.s_rec[idx];
+                if (rc.other == REC_NONE || lfix[rc.other] || lgrp[rc.other] != hg) continue;
+                const int o = rc.other;
+                const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
+                const double m = -rc.qc;                                   // H_ij = -qc v v^T
+                acc[0] += m * v0 * v0; acc[1] += m * v0 * v1; acc[2] += m * v0 * v2;
+                acc[3] += m * v1 * v1; acc[4] += m * v1 * v2; acc[5] += m * v2 * v2;
+            }
+            for (int idx = dbeg + lane; idx < dend; idx += 64) {
+                const DamperRec rc = P.d_rec[idx];
+                if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
+                const int role = rc.meta & 3;
+                const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
+                const double so = damper_sign(role);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (o[k] == REC_NONE || lfix[o[k]] || lgrp[o[k]] != hg) continue;
+                    const double c = so * damper_sign(k + (k >= role ? 1 : 0)) * rc.s;   // H_ik = sg_i sg_k s I
+                    acc[0] += c; acc[3] += c; acc[5] += c;
+                }
+            }
+        }
+        block_sum_store<6>(acc, lds, tid, P.co_ct + ((size_t)b * CO_TG + slot) * 6);
+        __syncthreads();
+    }
+    {   // tile-level block: the same sum restricted to j inside the tile (second, finer level)
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (t == 0 && !rfix) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = P.D[6 * (size_t)row + k];
+        }
+        for (int idx = sbeg + lane; idx < send; idx += 64) {
+            const SpringRec rc = P.s_rec[idx];
+            if (rc.other == REC_NONE || rc.other >= P.tile_rows || lfix[rc.other]) continue;
+            const int o = rc.other;
+            const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
+            const double m = -rc.qc;
+            acc[0] += m * v0 * v0; acc[1] += m * v0 * v1; acc[2] += m * v0 * v2;
+            acc[3] += m * v1 * v1; acc[4] += m * v1 * v2; acc[5] += m * v2 * v2;
+        }
+        for (int idx = dbeg + lane; idx < dend; idx += 64) {
+            const DamperRec rc = P.d_rec[idx];
+            if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
+            const int role = rc.meta & 3;
+            const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
+            const double so = damper_sign(role);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (o[k] == REC_NONE || o[k] >= P.tile_rows || lfix[o[k]]) continue;
+                const double c = so * damper_sign(k + (k >= role ? 1 : 0)) * rc.s;
+                acc[0] += c; acc[3] += c; acc[5] += c;
+            }
+        }
+        block_sum_store<6>(acc, lds, tid, P.co_bt + (size_t)b * 6);
+        __syncthreads();
+    }
+    // landmark-pose coupling of the tile's rows: sum of H_lp = J_l^T w J_p (3x6), two halves of 9
+    double cp[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) cp[k] = 0;
+    double tb[4] = {0, 0, 0, 0};
+    if (t == 0 && !rfix) {
+        const RowRec rc = P.rowrec[row];
+        if (rc.w != 0.0 && !P.pose_fixed[0]) {
+            const Pose Tcw = P.lin_pose[0];
+            double Rm[9];
+            quat_to_R(Tcw.q, Rm);
+            const double px = Rm[0] * xs[0] + Rm[1] * xs[1] + Rm[2] * xs[2] + Tcw.t[0];
+            const double py = Rm[3] * xs[0] + Rm[4] * xs[1] + Rm[5] * xs[2] + Tcw.t[1];
+            const double pz = Rm[6] * xs[0] + Rm[7] * xs[1] + Rm[8] * xs[2] + Tcw.t[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+                const double Jp[6] = {-j1 * pz + j2 * py, j0 * pz - j2 * px, -j0 * py + j1 * px, j0, j1, j2};
+                const double Jl[3] = {j0 * Rm[0] + j1 * Rm[3] + j2 * Rm[6], j0 * Rm[1] + j1 * Rm[4] + j2 * Rm[7],
+                                      j0 * Rm[2] + j1 * Rm[5] + j2 * Rm[8]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) cp[c * 6 + a] += rc.w * Jl[c] * Jp[a];
+            }
+        }
+        tb[0] = P.bl[3 * row]; tb[1] = P.bl[3 * row + 1]; tb[2] = P.bl[3 * row + 2];
+        tb[3] = 1.0;
+    }
+    block_sum_store<9>(cp, lds, tid, P.co_cp + (size_t)b * 18);
+    __syncthreads();
+    block_sum_store<9>(cp + 9, lds, tid, P.co_cp + (size_t)b * 18 + 9);
+    __syncthreads();
+    block_sum_store<4>(tb, lds, tid, P.co_tb + (size_t)b * 4);
+}
+
+__global__ __launch_bounds__(BLK) void k_coarse_reduce(Dev P) {
+    const int tid = threadIdx.x;
+    const int G = P.n_groups, n = P.co_n, rb = ROW_ALIGN / P.tile_rows;
+    for (int i = tid; i < n * n; i += BLK) P.co_c0[i] = 0;
+    __syncthreads();
+    // group-group blocks: thread per (g, h), fixed order over the group's tiles and their slots
+    for (int gh = tid; gh < G * G; gh += BLK) {
+        const int g = gh / G, h = gh % G;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int tl = g * rb; tl < (g + 1) * rb; ++tl)
+            for (int slot = 0; slot < CO_TG; ++slot)
+                if (P.co_tg[tl * CO_TG + slot] == h)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) acc[k] += P.co_ct[((size_t)tl * CO_TG + slot) * 6 + k];
+        const double m[9] = {acc[0], acc[1], acc[2], acc[1], acc[3], acc[4], acc[2], acc[4], acc[5]};
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) P.co_c0[(size_t)(3 * g + a) * n + 3 * h + c] = m[a * 3 + c];
+    }
+    // group sums of the coupling, of b and of the free-row counts
+    for (int g = tid; g < G; g += BLK) {
+        double cp[18], tb[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 18; ++k) cp[k] = 0;
+        for (int tl = g * rb; tl < (g + 1) * rb; ++tl) {
+            for (int k = 0; k < 18; ++k) cp[k] += P.co_cp[(size_t)tl * 18 + k];
+            for (int k = 0; k < 4; ++k) tb[k] += P.co_tb[(size_t)tl * 4 + k];
+        }
+        for (int c = 0; c < 3; ++c) {
+            for (int a = 0; a < 6; ++a) {
+                P.co_c0[(size_t)(3 * g + c) * n + 3 * G + a] = cp[c * 6 + a];
+                P.co_c0[(size_t)(3 * G + a) * n + 3 * g + c] = cp[c * 6 + a];
+            }
+            P.co_nn[3 * g + c] = tb[3];
+            P.co_bc[3 * g + c] = tb[c];
+        }
+    }
+    // pose block
+    if (tid < 36) {
+        const int a = tid / 6, c = tid % 6;
+        const int lo = a < c ? a : c, hi = a < c ? c : a;
+        const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+        const bool pfix = P.pose_fixed[0] != 0;
+        P.co_c0[(size_t)(3 * G + a) * n + 3 * G + c] = pfix ? (a == c ? 1.0 : 0.0) : P.Hpp[pk];
+        if (c == 0) { P.co_nn[3 * G + a] = pfix ? 0.0 : 1.0; P.co_bc[3 * G + a] = pfix ? 0.0 : P.bp[a]; }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_coarse_invert(Dev P, double lam) {
+    // In-place Gauss-Jordan (SPD: no pivoting) with the matrix in REGISTERS: thread (br, bc) keeps a
+    // 6x6 block; per pivot step only the pivot row and column go through LDS (double-buffered: one
+    // barrier per step).  The matrix is padded to a multiple of 6 with an identity block.  A
+    // non-positive pivot switches the coarse level off for this trial.
+    extern __shared__ double A[];                                          // n x n (result, for y0)
+    constexpr int BS = 6, NBMAX = (CO_MAX + BS - 1) / BS;
+    __shared__ double colb[2][NBMAX * BS], rowb[2][NBMAX * BS];
+    __shared__ int bad;
+    const int tid = threadIdx.x, n = P.co_n;
+    const int nb = (n + BS - 1) / BS;
+    const bool act = tid < nb * nb;
+    const int br = act ? tid / nb : 0, bc = act ? tid % nb : 0;
+    if (tid == 0) bad = 0;
+    double a[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+            const int r = br * BS + i, c = bc * BS + j;
+            double v = r == c ? 1.0 : 0.0;
+            if (act && r < n && c < n) {
+                v = P.co_c0[(size_t)r * n + c];
+                if (r == c) {
+                    v += lam * P.co_nn[r];
+                    if (P.co_nn[r] == 0.0 && v == 0.0) v = 1.0;            // empty group: keep the system regular
+                }
+            }
+            a[i][j] = v;
+        }
+    __syncthreads();
+    const int np = nb * BS;
+    bool ok = true;
+    for (int p = 0; p < np; ++p) {
+        const int pb = p / BS, pi = p % BS, buf = p & 1;
+        if (act && bc == pb) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                double v = a[i][0];
+#pragma unroll
+                for (int j = 1; j < BS; ++j) v = (pi == j) ? a[i][j] : v;
+                colb[buf][br * BS + i] = v;
+            }
+        }
+        if (act && br == pb) {
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                double v = a[0][j];
+#pragma unroll
+                for (int i = 1; i < BS; ++i) v = (pi == i) ? a[i][j] : v;
+                rowb[buf][bc * BS + j] = v;
+            }
+        }
+        __syncthreads();
+        const double piv = rowb[buf][p];
+        if (!(piv > 0) || !isfinite(piv)) { ok = false; break; }
+        const double pinv = 1.0 / piv;
+        double cr[BS], rw[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) { cr[i] = colb[buf][br * BS + i]; rw[i] = rowb[buf][bc * BS + i]; }
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const bool rp = br * BS + i == p, cp = bc * BS + j == p;
+                const double upd = a[i][j] - cr[i] * rw[j] * pinv;
+                a[i][j] = rp ? (cp ? pinv : rw[j] * pinv) : (cp ? -cr[i] * pinv : upd);
+            }
+    }
+    if (!ok && tid == 0) bad = 1;
+    __syncthreads();
+    const bool off = bad != 0;
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const int r = br * BS + i, c = bc * BS + j;
+                if (r < n && c < n) { const double v = off ? 0.0 : a[i][j]; A[r * n + c] = v; P.co_inv[(size_t)r * n + c] = v; }
+            }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += BLK) {
+        double y = 0;
+        for (int c = 0; c < n; ++c) y += A[j * n + c] * P.co_bc[c];
+        P.co_y0[j] = y;
+    }
+}
+
+// =====================================================================================
 // per-trial setup: block-Jacobi preconditioner for (H + lambda I) and the PCG start vectors
 //   x = 0, r = b, u = M^-1 r, p = s = 0.
 // =====================================================================================
@@ -774,9 +1073,16 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
         for (int k = 0; k < 6; ++k) P.Dinv[6 * (size_t)i + k] = Di[k];
         const double r0 = P.bl[3 * i], r1 = P.bl[3 * i + 1], r2 = P.bl[3 * i + 2];
         P.rv[3 * i] = r0; P.rv[3 * i + 1] = r1; P.rv[3 * i + 2] = r2;
-        P.uv3[3 * i] = Di[0] * r0 + Di[1] * r1 + Di[2] * r2;
-        P.uv3[3 * i + 1] = Di[1] * r0 + Di[3] * r1 + Di[4] * r2;
-        P.uv3[3 * i + 2] = Di[2] * r0 + Di[4] * r1 + Di[5] * r2;
+        double y0 = 0, y1 = 0, y2 = 0;
+        if (P.coarse && !(P.rflag[i] & RF_FIXED)) {
+            const int g = i / ROW_ALIGN, tl = i / P.tile_rows;
+            double yt[3];
+            tile_level(P.co_bt + 6 * (size_t)tl, P.co_tb[4 * (size_t)tl + 3], lam, P.co_tb + 4 * (size_t)tl, yt);
+            y0 = P.co_y0[3 * g] + yt[0]; y1 = P.co_y0[3 * g + 1] + yt[1]; y2 = P.co_y0[3 * g + 2] + yt[2];
+        }
+        P.uv3[3 * i] = Di[0] * r0 + Di[1] * r1 + Di[2] * r2 + y0;
+        P.uv3[3 * i + 1] = Di[1] * r0 + Di[3] * r1 + Di[4] * r2 + y1;
+        P.uv3[3 * i + 2] = Di[2] * r0 + Di[4] * r1 + Di[5] * r2 + y2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { P.xv[3 * i + k] = 0; P.pv[3 * i + k] = 0; P.sv[3 * i + k] = 0; }
     }
@@ -787,6 +1093,7 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
         for (int a = 0; a < 6; ++a) {
             double s = 0;
             for (int c = 0; c < 6; ++c) s += Ai[a * 6 + c] * P.bp[6 * i + c];
+            if (P.coarse && !P.pose_fixed[i]) s += P.co_y0[3 * P.n_groups + a];
             P.up[6 * i + a] = s;
             P.rp[6 * i + a] = P.bp[6 * i + a];
             P.xp[6 * i + a] = 0; P.pp[6 * i + a] = 0; P.sp[6 * i + a] = 0;
@@ -1238,7 +1545,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
 // the new values while neighbours still read the old ones.  Same arithmetic, in the same order, as
 // k_pcg_update + k_spmv.
 // =====================================================================================
-template <int T>
+template <int T, bool CO>
 __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, double tol2, double peek_tol2) {
     __shared__ double lds[4 * 9];
     __shared__ double s_up[6];
@@ -1259,6 +1566,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const double* up_in = hin ? P.up2 : P.up;   double* up_out = hout ? P.up2 : P.up;
     const double* part_in = hin ? P.part_spmv2 : P.part_spmv;
     double* part_out = hout ? P.part_spmv2 : P.part_spmv;
+    const double* ts_in = hin ? P.part_ts2 : P.part_ts;
+    double* ts_out = hout ? P.part_ts2 : P.part_ts;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
@@ -1282,11 +1591,17 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= phase 1: every global load this launch needs is requested up front (the
     // launch is a chain of dependent round trips otherwise: partials -> vectors -> records)
     double v[3] = {0, 0, 0};
+    const bool coarse = CO && it > 0;                              // CO: two-level preconditioner compiled in
+    double ts9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                  // thread q: sums of r, s, w of tile q (coarse level)
     if (it > 0) {
         for (int q = tid; q < P.n_regblk; q += BLK) {
             v[0] += part_in[(size_t)q * NPART];
             v[1] += part_in[(size_t)q * NPART + 1];
             v[2] += part_in[(size_t)q * NPART + 2];
+        }
+        if (coarse && tid < P.n_regblk) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) ts9[c] = ts_in[(size_t)c * P.n_regblk + tid];   // component-major: coalesced
         }
         for (int i = tid; i < 6 * P.K; i += BLK) {
             const int k = i / 6, a = i % 6;
@@ -1309,6 +1624,38 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const size_t hrow = (size_t)P.halo_fix[(size_t)b * BLK + tid];
     double h_w[3], h_s[3], h_r[3], h_D[6];
     double x_own[3] = {0, 0, 0}, x_h[3] = {0, 0, 0};
+    const bool o_free = own && !(P.rflag[orow] & RF_FIXED);
+    const bool h_free = hh && !(P.rflag[hrow] & RF_FIXED);
+    // coarse level: a workgroup needs y only for the groups its rows belong to (own group = slot 0,
+    // the groups of its halo rows = slots 1..7) and for the pose: 30 rows of A_c^-1, 8 threads per row
+    constexpr int CO_ROWS = 3 * CO_TG + 6, CO_PART = 8, CO_KMAX = (CO_MAX + CO_PART - 1) / CO_PART;
+    const int cn = P.co_n, cG = P.n_groups;
+    const int c_r = tid / CO_PART, c_p = tid % CO_PART;
+    int c_ci = -1;
+    double c_m[CO_KMAX];
+    int c_tg[CO_TG];
+    double bt_own[6], bt_h[6], nf_own = 0, nf_h = 0;
+    const int th_h = (int)(hrow / (size_t)P.tile_rows);              // tile of this thread's halo row
+    if (coarse) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bt[6 * (size_t)b + q]; bt_h[q] = P.co_bt[6 * (size_t)th_h + q]; }
+        nf_own = P.co_tb[4 * (size_t)b + 3]; nf_h = P.co_tb[4 * (size_t)th_h + 3];
+#pragma unroll
+        for (int q = 0; q < CO_TG; ++q) c_tg[q] = P.co_tg[b * CO_TG + q];
+        if (c_r < 3 * CO_TG) {
+            int g = c_tg[0];
+#pragma unroll
+            for (int q = 1; q < CO_TG; ++q) g = (c_r / 3 == q) ? c_tg[q] : g;
+            c_ci = g >= 0 ? 3 * g + c_r % 3 : -1;
+        } else if (c_r < CO_ROWS) {
+            c_ci = 3 * cG + (c_r - 3 * CO_TG);
+        }
+#pragma unroll
+        for (int q = 0; q < CO_KMAX; ++q) {
+            const int c = c_p + CO_PART * q;
+            c_m[q] = (c_ci >= 0 && c < cn) ? P.co_inv[(size_t)c_ci * cn + c] : 0.0;
+        }
+    }
     if (own) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) x_own[k] = P.lin_xl[3 * orow + k] + (P.X0 ? P.X0[3 * orow + k] : 0.0);
@@ -1389,6 +1736,62 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     load_dampers(dbeg + lane);
 
     if (done_flag) return;
+    // wave 0: w_p = (H_pp + lambda) u_p + sum_l H_pl u_l of the tile's pose (independent of alpha, beta)
+    double w_pose = 0, ua_pose = 0;
+    if (wave == 0) {
+        ua_pose = q_up[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) ua_pose = (pa == q) ? q_up[q] : ua_pose;
+        if (it > 0) {
+            double acc[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[c] = q_acc[c];
+            for (int g = pg0 + lane + 64; g < pg1; g += 64) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[c] += part_in[(size_t)g * NPART + 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
+            double hw = acc[0];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) hw = (pa == q) ? acc[q] : hw;
+            w_pose = lam * ua_pose + hw;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) w_pose += q_H[c] * q_up[c];
+        }
+    }
+    // ================= coarse level: y = A_c^-1 Z^T r_new with r_new = r - alpha w - alpha beta s, i.e.
+    // y = yR - alpha yW - alpha beta yS; the three products are formed before alpha, beta are known
+    double* c_ts = dyn + 6 * (size_t)(P.tile_rows + P.max_halo);  // n_regblk x 9 tile sums
+    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 7 vectors of CO_MAX: Rc Sc Wc yR yS yW y
+    if (coarse) {
+        if (tid < P.n_regblk) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) c_ts[9 * tid + c] = ts9[c];
+        }
+        if (wave == 0 && lane < 6) {
+            c_v[0 * CO_MAX + 3 * cG + lane] = q_rp;
+            c_v[1 * CO_MAX + 3 * cG + lane] = q_sp;
+            c_v[2 * CO_MAX + 3 * cG + lane] = w_pose;
+        }
+        __syncthreads();
+        const int rb = ROW_ALIGN / P.tile_rows;
+        if (tid < 9 * cG) {                                        // group sums in fixed order
+            const int g = tid / 9, c = tid % 9;
+            double sum = 0;
+            for (int j = 0; j < rb; ++j) sum += c_ts[9 * (g * rb + j) + c];
+            c_v[(c / 3) * CO_MAX + 3 * g + c % 3] = sum;
+        }
+        __syncthreads();
+        double yr = 0, ys = 0, yw = 0;
+#pragma unroll
+        for (int q = 0; q < CO_KMAX; ++q) {
+            const int c = c_p + CO_PART * q;
+            if (c < cn) { yr += c_m[q] * c_v[c]; ys += c_m[q] * c_v[CO_MAX + c]; yw += c_m[q] * c_v[2 * CO_MAX + c]; }
+        }
+        yr = group_sum<CO_PART>(yr); ys = group_sum<CO_PART>(ys); yw = group_sum<CO_PART>(yw);
+        if (c_p == 0 && c_r < CO_ROWS) { c_v[3 * CO_MAX + c_r] = yr; c_v[4 * CO_MAX + c_r] = ys; c_v[5 * CO_MAX + c_r] = yw; }
+    }
     // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
     double alpha = 0, beta = 0;
     if (it > 0) {
@@ -1418,36 +1821,26 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
         }
     }
+    if (coarse) {                                                  // (the reduction above was a barrier: yR, yS, yW are visible)
+        if (tid < CO_ROWS) c_v[6 * CO_MAX + tid] = c_v[3 * CO_MAX + tid] - alpha * c_v[5 * CO_MAX + tid] - alpha * beta * c_v[4 * CO_MAX + tid];
+        __syncthreads();
+    }
+    const double* ycor = c_v + 6 * CO_MAX;
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
     // it, the first workgroup of the pose also stores the pose part of the state)
     if (wave == 0) {
         const int a = pa;
         const int i = 6 * kf + a;
-        double ua = q_up[0];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) ua = (a == q) ? q_up[q] : ua;
+        const double ua = ua_pose;
         double unew = ua;
         if (it > 0) {
-            double acc[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[c] = q_acc[c];
-            for (int g = pg0 + lane + 64; g < pg1; g += 64) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) acc[c] += part_in[(size_t)g * NPART + 3 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
-            double hw = acc[0];
-#pragma unroll
-            for (int q = 1; q < 6; ++q) hw = (a == q) ? acc[q] : hw;
-            double w = lam * ua + hw;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) w += q_H[c] * q_up[c];
+            const double w = w_pose;
             const double sN = w + beta * q_sp;
             const double rnew = q_rp - alpha * sN;
             unew = 0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) unew += q_Hi[c] * __shfl(rnew, c, 64);
+            if (coarse && pmask != 0.0) unew += ycor[3 * CO_TG + a];
             if (lane < 6 && b == pg0) {
                 const double p = ua + beta * q_pp;
                 P.pp[i] = p;
@@ -1462,6 +1855,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= phase 4: u of the tile (own rows: full update, stored; halo rows:
     // recomputed from r, s, w, M^-1, LDS only)
     double dot_ru = 0;                                             // r.u of this thread's own row (after the update)
+    double sum9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                  // this tile's sums of r, s, w for the next launch
     if (it > 0) {
         if (own) {
             double rn[3];
@@ -1474,10 +1868,18 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 P.xv[3 * orow + k] = o_x[k] + alpha * p;
                 rn[k] = o_r[k] - alpha * sN;
                 r_out[3 * orow + k] = rn[k];
+                sum9[k] = rn[k]; sum9[3 + k] = sN;
             }
-            const double u0 = o_D[0] * rn[0] + o_D[1] * rn[1] + o_D[2] * rn[2];
-            const double u1 = o_D[1] * rn[0] + o_D[3] * rn[1] + o_D[4] * rn[2];
-            const double u2 = o_D[2] * rn[0] + o_D[4] * rn[1] + o_D[5] * rn[2];
+            double u0 = o_D[0] * rn[0] + o_D[1] * rn[1] + o_D[2] * rn[2];
+            double u1 = o_D[1] * rn[0] + o_D[3] * rn[1] + o_D[4] * rn[2];
+            double u2 = o_D[2] * rn[0] + o_D[4] * rn[1] + o_D[5] * rn[2];
+            if (coarse && o_free) {                                // slot 0 = own group; + tile level
+                double rc3[3], yt[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * b + k] - alpha * c_ts[9 * b + 6 + k] - alpha * beta * c_ts[9 * b + 3 + k];
+                tile_level(bt_own, nf_own, lam, rc3, yt);
+                u0 += ycor[0] + yt[0]; u1 += ycor[1] + yt[1]; u2 += ycor[2] + yt[2];
+            }
             P.uv3[3 * orow] = u0; P.uv3[3 * orow + 1] = u1; P.uv3[3 * orow + 2] = u2;
             lu[3 * tid] = u0; lu[3 * tid + 1] = u1; lu[3 * tid + 2] = u2;
             dot_ru = rn[0] * u0 + rn[1] * u1 + rn[2] * u2;
@@ -1494,9 +1896,28 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
 #pragma unroll
             for (int k = 0; k < 3; ++k) rn[k] = h_r[k] - alpha * (h_w[k] + beta * h_s[k]);
             double* dst = lu + 3 * (size_t)(P.tile_rows + i);
-            dst[0] = h_D[0] * rn[0] + h_D[1] * rn[1] + h_D[2] * rn[2];
-            dst[1] = h_D[1] * rn[0] + h_D[3] * rn[1] + h_D[4] * rn[2];
-            dst[2] = h_D[2] * rn[0] + h_D[4] * rn[1] + h_D[5] * rn[2];
+            double y0 = 0, y1 = 0, y2 = 0;
+            if (coarse) {
+                const size_t r2 = i == tid ? hrow : (size_t)P.halo_rows[hb + i];
+                const bool fr = i == tid ? h_free : !(P.rflag[r2] & RF_FIXED);
+                if (fr) {
+                    const int g = (int)(r2 / ROW_ALIGN);
+                    int sl = 0;
+#pragma unroll
+                    for (int q = 1; q < CO_TG; ++q) sl = (c_tg[q] == g) ? q : sl;
+                    const int th = (int)(r2 / (size_t)P.tile_rows);
+                    double rc3[3], yt[3], btl[6];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * th + k] - alpha * c_ts[9 * th + 6 + k] - alpha * beta * c_ts[9 * th + 3 + k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) btl[k] = i == tid ? bt_h[k] : P.co_bt[6 * (size_t)th + k];
+                    tile_level(btl, i == tid ? nf_h : P.co_tb[4 * (size_t)th + 3], lam, rc3, yt);
+                    y0 = ycor[3 * sl] + yt[0]; y1 = ycor[3 * sl + 1] + yt[1]; y2 = ycor[3 * sl + 2] + yt[2];
+                }
+            }
+            dst[0] = h_D[0] * rn[0] + h_D[1] * rn[1] + h_D[2] * rn[2] + y0;
+            dst[1] = h_D[1] * rn[0] + h_D[3] * rn[1] + h_D[4] * rn[2] + y1;
+            dst[2] = h_D[2] * rn[0] + h_D[4] * rn[1] + h_D[5] * rn[2] + y2;
         }
     }
     if (own) { lx[3 * tid] = x_own[0]; lx[3 * tid + 1] = x_own[1]; lx[3 * tid + 2] = x_own[2]; }
@@ -1560,11 +1981,26 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         w_out[3 * row] = a0; w_out[3 * row + 1] = a1; w_out[3 * row + 2] = a2;
-        if (it == 0) part[0] = r_out[3 * row] * ul[0] + r_out[3 * row + 1] * ul[1] + r_out[3 * row + 2] * ul[2];
+        if (it == 0) {
+            const double r0 = r_out[3 * row], r1 = r_out[3 * row + 1], r2 = r_out[3 * row + 2];
+            part[0] = r0 * ul[0] + r1 * ul[1] + r2 * ul[2];
+            sum9[0] = r0; sum9[1] = r1; sum9[2] = r2;            // launch 0: r = b, s = 0
+        }
         part[1] = a0 * ul[0] + a1 * ul[1] + a2 * ul[2];
+        sum9[6] = a0; sum9[7] = a1; sum9[8] = a2;
     }
     part[0] += dot_ru;
     block_sum_store<9>(part, lds, tid, part_out + (size_t)b * NPART);
+    if (CO) {
+        __syncthreads();
+        block_sum<9>(sum9, lds, lane, wave);
+        if (tid < 9) {
+            double sv = sum9[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) sv = (tid == q) ? sum9[q] : sv;
+            ts_out[(size_t)tid * P.n_regblk + b] = sv;
+        }
+    }
 }
 
 // =====================================================================================
@@ -1714,6 +2150,17 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
     d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
     d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
+    {
+        const size_t nb = d.coarse ? (size_t)d.n_regblk : 1, nc = d.coarse ? (size_t)d.co_n : 1;
+        d.co_tg = A.get<int>(nb * CO_TG);
+        d.co_ct = A.get<double>(nb * CO_TG * 6);
+        d.co_cp = A.get<double>(nb * 18);
+        d.co_tb = A.get<double>(nb * 4);
+        d.co_bt = A.get<double>(nb * 6);
+        d.part_ts = A.get<double>(nb * 9); d.part_ts2 = A.get<double>(nb * 9);
+        d.co_c0 = A.get<double>(nc * nc); d.co_nn = A.get<double>(nc); d.co_bc = A.get<double>(nc);
+        d.co_inv = A.get<double>(nc * nc); d.co_y0 = A.get<double>(nc);
+    }
     d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
     d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
     d.red = A.get<double>(3 + 6 * K);
@@ -2041,6 +2488,27 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
+    // two-level preconditioner: fused path, one pose, small enough coarse system
+    std::vector<int> co_tg;
+    d.coarse = 0;
+    d.co_n = 3 * d.n_groups + 6;
+    if (d.fused && s.K == 1 && d.co_n <= CO_MAX && !getenv("NRS_NO_COARSE")) {
+        d.coarse = 1;
+        co_tg.assign((size_t)d.n_regblk * CO_TG, -1);
+        for (int b = 0; b < d.n_regblk && d.coarse; ++b) {
+            int* tg = &co_tg[(size_t)b * CO_TG];
+            int ntg = 0;
+            tg[ntg++] = b * d.tile_rows / ROW_ALIGN;
+            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i) {
+                const int g = halo_rows[i] / ROW_ALIGN;
+                bool seen = false;
+                for (int q = 0; q < ntg; ++q) seen |= tg[q] == g;
+                if (seen) continue;
+                if (ntg == CO_TG) { d.coarse = 0; break; }
+                tg[ntg++] = g;
+            }
+        }
+    }
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     // ---- device memory: one arena allocation, reused across calls when large enough
@@ -2069,7 +2537,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->dm_w.assign(s.dm_w, s.dm_w + (size_t)s.n_dm);
     e->un_ij.assign(s.un_ij, s.un_ij + 2 * (size_t)s.n_un);
     e->un_w.assign(s.un_w, s.un_w + (size_t)s.n_un);
-    e->h_rflag.assign(d.n_rows, 0);
+    e->h_rflag.assign(d.n_rows, RF_FIXED);            // padding rows: no edges, never move
     for (int v = 0; v < s.M; ++v) e->h_rflag[e->vrow[v]] = s.rflag[v];
     e->h_pose_fixed.assign(s.K, 0);
     if (s.pose_fixed) e->h_pose_fixed.assign(s.pose_fixed, s.pose_fixed + s.K);
@@ -2125,6 +2593,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
     NRS_TRY(h2d(c, d.halo_ns, halo_ns));
     NRS_TRY(h2d(c, d.tile_list, tile_list));
+    if (d.coarse) NRS_TRY(h2d(c, d.co_tg, co_tg));
     if (d.fused) {
         std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
         const int rb = ROW_ALIGN / d.tile_rows;
@@ -2280,6 +2749,19 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         launch_reg<LIN>(c, d, d.xl[which]);
     }
     if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.K), b, 0, c->stream, d);
+    if (LIN && d.coarse) {
+        const size_t rows = (size_t)(d.tile_rows + d.max_halo);
+        const size_t shm = sizeof(double) * 3 * rows + 3 * (rows + 8) + 16;
+        const dim3 g(d.n_regblk);
+        switch (d.T) {
+            case 1: hipLaunchKernelGGL((k_coarse_tile<1>), g, b, shm, c->stream, d); break;
+            case 2: hipLaunchKernelGGL((k_coarse_tile<2>), g, b, shm, c->stream, d); break;
+            case 4: hipLaunchKernelGGL((k_coarse_tile<4>), g, b, shm, c->stream, d); break;
+            case 16: hipLaunchKernelGGL((k_coarse_tile<16>), g, b, shm, c->stream, d); break;
+            default: hipLaunchKernelGGL((k_coarse_tile<8>), g, b, shm, c->stream, d); break;
+        }
+        hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
+    }
     hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d);
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
@@ -2305,6 +2787,7 @@ constexpr double PEEK_RHO_LVL[5] = {0, -0.25, -0.1, -0.03, -0.03};
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
+    if (d.coarse) hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(BLK), sizeof(double) * (size_t)d.co_n * d.co_n, c->stream, d, lam);
     hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
     *it = 0;
     return NRS_OK;
@@ -2320,13 +2803,23 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
     for (; it < stop; ++it) {
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
-            const size_t shm = sizeof(double) * 6 * (size_t)(d.tile_rows + d.max_halo);
+            const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 9 * (size_t)d.n_regblk + 7 * CO_MAX : 0));
             switch (d.T) {
-                case 1: hipLaunchKernelGGL((k_pcg_fused<1>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                case 2: hipLaunchKernelGGL((k_pcg_fused<2>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                case 4: hipLaunchKernelGGL((k_pcg_fused<4>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                case 16: hipLaunchKernelGGL((k_pcg_fused<16>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
-                default: hipLaunchKernelGGL((k_pcg_fused<8>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL); break;
+                case 1: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<1, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        else hipLaunchKernelGGL((k_pcg_fused<1, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        break;
+                case 2: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<2, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        else hipLaunchKernelGGL((k_pcg_fused<2, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        break;
+                case 4: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<4, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        else hipLaunchKernelGGL((k_pcg_fused<4, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        break;
+                case 16: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<16, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        else hipLaunchKernelGGL((k_pcg_fused<16, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        break;
+                default: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<8, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        else hipLaunchKernelGGL((k_pcg_fused<8, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                        break;
             }
             continue;
         }
