@@ -2511,6 +2511,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
+    if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
     {
