@@ -119,6 +119,7 @@ struct Dev {
     double* co_tb;                   // n_regblk x 4: sum of b (3) and number of free rows
     double* part_ts; double* part_ts2;   // 9 x n_regblk (component-major, ping-pong): tile sums of r, s, w
     double* co_bt;                   // n_regblk x 6: sum of H_ij over i, j in the tile (tile-level diagonal block)
+    double* co_bti;                  // n_regblk x 6: (B_t + lambda n_t I)^-1 of the current trial (0 if not positive)
     double* co_c0;                   // co_n x co_n: Z^T H Z ; co_nn: Z^T Z diagonal ; co_bc: Z^T b
     double* co_nn; double* co_bc;
     double* co_inv;                  // co_n x co_n: (C0 + lambda N)^-1 of the current trial
@@ -210,15 +211,11 @@ __device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double la
     return det > 0;
 }
 
-// tile-level coarse correction: y = (B_t + lambda n_t I)^-1 rc, zero when the block is not positive
-__device__ inline void tile_level(const double* Bt /*6*/, double nfree, double lam, const double* rc, double* y) {
-    double Bi[6];
-    y[0] = y[1] = y[2] = 0;
-    if (nfree > 0 && inv3_sym(Bt, lam * nfree, Bi) && Bi[0] > 0) {
-        y[0] = Bi[0] * rc[0] + Bi[1] * rc[1] + Bi[2] * rc[2];
-        y[1] = Bi[1] * rc[0] + Bi[3] * rc[1] + Bi[4] * rc[2];
-        y[2] = Bi[2] * rc[0] + Bi[4] * rc[1] + Bi[5] * rc[2];
-    }
+// tile-level coarse correction: y = Bi rc with Bi = (B_t + lambda n_t I)^-1 prepared per trial by k_coarse_invert
+__device__ inline void tile_level(const double* Bi /*6*/, const double* rc, double* y) {
+    y[0] = Bi[0] * rc[0] + Bi[1] * rc[1] + Bi[2] * rc[2];
+    y[1] = Bi[1] * rc[0] + Bi[3] * rc[1] + Bi[4] * rc[2];
+    y[2] = Bi[2] * rc[0] + Bi[4] * rc[1] + Bi[5] * rc[2];
 }
 
 // stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0).
@@ -945,6 +942,13 @@ __global__ __launch_bounds__(BLK) void k_coarse_invert(Dev P, double lam) {
     const bool act = tid < nb * nb;
     const int br = act ? tid / nb : 0, bc = act ? tid % nb : 0;
     if (tid == 0) bad = 0;
+    for (int tl = tid; tl < P.n_regblk; tl += BLK) {                       // tile-level 3x3 blocks of this trial
+        double Bi[6];
+        const double nf = P.co_tb[4 * (size_t)tl + 3];
+        const bool okb = nf > 0 && inv3_sym(P.co_bt + 6 * (size_t)tl, lam * nf, Bi) && Bi[0] > 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) P.co_bti[6 * (size_t)tl + q] = okb ? Bi[q] : 0.0;
+    }
     double a[BS][BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i)
@@ -1077,7 +1081,7 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
         if (P.coarse && !(P.rflag[i] & RF_FIXED)) {
             const int g = i / ROW_ALIGN, tl = i / P.tile_rows;
             double yt[3];
-            tile_level(P.co_bt + 6 * (size_t)tl, P.co_tb[4 * (size_t)tl + 3], lam, P.co_tb + 4 * (size_t)tl, yt);
+            tile_level(P.co_bti + 6 * (size_t)tl, P.co_tb + 4 * (size_t)tl, yt);
             y0 = P.co_y0[3 * g] + yt[0]; y1 = P.co_y0[3 * g + 1] + yt[1]; y2 = P.co_y0[3 * g + 2] + yt[2];
         }
         P.uv3[3 * i] = Di[0] * r0 + Di[1] * r1 + Di[2] * r2 + y0;
@@ -1634,12 +1638,11 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     int c_ci = -1;
     double c_m[CO_KMAX];
     int c_tg[CO_TG];
-    double bt_own[6], bt_h[6], nf_own = 0, nf_h = 0;
+    double bt_own[6], bt_h[6];
     const int th_h = (int)(hrow / (size_t)P.tile_rows);              // tile of this thread's halo row
     if (coarse) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bt[6 * (size_t)b + q]; bt_h[q] = P.co_bt[6 * (size_t)th_h + q]; }
-        nf_own = P.co_tb[4 * (size_t)b + 3]; nf_h = P.co_tb[4 * (size_t)th_h + 3];
+        for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bti[6 * (size_t)b + q]; bt_h[q] = P.co_bti[6 * (size_t)th_h + q]; }
 #pragma unroll
         for (int q = 0; q < CO_TG; ++q) c_tg[q] = P.co_tg[b * CO_TG + q];
         if (c_r < 3 * CO_TG) {
@@ -1877,7 +1880,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 double rc3[3], yt[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * b + k] - alpha * c_ts[9 * b + 6 + k] - alpha * beta * c_ts[9 * b + 3 + k];
-                tile_level(bt_own, nf_own, lam, rc3, yt);
+                tile_level(bt_own, rc3, yt);
                 u0 += ycor[0] + yt[0]; u1 += ycor[1] + yt[1]; u2 += ycor[2] + yt[2];
             }
             P.uv3[3 * orow] = u0; P.uv3[3 * orow + 1] = u1; P.uv3[3 * orow + 2] = u2;
@@ -1910,8 +1913,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
 #pragma unroll
                     for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * th + k] - alpha * c_ts[9 * th + 6 + k] - alpha * beta * c_ts[9 * th + 3 + k];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) btl[k] = i == tid ? bt_h[k] : P.co_bt[6 * (size_t)th + k];
-                    tile_level(btl, i == tid ? nf_h : P.co_tb[4 * (size_t)th + 3], lam, rc3, yt);
+                    for (int k = 0; k < 6; ++k) btl[k] = i == tid ? bt_h[k] : P.co_bti[6 * (size_t)th + k];
+                    tile_level(btl, rc3, yt);
                     y0 = ycor[3 * sl] + yt[0]; y1 = ycor[3 * sl + 1] + yt[1]; y2 = ycor[3 * sl + 2] + yt[2];
                 }
             }
@@ -2157,6 +2160,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
         d.co_cp = A.get<double>(nb * 18);
         d.co_tb = A.get<double>(nb * 4);
         d.co_bt = A.get<double>(nb * 6);
+        d.co_bti = A.get<double>(nb * 6);
         d.part_ts = A.get<double>(nb * 9); d.part_ts2 = A.get<double>(nb * 9);
         d.co_c0 = A.get<double>(nc * nc); d.co_nn = A.get<double>(nc); d.co_bc = A.get<double>(nc);
         d.co_inv = A.get<double>(nc * nc); d.co_y0 = A.get<double>(nc);
