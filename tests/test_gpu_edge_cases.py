@@ -138,3 +138,39 @@ def test_ba_two_tile_classes_bit_identical(ctx, monkeypatch):
         res.append((pq, xyz, [(t["accepted"], t["inner"], t["chi"], t["chi_new"]) for t in tr.trials]))
     assert res[0][2] == res[1][2]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_contexts_and_engines_do_not_leak_device_memory(lib_built):
+    """create / solve / destroy many times: device memory in use must not grow (arena reuse inside a
+    context, full release on nrs_destroy)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")          # the runtime instance libnrs_hip.so itself is linked to
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    p = S.make_dba_problem(400, 3, 77)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    tp = S.make_tracking_problem(300, 78)
+    camt = nrs.make_camera(tp["model"], tp["prm"])
+    fm = np.arange(300, dtype=np.int32)
+
+    def cycle():
+        c = nrs.Context()
+        for _ in range(3):
+            c.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 2)
+            c.track_deform_solve(camt, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
+                                 tp["pose_q"], tp["pose_t"], tp["scale"])
+        c.close()
+
+    cycle()                                   # warm-up: runtime / code-object allocations happen once
+    free0 = free_bytes()
+    for _ in range(25):
+        cycle()
+    free1 = free_bytes()
+    assert free0 - free1 < 8 << 20, "device memory in use grew by %d bytes over 25 create/solve/destroy cycles" % (free0 - free1)
