@@ -66,7 +66,7 @@ def cpu_baseline(seconds_budget=20.0, ctx=None):
                                    p["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], 5)
         iters += nit
         runs += 1
-        if time.perf_counter() - t0 > seconds_budget or runs >= 3:
+        if time.perf_counter() - t0 > seconds_budget or runs >= 5:
             break
     dt = time.perf_counter() - t0
     out = dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port",
