@@ -64,8 +64,8 @@ typedef struct {
     int32_t pcg_batch;        /* PCG iterations enqueued between host checks; 0 = default 8       */
     int32_t profile;          /* 1 = time the linearise and SpMV kernels with HIP events on the
                                  context stream (serialises launches; for bench roofline only)    */
-    int32_t exact_trials;     /* 0 (default): an LM trial whose gain ratio is already < -0.25 / -0.1 /
-                                 -0.03 when the inner solve has reached 1e-2 / 1e-3 / 1e-4 is rejected
+    int32_t exact_trials;     /* 0 (default): an LM trial whose gain ratio is already < -1 / -0.25 / -0.1 /
+                                 -0.03 when the inner solve has reached 1e-1 / 1e-2 / 1e-3 / 1e-4 is rejected
                                  there (its step would be discarded anyway; accepted steps are always
                                  solved to pcg_rtol, so the iterates are unchanged).
                                  1: every trial is solved to pcg_rtol. */

@@ -146,7 +146,8 @@ struct Engine {
     Dev d;
     Arena* arena = nullptr;
     int cur = 0;
-    int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes the next first batch)
+    int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)
+    int pred_peek = 0;               // iterations the last trial needed to reach the first peek milestone
     double* h_scal = nullptr;        // pinned host mirrors
     int* h_flags = nullptr;
     std::vector<int> vrow;           // vertex -> row
@@ -1468,7 +1469,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         if (it == 0) P.scal[SC_GAMMA0] = gamma;
         P.flags[1] = it + 1;
         // "peek" milestones for early trial rejection: level 1 at peek_tol, level 2 at peek_tol/10
-        if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
+        if (gamma <= peek_tol2 * gamma0) {
+            P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
+            if (P.flags[4] == 0) P.flags[4] = it + 1;               // iterations the first milestone took (sizes the next first batch)
+        }
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
@@ -1821,7 +1825,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             nslot[1] = alpha;
             if (ip == 0) P.scal[SC_GAMMA0] = gamma;
             P.flags[1] = ip + 1;
-            if (gamma <= peek_tol2 * gamma0) P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
+            if (gamma <= peek_tol2 * gamma0) {
+                P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
+                if (P.flags[4] == 0) P.flags[4] = ip + 1;
+            }
         }
     }
     if (coarse) {                                                  // (the reduction above was a barrier: yR, yS, yW are visible)
@@ -2780,14 +2787,14 @@ static int read_scalars(nrs_ctx* c, Engine* e) {
 
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
-constexpr double PEEK_RTOL = 1e-2;      // inner-solve accuracy at which a trial is first evaluated
+constexpr double PEEK_RTOL = 1e-1;      // inner-solve accuracy at which a trial is first evaluated
 // Gain ratio below which a trial is rejected at the looks taken when the inner solve reaches 1e-2,
 // 1e-3, 1e-4 (acceptance needs rho > 0).  The gain ratio of the partially converged step is within
 // ~1e-2 / 4e-3 / 2e-3 of the final one at those milestones (second order in the PCG error; measured
 // on the a2 and BA problems, profiles/README.md), so the thresholds keep a >10x margin.
-constexpr int PEEK_LEVELS = 3;
+constexpr int PEEK_LEVELS = 4;
 constexpr double PEEK_MIN_REL_INCREASE = 1e-5;
-constexpr double PEEK_RHO_LVL[5] = {0, -0.25, -0.1, -0.03, -0.03};
+constexpr double PEEK_RHO_LVL[5] = {0, -1.0, -0.25, -0.1, -0.03};
 
 static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
@@ -2849,6 +2856,8 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* i
         // what it predicts is left): fewer host round trips; launches past convergence are no-ops.
         int count = 0;
         if (stop_level == 0 && e->pred_iters > *it_io) count = std::min(std::max((e->pred_iters - *it_io) / 2, c->opt.pcg_batch), 8 * c->opt.pcg_batch);
+        if (stop_level == 0 && e->pred_iters >= *it_io && e->pred_iters + 1 - *it_io <= c->opt.pcg_batch) count = e->pred_iters + 1 - *it_io;   // short solves: finish in one batch
+        if (stop_level > 0 && e->pred_peek > 0) count = std::max(2, std::min(e->pred_peek, c->opt.pcg_batch));                                // waiting for a milestone: small steps
         pcg_enqueue_batch(c, e, lam, it_io, count);
         NRS_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d);
@@ -2866,7 +2875,6 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     NRS_HIP(c, hipSetDevice(c->device));
     Dev& d = e->d;
     double lam = -1, ni = 2;
-    bool speculate = true;
     const bool peek_debug = getenv("NRS_PEEK_DEBUG") != nullptr;
     const int peek_levels = peek_debug ? 4 : PEEK_LEVELS;
     for (int it = 0; it < iters; ++it) {
@@ -2892,19 +2900,17 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             };
             const bool peeking = !c->opt.exact_trials;
             // The first batch of PCG iterations and a speculative evaluation of its result go out
-            // together: most trials are decided by it (converged, or clearly rejected at the peek).
-            // (only while the previous trial was decided inside its first batch -- long solves skip it)
+            // together: most trials are decided by it (converged, or clearly rejected at a peek).  Its
+            // size is what the previous trial needed to reach the first milestone (the kernels record
+            // it), so a trial that is going to be rejected costs a handful of iterations.
             int seen = 0;                                  // peek levels already evaluated
-            if (speculate) {
-                // sized by the previous trial: one launch more than it needed detects convergence
-                // without a tail of no-op launches
-                const int first = e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch ? e->pred_iters + 1 : 0;
+            {
+                int first = 0;
+                if (peeking) first = e->pred_peek > 0 ? std::min(e->pred_peek, c->opt.pcg_batch) : std::max(1, c->opt.pcg_batch / 2);
+                else if (e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch) first = e->pred_iters + 1;
                 pcg_enqueue_batch(c, e, lam, &pit, first);
                 NRS_TRY(eval_trial());
                 done = e->h_flags[0] != 0 || pit >= c->opt.pcg_max_iters;
-            } else {
-                NRS_TRY(pcg_advance(c, e, lam, peeking ? 1 : 0, &pit, &done));
-                NRS_TRY(eval_trial());
             }
             while (true) {
                 temp = e->h_scal[SC_CHI];
@@ -2928,8 +2934,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             ok = e->h_flags[2] == 0;
             if (!early && !ok) temp = 1.7976931348623157e308;
-            speculate = pit <= 2 * c->opt.pcg_batch;
             if (!early) e->pred_iters = e->h_flags[1];
+            if (e->h_flags[4] > 0) e->pred_peek = e->h_flags[4];
             const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
             if (peek_debug) fprintf(stderr, "[peek] it %d trial %d FINAL pit %d rho %.4f\n", it, qmax, pit, rho);

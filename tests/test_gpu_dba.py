@@ -51,7 +51,7 @@ def test_residuals_and_gradient(ctx, model):
 @pytest.mark.parametrize("n,k,seed", [(120, 3, 31), (300, 4, 32), (600, 6, 33)])
 def test_solve_matches_oracle(ctx, ctx_exact, n, k, seed, exact):
     """exact=True: every trial solved to pcg_rtol, every chi2 compared.  exact=False (default
-    options): rejected trials stop at a peek (1e-2: rho < -0.25, 1e-3: rho < -0.1, 1e-4: rho < -0.03); their chi2_new is then only an
+    options): rejected trials stop at a peek (1e-1: rho < -1, 1e-2: rho < -0.25, 1e-3: rho < -0.1, 1e-4: rho < -0.03); their chi2_new is then only an
     approximation, but decisions, lambdas and all accepted iterates must be unchanged."""
     ctx = ctx_exact if exact else ctx
     p, e, cam, qt = _setup(n, k, seed)
