@@ -148,6 +148,7 @@ struct Engine {
     int cur = 0;
     int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)
     int pred_peek = 0;               // iterations the last trial needed to reach the first peek milestone
+    bool first_trial_accepted = false;   // outcome of the first trial of the previous LM iteration
     double* h_scal = nullptr;        // pinned host mirrors
     int* h_flags = nullptr;
     std::vector<int> vrow;           // vertex -> row
@@ -2670,6 +2671,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
 int engine_reset(nrs_ctx* c, Engine* e) {
     Dev& d = e->d;
     e->cur = 0;
+    e->pred_iters = 0; e->pred_peek = 0; e->first_trial_accepted = false;   // batch-size predictors start fresh, as in a new engine
     NRS_HIP(c, hipMemcpyAsync(d.pose[0], d.pose_init, sizeof(Pose) * d.K, hipMemcpyDeviceToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(d.xl[0], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(d.xl[1], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
@@ -2906,7 +2908,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             int seen = 0;                                  // peek levels already evaluated
             {
                 int first = 0;
-                if (peeking) first = e->pred_peek > 0 ? std::min(e->pred_peek, c->opt.pcg_batch) : std::max(1, c->opt.pcg_batch / 2);
+                // (after an iteration whose first trial was accepted, the next first trial usually is too:
+                // short solves then go out whole, without the intermediate look)
+                const bool expect_accept = qmax == 0 && e->first_trial_accepted && e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch;
+                if (peeking && !expect_accept) first = e->pred_peek > 0 ? std::min(e->pred_peek, c->opt.pcg_batch) : std::max(1, c->opt.pcg_batch / 2);
                 else if (e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch) first = e->pred_iters + 1;
                 pcg_enqueue_batch(c, e, lam, &pit, first);
                 NRS_TRY(eval_trial());
@@ -2936,6 +2941,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             if (!early && !ok) temp = 1.7976931348623157e308;
             if (!early) e->pred_iters = e->h_flags[1];
             if (e->h_flags[4] > 0) e->pred_peek = e->h_flags[4];
+            if (qmax == 0) e->first_trial_accepted = !early && (chi - temp) / scale > 0 && std::isfinite(temp);
             const int inner = e->h_flags[1];
             rho = (chi - temp) / scale;
             if (peek_debug) fprintf(stderr, "[peek] it %d trial %d FINAL pit %d rho %.4f\n", it, qmax, pit, rho);
