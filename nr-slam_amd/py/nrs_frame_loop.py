@@ -1,0 +1,241 @@
+"""Frame-loop harness: this build's counterpart of the tracked-frame branch of
+Tracking::TrackImage (reference modules/tracking/tracking.cc:72-112): DataAssociation (LK,
+:304-307) -> CameraPoseEstimation (motion-model seed + pose-only solve, :309-319) ->
+CameraPoseAndDeformationEstimation (:321-333) -> PointReuse (:394-506) -> KeyFrameInsertion
+cadence (:336-392) -> SetLastFrame.  It only orchestrates: every numerical step is a call through a
+*backend* -- `GpuBackend` = the C ABI of libnrs_hip.so through ctypes (one context for the main
+tracker, one for the two-level reuse tracker); the tests plug the oracle in behind the same calls.
+
+Not reproduced (out of the hot-path scope): map initialisation, feature extraction on keyframes
+(the keyframe step keeps the tracked points and refreshes their templates), the mapping thread
+(UpdateTriangulatedPoints, BA on keyframes), visualisation.
+
+Poses are Sophus::SE3f in the reference: unit quaternion + translation in float32, and so is the
+motion-model algebra here (`se3f_*`)."""
+import numpy as np
+
+F32 = np.float32
+TRACKED_WITH_3D, TRACKED, JUST_TRIANGULATED, BAD = 0, 1, 2, 3     # utilities/landmark_status.h:23-30
+
+
+# ---- SE3f (xyzw quaternion, translation), float32 arithmetic ---------------------------------
+def quat_mul_f(a, b):
+    ax, ay, az, aw = [F32(v) for v in a]
+    bx, by, bz, bw = [F32(v) for v in b]
+    q = np.array([aw * bx + ax * bw + ay * bz - az * by,
+                  aw * by - ax * bz + ay * bw + az * bx,
+                  aw * bz + ax * by - ay * bx + az * bw,
+                  aw * bw - ax * bx - ay * by - az * bz], F32)
+    return (q / F32(np.sqrt(np.dot(q, q)))).astype(F32)
+
+
+def quat_rot_f(q, v):
+    x, y, z, w = [F32(c) for c in q]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], F32)
+    return (R @ np.asarray(v, F32)).astype(F32)
+
+
+def se3f_mul(a, b):
+    return quat_mul_f(a[0], b[0]), (np.asarray(a[1], F32) + quat_rot_f(a[0], b[1])).astype(F32)
+
+
+def se3f_act(a, X):
+    """a * X for many points, float32, one fixed elementwise expression per coordinate."""
+    x, y, z, w = [F32(c) for c in a[0]]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], F32)
+    X = np.asarray(X, F32).reshape(-1, 3)
+    t = np.asarray(a[1], F32)
+    return np.stack([R[r, 0] * X[:, 0] + R[r, 1] * X[:, 1] + R[r, 2] * X[:, 2] + t[r] for r in range(3)], 1).astype(F32)
+
+
+def se3f_inv(a):
+    qi = np.array([-a[0][0], -a[0][1], -a[0][2], a[0][3]], F32)
+    return qi, (-quat_rot_f(qi, a[1])).astype(F32)
+
+
+def project_f32(model, prm, p):
+    """CameraModel::Project in float32 (calibration/pin_hole.cc:27-33, kannala_brandt_8.cc:34-51); the
+    KB8 trigonometry as defined in include/nrs.h (double function rounded to float)."""
+    prm = np.asarray(prm, F32)
+    p = np.asarray(p, F32).reshape(-1, 3)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    if model == 0:
+        return np.stack([prm[0] * x / z + prm[2], prm[1] * y / z + prm[3]], 1).astype(F32)
+    r2 = x * x + y * y
+    th = np.arctan2(np.sqrt(r2).astype(np.float64), z.astype(np.float64)).astype(F32)
+    psi = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(F32)
+    th2 = th * th
+    th3 = th * th2
+    th5 = th3 * th2
+    th7 = th5 * th2
+    th9 = th7 * th2
+    r = th + prm[4] * th3 + prm[5] * th5 + prm[6] * th7 + prm[7] * th9
+    return np.stack([prm[0] * r * np.cos(psi.astype(np.float64)).astype(F32) + prm[2],
+                     prm[1] * r * np.sin(psi.astype(np.float64)).astype(F32) + prm[3]], 1).astype(F32)
+
+
+class GpuBackend:
+    """The product path: two nrs contexts (each owns one LucasKanadeTracker state)."""
+
+    def __init__(self, nrs, model, prm, klt_opts):
+        self.nrs = nrs
+        self.cam = nrs.make_camera(model, prm)
+        self.ctx = nrs.Context()
+        self.ctx_reuse = nrs.Context()
+        self.klt_opts = klt_opts
+        self.ctx.klt_configure(klt_opts["win"], klt_opts["max_level"], klt_opts["max_iters"], klt_opts["epsilon"], klt_opts["min_eig"])
+
+    # main tracker
+    def klt_set_reference(self, im, pts):
+        self.ctx.klt_set_reference(im, pts)
+
+    def klt_track(self, im, pts, status, min_ssim):
+        xy, st, good, _ = self.ctx.klt_track(im, pts, status, initial_flow=True, min_ssim=min_ssim)
+        return xy, st
+
+    def klt_get_template(self, idx):
+        return self.ctx.klt_get_template(idx)
+
+    def klt_insert_template(self, t):
+        self.ctx.klt_insert_template(t)
+
+    # the tracker PointReuse builds for its candidates (maxLevel 1, tracking.cc:422-424)
+    def reuse_track(self, im, pts, templates, min_ssim):
+        o = self.klt_opts
+        self.ctx_reuse.klt_clear()
+        self.ctx_reuse.klt_configure(o["win"], 1, o["max_iters"], o["epsilon"], o["min_eig"])
+        for p, t in zip(pts, templates):
+            self.ctx_reuse.klt_insert_template(dict(t, xy=np.asarray(p, F32)))
+        xy, st, good, _ = self.ctx_reuse.klt_track(im, pts, np.zeros(len(pts), np.int32), initial_flow=True, min_ssim=min_ssim)
+        return xy, st
+
+    def pose_only(self, uv, X, q, t):
+        q2, t2, _ = self.ctx.pose_only_solve(self.cam, uv, X, q, t)
+        return q2, t2
+
+    def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
+        return self.ctx.track_deform_solve(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale)
+
+    def close(self):
+        self.ctx.close()
+        self.ctx_reuse.close()
+
+
+class FrameLoop:
+    """State of Tracking + the slice of Map / Frame it touches, on flat arrays."""
+
+    def __init__(self, backend, project_f32, wh, scale, kp0, X0, graph, pose_q, pose_t, im0,
+                 klt_min_ssim=0.7, images_to_insert_keyframe=5):
+        self.b, self.project, self.wh, self.scale = backend, project_f32, wh, float(scale)
+        n = len(kp0)
+        # current frame: slot i observes map point map_index[i]
+        self.kp = np.asarray(kp0, F32).copy()
+        self.pos = np.asarray(X0, F32).copy()
+        self.status = np.zeros(n, np.int32)
+        self.map_index = np.arange(n, dtype=np.int32)
+        # map
+        self.map_pos = np.asarray(X0, F32).copy()                  # MapPoint::GetLastWorldPosition
+        self.graph = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+        self.pose = (np.asarray(pose_q, F32), np.asarray(pose_t, F32))
+        self.last_pose = self.pose
+        self.motion = (np.array([0, 0, 0, 1], F32), np.zeros(3, F32))
+        self.min_ssim, self.kf_every, self.since_kf = klt_min_ssim, images_to_insert_keyframe, 0
+        # initial keyframe: klt reference + photometric information of every map point (tracking.cc:201-209)
+        self.b.klt_set_reference(im0, self.kp)
+        self.templates = [self.b.klt_get_template(i) for i in range(n)]
+        self.log = []
+
+    # ---- tracking.cc:72-112 (tracked branch)
+    def track_image(self, im):
+        lost = self.track_camera_and_deformation(im)
+        reused = self.point_reuse(im, lost)
+        n3d = int((self.status == TRACKED_WITH_3D).sum())
+        kf = False
+        if n3d >= 10:
+            kf = self.keyframe_insertion(im)
+            self.last_pose = self.pose
+        self.log.append(dict(pose_q=self.pose[0].copy(), pose_t=self.pose[1].copy(), lost=sorted(int(x) for x in lost),
+                             reused=reused, n_tracked=n3d, keyframe=kf,
+                             status_by_map=self._status_by_map(), pos_by_map=self._pos_by_map()))
+        return n3d >= 10
+
+    def _status_by_map(self):
+        s = np.full(len(self.map_pos), -1, np.int32)
+        s[self.map_index] = self.status
+        return s
+
+    def _pos_by_map(self):
+        p = np.zeros((len(self.map_pos), 3), F32)
+        p[self.map_index] = self.pos
+        return p
+
+    # ---- tracking.cc:291-333
+    def track_camera_and_deformation(self, im):
+        self.kp, self.status = self.b.klt_track(im, self.kp, self.status, self.min_ssim)
+        self.pose = se3f_mul(self.motion, self.pose)               # motion-model seed
+        m = self.status == TRACKED_WITH_3D
+        q, t = self.b.pose_only(self.kp[m], self.pos[m], self.pose[0].astype(np.float64), self.pose[1].astype(np.float64))
+        self.pose = (np.asarray(q, np.float64).astype(F32), np.asarray(t, np.float64).astype(F32))
+        r = self.b.track_deform(self.graph, self.map_pos, self.map_index, self.status, self.kp, self.pos,
+                                self.pose[0].astype(np.float64), self.pose[1].astype(np.float64), self.scale)
+        self.pose = (np.asarray(r["pose_q"], np.float64).astype(F32), np.asarray(r["pose_t"], np.float64).astype(F32))
+        self.pos, self.status = np.asarray(r["f_pos"], F32), np.asarray(r["f_status"], np.int32)
+        self.map_pos, self.graph = np.asarray(r["map_pos"], F32), r["graph"]
+        self.motion = se3f_mul(self.pose, se3f_inv(self.last_pose))
+        return set(int(x) for x in r["lost"])
+
+    # ---- tracking.cc:394-506
+    def point_reuse(self, im, lost):
+        w, h = self.wh
+        in_frame = np.full(len(self.map_pos), -1, np.int64)
+        in_frame[self.map_index] = np.arange(len(self.map_index))
+        cand = set(lost)
+        pc = se3f_act(self.pose, self.map_pos)
+        uv = self.project(pc) if len(pc) else np.zeros((0, 2), F32)
+        inside = (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
+        for mp in range(len(self.map_pos)):
+            i = in_frame[mp]
+            present = i >= 0 and self.status[i] in (TRACKED_WITH_3D, JUST_TRIANGULATED)
+            if not present and pc[mp, 2] >= 0 and inside[mp]:
+                cand.add(mp)
+        cand = [mp for mp in sorted(cand) if inside[mp] and not np.isnan(uv[mp]).any()]
+        if not cand:
+            return 0
+        seeds = uv[cand].astype(F32)
+        xy, st = self.b.reuse_track(im, seeds, [self.templates[mp] for mp in cand], 0.75)
+        reused = 0
+        for k, mp in enumerate(cand):
+            if st[k] != TRACKED_WITH_3D:
+                continue
+            ex, ey = F32(uv[mp, 0]) - F32(xy[k, 0]), F32(uv[mp, 1]) - F32(xy[k, 1])
+            if ex * ex + ey * ey > F32(5.99):
+                continue
+            i = in_frame[mp]
+            if i >= 0:
+                self.kp[i], self.pos[i], self.status[i] = xy[k], self.map_pos[mp], TRACKED_WITH_3D
+            else:
+                self.kp = np.vstack([self.kp, xy[k][None]]).astype(F32)
+                self.pos = np.vstack([self.pos, self.map_pos[mp][None]]).astype(F32)
+                self.status = np.append(self.status, TRACKED_WITH_3D).astype(np.int32)
+                self.map_index = np.append(self.map_index, mp).astype(np.int32)
+                in_frame[mp] = len(self.map_index) - 1
+                self.b.klt_insert_template(dict(self.templates[mp], xy=xy[k].astype(F32)))
+            reused += 1
+        return reused
+
+    # ---- tracking.cc:336-392 (without feature extraction)
+    def keyframe_insertion(self, im):
+        if self.since_kf < self.kf_every:
+            self.since_kf += 1
+            return False
+        self.since_kf = 0
+        keep = self.status == TRACKED_WITH_3D                      # KeyFrame(frame) + Frame::SetFromKeyFrame
+        self.kp, self.pos, self.status, self.map_index = self.kp[keep], self.pos[keep], self.status[keep], self.map_index[keep]
+        self.b.klt_set_reference(im, self.kp)
+        for i, mp in enumerate(self.map_index):
+            self.templates[mp] = self.b.klt_get_template(i)
+        return True

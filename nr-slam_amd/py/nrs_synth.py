@@ -340,3 +340,90 @@ def make_lk_sequence(n_points=500, seed=5, wh=(640, 480), flow_px=6.0):
     fx, fy = flow(pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64))
     truth = pts + np.stack([fx, fy], 1).astype(F32)
     return dict(im0=im0, im1=im1, pts=pts, truth=truth)
+
+
+def _texture(h, w, rng, margin=32):
+    tex = np.zeros((h + 2 * margin, w + 2 * margin), np.float64)
+    for sc, amp in ((4, 28.0), (8, 36.0), (16, 30.0), (32, 22.0)):
+        gh, gw = (h + 2 * margin) // sc + 3, (w + 2 * margin) // sc + 3
+        g = rng.normal(0, 1, (gh, gw))
+        yy = np.arange(h + 2 * margin) / sc
+        xx = np.arange(w + 2 * margin) / sc
+        y0, x0 = np.floor(yy).astype(int), np.floor(xx).astype(int)
+        fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+        fy, fx = fy * fy * (3 - 2 * fy), fx * fx * (3 - 2 * fx)
+        tex += amp * ((g[np.ix_(y0, x0)] * (1 - fx) + g[np.ix_(y0, x0 + 1)] * fx) * (1 - fy)
+                      + (g[np.ix_(y0 + 1, x0)] * (1 - fx) + g[np.ix_(y0 + 1, x0 + 1)] * fx) * fy)
+    return 120 + tex
+
+
+def make_frame_sequence(n_points=400, n_frames=6, seed=9, model=PINHOLE, step=0.012, occluders=2):
+    """A short consistent monocular sequence for the frame-loop harness: a deforming
+    surface seen by a slowly moving camera.  Frame 0 is the initialised map (keyframe): 3D positions
+    (truth + noise, map units), keypoints, regularisation graph; frames 1.. are images only.  Images
+    are one texture warped by the dense flow that interpolates the projected point motions, so the LK
+    tracker sees what the geometry says."""
+    from scipy.interpolate import griddata
+    rng = np.random.default_rng(seed)
+    prm = HAMLYN_PINHOLE if model == PINHOLE else ENDOMAPPER_KB8
+    w, h = (640, 480) if model == PINHOLE else (736, 552)
+    Xmm, nrm = surface_points(n_points, rng, model)
+    centroid = Xmm.mean(0)
+    scale = F32(3.0) / F32(np.median(Xmm[:, 2]))
+    sigma = F32(3.0) * F32(np.std(Xmm[:, 2].astype(F32))) * scale
+    s = float(scale)
+    poses_R, poses_t, Xt, uvt = [], [], [], []
+    for f in range(n_frames):
+        phi = step * f
+        if model == PINHOLE:
+            R, t = _look_at(np.array([6.0 * phi, 2.0 * np.sin(np.pi * phi), 0.0]), centroid)
+        else:
+            R = _small_rot(np.array([0.03 * phi, -0.04 * phi, 0.02 * phi]))
+            t = -R @ np.array([1.5 * phi, 1.0 * np.sin(np.pi * phi), 2.0 * phi])
+        amp = 1.2 * np.sin(2 * np.pi * f / 40.0) * (0.6 + 0.4 * np.sin(Xmm[:, 0] / 11.0 + 0.3) * np.cos(Xmm[:, 1] / 9.0))
+        X = Xmm + amp[:, None] * nrm
+        pc = X @ R.T + t
+        poses_R.append(R); poses_t.append(t * s); Xt.append(X * s)
+        uvt.append(_project(model, prm.astype(np.float64), pc))
+    uv0 = uvt[0]
+    vis = (uv0[:, 0] > 30) & (uv0[:, 0] < w - 30) & (uv0[:, 1] > 30) & (uv0[:, 1] < h - 30)
+    idx = np.where(vis)[0]
+    tex = _texture(h, w, rng)
+    occl = [np.clip(np.rint(_texture(46, 58, rng, 0)), 0, 255).astype(np.uint8) for _ in range(occluders)]
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    images = []
+    for f in range(n_frames):
+        if f == 0:
+            sx, sy = xs, ys
+        else:
+            # backward warp: displacement known at the points' positions in frame f, interpolated densely
+            d = uv0[idx] - uvt[f][idx]
+            pts = uvt[f][idx]
+            gx = griddata(pts, d[:, 0], (xs, ys), method="linear")
+            gy = griddata(pts, d[:, 1], (xs, ys), method="linear")
+            nx = griddata(pts, d[:, 0], (xs, ys), method="nearest")
+            ny = griddata(pts, d[:, 1], (xs, ys), method="nearest")
+            gx = np.where(np.isnan(gx), nx, gx); gy = np.where(np.isnan(gy), ny, gy)
+            sx, sy = xs + gx, ys + gy
+        sx2, sy2 = np.clip(sx + 32, 0, w + 62.0), np.clip(sy + 32, 0, h + 62.0)
+        x0, y0 = np.floor(sx2).astype(int), np.floor(sy2).astype(int)
+        x0, y0 = np.minimum(x0, w + 62), np.minimum(y0, h + 62)
+        fx, fy = sx2 - x0, sy2 - y0
+        v = (tex[y0, x0] * (1 - fx) + tex[y0, x0 + 1] * fx) * (1 - fy) + (tex[y0 + 1, x0] * (1 - fx) + tex[y0 + 1, x0 + 1] * fx) * fy
+        img = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        # moving occluders (from frame 2 on): points under them fail the tracker / its SSIM gate, are
+        # re-found by the point-reuse step once the patch has moved on
+        for k in range(occluders if f >= 2 else 0):
+            cx = int(w * (0.25 + 0.5 * k / max(1, occluders)) + 40 * (f - 2))
+            cy = int(h * (0.35 + 0.2 * k))
+            ph, pw = 46, 58
+            y1, x1 = max(0, cy - ph // 2), max(0, cx - pw // 2)
+            patch = occl[k][:min(ph, h - y1), :min(pw, w - x1)]
+            img[y1:y1 + patch.shape[0], x1:x1 + patch.shape[1]] = patch
+        images.append(img)
+    X0 = (Xt[0][idx] + rng.normal(0, 0.002, (len(idx), 3))).astype(F32)
+    graph = build_graph(X0, sigma, 16)
+    return dict(model=model, prm=prm, scale=float(scale), wh=(w, h), images=images, n_points=len(idx),
+                kp0=uv0[idx].astype(F32), X0=X0, graph=graph,
+                pose_q=[_R_to_quat(R).astype(F32) for R in poses_R], pose_t=[t.astype(F32) for t in poses_t],
+                uv_true=[u[idx].astype(F32) for u in uvt], X_true=[x[idx] for x in Xt])

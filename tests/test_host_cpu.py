@@ -91,3 +91,23 @@ def test_graph_wire_format():
         e = G["eid"][sl]
         pos = O.get_edges(G["col"][sl], G["e_w"][e], G["e_status"][e], G["min_w"])
         assert np.array_equal(G["col"][sl][pos], G["o_col"][G["o_rowptr"][i]:G["o_rowptr"][i + 1]])
+
+
+def test_frame_loop_harness_with_the_oracle_backend():
+    """SURVEY.md 8(f1) host logic on CPU: the frame loop (motion-model seed, point reuse, keyframe
+    cadence) driven by the oracle backend on a tiny consistent sequence."""
+    import nrs_frame_loop as FL
+    import nrs_synth as S
+    from frame_loop_backend import OracleBackend
+    sq = S.make_frame_sequence(90, 4, 9)
+    opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
+    loop = FL.FrameLoop(OracleBackend(sq["model"], sq["prm"], opts), lambda pc: FL.project_f32(sq["model"], sq["prm"], pc),
+                        sq["wh"], sq["scale"], sq["kp0"], sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0],
+                        sq["images"][0], images_to_insert_keyframe=1)
+    for f in range(1, 4):
+        assert loop.track_image(sq["images"][f])
+    assert [L["keyframe"] for L in loop.log] == [False, True, False]
+    assert loop.log[-1]["n_tracked"] > 0.7 * sq["n_points"]
+    # SE3f algebra of the motion model: T * T^-1 = identity to float accuracy
+    q, t = FL.se3f_mul(loop.pose, FL.se3f_inv(loop.pose))
+    assert np.allclose(q, [0, 0, 0, 1], atol=1e-6) and np.allclose(t, 0, atol=1e-5)
