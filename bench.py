@@ -102,36 +102,50 @@ def reduce_over_ranks(dist, dt, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def tracked_fps(ctx, n_points=5000, frames=5):
-    """Secondary figure of BASELINE.json's metric: tracked frames/s = klt_track + pose-only solve +
-    pose-and-deformation solve (with its graph update) on one 640x480 frame with n_points map
-    points (SURVEY.md 8d unit definition; reference tracking.cc:291-330 minus image decode).  The
-    three calls take host buffers (a frame arrives from the host), so this is PCIe-inclusive."""
+def tracked_fps(n_points=5000, frames=5):
+    """Secondary figure of BASELINE.json's metric: tracked frames/s, end to end through the frame-loop
+    harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode and
+    feature extraction) on a consistent synthetic 640x480 sequence with n_points map points: LK data
+    association, motion-model seed, pose-only solve, pose-and-deformation solve (with its graph
+    update), point reuse.  Every call takes host buffers (a frame arrives from the host): PCIe-inclusive."""
     import nrs
+    import nrs_frame_loop as FL
     import nrs_synth as S
-    sq = S.make_lk_sequence(n_points, 5)
-    tp = S.make_tracking_problem(n_points, 3)
-    cam = nrs.make_camera(tp["model"], tp["prm"])
-    m = tp["status"] == 0
-    fm = np.arange(n_points, dtype=np.int32)
-    ctx.klt_configure()
-    ctx.klt_set_reference(sq["im0"], sq["pts"])
-    st = np.zeros(len(sq["pts"]), np.int32)
-    parts = np.zeros(3)
-    for f in range(frames + 1):
+    sq = S.make_frame_sequence(n_points, frames + 1, 21)
+    opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts)
+    stage = {}
+
+    def wrap(name):
+        fn = getattr(gb, name)
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
+            return r
+        setattr(gb, name, w)
+    for nme in ("klt_track", "pose_only", "track_deform", "reuse_track"):
+        wrap(nme)
+    loop = FL.FrameLoop(gb, lambda pc: FL.project_f32(sq["model"], sq["prm"], pc), sq["wh"], sq["scale"], sq["kp0"], sq["X0"],
+                        sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0])
+    ts, trials, inner = [], 0, 0
+    for f in range(1, frames + 1):
+        if f == 2:
+            stage.clear()                                  # frame 1 warms the code objects up
         t0 = time.perf_counter()
-        ctx.klt_track(sq["im1"], sq["pts"], st)
-        t1 = time.perf_counter()
-        ctx.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
-        t2 = time.perf_counter()
-        ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
-                               tp["pose_q"], tp["pose_t"], tp["scale"])
-        t3 = time.perf_counter()
-        if f > 0:
-            parts += (t1 - t0, t2 - t1, t3 - t2)
-    parts /= frames
-    return dict(value=1.0 / parts.sum(), unit="frames/s", points=int(m.sum()), klt_points=len(sq["pts"]),
-                ms_klt_track=1e3 * parts[0], ms_pose_only=1e3 * parts[1], ms_pose_and_deformation=1e3 * parts[2])
+        loop.track_image(sq["images"][f])
+        if f > 1:
+            ts.append(time.perf_counter() - t0)
+            trials += len(gb.last_trace.trials)
+            inner += sum(t["inner"] for t in gb.last_trace.trials)
+    gb.close()
+    nf = len(ts)
+    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf,
+                tracked_last_frame=int(loop.log[-1]["n_tracked"]),
+                ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,
+                ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * stage.get("reuse_track", 0) / nf,
+                lm_trials_per_frame=trials / nf, pcg_iters_per_frame=inner / nf)
 
 
 def main():
@@ -231,7 +245,7 @@ def main():
                                    "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]},
         }
         if world == 1:
-            out["tracked_fps"] = tracked_fps(ctx)
+            out["tracked_fps"] = tracked_fps()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx=ctx)
     ctx.close()

@@ -238,6 +238,14 @@ int nrs_klt_get_template(nrs_ctx* ctx, int32_t idx, float xy[2], int16_t* gray, 
 int nrs_klt_insert_template(nrs_ctx* ctx, const float xy[2], const int16_t* gray, const int16_t* grad,
                             const float* mean, const uint8_t* valid);
 
+/* The same two calls for `count` consecutive points at once (no reference counterpart: the caller
+ * loops, tracking.cc:203-209,383-391,457-460): buffers are point-major, i.e. the single-point layout
+ * repeated; get reads points [first, first+count), insert appends. */
+int nrs_klt_get_templates(nrs_ctx* ctx, int32_t first, int32_t count, float* xy, int16_t* gray, int16_t* grad,
+                          float* mean, uint8_t* valid);
+int nrs_klt_insert_templates(nrs_ctx* ctx, int32_t count, const float* xy, const int16_t* gray,
+                             const int16_t* grad, const float* mean, const uint8_t* valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,8 @@ constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj
 constexpr int BLK = 256;             // threads per workgroup everywhere
 constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel: [0..2] dots, [3..8] pose sums
 constexpr int CO_MAX = 84;           // largest coarse system of the two-level preconditioner (fits one workgroup's LDS)
-constexpr int CO_TG = 8;             // row groups a tile's incidences may reach (own group included)
+constexpr int CO_GMAX = (CO_MAX - 6) / 3;   // row groups of the coarse level
+static_assert(CO_GMAX <= 32, "k_coarse_tile keeps the reached groups in a 32-bit mask");
 
 // incidence meta bits
 constexpr int SM_COUNT = 1 << 30;    // spring: this incidence adds the edge's rho to chi2
@@ -113,8 +114,7 @@ struct Dev {
     // two-level preconditioner of the fused path (single pose): coarse unknowns = one translation per
     // 256-row group + the pose; M^-1 = block-Jacobi + Z (Z^T H Z + lambda Z^T Z)^-1 Z^T
     int coarse, co_n;                // enabled, number of coarse unknowns (3 n_groups + 6)
-    int* co_tg;                      // n_regblk x CO_TG target groups of a tile (-1 padded)
-    double* co_ct;                   // n_regblk x CO_TG x 6: sum of H_ij over i in tile, j in target group
+    double* co_ct;                   // n_regblk x n_groups x 6: sum of H_ij over i in tile, j in each row group
     double* co_cp;                   // n_regblk x 18: sum of H_lp over the tile's rows (3x6)
     double* co_tb;                   // n_regblk x 4: sum of b (3) and number of free rows
     double* part_ts; double* part_ts2;   // 9 x n_regblk (component-major, ping-pong): tile sums of r, s, w
@@ -783,10 +783,35 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
-    for (int slot = 0; slot < CO_TG; ++slot) {
-        const int hg = P.co_tg[b * CO_TG + slot];
+    // which groups do this tile's incidences reach?  (bit mask, order-independent OR)
+    __shared__ unsigned int reach;
+    if (tid == 0) reach = 1u << own_grp;
+    __syncthreads();
+    {
+        unsigned int m = 0;
+        for (int idx = sbeg + lane; idx < send; idx += 64) {
+            const SpringRec rc = P.s_rec[idx];
+            if (rc.other != REC_NONE && !lfix[rc.other]) m |= 1u << lgrp[rc.other];
+        }
+        for (int idx = dbeg + lane; idx < dend; idx += 64) {
+            const DamperRec rc = P.d_rec[idx];
+            if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
+            const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (o[k] != REC_NONE && !lfix[o[k]]) m |= 1u << lgrp[o[k]];
+        }
+        if (m) atomicOr(&reach, m);
+    }
+    __syncthreads();
+    const unsigned int reached = reach;
+    for (int hg = 0; hg < P.n_groups; ++hg) {
         double acc[6] = {0, 0, 0, 0, 0, 0};
-        if (hg >= 0) {
+        if (!((reached >> hg) & 1u)) {                                 // uniform: nothing to sum
+            if (tid < 6) P.co_ct[((size_t)b * P.n_groups + hg) * 6 + tid] = 0;
+            continue;
+        }
+        {
             if (t == 0 && !rfix && hg == own_grp) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) acc[k] = P.D[6 * (size_t)row + k];
@@ -814,7 +839,7 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
                 }
             }
         }
-        block_sum_store<6>(acc, lds, tid, P.co_ct + ((size_t)b * CO_TG + slot) * 6);
+        block_sum_store<6>(acc, lds, tid, P.co_ct + ((size_t)b * P.n_groups + hg) * 6);
         __syncthreads();
     }
     {   // tile-level block: the same sum restricted to j inside the tile (second, finer level)
@@ -894,10 +919,8 @@ __global__ __launch_bounds__(BLK) void k_coarse_reduce(Dev P) {
         const int g = gh / G, h = gh % G;
         double acc[6] = {0, 0, 0, 0, 0, 0};
         for (int tl = g * rb; tl < (g + 1) * rb; ++tl)
-            for (int slot = 0; slot < CO_TG; ++slot)
-                if (P.co_tg[tl * CO_TG + slot] == h)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) acc[k] += P.co_ct[((size_t)tl * CO_TG + slot) * 6 + k];
+            for (int k = 0; k < 6; ++k) acc[k] += P.co_ct[((size_t)tl * G + h) * 6 + k];
         const double m[9] = {acc[0], acc[1], acc[2], acc[1], acc[3], acc[4], acc[2], acc[4], acc[5]};
         for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 3; ++c) P.co_c0[(size_t)(3 * g + a) * n + 3 * h + c] = m[a * 3 + c];
@@ -1635,34 +1658,12 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     double x_own[3] = {0, 0, 0}, x_h[3] = {0, 0, 0};
     const bool o_free = own && !(P.rflag[orow] & RF_FIXED);
     const bool h_free = hh && !(P.rflag[hrow] & RF_FIXED);
-    // coarse level: a workgroup needs y only for the groups its rows belong to (own group = slot 0,
-    // the groups of its halo rows = slots 1..7) and for the pose: 30 rows of A_c^-1, 8 threads per row
-    constexpr int CO_ROWS = 3 * CO_TG + 6, CO_PART = 8, CO_KMAX = (CO_MAX + CO_PART - 1) / CO_PART;
     const int cn = P.co_n, cG = P.n_groups;
-    const int c_r = tid / CO_PART, c_p = tid % CO_PART;
-    int c_ci = -1;
-    double c_m[CO_KMAX];
-    int c_tg[CO_TG];
     double bt_own[6], bt_h[6];
     const int th_h = (int)(hrow / (size_t)P.tile_rows);              // tile of this thread's halo row
     if (coarse) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bti[6 * (size_t)b + q]; bt_h[q] = P.co_bti[6 * (size_t)th_h + q]; }
-#pragma unroll
-        for (int q = 0; q < CO_TG; ++q) c_tg[q] = P.co_tg[b * CO_TG + q];
-        if (c_r < 3 * CO_TG) {
-            int g = c_tg[0];
-#pragma unroll
-            for (int q = 1; q < CO_TG; ++q) g = (c_r / 3 == q) ? c_tg[q] : g;
-            c_ci = g >= 0 ? 3 * g + c_r % 3 : -1;
-        } else if (c_r < CO_ROWS) {
-            c_ci = 3 * cG + (c_r - 3 * CO_TG);
-        }
-#pragma unroll
-        for (int q = 0; q < CO_KMAX; ++q) {
-            const int c = c_p + CO_PART * q;
-            c_m[q] = (c_ci >= 0 && c < cn) ? P.co_inv[(size_t)c_ci * cn + c] : 0.0;
-        }
     }
     if (own) {
 #pragma unroll
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= coarse level: y = A_c^-1 Z^T r_new with r_new = r - alpha w - alpha beta s, i.e.
     // y = yR - alpha yW - alpha beta yS; the three products are formed before alpha, beta are known
     double* c_ts = dyn + 6 * (size_t)(P.tile_rows + P.max_halo);  // n_regblk x 9 tile sums
-    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 7 vectors of CO_MAX: Rc Sc Wc yR yS yW y
+    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 10 vectors of CO_MAX: Rc Sc Wc yR yS yW y + second halves of yR yS yW
     if (coarse) {
         if (tid < P.n_regblk) {
 #pragma unroll
@@ -1791,14 +1792,18 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             c_v[(c / 3) * CO_MAX + 3 * g + c % 3] = sum;
         }
         __syncthreads();
-        double yr = 0, ys = 0, yw = 0;
-#pragma unroll
-        for (int q = 0; q < CO_KMAX; ++q) {
-            const int c = c_p + CO_PART * q;
-            if (c < cn) { yr += c_m[q] * c_v[c]; ys += c_m[q] * c_v[CO_MAX + c]; yw += c_m[q] * c_v[2 * CO_MAX + c]; }
+        if (tid < 2 * cn) {                                        // thread (row, half of the columns): three partial dot products
+            const int r = tid % cn, half = tid / cn;
+            const int c0 = half ? cn / 2 : 0, c1 = half ? cn : cn / 2;
+            double yr = 0, ys = 0, yw = 0;
+#pragma unroll 4
+            for (int c = c0; c < c1; ++c) {
+                const double m = P.co_inv[(size_t)c * cn + r];         // symmetric: column read, coalesced over r
+                yr += m * c_v[c]; ys += m * c_v[CO_MAX + c]; yw += m * c_v[2 * CO_MAX + c];
+            }
+            double* dst = c_v + (half ? 7 : 3) * CO_MAX;             // second halves go to scratch vectors 7..9
+            dst[r] = yr; dst[CO_MAX + r] = ys; dst[2 * CO_MAX + r] = yw;
         }
-        yr = group_sum<CO_PART>(yr); ys = group_sum<CO_PART>(ys); yw = group_sum<CO_PART>(yw);
-        if (c_p == 0 && c_r < CO_ROWS) { c_v[3 * CO_MAX + c_r] = yr; c_v[4 * CO_MAX + c_r] = ys; c_v[5 * CO_MAX + c_r] = yw; }
     }
     // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
     double alpha = 0, beta = 0;
@@ -1833,7 +1838,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         }
     }
     if (coarse) {                                                  // (the reduction above was a barrier: yR, yS, yW are visible)
-        if (tid < CO_ROWS) c_v[6 * CO_MAX + tid] = c_v[3 * CO_MAX + tid] - alpha * c_v[5 * CO_MAX + tid] - alpha * beta * c_v[4 * CO_MAX + tid];
+        if (tid < cn) c_v[6 * CO_MAX + tid] = (c_v[3 * CO_MAX + tid] + c_v[7 * CO_MAX + tid]) - alpha * (c_v[5 * CO_MAX + tid] + c_v[9 * CO_MAX + tid]) - alpha * beta * (c_v[4 * CO_MAX + tid] + c_v[8 * CO_MAX + tid]);
         __syncthreads();
     }
     const double* ycor = c_v + 6 * CO_MAX;
@@ -1851,7 +1856,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             unew = 0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) unew += q_Hi[c] * __shfl(rnew, c, 64);
-            if (coarse && pmask != 0.0) unew += ycor[3 * CO_TG + a];
+            if (coarse && pmask != 0.0) unew += ycor[3 * cG + a];
             if (lane < 6 && b == pg0) {
                 const double p = ua + beta * q_pp;
                 P.pp[i] = p;
@@ -1884,12 +1889,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             double u0 = o_D[0] * rn[0] + o_D[1] * rn[1] + o_D[2] * rn[2];
             double u1 = o_D[1] * rn[0] + o_D[3] * rn[1] + o_D[4] * rn[2];
             double u2 = o_D[2] * rn[0] + o_D[4] * rn[1] + o_D[5] * rn[2];
-            if (coarse && o_free) {                                // slot 0 = own group; + tile level
+            if (coarse && o_free) {                                // group level + tile level
                 double rc3[3], yt[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * b + k] - alpha * c_ts[9 * b + 6 + k] - alpha * beta * c_ts[9 * b + 3 + k];
                 tile_level(bt_own, rc3, yt);
-                u0 += ycor[0] + yt[0]; u1 += ycor[1] + yt[1]; u2 += ycor[2] + yt[2];
+                const int g = row0 / ROW_ALIGN;
+                u0 += ycor[3 * g] + yt[0]; u1 += ycor[3 * g + 1] + yt[1]; u2 += ycor[3 * g + 2] + yt[2];
             }
             P.uv3[3 * orow] = u0; P.uv3[3 * orow + 1] = u1; P.uv3[3 * orow + 2] = u2;
             lu[3 * tid] = u0; lu[3 * tid + 1] = u1; lu[3 * tid + 2] = u2;
@@ -1912,10 +1918,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 const size_t r2 = i == tid ? hrow : (size_t)P.halo_rows[hb + i];
                 const bool fr = i == tid ? h_free : !(P.rflag[r2] & RF_FIXED);
                 if (fr) {
-                    const int g = (int)(r2 / ROW_ALIGN);
-                    int sl = 0;
-#pragma unroll
-                    for (int q = 1; q < CO_TG; ++q) sl = (c_tg[q] == g) ? q : sl;
+                    const int sl = (int)(r2 / ROW_ALIGN);
                     const int th = (int)(r2 / (size_t)P.tile_rows);
                     double rc3[3], yt[3], btl[6];
 #pragma unroll
@@ -2163,8 +2166,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
     {
         const size_t nb = d.coarse ? (size_t)d.n_regblk : 1, nc = d.coarse ? (size_t)d.co_n : 1;
-        d.co_tg = A.get<int>(nb * CO_TG);
-        d.co_ct = A.get<double>(nb * CO_TG * 6);
+        d.co_ct = A.get<double>(nb * (d.coarse ? (size_t)d.n_groups : 1) * 6);
         d.co_cp = A.get<double>(nb * 18);
         d.co_tb = A.get<double>(nb * 4);
         d.co_bt = A.get<double>(nb * 6);
@@ -2501,26 +2503,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     // two-level preconditioner: fused path, one pose, small enough coarse system
-    std::vector<int> co_tg;
-    d.coarse = 0;
     d.co_n = 3 * d.n_groups + 6;
-    if (d.fused && s.K == 1 && d.co_n <= CO_MAX && !getenv("NRS_NO_COARSE")) {
-        d.coarse = 1;
-        co_tg.assign((size_t)d.n_regblk * CO_TG, -1);
-        for (int b = 0; b < d.n_regblk && d.coarse; ++b) {
-            int* tg = &co_tg[(size_t)b * CO_TG];
-            int ntg = 0;
-            tg[ntg++] = b * d.tile_rows / ROW_ALIGN;
-            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i) {
-                const int g = halo_rows[i] / ROW_ALIGN;
-                bool seen = false;
-                for (int q = 0; q < ntg; ++q) seen |= tg[q] == g;
-                if (seen) continue;
-                if (ntg == CO_TG) { d.coarse = 0; break; }
-                tg[ntg++] = g;
-            }
-        }
-    }
+    // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
+    // fixed and few free rows, converges in a few dozen block-Jacobi iterations anyway)
+    const bool pose_free = !(s.pose_fixed && s.pose_fixed[0]);
+    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && !getenv("NRS_NO_COARSE")) ? 1 : 0;
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
@@ -2606,7 +2593,6 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
     NRS_TRY(h2d(c, d.halo_ns, halo_ns));
     NRS_TRY(h2d(c, d.tile_list, tile_list));
-    if (d.coarse) NRS_TRY(h2d(c, d.co_tg, co_tg));
     if (d.fused) {
         std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
         const int rb = ROW_ALIGN / d.tile_rows;
@@ -2817,7 +2803,7 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
     for (; it < stop; ++it) {
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
-            const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 9 * (size_t)d.n_regblk + 7 * CO_MAX : 0));
+            const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 9 * (size_t)d.n_regblk + 10 * CO_MAX : 0));
             switch (d.T) {
                 case 1: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<1, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
                         else hipLaunchKernelGGL((k_pcg_fused<1, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);

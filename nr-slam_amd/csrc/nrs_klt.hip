@@ -587,3 +587,38 @@ extern "C" int nrs_klt_insert_template(nrs_ctx* c, const float xy[2], const int1
     k->n += 1;
     return NRS_OK;
 }
+
+extern "C" int nrs_klt_get_templates(nrs_ctx* c, int32_t first, int32_t count, float* xy, int16_t* gray, int16_t* grad,
+                                     float* mean, uint8_t* valid) {
+    if (!c) return NRS_ERR_INVALID;
+    KltState* k = c->klt;
+    if (!k || first < 0 || count < 0 || first + count > k->n) return c->fail(NRS_ERR_INVALID, "template range out of bounds");
+    if (count == 0) return NRS_OK;
+    if (!xy || !gray || !grad || !mean || !valid) return c->fail(NRS_ERR_INVALID, "null output");
+    const size_t L = (size_t)k->levels, s = (size_t)first * L, n = (size_t)count;
+    NRS_HIP(c, hipMemcpy(xy, k->prev.as<float>() + 2 * first, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(gray, k->tI.as<short>() + s * KA, sizeof(short) * KA * L * n, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(grad, k->tD.as<short2>() + s * KA, sizeof(short2) * KA * L * n, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(mean, k->tMean.as<float>() + 2 * s, sizeof(float) * 2 * L * n, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(valid, k->tValid.as<uint8_t>() + s, L * n, hipMemcpyDeviceToHost));
+    return NRS_OK;
+}
+
+extern "C" int nrs_klt_insert_templates(nrs_ctx* c, int32_t count, const float* xy, const int16_t* gray,
+                                        const int16_t* grad, const float* mean, const uint8_t* valid) {
+    if (!c) return NRS_ERR_INVALID;
+    if (count < 0) return c->fail(NRS_ERR_INVALID, "count < 0");
+    if (count == 0) return NRS_OK;
+    if (!xy || !gray || !grad || !mean || !valid) return c->fail(NRS_ERR_INVALID, "null input");
+    KltState* k = klt(c);
+    if (!k) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    NRS_TRY(reserve_points(c, k, k->n + count, true));
+    const size_t L = (size_t)k->levels, s = (size_t)k->n * L, n = (size_t)count;
+    NRS_HIP(c, hipMemcpy(k->prev.as<float>() + 2 * k->n, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    NRS_HIP(c, hipMemcpy(k->tI.as<short>() + s * KA, gray, sizeof(short) * KA * L * n, hipMemcpyHostToDevice));
+    NRS_HIP(c, hipMemcpy(k->tD.as<short2>() + s * KA, grad, sizeof(short2) * KA * L * n, hipMemcpyHostToDevice));
+    NRS_HIP(c, hipMemcpy(k->tMean.as<float>() + 2 * s, mean, sizeof(float) * 2 * L * n, hipMemcpyHostToDevice));
+    NRS_HIP(c, hipMemcpy(k->tValid.as<uint8_t>() + s, valid, L * n, hipMemcpyHostToDevice));
+    k->n += count;
+    return NRS_OK;
+}

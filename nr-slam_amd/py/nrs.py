@@ -22,7 +22,8 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
-           "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template"]
+           "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
+           "nrs_klt_insert_templates"]
 
 
 class NrsError(RuntimeError):
@@ -295,6 +296,29 @@ class Context:
         mean, valid = _f32(t["mean"]), np.ascontiguousarray(t["valid"], np.uint8)
         self._chk(self.lib.nrs_klt_insert_template(self.h, _p(xy, C.c_float), _p(gray, C.c_int16), _p(grad, C.c_int16),
                                                    _p(mean, C.c_float), _p(valid, C.c_uint8)))
+
+    def klt_get_templates(self, first, count):
+        """list of `count` template dicts (same layout as klt_get_template), one device read."""
+        L = getattr(self, "_klt_levels", 5)
+        xy = np.zeros((count, 2), np.float32)
+        gray, grad = np.zeros((count, L, 21, 21), np.int16), np.zeros((count, L, 21, 21, 2), np.int16)
+        mean, valid = np.zeros((count, L, 2), np.float32), np.zeros((count, L), np.uint8)
+        self._chk(self.lib.nrs_klt_get_templates(self.h, C.c_int32(first), C.c_int32(count), _p(xy, C.c_float), _p(gray, C.c_int16),
+                                                 _p(grad, C.c_int16), _p(mean, C.c_float), _p(valid, C.c_uint8)))
+        return [dict(xy=xy[i], gray=gray[i], grad=grad[i], mean=mean[i], valid=valid[i]) for i in range(count)]
+
+    def klt_insert_templates(self, ts):
+        """append several templates (each as returned by klt_get_template; levels beyond this tracker's are ignored)."""
+        L = getattr(self, "_klt_levels", 5)
+        if not ts:
+            return
+        xy = np.ascontiguousarray(np.stack([_f32(t["xy"]) for t in ts]), np.float32)
+        gray = np.ascontiguousarray(np.stack([np.asarray(t["gray"], np.int16)[:L] for t in ts]))
+        grad = np.ascontiguousarray(np.stack([np.asarray(t["grad"], np.int16)[:L] for t in ts]))
+        mean = np.ascontiguousarray(np.stack([_f32(t["mean"])[:L] for t in ts]), np.float32)
+        valid = np.ascontiguousarray(np.stack([np.asarray(t["valid"], np.uint8)[:L] for t in ts]))
+        self._chk(self.lib.nrs_klt_insert_templates(self.h, C.c_int32(len(ts)), _p(xy, C.c_float), _p(gray, C.c_int16),
+                                                    _p(grad, C.c_int16), _p(mean, C.c_float), _p(valid, C.c_uint8)))
 
     # ---- a3
     def _dba_args(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):

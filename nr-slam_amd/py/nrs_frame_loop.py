@@ -97,8 +97,8 @@ class GpuBackend:
         xy, st, good, _ = self.ctx.klt_track(im, pts, status, initial_flow=True, min_ssim=min_ssim)
         return xy, st
 
-    def klt_get_template(self, idx):
-        return self.ctx.klt_get_template(idx)
+    def klt_get_templates(self, n):
+        return self.ctx.klt_get_templates(0, n)
 
     def klt_insert_template(self, t):
         self.ctx.klt_insert_template(t)
@@ -108,8 +108,7 @@ class GpuBackend:
         o = self.klt_opts
         self.ctx_reuse.klt_clear()
         self.ctx_reuse.klt_configure(o["win"], 1, o["max_iters"], o["epsilon"], o["min_eig"])
-        for p, t in zip(pts, templates):
-            self.ctx_reuse.klt_insert_template(dict(t, xy=np.asarray(p, F32)))
+        self.ctx_reuse.klt_insert_templates([dict(t, xy=np.asarray(p, F32)) for p, t in zip(pts, templates)])
         xy, st, good, _ = self.ctx_reuse.klt_track(im, pts, np.zeros(len(pts), np.int32), initial_flow=True, min_ssim=min_ssim)
         return xy, st
 
@@ -118,7 +117,8 @@ class GpuBackend:
         return q2, t2
 
     def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
-        return self.ctx.track_deform_solve(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale)
+        self.last_trace = self.nrs.Trace(1024)
+        return self.ctx.track_deform_solve(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale, self.last_trace)
 
     def close(self):
         self.ctx.close()
@@ -146,7 +146,7 @@ class FrameLoop:
         self.min_ssim, self.kf_every, self.since_kf = klt_min_ssim, images_to_insert_keyframe, 0
         # initial keyframe: klt reference + photometric information of every map point (tracking.cc:201-209)
         self.b.klt_set_reference(im0, self.kp)
-        self.templates = [self.b.klt_get_template(i) for i in range(n)]
+        self.templates = self.b.klt_get_templates(n)
         self.log = []
 
     # ---- tracking.cc:72-112 (tracked branch)
@@ -236,6 +236,6 @@ class FrameLoop:
         keep = self.status == TRACKED_WITH_3D                      # KeyFrame(frame) + Frame::SetFromKeyFrame
         self.kp, self.pos, self.status, self.map_index = self.kp[keep], self.pos[keep], self.status[keep], self.map_index[keep]
         self.b.klt_set_reference(im, self.kp)
-        for i, mp in enumerate(self.map_index):
-            self.templates[mp] = self.b.klt_get_template(i)
+        for mp, t in zip(self.map_index, self.b.klt_get_templates(len(self.map_index))):
+            self.templates[mp] = t
         return True

@@ -50,8 +50,8 @@ class OracleBackend:
         xy, st, good, _ = self.lk.track(im, np.asarray(pts, F32).copy(), status, initial_flow=True, min_ssim=min_ssim)
         return xy, st
 
-    def klt_get_template(self, idx):
-        return _get_template(self.lk, idx)
+    def klt_get_templates(self, n):
+        return [_get_template(self.lk, i) for i in range(n)]
 
     def klt_insert_template(self, t):
         _insert_template(self.lk, t)

@@ -118,3 +118,31 @@ def test_full_size_properties(ctx):
     assert good == len(sq["pts"]) and np.all(st2 == 0)
     assert np.max(np.abs(xy - sq["pts"])) < 0.05
     assert np.nanmin(ssim) > 0.99
+
+
+def test_batched_templates_equal_single_point_calls(ctx):
+    """nrs_klt_get_templates / nrs_klt_insert_templates are the single-point calls in a loop."""
+    sq, lk = _setup(ctx, 40, 13)
+    n = ctx.klt_num_points()
+    batch = ctx.klt_get_templates(0, n)
+    for i in (0, 5, n - 1):
+        one = ctx.klt_get_template(i)
+        for k in ("xy", "gray", "grad", "mean", "valid"):
+            assert np.array_equal(batch[i][k], one[k]), k
+    # re-insert a few into a fresh two-level tracker, in one call and one by one
+    sel = [batch[i] for i in (1, 7, 20)]
+    res = []
+    for batched in (True, False):
+        ctx.klt_clear()
+        ctx.klt_configure(21, 1)
+        if batched:
+            ctx.klt_insert_templates(sel)
+        else:
+            for t in sel:
+                ctx.klt_insert_template(t)
+        assert ctx.klt_num_points() == 3
+        pts = np.stack([t["xy"] for t in sel])
+        res.append(ctx.klt_track(sq["im1"], pts + np.float32(0.5), np.zeros(3, np.int32)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    ctx.klt_clear()
+    ctx.klt_configure()
