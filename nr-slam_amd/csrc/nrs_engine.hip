@@ -540,6 +540,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             }
             return;
         }
+        if (!LIN && !(meta & SM_COUNT)) return;           // chi2 only: every edge is counted from one of its rows
         double y0, y1, y2;
         if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
         else {
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
             return;
         }
+        if (!LIN && !(meta & DM_COUNT)) return;           // chi2 only: counted from one of the edge's rows
         const int role = meta & 3;
         const double sgn_own = damper_sign(role);
         double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
@@ -2507,7 +2509,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
     // fixed and few free rows, converges in a few dozen block-Jacobi iterations anyway)
     const bool pose_free = !(s.pose_fixed && s.pose_fixed[0]);
-    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && !getenv("NRS_NO_COARSE")) ? 1 : 0;
+    const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 9 * (size_t)d.n_regblk + 10 * CO_MAX);
+    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && fused_shm <= 63 * 1024 &&
+                !getenv("NRS_NO_COARSE")) ? 1 : 0;
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
