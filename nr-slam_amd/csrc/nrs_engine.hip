@@ -2868,11 +2868,21 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     Dev& d = e->d;
     double lam = -1, ni = 2;
     const bool peek_debug = getenv("NRS_PEEK_DEBUG") != nullptr;
+    const bool check_chi = getenv("NRS_CHECK_CHI") != nullptr;
+    double chi_carry = 0;
     const int peek_levels = peek_debug ? 4 : PEEK_LEVELS;
     for (int it = 0; it < iters; ++it) {
         NRS_TRY(evaluate<true>(c, e, e->cur));
-        NRS_TRY(read_scalars(c, e));
-        double chi = e->h_scal[SC_CHI];
+        // computeActiveErrors at the start of an iteration re-derives the chi2 the last accepted trial
+        // already produced (same state, same summation order): after the first iteration the host
+        // does not wait for it, the linearisation and the first PCG batch go out back to back
+        double chi = chi_carry;
+        if (it == 0 || check_chi) {
+            NRS_TRY(read_scalars(c, e));
+            if (check_chi && it > 0 && e->h_scal[SC_CHI] != chi_carry)
+                fprintf(stderr, "[nrs] chi2 carried %.17g vs recomputed %.17g\n", chi_carry, e->h_scal[SC_CHI]);
+            chi = e->h_scal[SC_CHI];
+        }
         if (it == 0) { lam = 1e-5 * e->h_scal[SC_MAXDIAG]; ni = 2; }
         if (!std::isfinite(chi) || !std::isfinite(lam)) return c->fail(NRS_ERR_NUMERIC, "non-finite chi2/lambda at LM iteration %d", it);
         double rho = 0;
@@ -2959,6 +2969,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             ++qmax;
         } while (rho < 0 && qmax < 10);
+        chi_carry = chi;
         if (trace) trace->iterations++;
         if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;
     }
