@@ -15,19 +15,28 @@
 //     serves 64/T rows with T lanes per row; element (row r, lane t, step j) of a slice lives at
 //     base + j*64 + r*T + t so all loads of a wave are one contiguous 64-element run).  Nothing
 //     is scattered: no atomics, no assembly maps, bit-reproducible sums.
-//   * H is never assembled.  (H + lambda I) x = b is solved by a block-Jacobi preconditioned
-//     conjugate gradient (single-reduction Chronopoulos-Gear form: 2 launches per iteration)
-//     whose operator is applied from per-incidence factors:
-//         spring  : q g g^T is rank one          -> store g~ = sqrt(q) g      (24 B)
-//         damper  : all 16 blocks are +-s I3      -> store s                   (8 B)
-//         reproj  : H_pl (6x3), H_ll in the row's 3x3 diagonal block, H_pp reduced per pose
+//   * H is never assembled, not even block-wise.  (H + lambda I) x = b is solved by preconditioned
+//     conjugate gradients (single-reduction Chronopoulos-Gear form) whose operator is applied in
+//     FACTORED form from 16-byte incidence records and the LDS-staged linearisation point:
+//         spring  : block = qc v v^T, v = x_i - x_j re-formed from staged positions; stores qc  (8 B)
+//         damper  : all 16 blocks are +-s I3; stores s                                          (8 B)
+//         reproj  : J^T w J with J rebuilt from the fp32 projection Jacobian kept per row       (32 B)
+//     A tile (256/T rows) and the rows its incidences reach (the halo) are staged into LDS once per
+//     launch; neighbour ids in the records are tile-local.  Large problems: two launches per
+//     iteration (k_spmv_f + k_pcg_update).  Small problems (< 32768 rows): ONE launch per iteration
+//     (k_pcg_fused: vector update of iteration k-1 + operator of iteration k, halo rows re-derived
+//     locally), with, for single-pose problems, a two-level preconditioner whose coarse solve is
+//     applied inside that launch (k_coarse_tile / k_coarse_reduce / k_coarse_invert).
 //     The reference factorises the same matrix with a sparse Cholesky (no Schur: H_ll is not
 //     block diagonal); PCG to 1e-10 relative residual reproduces its iterates.
 //   * g2o levels / fixed vertices are byte masks: inactive edges store zero factors, fixed rows
 //     are identity rows whose columns vanish because their PCG vectors stay zero.
 //   * LM control flow (lambda schedule, accept/reject, <=10 trials) runs on the host exactly as in
-//     g2o; per trial the host reads back two scalars.  PCG convergence is detected on device; the
-//     host only polls a flag once per batch of iterations.
+//     g2o.  A trial's first PCG batch, the state update and the chi2 evaluation go out in one
+//     enqueue and are read back with one synchronisation (results are written by the last kernel
+//     into mapped host memory); trials that are going to be rejected are recognised at the 1e-1 ..
+//     1e-4 milestones of the inner solve and not solved further (nrs_options.exact_trials = 1
+//     turns that off); the iterates are the reference's either way.
 //   * XCD-aware launch order: logical tile = (blockIdx % 8) * ceil(nb/8) + blockIdx / 8, so each
 //     XCD's L2 serves one contiguous run of rows (neighbour gathers stay inside it).
 #include <algorithm>
