@@ -1,0 +1,410 @@
+// Linearisation kernels: residuals, Jacobians, Huber weights, per-incidence factors, fixed-order sums.
+// Part of nrs_engine.hip (one translation unit); see that file's header for the design.
+#pragma once
+
+namespace nrs {
+
+// =====================================================================================
+// linearisation, part 1: reprojection edges.  One thread per row, one pose per workgroup.
+//   ReprojectionError / ReprojectionErrorWithDeformation computeError + linearizeOplus
+//   (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68),
+//   quadratic form with Huber weight (base_fixed_sized_edge.hpp:49-63, base_edge.h:158-164).
+// =====================================================================================
+template <bool LIN>
+__global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ poses,
+                                                const double* __restrict__ xl) {
+    __shared__ double lds[4 * 28];
+    const int g = xcd_tile(blockIdx.x, P.n_groups);
+    if (g >= P.n_groups) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = g * ROW_ALIGN + tid;
+    const int kf = P.grp_pose[g];
+    const Pose Tcw = poses[kf];
+    const bool pfix = P.pose_fixed[kf] != 0;
+    double R[9];
+    quat_to_R(Tcw.q, R);
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    const int rf = P.rflag[row];
+    const bool rfix = (rf & RF_FIXED) != 0;
+    // an edge whose vertices are all fixed is not part of the optimisation (sparse_optimizer.cpp:236)
+    const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
+    bool wrote = false;
+    if (active) {
+        double x0 = xl[3 * row], x1 = xl[3 * row + 1], x2 = xl[3 * row + 2];
+        if (P.X0) { x0 += P.X0[3 * row]; x1 += P.X0[3 * row + 1]; x2 += P.X0[3 * row + 2]; }
+        const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + Tcw.t[0];
+        const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + Tcw.t[1];
+        const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + Tcw.t[2];
+        float u, v;
+        project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+        const double r0 = (double)P.uv[2 * row] - (double)u, r1 = (double)P.uv[2 * row + 1] - (double)v;
+        double rho0, rho1;
+        huber(P.info_reproj * (r0 * r0 + r1 * r1), P.delta_reproj, rho0, rho1);
+        acc[27] = rho0;
+        if (LIN) {
+            float Jf[6];
+            projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
+            const double w = rho1 * P.info_reproj;
+            const double pm = pfix ? 0.0 : 1.0, lm = rfix ? 0.0 : 1.0;
+            double Jp[2][6], Jl[2][3];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
+                Jp[rr][0] = pm * (-j1 * pz + j2 * py);
+                Jp[rr][1] = pm * (j0 * pz - j2 * px);
+                Jp[rr][2] = pm * (-j0 * py + j1 * px);
+                Jp[rr][3] = pm * j0; Jp[rr][4] = pm * j1; Jp[rr][5] = pm * j2;
+                Jl[rr][0] = lm * (j0 * R[0] + j1 * R[3] + j2 * R[6]);
+                Jl[rr][1] = lm * (j0 * R[1] + j1 * R[4] + j2 * R[7]);
+                Jl[rr][2] = lm * (j0 * R[2] + j1 * R[5] + j2 * R[8]);
+            }
+            int k = 0;
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = p; q < 6; ++q) { acc[k] = w * (Jp[0][p] * Jp[0][q] + Jp[1][p] * Jp[1][q]); ++k; }
+#pragma unroll
+            for (int p = 0; p < 6; ++p) acc[21 + p] = -w * (Jp[0][p] * r0 + Jp[1][p] * r1);
+            if (P.use_lds) {
+                // factored form: the PCG kernels rebuild J_l, J_p from these 32 bytes
+                RowRec rc;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
+                rc.w = lm * w;
+                P.rowrec[row] = rc;
+            } else {
+                // H_pl (6x3), component-major so that a wave writes 18 contiguous runs
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        P.Hpl[(size_t)(p * 3 + c) * P.n_rows + row] = w * (Jp[0][p] * Jl[0][c] + Jp[1][p] * Jl[1][c]);
+            }
+            double* D = P.D + 6 * (size_t)row;
+            D[0] = w * (Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0]);
+            D[1] = w * (Jl[0][0] * Jl[0][1] + Jl[1][0] * Jl[1][1]);
+            D[2] = w * (Jl[0][0] * Jl[0][2] + Jl[1][0] * Jl[1][2]);
+            D[3] = w * (Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1]);
+            D[4] = w * (Jl[0][1] * Jl[0][2] + Jl[1][1] * Jl[1][2]);
+            D[5] = w * (Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2]);
+            P.bl[3 * row] = -w * (Jl[0][0] * r0 + Jl[1][0] * r1);
+            P.bl[3 * row + 1] = -w * (Jl[0][1] * r0 + Jl[1][1] * r1);
+            P.bl[3 * row + 2] = -w * (Jl[0][2] * r0 + Jl[1][2] * r1);
+            wrote = true;
+        }
+    }
+    if (LIN && !wrote) {
+        if (P.use_lds) {
+            RowRec rc;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
+            rc.w = 0;
+            P.rowrec[row] = rc;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 18; ++c) P.Hpl[(size_t)c * P.n_rows + row] = 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) P.D[6 * (size_t)row + c] = 0;
+        P.bl[3 * row] = P.bl[3 * row + 1] = P.bl[3 * row + 2] = 0;
+    }
+    if (LIN) {
+        block_sum_store<28>(acc, lds, tid, P.part_lin + (size_t)g * 32);
+    } else {
+        double c1[1] = {acc[27]};
+        block_sum<1>(c1, lds, lane, wave);
+        if (tid == 0) P.part_lin[(size_t)g * 32 + 27] = c1[0];
+    }
+}
+
+// =====================================================================================
+// linearisation, part 2: springs and dampers from the incidence lists (T lanes per row).
+//   PositionRegularizer (position_regularizer.cc:32-61, Jacobian as written),
+//   PositionRegularizerWithDeformation (position_regularizer_with_deformation.cc:31-57),
+//   SpatialRegularizer (spatial_regularizer.cc:32-59), SpatialRegularizerWithDeformation
+//   (spatial_regularizer_with_deformation.cc:36-49), SpatialRegularizerFixed
+//   (spatial_regularizer_fixed.cc:32-43).
+// =====================================================================================
+template <int T, bool LIN, bool LDS>
+__global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g, int cls) {
+    __shared__ double lds[4 * 2];
+    extern __shared__ double dyn[];
+    constexpr int R = 64 / T;
+    int b = xcd_tile(blockIdx.x, LDS ? P.n_tiles_cls[cls] : P.n_regblk);
+    if (b >= (LDS ? P.n_tiles_cls[cls] : P.n_regblk)) return;
+    if (LDS) b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = b * 4 + wave;
+    const int row = slice * R + lane / T;
+    const int t = lane % T;
+    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
+    // record headers are double-buffered in two-record chunks; the first chunk of both streams is
+    // requested before the tile is staged
+    constexpr int U = 2;
+    const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
+    const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
+    uint2 shA[U], shB[U], dhA[U], dhB[U];
+    float dwA[U], dwB[U];
+    auto load_sh = [&](uint2* h, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0xFFFFu, 0u);
+            if (j < s_end) h[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 8);
+        }
+    };
+    auto load_dh = [&](uint2* h, float* w, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0u, 0xFFFF0000u);
+            w[q] = 0.f;
+            if (j < d_end) { h[q] = *reinterpret_cast<const uint2*>(P.d_rec + j); w[q] = P.d_w[j]; }
+        }
+    };
+    if (LDS) { load_sh(shA, s_beg + lane); load_dh(dhA, dwA, d_beg + lane); }
+    // xl: estimates (dampers act on them), xp: X0 + estimates (springs); with LDS staging both are
+    // tile-local arrays indexed by the local neighbour ids
+    const double* xl = xl_g;
+    const double* xp = nullptr;
+    int self = row;
+    if (LDS) {
+        double* lx = dyn;
+        stage_rows(P, b, tid, xl_g, nullptr, lx);
+        xl = lx;
+        if (P.X0) {
+            double* lp = dyn + 3 * (size_t)(P.tile_rows + P.cap_h[cls]);
+            stage_rows(P, b, tid, xl_g, P.X0, lp);
+            xp = lp;
+        }
+        __syncthreads();
+        self = row - b * P.tile_rows;
+    }
+    const double xo0 = xl[3 * self], xo1 = xl[3 * self + 1], xo2 = xl[3 * self + 2];
+    double xs0 = xo0, xs1 = xo1, xs2 = xo2;                 // spring position = X0 + x
+    if (P.X0) {
+        if (LDS) { xs0 = xp[3 * self]; xs1 = xp[3 * self + 1]; xs2 = xp[3 * self + 2]; }
+        else { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
+    }
+    double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
+    // ---- springs
+    const size_t nz = (size_t)P.ss_nnz;
+    auto spring = [&](int idx, int o, int meta, double d0) {
+        if (!(meta & SM_ACTIVE)) {
+            if (LIN) {
+                if (LDS) P.s_rec[idx].qc = 0;
+                else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
+            }
+            return;
+        }
+        if (!LIN && !(meta & SM_COUNT)) return;           // chi2 only: every edge is counted from one of its rows
+        double y0, y1, y2;
+        if (LDS && P.X0) { y0 = xp[3 * o]; y1 = xp[3 * o + 1]; y2 = xp[3 * o + 2]; }
+        else {
+            y0 = xl[3 * o]; y1 = xl[3 * o + 1]; y2 = xl[3 * o + 2];
+            if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
+        }
+        const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
+        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        const double r = P.k_spring * (d - d0) / d0;
+        double rho0, rho1;
+        huber(P.info_pos * r * r, P.delta_pos, rho0, rho1);
+        if (meta & SM_COUNT) chi += rho0;
+        if (LIN) {
+            const double cg = P.spring_form == 0 ? (P.k_spring / d0) * (1.0 / sqrt(d)) * 2.0
+                                                 : (P.k_spring / (2 * d0 * d)) * 2.0;
+            const double q = rfix ? 0.0 : rho1 * P.info_pos;
+            const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
+            if (LDS) P.s_rec[idx].qc = q * cg * cg;
+            else { const double sq = sqrt(q); P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
+            D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
+            D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
+            const double qr = q * r;
+            bb[0] -= qr * g0; bb[1] -= qr * g1; bb[2] -= qr * g2;
+        }
+    };
+    {
+        const int beg = P.ss_ptr[slice], end = P.ss_ptr[slice + 1];
+        if (LDS) {
+            auto do_sh = [&](const uint2* hdr, int idx) {
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int o = (int)(hdr[q].x & 0xFFFFu), m16 = (int)(hdr[q].x >> 16);
+                    if (o == REC_NONE) continue;
+                    const int meta = ((m16 & SR_ACTIVE) ? SM_ACTIVE : 0) | ((m16 & SR_COUNT) ? SM_COUNT : 0);
+                    spring(idx + 64 * q, o, meta, (double)__uint_as_float(hdr[q].y));
+                }
+            };
+            for (int base = beg; base < end; base += 128 * U) {    // wave-uniform trip count
+                load_sh(shB, base + 64 * U + lane);
+                do_sh(shA, base + lane);
+                load_sh(shA, base + 128 * U + lane);
+                do_sh(shB, base + 64 * U + lane);
+            }
+        } else {
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int o = P.s_other[idx];
+                if (o < 0) continue;
+                spring(idx, o, P.s_meta[idx], (double)P.s_d0[idx]);
+            }
+        }
+    }
+    // ---- dampers: r = w((x1n - x1c) - (x2n - x2c)), roles (1c,2c,1n,2n), signs (-,+,+,-)
+    auto damper = [&](int idx, int meta, const int* o, double w) {
+        if (!(meta & DM_ACTIVE)) {
+            if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
+            return;
+        }
+        if (!LIN && !(meta & DM_COUNT)) return;           // chi2 only: counted from one of the edge's rows
+        const int role = meta & 3;
+        const double sgn_own = damper_sign(role);
+        double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double sg = damper_sign(k + (k >= role ? 1 : 0));   // role of the k-th other vertex
+            if (o[k] >= 0) {
+                s0 += sg * xl[3 * o[k]]; s1 += sg * xl[3 * o[k] + 1]; s2 += sg * xl[3 * o[k] + 2];
+            }
+        }
+        const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
+        double rho0, rho1;
+        huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho0, rho1);
+        if (meta & DM_COUNT) chi += rho0;
+        if (LIN) {
+            const double fx = rfix ? 0.0 : 1.0;
+            const double sfac = fx * rho1 * P.info_spatial * w * w;
+            if (LDS) P.d_rec[idx].s = sfac; else P.d_s[idx] = sfac;
+            D[0] += sfac; D[3] += sfac; D[5] += sfac;
+            const double c = fx * sgn_own * rho1 * P.info_spatial * w;
+            bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
+        }
+    };
+    {
+        const int beg = P.sd_ptr[slice], end = P.sd_ptr[slice + 1];
+        if (LDS) {
+            auto do_dh = [&](const uint2* hdr, const float* ww, int idx) {
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int m16 = (int)(hdr[q].y >> 16);
+                    if (m16 == REC_NONE) continue;
+                    const int r0 = (int)(hdr[q].x & 0xFFFFu), r1 = (int)(hdr[q].x >> 16), r2 = (int)(hdr[q].y & 0xFFFFu);
+                    const int o[3] = {r0 == REC_NONE ? -1 : r0, r1 == REC_NONE ? -1 : r1, r2 == REC_NONE ? -1 : r2};
+                    damper(idx + 64 * q, m16, o, (double)ww[q]);
+                }
+            };
+            for (int base = beg; base < end; base += 128 * U) {
+                load_dh(dhB, dwB, base + 64 * U + lane);
+                do_dh(dhA, dwA, base + lane);
+                load_dh(dhA, dwA, base + 128 * U + lane);
+                do_dh(dhB, dwB, base + 64 * U + lane);
+            }
+        } else {
+            for (int idx = beg + lane; idx < end; idx += 64) {
+                const int meta = P.d_meta[idx];
+                if (meta < 0) continue;
+                const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
+                damper(idx, meta, o, (double)P.d_w[idx]);
+            }
+        }
+    }
+    double part[2];
+    part[0] = chi;
+    part[1] = 0;
+    if (LIN) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) D[k] = sub_sum_t<T>(D[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bb[k] = sub_sum_t<T>(bb[k]);
+        if (t == 0) {
+            double* Dr = P.D + 6 * (size_t)row;
+            double dd[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { dd[k] = Dr[k] + D[k]; Dr[k] = dd[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) P.bl[3 * row + k] += bb[k];
+            part[1] = fmax(fabs(dd[0]), fmax(fabs(dd[3]), fabs(dd[5])));
+        }
+    }
+    double c = wave_sum(part[0]);
+    double m = part[1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (lane == 0) { lds[wave * 2] = c; lds[wave * 2 + 1] = m; }
+    __syncthreads();
+    if (tid == 0) {
+        P.part_reg[2 * (size_t)b] = lds[0] + lds[2] + lds[4] + lds[6];
+        P.part_reg[2 * (size_t)b + 1] = fmax(fmax(lds[1], lds[3]), fmax(lds[5], lds[7]));
+    }
+}
+
+// =====================================================================================
+// finalize: fixed-order sums of the partials.  LIN: H_pp, b_p, chi2, max diag.  else chi2, scale.
+// =====================================================================================
+template <bool LIN>
+__global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
+    __shared__ double lds[4 * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double chi = 0, md = 0, sc = 0;
+    if (!LIN)
+        for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
+    for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    for (int b = tid; b < P.n_regblk; b += BLK) {
+        chi += P.part_reg[2 * (size_t)b];
+        md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+    }
+    if (LIN)
+        for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp|
+    double c = wave_sum(chi);
+    sc = wave_sum(sc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
+    if (lane == 0) { lds[wave * 3] = c; lds[wave * 3 + 1] = md; lds[wave * 3 + 2] = sc; }
+    __syncthreads();
+    if (tid == 0) {
+        P.scal[SC_CHI] = lds[0] + lds[3] + lds[6] + lds[9];
+        if (LIN) P.scal[SC_MAXDIAG] = fmax(fmax(lds[1], lds[4]), fmax(lds[7], lds[10]));
+        if (!LIN) P.scal[SC_SCALE] = lds[2] + lds[5] + lds[8] + lds[11];
+        // the host reads these after a stream synchronisation: written straight into mapped host memory
+        P.h_scal[SC_CHI] = P.scal[SC_CHI];
+        if (LIN) P.h_scal[SC_MAXDIAG] = P.scal[SC_MAXDIAG];
+        if (!LIN) P.h_scal[SC_SCALE] = P.scal[SC_SCALE];
+    }
+    if (tid < 8) P.h_flags[tid] = P.flags[tid];
+}
+
+// H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the k_reproj partials
+// (8 lanes per component, then the 8 in order); red[3 + k] = max |diagonal| for the LM lambda_0
+__global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
+    __shared__ double lds[8][32];
+    __shared__ double mdl[32];
+    const int k = blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
+    double s = 0;
+    if (c < 27)
+        for (int g = P.pose_grp_ptr[k] + gl; g < P.pose_grp_ptr[k + 1]; g += 8) s += P.part_lin[(size_t)g * 32 + c];
+    lds[gl][c] = s;
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0;
+        if (c < 27) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += lds[q][c];
+            if (c < 21) P.Hpp[k * 21 + c] = t; else P.bp[k * 6 + (c - 21)] = t;
+        }
+        // diagonal entries of the packed upper triangle: 0,6,11,15,18,20
+        mdl[c] = (c == 0 || c == 6 || c == 11 || c == 15 || c == 18 || c == 20) ? fabs(t) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0;
+        for (int q = 0; q < 21; ++q) m = fmax(m, mdl[q]);
+        P.red[3 + k] = m;
+    }
+}
+
+__global__ void k_publish(Dev P) {
+    if (threadIdx.x < 8) P.h_flags[threadIdx.x] = P.flags[threadIdx.x];
+}
+
+}  // namespace nrs

@@ -1,0 +1,573 @@
+// Host side of the engine: arena, row layout, sliced-ELL packing, halo lists, tile classes, uploads (engine_create and friends).
+// Part of nrs_engine.hip (one translation unit); see that file's header for the design.
+#pragma once
+
+namespace nrs {
+
+// =====================================================================================
+// host side
+// =====================================================================================
+int engine_num_poses(const Engine* e) { return e->d.K; }
+
+void arena_release(Arena* a) {
+    if (a->base) (void)hipFree(a->base);
+    a->base = nullptr;
+    a->cap = a->off = 0;
+}
+
+struct ArenaPlan {                   // two passes: size, then carve
+    Arena* a;
+    bool dry;
+    size_t off = 0;
+    template <class Tp> Tp* get(size_t n) {
+        const size_t bytes = ((n * sizeof(Tp) + 255) / 256) * 256 + 256;
+        Tp* p = dry ? nullptr : reinterpret_cast<Tp*>(a->base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, size_t n_halo, Engine* e) {
+    const size_t nr = (size_t)d.n_rows, K = (size_t)d.K;
+    d.grp_pose = A.get<int>(d.n_groups);
+    d.pose_grp_ptr = A.get<int>(K + 1);
+    d.rflag = A.get<uint8_t>(nr);
+    d.pose_fixed = A.get<uint8_t>(K);
+    d.uv = A.get<float>(2 * nr);
+    double* X0 = A.get<double>(has_X0 ? 3 * nr : 1);
+    d.X0 = has_X0 ? X0 : nullptr;
+    d.ss_ptr = A.get<int>(n_slices + 1);
+    d.sd_ptr = A.get<int>(n_slices + 1);
+    d.halo_ptr = A.get<int>((size_t)d.n_regblk + 1);
+    d.halo_rows = A.get<int>(n_halo);
+    d.halo_ns = A.get<int>((size_t)d.n_regblk);
+    d.tile_list = A.get<int>((size_t)d.n_regblk);
+    d.s_rec = A.get<SpringRec>(d.use_lds ? nnz_s : 1);
+    d.d_rec = A.get<DamperRec>(d.use_lds ? nnz_d : 1);
+    const size_t us = d.use_lds ? 1 : nnz_s, ud = d.use_lds ? 1 : nnz_d;     // unpacked arrays: fallback path only
+    d.s_other = A.get<int>(us); d.s_d0 = A.get<float>(us); d.s_meta = A.get<int>(us);
+    d.d_o0 = A.get<int>(ud); d.d_o1 = A.get<int>(ud); d.d_o2 = A.get<int>(ud);
+    d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(ud);
+    for (int s = 0; s < 2; ++s) { d.pose[s] = A.get<Pose>(K); d.xl[s] = A.get<double>(3 * nr); }
+    d.pose_init = A.get<Pose>(K);
+    d.xl_init = A.get<double>(3 * nr);
+    d.D = A.get<double>(6 * nr);
+    d.Hpl = A.get<double>(d.use_lds ? 1 : 18 * nr);
+    d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
+    d.s_g = A.get<double>(3 * us);
+    d.d_s = A.get<double>(ud);
+    d.Hpp = A.get<double>(21 * K);
+    d.bp = A.get<double>(6 * K);
+    d.bl = A.get<double>(3 * nr);
+    d.Dinv = A.get<double>(6 * nr);
+    d.Hppinv = A.get<double>(36 * K);
+    double** pv[] = {&d.xp, &d.rp, &d.up, &d.pp, &d.sp, &d.wp};
+    for (auto p : pv) *p = A.get<double>(6 * K);
+    double** rvv[] = {&d.xv, &d.rv, &d.uv3, &d.pv, &d.sv, &d.wv};
+    for (auto p : rvv) *p = A.get<double>(3 * nr);
+    d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
+    d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
+    d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
+    {
+        const size_t nb = d.coarse ? (size_t)d.n_regblk : 1, nc = d.coarse ? (size_t)d.co_n : 1;
+        d.co_ct = A.get<double>(nb * (d.coarse ? (size_t)d.n_groups : 1) * 6);
+        d.co_cp = A.get<double>(nb * 18);
+        d.co_tb = A.get<double>(nb * 4);
+        d.co_bt = A.get<double>(nb * 6);
+        d.co_bti = A.get<double>(nb * 6);
+        d.part_ts = A.get<double>(nb * 9); d.part_ts2 = A.get<double>(nb * 9);
+        d.co_c0 = A.get<double>(nc * nc); d.co_nn = A.get<double>(nc); d.co_bc = A.get<double>(nc);
+        d.co_inv = A.get<double>(nc * nc); d.co_y0 = A.get<double>(nc);
+    }
+    d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
+    d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
+    d.red = A.get<double>(3 + 6 * K);
+    d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
+    d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
+    d.part_spmv = A.get<double>(NPART * (size_t)d.n_regblk);
+    d.part_apply = A.get<double>((size_t)d.n_vecblk);
+    d.scal = A.get<double>(SC_N);
+    d.flags = A.get<int>(8);
+    e->t_vrow = A.get<int>(d.M);
+    e->t_sp = A.get<int>(2 * (size_t)d.n_sp);
+    e->t_dm = A.get<int>(4 * (size_t)d.n_dm);
+    e->t_d0 = A.get<float>(d.n_sp);
+    e->t_w = A.get<float>(d.n_dm);
+    e->t_out = A.get<double>(2 * (size_t)d.M + (size_t)d.n_sp + 3 * (size_t)d.n_dm);
+}
+
+template <class Tp>
+static int h2d(nrs_ctx* c, Tp* dst, const std::vector<Tp>& src) {
+    if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice, c->stream));
+    return NRS_OK;
+}
+
+// per-edge masks -> per-incidence meta words and per-row flags (host), then upload
+static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uint8_t* dm_active) {
+    Dev& d = e->d;
+    auto vfixed = [&](int v) { return (e->h_rflag[e->vrow[v]] & RF_FIXED) != 0; };
+    for (int s = 0; s < d.n_sp; ++s) {
+        const int i = e->sp_ij[2 * s], j = e->sp_ij[2 * s + 1];
+        const bool act = (!sp_active || sp_active[s]) && !(vfixed(i) && vfixed(j));
+        const int m = act ? SM_ACTIVE : 0;
+        e->h_s_meta[e->sp_pos[2 * s]] = m | (act ? SM_COUNT : 0);
+        e->h_s_meta[e->sp_pos[2 * s + 1]] = m;
+    }
+    for (int s = 0; s < d.n_dm; ++s) {
+        bool allfix = true;
+        int first = -1;
+        for (int r = 0; r < 4; ++r) {
+            const int v = e->dm_idx[4 * s + r];
+            if (v >= 0) { if (first < 0) first = r; allfix = allfix && vfixed(v); }
+        }
+        const bool act = (!dm_active || dm_active[s]) && !allfix;
+        for (int r = 0; r < 4; ++r) {
+            const int p = e->dm_pos[4 * s + r];
+            if (p < 0) continue;
+            e->h_d_meta[p] = r | (act ? DM_ACTIVE : 0) | ((act && r == first) ? DM_COUNT : 0);
+        }
+    }
+    for (int s = 0; s < d.n_un; ++s) {
+        const bool act = !vfixed(e->un_ij[2 * s]);
+        e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
+    }
+    if (d.use_lds) {
+        for (size_t i = 0; i < e->h_s_rec.size(); ++i) {
+            const int m = e->h_s_meta[i];
+            e->h_s_rec[i].meta = (uint16_t)(((m & SM_ACTIVE) ? SR_ACTIVE : 0) | ((m & SM_COUNT) ? SR_COUNT : 0));
+        }
+        for (size_t i = 0; i < e->h_d_rec.size(); ++i)
+            e->h_d_rec[i].meta = e->h_d_meta[i] < 0 ? REC_NONE : (uint16_t)e->h_d_meta[i];
+        NRS_TRY(h2d(c, d.s_rec, e->h_s_rec));
+        NRS_TRY(h2d(c, d.d_rec, e->h_d_rec));
+    } else {
+        NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
+        NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
+    }
+    NRS_TRY(h2d(c, d.rflag, e->h_rflag));
+    NRS_TRY(h2d(c, d.pose_fixed, e->h_pose_fixed));
+    return NRS_OK;
+}
+
+int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
+    *out = nullptr;
+    if (s.K <= 0 || s.M <= 0 || !s.poses || !s.x || !s.lm_pose || !s.uv || !s.rflag || s.n_sp < 0 || s.n_dm < 0 || s.n_un < 0)
+        return c->fail(NRS_ERR_INVALID, "engine: bad specification");
+    for (int i = 0; i < s.M; ++i)
+        if (s.lm_pose[i] < 0 || s.lm_pose[i] >= s.K || (i > 0 && s.lm_pose[i] < s.lm_pose[i - 1]))
+            return c->fail(NRS_ERR_INVALID, "vertex pose index must be non-decreasing and in [0, n_poses)");
+    for (int64_t i = 0; i < 2 * (int64_t)s.n_sp; ++i)
+        if (s.sp_ij[i] < 0 || s.sp_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "spring index out of range");
+    for (int64_t i = 0; i < 4 * (int64_t)s.n_dm; ++i)
+        if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+    for (int64_t i = 0; i < 2 * (int64_t)s.n_un; ++i)
+        if (s.un_ij[i] < 0 || s.un_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "unary damper index out of range");
+    const bool tm = getenv("NRS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!tm) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nrs] engine_create %-18s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    NRS_HIP(c, hipSetDevice(c->device));
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    struct Guard { nrs_ctx* c; Engine* e; bool keep = false; ~Guard() { if (!keep) engine_destroy(c, e); } } guard{c, e};
+    e->arena = arena;
+    Dev& d = e->d;
+    memset(&d, 0, sizeof(d));
+    // lanes per row: 2 measured best on C2 (92k rows), 8 on single-frame problems (4.5k rows), where
+    // the kernels are bound by per-lane latency chains rather than by traffic (profiles/README.md)
+    int n_pad_rows = 0;
+    {
+        std::vector<int> cnt(s.K, 0);
+        for (int i = 0; i < s.M; ++i) cnt[s.lm_pose[i]]++;
+        for (int k = 0; k < s.K; ++k) n_pad_rows += std::max(1, (cnt[k] + ROW_ALIGN - 1) / ROW_ALIGN) * ROW_ALIGN;
+    }
+    int T = n_pad_rows >= 32768 ? 2 : 8;
+    if (const char* ev = getenv("NRS_SELL_T")) {
+        const int v = atoi(ev);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) T = v;
+    }
+    d.T = T;
+    d.K = s.K; d.M = s.M; d.n_sp = s.n_sp; d.n_dm = s.n_dm; d.n_un = s.n_un;
+    d.cam = s.cam;
+    d.info_reproj = s.info_reproj; d.delta_reproj = s.delta_reproj;
+    d.info_pos = s.info_pos; d.delta_pos = s.delta_pos;
+    d.info_spatial = s.info_spatial; d.delta_spatial = s.delta_spatial;
+    d.k_spring = s.k_spring; d.spring_form = s.spring_form;
+
+    // ---- row layout: pose-major, each pose padded to ROW_ALIGN rows, Morton order inside
+    std::vector<int> pose_ptr(s.K + 1, 0);
+    for (int i = 0; i < s.M; ++i) pose_ptr[s.lm_pose[i] + 1]++;
+    for (int k = 0; k < s.K; ++k) pose_ptr[k + 1] += pose_ptr[k];
+    std::vector<int> pose_grp_ptr(s.K + 1, 0), grp_pose;
+    for (int k = 0; k < s.K; ++k) {
+        const int n = pose_ptr[k + 1] - pose_ptr[k];
+        const int ng = std::max(1, (n + ROW_ALIGN - 1) / ROW_ALIGN);
+        pose_grp_ptr[k + 1] = pose_grp_ptr[k] + ng;
+        for (int g = 0; g < ng; ++g) grp_pose.push_back(k);
+    }
+    d.n_groups = pose_grp_ptr[s.K];
+    d.n_rows = d.n_groups * ROW_ALIGN;
+    d.n_regblk = d.n_rows / (BLK / T);
+    d.n_vecblk = d.n_rows / BLK;
+    e->vrow.resize(s.M);
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        auto pos = [&](int v, int a) { return s.x[3 * (size_t)v + a] + (s.X0 ? s.X0[3 * (size_t)v + a] : 0.0); };
+        for (int v = 0; v < s.M; ++v)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos(v, a)); hi[a] = std::max(hi[a], pos(v, a)); }
+        auto spread = [](uint64_t v) {            // 21 bits -> every third bit
+            v &= 0x1fffff;
+            v = (v | v << 32) & 0x1f00000000ffffULL;
+            v = (v | v << 16) & 0x1f0000ff0000ffULL;
+            v = (v | v << 8) & 0x100f00f00f00f00fULL;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+            v = (v | v << 2) & 0x1249249249249249ULL;
+            return v;
+        };
+        const bool morton = getenv("NRS_NO_MORTON") == nullptr;
+        std::vector<std::pair<uint64_t, int>> keys;
+        for (int k = 0; k < s.K; ++k) {
+            keys.clear();
+            for (int v = pose_ptr[k]; v < pose_ptr[k + 1]; ++v) {
+                uint64_t code = 0;
+                if (morton)
+                    for (int a = 0; a < 3; ++a) {
+                        const double ext = hi[a] - lo[a];
+                        const double f = ext > 0 ? (pos(v, a) - lo[a]) / ext : 0.0;
+                        code |= spread((uint64_t)(f * 2097151.0)) << a;
+                    }
+                keys.emplace_back(code, v);
+            }
+            std::stable_sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size(); ++i) e->vrow[keys[i].second] = pose_grp_ptr[k] * ROW_ALIGN + (int)i;
+        }
+    }
+    mark("row layout");
+    // ---- incidence lists -> sliced ELL, built with two counting passes (no per-row containers)
+    const int Rw = 64 / T;
+    const int n_slices = d.n_rows / Rw;
+    const int dm_slots = 4 * s.n_dm;
+    e->sp_pos.assign(2 * (size_t)s.n_sp, -1);
+    e->dm_pos.assign(4 * (size_t)s.n_dm, -1);
+    e->un_pos.assign((size_t)s.n_un, -1);
+    std::vector<int> cnt_s(d.n_rows, 0), cnt_d(d.n_rows, 0);
+    for (int q = 0; q < s.n_sp; ++q) { cnt_s[e->vrow[s.sp_ij[2 * q]]]++; cnt_s[e->vrow[s.sp_ij[2 * q + 1]]]++; }
+    for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)
+        if (s.dm_idx[q] >= 0) cnt_d[e->vrow[s.dm_idx[q]]]++;
+    for (int q = 0; q < s.n_un; ++q) cnt_d[e->vrow[s.un_ij[2 * q]]]++;
+    std::vector<int> ss_ptr(n_slices + 1, 0), sd_ptr(n_slices + 1, 0);
+    for (int sl = 0; sl < n_slices; ++sl) {
+        int ws = 0, wd = 0;
+        for (int r = 0; r < Rw; ++r) {
+            ws = std::max(ws, (cnt_s[sl * Rw + r] + T - 1) / T);
+            wd = std::max(wd, (cnt_d[sl * Rw + r] + T - 1) / T);
+        }
+        ss_ptr[sl + 1] = ss_ptr[sl] + ws * 64;
+        sd_ptr[sl + 1] = sd_ptr[sl] + wd * 64;
+    }
+    const size_t nnz_s = (size_t)ss_ptr[n_slices], nnz_d = (size_t)sd_ptr[n_slices];
+    d.ss_nnz = (int)nnz_s;
+    d.sd_nnz = (int)nnz_d;
+    // packed position of the k-th incidence of a row
+    auto pos_of = [&](const std::vector<int>& ptr, int row, int k) {
+        const int sl = row / Rw, r = row - sl * Rw;
+        return (size_t)ptr[sl] + (size_t)(k / T) * 64 + (size_t)r * T + (size_t)(k % T);
+    };
+    std::vector<int> S_other(nnz_s, -1), D_o(3 * nnz_d, -1), D_role(nnz_d, -1);
+    std::vector<float> S_d0(nnz_s, 0.f), D_w(nnz_d, 0.f);
+    std::fill(cnt_s.begin(), cnt_s.end(), 0);
+    std::fill(cnt_d.begin(), cnt_d.end(), 0);
+    for (int q = 0; q < s.n_sp; ++q) {
+        const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
+        const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++), pb = pos_of(ss_ptr, b, cnt_s[b]++);
+        S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
+        S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
+    }
+    for (int q = 0; q < s.n_dm; ++q) {
+        int r4[4];
+        for (int k = 0; k < 4; ++k) r4[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
+        for (int role = 0; role < 4; ++role) {
+            if (r4[role] < 0) continue;
+            const size_t pz = pos_of(sd_ptr, r4[role], cnt_d[r4[role]]++);
+            int z = 0;
+            for (int k = 0; k < 4; ++k)
+                if (k != role) D_o[3 * pz + z++] = r4[k];
+            D_w[pz] = s.dm_w[q];
+            D_role[pz] = role;
+            e->dm_pos[4 * (size_t)q + role] = (int)pz;
+        }
+    }
+    for (int q = 0; q < s.n_un; ++q) {           // own role 2 (1n, +), value-only other in role 3 (2n, -)
+        const int row = e->vrow[s.un_ij[2 * q]];
+        const size_t pz = pos_of(sd_ptr, row, cnt_d[row]++);
+        D_o[3 * pz + 2] = e->vrow[s.un_ij[2 * q + 1]];
+        D_w[pz] = s.un_w[q];
+        D_role[pz] = 2;
+        e->un_pos[q] = (int)pz;
+    }
+    (void)dm_slots;
+    mark("sell pack");
+    // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
+    // outside the tile; neighbour ids become tile-local
+    d.tile_rows = BLK / T;
+    std::vector<int> halo_ptr(d.n_regblk + 1, 0), halo_rows, halo_ns(d.n_regblk, 0);
+    d.max_halo_s = 0;
+    std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
+    {
+        // tiles are independent: a few host threads each take a contiguous range of tiles
+        const int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 128}));
+        std::vector<std::vector<int>> part(nt);
+        std::vector<int> cnt(d.n_regblk, 0);
+        auto work = [&](int ti) {
+            const int b0 = (int)((int64_t)d.n_regblk * ti / nt), b1 = (int)((int64_t)d.n_regblk * (ti + 1) / nt);
+            std::vector<int> stamp(d.n_rows, -1), local(d.n_rows, 0), ext;
+            for (int b = b0; b < b1; ++b) {
+                const int row0 = b * d.tile_rows, row1 = row0 + d.tile_rows;
+                ext.clear();
+                const size_t s0 = (size_t)ss_ptr[b * 4], s1 = (size_t)ss_ptr[b * 4 + 4];
+                const size_t d0 = (size_t)sd_ptr[b * 4], d1 = (size_t)sd_ptr[b * 4 + 4];
+                auto see = [&](int o) {
+                    if (o >= 0 && (o < row0 || o >= row1) && stamp[o] != b) { stamp[o] = b; ext.push_back(o); }
+                };
+                // spring neighbours first (the SpMV stages positions for them only), then damper-only rows
+                for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
+                const size_t ns = ext.size();
+                for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
+                std::sort(ext.begin(), ext.begin() + ns);
+                std::sort(ext.begin() + ns, ext.end());
+                halo_ns[b] = (int)ns;
+                for (size_t i = 0; i < ext.size(); ++i) local[ext[i]] = d.tile_rows + (int)i;
+                auto loc = [&](int o) { return o < 0 ? -1 : (o >= row0 && o < row1) ? o - row0 : local[o]; };
+                for (size_t p2 = s0; p2 < s1; ++p2) L_s[p2] = loc(S_other[p2]);
+                for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) L_d[p2] = loc(D_o[p2]);
+                part[ti].insert(part[ti].end(), ext.begin(), ext.end());
+                cnt[b] = (int)ext.size();
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int ti = 0; ti < nt; ++ti) th.emplace_back(work, ti);
+            for (auto& t : th) t.join();
+        }
+        for (int b = 0; b < d.n_regblk; ++b) {
+            halo_ptr[b + 1] = halo_ptr[b] + cnt[b];
+            d.max_halo = std::max(d.max_halo, cnt[b]);
+            d.max_halo_s = std::max(d.max_halo_s, halo_ns[b]);
+        }
+        halo_rows.reserve((size_t)halo_ptr[d.n_regblk]);
+        for (int ti = 0; ti < nt; ++ti) halo_rows.insert(halo_rows.end(), part[ti].begin(), part[ti].end());
+    }
+    // ---- tile classes: if a few tiles have much larger halos than the rest they get their own
+    // launch (class 1) with their own LDS size, and the bulk (class 0) keeps its occupancy
+    std::vector<int> tile_list(d.n_regblk);
+    {
+        std::vector<int> hs(d.n_regblk);
+        for (int b = 0; b < d.n_regblk; ++b) hs[b] = halo_ptr[b + 1] - halo_ptr[b];
+        std::vector<int> sorted = hs;
+        std::sort(sorted.begin(), sorted.end());
+        int cut = d.max_halo;
+        if (d.n_regblk >= 1024) {                                  // small problems are latency-bound: one launch
+            // (the second launch has to fill the chip by itself: >= 4 workgroups per CU, or be needed
+            // for the bulk to fit the LDS budget at all)
+            const int p97 = sorted[(size_t)(0.97 * (d.n_regblk - 1))];
+            const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
+            if (4 * d.max_halo > 5 * p97 && (d.n_regblk - (int)(0.97 * d.n_regblk) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
+        }
+        if (getenv("NRS_TILE_CUT_PCT")) {                          // test switch: force a split at a percentile
+            const double pct = atof(getenv("NRS_TILE_CUT_PCT")) / 100.0;
+            cut = sorted[(size_t)(pct * (d.n_regblk - 1))];
+        }
+        int n0 = 0;
+        for (int b = 0; b < d.n_regblk; ++b) if (hs[b] <= cut) tile_list[n0++] = b;
+        int n1 = n0;
+        for (int b = 0; b < d.n_regblk; ++b) if (hs[b] > cut) tile_list[n1++] = b;
+        d.n_tiles_cls[0] = n0; d.n_tiles_cls[1] = d.n_regblk - n0;
+        d.cap_h[0] = d.cap_h[1] = d.cap_s[0] = d.cap_s[1] = 0;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int cls = hs[b] <= cut ? 0 : 1;
+            d.cap_h[cls] = std::max(d.cap_h[cls], hs[b]);
+            d.cap_s[cls] = std::max(d.cap_s[cls], halo_ns[b]);
+        }
+    }
+    d.use_lds = 1;
+    size_t lds_need = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+        if (!d.n_tiles_cls[cls]) continue;
+        lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (s.X0 ? 2 : 1));                          // linearise
+        lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2));                    // operator: u + positions
+    }
+    if (getenv("NRS_NO_LDS") || lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
+    const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
+    d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
+    d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
+    // two-level preconditioner: fused path, one pose, small enough coarse system
+    d.co_n = 3 * d.n_groups + 6;
+    // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
+    // fixed and few free rows, converges in a few dozen block-Jacobi iterations anyway)
+    const bool pose_free = !(s.pose_fixed && s.pose_fixed[0]);
+    const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 9 * (size_t)d.n_regblk + 10 * CO_MAX);
+    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && fused_shm <= 63 * 1024 &&
+                !getenv("NRS_NO_COARSE")) ? 1 : 0;
+    mark("halo");
+    if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
+    if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
+    // ---- device memory: one arena allocation, reused across calls when large enough
+    ArenaPlan dry{arena, true};
+    {
+        Dev tmp = d;
+        Engine te;
+        carve(dry, tmp, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), &te);
+    }
+    if (dry.off > arena->cap) {
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        arena_release(arena);
+        const size_t want = dry.off + dry.off / 8;
+        hipError_t he = hipMalloc((void**)&arena->base, want);
+        if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
+        arena->cap = want;
+    }
+    ArenaPlan real{arena, false};
+    carve(real, d, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), e);
+
+    mark("arena");
+    // ---- host mirrors + uploads
+    e->sp_ij.assign(s.sp_ij, s.sp_ij + 2 * (size_t)s.n_sp);
+    e->sp_d0.assign(s.sp_d0, s.sp_d0 + (size_t)s.n_sp);
+    e->dm_idx.assign(s.dm_idx, s.dm_idx + 4 * (size_t)s.n_dm);
+    e->dm_w.assign(s.dm_w, s.dm_w + (size_t)s.n_dm);
+    e->un_ij.assign(s.un_ij, s.un_ij + 2 * (size_t)s.n_un);
+    e->un_w.assign(s.un_w, s.un_w + (size_t)s.n_un);
+    e->h_rflag.assign(d.n_rows, RF_FIXED);            // padding rows: no edges, never move
+    for (int v = 0; v < s.M; ++v) e->h_rflag[e->vrow[v]] = s.rflag[v];
+    e->h_pose_fixed.assign(s.K, 0);
+    if (s.pose_fixed) e->h_pose_fixed.assign(s.pose_fixed, s.pose_fixed + s.K);
+    std::vector<float> uv((size_t)d.n_rows * 2, 0.f);
+    std::vector<double> xl((size_t)d.n_rows * 3, 0.0), X0;
+    if (s.X0) X0.assign((size_t)d.n_rows * 3, 0.0);
+    for (int v = 0; v < s.M; ++v) {
+        const size_t row = (size_t)e->vrow[v];
+        uv[2 * row] = s.uv[2 * v];
+        uv[2 * row + 1] = s.uv[2 * v + 1];
+        for (int k = 0; k < 3; ++k) {
+            xl[3 * row + k] = s.x[3 * (size_t)v + k];
+            if (s.X0) X0[3 * row + k] = s.X0[3 * (size_t)v + k];
+        }
+    }
+    e->h_s_meta.assign(nnz_s, 0);
+    e->h_d_meta.assign(nnz_d, -1);
+    for (size_t i = 0; i < nnz_d; ++i)
+        if (D_role[i] >= 0) e->h_d_meta[i] = D_role[i];
+    std::vector<int> d_o0, d_o1, d_o2;
+    if (d.use_lds) {
+        auto u16 = [](int v) { return v < 0 ? REC_NONE : (uint16_t)v; };
+        e->h_s_rec.resize(nnz_s);
+        for (size_t i = 0; i < nnz_s; ++i) {
+            SpringRec& r = e->h_s_rec[i];
+            r.qc = 0;
+            r.other = u16(L_s[i]); r.meta = 0; r.d0 = S_d0[i];
+        }
+        e->h_d_rec.resize(nnz_d);
+        for (size_t i = 0; i < nnz_d; ++i) {
+            DamperRec& r = e->h_d_rec[i];
+            r.o0 = u16(L_d[3 * i]); r.o1 = u16(L_d[3 * i + 1]); r.o2 = u16(L_d[3 * i + 2]);
+            r.meta = REC_NONE; r.s = 0;
+        }
+    } else {
+        d_o0.resize(nnz_d); d_o1.resize(nnz_d); d_o2.resize(nnz_d);
+        for (size_t i = 0; i < nnz_d; ++i) { d_o0[i] = D_o[3 * i]; d_o1[i] = D_o[3 * i + 1]; d_o2[i] = D_o[3 * i + 2]; }
+    }
+    const std::vector<int>& s_other = S_other;
+    const std::vector<float>& s_d0 = S_d0;
+    const std::vector<float>& d_w = D_w;
+    mark("host mirrors");
+    std::vector<Pose> poses(s.poses, s.poses + s.K);
+    NRS_TRY(h2d(c, d.grp_pose, grp_pose));
+    NRS_TRY(h2d(c, d.pose_grp_ptr, pose_grp_ptr));
+    NRS_TRY(h2d(c, d.uv, uv));
+    NRS_TRY(h2d(c, d.xl_init, xl));
+    if (s.X0) NRS_TRY(h2d(c, d.X0, X0));
+    NRS_TRY(h2d(c, d.pose_init, poses));
+    NRS_TRY(h2d(c, d.ss_ptr, ss_ptr));
+    NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
+    NRS_TRY(h2d(c, d.halo_ptr, halo_ptr));
+    NRS_TRY(h2d(c, d.halo_rows, halo_rows));
+    NRS_TRY(h2d(c, d.halo_ns, halo_ns));
+    NRS_TRY(h2d(c, d.tile_list, tile_list));
+    if (d.fused) {
+        std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
+        const int rb = ROW_ALIGN / d.tile_rows;
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int kf = grp_pose[(size_t)b * d.tile_rows / ROW_ALIGN];
+            int* td = &tile_desc[8 * (size_t)b];
+            td[0] = kf; td[1] = pose_grp_ptr[kf] * rb; td[2] = pose_grp_ptr[kf + 1] * rb;
+            td[3] = halo_ptr[b]; td[4] = halo_ptr[b + 1] - halo_ptr[b];
+            for (int i = 0; i < td[4] && i < BLK; ++i) halo_fix[(size_t)b * BLK + i] = halo_rows[td[3] + i];
+        }
+        NRS_TRY(h2d(c, d.tile_desc, tile_desc));
+        NRS_TRY(h2d(c, d.halo_fix, halo_fix));
+    }
+    if (!d.use_lds) {
+        NRS_TRY(h2d(c, d.s_other, s_other));
+        NRS_TRY(h2d(c, d.s_d0, s_d0));
+        NRS_TRY(h2d(c, d.d_o0, d_o0));
+        NRS_TRY(h2d(c, d.d_o1, d_o1));
+        NRS_TRY(h2d(c, d.d_o2, d_o2));
+    }
+    NRS_TRY(h2d(c, d.d_w, d_w));
+    NRS_TRY(push_masks(c, e, s.sp_active, s.dm_active));
+    NRS_TRY(h2d(c, e->t_vrow, e->vrow));
+    NRS_TRY(h2d(c, e->t_sp, e->sp_ij));
+    NRS_TRY(h2d(c, e->t_dm, e->dm_idx));
+    NRS_TRY(h2d(c, e->t_d0, e->sp_d0));
+    NRS_TRY(h2d(c, e->t_w, e->dm_w));
+    NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
+    NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
+    NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
+    mark("uploads enqueued");
+    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N, hipHostMallocMapped));      // pinned mirrors live in
+    if (!c->pin_flags) NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped));         // the context (reused)
+    e->h_scal = c->pin_scal;
+    e->h_flags = c->pin_flags;
+    e->d.h_scal = c->pin_scal;          // hipHostMalloc memory is mapped: same pointer on the device
+    e->d.h_flags = c->pin_flags;
+    NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
+    mark("pinned+sync");
+    NRS_TRY(engine_reset(c, e));
+    guard.keep = true;
+    *out = e;
+    return NRS_OK;
+}
+
+void engine_destroy(nrs_ctx* c, Engine* e) {
+    if (!e) return;
+    (void)hipStreamSynchronize(c->stream);
+    delete e;
+}
+
+int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8_t* pose_fixed,
+                        const uint8_t* sp_active, const uint8_t* dm_active) {
+    if (rflag)
+        for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
+    if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
+    NRS_TRY(push_masks(c, e, sp_active, dm_active));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+
+int engine_reset(nrs_ctx* c, Engine* e) {
+    Dev& d = e->d;
+    e->cur = 0;
+    e->pred_iters = 0; e->pred_peek = 0; e->first_trial_accepted = false;   // batch-size predictors start fresh, as in a new engine
+    NRS_HIP(c, hipMemcpyAsync(d.pose[0], d.pose_init, sizeof(Pose) * d.K, hipMemcpyDeviceToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.xl[0], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.xl[1], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
+    return NRS_OK;
+}
+
+}  // namespace nrs

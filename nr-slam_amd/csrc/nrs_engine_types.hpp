@@ -1,0 +1,312 @@
+// Types, constants and device helpers of the graph-LM engine (included by nrs_engine.hip only).
+// Part of nrs_engine.hip (one translation unit); see that file's header for the design.
+#pragma once
+
+namespace nrs {
+
+constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj workgroup
+constexpr int BLK = 256;             // threads per workgroup everywhere
+constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel: [0..2] dots, [3..8] pose sums
+constexpr int CO_MAX = 84;           // largest coarse system of the two-level preconditioner (fits one workgroup's LDS)
+constexpr int CO_GMAX = (CO_MAX - 6) / 3;   // row groups of the coarse level
+static_assert(CO_GMAX <= 32, "k_coarse_tile keeps the reached groups in a 32-bit mask");
+
+// incidence meta bits
+constexpr int SM_COUNT = 1 << 30;    // spring: this incidence adds the edge's rho to chi2
+constexpr int SM_ACTIVE = 1 << 29;   // spring: edge is at level 0
+constexpr int DM_COUNT = 1 << 2;     // damper: bits 0-1 role
+constexpr int DM_ACTIVE = 1 << 3;
+constexpr int DM_UNARY = 1 << 4;     // damper: the other vertex is a value, not a variable
+
+// packed incidence records of the LDS-staged path: one 16-byte load per incidence; neighbour ids
+// are tile-local (own rows, then halo).  The operator is applied in factored form: a spring block is
+// qc * v v^T with v = x_i - x_j re-formed from the staged linearisation point (qc = rho' Omega cg^2),
+// a reprojection block is J^T w J with J rebuilt from the fp32 projection Jacobian kept per row.
+struct __attribute__((aligned(16))) SpringRec { double qc; uint16_t other, meta; float d0; };   // 16 B
+struct __attribute__((aligned(16))) RowRec { float J[6]; double w; };                           // 32 B
+struct __attribute__((aligned(16))) DamperRec { uint16_t o0, o1, o2, meta; double s; };                  // 16 B
+constexpr uint16_t REC_NONE = 0xFFFF;
+constexpr uint16_t SR_ACTIVE = 1, SR_COUNT = 2;
+
+struct Dev {
+    int K, M, n_rows, n_groups;      // poses, vertices, padded rows, ROW_ALIGN groups
+    int T;                           // lanes per row
+    int n_sp, n_dm, n_un;
+    int n_regblk, n_vecblk;
+    Cam cam;
+    double info_reproj, delta_reproj, info_pos, delta_pos, info_spatial, delta_spatial, k_spring;
+    int spring_form;
+    // rows
+    int* grp_pose;                   // n_groups -> pose index
+    int* pose_grp_ptr;               // K+1 -> group ranges
+    uint8_t* rflag;                  // n_rows
+    uint8_t* pose_fixed;             // K
+    float* uv;                       // n_rows x 2
+    double* X0;                      // n_rows x 3 or null
+    // incidences (sliced ELL)
+    int* ss_ptr; int ss_nnz; int* sd_ptr; int sd_nnz;
+    int* s_other; float* s_d0; int* s_meta;
+    int* d_o0; int* d_o1; int* d_o2; float* d_w; int* d_meta;
+    // LDS staging: neighbour ids above are LOCAL to the workgroup's tile: [0, tile_rows) = own rows,
+    // tile_rows + i = halo_rows[halo_ptr[b] + i]
+    int use_lds, tile_rows, max_halo;
+    int max_halo_s;                  // halo lists start with the spring (same-keyframe) neighbours: at most this many
+    // tiles come in two classes so that a few tiles with very large halos do not set the LDS size
+    // (= occupancy) of all: tile_list = class-0 tiles, then class-1 tiles; caps per class
+    int* tile_list; int n_tiles_cls[2]; int cap_h[2], cap_s[2];
+    int* halo_ptr; int* halo_rows; int* halo_ns;   // halo_ns[b] = number of spring-halo rows of tile b
+    SpringRec* s_rec; DamperRec* d_rec;
+    RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
+    Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
+    // state (two copies: current / trial, swapped on accept)
+    Pose* pose[2]; double* xl[2];
+    Pose* pose_init; double* xl_init;
+    // linearisation
+    double* D;                       // n_rows x 6   (xx xy xz yy yz zz)
+    double* Hpl;                     // 18 x n_rows  (component-major; gather fallback path only)
+    double* s_g;                     // 3 x nnz_s
+    double* d_s;                     // nnz_d
+    double* Hpp;                     // K x 21
+    double* bp; double* bl;          // 6K, 3 n_rows
+    double* Dinv; double* Hppinv;    // n_rows x 6, K x 36
+    // PCG vectors: pose part [6K] and row part [3 n_rows]
+    double *xp, *rp, *up, *pp, *sp, *wp;
+    double *xv, *rv, *uv3, *pv, *sv, *wv;
+    // second halves of the ping-pong pairs used by the fused small-problem iteration
+    double *rp2, *sp2, *up2, *rv2, *sv2, *wv2, *part_spmv2;
+    int fused;
+    // two-level preconditioner of the fused path (single pose): coarse unknowns = one translation per
+    // 256-row group + the pose; M^-1 = block-Jacobi + Z (Z^T H Z + lambda Z^T Z)^-1 Z^T
+    int coarse, co_n;                // enabled, number of coarse unknowns (3 n_groups + 6)
+    double* co_ct;                   // n_regblk x n_groups x 6: sum of H_ij over i in tile, j in each row group
+    double* co_cp;                   // n_regblk x 18: sum of H_lp over the tile's rows (3x6)
+    double* co_tb;                   // n_regblk x 4: sum of b (3) and number of free rows
+    double* part_ts; double* part_ts2;   // 9 x n_regblk (component-major, ping-pong): tile sums of r, s, w
+    double* co_bt;                   // n_regblk x 6: sum of H_ij over i, j in the tile (tile-level diagonal block)
+    double* co_bti;                  // n_regblk x 6: (B_t + lambda n_t I)^-1 of the current trial (0 if not positive)
+    double* co_c0;                   // co_n x co_n: Z^T H Z ; co_nn: Z^T Z diagonal ; co_bc: Z^T b
+    double* co_nn; double* co_bc;
+    double* co_inv;                  // co_n x co_n: (C0 + lambda N)^-1 of the current trial
+    double* co_y0;                   // co_n: its product with Z^T b (start vector of the trial)
+    int* tile_desc;                  // fused path: 8 ints per tile {pose, first tile of pose, end tile of pose, halo begin, halo count, 0,0,0}
+    int* halo_fix;                   // fused path: BLK ints per tile = the first BLK halo rows (fixed stride: no pointer chase)
+    // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
+    // being re-summed by every workgroup of the update kernel (which is O(workgroups^2) reads)
+    int hier;
+    double* red;                     // [0..2] r.u, w.u, cross ; [3 + 6k + a] pose sums
+    // partials / scalars
+    double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
+    double* part_reg;                // n_regblk x 2    (chi, maxdiag)
+    double* part_spmv;               // n_regblk x NPART
+    double* part_apply;              // n_vecblk
+    double* scal;
+    double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
+    int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
+};
+
+enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
+
+struct Engine {
+    Dev d;
+    Arena* arena = nullptr;
+    int cur = 0;
+    int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)
+    int pred_peek = 0;               // iterations the last trial needed to reach the first peek milestone
+    bool first_trial_accepted = false;   // outcome of the first trial of the previous LM iteration
+    double* h_scal = nullptr;        // pinned host mirrors
+    int* h_flags = nullptr;
+    std::vector<int> vrow;           // vertex -> row
+    // host copies needed to rewrite masks and to run the edge taps
+    std::vector<int> sp_ij, dm_idx, un_ij;
+    std::vector<float> sp_d0, dm_w, un_w;
+    std::vector<int> sp_pos, dm_pos, un_pos;     // SELL positions of every incidence (2 / 4 / 1 per edge)
+    std::vector<int> h_s_meta, h_d_meta;
+    std::vector<SpringRec> h_s_rec;
+    std::vector<DamperRec> h_d_rec;
+    std::vector<uint8_t> h_rflag, h_pose_fixed;
+    // device copies for the taps
+    int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
+    float *t_d0 = nullptr, *t_w = nullptr;
+    double* t_out = nullptr;
+};
+
+// =====================================================================================
+// device helpers
+// =====================================================================================
+__device__ inline int xcd_tile(int b, int nb) {
+    const int nb8 = (nb + 7) >> 3;
+    return (b & 7) * nb8 + (b >> 3);
+}
+
+template <int N>
+__device__ inline void block_sum(double* v, double* lds /* 4*N */, int lane, int wave) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) lds[wave * N + k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = lds[k] + lds[N + k] + lds[2 * N + k] + lds[3 * N + k];
+    __syncthreads();
+}
+
+// same reduction, totals written to out[0..N) by the first N threads
+template <int N>
+__device__ inline void block_sum_store(const double* v, double* lds /* 4*N */, int tid, double* out) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) lds[wave * N + k] = s;
+    }
+    __syncthreads();
+    if (tid < N) out[tid] = lds[tid] + lds[N + tid] + lds[2 * N + tid] + lds[3 * N + tid];
+}
+
+template <int T>
+__device__ inline double sub_sum_t(double v) { return group_sum<T>(v); }   // reduce over the T lanes of a row
+
+__device__ inline bool inv3_sym(const double* d /*xx xy xz yy yz zz*/, double lam, double* o) {
+    const double a = d[0] + lam, b = d[1], c = d[2], e = d[3] + lam, f = d[4], g = d[5] + lam;
+    const double c00 = e * g - f * f, c01 = c * f - b * g, c02 = b * f - c * e;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a * g - c * c) * id; o[4] = (b * c - a * f) * id; o[5] = (a * e - b * b) * id;
+    return det > 0;
+}
+
+// tile-level coarse correction: y = Bi rc with Bi = (B_t + lambda n_t I)^-1 prepared per trial by k_coarse_invert
+__device__ inline void tile_level(const double* Bi /*6*/, const double* rc, double* y) {
+    y[0] = Bi[0] * rc[0] + Bi[1] * rc[1] + Bi[2] * rc[2];
+    y[1] = Bi[1] * rc[0] + Bi[3] * rc[1] + Bi[4] * rc[2];
+    y[2] = Bi[2] * rc[0] + Bi[4] * rc[1] + Bi[5] * rc[2];
+}
+
+// stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0).
+// The halo is a gather through an index list: all indices of a thread are requested first, then all
+// rows, so that a thread has its 2-4 gathers in flight together instead of one dependent pair at a time.
+constexpr int STAGE_K = 4;
+__device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __restrict__ v, const double* __restrict__ add,
+                                  double* lds) {
+    const int row0 = b * P.tile_rows;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    int idx[STAGE_K];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
+    for (int i = tid; i < 3 * P.tile_rows; i += BLK) lds[i] = v[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
+    double val[STAGE_K][3];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            const size_t r = (size_t)idx[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) val[k][c] = v[3 * r + c] + (add ? add[3 * r + c] : 0.0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            double* d = lds + 3 * (size_t)(P.tile_rows + tid + k * BLK);
+            d[0] = val[k][0]; d[1] = val[k][1]; d[2] = val[k][2];
+        }
+    }
+    for (int i = tid + STAGE_K * BLK; i < hn; i += BLK) {         // very large halos
+        const size_t r = (size_t)P.halo_rows[hb + i];
+        double* d = lds + 3 * (size_t)(P.tile_rows + i);
+        d[0] = v[3 * r] + (add ? add[3 * r] : 0.0);
+        d[1] = v[3 * r + 1] + (add ? add[3 * r + 1] : 0.0);
+        d[2] = v[3 * r + 2] + (add ? add[3 * r + 2] : 0.0);
+    }
+}
+
+// u and the (spring) positions of the linearisation point, one pass over the halo list
+__device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* __restrict__ u, const double* __restrict__ x,
+                                   const double* __restrict__ add, double* lu, double* lx) {
+    const int row0 = b * P.tile_rows;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
+    int idx[STAGE_K];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
+    for (int i = tid; i < 3 * P.tile_rows; i += BLK) {
+        lu[i] = u[3 * (size_t)row0 + i];
+        lx[i] = x[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
+    }
+    double uu[STAGE_K][3], xx[STAGE_K][3];
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        if (idx[k] >= 0) {
+            const size_t r = (size_t)idx[k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) uu[k][c] = u[3 * r + c];
+            if (tid + k * BLK < ns) {                              // positions: spring neighbours only
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xx[k][c] = x[3 * r + c] + (add ? add[3 * r + c] : 0.0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STAGE_K; ++k) {
+        const int i = tid + k * BLK;
+        if (idx[k] >= 0) {
+            double* d = lu + 3 * (size_t)(P.tile_rows + i);
+            d[0] = uu[k][0]; d[1] = uu[k][1]; d[2] = uu[k][2];
+            if (i < ns) {
+                double* e = lx + 3 * (size_t)(P.tile_rows + i);
+                e[0] = xx[k][0]; e[1] = xx[k][1]; e[2] = xx[k][2];
+            }
+        }
+    }
+    for (int i = tid + STAGE_K * BLK; i < hn; i += BLK) {         // very large halos
+        const size_t r = (size_t)P.halo_rows[hb + i];
+        double* d = lu + 3 * (size_t)(P.tile_rows + i);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = u[3 * r + k];
+        if (i < ns) {
+            double* e = lx + 3 * (size_t)(P.tile_rows + i);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e[k] = x[3 * r + k] + (add ? add[3 * r + k] : 0.0);
+        }
+    }
+}
+
+// reprojection block of one row in factored form (same expressions as k_reproj):
+//   a += J_l^T w (J_l u_l + J_p u_p) ; pose partial = J_p^T w J_l u_l ; cross = u_l . H_lp u_p
+__device__ inline void row_factored(const RowRec& rc, const Pose& Tcw, const double* xs, const double* ul, const double* up,
+                                    double pm, double& a0, double& a1, double& a2, double* part /*9*/) {
+    double R[9];
+    quat_to_R(Tcw.q, R);
+    const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
+    const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
+    const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
+    double tl[2], tp[2], Jl[2][3], Jp[2][6];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+        Jp[rr][0] = pm * (-j1 * pz + j2 * py);
+        Jp[rr][1] = pm * (j0 * pz - j2 * px);
+        Jp[rr][2] = pm * (-j0 * py + j1 * px);
+        Jp[rr][3] = pm * j0; Jp[rr][4] = pm * j1; Jp[rr][5] = pm * j2;
+        Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+        Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+        Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+        tl[rr] = Jl[rr][0] * ul[0] + Jl[rr][1] * ul[1] + Jl[rr][2] * ul[2];
+        double s = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) s += Jp[rr][p] * up[p];
+        tp[rr] = s;
+    }
+    const double w = rc.w;
+    const double c0 = w * (tl[0] + tp[0]), c1 = w * (tl[1] + tp[1]);
+    a0 += Jl[0][0] * c0 + Jl[1][0] * c1;
+    a1 += Jl[0][1] * c0 + Jl[1][1] * c1;
+    a2 += Jl[0][2] * c0 + Jl[1][2] * c1;
+    part[2] = w * (tl[0] * tp[0] + tl[1] * tp[1]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) part[3 + p] = w * (Jp[0][p] * tl[0] + Jp[1][p] * tl[1]);
+}
+
+__device__ inline double damper_sign(int role) { return (role == 0 || role == 3) ? -1.0 : 1.0; }
+
+}  // namespace nrs
