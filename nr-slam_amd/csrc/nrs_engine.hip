@@ -108,7 +108,7 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
     }
 }
 
-static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it) {
+static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol2) {
     if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0, it); return; }
     for (int cls = 0; cls < 2; ++cls) {
         const int n = d.n_tiles_cls[cls];
@@ -116,11 +116,11 @@ static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it) {
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         const dim3 g(((n + 7) / 8) * 8), b(BLK);
         switch (d.T) {
-            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls, it); break;
-            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls, it); break;
-            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls, it); break;
-            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls, it); break;
-            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls, it); break;
+            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
         }
     }
 }
@@ -216,7 +216,7 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
         }
         {
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
-            launch_spmv(c, d, lam, it);
+            launch_spmv(c, d, lam, it, tol2);
         }
         if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
         {

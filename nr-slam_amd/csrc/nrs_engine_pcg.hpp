@@ -48,7 +48,9 @@ __device__ inline bool inv6_spd(const double* Hu, double lam, double* Ainv /*36*
 }
 
 __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
+    __shared__ double lds_ru[4];
     const int i = blockIdx.x * BLK + threadIdx.x;
+    double ru[1] = {0};
     if (i < P.n_rows) {
         double Di[6];
         const bool ok = inv3_sym(P.D + 6 * (size_t)i, lam, Di);
@@ -64,9 +66,11 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
             tile_level(P.co_bti + 6 * (size_t)tl, P.co_tb + 4 * (size_t)tl, yt);
             y0 = P.co_y0[3 * g] + yt[0]; y1 = P.co_y0[3 * g + 1] + yt[1]; y2 = P.co_y0[3 * g + 2] + yt[2];
         }
-        P.uv3[3 * i] = Di[0] * r0 + Di[1] * r1 + Di[2] * r2 + y0;
-        P.uv3[3 * i + 1] = Di[1] * r0 + Di[3] * r1 + Di[4] * r2 + y1;
-        P.uv3[3 * i + 2] = Di[2] * r0 + Di[4] * r1 + Di[5] * r2 + y2;
+        const double u0 = Di[0] * r0 + Di[1] * r1 + Di[2] * r2 + y0;
+        const double u1 = Di[1] * r0 + Di[3] * r1 + Di[4] * r2 + y1;
+        const double u2 = Di[2] * r0 + Di[4] * r1 + Di[5] * r2 + y2;
+        P.uv3[3 * i] = u0; P.uv3[3 * i + 1] = u1; P.uv3[3 * i + 2] = u2;
+        ru[0] = r0 * u0 + r1 * u1 + r2 * u2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { P.xv[3 * i + k] = 0; P.pv[3 * i + k] = 0; P.sv[3 * i + k] = 0; }
     }
@@ -82,6 +86,10 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
             P.rp[6 * i + a] = P.bp[6 * i + a];
             P.xp[6 * i + a] = 0; P.pp[6 * i + a] = 0; P.sp[6 * i + a] = 0;
         }
+    }
+    if (P.ecd) {                                                   // r.u of iteration 0, half 0 of the pair
+        block_sum<1>(ru, lds_ru, threadIdx.x & 63, threadIdx.x >> 6);
+        if (threadIdx.x == 0) P.part_ru[blockIdx.x] = ru[0];
     }
 }
 
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
 template <int T>
-__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it) {
+__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
@@ -196,6 +204,20 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     // incidence loops are branch-free and the LDS reads of a whole chunk can be in flight together
     const int ZROW = P.tile_rows + P.cap_h[cls], ZROWX = P.tile_rows + P.cap_s[cls];
     if (tid < 3) { lu[3 * ZROW + tid] = 0; lx[3 * ZROWX + tid] = 0; }
+    // r.u of this iteration was left by the previous vector update (or the trial setup): its loads go
+    // out with the staging loads, the sum rides on the staging barrier
+    double gsum = 0;
+    if (P.ecd) {
+        const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
+        for (int i = tid; i < P.n_vecblk; i += BLK) gsum += pr[i];
+        const double* upp = (it & 1) ? P.up2 : P.up;
+        const double* rpp = (it & 1) ? P.rp2 : P.rp;
+        for (int i = tid; i < 6 * P.K; i += BLK) gsum += rpp[i] * upp[i];
+        gsum = wave_sum(gsum);
+        if (lane == 0) lds[wave] = gsum;
+    }
+    const double gamma0 = P.scal[SC_GAMMA0];
+    const int done_flag = P.flags[0];                              // launches behind a converged solve are no-ops
     stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
     // row factors and the first record chunks are requested while the staging loads are in flight
     RowRec rc;
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     double rv0 = 0, rv1 = 0, rv2 = 0;
     if (t == 0) {
         rc = P.rowrec[row];
-        rv0 = P.rv[3 * row]; rv1 = P.rv[3 * row + 1]; rv2 = P.rv[3 * row + 2];
+        if (!P.ecd) { rv0 = P.rv[3 * row]; rv1 = P.rv[3 * row + 1]; rv2 = P.rv[3 * row + 2]; }
     }
     // records are double-buffered: chunk k+1 is requested before chunk k is consumed (with ~3 waves
     // per SIMD the loops are bound by the latency of their own loads otherwise)
@@ -228,6 +250,21 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     load_springs(srA, sbeg + lane);
     load_dampers(drA, dbeg + lane);
     __syncthreads();
+    if (done_flag) return;
+    if (P.ecd && it > 0) {
+        const double gamma = lds[0] + lds[1] + lds[2] + lds[3];
+        const bool bad = !isfinite(gamma);
+        if (gamma <= tol2 * gamma0 || bad || gamma == 0.0) {       // converged: the operator is not applied again
+            if (blockIdx.x == 0 && tid == 0 && cls == 0) {
+                if (bad) P.flags[2] = 1;
+                P.flags[1] = it;
+                __threadfence();
+                P.flags[0] = 1;
+            }
+            return;
+        }
+        __syncthreads();                                           // lds is reused by the final reduction
+    }
     const int self = row - b * P.tile_rows;
     const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         P.wv[3 * row] = a0; P.wv[3 * row + 1] = a1; P.wv[3 * row + 2] = a2;
-        part[0] = rv0 * ul[0] + rv1 * ul[1] + rv2 * ul[2];
+        part[0] = P.ecd ? 0.0 : rv0 * ul[0] + rv1 * ul[1] + rv2 * ul[2];
         part[1] = a0 * ul[0] + a1 * ul[1] + a2 * ul[2];
     }
     block_sum_store<9>(part, lds, tid, P.part_spmv + (size_t)b * NPART);
@@ -406,9 +443,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         if (tid == 0) { v[0] = P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
     } else {
         for (int b = tid; b < P.n_regblk; b += BLK) {
-            v[0] += P.part_spmv[(size_t)b * NPART];
+            if (!P.ecd) v[0] += P.part_spmv[(size_t)b * NPART];
             v[1] += P.part_spmv[(size_t)b * NPART + 1];
             v[2] += P.part_spmv[(size_t)b * NPART + 2];
+        }
+        if (P.ecd) {
+            const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
+            for (int b = tid; b < P.n_vecblk; b += BLK) v[0] += pr[b];
         }
     }
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
@@ -480,6 +521,18 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
                 *reinterpret_cast<double2*>(P.rv + o + 2 * k) = make_double2(rr[2 * k], rr[2 * k + 1]);
                 *reinterpret_cast<double2*>(P.uv3 + o + 2 * k) = make_double2(uu[2 * k], uu[2 * k + 1]);
             }
+        }
+        if (P.ecd) {                                               // r.u of the next iteration, other half of the pair
+            double ru[1] = {0};
+            if (has_rows) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ru[0] += rr[k] * uu[k];
+            }
+            block_sum<1>(ru, lds, lane, wave);
+            const int w2 = 2 * xcd_tile(blockIdx.x, n_vec2);
+            double* pw = P.part_ru + (size_t)((it + 1) & 1) * P.n_vecblk;
+            if (tid == 0 && w2 < P.n_vecblk) pw[w2] = ru[0];
+            if (tid == 1 && w2 + 1 < P.n_vecblk) pw[w2 + 1] = 0.0;
         }
     } else {
         // pose workgroups: one wave per pose; its 64 lanes split the pose's SpMV partials

@@ -93,6 +93,9 @@ struct Dev {
     // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
     // being re-summed by every workgroup of the update kernel (which is O(workgroups^2) reads)
     int hier;
+    // two-kernel path: r.u of the next iteration is produced by the vector update (and by the trial
+    // setup), so the operator kernel can see convergence BEFORE applying the operator once more
+    int ecd; double* part_ru;        // 2 x n_vecblk (ping-pong by iteration parity)
     double* red;                     // [0..2] r.u, w.u, cross ; [3 + 6k + a] pose sums
     // partials / scalars
     double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
