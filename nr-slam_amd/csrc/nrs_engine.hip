@@ -216,6 +216,7 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
         }
         {
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
+            if (d.hier && d.ecd) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(BLK), 0, c->stream, d, it);
             launch_spmv(c, d, lam, it, tol2);
         }
         if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);

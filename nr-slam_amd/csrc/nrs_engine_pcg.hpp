@@ -209,7 +209,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     double gsum = 0;
     if (P.ecd) {
         const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
-        for (int i = tid; i < P.n_vecblk; i += BLK) gsum += pr[i];
+        if (P.hier) { if (tid == 0) gsum = P.red[3 + 6 * P.K]; }  // pre-reduced by k_reduce_ru
+        else for (int i = tid; i < P.n_vecblk; i += BLK) gsum += pr[i];
         const double* upp = (it & 1) ? P.up2 : P.up;
         const double* rpp = (it & 1) ? P.rp2 : P.rp;
         for (int i = tid; i < 6 * P.K; i += BLK) gsum += rpp[i] * upp[i];
@@ -336,6 +337,18 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
 // large problems only: fixed-order reduction of the SpMV partials.  Workgroup 0: the three dot
 // partials over all workgroups; workgroup 1 + k: the six pose sums of pose k.
 // =====================================================================================
+// large problems: fixed-order sum of the r.u partials the vector update (or the trial setup) left for
+// iteration `it`, so that the operator kernel reads one number
+__global__ __launch_bounds__(BLK) void k_reduce_ru(Dev P, int it) {
+    __shared__ double lds[4];
+    const int tid = threadIdx.x;
+    const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
+    double v[1] = {0};
+    for (int i = tid; i < P.n_vecblk; i += BLK) v[0] += pr[i];
+    block_sum<1>(v, lds, tid & 63, tid >> 6);
+    if (tid == 0) P.red[3 + 6 * P.K] = v[0];
+}
+
 __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
     __shared__ double lds[4 * 6];
     if (P.flags[0]) return;
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     }
     double v[3] = {0, 0, 0};
     if (P.hier) {
-        if (tid == 0) { v[0] = P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
+        if (tid == 0) { v[0] = P.ecd ? P.red[3 + 6 * P.K] : P.red[0]; v[1] = P.red[1]; v[2] = P.red[2]; }
     } else {
         for (int b = tid; b < P.n_regblk; b += BLK) {
             if (!P.ecd) v[0] += P.part_spmv[(size_t)b * NPART];

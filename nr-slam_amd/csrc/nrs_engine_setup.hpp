@@ -81,7 +81,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     }
     d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
     d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
-    d.red = A.get<double>(3 + 6 * K);
+    d.red = A.get<double>(4 + 6 * K);
     d.part_ru = A.get<double>(d.ecd ? 2 * (size_t)d.n_vecblk : 1);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
@@ -407,7 +407,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
-    d.ecd = (d.use_lds && !d.fused && !d.hier && !getenv("NRS_NO_ECD")) ? 1 : 0;
+    d.ecd = (d.use_lds && !d.fused && !getenv("NRS_NO_ECD")) ? 1 : 0;
     // two-level preconditioner: fused path, one pose, small enough coarse system
     d.co_n = 3 * d.n_groups + 6;
     // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
