@@ -1,0 +1,73 @@
+"""The C++ side of the boundary: nr-slam_amd/host/nrs_views.hpp (the reference's function names on
+flat views) compiled into nr-slam_amd/host_demo with plain g++ and run on the GPU.  Its results must
+be bit-identical to the ctypes path through the same C ABI (same library, same inputs)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import nrs
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "nr-slam_amd", "host_demo")
+
+
+def _w(f, a):
+    a = np.ascontiguousarray(a)
+    f.write(struct.pack("<q", a.nbytes))
+    f.write(a.tobytes())
+
+
+def _r(f, dtype):
+    (n,) = struct.unpack("<q", f.read(8))
+    return np.frombuffer(f.read(n), dtype=dtype).copy()
+
+
+def _graph(f, g, scale):
+    for k, dt in (("rowptr", np.int32), ("col", np.int32), ("eid", np.int32), ("e_w", np.float32), ("e_d0", np.float32),
+                  ("e_max", np.float32), ("e_min", np.float32), ("e_status", np.int32)):
+        _w(f, np.asarray(g[k], dt))
+
+
+def test_cpp_host_mirror_matches_ctypes_path(ctx, tmp_path):
+    assert os.path.exists(DEMO), "nr-slam_amd/host_demo not built (make -C nr-slam_amd)"
+    n = 300
+    tp = S.make_tracking_problem(n, 31)
+    p = S.make_dba_problem(220, 4, 32)
+    fm = np.arange(n, dtype=np.int32)
+    qt = np.concatenate([tp["pose_q"], tp["pose_t"]]).astype(np.float64)
+    kf_rowptr = np.concatenate([[0], np.cumsum([len(k) for k in p["kf_points"]])]).astype(np.int32)
+    kf_pt = np.concatenate(p["kf_points"]).astype(np.int32)
+    wqt = np.concatenate([p["poses_q"], p["poses_t"]], 1).astype(np.float64)
+    src, dst = tmp_path / "in.blob", tmp_path / "out.blob"
+    with open(src, "wb") as f:
+        _w(f, np.array([tp["model"]], np.int32)); _w(f, np.asarray(tp["prm"], np.float32))
+        _w(f, tp["uv"].astype(np.float32)); _w(f, tp["X_prev"].astype(np.float32)); _w(f, tp["status"].astype(np.int32)); _w(f, fm); _w(f, qt)
+        _graph(f, tp["graph"], tp["scale"]); _w(f, tp["X_prev"].astype(np.float32))
+        _w(f, np.array([tp["graph"]["sigma"], tp["graph"]["stretch_th"], tp["scale"]], np.float32))
+        _w(f, wqt); _w(f, kf_rowptr); _w(f, kf_pt); _w(f, p["lm_uv"].astype(np.float32)); _w(f, p["lm_xyz"].astype(np.float32))
+        _graph(f, p["graph"], p["scale"])
+        _w(f, np.array([p["graph"]["sigma"], p["graph"]["stretch_th"], p["scale"]], np.float32))
+    r = subprocess.run([DEMO, str(src), str(dst)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(dst, "rb") as f:
+        a1 = _r(f, np.float64)
+        a2_qt, a2_pos, a2_st, a2_lost, a2_map, a2_est = _r(f, np.float64), _r(f, np.float32), _r(f, np.int32), _r(f, np.int32), _r(f, np.float32), _r(f, np.int32)
+        a3_qt, a3_xyz = _r(f, np.float64), _r(f, np.float32)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    m = tp["status"] == 0
+    q, t, _ = ctx.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
+    assert np.array_equal(a1, np.concatenate([q, t]))
+    r2 = ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"])
+    assert np.array_equal(a2_qt, np.concatenate([r2["pose_q"], r2["pose_t"]]))
+    assert np.array_equal(a2_pos.reshape(-1, 3), r2["f_pos"]) and np.array_equal(a2_st, r2["f_status"])
+    assert sorted(a2_lost.tolist()) == sorted(r2["lost"]) and np.array_equal(a2_map.reshape(-1, 3), r2["map_pos"])
+    assert np.array_equal(a2_est, r2["graph"]["e_status"])
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    camb = nrs.make_camera(p["model"], p["prm"])
+    pq, xyz = ctx.dba_solve(camb, wqt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5)
+    assert np.array_equal(a3_qt.reshape(-1, 7), pq) and np.array_equal(a3_xyz.reshape(-1, 3), xyz)
