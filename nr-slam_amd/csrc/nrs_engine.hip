@@ -321,6 +321,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f\n", it, qmax, lvl, pit, rho_peek); early = false; }
                     if (early) break;
                     seen = lvl;
+                    // the remaining looks exist only to reject: a gain ratio this far above every
+                    // threshold cannot get there any more (estimates are within ~0.15), so the solve
+                    // runs to convergence without further interruptions
+                    if (rho_peek > 0.25 && !peek_debug) seen = peek_levels;
                 }
                 NRS_TRY(pcg_advance(c, e, lam, peeking && seen < peek_levels ? seen + 1 : 0, &pit, &done));
                 NRS_TRY(eval_trial());
