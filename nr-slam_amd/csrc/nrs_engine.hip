@@ -190,7 +190,8 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     int it = *it_io;
-    const int stop = std::min(it + (count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
+    // profiling contexts poll after every iteration, so that no launch queued behind a converged solve is timed
+    const int stop = std::min(it + (c->opt.profile ? 1 : count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
     for (; it < stop; ++it) {
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);

@@ -407,7 +407,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
-    d.ecd = (d.use_lds && !d.fused && !getenv("NRS_NO_ECD")) ? 1 : 0;
+    // (a profiling context times full operator launches only: no convergence-detecting early exits)
+    d.ecd = (d.use_lds && !d.fused && !c->opt.profile && !getenv("NRS_NO_ECD")) ? 1 : 0;
     // two-level preconditioner: fused path, one pose, small enough coarse system
     d.co_n = 3 * d.n_groups + 6;
     // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
