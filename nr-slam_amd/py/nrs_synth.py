@@ -414,11 +414,11 @@ def make_frame_sequence(n_points=400, n_frames=6, seed=9, model=PINHOLE, step=0.
         # moving occluders (from frame 2 on): points under them fail the tracker / its SSIM gate, are
         # re-found by the point-reuse step once the patch has moved on
         for k in range(occluders if f >= 2 else 0):
-            cx = int(w * (0.25 + 0.5 * k / max(1, occluders)) + 40 * (f - 2))
+            cx = int(w * (0.25 + 0.5 * k / max(1, occluders)) + 40 * (f - 2)) % w
             cy = int(h * (0.35 + 0.2 * k))
             ph, pw = 46, 58
             y1, x1 = max(0, cy - ph // 2), max(0, cx - pw // 2)
-            patch = occl[k][:min(ph, h - y1), :min(pw, w - x1)]
+            patch = occl[k][:max(0, min(ph, h - y1)), :max(0, min(pw, w - x1))]
             img[y1:y1 + patch.shape[0], x1:x1 + patch.shape[1]] = patch
         images.append(img)
     X0 = (Xt[0][idx] + rng.normal(0, 0.002, (len(idx), 3))).astype(F32)
