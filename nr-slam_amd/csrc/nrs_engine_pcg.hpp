@@ -1025,15 +1025,21 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         sum9[6] = a0; sum9[7] = a1; sum9[8] = a2;
     }
     part[0] += dot_ru;
-    block_sum_store<9>(part, lds, tid, part_out + (size_t)b * NPART);
-    if (CO) {
-        __syncthreads();
-        block_sum<9>(sum9, lds, lane, wave);
-        if (tid < 9) {
-            double sv = sum9[0];
+    if (!CO) {
+        block_sum_store<9>(part, lds, tid, part_out + (size_t)b * NPART);
+    } else {
+        // one reduction for the nine PCG partials and the nine tile sums (one barrier instead of three)
+        double* l18 = c_v;                                         // the coarse vectors are dead by now: 4 x 18 doubles
 #pragma unroll
-            for (int q = 1; q < 9; ++q) sv = (tid == q) ? sum9[q] : sv;
-            ts_out[(size_t)tid * P.n_regblk + b] = sv;
+        for (int k = 0; k < 9; ++k) {
+            const double a = wave_sum(part[k]), c = wave_sum(sum9[k]);
+            if (lane == 0) { l18[wave * 18 + k] = a; l18[wave * 18 + 9 + k] = c; }
+        }
+        __syncthreads();
+        if (tid < 18) {
+            const double tot = l18[tid] + l18[18 + tid] + l18[36 + tid] + l18[54 + tid];
+            if (tid < 9) part_out[(size_t)b * NPART + tid] = tot;
+            else ts_out[(size_t)(tid - 9) * P.n_regblk + b] = tot;
         }
     }
 }
