@@ -682,9 +682,26 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const int cn = P.co_n, cG = P.n_groups;
     double bt_own[6], bt_h[6];
     const int th_h = (int)(hrow / (size_t)P.tile_rows);              // tile of this thread's halo row
+    // A_c^-1 y: thread (row r, part) owns a run of columns.  With <= 64 coarse unknowns (frames up to ~4.9k
+    // points) four parts cover the workgroup and the <= 16 matrix entries of a thread are requested here,
+    // with all the other loads of the launch; larger systems use two parts and load on the fly.
+    constexpr int CO_PF = 16;
+    const bool co4 = 4 * cn <= BLK;
+    const int co_parts = co4 ? 4 : 2;
+    const int co_r = tid % (cn > 0 ? cn : 1), co_part = tid / (cn > 0 ? cn : 1);
+    const int co_len = (cn + co_parts - 1) / co_parts;
+    const int co_c0 = co_part * co_len, co_c1 = min(cn, co_c0 + co_len);
+    double c_m[CO_PF];
     if (coarse) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bti[6 * (size_t)b + q]; bt_h[q] = P.co_bti[6 * (size_t)th_h + q]; }
+        if (co4) {
+#pragma unroll
+            for (int q = 0; q < CO_PF; ++q) {
+                const int c = co_c0 + q;
+                c_m[q] = (co_part < 4 && c < co_c1) ? P.co_inv[(size_t)c * cn + co_r] : 0.0;   // symmetric: column read, coalesced over r
+            }
+        }
     }
     if (own) {
 #pragma unroll
@@ -793,7 +810,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= coarse level: y = A_c^-1 Z^T r_new with r_new = r - alpha w - alpha beta s, i.e.
     // y = yR - alpha yW - alpha beta yS; the three products are formed before alpha, beta are known
     double* c_ts = dyn + 6 * (size_t)(P.tile_rows + P.max_halo);  // n_regblk x 9 tile sums
-    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 10 vectors of CO_MAX: Rc Sc Wc yR yS yW y + second halves of yR yS yW
+    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 16 vectors of CO_MAX: Rc Sc Wc, (yR yS yW) x up to 4 column parts, y
     if (coarse) {
         if (tid < P.n_regblk) {
 #pragma unroll
@@ -813,17 +830,23 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             c_v[(c / 3) * CO_MAX + 3 * g + c % 3] = sum;
         }
         __syncthreads();
-        if (tid < 2 * cn) {                                        // thread (row, half of the columns): three partial dot products
-            const int r = tid % cn, half = tid / cn;
-            const int c0 = half ? cn / 2 : 0, c1 = half ? cn : cn / 2;
+        if (co_part < co_parts) {                                  // three partial dot products over this thread's columns
             double yr = 0, ys = 0, yw = 0;
+            if (co4) {
+#pragma unroll
+                for (int q = 0; q < CO_PF; ++q) {
+                    const int c = co_c0 + q;
+                    if (c < co_c1) { yr += c_m[q] * c_v[c]; ys += c_m[q] * c_v[CO_MAX + c]; yw += c_m[q] * c_v[2 * CO_MAX + c]; }
+                }
+            } else {
 #pragma unroll 4
-            for (int c = c0; c < c1; ++c) {
-                const double m = P.co_inv[(size_t)c * cn + r];         // symmetric: column read, coalesced over r
-                yr += m * c_v[c]; ys += m * c_v[CO_MAX + c]; yw += m * c_v[2 * CO_MAX + c];
+                for (int c = co_c0; c < co_c1; ++c) {
+                    const double m = P.co_inv[(size_t)c * cn + co_r];
+                    yr += m * c_v[c]; ys += m * c_v[CO_MAX + c]; yw += m * c_v[2 * CO_MAX + c];
+                }
             }
-            double* dst = c_v + (half ? 7 : 3) * CO_MAX;             // second halves go to scratch vectors 7..9
-            dst[r] = yr; dst[CO_MAX + r] = ys; dst[2 * CO_MAX + r] = yw;
+            double* dst = c_v + (3 + 3 * co_part) * CO_MAX;         // part p writes vectors 3+3p .. 5+3p
+            dst[co_r] = yr; dst[CO_MAX + co_r] = ys; dst[2 * CO_MAX + co_r] = yw;
         }
     }
     // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
@@ -859,10 +882,16 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         }
     }
     if (coarse) {                                                  // (the reduction above was a barrier: yR, yS, yW are visible)
-        if (tid < cn) c_v[6 * CO_MAX + tid] = (c_v[3 * CO_MAX + tid] + c_v[7 * CO_MAX + tid]) - alpha * (c_v[5 * CO_MAX + tid] + c_v[9 * CO_MAX + tid]) - alpha * beta * (c_v[4 * CO_MAX + tid] + c_v[8 * CO_MAX + tid]);
+        if (tid < cn) {
+            double yr = 0, ys = 0, yw = 0;
+            for (int p = 0; p < co_parts; ++p) {
+                yr += c_v[(3 + 3 * p) * CO_MAX + tid]; ys += c_v[(4 + 3 * p) * CO_MAX + tid]; yw += c_v[(5 + 3 * p) * CO_MAX + tid];
+            }
+            c_v[15 * CO_MAX + tid] = yr - alpha * yw - alpha * beta * ys;
+        }
         __syncthreads();
     }
-    const double* ycor = c_v + 6 * CO_MAX;
+    const double* ycor = c_v + 15 * CO_MAX;
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
     // it, the first workgroup of the pose also stores the pose part of the state)
     if (wave == 0) {
