@@ -680,7 +680,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const bool o_free = own && !(P.rflag[orow] & RF_FIXED);
     const bool h_free = hh && !(P.rflag[hrow] & RF_FIXED);
     const int cn = P.co_n, cG = P.n_groups;
-    double bt_own[6], bt_h[6];
+    double bt_q[6];                                                  // (B_t + lambda n_t)^-1 of tile `tid`
     const int th_h = (int)(hrow / (size_t)P.tile_rows);              // tile of this thread's halo row
     // A_c^-1 y: thread (row r, part) owns a run of columns.  With <= 64 coarse unknowns (frames up to ~4.9k
     // points) four parts cover the workgroup and the <= 16 matrix entries of a thread are requested here,
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     double c_m[CO_PF];
     if (coarse) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { bt_own[q] = P.co_bti[6 * (size_t)b + q]; bt_h[q] = P.co_bti[6 * (size_t)th_h + q]; }
+        for (int q = 0; q < 6; ++q) bt_q[q] = tid < P.n_regblk ? P.co_bti[6 * (size_t)tid + q] : 0.0;
         if (co4) {
 #pragma unroll
             for (int q = 0; q < CO_PF; ++q) {
@@ -810,7 +810,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     // ================= coarse level: y = A_c^-1 Z^T r_new with r_new = r - alpha w - alpha beta s, i.e.
     // y = yR - alpha yW - alpha beta yS; the three products are formed before alpha, beta are known
     double* c_ts = dyn + 6 * (size_t)(P.tile_rows + P.max_halo);  // n_regblk x 9 tile sums
-    double* c_v = c_ts + 9 * (size_t)P.n_regblk;                   // 16 vectors of CO_MAX: Rc Sc Wc, (yR yS yW) x up to 4 column parts, y
+    double* c_yt = c_ts + 9 * (size_t)P.n_regblk;                  // n_regblk x 3 tile-level corrections
+    double* c_v = c_yt + 3 * (size_t)P.n_regblk;                   // 16 vectors of CO_MAX: Rc Sc Wc, (yR yS yW) x up to 4 column parts, y
     if (coarse) {
         if (tid < P.n_regblk) {
 #pragma unroll
@@ -889,6 +890,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             }
             c_v[15 * CO_MAX + tid] = yr - alpha * yw - alpha * beta * ys;
         }
+        if (tid < P.n_regblk) {                                    // tile level: y_t = B_t^-1 (R - alpha W - alpha beta S)_t, every tile
+            double rc3[3], yt[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * tid + k] - alpha * c_ts[9 * tid + 6 + k] - alpha * beta * c_ts[9 * tid + 3 + k];
+            tile_level(bt_q, rc3, yt);
+            c_yt[3 * tid] = yt[0]; c_yt[3 * tid + 1] = yt[1]; c_yt[3 * tid + 2] = yt[2];
+        }
         __syncthreads();
     }
     const double* ycor = c_v + 15 * CO_MAX;
@@ -940,12 +948,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             double u1 = o_D[1] * rn[0] + o_D[3] * rn[1] + o_D[4] * rn[2];
             double u2 = o_D[2] * rn[0] + o_D[4] * rn[1] + o_D[5] * rn[2];
             if (coarse && o_free) {                                // group level + tile level
-                double rc3[3], yt[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * b + k] - alpha * c_ts[9 * b + 6 + k] - alpha * beta * c_ts[9 * b + 3 + k];
-                tile_level(bt_own, rc3, yt);
                 const int g = row0 / ROW_ALIGN;
-                u0 += ycor[3 * g] + yt[0]; u1 += ycor[3 * g + 1] + yt[1]; u2 += ycor[3 * g + 2] + yt[2];
+                u0 += ycor[3 * g] + c_yt[3 * b]; u1 += ycor[3 * g + 1] + c_yt[3 * b + 1]; u2 += ycor[3 * g + 2] + c_yt[3 * b + 2];
             }
             P.uv3[3 * orow] = u0; P.uv3[3 * orow + 1] = u1; P.uv3[3 * orow + 2] = u2;
             lu[3 * tid] = u0; lu[3 * tid + 1] = u1; lu[3 * tid + 2] = u2;
@@ -969,14 +973,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 const bool fr = i == tid ? h_free : !(P.rflag[r2] & RF_FIXED);
                 if (fr) {
                     const int sl = (int)(r2 / ROW_ALIGN);
-                    const int th = (int)(r2 / (size_t)P.tile_rows);
-                    double rc3[3], yt[3], btl[6];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) rc3[k] = c_ts[9 * th + k] - alpha * c_ts[9 * th + 6 + k] - alpha * beta * c_ts[9 * th + 3 + k];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) btl[k] = i == tid ? bt_h[k] : P.co_bti[6 * (size_t)th + k];
-                    tile_level(btl, rc3, yt);
-                    y0 = ycor[3 * sl] + yt[0]; y1 = ycor[3 * sl + 1] + yt[1]; y2 = ycor[3 * sl + 2] + yt[2];
+                    const int th = i == tid ? th_h : (int)(r2 / (size_t)P.tile_rows);
+                    y0 = ycor[3 * sl] + c_yt[3 * th]; y1 = ycor[3 * sl + 1] + c_yt[3 * th + 1]; y2 = ycor[3 * sl + 2] + c_yt[3 * th + 2];
                 }
             }
             dst[0] = h_D[0] * rn[0] + h_D[1] * rn[1] + h_D[2] * rn[2] + y0;

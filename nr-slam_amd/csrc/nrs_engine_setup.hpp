@@ -414,7 +414,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
     // fixed and few free rows, converges in a few dozen block-Jacobi iterations anyway)
     const bool pose_free = !(s.pose_fixed && s.pose_fixed[0]);
-    const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 9 * (size_t)d.n_regblk + 16 * CO_MAX);
+    const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 12 * (size_t)d.n_regblk + 16 * CO_MAX);
     d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && fused_shm <= 63 * 1024 &&
                 !getenv("NRS_NO_COARSE")) ? 1 : 0;
     mark("halo");
