@@ -174,3 +174,31 @@ def test_contexts_and_engines_do_not_leak_device_memory(lib_built):
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 8 << 20, "device memory in use grew by %d bytes over 25 create/solve/destroy cycles" % (free0 - free1)
+
+
+def test_non_finite_inputs_fail_fast_with_a_numeric_error(ctx):
+    """NaN / inf in observations, positions or poses: the solves return NRS_ERR_NUMERIC at once
+    (no hang, no non-finite output); the context stays usable."""
+    p = S.make_dba_problem(200, 3, 79)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    for what in ("uv", "xyz", "pose"):
+        uv, xyz, q = p["lm_uv"].copy(), p["lm_xyz"].copy(), qt.copy()
+        if what == "uv":
+            uv[5, 0] = np.nan
+        elif what == "xyz":
+            xyz[7, 2] = np.nan
+        else:
+            q[1, 4] = np.inf
+        with pytest.raises(nrs.NrsError, match="NRS_ERR_NUMERIC"):
+            ctx.dba_solve(cam, q, xyz, p["lm_kf"], uv, e, p["scale"], 5)
+    tp = S.make_tracking_problem(200, 80)
+    camt = nrs.make_camera(tp["model"], tp["prm"])
+    fm = np.arange(200, dtype=np.int32)
+    uv = tp["uv"].copy()
+    uv[np.where(tp["status"] == 0)[0][3], 1] = np.nan
+    with pytest.raises(nrs.NrsError, match="NRS_ERR_NUMERIC"):
+        ctx.track_deform_solve(camt, tp["graph"], tp["X_prev"], fm, tp["status"], uv, tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"])
+    pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 2)      # still works
+    assert np.isfinite(pq).all() and np.isfinite(xyz).all()
