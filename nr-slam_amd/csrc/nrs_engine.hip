@@ -319,7 +319,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     // projection (relative 1e-7 per evaluation): near convergence the gain ratio of a
                     // tiny step is noise over the 1e-3 regulariser of its denominator, at any accuracy
                     early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl] && (temp - chi) > PEEK_MIN_REL_INCREASE * chi;
-                    if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f\n", it, qmax, lvl, pit, rho_peek); early = false; }
+                    if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f relinc %.3e\n", it, qmax, lvl, pit, rho_peek, (temp - chi) / chi); early = false; }
                     if (early) break;
                     seen = lvl;
                     // the remaining looks exist only to reject: a gain ratio this far above every
