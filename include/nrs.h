@@ -37,7 +37,8 @@ typedef enum {
     NRS_ERR_HIP = -3,         /* HIP runtime error during the call (message in nrs_last_error)    */
     NRS_ERR_ALLOC = -4,       /* host or device allocation failed                                 */
     NRS_ERR_STATE = -5,       /* call sequence error (e.g. optimize before upload)                */
-    NRS_ERR_NUMERIC = -6      /* non-finite values reached the solver                             */
+    NRS_ERR_NUMERIC = -6,     /* non-finite values reached the solver                             */
+    NRS_ERR_COMM = -7         /* RCCL not loadable / a collective failed (message in nrs_last_error) */
 } nrs_status;
 
 typedef enum { NRS_CAM_PINHOLE = 0, NRS_CAM_KB8 = 1 } nrs_camera_model;
@@ -154,6 +155,33 @@ int nrs_dba_download(nrs_ctx* ctx, double* poses_qt, double* lm_xyz /* n_lm x 3,
 int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_spring /* n_spring */,
                       double* r_damper /* n_damper x 3 */);
 int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
+
+/* ---- multi-GPU: one deformable-BA window sharded over the GPUs of a node ---------
+ * The reference solves LocalDeformableBundleAdjustment (g2o_optimization.cc:880-1161) as one g2o graph
+ * in one thread; there is no reference interface for this -- it is the build's own extension of a3.
+ * One process (or thread) per GPU, one context each.  After nrs_comm_init_* every rank calls
+ * nrs_dba_upload with the SAME complete problem; each rank then runs the row kernels for its own
+ * contiguous range of keyframes (nrs_shard_plan) and the ranks exchange, on the context's stream,
+ *   - per linearisation / trial evaluation: one all-reduce (sum) of the pose blocks of the normal
+ *     equations (H_pp 21 + b_p 6 doubles per keyframe) together with chi2, the LM scale and the
+ *     max-diagonal slots, and the landmark rows of the boundary keyframes with the two neighbour ranks;
+ *   - per PCG iteration: the boundary rows of the search direction and one all-reduce of 3 + 6 n_kf
+ *     doubles (dot products, pose rows of the operator).
+ * nrs_dba_reset / optimize / download / residuals are collective: every rank calls them in the same
+ * order; they return the same trace and, after download, the same complete result on every rank.
+ * RCCL is bound at run time (dlopen): librccl must be loadable only if nrs_comm_init_rccl is used.   */
+#define NRS_COMM_ID_BYTES 128
+int nrs_comm_unique_id(uint8_t* id, int32_t capacity /* >= NRS_COMM_ID_BYTES */);      /* rank 0; broadcast by the caller */
+int nrs_comm_init_rccl(nrs_ctx* ctx, int32_t world, int32_t rank, const uint8_t* id, int32_t id_bytes);
+int nrs_comm_rank(const nrs_ctx* ctx, int32_t* rank, int32_t* world);
+/* keyframe ranges: rank r owns keyframes kf_begin[r] .. kf_begin[r+1]-1 (balanced by padded landmark
+ * rows, every rank at least one keyframe).  Host only, needs no device. */
+int nrs_shard_plan(int32_t n_kf, int32_t n_lm, const int32_t* lm_kf, int32_t world, int32_t* kf_begin /* world+1 */);
+/* Test harness: ranks are threads of one process, their contexts on the same GPU; rendezvous on the
+ * host.  Runs the sharded arithmetic on a 1-GPU box. */
+int nrs_local_group_create(int32_t world /* <= 8 */, void** group);
+void nrs_local_group_destroy(void* group);
+int nrs_comm_init_local(nrs_ctx* ctx, void* group, int32_t rank);
 
 /* ---- a19 / a20: RegularizationGraph (modules/map/regularization_graph.{h,cc}) ------------------
  * Flat form of the graph: undirected edges carry the fields of RegularizationGraph::Edge

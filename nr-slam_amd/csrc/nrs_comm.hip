@@ -1,0 +1,223 @@
+// Exchange steps of a sharded bundle-adjustment solve: one process per GPU, the ranks
+// own contiguous ranges of keyframes, and per linearisation / PCG iteration they exchange
+//   * an all-reduce (sum) of the pose-side normal-equation blocks and the scalar sums, and
+//   * the rows of the two boundary keyframes with the neighbouring ranks (dampers reach one keyframe
+//     to either side: reference g2o_optimization.cc:1073-1132 connects consecutive keyframes only).
+// Two back ends behind nrs::Comm:
+//   RCCL   ncclAllReduce / grouped ncclSend+ncclRecv on the context's stream (xGMI between the GPUs of a
+//          node).  librccl is bound at run time with dlopen/dlsym -- the copy already loaded in the
+//          process (PyTorch's) if there is one -- so single-GPU users of libnrs_hip.so do not need it.
+//   local  ranks are threads of ONE process driving contexts on the same GPU: a test harness that runs
+//          the sharded arithmetic on a 1-GPU box (tests/test_gpu_sharded.py); rendezvous by a host barrier.
+#include <condition_variable>
+#include <dlfcn.h>
+#include <mutex>
+#include <new>
+#include <rccl/rccl.h>
+#include "nrs_ctx.hpp"
+
+namespace nrs {
+
+// ------------------------------------------------------------------------------------- RCCL
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static const RcclApi* rccl_api(char* err, size_t errlen) {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (api.h) return &api;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;      // the copy the process already uses
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { snprintf(err, errlen, "librccl not found: %s", dlerror()); return nullptr; }
+    RcclApi a;
+    a.h = h;
+#define NRS_SYM(field, name)                                                          \
+    *(void**)(&a.field) = dlsym(h, name);                                             \
+    if (!a.field) { snprintf(err, errlen, "librccl: missing symbol %s", name); return nullptr; }
+    NRS_SYM(GetUniqueId, "ncclGetUniqueId")
+    NRS_SYM(CommInitRank, "ncclCommInitRank")
+    NRS_SYM(CommDestroy, "ncclCommDestroy")
+    NRS_SYM(AllReduce, "ncclAllReduce")
+    NRS_SYM(Send, "ncclSend")
+    NRS_SYM(Recv, "ncclRecv")
+    NRS_SYM(GroupStart, "ncclGroupStart")
+    NRS_SYM(GroupEnd, "ncclGroupEnd")
+    NRS_SYM(GetErrorString, "ncclGetErrorString")
+#undef NRS_SYM
+    api = a;
+    return &api;
+}
+
+#define NRS_NCCL(ctx, call)                                                                         \
+    do {                                                                                            \
+        ncclResult_t r__ = (call);                                                                  \
+        if (r__ != ncclSuccess)                                                                     \
+            return (ctx)->fail(NRS_ERR_COMM, "%s failed: %s", #call, api->GetErrorString(r__));     \
+    } while (0)
+
+struct RcclComm : Comm {
+    const RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    ~RcclComm() override { if (comm) (void)api->CommDestroy(comm); }
+    int allreduce(nrs_ctx* c, const double* send, double* recv, size_t n) override {
+        NRS_NCCL(c, api->AllReduce(send, recv, n, ncclDouble, ncclSum, comm, c->stream));
+        return NRS_OK;
+    }
+    int exchange(nrs_ctx* c, double* v, const HaloPlan& h) override {
+        if (world == 1) return NRS_OK;
+        NRS_NCCL(c, api->GroupStart());
+        if (rank > 0) {
+            NRS_NCCL(c, api->Send(v + h.lo_send, h.lo_send_n, ncclDouble, rank - 1, comm, c->stream));
+            NRS_NCCL(c, api->Recv(v + h.lo_recv, h.lo_recv_n, ncclDouble, rank - 1, comm, c->stream));
+        }
+        if (rank < world - 1) {
+            NRS_NCCL(c, api->Send(v + h.hi_send, h.hi_send_n, ncclDouble, rank + 1, comm, c->stream));
+            NRS_NCCL(c, api->Recv(v + h.hi_recv, h.hi_recv_n, ncclDouble, rank + 1, comm, c->stream));
+        }
+        NRS_NCCL(c, api->GroupEnd());
+        return NRS_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------- local (threads, one GPU)
+constexpr int LOCAL_MAX = 8;
+struct LocalGroup {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    const double* slot[LOCAL_MAX] = {};
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+struct PtrPack { const double* p[LOCAL_MAX]; };
+
+__global__ void k_local_sum(PtrPack in, int world, double* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int r = 0; r < world; ++r) s += in.p[r][i];               // rank order: the same bits on every rank
+    out[i] = s;
+}
+
+struct LocalComm : Comm {
+    LocalGroup* g = nullptr;
+    DevBuf tmp;
+    ~LocalComm() override { if (tmp.p) (void)hipFree(tmp.p); }
+    int allreduce(nrs_ctx* c, const double* send, double* recv, size_t n) override {
+        g->slot[rank] = send;
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        g->barrier();
+        PtrPack pp;
+        for (int r = 0; r < LOCAL_MAX; ++r) pp.p[r] = r < world ? g->slot[r] : nullptr;
+        NRS_TRY(c->ensure(tmp, sizeof(double) * n));               // send == recv is allowed: sum into a staging buffer
+        hipLaunchKernelGGL(k_local_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pp, world, tmp.as<double>(), n);
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        g->barrier();                                              // everybody has read every send buffer
+        NRS_HIP(c, hipMemcpyAsync(recv, tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        return NRS_OK;
+    }
+    int exchange(nrs_ctx* c, double* v, const HaloPlan& h) override {
+        if (world == 1) return NRS_OK;
+        g->slot[rank] = v;
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        g->barrier();
+        // the layout is the same on every rank: a neighbour's send range is this rank's receive range
+        if (rank > 0) NRS_HIP(c, hipMemcpyAsync(v + h.lo_recv, g->slot[rank - 1] + h.lo_recv, sizeof(double) * h.lo_recv_n, hipMemcpyDeviceToDevice, c->stream));
+        if (rank < world - 1) NRS_HIP(c, hipMemcpyAsync(v + h.hi_recv, g->slot[rank + 1] + h.hi_recv, sizeof(double) * h.hi_recv_n, hipMemcpyDeviceToDevice, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        g->barrier();
+        return NRS_OK;
+    }
+};
+
+void comm_free(nrs_ctx* c) {
+    delete c->comm;
+    c->comm = nullptr;
+}
+
+}  // namespace nrs
+
+using namespace nrs;
+
+extern "C" int nrs_comm_unique_id(uint8_t* id, int32_t capacity) {
+    if (!id || capacity < (int32_t)sizeof(ncclUniqueId)) return NRS_ERR_INVALID;
+    char err[256];
+    const RcclApi* api = rccl_api(err, sizeof(err));
+    if (!api) return NRS_ERR_COMM;
+    ncclUniqueId u;
+    if (api->GetUniqueId(&u) != ncclSuccess) return NRS_ERR_COMM;
+    memset(id, 0, (size_t)capacity);
+    memcpy(id, &u, sizeof(u));
+    return NRS_OK;
+}
+
+extern "C" int nrs_comm_init_rccl(nrs_ctx* c, int32_t world, int32_t rank, const uint8_t* id, int32_t id_bytes) {
+    if (!c) return NRS_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !id || id_bytes < (int32_t)sizeof(ncclUniqueId))
+        return c->fail(NRS_ERR_INVALID, "nrs_comm_init_rccl: bad argument");
+    if (c->dba) return c->fail(NRS_ERR_STATE, "set the communicator before uploading a problem");
+    comm_free(c);
+    const RcclApi* api = rccl_api(c->err, sizeof(c->err));
+    if (!api) return NRS_ERR_COMM;
+    NRS_HIP(c, hipSetDevice(c->device));
+    RcclComm* rc = new (std::nothrow) RcclComm();
+    if (!rc) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    rc->api = api; rc->rank = rank; rc->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclResult_t r = api->CommInitRank(&rc->comm, world, u, rank);
+    if (r != ncclSuccess) { rc->comm = nullptr; delete rc; return c->fail(NRS_ERR_COMM, "ncclCommInitRank failed: %s", api->GetErrorString(r)); }
+    c->comm = rc;
+    return NRS_OK;
+}
+
+extern "C" int nrs_local_group_create(int32_t world, void** group) {
+    if (!group || world < 1 || world > LOCAL_MAX) return NRS_ERR_INVALID;
+    LocalGroup* g = new (std::nothrow) LocalGroup();
+    if (!g) return NRS_ERR_ALLOC;
+    g->world = world;
+    *group = g;
+    return NRS_OK;
+}
+
+extern "C" void nrs_local_group_destroy(void* group) { delete static_cast<LocalGroup*>(group); }
+
+extern "C" int nrs_comm_init_local(nrs_ctx* c, void* group, int32_t rank) {
+    if (!c) return NRS_ERR_INVALID;
+    LocalGroup* g = static_cast<LocalGroup*>(group);
+    if (!g || rank < 0 || rank >= g->world) return c->fail(NRS_ERR_INVALID, "nrs_comm_init_local: bad argument");
+    if (c->dba) return c->fail(NRS_ERR_STATE, "set the communicator before uploading a problem");
+    comm_free(c);
+    LocalComm* lc = new (std::nothrow) LocalComm();
+    if (!lc) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    lc->g = g; lc->rank = rank; lc->world = g->world;
+    c->comm = lc;
+    return NRS_OK;
+}
+
+extern "C" int nrs_comm_rank(const nrs_ctx* c, int32_t* rank, int32_t* world) {
+    if (!c) return NRS_ERR_INVALID;
+    if (rank) *rank = c->comm ? c->comm->rank : 0;
+    if (world) *world = c->comm ? c->comm->world : 1;
+    return NRS_OK;
+}

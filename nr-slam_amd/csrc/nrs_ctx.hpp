@@ -18,6 +18,18 @@ struct DevBuf {
 
 struct Engine;       // nrs_engine.hip
 struct KltState;     // nrs_klt.hip
+
+// Exchange steps of a sharded solve (nrs_comm.hip): one process per GPU, every call is ordered on the
+// context's stream.  Two primitives are all the engine needs:
+//   allreduce : element-wise sum of n doubles over the ranks, the same bits on every rank
+//   exchange  : boundary rows of a replicated-layout row vector with rank-1 / rank+1 (offsets in doubles)
+struct HaloPlan { size_t lo_send = 0, lo_send_n = 0, hi_send = 0, hi_send_n = 0, lo_recv = 0, lo_recv_n = 0, hi_recv = 0, hi_recv_n = 0; };
+struct Comm {
+    int rank = 0, world = 1;
+    virtual ~Comm() {}
+    virtual int allreduce(nrs_ctx* c, const double* send, double* recv, size_t n) = 0;
+    virtual int exchange(nrs_ctx* c, double* vec, const HaloPlan& h) = 0;
+};
 struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 
 }  // namespace nrs
@@ -36,6 +48,7 @@ struct nrs_ctx {
     nrs::Engine* dba = nullptr;
     nrs::Arena arena_dba, arena_trk;
     nrs::KltState* klt = nullptr;
+    nrs::Comm* comm = nullptr;       // set by nrs_comm_init_*: BA problems uploaded afterwards are sharded over its ranks
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
 
@@ -80,5 +93,6 @@ struct nrs_ctx {
 
 namespace nrs {
 void dba_free(nrs_ctx* ctx);
+void comm_free(nrs_ctx* ctx);
 void klt_free(nrs_ctx* ctx);
 }

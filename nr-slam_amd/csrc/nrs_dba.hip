@@ -1,5 +1,6 @@
 // a3: LocalDeformableBundleAdjustment C-ABI entry points (reference
 // modules/optimization/g2o_optimization.cc:880-1161) on top of the graph LM engine.
+#include <algorithm>
 #include "nrs_engine.hpp"
 
 namespace nrs {
@@ -63,6 +64,18 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     s.delta_pos = 0.0;                  // no robust kernel on the BA springs (OPT:1057-1071)
     s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
     return engine_create(c, s, &c->arena_dba, &c->dba);
+}
+
+extern "C" int nrs_shard_plan(int32_t n_kf, int32_t n_lm, const int32_t* lm_kf, int32_t world, int32_t* kf_begin) {
+    if (n_kf <= 0 || n_lm < 0 || (n_lm > 0 && !lm_kf) || world < 1 || world > n_kf || !kf_begin) return NRS_ERR_INVALID;
+    std::vector<int> cnt(n_kf, 0), grp(n_kf + 1, 0);
+    for (int i = 0; i < n_lm; ++i) {
+        if (lm_kf[i] < 0 || lm_kf[i] >= n_kf) return NRS_ERR_INVALID;
+        cnt[lm_kf[i]]++;
+    }
+    for (int k = 0; k < n_kf; ++k) grp[k + 1] = grp[k] + std::max(1, (cnt[k] + 255) / 256);   // rows are padded to 256 per keyframe
+    shard_plan(n_kf, grp.data(), world, kf_begin);
+    return NRS_OK;
 }
 
 extern "C" int nrs_dba_reset(nrs_ctx* c) {

@@ -90,9 +90,9 @@ template <bool LIN>
 static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
     if (!d.use_lds) { launch_reg2<LIN, false>(c, d, xl, 0, d.n_regblk, 0); return; }
     for (int cls = 0; cls < 2; ++cls) {
-        if (d.n_tiles_cls[cls] == 0) continue;
+        if (d.sh_nt[cls] == 0) continue;
         const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
-        launch_reg2<LIN, true>(c, d, xl, shm, d.n_tiles_cls[cls], cls);
+        launch_reg2<LIN, true>(c, d, xl, shm, d.sh_nt[cls], cls);
     }
 }
 
@@ -111,7 +111,7 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
 static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol2) {
     if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0, it); return; }
     for (int cls = 0; cls < 2; ++cls) {
-        const int n = d.n_tiles_cls[cls];
+        const int n = d.sh_nt[cls];
         if (n == 0) continue;
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         const dim3 g(((n + 7) / 8) * 8), b(BLK);
@@ -130,7 +130,7 @@ template <bool LIN>
 static int evaluate(nrs_ctx* c, Engine* e, int which) {
     if (LIN) { e->d.lin_pose = e->d.pose[which]; e->d.lin_xl = e->d.xl[which]; }   // the PCG kernels re-form factors from it
     const Dev& d = e->d;
-    const dim3 gg(((d.n_groups + 7) / 8) * 8), b(BLK);
+    const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
     if (LIN) {
         Timer t(c, &c->prof.linearize_ms, &c->prof.linearize_launches);
         hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
@@ -139,7 +139,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
         launch_reg<LIN>(c, d, d.xl[which]);
     }
-    if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.K), b, 0, c->stream, d);
+    if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.sh_nk), b, 0, c->stream, d);
     if (LIN && d.coarse) {
         const size_t rows = (size_t)(d.tile_rows + d.max_halo);
         const size_t shm = sizeof(double) * 3 * rows + 3 * (rows + 8) + 16;
@@ -153,7 +153,16 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         }
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
-    hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d);
+    if (d.sh_on) {
+        // local sums -> packet -> all-reduce over the ranks (pose blocks of the normal equations, chi2,
+        // scale, one max-diagonal slot per rank) -> every rank publishes the same scalars
+        hipLaunchKernelGGL((k_finalize_pack<LIN>), dim3(1), b, 0, c->stream, d);
+        NRS_HIP(c, hipGetLastError());
+        NRS_TRY(c->comm->allreduce(c, d.pk_loc, d.pk, (size_t)(2 + d.sh_world + (LIN ? 27 * d.K : 0))));
+        hipLaunchKernelGGL((k_finalize_unpack<LIN>), dim3(1), b, 0, c->stream, d);
+    } else {
+        hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d);
+    }
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
@@ -179,13 +188,13 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     const Dev& d = e->d;
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     if (d.coarse) hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(BLK), sizeof(double) * (size_t)d.co_n * d.co_n, c->stream, d, lam);
-    hipLaunchKernelGGL(k_trial_setup, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam);
+    hipLaunchKernelGGL(k_trial_setup, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam);
     *it = 0;
     return NRS_OK;
 }
 
 // enqueue one batch of PCG iterations (no host synchronisation)
-static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int count = 0) {
+static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int count = 0) {
     const Dev& d = e->d;
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
@@ -215,19 +224,29 @@ static void pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int
             }
             continue;
         }
+        // sharded: the operator reads u of the neighbouring ranks' boundary keyframes (dampers)
+        if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.uv3, e->halo));
         {
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
             if (d.hier && d.ecd) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(BLK), 0, c->stream, d, it);
             launch_spmv(c, d, lam, it, tol2);
         }
-        if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
+        if (d.sh_on) {
+            // this rank's dot products and pose sums (other ranks' slots are zero), then the sum over the
+            // ranks: every rank continues with the same scalars and updates every pose identically
+            Dev dl = d;
+            dl.red = d.red_loc;
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, dl);
+            NRS_TRY(c->comm->allreduce(c, d.red_loc, d.red, (size_t)(3 + 6 * d.K)));
+        } else if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
         {
             Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-            hipLaunchKernelGGL(k_pcg_update, dim3((((d.n_vecblk + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
+            hipLaunchKernelGGL(k_pcg_update, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
                                d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
         }
     }
     *it_io = it;
+    return NRS_OK;
 }
 
 static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* it_io, bool* done) {
@@ -239,7 +258,7 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* i
         if (stop_level == 0 && e->pred_iters > *it_io) count = std::min(std::max((e->pred_iters - *it_io) / 2, c->opt.pcg_batch), 8 * c->opt.pcg_batch);
         if (stop_level == 0 && e->pred_iters >= *it_io && e->pred_iters + 1 - *it_io <= c->opt.pcg_batch) count = e->pred_iters + 1 - *it_io;   // short solves: finish in one batch
         if (stop_level > 0 && e->pred_peek > 0) count = std::max(2, std::min(e->pred_peek, c->opt.pcg_batch));                                // waiting for a milestone: small steps
-        pcg_enqueue_batch(c, e, lam, it_io, count);
+        NRS_TRY(pcg_enqueue_batch(c, e, lam, it_io, count));
         NRS_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d);
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -285,7 +304,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             NRS_TRY(pcg_begin(c, e, lam, &pit));
             auto eval_trial = [&]() -> int {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
-                hipLaunchKernelGGL(k_apply, dim3(d.n_vecblk), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo));   // the regularisers read the neighbours' boundary keyframes
                 NRS_TRY(evaluate<false>(c, e, trial));
                 return read_scalars(c, e);                 // one synchronisation: chi2, scale and the PCG flags
             };
@@ -302,7 +322,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                 const bool expect_accept = qmax == 0 && e->first_trial_accepted && e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch;
                 if (peeking && !expect_accept) first = e->pred_peek > 0 ? std::min(e->pred_peek, c->opt.pcg_batch) : std::max(1, c->opt.pcg_batch / 2);
                 else if (e->pred_iters > 0 && e->pred_iters + 1 <= 2 * c->opt.pcg_batch) first = e->pred_iters + 1;
-                pcg_enqueue_batch(c, e, lam, &pit, first);
+                NRS_TRY(pcg_enqueue_batch(c, e, lam, &pit, first));
                 NRS_TRY(eval_trial());
                 done = e->h_flags[0] != 0 || pit >= c->opt.pcg_max_iters;
             }
@@ -369,11 +389,27 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     return NRS_OK;
 }
 
+// sharded: the current estimates of all rows on every rank (each rank contributes its own rows, zeros
+// elsewhere, summed over the ranks); uses the PCG vectors w and s as scratch
+static int gather_state(nrs_ctx* c, Engine* e, const double** xl_full) {
+    Dev& d = e->d;
+    *xl_full = d.xl[e->cur];
+    if (!d.sh_on) return NRS_OK;
+    const size_t n = 3 * (size_t)d.n_rows;
+    hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d, d.xl[e->cur], d.wv);
+    NRS_HIP(c, hipGetLastError());
+    NRS_TRY(c->comm->allreduce(c, d.wv, d.sv, n));
+    *xl_full = d.sv;
+    return NRS_OK;
+}
+
 int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x) {
     Dev& d = e->d;
     std::vector<double> xl((size_t)d.n_rows * 3);
+    const double* src = nullptr;
+    NRS_TRY(gather_state(c, e, &src));
     if (poses) NRS_HIP(c, hipMemcpyAsync(poses, d.pose[e->cur], sizeof(Pose) * d.K, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(xl.data(), d.xl[e->cur], sizeof(double) * xl.size(), hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(xl.data(), src, sizeof(double) * xl.size(), hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     if (x)
         for (int v = 0; v < d.M; ++v)
@@ -387,7 +423,9 @@ int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, 
     double* rs = rr + 2 * (size_t)d.M;
     double* rd = rs + (size_t)d.n_sp;
     const int n = std::max(d.M, std::max(d.n_sp, d.n_dm));
-    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], d.xl[e->cur],
+    const double* xl_full = nullptr;
+    NRS_TRY(gather_state(c, e, &xl_full));
+    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], xl_full,
                        e->t_vrow, e->t_sp, e->t_d0, e->t_dm, e->t_w, rr, rs, rd);
     NRS_HIP(c, hipGetLastError());
     if (r_reproj) NRS_HIP(c, hipMemcpyAsync(r_reproj, rr, sizeof(double) * 2 * (size_t)d.M, hipMemcpyDeviceToHost, c->stream));
@@ -413,6 +451,7 @@ int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj, double* spring, doub
 
 int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag) {
     Dev& d = e->d;
+    if (d.sh_on) return c->fail(NRS_ERR_STATE, "the gradient tap is not available on a sharded problem");
     NRS_TRY(evaluate<true>(c, e, e->cur));
     std::vector<double> bp(6 * (size_t)d.K), Hpp(21 * (size_t)d.K), bl(3 * (size_t)d.n_rows), D(6 * (size_t)d.n_rows);
     NRS_HIP(c, hipMemcpyAsync(bp.data(), d.bp, sizeof(double) * bp.size(), hipMemcpyDeviceToHost, c->stream));

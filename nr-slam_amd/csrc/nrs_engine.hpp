@@ -58,6 +58,7 @@ int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
 int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);       // solver order, caller vertex order
 void arena_release(Arena* a);
+void shard_plan(int K, const int* grp_ptr, int world, int* kb);     // contiguous keyframe ranges, balanced by rows
 int engine_num_poses(const Engine* e);
 void ba_constants(EngineSpec& s, float scale);            // thresholds / informations of OPT:195-210,958-973
 

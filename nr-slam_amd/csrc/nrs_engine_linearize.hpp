@@ -14,8 +14,9 @@ template <bool LIN>
 __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ poses,
                                                 const double* __restrict__ xl) {
     __shared__ double lds[4 * 28];
-    const int g = xcd_tile(blockIdx.x, P.n_groups);
-    if (g >= P.n_groups) return;
+    const int gi = xcd_tile(blockIdx.x, P.sh_ng);
+    if (gi >= P.sh_ng) return;
+    const int g = P.sh_g0 + gi;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = g * ROW_ALIGN + tid;
     const int kf = P.grp_pose[g];
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     __shared__ double lds[4 * 2];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
-    int b = xcd_tile(blockIdx.x, LDS ? P.n_tiles_cls[cls] : P.n_regblk);
-    if (b >= (LDS ? P.n_tiles_cls[cls] : P.n_regblk)) return;
-    if (LDS) b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + b];
+    int b = xcd_tile(blockIdx.x, LDS ? P.sh_nt[cls] : P.n_regblk);
+    if (b >= (LDS ? P.sh_nt[cls] : P.n_regblk)) return;
+    if (LDS) b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
@@ -374,12 +375,79 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
     if (tid < 8) P.h_flags[tid] = P.flags[tid];
 }
 
+// Sharded evaluation (multi-GPU): the same fixed-order sums over this rank's partials (slots of other
+// ranks' tiles are never written and stay zero) go into a packet that is all-reduced (sum) across the
+// ranks; the maxima travel as one slot per rank.  LIN: the packet also carries H_pp and b_p of the
+// rank's own poses, so that after the all-reduce every rank holds the pose blocks of all poses --
+// the "all-reduce of the per-block normal equations" of SURVEY.md 8(e).
+template <bool LIN>
+__global__ __launch_bounds__(BLK) void k_finalize_pack(Dev P) {
+    __shared__ double lds[4 * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = 2 + P.sh_world + (LIN ? 27 * P.K : 0);
+    for (int i = tid; i < n; i += BLK) P.pk_loc[i] = 0.0;
+    double chi = 0, md = 0, sc = 0;
+    if (!LIN)
+        for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
+    for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    for (int b = tid; b < P.n_regblk; b += BLK) {
+        chi += P.part_reg[2 * (size_t)b];
+        md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+    }
+    if (LIN)
+        for (int k = P.sh_k0 + tid; k < P.sh_k0 + P.sh_nk; k += BLK) md = fmax(md, P.red_loc[3 + k]);
+    double c = wave_sum(chi);
+    sc = wave_sum(sc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
+    if (lane == 0) { lds[wave * 3] = c; lds[wave * 3 + 1] = md; lds[wave * 3 + 2] = sc; }
+    __syncthreads();
+    if (tid == 0) {
+        P.pk_loc[0] = lds[0] + lds[3] + lds[6] + lds[9];
+        P.pk_loc[1] = lds[2] + lds[5] + lds[8] + lds[11];
+        P.pk_loc[2 + P.sh_rank] = fmax(fmax(lds[1], lds[4]), fmax(lds[7], lds[10]));
+    }
+    if (LIN) {
+        double* q = P.pk_loc + 2 + P.sh_world;
+        for (int i = tid; i < 27 * P.sh_nk; i += BLK) {
+            const int k = P.sh_k0 + i / 27, cc = i % 27;
+            q[27 * k + cc] = cc < 21 ? P.Hpp[21 * k + cc] : P.bp[6 * k + (cc - 21)];
+        }
+    }
+}
+
+template <bool LIN>
+__global__ __launch_bounds__(BLK) void k_finalize_unpack(Dev P) {
+    const int tid = threadIdx.x;
+    if (LIN) {
+        const double* q = P.pk + 2 + P.sh_world;
+        for (int i = tid; i < 27 * P.K; i += BLK) {
+            const int k = i / 27, cc = i % 27;
+            if (cc < 21) P.Hpp[21 * k + cc] = q[i]; else P.bp[6 * k + (cc - 21)] = q[i];
+        }
+    }
+    if (tid == 0) {
+        P.scal[SC_CHI] = P.pk[0];
+        P.h_scal[SC_CHI] = P.pk[0];
+        if (LIN) {
+            double md = 0;
+            for (int r = 0; r < P.sh_world; ++r) md = fmax(md, P.pk[2 + r]);
+            P.scal[SC_MAXDIAG] = md;
+            P.h_scal[SC_MAXDIAG] = md;
+        } else {
+            P.scal[SC_SCALE] = P.pk[1];
+            P.h_scal[SC_SCALE] = P.pk[1];
+        }
+    }
+    if (tid < 8) P.h_flags[tid] = P.flags[tid];
+}
+
 // H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the k_reproj partials
 // (8 lanes per component, then the 8 in order); red[3 + k] = max |diagonal| for the LM lambda_0
 __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     __shared__ double lds[8][32];
     __shared__ double mdl[32];
-    const int k = blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
+    const int k = P.sh_k0 + blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
     double s = 0;
     if (c < 27)
         for (int g = P.pose_grp_ptr[k] + gl; g < P.pose_grp_ptr[k + 1]; g += 8) s += P.part_lin[(size_t)g * 32 + c];
@@ -399,7 +467,7 @@ __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     if (tid == 0) {
         double m = 0;
         for (int q = 0; q < 21; ++q) m = fmax(m, mdl[q]);
-        P.red[3 + k] = m;
+        (P.sh_on ? P.red_loc : P.red)[3 + k] = m;
     }
 }
 

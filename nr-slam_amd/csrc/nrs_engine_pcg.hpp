@@ -49,7 +49,7 @@ __device__ inline bool inv6_spd(const double* Hu, double lam, double* Ainv /*36*
 
 __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
     __shared__ double lds_ru[4];
-    const int i = blockIdx.x * BLK + threadIdx.x;
+    const int i = (P.sh_vb0 + blockIdx.x) * BLK + threadIdx.x;      // row (own range); poses below: every rank, all of them
     double ru[1] = {0};
     if (i < P.n_rows) {
         double Di[6];
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { P.xv[3 * i + k] = 0; P.pv[3 * i + k] = 0; P.sv[3 * i + k] = 0; }
     }
-    if (i < P.K) {
+    if (blockIdx.x * BLK + threadIdx.x < P.K) {
+        const int i = blockIdx.x * BLK + threadIdx.x;
         double Ai[36];
         if (!inv6_spd(P.Hpp + 21 * i, lam, Ai)) P.flags[2] = 1;
         for (int k = 0; k < 36; ++k) P.Hppinv[36 * i + k] = Ai[k];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(BLK) void k_trial_setup(Dev P, double lam) {
     }
     if (P.ecd) {                                                   // r.u of iteration 0, half 0 of the pair
         block_sum<1>(ru, lds_ru, threadIdx.x & 63, threadIdx.x >> 6);
-        if (threadIdx.x == 0) P.part_ru[blockIdx.x] = ru[0];
+        if (threadIdx.x == 0) P.part_ru[P.sh_vb0 + blockIdx.x] = ru[0];
     }
 }
 
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
-    const int bi = xcd_tile(blockIdx.x, P.n_tiles_cls[cls]);
-    if (bi >= P.n_tiles_cls[cls]) return;
-    const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + bi];
+    const int bi = xcd_tile(blockIdx.x, P.sh_nt[cls]);
+    if (bi >= P.sh_nt[cls]) return;
+    const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + bi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
 // =====================================================================================
 __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2) {
     __shared__ double lds[4 * 3];
-    const int n_vecblk = P.n_vecblk;
+    const int n_vecblk = P.sh_nvb;                                 // own row range (the whole problem when not sharded)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // u_p and r_p are read by every workgroup (for the scalars) and rewritten by the pose workgroups
     // of the same launch: they are a ping-pong pair (read half it&1, write the other)
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     const int n_vec2 = (n_vecblk + 1) >> 1;
     const int n_vec8 = ((n_vec2 + 7) >> 3) << 3;
     const bool row_wg = (int)blockIdx.x < n_vec8;
-    const int pair = row_wg ? xcd_tile(blockIdx.x, n_vec2) * BLK + tid : 0;
-    const bool has_rows = row_wg && 2 * pair < P.n_rows;
+    const int pair = row_wg ? P.sh_vb0 * (BLK / 2) + xcd_tile(blockIdx.x, n_vec2) * BLK + tid : 0;
+    const bool has_rows = row_wg && 2 * pair < (P.sh_vb0 + n_vecblk) * BLK;
     const size_t o = 6 * (size_t)pair;
     double uu[6], pp[6], ww[6], ss[6], rr[6], xx[6], Di[12];
     if (has_rows) {
@@ -1079,31 +1080,40 @@ __global__ __launch_bounds__(BLK) void k_apply(Dev P, double lam, const Pose* __
                                                const double* __restrict__ xl_in, Pose* pose_out, double* xl_out) {
     __shared__ double lds[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * BLK + tid;
+    const int i = (P.sh_vb0 + blockIdx.x) * BLK + tid;             // row (own range); poses below: every rank, all of them
     double sc[1] = {0};
     if (i < P.n_rows) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int j = 3 * i + k;
+            const size_t j = 3 * (size_t)i + k;
             const double x = P.xv[j];
             xl_out[j] = xl_in[j] + x;
             sc[0] += x * (lam * x + P.bl[j]);
         }
     }
-    if (i < P.K) {
+    if ((int)(blockIdx.x * BLK + tid) < P.K) {
+        const int i = blockIdx.x * BLK + tid;
         Pose Tcw = pose_in[i];
         if (!P.pose_fixed[i]) {
             double upd[6];
             for (int a = 0; a < 6; ++a) {
                 upd[a] = P.xp[6 * i + a];
-                sc[0] += upd[a] * (lam * upd[a] + P.bp[6 * i + a]);
+                if (P.sh_lead) sc[0] += upd[a] * (lam * upd[a] + P.bp[6 * i + a]);
             }
             pose_oplus(Tcw, upd);
         }
         pose_out[i] = Tcw;
     }
     block_sum<1>(sc, lds, lane, wave);
-    if (tid == 0) P.part_apply[blockIdx.x] = sc[0];
+    if (tid == 0) P.part_apply[P.sh_vb0 + blockIdx.x] = sc[0];
+}
+
+// sharded download: a rank's own rows, zeros elsewhere (summed over the ranks afterwards)
+__global__ void k_mask_rows(Dev P, const double* __restrict__ in, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= 3 * (size_t)P.n_rows) return;
+    const size_t lo = 3 * (size_t)P.sh_vb0 * BLK, hi = 3 * (size_t)(P.sh_vb0 + P.sh_nvb) * BLK;
+    out[i] = (i >= lo && i < hi) ? in[i] : 0.0;
 }
 
 // =====================================================================================

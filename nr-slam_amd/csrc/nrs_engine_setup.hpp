@@ -82,6 +82,9 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
     d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
     d.red = A.get<double>(4 + 6 * K);
+    d.red_loc = A.get<double>(4 + 6 * K);
+    d.pk = A.get<double>(2 + 8 + 27 * K);
+    d.pk_loc = A.get<double>(2 + 8 + 27 * K);
     d.part_ru = A.get<double>(d.ecd ? 2 * (size_t)d.n_vecblk : 1);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
@@ -148,6 +151,22 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
     NRS_TRY(h2d(c, d.rflag, e->h_rflag));
     NRS_TRY(h2d(c, d.pose_fixed, e->h_pose_fixed));
     return NRS_OK;
+}
+
+// Contiguous keyframe ranges for `world` ranks, balanced by padded rows, every rank at least one
+// keyframe: kb[r] .. kb[r+1] are rank r's keyframes.  grp_ptr[k] = first ROW_ALIGN group of keyframe k.
+void shard_plan(int K, const int* grp_ptr, int world, int* kb) {
+    const int total = grp_ptr[K];
+    kb[0] = 0;
+    for (int r = 1; r < world; ++r) {
+        const int64_t want = (int64_t)total * r / world;
+        int k = kb[r - 1] + 1;                                     // at least one keyframe for rank r-1 ...
+        while (k < K - (world - r) && grp_ptr[k] < want) ++k;      // ... and for every rank that follows
+        // the boundary closest to the ideal split
+        if (k - 1 > kb[r - 1] && want - grp_ptr[k - 1] < grp_ptr[k] - want) --k;
+        kb[r] = k;
+    }
+    kb[world] = K;
 }
 
 int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
@@ -417,6 +436,42 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 12 * (size_t)d.n_regblk + 16 * CO_MAX);
     d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && fused_shm <= 63 * 1024 &&
                 !getenv("NRS_NO_COARSE")) ? 1 : 0;
+    // ---- shard window: the whole problem, or this rank's contiguous range of poses (balanced by rows)
+    d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;
+    d.sh_k0 = 0; d.sh_nk = s.K; d.sh_g0 = 0; d.sh_ng = d.n_groups; d.sh_vb0 = 0; d.sh_nvb = d.n_vecblk;
+    for (int cls = 0; cls < 2; ++cls) { d.sh_t0[cls] = 0; d.sh_nt[cls] = d.n_tiles_cls[cls]; }
+    if (c->comm) {
+        const int W = c->comm->world, rk = c->comm->rank;
+        if (W > 8) return c->fail(NRS_ERR_INVALID, "sharded solve: at most 8 ranks");
+        if (s.K < W) return c->fail(NRS_ERR_INVALID, "sharded solve: %d keyframes cannot be split over %d ranks", s.K, W);
+        if (!d.use_lds) return c->fail(NRS_ERR_INVALID, "sharded solve: the graph's halo does not fit the LDS-staged path");
+        std::vector<int> kb(W + 1);
+        shard_plan(s.K, pose_grp_ptr.data(), W, kb.data());
+        d.sh_on = 1; d.sh_rank = rk; d.sh_world = W; d.sh_lead = rk == 0;
+        d.sh_k0 = kb[rk]; d.sh_nk = kb[rk + 1] - kb[rk];
+        d.sh_g0 = pose_grp_ptr[kb[rk]]; d.sh_ng = pose_grp_ptr[kb[rk + 1]] - d.sh_g0;
+        d.sh_vb0 = d.sh_g0 * (ROW_ALIGN / BLK); d.sh_nvb = d.sh_ng * (ROW_ALIGN / BLK);
+        if ((int64_t)d.sh_nvb * BLK < s.K) return c->fail(NRS_ERR_INVALID, "sharded solve: shard smaller than the pose count");
+        const int tb0 = d.sh_g0 * (ROW_ALIGN / d.tile_rows), tb1 = (d.sh_g0 + d.sh_ng) * (ROW_ALIGN / d.tile_rows);
+        for (int cls = 0; cls < 2; ++cls) {                       // tile_list is ascending inside a class
+            const int* tl = tile_list.data() + (cls ? d.n_tiles_cls[0] : 0);
+            const int n = d.n_tiles_cls[cls];
+            const int a = (int)(std::lower_bound(tl, tl + n, tb0) - tl), b2 = (int)(std::lower_bound(tl, tl + n, tb1) - tl);
+            d.sh_t0[cls] = a; d.sh_nt[cls] = b2 - a;
+        }
+        // everything the own tiles reference must be owned or lie in the keyframe next to the range
+        const int r_lo = (kb[rk] > 0 ? pose_grp_ptr[kb[rk] - 1] : d.sh_g0) * ROW_ALIGN;
+        const int r_hi = (kb[rk + 1] < s.K ? pose_grp_ptr[kb[rk + 1] + 1] : d.sh_g0 + d.sh_ng) * ROW_ALIGN;
+        for (int b = tb0; b < tb1; ++b)
+            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i)
+                if (halo_rows[i] < r_lo || halo_rows[i] >= r_hi)
+                    return c->fail(NRS_ERR_INVALID, "sharded solve: an edge of keyframe range [%d, %d) reaches beyond the adjacent keyframes", kb[rk], kb[rk + 1]);
+        HaloPlan& h = e->halo;
+        auto rows_of = [&](int k, size_t& off, size_t& n) { off = 3 * (size_t)pose_grp_ptr[k] * ROW_ALIGN; n = 3 * (size_t)(pose_grp_ptr[k + 1] - pose_grp_ptr[k]) * ROW_ALIGN; };
+        if (rk > 0) { rows_of(kb[rk], h.lo_send, h.lo_send_n); rows_of(kb[rk] - 1, h.lo_recv, h.lo_recv_n); }
+        if (rk < W - 1) { rows_of(kb[rk + 1] - 1, h.hi_send, h.hi_send_n); rows_of(kb[rk + 1], h.hi_recv, h.hi_recv_n); }
+        d.fused = 0; d.coarse = 0; d.ecd = 0; d.hier = 1;
+    }
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
@@ -530,6 +585,13 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, e->t_d0, e->sp_d0));
     NRS_TRY(h2d(c, e->t_w, e->dm_w));
     NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
+    if (d.sh_on) {                                                // slots of other ranks' tiles are never written: zero for good
+        NRS_HIP(c, hipMemsetAsync(d.part_lin, 0, sizeof(double) * 32 * (size_t)d.n_groups, c->stream));
+        NRS_HIP(c, hipMemsetAsync(d.part_reg, 0, sizeof(double) * 2 * (size_t)d.n_regblk, c->stream));
+        NRS_HIP(c, hipMemsetAsync(d.part_spmv, 0, sizeof(double) * NPART * (size_t)d.n_regblk, c->stream));
+        NRS_HIP(c, hipMemsetAsync(d.red, 0, sizeof(double) * (4 + 6 * (size_t)d.K), c->stream));
+        NRS_HIP(c, hipMemsetAsync(d.red_loc, 0, sizeof(double) * (4 + 6 * (size_t)d.K), c->stream));
+    }
     NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     mark("uploads enqueued");

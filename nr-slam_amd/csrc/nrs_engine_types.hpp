@@ -105,6 +105,16 @@ struct Dev {
     double* scal;
     double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
+    // shard window (multi-GPU): the layout is the whole problem on every rank, a rank
+    // launches the row kernels over its own contiguous range of poses only.  Unsharded: the full ranges.
+    int sh_on, sh_rank, sh_world;
+    int sh_lead;                     // this rank counts the pose-level terms of replicated sums (rank 0)
+    int sh_k0, sh_nk;                // poses
+    int sh_g0, sh_ng;                // ROW_ALIGN groups
+    int sh_vb0, sh_nvb;              // BLK-row vector blocks
+    int sh_t0[2], sh_nt[2];          // per tile class: first entry (relative to the class) and count in tile_list
+    double* red_loc;                 // this rank's SpMV sums before the all-reduce into red
+    double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
@@ -118,6 +128,7 @@ struct Engine {
     bool first_trial_accepted = false;   // outcome of the first trial of the previous LM iteration
     double* h_scal = nullptr;        // pinned host mirrors
     int* h_flags = nullptr;
+    HaloPlan halo;                   // sharded: boundary-keyframe rows exchanged with rank-1 / rank+1 (offsets in doubles)
     std::vector<int> vrow;           // vertex -> row
     // host copies needed to rewrite masks and to run the edge taps
     std::vector<int> sp_ij, dm_idx, un_ij;

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("NRS_LIB") or os.path.join(os.path.dirname(_HERE), "li
 
 OK = 0
 STATUS_NAMES = {0: "NRS_OK", -1: "NRS_ERR_INVALID", -2: "NRS_ERR_NO_DEVICE", -3: "NRS_ERR_HIP",
-                -4: "NRS_ERR_ALLOC", -5: "NRS_ERR_STATE", -6: "NRS_ERR_NUMERIC"}
+                -4: "NRS_ERR_ALLOC", -5: "NRS_ERR_STATE", -6: "NRS_ERR_NUMERIC", -7: "NRS_ERR_COMM"}
+COMM_ID_BYTES = 128
 
 # every symbol include/nrs.h declares (tests check that the library exports all of them)
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
@@ -23,7 +24,9 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
-           "nrs_klt_insert_templates"]
+           "nrs_klt_insert_templates",
+           "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
+           "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local"]
 
 
 class NrsError(RuntimeError):
@@ -81,7 +84,47 @@ def load_library(path=LIB_PATH):
     lib.nrs_last_error.restype = C.c_char_p
     lib.nrs_stream.restype = C.c_void_p
     lib.nrs_destroy.restype = None
+    lib.nrs_local_group_destroy.restype = None
+    lib.nrs_local_group_destroy.argtypes = [C.c_void_p]
+    lib.nrs_comm_init_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     return lib
+
+
+def comm_unique_id(lib=None):
+    """RCCL unique id (bytes) made on rank 0; the caller broadcasts it (torch.distributed, MPI, a file ...)."""
+    lib = lib or load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib.nrs_comm_unique_id(buf, C.c_int32(COMM_ID_BYTES))
+    if rc != OK:
+        raise NrsError(rc, "nrs_comm_unique_id (is librccl loadable?)")
+    return bytes(buf)
+
+
+def shard_plan(n_kf, lm_kf, world, lib=None):
+    """Keyframe ranges of a sharded BA window (host only)."""
+    lib = lib or load_library()
+    lm_kf = _i32(lm_kf)
+    kb = np.zeros(world + 1, np.int32)
+    rc = lib.nrs_shard_plan(C.c_int32(n_kf), C.c_int32(len(lm_kf)), _p(lm_kf, C.c_int32), C.c_int32(world), _p(kb, C.c_int32))
+    if rc != OK:
+        raise NrsError(rc, "nrs_shard_plan")
+    return kb
+
+
+class LocalGroup:
+    """Test harness: `world` ranks as threads of this process, contexts on the same GPU (include/nrs.h)."""
+    def __init__(self, world, lib=None):
+        self.lib = lib or load_library()
+        self.world = world
+        self.h = C.c_void_p()
+        rc = self.lib.nrs_local_group_create(C.c_int32(world), C.byref(self.h))
+        if rc != OK:
+            raise NrsError(rc, "nrs_local_group_create")
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_local_group_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def _p(a, t):
@@ -192,6 +235,18 @@ class Context:
     def _chk(self, rc):
         if rc != OK:
             raise NrsError(rc, self.lib.nrs_last_error(self.h).decode())
+
+    def comm_init_rccl(self, world, rank, uid):
+        buf = (C.c_uint8 * len(uid)).from_buffer_copy(uid)
+        self._chk(self.lib.nrs_comm_init_rccl(self.h, C.c_int32(world), C.c_int32(rank), buf, C.c_int32(len(uid))))
+
+    def comm_init_local(self, group, rank):
+        self._chk(self.lib.nrs_comm_init_local(self.h, group.h, C.c_int32(rank)))
+
+    def comm_rank(self):
+        r, w = C.c_int32(0), C.c_int32(1)
+        self._chk(self.lib.nrs_comm_rank(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -111,3 +111,46 @@ def test_frame_loop_harness_with_the_oracle_backend():
     # SE3f algebra of the motion model: T * T^-1 = identity to float accuracy
     q, t = FL.se3f_mul(loop.pose, FL.se3f_inv(loop.pose))
     assert np.allclose(q, [0, 0, 0, 1], atol=1e-6) and np.allclose(t, 0, atol=1e-5)
+
+
+@pytest.mark.parametrize("counts,world", [([300] * 8, 2), ([300] * 8, 8), ([100, 900, 100, 100, 2000, 10, 10], 3),
+                                          ([5] * 5, 5), ([4000, 1, 1, 1], 4), ([256, 257, 512, 1, 700, 90], 1)])
+def test_shard_plan_partitions_keyframes(lib_built, counts, world):
+    """nrs_shard_plan (host only): contiguous keyframe ranges that cover the window, every rank at least
+    one keyframe, and no rank's padded row count further from the ideal share than its largest
+    neighbouring keyframe (boundaries are the closest keyframe boundary to the ideal split)."""
+    nrs = lib_built
+    lm_kf = np.repeat(np.arange(len(counts)), counts).astype(np.int32)
+    kb = nrs.shard_plan(len(counts), lm_kf, world)
+    assert kb[0] == 0 and kb[-1] == len(counts) and np.all(np.diff(kb) >= 1)
+    rows = np.array([max(1, -(-c // 256)) for c in counts])
+    cum = np.concatenate([[0], np.cumsum(rows)])
+    for r in range(1, world):
+        ideal = cum[-1] * r // world
+        k = kb[r]
+        forced_lo, forced_hi = kb[r - 1] + 1, len(counts) - (world - r)
+        # a better boundary would have to be allowed by the "one keyframe per rank" rule
+        for alt in (k - 1, k + 1):
+            if forced_lo <= alt <= forced_hi:
+                assert abs(cum[k] - ideal) <= abs(cum[alt] - ideal) or alt == k + 1 and cum[k] >= ideal
+    assert nrs.shard_plan(3, np.zeros(0, np.int32), 3).tolist() == [0, 1, 2, 3]
+
+
+def test_shard_plan_rejects_bad_arguments(lib_built):
+    nrs = lib_built
+    with pytest.raises(nrs.NrsError):
+        nrs.shard_plan(2, np.array([0, 1], np.int32), 3)          # more ranks than keyframes
+    with pytest.raises(nrs.NrsError):
+        nrs.shard_plan(2, np.array([0, 2], np.int32), 2)          # keyframe index out of range
+
+
+def test_comm_needs_a_context(lib_built):
+    """The communicator entry points take a context; with a null context they fail cleanly (no device needed)."""
+    nrs = lib_built
+    lib = nrs.load_library()
+    assert lib.nrs_comm_init_local(None, None, 0) == -1
+    assert lib.nrs_comm_init_rccl(None, 1, 0, None, 0) == -1
+    g = nrs.LocalGroup(2)
+    g.close()
+    with pytest.raises(nrs.NrsError):
+        nrs.LocalGroup(9)
