@@ -7,9 +7,13 @@ BASELINE.json configs[1]: 5k map points x 20 keyframes (pinhole), every point a 
 node (parity mode).  Inputs are uploaded to HBM once, outside the timed
 region; each timed step is {reset estimates (device-to-device), optimize(5)}.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank solves its own,
-independent BA window of the same size (weak scaling, no data-path collective -- DESIGN.md
-"Multi-GPU"); ranks are bracketed by a barrier and the slowest rank's time is used.
+N > 1 (launched by torch.distributed.run, one rank per GPU): `value` is measured with every rank
+solving its own, independent BA window of the same size (weak scaling over independent windows, no
+data-path collective -- DESIGN.md "Multi-GPU"); ranks are bracketed by a barrier and the slowest
+rank's time is used.  After that the same line gets a "sharded" object: ONE window of C2's points
+x 20*N keyframes split over the N ranks by keyframes (include/nrs.h "multi-GPU": RCCL all-reduce of
+the pose blocks / PCG sums + boundary-keyframe exchange per iteration), run by one child process
+per rank so that a failure of that path cannot take the benchmark line with it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -148,6 +152,101 @@ def tracked_fps(n_points=5000, frames=5):
                 lm_trials_per_frame=trials / nf, pcg_iters_per_frame=inner / nf)
 
 
+def flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def sharded_child(a):
+    """One rank of the sharded window (no torch in this process: ctypes + librccl only).  Prints one
+    JSON line with this rank's timing; the parent ranks reduce them."""
+    import nrs
+    import nrs_synth as S
+    n_points, n_kf, seed, model = S.CONFIGS[a.workload]
+    p = S.make_dba_problem(n_points, n_kf * a.sh_world, seed, model)       # the same window on every rank
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx = nrs.Context(device=a.sh_device)
+    ctx.comm_init_rccl(a.sh_world, a.sh_rank, bytes.fromhex(a.sh_uid))
+    t_up = time.perf_counter()
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    t_up = time.perf_counter() - t_up
+    for _ in range(a.warmup):
+        ctx.dba_reset()
+        ctx.dba_optimize(5)                  # collective: the ranks leave it together
+    t0 = time.perf_counter()
+    lm_iters = trials = inner = 0
+    for _ in range(a.steps):
+        ctx.dba_reset()
+        tr = nrs.Trace(64)
+        ctx.dba_optimize(5, tr)
+        lm_iters += tr.iterations
+        trials += tr.c.count
+        inner += sum(t["inner"] for t in tr.trials)
+    dt = time.perf_counter() - t0
+    kb = nrs.shard_plan(n_kf * a.sh_world, p["lm_kf"], a.sh_world)
+    ctx.close()
+    flush_c_stdio()
+    print(json.dumps(dict(dt=dt, lm_iters=lm_iters, trials=trials, inner=inner, upload_s=t_up, n_kf=n_kf * a.sh_world,
+                          landmarks=len(p["lm_kf"]), springs=len(e["sp_ij"]), dampers=len(e["dm_idx"]),
+                          keyframes_of_rank=[int(kb[a.sh_rank]), int(kb[a.sh_rank + 1])])), flush=True)
+
+
+def run_sharded(args, dist, rank, world, local_rank, timeout_s=300):
+    """All parent ranks: start this rank's child of the sharded window, collect its line.  Returns the
+    "sharded" object on rank 0 (an {"error": ...} object if any rank's child failed or timed out)."""
+    import subprocess
+    import torch
+    import nrs
+    dev = "cuda" if torch.cuda.is_available() else "cpu"     # cpu: the gloo test of this bookkeeping
+    uid = torch.zeros(nrs.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        try:
+            uid = torch.tensor(list(nrs.comm_unique_id()), dtype=torch.uint8, device=dev)
+        except Exception as ex:                                # librccl not loadable: the children fail, nobody hangs
+            print("[bench] no RCCL unique id: %r" % (ex,), file=sys.stderr)
+    dist.broadcast(uid, src=0)
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--workload", args.workload,
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--sh-world", str(world), "--sh-rank", str(rank),
+           "--sh-device", str(local_rank), "--sh-uid", bytes(uid.cpu().tolist()).hex()]
+    res, err = None, None
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            err = "rank %d: exit %d: %s" % (rank, r.returncode, r.stderr.strip()[-300:])
+        else:
+            res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # (RCCL prints a banner on stdout)
+    except subprocess.TimeoutExpired:
+        err = "rank %d: no result after %d s" % (rank, timeout_s)
+    except Exception as ex:                                   # malformed output etc.
+        err = "rank %d: %r" % (rank, ex)
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1.0:
+        return {"error": err or "another rank's child failed"} if rank == 0 else None
+    dt, _ = reduce_over_ranks(dist, res["dt"], 0.0, dev)
+    if rank != 0:
+        return None
+    it_s = res["lm_iters"] / dt
+    return {"workload": "ONE window: %d map points x %d keyframes (= %d x C2's keyframes), keyframes split over %d ranks"
+                        % (S_points(args.workload), res["n_kf"], world, world),
+            "exchange": "RCCL: per linearisation all-reduce of H_pp/b_p/chi2 (27 K + 10 doubles) + boundary-keyframe rows; "
+                        "per PCG iteration boundary rows of u + all-reduce of 3 + 6 K doubles",
+            "lm_iters_per_s": it_s, "c2_windows_equivalent_iters_per_s": it_s * world, "ms_per_step": 1e3 * dt / args.steps,
+            "lm_trials_per_step": res["trials"] / args.steps, "pcg_iters_per_step": res["inner"] / args.steps,
+            "us_per_pcg_iter_incl_lm": 1e6 * dt / max(1, res["inner"]),
+            "landmarks": res["landmarks"], "springs": res["springs"], "dampers": res["dampers"], "upload_s": res["upload_s"]}
+
+
+def S_points(workload):
+    import nrs_synth as S
+    return S.CONFIGS[workload][0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,14 +254,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-window measurement")
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--sh-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--sh-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sh-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sh-uid", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sharded_child:
+        return sharded_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
-    if world > 1:
+    if world > 1 or os.environ.get("NRS_BENCH_FORCE_DIST"):   # (the switch: plumbing check of the N > 1 path on a 1-GPU box)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl")
@@ -249,11 +356,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx=ctx)
     ctx.close()
+    if dist is not None and not args.no_sharded:
+        dist.barrier()
+        sh = run_sharded(args, dist, rank, world, local_rank)
+        if rank == 0:
+            out["sharded"] = sh
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        flush_c_stdio()                      # RCCL's start-up banner sits in the C stdio buffer: the JSON line comes last
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,44 @@ def test_two_rank_reduction_and_seeding():
     assert res[0][3] != res[1][3]                 # every rank solves its own window
 
 
+def _worker_sharded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd", "py"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import bench
+    args = argparse.Namespace(workload="C2", steps=1, warmup=0)
+    sh = bench.run_sharded(args, dist, rank, world, rank, timeout_s=120)
+    dist.barrier()
+    q.put((rank, sh))
+    dist.destroy_process_group()
+
+
+def test_sharded_window_bookkeeping_without_gpu():
+    """bench.run_sharded on two gloo ranks of a box without a GPU: the unique id is broadcast, every rank
+    starts its child, the children fail (no HIP device: there is no CPU fallback), every rank learns that
+    through the MIN all-reduce and rank 0 gets an error object instead of a hang or a crash."""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    assert isinstance(res[0], dict) and "error" in res[0] and "rank 0" in res[0]["error"]
+
+
 def test_single_process_passthrough():
     sys.path.insert(0, ROOT)
     import bench
