@@ -156,6 +156,25 @@ int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_s
                       double* r_damper /* n_damper x 3 */);
 int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
 
+/* ---- f3: ShiTomasi (modules/features/shi_tomasi.{h,cc}) + Tracking::ExtractFeatures (tracking.cc:118-134) --
+ * nrs_shi_configure = ShiTomasi::ShiTomasi(Options) (shi_tomasi.cc:29-31): a fresh extractor (zeroed
+ * buffers on first use, feature ids from 0).  nrs_shi_extract = ShiTomasi::Extract (shi_tomasi.cc:38-54)
+ * followed by the caller's mask filter: prev_xy are the keypoints the frame already holds (their score
+ * cells are set to -1, shi_tomasi.cc:93-96; they are not returned), out = the NEW keypoints in the
+ * reference's row-major order with their class ids (ids are consumed before the mask drops points).
+ * The extractor is stateful exactly like the reference object: gradient and score buffers persist
+ * between calls (reallocated, zeroed, only when the image size changes) and the reference's single pass
+ * leaves some cells to the next call.  width >= height >= 5 is required: the reference's
+ * first / last row loops run their column index to rows-1 (shi_tomasi.cc:187,336).
+ * *n_out = number of keypoints found; if it exceeds capacity only the first `capacity` were written. */
+int nrs_shi_configure(nrs_ctx* ctx, int32_t nms_window /* Options::non_max_suprresion_window_size, default 5 */);
+int nrs_shi_extract(nrs_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                    const uint8_t* mask /* nullable: keep points where mask != 0 */, int32_t mask_stride,
+                    int32_t n_prev, const float* prev_xy /* n_prev x 2 */,
+                    int32_t capacity, float* out_xy /* capacity x 2 */, int32_t* out_id /* capacity */, int32_t* n_out);
+/* parity tap: the extractor's buffers after the last call (h x w each, any pointer may be null) */
+int nrs_shi_buffers(nrs_ctx* ctx, float* scores, int16_t* xgrad, int16_t* ygrad);
+
 /* ---- multi-GPU: one deformable-BA window sharded over the GPUs of a node ---------
  * The reference solves LocalDeformableBundleAdjustment (g2o_optimization.cc:880-1161) as one g2o graph
  * in one thread; there is no reference interface for this -- it is the build's own extension of a3.

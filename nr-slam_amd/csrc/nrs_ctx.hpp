@@ -18,6 +18,7 @@ struct DevBuf {
 
 struct Engine;       // nrs_engine.hip
 struct KltState;     // nrs_klt.hip
+struct ShiState;     // nrs_shi.hip
 
 // Exchange steps of a sharded solve (nrs_comm.hip): one process per GPU, every call is ordered on the
 // context's stream.  Two primitives are all the engine needs:
@@ -48,6 +49,7 @@ struct nrs_ctx {
     nrs::Engine* dba = nullptr;
     nrs::Arena arena_dba, arena_trk;
     nrs::KltState* klt = nullptr;
+    nrs::ShiState* shi = nullptr;
     nrs::Comm* comm = nullptr;       // set by nrs_comm_init_*: BA problems uploaded afterwards are sharded over its ranks
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
@@ -95,4 +97,5 @@ namespace nrs {
 void dba_free(nrs_ctx* ctx);
 void comm_free(nrs_ctx* ctx);
 void klt_free(nrs_ctx* ctx);
+void shi_free(nrs_ctx* ctx);
 }

@@ -63,6 +63,7 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     ba_constants(s, scale);
     s.delta_pos = 0.0;                  // no robust kernel on the BA springs (OPT:1057-1071)
     s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
+    s.shard = true;                     // with a communicator on the context: one window over its ranks (include/nrs.h)
     return engine_create(c, s, &c->arena_dba, &c->dba);
 }
 

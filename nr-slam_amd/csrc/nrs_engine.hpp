@@ -42,6 +42,7 @@ struct EngineSpec {
     double info_reproj = 0, delta_reproj = 0, info_pos = 0, delta_pos = 0, info_spatial = 0, delta_spatial = 0;
     double k_spring = 0;
     int spring_form = 0;                  // 0: BA Jacobian as written, 1: tracking form
+    bool shard = false;                   // split the poses over the ranks of the context's communicator (BA windows only)
 };
 
 struct Engine;

@@ -440,7 +440,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;
     d.sh_k0 = 0; d.sh_nk = s.K; d.sh_g0 = 0; d.sh_ng = d.n_groups; d.sh_vb0 = 0; d.sh_nvb = d.n_vecblk;
     for (int cls = 0; cls < 2; ++cls) { d.sh_t0[cls] = 0; d.sh_nt[cls] = d.n_tiles_cls[cls]; }
-    if (c->comm) {
+    if (c->comm && s.shard) {
         const int W = c->comm->world, rk = c->comm->rank;
         if (W > 8) return c->fail(NRS_ERR_INVALID, "sharded solve: at most 8 ranks");
         if (s.K < W) return c->fail(NRS_ERR_INVALID, "sharded solve: %d keyframes cannot be split over %d ranks", s.K, W);

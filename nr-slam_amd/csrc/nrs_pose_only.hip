@@ -362,6 +362,7 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     nrs::dba_free(c);
     nrs::klt_free(c);
+    nrs::shi_free(c);
     nrs::comm_free(c);
     if (c->pin_scal) (void)hipHostFree(c->pin_scal);
     if (c->pin_flags) (void)hipHostFree(c->pin_flags);

@@ -25,6 +25,7 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
            "nrs_klt_insert_templates",
+           "nrs_shi_configure", "nrs_shi_extract", "nrs_shi_buffers",
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local"]
 
@@ -235,6 +236,34 @@ class Context:
     def _chk(self, rc):
         if rc != OK:
             raise NrsError(rc, self.lib.nrs_last_error(self.h).decode())
+
+    # ---- f3: Shi-Tomasi extraction
+    def shi_configure(self, nms_window=5):
+        self._chk(self.lib.nrs_shi_configure(self.h, C.c_int32(nms_window)))
+
+    def shi_extract(self, img, prev_xy=None, mask=None, capacity=65536):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        prev = None if prev_xy is None or len(prev_xy) == 0 else _f32(np.asarray(prev_xy).reshape(-1, 2))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        xy = np.zeros((capacity, 2), np.float32)
+        ids = np.zeros(capacity, np.int32)
+        n = C.c_int32(0)
+        self._chk(self.lib.nrs_shi_extract(self.h, _p(img, C.c_uint8), C.c_int32(w), C.c_int32(h), C.c_int32(w),
+                                           _p(m, C.c_uint8), C.c_int32(w), C.c_int32(0 if prev is None else len(prev)),
+                                           _p(prev, C.c_float), C.c_int32(capacity), _p(xy, C.c_float), _p(ids, C.c_int32),
+                                           C.byref(n)))
+        self._shi_shape = (h, w)
+        k = min(n.value, capacity)
+        return xy[:k].copy(), ids[:k].copy(), n.value
+
+    def shi_buffers(self):
+        h, w = self._shi_shape
+        sc = np.zeros((h, w), np.float32)
+        xg = np.zeros((h, w), np.int16)
+        yg = np.zeros((h, w), np.int16)
+        self._chk(self.lib.nrs_shi_buffers(self.h, _p(sc, C.c_float), _p(xg, C.c_int16), _p(yg, C.c_int16)))
+        return sc, xg, yg
 
     def comm_init_rccl(self, world, rank, uid):
         buf = (C.c_uint8 * len(uid)).from_buffer_copy(uid)

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd", "py"))
 
 import lk_oracle as LK  # noqa: E402
+import shi_oracle as SH  # noqa: E402
 import nrs_oracle as O  # noqa: E402
 import nrs_synth as S  # noqa: E402
 
@@ -77,10 +78,30 @@ def lk():
                         out_xy=xy, out_status=st2, out_good=good, out_ssim=ssim)
 
 
+def shi():
+    """Two successive Extract calls of one extractor (its buffers persist): literal single-pass restatement."""
+    sq = S.make_lk_sequence(10, 105, wh=(160, 120), flow_px=3.0)
+    mask = np.ones((120, 160), np.uint8)
+    mask[:, :12] = 0
+    mask[100:, :] = 0
+    ex = SH.ShiTomasi(5)
+    xy0, id0 = ex.extract(sq["im0"], None, mask, literal=True)
+    keep = xy0[::3]                                        # the frame keeps a third of them; the rest may be found again
+    xy1, id1 = ex.extract(sq["im1"], keep, mask, literal=True)
+    np.savez_compressed(os.path.join(HERE, "shi_160x120.npz"), im0=sq["im0"], im1=sq["im1"], mask=mask, nms=5,
+                        out_xy0=xy0, out_id0=id0, prev1=keep, out_xy1=xy1, out_id1=id1,
+                        out_scores1=ex.scores, out_xg1=ex.Xg, out_yg1=ex.Yg)
+
+
 if __name__ == "__main__":
-    pose_only()
-    dba()
-    track()
-    lk()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        pose_only()
+        dba()
+        track()
+        lk()
+        shi()
     for f in sorted(os.listdir(HERE)):
         print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))

@@ -148,3 +148,37 @@ def test_sharded_rejects_too_many_ranks():
     assert ei.value.code == -1
     c.close()
     group.close()
+
+
+def test_sharded_c2_size(ctx):
+    """The bench window (C2: 92k rows, 2 lanes per row, two-kernel PCG) split over 4 ranks, against the
+    plain solve: same decisions, lambdas and chi2 to 1e-6, same result."""
+    p = S.make_dba_problem("C2")
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    tr = nrs.Trace()
+    ctx.dba_optimize(5, tr)
+    pq0, xyz0 = ctx.dba_download()
+    out = _run_sharded(4, p, e, cam, qt)
+    trials, pq, xyz = out[0][:3]
+    _same_trials(trials, tr.trials)
+    assert np.allclose(pq[:, :4], pq0[:, :4], atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], pq0[:, 4:], atol=1e-5, rtol=0)
+    assert np.allclose(xyz, xyz0, atol=1e-4, rtol=0)
+    assert np.array_equal(out[3][2], out[0][2])
+
+
+def test_sharded_with_two_tile_classes(ctx, monkeypatch):
+    """Tiles with outlier halos run as a second launch with its own LDS size; a rank's share
+    of each class is a sub-range of that class's list."""
+    p, e, cam, qt = _setup(500, 6, 48)
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    tr = nrs.Trace()
+    ctx.dba_optimize(5, tr)
+    pq0, xyz0 = ctx.dba_download()
+    monkeypatch.setenv("NRS_TILE_CUT_PCT", "60")
+    out = _run_sharded(3, p, e, cam, qt)
+    trials, pq, xyz = out[0][:3]
+    _same_trials(trials, tr.trials)
+    assert np.allclose(pq, pq0, atol=1e-5, rtol=0) and np.allclose(xyz, xyz0, atol=1e-4, rtol=0)
