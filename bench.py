@@ -129,7 +129,7 @@ def tracked_fps(n_points=5000, frames=5):
             stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
             return r
         setattr(gb, name, w)
-    for nme in ("klt_track", "pose_only", "track_deform", "reuse_track"):
+    for nme in ("klt_track", "pose_only", "track_deform", "reuse_track", "extract_features"):
         wrap(nme)
     loop = FL.FrameLoop(gb, lambda pc: FL.project_f32(sq["model"], sq["prm"], pc), sq["wh"], sq["scale"], sq["kp0"], sq["X0"],
                         sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0])
@@ -149,6 +149,7 @@ def tracked_fps(n_points=5000, frames=5):
                 tracked_last_frame=int(loop.log[-1]["n_tracked"]),
                 ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,
                 ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * stage.get("reuse_track", 0) / nf,
+                ms_keyframe_extract=1e3 * stage.get("extract_features", 0) / nf, features_2d_last_frame=int(loop.log[-1]["n_2d"]),
                 lm_trials_per_frame=trials / nf, pcg_iters_per_frame=inner / nf)
 
 
@@ -245,6 +246,33 @@ def run_sharded(args, dist, rank, world, local_rank, timeout_s=300):
 def S_points(workload):
     import nrs_synth as S
     return S.CONFIGS[workload][0]
+
+
+def shi_extract_bench(reps=20):
+    """Shi-Tomasi extraction on a 640x480 frame holding 1500 keypoints (host image in,
+    keypoints out: PCIe-inclusive), next to the oracle's per-cell NumPy form on this host (1 core)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nrs
+    import nrs_synth as S
+    import shi_oracle as SH
+    sq = S.make_lk_sequence(10, 5)
+    ctx = nrs.Context()
+    ctx.shi_configure(5)
+    held = ctx.shi_extract(sq["im0"])[0][:1500]
+    ctx.shi_extract(sq["im1"], held)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        xy, _, n = ctx.shi_extract(sq["im1"] if i % 2 else sq["im0"], held)
+    gpu_ms = 1e3 * (time.perf_counter() - t0) / reps
+    ctx.close()
+    ex = SH.ShiTomasi(5)
+    ex.extract(sq["im0"], held)
+    t0 = time.perf_counter()
+    for i in range(3):
+        ex.extract(sq["im1"] if i % 2 else sq["im0"], held)
+    cpu_ms = 1e3 * (time.perf_counter() - t0) / 3
+    return dict(image="640x480", held_keypoints=int(len(held)), new_keypoints=int(n), ms_per_call=gpu_ms,
+                cpu_oracle_ms_per_call=cpu_ms, cpu_kind="port (NumPy closed form, 1 core)")
 
 
 def main():
@@ -353,6 +381,7 @@ def main():
         }
         if world == 1:
             out["tracked_fps"] = tracked_fps()
+            out["shi_extract"] = shi_extract_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx=ctx)
     ctx.close()

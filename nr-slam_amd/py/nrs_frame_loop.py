@@ -6,9 +6,10 @@ cadence (:336-392) -> SetLastFrame.  It only orchestrates: every numerical step 
 *backend* -- `GpuBackend` = the C ABI of libnrs_hip.so through ctypes (one context for the main
 tracker, one for the two-level reuse tracker); the tests plug the oracle in behind the same calls.
 
-Not reproduced (out of the hot-path scope): map initialisation, feature extraction on keyframes
-(the keyframe step keeps the tracked points and refreshes their templates), the mapping thread
-(UpdateTriangulatedPoints, BA on keyframes), visualisation.
+Keyframes extract new Shi-Tomasi features (tracking.cc:350-372): they enter the frame
+as TRACKED observations without a map point and are followed by LK from then on.  Not reproduced (out of
+the hot-path scope): map initialisation, the mapping thread (triangulation of those features,
+UpdateTriangulatedPoints, BA on keyframes), visualisation.
 
 Poses are Sophus::SE3f in the reference: unit quaternion + translation in float32, and so is the
 motion-model algebra here (`se3f_*`)."""
@@ -112,6 +113,10 @@ class GpuBackend:
         xy, st, good, _ = self.ctx_reuse.klt_track(im, pts, np.zeros(len(pts), np.int32), initial_flow=True, min_ssim=min_ssim)
         return xy, st
 
+    def extract_features(self, im, held_xy, mask=None):
+        xy, ids, _ = self.ctx.shi_extract(im, held_xy, mask)
+        return xy, ids
+
     def pose_only(self, uv, X, q, t):
         q2, t2, _ = self.ctx.pose_only_solve(self.cam, uv, X, q, t)
         return q2, t2
@@ -129,7 +134,7 @@ class FrameLoop:
     """State of Tracking + the slice of Map / Frame it touches, on flat arrays."""
 
     def __init__(self, backend, project_f32, wh, scale, kp0, X0, graph, pose_q, pose_t, im0,
-                 klt_min_ssim=0.7, images_to_insert_keyframe=5):
+                 klt_min_ssim=0.7, images_to_insert_keyframe=5, extract_on_keyframes=True):
         self.b, self.project, self.wh, self.scale = backend, project_f32, wh, float(scale)
         n = len(kp0)
         # current frame: slot i observes map point map_index[i]
@@ -144,6 +149,7 @@ class FrameLoop:
         self.last_pose = self.pose
         self.motion = (np.array([0, 0, 0, 1], F32), np.zeros(3, F32))
         self.min_ssim, self.kf_every, self.since_kf = klt_min_ssim, images_to_insert_keyframe, 0
+        self.extract = extract_on_keyframes
         # initial keyframe: klt reference + photometric information of every map point (tracking.cc:201-209)
         self.b.klt_set_reference(im0, self.kp)
         self.templates = self.b.klt_get_templates(n)
@@ -159,18 +165,21 @@ class FrameLoop:
             kf = self.keyframe_insertion(im)
             self.last_pose = self.pose
         self.log.append(dict(pose_q=self.pose[0].copy(), pose_t=self.pose[1].copy(), lost=sorted(int(x) for x in lost),
-                             reused=reused, n_tracked=n3d, keyframe=kf,
+                             reused=reused, n_tracked=n3d, keyframe=kf, n_2d=int((self.status == TRACKED).sum()),
+                             kp_2d=self.kp[self.map_index < 0].copy(),
                              status_by_map=self._status_by_map(), pos_by_map=self._pos_by_map()))
         return n3d >= 10
 
     def _status_by_map(self):
         s = np.full(len(self.map_pos), -1, np.int32)
-        s[self.map_index] = self.status
+        m = self.map_index >= 0                                    # slots without a map point: extracted 2D features
+        s[self.map_index[m]] = self.status[m]
         return s
 
     def _pos_by_map(self):
         p = np.zeros((len(self.map_pos), 3), F32)
-        p[self.map_index] = self.pos
+        m = self.map_index >= 0
+        p[self.map_index[m]] = self.pos[m]
         return p
 
     # ---- tracking.cc:291-333
@@ -180,10 +189,11 @@ class FrameLoop:
         m = self.status == TRACKED_WITH_3D
         q, t = self.b.pose_only(self.kp[m], self.pos[m], self.pose[0].astype(np.float64), self.pose[1].astype(np.float64))
         self.pose = (np.asarray(q, np.float64).astype(F32), np.asarray(t, np.float64).astype(F32))
-        r = self.b.track_deform(self.graph, self.map_pos, self.map_index, self.status, self.kp, self.pos,
+        mm = self.map_index >= 0                                   # the optimisation walks Frame::IndexToMapPointId (OPT:212-236)
+        r = self.b.track_deform(self.graph, self.map_pos, self.map_index[mm], self.status[mm], self.kp[mm], self.pos[mm],
                                 self.pose[0].astype(np.float64), self.pose[1].astype(np.float64), self.scale)
         self.pose = (np.asarray(r["pose_q"], np.float64).astype(F32), np.asarray(r["pose_t"], np.float64).astype(F32))
-        self.pos, self.status = np.asarray(r["f_pos"], F32), np.asarray(r["f_status"], np.int32)
+        self.pos[mm], self.status[mm] = np.asarray(r["f_pos"], F32), np.asarray(r["f_status"], np.int32)
         self.map_pos, self.graph = np.asarray(r["map_pos"], F32), r["graph"]
         self.motion = se3f_mul(self.pose, se3f_inv(self.last_pose))
         return set(int(x) for x in r["lost"])
@@ -192,7 +202,8 @@ class FrameLoop:
     def point_reuse(self, im, lost):
         w, h = self.wh
         in_frame = np.full(len(self.map_pos), -1, np.int64)
-        in_frame[self.map_index] = np.arange(len(self.map_index))
+        has_mp = self.map_index >= 0
+        in_frame[self.map_index[has_mp]] = np.nonzero(has_mp)[0]
         cand = set(lost)
         pc = se3f_act(self.pose, self.map_pos)
         uv = self.project(pc) if len(pc) else np.zeros((0, 2), F32)
@@ -227,15 +238,31 @@ class FrameLoop:
             reused += 1
         return reused
 
-    # ---- tracking.cc:336-392 (without feature extraction)
+    # ---- tracking.cc:336-392
     def keyframe_insertion(self, im):
         if self.since_kf < self.kf_every:
             self.since_kf += 1
             return False
         self.since_kf = 0
-        keep = self.status == TRACKED_WITH_3D                      # KeyFrame(frame) + Frame::SetFromKeyFrame
-        self.kp, self.pos, self.status, self.map_index = self.kp[keep], self.pos[keep], self.status[keep], self.map_index[keep]
+        if self.extract:
+            # ExtractFeaturesInFrame (tracking.cc:374-382): the extractor is told the keypoints the frame
+            # holds (TRACKED_WITH_3D and TRACKED, in slot order); new corners become TRACKED observations
+            held = (self.status == TRACKED_WITH_3D) | (self.status == TRACKED)
+            xy, _ = self.b.extract_features(im, self.kp[held])
+            k = len(xy)
+            self.kp = np.vstack([self.kp, xy]).astype(F32)
+            self.pos = np.vstack([self.pos, np.zeros((k, 3), F32)]).astype(F32)
+            self.status = np.concatenate([self.status, np.full(k, TRACKED, np.int32)]).astype(np.int32)
+            self.map_index = np.concatenate([self.map_index, np.full(k, -1, np.int32)]).astype(np.int32)
+        # KeyFrame(frame) + Frame::SetFromKeyFrame (keyframe.cc:26-55, frame.cc:47-77): the slots with 3D, then
+        # the TRACKED ones; everything else leaves the frame
+        order = np.concatenate([np.nonzero(self.status == TRACKED_WITH_3D)[0], np.nonzero(self.status == TRACKED)[0]])
+        self.kp, self.pos, self.status, self.map_index = self.kp[order], self.pos[order], self.status[order], self.map_index[order]
+        self.pos[self.status == TRACKED] = 0
+        self.map_index[self.status == TRACKED] = -1               # only the 3D slots keep their map point (frame.cc:56-62)
         self.b.klt_set_reference(im, self.kp)
-        for mp, t in zip(self.map_index, self.b.klt_get_templates(len(self.map_index))):
-            self.templates[mp] = t
+        tpl = self.b.klt_get_templates(len(self.map_index))
+        for i, mp in enumerate(self.map_index):                    # Frame::MapPointIdToIndex: slots that have a map point
+            if mp >= 0:
+                self.templates[mp] = tpl[i]
         return True

@@ -6,6 +6,7 @@ import numpy as np
 
 import lk_oracle as LK
 import nrs_oracle as O
+import shi_oracle as SH
 
 F32 = np.float32
 
@@ -63,6 +64,11 @@ class OracleBackend:
             _insert_template(lk, dict(t, xy=np.asarray(p, F32)))
         xy, st, good, _ = lk.track(im, np.asarray(pts, F32).copy(), np.zeros(len(pts), np.int32), initial_flow=True, min_ssim=min_ssim)
         return xy, st
+
+    def extract_features(self, im, held_xy, mask=None):
+        if not hasattr(self, "shi"):
+            self.shi = SH.ShiTomasi(5)
+        return self.shi.extract(im, held_xy, mask)
 
     def pose_only(self, uv, X, q, t):
         q2, t2, _ = O.pose_only_solve(self.model, self.prm, uv, X, q, t)

@@ -42,6 +42,8 @@ def test_frame_loop_matches_oracle_loop(n, frames, seed, model):
         assert np.array_equal(g["status_by_map"], o["status_by_map"]), f
         assert np.allclose(g["pos_by_map"], o["pos_by_map"], atol=2e-4, rtol=0), f
         assert g["n_tracked"] == o["n_tracked"] and g["n_tracked"] > 0.8 * sq["n_points"]
+        assert g["n_2d"] == o["n_2d"] and np.array_equal(g["kp_2d"], o["kp_2d"]), f      # extracted features, then LK: bit-exact
+    assert glog[-1]["n_2d"] > 0                                                           # keyframes did extract new corners
     # and the loop does track the scene: reprojection of the estimated landmarks with the estimated pose
     # lands on the true image positions
     last = glog[-1]
