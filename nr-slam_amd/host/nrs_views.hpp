@@ -125,6 +125,29 @@ public:
                             w.lm_uv.data(), ns, sp.data(), d0.data(), nd, dm.data(), dw.data(), m.scale, iterations, nullptr));
     }
 
+    // ShiTomasi::Extract(const cv::Mat&, std::vector<cv::KeyPoint>&)  features/shi_tomasi.h:45 followed by the
+    // mask filter of Tracking::ExtractFeatures (tracking.cc:118-134): `keypoints` holds the frame's keypoints on
+    // entry and the NEW ones (x, y) on return, `ids` their class ids.  The extractor's buffers live in the context
+    // like the reference object's members; ShiTomasi(Options) = ConfigureShiTomasi.
+    void ConfigureShiTomasi(int non_max_suppression_window = 5) { check(nrs_shi_configure(ctx_, non_max_suppression_window)); }
+    void ExtractFeatures(const uint8_t* im, int w, int h, int stride, const uint8_t* mask, int mask_stride,
+                         std::vector<float>& keypoints, std::vector<int32_t>& ids) {
+        std::vector<float> held = keypoints;
+        int32_t n = 0;
+        std::vector<float> xy(2 * 4096);
+        std::vector<int32_t> id(4096);
+        for (;;) {
+            check(nrs_shi_extract(ctx_, im, w, h, stride, mask, mask_stride, (int32_t)(held.size() / 2), held.data(),
+                                  (int32_t)id.size(), xy.data(), id.data(), &n));
+            if ((size_t)n <= id.size()) break;
+            // truncated: the call has consumed ids and left its marks, like a reference Extract would; a larger
+            // buffer cannot replay it.  4096 new corners per 640x480 keyframe are never reached (31x31 exclusion).
+            throw std::runtime_error("nrs_shi_extract: more keypoints than the shim's buffer");
+        }
+        keypoints.assign(xy.begin(), xy.begin() + 2 * (size_t)n);
+        ids.assign(id.begin(), id.begin() + n);
+    }
+
     nrs_ctx* raw() { return ctx_; }
 
 private:
