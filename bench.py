@@ -90,6 +90,38 @@ def cpu_baseline(seconds_budget=20.0, ctx=None):
             ctx.dba_optimize(5, tr)
             g_it += tr.iterations
         out["gpu_same_sample"] = g_it / (time.perf_counter() - t1)
+    out["tracked_fps"] = cpu_tracked_fps(ctx is not None)
+    return out
+
+
+def cpu_tracked_fps(with_gpu, n_points=600):
+    """The frame loop driven by the oracle (1 core) on a bounded sample: ONE tracked frame of a 640x480
+    sequence with 600 map points (about 10 s; the metric's 4.4k points take minutes per frame in NumPy),
+    and the product path on the very same frames."""
+    import nrs
+    import nrs_frame_loop as FL
+    import nrs_synth as S
+    from frame_loop_backend import OracleBackend
+    sq = S.make_frame_sequence(n_points, 3, 21)
+    opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
+
+    def run(backend, frames):
+        loop = FL.FrameLoop(backend, lambda pc: FL.project_f32(sq["model"], sq["prm"], pc), sq["wh"], sq["scale"], sq["kp0"],
+                            sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0])
+        ts = []
+        for f in frames:
+            t0 = time.perf_counter()
+            loop.track_image(sq["images"][f])
+            ts.append(time.perf_counter() - t0)
+        return ts
+    t = run(OracleBackend(sq["model"], sq["prm"], opts), [1])
+    out = dict(value=1.0 / t[0], unit="frames/s", cores=1, kind="port",
+               sample="1 tracked frame, %d map points, 640x480 (LK + pose-only + pose-and-deformation + point reuse), %.1f s" % (sq["n_points"], t[0]))
+    if with_gpu:
+        gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts)
+        tg = run(gb, [1, 2])
+        gb.close()
+        out["gpu_same_sample"] = 1.0 / tg[0]
     return out
 
 
@@ -106,7 +138,7 @@ def reduce_over_ranks(dist, dt, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def tracked_fps(n_points=5000, frames=5):
+def tracked_fps(n_points=5000, frames=7):
     """Secondary figure of BASELINE.json's metric: tracked frames/s, end to end through the frame-loop
     harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode and
     feature extraction) on a consistent synthetic 640x480 sequence with n_points map points: LK data

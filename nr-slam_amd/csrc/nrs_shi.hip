@@ -159,14 +159,22 @@ __global__ void k_shi_nms(const float* __restrict__ sc, int w, int h, int nms, u
     if (c >= w) return;
     const float cur = sc[(size_t)r * w + c];
     bool ok = !(cur == -1.f) && !(cur < 80.f);                     // a NaN score passes both tests, as in the reference
+    // IsLocalMaximum returns false for a mark anywhere in the 31x31 window OR a larger score in the inner
+    // window; the order of the two scans does not matter: the (small) inner window goes first, it
+    // eliminates all but the local maxima, and only those look at the 961 cells for marks
     if (ok) {
-        const int r0 = max(0, r - 15), r1 = min(h - 1, r + 15), c0 = max(0, c - 15), c1 = min(w - 1, c + 15);
+        const int r0 = max(0, r - nms), r1 = min(h - 1, r + nms), c0 = max(0, c - nms), c1 = min(w - 1, c + nms);
         for (int i = r0; i <= r1 && ok; ++i)
             for (int j = c0; j <= c1; ++j) {
                 const float v = sc[(size_t)i * w + j];
-                if (v == -1.f) { ok = false; break; }
-                if (abs(i - r) <= nms && abs(j - c) <= nms && v > cur) { ok = false; break; }
+                if (v == -1.f || v > cur) { ok = false; break; }
             }
+    }
+    if (ok) {
+        const int r0 = max(0, r - 15), r1 = min(h - 1, r + 15), c0 = max(0, c - 15), c1 = min(w - 1, c + 15);
+        for (int i = r0; i <= r1 && ok; ++i)
+            for (int j = c0; j <= c1; ++j)
+                if (sc[(size_t)i * w + j] == -1.f) { ok = false; break; }
     }
     flags[(size_t)r * w + c] = ok ? 1 : 0;
 }
