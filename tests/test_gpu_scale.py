@@ -47,3 +47,40 @@ def test_c3_operator_paths_agree(ctx, c3, monkeypatch):
     g = _solve(ctx, c3, 2)
     assert [t["accepted"] for t in a[2]] == [t["accepted"] for t in g[2]]
     assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)
+
+
+def test_c3_sharded_over_thread_ranks(ctx, c3):
+    """C3 split over 5 ranks (threads on this one GPU, tests/test_gpu_sharded.py): 10 keyframes per rank,
+    5760+ tiles, the hierarchical reductions -- same LM decisions and result as the plain solve."""
+    import threading
+    p, e, cam, qt = c3
+    ref = _solve(ctx, c3, 3)
+    world = 5
+    group = nrs.LocalGroup(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            c = nrs.Context()
+            c.comm_init_local(group, r)
+            c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+            tr = nrs.Trace(128)
+            c.dba_optimize(3, tr)
+            pq, xyz = c.dba_download()
+            out[r] = (pq, xyz.astype(np.float32), tr.trials)
+            c.close()
+        except Exception as ex:
+            errs.append((r, ex))
+            raise
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs and all(o is not None for o in out), errs
+    group.close()
+    pq, xyz, trials = out[0]
+    assert [t["accepted"] for t in trials] == [t["accepted"] for t in ref[2]]
+    assert all(abs(s["lam"] - t["lam"]) <= 1e-6 * t["lam"] and abs(s["chi"] - t["chi"]) <= 1e-6 * t["chi"] for s, t in zip(trials, ref[2]))
+    assert np.allclose(pq, ref[0], atol=1e-6, rtol=0) and np.allclose(xyz, ref[1], atol=1e-4, rtol=0)
+    assert np.array_equal(out[4][0], pq) and np.array_equal(out[4][1], xyz)
