@@ -198,7 +198,8 @@ def sharded_child(a):
     JSON line with this rank's timing; the parent ranks reduce them."""
     import nrs
     import nrs_synth as S
-    n_points, n_kf, seed, model = S.CONFIGS[a.workload]
+    _, _, seed, model = S.CONFIGS[a.workload]
+    n_points, n_kf = a.sh_points, a.sh_kf
     p = S.make_dba_problem(n_points, n_kf * a.sh_world, seed, model)       # the same window on every rank
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
@@ -229,9 +230,13 @@ def sharded_child(a):
                           keyframes_of_rank=[int(kb[a.sh_rank]), int(kb[a.sh_rank + 1])])), flush=True)
 
 
-def run_sharded(args, dist, rank, world, local_rank, timeout_s=300):
+def run_sharded(args, dist, rank, world, local_rank, timeout_s=300, n_points=None, kf_per_rank=None):
     """All parent ranks: start this rank's child of the sharded window, collect its line.  Returns the
-    "sharded" object on rank 0 (an {"error": ...} object if any rank's child failed or timed out)."""
+    "sharded" object on rank 0 (an {"error": ...} object if any rank's child failed or timed out).
+    Window: n_points map points x kf_per_rank * world keyframes (default: the workload's own size per rank)."""
+    import nrs_synth as S0
+    n_points = n_points or S0.CONFIGS[args.workload][0]
+    kf_per_rank = kf_per_rank or S0.CONFIGS[args.workload][1]
     import subprocess
     import torch
     import nrs
@@ -245,7 +250,8 @@ def run_sharded(args, dist, rank, world, local_rank, timeout_s=300):
     dist.broadcast(uid, src=0)
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--workload", args.workload,
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--sh-world", str(world), "--sh-rank", str(rank),
-           "--sh-device", str(local_rank), "--sh-uid", bytes(uid.cpu().tolist()).hex()]
+           "--sh-device", str(local_rank), "--sh-uid", bytes(uid.cpu().tolist()).hex(),
+           "--sh-points", str(n_points), "--sh-kf", str(kf_per_rank)]
     res, err = None, None
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
@@ -265,19 +271,39 @@ def run_sharded(args, dist, rank, world, local_rank, timeout_s=300):
     if rank != 0:
         return None
     it_s = res["lm_iters"] / dt
-    return {"workload": "ONE window: %d map points x %d keyframes (= %d x C2's keyframes), keyframes split over %d ranks"
-                        % (S_points(args.workload), res["n_kf"], world, world),
+    return {"workload": "ONE window: %d map points x %d keyframes (%d per rank), keyframes split over %d ranks"
+                        % (n_points, res["n_kf"], kf_per_rank, world),
             "exchange": "RCCL: per linearisation all-reduce of H_pp/b_p/chi2 (27 K + 10 doubles) + boundary-keyframe rows; "
                         "per PCG iteration boundary rows of u + all-reduce of 3 + 6 K doubles",
-            "lm_iters_per_s": it_s, "c2_windows_equivalent_iters_per_s": it_s * world, "ms_per_step": 1e3 * dt / args.steps,
+            "lm_iters_per_s": it_s, "per_rank_windows_equivalent_iters_per_s": it_s * world, "ms_per_step": 1e3 * dt / args.steps,
             "lm_trials_per_step": res["trials"] / args.steps, "pcg_iters_per_step": res["inner"] / args.steps,
             "us_per_pcg_iter_incl_lm": 1e6 * dt / max(1, res["inner"]),
             "landmarks": res["landmarks"], "springs": res["springs"], "dampers": res["dampers"], "upload_s": res["upload_s"]}
 
 
-def S_points(workload):
+def single_gpu_reference(ctx_device, workload, n_points, n_kf, steps, warmup):
+    """The per-rank share of a sharded window as a plain single-GPU window (what N = 1 would run)."""
+    import nrs
     import nrs_synth as S
-    return S.CONFIGS[workload][0]
+    _, _, seed, model = S.CONFIGS[workload]
+    p = S.make_dba_problem(n_points, n_kf, seed, model)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    ctx = nrs.Context(device=ctx_device)
+    ctx.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"],
+                   p["lm_uv"], e, p["scale"])
+    for _ in range(warmup):
+        ctx.dba_reset()
+        ctx.dba_optimize(5)
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(steps):
+        ctx.dba_reset()
+        tr = nrs.Trace(64)
+        ctx.dba_optimize(5, tr)
+        its += tr.iterations
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return dict(lm_iters_per_s=its / dt, ms_per_step=1e3 * dt / steps, landmarks=len(p["lm_kf"]))
 
 
 def shi_extract_bench(reps=20):
@@ -320,6 +346,8 @@ def main():
     ap.add_argument("--sh-rank", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sh-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sh-uid", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--sh-points", type=int, default=5000, help=argparse.SUPPRESS)
+    ap.add_argument("--sh-kf", type=int, default=20, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sharded_child:
         return sharded_child(args)
@@ -420,8 +448,14 @@ def main():
     if dist is not None and not args.no_sharded:
         dist.barrier()
         sh = run_sharded(args, dist, rank, world, local_rank)
+        # the same with 2.5x larger shards (10k points x 25 keyframes per rank): where the exchange steps weigh less
+        big_pts, big_kf = 10000, 25
+        sh2 = run_sharded(args, dist, rank, world, local_rank, n_points=big_pts, kf_per_rank=big_kf)
         if rank == 0:
             out["sharded"] = sh
+            if isinstance(sh2, dict) and "error" not in sh2:
+                sh2["single_gpu_same_shard"] = single_gpu_reference(local_rank, args.workload, big_pts, big_kf, args.steps, args.warmup)
+            out["sharded_large_shards"] = sh2
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
