@@ -76,16 +76,16 @@ struct RcclComm : Comm {
         NRS_NCCL(c, api->AllReduce(send, recv, n, ncclDouble, ncclSum, comm, c->stream));
         return NRS_OK;
     }
-    int exchange(nrs_ctx* c, double* v, const HaloPlan& h) override {
+    int exchange(nrs_ctx* c, double* v, const HaloPlan& h, hipStream_t st) override {
         if (world == 1) return NRS_OK;
         NRS_NCCL(c, api->GroupStart());
         if (rank > 0) {
-            NRS_NCCL(c, api->Send(v + h.lo_send, h.lo_send_n, ncclDouble, rank - 1, comm, c->stream));
-            NRS_NCCL(c, api->Recv(v + h.lo_recv, h.lo_recv_n, ncclDouble, rank - 1, comm, c->stream));
+            NRS_NCCL(c, api->Send(v + h.lo_send, h.lo_send_n, ncclDouble, rank - 1, comm, st));
+            NRS_NCCL(c, api->Recv(v + h.lo_recv, h.lo_recv_n, ncclDouble, rank - 1, comm, st));
         }
         if (rank < world - 1) {
-            NRS_NCCL(c, api->Send(v + h.hi_send, h.hi_send_n, ncclDouble, rank + 1, comm, c->stream));
-            NRS_NCCL(c, api->Recv(v + h.hi_recv, h.hi_recv_n, ncclDouble, rank + 1, comm, c->stream));
+            NRS_NCCL(c, api->Send(v + h.hi_send, h.hi_send_n, ncclDouble, rank + 1, comm, st));
+            NRS_NCCL(c, api->Recv(v + h.hi_recv, h.hi_recv_n, ncclDouble, rank + 1, comm, st));
         }
         NRS_NCCL(c, api->GroupEnd());
         return NRS_OK;
@@ -136,15 +136,15 @@ struct LocalComm : Comm {
         NRS_HIP(c, hipMemcpyAsync(recv, tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
         return NRS_OK;
     }
-    int exchange(nrs_ctx* c, double* v, const HaloPlan& h) override {
+    int exchange(nrs_ctx* c, double* v, const HaloPlan& h, hipStream_t st) override {
         if (world == 1) return NRS_OK;
         g->slot[rank] = v;
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        NRS_HIP(c, hipStreamSynchronize(st));
         g->barrier();
         // the layout is the same on every rank: a neighbour's send range is this rank's receive range
-        if (rank > 0) NRS_HIP(c, hipMemcpyAsync(v + h.lo_recv, g->slot[rank - 1] + h.lo_recv, sizeof(double) * h.lo_recv_n, hipMemcpyDeviceToDevice, c->stream));
-        if (rank < world - 1) NRS_HIP(c, hipMemcpyAsync(v + h.hi_recv, g->slot[rank + 1] + h.hi_recv, sizeof(double) * h.hi_recv_n, hipMemcpyDeviceToDevice, c->stream));
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        if (rank > 0) NRS_HIP(c, hipMemcpyAsync(v + h.lo_recv, g->slot[rank - 1] + h.lo_recv, sizeof(double) * h.lo_recv_n, hipMemcpyDeviceToDevice, st));
+        if (rank < world - 1) NRS_HIP(c, hipMemcpyAsync(v + h.hi_recv, g->slot[rank + 1] + h.hi_recv, sizeof(double) * h.hi_recv_n, hipMemcpyDeviceToDevice, st));
+        NRS_HIP(c, hipStreamSynchronize(st));
         g->barrier();
         return NRS_OK;
     }
@@ -153,6 +153,18 @@ struct LocalComm : Comm {
 void comm_free(nrs_ctx* c) {
     delete c->comm;
     c->comm = nullptr;
+    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    if (c->ev_vec) { (void)hipEventDestroy(c->ev_vec); c->ev_vec = nullptr; }
+    if (c->ev_halo) { (void)hipEventDestroy(c->ev_halo); c->ev_halo = nullptr; }
+}
+
+// second stream + the two events that order it against the context's stream (hand-offs are events only)
+static int comm_streams(nrs_ctx* c) {
+    NRS_HIP(c, hipSetDevice(c->device));
+    if (!c->comm_stream) NRS_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    if (!c->ev_vec) NRS_HIP(c, hipEventCreateWithFlags(&c->ev_vec, hipEventDisableTiming));
+    if (!c->ev_halo) NRS_HIP(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    return NRS_OK;
 }
 
 }  // namespace nrs
@@ -188,7 +200,7 @@ extern "C" int nrs_comm_init_rccl(nrs_ctx* c, int32_t world, int32_t rank, const
     ncclResult_t r = api->CommInitRank(&rc->comm, world, u, rank);
     if (r != ncclSuccess) { rc->comm = nullptr; delete rc; return c->fail(NRS_ERR_COMM, "ncclCommInitRank failed: %s", api->GetErrorString(r)); }
     c->comm = rc;
-    return NRS_OK;
+    return comm_streams(c);
 }
 
 extern "C" int nrs_local_group_create(int32_t world, void** group) {
@@ -212,7 +224,7 @@ extern "C" int nrs_comm_init_local(nrs_ctx* c, void* group, int32_t rank) {
     if (!lc) return c->fail(NRS_ERR_ALLOC, "out of host memory");
     lc->g = g; lc->rank = rank; lc->world = g->world;
     c->comm = lc;
-    return NRS_OK;
+    return comm_streams(c);
 }
 
 extern "C" int nrs_comm_rank(const nrs_ctx* c, int32_t* rank, int32_t* world) {

@@ -29,7 +29,7 @@ struct Comm {
     int rank = 0, world = 1;
     virtual ~Comm() {}
     virtual int allreduce(nrs_ctx* c, const double* send, double* recv, size_t n) = 0;
-    virtual int exchange(nrs_ctx* c, double* vec, const HaloPlan& h) = 0;
+    virtual int exchange(nrs_ctx* c, double* vec, const HaloPlan& h, hipStream_t stream) = 0;   // ordered on `stream`
 };
 struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 
@@ -51,6 +51,8 @@ struct nrs_ctx {
     nrs::KltState* klt = nullptr;
     nrs::ShiState* shi = nullptr;
     nrs::Comm* comm = nullptr;       // set by nrs_comm_init_*: BA problems uploaded afterwards are sharded over its ranks
+    hipStream_t comm_stream = nullptr;   // boundary-row exchanges run here, next to the interior tiles on `stream`
+    hipEvent_t ev_vec = nullptr, ev_halo = nullptr;
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
 

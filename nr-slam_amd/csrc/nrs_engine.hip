@@ -111,7 +111,7 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
 static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol2) {
     if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0, it); return; }
     for (int cls = 0; cls < 2; ++cls) {
-        const int n = d.sh_nt[cls];
+        const int n = d.sh_nt[cls] + d.sh_ntb[cls];
         if (n == 0) continue;
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         const dim3 g(((n + 7) / 8) * 8), b(BLK);
@@ -224,9 +224,25 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             }
             continue;
         }
-        // sharded: the operator reads u of the neighbouring ranks' boundary keyframes (dampers)
-        if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.uv3, e->halo));
-        {
+        if (d.sh_on && d.sh_world > 1) {
+            // sharded: the operator reads u of the neighbouring ranks' boundary keyframes (dampers).  The rows
+            // travel on the second stream while the interior tiles run; the boundary tiles follow them.
+            NRS_HIP(c, hipEventRecord(c->ev_vec, c->stream));
+            NRS_HIP(c, hipStreamWaitEvent(c->comm_stream, c->ev_vec, 0));
+            NRS_TRY(c->comm->exchange(c, d.uv3, e->halo, c->comm_stream));
+            NRS_HIP(c, hipEventRecord(c->ev_halo, c->comm_stream));
+            Dev di = d, db = d;
+            for (int cls = 0; cls < 2; ++cls) {
+                di.sh_t0[cls] = d.sh_t0[cls] + d.sh_front[cls];
+                di.sh_nt[cls] = d.sh_nt[cls] - d.sh_front[cls] - d.sh_back[cls];
+                db.sh_nt[cls] = d.sh_front[cls];
+                db.sh_t0b[cls] = d.sh_t0[cls] + d.sh_nt[cls] - d.sh_back[cls];
+                db.sh_ntb[cls] = d.sh_back[cls];
+            }
+            launch_spmv(c, di, lam, it, tol2);
+            NRS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+            launch_spmv(c, db, lam, it, tol2);
+        } else {
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches);
             if (d.hier && d.ecd) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(BLK), 0, c->stream, d, it);
             launch_spmv(c, d, lam, it, tol2);
@@ -305,7 +321,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             auto eval_trial = [&]() -> int {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
                 hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
-                if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo));   // the regularisers read the neighbours' boundary keyframes
+                if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo, c->stream));   // the regularisers read the neighbours' boundary keyframes
                 NRS_TRY(evaluate<false>(c, e, trial));
                 return read_scalars(c, e);                 // one synchronisation: chi2, scale and the PCG flags
             };

@@ -188,9 +188,9 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
-    const int bi = xcd_tile(blockIdx.x, P.sh_nt[cls]);
-    if (bi >= P.sh_nt[cls]) return;
-    const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + bi];
+    const int bi = xcd_tile(blockIdx.x, P.sh_nt[cls] + P.sh_ntb[cls]);
+    if (bi >= P.sh_nt[cls] + P.sh_ntb[cls]) return;
+    const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + (bi < P.sh_nt[cls] ? P.sh_t0[cls] + bi : P.sh_t0b[cls] + bi - P.sh_nt[cls])];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;

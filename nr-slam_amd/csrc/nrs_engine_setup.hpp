@@ -439,7 +439,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // ---- shard window: the whole problem, or this rank's contiguous range of poses (balanced by rows)
     d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;
     d.sh_k0 = 0; d.sh_nk = s.K; d.sh_g0 = 0; d.sh_ng = d.n_groups; d.sh_vb0 = 0; d.sh_nvb = d.n_vecblk;
-    for (int cls = 0; cls < 2; ++cls) { d.sh_t0[cls] = 0; d.sh_nt[cls] = d.n_tiles_cls[cls]; }
+    for (int cls = 0; cls < 2; ++cls) {
+        d.sh_t0[cls] = 0; d.sh_nt[cls] = d.n_tiles_cls[cls];
+        d.sh_t0b[cls] = d.sh_ntb[cls] = d.sh_front[cls] = d.sh_back[cls] = 0;
+    }
     if (c->comm && s.shard) {
         const int W = c->comm->world, rk = c->comm->rank;
         if (W > 8) return c->fail(NRS_ERR_INVALID, "sharded solve: at most 8 ranks");
@@ -466,6 +469,26 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i)
                 if (halo_rows[i] < r_lo || halo_rows[i] >= r_hi)
                     return c->fail(NRS_ERR_INVALID, "sharded solve: an edge of keyframe range [%d, %d) reaches beyond the adjacent keyframes", kb[rk], kb[rk + 1]);
+        // boundary tiles (their halo holds rows of another rank) sit at the two ends of the rank's tile range:
+        // they run after the interior tiles, once the neighbours' rows have arrived
+        const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
+        auto foreign = [&](int b) {
+            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i)
+                if (halo_rows[i] < own_lo || halo_rows[i] >= own_hi) return true;
+            return false;
+        };
+        for (int cls = 0; cls < 2; ++cls) {
+            const int* tl = tile_list.data() + (cls ? d.n_tiles_cls[0] : 0) + d.sh_t0[cls];
+            const int n = d.sh_nt[cls];
+            int first = n, last = -1;                              // first / last own tile of the class that is interior
+            for (int i = 0; i < n; ++i) if (!foreign(tl[i])) { first = i; break; }
+            for (int i = n - 1; i >= 0; --i) if (!foreign(tl[i])) { last = i; break; }
+            if (last < first) { d.sh_front[cls] = n; d.sh_back[cls] = 0; continue; }          // no interior tile at all
+            bool clean = true;                                     // (dampers reach one keyframe: the middle is interior)
+            for (int i = first; i <= last && clean; ++i) clean = !foreign(tl[i]);
+            if (!clean) { d.sh_front[cls] = n; d.sh_back[cls] = 0; continue; }
+            d.sh_front[cls] = first; d.sh_back[cls] = n - 1 - last;
+        }
         HaloPlan& h = e->halo;
         auto rows_of = [&](int k, size_t& off, size_t& n) { off = 3 * (size_t)pose_grp_ptr[k] * ROW_ALIGN; n = 3 * (size_t)(pose_grp_ptr[k + 1] - pose_grp_ptr[k]) * ROW_ALIGN; };
         if (rk > 0) { rows_of(kb[rk], h.lo_send, h.lo_send_n); rows_of(kb[rk] - 1, h.lo_recv, h.lo_recv_n); }

@@ -113,6 +113,11 @@ struct Dev {
     int sh_g0, sh_ng;                // ROW_ALIGN groups
     int sh_vb0, sh_nvb;              // BLK-row vector blocks
     int sh_t0[2], sh_nt[2];          // per tile class: first entry (relative to the class) and count in tile_list
+    // a launch of the operator may cover two pieces of a class list: [sh_t0, sh_t0 + sh_nt) then [sh_t0b, sh_t0b + sh_ntb)
+    // (the boundary tiles at both ends of a rank's range); sh_ntb = 0 otherwise
+    int sh_t0b[2], sh_ntb[2];
+    // of the rank's own tiles in each class: the first sh_front and the last sh_back read rows of other ranks
+    int sh_front[2], sh_back[2];
     double* red_loc;                 // this rank's SpMV sums before the all-reduce into red
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
