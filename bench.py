@@ -230,7 +230,7 @@ def sharded_child(a):
                           keyframes_of_rank=[int(kb[a.sh_rank]), int(kb[a.sh_rank + 1])])), flush=True)
 
 
-def run_sharded(args, dist, rank, world, local_rank, timeout_s=300, n_points=None, kf_per_rank=None):
+def run_sharded(args, dist, rank, world, local_rank, timeout_s=120, n_points=None, kf_per_rank=None):
     """All parent ranks: start this rank's child of the sharded window, collect its line.  Returns the
     "sharded" object on rank 0 (an {"error": ...} object if any rank's child failed or timed out).
     Window: n_points map points x kf_per_rank * world keyframes (default: the workload's own size per rank)."""
@@ -450,7 +450,10 @@ def main():
         sh = run_sharded(args, dist, rank, world, local_rank)
         # the same with 2.5x larger shards (10k points x 25 keyframes per rank): where the exchange steps weigh less
         big_pts, big_kf = 10000, 25
-        sh2 = run_sharded(args, dist, rank, world, local_rank, n_points=big_pts, kf_per_rank=big_kf)
+        ok1 = torch.tensor([1.0 if (rank != 0 or (isinstance(sh, dict) and "error" not in sh)) else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ok1, op=dist.ReduceOp.MIN)               # every rank learns whether the first window worked
+        sh2 = run_sharded(args, dist, rank, world, local_rank, n_points=big_pts, kf_per_rank=big_kf) if ok1.item() > 0 else (
+            {"error": "skipped: the first sharded window failed"} if rank == 0 else None)
         if rank == 0:
             out["sharded"] = sh
             if isinstance(sh2, dict) and "error" not in sh2:
