@@ -205,7 +205,18 @@ def sharded_child(a):
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     ctx = nrs.Context(device=a.sh_device)
-    ctx.comm_init_rccl(a.sh_world, a.sh_rank, bytes.fromhex(a.sh_uid))
+    # the RCCL id is made by the rank-0 CHILD and handed to the others through a file on this node: all
+    # children load the same librccl (the parents' copy, PyTorch's, may be another version)
+    if a.sh_rank == 0:
+        with open(a.sh_uid_file + ".tmp", "wb") as f:
+            f.write(nrs.comm_unique_id())
+        os.replace(a.sh_uid_file + ".tmp", a.sh_uid_file)
+    t_wait = time.perf_counter()
+    while not os.path.exists(a.sh_uid_file):
+        if time.perf_counter() - t_wait > 60:
+            raise RuntimeError("no RCCL id from rank 0 after 60 s")
+        time.sleep(0.01)
+    ctx.comm_init_rccl(a.sh_world, a.sh_rank, open(a.sh_uid_file, "rb").read())
     t_up = time.perf_counter()
     ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
     t_up = time.perf_counter() - t_up
@@ -240,17 +251,21 @@ def run_sharded(args, dist, rank, world, local_rank, timeout_s=120, n_points=Non
     import subprocess
     import torch
     import nrs
+    import tempfile
     dev = "cuda" if torch.cuda.is_available() else "cpu"     # cpu: the gloo test of this bookkeeping
-    uid = torch.zeros(nrs.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    # rendezvous file for the children's RCCL id (one node): rank 0 picks the name, everybody learns it
+    name = torch.zeros(256, dtype=torch.uint8, device=dev)
     if rank == 0:
-        try:
-            uid = torch.tensor(list(nrs.comm_unique_id()), dtype=torch.uint8, device=dev)
-        except Exception as ex:                                # librccl not loadable: the children fail, nobody hangs
-            print("[bench] no RCCL unique id: %r" % (ex,), file=sys.stderr)
-    dist.broadcast(uid, src=0)
+        fd, path = tempfile.mkstemp(prefix="nrs_rccl_id_", suffix=".bin")
+        os.close(fd)
+        os.unlink(path)                                        # the rank-0 child creates it (atomically)
+        raw = path.encode()[:255]
+        name[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+    dist.broadcast(name, src=0)
+    uid_file = bytes(name.cpu().tolist()).rstrip(b"\0").decode()
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--workload", args.workload,
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--sh-world", str(world), "--sh-rank", str(rank),
-           "--sh-device", str(local_rank), "--sh-uid", bytes(uid.cpu().tolist()).hex(),
+           "--sh-device", str(local_rank), "--sh-uid-file", uid_file,
            "--sh-points", str(n_points), "--sh-kf", str(kf_per_rank)]
     res, err = None, None
     try:
@@ -265,6 +280,10 @@ def run_sharded(args, dist, rank, world, local_rank, timeout_s=120, n_points=Non
         err = "rank %d: %r" % (rank, ex)
     ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        for f in (uid_file, uid_file + ".tmp"):
+            if os.path.exists(f):
+                os.unlink(f)
     if ok.item() < 1.0:
         return {"error": err or "another rank's child failed"} if rank == 0 else None
     dt, _ = reduce_over_ranks(dist, res["dt"], 0.0, dev)
@@ -345,7 +364,7 @@ def main():
     ap.add_argument("--sh-world", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--sh-rank", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--sh-device", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--sh-uid", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--sh-uid-file", default="", help=argparse.SUPPRESS)
     ap.add_argument("--sh-points", type=int, default=5000, help=argparse.SUPPRESS)
     ap.add_argument("--sh-kf", type=int, default=20, help=argparse.SUPPRESS)
     args = ap.parse_args()
