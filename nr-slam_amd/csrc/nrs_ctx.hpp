@@ -55,6 +55,7 @@ struct nrs_ctx {
     hipEvent_t ev_vec = nullptr, ev_halo = nullptr;
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
+    int seq = 0;                     // sequence number of the last publication the host waited for (pin_flags[7])
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;

@@ -40,6 +40,7 @@
 //   * XCD-aware launch order: logical tile = (blockIdx % 8) * ceil(nb/8) + blockIdx / 8, so each
 //     XCD's L2 serves one contiguous run of rows (neighbour gathers stay inside it).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -159,19 +160,32 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         hipLaunchKernelGGL((k_finalize_pack<LIN>), dim3(1), b, 0, c->stream, d);
         NRS_HIP(c, hipGetLastError());
         NRS_TRY(c->comm->allreduce(c, d.pk_loc, d.pk, (size_t)(2 + d.sh_world + (LIN ? 27 * d.K : 0))));
-        hipLaunchKernelGGL((k_finalize_unpack<LIN>), dim3(1), b, 0, c->stream, d);
+        hipLaunchKernelGGL((k_finalize_unpack<LIN>), dim3(1), b, 0, c->stream, d, ++c->seq);
     } else {
-        hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d);
+        hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d, ++c->seq);
     }
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
 
-static int read_scalars(nrs_ctx* c, Engine* e) {
-    // k_finalize (always the last kernel enqueued before this) has written both mirrors
-    NRS_HIP(c, hipStreamSynchronize(c->stream));
+// Wait for the publication numbered c->seq (k_finalize / k_publish: always the last kernel enqueued before
+// this).  The host polls the sequence word in mapped host memory; if it does not show up within ~2 s the
+// stream is synchronised instead, which also surfaces a device fault as an error.
+static int wait_published(nrs_ctx* c, Engine* e) {
+    volatile int* w = e->h_flags + 7;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *w != c->seq; ++spins) {
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            NRS_HIP(c, hipStreamSynchronize(c->stream));
+            if (*w != c->seq) return c->fail(NRS_ERR_HIP, "device results were not published");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return NRS_OK;
 }
+
+static int read_scalars(nrs_ctx* c, Engine* e) { return wait_published(c, e); }
 
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
@@ -276,8 +290,8 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* i
         if (stop_level > 0 && e->pred_peek > 0) count = std::max(2, std::min(e->pred_peek, c->opt.pcg_batch));                                // waiting for a milestone: small steps
         NRS_TRY(pcg_enqueue_batch(c, e, lam, it_io, count));
         NRS_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d);
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d, ++c->seq);
+        NRS_TRY(wait_published(c, e));
         if (e->h_flags[0] || *it_io >= c->opt.pcg_max_iters) { *done = true; break; }
         if (stop_level && e->h_flags[3] >= stop_level) { *done = false; break; }
     }

@@ -343,8 +343,19 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
 // =====================================================================================
 // finalize: fixed-order sums of the partials.  LIN: H_pp, b_p, chi2, max diag.  else chi2, scale.
 // =====================================================================================
+// Publication to the host: everything goes into mapped host memory from ONE thread, then a system-scope
+// fence, then the sequence number the host is polling for (h_flags[7]) -- a host round trip is then the
+// latency of that word (measured 9.5 us per {two launches + wait} against 15.2 us with
+// hipStreamSynchronize, tools/micro/sync_latency.hip).
+__device__ inline void publish_flags(const Dev& P, int seq) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) P.h_flags[k] = P.flags[k];
+    __threadfence_system();
+    *reinterpret_cast<volatile int*>(P.h_flags + 7) = seq;
+}
+
 template <bool LIN>
-__global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
+__global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
     __shared__ double lds[4 * 3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double chi = 0, md = 0, sc = 0;
@@ -367,12 +378,12 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P) {
         P.scal[SC_CHI] = lds[0] + lds[3] + lds[6] + lds[9];
         if (LIN) P.scal[SC_MAXDIAG] = fmax(fmax(lds[1], lds[4]), fmax(lds[7], lds[10]));
         if (!LIN) P.scal[SC_SCALE] = lds[2] + lds[5] + lds[8] + lds[11];
-        // the host reads these after a stream synchronisation: written straight into mapped host memory
+        // written straight into mapped host memory (no copy kernels)
         P.h_scal[SC_CHI] = P.scal[SC_CHI];
         if (LIN) P.h_scal[SC_MAXDIAG] = P.scal[SC_MAXDIAG];
         if (!LIN) P.h_scal[SC_SCALE] = P.scal[SC_SCALE];
+        publish_flags(P, seq);
     }
-    if (tid < 8) P.h_flags[tid] = P.flags[tid];
 }
 
 // Sharded evaluation (multi-GPU): the same fixed-order sums over this rank's partials (slots of other
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(BLK) void k_finalize_pack(Dev P) {
 }
 
 template <bool LIN>
-__global__ __launch_bounds__(BLK) void k_finalize_unpack(Dev P) {
+__global__ __launch_bounds__(BLK) void k_finalize_unpack(Dev P, int seq) {
     const int tid = threadIdx.x;
     if (LIN) {
         const double* q = P.pk + 2 + P.sh_world;
@@ -438,8 +449,8 @@ __global__ __launch_bounds__(BLK) void k_finalize_unpack(Dev P) {
             P.scal[SC_SCALE] = P.pk[1];
             P.h_scal[SC_SCALE] = P.pk[1];
         }
+        publish_flags(P, seq);
     }
-    if (tid < 8) P.h_flags[tid] = P.flags[tid];
 }
 
 // H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the k_reproj partials
@@ -471,8 +482,8 @@ __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     }
 }
 
-__global__ void k_publish(Dev P) {
-    if (threadIdx.x < 8) P.h_flags[threadIdx.x] = P.flags[threadIdx.x];
+__global__ void k_publish(Dev P, int seq) {
+    if (threadIdx.x == 0) publish_flags(P, seq);
 }
 
 }  // namespace nrs

@@ -619,7 +619,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     mark("uploads enqueued");
     if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N, hipHostMallocMapped));      // pinned mirrors live in
-    if (!c->pin_flags) NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped));         // the context (reused)
+    if (!c->pin_flags) {                                                                                              // the context (reused)
+        NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped));
+        memset(c->pin_flags, 0, sizeof(int) * 8);                  // [7] is the publication sequence word the host polls
+    }
     e->h_scal = c->pin_scal;
     e->h_flags = c->pin_flags;
     e->d.h_scal = c->pin_scal;          // hipHostMalloc memory is mapped: same pointer on the device
