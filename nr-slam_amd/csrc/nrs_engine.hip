@@ -138,7 +138,8 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         launch_reg<LIN>(c, d, d.xl[which]);
     } else {
         hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
-        launch_reg<LIN>(c, d, d.xl[which]);
+        if (d.ec_on) hipLaunchKernelGGL(k_chi_edges, dim3(std::max(1, d.ec_nblk)), b, 0, c->stream, d, d.xl[which]);
+        else launch_reg<LIN>(c, d, d.xl[which]);
     }
     if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.sh_nk), b, 0, c->stream, d);
     if (LIN && d.coarse) {

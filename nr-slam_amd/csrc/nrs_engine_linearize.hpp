@@ -341,6 +341,41 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
 }
 
 // =====================================================================================
+// chi2 of a trial state, one thread per edge (BA windows: no masks, nothing fixed).  Same residuals and
+// Huber as k_reg; only the order of the sum differs from the incidence-ordered one (relative 1e-16).
+// =====================================================================================
+__global__ __launch_bounds__(BLK) void k_chi_edges(Dev P, const double* __restrict__ xl) {
+    __shared__ double lds[4];
+    const int tid = threadIdx.x, i = blockIdx.x * BLK + tid;
+    double rho[1] = {0};
+    if (i < P.ec_nsp) {
+        const EcSpring s = P.ec_sp[i];
+        const double v0 = xl[3 * (size_t)s.a] - xl[3 * (size_t)s.b], v1 = xl[3 * (size_t)s.a + 1] - xl[3 * (size_t)s.b + 1],
+                     v2 = xl[3 * (size_t)s.a + 2] - xl[3 * (size_t)s.b + 2];
+        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2), d0 = (double)s.d0;
+        const double r = P.k_spring * (d - d0) / d0;
+        double rho1;
+        huber(P.info_pos * r * r, P.delta_pos, rho[0], rho1);
+    } else if (i < P.ec_nsp + P.ec_ndm) {
+        const EcDamper dd = P.ec_dm[i - P.ec_nsp];
+        const double w = (double)P.ec_w[i - P.ec_nsp];
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dd.r[k] >= 0) {
+                const double sg = damper_sign(k);
+                s0 += sg * xl[3 * (size_t)dd.r[k]]; s1 += sg * xl[3 * (size_t)dd.r[k] + 1]; s2 += sg * xl[3 * (size_t)dd.r[k] + 2];
+            }
+        }
+        const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
+        double rho1;
+        huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho[0], rho1);
+    }
+    block_sum<1>(rho, lds, tid & 63, tid >> 6);
+    if (tid == 0) P.part_ec[blockIdx.x] = rho[0];
+}
+
+// =====================================================================================
 // finalize: fixed-order sums of the partials.  LIN: H_pp, b_p, chi2, max diag.  else chi2, scale.
 // =====================================================================================
 // Publication to the host: everything goes into mapped host memory from ONE thread, then a system-scope
@@ -362,9 +397,13 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
     for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
-    for (int b = tid; b < P.n_regblk; b += BLK) {
-        chi += P.part_reg[2 * (size_t)b];
-        md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+    if (!LIN && P.ec_on) {
+        for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
+    } else {
+        for (int b = tid; b < P.n_regblk; b += BLK) {
+            chi += P.part_reg[2 * (size_t)b];
+            md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+        }
     }
     if (LIN)
         for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp|
@@ -401,9 +440,13 @@ __global__ __launch_bounds__(BLK) void k_finalize_pack(Dev P) {
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
     for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
-    for (int b = tid; b < P.n_regblk; b += BLK) {
-        chi += P.part_reg[2 * (size_t)b];
-        md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+    if (!LIN && P.ec_on) {
+        for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
+    } else {
+        for (int b = tid; b < P.n_regblk; b += BLK) {
+            chi += P.part_reg[2 * (size_t)b];
+            md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
+        }
     }
     if (LIN)
         for (int k = P.sh_k0 + tid; k < P.sh_k0 + P.sh_nk; k += BLK) md = fmax(md, P.red_loc[3 + k]);

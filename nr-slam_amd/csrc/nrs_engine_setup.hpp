@@ -92,6 +92,10 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.part_apply = A.get<double>((size_t)d.n_vecblk);
     d.scal = A.get<double>(SC_N);
     d.flags = A.get<int>(8);
+    d.ec_sp = A.get<EcSpring>(d.ec_on ? std::max(1, d.ec_nsp) : 1);
+    d.ec_dm = A.get<EcDamper>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
+    d.ec_w = A.get<float>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
+    d.part_ec = A.get<double>(d.ec_on ? std::max(1, d.ec_nblk) : 1);
     e->t_vrow = A.get<int>(d.M);
     e->t_sp = A.get<int>(2 * (size_t)d.n_sp);
     e->t_dm = A.get<int>(4 * (size_t)d.n_dm);
@@ -498,6 +502,43 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     mark("halo");
     if (tm) fprintf(stderr, "[nrs] tiles %d x %d rows (T=%d), halo rows: max %d, mean %.1f, spring part max %d, classes %d (cap %d/%d) + %d (cap %d/%d), lds %d, fused %d\n", d.n_regblk, d.tile_rows, T, d.max_halo, (double)halo_rows.size() / d.n_regblk, d.max_halo_s, d.n_tiles_cls[0], d.cap_h[0], d.cap_s[0], d.n_tiles_cls[1], d.cap_h[1], d.cap_s[1], d.use_lds, d.fused);
     if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
+    // ---- edge lists for the chi2-only evaluation of trial states (BA form, nothing masked or fixed): each
+    // edge once, ordered by the row that counts it (locality of the gathers); a rank keeps the edges it counts
+    std::vector<EcSpring> ec_sp;
+    std::vector<EcDamper> ec_dm;
+    std::vector<float> ec_w;
+    {
+        bool plain = !s.X0 && s.n_un == 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !getenv("NRS_NO_EDGE_CHI");
+        for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
+        d.ec_on = plain ? 1 : 0;
+        if (plain) {
+            const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
+            std::vector<std::pair<int, int>> order;              // (counting row, edge)
+            for (int q = 0; q < s.n_sp; ++q) {
+                const int r = e->vrow[s.sp_ij[2 * q]];
+                if (r >= own_lo && r < own_hi) order.emplace_back(r, q);
+            }
+            std::sort(order.begin(), order.end());
+            ec_sp.reserve(order.size());
+            for (auto& o : order) ec_sp.push_back(EcSpring{e->vrow[s.sp_ij[2 * o.second]], e->vrow[s.sp_ij[2 * o.second + 1]], s.sp_d0[o.second], 0});
+            order.clear();
+            for (int q = 0; q < s.n_dm; ++q) {
+                int first = -1;
+                for (int k = 0; k < 4 && first < 0; ++k) if (s.dm_idx[4 * q + k] >= 0) first = e->vrow[s.dm_idx[4 * q + k]];
+                if (first >= own_lo && first < own_hi) order.emplace_back(first, q);
+            }
+            std::sort(order.begin(), order.end());
+            for (auto& o : order) {
+                EcDamper dd;
+                for (int k = 0; k < 4; ++k) dd.r[k] = s.dm_idx[4 * o.second + k] >= 0 ? e->vrow[s.dm_idx[4 * o.second + k]] : -1;
+                ec_dm.push_back(dd);
+                ec_w.push_back(s.dm_w[o.second]);
+            }
+        }
+        d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
+        d.ec_nblk = (d.ec_nsp + d.ec_ndm + BLK - 1) / BLK;
+    }
+    mark("edge lists");
     // ---- device memory: one arena allocation, reused across calls when large enough
     ArenaPlan dry{arena, true};
     {
@@ -601,6 +642,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_TRY(h2d(c, d.d_o2, d_o2));
     }
     NRS_TRY(h2d(c, d.d_w, d_w));
+    if (d.ec_on) {
+        NRS_TRY(h2d(c, d.ec_sp, ec_sp));
+        NRS_TRY(h2d(c, d.ec_dm, ec_dm));
+        NRS_TRY(h2d(c, d.ec_w, ec_w));
+    }
     NRS_TRY(push_masks(c, e, s.sp_active, s.dm_active));
     NRS_TRY(h2d(c, e->t_vrow, e->vrow));
     NRS_TRY(h2d(c, e->t_sp, e->sp_ij));
@@ -646,6 +692,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
     if (rflag)
         for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
     if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
+    e->d.ec_on = 0;                                                // masks / fixed vertices: chi2 comes from the incidence records
     NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;

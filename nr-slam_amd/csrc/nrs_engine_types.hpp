@@ -28,6 +28,10 @@ struct __attribute__((aligned(16))) DamperRec { uint16_t o0, o1, o2, meta; doubl
 constexpr uint16_t REC_NONE = 0xFFFF;
 constexpr uint16_t SR_ACTIVE = 1, SR_COUNT = 2;
 
+// edge lists of the chi2-only evaluation (BA form): every edge once, rows instead of vertex ids
+struct __attribute__((aligned(16))) EcSpring { int a, b; float d0; int pad; };
+struct __attribute__((aligned(16))) EcDamper { int r[4]; };         // roles 1c 2c 1n 2n, -1 = absent
+
 struct Dev {
     int K, M, n_rows, n_groups;      // poses, vertices, padded rows, ROW_ALIGN groups
     int T;                           // lanes per row
@@ -103,6 +107,10 @@ struct Dev {
     double* part_spmv;               // n_regblk x NPART
     double* part_apply;              // n_vecblk
     double* scal;
+    // chi2 of a trial state, edge-parallel (BA windows without masks: every spring / damper is evaluated
+    // once from these lists instead of from the incidence records of the row that counts it)
+    int ec_on, ec_nsp, ec_ndm, ec_nblk;
+    EcSpring* ec_sp; EcDamper* ec_dm; float* ec_w; double* part_ec;
     double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag
     // shard window (multi-GPU): the layout is the whole problem on every rank, a rank

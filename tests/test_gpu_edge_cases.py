@@ -140,6 +140,32 @@ def test_ba_two_tile_classes_bit_identical(ctx, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("exact", [0, 1])
+def test_ba_trial_chi2_paths_agree(exact, monkeypatch):
+    """Trial states of a BA window are evaluated edge-parallel (one thread per spring / damper); the
+    switch NRS_NO_EDGE_CHI=1 evaluates them from the incidence records of the counting rows instead.
+    Same residuals and Huber, another order of the sum: identical decisions, chi2 to 1e-12 relative,
+    same result."""
+    p = S.make_dba_problem(900, 6, 76)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    res = []
+    for sw in (None, "1"):
+        if sw:
+            monkeypatch.setenv("NRS_NO_EDGE_CHI", sw)
+        c = nrs.Context(exact_trials=exact)
+        tr = nrs.Trace()
+        pq, xyz = c.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr)
+        c.close()
+        res.append((pq, xyz, tr.trials))
+    a, b = res
+    assert [(t["accepted"], t["early"], t["inner"]) for t in a[2]] == [(t["accepted"], t["early"], t["inner"]) for t in b[2]]
+    for s, t in zip(a[2], b[2]):
+        assert abs(s["chi_new"] - t["chi_new"]) <= 1e-12 * abs(t["chi_new"]) and abs(s["chi"] - t["chi"]) <= 1e-12 * abs(t["chi"])
+    assert np.allclose(a[0], b[0], atol=1e-9, rtol=0) and np.allclose(a[1], b[1], atol=1e-6, rtol=0)
+
+
 def test_contexts_and_engines_do_not_leak_device_memory(lib_built):
     """create / solve / destroy many times: device memory in use must not grow (arena reuse inside a
     context, full release on nrs_destroy)."""
