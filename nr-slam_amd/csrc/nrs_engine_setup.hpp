@@ -335,6 +335,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     (void)dm_slots;
     mark("sell pack");
+    mark("sell vectors");
     // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
     // outside the tile; neighbour ids become tile-local
     d.tile_rows = BLK / T;
@@ -372,12 +373,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                 cnt[b] = (int)ext.size();
             }
         };
+        mark("halo prep");
         if (nt == 1) work(0);
         else {
             std::vector<std::thread> th;
             for (int ti = 0; ti < nt; ++ti) th.emplace_back(work, ti);
             for (auto& t : th) t.join();
         }
+        mark("halo work");
         for (int b = 0; b < d.n_regblk; ++b) {
             halo_ptr[b + 1] = halo_ptr[b] + cnt[b];
             d.max_halo = std::max(d.max_halo, cnt[b]);
@@ -386,6 +389,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         halo_rows.reserve((size_t)halo_ptr[d.n_regblk]);
         for (int ti = 0; ti < nt; ++ti) halo_rows.insert(halo_rows.end(), part[ti].begin(), part[ti].end());
     }
+    mark("halo lists");
     // ---- tile classes: if a few tiles have much larger halos than the rest they get their own
     // launch (class 1) with their own LDS size, and the bulk (class 0) keeps its occupancy
     std::vector<int> tile_list(d.n_regblk);
