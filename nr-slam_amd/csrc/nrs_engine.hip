@@ -209,7 +209,8 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
 }
 
 // enqueue one batch of PCG iterations (no host synchronisation)
-static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int count = 0) {
+// pub_seq != 0: the last launch of the batch publishes the flags under that sequence number (the host waits for it)
+static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int count = 0, int pub_seq = 0) {
     const Dev& d = e->d;
     const int n_poseblk = (d.K + 3) / 4;
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
@@ -217,24 +218,25 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
     // profiling contexts poll after every iteration, so that no launch queued behind a converged solve is timed
     const int stop = std::min(it + (c->opt.profile ? 1 : count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
     for (; it < stop; ++it) {
+        const int pub = it + 1 == stop ? pub_seq : 0;
         if (d.fused) {
             const dim3 g(((d.n_regblk + 7) / 8) * 8), bb(BLK);
             const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 12 * (size_t)d.n_regblk + 16 * CO_MAX : 0));
             switch (d.T) {
-                case 1: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<1, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-                        else hipLaunchKernelGGL((k_pcg_fused<1, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                case 1: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<1, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                        else hipLaunchKernelGGL((k_pcg_fused<1, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         break;
-                case 2: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<2, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-                        else hipLaunchKernelGGL((k_pcg_fused<2, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                case 2: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<2, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                        else hipLaunchKernelGGL((k_pcg_fused<2, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         break;
-                case 4: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<4, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-                        else hipLaunchKernelGGL((k_pcg_fused<4, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                case 4: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<4, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                        else hipLaunchKernelGGL((k_pcg_fused<4, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         break;
-                case 16: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<16, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-                        else hipLaunchKernelGGL((k_pcg_fused<16, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                case 16: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<16, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                        else hipLaunchKernelGGL((k_pcg_fused<16, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         break;
-                default: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<8, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
-                        else hipLaunchKernelGGL((k_pcg_fused<8, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                default: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<8, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                        else hipLaunchKernelGGL((k_pcg_fused<8, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         break;
             }
             continue;
@@ -273,7 +275,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
         {
             Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
             hipLaunchKernelGGL(k_pcg_update, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
-                               d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL);
+                               d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
         }
     }
     *it_io = it;
@@ -281,7 +283,6 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
 }
 
 static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* it_io, bool* done) {
-    const Dev& d = e->d;
     while (true) {
         // Once no peek is pending, batches are sized by the previous trial's iteration count (half of
         // what it predicts is left): fewer host round trips; launches past convergence are no-ops.
@@ -289,9 +290,9 @@ static int pcg_advance(nrs_ctx* c, Engine* e, double lam, int stop_level, int* i
         if (stop_level == 0 && e->pred_iters > *it_io) count = std::min(std::max((e->pred_iters - *it_io) / 2, c->opt.pcg_batch), 8 * c->opt.pcg_batch);
         if (stop_level == 0 && e->pred_iters >= *it_io && e->pred_iters + 1 - *it_io <= c->opt.pcg_batch) count = e->pred_iters + 1 - *it_io;   // short solves: finish in one batch
         if (stop_level > 0 && e->pred_peek > 0) count = std::max(2, std::min(e->pred_peek, c->opt.pcg_batch));                                // waiting for a milestone: small steps
-        NRS_TRY(pcg_enqueue_batch(c, e, lam, it_io, count));
+        if (*it_io >= c->opt.pcg_max_iters) { *done = true; break; }
+        NRS_TRY(pcg_enqueue_batch(c, e, lam, it_io, count, ++c->seq));      // its last launch publishes the flags
         NRS_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, d, ++c->seq);
         NRS_TRY(wait_published(c, e));
         if (e->h_flags[0] || *it_io >= c->opt.pcg_max_iters) { *done = true; break; }
         if (stop_level && e->h_flags[3] >= stop_level) { *done = false; break; }

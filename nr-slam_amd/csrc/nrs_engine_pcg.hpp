@@ -387,7 +387,7 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
 //   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = M^-1 r
 // Workgroups >= n_vec8 own the pose rows (w_p = (H_pp + lambda) u_p + sum_l H_pl u_l).
 // =====================================================================================
-__global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2) {
+__global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2, int pub_seq) {
     __shared__ double lds[4 * 3];
     const int n_vecblk = P.sh_nvb;                                 // own row range (the whole problem when not sharded)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,7 +479,13 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
         }
         v[1] += ua * s;
     }
-    if (done_flag) return;
+    // pub_seq != 0: this is the last launch of a batch the host is waiting for -- the thread that owns the
+    // flags publishes them (mapped host memory + sequence word) as soon as they are final
+    const bool publisher = pub_seq != 0 && blockIdx.x == 0 && tid == 0;
+    if (done_flag) {
+        if (publisher) publish_flags(P, pub_seq);
+        return;
+    }
     block_sum<3>(v, lds, lane, wave);
     const double gamma = v[0], delta = v[1] + v[2];
     double* nslot = P.scal + ((it & 1) ? SC_SLOT0 : SC_SLOT1);
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             P.flags[1] = it;
             __threadfence();
             P.flags[0] = 1;
+            if (publisher) publish_flags(P, pub_seq);
         }
         return;
     }
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
             if (P.flags[4] == 0) P.flags[4] = it + 1;               // iterations the first milestone took (sizes the next first batch)
         }
+        if (publisher) publish_flags(P, pub_seq);
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
 // k_pcg_update + k_spmv.
 // =====================================================================================
 template <int T, bool CO>
-__global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, double tol2, double peek_tol2) {
+__global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, double tol2, double peek_tol2, int pub_seq) {
     __shared__ double lds[4 * 9];
     __shared__ double s_up[6];
     extern __shared__ double dyn[];
@@ -783,7 +791,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     load_springs(sbeg + lane);
     load_dampers(dbeg + lane);
 
-    if (done_flag) return;
+    if (done_flag) {
+        if (pub_seq != 0 && blockIdx.x == 0 && tid == 0) publish_flags(P, pub_seq);      // (see k_pcg_update)
+        return;
+    }
     // wave 0: w_p = (H_pp + lambda) u_p + sum_l H_pl u_l of the tile's pose (independent of alpha, beta)
     double w_pose = 0, ua_pose = 0;
     if (wave == 0) {
@@ -867,6 +878,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 P.flags[1] = ip;
                 __threadfence();
                 P.flags[0] = 1;
+                if (pub_seq != 0) publish_flags(P, pub_seq);
             }
             return;
         }
@@ -881,8 +893,9 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 P.flags[3] = max(P.flags[3], (gamma <= 1e-6 * peek_tol2 * gamma0 ? 4 : gamma <= 1e-4 * peek_tol2 * gamma0 ? 3 : gamma <= 1e-2 * peek_tol2 * gamma0 ? 2 : 1));
                 if (P.flags[4] == 0) P.flags[4] = ip + 1;
             }
+            if (pub_seq != 0) publish_flags(P, pub_seq);
         }
-    }
+    } else if (pub_seq != 0 && blockIdx.x == 0 && tid == 0) publish_flags(P, pub_seq);   // F(0) finishes no iteration
     if (coarse) {                                                  // (the reduction above was a barrier: yR, yS, yW are visible)
         if (tid < cn) {
             double yr = 0, ys = 0, yw = 0;
