@@ -344,7 +344,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
     {
         // tiles are independent: a few host threads each take a contiguous range of tiles
-        const int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 128}));
+        const int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 32}));   // (a 4.5k-point frame: 4 threads, 1.5 -> 0.5 ms)
         std::vector<std::vector<int>> part(nt);
         std::vector<int> cnt(d.n_regblk, 0);
         auto work = [&](int ti) {
