@@ -668,9 +668,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_HIP(c, hipMemsetAsync(d.scal, 0, sizeof(double) * SC_N, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     mark("uploads enqueued");
-    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N, hipHostMallocMapped));      // pinned mirrors live in
+    if (!c->pin_scal) NRS_HIP(c, hipHostMalloc((void**)&c->pin_scal, sizeof(double) * SC_N, hipHostMallocMapped | hipHostMallocCoherent));      // pinned mirrors live in
     if (!c->pin_flags) {                                                                                              // the context (reused)
-        NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped));
+        NRS_HIP(c, hipHostMalloc((void**)&c->pin_flags, sizeof(int) * 8, hipHostMallocMapped | hipHostMallocCoherent));
         memset(c->pin_flags, 0, sizeof(int) * 8);                  // [7] is the publication sequence word the host polls
     }
     e->h_scal = c->pin_scal;
