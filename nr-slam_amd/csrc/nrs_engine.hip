@@ -176,6 +176,7 @@ static int wait_published(nrs_ctx* c, Engine* e) {
     volatile int* w = e->h_flags + 7;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0; *w != c->seq; ++spins) {
+        if (spins > 200000) std::this_thread::yield();             // long kernels (large windows): stop hogging the core
         if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             NRS_HIP(c, hipStreamSynchronize(c->stream));
             if (*w != c->seq) return c->fail(NRS_ERR_HIP, "device results were not published");
