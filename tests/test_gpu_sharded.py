@@ -64,12 +64,16 @@ def _run_sharded(world, p, e, cam, qt, iters=5, exact=0, resets=0):
 
 
 def _same_trials(a, b, rtol=1e-6):
+    """Same decisions, lambdas and chi2.  WHERE a rejected trial stops being solved (the early-rejection
+    looks) depends on the batching of the inner solve, which differs between the two paths (no convergence
+    look-ahead when sharded): a trial cut short on one side and solved out on the other is rejected on both,
+    only its chi2_new (an approximation when cut short) is not comparable (tools/sharded_sweep.py, seed 26)."""
     assert [t["accepted"] for t in a] == [t["accepted"] for t in b]
-    assert [t["early"] for t in a] == [t["early"] for t in b]
     for x, y in zip(a, b):
         assert abs(x["lam"] - y["lam"]) <= rtol * abs(y["lam"])
         assert abs(x["chi"] - y["chi"]) <= rtol * abs(y["chi"])
-        if not y["early"]:
+        assert not (x["early"] or y["early"]) or not (x["accepted"] or y["accepted"])
+        if not y["early"] and not x["early"]:
             assert abs(x["chi_new"] - y["chi_new"]) <= rtol * abs(y["chi_new"])
 
 
