@@ -73,3 +73,24 @@ def test_capacity_and_bad_arguments(ctx):
         ctx.shi_extract(sq["im0"], np.array([[400.0, 3.0]], np.float32))
     with pytest.raises(nrs.NrsError):
         ctx.shi_configure(40)
+
+
+def test_strided_image_and_mask(ctx):
+    """cv::Mat rows are `step` bytes apart: image and mask with padded rows give the result of the packed ones."""
+    import ctypes as C
+    sq = S.make_lk_sequence(10, 9, wh=(160, 120))
+    im = sq["im0"]
+    h, w = im.shape
+    rng = np.random.default_rng(3)
+    mask = (rng.uniform(size=(h, w)) > 0.3).astype(np.uint8)
+    ctx.shi_configure(4)
+    ref_xy, ref_id, n_ref = ctx.shi_extract(im, None, mask)
+    pad_im = np.full((h, w + 37), 255, np.uint8); pad_im[:, :w] = im
+    pad_mk = np.zeros((h, w + 11), np.uint8); pad_mk[:, :w] = mask
+    ctx.shi_configure(4)
+    xy = np.zeros((4096, 2), np.float32); ids = np.zeros(4096, np.int32); n = C.c_int32(0)
+    rc = ctx.lib.nrs_shi_extract(ctx.h, pad_im.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int32(w), C.c_int32(h), C.c_int32(w + 37),
+                                 pad_mk.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int32(w + 11), C.c_int32(0), None,
+                                 C.c_int32(4096), xy.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n))
+    assert rc == 0 and n.value == n_ref > 10
+    assert np.array_equal(xy[:n.value], ref_xy) and np.array_equal(ids[:n.value], ref_id)
