@@ -211,14 +211,35 @@ __global__ __launch_bounds__(BLK) void k_coarse_reduce(Dev P) {
     }
 }
 
+// 6x6 in-place inverse in registers (Gauss-Jordan without pivoting, every index static); false if a pivot is not positive
+__device__ inline bool inv6_inplace(double (&m)[6][6]) {
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const double piv = m[p][p];
+        ok = ok && piv > 0 && isfinite(piv);
+        const double pinv = 1.0 / piv;
+        double col[6], row[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { col[i] = m[i][p]; row[i] = m[p][i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                m[i][j] = (i == p) ? ((j == p) ? pinv : row[j] * pinv) : ((j == p) ? -col[i] * pinv : m[i][j] - col[i] * row[j] * pinv);
+    }
+    return ok;
+}
+
 __global__ __launch_bounds__(BLK) void k_coarse_invert(Dev P, double lam) {
-    // In-place Gauss-Jordan (SPD: no pivoting) with the matrix in REGISTERS: thread (br, bc) keeps a
-    // 6x6 block; per pivot step only the pivot row and column go through LDS (double-buffered: one
-    // barrier per step).  The matrix is padded to a multiple of 6 with an identity block.  A
-    // non-positive pivot switches the coarse level off for this trial.
-    extern __shared__ double A[];                                          // n x n (result, for y0)
+    // In-place BLOCK Gauss-Jordan (SPD: no pivoting) with the matrix in REGISTERS: thread (br, bc) keeps a
+    // 6x6 block.  Per block step the pivot block is inverted in its owner's registers, the pivot block row
+    // is scaled by it, and every other block takes one 6x6x6 update; only the pivot block, row and column go
+    // through LDS (double-buffered by step parity: two barriers per step, n/6 steps instead of n pivots).
+    // The matrix is padded to a multiple of 6 with an identity block.  A non-positive pivot switches the
+    // coarse level off for this trial.
     constexpr int BS = 6, NBMAX = (CO_MAX + BS - 1) / BS;
-    __shared__ double colb[2][NBMAX * BS], rowb[2][NBMAX * BS];
+    __shared__ double colb[2][NBMAX][BS * BS], rowb[2][NBMAX][BS * BS], pivb[2][BS * BS];
     __shared__ int bad;
     const int tid = threadIdx.x, n = P.co_n;
     const int nb = (n + BS - 1) / BS;
@@ -249,60 +270,96 @@ __global__ __launch_bounds__(BLK) void k_coarse_invert(Dev P, double lam) {
             a[i][j] = v;
         }
     __syncthreads();
-    const int np = nb * BS;
-    bool ok = true;
-    for (int p = 0; p < np; ++p) {
-        const int pb = p / BS, pi = p % BS, buf = p & 1;
+    for (int pb = 0; pb < nb; ++pb) {
+        const int buf = pb & 1;
+        // phase A: the pivot block's owner inverts it; the pivot block column is published as it is
         if (act && bc == pb) {
+            if (br == pb) {
+                if (!inv6_inplace(a)) bad = 1;
 #pragma unroll
-            for (int i = 0; i < BS; ++i) {
-                double v = a[i][0];
+                for (int i = 0; i < BS; ++i)
 #pragma unroll
-                for (int j = 1; j < BS; ++j) v = (pi == j) ? a[i][j] : v;
-                colb[buf][br * BS + i] = v;
-            }
-        }
-        if (act && br == pb) {
+                    for (int j = 0; j < BS; ++j) pivb[buf][i * BS + j] = a[i][j];
+            } else {
 #pragma unroll
-            for (int j = 0; j < BS; ++j) {
-                double v = a[0][j];
+                for (int i = 0; i < BS; ++i)
 #pragma unroll
-                for (int i = 1; i < BS; ++i) v = (pi == i) ? a[i][j] : v;
-                rowb[buf][bc * BS + j] = v;
+                    for (int j = 0; j < BS; ++j) colb[buf][br][i * BS + j] = a[i][j];
             }
         }
         __syncthreads();
-        const double piv = rowb[buf][p];
-        if (!(piv > 0) || !isfinite(piv)) { ok = false; break; }
-        const double pinv = 1.0 / piv;
-        double cr[BS], rw[BS];
+        if (bad) break;                                                    // (uniform: read after the barrier)
+        // phase B: pivot block row <- P^-1 * row, published; pivot block column <- -column * P^-1
+        if (act && br == pb && bc != pb) {                                  // row: R = P^-1 * A_pj
+            double t[BS][BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) { cr[i] = colb[buf][br * BS + i]; rw[i] = rowb[buf][bc * BS + i]; }
+            for (int i = 0; i < BS; ++i)
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
+                for (int j = 0; j < BS; ++j) {
+                    double sacc = 0;
 #pragma unroll
-            for (int j = 0; j < BS; ++j) {
-                const bool rp = br * BS + i == p, cp = bc * BS + j == p;
-                const double upd = a[i][j] - cr[i] * rw[j] * pinv;
-                a[i][j] = rp ? (cp ? pinv : rw[j] * pinv) : (cp ? -cr[i] * pinv : upd);
-            }
+                    for (int k = 0; k < BS; ++k) sacc += pivb[buf][i * BS + k] * a[k][j];
+                    t[i][j] = sacc;
+                }
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) { a[i][j] = t[i][j]; rowb[buf][bc][i * BS + j] = t[i][j]; }
+        } else if (act && bc == pb && br != pb) {                           // column: -A_ip * P^-1
+            double t[BS][BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) sacc += a[i][k] * pivb[buf][k * BS + j];
+                    t[i][j] = -sacc;
+                }
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) a[i][j] = t[i][j];
+        }
+        __syncthreads();
+        // phase C: every other block takes A_ij -= C_i * R_j
+        if (act && br != pb && bc != pb) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+                for (int j = 0; j < BS; ++j) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) sacc += colb[buf][br][i * BS + k] * rowb[buf][bc][k * BS + j];
+                    a[i][j] -= sacc;
+                }
+        }
     }
-    if (!ok && tid == 0) bad = 1;
     __syncthreads();
     const bool off = bad != 0;
+    // result -> global; y0 = A^-1 (Z^T b): every thread multiplies its block with its slice of the vector, the
+    // nb partial sums of a row are added in a fixed order
+    __shared__ double ypart[NBMAX * NBMAX][BS];
     if (act) {
+        double bcv[BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
+        for (int j = 0; j < BS; ++j) bcv[j] = bc * BS + j < n ? P.co_bc[bc * BS + j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            double y = 0;
 #pragma unroll
             for (int j = 0; j < BS; ++j) {
                 const int r = br * BS + i, c = bc * BS + j;
-                if (r < n && c < n) { const double v = off ? 0.0 : a[i][j]; A[r * n + c] = v; P.co_inv[(size_t)r * n + c] = v; }
+                const double v = off ? 0.0 : a[i][j];
+                if (r < n && c < n) { P.co_inv[(size_t)r * n + c] = v; y += v * bcv[j]; }
             }
+            ypart[br * nb + bc][i] = y;
+        }
     }
     __syncthreads();
     for (int j = tid; j < n; j += BLK) {
         double y = 0;
-        for (int c = 0; c < n; ++c) y += A[j * n + c] * P.co_bc[c];
+        for (int q = 0; q < nb; ++q) y += ypart[(j / BS) * nb + q][j % BS];
         P.co_y0[j] = y;
     }
 }
