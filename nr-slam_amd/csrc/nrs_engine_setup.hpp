@@ -517,26 +517,34 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.ec_on = plain ? 1 : 0;
         if (plain) {
             const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
-            std::vector<std::pair<int, int>> order;              // (counting row, edge)
-            for (int q = 0; q < s.n_sp; ++q) {
-                const int r = e->vrow[s.sp_ij[2 * q]];
-                if (r >= own_lo && r < own_hi) order.emplace_back(r, q);
-            }
-            std::sort(order.begin(), order.end());
-            ec_sp.reserve(order.size());
-            for (auto& o : order) ec_sp.push_back(EcSpring{e->vrow[s.sp_ij[2 * o.second]], e->vrow[s.sp_ij[2 * o.second + 1]], s.sp_d0[o.second], 0});
-            order.clear();
-            for (int q = 0; q < s.n_dm; ++q) {
-                int first = -1;
-                for (int k = 0; k < 4 && first < 0; ++k) if (s.dm_idx[4 * q + k] >= 0) first = e->vrow[s.dm_idx[4 * q + k]];
-                if (first >= own_lo && first < own_hi) order.emplace_back(first, q);
-            }
-            std::sort(order.begin(), order.end());
-            for (auto& o : order) {
+            // counting sort by the counting row (stable: edges of a row keep their order)
+            std::vector<int> key, pos(d.n_rows + 1);
+            auto order_by_row = [&](int n_edges, auto row_of) {
+                key.assign(n_edges, -1);
+                std::fill(pos.begin(), pos.end(), 0);
+                for (int q = 0; q < n_edges; ++q) {
+                    const int r = row_of(q);
+                    if (r >= own_lo && r < own_hi) { key[q] = r; pos[r + 1]++; }
+                }
+                for (int r = 0; r < d.n_rows; ++r) pos[r + 1] += pos[r];
+                std::vector<int> out(pos[d.n_rows]);
+                for (int q = 0; q < n_edges; ++q)
+                    if (key[q] >= 0) out[pos[key[q]]++] = q;
+                return out;
+            };
+            const std::vector<int> so = order_by_row(s.n_sp, [&](int q) { return e->vrow[s.sp_ij[2 * q]]; });
+            ec_sp.reserve(so.size());
+            for (int q : so) ec_sp.push_back(EcSpring{e->vrow[s.sp_ij[2 * q]], e->vrow[s.sp_ij[2 * q + 1]], s.sp_d0[q], 0});
+            const std::vector<int> dord = order_by_row(s.n_dm, [&](int q) {
+                for (int k = 0; k < 4; ++k) if (s.dm_idx[4 * q + k] >= 0) return e->vrow[s.dm_idx[4 * q + k]];
+                return -1;
+            });
+            ec_dm.reserve(dord.size()); ec_w.reserve(dord.size());
+            for (int q : dord) {
                 EcDamper dd;
-                for (int k = 0; k < 4; ++k) dd.r[k] = s.dm_idx[4 * o.second + k] >= 0 ? e->vrow[s.dm_idx[4 * o.second + k]] : -1;
+                for (int k = 0; k < 4; ++k) dd.r[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
                 ec_dm.push_back(dd);
-                ec_w.push_back(s.dm_w[o.second]);
+                ec_w.push_back(s.dm_w[q]);
             }
         }
         d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
