@@ -101,13 +101,35 @@ struct LocalGroup {
     int waiting = 0;
     uint64_t generation = 0;
     const double* slot[LOCAL_MAX] = {};
-    void barrier() {
+    bool aborted = false;            // a rank failed between two barriers: every waiter is released with an error
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const uint64_t g = generation;
         if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        else cv.wait(lk, [&] { return generation != g || aborted; });
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
+
+// a failing step of a thread rank must not leave its peers in a barrier
+#define NRS_LOCAL(ctx, grp, expr)                                                      \
+    do {                                                                               \
+        int rc__ = (expr);                                                             \
+        if (rc__ != NRS_OK) { (grp)->abort(); return rc__; }                           \
+    } while (0)
+#define NRS_LOCAL_BARRIER(ctx, grp)                                                    \
+    do {                                                                               \
+        if (!(grp)->barrier()) return (ctx)->fail(NRS_ERR_COMM, "a peer rank of the local group failed"); \
+    } while (0)
+static inline int hip_rc(nrs_ctx* c, hipError_t e, const char* what) {
+    return e == hipSuccess ? NRS_OK : c->fail(NRS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
 
 struct PtrPack { const double* p[LOCAL_MAX]; };
 
@@ -125,37 +147,60 @@ struct LocalComm : Comm {
     ~LocalComm() override { if (tmp.p) (void)hipFree(tmp.p); }
     int allreduce(nrs_ctx* c, const double* send, double* recv, size_t n) override {
         g->slot[rank] = send;
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
-        g->barrier();
+        NRS_LOCAL(c, g, hip_rc(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize"));
+        NRS_LOCAL_BARRIER(c, g);
         PtrPack pp;
         for (int r = 0; r < LOCAL_MAX; ++r) pp.p[r] = r < world ? g->slot[r] : nullptr;
-        NRS_TRY(c->ensure(tmp, sizeof(double) * n));               // send == recv is allowed: sum into a staging buffer
+        NRS_LOCAL(c, g, c->ensure(tmp, sizeof(double) * n));       // send == recv is allowed: sum into a staging buffer
         hipLaunchKernelGGL(k_local_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pp, world, tmp.as<double>(), n);
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
-        g->barrier();                                              // everybody has read every send buffer
+        NRS_LOCAL(c, g, hip_rc(c, hipStreamSynchronize(c->stream), "k_local_sum"));
+        NRS_LOCAL_BARRIER(c, g);                                   // everybody has read every send buffer
         NRS_HIP(c, hipMemcpyAsync(recv, tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
         return NRS_OK;
     }
     int exchange(nrs_ctx* c, double* v, const HaloPlan& h, hipStream_t st) override {
         if (world == 1) return NRS_OK;
         g->slot[rank] = v;
-        NRS_HIP(c, hipStreamSynchronize(st));
-        g->barrier();
+        NRS_LOCAL(c, g, hip_rc(c, hipStreamSynchronize(st), "hipStreamSynchronize"));
+        NRS_LOCAL_BARRIER(c, g);
         // the layout is the same on every rank: a neighbour's send range is this rank's receive range
-        if (rank > 0) NRS_HIP(c, hipMemcpyAsync(v + h.lo_recv, g->slot[rank - 1] + h.lo_recv, sizeof(double) * h.lo_recv_n, hipMemcpyDeviceToDevice, st));
-        if (rank < world - 1) NRS_HIP(c, hipMemcpyAsync(v + h.hi_recv, g->slot[rank + 1] + h.hi_recv, sizeof(double) * h.hi_recv_n, hipMemcpyDeviceToDevice, st));
-        NRS_HIP(c, hipStreamSynchronize(st));
-        g->barrier();
+        if (rank > 0) NRS_LOCAL(c, g, hip_rc(c, hipMemcpyAsync(v + h.lo_recv, g->slot[rank - 1] + h.lo_recv, sizeof(double) * h.lo_recv_n, hipMemcpyDeviceToDevice, st), "halo copy"));
+        if (rank < world - 1) NRS_LOCAL(c, g, hip_rc(c, hipMemcpyAsync(v + h.hi_recv, g->slot[rank + 1] + h.hi_recv, sizeof(double) * h.hi_recv_n, hipMemcpyDeviceToDevice, st), "halo copy"));
+        NRS_LOCAL(c, g, hip_rc(c, hipStreamSynchronize(st), "hipStreamSynchronize"));
+        NRS_LOCAL_BARRIER(c, g);
         return NRS_OK;
     }
 };
 
 void comm_free(nrs_ctx* c) {
+    // exchanges may still be in flight on either stream: drain both before the communicator goes away
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->comm;
     c->comm = nullptr;
-    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
     if (c->ev_vec) { (void)hipEventDestroy(c->ev_vec); c->ev_vec = nullptr; }
     if (c->ev_halo) { (void)hipEventDestroy(c->ev_halo); c->ev_halo = nullptr; }
+}
+
+// Every rank passes the status of its rank-local set-up; all of them return NRS_OK, or none does.  Without
+// this a rank whose set-up failed returns to its caller while its peers walk into the first collective.
+int comm_agree(nrs_ctx* c, int rc) {
+    if (!c->comm || c->comm->world == 1) return rc;
+    double flag = rc == NRS_OK ? 0.0 : 1.0, sum = 0.0;
+    if (c->ensure(c->comm_flag, 2 * sizeof(double)) != NRS_OK) return rc != NRS_OK ? rc : NRS_ERR_ALLOC;
+    double* d = c->comm_flag.as<double>();
+    char keep[sizeof(c->err)];
+    memcpy(keep, c->err, sizeof(keep));                            // the first failure's text is the useful one
+    int st = NRS_OK;
+    if (hipMemcpyAsync(d, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) st = NRS_ERR_HIP;
+    if (st == NRS_OK) st = c->comm->allreduce(c, d, d + 1, 1);
+    if (st == NRS_OK && hipMemcpyAsync(&sum, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = NRS_ERR_HIP;
+    if (st == NRS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = NRS_ERR_HIP;
+    if (rc != NRS_OK) { memcpy(c->err, keep, sizeof(keep)); return rc; }
+    if (st != NRS_OK) return st;
+    if (sum != 0.0) return c->fail(NRS_ERR_COMM, "%d peer rank(s) failed to set up the sharded window", (int)sum);
+    return NRS_OK;
 }
 
 // second stream + the two events that order it against the context's stream (hand-offs are events only)

@@ -53,6 +53,7 @@ struct nrs_ctx {
     nrs::Comm* comm = nullptr;       // set by nrs_comm_init_*: BA problems uploaded afterwards are sharded over its ranks
     hipStream_t comm_stream = nullptr;   // boundary-row exchanges run here, next to the interior tiles on `stream`
     hipEvent_t ev_vec = nullptr, ev_halo = nullptr;
+    nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
     int seq = 0;                     // sequence number of the last publication the host waited for (pin_flags[7])
@@ -99,6 +100,7 @@ struct nrs_ctx {
 namespace nrs {
 void dba_free(nrs_ctx* ctx);
 void comm_free(nrs_ctx* ctx);
+int comm_agree(nrs_ctx* ctx, int rc);    // collective: 0 if every rank passed 0, else an error on every rank
 void klt_free(nrs_ctx* ctx);
 void shi_free(nrs_ctx* ctx);
 }

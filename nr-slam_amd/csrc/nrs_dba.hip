@@ -64,7 +64,10 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     s.delta_pos = 0.0;                  // no robust kernel on the BA springs (OPT:1057-1071)
     s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
     s.shard = true;                     // with a communicator on the context: one window over its ranks (include/nrs.h)
-    return engine_create(c, s, &c->arena_dba, &c->dba);
+    // rank-local checks and allocations can fail on one rank only: the ranks agree before the first collective
+    const int rc = comm_agree(c, engine_create(c, s, &c->arena_dba, &c->dba));
+    if (rc != NRS_OK) dba_free(c);
+    return rc;
 }
 
 extern "C" int nrs_shard_plan(int32_t n_kf, int32_t n_lm, const int32_t* lm_kf, int32_t world, int32_t* kf_begin) {
@@ -135,4 +138,38 @@ extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
     if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
     if (!b || !diag) return c->fail(NRS_ERR_INVALID, "null output");
     return engine_gradient(c, c->dba, b, diag);
+}
+
+// parity tap (include/nrs.h): an explicit one-pose / n-row block system through the engine's PCG kernels
+extern "C" int nrs_debug_pcg_solve(nrs_ctx* c, int32_t n_rows, const double* Hpp21, const double* bp, const double* D6,
+                                   const double* Hpl18, const double* bl, double lambda, double* x, int32_t* iters) {
+    if (!c) return NRS_ERR_INVALID;
+    if (n_rows <= 0 || !Hpp21 || !bp || !D6 || !Hpl18 || !bl || !x || !(lambda >= 0)) return c->fail(NRS_ERR_INVALID, "nrs_debug_pcg_solve: bad argument");
+    EngineSpec s;
+    s.K = 1; s.M = n_rows;
+    Pose id;
+    id.q[0] = id.q[1] = id.q[2] = 0; id.q[3] = 1; id.t[0] = id.t[1] = id.t[2] = 0;
+    std::vector<double> xs(3 * (size_t)n_rows);
+    for (int i = 0; i < n_rows; ++i) { xs[3 * i] = i; xs[3 * i + 1] = 0; xs[3 * i + 2] = 1; }
+    std::vector<int> lm_pose(n_rows, 0);
+    std::vector<float> uv(2 * (size_t)n_rows, 0.f);
+    std::vector<uint8_t> rflag(n_rows, 0);
+    s.poses = &id; s.x = xs.data(); s.lm_pose = lm_pose.data(); s.uv = uv.data(); s.rflag = rflag.data();
+    s.cam.model = NRS_CAM_PINHOLE;
+    for (int i = 0; i < 8; ++i) s.cam.p[i] = 1.f;
+    ba_constants(s, 1.f);
+    s.force_gather = true;
+    Engine* e = nullptr;
+    Arena arena;
+    nrs::Comm* keep = c->comm;
+    c->comm = nullptr;                                               // never sharded
+    int rc = engine_create(c, s, &arena, &e);
+    int it = 0, ok = 0;
+    if (rc == NRS_OK) rc = engine_debug_solve(c, e, Hpp21, bp, D6, Hpl18, bl, lambda, x, x + 6, &it, &ok);
+    if (e) engine_destroy(c, e);
+    arena_release(&arena);
+    c->comm = keep;
+    if (iters) *iters = it;
+    if (rc == NRS_OK && !ok) return c->fail(NRS_ERR_NUMERIC, "debug solve: not positive definite or not converged after %d iterations", it);
+    return rc;
 }

@@ -506,4 +506,49 @@ int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag) {
     return NRS_OK;
 }
 
+// Parity tap for the linear solve (a18): the reference's known-answer test hands its solver an explicit
+// block-sparse SPD matrix (third_party/g2o/unit_test/solver/linear_solver_test.cpp:72-85).  A matrix with one
+// 6x6 block coupled to 3x3 diagonal blocks is exactly what the stored-block operator path represents (H_pp,
+// H_pl, D), so the blocks are written where the lineariser would have put them and the product's own kernels
+// (k_trial_setup: inv3_sym / inv6_spd preconditioner, k_spmv, k_reduce_partials, k_pcg_update) solve it.
+int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,
+                       const double* bl, double lam, double* xp, double* xl, int* iters, int* ok) {
+    Dev& d = e->d;
+    if (d.K != 1 || d.use_lds || d.fused || d.sh_on) return c->fail(NRS_ERR_STATE, "debug solve: needs a single-pose, stored-block engine");
+    NRS_HIP(c, hipSetDevice(c->device));
+    const size_t nr = (size_t)d.n_rows;
+    std::vector<double> hD(6 * nr, 0.0), hH(18 * nr, 0.0), hb(3 * nr, 0.0);
+    for (size_t r = 0; r < nr; ++r) { hD[6 * r] = hD[6 * r + 3] = hD[6 * r + 5] = 1.0; }        // padding rows: identity (lam may be 0 here)
+    for (int v = 0; v < d.M; ++v) {
+        const size_t row = (size_t)e->vrow[v];
+        for (int k = 0; k < 6; ++k) hD[6 * row + k] = D6[6 * (size_t)v + k];
+        for (int k = 0; k < 18; ++k) hH[(size_t)k * nr + row] = Hpl18[18 * (size_t)v + k];      // component-major on the device
+        for (int k = 0; k < 3; ++k) hb[3 * row + k] = bl[3 * (size_t)v + k];
+    }
+    // rows of the caller are free variables; padding rows stay identity rows (zero blocks, zero right-hand side)
+    std::vector<uint8_t> rf(nr, RF_FIXED);
+    for (int v = 0; v < d.M; ++v) rf[e->vrow[v]] = 0;
+    NRS_HIP(c, hipMemcpyAsync(d.rflag, rf.data(), nr, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.D, hD.data(), sizeof(double) * hD.size(), hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.Hpl, hH.data(), sizeof(double) * hH.size(), hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.bl, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.Hpp, Hpp21, sizeof(double) * 21, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.bp, bp, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    int pit = 0;
+    bool done = false;
+    e->pred_iters = 0; e->pred_peek = 0;
+    NRS_TRY(pcg_begin(c, e, lam, &pit));
+    NRS_TRY(pcg_advance(c, e, lam, 0, &pit, &done));
+    if (iters) *iters = e->h_flags[1];
+    if (ok) *ok = e->h_flags[2] == 0 && e->h_flags[0] != 0;
+    std::vector<double> hx(3 * nr);
+    NRS_HIP(c, hipMemcpyAsync(xp, d.xp, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(hx.data(), d.xv, sizeof(double) * hx.size(), hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    for (int v = 0; v < d.M; ++v)
+        for (int k = 0; k < 3; ++k) xl[3 * (size_t)v + k] = hx[3 * (size_t)e->vrow[v] + k];
+    return NRS_OK;
+}
+
 }  // namespace nrs

@@ -43,6 +43,7 @@ struct EngineSpec {
     double k_spring = 0;
     int spring_form = 0;                  // 0: BA Jacobian as written, 1: tracking form
     bool shard = false;                   // split the poses over the ranks of the context's communicator (BA windows only)
+    bool force_gather = false;            // stored-block operator (k_spmv gather path) instead of the LDS-staged factored one
 };
 
 struct Engine;
@@ -58,6 +59,10 @@ int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x);      // call
 int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring /*n_sp*/, double* damper /*n_dm*/);
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
 int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);       // solver order, caller vertex order
+// parity tap: (H + lam I) x = b for explicitly given blocks (one pose, M landmark rows, no regularisers) through
+// the engine's own PCG kernels; the engine must have been created with force_gather and K = 1
+int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,
+                       const double* bl, double lam, double* xp, double* xl, int* iters, int* ok);
 void arena_release(Arena* a);
 void shard_plan(int K, const int* grp_ptr, int world, int* kb);     // contiguous keyframe ranges, balanced by rows
 int engine_num_poses(const Engine* e);

@@ -59,6 +59,8 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
     const int32_t cap_s = *n_spring, cap_d = *n_damper;
     for (int32_t i = 0; i < kf_rowptr[n_kf]; ++i)
         if (kf_pt[i] < 0 || kf_pt[i] >= n_points) return NRS_ERR_INVALID;
+    for (int32_t i = 0; i < (n_points > 0 ? nbr_rowptr[n_points] : 0); ++i)    // both edge loops index cur[] / nxt[] with these
+        if (nbr_col[i] < 0 || nbr_col[i] >= n_points) return NRS_ERR_INVALID;
 
     // inserted_landmarks[kf][mappoint] -> landmark index (OPT:927-952), two rolling rows suffice
     std::vector<int32_t> cur(n_points, -1), nxt(n_points, -1);
@@ -84,7 +86,6 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
             for (int32_t e = lo; e < hi; ++e) {                                     // OPT:1033-1074
                 if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
                 const int32_t o = nbr_col[e];
-                if (o < 0 || o >= n_points) return NRS_ERR_INVALID;
                 if (cur[o] < 0) continue;
                 if (!spring_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
                 if (fill) {

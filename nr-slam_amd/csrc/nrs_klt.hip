@@ -447,11 +447,17 @@ static int reserve_points(nrs_ctx* c, KltState* k, int n, bool keep) {
     const int cap = std::max(n + n / 2, 256);
     const size_t L = (size_t)k->levels;
     DevBuf nI, nD, nM, nV, nP;
-    NRS_TRY(c->ensure(nI, sizeof(short) * KA * L * cap));
-    NRS_TRY(c->ensure(nD, sizeof(short2) * KA * L * cap));
-    NRS_TRY(c->ensure(nM, sizeof(float) * 2 * L * cap));
-    NRS_TRY(c->ensure(nV, L * cap));
-    NRS_TRY(c->ensure(nP, sizeof(float) * 2 * cap));
+    {
+        int rc = c->ensure(nI, sizeof(short) * KA * L * cap);
+        if (rc == NRS_OK) rc = c->ensure(nD, sizeof(short2) * KA * L * cap);
+        if (rc == NRS_OK) rc = c->ensure(nM, sizeof(float) * 2 * L * cap);
+        if (rc == NRS_OK) rc = c->ensure(nV, L * cap);
+        if (rc == NRS_OK) rc = c->ensure(nP, sizeof(float) * 2 * cap);
+        if (rc != NRS_OK) {                                        // nothing of a half-made set is kept
+            c->release(nI); c->release(nD); c->release(nM); c->release(nV); c->release(nP);
+            return rc;
+        }
+    }
     if (keep && k->n > 0) {
         const size_t m = (size_t)k->n;
         NRS_HIP(c, hipMemcpyAsync(nI.p, k->tI.p, sizeof(short) * KA * L * m, hipMemcpyDeviceToDevice, c->stream));
@@ -478,6 +484,12 @@ extern "C" int nrs_klt_configure(nrs_ctx* c, const nrs_klt_config* cfg) {
     KltState* k = klt(c);
     if (!k) return c->fail(NRS_ERR_ALLOC, "out of host memory");
     if (k->n > 0 && cfg->max_level != k->max_level) return c->fail(NRS_ERR_STATE, "cannot change max_level while templates are stored (call nrs_klt_clear)");
+    if (cfg->max_level + 1 != k->levels && k->cap > 0) {
+        // the template buffers are sized cap x levels: another level count invalidates them (k->n == 0 here)
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        c->release(k->tI); c->release(k->tD); c->release(k->tMean); c->release(k->tValid); c->release(k->prev);
+        k->cap = 0;
+    }
     k->max_level = cfg->max_level; k->levels = cfg->max_level + 1;
     k->max_iters = cfg->max_iters; k->eps = cfg->epsilon; k->min_eig = cfg->min_eig_threshold;
     return NRS_OK;

@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_debug_pcg_solve",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -445,6 +445,19 @@ class Context:
         rd = np.zeros((self._n_dm, 3), np.float64)
         self._chk(self.lib.nrs_dba_residuals(self.h, _p(rr, C.c_double), _p(rs, C.c_double), _p(rd, C.c_double)))
         return rr, rs, rd
+
+    def debug_pcg_solve(self, Hpp21, bp, D6, Hpl18, bl, lam=0.0):
+        """include/nrs.h nrs_debug_pcg_solve: returns (x[6 + 3n], PCG iterations)."""
+        D6 = np.ascontiguousarray(D6, np.float64).reshape(-1, 6)
+        n = len(D6)
+        Hpp21, bp = np.ascontiguousarray(Hpp21, np.float64), np.ascontiguousarray(bp, np.float64)
+        Hpl18 = np.ascontiguousarray(Hpl18, np.float64).reshape(n, 18)
+        bl = np.ascontiguousarray(bl, np.float64).reshape(n, 3)
+        x = np.zeros(6 + 3 * n, np.float64)
+        it = C.c_int32(0)
+        self._chk(self.lib.nrs_debug_pcg_solve(self.h, C.c_int32(n), _p(Hpp21, C.c_double), _p(bp, C.c_double), _p(D6, C.c_double),
+                                               _p(Hpl18, C.c_double), _p(bl, C.c_double), C.c_double(lam), _p(x, C.c_double), C.byref(it)))
+        return x, it.value
 
     def dba_gradient(self):
         n = 6 * self._n_kf + 3 * self._n_lm

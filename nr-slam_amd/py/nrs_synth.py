@@ -427,3 +427,15 @@ def make_frame_sequence(n_points=400, n_frames=6, seed=9, model=PINHOLE, step=0.
                 kp0=uv0[idx].astype(F32), X0=X0, graph=graph,
                 pose_q=[_R_to_quat(R).astype(F32) for R in poses_R], pose_t=[t.astype(F32) for t in poses_t],
                 uv_true=[u[idx].astype(F32) for u in uvt], X_true=[x[idx] for x in Xt])
+
+
+def edge_checksum(e):
+    """order-sensitive 64-bit checksum of a BA edge list (sp_ij, sp_d0, dm_idx, dm_w): golden files carry it so that
+    a trace is only ever compared on the edge list it was computed from"""
+    import zlib
+    h = 0
+    for key in ("sp_ij", "sp_d0", "dm_idx", "dm_w"):
+        a = np.ascontiguousarray(e[key])
+        a = a.astype(np.int32) if a.dtype.kind == "i" else a.astype(np.float32)
+        h = (h * 1000003 + zlib.crc32(a.tobytes())) & 0xFFFFFFFFFFFF
+    return int(h)

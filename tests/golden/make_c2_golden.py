@@ -51,8 +51,18 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C2"
     p = S.make_dba_problem(name)
     nb = p["nbr"]
-    import nrs
-    e = nrs.dba_build_edges(p["kf_points"], nb)          # host builder == oracle builder (tests/test_host_cpu.py)
+    e = O.dba_build(p["kf_points"], nb["rowptr"], nb["col"], nb["w"], nb["d0"], nb["status"])   # the oracle's own edge list
+    out = os.path.join(HERE, "dba_%s_trace.npz" % name)
+    stamp = dict(n_sp=len(e["sp_ij"]), n_dm=len(e["dm_idx"]), edge_checksum=S.edge_checksum(e))
+    if "--stamp-edges" in sys.argv:
+        # the solve below takes ~7 minutes; when only the provenance of the edge list changed (it used to come from
+        # the product's host builder, which tests/test_host_cpu.py holds equal to the oracle's at this size) the
+        # existing trace stays valid and just receives the oracle edge list's size and checksum
+        old = dict(np.load(out))
+        old.update(stamp)
+        np.savez_compressed(out, **old)
+        print("stamped", out, stamp)
+        return
     t0 = time.time()
     tr = []
     q, t, pts, nit = O.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"], p["lm_uv"],
@@ -60,10 +70,10 @@ def main():
                                  solver=make_pcg_solver(6 * p["n_kf"]))
     print("oracle %s: %d LM iterations, %d trials, %.0f s" % (name, nit, len(tr), time.time() - t0))
     sel = np.linspace(0, len(pts) - 1, 2000).astype(np.int64)
-    np.savez_compressed(os.path.join(HERE, "dba_%s_trace.npz" % name), out_q=q, out_t=t, out_iters=nit,
+    np.savez_compressed(out, out_q=q, out_t=t, out_iters=nit,
                         out_accepted=np.array([x["accepted"] for x in tr]), out_chi=np.array([x["chi"] for x in tr]),
                         out_chi_new=np.array([x["chi_new"] for x in tr]), out_lam=np.array([x["lam"] for x in tr]),
-                        sel=sel, out_pts_sel=pts[sel], out_pts_sum=pts.sum(0), n_lm=len(pts))
+                        sel=sel, out_pts_sel=pts[sel], out_pts_sum=pts.sum(0), n_lm=len(pts), **stamp)
     for x in tr:
         print(x["iter"], x["trial"], x["accepted"], "%.6e %.6e" % (x["chi"], x["chi_new"]))
 

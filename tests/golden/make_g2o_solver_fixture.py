@@ -3,6 +3,8 @@
 Source of the DATA (not code): the string/number literals of
 /root/reference/third_party/g2o/unit_test/solver/sparse_system_helper.cpp
   :52-149  block-sparse SPD matrix (upper-triangular blocks, 12 x 12 blocks of 3 x 3)
+  :151-194 dense inverse of that matrix (36 x 36), used by the reference's SolvePattern / SolveBlocks tests
+           (linear_solver_test.cpp:88-140)
   :255     right-hand side b (createTestVectorB)
   :298     expected solution x (createTestVectorX)
 checked there by linear_solver_test.cpp:72-85 with isApprox(1e-6).
@@ -39,7 +41,11 @@ def main():
 
     b, x = vec("createTestVectorB"), vec("createTestVectorX")
     assert len(b) == 36 and len(x) == 36 and rbi[-1] == 36
-    json.dump(dict(source=SRC + ":52-149,255,298", block_offsets=rbi, blocks=blocks, b=b, x=x, tol=1e-6),
+    ibody = txt[txt.index("std::string denseInverseMatrixString()"):]
+    ibody = ibody[:ibody.index("return aux.str();")]
+    inv = [[float(v) for v in ln.split()] for ln in re.findall(r'aux << "([^"#]*)"', ibody) if ln.strip()]
+    assert len(inv) == 36 and all(len(r) == 36 for r in inv)
+    json.dump(dict(source=SRC + ":52-149,151-194,255,298", block_offsets=rbi, blocks=blocks, b=b, x=x, inverse=inv, tol=1e-6),
               open(OUT, "w"), indent=0)
     print("wrote", OUT, len(blocks), "blocks")
 

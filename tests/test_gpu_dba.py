@@ -147,7 +147,10 @@ def test_full_size_c2_matches_oracle_golden(ctx, ctx_exact, exact):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dba_C2_trace.npz"))
     c = ctx_exact if exact else ctx
     p = S.make_dba_problem("C2")
-    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    nb = p["nbr"]
+    e = O.dba_build(p["kf_points"], nb["rowptr"], nb["col"], nb["w"], nb["d0"], nb["status"])    # the ORACLE's edge list
+    assert int(g["n_sp"]) == len(e["sp_ij"]) and int(g["n_dm"]) == len(e["dm_idx"])
+    assert int(g["edge_checksum"]) == S.edge_checksum(e)
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     assert len(p["lm_kf"]) == int(g["n_lm"])

@@ -49,10 +49,11 @@ def test_pose_only_matches_oracle_pinhole(ctx, n, seed):
 def test_pose_only_kb8(ctx):
     tp, uv, X = _problem(800, 4, S.KB8)
     (q, t, inl, tr), (q2, t2, inl2, otr) = _compare(ctx, tp, uv, X)
-    # device atan2f/sinf/cosf differ from the host libm in the last ulp: tolerance-level parity
+    # atan2f / sinf / cosf are defined on both sides as the double routine rounded to float,
+    # so KB8 holds the pinhole bar: identical inlier mask
     assert np.allclose(q, q2, atol=1e-6, rtol=0)
     assert np.allclose(t, t2, atol=1e-5, rtol=0)
-    assert np.mean(inl == inl2) > 0.995
+    assert np.array_equal(inl, inl2)
 
 
 def test_pose_only_edge_cases(ctx):

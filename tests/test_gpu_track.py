@@ -111,8 +111,13 @@ def test_track_deform_kb8(ctx):
     tp, r, o, tr, otr = _track_compare(ctx, 400, 21, S.KB8)
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
     assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
-    assert np.mean(r["f_status"] == o["f_status"]) > 0.99
+    # KB8 trigonometry is defined on both sides as the double routine rounded to float: the
+    # classification is then as exact as the pinhole one
+    assert np.array_equal(r["f_status"], o["f_status"])
+    assert r["lost"] == o["lost"]
     assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-4, rtol=0)
+    assert np.allclose(r["map_pos"], o["map_pos"], atol=1e-4, rtol=0)
+    assert np.array_equal(r["graph"]["e_status"], o["graph"]["e_status"])
 
 
 def test_track_deform_no_lost_points(ctx):

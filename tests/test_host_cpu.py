@@ -52,6 +52,20 @@ def test_edge_builder_matches_oracle(lib_built, n, k, seed, bad):
         assert len(e["dm_idx"]) == 0
 
 
+def test_edge_builder_matches_oracle_full_size_c2(lib_built):
+    """BASELINE configs[1] at full size (91 749 landmarks, 570k springs, 513k dampers): the product's host builder
+    against the oracle's restatement of OPT:927-1137, index for index.  The C2 golden and the GPU tests feed the
+    ORACLE's edge list; this is what makes the product's equal to it."""
+    nrs = lib_built
+    p = S.make_dba_problem("C2")
+    g = p["nbr"]
+    eo = O.dba_build(p["kf_points"], g["rowptr"], g["col"], g["w"], g["d0"], g["status"])
+    e = nrs.dba_build_edges(p["kf_points"], g)
+    for key in ("sp_ij", "sp_d0", "dm_idx", "dm_w"):
+        assert np.array_equal(e[key], eo[key]), key
+    assert np.array_equal(eo["lm_kf"], p["lm_kf"]) and len(eo["sp_ij"]) > 500000
+
+
 def test_edge_builder_rejects_bad_input(lib_built):
     nrs = lib_built
     p = S.make_dba_problem(60, 2, 5)
