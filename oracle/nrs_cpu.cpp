@@ -1,0 +1,1010 @@
+// CPU restatement of the reference's deformable bundle adjustment in C++ -- TEST INFRASTRUCTURE ONLY.
+//
+// What it is: the timed CPU baseline (bench.py cpu_baseline leg) and a second, independently written checker
+// next to oracle/nrs_oracle.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// it; nothing under nr-slam_amd/ does.  Built by oracle/Makefile with g++ (-O3 -march=native -fopenmp) into
+// oracle/_build/libnrs_cpu.so.
+//
+// What it follows (file:line under /root/reference):
+//   LocalDeformableBundleAdjustment              modules/optimization/g2o_optimization.cc:880-1161
+//   ReprojectionError                            modules/optimization/reprojection_error.cc:32-64
+//   PositionRegularizer (Jacobian as written)    modules/optimization/position_regularizer.cc:32-61
+//   SpatialRegularizer (4 vertices)              modules/optimization/spatial_regularizer.cc:32-59
+//   PinHole / KannalaBrandt8 in fp32             modules/calibration/pin_hole.cc:27-49, kannala_brandt_8.cc:34-51,87-116,
+//                                                camera_model.h:89-95,131-137 (double -> float -> double)
+//   Huber, quadratic form without rho''          third_party/g2o/g2o/core/robust_kernel_impl.cpp:60-74,
+//                                                base_fixed_sized_edge.hpp:49-63,92-133, base_edge.h:158-164
+//   Levenberg-Marquardt                          third_party/g2o/g2o/core/optimization_algorithm_levenberg.cpp:57-174
+//   SE3Quat::exp, operator*, VertexSE3Expmap     third_party/g2o/g2o/types/slam3d/se3quat.h:96-102,201-229,
+//                                                types/sba/vertex_se3_expmap.cpp:48-51
+//   linear solve                                 third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-173:
+//                                                full (no Schur) sparse Cholesky of H + lambda I, fill-reducing
+//                                                ordering computed on the BLOCK pattern, symbolic step once per
+//                                                optimize(), numeric factorisation per LM trial.
+// Eigen is not in this image, so the factorisation is this file's own: an approximate-minimum-degree ordering
+// of the 3x3-block graph (pose vertices = two 3-blocks, ordered last) and an up-looking block Cholesky; the
+// solution of an SPD system is unique, so this is parity-neutral.  solver = 1 replaces the factorisation by
+// block-Jacobi PCG (OpenMP over block rows) -- not what the reference does, but the faster CPU algorithm on
+// windows far beyond the reference's 5-keyframe cap, and the one that runs C2 within a bench-sized budget.
+//
+// Parity pinning: as oracle/nrs_oracle.py -- the reference cannot be built here (Eigen3 / OpenCV absent), so this
+// restatement is pinned by g2o's 36x36 known-answer system through its Cholesky (tests/test_oracle_cpp_cpu.py)
+// and is otherwise "parity unpinned"; it is held to the NumPy oracle and to the committed goldens.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+using std::vector;
+typedef double B3[9];   // 3x3 block, row-major
+
+struct Pose { double q[4], t[3]; };
+
+// ------------------------------------------------------------------------------------------------ SE(3)
+void quat_normalize(double* q) {
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+void quat_mul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+void quat_to_R(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// Eigen QuaternionBase::_transformVector (what SE3Quat::map evaluates): v + w uv + qv x uv, uv = 2 qv x v
+void quat_rotate(const double* q, const double* v, double* o) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+void R_to_quat(const double R[9], double* q) {                      // Eigen's rotation matrix -> quaternion
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+}
+// pose <- exp([omega, upsilon]) * pose   (se3quat.h:201-229, :96-102; vertex_se3_expmap.cpp:48-51)
+void pose_oplus(Pose& P, const double* upd) {
+    const double wx = upd[0], wy = upd[1], wz = upd[2];
+    const double theta = std::sqrt(wx * wx + wy * wy + wz * wz);
+    const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double Om2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += Om[3 * i + k] * Om[3 * k + j]; Om2[3 * i + j] = s; }
+    double a, b, c, d;
+    if (theta < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
+    else { a = std::sin(theta) / theta; b = (1 - std::cos(theta)) / (theta * theta); c = b; d = (theta - std::sin(theta)) / (theta * theta * theta); }
+    double R[9], V[9];
+    for (int i = 0; i < 9; ++i) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R[i] = id + a * Om[i] + b * Om2[i]; V[i] = id + c * Om[i] + d * Om2[i]; }
+    double qe[4], te[3], rt[3], qn[4];
+    R_to_quat(R, qe);
+    quat_normalize(qe);
+    for (int i = 0; i < 3; ++i) te[i] = V[3 * i] * upd[3] + V[3 * i + 1] * upd[4] + V[3 * i + 2] * upd[5];
+    quat_rotate(qe, P.t, rt);
+    quat_mul(qe, P.q, qn);
+    quat_normalize(qn);
+    for (int i = 0; i < 3; ++i) P.t[i] = te[i] + rt[i];
+    for (int i = 0; i < 4; ++i) P.q[i] = qn[i];
+}
+
+// ------------------------------------------------------------------------------------------------ cameras, fp32
+// (compiled with -ffp-contract=off: the reference builds with -O3 only, no FMA contraction on x86-64 baseline;
+//  atan2f / cosf / sinf are taken as the double routine rounded to float, the convention shared with the device
+//  and the NumPy oracle)
+__attribute__((optimize("fp-contract=off"))) void project_f32(int model, const float* p, float x, float y, float z, float& u, float& v) {
+    if (model == 0) { u = p[0] * x / z + p[2]; v = p[1] * y / z + p[3]; return; }
+    const float r2 = x * x + y * y;
+    const float th = (float)std::atan2((double)std::sqrt(r2), (double)z);
+    const float psi = (float)std::atan2((double)y, (double)x);
+    const float th2 = th * th, th3 = th * th2, th5 = th3 * th2, th7 = th5 * th2, th9 = th7 * th2;
+    const float r = th + p[4] * th3 + p[5] * th5 + p[6] * th7 + p[7] * th9;
+    u = p[0] * r * (float)std::cos((double)psi) + p[2];
+    v = p[1] * r * (float)std::sin((double)psi) + p[3];
+}
+__attribute__((optimize("fp-contract=off"))) void projjac_f32(int model, const float* p, float x, float y, float z, float* J) {
+    if (model == 0) {
+        J[0] = p[0] / z; J[1] = 0.f; J[2] = -p[0] * x / (z * z);
+        J[3] = 0.f; J[4] = p[1] / z; J[5] = -p[1] * y / (z * z);
+        return;
+    }
+    const float fx = p[0], fy = p[1], k0 = p[4], k1 = p[5], k2 = p[6], k3 = p[7];
+    const float x2 = x * x, y2 = y * y, z2 = z * z, r2 = x2 + y2, r = std::sqrt(r2), r3 = r2 * r;
+    const float th = (float)std::atan2((double)r, (double)z);
+    const float th2 = th * th, th3 = th2 * th, th4 = th2 * th2, th5 = th4 * th, th6 = th2 * th4, th7 = th6 * th, th8 = th4 * th4, th9 = th8 * th;
+    const float f = th + th3 * k0 + th5 * k1 + th7 * k2 + th9 * k3;
+    const float fd = 1 + 3 * k0 * th2 + 5 * k1 * th4 + 7 * k2 * th6 + 9 * k3 * th8;
+    J[0] = fx * (fd * z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+    J[1] = fx * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+    J[2] = -fx * fd * x / (r2 + z2);
+    J[3] = fy * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+    J[4] = fy * (fd * z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+    J[5] = -fy * fd * y / (r2 + z2);
+}
+
+inline void huber(double e, double delta, double& rho0, double& rho1) {      // delta <= 0: no kernel
+    const double dsqr = delta * delta;
+    if (delta <= 0 || e <= dsqr) { rho0 = e; rho1 = 1.0; }
+    else { const double sq = std::sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ================================================================================================
+// symmetric block-sparse matrix, 3x3 blocks, full pattern in CSR with sorted columns (both triangles)
+// ================================================================================================
+struct BlockMat {
+    int n = 0;
+    vector<int64_t> ptr;
+    vector<int> col;
+    vector<double> val;              // 9 per block
+    vector<int64_t> diag;            // position of (i, i)
+    int64_t find(int r, int c) const {
+        const int* b = col.data() + ptr[r];
+        const int* e = col.data() + ptr[r + 1];
+        const int* p = std::lower_bound(b, e, c);
+        return (p != e && *p == c) ? (int64_t)(p - col.data()) : -1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// approximate minimum degree on the block graph (quotient graph with element absorption and the
+// |Le \ Lp| degree bound; no supervariables).  `last` vertices (the pose blocks: dense rows) are
+// left out of the graph and ordered last, which is what an ordering does with dense rows anyway.
+// Returns perm: perm[new] = old.
+// ------------------------------------------------------------------------------------------------
+vector<int> amd_order(const BlockMat& A, const vector<uint8_t>& is_last) {
+    const int n = A.n;
+    vector<vector<int>> adj(n), el(n), Le(n);
+    vector<int> state(n, 0);                       // 0 variable, 1 element, 2 dead element, 3 excluded
+    int n_live = 0;
+    for (int i = 0; i < n; ++i) {
+        if (is_last[i]) { state[i] = 3; continue; }
+        ++n_live;
+        for (int64_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p) { const int j = A.col[p]; if (j != i && !is_last[j]) adj[i].push_back(j); }
+    }
+    vector<int> deg(n, 0), w(n, 0), wtag(n, -1), mark(n, -1);
+    typedef std::pair<int, int> DI;
+    std::priority_queue<DI, vector<DI>, std::greater<DI>> heap;
+    for (int i = 0; i < n; ++i) if (state[i] == 0) { deg[i] = (int)adj[i].size(); heap.push(DI(deg[i], i)); }
+    vector<int> perm;
+    perm.reserve(n);
+    vector<int> Lp;
+    int tag = 0;
+    while (n_live > 0) {
+        DI top = heap.top();
+        heap.pop();
+        const int p = top.second;
+        if (state[p] != 0 || top.first != deg[p]) continue;         // stale entry
+        // ---- new element: Lp = (adj[p] U union of the element lists of p) \ {p}
+        Lp.clear();
+        ++tag;
+        mark[p] = tag;
+        for (int v : adj[p]) if (state[v] == 0 && mark[v] != tag) { mark[v] = tag; Lp.push_back(v); }
+        for (int e : el[p]) {
+            if (state[e] != 1) continue;
+            for (int v : Le[e]) if (state[v] == 0 && mark[v] != tag) { mark[v] = tag; Lp.push_back(v); }
+            state[e] = 2;                                           // absorbed
+            vector<int>().swap(Le[e]);
+        }
+        state[p] = 1;
+        perm.push_back(p);
+        --n_live;
+        vector<int>().swap(adj[p]);
+        vector<int>().swap(el[p]);
+        // ---- w[e] = |Le \ Lp| for every element next to a variable of Lp
+        for (int u : Lp)
+            for (int e : el[u]) {
+                if (state[e] != 1) continue;
+                if (wtag[e] != tag) { wtag[e] = tag; w[e] = (int)Le[e].size(); }
+                --w[e];
+            }
+        const int lp = (int)Lp.size();
+        for (int u : Lp) {
+            // prune the element list (dead ones, and those swallowed by the new element)
+            int64_t dsum = 0;
+            size_t k = 0;
+            for (int e : el[u]) {
+                if (state[e] != 1) continue;
+                if (w[e] == 0) {                                    // Le subset of Lp: aggressive absorption
+                    state[e] = 2;
+                    vector<int>().swap(Le[e]);
+                    continue;
+                }
+                el[u][k++] = e;
+                dsum += w[e];
+            }
+            el[u].resize(k);
+            // prune the variable list: eliminated vertices, and members of Lp (now covered by element p)
+            k = 0;
+            for (int v : adj[u]) if (state[v] == 0 && mark[v] != tag) adj[u][k++] = v;
+            adj[u].resize(k);
+            el[u].push_back(p);
+            int64_t d = (int64_t)adj[u].size() + (lp - 1) + dsum;
+            if (d > n_live - 1) d = n_live - 1;
+            deg[u] = (int)d;
+            heap.push(DI(deg[u], u));
+        }
+        Le[p] = Lp;
+    }
+    for (int i = 0; i < n; ++i) if (state[i] == 3) perm.push_back(i);
+    return perm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// up-looking block Cholesky  L L^T = A + lambda I  (A symmetric, full CSR with sorted columns).
+// Row k of L is computed from rows < k:  L_ki = (A_ki - sum_j L_kj L_ij^T) L_ii^-T ; the pattern of row k
+// is the reach of the entries of A(k, 0:k) in the elimination tree.
+// ------------------------------------------------------------------------------------------------
+struct BlockChol {
+    int n = 0;
+    vector<int> parent;
+    vector<int64_t> cptr;            // column pointers of L (strictly lower part)
+    vector<int> rowi;                // row index per stored block
+    vector<double> Lx;               // 9 per block: L(row, col)
+    vector<double> Ld;               // 9 per column: diagonal block (lower triangular)
+    vector<int64_t> fill_pos;        // next free slot per column (numeric phase)
+    double flops = 0;                // of one numeric factorisation (multiply-adds x 2)
+    int64_t nnz_blocks = 0;
+
+    static int ereach(const BlockMat& A, int k, const vector<int>& parent, vector<int>& s, vector<int>& w, int n) {
+        int top = n;
+        w[k] = k;
+        for (int64_t p = A.ptr[k]; p < A.ptr[k + 1]; ++p) {
+            int i = A.col[p];
+            if (i >= k) break;                                       // sorted columns: lower part of row k only
+            int len = 0;
+            for (; w[i] != k; i = parent[i]) { s[len++] = i; w[i] = k; }
+            while (len > 0) s[--top] = s[--len];
+        }
+        return top;
+    }
+    void analyze(const BlockMat& A) {
+        n = A.n;
+        parent.assign(n, -1);
+        vector<int> anc(n, -1);
+        for (int k = 0; k < n; ++k)                                 // elimination tree (Liu), path compression
+            for (int64_t p = A.ptr[k]; p < A.ptr[k + 1]; ++p) {
+                int i = A.col[p];
+                if (i >= k) break;
+                while (i != -1 && i < k) { const int nx = anc[i]; anc[i] = k; if (nx == -1) parent[i] = k; i = nx; }
+            }
+        vector<int> s(n), w(n, -1);
+        vector<int64_t> cnt(n, 0);
+        flops = 0;
+        for (int k = 0; k < n; ++k) {
+            const int top = ereach(A, k, parent, s, w, n);
+            for (int t = top; t < n; ++t) cnt[s[t]]++;
+        }
+        cptr.assign(n + 1, 0);
+        for (int i = 0; i < n; ++i) cptr[i + 1] = cptr[i] + cnt[i];
+        nnz_blocks = cptr[n];
+        for (int i = 0; i < n; ++i) flops += 54.0 * ((double)cnt[i] * (double)(cnt[i] + 3) / 2.0 + 1.0);   // 27 fma per block product
+        fill_pos.assign(n, 0);                                       // (L itself is allocated by the first factor())
+    }
+    // returns false when a pivot block is not positive definite
+    bool factor(const BlockMat& A, double lam) {
+        vector<int> s(n), w(n, -1);
+        vector<double> x(9 * (size_t)n, 0.0);
+        if (rowi.size() != (size_t)nnz_blocks) {
+            rowi.assign((size_t)nnz_blocks, 0);
+            Lx.assign(9 * (size_t)nnz_blocks, 0.0);
+            Ld.assign(9 * (size_t)n, 0.0);
+        }
+        for (int i = 0; i < n; ++i) fill_pos[i] = cptr[i];
+        for (int k = 0; k < n; ++k) {
+            const int top = ereach(A, k, parent, s, w, n);
+            double d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t p = A.ptr[k]; p < A.ptr[k + 1]; ++p) {
+                const int i = A.col[p];
+                if (i > k) break;
+                const double* a = &A.val[9 * (size_t)p];
+                if (i == k) { for (int q = 0; q < 9; ++q) d[q] = a[q]; d[0] += lam; d[4] += lam; d[8] += lam; }
+                else { double* xi = &x[9 * (size_t)i]; for (int q = 0; q < 9; ++q) xi[q] = a[q]; }     // A(k, i)
+            }
+            for (int t = top; t < n; ++t) {
+                const int i = s[t];
+                double* xi = &x[9 * (size_t)i];
+                // L_ki = x_i L_ii^-T : solve Y L_ii^T = x_i row by row (L_ii lower triangular)
+                const double* Li = &Ld[9 * (size_t)i];
+                double lk[9];
+                for (int r = 0; r < 3; ++r) {
+                    const double y0 = xi[3 * r] / Li[0];
+                    const double y1 = (xi[3 * r + 1] - y0 * Li[3]) / Li[4];
+                    const double y2 = (xi[3 * r + 2] - y0 * Li[6] - y1 * Li[7]) / Li[8];
+                    lk[3 * r] = y0; lk[3 * r + 1] = y1; lk[3 * r + 2] = y2;
+                }
+                for (int q = 0; q < 9; ++q) xi[q] = 0.0;
+                // x_r -= L_ki L_ri^T for the rows r already stored in column i (all of them are < k)
+                const int64_t p0 = cptr[i], p1 = fill_pos[i];
+                for (int64_t p = p0; p < p1; ++p) {
+                    const double* lr = &Lx[9 * (size_t)p];
+                    double* xr = &x[9 * (size_t)rowi[p]];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b)
+                            xr[3 * a + b] -= lk[3 * a] * lr[3 * b] + lk[3 * a + 1] * lr[3 * b + 1] + lk[3 * a + 2] * lr[3 * b + 2];
+                }
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        d[3 * a + b] -= lk[3 * a] * lk[3 * b] + lk[3 * a + 1] * lk[3 * b + 1] + lk[3 * a + 2] * lk[3 * b + 2];
+                rowi[p1] = k;
+                for (int q = 0; q < 9; ++q) Lx[9 * (size_t)p1 + q] = lk[q];
+                fill_pos[i] = p1 + 1;
+            }
+            // diagonal block: 3x3 Cholesky
+            double* Lk = &Ld[9 * (size_t)k];
+            if (!(d[0] > 0)) return false;
+            Lk[0] = std::sqrt(d[0]); Lk[1] = 0; Lk[2] = 0;
+            Lk[3] = d[3] / Lk[0];
+            const double e = d[4] - Lk[3] * Lk[3];
+            if (!(e > 0)) return false;
+            Lk[4] = std::sqrt(e); Lk[5] = 0;
+            Lk[6] = d[6] / Lk[0];
+            Lk[7] = (d[7] - Lk[6] * Lk[3]) / Lk[4];
+            const double g = d[8] - Lk[6] * Lk[6] - Lk[7] * Lk[7];
+            if (!(g > 0)) return false;
+            Lk[8] = std::sqrt(g);
+        }
+        return true;
+    }
+    void solve(const double* b, double* xo) const {                   // L L^T x = b
+        vector<double> y(b, b + 3 * (size_t)n);
+        for (int j = 0; j < n; ++j) {                                 // forward, column oriented
+            const double* L = &Ld[9 * (size_t)j];
+            double* yj = &y[3 * (size_t)j];
+            yj[0] = yj[0] / L[0];
+            yj[1] = (yj[1] - L[3] * yj[0]) / L[4];
+            yj[2] = (yj[2] - L[6] * yj[0] - L[7] * yj[1]) / L[8];
+            for (int64_t p = cptr[j]; p < cptr[j + 1]; ++p) {
+                const double* l = &Lx[9 * (size_t)p];
+                double* yr = &y[3 * (size_t)rowi[p]];
+                for (int a = 0; a < 3; ++a) yr[a] -= l[3 * a] * yj[0] + l[3 * a + 1] * yj[1] + l[3 * a + 2] * yj[2];
+            }
+        }
+        for (int j = n - 1; j >= 0; --j) {                            // backward: x_j = L_jj^-T (y_j - sum_r L_rj^T x_r)
+            double* yj = &y[3 * (size_t)j];
+            for (int64_t p = cptr[j]; p < cptr[j + 1]; ++p) {
+                const double* l = &Lx[9 * (size_t)p];
+                const double* xr = &y[3 * (size_t)rowi[p]];
+                for (int a = 0; a < 3; ++a) yj[a] -= l[a] * xr[0] + l[3 + a] * xr[1] + l[6 + a] * xr[2];
+            }
+            const double* L = &Ld[9 * (size_t)j];
+            yj[2] = yj[2] / L[8];
+            yj[1] = (yj[1] - L[7] * yj[2]) / L[4];
+            yj[0] = (yj[0] - L[3] * yj[1] - L[6] * yj[2]) / L[0];
+        }
+        std::memcpy(xo, y.data(), sizeof(double) * 3 * (size_t)n);
+    }
+};
+
+// ================================================================================================
+// the BA graph
+// ================================================================================================
+struct Stats {                 // mirrored by the ctypes structure in tests / bench
+    double t_total, t_linearize, t_analyze, t_factor, t_solve, t_errors, t_structure;
+    double chol_flops;         // per numeric factorisation
+    int64_t chol_blocks;       // 3x3 blocks of L below the diagonal
+    int64_t h_blocks;          // 3x3 blocks of H (full pattern)
+    int32_t n_factor, n_pcg_iters, n_trials, n_iters, threads, unknowns;
+};
+
+struct Trial { int32_t iter, trial, accepted, ok, inner; double lam, chi, chi_new, rho; };
+
+struct Graph {
+    int model = 0;
+    float prm[8];
+    int K = 0, M = 0;
+    vector<Pose> pose, pose_bak;
+    vector<double> x, x_bak;          // 3 M landmark estimates
+    const int32_t* lm_kf = nullptr;
+    vector<double> uv;                // 2 M
+    int n_sp = 0, n_dm = 0;
+    const int32_t* sp_ij = nullptr; const float* sp_d0 = nullptr;
+    const int32_t* dm_idx = nullptr; const float* dm_w = nullptr;
+    double info_reproj, delta_reproj, info_pos, info_spatial, delta_spatial, k_spring;
+    // unknown layout: block 2k, 2k+1 = pose k (omega, upsilon); block 2K + i = landmark i; pinv: natural -> permuted
+    int nb = 0;
+    vector<int> pinv;
+    BlockMat H;
+    vector<double> b;
+    // per-edge slots into H.val (positions of 3x3 blocks)
+    vector<int64_t> slot_r;           // per landmark: (a,a) (a,b) (b,a) (b,b) (a,l) (l,a) (b,l) (l,b) (l,l)
+    vector<int64_t> slot_s;           // per spring: (i,i) (i,j) (j,i) (j,j)
+    vector<int64_t> slot_d;           // per damper: 16 = (va, vb) row-major over the 4 vertices
+    int threads = 1;
+
+    double chi2() const {
+        double chi = 0;
+#pragma omp parallel for reduction(+ : chi) schedule(static) num_threads(threads)
+        for (int i = 0; i < M; ++i) {
+            const Pose& T = pose[lm_kf[i]];
+            double pc[3];
+            quat_rotate(T.q, &x[3 * (size_t)i], pc);
+            float u, v;
+            project_f32(model, prm, (float)(pc[0] + T.t[0]), (float)(pc[1] + T.t[1]), (float)(pc[2] + T.t[2]), u, v);
+            const double r0 = uv[2 * (size_t)i] - (double)u, r1 = uv[2 * (size_t)i + 1] - (double)v;
+            double rho0, rho1;
+            huber(info_reproj * (r0 * r0 + r1 * r1), delta_reproj, rho0, rho1);
+            chi += rho0;
+        }
+#pragma omp parallel for reduction(+ : chi) schedule(static) num_threads(threads)
+        for (int s = 0; s < n_sp; ++s) {
+            const double* a = &x[3 * (size_t)sp_ij[2 * (size_t)s]];
+            const double* c = &x[3 * (size_t)sp_ij[2 * (size_t)s + 1]];
+            const double v0 = a[0] - c[0], v1 = a[1] - c[1], v2 = a[2] - c[2];
+            const double d = std::sqrt(v0 * v0 + v1 * v1 + v2 * v2), d0 = (double)sp_d0[s];
+            const double r = k_spring * (d - d0) / d0;
+            chi += info_pos * r * r;                                 // no robust kernel on BA springs (OPT:1057-1071)
+        }
+#pragma omp parallel for reduction(+ : chi) schedule(static) num_threads(threads)
+        for (int s = 0; s < n_dm; ++s) {
+            const int32_t* v = dm_idx + 4 * (size_t)s;
+            const double w = (double)dm_w[s];
+            double e = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double r = w * ((x[3 * (size_t)v[2] + k] - x[3 * (size_t)v[0] + k]) - (x[3 * (size_t)v[3] + k] - x[3 * (size_t)v[1] + k]));
+                e += r * r;
+            }
+            double rho0, rho1;
+            huber(info_spatial * e, delta_spatial, rho0, rho1);
+            chi += rho0;
+        }
+        return chi;
+    }
+
+    // block pattern of H from the edges (block_solver.hpp:108-266 restated on flat arrays)
+    void build_structure() {
+        nb = 2 * K + M;
+        vector<std::pair<int, int>> pr;
+        pr.reserve((size_t)M * 9 + (size_t)n_sp * 4 + (size_t)n_dm * 16);
+        auto P = [&](int v) { return pinv[v]; };
+        for (int i = 0; i < M; ++i) {
+            const int a = P(2 * lm_kf[i]), c = P(2 * lm_kf[i] + 1), l = P(2 * K + i);
+            const int v3[3] = {a, c, l};
+            for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) pr.emplace_back(v3[p], v3[q]);
+        }
+        for (int k = 0; k < K; ++k) {                               // poses without observations keep a diagonal
+            const int a = P(2 * k), c = P(2 * k + 1);
+            pr.emplace_back(a, a); pr.emplace_back(a, c); pr.emplace_back(c, a); pr.emplace_back(c, c);
+        }
+        for (int s = 0; s < n_sp; ++s) {
+            const int i = P(2 * K + sp_ij[2 * (size_t)s]), j = P(2 * K + sp_ij[2 * (size_t)s + 1]);
+            pr.emplace_back(i, i); pr.emplace_back(i, j); pr.emplace_back(j, i); pr.emplace_back(j, j);
+        }
+        for (int s = 0; s < n_dm; ++s) {
+            int v[4];
+            for (int k = 0; k < 4; ++k) v[k] = P(2 * K + dm_idx[4 * (size_t)s + k]);
+            for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) pr.emplace_back(v[p], v[q]);
+        }
+        std::sort(pr.begin(), pr.end());
+        pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+        H.n = nb;
+        H.ptr.assign(nb + 1, 0);
+        H.col.resize(pr.size());
+        for (size_t i = 0; i < pr.size(); ++i) { H.ptr[pr[i].first + 1]++; H.col[i] = pr[i].second; }
+        for (int i = 0; i < nb; ++i) H.ptr[i + 1] += H.ptr[i];
+        H.val.assign(9 * pr.size(), 0.0);
+        H.diag.resize(nb);
+        for (int i = 0; i < nb; ++i) H.diag[i] = H.find(i, i);
+        vector<std::pair<int, int>>().swap(pr);
+        slot_r.resize(9 * (size_t)M);
+        for (int i = 0; i < M; ++i) {
+            const int a = P(2 * lm_kf[i]), c = P(2 * lm_kf[i] + 1), l = P(2 * K + i);
+            int64_t* s = &slot_r[9 * (size_t)i];
+            s[0] = H.find(a, a); s[1] = H.find(a, c); s[2] = H.find(c, a); s[3] = H.find(c, c);
+            s[4] = H.find(a, l); s[5] = H.find(l, a); s[6] = H.find(c, l); s[7] = H.find(l, c); s[8] = H.find(l, l);
+        }
+        slot_s.resize(4 * (size_t)n_sp);
+        for (int s = 0; s < n_sp; ++s) {
+            const int i = P(2 * K + sp_ij[2 * (size_t)s]), j = P(2 * K + sp_ij[2 * (size_t)s + 1]);
+            slot_s[4 * (size_t)s] = H.find(i, i); slot_s[4 * (size_t)s + 1] = H.find(i, j);
+            slot_s[4 * (size_t)s + 2] = H.find(j, i); slot_s[4 * (size_t)s + 3] = H.find(j, j);
+        }
+        slot_d.resize(16 * (size_t)n_dm);
+        for (int s = 0; s < n_dm; ++s) {
+            int v[4];
+            for (int k = 0; k < 4; ++k) v[k] = P(2 * K + dm_idx[4 * (size_t)s + k]);
+            for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) slot_d[16 * (size_t)s + 4 * p + q] = H.find(v[p], v[q]);
+        }
+        b.assign(3 * (size_t)nb, 0.0);
+    }
+
+    static inline void add_outer(double* blk, const double* Ja, const double* Jc, int rows, double w) {
+        // blk(3x3) += w * Ja^T Jc  with Ja, Jc given as rows x 3 (row-major)
+        for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) {
+                double s = 0;
+                for (int r = 0; r < rows; ++r) s += Ja[3 * r + p] * Jc[3 * r + q];
+                blk[3 * p + q] += w * s;
+            }
+    }
+
+    // computeActiveErrors + linearizeOplus + constructQuadraticForm over all edges (block_solver.hpp:495-562);
+    // returns chi2 of the linearisation point
+    double linearize() {
+        std::fill(H.val.begin(), H.val.end(), 0.0);
+        std::fill(b.begin(), b.end(), 0.0);
+        double chi = 0;
+        vector<double> Rk(9 * (size_t)K);
+        for (int k = 0; k < K; ++k) quat_to_R(pose[k].q, &Rk[9 * (size_t)k]);
+        // edges are evaluated in parallel into per-edge factors, then added serially (fixed order)
+        struct RF { double r[2], w, Jp[12], Jl[6]; };
+        vector<RF> rf((size_t)M);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < M; ++i) {
+            const int k = lm_kf[i];
+            const Pose& T = pose[k];
+            double pc[3];
+            quat_rotate(T.q, &x[3 * (size_t)i], pc);
+            const double px = pc[0] + T.t[0], py = pc[1] + T.t[1], pz = pc[2] + T.t[2];
+            float u, v, Jf[6];
+            project_f32(model, prm, (float)px, (float)py, (float)pz, u, v);
+            projjac_f32(model, prm, (float)px, (float)py, (float)pz, Jf);
+            RF& f = rf[i];
+            f.r[0] = uv[2 * (size_t)i] - (double)u; f.r[1] = uv[2 * (size_t)i + 1] - (double)v;
+            double rho0, rho1;
+            huber(info_reproj * (f.r[0] * f.r[0] + f.r[1] * f.r[1]), delta_reproj, rho0, rho1);
+            f.w = rho1 * info_reproj;
+            const double* R = &Rk[9 * (size_t)k];
+            for (int rr = 0; rr < 2; ++rr) {
+                const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
+                // J_pose = -Jpi [ -[p]x | I ]  (reprojection_error.cc:57-63), rows of 6 stored as two 3-blocks
+                f.Jp[3 * rr] = -j1 * pz + j2 * py; f.Jp[3 * rr + 1] = j0 * pz - j2 * px; f.Jp[3 * rr + 2] = -j0 * py + j1 * px;
+                f.Jp[6 + 3 * rr] = j0; f.Jp[6 + 3 * rr + 1] = j1; f.Jp[6 + 3 * rr + 2] = j2;
+                f.Jl[3 * rr] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+                f.Jl[3 * rr + 1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+                f.Jl[3 * rr + 2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+            }
+        }
+        for (int i = 0; i < M; ++i) {
+            const RF& f = rf[i];
+            double rho0, rho1;
+            huber(info_reproj * (f.r[0] * f.r[0] + f.r[1] * f.r[1]), delta_reproj, rho0, rho1);
+            chi += rho0;
+            const int64_t* s = &slot_r[9 * (size_t)i];
+            const double* Ja = f.Jp; const double* Jc = f.Jp + 6; const double* Jl = f.Jl;
+            add_outer(&H.val[9 * s[0]], Ja, Ja, 2, f.w); add_outer(&H.val[9 * s[1]], Ja, Jc, 2, f.w);
+            add_outer(&H.val[9 * s[2]], Jc, Ja, 2, f.w); add_outer(&H.val[9 * s[3]], Jc, Jc, 2, f.w);
+            add_outer(&H.val[9 * s[4]], Ja, Jl, 2, f.w); add_outer(&H.val[9 * s[5]], Jl, Ja, 2, f.w);
+            add_outer(&H.val[9 * s[6]], Jc, Jl, 2, f.w); add_outer(&H.val[9 * s[7]], Jl, Jc, 2, f.w);
+            add_outer(&H.val[9 * s[8]], Jl, Jl, 2, f.w);
+            const int a = pinv[2 * lm_kf[i]], c = pinv[2 * lm_kf[i] + 1], l = pinv[2 * K + i];
+            for (int p = 0; p < 3; ++p) {
+                b[3 * (size_t)a + p] -= f.w * (Ja[p] * f.r[0] + Ja[3 + p] * f.r[1]);
+                b[3 * (size_t)c + p] -= f.w * (Jc[p] * f.r[0] + Jc[3 + p] * f.r[1]);
+                b[3 * (size_t)l + p] -= f.w * (Jl[p] * f.r[0] + Jl[3 + p] * f.r[1]);
+            }
+        }
+        vector<RF>().swap(rf);
+        // springs: r = k (d - d0)/d0 ; J_i = (k/d0)(1/sqrt(d)) 2 (x_i - x_j)^T as written (position_regularizer.cc:51-60)
+        for (int s = 0; s < n_sp; ++s) {
+            const int vi = sp_ij[2 * (size_t)s], vj = sp_ij[2 * (size_t)s + 1];
+            const double* a = &x[3 * (size_t)vi]; const double* c = &x[3 * (size_t)vj];
+            const double v[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
+            const double d = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), d0 = (double)sp_d0[s];
+            const double r = k_spring * (d - d0) / d0;
+            chi += info_pos * r * r;
+            const double cg = (k_spring / d0) * (1.0 / std::sqrt(d));
+            const double g[3] = {cg * 2.0 * v[0], cg * 2.0 * v[1], cg * 2.0 * v[2]};
+            const int64_t* sl = &slot_s[4 * (size_t)s];
+            double* Hii = &H.val[9 * sl[0]]; double* Hij = &H.val[9 * sl[1]]; double* Hji = &H.val[9 * sl[2]]; double* Hjj = &H.val[9 * sl[3]];
+            for (int p = 0; p < 3; ++p)
+                for (int q = 0; q < 3; ++q) {
+                    const double t = info_pos * g[p] * g[q];
+                    Hii[3 * p + q] += t; Hjj[3 * p + q] += t; Hij[3 * p + q] -= t; Hji[3 * p + q] -= t;
+                }
+            const int bi = pinv[2 * K + vi], bj = pinv[2 * K + vj];
+            for (int p = 0; p < 3; ++p) { b[3 * (size_t)bi + p] -= info_pos * r * g[p]; b[3 * (size_t)bj + p] += info_pos * r * g[p]; }
+        }
+        // dampers: r = w ((x1n - x1c) - (x2n - x2c)); J = (-w, +w, +w, -w) I on (1c, 2c, 1n, 2n) (spatial_regularizer.cc:32-59)
+        static const double sg[4] = {-1, 1, 1, -1};
+        for (int s = 0; s < n_dm; ++s) {
+            const int32_t* v = dm_idx + 4 * (size_t)s;
+            const double w = (double)dm_w[s];
+            double r[3], e = 0;
+            for (int k = 0; k < 3; ++k) {
+                r[k] = w * ((x[3 * (size_t)v[2] + k] - x[3 * (size_t)v[0] + k]) - (x[3 * (size_t)v[3] + k] - x[3 * (size_t)v[1] + k]));
+                e += r[k] * r[k];
+            }
+            double rho0, rho1;
+            huber(info_spatial * e, delta_spatial, rho0, rho1);
+            chi += rho0;
+            const double wi = rho1 * info_spatial;
+            const double sfac = wi * w * w;
+            const int64_t* sl = &slot_d[16 * (size_t)s];
+            for (int p = 0; p < 4; ++p) {
+                for (int q = 0; q < 4; ++q) {
+                    double* blk = &H.val[9 * sl[4 * p + q]];
+                    const double t = sg[p] * sg[q] * sfac;
+                    blk[0] += t; blk[4] += t; blk[8] += t;
+                }
+                const int bv = pinv[2 * K + v[p]];
+                for (int k = 0; k < 3; ++k) b[3 * (size_t)bv + k] -= sg[p] * w * wi * r[k];
+            }
+        }
+        return chi;
+    }
+
+    void push() { pose_bak = pose; x_bak = x; }
+    void pop() { pose = pose_bak; x = x_bak; }
+    void update(const double* dx) {                                   // sparse_optimizer.cpp:457-470
+        for (int k = 0; k < K; ++k) {
+            double upd[6];
+            for (int a = 0; a < 3; ++a) { upd[a] = dx[3 * (size_t)pinv[2 * k] + a]; upd[3 + a] = dx[3 * (size_t)pinv[2 * k + 1] + a]; }
+            pose_oplus(pose[k], upd);
+        }
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < M; ++i)
+            for (int a = 0; a < 3; ++a) x[3 * (size_t)i + a] += dx[3 * (size_t)pinv[2 * K + i] + a];
+    }
+};
+
+// block-Jacobi PCG on (H + lam I) x = b, OpenMP over block rows; pose blocks use their 6x6 inverse
+struct Pcg {
+    const Graph* G;
+    vector<double> Minv;          // 9 per block (3x3 inverse) ; pose pairs: 36 in Mp
+    vector<double> Mp;
+    vector<double> r, u, p, w;
+    int iters = 0;
+    static bool inv_spd(int n, const double* A, double* Ai) {        // small dense Cholesky inverse
+        double L[36], Y[36];
+        for (int j = 0; j < n; ++j) {
+            double d = A[j * n + j];
+            for (int q = 0; q < j; ++q) d -= L[j * n + q] * L[j * n + q];
+            if (!(d > 0)) return false;
+            L[j * n + j] = std::sqrt(d);
+            for (int i = j + 1; i < n; ++i) {
+                double s = A[i * n + j];
+                for (int q = 0; q < j; ++q) s -= L[i * n + q] * L[j * n + q];
+                L[i * n + j] = s / L[j * n + j];
+            }
+        }
+        for (int c = 0; c < n; ++c) {
+            for (int i = 0; i < n; ++i) {
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int q = 0; q < i; ++q) s -= L[i * n + q] * Y[q * n + c];
+                Y[i * n + c] = s / L[i * n + i];
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double s = Y[i * n + c];
+                for (int q = i + 1; q < n; ++q) s -= L[q * n + i] * Ai[q * n + c];
+                Ai[i * n + c] = s / L[i * n + i];
+            }
+        }
+        return true;
+    }
+    bool solve(double lam, double rtol, int max_it, double* xo) {
+        const BlockMat& H = G->H;
+        const int nb = H.n, K = G->K, T = G->threads;
+        const size_t n = 3 * (size_t)nb;
+        Minv.assign(9 * (size_t)nb, 0.0);
+        Mp.assign(36 * (size_t)K, 0.0);
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(T)
+        for (int i = 0; i < nb; ++i) {
+            double A[9];
+            for (int q = 0; q < 9; ++q) A[q] = H.val[9 * H.diag[i] + q];
+            A[0] += lam; A[4] += lam; A[8] += lam;
+            if (!inv_spd(3, A, &Minv[9 * (size_t)i])) ++bad;
+        }
+        bool ok = bad == 0;
+        for (int k = 0; k < K; ++k) {
+            const int a = G->pinv[2 * k], c = G->pinv[2 * k + 1];
+            double A[36];
+            const int bl[2] = {a, c};
+            for (int p = 0; p < 2; ++p)
+                for (int q = 0; q < 2; ++q) {
+                    const double* blk = &H.val[9 * H.find(bl[p], bl[q])];
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[(3 * p + i) * 6 + 3 * q + j] = blk[3 * i + j];
+                }
+            for (int i = 0; i < 6; ++i) A[i * 6 + i] += lam;
+            if (!inv_spd(6, A, &Mp[36 * (size_t)k])) ok = false;
+        }
+        if (!ok) return false;
+        vector<uint8_t> is_pose(nb, 0);
+        for (int k = 0; k < K; ++k) { is_pose[G->pinv[2 * k]] = 1; is_pose[G->pinv[2 * k + 1]] = 1; }
+        auto precond = [&](const vector<double>& rr, vector<double>& uu) {
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int i = 0; i < nb; ++i) {
+                if (is_pose[i]) continue;
+                const double* Mi = &Minv[9 * (size_t)i];
+                for (int a = 0; a < 3; ++a) uu[3 * (size_t)i + a] = Mi[3 * a] * rr[3 * (size_t)i] + Mi[3 * a + 1] * rr[3 * (size_t)i + 1] + Mi[3 * a + 2] * rr[3 * (size_t)i + 2];
+            }
+            for (int k = 0; k < K; ++k) {
+                const int bl[2] = {G->pinv[2 * k], G->pinv[2 * k + 1]};
+                double v[6], o[6];
+                for (int a = 0; a < 3; ++a) { v[a] = rr[3 * (size_t)bl[0] + a]; v[3 + a] = rr[3 * (size_t)bl[1] + a]; }
+                for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Mp[36 * (size_t)k + 6 * i + j] * v[j]; o[i] = s; }
+                for (int a = 0; a < 3; ++a) { uu[3 * (size_t)bl[0] + a] = o[a]; uu[3 * (size_t)bl[1] + a] = o[3 + a]; }
+            }
+        };
+        auto dot = [&](const vector<double>& a, const vector<double>& c) {
+            double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static) num_threads(T)
+            for (int64_t i = 0; i < (int64_t)n; ++i) s += a[i] * c[i];
+            return s;
+        };
+        r.assign(G->b.begin(), G->b.end());
+        u.assign(n, 0.0); p.assign(n, 0.0); w.assign(n, 0.0);
+        std::fill(xo, xo + n, 0.0);
+        precond(r, u);
+        double gamma = dot(r, u);
+        const double gamma0 = gamma;
+        p = u;
+        iters = 0;
+        while (iters < max_it && gamma > rtol * rtol * gamma0 && gamma != 0.0) {
+#pragma omp parallel for schedule(dynamic, 256) num_threads(T)
+            for (int i = 0; i < nb; ++i) {
+                double a0 = lam * p[3 * (size_t)i], a1 = lam * p[3 * (size_t)i + 1], a2 = lam * p[3 * (size_t)i + 2];
+                for (int64_t q = H.ptr[i]; q < H.ptr[i + 1]; ++q) {
+                    const double* blk = &H.val[9 * (size_t)q];
+                    const double* pj = &p[3 * (size_t)H.col[q]];
+                    a0 += blk[0] * pj[0] + blk[1] * pj[1] + blk[2] * pj[2];
+                    a1 += blk[3] * pj[0] + blk[4] * pj[1] + blk[5] * pj[2];
+                    a2 += blk[6] * pj[0] + blk[7] * pj[1] + blk[8] * pj[2];
+                }
+                w[3 * (size_t)i] = a0; w[3 * (size_t)i + 1] = a1; w[3 * (size_t)i + 2] = a2;
+            }
+            const double alpha = gamma / dot(p, w);
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = 0; i < (int64_t)n; ++i) { xo[i] += alpha * p[i]; r[i] -= alpha * w[i]; }
+            precond(r, u);
+            const double g2 = dot(r, u);
+            const double beta = g2 / gamma;
+            gamma = g2;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = 0; i < (int64_t)n; ++i) p[i] = u[i] + beta * p[i];
+            ++iters;
+        }
+        return std::isfinite(gamma);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// g2o's known-answer test shape: explicit block-sparse SPD matrix (upper triangle blocks, 3x3) -> x.
+// Used by tests/test_oracle_cpp_cpu.py to pin the Cholesky against third_party/g2o/unit_test/solver/
+// sparse_system_helper.cpp:52-149,255,298.  ordering: 0 natural, 1 AMD.
+int nrs_cpu_block_cholesky_solve(int32_t nb, int32_t n_blocks, const int32_t* br, const int32_t* bc, const double* bv,
+                                 const double* rhs, double lam, int32_t ordering, double* x) {
+    vector<std::pair<std::pair<int, int>, int>> ent;
+    for (int i = 0; i < n_blocks; ++i) {
+        ent.push_back({{br[i], bc[i]}, i});
+        if (br[i] != bc[i]) ent.push_back({{bc[i], br[i]}, -i - 1});
+    }
+    std::sort(ent.begin(), ent.end());
+    BlockMat A0;
+    A0.n = nb;
+    A0.ptr.assign(nb + 1, 0);
+    for (auto& e : ent) A0.ptr[e.first.first + 1]++;
+    for (int i = 0; i < nb; ++i) A0.ptr[i + 1] += A0.ptr[i];
+    A0.col.resize(ent.size());
+    A0.val.resize(9 * ent.size());
+    for (size_t k = 0; k < ent.size(); ++k) {
+        A0.col[k] = ent[k].first.second;
+        const int id = ent[k].second;
+        const double* v = bv + 9 * (size_t)(id >= 0 ? id : -id - 1);
+        for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) A0.val[9 * k + 3 * p + q] = id >= 0 ? v[3 * p + q] : v[3 * q + p];
+    }
+    vector<int> perm(nb);
+    for (int i = 0; i < nb; ++i) perm[i] = i;
+    if (ordering == 1) perm = amd_order(A0, vector<uint8_t>(nb, 0));
+    vector<int> pinv(nb);
+    for (int i = 0; i < nb; ++i) pinv[perm[i]] = i;
+    // permuted copy
+    vector<std::pair<std::pair<int, int>, int64_t>> pe;
+    for (int r = 0; r < nb; ++r)
+        for (int64_t p = A0.ptr[r]; p < A0.ptr[r + 1]; ++p) pe.push_back({{pinv[r], pinv[A0.col[p]]}, p});
+    std::sort(pe.begin(), pe.end());
+    BlockMat A;
+    A.n = nb;
+    A.ptr.assign(nb + 1, 0);
+    A.col.resize(pe.size());
+    A.val.resize(9 * pe.size());
+    for (size_t k = 0; k < pe.size(); ++k) {
+        A.ptr[pe[k].first.first + 1]++;
+        A.col[k] = pe[k].first.second;
+        std::memcpy(&A.val[9 * k], &A0.val[9 * (size_t)pe[k].second], 72);
+    }
+    for (int i = 0; i < nb; ++i) A.ptr[i + 1] += A.ptr[i];
+    BlockChol ch;
+    ch.analyze(A);
+    if (!ch.factor(A, lam)) return 1;
+    vector<double> bp(3 * (size_t)nb), xp(3 * (size_t)nb);
+    for (int i = 0; i < nb; ++i) for (int a = 0; a < 3; ++a) bp[3 * (size_t)pinv[i] + a] = rhs[3 * (size_t)i + a];
+    ch.solve(bp.data(), xp.data());
+    for (int i = 0; i < nb; ++i) for (int a = 0; a < 3; ++a) x[3 * (size_t)i + a] = xp[3 * (size_t)pinv[i] + a];
+    return 0;
+}
+
+// LocalDeformableBundleAdjustment on flat arrays (same argument meaning as nrs_dba_solve in include/nrs.h).
+// solver: 0 = sparse block Cholesky (reference-equivalent), 1 = block-Jacobi PCG to pcg_rtol.
+// max_trials_total > 0 stops after that many LM trials (bounded timing samples on large windows).
+int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
+                      const int32_t* lm_kf, const float* lm_uv, int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                      int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale, int32_t iters,
+                      int32_t solver, double pcg_rtol, int32_t threads, int32_t max_trials_total,
+                      Trial* trace, int32_t trace_cap, int32_t* trace_n, double* lm_xyz64, Stats* st) {
+    const double t_begin = now_s();
+    Graph G;
+    G.model = model;
+    std::memcpy(G.prm, prm, sizeof(float) * 8);
+    G.K = n_kf; G.M = n_lm;
+#ifdef _OPENMP
+    G.threads = threads > 0 ? threads : omp_get_max_threads();
+#else
+    G.threads = 1;
+#endif
+    G.pose.resize(n_kf);
+    for (int k = 0; k < n_kf; ++k) {
+        for (int i = 0; i < 4; ++i) G.pose[k].q[i] = poses_qt[7 * k + i];
+        for (int i = 0; i < 3; ++i) G.pose[k].t[i] = poses_qt[7 * k + 4 + i];
+        quat_normalize(G.pose[k].q);                                 // SE3Quat constructor (se3quat.h:56-58)
+    }
+    G.x.resize(3 * (size_t)n_lm);
+    for (size_t i = 0; i < G.x.size(); ++i) G.x[i] = (double)lm_xyz[i];          // OPT:943
+    G.uv.resize(2 * (size_t)n_lm);
+    for (size_t i = 0; i < G.uv.size(); ++i) G.uv[i] = (double)lm_uv[i];
+    G.lm_kf = lm_kf;
+    G.n_sp = n_sp; G.sp_ij = sp_ij; G.sp_d0 = sp_d0;
+    G.n_dm = n_dm; G.dm_idx = dm_idx; G.dm_w = dm_w;
+    {   // OPT:958-973, float arithmetic widened to double
+        const float th2 = std::sqrt(5.99f), th3 = std::sqrt(0.584f);
+        const float sigma_spatial = (float)(0.1 * (double)scale);
+        G.info_reproj = (double)(1.0f / (0.5f * 0.5f));
+        G.delta_reproj = (double)th2;
+        G.info_pos = (double)(1.0f / (0.1f * 0.1f));
+        G.info_spatial = (double)(1.0f / (sigma_spatial * sigma_spatial));
+        G.delta_spatial = (double)th3;
+        G.k_spring = (double)1.1f;
+    }
+    Stats S;
+    std::memset(&S, 0, sizeof(S));
+    S.threads = G.threads;
+    const int nb = 2 * n_kf + n_lm;
+    S.unknowns = 3 * nb;
+    // ---- structure + ordering (once per optimize(), like g2o's symbolic decomposition)
+    double t0 = now_s();
+    G.pinv.resize(nb);
+    for (int i = 0; i < nb; ++i) G.pinv[i] = i;
+    G.build_structure();
+    BlockChol chol;
+    if (solver == 0) {
+        vector<uint8_t> last(nb, 0);
+        for (int k = 0; k < 2 * n_kf; ++k) last[k] = 1;
+        vector<int> perm = amd_order(G.H, last);
+        for (int i = 0; i < nb; ++i) G.pinv[perm[i]] = i;
+        G.build_structure();                                         // in the permuted order
+        S.t_structure = now_s() - t0;
+        t0 = now_s();
+        chol.analyze(G.H);
+        S.t_analyze = now_s() - t0;
+        S.chol_flops = chol.flops;
+        S.chol_blocks = chol.nnz_blocks;
+    } else {
+        S.t_structure = now_s() - t0;
+    }
+    S.h_blocks = (int64_t)G.H.col.size();
+    Pcg pcg;
+    pcg.G = &G;
+    vector<double> dx(3 * (size_t)nb, 0.0);
+    // ---- OptimizationAlgorithmLevenberg::solve (levenberg.cpp:57-174)
+    double lam = -1, ni = 2;
+    int n_tr = 0, done_iters = 0;
+    bool stop_all = false;
+    for (int it = 0; it < iters && !stop_all; ++it) {
+        t0 = now_s();
+        double chi = G.linearize();
+        S.t_linearize += now_s() - t0;
+        if (it == 0) {
+            double md = 0;
+            for (int i = 0; i < nb; ++i) { const double* d = &G.H.val[9 * G.H.diag[i]]; md = std::max(md, std::max(std::fabs(d[0]), std::max(std::fabs(d[4]), std::fabs(d[8])))); }
+            lam = 1e-5 * md;
+            ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            G.push();
+            bool ok;
+            int inner = 0;
+            if (solver == 0) {
+                t0 = now_s();
+                ok = chol.factor(G.H, lam);
+                S.t_factor += now_s() - t0;
+                S.n_factor++;
+                t0 = now_s();
+                if (ok) chol.solve(G.b.data(), dx.data());
+                S.t_solve += now_s() - t0;
+            } else {
+                t0 = now_s();
+                ok = pcg.solve(lam, pcg_rtol, 20000, dx.data());
+                inner = pcg.iters;
+                S.n_pcg_iters += inner;
+                S.t_solve += now_s() - t0;
+            }
+            G.update(dx.data());
+            t0 = now_s();
+            const double temp = ok ? G.chi2() : std::numeric_limits<double>::max();
+            S.t_errors += now_s() - t0;
+            double scale_lm = 1e-3;
+            for (size_t i = 0; i < dx.size(); ++i) scale_lm += dx[i] * (lam * dx[i] + G.b[i]);
+            rho = (chi - temp) / scale_lm;
+            const bool accepted = rho > 0 && std::isfinite(temp);
+            if (trace && n_tr < trace_cap) trace[n_tr] = Trial{it, qmax, accepted, ok, inner, lam, chi, temp, rho};
+            ++n_tr;
+            if (accepted) {
+                double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2.0 / 3.0);
+                lam *= std::max(1.0 / 3.0, alpha);
+                ni = 2;
+                chi = temp;
+            } else {
+                lam *= ni;
+                ni *= 2;
+                G.pop();
+                if (!std::isfinite(lam)) break;
+            }
+            ++qmax;
+            if (max_trials_total > 0 && n_tr >= max_trials_total) { stop_all = true; break; }
+        } while (rho < 0 && qmax < 10);
+        ++done_iters;
+        if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;
+    }
+    for (int k = 0; k < n_kf; ++k) {
+        for (int i = 0; i < 4; ++i) poses_qt[7 * k + i] = G.pose[k].q[i];
+        for (int i = 0; i < 3; ++i) poses_qt[7 * k + 4 + i] = G.pose[k].t[i];
+    }
+    for (size_t i = 0; i < G.x.size(); ++i) lm_xyz[i] = (float)G.x[i];              // OPT:1158
+    if (lm_xyz64) std::memcpy(lm_xyz64, G.x.data(), sizeof(double) * G.x.size());
+    if (trace_n) *trace_n = n_tr;
+    S.n_trials = n_tr;
+    S.n_iters = done_iters;
+    S.t_total = now_s() - t_begin;
+    if (st) *st = S;
+    return 0;
+}
+
+int nrs_cpu_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

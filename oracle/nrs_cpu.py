@@ -1,0 +1,83 @@
+"""ctypes binding of oracle/_build/libnrs_cpu.so (oracle/nrs_cpu.cpp) -- TEST INFRASTRUCTURE ONLY: the C++ CPU
+restatement of the deformable BA, used by tests/ and by bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Stats(C.Structure):
+    _fields_ = [("t_total", C.c_double), ("t_linearize", C.c_double), ("t_analyze", C.c_double), ("t_factor", C.c_double),
+                ("t_solve", C.c_double), ("t_errors", C.c_double), ("t_structure", C.c_double), ("chol_flops", C.c_double),
+                ("chol_blocks", C.c_int64), ("h_blocks", C.c_int64), ("n_factor", C.c_int32), ("n_pcg_iters", C.c_int32),
+                ("n_trials", C.c_int32), ("n_iters", C.c_int32), ("threads", C.c_int32), ("unknowns", C.c_int32)]
+
+
+class Trial(C.Structure):
+    _fields_ = [("iter", C.c_int32), ("trial", C.c_int32), ("accepted", C.c_int32), ("ok", C.c_int32), ("inner", C.c_int32),
+                ("lam", C.c_double), ("chi", C.c_double), ("chi_new", C.c_double), ("rho", C.c_double)]
+
+
+def build(native=False):
+    """make -C oracle; native=True: a -march=native copy for timing on THIS host (oracle/_build/native)."""
+    args = ["make", "-s", "-C", HERE]
+    if native:
+        args += ["ARCH=native", "OUT=_build/native"]
+    subprocess.check_call(args)
+    return os.path.join(HERE, "_build", "native" if native else "", "libnrs_cpu.so")
+
+
+def load(native=False):
+    path = os.path.join(HERE, "_build", "native" if native else "", "libnrs_cpu.so")
+    if not os.path.exists(path):
+        path = build(native)
+    return C.CDLL(path)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def block_cholesky_solve(nb, br, bc, bv, rhs, lam=0.0, ordering=1, lib=None):
+    lib = lib or load()
+    br, bc = np.ascontiguousarray(br, np.int32), np.ascontiguousarray(bc, np.int32)
+    bv, rhs = np.ascontiguousarray(bv, np.float64), np.ascontiguousarray(rhs, np.float64)
+    x = np.zeros(3 * nb)
+    rc = lib.nrs_cpu_block_cholesky_solve(C.c_int32(nb), C.c_int32(len(br)), _p(br, C.c_int32), _p(bc, C.c_int32), _p(bv, C.c_double),
+                                          _p(rhs, C.c_double), C.c_double(lam), C.c_int32(ordering), _p(x, C.c_double))
+    return rc == 0, x
+
+
+def dba_solve(model, prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w, scale, iters=5,
+              solver=0, pcg_rtol=1e-10, threads=1, max_trials=0, lib=None):
+    """returns (poses_q, poses_t, landmarks fp64, trace list, stats dict); solver 0 = sparse Cholesky, 1 = PCG"""
+    lib = lib or load()
+    p8 = np.zeros(8, np.float32)
+    p8[:len(prm)] = np.asarray(prm, np.float32)
+    qt = np.ascontiguousarray(np.concatenate([np.asarray(poses_q, np.float64), np.asarray(poses_t, np.float64)], 1))
+    xyz = np.ascontiguousarray(lm_xyz, np.float32).copy()
+    kf, uv = np.ascontiguousarray(lm_kf, np.int32), np.ascontiguousarray(lm_uv, np.float32)
+    sp, d0 = np.ascontiguousarray(sp_ij, np.int32).reshape(-1, 2), np.ascontiguousarray(sp_d0, np.float32)
+    dm, dw = np.ascontiguousarray(dm_idx, np.int32).reshape(-1, 4), np.ascontiguousarray(dm_w, np.float32)
+    tr = (Trial * 256)()
+    ntr = C.c_int32(0)
+    x64 = np.zeros((len(xyz), 3), np.float64)
+    st = Stats()
+    rc = lib.nrs_cpu_dba_solve(C.c_int32(int(model)), _p(p8, C.c_float), C.c_int32(len(qt)), _p(qt, C.c_double), C.c_int32(len(xyz)),
+                               _p(xyz, C.c_float), _p(kf, C.c_int32), _p(uv, C.c_float), C.c_int32(len(sp)), _p(sp, C.c_int32),
+                               _p(d0, C.c_float), C.c_int32(len(dm)), _p(dm, C.c_int32), _p(dw, C.c_float), C.c_float(scale),
+                               C.c_int32(iters), C.c_int32(solver), C.c_double(pcg_rtol), C.c_int32(threads), C.c_int32(max_trials),
+                               tr, C.c_int32(256), C.byref(ntr), _p(x64, C.c_double), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("nrs_cpu_dba_solve failed: %d" % rc)
+    trace = [dict(iter=t.iter, trial=t.trial, accepted=bool(t.accepted), ok=bool(t.ok), inner=t.inner, lam=t.lam, chi=t.chi,
+                  chi_new=t.chi_new, rho=t.rho) for t in tr[:min(ntr.value, 256)]]
+    stats = {k: getattr(st, k) for k, _ in Stats._fields_}
+    return qt[:, :4].copy(), qt[:, 4:].copy(), x64, trace, stats
+
+
+def max_threads(lib=None):
+    return (lib or load()).nrs_cpu_max_threads()
