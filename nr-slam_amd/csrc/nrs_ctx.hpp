@@ -54,6 +54,7 @@ struct nrs_ctx {
     hipStream_t comm_stream = nullptr;   // boundary-row exchanges run here, next to the interior tiles on `stream`
     hipEvent_t ev_vec = nullptr, ev_halo = nullptr;
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
+    bool err_local = true;           // last set-up failure may be specific to this rank (allocation, HIP, rank-dependent checks)
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
     int seq = 0;                     // sequence number of the last publication the host waited for (pin_flags[7])

@@ -65,7 +65,8 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
     s.shard = true;                     // with a communicator on the context: one window over its ranks (include/nrs.h)
     // rank-local checks and allocations can fail on one rank only: the ranks agree before the first collective
-    const int rc = comm_agree(c, engine_create(c, s, &c->arena_dba, &c->dba));
+    int rc = engine_create(c, s, &c->arena_dba, &c->dba);
+    if (rc == NRS_OK || c->err_local) rc = comm_agree(c, rc);
     if (rc != NRS_OK) dba_free(c);
     return rc;
 }

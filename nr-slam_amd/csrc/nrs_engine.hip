@@ -93,7 +93,7 @@ static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
     for (int cls = 0; cls < 2; ++cls) {
         if (d.sh_nt[cls] == 0) continue;
         const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
-        launch_reg2<LIN, true>(c, d, xl, shm, d.sh_nt[cls], cls);
+        launch_reg2<LIN, true>(c, d, xl, shm, d.sh_nt[cls], cls);        // (LIN: the linearisation point is d.lin_pose / xl)
     }
 }
 
@@ -133,8 +133,9 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
     const Dev& d = e->d;
     const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
     if (LIN) {
+        // LDS path: one fused pass (reprojection + springs + dampers per row); gather path: two
         Timer t(c, &c->prof.linearize_ms, &c->prof.linearize_launches);
-        hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
+        if (!d.use_lds) hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
         launch_reg<LIN>(c, d, d.xl[which]);
     } else {
         hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);

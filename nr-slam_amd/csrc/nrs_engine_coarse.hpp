@@ -48,11 +48,11 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
     {
         unsigned int m = 0;
         for (int idx = sbeg + lane; idx < send; idx += 64) {
-            const SpringRec rc = P.s_rec[idx];
+            const SpringRec rc = load_spring(P, idx);
             if (rc.other != REC_NONE && !lfix[rc.other]) m |= 1u << lgrp[rc.other];
         }
         for (int idx = dbeg + lane; idx < dend; idx += 64) {
-            const DamperRec rc = P.d_rec[idx];
+            const DamperRec rc = load_damper(P, idx);
             if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
             const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
                 for (int k = 0; k < 6; ++k) acc[k] = P.D[6 * (size_t)row + k];
             }
             for (int idx = sbeg + lane; idx < send; idx += 64) {
-                const SpringRec rc = P.s_rec[idx];
+                const SpringRec rc = load_spring(P, idx);
                 if (rc.other == REC_NONE || lfix[rc.other] || lgrp[rc.other] != hg) continue;
                 const int o = rc.other;
                 const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
                 acc[3] += m * v1 * v1; acc[4] += m * v1 * v2; acc[5] += m * v2 * v2;
             }
             for (int idx = dbeg + lane; idx < dend; idx += 64) {
-                const DamperRec rc = P.d_rec[idx];
+                const DamperRec rc = load_damper(P, idx);
                 if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
                 const int role = rc.meta & 3;
                 const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
             for (int k = 0; k < 6; ++k) acc[k] = P.D[6 * (size_t)row + k];
         }
         for (int idx = sbeg + lane; idx < send; idx += 64) {
-            const SpringRec rc = P.s_rec[idx];
+            const SpringRec rc = load_spring(P, idx);
             if (rc.other == REC_NONE || rc.other >= P.tile_rows || lfix[rc.other]) continue;
             const int o = rc.other;
             const double v0 = xs[0] - lx[3 * o], v1 = xs[1] - lx[3 * o + 1], v2 = xs[2] - lx[3 * o + 2];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
             acc[3] += m * v1 * v1; acc[4] += m * v1 * v2; acc[5] += m * v2 * v2;
         }
         for (int idx = dbeg + lane; idx < dend; idx += 64) {
-            const DamperRec rc = P.d_rec[idx];
+            const DamperRec rc = load_damper(P, idx);
             if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
             const int role = rc.meta & 3;
             const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};

@@ -6,6 +6,8 @@ namespace nrs {
 
 // =====================================================================================
 // linearisation, part 1: reprojection edges.  One thread per row, one pose per workgroup.
+// LIN = true is the stored-block (gather) path only: on the LDS path the reprojection edges are linearised inside
+// k_reg, in the same pass as the regularisers (D, b_l written once).  LIN = false: chi2 of a trial state, both paths.
 //   ReprojectionError / ReprojectionErrorWithDeformation computeError + linearizeOplus
 //   (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68),
 //   quadratic form with Huber weight (base_fixed_sized_edge.hpp:49-63, base_edge.h:158-164).
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
     } else {
         double c1[1] = {acc[27]};
         block_sum<1>(c1, lds, lane, wave);
-        if (tid == 0) P.part_lin[(size_t)g * 32 + 27] = c1[0];
+        if (tid == 0) P.part_rchi[g] = c1[0];
     }
 }
 
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
 template <int T, bool LIN, bool LDS>
 __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double lds[4 * 2];
+    __shared__ double lds28[(LIN && LDS) ? 4 * 28 : 1];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     int b = xcd_tile(blockIdx.x, LDS ? P.sh_nt[cls] : P.n_regblk);
@@ -140,8 +143,9 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
-    const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
-    // record headers are double-buffered in two-record chunks; the first chunk of both streams is
+    const int rf = P.rflag[row];
+    const bool rfix = (rf & RF_FIXED) != 0;
+    // incidence headers are double-buffered in two-record chunks; the first chunk of both streams is
     // requested before the tile is staged
     constexpr int U = 2;
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             h[q] = make_uint2(0xFFFFu, 0u);
-            if (j < s_end) h[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.s_rec + j) + 8);
+            if (j < s_end) h[q] = make_uint2(P.s_om[j], __float_as_uint(P.s_d0[j]));
         }
     };
     auto load_dh = [&](uint2* h, float* w, int idx) {
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             const int j = idx + 64 * q;
             h[q] = make_uint2(0u, 0xFFFF0000u);
             w[q] = 0.f;
-            if (j < d_end) { h[q] = *reinterpret_cast<const uint2*>(P.d_rec + j); w[q] = P.d_w[j]; }
+            if (j < d_end) { h[q] = P.d_hdr[j]; w[q] = P.d_w[j]; }
         }
     };
     if (LDS) { load_sh(shA, s_beg + lane); load_dh(dhA, dwA, d_beg + lane); }
@@ -190,12 +194,104 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         else { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
     }
     double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
+    // ---- reprojection edge of the row (LDS path, linearisation): ReprojectionError / ...WithDeformation
+    // computeError + linearizeOplus (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68)
+    // and its quadratic form (base_fixed_sized_edge.hpp:49-63).  The first two lanes of a row take one residual
+    // component each (T = 1: one lane takes both): the H_pp / b_p partials and the row's diagonal block are sums
+    // over the two components anyway, and they leave through the reductions that follow.
+    if (LIN && LDS) {
+        constexpr int NRR = T == 1 ? 2 : 1;                 // residual components per participating lane
+        const int kf = P.grp_pose[row / ROW_ALIGN];
+        const bool pfix = P.pose_fixed[kf] != 0;
+        // an edge whose vertices are all fixed is not part of the optimisation (sparse_optimizer.cpp:236)
+        const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
+        RowRec rc;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
+        rc.w = 0;
+        double Jp[NRR][6], rres[NRR], w = 0, chi_r = 0;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            rres[a] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jp[a][q] = 0;
+        }
+        if (active && t < (T == 1 ? 1 : 2)) {
+            const Pose Tcw = P.lin_pose[kf];
+            double Rm[9];
+            quat_to_R(Tcw.q, Rm);
+            const double px = Rm[0] * xs0 + Rm[1] * xs1 + Rm[2] * xs2 + Tcw.t[0];
+            const double py = Rm[3] * xs0 + Rm[4] * xs1 + Rm[5] * xs2 + Tcw.t[1];
+            const double pz = Rm[6] * xs0 + Rm[7] * xs1 + Rm[8] * xs2 + Tcw.t[2];
+            float u, v, Jf[6];
+            project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+            projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
+            const double r2[2] = {(double)P.uv[2 * row] - (double)u, (double)P.uv[2 * row + 1] - (double)v};
+            double rho0, rho1;
+            huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);
+            if (t == 0) chi_r = rho0;
+            w = rho1 * P.info_reproj;
+            const double pm = pfix ? 0.0 : 1.0, lm = rfix ? 0.0 : 1.0;
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                const int rr = T == 1 ? a : t;
+                const double j0 = -(double)(rr ? Jf[3] : Jf[0]), j1 = -(double)(rr ? Jf[4] : Jf[1]), j2 = -(double)(rr ? Jf[5] : Jf[2]);
+                const double r = rr ? r2[1] : r2[0];
+                rres[a] = r;
+                Jp[a][0] = pm * (-j1 * pz + j2 * py);
+                Jp[a][1] = pm * (j0 * pz - j2 * px);
+                Jp[a][2] = pm * (-j0 * py + j1 * px);
+                Jp[a][3] = pm * j0; Jp[a][4] = pm * j1; Jp[a][5] = pm * j2;
+                const double Jl0 = lm * (j0 * Rm[0] + j1 * Rm[3] + j2 * Rm[6]);
+                const double Jl1 = lm * (j0 * Rm[1] + j1 * Rm[4] + j2 * Rm[7]);
+                const double Jl2 = lm * (j0 * Rm[2] + j1 * Rm[5] + j2 * Rm[8]);
+                D[0] += w * (Jl0 * Jl0); D[1] += w * (Jl0 * Jl1); D[2] += w * (Jl0 * Jl2);
+                D[3] += w * (Jl1 * Jl1); D[4] += w * (Jl1 * Jl2); D[5] += w * (Jl2 * Jl2);
+                bb[0] -= w * (Jl0 * r); bb[1] -= w * (Jl1 * r); bb[2] -= w * (Jl2 * r);
+            }
+            if (t == 0) {
+                // factored form: the PCG kernels rebuild J_l, J_p from these 32 bytes
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
+                rc.w = lm * w;
+            }
+        }
+        if (t == 0) P.rowrec[row] = rc;
+        // H_pp (21 packed) / b_p (6) / chi2 partials of the tile: every value is formed right before its wave
+        // reduction, so the 28 of them never sit in registers together
+        int k = 0;
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+            for (int q = pp; q < 6; ++q) {
+                double v = 0;
+#pragma unroll
+                for (int a = 0; a < NRR; ++a) v += Jp[a][pp] * Jp[a][q];
+                const double sm = wave_sum(w * v);
+                if (lane == 0) lds28[wave * 28 + k] = sm;
+                ++k;
+            }
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            double v = 0;
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) v += Jp[a][pp] * rres[a];
+            const double sm = wave_sum(-w * v);
+            if (lane == 0) lds28[wave * 28 + 21 + pp] = sm;
+        }
+        {
+            const double sm = wave_sum(chi_r);
+            if (lane == 0) lds28[wave * 28 + 27] = sm;
+        }
+        __syncthreads();
+        if (tid < 28) P.part_lin[(size_t)b * 32 + tid] = lds28[tid] + lds28[28 + tid] + lds28[56 + tid] + lds28[84 + tid];
+    }
     // ---- springs
     const size_t nz = (size_t)P.ss_nnz;
     auto spring = [&](int idx, int o, int meta, double d0) {
         if (!(meta & SM_ACTIVE)) {
             if (LIN) {
-                if (LDS) P.s_rec[idx].qc = 0;
+                if (LDS) P.s_qc[idx] = 0;
                 else { P.s_g[idx] = 0; P.s_g[nz + idx] = 0; P.s_g[2 * nz + idx] = 0; }
             }
             return;
@@ -208,17 +304,23 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             if (P.X0) { y0 += P.X0[3 * o]; y1 += P.X0[3 * o + 1]; y2 += P.X0[3 * o + 2]; }
         }
         const double v0 = xs0 - y0, v1 = xs1 - y1, v2 = xs2 - y2;
-        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
-        const double r = P.k_spring * (d - d0) / d0;
+        const double d2 = v0 * v0 + v1 * v1 + v2 * v2;
+        // The linearisation pass is bound by fp64 VALU work as much as by traffic, and this is the bulk of it (two
+        // sqrt and three divisions as the reference writes it, position_regularizer.cc:40-60).  Same quantities from one
+        // rsqrt, one reciprocal (and one sqrt for the BA form's 1/sqrt(d)): results within 2 ulp of the literal form.
+        double d, id0 = 0, rs = 0;
+        if (LIN) { rs = rsqrt(d2); d = d2 * rs; id0 = 1.0 / d0; }
+        else d = sqrt(d2);
+        const double r = LIN ? P.k_spring * (d - d0) * id0 : P.k_spring * (d - d0) / d0;
         double rho0, rho1;
         huber(P.info_pos * r * r, P.delta_pos, rho0, rho1);
         if (meta & SM_COUNT) chi += rho0;
         if (LIN) {
-            const double cg = P.spring_form == 0 ? (P.k_spring / d0) * (1.0 / sqrt(d)) * 2.0
-                                                 : (P.k_spring / (2 * d0 * d)) * 2.0;
+            const double cg = P.spring_form == 0 ? 2.0 * P.k_spring * id0 * sqrt(rs)      // (k/d0) (1/sqrt(d)) 2
+                                                 : P.k_spring * id0 * rs;               // (k/(2 d0 d)) 2
             const double q = rfix ? 0.0 : rho1 * P.info_pos;
             const double g0 = cg * v0, g1 = cg * v1, g2 = cg * v2;
-            if (LDS) P.s_rec[idx].qc = q * cg * cg;
+            if (LDS) P.s_qc[idx] = q * cg * cg;
             else { const double sq = sqrt(q); P.s_g[idx] = sq * g0; P.s_g[nz + idx] = sq * g1; P.s_g[2 * nz + idx] = sq * g2; }
             D[0] += q * g0 * g0; D[1] += q * g0 * g1; D[2] += q * g0 * g2;
             D[3] += q * g1 * g1; D[4] += q * g1 * g2; D[5] += q * g2 * g2;
@@ -233,7 +335,10 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
                     const int o = (int)(hdr[q].x & 0xFFFFu), m16 = (int)(hdr[q].x >> 16);
-                    if (o == REC_NONE) continue;
+                    if (o == REC_NONE) {                           // padding slot: the operator reads its factor
+                        if (LIN && idx + 64 * q < end) P.s_qc[idx + 64 * q] = 0;
+                        continue;
+                    }
                     const int meta = ((m16 & SR_ACTIVE) ? SM_ACTIVE : 0) | ((m16 & SR_COUNT) ? SM_COUNT : 0);
                     spring(idx + 64 * q, o, meta, (double)__uint_as_float(hdr[q].y));
                 }
@@ -253,12 +358,13 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         }
     }
     // ---- dampers: r = w((x1n - x1c) - (x2n - x2c)), roles (1c,2c,1n,2n), signs (-,+,+,-)
-    auto damper = [&](int idx, int meta, const int* o, double w) {
+    auto damper = [&](int idx, int meta, const int* o, float wf) {
         if (!(meta & DM_ACTIVE)) {
-            if (LIN) { if (LDS) P.d_rec[idx].s = 0; else P.d_s[idx] = 0; }
+            if (LIN) P.d_s[idx] = 0;
             return;
         }
         if (!LIN && !(meta & DM_COUNT)) return;           // chi2 only: counted from one of the edge's rows
+        const double w = (double)wf;
         const int role = meta & 3;
         const double sgn_own = damper_sign(role);
         double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;
@@ -276,7 +382,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         if (LIN) {
             const double fx = rfix ? 0.0 : 1.0;
             const double sfac = fx * rho1 * P.info_spatial * w * w;
-            if (LDS) P.d_rec[idx].s = sfac; else P.d_s[idx] = sfac;
+            P.d_s[idx] = sfac;
             D[0] += sfac; D[3] += sfac; D[5] += sfac;
             const double c = fx * sgn_own * rho1 * P.info_spatial * w;
             bb[0] -= c * r0; bb[1] -= c * r1; bb[2] -= c * r2;
@@ -292,7 +398,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                     if (m16 == REC_NONE) continue;
                     const int r0 = (int)(hdr[q].x & 0xFFFFu), r1 = (int)(hdr[q].x >> 16), r2 = (int)(hdr[q].y & 0xFFFFu);
                     const int o[3] = {r0 == REC_NONE ? -1 : r0, r1 == REC_NONE ? -1 : r1, r2 == REC_NONE ? -1 : r2};
-                    damper(idx + 64 * q, m16, o, (double)ww[q]);
+                    damper(idx + 64 * q, m16, o, ww[q]);
                 }
             };
             for (int base = beg; base < end; base += 128 * U) {
@@ -306,7 +412,7 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                 const int meta = P.d_meta[idx];
                 if (meta < 0) continue;
                 const int o[3] = {P.d_o0[idx], P.d_o1[idx], P.d_o2[idx]};
-                damper(idx, meta, o, (double)P.d_w[idx]);
+                damper(idx, meta, o, P.d_w[idx]);
             }
         }
     }
@@ -321,10 +427,17 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         if (t == 0) {
             double* Dr = P.D + 6 * (size_t)row;
             double dd[6];
+            if (LDS) {                                      // the row's whole diagonal block and gradient: written once
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { dd[k] = Dr[k] + D[k]; Dr[k] = dd[k]; }
+                for (int k = 0; k < 6; ++k) { dd[k] = D[k]; Dr[k] = dd[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) P.bl[3 * row + k] += bb[k];
+                for (int k = 0; k < 3; ++k) P.bl[3 * row + k] = bb[k];
+            } else {                                        // gather path: k_reproj<true> left the reprojection part
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { dd[k] = Dr[k] + D[k]; Dr[k] = dd[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) P.bl[3 * row + k] += bb[k];
+            }
             part[1] = fmax(fabs(dd[0]), fmax(fabs(dd[3]), fabs(dd[5])));
         }
     }
@@ -396,7 +509,8 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
     double chi = 0, md = 0, sc = 0;
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
-    for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    else for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_rchi[g];
     if (!LIN && P.ec_on) {
         for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
     } else {
@@ -439,7 +553,8 @@ __global__ __launch_bounds__(BLK) void k_finalize_pack(Dev P) {
     double chi = 0, md = 0, sc = 0;
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
-    for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    else for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_rchi[g];
     if (!LIN && P.ec_on) {
         for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
     } else {
@@ -496,7 +611,7 @@ __global__ __launch_bounds__(BLK) void k_finalize_unpack(Dev P, int seq) {
     }
 }
 
-// H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the k_reproj partials
+// H_pp (21 packed) and b_p (6) of one pose per workgroup: fixed-order sums of the lineariser's partials
 // (8 lanes per component, then the 8 in order); red[3 + k] = max |diagonal| for the LM lambda_0
 __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     __shared__ double lds[8][32];
@@ -504,7 +619,7 @@ __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     const int k = P.sh_k0 + blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
     double s = 0;
     if (c < 27)
-        for (int g = P.pose_grp_ptr[k] + gl; g < P.pose_grp_ptr[k + 1]; g += 8) s += P.part_lin[(size_t)g * 32 + c];
+        for (int g = P.pose_grp_ptr[k] * P.lin_rb + gl; g < P.pose_grp_ptr[k + 1] * P.lin_rb; g += 8) s += P.part_lin[(size_t)g * 32 + c];
     lds[gl][c] = s;
     __syncthreads();
     if (tid < 32) {

@@ -177,9 +177,10 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 
 // =====================================================================================
 // PCG kernel 1, LDS-staged path: the same operator in factored form.  The tile's u and the positions
-// of the linearisation point are staged (own rows + halo); per incidence the kernel reads ONE
-// 16-byte record: spring  a_i += qc (v . (u_i - u_j)) v,  v = x_i - x_j;
-//                 damper  a_i += sg_i s (sum_k sg_k u_k)  (all four vertices, the own one included);
+// of the linearisation point are staged (own rows + halo); per incidence the kernel reads 12 bytes
+// (nrs_engine_types.hpp): spring {4-byte header, qc}  a_i += qc (v . (u_i - u_j)) v,  v = x_i - x_j;
+//                 damper {8-byte header, 4-byte weight}  a_i += sg_i s (sum_k sg_k u_k)  (all four vertices, the own one
+//                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
 template <int T>
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             sr[q].other = REC_NONE; sr[q].qc = 0;
-            if (j < send) sr[q] = P.s_rec[j];
+            if (j < send) sr[q] = load_spring(P, j);
         }
     };
     auto load_dampers = [&](DamperRec* dr, int idx) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             dr[q].meta = 0; dr[q].s = 0; dr[q].o0 = dr[q].o1 = dr[q].o2 = REC_NONE;
-            if (j < dend) dr[q] = P.d_rec[j];
+            if (j < dend) dr[q] = load_damper(P, j);
         }
     };
     load_springs(srA, sbeg + lane);
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             sr[q].other = REC_NONE;
-            if (j < send) sr[q] = P.s_rec[j];
+            if (j < send) sr[q] = load_spring(P, j);
         }
     };
     auto load_dampers = [&](int idx) {
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             dr[q].meta = REC_NONE;
-            if (j < dend) dr[q] = P.d_rec[j];
+            if (j < dend) dr[q] = load_damper(P, j);
         }
     };
     load_springs(sbeg + lane);

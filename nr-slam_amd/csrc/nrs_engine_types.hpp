@@ -18,13 +18,24 @@ constexpr int DM_COUNT = 1 << 2;     // damper: bits 0-1 role
 constexpr int DM_ACTIVE = 1 << 3;
 constexpr int DM_UNARY = 1 << 4;     // damper: the other vertex is a value, not a variable
 
-// packed incidence records of the LDS-staged path: one 16-byte load per incidence; neighbour ids
-// are tile-local (own rows, then halo).  The operator is applied in factored form: a spring block is
-// qc * v v^T with v = x_i - x_j re-formed from the staged linearisation point (qc = rho' Omega cg^2),
-// a reprojection block is J^T w J with J rebuilt from the fp32 projection Jacobian kept per row.
-struct __attribute__((aligned(16))) SpringRec { double qc; uint16_t other, meta; float d0; };   // 16 B
+// Incidence data of the LDS-staged path: structure-of-arrays streams in sliced-ELL order, every load / store of a
+// wave one contiguous run; neighbour ids are tile-local (own rows, then halo).
+//   springs : s_om  u32 {other u16 | meta u16 << 16}      static
+//             s_d0  f32 rest length                          static, lineariser only
+//             s_qc  f64 rho' Omega cg^2                      written by the lineariser (full-width stores), read by the operator
+//   dampers : d_hdr 2 x u32 {o0 | o1 << 16, o2 | meta << 16} static
+//             d_w   f32 edge weight                          static, lineariser only
+//             d_s   f64 rho' Omega w^2                       written by the lineariser (full-width stores), read by the operator
+// Every load is unconditional, so a chunk's loads are all in flight before anything waits on them.  (Tried and
+// dropped: re-forming s = Omega w w in the operator from the 4-byte weight and storing s only for Huber-active edges
+// -- 25 % less damper traffic, but the conditional load needs the weight first, which serialises the record
+// prefetch: operator 25 -> 32 us on C2.)
+// The operator is applied in factored form: a spring block is qc * v v^T with v = x_i - x_j re-formed from the staged
+// linearisation point, a damper block is +-s I3, a reprojection block is J^T w J with J rebuilt from the fp32
+// projection Jacobian kept per row.  SpringRec / DamperRec are the register views the kernels work on.
+struct SpringRec { double qc; uint16_t other, meta; };
 struct __attribute__((aligned(16))) RowRec { float J[6]; double w; };                           // 32 B
-struct __attribute__((aligned(16))) DamperRec { uint16_t o0, o1, o2, meta; double s; };                  // 16 B
+struct DamperRec { uint16_t o0, o1, o2, meta; double s; };
 constexpr uint16_t REC_NONE = 0xFFFF;
 constexpr uint16_t SR_ACTIVE = 1, SR_COUNT = 2;
 
@@ -59,7 +70,7 @@ struct Dev {
     // (= occupancy) of all: tile_list = class-0 tiles, then class-1 tiles; caps per class
     int* tile_list; int n_tiles_cls[2]; int cap_h[2], cap_s[2];
     int* halo_ptr; int* halo_rows; int* halo_ns;   // halo_ns[b] = number of spring-halo rows of tile b
-    SpringRec* s_rec; DamperRec* d_rec;
+    uint32_t* s_om; double* s_qc; uint2* d_hdr;      // (s_d0, d_w, d_s: above; sized by the incidence count in both paths)
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
     Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
     // state (two copies: current / trial, swapped on accept)
@@ -102,7 +113,9 @@ struct Dev {
     int ecd; double* part_ru;        // 2 x n_vecblk (ping-pong by iteration parity)
     double* red;                     // [0..2] r.u, w.u, cross ; [3 + 6k + a] pose sums
     // partials / scalars
-    double* part_lin;                // n_groups x 32   (reproj kernel: 27 pose sums + chi)
+    double* part_lin;                // lin_slots x 32  (lineariser: 27 pose sums + chi; per tile on the LDS path, else per group)
+    double* part_rchi;               // n_groups        (chi2-only reprojection pass)
+    int lin_rb;                      // part_lin slots per ROW_ALIGN group (tiles per group on the LDS path, else 1)
     double* part_reg;                // n_regblk x 2    (chi, maxdiag)
     double* part_spmv;               // n_regblk x NPART
     double* part_apply;              // n_vecblk
@@ -148,8 +161,8 @@ struct Engine {
     std::vector<float> sp_d0, dm_w, un_w;
     std::vector<int> sp_pos, dm_pos, un_pos;     // SELL positions of every incidence (2 / 4 / 1 per edge)
     std::vector<int> h_s_meta, h_d_meta;
-    std::vector<SpringRec> h_s_rec;
-    std::vector<DamperRec> h_d_rec;
+    std::vector<uint32_t> h_s_om;
+    std::vector<uint2> h_d_hdr;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
     // device copies for the taps
     int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
@@ -332,6 +345,22 @@ __device__ inline void row_factored(const RowRec& rc, const Pose& Tcw, const dou
     part[2] = w * (tl[0] * tp[0] + tl[1] * tp[1]);
 #pragma unroll
     for (int p = 0; p < 6; ++p) part[3 + p] = w * (Jp[0][p] * tl[0] + Jp[1][p] * tl[1]);
+}
+
+// register views of one incidence (see the stream layout at the top)
+__device__ inline SpringRec load_spring(const Dev& P, int j) {
+    const uint32_t om = P.s_om[j];
+    SpringRec r;
+    r.qc = P.s_qc[j];
+    r.other = (uint16_t)(om & 0xFFFFu); r.meta = (uint16_t)(om >> 16);
+    return r;
+}
+__device__ inline DamperRec load_damper(const Dev& P, int j) {
+    const uint2 h = P.d_hdr[j];
+    DamperRec r;
+    r.s = P.d_s[j];                                                // (0 for padding slots and for edges at level != 0)
+    r.o0 = (uint16_t)(h.x & 0xFFFFu); r.o1 = (uint16_t)(h.x >> 16); r.o2 = (uint16_t)(h.y & 0xFFFFu); r.meta = (uint16_t)(h.y >> 16);
+    return r;
 }
 
 __device__ inline double damper_sign(int role) { return (role == 0 || role == 3) ? -1.0 : 1.0; }
