@@ -2,18 +2,21 @@
 """bench.py -- deformable-BA LM iterations/sec on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one synthetic batch = one reference-shaped
-LocalDeformableBundleAdjustment solve, optimize(5) (reference g2o_optimization.cc:1141-1143), on
-BASELINE.json configs[1]: 5k map points x 20 keyframes (pinhole), every point a deformation-graph
-node (parity mode).  Inputs are uploaded to HBM once, outside the timed
-region; each timed step is {reset estimates (device-to-device), optimize(5)}.
+LocalDeformableBundleAdjustment solve, optimize(5) (reference g2o_optimization.cc:1141-1143).  Inputs are uploaded
+to HBM once, outside the timed region; each timed step is {reset estimates (device-to-device), optimize(5)}.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): `value` is measured with every rank
-solving its own, independent BA window of the same size (weak scaling over independent windows, no
-data-path collective -- DESIGN.md "Multi-GPU"); ranks are bracketed by a barrier and the slowest
-rank's time is used.  After that the same line gets a "sharded" object: ONE window of C2's points
-x 20*N keyframes split over the N ranks by keyframes (include/nrs.h "multi-GPU": RCCL all-reduce of
-the pose blocks / PCG sums + boundary-keyframe exchange per iteration), run by one child process
-per rank so that a failure of that path cannot take the benchmark line with it.
+N = 1: BASELINE.json configs[1] (C2: 5k map points x 20 keyframes, pinhole), every point a deformation-graph node
+(parity mode).  The line also carries `value_exact_trials` (every LM trial solved to 1e-10, as
+g2o does; `value` uses the early-rejection heuristic of nrs_options), the rooflines of the two dominant kernels
+(HIP events on the context's stream), the tracked-fps half of the metric and the CPU baseline (C++ restatement).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): `value` comes from ONE window -- BASELINE.json
+configs[3] (C4: 50k points x 200 keyframes) -- sharded over the N ranks by keyframes, in this process: RCCL
+all-reduce of the pose blocks of the normal equations / the PCG sums + boundary-keyframe exchange per iteration
+(include/nrs.h "multi-GPU"), "scaling": "strong".  Secondary fields: `independent_windows` (every rank its own C2
+window, no data-path collective: what a node does with independent LocalDeformableBundleAdjustment calls) and
+`single_gpu_same_window` (rank 0 alone on the same C4 window, for a like-for-like strong-scaling ratio).
+A watchdog prints the line with the independent-window figure as `value` if the sharded section does not finish.
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,45 +54,82 @@ def algorithmic_bytes(n_lm, n_sp, n_dm, n_blocks):
     return lin, spmv
 
 
-def cpu_baseline(seconds_budget=20.0, ctx=None):
-    """The oracle (kind "port": NumPy/SciPy restatement of the reference, oracle/nrs_oracle.py)
-    timed on this host, 1 core, on a bounded sample: the same generator at the reference's own
-    window size (5 keyframes, g2o_optimization.cc:894) with 400 points -- C2 itself (275k unknowns,
-    full sparse Cholesky per trial) does not finish in minutes on a CPU."""
+def gpu_iters_per_s(ctx, p, e, reps=10):
+    """the product path, resident like `value`, on a given window (for like-for-like ratios next to CPU samples)"""
+    import nrs
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    ctx.dba_optimize(5)
+    g_it = 0
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ctx.dba_reset()
+        tr = nrs.Trace(64)
+        ctx.dba_optimize(5, tr)
+        g_it += tr.iterations
+    return g_it / (time.perf_counter() - t1)
+
+
+def cpu_baseline(p2, e2, ctx=None, ctx_exact=None):
+    """The CPU side of the metric on THIS host: the C++ restatement of the reference's deformable BA
+    (oracle/nrs_cpu.cpp, kind "port"; rebuilt here with -O3 -march=native; checked against the NumPy oracle, the
+    g2o known-answer system and the C2 golden in tests/test_oracle_cpp_cpu.py), on bounded samples:
+      value            C2 itself, optimize(5), block-Jacobi PCG to 1e-10 on all cores (OpenMP): the fastest CPU
+                       form of the same LM (same trials, same iterates as the GPU's exact mode)
+      one_core         the reference's own window cap (5 keyframes x 5000 points), PCG, 1 core
+      sparse_cholesky  what the reference actually runs (full sparse Cholesky per LM trial, 1 thread: g2o OpenMP is
+                       off): AMD-ordered block Cholesky on 1000 points x 5 keyframes; C2 itself needs 8.3 TFLOP per
+                       factorisation (symbolic count, profiles/r02_cpu_baseline.json) = hours per optimize(5)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nrs
-    import nrs_oracle as O
+    import nrs_cpu as CPU
     import nrs_synth as S
-    p = S.make_dba_problem(400, 5, 1)
-    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
-    t0 = time.perf_counter()
-    iters = 0
-    runs = 0
-    while True:
-        _, _, _, nit = O.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"],
-                                   p["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], 5)
-        iters += nit
-        runs += 1
-        if time.perf_counter() - t0 > seconds_budget or runs >= 5:
-            break
-    dt = time.perf_counter() - t0
-    out = dict(value=iters / dt, unit="LM iters/s", cores=1, kind="port",
-               sample="optimize(5) on 400 points x 5 keyframes (%d landmarks, %d springs, %d dampers), %d runs, %.1f s"
-                      % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]), runs, dt))
+    try:
+        CPU.build(native=True)
+        lib, flags = CPU.load(native=True), "-O3 -march=native -fopenmp"
+    except Exception:                                        # no compiler on this host: the copy that travelled with the repo
+        lib, flags = CPU.load(), "-O3 -march=x86-64-v3 -fopenmp"
+    cores = CPU.max_threads(lib)
+
+    def run(p, e, solver, threads, max_trials=0):
+        t0 = time.perf_counter()
+        _, _, _, tr, st = CPU.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"], p["lm_uv"],
+                                        e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], 5, solver, 1e-10, threads, max_trials, lib)
+        return time.perf_counter() - t0, st
+
+    def shape(p, e):
+        return "%d landmarks, %d springs, %d dampers" % (len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"]))
+    # the PCG is memory-bound: more threads than memory channels make it slower (128 threads on the GPU box: 16 s, 32: ~5 s).
+    # The thread count is the fastest of a short sweep on the first LM trial of C2.
+    cand = sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
+    best = min(cand, key=lambda t: run(p2, e2, 1, t, 1)[1]["t_solve"])
+    avail, cores = cores, best
+    dt, st = run(p2, e2, 1, cores)
+    out = dict(value=st["n_iters"] / dt, unit="LM iters/s", cores=cores, cores_available=avail, kind="port",
+               sample="C2 itself (%s), one optimize(5): %d LM trials, %d PCG iterations, %.1f s; C++ restatement "
+                      "oracle/nrs_cpu.cpp (%s), block-Jacobi PCG 1e-10, OpenMP %d threads"
+                      % (shape(p2, e2), st["n_trials"], st["n_pcg_iters"], dt, flags, cores),
+               linearize_ms_per_lm_iter=1e3 * st["t_linearize"] / max(1, st["n_iters"]))
+    if ctx_exact is not None:
+        out["gpu_same_sample_exact_trials"] = gpu_iters_per_s(ctx_exact, p2, e2, 3)       # every trial solved to 1e-10 on both sides
+    p5 = S.make_dba_problem(5000, 5, 1)
+    e5 = nrs.dba_build_edges(p5["kf_points"], p5["nbr"])
+    dt, st = run(p5, e5, 1, 1)
+    out["one_core"] = dict(value=st["n_iters"] / dt, unit="LM iters/s", cores=1, solver="block-Jacobi PCG 1e-10",
+                           sample="5000 points x 5 keyframes = the reference's window cap (%s), optimize(5), %.1f s" % (shape(p5, e5), dt))
     if ctx is not None:
-        # the GPU path on the very same sample (resident, like `value`), for a like-for-like ratio
-        cam = nrs.make_camera(p["model"], p["prm"])
-        qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-        ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-        g_it, reps = 0, 20
-        ctx.dba_optimize(5)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            ctx.dba_reset()
-            tr = nrs.Trace(64)
-            ctx.dba_optimize(5, tr)
-            g_it += tr.iterations
-        out["gpu_same_sample"] = g_it / (time.perf_counter() - t1)
+        out["one_core"]["gpu_same_sample"] = gpu_iters_per_s(ctx, p5, e5)
+    p1 = S.make_dba_problem(1000, 5, 1)
+    e1 = nrs.dba_build_edges(p1["kf_points"], p1["nbr"])
+    dt, st = run(p1, e1, 0, 1)
+    out["sparse_cholesky"] = dict(value=st["n_iters"] / dt, unit="LM iters/s", cores=1,
+                                  solver="full sparse block Cholesky per LM trial, AMD ordering on the block pattern (what g2o + Eigen SimplicialLLT do)",
+                                  sample="1000 points x 5 keyframes (%s), optimize(5): %d factorisations of %.1f GFLOP at %.1f GFLOP/s, %.1f s"
+                                         % (shape(p1, e1), st["n_factor"], st["chol_flops"] / 1e9,
+                                            st["chol_flops"] * st["n_factor"] / max(1e-9, st["t_factor"]) / 1e9, dt))
+    if ctx is not None:
+        out["sparse_cholesky"]["gpu_same_sample"] = gpu_iters_per_s(ctx, p1, e1)
     out["tracked_fps"] = cpu_tracked_fps(ctx is not None)
     return out
 
@@ -193,136 +233,82 @@ def flush_c_stdio():
         pass
 
 
-def sharded_child(a):
-    """One rank of the sharded window (no torch in this process: ctypes + librccl only).  Prints one
-    JSON line with this rank's timing; the parent ranks reduce them."""
+def make_window(workload, seed_offset=0, n_points=None, n_kf=None):
     import nrs
     import nrs_synth as S
-    _, _, seed, model = S.CONFIGS[a.workload]
-    n_points, n_kf = a.sh_points, a.sh_kf
-    p = S.make_dba_problem(n_points, n_kf * a.sh_world, seed, model)       # the same window on every rank
+    np_, nk_, seed, model = S.CONFIGS[workload]
+    p = S.make_dba_problem(n_points or np_, n_kf or nk_, seed + seed_offset, model)
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
-    cam = nrs.make_camera(p["model"], p["prm"])
-    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-    ctx = nrs.Context(device=a.sh_device)
-    # the RCCL id is made by the rank-0 CHILD and handed to the others through a file on this node: all
-    # children load the same librccl (the parents' copy, PyTorch's, may be another version)
-    if a.sh_rank == 0:
-        with open(a.sh_uid_file + ".tmp", "wb") as f:
-            f.write(nrs.comm_unique_id())
-        os.replace(a.sh_uid_file + ".tmp", a.sh_uid_file)
-    t_wait = time.perf_counter()
-    while not os.path.exists(a.sh_uid_file):
-        if time.perf_counter() - t_wait > 60:
-            raise RuntimeError("no RCCL id from rank 0 after 60 s")
-        time.sleep(0.01)
-    ctx.comm_init_rccl(a.sh_world, a.sh_rank, open(a.sh_uid_file, "rb").read())
-    t_up = time.perf_counter()
-    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-    t_up = time.perf_counter() - t_up
-    for _ in range(a.warmup):
-        ctx.dba_reset()
-        ctx.dba_optimize(5)                  # collective: the ranks leave it together
-    t0 = time.perf_counter()
-    lm_iters = trials = inner = 0
-    for _ in range(a.steps):
-        ctx.dba_reset()
-        tr = nrs.Trace(64)
-        ctx.dba_optimize(5, tr)
-        lm_iters += tr.iterations
-        trials += tr.c.count
-        inner += sum(t["inner"] for t in tr.trials)
-    dt = time.perf_counter() - t0
-    kb = nrs.shard_plan(n_kf * a.sh_world, p["lm_kf"], a.sh_world)
-    ctx.close()
-    flush_c_stdio()
-    print(json.dumps(dict(dt=dt, lm_iters=lm_iters, trials=trials, inner=inner, upload_s=t_up, n_kf=n_kf * a.sh_world,
-                          landmarks=len(p["lm_kf"]), springs=len(e["sp_ij"]), dampers=len(e["dm_idx"]),
-                          keyframes_of_rank=[int(kb[a.sh_rank]), int(kb[a.sh_rank + 1])])), flush=True)
+    return p, e, nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1)
 
 
-def run_sharded(args, dist, rank, world, local_rank, timeout_s=120, n_points=None, kf_per_rank=None):
-    """All parent ranks: start this rank's child of the sharded window, collect its line.  Returns the
-    "sharded" object on rank 0 (an {"error": ...} object if any rank's child failed or timed out).
-    Window: n_points map points x kf_per_rank * world keyframes (default: the workload's own size per rank)."""
-    import nrs_synth as S0
-    n_points = n_points or S0.CONFIGS[args.workload][0]
-    kf_per_rank = kf_per_rank or S0.CONFIGS[args.workload][1]
-    import subprocess
-    import torch
+def timed_steps(ctx, steps, warmup, barrier):
+    """W untimed steps, then exactly K timed steps bracketed by barrier(); returns this rank's figures"""
     import nrs
-    import tempfile
-    dev = "cuda" if torch.cuda.is_available() else "cpu"     # cpu: the gloo test of this bookkeeping
-    # rendezvous file for the children's RCCL id (one node): rank 0 picks the name, everybody learns it
-    name = torch.zeros(256, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        fd, path = tempfile.mkstemp(prefix="nrs_rccl_id_", suffix=".bin")
-        os.close(fd)
-        os.unlink(path)                                        # the rank-0 child creates it (atomically)
-        raw = path.encode()[:255]
-        name[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
-    dist.broadcast(name, src=0)
-    uid_file = bytes(name.cpu().tolist()).rstrip(b"\0").decode()
-    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--workload", args.workload,
-           "--steps", str(args.steps), "--warmup", str(args.warmup), "--sh-world", str(world), "--sh-rank", str(rank),
-           "--sh-device", str(local_rank), "--sh-uid-file", uid_file,
-           "--sh-points", str(n_points), "--sh-kf", str(kf_per_rank)]
-    res, err = None, None
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
-        if r.returncode != 0:
-            err = "rank %d: exit %d: %s" % (rank, r.returncode, r.stderr.strip()[-300:])
-        else:
-            res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # (RCCL prints a banner on stdout)
-    except subprocess.TimeoutExpired:
-        err = "rank %d: no result after %d s" % (rank, timeout_s)
-    except Exception as ex:                                   # malformed output etc.
-        err = "rank %d: %r" % (rank, ex)
-    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        for f in (uid_file, uid_file + ".tmp"):
-            if os.path.exists(f):
-                os.unlink(f)
-    if ok.item() < 1.0:
-        return {"error": err or "another rank's child failed"} if rank == 0 else None
-    dt, _ = reduce_over_ranks(dist, res["dt"], 0.0, dev)
-    if rank != 0:
-        return None
-    it_s = res["lm_iters"] / dt
-    return {"workload": "ONE window: %d map points x %d keyframes (%d per rank), keyframes split over %d ranks"
-                        % (n_points, res["n_kf"], kf_per_rank, world),
-            "exchange": "RCCL: per linearisation all-reduce of H_pp/b_p/chi2 (27 K + 10 doubles) + boundary-keyframe rows; "
-                        "per PCG iteration boundary rows of u + all-reduce of 3 + 6 K doubles",
-            "lm_iters_per_s": it_s, "per_rank_windows_equivalent_iters_per_s": it_s * world, "ms_per_step": 1e3 * dt / args.steps,
-            "lm_trials_per_step": res["trials"] / args.steps, "pcg_iters_per_step": res["inner"] / args.steps,
-            "us_per_pcg_iter_incl_lm": 1e6 * dt / max(1, res["inner"]),
-            "landmarks": res["landmarks"], "springs": res["springs"], "dampers": res["dampers"], "upload_s": res["upload_s"]}
-
-
-def single_gpu_reference(ctx_device, workload, n_points, n_kf, steps, warmup):
-    """The per-rank share of a sharded window as a plain single-GPU window (what N = 1 would run)."""
-    import nrs
-    import nrs_synth as S
-    _, _, seed, model = S.CONFIGS[workload]
-    p = S.make_dba_problem(n_points, n_kf, seed, model)
-    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
-    ctx = nrs.Context(device=ctx_device)
-    ctx.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"],
-                   p["lm_uv"], e, p["scale"])
     for _ in range(warmup):
         ctx.dba_reset()
         ctx.dba_optimize(5)
+    barrier()
     t0 = time.perf_counter()
-    its = 0
+    lm_iters = trials = inner = 0
     for _ in range(steps):
         ctx.dba_reset()
         tr = nrs.Trace(64)
-        ctx.dba_optimize(5, tr)
-        its += tr.iterations
-    dt = time.perf_counter() - t0
+        ctx.dba_optimize(5, tr)              # returns after the last host read-back: the stream is idle
+        lm_iters += tr.iterations
+        trials += tr.c.count
+        inner += sum(t["inner"] for t in tr.trials)
+    barrier()
+    return dict(dt=time.perf_counter() - t0, lm_iters=lm_iters, trials=trials, inner=inner)
+
+
+def run_sharded(dist, rank, world, local_rank, steps, warmup, barrier, window, dev):
+    """ONE window over all ranks, in this process.  The RCCL unique id is made by rank 0's library and broadcast
+    with torch.distributed; every rank uploads the same window and owns a contiguous keyframe range of it
+    (nrs_shard_plan); reset / optimize are collective.  Returns this rank's timing."""
+    import torch
+    import nrs
+    p, e, cam, qt = window
+    msg = torch.zeros(1 + nrs.COMM_ID_BYTES, dtype=torch.uint8, device=dev)      # [ok, id bytes]
+    if rank == 0:
+        try:
+            msg = torch.tensor([1] + list(nrs.comm_unique_id()), dtype=torch.uint8, device=dev)
+        except Exception:                                       # librccl not loadable / no device: every rank must learn it
+            pass
+    dist.broadcast(msg, src=0)
+    raw = bytes(msg.cpu().tolist())
+    if raw[0] != 1:
+        raise RuntimeError("rank 0 could not create an RCCL unique id")
+    ctx = nrs.Context(device=local_rank)
+    ctx.comm_init_rccl(world, rank, raw[1:])
+    t_up = time.perf_counter()
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    t_up = time.perf_counter() - t_up
+    res = timed_steps(ctx, steps, warmup, barrier)
+    kb = nrs.shard_plan(len(qt), p["lm_kf"], world)
+    res.update(upload_s=t_up, keyframes_of_rank=[int(kb[rank]), int(kb[rank + 1])], rccl_world=ctx.comm_rank()[1])
     ctx.close()
-    return dict(lm_iters_per_s=its / dt, ms_per_step=1e3 * dt / steps, landmarks=len(p["lm_kf"]))
+    return res
+
+
+def sharded_section(dist, rank, world, local_rank, steps, warmup, barrier, window, dev):
+    """run_sharded + agreement: returns (result, None) on every rank, or (None, error text) on every rank.  Failures
+    that every rank sees (no device, librccl missing, a window that cannot be split) come back as errors; a rank that
+    dies inside a collective is the watchdog's business (main)."""
+    import torch
+    err, res = None, None
+    try:
+        res = run_sharded(dist, rank, world, local_rank, steps, warmup, barrier, window, dev)
+    except Exception as ex:
+        err = "rank %d: %r" % (rank, ex)
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() > 0:
+        seen = torch.tensor([float(res["rccl_world"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+        res["rccl_ranks_seen"] = int(seen.item())
+        return res, None
+    return None, err or "another rank failed"
 
 
 def shi_extract_bench(reps=20):
@@ -357,66 +343,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--workload", default="C2", help="N = 1: the window `value` is measured on")
+    ap.add_argument("--sharded-workload", default="C4", help="N > 1: the ONE window that is sharded over the ranks")
+    ap.add_argument("--sharded-points", type=int, default=0, help="override the sharded window's map points (tests)")
+    ap.add_argument("--sharded-kf", type=int, default=0, help="override the sharded window's keyframes (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-window measurement")
-    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--sh-world", type=int, default=1, help=argparse.SUPPRESS)
-    ap.add_argument("--sh-rank", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--sh-device", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--sh-uid-file", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--sh-points", type=int, default=5000, help=argparse.SUPPRESS)
-    ap.add_argument("--sh-kf", type=int, default=20, help=argparse.SUPPRESS)
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: independent windows only")
+    ap.add_argument("--sharded-timeout", type=float, default=900.0)
     args = ap.parse_args()
-    if args.sharded_child:
-        return sharded_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
-    if world > 1 or os.environ.get("NRS_BENCH_FORCE_DIST"):   # (the switch: plumbing check of the N > 1 path on a 1-GPU box)
+    multi = world > 1 or bool(os.environ.get("NRS_BENCH_FORCE_DIST"))   # (the switch: plumbing check of the N > 1 path on a 1-GPU box)
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl")
     import nrs
     import nrs_synth as S
 
-    n_points, n_kf, seed, model = S.CONFIGS[args.workload]
-    p = S.make_dba_problem(n_points, n_kf, seed + 1000 * rank, model)
-    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
-    cam = nrs.make_camera(p["model"], p["prm"])
-    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-    ctx = nrs.Context(device=local_rank)          # fails loudly without a HIP device
-    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ctx.dba_reset()
-        ctx.dba_optimize(5)
-    barrier()
-    t0 = time.perf_counter()
-    lm_iters = 0
-    trials = 0
-    inner = 0
-    for _ in range(args.steps):
-        ctx.dba_reset()
-        tr = nrs.Trace(64)
-        ctx.dba_optimize(5, tr)              # returns after the last host read-back: stream is idle
-        lm_iters += tr.iterations
-        trials += tr.c.count
-        inner += sum(t["inner"] for t in tr.trials)
-    barrier()
-    dt = time.perf_counter() - t0
-    dt, lm_iters_all = reduce_over_ranks(dist, dt, lm_iters, "cuda" if dist is not None else None)
+    n_points, n_kf, seed, model = S.CONFIGS[args.workload]
+    p, e, cam, qt = make_window(args.workload, 1000 * rank)
+    ctx = nrs.Context(device=local_rank)          # fails loudly without a HIP device
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    r = timed_steps(ctx, args.steps, args.warmup, barrier)
+    dev = "cuda" if dist is not None else None
+    dt, lm_iters_all = reduce_over_ranks(dist, r["dt"], r["lm_iters"], dev)
+    arith = "fp64 state / normal equations / PCG, fp32 projection and projection Jacobian (as the reference)"
+    n_lm, n_sp, n_dm = len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"])
+
+    def describe(name, npts, nkf, mdl):
+        return "%s: %d map points x %d keyframes, %s, every point a graph node; optimize(5) per step" % (
+            name, npts, nkf, "pinhole" if mdl == 0 else "KannalaBrandt8")
 
     out = None
     if rank == 0:
+        out = {"metric": "deformable-BA LM iters/sec", "value": lm_iters_all / dt, "unit": "LM iters/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": describe(args.workload, n_points, n_kf, model), "arithmetic": arith,
+                          "landmarks": n_lm, "springs": n_sp, "dampers": n_dm, "lm_trials_per_step": r["trials"] / args.steps,
+                          "pcg_iters_per_step": r["inner"] / args.steps,
+                          "parallelism": "independent BA window per GPU" if world > 1 else "1 GPU"}}
+    if not multi and rank == 0:
+        # ---- the same steps with every LM trial solved to pcg_rtol (g2o's behaviour; `value` rejects hopeless trials early)
+        xctx = nrs.Context(device=local_rank, exact_trials=1)
+        xctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        rx = timed_steps(xctx, max(2, args.steps // 4), 1, barrier)
+        out["value_exact_trials"] = rx["lm_iters"] / rx["dt"]
+        out["config"]["pcg_iters_per_step_exact_trials"] = rx["inner"] / max(2, args.steps // 4)
         # ---- roofline of the dominant kernels: HIP events on the context's own stream ----------
         pctx = nrs.Context(device=local_rank, profile=1)
         pctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
@@ -426,7 +409,6 @@ def main():
         pctx.dba_optimize(5)
         prof = pctx.profile()
         pctx.close()
-        n_lm, n_sp, n_dm = len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"])
         nblk = unique_blocks(n_lm, e["sp_ij"], e["dm_idx"])
         lin_b, spmv_b = algorithmic_bytes(n_lm, n_sp, n_dm, nblk)
         spmv_us = 1e3 * prof["spmv_ms"] / max(1, prof["spmv_launches"])
@@ -437,47 +419,68 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {})
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
         lin_gbs = lin_b / (lin_us * 1e-6) / 1e9
-        out = {
-            "metric": "deformable-BA LM iters/sec", "value": lm_iters_all / dt, "unit": "LM iters/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d map points x %d keyframes, %s, every point a graph node; "
-                                   "optimize(5) per step" % (args.workload, n_points, n_kf,
-                                                             "pinhole" if model == 0 else "KannalaBrandt8"),
-                       "arithmetic": "fp64 state / normal equations / PCG, fp32 projection and projection Jacobian (as the reference)",
-                       "landmarks": n_lm, "springs": n_sp, "dampers": n_dm,
-                       "lm_trials_per_step": trials / args.steps, "pcg_iters_per_step": inner / args.steps,
-                       "parallelism": "independent BA window per GPU" if world > 1 else "1 GPU"},
-            "roofline": {"kernel": "k_spmv (PCG operator apply, dominant: see profiles/)", "bound": "hbm",
-                         "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                         "traffic": (traffic or {}).get("k_spmv"), "avg_us": spmv_us,
-                         "algorithmic_bytes": spmv_b, "launches": prof["spmv_launches"]},
-            "roofline_linearize": {"kernel": "k_reproj<true> + k_reg<true> (residual/Jacobian + assemble)", "bound": "hbm",
-                                   "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"),
-                                   "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]},
-        }
-        if world == 1:
-            out["tracked_fps"] = tracked_fps()
-            out["shi_extract"] = shi_extract_bench()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx=ctx)
+        out["roofline"] = {"kernel": "k_spmv_f (PCG operator apply, dominant: see profiles/)", "bound": "hbm",
+                           "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                           "traffic": (traffic or {}).get("k_spmv"), "avg_us": spmv_us,
+                           "algorithmic_bytes": spmv_b, "launches": prof["spmv_launches"]}
+        out["roofline_linearize"] = {"kernel": "k_reg<T, true, true> (residuals + Jacobians + Huber + per-incidence factors + row blocks, one fused pass)",
+                                     "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"),
+                                     "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]}
+        out["tracked_fps"] = tracked_fps()
+        out["shi_extract"] = shi_extract_bench()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
+        xctx.close()
     ctx.close()
-    if dist is not None and not args.no_sharded:
-        dist.barrier()
-        sh = run_sharded(args, dist, rank, world, local_rank)
-        # the same with 2.5x larger shards (10k points x 25 keyframes per rank): where the exchange steps weigh less
-        big_pts, big_kf = 10000, 25
-        ok1 = torch.tensor([1.0 if (rank != 0 or (isinstance(sh, dict) and "error" not in sh)) else 0.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ok1, op=dist.ReduceOp.MIN)               # every rank learns whether the first window worked
-        sh2 = run_sharded(args, dist, rank, world, local_rank, n_points=big_pts, kf_per_rank=big_kf) if ok1.item() > 0 else (
-            {"error": "skipped: the first sharded window failed"} if rank == 0 else None)
+
+    if multi and not args.no_sharded:
+        # ---- ONE window sharded over the ranks: this is `value` at N > 1 ------------------------------------
+        import threading
         if rank == 0:
-            out["sharded"] = sh
-            if isinstance(sh2, dict) and "error" not in sh2:
-                sh2["single_gpu_same_shard"] = single_gpu_reference(local_rank, args.workload, big_pts, big_kf, args.steps, args.warmup)
-            out["sharded_large_shards"] = sh2
+            out["independent_windows"] = {"value": out["value"], "unit": "LM iters/s", "ms_per_step": out["ms_per_step"],
+                                          "workload": out["config"]["workload"], "note": "every rank its own window, no data-path collective"}
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(args.sharded_timeout):
+                return
+            if rank == 0:                                     # the sharded section hangs: the independent-window figure stands
+                out["sharded_error"] = "the sharded window did not finish within %.0f s" % args.sharded_timeout
+                flush_c_stdio()
+                print(json.dumps(out), flush=True)
+            os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        sn, sk, _, smodel = S.CONFIGS[args.sharded_workload]
+        sn, sk = args.sharded_points or sn, args.sharded_kf or sk
+        win = make_window(args.sharded_workload, 0, sn, sk)          # the same window on every rank
+        res, err = sharded_section(dist, rank, world, local_rank, args.steps, args.warmup, barrier, win, "cuda")
+        if res is not None:
+            sdt, _ = reduce_over_ranks(dist, res["dt"], 0.0, "cuda")
+            single = None
+            if rank == 0 and world > 1:
+                # rank 0 alone on the same window (the other ranks wait at the barrier below)
+                c1 = nrs.Context(device=local_rank)
+                pw, ew, camw, qtw = win
+                c1.dba_upload(camw, qtw, pw["lm_xyz"], pw["lm_kf"], pw["lm_uv"], ew, pw["scale"])
+                r1 = timed_steps(c1, max(2, args.steps // 4), 1, lambda: torch.cuda.synchronize())
+                c1.close()
+                single = {"value": r1["lm_iters"] / r1["dt"], "unit": "LM iters/s", "ms_per_step": 1e3 * r1["dt"] / max(2, args.steps // 4)}
+            if rank == 0:
+                pw, ew = win[0], win[1]
+                out.update({"value": res["lm_iters"] / sdt, "ms_per_step": 1e3 * sdt / args.steps, "scaling": "strong"})
+                out["config"] = {"workload": "ONE window sharded over %d ranks by keyframes -- " % world + describe(args.sharded_workload, sn, sk, smodel),
+                                 "arithmetic": arith, "landmarks": len(pw["lm_kf"]), "springs": len(ew["sp_ij"]), "dampers": len(ew["dm_idx"]),
+                                 "lm_trials_per_step": res["trials"] / args.steps, "pcg_iters_per_step": res["inner"] / args.steps,
+                                 "parallelism": "keyframe ranges over %d GPUs; RCCL all-reduce of H_pp / b_p / chi2 per linearisation and of 3 + 6 K "
+                                                "PCG sums per iteration, boundary-keyframe rows with rank +-1" % world,
+                                 "rccl_ranks_seen": res["rccl_ranks_seen"], "upload_s_rank0": res["upload_s"],
+                                 "keyframes_of_rank0": res["keyframes_of_rank"]}
+                if single:
+                    out["single_gpu_same_window"] = single
+        elif rank == 0:
+            out["sharded_error"] = err or "another rank failed"
+        done.set()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -459,30 +459,37 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
 // =====================================================================================
 __global__ __launch_bounds__(BLK) void k_chi_edges(Dev P, const double* __restrict__ xl) {
     __shared__ double lds[4];
-    const int tid = threadIdx.x, i = blockIdx.x * BLK + tid;
+    // a fixed number of workgroups (<= 2048, so that the single-workgroup k_finalize has few partials to sum: on C4
+    // 428k partials made it 760 us per trial), each over a contiguous range of edges in a fixed order
+    const int tid = threadIdx.x, n = P.ec_nsp + P.ec_ndm;
+    const int per = (int)((((int64_t)n + P.ec_nblk - 1) / P.ec_nblk + BLK - 1) / BLK) * BLK;
+    const int64_t beg = (int64_t)blockIdx.x * per;
+    const int end = (int)(beg + per < n ? beg + per : n);
     double rho[1] = {0};
-    if (i < P.ec_nsp) {
-        const EcSpring s = P.ec_sp[i];
-        const double v0 = xl[3 * (size_t)s.a] - xl[3 * (size_t)s.b], v1 = xl[3 * (size_t)s.a + 1] - xl[3 * (size_t)s.b + 1],
-                     v2 = xl[3 * (size_t)s.a + 2] - xl[3 * (size_t)s.b + 2];
-        const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2), d0 = (double)s.d0;
-        const double r = P.k_spring * (d - d0) / d0;
-        double rho1;
-        huber(P.info_pos * r * r, P.delta_pos, rho[0], rho1);
-    } else if (i < P.ec_nsp + P.ec_ndm) {
-        const EcDamper dd = P.ec_dm[i - P.ec_nsp];
-        const double w = (double)P.ec_w[i - P.ec_nsp];
-        double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = (int)beg + tid; i < end; i += BLK) {
+        double r0v, rho1;
+        if (i < P.ec_nsp) {
+            const EcSpring s = P.ec_sp[i];
+            const double v0 = xl[3 * (size_t)s.a] - xl[3 * (size_t)s.b], v1 = xl[3 * (size_t)s.a + 1] - xl[3 * (size_t)s.b + 1],
+                         v2 = xl[3 * (size_t)s.a + 2] - xl[3 * (size_t)s.b + 2];
+            const double d = sqrt(v0 * v0 + v1 * v1 + v2 * v2), d0 = (double)s.d0;
+            const double r = P.k_spring * (d - d0) / d0;
+            huber(P.info_pos * r * r, P.delta_pos, r0v, rho1);
+        } else {
+            const EcDamper dd = P.ec_dm[i - P.ec_nsp];
+            const double w = (double)P.ec_w[i - P.ec_nsp];
+            double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (dd.r[k] >= 0) {
-                const double sg = damper_sign(k);
-                s0 += sg * xl[3 * (size_t)dd.r[k]]; s1 += sg * xl[3 * (size_t)dd.r[k] + 1]; s2 += sg * xl[3 * (size_t)dd.r[k] + 2];
+            for (int k = 0; k < 4; ++k) {
+                if (dd.r[k] >= 0) {
+                    const double sg = damper_sign(k);
+                    s0 += sg * xl[3 * (size_t)dd.r[k]]; s1 += sg * xl[3 * (size_t)dd.r[k] + 1]; s2 += sg * xl[3 * (size_t)dd.r[k] + 2];
+                }
             }
+            const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
+            huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, r0v, rho1);
         }
-        const double r0 = w * s0, r1 = w * s1, r2 = w * s2;
-        double rho1;
-        huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho[0], rho1);
+        rho[0] += r0v;
     }
     block_sum<1>(rho, lds, tid & 63, tid >> 6);
     if (tid == 0) P.part_ec[blockIdx.x] = rho[0];

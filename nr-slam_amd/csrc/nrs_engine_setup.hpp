@@ -581,7 +581,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             }
         }
         d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
-        d.ec_nblk = (d.ec_nsp + d.ec_ndm + BLK - 1) / BLK;
+        d.ec_nblk = std::min((d.ec_nsp + d.ec_ndm + BLK - 1) / BLK, 2048);
     }
     mark("edge lists");
     // ---- device memory: one arena allocation, reused across calls when large enough

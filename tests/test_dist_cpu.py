@@ -51,19 +51,21 @@ def _worker_sharded(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd", "py"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import argparse
     import bench
-    args = argparse.Namespace(workload="C2", steps=1, warmup=0)
-    sh = bench.run_sharded(args, dist, rank, world, rank, timeout_s=120)
+    import nrs
+    win = bench.make_window("C2", 0, 120, 4)                  # the same small window on both ranks
+    kb = nrs.shard_plan(4, win[0]["lm_kf"], world)
+    res, err = bench.sharded_section(dist, rank, world, rank, 1, 0, dist.barrier, win, "cpu")
     dist.barrier()
-    q.put((rank, sh))
+    q.put((rank, res, err, kb.tolist(), float(win[0]["lm_xyz"].sum())))
     dist.destroy_process_group()
 
 
 def test_sharded_window_bookkeeping_without_gpu():
-    """bench.run_sharded on two gloo ranks of a box without a GPU: the unique id is broadcast, every rank
-    starts its child, the children fail (no HIP device: there is no CPU fallback), every rank learns that
-    through the MIN all-reduce and rank 0 gets an error object instead of a hang or a crash."""
+    """bench.sharded_section (what `value` comes from at N > 1) on two gloo ranks of a box without a GPU: the RCCL id
+    (or the fact that there is none) is broadcast, both ranks build the SAME window and the same keyframe plan, the
+    upload fails on every rank (no HIP device: there is no CPU fallback), every rank learns that through the MIN
+    all-reduce and gets an error text instead of a hang or a crash."""
     if torch.cuda.is_available():
         import pytest
         pytest.skip("a GPU is present")
@@ -76,12 +78,14 @@ def test_sharded_window_bookkeeping_without_gpu():
     procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
+    res = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[1] is None
-    assert isinstance(res[0], dict) and "error" in res[0] and "rank 0" in res[0]["error"]
+    assert res[0][1] is None and res[1][1] is None
+    assert isinstance(res[0][2], str) and isinstance(res[1][2], str)
+    assert res[0][3] == res[1][3] == [0, 2, 4]                 # the plan: two keyframes per rank
+    assert res[0][4] == res[1][4]                              # one window, not one per rank
 
 
 def test_single_process_passthrough():
