@@ -311,6 +311,50 @@ def sharded_section(dist, rank, world, local_rank, steps, warmup, barrier, windo
     return None, err or "another rank failed"
 
 
+def rgraph_bench(n=5000):
+    """a19 / a20 at the reference's density (all-pairs graph over n points): all-pairs initialisation,
+    UpdateVertex of 90 % of the points (n - 1 connections each), GetEdges of every point -- host ids / positions in,
+    results out (PCIe-inclusive) -- next to the NumPy restatement oracle/rgraph_oracle.py on a 600-point graph (1 core)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nrs
+    import rgraph_oracle as RG
+    rng = np.random.default_rng(5)
+    pos = np.stack([rng.uniform(-22, 22, n), rng.uniform(-17, 17, n), 60 + rng.normal(0, 1, n)], 1).astype(np.float32)
+    ids = np.arange(n, dtype=np.int32)
+    upd = np.sort(rng.choice(n, int(0.9 * n), replace=False)).astype(np.int32)
+    ctx = nrs.Context()
+    g = nrs.RGraph(ctx, n, 2.2, 1.1)
+    g.add_edges(pos, ids, ids)
+
+    def t(fn, reps=5):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return 1e3 * (time.perf_counter() - t0) / reps
+    out = dict(points=n, connections_per_point=n - 1, dense_state_MB=13 * n * n / 1e6,
+               ms_add_all_pairs=t(lambda: g.add_edges(pos, ids, ids)),
+               ms_update_vertices=t(lambda: g.update(pos + np.float32(0.01), upd)), updated_points=int(len(upd)),
+               ms_get_edges_all_points=t(lambda: g.get_edges(ids, 256)))
+    g.close()
+    ctx.close()
+    m = 600
+    D = RG.DenseGraph(m, 2.2 * np.sqrt(5000 / m), 1.1)
+    pm = pos[:m]
+    t0 = time.perf_counter()
+    D.add_edges(pm, np.arange(m), np.arange(m))
+    t1 = time.perf_counter()
+    for i in range(0, m, 2):
+        D.update_vertex(pm, i)
+    t2 = time.perf_counter()
+    for i in range(m):
+        D.get_edges(i)
+    t3 = time.perf_counter()
+    out["cpu_oracle"] = dict(points=m, kind="port (NumPy, 1 core)", ms_add_all_pairs=1e3 * (t1 - t0), ms_update_vertices=1e3 * (t2 - t1),
+                             updated_points=m // 2, ms_get_edges_all_points=1e3 * (t3 - t2))
+    return out
+
+
 def shi_extract_bench(reps=20):
     """Shi-Tomasi extraction on a 640x480 frame holding 1500 keypoints (host image in,
     keypoints out: PCIe-inclusive), next to the oracle's per-cell NumPy form on this host (1 core)."""
@@ -429,6 +473,7 @@ def main():
                                      "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]}
         out["tracked_fps"] = tracked_fps()
         out["shi_extract"] = shi_extract_bench()
+        out["graph_dense"] = rgraph_bench()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
         xctx.close()

@@ -250,6 +250,36 @@ int nrs_graph_select_neighbours(nrs_ctx* ctx, const nrs_graph* g, int32_t* o_row
 int nrs_graph_update(nrs_ctx* ctx, nrs_graph* g, const float* pos, int32_t n_ids, const int32_t* ids,
                      int32_t* good_count);
 
+/* ---- a19 / a20 at the reference's density: RegularizationGraph as a device-resident object ----------------------
+ * The reference graph is all-pairs (Map::InitializeRegularizationGraph, modules/map/map.cc:148-166; graph growth
+ * modules/mapping/mapping.cc:240-256): every vertex has N - 1 connections, UpdateVertex counts ALL of them (its
+ * return value feeds the caller's "fewer than 5 good connections -> BAD", g2o_optimization.cc:468-473), so a radius
+ * cut-off is not equivalent.  nrs_rgraph keeps the dense edge state in HBM (capacity^2 x 13 bytes: 5k points =
+ * 325 MB) and replaces the bodies of the class' methods (modules/map/regularization_graph.cc):
+ *   nrs_rgraph_create     RegularizationGraph(Options&, Map*) :27-31       point indices are 0 .. capacity-1
+ *   nrs_rgraph_set_sigma  SetSigma :33-36
+ *   nrs_rgraph_add_edges  AddEdge :38-55 for every (new, other) pair, new != other, relative position pos[other] -
+ *                         pos[new]; all-pairs initialisation: new = other = every initial point
+ *   nrs_rgraph_update     UpdateVertex :130-146 for the listed points; good_count[i] = its return value
+ *   nrs_rgraph_get_edges  GetEdges :71-87 for the listed points: (status asc, weight desc, index asc), cut at the first
+ *                         weight below min_weight; fixed-stride outputs [n_ids][cap_per_point] + count[n_ids];
+ *                         NRS_ERR_INVALID if a point has more than cap_per_point entries
+ *   nrs_rgraph_edge       GetEdge :57-59 (out = weight, first, max, min distance; status -1 = no such edge)
+ * pos is capacity x 3 floats (positions by point index; rows of unlisted points are not read). */
+typedef struct nrs_rgraph nrs_rgraph;
+int nrs_rgraph_create(nrs_ctx* ctx, int32_t capacity, float sigma, float stretch_th, nrs_rgraph** out);
+void nrs_rgraph_destroy(nrs_rgraph* g);
+int nrs_rgraph_set_sigma(nrs_rgraph* g, float sigma);
+float nrs_rgraph_min_weight(const nrs_rgraph* g);
+int nrs_rgraph_add_edges(nrs_rgraph* g, const float* pos, int32_t n_new, const int32_t* new_ids, int32_t n_other,
+                         const int32_t* other_ids);
+int nrs_rgraph_update(nrs_rgraph* g, const float* pos, int32_t n_ids, const int32_t* ids, int32_t* good_count);
+int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, int32_t* count,
+                         int32_t* col, float* w, float* d0, int32_t* status);
+int nrs_rgraph_edge(nrs_rgraph* g, int32_t i, int32_t j, float out[4], int32_t* status);
+/* parity tap: rows of the dense state, n_ids x capacity each (status 255 = no edge; any pointer may be null) */
+int nrs_rgraph_rows(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, float* maxd, float* mind, float* d0, uint8_t* status);
+
 /* ---- a2: CameraPoseAndDeformationOptimization (g2o_optimization.cc:148-557) ------------------
  * Frame side: n_f landmarks in frame index order with their map-point index (f_map, -1 = none),
  * LandmarkStatus (in/out), keypoint (f_uv) and position (f_pos, in/out).  Map side: the graph

@@ -1,0 +1,365 @@
+// a19 / a20 at the reference's density: RegularizationGraph (reference modules/map/regularization_graph.{h,cc}) as a
+// device-resident object.
+//
+// The reference graph is all-pairs: Map::InitializeRegularizationGraph adds an edge for EVERY pair of initial points
+// (modules/map/map.cc:148-166) and Mapping adds every new landmark against every current one
+// (modules/mapping/mapping.cc:240-256), so a vertex has N - 1 connections, GetEdges copies and sorts all of them per
+// call (regularization_graph.cc:71-87) and UpdateVertex walks all of them (:130-146).  A radius cut-off is NOT
+// equivalent: UpdateVertex's return value counts every connection that passes the stretch test, far ones included,
+// and the caller marks a point BAD below 5 (g2o_optimization.cc:468-473).  So the graph is kept the way the hardware
+// likes it -- dense: four capacity x capacity arrays (max / min / first distance as fp32, status as a byte), the pair
+// (i, j) stored once at [min(i,j)][max(i,j)]; 5k points = 325 MB, 10k = 1.3 GB of the 288 GB.  The weight is not
+// stored: it is InterpolationWeight(max_distance, sigma) at every point where the reference writes it (AddEdge :46,
+// UpdateConnection :113), so it is re-formed where it is read.
+//   add_edges : one thread per (new, other) pair                               O(1) per pair, coalesced rows
+//   update    : one workgroup sweep per listed vertex over its row/column      O(deg), good_count by block reduction
+//   get_edges : one wave per listed vertex: one pass finds the status class at which GetEdges' "break at the first
+//               weight < min_weight" falls and compacts the surviving entries (they all lie within 1.5 sigma: a few
+//               dozen), which are then rank-sorted by (status, -weight, index)  O(deg) + O(k^2 / 64)
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+#include "nrs_ctx.hpp"
+
+struct nrs_rgraph {
+    nrs_ctx* c = nullptr;
+    int cap = 0;
+    float sigma = 1.f, stretch_th = 1.1f, min_w = 0.f;
+    float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
+    uint8_t* st = nullptr;
+    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good;
+};
+
+namespace nrs {
+
+constexpr uint8_t RG_NONE = 0xFF;
+
+// InterpolationWeight (utilities/geometry_toolbox.cc:26-28): float argument, exp evaluated in double and rounded
+// to float (the definition shared with the oracle and nrs_track.hip, DESIGN.md "weights")
+__host__ __device__ inline float rg_weight(float d, float sigma) {
+#pragma clang fp contract(off)
+    const float arg = -(d * d) / (2.0f * sigma * sigma);
+    return (float)exp((double)arg);
+}
+
+__device__ inline size_t rg_at(int i, int j, int cap) { return i < j ? (size_t)i * cap + j : (size_t)j * cap + i; }
+
+__device__ inline float rg_dist(const float* __restrict__ pos, int i, int j) {
+#pragma clang fp contract(off)
+    const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// AddEdge (regularization_graph.cc:38-55) for every (new, other) pair, new != other: a fresh NEUTRAL edge whose
+// first / max / min distance is the current one.  A pair listed from both sides is written twice with the same bits.
+__global__ void k_rg_add(int n_new, const int* __restrict__ new_ids, int n_other, const int* __restrict__ other_ids,
+                         const float* __restrict__ pos, int cap, float* maxd, float* mind, float* d0, uint8_t* st) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+    if (b >= n_other || a >= n_new) return;
+    const int i = new_ids[a], j = other_ids[b];
+    if (i == j) return;
+    const float d = rg_dist(pos, i, j);
+    const size_t k = rg_at(i, j, cap);
+    maxd[k] = d; mind[k] = d; d0[k] = d; st[k] = (uint8_t)NRS_GRAPH_NEUTRAL;
+}
+
+// UpdateVertex (regularization_graph.cc:130-146) + UpdateConnection (:89-128) for one listed vertex per blockIdx.y.
+// Two listed vertices sharing an edge compute the same values from the same positions: idempotent.
+__global__ __launch_bounds__(256) void k_rg_update(int n_ids, const int* __restrict__ ids, const float* __restrict__ pos, int cap,
+                                                   float* maxd, float* mind, uint8_t* st, float stretch_th, int* good) {
+#pragma clang fp contract(off)
+    __shared__ int lds[4];
+    const int i = ids[blockIdx.y];
+    int n_good = 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < cap; j += gridDim.x * 256) {
+        if (j == i) continue;
+        const size_t k = rg_at(i, j, cap);
+        if (st[k] == RG_NONE) continue;
+        const float d = rg_dist(pos, i, j);
+        float mx = maxd[k], mn = mind[k];
+        if (d > mx) mx = d;
+        if (d < mn) mn = d;
+        maxd[k] = mx; mind[k] = mn;
+        if (fabsf((mx - mn) / mn) > stretch_th) st[k] = (uint8_t)NRS_GRAPH_BAD;
+        else ++n_good;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_good += __shfl_xor(n_good, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = n_good;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&good[blockIdx.y], lds[0] + lds[1] + lds[2] + lds[3]);      // integer: order-free
+}
+
+// GetEdges (regularization_graph.cc:71-87) for one listed vertex per wave.  The sorted list is
+// [status 0 by weight desc][status 1 ...]...; the loop breaks at the FIRST entry below min_weight, i.e. inside the
+// lowest status class s* that holds any such entry: the result is every entry of the classes below s* plus the
+// entries of s* at or above min_weight -- all of them at or above min_weight, ordered by (status, -weight, index).
+// (ties: ascending index, the build's documented choice where std::sort leaves the order open)
+struct RgCand { int j; float w; int s; };
+
+__global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __restrict__ ids, int cap, const float* __restrict__ maxd,
+                                                     const float* __restrict__ d0, const uint8_t* __restrict__ st, float sigma,
+                                                     float min_w, float d_hi, int cand_cap, int out_cap, int* o_count, int* o_col,
+                                                     float* o_w, float* o_d0, int* o_st, int* overflow) {
+    extern __shared__ RgCand cand[];
+    __shared__ int n_cand;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_ids) return;
+    const int i = ids[r];
+    if (lane == 0) n_cand = 0;
+    __syncthreads();
+    int s_star = 255;                                         // lowest status class holding an entry below min_weight
+    for (int j0 = 0; j0 < cap; j0 += 64) {
+        const int j = j0 + lane;
+        bool keep = false;
+        float w = 0.f;
+        int s = 255;
+        if (j < cap && j != i) {
+            const size_t k = rg_at(i, j, cap);
+            s = st[k];
+            if (s != RG_NONE) {
+                const float mx = maxd[k];
+                // beyond d_hi = 1.5 sigma (1 + 1e-4) the weight is below min_weight for sure; inside, the exact value decides
+                if (mx <= d_hi) { w = rg_weight(mx, sigma); keep = !(w < min_w); }
+                if (!keep) s_star = min(s_star, s);
+            }
+        }
+        // wave-ordered compaction (ascending j inside the candidate list: not needed for the result, but deterministic)
+        const unsigned long long m = __ballot(keep);
+        const int base = n_cand;
+        if (keep) {
+            const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (p < cand_cap) { cand[p].j = j; cand[p].w = w; cand[p].s = s; }
+        }
+        __syncthreads();
+        if (lane == 0) n_cand = base + __popcll(m);
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) s_star = min(s_star, __shfl_xor(s_star, off, 64));
+    const int n = n_cand;
+    if (n > cand_cap) { if (lane == 0) atomicMax(overflow, n); return; }
+    // rank sort of the survivors (status <= s*), key (status asc, weight desc, index asc)
+    int n_out = 0;
+    for (int a0 = 0; a0 < n; a0 += 64) {
+        const int a = a0 + lane;
+        if (a < n && cand[a].s <= s_star) {
+            const RgCand ca = cand[a];
+            int rank = 0;
+            for (int b = 0; b < n; ++b) {
+                const RgCand cb = cand[b];
+                if (cb.s > s_star) continue;
+                const bool before = (cb.s != ca.s) ? (cb.s < ca.s) : ((cb.w != ca.w) ? (cb.w > ca.w) : (cb.j < ca.j));
+                rank += before ? 1 : 0;
+            }
+            if (rank < out_cap) {
+                const size_t o = (size_t)r * out_cap + rank;
+                o_col[o] = ca.j; o_w[o] = ca.w; o_st[o] = ca.s; o_d0[o] = d0[rg_at(i, ca.j, cap)];
+            }
+            ++n_out;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
+    if (lane == 0) {
+        o_count[r] = n_out;
+        if (n_out > out_cap) atomicMax(overflow, n_out);
+    }
+}
+
+__global__ void k_rg_fill(uint8_t* st, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st[i] = RG_NONE;
+}
+
+static int rg_check_ids(nrs_rgraph* g, int n, const int32_t* ids, const char* what) {
+    if (n < 0 || (n > 0 && !ids)) return g->c->fail(NRS_ERR_INVALID, "%s: null / negative id list", what);
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= g->cap) return g->c->fail(NRS_ERR_INVALID, "%s: point index %d outside [0, %d)", what, ids[i], g->cap);
+    return NRS_OK;
+}
+
+}  // namespace nrs
+
+using namespace nrs;
+
+extern "C" int nrs_rgraph_create(nrs_ctx* c, int32_t capacity, float sigma, float stretch_th, nrs_rgraph** out) {
+    if (!c || !out) return NRS_ERR_INVALID;
+    *out = nullptr;
+    if (capacity <= 1 || capacity > 200000 || !(sigma > 0) || !(stretch_th > 0)) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_create: bad argument");
+    NRS_HIP(c, hipSetDevice(c->device));
+    nrs_rgraph* g = new (std::nothrow) nrs_rgraph();
+    if (!g) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    g->c = c; g->cap = capacity; g->stretch_th = stretch_th;
+    g->sigma = sigma;
+    g->min_w = rg_weight((float)((double)sigma * 1.5), sigma);          // regularization_graph.cc:29 (float * double literal -> float argument)
+    const size_t n2 = (size_t)capacity * capacity;
+    hipError_t e = hipMalloc((void**)&g->maxd, n2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->mind, n2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d0, n2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->st, n2);
+    if (e != hipSuccess) {
+        const int rc = c->fail(NRS_ERR_ALLOC, "nrs_rgraph_create: %zu bytes for %d points: %s", n2 * 13, capacity, hipGetErrorString(e));
+        if (g->maxd) (void)hipFree(g->maxd);
+        if (g->mind) (void)hipFree(g->mind);
+        if (g->d0) (void)hipFree(g->d0);
+        delete g;
+        return rc;
+    }
+    hipLaunchKernelGGL(k_rg_fill, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, c->stream, g->st, n2);
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    *out = g;
+    return NRS_OK;
+}
+
+extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
+    if (!g) return;
+    nrs_ctx* c = g->c;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
+    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good);
+    delete g;
+}
+
+extern "C" int nrs_rgraph_set_sigma(nrs_rgraph* g, float sigma) {
+    if (!g) return NRS_ERR_INVALID;
+    if (!(sigma > 0)) return g->c->fail(NRS_ERR_INVALID, "sigma must be positive");
+    g->sigma = sigma;
+    g->min_w = rg_weight((float)((double)sigma * 1.5), sigma);          // RegularizationGraph::SetSigma (:33-36)
+    return NRS_OK;
+}
+
+extern "C" float nrs_rgraph_min_weight(const nrs_rgraph* g) { return g ? g->min_w : 0.f; }
+
+extern "C" int nrs_rgraph_add_edges(nrs_rgraph* g, const float* pos, int32_t n_new, const int32_t* new_ids, int32_t n_other,
+                                    const int32_t* other_ids) {
+    if (!g) return NRS_ERR_INVALID;
+    nrs_ctx* c = g->c;
+    if (!pos) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_add_edges: null positions");
+    NRS_TRY(rg_check_ids(g, n_new, new_ids, "nrs_rgraph_add_edges"));
+    NRS_TRY(rg_check_ids(g, n_other, other_ids, "nrs_rgraph_add_edges"));
+    if (n_new == 0 || n_other == 0) return NRS_OK;
+    NRS_HIP(c, hipSetDevice(c->device));
+    NRS_TRY(c->ensure(g->pos, sizeof(float) * 3 * (size_t)g->cap));
+    NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_new));
+    NRS_TRY(c->ensure(g->ids_b, sizeof(int) * (size_t)n_other));
+    NRS_HIP(c, hipMemcpyAsync(g->pos.p, pos, sizeof(float) * 3 * (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, new_ids, sizeof(int) * (size_t)n_new, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(g->ids_b.p, other_ids, sizeof(int) * (size_t)n_other, hipMemcpyHostToDevice, c->stream));
+    for (int a0 = 0; a0 < n_new; a0 += 32768) {                   // grid.y limit
+        const int na = std::min(32768, n_new - a0);
+        hipLaunchKernelGGL(k_rg_add, dim3((n_other + 255) / 256, na), dim3(256), 0, c->stream, na, g->ids_a.as<int>() + a0, n_other,
+                           g->ids_b.as<int>(), g->pos.as<float>(), g->cap, g->maxd, g->mind, g->d0, g->st);
+    }
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+
+extern "C" int nrs_rgraph_update(nrs_rgraph* g, const float* pos, int32_t n_ids, const int32_t* ids, int32_t* good_count) {
+    if (!g) return NRS_ERR_INVALID;
+    nrs_ctx* c = g->c;
+    if (!pos || (n_ids > 0 && !good_count)) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_update: null argument");
+    NRS_TRY(rg_check_ids(g, n_ids, ids, "nrs_rgraph_update"));
+    if (n_ids == 0) return NRS_OK;
+    NRS_HIP(c, hipSetDevice(c->device));
+    NRS_TRY(c->ensure(g->pos, sizeof(float) * 3 * (size_t)g->cap));
+    NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_ids));
+    NRS_TRY(c->ensure(g->good, sizeof(int) * (size_t)n_ids));
+    NRS_HIP(c, hipMemcpyAsync(g->pos.p, pos, sizeof(float) * 3 * (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemsetAsync(g->good.p, 0, sizeof(int) * (size_t)n_ids, c->stream));
+    const int bx = std::max(1, std::min(8, (g->cap + 1023) / 1024));
+    for (int a0 = 0; a0 < n_ids; a0 += 32768) {
+        const int na = std::min(32768, n_ids - a0);
+        hipLaunchKernelGGL(k_rg_update, dim3(bx, na), dim3(256), 0, c->stream, na, g->ids_a.as<int>() + a0, g->pos.as<float>(), g->cap,
+                           g->maxd, g->mind, g->st, g->stretch_th, g->good.as<int>() + a0);
+    }
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipMemcpyAsync(good_count, g->good.p, sizeof(int) * (size_t)n_ids, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+
+extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, int32_t* count,
+                                    int32_t* col, float* w, float* d0, int32_t* status) {
+    if (!g) return NRS_ERR_INVALID;
+    nrs_ctx* c = g->c;
+    if (cap_per_point <= 0 || (n_ids > 0 && (!count || !col || !w || !d0 || !status))) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: bad argument");
+    NRS_TRY(rg_check_ids(g, n_ids, ids, "nrs_rgraph_get_edges"));
+    if (n_ids == 0) return NRS_OK;
+    NRS_HIP(c, hipSetDevice(c->device));
+    const size_t no = (size_t)n_ids * cap_per_point;
+    NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_ids));
+    NRS_TRY(c->ensure(g->out_i, sizeof(int) * (2 * no + (size_t)n_ids + 4)));
+    NRS_TRY(c->ensure(g->out_f, sizeof(float) * 2 * no));
+    int* d_col = g->out_i.as<int>();
+    int* d_st = d_col + no;
+    int* d_cnt = d_st + no;
+    int* d_ovf = d_cnt + n_ids;
+    float* d_w = g->out_f.as<float>();
+    float* d_d0 = d_w + no;
+    NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
+    const int cand_cap = std::max(256, std::min(4096, 4 * cap_per_point));
+    const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
+    hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), sizeof(RgCand) * (size_t)cand_cap, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
+                       g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
+    NRS_HIP(c, hipGetLastError());
+    int ovf = 0;
+    NRS_HIP(c, hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(count, d_cnt, sizeof(int) * (size_t)n_ids, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(col, d_col, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(status, d_st, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(w, d_w, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d0, d_d0, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    if (ovf > 0) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight; cap_per_point = %d is too small", ovf, cap_per_point);
+    return NRS_OK;
+}
+
+// GetEdge (regularization_graph.cc:57-59) / parity tap: out = {weight, first_distance, max_distance, min_distance}; status -1 = no edge
+extern "C" int nrs_rgraph_edge(nrs_rgraph* g, int32_t i, int32_t j, float out[4], int32_t* status) {
+    if (!g) return NRS_ERR_INVALID;
+    nrs_ctx* c = g->c;
+    if (i < 0 || j < 0 || i >= g->cap || j >= g->cap || i == j || !out || !status) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_edge: bad argument");
+    NRS_HIP(c, hipSetDevice(c->device));
+    const size_t k = i < j ? (size_t)i * g->cap + j : (size_t)j * g->cap + i;
+    uint8_t s = 0;
+    NRS_HIP(c, hipMemcpy(&s, g->st + k, 1, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(&out[2], g->maxd + k, 4, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(&out[3], g->mind + k, 4, hipMemcpyDeviceToHost));
+    NRS_HIP(c, hipMemcpy(&out[1], g->d0 + k, 4, hipMemcpyDeviceToHost));
+    out[0] = rg_weight(out[2], g->sigma);
+    *status = s == RG_NONE ? -1 : (int32_t)s;
+    return NRS_OK;
+}
+
+// parity tap: rows of the dense state (n_ids x capacity each; status 255 = no edge)
+extern "C" int nrs_rgraph_rows(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, float* maxd, float* mind, float* d0, uint8_t* status) {
+    if (!g) return NRS_ERR_INVALID;
+    nrs_ctx* c = g->c;
+    NRS_TRY(rg_check_ids(g, n_ids, ids, "nrs_rgraph_rows"));
+    NRS_HIP(c, hipSetDevice(c->device));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    const int cap = g->cap;
+    std::vector<float> col(cap);
+    std::vector<uint8_t> colb(cap);
+    for (int r = 0; r < n_ids; ++r) {
+        const int i = ids[r];
+        // row part (j > i) is contiguous; the column part (j < i) is strided in the canonical storage
+        auto fetch = [&](const float* src, float* dst) -> int {
+            if (!dst) return NRS_OK;
+            NRS_HIP(c, hipMemcpy(dst + (size_t)r * cap + i, src + (size_t)i * cap + i, sizeof(float) * (size_t)(cap - i), hipMemcpyDeviceToHost));
+            if (i > 0) NRS_HIP(c, hipMemcpy2D(dst + (size_t)r * cap, sizeof(float), src + i, sizeof(float) * (size_t)cap, sizeof(float), (size_t)i, hipMemcpyDeviceToHost));
+            return NRS_OK;
+        };
+        NRS_TRY(fetch(g->maxd, maxd)); NRS_TRY(fetch(g->mind, mind)); NRS_TRY(fetch(g->d0, d0));
+        if (status) {
+            NRS_HIP(c, hipMemcpy(status + (size_t)r * cap + i, g->st + (size_t)i * cap + i, (size_t)(cap - i), hipMemcpyDeviceToHost));
+            if (i > 0) NRS_HIP(c, hipMemcpy2D(status + (size_t)r * cap, 1, g->st + i, (size_t)cap, 1, (size_t)i, hipMemcpyDeviceToHost));
+            status[(size_t)r * cap + i] = RG_NONE;
+        }
+    }
+    return NRS_OK;
+}

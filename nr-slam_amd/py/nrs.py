@@ -27,7 +27,9 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_klt_insert_templates",
            "nrs_shi_configure", "nrs_shi_extract", "nrs_shi_buffers",
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
-           "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local"]
+           "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
+           "nrs_rgraph_create", "nrs_rgraph_destroy", "nrs_rgraph_set_sigma", "nrs_rgraph_min_weight", "nrs_rgraph_add_edges",
+           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows"]
 
 
 class NrsError(RuntimeError):
@@ -86,6 +88,10 @@ def load_library(path=LIB_PATH):
     lib.nrs_stream.restype = C.c_void_p
     lib.nrs_destroy.restype = None
     lib.nrs_local_group_destroy.restype = None
+    lib.nrs_rgraph_destroy.restype = None
+    lib.nrs_rgraph_destroy.argtypes = [C.c_void_p]
+    lib.nrs_rgraph_min_weight.restype = C.c_float
+    lib.nrs_rgraph_min_weight.argtypes = [C.c_void_p]
     lib.nrs_local_group_destroy.argtypes = [C.c_void_p]
     lib.nrs_comm_init_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     return lib
@@ -211,6 +217,66 @@ def dba_build_edges(kf_points, graph, lib=None):
     if rc != OK:
         raise NrsError(rc, "nrs_dba_build_edges (fill)")
     return dict(sp_ij=sp_ij, sp_d0=sp_d0, dm_idx=dm_idx, dm_w=dm_w)
+
+
+class RGraph:
+    """nrs_rgraph_* (include/nrs.h): the dense, device-resident RegularizationGraph of a context"""
+
+    def __init__(self, ctx, capacity, sigma, stretch_th=1.1):
+        self.ctx, self.lib, self.cap = ctx, ctx.lib, capacity
+        self.h = C.c_void_p()
+        ctx._chk(self.lib.nrs_rgraph_create(ctx.h, C.c_int32(capacity), C.c_float(sigma), C.c_float(stretch_th), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_rgraph_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _pos(self, pos):
+        pos = _f32(pos).reshape(-1, 3)
+        assert len(pos) == self.cap
+        return pos
+
+    def set_sigma(self, sigma):
+        self.ctx._chk(self.lib.nrs_rgraph_set_sigma(self.h, C.c_float(sigma)))
+
+    def min_weight(self):
+        return float(self.lib.nrs_rgraph_min_weight(self.h))
+
+    def add_edges(self, pos, new_ids, other_ids):
+        pos, a, b = self._pos(pos), _i32(new_ids), _i32(other_ids)
+        self.ctx._chk(self.lib.nrs_rgraph_add_edges(self.h, _p(pos, C.c_float), C.c_int32(len(a)), _p(a, C.c_int32), C.c_int32(len(b)), _p(b, C.c_int32)))
+
+    def update(self, pos, ids):
+        pos, ids = self._pos(pos), _i32(ids)
+        good = np.zeros(len(ids), np.int32)
+        self.ctx._chk(self.lib.nrs_rgraph_update(self.h, _p(pos, C.c_float), C.c_int32(len(ids)), _p(ids, C.c_int32), _p(good, C.c_int32)))
+        return good
+
+    def get_edges(self, ids, cap_per_point=256):
+        ids = _i32(ids)
+        n = len(ids)
+        cnt = np.zeros(n, np.int32)
+        col, st = np.zeros((n, cap_per_point), np.int32), np.zeros((n, cap_per_point), np.int32)
+        w, d0 = np.zeros((n, cap_per_point), np.float32), np.zeros((n, cap_per_point), np.float32)
+        self.ctx._chk(self.lib.nrs_rgraph_get_edges(self.h, C.c_int32(n), _p(ids, C.c_int32), C.c_int32(cap_per_point), _p(cnt, C.c_int32),
+                                                    _p(col, C.c_int32), _p(w, C.c_float), _p(d0, C.c_float), _p(st, C.c_int32)))
+        return cnt, col, w, d0, st
+
+    def edge(self, i, j):
+        out = (C.c_float * 4)()
+        st = C.c_int32(0)
+        self.ctx._chk(self.lib.nrs_rgraph_edge(self.h, C.c_int32(i), C.c_int32(j), out, C.byref(st)))
+        return dict(w=out[0], d0=out[1], max=out[2], min=out[3], status=st.value)
+
+    def rows(self, ids):
+        ids = _i32(ids)
+        n = len(ids)
+        mx, mn, d0 = (np.zeros((n, self.cap), np.float32) for _ in range(3))
+        st = np.zeros((n, self.cap), np.uint8)
+        self.ctx._chk(self.lib.nrs_rgraph_rows(self.h, C.c_int32(n), _p(ids, C.c_int32), _p(mx, C.c_float), _p(mn, C.c_float), _p(d0, C.c_float),
+                                               _p(st, C.c_uint8)))
+        return mx, mn, d0, st
 
 
 class Context:
