@@ -355,6 +355,31 @@ def rgraph_bench(n=5000):
     return out
 
 
+def triangulation_bench():
+    """f2: every triangulation candidate of a frame in one call (21 buffered snapshots, host buffers in, points out),
+    next to the NumPy restatement (oracle/triang_oracle.py, 1 core) on the first 10 candidates."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nrs
+    import nrs_synth as S
+    import triang_oracle as T
+    tb = S.make_temporal_buffer(21, 7, baseline=0.3, spacing=22.0)
+    ctx = nrs.Context()
+    cam = nrs.make_camera(tb["model"], tb["prm"])
+    st, _ = ctx.triangulate_batch(cam, tb, tb["cand"])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        st, _ = ctx.triangulate_batch(cam, tb, tb["cand"])
+    gpu_ms = 1e3 * (time.perf_counter() - t0) / 5
+    ctx.close()
+    t0 = time.perf_counter()
+    for c in tb["cand"][:10]:
+        T.deformable_triangulation(tb, int(c), tb["model"], tb["prm"])
+    cpu_ms = 1e3 * (time.perf_counter() - t0) / 10
+    return dict(candidates=int(len(tb["cand"])), triangulated=int((st == 0).sum()), snapshots=21, keypoint_ids=int(tb["has_kp"].shape[1]),
+                ms_per_batch=gpu_ms, us_per_candidate=1e3 * gpu_ms / max(1, len(tb["cand"])), cpu_oracle_ms_per_candidate=cpu_ms,
+                cpu_kind="port (NumPy, 1 core)")
+
+
 def shi_extract_bench(reps=20):
     """Shi-Tomasi extraction on a 640x480 frame holding 1500 keypoints (host image in,
     keypoints out: PCIe-inclusive), next to the oracle's per-cell NumPy form on this host (1 core)."""
@@ -474,6 +499,7 @@ def main():
         out["tracked_fps"] = tracked_fps()
         out["shi_extract"] = shi_extract_bench()
         out["graph_dense"] = rgraph_bench()
+        out["triangulation"] = triangulation_bench()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
         xctx.close()

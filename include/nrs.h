@@ -280,6 +280,26 @@ int nrs_rgraph_edge(nrs_rgraph* g, int32_t i, int32_t j, float out[4], int32_t* 
 /* parity tap: rows of the dense state, n_ids x capacity each (status 255 = no edge; any pointer may be null) */
 int nrs_rgraph_rows(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, float* maxd, float* mind, float* d0, uint8_t* status);
 
+/* ---- f2: DeformableTriangulation, batched (modules/optimization/g2o_optimization.cc:559-814) --------------------
+ * One call triangulates every candidate feature of a frame (the reference calls the function once per candidate from
+ * Mapping::LandmarkTriangulation, modules/mapping/mapping.cc:65-116).  Input = the TemporalBuffer flattened
+ * (modules/map/temporal_buffer.h:43-63): n_frames <= 21 snapshots, oldest first; per snapshot its
+ * camera_transform_world (Sophus::SE3f as qx qy qz qw tx ty tz) and, per keypoint id 0 .. n_ids-1, whether the id has
+ * a keypoint there (keypoint_tracks) and a landmark position (mapppoint_tracks_); last_status = keypoint_tracks_status
+ * of the LAST snapshot (GetClosestMapPointsToFeature looks for TRACKED_WITH_3D neighbours there).
+ * out_status: 0 ok, else the InternalError the reference returns: 1 "Feature too close to other ones." 2 / 3 "High
+ * reprojection error at first / second camera." 4 "Low parallax." 5 "Found no neighbours in a temporal point."
+ * 6 "Negative initial depth." 7 "Optimization is empty." 8 "Triangulation has to many bad neighbors." 9 "Triangulation
+ * has to much error." 10 the caller's "Short track" (track shorter than min_track; mapping.cc:88 uses 5).
+ * out_xyz: the triangulated world position (zeros unless status 0).  out_debug (nullable, n_cand x 4): final chi2,
+ * LM iterations, LM trials, regulariser edges.  The reprojection edge has no analytic Jacobian in the reference: it is
+ * g2o's numeric one (delta 1e-9, central) through the fp32 projection, reproduced as such. */
+int nrs_triangulate_batch(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_frames, const float* poses /* n_frames x 7 */,
+                          int32_t n_ids, const uint8_t* has_kp /* n_frames x n_ids */, const float* kp_xy /* .. x 2 */,
+                          const uint8_t* has_lm, const float* lm_xyz /* .. x 3 */, const int32_t* last_status /* n_ids */,
+                          int32_t n_cand, const int32_t* cand_ids, int32_t min_track, int32_t* out_status,
+                          float* out_xyz /* n_cand x 3 */, double* out_debug);
+
 /* ---- a2: CameraPoseAndDeformationOptimization (g2o_optimization.cc:148-557) ------------------
  * Frame side: n_f landmarks in frame index order with their map-point index (f_map, -1 = none),
  * LandmarkStatus (in/out), keypoint (f_uv) and position (f_pos, in/out).  Map side: the graph

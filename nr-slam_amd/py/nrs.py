@@ -29,7 +29,7 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
            "nrs_rgraph_create", "nrs_rgraph_destroy", "nrs_rgraph_set_sigma", "nrs_rgraph_min_weight", "nrs_rgraph_add_edges",
-           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows"]
+           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch"]
 
 
 class NrsError(RuntimeError):
@@ -366,6 +366,22 @@ class Context:
                                                _p(X, C.c_float), _p(qt, C.c_double), _p(inl, C.c_uint8),
                                                C.byref(trace.c) if trace else None))
         return qt[:4].copy(), qt[4:].copy(), inl.astype(bool)
+
+    # ---- f2
+    def triangulate_batch(self, cam, tb, cand_ids, min_track=5, debug=False):
+        """tb: flat temporal buffer dict (nrs_synth.make_temporal_buffer); returns (status[n], xyz[n,3][, debug[n,4]])"""
+        F, n = tb["has_kp"].shape
+        poses = _f32(tb["poses"]).reshape(F, 7)
+        has_kp, has_lm = np.ascontiguousarray(tb["has_kp"], np.uint8), np.ascontiguousarray(tb["has_lm"], np.uint8)
+        kp, lm = _f32(tb["kp_xy"]).reshape(F, n, 2), _f32(tb["lm_xyz"]).reshape(F, n, 3)
+        st, cand = _i32(tb["status"]), _i32(cand_ids)
+        o_st, o_xyz = np.zeros(len(cand), np.int32), np.zeros((len(cand), 3), np.float32)
+        dbg = np.zeros((len(cand), 4), np.float64) if debug else None
+        self._chk(self.lib.nrs_triangulate_batch(self.h, C.byref(cam), C.c_int32(F), _p(poses, C.c_float), C.c_int32(n), _p(has_kp, C.c_uint8),
+                                                 _p(kp, C.c_float), _p(has_lm, C.c_uint8), _p(lm, C.c_float), _p(st, C.c_int32), C.c_int32(len(cand)),
+                                                 _p(cand, C.c_int32), C.c_int32(min_track), _p(o_st, C.c_int32), _p(o_xyz, C.c_float),
+                                                 _p(dbg, C.c_double)))
+        return (o_st, o_xyz, dbg) if debug else (o_st, o_xyz)
 
     # ---- a19 / a20
     def graph_select_neighbours(self, g):

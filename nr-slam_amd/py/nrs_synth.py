@@ -439,3 +439,64 @@ def edge_checksum(e):
         a = a.astype(np.int32) if a.dtype.kind == "i" else a.astype(np.float32)
         h = (h * 1000003 + zlib.crc32(a.tobytes())) & 0xFFFFFFFFFFFF
     return int(h)
+
+
+def make_temporal_buffer(n_frames=12, seed=3, model=PINHOLE, spacing=26.0, cand_frac=0.3, lm_noise=0.004, kp_noise=0.25,
+                         baseline=0.35):
+    """A flat TemporalBuffer (reference modules/map/temporal_buffer.h:43-63) for DeformableTriangulation: n_frames
+    snapshots of a deforming surface seen by a translating camera.  Features sit on a jittered image grid (the
+    extractor's non-maximum suppression keeps features apart; GetClosestMapPointsToFeature rejects a candidate with a
+    3D neighbour closer than 20 px): (1 - cand_frac) of them are map points (landmark position in every snapshot they
+    are seen in, TRACKED_WITH_3D in the last one), the rest are 2D-only candidates with tracks of varying length.
+    Returns the dict nrs.triangulate_batch / oracle/triang_oracle.py read, plus `cand` (ids) and `truth` (world
+    positions of the candidates in the last frame)."""
+    rng = np.random.default_rng(seed)
+    prm = HAMLYN_PINHOLE if model == PINHOLE else ENDOMAPPER_KB8
+    w, h = (640, 480) if model == PINHOLE else (736, 552)
+    gx, gy = np.meshgrid(np.arange(40, w - 40, spacing), np.arange(40, h - 40, spacing))
+    uv0 = np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-2.0, 2.0, (gx.size, 2))
+    n = len(uv0)
+    # back-project the grid onto the surface z = 60 + 8 sin(x/15) cos(y/12) (two fixed-point steps are plenty)
+    P = prm.astype(np.float64)
+    z = np.full(n, 60.0)
+    for _ in range(3):
+        if model == PINHOLE:
+            x, y = (uv0[:, 0] - P[2]) / P[0] * z, (uv0[:, 1] - P[3]) / P[1] * z
+        else:
+            th = np.hypot((uv0[:, 0] - P[2]) / P[0], (uv0[:, 1] - P[3]) / P[1])
+            psi = np.arctan2((uv0[:, 1] - P[3]) / P[1], (uv0[:, 0] - P[2]) / P[0])
+            x, y = z * np.tan(th) * np.cos(psi), z * np.tan(th) * np.sin(psi)
+        z = 60.0 + 8.0 * np.sin(x / 15.0) * np.cos(y / 12.0)
+    Xmm = np.stack([x, y, z], 1)
+    nrm = np.array([0.0, 0.0, 1.0])
+    scale = 3.0 / np.median(z)
+    is_cand = rng.uniform(size=n) < cand_frac
+    poses, has_kp, kp_xy, has_lm, lm_xyz = [], np.zeros((n_frames, n), bool), np.zeros((n_frames, n, 2), F32), np.zeros((n_frames, n), bool), np.zeros((n_frames, n, 3), F32)
+    start = np.where(is_cand, rng.integers(0, n_frames - 2, n), 0)           # candidates appear at different times
+    truth = np.zeros((n, 3))
+    for f in range(n_frames):
+        R = _small_rot(np.array([0.002 * f, -0.003 * f, 0.001 * f]))
+        C = np.array([baseline * f, 0.12 * baseline * f, 0.0])              # camera centre (mm)
+        t = -R @ C
+        amp = 0.8 * np.sin(2 * np.pi * f / 30.0) * (0.6 + 0.4 * np.sin(Xmm[:, 0] / 11.0 + 0.3) * np.cos(Xmm[:, 1] / 9.0))
+        X = Xmm + amp[:, None] * nrm
+        uv = _project(model, P, X @ R.T + t) + rng.normal(0, kp_noise, (n, 2))
+        q = _rot_to_quat(R)
+        poses.append(np.concatenate([q, t * scale]))
+        seen = (f >= start) & (uv[:, 0] > 12) & (uv[:, 0] < w - 12) & (uv[:, 1] > 12) & (uv[:, 1] < h - 12)
+        has_kp[f] = seen
+        kp_xy[f] = uv.astype(F32)
+        has_lm[f] = seen & ~is_cand & (rng.uniform(size=n) > 0.03)          # a few map points drop out of a snapshot
+        lm_xyz[f] = (X * scale + rng.normal(0, lm_noise, (n, 3))).astype(F32)
+        truth = X * scale
+    status = np.where(is_cand, 1, 0).astype(np.int32)                        # TRACKED (2D) / TRACKED_WITH_3D
+    status[~has_kp[-1]] = 3
+    cand = np.where(is_cand & has_kp[-1])[0].astype(np.int32)
+    return dict(n_frames=n_frames, poses=np.array(poses, F32), has_kp=has_kp, kp_xy=kp_xy, has_lm=has_lm, lm_xyz=lm_xyz,
+                status=status, cand=cand, truth=truth[cand].astype(F32), model=model, prm=prm, scale=F32(scale))
+
+
+def _rot_to_quat(R):
+    """unit quaternion (x y z w) of a rotation matrix, w >= 0"""
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
