@@ -78,6 +78,18 @@ struct Timer {                       // HIP-event timing of one launch when prof
 template <bool LIN, bool LDS>
 static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, int n, int cls) {
     const dim3 g(((n + 7) / 8) * 8), b(BLK);
+    if constexpr (LIN && LDS) {
+        if (d.dform) {                                             // temporal-difference dampers (two-kernel path: T = 2 unless overridden)
+            switch (d.T) {
+                case 1: hipLaunchKernelGGL((k_reg<1, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;
+                case 4: hipLaunchKernelGGL((k_reg<4, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;
+                case 8: hipLaunchKernelGGL((k_reg<8, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;
+                case 16: hipLaunchKernelGGL((k_reg<16, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;
+                default: hipLaunchKernelGGL((k_reg<2, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;
+            }
+            return;
+        }
+    }
     switch (d.T) {
         case 1: hipLaunchKernelGGL((k_reg<1, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
         case 4: hipLaunchKernelGGL((k_reg<4, LIN, LDS>), g, b, shm, c->stream, d, xl, cls); break;
@@ -92,7 +104,8 @@ static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
     if (!d.use_lds) { launch_reg2<LIN, false>(c, d, xl, 0, d.n_regblk, 0); return; }
     for (int cls = 0; cls < 2; ++cls) {
         if (d.sh_nt[cls] == 0) continue;
-        const size_t shm = sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
+        const size_t shm = (LIN && d.dform) ? sizeof(double) * 9 * (size_t)(d.tile_rows + d.cap_h[cls] + 1)
+                                            : sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
         launch_reg2<LIN, true>(c, d, xl, shm, d.sh_nt[cls], cls);        // (LIN: the linearisation point is d.lin_pose / xl)
     }
 }
@@ -114,14 +127,25 @@ static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol
     for (int cls = 0; cls < 2; ++cls) {
         const int n = d.sh_nt[cls] + d.sh_ntb[cls];
         if (n == 0) continue;
-        const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         const dim3 g(((n + 7) / 8) * 8), b(BLK);
+        if (d.dform) {
+            const size_t shm = sizeof(double) * 3 * (3 * (size_t)(d.tile_rows + d.cap_h[cls] + 1) + d.tile_rows + d.cap_s[cls] + 1);
+            switch (d.T) {
+                case 1: hipLaunchKernelGGL((k_spmv_f<1, true>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+                case 4: hipLaunchKernelGGL((k_spmv_f<4, true>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+                case 8: hipLaunchKernelGGL((k_spmv_f<8, true>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+                case 16: hipLaunchKernelGGL((k_spmv_f<16, true>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+                default: hipLaunchKernelGGL((k_spmv_f<2, true>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            }
+            continue;
+        }
+        const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
         switch (d.T) {
-            case 1: hipLaunchKernelGGL((k_spmv_f<1>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
-            case 4: hipLaunchKernelGGL((k_spmv_f<4>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
-            case 8: hipLaunchKernelGGL((k_spmv_f<8>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
-            case 16: hipLaunchKernelGGL((k_spmv_f<16>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
-            default: hipLaunchKernelGGL((k_spmv_f<2>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 1: hipLaunchKernelGGL((k_spmv_f<1, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 4: hipLaunchKernelGGL((k_spmv_f<4, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 8: hipLaunchKernelGGL((k_spmv_f<8, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            case 16: hipLaunchKernelGGL((k_spmv_f<16, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            default: hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
         }
     }
 }

@@ -130,8 +130,9 @@ __global__ __launch_bounds__(BLK) void k_reproj(Dev P, const Pose* __restrict__ 
 //   (spatial_regularizer_with_deformation.cc:36-49), SpatialRegularizerFixed
 //   (spatial_regularizer_fixed.cc:32-43).
 // =====================================================================================
-template <int T, bool LIN, bool LDS>
+template <int T, bool LIN, bool LDS, bool DF = false>
 __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ xl_g, int cls) {
+    static_assert(!DF || (LIN && LDS), "temporal-difference dampers: linearisation on the LDS path only");
     __shared__ double lds[4 * 2];
     __shared__ double lds28[(LIN && LDS) ? 4 * 28 : 1];
     extern __shared__ double dyn[];
@@ -166,7 +167,11 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
             const int j = idx + 64 * q;
             h[q] = make_uint2(0u, 0xFFFF0000u);
             w[q] = 0.f;
-            if (j < d_end) { h[q] = P.d_hdr[j]; w[q] = P.d_w[j]; }
+            if (j < d_end) {
+                if (DF) { const uint32_t om = P.d_om[j]; h[q] = make_uint2(om & 0xFFFFu, om & 0xFFFF0000u); }   // partner in .x, meta in the high half of .y
+                else h[q] = P.d_hdr[j];
+                w[q] = P.d_w[j];
+            }
         }
     };
     if (LDS) { load_sh(shA, s_beg + lane); load_dh(dhA, dwA, d_beg + lane); }
@@ -175,7 +180,16 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
     const double* xl = xl_g;
     const double* xp = nullptr;
     int self = row;
-    if (LDS) {
+    const double* lgf = nullptr;
+    const double* lgb = nullptr;
+    if (LDS && DF) {
+        const size_t nst = (size_t)(P.tile_rows + P.cap_h[cls] + 1);
+        double* lx = dyn;
+        stage_rows_d(P, b, tid, xl_g, lx, dyn + 3 * nst, dyn + 6 * nst);
+        xl = lx; lgf = dyn + 3 * nst; lgb = dyn + 6 * nst;
+        __syncthreads();
+        self = row - b * P.tile_rows;
+    } else if (LDS) {
         double* lx = dyn;
         stage_rows(P, b, tid, xl_g, nullptr, lx);
         xl = lx;
@@ -358,9 +372,29 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         }
     }
     // ---- dampers: r = w((x1n - x1c) - (x2n - x2c)), roles (1c,2c,1n,2n), signs (-,+,+,-)
+    double gfo0 = 0, gfo1 = 0, gfo2 = 0, gbo0 = 0, gbo1 = 0, gbo2 = 0;
+    if (DF) {
+        gfo0 = lgf[3 * self]; gfo1 = lgf[3 * self + 1]; gfo2 = lgf[3 * self + 2];
+        gbo0 = lgb[3 * self]; gbo1 = lgb[3 * self + 1]; gbo2 = lgb[3 * self + 2];
+    }
     auto damper = [&](int idx, int meta, const int* o, float wf) {
         if (!(meta & DM_ACTIVE)) {
             if (LIN) P.d_s[idx] = 0;
+            return;
+        }
+        if (DF) {
+            // temporal-difference form: r = +-w (G^d_i - G^d_o), G^d of the positions (forward: roles 1c / 2c)
+            const double w = (double)wf;
+            const bool bw = (meta & 2) != 0;
+            const double* lg = bw ? lgb : lgf;
+            const double g0 = (bw ? gbo0 : gfo0) - lg[3 * o[0]], g1 = (bw ? gbo1 : gfo1) - lg[3 * o[0] + 1], g2 = (bw ? gbo2 : gfo2) - lg[3 * o[0] + 2];
+            double rho0, rho1;
+            huber(P.info_spatial * ((w * g0) * (w * g0) + (w * g1) * (w * g1) + (w * g2) * (w * g2)), P.delta_spatial, rho0, rho1);
+            if (meta & DM_COUNT) chi += rho0;
+            const double sfac = (rfix ? 0.0 : 1.0) * rho1 * P.info_spatial * w * w;
+            P.d_s[idx] = sfac;
+            D[0] += sfac; D[3] += sfac; D[5] += sfac;
+            bb[0] -= sfac * g0; bb[1] -= sfac * g1; bb[2] -= sfac * g2;
             return;
         }
         if (!LIN && !(meta & DM_COUNT)) return;           // chi2 only: counted from one of the edge's rows

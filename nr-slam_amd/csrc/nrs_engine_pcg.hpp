@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 //                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
-template <int T>
+template <int T, bool DF>
 __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
@@ -200,12 +200,19 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const int kf = P.grp_pose[row / ROW_ALIGN];
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
+    // DF (temporal-difference dampers): u, G^f, G^b for tile + halo, then the spring positions; else u, positions
+    const size_t nst = (size_t)(P.tile_rows + P.cap_h[cls] + 1);
     double* lu = dyn;
-    double* lx = dyn + 3 * (size_t)(P.tile_rows + P.cap_h[cls] + 1);
-    // row ZROW of both arrays is zero: padding records and absent damper vertices point at it, so the
+    double* lgf = dyn + 3 * nst;
+    double* lgb = dyn + 6 * nst;
+    double* lx = dyn + (DF ? 9 : 3) * nst;
+    // row ZROW of the arrays is zero: padding records and absent damper vertices point at it, so the
     // incidence loops are branch-free and the LDS reads of a whole chunk can be in flight together
     const int ZROW = P.tile_rows + P.cap_h[cls], ZROWX = P.tile_rows + P.cap_s[cls];
-    if (tid < 3) { lu[3 * ZROW + tid] = 0; lx[3 * ZROWX + tid] = 0; }
+    if (tid < 3) {
+        lu[3 * ZROW + tid] = 0; lx[3 * ZROWX + tid] = 0;
+        if (DF) { lgf[3 * ZROW + tid] = 0; lgb[3 * ZROW + tid] = 0; }
+    }
     // r.u of this iteration was left by the previous vector update (or the trial setup): its loads go
     // out with the staging loads, the sum rides on the staging barrier
     double gsum = 0;
@@ -221,7 +228,14 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     }
     const double gamma0 = P.scal[SC_GAMMA0];
     const int done_flag = P.flags[0];                              // launches behind a converged solve are no-ops
-    stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
+    if (DF) {
+        stage_rows_d(P, b, tid, P.uv3, lu, lgf, lgb);
+        const int row0 = b * P.tile_rows, hb = P.halo_ptr[b], ns = P.halo_ns[b];
+        for (int i = tid; i < P.tile_rows + ns; i += BLK) {        // positions of the linearisation point: tile + spring halo
+            const size_t r = 3 * (size_t)(i < P.tile_rows ? row0 + i : P.halo_rows[hb + i - P.tile_rows]);
+            lx[3 * i] = P.lin_xl[r]; lx[3 * i + 1] = P.lin_xl[r + 1]; lx[3 * i + 2] = P.lin_xl[r + 2];
+        }
+    } else stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
     // row factors and the first record chunks are requested while the staging loads are in flight
     RowRec rc;
     rc.w = 0;
@@ -247,7 +261,13 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         for (int q = 0; q < U; ++q) {
             const int j = idx + 64 * q;
             dr[q].meta = 0; dr[q].s = 0; dr[q].o0 = dr[q].o1 = dr[q].o2 = REC_NONE;
-            if (j < dend) dr[q] = load_damper(P, j);
+            if (j < dend) {
+                if (DF) {                                          // {partner | meta << 16} + s: 12 bytes
+                    const uint32_t om = P.d_om[j];
+                    dr[q].s = P.d_s[j];
+                    dr[q].o0 = (uint16_t)(om & 0xFFFFu); dr[q].meta = (uint16_t)(om >> 16);
+                } else dr[q] = load_damper(P, j);
+            }
         }
     };
     load_springs(srA, sbeg + lane);
@@ -282,9 +302,22 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
         }
     };
+    const double gfo[3] = {DF ? lgf[3 * self] : 0.0, DF ? lgf[3 * self + 1] : 0.0, DF ? lgf[3 * self + 2] : 0.0};
+    const double gbo[3] = {DF ? lgb[3 * self] : 0.0, DF ? lgb[3 * self + 1] : 0.0, DF ? lgb[3 * self + 2] : 0.0};
     auto do_dampers = [&](const DamperRec* dr) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
+            if (DF) {
+                // a_i += s (G^d_i - G^d_o): forward differences for roles 1c / 2c, backward for 1n / 2n
+                const bool pad = dr[q].meta == REC_NONE || dr[q].o0 == REC_NONE;
+                const int o = pad ? ZROW : (int)dr[q].o0;
+                const double sv = pad ? 0.0 : dr[q].s;
+                const bool bw = (dr[q].meta & 2) != 0;
+                const double* lg = bw ? lgb : lgf;
+                const double g0 = (bw ? gbo[0] : gfo[0]) - lg[3 * o], g1 = (bw ? gbo[1] : gfo[1]) - lg[3 * o + 1], g2 = (bw ? gbo[2] : gfo[2]) - lg[3 * o + 2];
+                a0 += sv * g0; a1 += sv * g1; a2 += sv * g2;
+                continue;
+            }
             // padding records carry s = 0; a unary damper (the other vertex is a value) and absent
             // vertices read the zero row, which leaves the diagonal term s u_i
             const int meta = dr[q].meta == REC_NONE ? 0 : (int)dr[q].meta;

@@ -44,7 +44,10 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.tile_list = A.get<int>((size_t)d.n_regblk);
     d.s_om = A.get<uint32_t>(d.use_lds ? nnz_s : 1);
     d.s_qc = A.get<double>(d.use_lds ? nnz_s : 1);
-    d.d_hdr = A.get<uint2>(d.use_lds ? nnz_d : 1);
+    d.d_hdr = A.get<uint2>(d.use_lds && !d.dform ? nnz_d : 1);
+    d.d_om = A.get<uint32_t>(d.use_lds && d.dform ? nnz_d : 1);
+    d.nxt_row = A.get<int>(d.dform ? nr : 1); d.prv_row = A.get<int>(d.dform ? nr : 1);
+    d.halo_nxt = A.get<int>(d.dform ? std::max<size_t>(1, n_halo) : 1); d.halo_prv = A.get<int>(d.dform ? std::max<size_t>(1, n_halo) : 1);
     const size_t us = d.use_lds ? 1 : nnz_s, ud = d.use_lds ? 1 : nnz_d;     // unpacked arrays: fallback path only
     d.s_other = A.get<int>(us); d.s_d0 = A.get<float>(nnz_s); d.s_meta = A.get<int>(us);
     d.d_o0 = A.get<int>(ud); d.d_o1 = A.get<int>(ud); d.d_o2 = A.get<int>(ud);
@@ -152,8 +155,13 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
             const uint32_t m16 = e->h_d_meta[i] < 0 ? (uint32_t)REC_NONE : (uint32_t)(e->h_d_meta[i] & 0xFFFF);
             e->h_d_hdr[i].y = (e->h_d_hdr[i].y & 0xFFFFu) | (m16 << 16);
         }
+        for (size_t i = 0; i < e->h_d_om.size(); ++i) {
+            const uint32_t m16 = e->h_d_meta[i] < 0 ? (uint32_t)REC_NONE : (uint32_t)(e->h_d_meta[i] & 0xFFFF);
+            e->h_d_om[i] = (e->h_d_om[i] & 0xFFFFu) | (m16 << 16);
+        }
         NRS_TRY(h2d(c, d.s_om, e->h_s_om));
-        NRS_TRY(h2d(c, d.d_hdr, e->h_d_hdr));
+        if (d.dform) NRS_TRY(h2d(c, d.d_om, e->h_d_om));
+        else NRS_TRY(h2d(c, d.d_hdr, e->h_d_hdr));
     } else {
         NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
         NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
@@ -366,6 +374,37 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     (void)dm_slots;
     mark("sell pack");
     mark("sell vectors");
+    // ---- temporal-difference form of the dampers (nrs_engine_types.hpp), OPT-IN (NRS_DFORM=1).  Measured: C2 (cache
+    // resident) operator 24.4 -> 24.9 us, lineariser 42 -> 43 us: neutral; C4 (HBM regime) operator 1.77 -> 4.15 ms,
+    // lineariser 3.08 -> 5.69 ms: the three gathers per staged row (v, v[next], v[prev]; 954 row reads per tile against
+    // 648 for the generic halo) cost more than the LDS reads and instructions they save.  Kept because it is parity-green
+    // and the natural form once G^f / G^b come from a streaming pre-pass.  Needs every damper to join the same two
+    // vertices' successors -- next(1c) = 1n, next(2c) = 2n, consistently over all dampers -- a BA window without masks,
+    // offsets or unary dampers, and the two-kernel path (the fused single-launch iteration re-derives u for halo rows
+    // and keeps the generic four-vertex records)
+    std::vector<int> nxt_row, prv_row;
+    {
+        const int fused_max0 = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
+        bool plain = !s.X0 && s.n_un == 0 && s.n_dm > 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !getenv("NRS_NO_EDGE_CHI") && getenv("NRS_DFORM") &&
+                     !getenv("NRS_NO_LDS") && !s.force_gather;
+        for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
+        const bool two_kernel = d.n_rows >= fused_max0 || getenv("NRS_NO_FUSED") || (c->comm && s.shard);
+        if (plain && two_kernel) {
+            nxt_row.assign(d.n_rows, -1); prv_row.assign(d.n_rows, -1);
+            for (int q = 0; q < s.n_dm && plain; ++q) {
+                int r4[4];
+                for (int k = 0; k < 4; ++k) { r4[k] = s.dm_idx[4 * (size_t)q + k] >= 0 ? e->vrow[s.dm_idx[4 * (size_t)q + k]] : -1; plain = plain && r4[k] >= 0; }
+                if (!plain) break;
+                for (int h = 0; h < 2 && plain; ++h) {
+                    const int cur = r4[h], nx = r4[2 + h];
+                    if ((nxt_row[cur] >= 0 && nxt_row[cur] != nx) || (prv_row[nx] >= 0 && prv_row[nx] != cur) || cur == nx) plain = false;
+                    nxt_row[cur] = nx; prv_row[nx] = cur;
+                }
+            }
+            d.dform = plain ? 1 : 0;
+        }
+        if (!d.dform) { nxt_row.clear(); prv_row.clear(); }
+    }
     // ---- LDS staging: per workgroup (= 4 slices = BLK/T rows) the sorted list of rows referenced
     // outside the tile; neighbour ids become tile-local
     d.tile_rows = BLK / T;
@@ -391,7 +430,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                 // spring neighbours first (the SpMV stages positions for them only), then damper-only rows
                 for (size_t p2 = s0; p2 < s1; ++p2) see(S_other[p2]);
                 const size_t ns = ext.size();
-                for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
+                if (d.dform) {                                     // the partner in the same keyframe: 2c / 1c (slot 0) or 2n / 1n (slot 2)
+                    for (size_t p2 = d0; p2 < d1; ++p2)
+                        if (D_role[p2] >= 0) see(D_o[3 * p2 + (D_role[p2] < 2 ? 0 : 2)]);
+                } else
+                    for (size_t p2 = 3 * d0; p2 < 3 * d1; ++p2) see(D_o[p2]);
                 std::sort(ext.begin(), ext.begin() + ns);
                 std::sort(ext.begin() + ns, ext.end());
                 halo_ns[b] = (int)ns;
@@ -456,10 +499,16 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     size_t lds_need = 0;
     for (int cls = 0; cls < 2; ++cls) {
         if (!d.n_tiles_cls[cls]) continue;
+        if (d.dform) {
+            lds_need = std::max(lds_need, sizeof(double) * 9 * (size_t)(d.tile_rows + d.cap_h[cls] + 1));                                    // linearise: x, G^f, G^b
+            lds_need = std::max(lds_need, sizeof(double) * 3 * (3 * (size_t)(d.tile_rows + d.cap_h[cls] + 1) + d.tile_rows + d.cap_s[cls] + 1));  // operator: u, G^f, G^b + positions
+            continue;
+        }
         lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (s.X0 ? 2 : 1));                          // linearise
         lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2));                    // operator: u + positions
     }
     if (getenv("NRS_NO_LDS") || s.force_gather || lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    if (!d.use_lds) d.dform = 0;
     d.lin_rb = d.use_lds ? ROW_ALIGN / d.tile_rows : 1;              // lineariser partials: per tile (LDS path) or per group
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
@@ -513,9 +562,15 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         // boundary tiles (their halo holds rows of another rank) sit at the two ends of the rank's tile range:
         // they run after the interior tiles, once the neighbours' rows have arrived
         const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
+        auto outside = [&](int r) { return r >= 0 && (r < own_lo || r >= own_hi); };
         auto foreign = [&](int b) {
-            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i)
-                if (halo_rows[i] < own_lo || halo_rows[i] >= own_hi) return true;
+            for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i) {
+                if (outside(halo_rows[i])) return true;
+                if (d.dform && (outside(nxt_row[halo_rows[i]]) || outside(prv_row[halo_rows[i]]))) return true;
+            }
+            if (d.dform)
+                for (int r = b * d.tile_rows; r < (b + 1) * d.tile_rows; ++r)
+                    if (outside(nxt_row[r]) || outside(prv_row[r])) return true;
             return false;
         };
         for (int cls = 0; cls < 2; ++cls) {
@@ -635,9 +690,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         auto u16 = [](int v) { return v < 0 ? (uint32_t)REC_NONE : (uint32_t)(v & 0xFFFF); };
         e->h_s_om.resize(nnz_s);
         for (size_t i = 0; i < nnz_s; ++i) e->h_s_om[i] = u16(L_s[i]);                        // meta: push_masks
-        e->h_d_hdr.resize(nnz_d);
-        for (size_t i = 0; i < nnz_d; ++i)
-            e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i]) | (u16(L_d[3 * i + 1]) << 16), u16(L_d[3 * i + 2]) | ((uint32_t)REC_NONE << 16));
+        if (d.dform) {
+            e->h_d_om.resize(nnz_d);
+            for (size_t i = 0; i < nnz_d; ++i) e->h_d_om[i] = D_role[i] < 0 ? (uint32_t)REC_NONE : u16(L_d[3 * i + (D_role[i] < 2 ? 0 : 2)]);
+        } else {
+            e->h_d_hdr.resize(nnz_d);
+            for (size_t i = 0; i < nnz_d; ++i)
+                e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i]) | (u16(L_d[3 * i + 1]) << 16), u16(L_d[3 * i + 2]) | ((uint32_t)REC_NONE << 16));
+        }
     } else {
         d_o0.resize(nnz_d); d_o1.resize(nnz_d); d_o2.resize(nnz_d);
         for (size_t i = 0; i < nnz_d; ++i) { d_o0[i] = D_o[3 * i]; d_o1[i] = D_o[3 * i + 1]; d_o2[i] = D_o[3 * i + 2]; }
@@ -659,6 +719,15 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     NRS_TRY(h2d(c, d.halo_rows, halo_rows));
     NRS_TRY(h2d(c, d.halo_ns, halo_ns));
     NRS_TRY(h2d(c, d.tile_list, tile_list));
+    if (d.dform) {
+        std::vector<int> hn(halo_rows.size()), hp(halo_rows.size());
+        for (size_t i = 0; i < halo_rows.size(); ++i) { hn[i] = nxt_row[halo_rows[i]]; hp[i] = prv_row[halo_rows[i]]; }
+        NRS_TRY(h2d(c, d.nxt_row, nxt_row));
+        NRS_TRY(h2d(c, d.prv_row, prv_row));
+        NRS_TRY(h2d(c, d.halo_nxt, hn));
+        NRS_TRY(h2d(c, d.halo_prv, hp));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));               // hn / hp die here
+    }
     if (d.fused) {
         std::vector<int> tile_desc(8 * (size_t)d.n_regblk, 0), halo_fix((size_t)BLK * d.n_regblk, 0);
         const int rb = ROW_ALIGN / d.tile_rows;

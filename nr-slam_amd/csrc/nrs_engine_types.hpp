@@ -71,6 +71,17 @@ struct Dev {
     int* tile_list; int n_tiles_cls[2]; int cap_h[2], cap_s[2];
     int* halo_ptr; int* halo_rows; int* halo_ns;   // halo_ns[b] = number of spring-halo rows of tile b
     uint32_t* s_om; double* s_qc; uint2* d_hdr;      // (s_d0, d_w, d_s: above; sized by the incidence count in both paths)
+    // Temporal-difference form of the dampers (BA windows on the two-kernel path).  A reference damper joins the SAME two
+    // map points in two consecutive keyframes, (1c, 2c, 1n, 2n) with 1n = next(1c), 2n = next(2c) (OPT:1076-1136), so
+    // with G^f_r = v_r - v_next(r) and G^b_r = v_r - v_prev(r) every incidence is
+    //     a_i += s (G^d_i - G^d_o),  o = the partner row in the same keyframe, d = forward for roles 1c / 2c, backward for 1n / 2n.
+    // The kernels stage v, G^f, G^b for the tile and its same-keyframe halo (the temporal partners are read from global
+    // memory once per staged row): one LDS vector per damper incidence instead of three, a 4-byte header instead of 8,
+    // and a halo of ~190 rows instead of ~520 (the rows of the two adjacent keyframes are no longer part of it).
+    int dform;
+    uint32_t* d_om;                  // dform: {partner u16 | meta u16 << 16} per damper incidence
+    int* nxt_row; int* prv_row;      // dform: row of the same map point in the next / previous keyframe (-1: none)
+    int* halo_nxt; int* halo_prv;    // dform: the same for the halo rows (indexed like halo_rows)
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
     Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
     // state (two copies: current / trial, swapped on accept)
@@ -163,6 +174,7 @@ struct Engine {
     std::vector<int> h_s_meta, h_d_meta;
     std::vector<uint32_t> h_s_om;
     std::vector<uint2> h_d_hdr;
+    std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
     // device copies for the taps
     int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
@@ -258,6 +270,24 @@ __device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __
         d[0] = v[3 * r] + (add ? add[3 * r] : 0.0);
         d[1] = v[3 * r + 1] + (add ? add[3 * r + 1] : 0.0);
         d[2] = v[3 * r + 2] + (add ? add[3 * r + 2] : 0.0);
+    }
+}
+
+// temporal-difference form: v and its forward / backward differences for the tile's rows and its (same-keyframe) halo
+__device__ inline void stage_rows_d(const Dev& P, int b, int tid, const double* __restrict__ v, double* lv, double* lf, double* lb) {
+    const int row0 = b * P.tile_rows;
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+    for (int i = tid; i < P.tile_rows + hn; i += BLK) {
+        int r, rn, rp;
+        if (i < P.tile_rows) { r = row0 + i; rn = P.nxt_row[r]; rp = P.prv_row[r]; }
+        else { const int j = hb + i - P.tile_rows; r = P.halo_rows[j]; rn = P.halo_nxt[j]; rp = P.halo_prv[j]; }
+        const size_t a = 3 * (size_t)r, an = 3 * (size_t)(rn >= 0 ? rn : r), ap = 3 * (size_t)(rp >= 0 ? rp : r);
+        const double v0 = v[a], v1 = v[a + 1], v2 = v[a + 2];
+        const double n0 = v[an], n1 = v[an + 1], n2 = v[an + 2];
+        const double p0 = v[ap], p1 = v[ap + 1], p2 = v[ap + 2];
+        lv[3 * i] = v0; lv[3 * i + 1] = v1; lv[3 * i + 2] = v2;
+        lf[3 * i] = v0 - n0; lf[3 * i + 1] = v1 - n1; lf[3 * i + 2] = v2 - n2;
+        lb[3 * i] = v0 - p0; lb[3 * i + 1] = v1 - p1; lb[3 * i + 2] = v2 - p2;
     }
 }
 

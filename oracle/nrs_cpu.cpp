@@ -705,6 +705,133 @@ struct Pcg {
         }
         return true;
     }
+    // y = (H + lam I) v over all block rows (OpenMP over rows)
+    void spmv(double lam, const vector<double>& v, vector<double>& y) const {
+        const BlockMat& H = G->H;
+        const int nb = H.n, T = G->threads;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(T)
+        for (int i = 0; i < nb; ++i) {
+            double a0 = lam * v[3 * (size_t)i], a1 = lam * v[3 * (size_t)i + 1], a2 = lam * v[3 * (size_t)i + 2];
+            for (int64_t q = H.ptr[i]; q < H.ptr[i + 1]; ++q) {
+                const double* blk = &H.val[9 * (size_t)q];
+                const double* pj = &v[3 * (size_t)H.col[q]];
+                a0 += blk[0] * pj[0] + blk[1] * pj[1] + blk[2] * pj[2];
+                a1 += blk[3] * pj[0] + blk[4] * pj[1] + blk[5] * pj[2];
+                a2 += blk[6] * pj[0] + blk[7] * pj[1] + blk[8] * pj[2];
+            }
+            y[3 * (size_t)i] = a0; y[3 * (size_t)i + 1] = a1; y[3 * (size_t)i + 2] = a2;
+        }
+    }
+    // Measurement variant for the north star's "Schur complement" question: the pose blocks (block-diagonal
+    // 6x6: there are no pose-pose edges) are eliminated exactly and PCG runs on the landmark system
+    //   S = (H_ll + lam) - H_lp (H_pp + lam)^-1 H_pl   with its exact 3x3 diagonal blocks as preconditioner.
+    // H_ll is NOT block diagonal here (springs and dampers couple landmarks), so this is the only Schur step that is free.
+    bool solve_pose_eliminated(double lam, double rtol, int max_it, double* xo) {
+        const BlockMat& H = G->H;
+        const int nb = H.n, K = G->K, T = G->threads;
+        const size_t n = 3 * (size_t)nb;
+        Mp.assign(36 * (size_t)K, 0.0);
+        for (int k = 0; k < K; ++k) {
+            double A[36];
+            const int bl[2] = {2 * k, 2 * k + 1};
+            for (int p = 0; p < 2; ++p)
+                for (int q = 0; q < 2; ++q) {
+                    const double* blk = &H.val[9 * H.find(bl[p], bl[q])];
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[(3 * p + i) * 6 + 3 * q + j] = blk[3 * i + j];
+                }
+            for (int i = 0; i < 6; ++i) A[i * 6 + i] += lam;
+            if (!inv_spd(6, A, &Mp[36 * (size_t)k])) return false;
+        }
+        auto pose_solve = [&](vector<double>& v) {                    // v_p <- (H_pp + lam)^-1 v_p, landmark part untouched
+            for (int k = 0; k < K; ++k) {
+                double o[6];
+                for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Mp[36 * (size_t)k + 6 * i + j] * v[6 * (size_t)k + j]; o[i] = s; }
+                for (int i = 0; i < 6; ++i) v[6 * (size_t)k + i] = o[i];
+            }
+        };
+        const size_t np = 6 * (size_t)K;
+        vector<double> t1(n), t2(n), t3(n);
+        auto apply_S = [&](const vector<double>& v, vector<double>& y) {   // v, y: zero pose part
+            spmv(lam, v, t1);                                          // [H_pl v ; (H_ll + lam) v]
+            std::fill(t2.begin(), t2.end(), 0.0);
+            for (size_t i = 0; i < np; ++i) t2[i] = t1[i];
+            pose_solve(t2);                                            // z = (H_pp + lam)^-1 H_pl v
+            spmv(0.0, t2, t3);                                         // [H_pp z ; H_lp z]
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = (int64_t)np; i < (int64_t)n; ++i) y[i] = t1[i] - t3[i];
+            for (size_t i = 0; i < np; ++i) y[i] = 0.0;
+        };
+        // exact diagonal blocks of S: D_l - H_lp (H_pp + lam)^-1 H_pl (one pose per landmark)
+        Minv.assign(9 * (size_t)nb, 0.0);
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(T)
+        for (int i = 2 * K; i < nb; ++i) {
+            double A[9];
+            for (int q = 0; q < 9; ++q) A[q] = H.val[9 * H.diag[i] + q];
+            A[0] += lam; A[4] += lam; A[8] += lam;
+            const int k = G->lm_kf[i - 2 * K];
+            double Hlp[3][6];
+            for (int h = 0; h < 2; ++h) {
+                const double* blk = &H.val[9 * H.find(i, 2 * k + h)];
+                for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) Hlp[a][3 * h + c] = blk[3 * a + c];
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c) {
+                    double sacc = 0;
+                    for (int p = 0; p < 6; ++p) for (int q = 0; q < 6; ++q) sacc += Hlp[a][p] * Mp[36 * (size_t)k + 6 * p + q] * Hlp[c][q];
+                    A[3 * a + c] -= sacc;
+                }
+            if (!inv_spd(3, A, &Minv[9 * (size_t)i])) ++bad;
+        }
+        if (bad) return false;
+        auto precond = [&](const vector<double>& rr, vector<double>& uu) {
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int i = 2 * K; i < nb; ++i) {
+                const double* Mi = &Minv[9 * (size_t)i];
+                for (int a = 0; a < 3; ++a) uu[3 * (size_t)i + a] = Mi[3 * a] * rr[3 * (size_t)i] + Mi[3 * a + 1] * rr[3 * (size_t)i + 1] + Mi[3 * a + 2] * rr[3 * (size_t)i + 2];
+            }
+        };
+        auto dot = [&](const vector<double>& a, const vector<double>& c) {
+            double sm = 0;
+#pragma omp parallel for reduction(+ : sm) schedule(static) num_threads(T)
+            for (int64_t i = (int64_t)np; i < (int64_t)n; ++i) sm += a[i] * c[i];
+            return sm;
+        };
+        // g = b_l - H_lp (H_pp + lam)^-1 b_p
+        vector<double> bp(n, 0.0), hb(n);
+        for (size_t i = 0; i < np; ++i) bp[i] = G->b[i];
+        pose_solve(bp);
+        spmv(0.0, bp, hb);
+        r.assign(n, 0.0); u.assign(n, 0.0); p.assign(n, 0.0); w.assign(n, 0.0);
+        for (size_t i = np; i < n; ++i) r[i] = G->b[i] - hb[i];
+        vector<double> xl(n, 0.0);
+        precond(r, u);
+        double gamma = dot(r, u);
+        const double gamma0 = gamma;
+        p = u;
+        iters = 0;
+        while (iters < max_it && gamma > rtol * rtol * gamma0 && gamma != 0.0) {
+            apply_S(p, w);
+            const double alpha = gamma / dot(p, w);
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = (int64_t)np; i < (int64_t)n; ++i) { xl[i] += alpha * p[i]; r[i] -= alpha * w[i]; }
+            precond(r, u);
+            const double g2 = dot(r, u);
+            const double beta = g2 / gamma;
+            gamma = g2;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = (int64_t)np; i < (int64_t)n; ++i) p[i] = u[i] + beta * p[i];
+            ++iters;
+        }
+        // back-substitution: x_p = (H_pp + lam)^-1 (b_p - H_pl x_l)
+        spmv(0.0, xl, t1);
+        std::fill(t2.begin(), t2.end(), 0.0);
+        for (size_t i = 0; i < np; ++i) t2[i] = G->b[i] - t1[i];
+        pose_solve(t2);
+        for (size_t i = 0; i < np; ++i) xo[i] = t2[i];
+        for (size_t i = np; i < n; ++i) xo[i] = xl[i];
+        return std::isfinite(gamma);
+    }
     bool solve(double lam, double rtol, int max_it, double* xo) {
         const BlockMat& H = G->H;
         const int nb = H.n, K = G->K, T = G->threads;
@@ -852,7 +979,8 @@ int nrs_cpu_block_cholesky_solve(int32_t nb, int32_t n_blocks, const int32_t* br
 }
 
 // LocalDeformableBundleAdjustment on flat arrays (same argument meaning as nrs_dba_solve in include/nrs.h).
-// solver: 0 = sparse block Cholesky (reference-equivalent), 1 = block-Jacobi PCG to pcg_rtol.
+// solver: 0 = sparse block Cholesky (reference-equivalent), 1 = block-Jacobi PCG to pcg_rtol, 2 = the same PCG on the
+// pose-eliminated (Schur) landmark system -- a measurement variant (natural block order: poses first).
 // max_trials_total > 0 stops after that many LM trials (bounded timing samples on large windows).
 int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
                       const int32_t* lm_kf, const float* lm_uv, int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
@@ -952,7 +1080,7 @@ int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* pos
                 S.t_solve += now_s() - t0;
             } else {
                 t0 = now_s();
-                ok = pcg.solve(lam, pcg_rtol, 20000, dx.data());
+                ok = solver == 2 ? pcg.solve_pose_eliminated(lam, pcg_rtol, 20000, dx.data()) : pcg.solve(lam, pcg_rtol, 20000, dx.data());
                 inner = pcg.iters;
                 S.n_pcg_iters += inner;
                 S.t_solve += now_s() - t0;

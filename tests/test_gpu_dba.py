@@ -90,6 +90,40 @@ def test_solve_kb8(ctx):
     assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("model", [S.PINHOLE, S.KB8])
+def test_two_kernel_path_with_temporal_difference_dampers(ctx, monkeypatch, model):
+    """Small windows take the fused single-launch PCG iteration, large ones the two-kernel path (k_spmv_f + k_pcg_update).
+    NRS_NO_FUSED puts a small window on the two-kernel path, so that it is held to the oracle trial by trial like the
+    other; NRS_DFORM=1 additionally switches its dampers to the opt-in temporal-difference form (G^f / G^b staged per
+    tile, nrs_engine_types.hpp): both must agree with each other far below the oracle tolerances."""
+    p, e, cam, qt = _setup(500, 5, 34, model)
+    otr = []
+    oq, ot, opts, nit = O.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"],
+                                    p["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"], p["scale"], 5, otr)
+    out = {}
+    for name, env in (("dform", {"NRS_NO_FUSED": "1", "NRS_DFORM": "1"}), ("generic", {"NRS_NO_FUSED": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = nrs.Trace()
+        pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr)
+        ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        rr, rs, rd = ctx.dba_residuals()
+        b, dg = ctx.dba_gradient()
+        out[name] = (pq, xyz, tr.trials, b, dg)
+        assert tr.iterations == nit and [t["accepted"] for t in tr.trials] == [t["accepted"] for t in otr]
+        for a, o in zip(tr.trials, otr):
+            assert abs(a["lam"] - o["lam"]) <= 1e-6 * o["lam"] and abs(a["chi"] - o["chi"]) <= 1e-6 * o["chi"]
+            if not a["early"]:
+                assert abs(a["chi_new"] - o["chi_new"]) <= 1e-6 * o["chi_new"]
+        assert np.allclose(pq[:, :4], oq, atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
+        assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
+        for k in env:
+            monkeypatch.delenv(k)
+    a, g = out["dform"], out["generic"]
+    assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)
+    assert np.max(np.abs(a[3] - g[3])) <= 1e-10 * np.max(np.abs(g[3])) and np.max(np.abs(a[4] - g[4])) <= 1e-10 * np.max(np.abs(g[4]))
+
+
 def test_resident_reset_and_determinism(ctx):
     p, e, cam, qt = _setup(400, 5, 51)
     ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
