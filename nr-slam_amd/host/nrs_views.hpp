@@ -67,6 +67,26 @@ struct KeyFrameWindow {                   // the BA window, oldest keyframe firs
     std::vector<float> lm_uv, lm_xyz;     // per (keyframe, point) landmark, keyframe-major
 };
 
+// TemporalBuffer flattened (map/temporal_buffer.h:43-63): n_frames snapshots, oldest first; per snapshot the camera pose
+// and, per keypoint id, the keypoint (keypoint_tracks) and the landmark position (mapppoint_tracks_) when present.
+// This is the wire form nrs_triangulate_batch reads (and what tests/golden stores for f2).
+struct TemporalBufferView {
+    int32_t n_frames = 0, n_ids = 0;
+    std::vector<float> poses;             // n_frames x 7   Snapshot::camera_transform_world (qx qy qz qw tx ty tz)
+    std::vector<uint8_t> has_kp, has_lm;  // n_frames x n_ids
+    std::vector<float> kp_xy;             // n_frames x n_ids x 2
+    std::vector<float> lm_xyz;            // n_frames x n_ids x 3
+    std::vector<int32_t> last_status;     // n_ids          keypoint_tracks_status of the last snapshot
+};
+
+// KeyFrame snapshot (map/keyframe.cc:26-55): what a keyframe keeps of its frame, i.e. one block of KeyFrameWindow
+struct KeyFrameView {
+    double pose_qt[7];
+    std::vector<int32_t> map_index;       // TRACKED_WITH_3D observations in keyframe index order
+    std::vector<float> uv, xyz;
+    void append_to(KeyFrameWindow& w) const;
+};
+
 class Engine {                            // owns one nrs_ctx; not thread-safe, like the reference's callers
 public:
     explicit Engine(int device = -1) {
@@ -148,7 +168,20 @@ public:
         ids.assign(id.begin(), id.begin() + n);
     }
 
+    // absl::StatusOr<Eigen::Vector3f> DeformableTriangulation(TemporalBuffer&, int candidate_id, shared_ptr<CameraModel>, float)
+    // g2o_optimization.h:34-37, for every candidate of Mapping::LandmarkTriangulation at once (mapping.cc:65-116):
+    // status[i] = 0 (ok) or the InternalError code of include/nrs.h; xyz = the triangulated positions.
+    void DeformableTriangulation(const CameraView& cam, const TemporalBufferView& tb, const std::vector<int32_t>& candidate_ids,
+                                 std::vector<int32_t>& status, std::vector<float>& xyz, int min_track = 5) {
+        status.assign(candidate_ids.size(), 0);
+        xyz.assign(3 * candidate_ids.size(), 0.f);
+        check(nrs_triangulate_batch(ctx_, &cam.cam, tb.n_frames, tb.poses.data(), tb.n_ids, tb.has_kp.data(), tb.kp_xy.data(),
+                                    tb.has_lm.data(), tb.lm_xyz.data(), tb.last_status.data(), (int32_t)candidate_ids.size(),
+                                    candidate_ids.data(), min_track, status.data(), xyz.data(), nullptr));
+    }
+
     nrs_ctx* raw() { return ctx_; }
+    void check_rc(int rc) { check(rc); }
 
 private:
     void check(int rc) {
@@ -156,6 +189,103 @@ private:
         if (rc != NRS_OK) throw std::runtime_error(std::string("nrs: ") + nrs_last_error(ctx_));
     }
     nrs_ctx* ctx_ = nullptr;
+};
+
+inline void KeyFrameView::append_to(KeyFrameWindow& w) const {
+    if (w.kf_rowptr.empty()) w.kf_rowptr.push_back(0);
+    w.poses_qt.insert(w.poses_qt.end(), pose_qt, pose_qt + 7);
+    w.kf_pt.insert(w.kf_pt.end(), map_index.begin(), map_index.end());
+    w.lm_uv.insert(w.lm_uv.end(), uv.begin(), uv.end());
+    w.lm_xyz.insert(w.lm_xyz.end(), xyz.begin(), xyz.end());
+    w.kf_rowptr.push_back((int32_t)w.kf_pt.size());
+}
+
+// LucasKanadeTracker (modules/matching/lucas_kanade_tracker.h:55-70): same method names and argument meaning; the
+// template caches the reference keeps as public members (Iref_, Idref_, vMeanI_, vMeanI2_, prevPts_) live in the context.
+struct PhotometricInformation {           // lucas_kanade_tracker.h:38-45, all pyramid levels of one point
+    float xy[2];
+    std::vector<int16_t> gray, grad;
+    std::vector<float> mean;
+    std::vector<uint8_t> valid;
+};
+
+class LucasKanadeTracker {
+public:
+    // LucasKanadeTracker(cv::Size winSize, int maxLevel, int maxIters, float epsilon, float minEigThreshold)
+    LucasKanadeTracker(Engine& e, int win_size = 21, int max_level = 4, int max_iters = 10, float epsilon = 1e-4f, float min_eig = 1e-4f)
+        : e_(e), levels_(max_level + 1) {
+        nrs_klt_config cfg{win_size, max_level, max_iters, epsilon, min_eig};
+        e_.check_rc(nrs_klt_configure(e_.raw(), &cfg));
+    }
+    // void SetReferenceImage(cv::Mat& refIm, std::vector<cv::KeyPoint>& refPts, cv::Mat mask)
+    void SetReferenceImage(const uint8_t* im, int w, int h, int stride, const std::vector<float>& ref_pts, const uint8_t* mask = nullptr) {
+        e_.check_rc(nrs_klt_set_reference(e_.raw(), im, w, h, stride, mask, (int32_t)(ref_pts.size() / 2), ref_pts.data()));
+    }
+    // int Track(cv::Mat& newIm, std::vector<cv::KeyPoint>& nextPts, std::vector<LandmarkStatus>& status,
+    //           const bool bInitialFlow, const float minSSIM, cv::Mat mask)
+    int Track(const uint8_t* im, int w, int h, int stride, std::vector<float>& next_pts, std::vector<int32_t>& status,
+              bool initial_flow, float min_ssim) {
+        int32_t good = 0;
+        e_.check_rc(nrs_klt_track(e_.raw(), im, w, h, stride, (int32_t)status.size(), next_pts.data(), status.data(), initial_flow ? 1 : 0,
+                                  min_ssim, &good, nullptr));
+        return good;
+    }
+    PhotometricInformation GetPhotometricInformationOfPoint(int idx) {
+        PhotometricInformation p;
+        p.gray.resize((size_t)levels_ * 441); p.grad.resize((size_t)levels_ * 882); p.mean.resize((size_t)levels_ * 2); p.valid.resize((size_t)levels_);
+        e_.check_rc(nrs_klt_get_template(e_.raw(), idx, p.xy, p.gray.data(), p.grad.data(), p.mean.data(), p.valid.data()));
+        return p;
+    }
+    void InsertPhotometricInformation(const PhotometricInformation& p) {
+        e_.check_rc(nrs_klt_insert_template(e_.raw(), p.xy, p.gray.data(), p.grad.data(), p.mean.data(), p.valid.data()));
+    }
+    void clear() { e_.check_rc(nrs_klt_clear(e_.raw())); }
+    int size() { return nrs_klt_num_points(e_.raw()); }
+
+private:
+    Engine& e_;
+    int levels_;
+};
+
+// RegularizationGraph (modules/map/regularization_graph.h:34-96) at the reference's all-pairs density, device resident.
+// Point "ids" are indices 0 .. capacity-1 (the shim keeps the MapPoint ID <-> index map, as it does for frames).
+class RegularizationGraph {
+public:
+    struct Neighbour { int32_t id; float weight, first_distance; int32_t status; };
+    RegularizationGraph(Engine& e, int capacity, float weight_sigma, float streching_th) : e_(e), cap_(capacity) {
+        e_.check_rc(nrs_rgraph_create(e_.raw(), capacity, weight_sigma, streching_th, &g_));
+    }
+    ~RegularizationGraph() { nrs_rgraph_destroy(g_); }
+    RegularizationGraph(const RegularizationGraph&) = delete;
+    RegularizationGraph& operator=(const RegularizationGraph&) = delete;
+    void SetSigma(float sigma) { e_.check_rc(nrs_rgraph_set_sigma(g_, sigma)); }
+    float GetMinWeightAllowed() const { return nrs_rgraph_min_weight(g_); }
+    // AddEdge(id, other, relative_position) for every (new, other) pair; positions = capacity x 3, by index
+    void AddEdges(const std::vector<float>& positions, const std::vector<int32_t>& new_ids, const std::vector<int32_t>& other_ids) {
+        e_.check_rc(nrs_rgraph_add_edges(g_, positions.data(), (int32_t)new_ids.size(), new_ids.data(), (int32_t)other_ids.size(), other_ids.data()));
+    }
+    // int UpdateVertex(ID) for each listed vertex: returns the good-connection counts
+    std::vector<int32_t> UpdateVertices(const std::vector<float>& last_world_positions, const std::vector<int32_t>& ids) {
+        std::vector<int32_t> good(ids.size());
+        e_.check_rc(nrs_rgraph_update(g_, last_world_positions.data(), (int32_t)ids.size(), ids.data(), good.data()));
+        return good;
+    }
+    // std::vector<std::pair<ID, shared_ptr<Edge>>> GetEdges(ID) for each listed vertex
+    std::vector<std::vector<Neighbour>> GetEdges(const std::vector<int32_t>& ids, int cap_per_point = 256) {
+        const size_t n = ids.size(), no = n * (size_t)cap_per_point;
+        std::vector<int32_t> cnt(n), col(no), st(no);
+        std::vector<float> w(no), d0(no);
+        e_.check_rc(nrs_rgraph_get_edges(g_, (int32_t)n, ids.data(), cap_per_point, cnt.data(), col.data(), w.data(), d0.data(), st.data()));
+        std::vector<std::vector<Neighbour>> out(n);
+        for (size_t r = 0; r < n; ++r)
+            for (int k = 0; k < cnt[r]; ++k) out[r].push_back({col[r * cap_per_point + k], w[r * cap_per_point + k], d0[r * cap_per_point + k], st[r * cap_per_point + k]});
+        return out;
+    }
+
+private:
+    Engine& e_;
+    int cap_;
+    nrs_rgraph* g_ = nullptr;
 };
 
 }  // namespace nrs_host

@@ -72,3 +72,57 @@ def test_cpp_host_mirror_matches_ctypes_path(ctx, tmp_path):
     camb = nrs.make_camera(p["model"], p["prm"])
     pq, xyz = ctx.dba_solve(camb, wqt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5)
     assert np.array_equal(a3_qt.reshape(-1, 7), pq) and np.array_equal(a3_xyz.reshape(-1, 3), xyz)
+
+
+def test_cpp_tracker_graph_and_triangulation_mirror(tmp_path):
+    """LucasKanadeTracker / RegularizationGraph / DeformableTriangulation through the compiled C++ mirror classes
+    (nr-slam_amd/host/nrs_views.hpp, host_demo2.cpp; the reference's method names) against the ctypes path."""
+    demo = os.path.join(ROOT, "nr-slam_amd", "host_demo2")
+    if not os.path.exists(demo):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "nr-slam_amd"), "host_demo2"], check=True, capture_output=True, timeout=600)
+    sq = S.make_lk_sequence(300, 5)
+    h, w = sq["im0"].shape
+    rng = np.random.default_rng(4)
+    n = 400
+    pos0 = np.stack([rng.uniform(-10, 10, n), rng.uniform(-8, 8, n), 60 + rng.normal(0, 1, n)], 1).astype(np.float32)
+    pos1 = (pos0 * np.array([1.9, 1.9, 1.0], np.float32) + rng.normal(0, 0.02, pos0.shape)).astype(np.float32)
+    upd = np.sort(rng.choice(n, 300, replace=False)).astype(np.int32)
+    tb = S.make_temporal_buffer(10, 12)
+    src, dst = tmp_path / "in2.blob", tmp_path / "out2.blob"
+    with open(src, "wb") as f:
+        _w(f, np.array([w, h], np.int32)); _w(f, sq["im0"]); _w(f, sq["im1"]); _w(f, sq["pts"].astype(np.float32))
+        _w(f, np.array([3.0, 1.1], np.float32)); _w(f, pos0); _w(f, pos1); _w(f, upd)
+        _w(f, np.array([tb["model"]], np.int32)); _w(f, np.asarray(tb["prm"], np.float32))
+        _w(f, np.array(tb["has_kp"].shape, np.int32)); _w(f, tb["poses"].astype(np.float32)); _w(f, tb["has_kp"].astype(np.uint8))
+        _w(f, tb["kp_xy"].astype(np.float32)); _w(f, tb["has_lm"].astype(np.uint8)); _w(f, tb["lm_xyz"].astype(np.float32))
+        _w(f, tb["status"].astype(np.int32)); _w(f, tb["cand"].astype(np.int32))
+    r = subprocess.run([demo, str(src), str(dst)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(dst, "rb") as f:
+        nxt, st, good, npts, gray = _r(f, np.float32), _r(f, np.int32), _r(f, np.int32), _r(f, np.int32), _r(f, np.int16)
+        goodc, flat, fw = _r(f, np.int32), _r(f, np.int32), _r(f, np.float32)
+        tst, txyz = _r(f, np.int32), _r(f, np.float32)
+    c = nrs.Context()
+    c.klt_configure()
+    c.klt_set_reference(sq["im0"], sq["pts"])
+    xy, st2, good2, _ = c.klt_track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32), True, 0.7)
+    assert np.array_equal(nxt.reshape(-1, 2), xy) and np.array_equal(st, st2) and good[0] == good2
+    assert npts[0] == len(sq["pts"]) + 1 and np.array_equal(gray.reshape(-1, 21, 21), c.klt_get_template(3)["gray"])
+    g = nrs.RGraph(c, n, 3.0, 1.1)
+    ids = np.arange(n, dtype=np.int32)
+    g.add_edges(pos0, ids, ids)
+    assert np.array_equal(goodc, g.update(pos1, upd))
+    cnt, col, wv, d0, stg = g.get_edges(ids, 256)
+    k = kf = 0
+    for i in range(n):
+        assert flat[k] == cnt[i]
+        row = flat[k + 1:k + 1 + 2 * cnt[i]].reshape(-1, 2)
+        assert np.array_equal(row[:, 0], col[i, :cnt[i]]) and np.array_equal(row[:, 1], stg[i, :cnt[i]])
+        fr = fw[kf:kf + 2 * cnt[i]].reshape(-1, 2)
+        assert np.array_equal(fr[:, 0], wv[i, :cnt[i]]) and np.array_equal(fr[:, 1], d0[i, :cnt[i]])
+        k += 1 + 2 * cnt[i]
+        kf += 2 * cnt[i]
+    g.close()
+    s2, x2 = c.triangulate_batch(nrs.make_camera(tb["model"], tb["prm"]), tb, tb["cand"])
+    assert np.array_equal(tst, s2) and np.array_equal(txyz.reshape(-1, 3), x2)
+    c.close()
