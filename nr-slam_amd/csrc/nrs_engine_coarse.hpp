@@ -86,13 +86,11 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
             for (int idx = dbeg + lane; idx < dend; idx += 64) {
                 const DamperRec rc = load_damper(P, idx);
                 if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
-                const int role = rc.meta & 3;
                 const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
-                const double so = damper_sign(role);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     if (o[k] == REC_NONE || lfix[o[k]] || lgrp[o[k]] != hg) continue;
-                    const double c = so * damper_sign(k + (k >= role ? 1 : 0)) * rc.s;   // H_ik = sg_i sg_k s I
+                    const double c = (k == 2 ? 1.0 : -1.0) * rc.s;     // canonical order: a_i = s ((u_i - u[o1]) - (u[o0] - u[o2])) => H_ik = (-, -, +) s I
                     acc[0] += c; acc[3] += c; acc[5] += c;
                 }
             }
@@ -118,13 +116,11 @@ __global__ __launch_bounds__(BLK) void k_coarse_tile(Dev P) {
         for (int idx = dbeg + lane; idx < dend; idx += 64) {
             const DamperRec rc = load_damper(P, idx);
             if (rc.meta == REC_NONE || (rc.meta & DM_UNARY)) continue;
-            const int role = rc.meta & 3;
             const uint16_t o[3] = {rc.o0, rc.o1, rc.o2};
-            const double so = damper_sign(role);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (o[k] == REC_NONE || o[k] >= P.tile_rows || lfix[o[k]]) continue;
-                const double c = so * damper_sign(k + (k >= role ? 1 : 0)) * rc.s;
+                const double c = (k == 2 ? 1.0 : -1.0) * rc.s;
                 acc[0] += c; acc[3] += c; acc[5] += c;
             }
         }

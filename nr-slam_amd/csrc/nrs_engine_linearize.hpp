@@ -399,6 +399,29 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         }
         if (!LIN && !(meta & DM_COUNT)) return;           // chi2 only: counted from one of the edge's rows
         const double w = (double)wf;
+        if (LDS) {
+            // LDS records list the others in canonical order (engine_create): sg_i * sum_k sg_k x_k =
+            // (x_i - x[o1]) - (x[o0] - x[o2]) for every role, absent vertices read as zero
+            double v[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool has = o[k] >= 0;
+                const int ok = has ? o[k] : 0;
+                v[k][0] = has ? xl[3 * ok] : 0.0; v[k][1] = has ? xl[3 * ok + 1] : 0.0; v[k][2] = has ? xl[3 * ok + 2] : 0.0;
+            }
+            const double g0 = (xo0 - v[1][0]) - (v[0][0] - v[2][0]), g1 = (xo1 - v[1][1]) - (v[0][1] - v[2][1]), g2 = (xo2 - v[1][2]) - (v[0][2] - v[2][2]);
+            const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
+            double rho0, rho1;
+            huber(P.info_spatial * (r0 * r0 + r1 * r1 + r2 * r2), P.delta_spatial, rho0, rho1);
+            if (meta & DM_COUNT) chi += rho0;
+            if (LIN) {
+                const double sfac = (rfix ? 0.0 : 1.0) * rho1 * P.info_spatial * w * w;
+                P.d_s[idx] = sfac;
+                D[0] += sfac; D[3] += sfac; D[5] += sfac;
+                bb[0] -= sfac * g0; bb[1] -= sfac * g1; bb[2] -= sfac * g2;
+            }
+            return;
+        }
         const int role = meta & 3;
         const double sgn_own = damper_sign(role);
         double s0 = sgn_own * xo0, s1 = sgn_own * xo1, s2 = sgn_own * xo2;

@@ -323,17 +323,14 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             const int meta = dr[q].meta == REC_NONE ? 0 : (int)dr[q].meta;
             const double sv = dr[q].meta == REC_NONE ? 0.0 : dr[q].s;
             const bool un = (meta & DM_UNARY) != 0;
-            const int role = meta & 3;
             const int o0 = (un || dr[q].o0 == REC_NONE) ? ZROW : (int)dr[q].o0;
             const int o1 = (un || dr[q].o1 == REC_NONE) ? ZROW : (int)dr[q].o1;
             const int o2 = (un || dr[q].o2 == REC_NONE) ? ZROW : (int)dr[q].o2;
-            const double so = damper_sign(role);
-            const double g0 = damper_sign(role == 0 ? 1 : 0), g1 = damper_sign(role <= 1 ? 2 : 1), g2 = damper_sign(role <= 2 ? 3 : 2);
-            const double s0 = so * ul[0] + g0 * lu[3 * o0] + g1 * lu[3 * o1] + g2 * lu[3 * o2];
-            const double s1 = so * ul[1] + g0 * lu[3 * o0 + 1] + g1 * lu[3 * o1 + 1] + g2 * lu[3 * o2 + 1];
-            const double s2 = so * ul[2] + g0 * lu[3 * o0 + 2] + g1 * lu[3 * o1 + 2] + g2 * lu[3 * o2 + 2];
-            const double c = so * sv;
-            a0 += c * s0; a1 += c * s1; a2 += c * s2;
+            // the others come in canonical order (engine_create): a_i += s ((u_i - u[o1]) - (u[o0] - u[o2])) for every role
+            const double g0 = (ul[0] - lu[3 * o1]) - (lu[3 * o0] - lu[3 * o2]);
+            const double g1 = (ul[1] - lu[3 * o1 + 1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
+            const double g2 = (ul[2] - lu[3 * o1 + 2]) - (lu[3 * o0 + 2] - lu[3 * o2 + 2]);
+            a0 += sv * g0; a1 += sv * g1; a2 += sv * g2;
         }
     };
     for (int base = sbeg; base < send; base += 128 * U) {          // wave-uniform trip count
@@ -1075,17 +1072,18 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
                 a0 += dr[q].s * ul[0]; a1 += dr[q].s * ul[1]; a2 += dr[q].s * ul[2];
                 continue;
             }
-            const int role = dr[q].meta & 3;
+            // canonical order of the others: a_i += s ((u_i - u[o1]) - (u[o0] - u[o2])), absent vertices are zeros
             const uint16_t o[3] = {dr[q].o0, dr[q].o1, dr[q].o2};
-            const double so = damper_sign(role);
-            double s0 = so * ul[0], s1 = so * ul[1], s2 = so * ul[2];
+            double v[3][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double sg = damper_sign(k + (k >= role ? 1 : 0));
-                if (o[k] != REC_NONE) { s0 += sg * lu[3 * o[k]]; s1 += sg * lu[3 * o[k] + 1]; s2 += sg * lu[3 * o[k] + 2]; }
+                const bool has = o[k] != REC_NONE;
+                v[k][0] = has ? lu[3 * o[k]] : 0.0; v[k][1] = has ? lu[3 * o[k] + 1] : 0.0; v[k][2] = has ? lu[3 * o[k] + 2] : 0.0;
             }
-            const double c = so * dr[q].s;
-            a0 += c * s0; a1 += c * s1; a2 += c * s2;
+            const double sv = dr[q].s;
+            a0 += sv * ((ul[0] - v[1][0]) - (v[0][0] - v[2][0]));
+            a1 += sv * ((ul[1] - v[1][1]) - (v[0][1] - v[2][1]));
+            a2 += sv * ((ul[2] - v[1][2]) - (v[0][2] - v[2][2]));
         }
     }
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);

@@ -694,9 +694,15 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             e->h_d_om.resize(nnz_d);
             for (size_t i = 0; i < nnz_d; ++i) e->h_d_om[i] = D_role[i] < 0 ? (uint32_t)REC_NONE : u16(L_d[3 * i + (D_role[i] < 2 ? 0 : 2)]);
         } else {
+            // canonical order of the three other vertices, so that every role evaluates the same expression
+            //   g = (v_i - v[o1]) - (v[o0] - v[o2])   (= sg_i * sum_k sg_k v_k; absent vertices read zeros):
+            // o0 = the partner in the same keyframe, o1 = the own temporal partner, o2 = the partner's temporal partner
+            static const int perm[4][3] = {{0, 1, 2}, {0, 2, 1}, {2, 0, 1}, {2, 1, 0}};    // indices into the others in ascending role order
             e->h_d_hdr.resize(nnz_d);
-            for (size_t i = 0; i < nnz_d; ++i)
-                e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i]) | (u16(L_d[3 * i + 1]) << 16), u16(L_d[3 * i + 2]) | ((uint32_t)REC_NONE << 16));
+            for (size_t i = 0; i < nnz_d; ++i) {
+                const int* pm = perm[D_role[i] < 0 ? 0 : D_role[i]];
+                e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i + pm[0]]) | (u16(L_d[3 * i + pm[1]]) << 16), u16(L_d[3 * i + pm[2]]) | ((uint32_t)REC_NONE << 16));
+            }
         }
     } else {
         d_o0.resize(nnz_d); d_o1.resize(nnz_d); d_o2.resize(nnz_d);
