@@ -39,3 +39,24 @@ def ctx_exact():
     c = nrs.Context(exact_trials=1)
     yield c
     c.close()
+
+
+def compare_lm_traces(dev, ora, rounds, rtol=1e-6, noise=3e-7):
+    """Every LM trial of every round against the oracle's, up to the point where the oracle's own decision sits on the
+    fp32-projection noise floor: a trial whose chi2 change is below `noise` * chi2 is decided by the last bits of 4.5k
+    float projections, and from there on the two traces may legitimately part (OPT:103,338: the rounds restart from
+    stored states, so a later round is compared again from its first trial).  Returns the number of trials compared."""
+    n = 0
+    for rnd in range(rounds):
+        a = [x for x in dev if x["round"] == rnd]
+        b = ora[rnd] if isinstance(ora, list) and ora and isinstance(ora[0], list) else [x for x in ora if x.get("round") == rnd]
+        assert len(b) > 0
+        for i, y in enumerate(b):
+            if abs(y["chi"] - y["chi_new"]) <= noise * abs(y["chi"]):
+                break
+            assert i < len(a), "the device ran fewer trials than the oracle in round %d" % rnd
+            x = a[i]
+            assert x["accepted"] == y["accepted"], (rnd, i, x, y)
+            assert abs(x["chi"] - y["chi"]) <= rtol * abs(y["chi"]) + 1e-9 and abs(x["lam"] - y["lam"]) <= rtol * abs(y["lam"]), (rnd, i, x, y)
+            n += 1
+    return n

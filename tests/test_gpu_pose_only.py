@@ -36,14 +36,9 @@ def test_pose_only_matches_oracle_pinhole(ctx, n, seed):
     assert np.allclose(q, q2, atol=1e-6, rtol=0)
     assert np.allclose(t, t2, atol=1e-5, rtol=0)
     assert np.array_equal(inl, inl2)
-    # the first trials of every round are far above the fp32 noise floor: they must agree exactly
-    for rnd in range(3):
-        a = [x for x in tr if x["round"] == rnd][:3]
-        b = [x for x in otr if x["round"] == rnd][:3]
-        assert [x["accepted"] for x in a] == [x["accepted"] for x in b]
-        for x, y in zip(a, b):
-            assert abs(x["chi"] - y["chi"]) <= 1e-6 * abs(y["chi"])
-            assert abs(x["lam"] - y["lam"]) <= 1e-6 * abs(y["lam"])
+    # every trial of every round until the oracle's own decision sits on the fp32 noise floor (tests/conftest.py)
+    from conftest import compare_lm_traces
+    assert compare_lm_traces(tr, otr, 3) >= 9
 
 
 def test_pose_only_kb8(ctx):

@@ -96,15 +96,9 @@ def test_track_deform_matches_oracle(ctx, n, seed):
     assert abs(r["median"] - o["median"]) < 1e-5
     assert np.array_equal(r["graph"]["e_status"], o["graph"]["e_status"])
     assert np.allclose(r["graph"]["e_w"], o["graph"]["e_w"], atol=1e-5)
-    # the leading trials of every round are well above the noise floor: identical decisions
-    for rnd in range(3):
-        a = [x for x in tr if x["round"] == rnd][:3]
-        b = otr[rnd][:3]
-        assert len(a) == len(b) and len(a) > 0
-        assert [x["accepted"] for x in a] == [x["accepted"] for x in b]
-        for x, y in zip(a, b):
-            assert abs(x["chi"] - y["chi"]) <= 1e-6 * abs(y["chi"]) + 1e-9
-            assert abs(x["lam"] - y["lam"]) <= 1e-6 * abs(y["lam"])
+    # every trial of every round until the oracle's own decision sits on the fp32 noise floor (tests/conftest.py)
+    from conftest import compare_lm_traces
+    assert compare_lm_traces(tr, otr, 3) >= 9
 
 
 def test_track_deform_kb8(ctx):
