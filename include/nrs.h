@@ -262,8 +262,9 @@ int nrs_graph_update(nrs_ctx* ctx, nrs_graph* g, const float* pos, int32_t n_ids
  *                         pos[new]; all-pairs initialisation: new = other = every initial point
  *   nrs_rgraph_update     UpdateVertex :130-146 for the listed points; good_count[i] = its return value
  *   nrs_rgraph_get_edges  GetEdges :71-87 for the listed points: (status asc, weight desc, index asc), cut at the first
- *                         weight below min_weight; fixed-stride outputs [n_ids][cap_per_point] + count[n_ids];
- *                         NRS_ERR_INVALID if a point has more than cap_per_point entries
+ *                         weight below min_weight; fixed-stride outputs [n_ids][cap_per_point] + count[n_ids] = the
+ *                         FULL length of the list, of which the first min(count, cap_per_point) entries are written
+ *                         (the reference's callers walk a prefix: 11 accepted neighbours or the first BAD edge)
  *   nrs_rgraph_edge       GetEdge :57-59 (out = weight, first, max, min distance; status -1 = no such edge)
  * pos is capacity x 3 floats (positions by point index; rows of unlisted points are not read). */
 typedef struct nrs_rgraph nrs_rgraph;
@@ -310,6 +311,16 @@ int nrs_track_deform_solve(nrs_ctx* ctx, const nrs_camera* cam, nrs_graph* g, fl
                            int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
                            float* f_pos, double pose_qt[7], float scale, float* deform_median,
                            int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
+
+/* The same function with the RegularizationGraph held on the device at the reference's all-pairs density (nrs_rgraph,
+ * above): GetEdges (OPT:252, 496) and UpdateVertex (OPT:468) are served from it, so a point's good-connection count is
+ * taken over all of its N - 1 connections as in the reference (the "fewer than 5 -> BAD" rule, OPT:470-473).
+ * n_points = the graph's capacity = rows of map_pos; cap_per_point = how much of each point's GetEdges list is fetched
+ * (NRS_ERR_INVALID if the walk of OPT:255-279 reaches the end of a truncated list). */
+int nrs_track_deform_solve_rg(nrs_ctx* ctx, const nrs_camera* cam, nrs_rgraph* g, int32_t n_points, int32_t cap_per_point,
+                              float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                              float* f_pos, double pose_qt[7], float scale, float* deform_median, int32_t* n_lost,
+                              int32_t* lost, nrs_lm_trace* trace);
 
 /* ---- a21-a23: LucasKanadeTracker (modules/matching/lucas_kanade_tracker.{h,cc}) ----------------
  * The context holds what the reference's tracker object holds: the reference points and, per point

@@ -14,8 +14,9 @@
 //   add_edges : one thread per (new, other) pair                               O(1) per pair, coalesced rows
 //   update    : one workgroup sweep per listed vertex over its row/column      O(deg), good_count by block reduction
 //   get_edges : one wave per listed vertex: one pass finds the status class at which GetEdges' "break at the first
-//               weight < min_weight" falls and compacts the surviving entries (they all lie within 1.5 sigma: a few
-//               dozen), which are then rank-sorted by (status, -weight, index)  O(deg) + O(k^2 / 64)
+//               weight < min_weight" falls and compacts the surviving entries (they all lie within 1.5 sigma), which are
+//               rank-sorted by (status, -weight, index) when they are a few hundred, O(deg) + O(k^2 / 64), or extracted
+//               in key order for the first cap_per_point of them when sigma covers most of the map
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -138,31 +139,62 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
     for (int off = 32; off > 0; off >>= 1) s_star = min(s_star, __shfl_xor(s_star, off, 64));
     const int n = n_cand;
     if (n > cand_cap) { if (lane == 0) atomicMax(overflow, n); return; }
-    // rank sort of the survivors (status <= s*), key (status asc, weight desc, index asc)
+    // the survivors (status <= s*) in the order (status asc, weight desc, index asc); only the first out_cap are
+    // written (callers walk a prefix: OPT:255-279 stops after 11 accepted neighbours or at the first BAD edge),
+    // o_count is the full length
     int n_out = 0;
-    for (int a0 = 0; a0 < n; a0 += 64) {
-        const int a = a0 + lane;
-        if (a < n && cand[a].s <= s_star) {
-            const RgCand ca = cand[a];
-            int rank = 0;
-            for (int b = 0; b < n; ++b) {
-                const RgCand cb = cand[b];
-                if (cb.s > s_star) continue;
-                const bool before = (cb.s != ca.s) ? (cb.s < ca.s) : ((cb.w != ca.w) ? (cb.w > ca.w) : (cb.j < ca.j));
-                rank += before ? 1 : 0;
+    for (int a = lane; a < n; a += 64) n_out += cand[a].s <= s_star ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
+    if (n <= 384) {
+        // short lists: rank sort, O(n^2 / 64)
+        for (int a0 = 0; a0 < n; a0 += 64) {
+            const int a = a0 + lane;
+            if (a < n && cand[a].s <= s_star) {
+                const RgCand ca = cand[a];
+                int rank = 0;
+                for (int b = 0; b < n; ++b) {
+                    const RgCand cb = cand[b];
+                    if (cb.s > s_star) continue;
+                    const bool before = (cb.s != ca.s) ? (cb.s < ca.s) : ((cb.w != ca.w) ? (cb.w > ca.w) : (cb.j < ca.j));
+                    rank += before ? 1 : 0;
+                }
+                if (rank < out_cap) {
+                    const size_t o = (size_t)r * out_cap + rank;
+                    o_col[o] = ca.j; o_w[o] = ca.w; o_st[o] = ca.s; o_d0[o] = d0[rg_at(i, ca.j, cap)];
+                }
             }
-            if (rank < out_cap) {
-                const size_t o = (size_t)r * out_cap + rank;
-                o_col[o] = ca.j; o_w[o] = ca.w; o_st[o] = ca.s; o_d0[o] = d0[rg_at(i, ca.j, cap)];
+        }
+    } else {
+        // long lists (a sigma that covers most of the map): extract the next entry in key order, min(n_out, out_cap) times
+        int ls = -1, lj = -1;
+        float lw = 0.f;
+        const int rounds = min(n_out, out_cap);
+        for (int k = 0; k < rounds; ++k) {
+            int bs = 0x7fffffff, bj = 0x7fffffff, ba = -1;
+            float bw = 0.f;
+            for (int a = lane; a < n; a += 64) {
+                const RgCand ca = cand[a];
+                if (ca.s > s_star) continue;
+                const bool after = ls < 0 || ((ca.s != ls) ? (ca.s > ls) : ((ca.w != lw) ? (ca.w < lw) : (ca.j > lj)));
+                if (!after) continue;
+                const bool better = ba < 0 || ((ca.s != bs) ? (ca.s < bs) : ((ca.w != bw) ? (ca.w > bw) : (ca.j < bj)));
+                if (better) { bs = ca.s; bw = ca.w; bj = ca.j; ba = a; }
             }
-            ++n_out;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int os = __shfl_xor(bs, off, 64), oj = __shfl_xor(bj, off, 64), oa = __shfl_xor(ba, off, 64);
+                const float ow = __shfl_xor(bw, off, 64);
+                const bool better = oa >= 0 && (ba < 0 || ((os != bs) ? (os < bs) : ((ow != bw) ? (ow > bw) : (oj < bj))));
+                if (better) { bs = os; bw = ow; bj = oj; ba = oa; }
+            }
+            if (lane == 0) {
+                const size_t o = (size_t)r * out_cap + k;
+                o_col[o] = bj; o_w[o] = bw; o_st[o] = bs; o_d0[o] = d0[rg_at(i, bj, cap)];
+            }
+            ls = bs; lw = bw; lj = bj;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
-    if (lane == 0) {
-        o_count[r] = n_out;
-        if (n_out > out_cap) atomicMax(overflow, n_out);
-    }
+    if (lane == 0) o_count[r] = n_out;
 }
 
 __global__ void k_rg_fill(uint8_t* st, size_t n) {
@@ -301,8 +333,9 @@ extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t*
     float* d_d0 = d_w + no;
     NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
-    const int cand_cap = std::max(256, std::min(4096, 4 * cap_per_point));
+    const int cand_cap = std::min(g->cap, 12000);                 // every connection of a row may pass (a sigma that covers the map): 12 B each
     const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
+    NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(RgCand) * (size_t)cand_cap)));
     hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), sizeof(RgCand) * (size_t)cand_cap, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
                        g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
     NRS_HIP(c, hipGetLastError());
@@ -314,7 +347,7 @@ extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t*
     NRS_HIP(c, hipMemcpyAsync(w, d_w, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipMemcpyAsync(d0, d_d0, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
-    if (ovf > 0) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight; cap_per_point = %d is too small", ovf, cap_per_point);
+    if (ovf > 0) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight: more than this build stages per row (%d)", ovf, cand_cap);
     return NRS_OK;
 }
 

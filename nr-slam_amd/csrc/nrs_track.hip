@@ -201,6 +201,57 @@ static int graph_update(nrs_ctx* c, GraphDevice& G, nrs_graph* g, const float* p
     return NRS_OK;
 }
 
+// Where a2 gets RegularizationGraph::GetEdges / UpdateVertex from: the host-owned flat graph (nrs_graph) or the
+// device-resident dense one (nrs_rgraph: the reference's all-pairs density).
+struct NeighbourSource {
+    int n_points = 0;
+    virtual ~NeighbourSource() {}
+    // GetEdges of every map point, in the reference's order: CSR of (other, weight, first_distance, status)
+    virtual int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) = 0;
+    // UpdateVertex of the listed points from the last world positions; good[i] = its return value
+    virtual int update(const float* map_pos, int n, const int* ids, int* good) = 0;
+    std::vector<char> truncated;      // per point: select() returned only a prefix of its list
+};
+
+struct FlatSource : NeighbourSource {
+    nrs_ctx* c; nrs_graph* g; GraphDevice G;
+    int init() { n_points = g->n_points; return graph_upload(c, G, g); }
+    int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) override {
+        std::vector<int> eid;
+        NRS_TRY(graph_select(c, G, g->sigma, rp, col, eid));
+        w.resize(eid.size()); d0.resize(eid.size()); st.resize(eid.size());
+        for (size_t a = 0; a < eid.size(); ++a) { w[a] = g->e_w[eid[a]]; d0[a] = g->e_d0[eid[a]]; st[a] = g->e_status[eid[a]]; }
+        return NRS_OK;
+    }
+    int update(const float* map_pos, int n, const int* ids, int* good) override { return graph_update(c, G, g, map_pos, n, ids, good); }
+};
+
+struct DenseSource : NeighbourSource {
+    nrs_ctx* c; nrs_rgraph* g; int cap;
+    int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) override {
+        const size_t n = (size_t)n_points, no = n * (size_t)cap;
+        std::vector<int> ids(n), cnt(n), fc(no), fs(no);
+        std::vector<float> fw(no), fd(no);
+        for (size_t i = 0; i < n; ++i) ids[i] = (int)i;
+        NRS_TRY(nrs_rgraph_get_edges(g, (int32_t)n, ids.data(), cap, cnt.data(), fc.data(), fw.data(), fd.data(), fs.data()));
+        rp.assign(n + 1, 0);
+        truncated.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) { truncated[i] = cnt[i] > cap; cnt[i] = std::min(cnt[i], cap); rp[i + 1] = rp[i] + cnt[i]; }
+        col.resize(rp[n]); w.resize(rp[n]); d0.resize(rp[n]); st.resize(rp[n]);
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < cnt[i]; ++k) {
+                const size_t a = (size_t)rp[i] + k, b = i * (size_t)cap + k;
+                col[a] = fc[b]; w[a] = fw[b]; d0[a] = fd[b]; st[a] = fs[b];
+            }
+        return NRS_OK;
+    }
+    int update(const float* map_pos, int n, const int* ids, int* good) override { return n ? nrs_rgraph_update(g, map_pos, n, ids, good) : NRS_OK; }
+};
+
+static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
+                      int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
+                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
+
 }  // namespace nrs
 
 using namespace nrs;
@@ -244,10 +295,36 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
     if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
     NRS_TRY(graph_validate(c, g));
     NRS_HIP(c, hipSetDevice(c->device));
+    FlatSource src;
+    src.c = c; src.g = g;
+    NRS_TRY(src.init());
+    return track_core(c, cam, src, map_pos, n_f, f_map, f_status, f_uv, f_pos, pose_qt, scale, deform_median, n_lost, lost, trace);
+}
+
+// The same function on the device-resident dense graph (include/nrs.h): GetEdges / UpdateVertex see all N - 1
+// connections of a point, as in the reference.
+extern "C" int nrs_track_deform_solve_rg(nrs_ctx* c, const nrs_camera* cam, nrs_rgraph* g, int32_t n_points, int32_t cap_per_point,
+                                         float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                                         float* f_pos, double pose_qt[7], float scale, float* deform_median, int32_t* n_lost,
+                                         int32_t* lost, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!cam || !g || !map_pos || n_points <= 0 || cap_per_point <= 0 || n_f < 0 || !pose_qt || !n_lost || (n_f > 0 && (!f_map || !f_status || !f_uv || !f_pos)))
+        return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve_rg: bad argument");
+    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    NRS_HIP(c, hipSetDevice(c->device));
+    DenseSource src;
+    src.c = c; src.g = g; src.cap = cap_per_point; src.n_points = n_points;
+    return track_core(c, cam, src, map_pos, n_f, f_map, f_status, f_uv, f_pos, pose_qt, scale, deform_median, n_lost, lost, trace);
+}
+
+namespace nrs {
+static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
+                      int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
+                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace) {
     if (trace) { trace->count = 0; trace->iterations = 0; }
     *n_lost = 0;
     if (deform_median) *deform_median = 0.f;
-    const int n_map = g->n_points;
+    const int n_map = src.n_points;
     std::vector<int> map_to_frame(n_map, -1);
     for (int i = 0; i < n_f; ++i) {
         if (f_map[i] >= n_map) return c->fail(NRS_ERR_INVALID, "f_map out of range");
@@ -262,10 +339,9 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
     std::vector<int> id_to_idx(n_map, -1);
     for (int i = 0; i < N; ++i) id_to_idx[ids[i]] = i;
 
-    GraphDevice G;
-    NRS_TRY(graph_upload(c, G, g));
-    std::vector<int> orp, ocol, oeid;
-    NRS_TRY(graph_select(c, G, g->sigma, orp, ocol, oeid));
+    std::vector<int> orp, ocol, ost;
+    std::vector<float> ow, od0;
+    NRS_TRY(src.select(orp, ocol, ow, od0, ost));
 
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
@@ -275,9 +351,10 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
     for (int idx = 0; idx < N; ++idx) {
         const int p = ids[idx];
         int n_reg = 0;
+        bool ended = false;
         for (int a = orp[p]; a < orp[p + 1]; ++a) {
-            const int e = oeid[a], other = ocol[a];
-            if (n_reg > 10 || g->e_status[e] == NRS_GRAPH_BAD) break;
+            const int other = ocol[a];
+            if (n_reg > 10 || ost[a] == NRS_GRAPH_BAD) { ended = true; break; }
             const int fo = map_to_frame[other];
             if (fo < 0 || f_status[fo] != NRS_TRACKED_WITH_3D) {
                 if (fo >= 0 && f_status[fo] != NRS_JUST_TRIANGULATED) lost_set.insert(other);
@@ -289,13 +366,15 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
             if (dup) continue;
             const int k = (int)dm_w.size();
             dm_idx.insert(dm_idx.end(), {-1, -1, idx, io});      // r = w (delta_idx - delta_io)
-            dm_w.push_back(g->e_w[e]);
+            dm_w.push_back(ow[a]);
             sp_ij.insert(sp_ij.end(), {idx, io});
-            sp_d0.push_back(g->e_d0[e]);
+            sp_d0.push_back(od0[a]);
             reg[idx].push_back({io, k});
             reg[io].push_back({idx, k});
             ++n_reg;
         }
+        if (!ended && !src.truncated.empty() && src.truncated[p])
+            return c->fail(NRS_ERR_INVALID, "cap_per_point is too small: the neighbour walk of map point %d ran off its truncated list", p);
     }
     const int E = (int)dm_w.size();
 
@@ -384,14 +463,14 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
         for (int idx = 0; idx < N; ++idx)
             if (inl[idx]) { upd_ids.push_back(ids[idx]); upd_idx.push_back(idx); }
         std::vector<int> good(upd_ids.size());
-        NRS_TRY(graph_update(c, G, g, map_pos, (int)upd_ids.size(), upd_ids.data(), good.data()));
+        NRS_TRY(src.update(map_pos, (int)upd_ids.size(), upd_ids.data(), good.data()));
         for (size_t i = 0; i < upd_ids.size(); ++i)
             if (good[i] < 10 * 0.5) f_status[opt_f[upd_idx[i]]] = NRS_BAD;
     }
     if (lost_set.empty()) return NRS_OK;
 
     // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
-    NRS_TRY(graph_select(c, G, g->sigma, orp, ocol, oeid));       // GetEdges sees the updated graph
+    NRS_TRY(src.select(orp, ocol, ow, od0, ost));                 // GetEdges sees the updated graph
     std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
     const int L = (int)lost_ids.size();
     std::vector<int> un_ij;
@@ -399,14 +478,17 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
     for (int li = 0; li < L; ++li) {
         const int p = lost_ids[li];
         int n_reg = 0;
+        bool ended = false;
         for (int a = orp[p]; a < orp[p + 1]; ++a) {
-            if (n_reg > 10) break;
+            if (n_reg > 10) { ended = true; break; }
             const int io = id_to_idx[ocol[a]];
             if (io < 0) continue;
             un_ij.insert(un_ij.end(), {N + li, io});
-            un_w.push_back(g->e_w[oeid[a]]);
+            un_w.push_back(ow[a]);
             ++n_reg;
         }
+        if (!ended && !src.truncated.empty() && src.truncated[p])
+            return c->fail(NRS_ERR_INVALID, "cap_per_point is too small: the neighbour walk of lost map point %d ran off its truncated list", p);
     }
     const int M2 = N + L;
     std::vector<double> x2(3 * (size_t)M2, 0.0), X02(3 * (size_t)M2, 0.0);
@@ -442,3 +524,4 @@ extern "C" int nrs_track_deform_solve(nrs_ctx* c, const nrs_camera* cam, nrs_gra
     *n_lost = L;
     return NRS_OK;
 }
+}  // namespace nrs

@@ -29,7 +29,7 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
            "nrs_rgraph_create", "nrs_rgraph_destroy", "nrs_rgraph_set_sigma", "nrs_rgraph_min_weight", "nrs_rgraph_add_edges",
-           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch"]
+           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch", "nrs_track_deform_solve_rg"]
 
 
 class NrsError(RuntimeError):
@@ -417,6 +417,22 @@ class Context:
             C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     graph=ga.as_dict(g), median=float(med.value), lost=lost[:n_lost.value].tolist())
+
+    def track_deform_solve_rg(self, cam, rg, map_pos, f_map, f_status, f_uv, f_pos, pose_q, pose_t, scale, trace=None, cap_per_point=128):
+        """a2 on the device-resident dense graph `rg` (nrs.RGraph of this context); the graph is updated in place"""
+        map_pos = _f32(map_pos).reshape(-1, 3).copy()
+        assert len(map_pos) == rg.cap
+        f_map, f_status = _i32(f_map), _i32(f_status).copy()
+        f_uv, f_pos = _f32(f_uv).reshape(-1, 2), _f32(f_pos).reshape(-1, 3).copy()
+        qt = np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)])
+        med, n_lost = C.c_float(0), C.c_int32(0)
+        lost = np.zeros(len(map_pos), np.int32)
+        self._chk(self.lib.nrs_track_deform_solve_rg(
+            self.h, C.byref(cam), rg.h, C.c_int32(rg.cap), C.c_int32(cap_per_point), _p(map_pos, C.c_float), C.c_int32(len(f_map)),
+            _p(f_map, C.c_int32), _p(f_status, C.c_int32), _p(f_uv, C.c_float), _p(f_pos, C.c_float), _p(qt, C.c_double), C.c_float(scale),
+            C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
+        return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
+                    median=float(med.value), lost=lost[:n_lost.value].tolist())
 
     # ---- a21-a23
     def klt_configure(self, win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4):

@@ -849,7 +849,24 @@ def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv
                        scale, trace=None, solver=solve_spd):
     """Flat restatement.  graph / map_pos / f_status / f_pos are copied, the updated copies are
     returned.  f_map[i] = map-point index of frame landmark i (-1: none)."""
-    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+    if isinstance(graph, dict):
+        g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+
+        def get_edges_of(p):                       # GetEdges: (other, weight, first_distance, status) in the reference's order
+            return [(o, g["e_w"][e], g["e_d0"][e], g["e_status"][e]) for o, e in graph_get_edges(g, p)]
+
+        def update_vertex_of(p, pos):
+            return graph_update_vertex_flat(g, p, pos)
+    else:
+        # a dense all-pairs graph object (oracle/rgraph_oracle.DenseGraph): updated IN PLACE, the caller passes a copy
+        g = graph
+
+        def get_edges_of(p):
+            js, w, d0, st = g.get_edges(p)
+            return list(zip(js.tolist(), w, d0, st.tolist()))
+
+        def update_vertex_of(p, pos):
+            return g.update_vertex(pos, p)
     map_pos = np.array(map_pos, F32)
     f_status = np.array(f_status, np.int32)
     f_pos = np.array(f_pos, F32)
@@ -874,8 +891,8 @@ def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv
     lost = set()
     for idx in range(N):
         n_reg = 0
-        for other, e in graph_get_edges(g, int(ids[idx])):
-            if n_reg > REGULARIZERS_PER_POINT or g["e_status"][e] == GRAPH_BAD:
+        for other, e_w, e_d0, e_st in get_edges_of(int(ids[idx])):
+            if n_reg > REGULARIZERS_PER_POINT or e_st == GRAPH_BAD:
                 break
             fo = map_to_frame[other]
             if fo < 0 or f_status[fo] != TRACKED_WITH_3D:
@@ -886,7 +903,7 @@ def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv
             if io in reg[idx]:
                 continue
             k = len(dm_i)
-            dm_i.append(idx); dm_j.append(io); dm_w.append(g["e_w"][e]); sp_d0.append(g["e_d0"][e])
+            dm_i.append(idx); dm_j.append(io); dm_w.append(e_w); sp_d0.append(e_d0)
             reg[idx][io] = k
             reg[io][idx] = k
             n_reg += 1
@@ -946,7 +963,7 @@ def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv
     for idx in range(N):
         if not inl[idx]:
             continue
-        good = graph_update_vertex_flat(g, int(ids[idx]), map_pos)
+        good = update_vertex_of(int(ids[idx]), map_pos)
         if good < REGULARIZERS_PER_POINT * 0.5:
             f_status[opt_f[idx]] = BAD
     res = dict(pose_q=pose_q_out, pose_t=pose_t_out, f_pos=f_pos, f_status=f_status, map_pos=map_pos, graph=g,
@@ -962,12 +979,12 @@ def track_deform_solve(cam_model, cam_prm, graph, map_pos, f_map, f_status, f_uv
     ui, uj, uw = [], [], []
     for li, lid in enumerate(lost_sorted):
         n_reg = 0
-        for other, e in graph_get_edges(g, lid):
+        for other, e_w, e_d0, e_st in get_edges_of(lid):
             if n_reg > 10:
                 break
             if id_to_idx[other] < 0:
                 continue
-            ui.append(N + li); uj.append(int(id_to_idx[other])); uw.append(g["e_w"][e])
+            ui.append(N + li); uj.append(int(id_to_idx[other])); uw.append(e_w)
             n_reg += 1
     G.groups.append(DamperFixedEdges(ui, uj, np.asarray(uw, F32).astype(np.float64), info_sp, TH3))
     G.pose_fixed[0] = True
