@@ -355,6 +355,50 @@ def rgraph_bench(n=5000):
     return out
 
 
+def skinned_bench(n=5000, m=500, n_kf=20):
+    """N2, the metric's "5k pts x 500 graph nodes" read as the skinned mode (include/nrs.h): m farthest-point nodes carry the
+    free variables, the other tracked points follow them through the reference's stage 2 (OPT:476-553).  (i) one frame of
+    CameraPoseAndDeformationOptimization on the device-resident all-pairs graph of the n points, (ii) the local BA window
+    over the m nodes x n_kf keyframes.  The default bench line is the parity mode (every point a node)."""
+    import nrs
+    import nrs_synth as S
+    tp = S.make_tracking_problem(n, 3)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    ctx = nrs.Context()
+    fm = np.arange(n, dtype=np.int32)
+    t0 = time.perf_counter()
+    nodes = ctx.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0)
+    t_sel = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nodes = ctx.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0)
+    t_sel = min(t_sel, time.perf_counter() - t0)
+    st = nrs.skinned_status(tp["status"], fm, nodes)
+    g = nrs.RGraph(ctx, n, tp["graph"]["sigma"], tp["graph"]["stretch_th"])
+    g.add_edges(tp["X_prev"], fm, fm)
+    ms, r = [], None
+    for rep in range(4):
+        g.add_edges(tp["X_prev"], fm, fm)                           # the graph as it was before the frame
+        tr = nrs.Trace(1024)
+        t0 = time.perf_counter()
+        r = ctx.track_deform_solve_rg(cam, g, tp["X_prev"], fm, st, tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr, 512)
+        ms.append(1e3 * (time.perf_counter() - t0))
+    out = dict(points=n, nodes=m, tracked_points=int((tp["status"] == 0).sum()), ms_select_nodes=1e3 * t_sel,
+               ms_pose_and_deformation=float(np.median(ms[1:])), skinned_points=len(r["lost"]),
+               lm_trials=len(tr.trials), pcg_iters=int(sum(x["inner"] for x in tr.trials)))
+    g.close()
+    # the BA window over the nodes
+    p = S.make_dba_problem(m, n_kf, 11, 0)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    camw = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ctx.dba_upload(camw, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    rr = timed_steps(ctx, 20, 3, lambda: None)
+    out["ba_window"] = dict(nodes=m, keyframes=n_kf, landmarks=int(len(p["lm_kf"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
+                            ms_per_step=1e3 * rr["dt"] / 20)
+    ctx.close()
+    return out
+
+
 def triangulation_bench():
     """f2: every triangulation candidate of a frame in one call (21 buffered snapshots, host buffers in, points out),
     next to the NumPy restatement (oracle/triang_oracle.py, 1 core) on the first 10 candidates."""
@@ -500,6 +544,7 @@ def main():
         out["shi_extract"] = shi_extract_bench()
         out["graph_dense"] = rgraph_bench()
         out["triangulation"] = triangulation_bench()
+        out["skinned"] = skinned_bench()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
         xctx.close()

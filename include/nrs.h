@@ -369,6 +369,17 @@ int nrs_klt_get_templates(nrs_ctx* ctx, int32_t first, int32_t count, float* xy,
 int nrs_klt_insert_templates(nrs_ctx* ctx, int32_t count, const float* xy, const int16_t* gray,
                              const int16_t* grad, const float* mean, const uint8_t* valid);
 
+/* ---- N2: the skinned mode ("5k points x 500 graph nodes") --------------------------------------------------------
+ * The reference has no separate node set; its skinning is stage 2 of CameraPoseAndDeformationOptimization
+ * (modules/optimization/g2o_optimization.cc:476-553, spatial_regularizer_fixed.cc:32-43): points of the frame that are not
+ * optimised follow <= 11 optimised graph neighbours.  Skinned mode = that algorithm with a chosen node set: the nodes
+ * keep NRS_TRACKED_WITH_3D, every other point of the frame is handed over as NRS_TRACKED (in the frame, no 3D), and
+ * nrs_track_deform_solve / nrs_track_deform_solve_rg run unchanged.  This call chooses the nodes: farthest point
+ * sampling over the eligible points (eligible == NULL: all), first pick = lowest eligible index, fp32 squared distances,
+ * ties to the lowest index.  node_ids[n_nodes] in pick order.  NRS_ERR_INVALID if fewer points are eligible. */
+int nrs_skin_select_nodes(nrs_ctx* ctx, int32_t n_points, const float* pos /* n_points x 3 */, const uint8_t* eligible /* nullable */,
+                          int32_t n_nodes, int32_t* node_ids);
+
 #ifdef __cplusplus
 }
 #endif

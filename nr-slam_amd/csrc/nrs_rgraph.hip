@@ -30,6 +30,8 @@ struct nrs_rgraph {
     float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
     uint8_t* st = nullptr;
     nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good;
+    char* pin = nullptr;             // pinned staging area of the GetEdges results (page-faulting pageable targets cost more than the kernel)
+    size_t pin_cap = 0;
 };
 
 namespace nrs {
@@ -97,64 +99,108 @@ __global__ __launch_bounds__(256) void k_rg_update(int n_ids, const int* __restr
 // entries of s* at or above min_weight -- all of them at or above min_weight, ordered by (status, -weight, index).
 // (ties: ascending index, the build's documented choice where std::sort leaves the order open)
 struct RgCand { int j; float w; int s; };
+constexpr int RG_BINS = 256;     // weight histogram bins per status class (selection of the first out_cap entries)
+constexpr int RG_CLASSES = 4;    // NRS_GRAPH_VERIFIED .. NRS_GRAPH_BAD
+constexpr int RG_SLACK = 1024;   // candidates staged beyond out_cap (the population of the bin the cut falls into)
 
+// Only the first out_cap entries of the list are wanted (the callers walk a prefix), and with the reference's sigma most
+// of the N - 1 connections survive the min_weight cut.  So the row is read twice: pass 1 finds s* and a 256-bin histogram
+// of the surviving weights per status class, from which the (class, bin) at which the first out_cap entries end is
+// known; pass 2 stages only the entries up to that bin (<= out_cap + one bin's population) and those are put in order.
+// `select_all`: stage every survivor (the fallback when a bin holds more than RG_SLACK entries: many equal distances).
 __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __restrict__ ids, int cap, const float* __restrict__ maxd,
                                                      const float* __restrict__ d0, const uint8_t* __restrict__ st, float sigma,
-                                                     float min_w, float d_hi, int cand_cap, int out_cap, int* o_count, int* o_col,
-                                                     float* o_w, float* o_d0, int* o_st, int* overflow) {
+                                                     float min_w, float d_hi, int cand_cap, int out_cap, int select_all, int* o_count,
+                                                     int* o_col, float* o_w, float* o_d0, int* o_st, int* overflow) {
     extern __shared__ RgCand cand[];
-    __shared__ int n_cand;
+    __shared__ int hist[RG_CLASSES][RG_BINS];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= n_ids) return;
     const int i = ids[r];
-    if (lane == 0) n_cand = 0;
+    for (int q = lane; q < RG_CLASSES * RG_BINS; q += 64) (&hist[0][0])[q] = 0;
     __syncthreads();
-    int s_star = 255;                                         // lowest status class holding an entry below min_weight
+    const float bin_scale = (float)RG_BINS / (1.f - min_w);
+    auto entry = [&](int j, float& w, int& s) -> bool {         // does connection (i, j) survive the min_weight cut?
+        s = 255; w = 0.f;
+        if (j >= cap || j == i) return false;
+        const size_t k = rg_at(i, j, cap);
+        s = st[k];
+        if (s == RG_NONE) { s = 255; return false; }
+        const float mx = maxd[k];
+        // beyond d_hi = 1.5 sigma (1 + 1e-4) the weight is below min_weight for sure; inside, the exact value decides
+        if (mx <= d_hi) { w = rg_weight(mx, sigma); return !(w < min_w); }
+        return false;
+    };
+    auto bin_of = [&](float w) { return min(RG_BINS - 1, max(0, (int)((1.f - w) * bin_scale))); };   // monotone in -w
+    // ---- pass 1: s* (lowest status class holding an entry below min_weight) and the histograms
+    int s_star = 255;
     for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        bool keep = false;
-        float w = 0.f;
-        int s = 255;
-        if (j < cap && j != i) {
-            const size_t k = rg_at(i, j, cap);
-            s = st[k];
-            if (s != RG_NONE) {
-                const float mx = maxd[k];
-                // beyond d_hi = 1.5 sigma (1 + 1e-4) the weight is below min_weight for sure; inside, the exact value decides
-                if (mx <= d_hi) { w = rg_weight(mx, sigma); keep = !(w < min_w); }
-                if (!keep) s_star = min(s_star, s);
-            }
-        }
-        // wave-ordered compaction (ascending j inside the candidate list: not needed for the result, but deterministic)
-        const unsigned long long m = __ballot(keep);
-        const int base = n_cand;
-        if (keep) {
-            const int p = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (p < cand_cap) { cand[p].j = j; cand[p].w = w; cand[p].s = s; }
-        }
-        __syncthreads();
-        if (lane == 0) n_cand = base + __popcll(m);
-        __syncthreads();
+        float w; int s;
+        const bool keep = entry(j0 + lane, w, s);
+        if (!keep && s != 255) s_star = min(s_star, s);
+        if (keep) atomicAdd(&hist[min(s, RG_CLASSES - 1)][bin_of(w)], 1);
     }
     for (int off = 32; off > 0; off >>= 1) s_star = min(s_star, __shfl_xor(s_star, off, 64));
-    const int n = n_cand;
-    if (n > cand_cap) { if (lane == 0) atomicMax(overflow, n); return; }
+    __syncthreads();
+    // ---- where do the first out_cap entries end?  cut[c] = last bin of class c that is staged (-1: none)
+    int cut[RG_CLASSES];
+    int n_out = 0, taken = 0;
+#pragma unroll
+    for (int c = 0; c < RG_CLASSES; ++c) {
+        int loc[RG_BINS / 64], mine = 0;
+#pragma unroll
+        for (int q = 0; q < RG_BINS / 64; ++q) { loc[q] = hist[c][lane * (RG_BINS / 64) + q]; mine += loc[q]; }
+        int incl = mine;                                         // inclusive scan over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        const int total = __shfl(incl, 63, 64);
+        cut[c] = -1;
+        if (c > s_star || total == 0) continue;
+        n_out += total;
+        const int rem = out_cap - taken;
+        if (select_all || total <= rem) { cut[c] = RG_BINS - 1; taken += total; continue; }
+        if (rem <= 0) continue;
+        // first bin at which the running count reaches rem
+        int run = incl - mine, hit = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < RG_BINS / 64; ++q) { run += loc[q]; if (run >= rem && hit == 0x7fffffff) hit = lane * (RG_BINS / 64) + q; }
+        for (int off = 32; off > 0; off >>= 1) hit = min(hit, __shfl_xor(hit, off, 64));
+        cut[c] = hit;
+        taken = out_cap;
+    }
+    // ---- pass 2: stage the entries up to the cut (wave-ordered compaction; the counter is wave-uniform)
+    int n = 0;
+    for (int j0 = 0; j0 < cap; j0 += 64) {
+        float w; int s;
+        bool keep = entry(j0 + lane, w, s);
+        if (keep) {
+            const int c = min(s, RG_CLASSES - 1);
+            int cc = cut[0];
+#pragma unroll
+            for (int q = 1; q < RG_CLASSES; ++q) cc = c == q ? cut[q] : cc;
+            keep = s <= s_star && bin_of(w) <= cc;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int p = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (p < cand_cap) { cand[p].j = j0 + lane; cand[p].w = w; cand[p].s = s; }
+        }
+        n += __popcll(m);
+    }
+    __syncthreads();
+    if (n > cand_cap) { if (lane == 0) { atomicMax(overflow, n); o_count[r] = -1; } return; }
     // the survivors (status <= s*) in the order (status asc, weight desc, index asc); only the first out_cap are
     // written (callers walk a prefix: OPT:255-279 stops after 11 accepted neighbours or at the first BAD edge),
-    // o_count is the full length
-    int n_out = 0;
-    for (int a = lane; a < n; a += 64) n_out += cand[a].s <= s_star ? 1 : 0;
-    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
+    // o_count is the full length (n_out, from the histograms)
     if (n <= 384) {
         // short lists: rank sort, O(n^2 / 64)
         for (int a0 = 0; a0 < n; a0 += 64) {
             const int a = a0 + lane;
-            if (a < n && cand[a].s <= s_star) {
+            if (a < n) {
                 const RgCand ca = cand[a];
                 int rank = 0;
                 for (int b = 0; b < n; ++b) {
                     const RgCand cb = cand[b];
-                    if (cb.s > s_star) continue;
                     const bool before = (cb.s != ca.s) ? (cb.s < ca.s) : ((cb.w != ca.w) ? (cb.w > ca.w) : (cb.j < ca.j));
                     rank += before ? 1 : 0;
                 }
@@ -168,13 +214,12 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
         // long lists (a sigma that covers most of the map): extract the next entry in key order, min(n_out, out_cap) times
         int ls = -1, lj = -1;
         float lw = 0.f;
-        const int rounds = min(n_out, out_cap);
+        const int rounds = min(n, out_cap);
         for (int k = 0; k < rounds; ++k) {
             int bs = 0x7fffffff, bj = 0x7fffffff, ba = -1;
             float bw = 0.f;
             for (int a = lane; a < n; a += 64) {
                 const RgCand ca = cand[a];
-                if (ca.s > s_star) continue;
                 const bool after = ls < 0 || ((ca.s != ls) ? (ca.s > ls) : ((ca.w != lw) ? (ca.w < lw) : (ca.j > lj)));
                 if (!after) continue;
                 const bool better = ba < 0 || ((ca.s != bs) ? (ca.s < bs) : ((ca.w != bw) ? (ca.w > bw) : (ca.j < bj)));
@@ -249,6 +294,7 @@ extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
+    if (g->pin) (void)hipHostFree(g->pin);
     c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good);
     delete g;
 }
@@ -313,6 +359,58 @@ extern "C" int nrs_rgraph_update(nrs_rgraph* g, const float* pos, int32_t n_ids,
     return NRS_OK;
 }
 
+// GetEdges of the listed points into the graph's pinned staging area: count[n_ids] | col | status | weight | first distance
+// (each n_ids x cap_per_point).  nrs_rgraph_get_edges copies from there; the a2 driver reads it in place.
+namespace nrs {
+int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
+                        const int** status, const float** w, const float** d0) {
+    nrs_ctx* c = g->c;
+    NRS_HIP(c, hipSetDevice(c->device));
+    const size_t no = (size_t)n_ids * cap_per_point;
+    NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_ids));
+    NRS_TRY(c->ensure(g->out_i, sizeof(int) * (4 * no + (size_t)n_ids + 4)));
+    // one device block in the staging layout: count | col | status | weight | first distance | overflow word
+    int* d_cnt = g->out_i.as<int>();
+    int* d_col = d_cnt + n_ids;
+    int* d_st = d_col + no;
+    float* d_w = reinterpret_cast<float*>(d_st + no);
+    float* d_d0 = d_w + no;
+    int* d_ovf = reinterpret_cast<int*>(d_d0 + no);
+    const size_t bytes = sizeof(int) * (4 * no + (size_t)n_ids + 1);
+    if (bytes > g->pin_cap) {
+        if (g->pin) (void)hipHostFree(g->pin);
+        g->pin = nullptr; g->pin_cap = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipHostMalloc((void**)&g->pin, want, hipHostMallocDefault) != hipSuccess) return c->fail(NRS_ERR_ALLOC, "nrs_rgraph_get_edges: %zu bytes of pinned host memory", want);
+        g->pin_cap = want;
+    }
+    NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
+    const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
+    // first the selecting form (stages <= cap_per_point + one histogram bin per row); if a bin overflows the staging area
+    // (many equal distances), once more with every survivor of a row staged
+    int* h = reinterpret_cast<int*>(g->pin);
+    int cand_cap = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        cand_cap = pass == 0 ? std::min(g->cap, cap_per_point + RG_SLACK) : std::min(g->cap, 12000);
+        NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(RgCand) * (size_t)cand_cap)));
+        hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), sizeof(RgCand) * (size_t)cand_cap, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
+                           g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
+        NRS_HIP(c, hipGetLastError());
+        NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        if (h[4 * no + (size_t)n_ids] == 0) break;
+        if (pass == 1) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight: more than this build stages per row (%d)", h[4 * no + (size_t)n_ids], cand_cap);
+    }
+    *count = h;
+    *col = h + n_ids;
+    *status = h + n_ids + no;
+    *w = reinterpret_cast<const float*>(h + n_ids + 2 * no);
+    *d0 = reinterpret_cast<const float*>(h + n_ids + 3 * no);
+    return NRS_OK;
+}
+}  // namespace nrs
+
 extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, int32_t* count,
                                     int32_t* col, float* w, float* d0, int32_t* status) {
     if (!g) return NRS_ERR_INVALID;
@@ -320,34 +418,15 @@ extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t*
     if (cap_per_point <= 0 || (n_ids > 0 && (!count || !col || !w || !d0 || !status))) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: bad argument");
     NRS_TRY(rg_check_ids(g, n_ids, ids, "nrs_rgraph_get_edges"));
     if (n_ids == 0) return NRS_OK;
-    NRS_HIP(c, hipSetDevice(c->device));
+    const int *h_cnt, *h_col, *h_st;
+    const float *h_w, *h_d0;
+    NRS_TRY(rg_get_edges_staged(g, n_ids, ids, cap_per_point, &h_cnt, &h_col, &h_st, &h_w, &h_d0));
     const size_t no = (size_t)n_ids * cap_per_point;
-    NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_ids));
-    NRS_TRY(c->ensure(g->out_i, sizeof(int) * (2 * no + (size_t)n_ids + 4)));
-    NRS_TRY(c->ensure(g->out_f, sizeof(float) * 2 * no));
-    int* d_col = g->out_i.as<int>();
-    int* d_st = d_col + no;
-    int* d_cnt = d_st + no;
-    int* d_ovf = d_cnt + n_ids;
-    float* d_w = g->out_f.as<float>();
-    float* d_d0 = d_w + no;
-    NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
-    NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
-    const int cand_cap = std::min(g->cap, 12000);                 // every connection of a row may pass (a sigma that covers the map): 12 B each
-    const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
-    NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(RgCand) * (size_t)cand_cap)));
-    hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), sizeof(RgCand) * (size_t)cand_cap, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
-                       g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
-    NRS_HIP(c, hipGetLastError());
-    int ovf = 0;
-    NRS_HIP(c, hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(count, d_cnt, sizeof(int) * (size_t)n_ids, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(col, d_col, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(status, d_st, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(w, d_w, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(d0, d_d0, sizeof(float) * no, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipStreamSynchronize(c->stream));
-    if (ovf > 0) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight: more than this build stages per row (%d)", ovf, cand_cap);
+    memcpy(count, h_cnt, sizeof(int) * (size_t)n_ids);
+    memcpy(col, h_col, sizeof(int) * no);
+    memcpy(status, h_st, sizeof(int) * no);
+    memcpy(w, h_w, sizeof(float) * no);
+    memcpy(d0, h_d0, sizeof(float) * no);
     return NRS_OK;
 }
 

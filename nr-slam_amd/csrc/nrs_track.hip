@@ -226,23 +226,29 @@ struct FlatSource : NeighbourSource {
     int update(const float* map_pos, int n, const int* ids, int* good) override { return graph_update(c, G, g, map_pos, n, ids, good); }
 };
 
+int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
+                        const int** status, const float** w, const float** d0);   // nrs_rgraph.hip
+
 struct DenseSource : NeighbourSource {
     nrs_ctx* c; nrs_rgraph* g; int cap;
     int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) override {
-        const size_t n = (size_t)n_points, no = n * (size_t)cap;
-        std::vector<int> ids(n), cnt(n), fc(no), fs(no);
-        std::vector<float> fw(no), fd(no);
+        const size_t n = (size_t)n_points;
+        std::vector<int> ids(n);
         for (size_t i = 0; i < n; ++i) ids[i] = (int)i;
-        NRS_TRY(nrs_rgraph_get_edges(g, (int32_t)n, ids.data(), cap, cnt.data(), fc.data(), fw.data(), fd.data(), fs.data()));
+        const int *cnt, *fc, *fs;
+        const float *fw, *fd;
+        NRS_TRY(rg_get_edges_staged(g, (int32_t)n, ids.data(), cap, &cnt, &fc, &fs, &fw, &fd));   // pinned staging area, read in place
         rp.assign(n + 1, 0);
         truncated.assign(n, 0);
-        for (size_t i = 0; i < n; ++i) { truncated[i] = cnt[i] > cap; cnt[i] = std::min(cnt[i], cap); rp[i + 1] = rp[i] + cnt[i]; }
+        for (size_t i = 0; i < n; ++i) { truncated[i] = cnt[i] > cap; rp[i + 1] = rp[i] + std::min(cnt[i], cap); }
         col.resize(rp[n]); w.resize(rp[n]); d0.resize(rp[n]); st.resize(rp[n]);
-        for (size_t i = 0; i < n; ++i)
-            for (int k = 0; k < cnt[i]; ++k) {
-                const size_t a = (size_t)rp[i] + k, b = i * (size_t)cap + k;
-                col[a] = fc[b]; w[a] = fw[b]; d0[a] = fd[b]; st[a] = fs[b];
-            }
+        for (size_t i = 0; i < n; ++i) {
+            const size_t a = (size_t)rp[i], b = i * (size_t)cap, m = (size_t)(rp[i + 1] - rp[i]);
+            std::copy(fc + b, fc + b + m, col.begin() + a);
+            std::copy(fw + b, fw + b + m, w.begin() + a);
+            std::copy(fd + b, fd + b + m, d0.begin() + a);
+            std::copy(fs + b, fs + b + m, st.begin() + a);
+        }
         return NRS_OK;
     }
     int update(const float* map_pos, int n, const int* ids, int* good) override { return n ? nrs_rgraph_update(g, map_pos, n, ids, good) : NRS_OK; }

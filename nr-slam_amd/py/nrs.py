@@ -29,7 +29,8 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
            "nrs_rgraph_create", "nrs_rgraph_destroy", "nrs_rgraph_set_sigma", "nrs_rgraph_min_weight", "nrs_rgraph_add_edges",
-           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch", "nrs_track_deform_solve_rg"]
+           "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch", "nrs_track_deform_solve_rg",
+           "nrs_skin_select_nodes"]
 
 
 class NrsError(RuntimeError):
@@ -434,6 +435,16 @@ class Context:
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     median=float(med.value), lost=lost[:n_lost.value].tolist())
 
+    # ---- N2: skinned mode
+    def skin_select_nodes(self, pos, n_nodes, eligible=None):
+        """farthest point sampling of n_nodes graph nodes among the eligible points (pick order)"""
+        pos = _f32(pos).reshape(-1, 3)
+        el = None if eligible is None else np.ascontiguousarray(eligible, np.uint8)
+        out = np.zeros(n_nodes, np.int32)
+        self._chk(self.lib.nrs_skin_select_nodes(self.h, C.c_int32(len(pos)), _p(pos, C.c_float), _p(el, C.c_uint8) if el is not None else None,
+                                                 C.c_int32(n_nodes), _p(out, C.c_int32)))
+        return out
+
     # ---- a21-a23
     def klt_configure(self, win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4):
         cfg = KltConfig(win, max_level, max_iters, epsilon, min_eig)
@@ -563,3 +574,15 @@ class Context:
         d = np.zeros(n, np.float64)
         self._chk(self.lib.nrs_dba_gradient(self.h, _p(b, C.c_double), _p(d, C.c_double)))
         return b, d
+
+
+def skinned_status(f_status, f_map, nodes):
+    """Skinned mode (include/nrs.h, N2): the nodes keep TRACKED_WITH_3D (0), every other TRACKED_WITH_3D point of the frame
+    becomes TRACKED (1: in the frame, no 3D) and is carried by stage 2 of the pose-and-deformation solve"""
+    st = np.array(f_status, np.int32)
+    is_node = np.zeros(int(np.max(f_map)) + 1, bool)
+    is_node[np.asarray(nodes)] = True
+    fm = np.asarray(f_map)
+    demote = (st == 0) & (fm >= 0) & ~is_node[np.maximum(fm, 0)]
+    st[demote] = 1
+    return st

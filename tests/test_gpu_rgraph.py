@@ -119,6 +119,18 @@ def test_break_semantics_and_errors(ctx):
     cnt = _compare_get_edges(wide, Dw, np.array([0, 5, 250, 777, 1499], np.int32), 64)
     assert cnt.max() > 1000
     wide.close()
+    # 1400 connections of one weight (coincident points): the selecting pass overflows its staging area on purpose and
+    # every survivor of the row is staged instead; ties come out by index
+    rng, p = _scene(1600, 11)
+    p[100:1500] = np.float32([3.0, 1.0, 60.0])
+    p[0] = np.float32([0.0, 0.0, 60.0])
+    eq = nrs.RGraph(ctx, 1600, 40.0, 1.1)
+    De = RG.DenseGraph(1600, 40.0, 1.1)
+    ids = np.arange(1600, dtype=np.int32)
+    eq.add_edges(p, ids, ids)
+    De.add_edges(p, ids, ids)
+    _compare_get_edges(eq, De, np.array([0, 99, 100, 1599], np.int32), 32)
+    eq.close()
 
 
 @pytest.mark.parametrize("n,seed,model", [(500, 21, 0), (900, 22, 1)])
