@@ -208,6 +208,11 @@ int nrs_shi_buffers(nrs_ctx* ctx, float* scores, int16_t* xgrad, int16_t* ygrad)
 int nrs_comm_unique_id(uint8_t* id, int32_t capacity /* >= NRS_COMM_ID_BYTES */);      /* rank 0; broadcast by the caller */
 int nrs_comm_init_rccl(nrs_ctx* ctx, int32_t world, int32_t rank, const uint8_t* id, int32_t id_bytes);
 int nrs_comm_rank(const nrs_ctx* ctx, int32_t* rank, int32_t* world);
+/* Sizes of the BA problem resident on THIS rank: stats[0] padded landmark rows of the window, [1] rows whose incidence
+ * records this rank packed and holds (sharded: the rows of its keyframe range), [2] / [3] spring / damper incidence
+ * slots held, [4] device bytes of the problem.  (Vectors stay full length on every rank: the replicated row layout is
+ * what the boundary exchange and the final gather address.) */
+int nrs_dba_stats(nrs_ctx* ctx, int64_t stats[5]);
 /* keyframe ranges: rank r owns keyframes kf_begin[r] .. kf_begin[r+1]-1 (balanced by padded landmark
  * rows, every rank at least one keyframe).  Host only, needs no device. */
 int nrs_shard_plan(int32_t n_kf, int32_t n_lm, const int32_t* lm_kf, int32_t world, int32_t* kf_begin /* world+1 */);

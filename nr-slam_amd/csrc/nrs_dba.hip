@@ -71,6 +71,13 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     return rc;
 }
 
+extern "C" int nrs_dba_stats(nrs_ctx* c, int64_t stats[5]) {
+    if (!c || !stats) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    engine_stats(c->dba, stats);
+    return NRS_OK;
+}
+
 extern "C" int nrs_shard_plan(int32_t n_kf, int32_t n_lm, const int32_t* lm_kf, int32_t world, int32_t* kf_begin) {
     if (n_kf <= 0 || n_lm < 0 || (n_lm > 0 && !lm_kf) || world < 1 || world > n_kf || !kf_begin) return NRS_ERR_INVALID;
     std::vector<int> cnt(n_kf, 0), grp(n_kf + 1, 0);

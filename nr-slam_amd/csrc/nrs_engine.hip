@@ -477,14 +477,33 @@ int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x) {
 
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper) {
     Dev& d = e->d;
-    double* rr = e->t_out;
+    // the taps read the edges by vertex (not the packed incidence records): their device copies and the output block live in a
+    // context buffer that is filled when an engine is first asked for residuals (BA windows that never are hold none of it)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_vrow = 0, o_sp = o_vrow + al(sizeof(int) * (size_t)d.M), o_dm = o_sp + al(sizeof(int) * 2 * (size_t)d.n_sp),
+                 o_d0 = o_dm + al(sizeof(int) * 4 * (size_t)d.n_dm), o_w = o_d0 + al(sizeof(float) * (size_t)d.n_sp),
+                 o_out = o_w + al(sizeof(float) * (size_t)d.n_dm),
+                 total = o_out + sizeof(double) * (2 * (size_t)d.M + (size_t)d.n_sp + 3 * (size_t)d.n_dm);
+    if (total > c->tap.cap || !c->tap.p) { c->tap_serial = 0; NRS_TRY(c->ensure(c->tap, total)); }
+    char* tb = c->tap.as<char>();
+    int *t_vrow = reinterpret_cast<int*>(tb + o_vrow), *t_sp = reinterpret_cast<int*>(tb + o_sp), *t_dm = reinterpret_cast<int*>(tb + o_dm);
+    float *t_d0 = reinterpret_cast<float*>(tb + o_d0), *t_w = reinterpret_cast<float*>(tb + o_w);
+    if (c->tap_serial != e->serial) {
+        NRS_HIP(c, hipMemcpyAsync(t_vrow, e->vrow.data(), sizeof(int) * (size_t)d.M, hipMemcpyHostToDevice, c->stream));
+        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_sp, e->sp_ij.data(), sizeof(int) * 2 * (size_t)d.n_sp, hipMemcpyHostToDevice, c->stream));
+        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_d0, e->sp_d0.data(), sizeof(float) * (size_t)d.n_sp, hipMemcpyHostToDevice, c->stream));
+        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_dm, e->dm_idx.data(), sizeof(int) * 4 * (size_t)d.n_dm, hipMemcpyHostToDevice, c->stream));
+        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_w, e->dm_w.data(), sizeof(float) * (size_t)d.n_dm, hipMemcpyHostToDevice, c->stream));
+        c->tap_serial = e->serial;
+    }
+    double* rr = reinterpret_cast<double*>(tb + o_out);
     double* rs = rr + 2 * (size_t)d.M;
     double* rd = rs + (size_t)d.n_sp;
     const int n = std::max(d.M, std::max(d.n_sp, d.n_dm));
     const double* xl_full = nullptr;
     NRS_TRY(gather_state(c, e, &xl_full));
     hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], xl_full,
-                       e->t_vrow, e->t_sp, e->t_d0, e->t_dm, e->t_w, rr, rs, rd);
+                       t_vrow, t_sp, t_d0, t_dm, t_w, rr, rs, rd);
     NRS_HIP(c, hipGetLastError());
     if (r_reproj) NRS_HIP(c, hipMemcpyAsync(r_reproj, rr, sizeof(double) * 2 * (size_t)d.M, hipMemcpyDeviceToHost, c->stream));
     if (r_spring && d.n_sp) NRS_HIP(c, hipMemcpyAsync(r_spring, rs, sizeof(double) * (size_t)d.n_sp, hipMemcpyDeviceToHost, c->stream));

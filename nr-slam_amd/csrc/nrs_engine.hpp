@@ -64,6 +64,7 @@ int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);       // so
 int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,
                        const double* bl, double lam, double* xp, double* xl, int* iters, int* ok);
 void arena_release(Arena* a);
+void engine_stats(const Engine* e, int64_t stats[5]);              // rows, rows packed here, spring / damper incidence slots, device bytes
 void shard_plan(int K, const int* grp_ptr, int world, int* kb);     // contiguous keyframe ranges, balanced by rows
 int engine_num_poses(const Engine* e);
 void ba_constants(EngineSpec& s, float scale);            // thresholds / informations of OPT:195-210,958-973

@@ -101,12 +101,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.ec_dm = A.get<EcDamper>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
     d.ec_w = A.get<float>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
     d.part_ec = A.get<double>(d.ec_on ? std::max(1, d.ec_nblk) : 1);
-    e->t_vrow = A.get<int>(d.M);
-    e->t_sp = A.get<int>(2 * (size_t)d.n_sp);
-    e->t_dm = A.get<int>(4 * (size_t)d.n_dm);
-    e->t_d0 = A.get<float>(d.n_sp);
-    e->t_w = A.get<float>(d.n_dm);
-    e->t_out = A.get<double>(2 * (size_t)d.M + (size_t)d.n_sp + 3 * (size_t)d.n_dm);
+    (void)e;
 }
 
 template <class Tp>
@@ -123,8 +118,8 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
         const int i = e->sp_ij[2 * s], j = e->sp_ij[2 * s + 1];
         const bool act = (!sp_active || sp_active[s]) && !(vfixed(i) && vfixed(j));
         const int m = act ? SM_ACTIVE : 0;
-        e->h_s_meta[e->sp_pos[2 * s]] = m | (act ? SM_COUNT : 0);
-        e->h_s_meta[e->sp_pos[2 * s + 1]] = m;
+        if (e->sp_pos[2 * s] >= 0) e->h_s_meta[e->sp_pos[2 * s]] = m | (act ? SM_COUNT : 0);      // (-1: the row belongs to another rank)
+        if (e->sp_pos[2 * s + 1] >= 0) e->h_s_meta[e->sp_pos[2 * s + 1]] = m;
     }
     for (int s = 0; s < d.n_dm; ++s) {
         bool allfix = true;
@@ -142,7 +137,7 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
     }
     for (int s = 0; s < d.n_un; ++s) {
         const bool act = !vfixed(e->un_ij[2 * s]);
-        e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
+        if (e->un_pos[s] >= 0) e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
     }
     if (d.use_lds) {
         // the meta half-words of the static header streams (the factor streams are not touched)
@@ -316,11 +311,28 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->sp_pos.assign(2 * (size_t)s.n_sp, -1);
     e->dm_pos.assign(4 * (size_t)s.n_dm, -1);
     e->un_pos.assign((size_t)s.n_un, -1);
+    // Sharded: a rank packs (and later stores) the incidence records of ITS rows only -- the rows of its keyframe range.
+    // Rows of other ranks keep empty lists: their tiles never run here, and what this rank's tiles read of them are
+    // vector rows (the boundary-keyframe exchange), not records.  Packing time and record memory scale with 1 / ranks.
+    int pack_lo = 0, pack_hi = d.n_rows;
+    if (c->comm && s.shard && c->comm->world <= 8 && s.K >= c->comm->world && !getenv("NRS_SHARD_PACK_ALL")) {
+        std::vector<int> kb0(c->comm->world + 1);
+        shard_plan(s.K, pose_grp_ptr.data(), c->comm->world, kb0.data());
+        pack_lo = pose_grp_ptr[kb0[c->comm->rank]] * ROW_ALIGN;
+        pack_hi = pose_grp_ptr[kb0[c->comm->rank + 1]] * ROW_ALIGN;
+    }
+    auto mine = [&](int row) { return row >= pack_lo && row < pack_hi; };
+    e->pack_rows = pack_hi - pack_lo;
     std::vector<int> cnt_s(d.n_rows, 0), cnt_d(d.n_rows, 0);
-    for (int q = 0; q < s.n_sp; ++q) { cnt_s[e->vrow[s.sp_ij[2 * q]]]++; cnt_s[e->vrow[s.sp_ij[2 * q + 1]]]++; }
+    for (int q = 0; q < s.n_sp; ++q) {
+        const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
+        if (mine(a)) cnt_s[a]++;
+        if (mine(b)) cnt_s[b]++;
+    }
     for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)
-        if (s.dm_idx[q] >= 0) cnt_d[e->vrow[s.dm_idx[q]]]++;
-    for (int q = 0; q < s.n_un; ++q) cnt_d[e->vrow[s.un_ij[2 * q]]]++;
+        if (s.dm_idx[q] >= 0 && mine(e->vrow[s.dm_idx[q]])) cnt_d[e->vrow[s.dm_idx[q]]]++;
+    for (int q = 0; q < s.n_un; ++q)
+        if (mine(e->vrow[s.un_ij[2 * q]])) cnt_d[e->vrow[s.un_ij[2 * q]]]++;
     std::vector<int> ss_ptr(n_slices + 1, 0), sd_ptr(n_slices + 1, 0);
     for (int sl = 0; sl < n_slices; ++sl) {
         int ws = 0, wd = 0;
@@ -345,15 +357,20 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::fill(cnt_d.begin(), cnt_d.end(), 0);
     for (int q = 0; q < s.n_sp; ++q) {
         const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
-        const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++), pb = pos_of(ss_ptr, b, cnt_s[b]++);
-        S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
-        S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
+        if (mine(a)) {
+            const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++);
+            S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
+        }
+        if (mine(b)) {
+            const size_t pb = pos_of(ss_ptr, b, cnt_s[b]++);
+            S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
+        }
     }
     for (int q = 0; q < s.n_dm; ++q) {
         int r4[4];
         for (int k = 0; k < 4; ++k) r4[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
         for (int role = 0; role < 4; ++role) {
-            if (r4[role] < 0) continue;
+            if (r4[role] < 0 || !mine(r4[role])) continue;
             const size_t pz = pos_of(sd_ptr, r4[role], cnt_d[r4[role]]++);
             int z = 0;
             for (int k = 0; k < 4; ++k)
@@ -365,6 +382,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     for (int q = 0; q < s.n_un; ++q) {           // own role 2 (1n, +), value-only other in role 3 (2n, -)
         const int row = e->vrow[s.un_ij[2 * q]];
+        if (!mine(row)) continue;
         const size_t pz = pos_of(sd_ptr, row, cnt_d[row]++);
         D_o[3 * pz + 2] = e->vrow[s.un_ij[2 * q + 1]];
         D_w[pz] = s.un_w[q];
@@ -656,6 +674,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     ArenaPlan real{arena, false};
     carve(real, d, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), e);
+    e->arena_bytes = real.off;
 
     mark("arena");
     // ---- host mirrors + uploads
@@ -765,11 +784,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_TRY(h2d(c, d.ec_w, ec_w));
     }
     NRS_TRY(push_masks(c, e, s.sp_active, s.dm_active));
-    NRS_TRY(h2d(c, e->t_vrow, e->vrow));
-    NRS_TRY(h2d(c, e->t_sp, e->sp_ij));
-    NRS_TRY(h2d(c, e->t_dm, e->dm_idx));
-    NRS_TRY(h2d(c, e->t_d0, e->sp_d0));
-    NRS_TRY(h2d(c, e->t_w, e->dm_w));
+    e->serial = ++c->engine_serial;                                // (the residual taps are staged on first use: engine_residuals)
     NRS_HIP(c, hipMemsetAsync(d.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
     if (d.sh_on) {                                                // slots of other ranks' tiles are never written: zero for good
         NRS_HIP(c, hipMemsetAsync(d.part_lin, 0, sizeof(double) * 32 * (size_t)d.n_groups * (size_t)d.lin_rb, c->stream));
@@ -797,6 +812,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     guard.keep = true;
     *out = e;
     return NRS_OK;
+}
+
+void engine_stats(const Engine* e, int64_t stats[5]) {
+    stats[0] = e->d.n_rows; stats[1] = e->pack_rows; stats[2] = e->d.ss_nnz; stats[3] = e->d.sd_nnz; stats[4] = (int64_t)e->arena_bytes;
 }
 
 void engine_destroy(nrs_ctx* c, Engine* e) {

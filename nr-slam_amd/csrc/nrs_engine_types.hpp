@@ -161,6 +161,8 @@ struct Engine {
     Arena* arena = nullptr;
     int cur = 0;
     int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)
+    int pack_rows = 0;               // rows whose incidence records this engine holds (sharded: the rank's keyframe range)
+    size_t arena_bytes = 0;          // device bytes carved for it
     int pred_peek = 0;               // iterations the last trial needed to reach the first peek milestone
     bool first_trial_accepted = false;   // outcome of the first trial of the previous LM iteration
     double* h_scal = nullptr;        // pinned host mirrors
@@ -176,10 +178,7 @@ struct Engine {
     std::vector<uint2> h_d_hdr;
     std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
-    // device copies for the taps
-    int *t_vrow = nullptr, *t_sp = nullptr, *t_dm = nullptr;
-    float *t_d0 = nullptr, *t_w = nullptr;
-    double* t_out = nullptr;
+    unsigned long long serial = 0;   // identifies this engine to the context's tap buffer (nrs_ctx::tap)
 };
 
 // =====================================================================================

@@ -30,7 +30,7 @@ SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nr
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
            "nrs_rgraph_create", "nrs_rgraph_destroy", "nrs_rgraph_set_sigma", "nrs_rgraph_min_weight", "nrs_rgraph_add_edges",
            "nrs_rgraph_update", "nrs_rgraph_get_edges", "nrs_rgraph_edge", "nrs_rgraph_rows", "nrs_triangulate_batch", "nrs_track_deform_solve_rg",
-           "nrs_skin_select_nodes"]
+           "nrs_skin_select_nodes", "nrs_dba_stats"]
 
 
 class NrsError(RuntimeError):
@@ -434,6 +434,12 @@ class Context:
             C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     median=float(med.value), lost=lost[:n_lost.value].tolist())
+
+    def dba_stats(self):
+        """sizes of the resident BA problem on this rank (include/nrs.h nrs_dba_stats)"""
+        st = (C.c_int64 * 5)()
+        self._chk(self.lib.nrs_dba_stats(self.h, st))
+        return dict(rows=st[0], packed_rows=st[1], spring_slots=st[2], damper_slots=st[3], device_bytes=st[4])
 
     # ---- N2: skinned mode
     def skin_select_nodes(self, pos, n_nodes, eligible=None):

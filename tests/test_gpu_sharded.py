@@ -31,6 +31,7 @@ def _setup(n, k, seed, model=S.PINHOLE):
 def _run_sharded(world, p, e, cam, qt, iters=5, exact=0, resets=0):
     group = nrs.LocalGroup(world)
     out, errs = [None] * world, []
+    stats = _run_sharded.stats = [None] * world
 
     def rank_main(r):
         try:
@@ -47,6 +48,7 @@ def _run_sharded(world, p, e, cam, qt, iters=5, exact=0, resets=0):
             pq, xyz = c.dba_download()
             rr, rs, rd = c.dba_residuals()
             out[r] = (tr.trials, pq, xyz, rr, rs, rd)
+            stats[r] = c.dba_stats()
             c.close()
         except Exception as ex:                      # a failed rank would leave the others in the barrier
             errs.append((r, ex))
@@ -186,3 +188,22 @@ def test_sharded_with_two_tile_classes(ctx, monkeypatch):
     trials, pq, xyz = out[0][:3]
     _same_trials(trials, tr.trials)
     assert np.allclose(pq, pq0, atol=1e-5, rtol=0) and np.allclose(xyz, xyz0, atol=1e-4, rtol=0)
+
+
+def test_every_rank_packs_only_its_keyframe_range(ctx):
+    """storage and set-up scale with 1 / ranks: a rank holds the incidence records of its own rows only (nrs_dba_stats)"""
+    p, e, cam, qt = _setup(600, 8, 47)
+    ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    whole = ctx.dba_stats()
+    assert whole["packed_rows"] == whole["rows"]
+    world = 4
+    out = _run_sharded(world, p, e, cam, qt)
+    st = _run_sharded.stats
+    kb = nrs.shard_plan(8, p["lm_kf"], world)
+    assert sum(x["packed_rows"] for x in st) == whole["rows"]                      # the ranges tile the window
+    assert sum(x["spring_slots"] for x in st) <= whole["spring_slots"] + 64 * 4 * world
+    assert sum(x["damper_slots"] for x in st) <= whole["damper_slots"] + 64 * 4 * world
+    for r in range(world):
+        own_kf = np.isin(p["lm_kf"], np.arange(kb[r], kb[r + 1]))
+        assert st[r]["rows"] == whole["rows"] and own_kf.sum() <= st[r]["packed_rows"] < own_kf.sum() + 256 * (kb[r + 1] - kb[r])
+        assert st[r]["spring_slots"] < 0.45 * whole["spring_slots"] and st[r]["device_bytes"] < 0.6 * whole["device_bytes"]
