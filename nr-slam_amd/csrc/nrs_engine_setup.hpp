@@ -110,18 +110,43 @@ static int h2d(nrs_ctx* c, Tp* dst, const std::vector<Tp>& src) {
     return NRS_OK;
 }
 
+// Host-side set-up work split over a few threads.  Every use below is order-free (disjoint outputs, or integer counts) or
+// reproduces the sequential order (a thread owns a range of ROWS and scans the edges in edge order): the packed problem is
+// the same bits for any thread count (tests/test_gpu_scale.py).
+static int host_threads(size_t work) {
+    if (work < 200000) return 1;                                   // single-frame problems: a thread costs more than it saves
+    int n = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* ev = getenv("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
+    return n;
+}
+template <class F>
+static void parallel_for(int nt, F&& fn) {                         // fn(thread index, thread count)
+    if (nt <= 1) { fn(0, 1); return; }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t, nt] { fn(t, nt); });
+    fn(0, nt);
+    for (auto& x : th) x.join();
+}
+static inline void chunk(int64_t n, int t, int nt, int64_t& a, int64_t& b) { a = n * t / nt; b = n * (t + 1) / nt; }
+
 // per-edge masks -> per-incidence meta words and per-row flags (host), then upload
 static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uint8_t* dm_active) {
     Dev& d = e->d;
     auto vfixed = [&](int v) { return (e->h_rflag[e->vrow[v]] & RF_FIXED) != 0; };
-    for (int s = 0; s < d.n_sp; ++s) {
+    const int nt = host_threads((size_t)d.n_sp + (size_t)d.n_dm);
+    parallel_for(nt, [&](int ti, int n_thr) {                     // every edge writes its own incidence slots
+    int64_t q0, q1;
+    chunk(d.n_sp, ti, n_thr, q0, q1);
+    for (int s = (int)q0; s < (int)q1; ++s) {
         const int i = e->sp_ij[2 * s], j = e->sp_ij[2 * s + 1];
         const bool act = (!sp_active || sp_active[s]) && !(vfixed(i) && vfixed(j));
         const int m = act ? SM_ACTIVE : 0;
         if (e->sp_pos[2 * s] >= 0) e->h_s_meta[e->sp_pos[2 * s]] = m | (act ? SM_COUNT : 0);      // (-1: the row belongs to another rank)
         if (e->sp_pos[2 * s + 1] >= 0) e->h_s_meta[e->sp_pos[2 * s + 1]] = m;
     }
-    for (int s = 0; s < d.n_dm; ++s) {
+    chunk(d.n_dm, ti, n_thr, q0, q1);
+    for (int s = (int)q0; s < (int)q1; ++s) {
         bool allfix = true;
         int first = -1;
         for (int r = 0; r < 4; ++r) {
@@ -135,21 +160,28 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
             e->h_d_meta[p] = r | (act ? DM_ACTIVE : 0) | ((act && r == first) ? DM_COUNT : 0);
         }
     }
-    for (int s = 0; s < d.n_un; ++s) {
+    chunk(d.n_un, ti, n_thr, q0, q1);
+    for (int s = (int)q0; s < (int)q1; ++s) {
         const bool act = !vfixed(e->un_ij[2 * s]);
         if (e->un_pos[s] >= 0) e->h_d_meta[e->un_pos[s]] = 2 | DM_UNARY | (act ? (DM_ACTIVE | DM_COUNT) : 0);
     }
+    });
     if (d.use_lds) {
         // the meta half-words of the static header streams (the factor streams are not touched)
-        for (size_t i = 0; i < e->h_s_om.size(); ++i) {
-            const int m = e->h_s_meta[i];
-            const uint32_t m16 = (uint32_t)(((m & SM_ACTIVE) ? SR_ACTIVE : 0) | ((m & SM_COUNT) ? SR_COUNT : 0));
-            e->h_s_om[i] = (e->h_s_om[i] & 0xFFFFu) | (m16 << 16);
-        }
-        for (size_t i = 0; i < e->h_d_hdr.size(); ++i) {
-            const uint32_t m16 = e->h_d_meta[i] < 0 ? (uint32_t)REC_NONE : (uint32_t)(e->h_d_meta[i] & 0xFFFF);
-            e->h_d_hdr[i].y = (e->h_d_hdr[i].y & 0xFFFFu) | (m16 << 16);
-        }
+        parallel_for(nt, [&](int ti, int n_thr) {
+            int64_t a, b;
+            chunk((int64_t)e->h_s_om.size(), ti, n_thr, a, b);
+            for (int64_t i = a; i < b; ++i) {
+                const int m = e->h_s_meta[i];
+                const uint32_t m16 = (uint32_t)(((m & SM_ACTIVE) ? SR_ACTIVE : 0) | ((m & SM_COUNT) ? SR_COUNT : 0));
+                e->h_s_om[i] = (e->h_s_om[i] & 0xFFFFu) | (m16 << 16);
+            }
+            chunk((int64_t)e->h_d_hdr.size(), ti, n_thr, a, b);
+            for (int64_t i = a; i < b; ++i) {
+                const uint32_t m16 = e->h_d_meta[i] < 0 ? (uint32_t)REC_NONE : (uint32_t)(e->h_d_meta[i] & 0xFFFF);
+                e->h_d_hdr[i].y = (e->h_d_hdr[i].y & 0xFFFFu) | (m16 << 16);
+            }
+        });
         for (size_t i = 0; i < e->h_d_om.size(); ++i) {
             const uint32_t m16 = e->h_d_meta[i] < 0 ? (uint32_t)REC_NONE : (uint32_t)(e->h_d_meta[i] & 0xFFFF);
             e->h_d_om[i] = (e->h_d_om[i] & 0xFFFFu) | (m16 << 16);
@@ -266,8 +298,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             return v;
         };
         const bool morton = getenv("NRS_NO_MORTON") == nullptr;
+        const int nt_rows = host_threads((size_t)s.M);
+        parallel_for(std::min(nt_rows, s.K), [&](int ti, int nt) {
         std::vector<std::pair<uint64_t, int>> keys;
-        for (int k = 0; k < s.K; ++k) {
+        int64_t k0, k1;
+        chunk(s.K, ti, nt, k0, k1);
+        for (int k = (int)k0; k < (int)k1; ++k) {
             keys.clear();
             for (int v = pose_ptr[k]; v < pose_ptr[k + 1]; ++v) {
                 uint64_t code = 0;
@@ -282,26 +318,39 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             std::stable_sort(keys.begin(), keys.end());
             for (size_t i = 0; i < keys.size(); ++i) e->vrow[keys[i].second] = pose_grp_ptr[k] * ROW_ALIGN + (int)i;
         }
+        });
     }
     // Inside a tile the row order is free (neighbour ids are tile-local, the vector kernels stream): rows are sorted
     // by their incidence counts, so that the rows of a slice (64 / T consecutive rows share the slice's width) have
     // similar counts.  C2: sliced-ELL padding 1.34x / 1.37x (springs / dampers) -> 1.22x / 1.15x of the incidences.
     if (!getenv("NRS_NO_TILE_SORT")) {
         std::vector<int> cs(s.M, 0), cd(s.M, 0);
-        for (int64_t q = 0; q < 2 * (int64_t)s.n_sp; ++q) cs[s.sp_ij[q]]++;
-        for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)
-            if (s.dm_idx[q] >= 0) cd[s.dm_idx[q]]++;
-        for (int q = 0; q < s.n_un; ++q) cd[s.un_ij[2 * q]]++;
+        const int nt = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm);
+        parallel_for(nt, [&](int ti, int n) {                      // integer counts: order-free
+            int64_t a, b;
+            chunk(2 * (int64_t)s.n_sp, ti, n, a, b);
+            for (int64_t q = a; q < b; ++q) __atomic_fetch_add(&cs[s.sp_ij[q]], 1, __ATOMIC_RELAXED);
+            chunk(4 * (int64_t)s.n_dm, ti, n, a, b);
+            for (int64_t q = a; q < b; ++q)
+                if (s.dm_idx[q] >= 0) __atomic_fetch_add(&cd[s.dm_idx[q]], 1, __ATOMIC_RELAXED);
+            chunk(s.n_un, ti, n, a, b);
+            for (int64_t q = a; q < b; ++q) __atomic_fetch_add(&cd[s.un_ij[2 * q]], 1, __ATOMIC_RELAXED);
+        });
         const int tile = BLK / T;
         std::vector<int> row_v((size_t)d.n_rows, -1);
         for (int v = 0; v < s.M; ++v) row_v[e->vrow[v]] = v;
-        std::vector<int> seg;
-        for (int r0 = 0; r0 < d.n_rows; r0 += tile) {
-            seg.clear();
-            for (int r = r0; r < r0 + tile; ++r) if (row_v[r] >= 0) seg.push_back(row_v[r]);
-            std::stable_sort(seg.begin(), seg.end(), [&](int a, int b2) { return cd[a] != cd[b2] ? cd[a] > cd[b2] : cs[a] > cs[b2]; });
-            for (size_t i = 0; i < seg.size(); ++i) e->vrow[seg[i]] = r0 + (int)i;
-        }
+        parallel_for(nt, [&](int ti, int n) {                      // tiles are independent
+            std::vector<int> seg;
+            int64_t t0, t1;
+            chunk(d.n_rows / tile, ti, n, t0, t1);
+            for (int64_t tl = t0; tl < t1; ++tl) {
+                const int r0 = (int)tl * tile;
+                seg.clear();
+                for (int r = r0; r < r0 + tile; ++r) if (row_v[r] >= 0) seg.push_back(row_v[r]);
+                std::stable_sort(seg.begin(), seg.end(), [&](int a, int b2) { return cd[a] != cd[b2] ? cd[a] > cd[b2] : cs[a] > cs[b2]; });
+                for (size_t i = 0; i < seg.size(); ++i) e->vrow[seg[i]] = r0 + (int)i;
+            }
+        });
     }
     mark("row layout");
     // ---- incidence lists -> sliced ELL, built with two counting passes (no per-row containers)
@@ -323,16 +372,31 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     auto mine = [&](int row) { return row >= pack_lo && row < pack_hi; };
     e->pack_rows = pack_hi - pack_lo;
+    // the row of every incidence, once (the passes below scan these flat arrays instead of chasing vrow)
+    const int nt_pack = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm + (size_t)s.n_un);
+    std::vector<int> sp_row(2 * (size_t)s.n_sp), dm_row(4 * (size_t)s.n_dm), un_row((size_t)s.n_un);
     std::vector<int> cnt_s(d.n_rows, 0), cnt_d(d.n_rows, 0);
-    for (int q = 0; q < s.n_sp; ++q) {
-        const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
-        if (mine(a)) cnt_s[a]++;
-        if (mine(b)) cnt_s[b]++;
-    }
-    for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)
-        if (s.dm_idx[q] >= 0 && mine(e->vrow[s.dm_idx[q]])) cnt_d[e->vrow[s.dm_idx[q]]]++;
-    for (int q = 0; q < s.n_un; ++q)
-        if (mine(e->vrow[s.un_ij[2 * q]])) cnt_d[e->vrow[s.un_ij[2 * q]]]++;
+    parallel_for(nt_pack, [&](int ti, int n) {
+        int64_t a, b;
+        chunk(2 * (int64_t)s.n_sp, ti, n, a, b);
+        for (int64_t q = a; q < b; ++q) {
+            const int r = e->vrow[s.sp_ij[q]];
+            sp_row[q] = r;
+            if (mine(r)) __atomic_fetch_add(&cnt_s[r], 1, __ATOMIC_RELAXED);
+        }
+        chunk(4 * (int64_t)s.n_dm, ti, n, a, b);
+        for (int64_t q = a; q < b; ++q) {
+            const int r = s.dm_idx[q] >= 0 ? e->vrow[s.dm_idx[q]] : -1;
+            dm_row[q] = r;
+            if (r >= 0 && mine(r)) __atomic_fetch_add(&cnt_d[r], 1, __ATOMIC_RELAXED);
+        }
+        chunk(s.n_un, ti, n, a, b);
+        for (int64_t q = a; q < b; ++q) {
+            const int r = e->vrow[s.un_ij[2 * q]];
+            un_row[q] = r;
+            if (mine(r)) __atomic_fetch_add(&cnt_d[r], 1, __ATOMIC_RELAXED);
+        }
+    });
     std::vector<int> ss_ptr(n_slices + 1, 0), sd_ptr(n_slices + 1, 0);
     for (int sl = 0; sl < n_slices; ++sl) {
         int ws = 0, wd = 0;
@@ -355,40 +419,59 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<float> S_d0(nnz_s, 0.f), D_w(nnz_d, 0.f);
     std::fill(cnt_s.begin(), cnt_s.end(), 0);
     std::fill(cnt_d.begin(), cnt_d.end(), 0);
-    for (int q = 0; q < s.n_sp; ++q) {
-        const int a = e->vrow[s.sp_ij[2 * q]], b = e->vrow[s.sp_ij[2 * q + 1]];
-        if (mine(a)) {
-            const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++);
-            S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
-        }
-        if (mine(b)) {
-            const size_t pb = pos_of(ss_ptr, b, cnt_s[b]++);
-            S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
-        }
-    }
-    for (int q = 0; q < s.n_dm; ++q) {
-        int r4[4];
-        for (int k = 0; k < 4; ++k) r4[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
-        for (int role = 0; role < 4; ++role) {
-            if (r4[role] < 0 || !mine(r4[role])) continue;
-            const size_t pz = pos_of(sd_ptr, r4[role], cnt_d[r4[role]]++);
-            int z = 0;
-            for (int k = 0; k < 4; ++k)
-                if (k != role) D_o[3 * pz + z++] = r4[k];
-            D_w[pz] = s.dm_w[q];
-            D_role[pz] = role;
-            e->dm_pos[4 * (size_t)q + role] = (int)pz;
+    // fill: a thread owns a contiguous range of rows (balanced by slots) and scans ALL incidences in edge order, taking the
+    // ones of its rows -- the k-th incidence of a row is the k-th in edge order, as in a sequential pass
+    std::vector<int> row_cut(nt_pack + 1, pack_hi);
+    row_cut[0] = pack_lo;
+    {
+        const int sl_lo = pack_lo / Rw, sl_hi = pack_hi / Rw;
+        const int64_t tot = ((int64_t)ss_ptr[sl_hi] - ss_ptr[sl_lo]) + ((int64_t)sd_ptr[sl_hi] - sd_ptr[sl_lo]);
+        int sl = sl_lo;
+        for (int t = 1; t < nt_pack; ++t) {
+            const int64_t want = tot * t / nt_pack;
+            while (sl < sl_hi && ((int64_t)ss_ptr[sl] - ss_ptr[sl_lo]) + ((int64_t)sd_ptr[sl] - sd_ptr[sl_lo]) < want) ++sl;
+            row_cut[t] = sl * Rw;
         }
     }
-    for (int q = 0; q < s.n_un; ++q) {           // own role 2 (1n, +), value-only other in role 3 (2n, -)
-        const int row = e->vrow[s.un_ij[2 * q]];
-        if (!mine(row)) continue;
-        const size_t pz = pos_of(sd_ptr, row, cnt_d[row]++);
-        D_o[3 * pz + 2] = e->vrow[s.un_ij[2 * q + 1]];
-        D_w[pz] = s.un_w[q];
-        D_role[pz] = 2;
-        e->un_pos[q] = (int)pz;
-    }
+    parallel_for(nt_pack, [&](int ti, int) {
+        const int lo = row_cut[ti], hi = row_cut[ti + 1];
+        if (lo >= hi) return;
+        auto own = [&](int r) { return r >= lo && r < hi; };
+        for (int q = 0; q < s.n_sp; ++q) {
+            const int a = sp_row[2 * (size_t)q], b = sp_row[2 * (size_t)q + 1];
+            if (own(a)) {
+                const size_t pa = pos_of(ss_ptr, a, cnt_s[a]++);
+                S_other[pa] = b; S_d0[pa] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q] = (int)pa;
+            }
+            if (own(b)) {
+                const size_t pb = pos_of(ss_ptr, b, cnt_s[b]++);
+                S_other[pb] = a; S_d0[pb] = s.sp_d0[q]; e->sp_pos[2 * (size_t)q + 1] = (int)pb;
+            }
+        }
+        for (int q = 0; q < s.n_dm; ++q) {
+            const int* r4 = &dm_row[4 * (size_t)q];
+            if (!(own(r4[0]) || own(r4[1]) || own(r4[2]) || own(r4[3]))) continue;
+            for (int role = 0; role < 4; ++role) {
+                if (r4[role] < 0 || !own(r4[role])) continue;
+                const size_t pz = pos_of(sd_ptr, r4[role], cnt_d[r4[role]]++);
+                int z = 0;
+                for (int k = 0; k < 4; ++k)
+                    if (k != role) D_o[3 * pz + z++] = r4[k];
+                D_w[pz] = s.dm_w[q];
+                D_role[pz] = role;
+                e->dm_pos[4 * (size_t)q + role] = (int)pz;
+            }
+        }
+        for (int q = 0; q < s.n_un; ++q) {       // own role 2 (1n, +), value-only other in role 3 (2n, -)
+            const int row = un_row[q];
+            if (!own(row)) continue;
+            const size_t pz = pos_of(sd_ptr, row, cnt_d[row]++);
+            D_o[3 * pz + 2] = e->vrow[s.un_ij[2 * q + 1]];
+            D_w[pz] = s.un_w[q];
+            D_role[pz] = 2;
+            e->un_pos[q] = (int)pz;
+        }
+    });
     (void)dm_slots;
     mark("sell pack");
     mark("sell vectors");
@@ -623,35 +706,59 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.ec_on = plain ? 1 : 0;
         if (plain) {
             const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
-            // counting sort by the counting row (stable: edges of a row keep their order)
+            // counting sort by the counting row (stable: edges of a row keep their order); threads: keys and counts are
+            // order-free, the scatter gives every thread a range of rows and scans the keys in edge order
             std::vector<int> key, pos(d.n_rows + 1);
+            const int nt_ec = host_threads((size_t)s.n_sp + (size_t)s.n_dm);
             auto order_by_row = [&](int n_edges, auto row_of) {
                 key.assign(n_edges, -1);
                 std::fill(pos.begin(), pos.end(), 0);
-                for (int q = 0; q < n_edges; ++q) {
-                    const int r = row_of(q);
-                    if (r >= own_lo && r < own_hi) { key[q] = r; pos[r + 1]++; }
-                }
+                parallel_for(nt_ec, [&](int ti, int n) {
+                    int64_t a, b;
+                    chunk(n_edges, ti, n, a, b);
+                    for (int64_t q = a; q < b; ++q) {
+                        const int r = row_of((int)q);
+                        if (r >= own_lo && r < own_hi) { key[q] = r; __atomic_fetch_add(&pos[r + 1], 1, __ATOMIC_RELAXED); }
+                    }
+                });
                 for (int r = 0; r < d.n_rows; ++r) pos[r + 1] += pos[r];
                 std::vector<int> out(pos[d.n_rows]);
-                for (int q = 0; q < n_edges; ++q)
-                    if (key[q] >= 0) out[pos[key[q]]++] = q;
+                std::vector<int> cut(nt_ec + 1, d.n_rows);
+                cut[0] = 0;
+                for (int t = 1, r = 0; t < nt_ec; ++t) {
+                    const int64_t want = (int64_t)out.size() * t / nt_ec;
+                    while (r < d.n_rows && pos[r] < want) ++r;
+                    cut[t] = r;
+                }
+                parallel_for(nt_ec, [&](int ti, int) {
+                    const int lo = cut[ti], hi = cut[ti + 1];
+                    if (lo >= hi) return;
+                    for (int q = 0; q < n_edges; ++q)
+                        if (key[q] >= lo && key[q] < hi) out[pos[key[q]]++] = q;
+                });
                 return out;
             };
-            const std::vector<int> so = order_by_row(s.n_sp, [&](int q) { return e->vrow[s.sp_ij[2 * q]]; });
-            ec_sp.reserve(so.size());
-            for (int q : so) ec_sp.push_back(EcSpring{e->vrow[s.sp_ij[2 * q]], e->vrow[s.sp_ij[2 * q + 1]], s.sp_d0[q], 0});
+            const std::vector<int> so = order_by_row(s.n_sp, [&](int q) { return sp_row[2 * (size_t)q]; });
+            ec_sp.resize(so.size());
+            parallel_for(nt_ec, [&](int ti, int n) {
+                int64_t a, b;
+                chunk((int64_t)so.size(), ti, n, a, b);
+                for (int64_t i = a; i < b; ++i) { const int q = so[i]; ec_sp[i] = EcSpring{sp_row[2 * (size_t)q], sp_row[2 * (size_t)q + 1], s.sp_d0[q], 0}; }
+            });
             const std::vector<int> dord = order_by_row(s.n_dm, [&](int q) {
-                for (int k = 0; k < 4; ++k) if (s.dm_idx[4 * q + k] >= 0) return e->vrow[s.dm_idx[4 * q + k]];
+                for (int k = 0; k < 4; ++k) if (dm_row[4 * (size_t)q + k] >= 0) return dm_row[4 * (size_t)q + k];
                 return -1;
             });
-            ec_dm.reserve(dord.size()); ec_w.reserve(dord.size());
-            for (int q : dord) {
-                EcDamper dd;
-                for (int k = 0; k < 4; ++k) dd.r[k] = s.dm_idx[4 * q + k] >= 0 ? e->vrow[s.dm_idx[4 * q + k]] : -1;
-                ec_dm.push_back(dd);
-                ec_w.push_back(s.dm_w[q]);
-            }
+            ec_dm.resize(dord.size()); ec_w.resize(dord.size());
+            parallel_for(nt_ec, [&](int ti, int n) {
+                int64_t a, b;
+                chunk((int64_t)dord.size(), ti, n, a, b);
+                for (int64_t i = a; i < b; ++i) {
+                    const int q = dord[i];
+                    for (int k = 0; k < 4; ++k) ec_dm[i].r[k] = dm_row[4 * (size_t)q + k];
+                    ec_w[i] = s.dm_w[q];
+                }
+            });
         }
         d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
         d.ec_nblk = std::min((d.ec_nsp + d.ec_ndm + BLK - 1) / BLK, 2048);
@@ -702,13 +809,22 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     e->h_s_meta.assign(nnz_s, 0);
     e->h_d_meta.assign(nnz_d, -1);
-    for (size_t i = 0; i < nnz_d; ++i)
-        if (D_role[i] >= 0) e->h_d_meta[i] = D_role[i];
+    const int nt_mir = host_threads(nnz_s + nnz_d);
+    parallel_for(nt_mir, [&](int ti, int n) {
+        int64_t a, b;
+        chunk((int64_t)nnz_d, ti, n, a, b);
+        for (int64_t i = a; i < b; ++i)
+            if (D_role[i] >= 0) e->h_d_meta[i] = D_role[i];
+    });
     std::vector<int> d_o0, d_o1, d_o2;
     if (d.use_lds) {
         auto u16 = [](int v) { return v < 0 ? (uint32_t)REC_NONE : (uint32_t)(v & 0xFFFF); };
         e->h_s_om.resize(nnz_s);
-        for (size_t i = 0; i < nnz_s; ++i) e->h_s_om[i] = u16(L_s[i]);                        // meta: push_masks
+        parallel_for(nt_mir, [&](int ti, int n) {
+            int64_t a, b;
+            chunk((int64_t)nnz_s, ti, n, a, b);
+            for (int64_t i = a; i < b; ++i) e->h_s_om[i] = u16(L_s[i]);                        // meta: push_masks
+        });
         if (d.dform) {
             e->h_d_om.resize(nnz_d);
             for (size_t i = 0; i < nnz_d; ++i) e->h_d_om[i] = D_role[i] < 0 ? (uint32_t)REC_NONE : u16(L_d[3 * i + (D_role[i] < 2 ? 0 : 2)]);
@@ -718,10 +834,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             // o0 = the partner in the same keyframe, o1 = the own temporal partner, o2 = the partner's temporal partner
             static const int perm[4][3] = {{0, 1, 2}, {0, 2, 1}, {2, 0, 1}, {2, 1, 0}};    // indices into the others in ascending role order
             e->h_d_hdr.resize(nnz_d);
-            for (size_t i = 0; i < nnz_d; ++i) {
-                const int* pm = perm[D_role[i] < 0 ? 0 : D_role[i]];
-                e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i + pm[0]]) | (u16(L_d[3 * i + pm[1]]) << 16), u16(L_d[3 * i + pm[2]]) | ((uint32_t)REC_NONE << 16));
-            }
+            parallel_for(nt_mir, [&](int ti, int n) {
+                int64_t a, b;
+                chunk((int64_t)nnz_d, ti, n, a, b);
+                for (int64_t i = a; i < b; ++i) {
+                    const int* pm = perm[D_role[i] < 0 ? 0 : D_role[i]];
+                    e->h_d_hdr[i] = make_uint2(u16(L_d[3 * i + pm[0]]) | (u16(L_d[3 * i + pm[1]]) << 16), u16(L_d[3 * i + pm[2]]) | ((uint32_t)REC_NONE << 16));
+                }
+            });
         }
     } else {
         d_o0.resize(nnz_d); d_o1.resize(nnz_d); d_o2.resize(nnz_d);

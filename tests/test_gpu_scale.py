@@ -84,3 +84,20 @@ def test_c3_sharded_over_thread_ranks(ctx, c3):
     assert all(abs(s["lam"] - t["lam"]) <= 1e-6 * t["lam"] and abs(s["chi"] - t["chi"]) <= 1e-6 * t["chi"] for s, t in zip(trials, ref[2]))
     assert np.allclose(pq, ref[0], atol=1e-6, rtol=0) and np.allclose(xyz, ref[1], atol=1e-4, rtol=0)
     assert np.array_equal(out[4][0], pq) and np.array_equal(out[4][1], xyz)
+
+
+def test_host_packing_is_thread_count_independent(ctx, c3, monkeypatch):
+    """engine set-up runs on a few host threads (row layout, incidence packing, edge lists, masks): the packed problem --
+    hence every sum of the solve -- is the same bits for any thread count"""
+    p, e, cam, qt = c3
+    runs = []
+    for nt in ("1", "7", "16"):
+        monkeypatch.setenv("NRS_HOST_THREADS", nt)
+        ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        tr = nrs.Trace()
+        ctx.dba_optimize(2, tr)
+        runs.append((tr.trials, *ctx.dba_download(), ctx.dba_stats()))
+    for r in runs[1:]:
+        key = lambda tr: [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in tr]
+        assert key(r[0]) == key(runs[0][0]) and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
+        assert r[3] == runs[0][3]
