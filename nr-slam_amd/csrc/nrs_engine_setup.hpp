@@ -397,6 +397,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             if (mine(r)) __atomic_fetch_add(&cnt_d[r], 1, __ATOMIC_RELAXED);
         }
     });
+    mark("incidence rows");
     std::vector<int> ss_ptr(n_slices + 1, 0), sd_ptr(n_slices + 1, 0);
     for (int sl = 0; sl < n_slices; ++sl) {
         int ws = 0, wd = 0;
@@ -419,6 +420,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<float> S_d0(nnz_s, 0.f), D_w(nnz_d, 0.f);
     std::fill(cnt_s.begin(), cnt_s.end(), 0);
     std::fill(cnt_d.begin(), cnt_d.end(), 0);
+    mark("sell arrays");
     // fill: a thread owns a contiguous range of rows (balanced by slots) and scans ALL incidences in edge order, taking the
     // ones of its rows -- the k-th incidence of a row is the k-th in edge order, as in a sequential pass
     std::vector<int> row_cut(nt_pack + 1, pack_hi);
