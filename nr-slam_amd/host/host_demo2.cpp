@@ -86,7 +86,39 @@ int main(int argc, char** argv) {
         eng.DeformableTriangulation(cam, tb, cand, tst, txyz);
         wr(out, tst.data(), tst.size());
         wr(out, txyz.data(), txyz.size());
-        std::printf("host_demo2: ok (%d tracked, %d graph points, %zu candidates)\n", good, n, cand.size());
+        // ---- skinned pose-and-deformation: node selection, then CameraPoseAndDeformationOptimization on the device-resident graph
+        const auto m2 = rd<int32_t>(in);                     // camera model, number of nodes
+        const auto prm2 = rd<float>(in);
+        nrs_host::CameraView cam2 = m2[0] == NRS_CAM_PINHOLE ? nrs_host::CameraView::PinHole(prm2[0], prm2[1], prm2[2], prm2[3])
+                                                             : nrs_host::CameraView::KannalaBrandt8(prm2.data());
+        nrs_host::FrameView f;
+        f.uv = rd<float>(in); f.pos = rd<float>(in); f.status = rd<int32_t>(in); f.map_index = rd<int32_t>(in);
+        const auto qt = rd<double>(in);
+        std::memcpy(f.pose_qt, qt.data(), sizeof(double) * 7);
+        nrs_host::MapView mv;
+        mv.last_world_position = rd<float>(in);
+        const auto sss = rd<float>(in);                      // sigma, stretch threshold, scale
+        mv.sigma = sss[0]; mv.stretch_th = sss[1]; mv.scale = sss[2];
+        const int np = (int)(mv.last_world_position.size() / 3);
+        nrs_host::RegularizationGraph rg2(eng, np, mv.sigma, mv.stretch_th);
+        std::vector<int32_t> all2(np);
+        for (int i = 0; i < np; ++i) all2[i] = i;
+        rg2.AddEdges(mv.last_world_position, all2, all2);
+        std::vector<uint8_t> eligible(np, 0);
+        for (size_t i = 0; i < f.status.size(); ++i)
+            if (f.status[i] == NRS_TRACKED_WITH_3D && f.map_index[i] >= 0) eligible[f.map_index[i]] = 1;
+        const std::vector<int32_t> nodes = eng.SelectGraphNodes(mv.last_world_position, eligible, m2[1]);
+        std::vector<uint8_t> is_node(np, 0);
+        for (int32_t id : nodes) is_node[id] = 1;
+        for (size_t i = 0; i < f.status.size(); ++i)
+            if (f.status[i] == NRS_TRACKED_WITH_3D && f.map_index[i] >= 0 && !is_node[f.map_index[i]]) f.status[i] = NRS_TRACKED;   // carried by stage 2
+        const std::vector<int32_t> lost = eng.CameraPoseAndDeformationOptimization(cam2, f, mv, rg2, 256);
+        wr(out, nodes.data(), nodes.size());
+        wr(out, f.pose_qt, 7);
+        wr(out, f.status.data(), f.status.size());
+        wr(out, lost.data(), lost.size());
+        wr(out, mv.last_world_position.data(), mv.last_world_position.size());
+        std::printf("host_demo2: ok (%d tracked, %d graph points, %zu candidates, %zu nodes, %zu skinned)\n", good, n, cand.size(), nodes.size(), lost.size());
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "host_demo2: %s\n", e.what());

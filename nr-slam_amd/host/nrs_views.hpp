@@ -122,6 +122,18 @@ public:
         return lost;
     }
 
+    // The same with the map's graph kept as a device-resident RegularizationGraph (all-pairs density): GetEdges / UpdateVertex
+    // of OPT:252,468,496 are served there.  cap_per_point = how much of each sorted neighbour list is fetched.
+    inline std::vector<int32_t> CameraPoseAndDeformationOptimization(const CameraView& cam, FrameView& f, MapView& m, class RegularizationGraph& graph,
+                                                                     int cap_per_point = 64);
+
+    // Skinned mode (include/nrs.h N2): M farthest-point graph nodes among the eligible map points (pick order)
+    std::vector<int32_t> SelectGraphNodes(const std::vector<float>& positions, const std::vector<uint8_t>& eligible, int n_nodes) {
+        std::vector<int32_t> nodes((size_t)n_nodes);
+        check(nrs_skin_select_nodes(ctx_, (int32_t)(positions.size() / 3), positions.data(), eligible.empty() ? nullptr : eligible.data(), n_nodes, nodes.data()));
+        return nodes;
+    }
+
     // void LocalDeformableBundleAdjustment(shared_ptr<Map>, float scale)   g2o_optimization.h:39-40
     void LocalDeformableBundleAdjustment(const CameraView& cam, KeyFrameWindow& w, MapView& m, int iterations = 5) {
         const int32_t n_kf = (int32_t)w.kf_rowptr.size() - 1;
@@ -278,14 +290,28 @@ public:
         e_.check_rc(nrs_rgraph_get_edges(g_, (int32_t)n, ids.data(), cap_per_point, cnt.data(), col.data(), w.data(), d0.data(), st.data()));
         std::vector<std::vector<Neighbour>> out(n);
         for (size_t r = 0; r < n; ++r)
-            for (int k = 0; k < cnt[r]; ++k) out[r].push_back({col[r * cap_per_point + k], w[r * cap_per_point + k], d0[r * cap_per_point + k], st[r * cap_per_point + k]});
+            for (int k = 0; k < cnt[r] && k < cap_per_point; ++k) out[r].push_back({col[r * cap_per_point + k], w[r * cap_per_point + k], d0[r * cap_per_point + k], st[r * cap_per_point + k]});
         return out;
     }
+
+    nrs_rgraph* raw() { return g_; }
+    int capacity() const { return cap_; }
 
 private:
     Engine& e_;
     int cap_;
     nrs_rgraph* g_ = nullptr;
 };
+
+inline std::vector<int32_t> Engine::CameraPoseAndDeformationOptimization(const CameraView& cam, FrameView& f, MapView& m, RegularizationGraph& graph,
+                                                                         int cap_per_point) {
+    std::vector<int32_t> lost((size_t)graph.capacity());
+    int32_t n_lost = 0;
+    check(nrs_track_deform_solve_rg(ctx_, &cam.cam, graph.raw(), graph.capacity(), cap_per_point, m.last_world_position.data(), (int32_t)f.status.size(),
+                                    f.map_index.data(), f.status.data(), f.uv.data(), f.pos.data(), f.pose_qt, m.scale,
+                                    &f.deformation_magnitude, &n_lost, lost.data(), nullptr));
+    lost.resize((size_t)n_lost);
+    return lost;
+}
 
 }  // namespace nrs_host

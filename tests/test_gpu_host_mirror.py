@@ -96,12 +96,21 @@ def test_cpp_tracker_graph_and_triangulation_mirror(tmp_path):
         _w(f, np.array(tb["has_kp"].shape, np.int32)); _w(f, tb["poses"].astype(np.float32)); _w(f, tb["has_kp"].astype(np.uint8))
         _w(f, tb["kp_xy"].astype(np.float32)); _w(f, tb["has_lm"].astype(np.uint8)); _w(f, tb["lm_xyz"].astype(np.float32))
         _w(f, tb["status"].astype(np.int32)); _w(f, tb["cand"].astype(np.int32))
+        # skinned pose-and-deformation on the device-resident graph
+        tp = S.make_tracking_problem(500, 37)
+        n_nodes = 80
+        fm = np.arange(500, dtype=np.int32)
+        _w(f, np.array([tp["model"], n_nodes], np.int32)); _w(f, np.asarray(tp["prm"], np.float32))
+        _w(f, tp["uv"].astype(np.float32)); _w(f, tp["X_prev"].astype(np.float32)); _w(f, tp["status"].astype(np.int32)); _w(f, fm)
+        _w(f, np.concatenate([tp["pose_q"], tp["pose_t"]]).astype(np.float64)); _w(f, tp["X_prev"].astype(np.float32))
+        _w(f, np.array([tp["graph"]["sigma"], tp["graph"]["stretch_th"], tp["scale"]], np.float32))
     r = subprocess.run([demo, str(src), str(dst)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     with open(dst, "rb") as f:
         nxt, st, good, npts, gray = _r(f, np.float32), _r(f, np.int32), _r(f, np.int32), _r(f, np.int32), _r(f, np.int16)
         goodc, flat, fw = _r(f, np.int32), _r(f, np.int32), _r(f, np.float32)
         tst, txyz = _r(f, np.int32), _r(f, np.float32)
+        sk_nodes, sk_qt, sk_st, sk_lost, sk_map = _r(f, np.int32), _r(f, np.float64), _r(f, np.int32), _r(f, np.int32), _r(f, np.float32)
     c = nrs.Context()
     c.klt_configure()
     c.klt_set_reference(sq["im0"], sq["pts"])
@@ -125,4 +134,13 @@ def test_cpp_tracker_graph_and_triangulation_mirror(tmp_path):
     g.close()
     s2, x2 = c.triangulate_batch(nrs.make_camera(tb["model"], tb["prm"]), tb, tb["cand"])
     assert np.array_equal(tst, s2) and np.array_equal(txyz.reshape(-1, 3), x2)
+    nodes = c.skin_select_nodes(tp["X_prev"], n_nodes, tp["status"] == 0)
+    assert np.array_equal(sk_nodes, nodes)
+    g2 = nrs.RGraph(c, 500, tp["graph"]["sigma"], tp["graph"]["stretch_th"])
+    g2.add_edges(tp["X_prev"], fm, fm)
+    r3 = c.track_deform_solve_rg(nrs.make_camera(tp["model"], tp["prm"]), g2, tp["X_prev"], fm, nrs.skinned_status(tp["status"], fm, nodes), tp["uv"],
+                                 tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], None, 256)
+    assert np.array_equal(sk_qt, np.concatenate([r3["pose_q"], r3["pose_t"]])) and np.array_equal(sk_st, r3["f_status"])
+    assert sorted(sk_lost.tolist()) == sorted(r3["lost"]) and np.array_equal(sk_map.reshape(-1, 3), r3["map_pos"])
+    g2.close()
     c.close()
