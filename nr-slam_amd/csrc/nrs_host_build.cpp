@@ -11,6 +11,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <algorithm>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 #include "../../include/nrs.h"
 
@@ -62,23 +64,29 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
     for (int32_t i = 0; i < (n_points > 0 ? nbr_rowptr[n_points] : 0); ++i)    // both edge loops index cur[] / nxt[] with these
         if (nbr_col[i] < 0 || nbr_col[i] >= n_points) return NRS_ERR_INVALID;
 
-    // inserted_landmarks[kf][mappoint] -> landmark index (OPT:927-952), two rolling rows suffice
-    std::vector<int32_t> cur(n_points, -1), nxt(n_points, -1);
-    auto load = [&](std::vector<int32_t>& row, int k) {
-        for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) row[kf_pt[i]] = i;
+    // A keyframe's edges depend on its own landmarks and the next keyframe's only, so keyframes are independent: a few host
+    // threads take contiguous ranges of keyframes.  Pass 1 counts per keyframe, pass 2 (fill) writes at the prefix offsets:
+    // the output is index-for-index the sequential one for any thread count.
+    struct Work {
+        std::vector<int32_t> cur, nxt;       // inserted_landmarks[kf][mappoint] -> landmark index (OPT:927-952): two rows suffice
+        PairSet spring_seen, damper_seen;
+        bool overflow = false;               // an edge did not fit the caller's arrays
     };
-    auto clear = [&](std::vector<int32_t>& row, int k) {
-        for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) row[kf_pt[i]] = -1;
-    };
-    int64_t ns = 0, nd = 0;
-    PairSet spring_seen, damper_seen;
-    if (n_kf > 0) load(cur, 0);
-    for (int k = 0; k < n_kf; ++k) {
+    auto keyframe = [&](Work& w, int k, bool emit, int64_t ns0, int64_t nd0, int64_t& ns_out, int64_t& nd_out) {
+        auto load = [&](std::vector<int32_t>& row, int kk) {
+            for (int32_t i = kf_rowptr[kk]; i < kf_rowptr[kk + 1]; ++i) row[kf_pt[i]] = i;
+        };
+        auto clear = [&](std::vector<int32_t>& row, int kk) {
+            for (int32_t i = kf_rowptr[kk]; i < kf_rowptr[kk + 1]; ++i) row[kf_pt[i]] = -1;
+        };
+        std::vector<int32_t>&cur = w.cur, &nxt = w.nxt;
         const bool has_next = k + 1 < n_kf;
+        load(cur, k);
         if (has_next) load(nxt, k + 1);
+        int64_t ns = ns0, nd = nd0;
         // keys carry the keyframe id: a per-keyframe set is equivalent (<= 11 insertions per point)
-        spring_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
-        damper_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        w.spring_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        w.damper_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
         for (int32_t l = kf_rowptr[k]; l < kf_rowptr[k + 1]; ++l) {
             const int32_t p = kf_pt[l];
             const int32_t lo = nbr_rowptr[p], hi = nbr_rowptr[p + 1];
@@ -87,9 +95,9 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
                 if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
                 const int32_t o = nbr_col[e];
                 if (cur[o] < 0) continue;
-                if (!spring_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
-                if (fill) {
-                    if (ns >= cap_s) return NRS_ERR_INVALID;
+                if (!w.spring_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
+                if (emit && ns >= cap_s) w.overflow = true;
+                else if (emit) {
                     sp_ij[2 * ns] = l;
                     sp_ij[2 * ns + 1] = cur[o];
                     sp_d0[ns] = nbr_d0[e];
@@ -105,9 +113,9 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
                     if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
                     const int32_t o = nbr_col[e];
                     if (cur[o] < 0 || nxt[o] < 0) continue;
-                    if (!damper_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
-                    if (fill) {
-                        if (nd >= cap_d) return NRS_ERR_INVALID;
+                    if (!w.damper_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
+                    if (emit && nd >= cap_d) w.overflow = true;
+                    else if (emit) {
                         dm_idx[4 * nd] = l;
                         dm_idx[4 * nd + 1] = cur[o];
                         dm_idx[4 * nd + 2] = ln;
@@ -120,8 +128,54 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
             }
         }
         clear(cur, k);
-        if (has_next) cur.swap(nxt);
+        if (has_next) clear(nxt, k + 1);
+        ns_out = ns - ns0; nd_out = nd - nd0;
+    };
+    int nt = 1;
+    if (n_kf > 1 && kf_rowptr[n_kf] >= 20000) {
+        nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* ev = getenv("NRS_HOST_THREADS")) nt = std::max(1, std::min(64, atoi(ev)));
+        nt = std::min(nt, n_kf);
     }
+    std::vector<int64_t> cs((size_t)n_kf + 1, 0), cd((size_t)n_kf + 1, 0);
+    bool overflow = false;
+    auto run = [&](bool emit, bool offsets_known) {
+        auto body = [&](int ti) {
+            Work w;
+            w.cur.assign(n_points, -1); w.nxt.assign(n_points, -1);
+            const int k0 = (int)((int64_t)n_kf * ti / nt), k1 = (int)((int64_t)n_kf * (ti + 1) / nt);
+            for (int k = k0; k < k1; ++k) {
+                int64_t a = 0, b2 = 0;
+                keyframe(w, k, emit, cs[k], cd[k], a, b2);
+                if (!offsets_known) { cs[k + 1] = cs[k] + a; cd[k + 1] = cd[k] + b2; }      // (one thread: running offsets)
+            }
+            if (w.overflow) overflow = true;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+        body(0);
+        for (auto& x : th) x.join();
+    };
+    if (nt == 1) run(fill, false);                                  // one pass, offsets accumulate as it goes
+    else {
+        // counts per keyframe (every thread starts its range at 0: cs[k + 1] - cs[k] is what matters), prefix, fill
+        auto count_body = [&](int ti) {
+            Work w;
+            w.cur.assign(n_points, -1); w.nxt.assign(n_points, -1);
+            const int k0 = (int)((int64_t)n_kf * ti / nt), k1 = (int)((int64_t)n_kf * (ti + 1) / nt);
+            for (int k = k0; k < k1; ++k) keyframe(w, k, false, 0, 0, cs[k + 1], cd[k + 1]);
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(count_body, t);
+            count_body(0);
+            for (auto& x : th) x.join();
+        }
+        for (int k = 0; k < n_kf; ++k) { cs[k + 1] += cs[k]; cd[k + 1] += cd[k]; }
+        if (fill) run(true, true);
+    }
+    if (overflow) return NRS_ERR_INVALID;
+    const int64_t ns = cs[n_kf], nd = cd[n_kf];
     if (ns > INT32_MAX || nd > INT32_MAX) return NRS_ERR_INVALID;
     *n_spring = (int32_t)ns;
     *n_damper = (int32_t)nd;
