@@ -220,7 +220,7 @@ def tracked_fps(n_points=5000, frames=7):
     # the pose-and-deformation solve is one single-launch PCG iteration after another: bounded by launch latency, not by
     # traffic.  Its "roofline" is the cost of such a launch with the arithmetic removed (launch + two dependent fetch levels of
     # what the previous launch wrote + one block reduction: 6.9 us) against the all-in time per iteration.
-    us_iter = 1e3 * stage.get("track_deform", 0) / max(1, inner)
+    us_iter = 1e6 * stage.get("track_deform", 0) / max(1, inner)
     latency = dict(kernel="k_pcg_fused (one launch per PCG iteration)", launches_per_frame=inner / nf, us_per_iteration_all_in=us_iter,
                    floor_us=6.9, frac=6.9 / us_iter if us_iter > 0 else None)
     return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf, pcg_latency=latency,
