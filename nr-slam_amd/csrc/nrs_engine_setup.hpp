@@ -267,6 +267,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.info_spatial = s.info_spatial; d.delta_spatial = s.delta_spatial;
     d.k_spring = s.k_spring; d.spring_form = s.spring_form;
 
+    const int nt_all = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm + (size_t)s.n_un);   // one decision for every set-up stage
     // ---- row layout: pose-major, each pose padded to ROW_ALIGN rows, Morton order inside
     std::vector<int> pose_ptr(s.K + 1, 0);
     for (int i = 0; i < s.M; ++i) pose_ptr[s.lm_pose[i] + 1]++;
@@ -298,7 +299,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             return v;
         };
         const bool morton = getenv("NRS_NO_MORTON") == nullptr;
-        const int nt_rows = host_threads((size_t)s.M);
+        const int nt_rows = nt_all;
         parallel_for(std::min(nt_rows, s.K), [&](int ti, int nt) {
         std::vector<std::pair<uint64_t, int>> keys;
         int64_t k0, k1;
@@ -325,7 +326,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // similar counts.  C2: sliced-ELL padding 1.34x / 1.37x (springs / dampers) -> 1.22x / 1.15x of the incidences.
     if (!getenv("NRS_NO_TILE_SORT")) {
         std::vector<int> cs(s.M, 0), cd(s.M, 0);
-        const int nt = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm);
+        const int nt = nt_all;
         parallel_for(nt, [&](int ti, int n) {                      // integer counts: order-free
             int64_t a, b;
             chunk(2 * (int64_t)s.n_sp, ti, n, a, b);
@@ -373,7 +374,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     auto mine = [&](int row) { return row >= pack_lo && row < pack_hi; };
     e->pack_rows = pack_hi - pack_lo;
     // the row of every incidence, once (the passes below scan these flat arrays instead of chasing vrow)
-    const int nt_pack = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm + (size_t)s.n_un);
+    const int nt_pack = nt_all;
     std::vector<int> sp_row(2 * (size_t)s.n_sp), dm_row(4 * (size_t)s.n_dm), un_row((size_t)s.n_un);
     std::vector<int> cnt_s(d.n_rows, 0), cnt_d(d.n_rows, 0);
     parallel_for(nt_pack, [&](int ti, int n) {
@@ -711,7 +712,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             // counting sort by the counting row (stable: edges of a row keep their order); threads: keys and counts are
             // order-free, the scatter gives every thread a range of rows and scans the keys in edge order
             std::vector<int> key, pos(d.n_rows + 1);
-            const int nt_ec = host_threads((size_t)s.n_sp + (size_t)s.n_dm);
+            const int nt_ec = nt_all;
             auto order_by_row = [&](int n_edges, auto row_of) {
                 key.assign(n_edges, -1);
                 std::fill(pos.begin(), pos.end(), 0);
@@ -811,7 +812,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     e->h_s_meta.assign(nnz_s, 0);
     e->h_d_meta.assign(nnz_d, -1);
-    const int nt_mir = host_threads(nnz_s + nnz_d);
+    const int nt_mir = nt_all;
     parallel_for(nt_mir, [&](int ti, int n) {
         int64_t a, b;
         chunk((int64_t)nnz_d, ti, n, a, b);
