@@ -51,3 +51,102 @@ def test_keyframes_extract_and_reorder_slots():
     # new corners respect the 31x31 exclusion around held keypoints (shi_tomasi.cc:123-160)
     kf_log = loop.log[1]
     assert kf_log["n_2d"] == new
+
+
+class _Scripted:
+    """backend stand-in: LK results are a fixed function of the seeds, nothing numerical runs"""
+
+    def __init__(self, rng):
+        self.rng, self.inserted = rng, []
+
+    def klt_set_reference(self, im, pts):
+        self.ref = np.asarray(pts, np.float32).copy()
+
+    def klt_get_templates(self, n):
+        return [dict(id=i) for i in range(n)]
+
+    def klt_insert_template(self, t):
+        self.inserted.append((t["id"], tuple(np.asarray(t["xy"], np.float32).tolist())))
+
+    def script(self, seeds):
+        s = np.asarray(seeds, np.float64)
+        code = np.floor(s[:, 0] * 7.0 + s[:, 1] * 3.0).astype(np.int64)
+        st = np.where(code % 4 == 0, 1, 0).astype(np.int32)                      # a quarter of the candidates lose their 3D status
+        off = np.stack([(code % 5 - 2) * 0.9, (code % 3 - 1) * 1.1], 1)          # some land more than sqrt(5.99) px away
+        return (s + off).astype(np.float32), st
+
+    def reuse_track(self, im, pts, templates, min_ssim):
+        self.last_templates = [t["id"] for t in templates]
+        return self.script(pts)
+
+    def extract_features(self, im, held_xy, mask=None):
+        k = 5 + len(held_xy) % 7
+        xy = (np.arange(2 * k, dtype=np.float32).reshape(k, 2) * 3.5 + len(held_xy)).astype(np.float32)
+        self.last_held = np.asarray(held_xy, np.float32).copy()
+        return xy, np.arange(k)
+
+
+def _literal_of(loop):
+    import frame_literal as L
+    f = L.LiteralFrame()
+    for i in range(len(loop.status)):
+        f.keypoints.append(loop.kp[i].copy()); f.landmark_positions.append(loop.pos[i].copy()); f.landmark_status.append(int(loop.status[i]))
+        if loop.map_index[i] >= 0:
+            f.mappoint_id_to_index[int(loop.map_index[i])] = i
+            f.index_to_mappoint_id[i] = int(loop.map_index[i])
+    return f
+
+
+def _same_frame(loop, f):
+    assert len(f.keypoints) == len(loop.status)
+    assert np.array_equal(np.asarray(f.keypoints, np.float32).reshape(-1, 2), loop.kp)
+    assert np.array_equal(np.asarray(f.landmark_positions, np.float32).reshape(-1, 3), loop.pos)
+    assert f.landmark_status == loop.status.tolist()
+    mi = -np.ones(len(loop.status), np.int32)
+    for i, mp in f.index_to_mappoint_id.items():
+        mi[i] = mp
+    assert np.array_equal(mi, loop.map_index)
+    assert f.mappoint_id_to_index == {int(mp): i for i, mp in enumerate(loop.map_index) if mp >= 0}
+
+
+def test_point_reuse_and_keyframe_bookkeeping_against_the_container_model():
+    """f1's host logic against a second restatement in the reference's container form (oracle/frame_literal.py): PointReuse
+    (tracking.cc:394-506) and CreateNewKeyFrame (tracking.cc:347-382, keyframe.cc:26-55, frame.cc:47-77) on random frames,
+    a scripted tracker behind both: slots, statuses, positions, id maps, template insertions -- exact."""
+    import frame_literal as L
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        sq = S.make_frame_sequence(90, 2, 100 + seed)
+        b = _Scripted(rng)
+        proj = lambda pc: FL.project_f32(sq["model"], sq["prm"], pc)
+        loop = FL.FrameLoop(b, proj, sq["wh"], sq["scale"], sq["kp0"], sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0],
+                            images_to_insert_keyframe=0)
+        n = len(loop.status)
+        # a random frame state: statuses of every kind, some slots without a map point, some map points not in the frame
+        loop.status = rng.choice([0, 0, 0, 1, 2, 3], n).astype(np.int32)
+        drop = rng.uniform(size=n) < 0.15
+        keep = ~drop
+        loop.kp, loop.pos, loop.status, loop.map_index = loop.kp[keep], loop.pos[keep], loop.status[keep], loop.map_index[keep]
+        no_mp = (loop.status == 1) & (rng.uniform(size=len(loop.status)) < 0.5)
+        loop.map_index = np.where(no_mp, -1, loop.map_index).astype(np.int32)
+        loop.map_pos = (loop.map_pos + rng.normal(0, 0.3, loop.map_pos.shape)).astype(np.float32)
+        loop.map_pos[rng.integers(0, len(loop.map_pos), 4), 2] *= np.float32(-1)                  # behind the camera
+        loop.map_pos[rng.integers(0, len(loop.map_pos), 4), 0] += np.float32(500)                 # outside the image
+        lost = set(int(x) for x in rng.choice(len(loop.map_pos), 12, replace=False))
+        f = _literal_of(loop)
+        inserted = []
+        mp_dict = {i: loop.map_pos[i].copy() for i in range(len(loop.map_pos))}
+        reused_l = L.point_reuse(f, mp_dict, lambda X: FL.se3f_act(loop.pose, X), proj, sq["wh"], lost,
+                                 lambda seeds, ids: b.script(seeds), lambda mp, xy: inserted.append((mp, tuple(np.asarray(xy, np.float32).tolist()))))
+        reused = loop.point_reuse(sq["images"][1], lost)
+        assert reused == reused_l and reused > 0
+        _same_frame(loop, f)
+        assert b.inserted == inserted
+        # keyframe insertion on the state PointReuse left
+        held = [f.keypoints[i] for i in f.with_status({0, 1})]
+        xy_new, _ = _Scripted(rng).extract_features(None, np.asarray(held, np.float32).reshape(-1, 2))
+        f2 = L.create_new_keyframe(f, xy_new)
+        assert loop.keyframe_insertion(sq["images"][1])
+        assert np.array_equal(b.last_held, np.asarray(held, np.float32).reshape(-1, 2))
+        _same_frame(loop, f2)
+        assert np.array_equal(b.ref, loop.kp)                                     # SetKLTReference on the new slot order
