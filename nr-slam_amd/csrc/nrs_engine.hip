@@ -45,6 +45,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <system_error>
 #include <thread>
 #include "nrs_engine.hpp"
 

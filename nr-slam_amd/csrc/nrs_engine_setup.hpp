@@ -124,7 +124,10 @@ static void parallel_for(int nt, F&& fn) {                         // fn(thread 
     if (nt <= 1) { fn(0, 1); return; }
     std::vector<std::thread> th;
     th.reserve(nt - 1);
-    for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t, nt] { fn(t, nt); });
+    for (int t = 1; t < nt; ++t) {
+        try { th.emplace_back([&fn, t, nt] { fn(t, nt); }); }
+        catch (const std::system_error&) { fn(t, nt); }            // no thread to be had: this share runs here
+    }
     fn(0, nt);
     for (auto& x : th) x.join();
 }

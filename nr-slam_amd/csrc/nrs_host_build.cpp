@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include "../../include/nrs.h"
@@ -152,7 +153,9 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
             if (w.overflow) overflow = true;
         };
         std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+        for (int t = 1; t < nt; ++t) {
+            try { th.emplace_back(body, t); } catch (const std::system_error&) { body(t); }      // no thread to be had: this share runs here
+        }
         body(0);
         for (auto& x : th) x.join();
     };
@@ -167,7 +170,9 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
         };
         {
             std::vector<std::thread> th;
-            for (int t = 1; t < nt; ++t) th.emplace_back(count_body, t);
+            for (int t = 1; t < nt; ++t) {
+                try { th.emplace_back(count_body, t); } catch (const std::system_error&) { count_body(t); }
+            }
             count_body(0);
             for (auto& x : th) x.join();
         }
