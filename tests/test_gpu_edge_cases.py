@@ -85,6 +85,9 @@ def test_calls_before_upload_fail(lib_built):
     assert ei.value.code == -5
     with pytest.raises(nrs.NrsError):
         c.dba_reset()
+    with pytest.raises(nrs.NrsError) as ei:
+        c.dba_stats()
+    assert ei.value.code == -5
     c.close()
 
 
@@ -192,6 +195,15 @@ def test_contexts_and_engines_do_not_leak_device_memory(lib_built):
             c.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 2)
             c.track_deform_solve(camt, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
                                  tp["pose_q"], tp["pose_t"], tp["scale"])
+        c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+        c.dba_residuals()                         # the lazily staged tap buffer of the context
+        g = nrs.RGraph(c, 300, tp["graph"]["sigma"], 1.1)   # dense graph: device state + pinned staging area
+        g.add_edges(tp["X_prev"], fm, fm)
+        g.get_edges(fm, 64)
+        nodes = c.skin_select_nodes(tp["X_prev"], 40, tp["status"] == 0)
+        c.track_deform_solve_rg(camt, g, tp["X_prev"], fm, nrs.skinned_status(tp["status"], fm, nodes), tp["uv"], tp["X_prev"],
+                                tp["pose_q"], tp["pose_t"], tp["scale"], None, 256)
+        g.close()
         c.close()
 
     cycle()                                   # warm-up: runtime / code-object allocations happen once
