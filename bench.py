@@ -460,8 +460,8 @@ def shi_extract_bench(reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2", help="N = 1: the window `value` is measured on")
     ap.add_argument("--sharded-workload", default="C4", help="N > 1: the ONE window that is sharded over the ranks")
     ap.add_argument("--sharded-points", type=int, default=0, help="override the sharded window's map points (tests)")
@@ -516,9 +516,10 @@ def main():
         # ---- the same steps with every LM trial solved to pcg_rtol (g2o's behaviour; `value` rejects hopeless trials early)
         xctx = nrs.Context(device=local_rank, exact_trials=1)
         xctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-        rx = timed_steps(xctx, max(2, args.steps // 4), 1, barrier)
+        n_exact = max(2, min(25, args.steps // 4))
+        rx = timed_steps(xctx, n_exact, 1, barrier)
         out["value_exact_trials"] = rx["lm_iters"] / rx["dt"]
-        out["config"]["pcg_iters_per_step_exact_trials"] = rx["inner"] / max(2, args.steps // 4)
+        out["config"]["pcg_iters_per_step_exact_trials"] = rx["inner"] / n_exact
         # ---- roofline of the dominant kernels: HIP events on the context's own stream ----------
         pctx = nrs.Context(device=local_rank, profile=1)
         pctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
@@ -585,9 +586,10 @@ def main():
                 c1 = nrs.Context(device=local_rank)
                 pw, ew, camw, qtw = win
                 c1.dba_upload(camw, qtw, pw["lm_xyz"], pw["lm_kf"], pw["lm_uv"], ew, pw["scale"])
-                r1 = timed_steps(c1, max(2, args.steps // 4), 1, lambda: torch.cuda.synchronize())
+                n_single = max(2, min(10, args.steps // 4))
+                r1 = timed_steps(c1, n_single, 1, lambda: torch.cuda.synchronize())
                 c1.close()
-                single = {"value": r1["lm_iters"] / r1["dt"], "unit": "LM iters/s", "ms_per_step": 1e3 * r1["dt"] / max(2, args.steps // 4)}
+                single = {"value": r1["lm_iters"] / r1["dt"], "unit": "LM iters/s", "ms_per_step": 1e3 * r1["dt"] / n_single}
             if rank == 0:
                 pw, ew = win[0], win[1]
                 out.update({"value": res["lm_iters"] / sdt, "ms_per_step": 1e3 * sdt / args.steps, "scaling": "strong"})
