@@ -1,7 +1,7 @@
 """N1 (north star: "Schur-complement LM solve"): does eliminating the pose blocks buy PCG iterations on the windows
 where it could matter (K = 50 / 200 keyframes)?  C++ restatement (oracle/nrs_cpu.cpp), same LM, same tolerance:
 solver 1 = block-Jacobi PCG on the full system, solver 2 = PCG on the pose-eliminated landmark system with its exact
-diagonal blocks.  Prints PCG iterations per LM trial for both.   python tools/schur_probe.py C3 [max_trials]"""
+diagonal blocks.  Prints PCG iterations per LM trial for both.   python tools/schur_probe.py C3|<points>x<keyframes> [max_trials] [threads]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd/py")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -9,7 +9,11 @@ import numpy as np, nrs, nrs_synth as S, nrs_cpu as CPU
 w = sys.argv[1] if len(sys.argv) > 1 else "C3"
 mt = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 th = int(sys.argv[3]) if len(sys.argv) > 3 else min(32, CPU.max_threads())
-p = S.make_dba_problem(w)
+if "x" in w:                                                      # "2500x200": points x keyframes, pinhole (a K = 200 window at C3 cost)
+    n_pts, n_kf = (int(v) for v in w.split("x"))
+    p = S.make_dba_problem(n_pts, n_kf, 7, 0)
+else:
+    p = S.make_dba_problem(w)
 e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
 out = {}
 for solver in (1, 2):
