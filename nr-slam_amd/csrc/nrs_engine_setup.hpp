@@ -114,7 +114,7 @@ static int h2d(nrs_ctx* c, Tp* dst, const std::vector<Tp>& src) {
 // reproduces the sequential order (a thread owns a range of ROWS and scans the edges in edge order): the packed problem is
 // the same bits for any thread count (tests/test_gpu_scale.py).
 static int host_threads(size_t work) {
-    if (work < 200000) return 1;                                   // single-frame problems: a thread costs more than it saves
+    if (work < 600000) return 1;                                   // single-frame problems (a 4.5k-point frame: 0.3 M): threads cost 8 ms per frame, they save nothing
     int n = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* ev = getenv("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
     return n;
@@ -132,6 +132,9 @@ static void parallel_for(int nt, F&& fn) {                         // fn(thread 
     for (auto& x : th) x.join();
 }
 static inline void chunk(int64_t n, int t, int nt, int64_t& a, int64_t& b) { a = n * t / nt; b = n * (t + 1) / nt; }
+// count into a shared array: a plain increment when the stage runs on one thread (a locked add costs ~2 ns even uncontended:
+// 2.5 ms per tracked frame over its two engines)
+static inline void count_up(int* p, int nt) { if (nt == 1) ++*p; else __atomic_fetch_add(p, 1, __ATOMIC_RELAXED); }
 
 // per-edge masks -> per-incidence meta words and per-row flags (host), then upload
 static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uint8_t* dm_active) {
@@ -333,12 +336,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         parallel_for(nt, [&](int ti, int n) {                      // integer counts: order-free
             int64_t a, b;
             chunk(2 * (int64_t)s.n_sp, ti, n, a, b);
-            for (int64_t q = a; q < b; ++q) __atomic_fetch_add(&cs[s.sp_ij[q]], 1, __ATOMIC_RELAXED);
+            for (int64_t q = a; q < b; ++q) count_up(&cs[s.sp_ij[q]], n);
             chunk(4 * (int64_t)s.n_dm, ti, n, a, b);
             for (int64_t q = a; q < b; ++q)
-                if (s.dm_idx[q] >= 0) __atomic_fetch_add(&cd[s.dm_idx[q]], 1, __ATOMIC_RELAXED);
+                if (s.dm_idx[q] >= 0) count_up(&cd[s.dm_idx[q]], n);
             chunk(s.n_un, ti, n, a, b);
-            for (int64_t q = a; q < b; ++q) __atomic_fetch_add(&cd[s.un_ij[2 * q]], 1, __ATOMIC_RELAXED);
+            for (int64_t q = a; q < b; ++q) count_up(&cd[s.un_ij[2 * q]], n);
         });
         const int tile = BLK / T;
         std::vector<int> row_v((size_t)d.n_rows, -1);
@@ -386,19 +389,19 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         for (int64_t q = a; q < b; ++q) {
             const int r = e->vrow[s.sp_ij[q]];
             sp_row[q] = r;
-            if (mine(r)) __atomic_fetch_add(&cnt_s[r], 1, __ATOMIC_RELAXED);
+            if (mine(r)) count_up(&cnt_s[r], n);
         }
         chunk(4 * (int64_t)s.n_dm, ti, n, a, b);
         for (int64_t q = a; q < b; ++q) {
             const int r = s.dm_idx[q] >= 0 ? e->vrow[s.dm_idx[q]] : -1;
             dm_row[q] = r;
-            if (r >= 0 && mine(r)) __atomic_fetch_add(&cnt_d[r], 1, __ATOMIC_RELAXED);
+            if (r >= 0 && mine(r)) count_up(&cnt_d[r], n);
         }
         chunk(s.n_un, ti, n, a, b);
         for (int64_t q = a; q < b; ++q) {
             const int r = e->vrow[s.un_ij[2 * q]];
             un_row[q] = r;
-            if (mine(r)) __atomic_fetch_add(&cnt_d[r], 1, __ATOMIC_RELAXED);
+            if (mine(r)) count_up(&cnt_d[r], n);
         }
     });
     mark("incidence rows");
@@ -724,7 +727,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                     chunk(n_edges, ti, n, a, b);
                     for (int64_t q = a; q < b; ++q) {
                         const int r = row_of((int)q);
-                        if (r >= own_lo && r < own_hi) { key[q] = r; __atomic_fetch_add(&pos[r + 1], 1, __ATOMIC_RELAXED); }
+                        if (r >= own_lo && r < own_hi) { key[q] = r; count_up(&pos[r + 1], n); }
                     }
                 });
                 for (int r = 0; r < d.n_rows; ++r) pos[r + 1] += pos[r];
