@@ -15,8 +15,8 @@
 //   update    : one workgroup sweep per listed vertex over its row/column      O(deg), good_count by block reduction
 //   get_edges : one wave per listed vertex: one pass finds the status class at which GetEdges' "break at the first
 //               weight < min_weight" falls and compacts the surviving entries (they all lie within 1.5 sigma), which are
-//               rank-sorted by (status, -weight, index) when they are a few hundred, O(deg) + O(k^2 / 64), or extracted
-//               in key order for the first cap_per_point of them when sigma covers most of the map
+//               put in order as 64-bit keys (status | inverted weight bits | index): rank sort when they are a few hundred,
+//               O(deg) + O(k^2 / 64), a bitonic sort in LDS beyond (a sigma that covers most of the map)
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -98,7 +98,11 @@ __global__ __launch_bounds__(256) void k_rg_update(int n_ids, const int* __restr
 // lowest status class s* that holds any such entry: the result is every entry of the classes below s* plus the
 // entries of s* at or above min_weight -- all of them at or above min_weight, ordered by (status, -weight, index).
 // (ties: ascending index, the build's documented choice where std::sort leaves the order open)
-struct RgCand { int j; float w; int s; };
+// a staged connection as one sortable word: status (8 bits) | inverted weight bits (32) | index (24): ascending keys =
+// (status asc, weight desc, index asc)
+__device__ inline unsigned long long rg_key(int s, float w, int j) {
+    return ((unsigned long long)s << 56) | ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(w)) << 24) | (unsigned long long)j;
+}
 constexpr int RG_BINS = 256;     // weight histogram bins per status class (selection of the first out_cap entries)
 constexpr int RG_CLASSES = 4;    // NRS_GRAPH_VERIFIED .. NRS_GRAPH_BAD
 constexpr int RG_SLACK = 1024;   // candidates staged beyond out_cap (the population of the bin the cut falls into)
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
                                                      const float* __restrict__ d0, const uint8_t* __restrict__ st, float sigma,
                                                      float min_w, float d_hi, int cand_cap, int out_cap, int select_all, int* o_count,
                                                      int* o_col, float* o_w, float* o_d0, int* o_st, int* overflow) {
-    extern __shared__ RgCand cand[];
+    extern __shared__ unsigned long long cand[];              // keys of the staged connections (padded to a power of two for the sort)
     __shared__ int hist[RG_CLASSES][RG_BINS];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= n_ids) return;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const int p = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (p < cand_cap) { cand[p].j = j0 + lane; cand[p].w = w; cand[p].s = s; }
+            if (p < cand_cap) cand[p] = rg_key(s, w, j0 + lane);
         }
         n += __popcll(m);
     }
@@ -192,52 +196,40 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
     // the survivors (status <= s*) in the order (status asc, weight desc, index asc); only the first out_cap are
     // written (callers walk a prefix: OPT:255-279 stops after 11 accepted neighbours or at the first BAD edge),
     // o_count is the full length (n_out, from the histograms)
+    auto emit = [&](int rank, unsigned long long key) {
+        const int j = (int)(key & 0xFFFFFFull);
+        const size_t o = (size_t)r * out_cap + rank;
+        o_col[o] = j; o_w[o] = __uint_as_float(0xFFFFFFFFu - (unsigned)((key >> 24) & 0xFFFFFFFFull)); o_st[o] = (int)(key >> 56);
+        o_d0[o] = d0[rg_at(i, j, cap)];
+    };
     if (n <= 384) {
         // short lists: rank sort, O(n^2 / 64)
         for (int a0 = 0; a0 < n; a0 += 64) {
             const int a = a0 + lane;
             if (a < n) {
-                const RgCand ca = cand[a];
+                const unsigned long long ka = cand[a];
                 int rank = 0;
-                for (int b = 0; b < n; ++b) {
-                    const RgCand cb = cand[b];
-                    const bool before = (cb.s != ca.s) ? (cb.s < ca.s) : ((cb.w != ca.w) ? (cb.w > ca.w) : (cb.j < ca.j));
-                    rank += before ? 1 : 0;
-                }
-                if (rank < out_cap) {
-                    const size_t o = (size_t)r * out_cap + rank;
-                    o_col[o] = ca.j; o_w[o] = ca.w; o_st[o] = ca.s; o_d0[o] = d0[rg_at(i, ca.j, cap)];
-                }
+                for (int b = 0; b < n; ++b) rank += cand[b] < ka ? 1 : 0;
+                if (rank < out_cap) emit(rank, ka);
             }
         }
     } else {
-        // long lists (a sigma that covers most of the map): extract the next entry in key order, min(n_out, out_cap) times
-        int ls = -1, lj = -1;
-        float lw = 0.f;
-        const int rounds = min(n, out_cap);
-        for (int k = 0; k < rounds; ++k) {
-            int bs = 0x7fffffff, bj = 0x7fffffff, ba = -1;
-            float bw = 0.f;
-            for (int a = lane; a < n; a += 64) {
-                const RgCand ca = cand[a];
-                const bool after = ls < 0 || ((ca.s != ls) ? (ca.s > ls) : ((ca.w != lw) ? (ca.w < lw) : (ca.j > lj)));
-                if (!after) continue;
-                const bool better = ba < 0 || ((ca.s != bs) ? (ca.s < bs) : ((ca.w != bw) ? (ca.w > bw) : (ca.j < bj)));
-                if (better) { bs = ca.s; bw = ca.w; bj = ca.j; ba = a; }
+        // long lists (a sigma that covers most of the map): bitonic sort of the staged keys in LDS, one wave
+        int N = 512;
+        while (N < n) N <<= 1;
+        for (int a = n + lane; a < N; a += 64) cand[a] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int t = lane; t < N / 2; t += 64) {
+                    const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), hi = lo | jj;    // the t-th pair at distance jj
+                    const unsigned long long x = cand[lo], y = cand[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((x > y) == up) { cand[lo] = y; cand[hi] = x; }
+                }
+                __syncthreads();
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const int os = __shfl_xor(bs, off, 64), oj = __shfl_xor(bj, off, 64), oa = __shfl_xor(ba, off, 64);
-                const float ow = __shfl_xor(bw, off, 64);
-                const bool better = oa >= 0 && (ba < 0 || ((os != bs) ? (os < bs) : ((ow != bw) ? (ow > bw) : (oj < bj))));
-                if (better) { bs = os; bw = ow; bj = oj; ba = oa; }
-            }
-            if (lane == 0) {
-                const size_t o = (size_t)r * out_cap + k;
-                o_col[o] = bj; o_w[o] = bw; o_st[o] = bs; o_d0[o] = d0[rg_at(i, bj, cap)];
-            }
-            ls = bs; lw = bw; lj = bj;
-        }
+        for (int a = lane; a < min(n, out_cap); a += 64) emit(a, cand[a]);
     }
     if (lane == 0) o_count[r] = n_out;
 }
@@ -393,8 +385,11 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
     for (int pass = 0; pass < 2; ++pass) {
         cand_cap = pass == 0 ? std::min(g->cap, cap_per_point + RG_SLACK) : std::min(g->cap, 12000);
         NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(RgCand) * (size_t)cand_cap)));
-        hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), sizeof(RgCand) * (size_t)cand_cap, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
+        size_t pad = 512;                                          // the long-list path sorts a power-of-two number of keys
+        while (pad < (size_t)cand_cap) pad <<= 1;
+        const size_t shm = sizeof(unsigned long long) * pad;
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), shm, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
                            g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
         NRS_HIP(c, hipGetLastError());
         NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
