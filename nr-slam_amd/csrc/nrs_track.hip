@@ -206,8 +206,10 @@ static int graph_update(nrs_ctx* c, GraphDevice& G, nrs_graph* g, const float* p
 struct NeighbourSource {
     int n_points = 0;
     virtual ~NeighbourSource() {}
-    // GetEdges of every map point, in the reference's order: CSR of (other, weight, first_distance, status)
-    virtual int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) = 0;
+    // GetEdges of the map points in `want` (a source may serve every point), in the reference's order: CSR over ALL map
+    // points of (other, weight, first_distance, status); rows that were not asked for may be empty
+    virtual int select(const std::vector<int>& want, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
+                       std::vector<int>& st) = 0;
     // UpdateVertex of the listed points from the last world positions; good[i] = its return value
     virtual int update(const float* map_pos, int n, const int* ids, int* good) = 0;
     std::vector<char> truncated;      // per point: select() returned only a prefix of its list
@@ -216,7 +218,8 @@ struct NeighbourSource {
 struct FlatSource : NeighbourSource {
     nrs_ctx* c; nrs_graph* g; GraphDevice G;
     int init() { n_points = g->n_points; return graph_upload(c, G, g); }
-    int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) override {
+    int select(const std::vector<int>&, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
+               std::vector<int>& st) override {
         std::vector<int> eid;
         NRS_TRY(graph_select(c, G, g->sigma, rp, col, eid));
         w.resize(eid.size()); d0.resize(eid.size()); st.resize(eid.size());
@@ -231,23 +234,25 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
 
 struct DenseSource : NeighbourSource {
     nrs_ctx* c; nrs_rgraph* g; int cap;
-    int select(std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0, std::vector<int>& st) override {
-        const size_t n = (size_t)n_points;
-        std::vector<int> ids(n);
-        for (size_t i = 0; i < n; ++i) ids[i] = (int)i;
-        const int *cnt, *fc, *fs;
-        const float *fw, *fd;
-        NRS_TRY(rg_get_edges_staged(g, (int32_t)n, ids.data(), cap, &cnt, &fc, &fs, &fw, &fd));   // pinned staging area, read in place
+    int select(const std::vector<int>& want, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
+               std::vector<int>& st) override {
+        const size_t n = (size_t)n_points, m = want.size();
         rp.assign(n + 1, 0);
         truncated.assign(n, 0);
-        for (size_t i = 0; i < n; ++i) { truncated[i] = cnt[i] > cap; rp[i + 1] = rp[i] + std::min(cnt[i], cap); }
+        col.clear(); w.clear(); d0.clear(); st.clear();
+        if (m == 0) return NRS_OK;
+        const int *cnt, *fc, *fs;
+        const float *fw, *fd;
+        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &fc, &fs, &fw, &fd));   // pinned staging area, read in place
+        for (size_t r = 0; r < m; ++r) { truncated[want[r]] = cnt[r] > cap; rp[(size_t)want[r] + 1] = std::min(cnt[r], cap); }
+        for (size_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
         col.resize(rp[n]); w.resize(rp[n]); d0.resize(rp[n]); st.resize(rp[n]);
-        for (size_t i = 0; i < n; ++i) {
-            const size_t a = (size_t)rp[i], b = i * (size_t)cap, m = (size_t)(rp[i + 1] - rp[i]);
-            std::copy(fc + b, fc + b + m, col.begin() + a);
-            std::copy(fw + b, fw + b + m, w.begin() + a);
-            std::copy(fd + b, fd + b + m, d0.begin() + a);
-            std::copy(fs + b, fs + b + m, st.begin() + a);
+        for (size_t r = 0; r < m; ++r) {
+            const size_t a = (size_t)rp[want[r]], b = r * (size_t)cap, len = (size_t)(rp[(size_t)want[r] + 1] - rp[want[r]]);
+            std::copy(fc + b, fc + b + len, col.begin() + a);
+            std::copy(fw + b, fw + b + len, w.begin() + a);
+            std::copy(fd + b, fd + b + len, d0.begin() + a);
+            std::copy(fs + b, fs + b + len, st.begin() + a);
         }
         return NRS_OK;
     }
@@ -347,7 +352,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
 
     std::vector<int> orp, ocol, ost;
     std::vector<float> ow, od0;
-    NRS_TRY(src.select(orp, ocol, ow, od0, ost));
+    NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
 
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
@@ -476,8 +481,8 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     if (lost_set.empty()) return NRS_OK;
 
     // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
-    NRS_TRY(src.select(orp, ocol, ow, od0, ost));                 // GetEdges sees the updated graph
     std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
+    NRS_TRY(src.select(lost_ids, orp, ocol, ow, od0, ost));       // GetEdges sees the updated graph
     const int L = (int)lost_ids.size();
     std::vector<int> un_ij;
     std::vector<float> un_w;
