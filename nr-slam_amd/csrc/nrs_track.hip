@@ -10,6 +10,7 @@
 // part of the reference's semantics (SURVEY.md 8a "container-order dependencies").
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <set>
 #include "nrs_engine.hpp"
 
@@ -332,6 +333,14 @@ namespace nrs {
 static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
                       int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
                       int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace) {
+    const bool tm = getenv("NRS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!tm) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nrs] a2 %-22s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (trace) { trace->count = 0; trace->iterations = 0; }
     *n_lost = 0;
     if (deform_median) *deform_median = 0.f;
@@ -354,10 +363,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     std::vector<float> ow, od0;
     NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
 
+    mark("GetEdges");
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
+    for (auto& v : reg) v.reserve(24);                            // (one allocation per point: <= 11 own + the neighbours' entries)
     std::vector<int> dm_idx, sp_ij;
     std::vector<float> dm_w, sp_d0;
+    dm_idx.reserve(48 * (size_t)N); sp_ij.reserve(24 * (size_t)N); dm_w.reserve(12 * (size_t)N); sp_d0.reserve(12 * (size_t)N);
     std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
     for (int idx = 0; idx < N; ++idx) {
         const int p = ids[idx];
@@ -389,6 +401,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     }
     const int E = (int)dm_w.size();
 
+    mark("edge construction");
     // ---- engine for the two inlier rounds
     EngineSpec s;
     Pose seed;
@@ -419,6 +432,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     NRS_TRY(engine_create(c, s, &c->arena_trk, &eng));
     struct EG { nrs_ctx* c; Engine* e; ~EG() { engine_destroy(c, e); } } eg{c, eng};
 
+    mark("engine 1");
     const float th2_sq = 5.99f, th3_sq = 0.584f;
     std::vector<char> inl(N, 1);
     std::vector<double> chi_r(N), chi_d(E);
@@ -435,6 +449,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         }
         NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
     }
+    mark("two rounds");
     Pose pose_out;
     std::vector<double> delta(3 * (size_t)N);
     NRS_TRY(engine_download(c, eng, &pose_out, delta.data()));
@@ -468,6 +483,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         std::nth_element(m2.begin(), m2.begin() + N / 2, m2.end());
         *deform_median = m2[N / 2];
     }
+    mark("statistics");
     // ---- graph update OPT:457-474
     {
         std::vector<int> upd_ids, upd_idx;
@@ -478,6 +494,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         for (size_t i = 0; i < upd_ids.size(); ++i)
             if (good[i] < 10 * 0.5) f_status[opt_f[upd_idx[i]]] = NRS_BAD;
     }
+    mark("UpdateVertex");
     if (lost_set.empty()) return NRS_OK;
 
     // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
@@ -501,6 +518,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         if (!ended && !src.truncated.empty() && src.truncated[p])
             return c->fail(NRS_ERR_INVALID, "cap_per_point is too small: the neighbour walk of lost map point %d ran off its truncated list", p);
     }
+    mark("GetEdges 2 + walk");
     const int M2 = N + L;
     std::vector<double> x2(3 * (size_t)M2, 0.0), X02(3 * (size_t)M2, 0.0);
     std::copy(delta.begin(), delta.end(), x2.begin());
@@ -524,7 +542,9 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     Engine* eng2 = nullptr;
     NRS_TRY(engine_create(c, s2, &c->arena_trk, &eng2));
     eg.e = eng2;
+    mark("engine 2");
     NRS_TRY(engine_optimize(c, eng2, 10, 2, trace));
+    mark("stage 2 solve");
     std::vector<double> x_out(3 * (size_t)M2);
     NRS_TRY(engine_download(c, eng2, nullptr, x_out.data()));
     for (int li = 0; li < L; ++li) {
