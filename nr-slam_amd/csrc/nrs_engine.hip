@@ -111,8 +111,9 @@ static void launch_reg(nrs_ctx* c, const Dev& d, const double* xl) {
     if (!d.use_lds) { launch_reg2<LIN, false>(c, d, xl, 0, d.n_regblk, 0); return; }
     for (int cls = 0; cls < 2; ++cls) {
         if (d.sh_nt[cls] == 0) continue;
-        const size_t shm = (LIN && d.dform) ? sizeof(double) * 9 * (size_t)(d.tile_rows + d.cap_h[cls] + 1)
-                                            : sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
+        size_t shm = (LIN && d.dform) ? sizeof(double) * 9 * (size_t)(d.tile_rows + d.cap_h[cls] + 1)
+                                      : sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (d.X0 ? 2 : 1);
+        if (LIN) shm = std::max(shm, sizeof(double) * 4 * 64 * 8);        // the pose-block product reuses the staging area: 4 KB per wave
         launch_reg2<LIN, true>(c, d, xl, shm, d.sh_nt[cls], cls);        // (LIN: the linearisation point is d.lin_pose / xl)
     }
 }

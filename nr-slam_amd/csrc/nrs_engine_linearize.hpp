@@ -208,98 +208,6 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
         else { xs0 += P.X0[3 * row]; xs1 += P.X0[3 * row + 1]; xs2 += P.X0[3 * row + 2]; }
     }
     double D[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0}, chi = 0;
-    // ---- reprojection edge of the row (LDS path, linearisation): ReprojectionError / ...WithDeformation
-    // computeError + linearizeOplus (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68)
-    // and its quadratic form (base_fixed_sized_edge.hpp:49-63).  The first two lanes of a row take one residual
-    // component each (T = 1: one lane takes both): the H_pp / b_p partials and the row's diagonal block are sums
-    // over the two components anyway, and they leave through the reductions that follow.
-    if (LIN && LDS) {
-        constexpr int NRR = T == 1 ? 2 : 1;                 // residual components per participating lane
-        const int kf = P.grp_pose[row / ROW_ALIGN];
-        const bool pfix = P.pose_fixed[kf] != 0;
-        // an edge whose vertices are all fixed is not part of the optimisation (sparse_optimizer.cpp:236)
-        const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
-        RowRec rc;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
-        rc.w = 0;
-        double Jp[NRR][6], rres[NRR], w = 0, chi_r = 0;
-#pragma unroll
-        for (int a = 0; a < NRR; ++a) {
-            rres[a] = 0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) Jp[a][q] = 0;
-        }
-        if (active && t < (T == 1 ? 1 : 2)) {
-            const Pose Tcw = P.lin_pose[kf];
-            double Rm[9];
-            quat_to_R(Tcw.q, Rm);
-            const double px = Rm[0] * xs0 + Rm[1] * xs1 + Rm[2] * xs2 + Tcw.t[0];
-            const double py = Rm[3] * xs0 + Rm[4] * xs1 + Rm[5] * xs2 + Tcw.t[1];
-            const double pz = Rm[6] * xs0 + Rm[7] * xs1 + Rm[8] * xs2 + Tcw.t[2];
-            float u, v, Jf[6];
-            project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
-            projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
-            const double r2[2] = {(double)P.uv[2 * row] - (double)u, (double)P.uv[2 * row + 1] - (double)v};
-            double rho0, rho1;
-            huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);
-            if (t == 0) chi_r = rho0;
-            w = rho1 * P.info_reproj;
-            const double pm = pfix ? 0.0 : 1.0, lm = rfix ? 0.0 : 1.0;
-#pragma unroll
-            for (int a = 0; a < NRR; ++a) {
-                const int rr = T == 1 ? a : t;
-                const double j0 = -(double)(rr ? Jf[3] : Jf[0]), j1 = -(double)(rr ? Jf[4] : Jf[1]), j2 = -(double)(rr ? Jf[5] : Jf[2]);
-                const double r = rr ? r2[1] : r2[0];
-                rres[a] = r;
-                Jp[a][0] = pm * (-j1 * pz + j2 * py);
-                Jp[a][1] = pm * (j0 * pz - j2 * px);
-                Jp[a][2] = pm * (-j0 * py + j1 * px);
-                Jp[a][3] = pm * j0; Jp[a][4] = pm * j1; Jp[a][5] = pm * j2;
-                const double Jl0 = lm * (j0 * Rm[0] + j1 * Rm[3] + j2 * Rm[6]);
-                const double Jl1 = lm * (j0 * Rm[1] + j1 * Rm[4] + j2 * Rm[7]);
-                const double Jl2 = lm * (j0 * Rm[2] + j1 * Rm[5] + j2 * Rm[8]);
-                D[0] += w * (Jl0 * Jl0); D[1] += w * (Jl0 * Jl1); D[2] += w * (Jl0 * Jl2);
-                D[3] += w * (Jl1 * Jl1); D[4] += w * (Jl1 * Jl2); D[5] += w * (Jl2 * Jl2);
-                bb[0] -= w * (Jl0 * r); bb[1] -= w * (Jl1 * r); bb[2] -= w * (Jl2 * r);
-            }
-            if (t == 0) {
-                // factored form: the PCG kernels rebuild J_l, J_p from these 32 bytes
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
-                rc.w = lm * w;
-            }
-        }
-        if (t == 0) P.rowrec[row] = rc;
-        // H_pp (21 packed) / b_p (6) / chi2 partials of the tile: every value is formed right before its wave
-        // reduction, so the 28 of them never sit in registers together
-        int k = 0;
-#pragma unroll
-        for (int pp = 0; pp < 6; ++pp)
-#pragma unroll
-            for (int q = pp; q < 6; ++q) {
-                double v = 0;
-#pragma unroll
-                for (int a = 0; a < NRR; ++a) v += Jp[a][pp] * Jp[a][q];
-                const double sm = wave_sum(w * v);
-                if (lane == 0) lds28[wave * 28 + k] = sm;
-                ++k;
-            }
-#pragma unroll
-        for (int pp = 0; pp < 6; ++pp) {
-            double v = 0;
-#pragma unroll
-            for (int a = 0; a < NRR; ++a) v += Jp[a][pp] * rres[a];
-            const double sm = wave_sum(-w * v);
-            if (lane == 0) lds28[wave * 28 + 21 + pp] = sm;
-        }
-        {
-            const double sm = wave_sum(chi_r);
-            if (lane == 0) lds28[wave * 28 + 27] = sm;
-        }
-        __syncthreads();
-        if (tid < 28) P.part_lin[(size_t)b * 32 + tid] = lds28[tid] + lds28[28 + tid] + lds28[56 + tid] + lds28[84 + tid];
-    }
     // ---- springs
     const size_t nz = (size_t)P.ss_nnz;
     auto spring = [&](int idx, int o, int meta, double d0) {
@@ -472,6 +380,117 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
                 damper(idx, meta, o, P.d_w[idx]);
             }
         }
+    }
+    // ---- reprojection edge of the row (LDS path, linearisation; after the incidence loops: the staged positions are dead by
+    // then and their LDS holds the operands of the pose-block product): ReprojectionError / ...WithDeformation
+    // computeError + linearizeOplus (reference reprojection_error.cc:32-64, reprojection_error_with_deformation.cc:37-68)
+    // and its quadratic form (base_fixed_sized_edge.hpp:49-63).  The first two lanes of a row take one residual
+    // component each (T = 1: one lane takes both): the H_pp / b_p partials and the row's diagonal block are sums
+    // over the two components anyway, and they leave through the reductions that follow.
+    if (LIN && LDS) {
+        constexpr int NRR = T == 1 ? 2 : 1;                 // residual components per participating lane
+        const int kf = P.grp_pose[row / ROW_ALIGN];
+        const bool pfix = P.pose_fixed[kf] != 0;
+        // an edge whose vertices are all fixed is not part of the optimisation (sparse_optimizer.cpp:236)
+        const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
+        RowRec rc;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
+        rc.w = 0;
+        double Jp[NRR][6], rres[NRR], w = 0, chi_r = 0;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            rres[a] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jp[a][q] = 0;
+        }
+        if (active && t < (T == 1 ? 1 : 2)) {
+            const Pose Tcw = P.lin_pose[kf];
+            double Rm[9];
+            quat_to_R(Tcw.q, Rm);
+            const double px = Rm[0] * xs0 + Rm[1] * xs1 + Rm[2] * xs2 + Tcw.t[0];
+            const double py = Rm[3] * xs0 + Rm[4] * xs1 + Rm[5] * xs2 + Tcw.t[1];
+            const double pz = Rm[6] * xs0 + Rm[7] * xs1 + Rm[8] * xs2 + Tcw.t[2];
+            float u, v, Jf[6];
+            project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+            projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
+            const double r2[2] = {(double)P.uv[2 * row] - (double)u, (double)P.uv[2 * row + 1] - (double)v};
+            double rho0, rho1;
+            huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);
+            if (t == 0) chi_r = rho0;
+            w = rho1 * P.info_reproj;
+            const double pm = pfix ? 0.0 : 1.0, lm = rfix ? 0.0 : 1.0;
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                const int rr = T == 1 ? a : t;
+                const double j0 = -(double)(rr ? Jf[3] : Jf[0]), j1 = -(double)(rr ? Jf[4] : Jf[1]), j2 = -(double)(rr ? Jf[5] : Jf[2]);
+                const double r = rr ? r2[1] : r2[0];
+                rres[a] = r;
+                Jp[a][0] = pm * (-j1 * pz + j2 * py);
+                Jp[a][1] = pm * (j0 * pz - j2 * px);
+                Jp[a][2] = pm * (-j0 * py + j1 * px);
+                Jp[a][3] = pm * j0; Jp[a][4] = pm * j1; Jp[a][5] = pm * j2;
+                const double Jl0 = lm * (j0 * Rm[0] + j1 * Rm[3] + j2 * Rm[6]);
+                const double Jl1 = lm * (j0 * Rm[1] + j1 * Rm[4] + j2 * Rm[7]);
+                const double Jl2 = lm * (j0 * Rm[2] + j1 * Rm[5] + j2 * Rm[8]);
+                D[0] += w * (Jl0 * Jl0); D[1] += w * (Jl0 * Jl1); D[2] += w * (Jl0 * Jl2);
+                D[3] += w * (Jl1 * Jl1); D[4] += w * (Jl1 * Jl2); D[5] += w * (Jl2 * Jl2);
+                bb[0] -= w * (Jl0 * r); bb[1] -= w * (Jl1 * r); bb[2] -= w * (Jl2 * r);
+            }
+            if (t == 0) {
+                // factored form: the PCG kernels rebuild J_l, J_p from these 32 bytes
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
+                rc.w = lm * w;
+            }
+        }
+        if (t == 0) P.rowrec[row] = rc;
+        // H_pp (21 packed) / b_p (6) partials of the tile = the dense pose block of the normal equations,
+        //   [H_pp | b_p] = sum_k (w_k Jp_k)^T [Jp_k | -r_k]     (k = the wave's 64 lanes: one residual component each)
+        // a (6 x 64) x (64 x 7) product per wave: sixteen v_mfma_f64_16x16x4 instead of 27 wave reductions.  Every lane
+        // leaves its seven values and its weight in LDS; for MFMA m lane (e = lane % 16, kk = lane / 16) supplies
+        // A[e][kk] = w Jp[e] and B[kk][e] = Jp[e] | -r of lane 4 m + kk.  Result layout of the f64 form: register g of a lane
+        // holds C[row = kk + 4 g][col = e].
+        {
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            __syncthreads();                                       // every wave is done with the staged positions
+            double* mb = dyn + wave * 512;                         // [64 lanes][8], the wave's own
+            const int e = lane & 15, kk = lane >> 4;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                // (the buffer is the wave's own: its LDS operations execute in order, a wave-level fence is all it takes)
+                if (a > 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) mb[lane * 8 + q] = Jp[a][q];
+                mb[lane * 8 + 6] = -rres[a];
+                mb[lane * 8 + 7] = w;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+                for (int m = 0; m < 16; ++m) {
+                    const int kq = 4 * m + kk;
+                    const double val = e < 7 ? mb[kq * 8 + e] : 0.0;
+                    const double av = e < 6 ? mb[kq * 8 + 7] * val : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, val, acc, 0, 0, 0);
+                }
+            }
+            auto put = [&](int row, double c) {
+                if (row < 6) {
+                    if (e >= row && e < 6) lds28[wave * 28 + row * 6 - (row * (row - 1)) / 2 + (e - row)] = c;
+                    if (e == 6) lds28[wave * 28 + 21 + row] = c;
+                }
+            };
+            put(kk, acc.x);
+            put(4 + kk, acc.y);
+        }
+        {
+            const double sm = wave_sum(chi_r);
+            if (lane == 0) lds28[wave * 28 + 27] = sm;
+        }
+        __syncthreads();
+        if (tid < 28) P.part_lin[(size_t)b * 32 + tid] = lds28[tid] + lds28[28 + tid] + lds28[56 + tid] + lds28[84 + tid];
     }
     double part[2];
     part[0] = chi;
