@@ -168,3 +168,14 @@ def test_comm_needs_a_context(lib_built):
     g.close()
     with pytest.raises(nrs.NrsError):
         nrs.LocalGroup(9)
+
+
+def test_skinned_status_demotes_everything_but_the_nodes():
+    """skinned mode (include/nrs.h N2): nodes keep TRACKED_WITH_3D, other tracked points of the frame become TRACKED, slots
+    without a map point and other statuses are left alone"""
+    import nrs
+    f_status = np.array([0, 0, 0, 1, 3, 0, 2, 0], np.int32)
+    f_map = np.array([5, 2, 7, 1, 0, -1, 3, 4], np.int32)
+    st = nrs.skinned_status(f_status, f_map, [2, 4])
+    assert st.tolist() == [1, 0, 1, 1, 3, 0, 2, 0]
+    assert f_status.tolist() == [0, 0, 0, 1, 3, 0, 2, 0]                      # the input is not modified
