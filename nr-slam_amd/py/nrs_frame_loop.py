@@ -82,8 +82,9 @@ def project_f32(model, prm, p):
 class GpuBackend:
     """The product path: two nrs contexts (each owns one LucasKanadeTracker state)."""
 
-    def __init__(self, nrs, model, prm, klt_opts):
+    def __init__(self, nrs, model, prm, klt_opts, dense_graph=False, cap_per_point=64):
         self.nrs = nrs
+        self.dense, self.cap, self.rg = dense_graph, cap_per_point, None
         self.cam = nrs.make_camera(model, prm)
         self.ctx = nrs.Context()
         self.ctx_reuse = nrs.Context()
@@ -121,11 +122,27 @@ class GpuBackend:
         q2, t2, _ = self.ctx.pose_only_solve(self.cam, uv, X, q, t)
         return q2, t2
 
+    # dense_graph: the map's RegularizationGraph at the reference's density -- every pair of initial map points connected
+    # (modules/map/map.cc:148-166) -- resident on the device; otherwise the caller's flat graph
+    def make_graph(self, graph, X0):
+        if not self.dense:
+            return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+        ids = np.arange(len(X0), dtype=np.int32)
+        self.rg = self.nrs.RGraph(self.ctx, len(X0), graph["sigma"], graph["stretch_th"])
+        self.rg.add_edges(np.asarray(X0, F32), ids, ids)
+        return self.rg
+
     def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
         self.last_trace = self.nrs.Trace(1024)
+        if self.dense:
+            r = self.ctx.track_deform_solve_rg(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale, self.last_trace, self.cap)
+            r["graph"] = graph                                     # updated in place on the device
+            return r
         return self.ctx.track_deform_solve(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale, self.last_trace)
 
     def close(self):
+        if self.rg is not None:
+            self.rg.close()
         self.ctx.close()
         self.ctx_reuse.close()
 
@@ -144,7 +161,9 @@ class FrameLoop:
         self.map_index = np.arange(n, dtype=np.int32)
         # map
         self.map_pos = np.asarray(X0, F32).copy()                  # MapPoint::GetLastWorldPosition
-        self.graph = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+        # the caller's flat graph, or (a backend that keeps one) the all-pairs graph of the map
+        self.graph = backend.make_graph(graph, X0) if hasattr(backend, "make_graph") else \
+            {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
         self.pose = (np.asarray(pose_q, F32), np.asarray(pose_t, F32))
         self.last_pose = self.pose
         self.motion = (np.array([0, 0, 0, 1], F32), np.zeros(3, F32))

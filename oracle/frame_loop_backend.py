@@ -40,8 +40,8 @@ def _insert_template(lk, t):
 
 
 class OracleBackend:
-    def __init__(self, model, prm, klt_opts):
-        self.model, self.prm, self.o = model, prm, klt_opts
+    def __init__(self, model, prm, klt_opts, dense_graph=False):
+        self.model, self.prm, self.o, self.dense = model, prm, klt_opts, dense_graph
         self.lk = LK.LucasKanadeOracle(klt_opts["win"], klt_opts["max_level"], klt_opts["max_iters"], klt_opts["epsilon"], klt_opts["min_eig"])
 
     def klt_set_reference(self, im, pts):
@@ -73,6 +73,15 @@ class OracleBackend:
     def pose_only(self, uv, X, q, t):
         q2, t2, _ = O.pose_only_solve(self.model, self.prm, uv, X, q, t)
         return q2, t2
+
+    def make_graph(self, graph, X0):
+        if not self.dense:
+            return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+        import rgraph_oracle as RG                                  # all pairs (modules/map/map.cc:148-166)
+        g = RG.DenseGraph(len(X0), graph["sigma"], graph["stretch_th"])
+        ids = np.arange(len(X0))
+        g.add_edges(np.asarray(X0, F32), ids, ids)
+        return g
 
     def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
         return O.track_deform_solve(self.model, self.prm, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale)

@@ -24,15 +24,17 @@ def _run(backend, sq, n_frames, kf_every):
     return loop.log
 
 
-@pytest.mark.parametrize("n,frames,seed,model", [(260, 5, 9, S.PINHOLE), (200, 4, 12, S.KB8)])
-def test_frame_loop_matches_oracle_loop(n, frames, seed, model):
+@pytest.mark.parametrize("n,frames,seed,model,dense", [(260, 5, 9, S.PINHOLE, False), (200, 4, 12, S.KB8, False),
+                                                        (240, 4, 14, S.PINHOLE, True)])
+def test_frame_loop_matches_oracle_loop(n, frames, seed, model, dense):
+    """dense: the map's graph at the reference's density (all pairs, device resident / oracle DenseGraph) instead of a flat kNN graph"""
     sq = S.make_frame_sequence(n, frames, seed, model)
-    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS, dense_graph=dense)
     try:
         glog = _run(gb, sq, frames, 2)
     finally:
         gb.close()
-    olog = _run(OracleBackend(sq["model"], sq["prm"], OPTS), sq, frames, 2)
+    olog = _run(OracleBackend(sq["model"], sq["prm"], OPTS, dense_graph=dense), sq, frames, 2)
     assert any(L["keyframe"] for L in glog) and any(L["reused"] > 0 for L in glog)
     assert any((L["status_by_map"] != FL.TRACKED_WITH_3D).any() for L in glog)      # the occluders do knock points out
     for f, (g, o) in enumerate(zip(glog, olog), 1):
