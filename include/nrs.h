@@ -320,8 +320,9 @@ int nrs_track_deform_solve(nrs_ctx* ctx, const nrs_camera* cam, nrs_graph* g, fl
 /* The same function with the RegularizationGraph held on the device at the reference's all-pairs density (nrs_rgraph,
  * above): GetEdges (OPT:252, 496) and UpdateVertex (OPT:468) are served from it, so a point's good-connection count is
  * taken over all of its N - 1 connections as in the reference (the "fewer than 5 -> BAD" rule, OPT:470-473).
- * n_points = the graph's capacity = rows of map_pos; cap_per_point = how much of each point's GetEdges list is fetched
- * (NRS_ERR_INVALID if the walk of OPT:255-279 reaches the end of a truncated list). */
+ * n_points = the graph's capacity = rows of map_pos; cap_per_point = how much of each point's GetEdges list is fetched at
+ * first (if a walk of OPT:255-279 reaches the end of a truncated list, four times as much is fetched and the walks start
+ * over: the result does not depend on cap_per_point, the time does). */
 int nrs_track_deform_solve_rg(nrs_ctx* ctx, const nrs_camera* cam, nrs_rgraph* g, int32_t n_points, int32_t cap_per_point,
                               float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
                               float* f_pos, double pose_qt[7], float scale, float* deform_median, int32_t* n_lost,

@@ -214,6 +214,7 @@ struct NeighbourSource {
     // UpdateVertex of the listed points from the last world positions; good[i] = its return value
     virtual int update(const float* map_pos, int n, const int* ids, int* good) = 0;
     std::vector<char> truncated;      // per point: select() returned only a prefix of its list
+    virtual bool grow() { return false; }                          // fetch longer prefixes next time (false: there is nothing longer)
 };
 
 struct FlatSource : NeighbourSource {
@@ -257,6 +258,7 @@ struct DenseSource : NeighbourSource {
         }
         return NRS_OK;
     }
+    bool grow() override { if (cap >= n_points) return false; cap = std::min(n_points, 4 * cap); return true; }
     int update(const float* map_pos, int n, const int* ids, int* good) override { return n ? nrs_rgraph_update(g, map_pos, n, ids, good) : NRS_OK; }
 };
 
@@ -361,9 +363,6 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
 
     std::vector<int> orp, ocol, ost;
     std::vector<float> ow, od0;
-    NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
-
-    mark("GetEdges");
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
     for (auto& v : reg) v.reserve(24);                            // (one allocation per point: <= 11 own + the neighbours' entries)
@@ -371,7 +370,12 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     std::vector<float> dm_w, sp_d0;
     dm_idx.reserve(48 * (size_t)N); sp_ij.reserve(24 * (size_t)N); dm_w.reserve(12 * (size_t)N); sp_d0.reserve(12 * (size_t)N);
     std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
-    for (int idx = 0; idx < N; ++idx) {
+    for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
+    again = false;
+    NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
+    for (auto& v : reg) v.clear();
+    dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); lost_set.clear();
+    for (int idx = 0; idx < N && !again; ++idx) {
         const int p = ids[idx];
         int n_reg = 0;
         bool ended = false;
@@ -396,12 +400,15 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             reg[io].push_back({idx, k});
             ++n_reg;
         }
-        if (!ended && !src.truncated.empty() && src.truncated[p])
-            return c->fail(NRS_ERR_INVALID, "cap_per_point is too small: the neighbour walk of map point %d ran off its truncated list", p);
+        if (!ended && !src.truncated.empty() && src.truncated[p]) {
+            if (!src.grow()) return c->fail(NRS_ERR_INVALID, "the neighbour walk of map point %d ran off its list", p);
+            again = true;
+        }
     }
+    }
+    mark("GetEdges + edge construction");
     const int E = (int)dm_w.size();
 
-    mark("edge construction");
     // ---- engine for the two inlier rounds
     EngineSpec s;
     Pose seed;
@@ -499,11 +506,14 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
 
     // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
     std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
-    NRS_TRY(src.select(lost_ids, orp, ocol, ow, od0, ost));       // GetEdges sees the updated graph
     const int L = (int)lost_ids.size();
     std::vector<int> un_ij;
     std::vector<float> un_w;
-    for (int li = 0; li < L; ++li) {
+    for (bool again = true; again;) {
+    again = false;
+    NRS_TRY(src.select(lost_ids, orp, ocol, ow, od0, ost));       // GetEdges sees the updated graph
+    un_ij.clear(); un_w.clear();
+    for (int li = 0; li < L && !again; ++li) {
         const int p = lost_ids[li];
         int n_reg = 0;
         bool ended = false;
@@ -515,8 +525,11 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             un_w.push_back(ow[a]);
             ++n_reg;
         }
-        if (!ended && !src.truncated.empty() && src.truncated[p])
-            return c->fail(NRS_ERR_INVALID, "cap_per_point is too small: the neighbour walk of lost map point %d ran off its truncated list", p);
+        if (!ended && !src.truncated.empty() && src.truncated[p]) {
+            if (!src.grow()) return c->fail(NRS_ERR_INVALID, "the neighbour walk of lost map point %d ran off its list", p);
+            again = true;
+        }
+    }
     }
     mark("GetEdges 2 + walk");
     const int M2 = N + L;

@@ -61,3 +61,30 @@ def test_skinned_pose_and_deformation(ctx, n, m, seed, model):
     assert np.median(moved) > 1e-3                               # the skinned points did follow the nodes
     assert compare_lm_traces(tr.trials, otr, len(otr)) >= 6
     g.close()
+
+
+def test_result_does_not_depend_on_cap_per_point(ctx):
+    """a walk that runs off a truncated GetEdges prefix makes the driver fetch four times as much and start over: the
+    skinned solve (walks ~10x longer than in parity mode) from cap_per_point = 8 equals the one from 512, bit for bit"""
+    import nrs_synth as S
+    n, m = 500, 60
+    tp = S.make_tracking_problem(n, 41)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    ids = np.arange(n, dtype=np.int32)
+    st = nrs.skinned_status(tp["status"], ids, ctx.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0))
+    out = []
+    for cap in (8, 512):
+        g = nrs.RGraph(ctx, n, tp["graph"]["sigma"], tp["graph"]["stretch_th"])
+        g.add_edges(tp["X_prev"], ids, ids)
+        tr = nrs.Trace(1024)
+        r = ctx.track_deform_solve_rg(cam, g, tp["X_prev"], ids, st, tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr, cap)
+        out.append((r, [(t["lam"], t["chi"], t["chi_new"], t["accepted"]) for t in tr.trials], g.rows(ids[:40])))
+        g.close()
+    a, b = out
+    assert a[1] == b[1] and a[0]["lost"] == b[0]["lost"]
+    for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[2][3], b[2][3])                                       # statuses of the dense rows
+    ex = a[2][3] != 255                                                           # (slots without an edge hold no data)
+    for x, y in zip(a[2][:3], b[2][:3]):
+        assert np.array_equal(x[ex], y[ex])
