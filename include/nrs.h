@@ -380,7 +380,11 @@ int nrs_klt_insert_templates(nrs_ctx* ctx, int32_t count, const float* xy, const
  * (modules/optimization/g2o_optimization.cc:476-553, spatial_regularizer_fixed.cc:32-43): points of the frame that are not
  * optimised follow <= 11 optimised graph neighbours.  Skinned mode = that algorithm with a chosen node set: the nodes
  * keep NRS_TRACKED_WITH_3D, every other point of the frame is handed over as NRS_TRACKED (in the frame, no 3D), and
- * nrs_track_deform_solve / nrs_track_deform_solve_rg run unchanged.  This call chooses the nodes: farthest point
+ * nrs_track_deform_solve / nrs_track_deform_solve_rg run unchanged.  Coverage is the reference's, not "every point": stage 2
+ * carries the points of the lost set, i.e. the non-node points met during some node's GetEdges walk before that walk stops
+ * (11 accepted node neighbours or the first BAD edge, OPT:255-279).  A non-node point outside every node's walked prefix is
+ * not in `lost`, keeps its old position and its NRS_TRACKED status: callers find them as "status NRS_TRACKED and not listed
+ * in lost" (farthest point sampling with n_nodes >= n_points / 10 leaves < 10 % of them on the synthetic frames).  This call chooses the nodes: farthest point
  * sampling over the eligible points (eligible == NULL: all), first pick = lowest eligible index, fp32 squared distances,
  * ties to the lowest index.  node_ids[n_nodes] in pick order.  NRS_ERR_INVALID if fewer points are eligible. */
 int nrs_skin_select_nodes(nrs_ctx* ctx, int32_t n_points, const float* pos /* n_points x 3 */, const uint8_t* eligible /* nullable */,

@@ -86,6 +86,21 @@ template <bool LIN, bool LDS>
 static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, int n, int cls) {
     const dim3 g(((n + 7) / 8) * 8), b(BLK);
     if constexpr (LIN && LDS) {
+        if (d.plain) {                                             // plain BA window: the specialised pass
+            switch (d.T) {
+                case 1: hipLaunchKernelGGL((k_lin_plain<1>), g, b, shm, c->stream, d, xl, cls); break;
+                case 4: hipLaunchKernelGGL((k_lin_plain<4>), g, b, shm, c->stream, d, xl, cls); break;
+                case 8: hipLaunchKernelGGL((k_lin_plain<8>), g, b, shm, c->stream, d, xl, cls); break;
+                case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
+                default: {
+                    static const int occ = getenv("NRS_LIN_OCC") ? atoi(getenv("NRS_LIN_OCC")) : 4;
+                    if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3>), g, b, shm, c->stream, d, xl, cls);
+                    else hipLaunchKernelGGL((k_lin_plain<2, 4>), g, b, shm, c->stream, d, xl, cls);
+                    break;
+                }
+            }
+            return;
+        }
         if (d.dform) {                                             // temporal-difference dampers (two-kernel path: T = 2 unless overridden)
             switch (d.T) {
                 case 1: hipLaunchKernelGGL((k_reg<1, true, true, true>), g, b, shm, c->stream, d, xl, cls); break;

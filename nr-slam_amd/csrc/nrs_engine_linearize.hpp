@@ -530,6 +530,261 @@ __global__ __launch_bounds__(BLK) void k_reg(Dev P, const double* __restrict__ x
 }
 
 // =====================================================================================
+// The same fused pass for PLAIN deformable-BA windows (LocalDeformableBundleAdjustment as the reference builds it,
+// OPT:927-1137: nothing fixed, no masks, no offsets, every damper with its four vertices, springs without a robust
+// kernel) on the LDS path -- the case the benchmark configurations C2-C5 are.  Same streams in, same outputs as
+// k_reg<T, true, true> (per-incidence factors, row factors, D, b_l, tile partials); what differs is the instruction
+// count: the incidence bodies are branch-free (padding slots run on safe operands and contribute zeros) and free of the
+// mask / level / fixed-vertex logic, and the spring's 1/d0, 1/d, 1/sqrt(d) come from the hardware estimates plus
+// Newton steps written out (positive normal operands by construction) instead of the library's division and sqrt
+// sequences.  Reference arithmetic: position_regularizer.cc:32-61 (Jacobian as written), spatial_regularizer.cc:32-59,
+// reprojection_error.cc:32-64, base_fixed_sized_edge.hpp:49-133.
+// =====================================================================================
+__device__ inline double fast_rcp_pos(double a) {                   // 1/a, a > 0 normal: v_rcp_f64 + two Newton steps (<= 1 ulp)
+    double y = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ inline double fast_rsqrt_pos(double a) {                 // a^-1/2, a > 0 normal: v_rsq_f64 + one third-order step
+    const double y = __builtin_amdgcn_rsq(a);
+    const double e = fma(-a * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+__device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a > 0 normal: rsq estimate + two coupled Newton steps
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double e2 = fma(-g, g, a);
+    return fma(e2, h, g);
+}
+
+template <int T, int OCC = 4>
+__global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
+    __shared__ double lds[4 * 2];
+    __shared__ double lds28[4 * 28];
+    extern __shared__ double dyn[];
+    constexpr int R = 64 / T;
+    constexpr int U = 2;
+    int b = xcd_tile(blockIdx.x, P.sh_nt[cls]);
+    if (b >= P.sh_nt[cls]) return;
+    b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = b * 4 + wave;
+    const int row = slice * R + lane / T;
+    const int t = lane % T;
+    const int rf = P.rflag[row];
+    const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
+    const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
+    uint2 shA[U], shB[U], dhA[U], dhB[U];
+    float dwA[U], dwB[U];
+    auto load_sh = [&](uint2* h, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0xFFFFu, 0x3F800000u);                // padding: no neighbour, rest length 1
+            if (j < s_end) h[q] = make_uint2(P.s_om[j], __float_as_uint(P.s_d0[j]));
+        }
+    };
+    auto load_dh = [&](uint2* h, float* w, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int j = idx + 64 * q;
+            h[q] = make_uint2(0u, 0xFFFF0000u);
+            w[q] = 0.f;
+            if (j < d_end) { h[q] = P.d_hdr[j]; w[q] = P.d_w[j]; }
+        }
+    };
+    load_sh(shA, s_beg + lane);
+    load_dh(dhA, dwA, d_beg + lane);
+    double* lx = dyn;
+    stage_rows(P, b, tid, xl_g, nullptr, lx);
+    __syncthreads();
+    const int self = row - b * P.tile_rows;
+    const double xo0 = lx[3 * self], xo1 = lx[3 * self + 1], xo2 = lx[3 * self + 2];
+    double D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0, D5 = 0, bb0 = 0, bb1 = 0, bb2 = 0, chi = 0;
+    // ---- springs: r = k (d - d0) / d0, J = cg (x_i - x_j)^T with cg = (k / d0) 2 / sqrt(d) as the reference writes it
+    // (position_regularizer.cc:51-60) or k / (d0 d) (tracking form); information info_pos, no kernel
+    const double ks = P.k_spring, ip = P.info_pos;
+    const bool ba_form = P.spring_form == 0;
+    auto do_sh = [&](const uint2* hdr, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const uint32_t om = hdr[q].x;
+            const int o16 = (int)(om & 0xFFFFu);
+            const bool pad = o16 == REC_NONE;                       // (slots past the slice's end were loaded as padding)
+            const int o = pad ? self : o16;
+            const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
+            double d2 = v0 * v0 + v1 * v1 + v2 * v2;
+            d2 = pad ? 1.0 : d2;
+            const double d0 = pad ? 1.0 : (double)__uint_as_float(hdr[q].y);
+            const double rs = fast_rsqrt_pos(d2), id0 = fast_rcp_pos(d0);
+            const double r = ks * fma(d2, rs, -d0) * id0;
+            const double cg = ba_form ? 2.0 * ks * id0 * fast_sqrt_pos(rs) : ks * id0 * rs;
+            const double qc = pad ? 0.0 : ip * cg * cg;
+            if (idx + 64 * q < s_end) P.s_qc[idx + 64 * q] = qc;
+            chi += (om & ((uint32_t)SR_COUNT << 16)) && !pad ? ip * r * r : 0.0;
+            const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
+            D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
+            D3 = fma(t1, v1, D3); D4 = fma(t1, v2, D4); D5 = fma(t2, v2, D5);
+            const double qr = ip * r * cg;                          // (v = 0 on padding slots)
+            bb0 = fma(-qr, v0, bb0); bb1 = fma(-qr, v1, bb1); bb2 = fma(-qr, v2, bb2);
+        }
+    };
+    for (int base = s_beg; base < s_end; base += 128 * U) {        // wave-uniform trip count
+        load_sh(shB, base + 64 * U + lane);
+        do_sh(shA, base + lane);
+        load_sh(shA, base + 128 * U + lane);
+        do_sh(shB, base + 64 * U + lane);
+    }
+    // ---- dampers: r = w ((x1n - x1c) - (x2n - x2c)); the records list the three others in canonical order
+    // (engine_create), so that sg_i * sum_k sg_k x_k = (x_i - x[o1]) - (x[o0] - x[o2]) for every role
+    const double isp = P.info_spatial, dsp = P.delta_spatial;
+    auto do_dh = [&](const uint2* hdr, const float* ww, int idx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const uint32_t m16 = hdr[q].y >> 16;
+            const bool pad = m16 == REC_NONE;
+            const int o0 = pad ? self : (int)(hdr[q].x & 0xFFFFu), o1 = pad ? self : (int)(hdr[q].x >> 16), o2 = pad ? self : (int)(hdr[q].y & 0xFFFFu);
+            const double g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
+            const double g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
+            const double g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+            const double w = pad ? 0.0 : (double)ww[q];
+            const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
+            double rho0, rho1;
+            huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
+            chi += (m16 & DM_COUNT) ? rho0 : 0.0;                  // (padding: rho0 = 0)
+            const double sfac = rho1 * isp * w * w;
+            if (idx + 64 * q < d_end) P.d_s[idx + 64 * q] = sfac;
+            D0 += sfac; D3 += sfac; D5 += sfac;
+            bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
+        }
+    };
+    for (int base = d_beg; base < d_end; base += 128 * U) {
+        load_dh(dhB, dwB, base + 64 * U + lane);
+        do_dh(dhA, dwA, base + lane);
+        load_dh(dhA, dwA, base + 128 * U + lane);
+        do_dh(dhB, dwB, base + 64 * U + lane);
+    }
+    // ---- reprojection edge of the row (as in k_reg: the first two lanes of a row take one residual component each)
+    constexpr int NRR = T == 1 ? 2 : 1;
+    const int kf = P.grp_pose[row / ROW_ALIGN];
+    const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE);
+    RowRec rc;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rc.J[q] = 0.f;
+    rc.w = 0;
+    double Jp[NRR][6], rres[NRR], w = 0, chi_r = 0;
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        rres[a] = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jp[a][q] = 0;
+    }
+    if (active && t < (T == 1 ? 1 : 2)) {
+        const Pose Tcw = P.lin_pose[kf];
+        double Rm[9];
+        quat_to_R(Tcw.q, Rm);
+        const double px = Rm[0] * xo0 + Rm[1] * xo1 + Rm[2] * xo2 + Tcw.t[0];
+        const double py = Rm[3] * xo0 + Rm[4] * xo1 + Rm[5] * xo2 + Tcw.t[1];
+        const double pz = Rm[6] * xo0 + Rm[7] * xo1 + Rm[8] * xo2 + Tcw.t[2];
+        float u, v, Jf[6];
+        project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+        projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
+        const double r2[2] = {(double)P.uv[2 * row] - (double)u, (double)P.uv[2 * row + 1] - (double)v};
+        double rho0, rho1;
+        huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);
+        if (t == 0) chi_r = rho0;
+        w = rho1 * P.info_reproj;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            const int rr = T == 1 ? a : t;
+            const double j0 = -(double)(rr ? Jf[3] : Jf[0]), j1 = -(double)(rr ? Jf[4] : Jf[1]), j2 = -(double)(rr ? Jf[5] : Jf[2]);
+            const double r = rr ? r2[1] : r2[0];
+            rres[a] = r;
+            Jp[a][0] = -j1 * pz + j2 * py;
+            Jp[a][1] = j0 * pz - j2 * px;
+            Jp[a][2] = -j0 * py + j1 * px;
+            Jp[a][3] = j0; Jp[a][4] = j1; Jp[a][5] = j2;
+            const double Jl0 = j0 * Rm[0] + j1 * Rm[3] + j2 * Rm[6];
+            const double Jl1 = j0 * Rm[1] + j1 * Rm[4] + j2 * Rm[7];
+            const double Jl2 = j0 * Rm[2] + j1 * Rm[5] + j2 * Rm[8];
+            D0 += w * (Jl0 * Jl0); D1 += w * (Jl0 * Jl1); D2 += w * (Jl0 * Jl2);
+            D3 += w * (Jl1 * Jl1); D4 += w * (Jl1 * Jl2); D5 += w * (Jl2 * Jl2);
+            bb0 -= w * (Jl0 * r); bb1 -= w * (Jl1 * r); bb2 -= w * (Jl2 * r);
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rc.J[q] = Jf[q];
+            rc.w = w;
+        }
+    }
+    if (t == 0) P.rowrec[row] = rc;
+    // [H_pp | b_p] partials of the tile on the matrix cores (see k_reg)
+    {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        __syncthreads();                                           // every wave is done with the staged positions
+        double* mb = dyn + wave * 512;                             // [64 lanes][8], the wave's own
+        const int e = lane & 15, kk = lane >> 4;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            if (a > 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) mb[lane * 8 + q] = Jp[a][q];
+            mb[lane * 8 + 6] = -rres[a];
+            mb[lane * 8 + 7] = w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+            for (int m = 0; m < 16; ++m) {
+                const int kq = 4 * m + kk;
+                const double val = e < 7 ? mb[kq * 8 + e] : 0.0;
+                const double av = e < 6 ? mb[kq * 8 + 7] * val : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, val, acc, 0, 0, 0);
+            }
+        }
+        auto put = [&](int prow, double c) {
+            if (prow < 6) {
+                if (e >= prow && e < 6) lds28[wave * 28 + prow * 6 - (prow * (prow - 1)) / 2 + (e - prow)] = c;
+                if (e == 6) lds28[wave * 28 + 21 + prow] = c;
+            }
+        };
+        put(kk, acc.x);
+        put(4 + kk, acc.y);
+    }
+    {
+        const double sm = wave_sum(chi_r);
+        if (lane == 0) lds28[wave * 28 + 27] = sm;
+    }
+    __syncthreads();
+    if (tid < 28) P.part_lin[(size_t)b * 32 + tid] = lds28[tid] + lds28[28 + tid] + lds28[56 + tid] + lds28[84 + tid];
+    D0 = sub_sum_t<T>(D0); D1 = sub_sum_t<T>(D1); D2 = sub_sum_t<T>(D2);
+    D3 = sub_sum_t<T>(D3); D4 = sub_sum_t<T>(D4); D5 = sub_sum_t<T>(D5);
+    bb0 = sub_sum_t<T>(bb0); bb1 = sub_sum_t<T>(bb1); bb2 = sub_sum_t<T>(bb2);
+    double md = 0;
+    if (t == 0) {
+        double* Dr = P.D + 6 * (size_t)row;
+        Dr[0] = D0; Dr[1] = D1; Dr[2] = D2; Dr[3] = D3; Dr[4] = D4; Dr[5] = D5;
+        P.bl[3 * row] = bb0; P.bl[3 * row + 1] = bb1; P.bl[3 * row + 2] = bb2;
+        md = fmax(fabs(D0), fmax(fabs(D3), fabs(D5)));
+    }
+    const double c = wave_sum(chi);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
+    if (lane == 0) { lds[wave * 2] = c; lds[wave * 2 + 1] = md; }
+    __syncthreads();
+    if (tid == 0) {
+        P.part_reg[2 * (size_t)b] = lds[0] + lds[2] + lds[4] + lds[6];
+        P.part_reg[2 * (size_t)b + 1] = fmax(fmax(lds[1], lds[3]), fmax(lds[5], lds[7]));
+    }
+}
+
+// =====================================================================================
 // chi2 of a trial state, one thread per edge (BA windows: no masks, nothing fixed).  Same residuals and
 // Huber as k_reg; only the order of the sum differs from the incidence-ordered one (relative 1e-16).
 // =====================================================================================

@@ -523,7 +523,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<int> L_s(nnz_s, -1), L_d(3 * nnz_d, -1);      // tile-local ids
     {
         // tiles are independent: a few host threads each take a contiguous range of tiles
-        const int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 32}));   // (a 4.5k-point frame: 4 threads, 1.5 -> 0.5 ms)
+        int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 32}));   // (a 4.5k-point frame: 4 threads, 1.5 -> 0.5 ms)
+        if (const char* ev = getenv("NRS_HOST_THREADS")) nt = std::max(1, std::min({64, atoi(ev), std::max(1, d.n_regblk)}));
         std::vector<std::vector<int>> part(nt);
         std::vector<int> cnt(d.n_regblk, 0);
         auto work = [&](int ti) {
@@ -557,12 +558,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             }
         };
         mark("halo prep");
-        if (nt == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (int ti = 0; ti < nt; ++ti) th.emplace_back(work, ti);
-            for (auto& t : th) t.join();
-        }
+        parallel_for(nt, [&](int ti, int) { work(ti); });          // (a share runs inline when no thread can be created)
         mark("halo work");
         for (int b = 0; b < d.n_regblk; ++b) {
             halo_ptr[b + 1] = halo_ptr[b] + cnt[b];
@@ -713,6 +709,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         bool plain = !s.X0 && s.n_un == 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !getenv("NRS_NO_EDGE_CHI");
         for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
         d.ec_on = plain ? 1 : 0;
+        {   // the specialised lineariser additionally wants every damper with its four vertices and springs without a kernel
+            bool p4 = plain && d.use_lds && !d.dform && !(s.delta_pos > 0) && !getenv("NRS_NO_PLAIN");
+            for (int64_t q = 0; q < 4 * (int64_t)s.n_dm && p4; ++q) p4 = s.dm_idx[q] >= 0;
+            d.plain = p4 ? 1 : 0;
+        }
         if (plain) {
             const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
             // counting sort by the counting row (stable: edges of a row keep their order); threads: keys and counts are
@@ -959,6 +960,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
         for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
     if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
     e->d.ec_on = 0;                                                // masks / fixed vertices: chi2 comes from the incidence records
+    e->d.plain = 0;
     NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;

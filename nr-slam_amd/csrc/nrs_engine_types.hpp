@@ -134,6 +134,7 @@ struct Dev {
     // chi2 of a trial state, edge-parallel (BA windows without masks: every spring / damper is evaluated
     // once from these lists instead of from the incidence records of the row that counts it)
     int ec_on, ec_nsp, ec_ndm, ec_nblk;
+    int plain;                       // plain BA window on the LDS path: the lineariser is k_lin_plain (nrs_engine_linearize.hpp)
     EcSpring* ec_sp; EcDamper* ec_dm; float* ec_w; double* part_ec;
     double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
     int* flags;                      // [0] pcg done, [1] pcg iterations, [2] nan flag

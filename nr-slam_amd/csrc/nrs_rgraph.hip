@@ -354,10 +354,29 @@ extern "C" int nrs_rgraph_update(nrs_rgraph* g, const float* pos, int32_t n_ids,
 // GetEdges of the listed points into the graph's pinned staging area: count[n_ids] | col | status | weight | first distance
 // (each n_ids x cap_per_point).  nrs_rgraph_get_edges copies from there; the a2 driver reads it in place.
 namespace nrs {
+int rg_capacity(const nrs_rgraph* g) { return g->cap; }
+// the longest GetEdges prefix a call can ask for: the candidates of a row are sorted in LDS
+int rg_max_cap_per_point(const nrs_rgraph* g) {
+    int lds_max = 65536;
+    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, g->c->device);
+    size_t cand_max = 512;
+    while (sizeof(unsigned long long) * (cand_max << 1) + 4096 + 512 <= (size_t)lds_max) cand_max <<= 1;
+    return std::min(g->cap, (int)cand_max - RG_SLACK);
+}
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
                         const int** status, const float** w, const float** d0) {
     nrs_ctx* c = g->c;
+    NRS_TRY(rg_check_ids(g, n_ids, ids, "GetEdges"));               // (also the a2 driver's entry: ids index the dense state)
+    if (cap_per_point <= 0) return c->fail(NRS_ERR_INVALID, "GetEdges: cap_per_point must be positive");
     NRS_HIP(c, hipSetDevice(c->device));
+    // the sort buffer of a row lives in LDS: 8 bytes per staged candidate (a power of two of them) + 4 KB of histogram
+    int lds_max = 0;
+    NRS_HIP(c, hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+    size_t cand_max = 512;
+    while (sizeof(unsigned long long) * (cand_max << 1) + 4096 + 512 <= (size_t)lds_max) cand_max <<= 1;
+    if ((size_t)std::min(g->cap, cap_per_point + RG_SLACK) > cand_max)
+        return c->fail(NRS_ERR_INVALID, "GetEdges: cap_per_point %d needs more than the %zu candidates per row that fit this device's %d bytes of LDS",
+                       cap_per_point, cand_max, lds_max);
     const size_t no = (size_t)n_ids * cap_per_point;
     NRS_TRY(c->ensure(g->ids_a, sizeof(int) * (size_t)n_ids));
     NRS_TRY(c->ensure(g->out_i, sizeof(int) * (4 * no + (size_t)n_ids + 4)));
@@ -383,7 +402,7 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
     int* h = reinterpret_cast<int*>(g->pin);
     int cand_cap = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        cand_cap = pass == 0 ? std::min(g->cap, cap_per_point + RG_SLACK) : std::min(g->cap, 12000);
+        cand_cap = pass == 0 ? std::min(g->cap, cap_per_point + RG_SLACK) : (int)std::min<size_t>({(size_t)g->cap, (size_t)12000, cand_max});
         NRS_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(int), c->stream));
         size_t pad = 512;                                          // the long-list path sorts a power-of-two number of keys
         while (pad < (size_t)cand_cap) pad <<= 1;

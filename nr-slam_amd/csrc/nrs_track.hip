@@ -233,6 +233,8 @@ struct FlatSource : NeighbourSource {
 
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
                         const int** status, const float** w, const float** d0);   // nrs_rgraph.hip
+int rg_capacity(const nrs_rgraph* g);
+int rg_max_cap_per_point(const nrs_rgraph* g);
 
 struct DenseSource : NeighbourSource {
     nrs_ctx* c; nrs_rgraph* g; int cap;
@@ -258,7 +260,13 @@ struct DenseSource : NeighbourSource {
         }
         return NRS_OK;
     }
-    bool grow() override { if (cap >= n_points) return false; cap = std::min(n_points, 4 * cap); return true; }
+    // (longer prefixes up to what one row's sort buffer holds in LDS; a walk that needs more than that is reported, not cut)
+    bool grow() override {
+        const int lim = std::min(n_points, rg_max_cap_per_point(g));
+        if (cap >= lim) return false;
+        cap = std::min(lim, 4 * cap);
+        return true;
+    }
     int update(const float* map_pos, int n, const int* ids, int* good) override { return n ? nrs_rgraph_update(g, map_pos, n, ids, good) : NRS_OK; }
 };
 
@@ -325,9 +333,13 @@ extern "C" int nrs_track_deform_solve_rg(nrs_ctx* c, const nrs_camera* cam, nrs_
     if (!cam || !g || !map_pos || n_points <= 0 || cap_per_point <= 0 || n_f < 0 || !pose_qt || !n_lost || (n_f > 0 && (!f_map || !f_status || !f_uv || !f_pos)))
         return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve_rg: bad argument");
     if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    // the dense state is capacity x capacity and map_pos has one row per point of it: a different n_points would index either
+    // past the end (regularization_graph.cc has no such failure mode: its maps are keyed by ID)
+    if (n_points != rg_capacity(g))
+        return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve_rg: n_points %d is not the graph's capacity %d", n_points, rg_capacity(g));
     NRS_HIP(c, hipSetDevice(c->device));
     DenseSource src;
-    src.c = c; src.g = g; src.cap = cap_per_point; src.n_points = n_points;
+    src.c = c; src.g = g; src.cap = std::min(cap_per_point, rg_max_cap_per_point(g)); src.n_points = n_points;
     return track_core(c, cam, src, map_pos, n_f, f_map, f_status, f_uv, f_pos, pose_qt, scale, deform_median, n_lost, lost, trace);
 }
 

@@ -586,8 +586,9 @@ def skinned_status(f_status, f_map, nodes):
     """Skinned mode (include/nrs.h, N2): the nodes keep TRACKED_WITH_3D (0), every other TRACKED_WITH_3D point of the frame
     becomes TRACKED (1: in the frame, no 3D) and is carried by stage 2 of the pose-and-deformation solve"""
     st = np.array(f_status, np.int32)
-    is_node = np.zeros(int(np.max(f_map)) + 1, bool)
-    is_node[np.asarray(nodes)] = True
+    nodes = np.asarray(nodes, np.int64)
+    is_node = np.zeros(int(max(np.max(f_map), nodes.max() if nodes.size else -1)) + 1, bool)
+    is_node[nodes] = True
     fm = np.asarray(f_map)
     demote = (st == 0) & (fm >= 0) & ~is_node[np.maximum(fm, 0)]
     st[demote] = 1

@@ -1,0 +1,56 @@
+"""BASELINE configs[0] stand-in on the GPU path: Hamlyn intrinsics (data/hamlyn_01/settings.yaml:7-10), 640x480, ~1k map
+points, 50 frames, a keyframe every 5 frames (10 keyframes), the map's graph at the reference's all-pairs density, through
+the frame loop (LK -> motion-model seed -> pose-only -> pose + deformation -> point reuse -> keyframe
+cadence with Shi-Tomasi extraction).  The dataset itself is not in the repository and the reference cannot be built here
+(SURVEY.md 8c); the expected values are the ORACLE-driven loop's, generated once in the build container by
+tests/golden/make_c1_golden.py (45 s per frame on the CPU: too slow to repeat on the GPU box) and committed as
+tests/golden/c1_standin_1000x50.npz.
+
+Held frame by frame at the tolerances of tests/test_gpu_frame_loop.py: pose 2e-6 / 2e-5, every landmark's status, the
+lost-id set, reused count, keyframe flag, extracted keypoints exact, positions 2e-4."""
+import os
+
+import numpy as np
+import pytest
+
+import nrs
+import nrs_frame_loop as FL
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_standin_1000x50.npz")
+OPTS = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)      # SLAM/system.cc:77-84
+
+
+def test_c1_standin_50_frames_match_oracle_golden():
+    g = np.load(GOLD)
+    n_frames = int(g["n_frames"])
+    assert n_frames == 50 and int(g["keyframe"].sum()) >= 8
+    sq = S.make_frame_sequence(int(g["n_points"]), n_frames, int(g["seed"]), S.PINHOLE)
+    assert np.allclose(sq["prm"][:4], [766.380279, 766.380279, 304.8638, 258.3344], atol=1e-3) and sq["wh"] == (640, 480)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS, dense_graph=True)
+    try:
+        proj = lambda pc: FL.project_f32(sq["model"], sq["prm"], pc)
+        loop = FL.FrameLoop(gb, proj, sq["wh"], sq["scale"], sq["kp0"], sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0],
+                            sq["images"][0], images_to_insert_keyframe=int(g["kf_every"]))
+        for f in range(1, n_frames):
+            assert loop.track_image(sq["images"][f])
+            L, i = loop.log[-1], f - 1
+            assert np.allclose(L["pose_q"], g["pose_q"][i], atol=2e-6, rtol=0), f
+            assert np.allclose(L["pose_t"], g["pose_t"][i], atol=2e-5, rtol=0), f
+            assert np.array_equal(L["status_by_map"], g["status"][i]), (f, np.flatnonzero(L["status_by_map"] != g["status"][i]))
+            assert sorted(L["lost"]) == list(g["lost_ids"][g["lost_ptr"][i]:g["lost_ptr"][i + 1]]), f
+            assert L["reused"] == g["reused"][i] and bool(L["keyframe"]) == bool(g["keyframe"][i]), f
+            assert L["n_tracked"] == g["n_tracked"][i] and L["n_2d"] == g["n_2d"][i], f
+            assert np.array_equal(np.asarray(L["kp_2d"], np.float32).reshape(-1, 2), g["kp_2d"][g["kp_ptr"][i]:g["kp_ptr"][i + 1]]), f
+            assert np.allclose(L["pos_by_map"], g["pos"][i], atol=2e-4, rtol=0), f
+    finally:
+        gb.close()
+    # the loop does track the scene over the 50 frames
+    last = loop.log[-1]
+    ok = last["status_by_map"] == FL.TRACKED_WITH_3D
+    assert ok.sum() > 0.7 * len(ok)
+    pc = FL.se3f_act((last["pose_q"], last["pose_t"]), last["pos_by_map"][ok])
+    uv = FL.project_f32(sq["model"], sq["prm"], pc)
+    assert np.median(np.linalg.norm(uv - sq["uv_true"][n_frames - 1][ok], axis=1)) < 1.5

@@ -11,8 +11,11 @@ are anchored on it where the LM's decisions come from -- chi2 -- and held to siz
   * bit-reproducible across runs; default (early-rejecting) and exact trial modes take identical decisions with
     identical lambdas and produce bit-identical states; chi2 strictly decreases over accepted trials;
   * (C4) LDS-staged factored operator and stored-block gather operator agree.
-The 8-rank sharded C4 run lives in tests/test_gpu_sharded.py."""
+  * (C4) the window sharded over 8 ranks (thread ranks on the one GPU, nrs_comm_init_local: the multi-GPU arithmetic with
+    device copies as the exchange) against the plain solve: same decisions, lambda / chi2 to 1e-6, ranks bit-identical.
+Smaller sharded windows (2-8 ranks, up to C3) live in tests/test_gpu_sharded.py / tests/test_gpu_scale.py."""
 import gc
+import threading
 
 import numpy as np
 import pytest
@@ -128,3 +131,58 @@ def test_full_size_operator_paths_agree(ctx, big, monkeypatch):
     g = _run(ctx, big, 2)
     assert [x["accepted"] for x in tr.trials] == [x["accepted"] for x in g[2]]
     assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)
+
+
+def test_c4_sharded_8_thread_ranks(ctx, big):
+    """BASELINE configs[3] as it is meant to run: C4 cut into 8 keyframe ranges.  The ranks are threads of this process
+    (one context each on the one GPU); every rank packs and holds its own range only (nrs_dba_stats)."""
+    name, p, e, cam, qt = big
+    if name != "C4":
+        pytest.skip("configs[3] is the sharded configuration")
+    iters, world = 2, 8
+    ref = _run(ctx, big, iters)                      # plain solve of the same window
+    ctx.dba_upload(cam, qt[:3], p["lm_xyz"][:3], np.arange(3, dtype=np.int32), p["lm_uv"][:3],
+                   dict(sp_ij=np.zeros((0, 2), np.int32), sp_d0=np.zeros(0, np.float32),
+                        dm_idx=np.zeros((0, 4), np.int32), dm_w=np.zeros(0, np.float32)), p["scale"])   # frees its 14 GB
+    group = nrs.LocalGroup(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            c = nrs.Context()
+            c.comm_init_local(group, r)
+            c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+            tr = nrs.Trace(128)
+            c.dba_optimize(iters, tr)
+            st = c.dba_stats()
+            pq, xyz = c.dba_download()
+            out[r] = (tr.trials, pq, xyz if r == 0 else hash(xyz.tobytes()), st)
+            c.close()
+        except Exception as ex:                      # a failed rank releases its peers (nrs_comm: abort)
+            errs.append((r, repr(ex)))
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+    group.close()
+    t0, pq0, xyz0, _ = out[0]
+    h0 = hash(xyz0.tobytes())
+    for r in range(1, world):                        # every rank returns the same complete result, bit for bit
+        assert [(x["accepted"], x["lam"], x["chi"], x["chi_new"]) for x in out[r][0]] == [(x["accepted"], x["lam"], x["chi"], x["chi_new"]) for x in t0]
+        assert np.array_equal(out[r][1], pq0) and out[r][2] == h0
+    # against the plain solve: same decisions, lambda and chi2 to 1e-6 (sums are taken in another order, nothing else differs)
+    assert [x["accepted"] for x in t0] == [x["accepted"] for x in ref[2]]
+    for x, y in zip(t0, ref[2]):
+        assert abs(x["lam"] - y["lam"]) <= 1e-6 * abs(y["lam"]) and abs(x["chi"] - y["chi"]) <= 1e-6 * abs(y["chi"])
+        if not x["early"] and not y["early"]:
+            assert abs(x["chi_new"] - y["chi_new"]) <= 1e-6 * abs(y["chi_new"])
+    assert np.allclose(pq0[:, :4], ref[0][:, :4], atol=1e-6, rtol=0) and np.allclose(pq0[:, 4:], ref[0][:, 4:], atol=1e-5, rtol=0)
+    assert np.allclose(xyz0, ref[1], atol=1e-4, rtol=0)
+    # a rank holds the records of its own keyframe range: the ranges tile the window
+    assert sum(o[3]["packed_rows"] for o in out) == out[0][3]["rows"]
+    assert max(o[3]["device_bytes"] for o in out) < 0.45 * 16.5e9  # device bytes per rank against the replicated window
