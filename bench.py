@@ -406,6 +406,73 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     return out
 
 
+def hbm_regime_leg(device, workload="C4"):
+    """The two roofline kernels on a window that does NOT fit the 256 MB Infinity Cache (C4: 50k points x 200 keyframes,
+    ~14 GB resident): HIP events on the context's own stream around back-to-back full launches (nrs_options.profile), one
+    optimize(2) -- a bounded extra leg (window generation + upload dominate: ~30 s)."""
+    import nrs
+    p, e, cam, qt = make_window(workload)
+    c = nrs.Context(device=device, profile=1)
+    c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    c.dba_optimize(1)
+    c.reset_profile()
+    c.dba_reset()
+    t0 = time.perf_counter()
+    tr = nrs.Trace(64)
+    c.dba_optimize(2, tr)
+    dt = time.perf_counter() - t0
+    prof = c.profile()
+    st = c.dba_stats()
+    c.close()
+    n_lm, n_sp, n_dm = len(p["lm_kf"]), len(e["sp_ij"]), len(e["dm_idx"])
+    lin_b, spmv_b = algorithmic_bytes(n_lm, n_sp, n_dm, unique_blocks(n_lm, e["sp_ij"], e["dm_idx"]))
+    spmv_us = 1e3 * prof["spmv_ms"] / max(1, prof["spmv_launches"])
+    lin_us = 1e3 * prof["linearize_ms"] / max(1, prof["linearize_launches"])
+    return {"workload": "%s: %d landmarks, %d springs, %d dampers, %.1f GB resident" % (workload, n_lm, n_sp, n_dm, st["device_bytes"] / 1e9),
+            "operator": {"kernel": "k_spmv_f", "avg_us": spmv_us, "algorithmic_bytes": spmv_b, "achieved": spmv_b / (spmv_us * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_b / (spmv_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches": prof["spmv_launches"]},
+            "linearize": {"kernel": "k_lin_plain", "avg_us": lin_us, "algorithmic_bytes": lin_b, "achieved": lin_b / (lin_us * 1e-6) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lin_b / (lin_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches": prof["linearize_launches"]},
+            "note": "profiling context: launches serialised by events, LM trials %d in %.2f s" % (len(tr.trials), dt)}
+
+
+def oneshot_leg(device, p, e, cam, qt, reps=5):
+    """What a drop-in caller pays per LocalDeformableBundleAdjustment call (mapping.cc:57: a NEW window every keyframe): the
+    one-shot nrs_dba_solve -- host buffers in and out, PCIe-inclusive, including the packing of the incidence streams --
+    on the bench window and on a reference-sized window (5 keyframes, OPT:894), next to the resident reset + optimize
+    that `value` times.  Also nrs_dba_build_edges (host only: OPT:927-1137's edge construction)."""
+    import nrs
+    import nrs_synth as S
+    out = {}
+    p5 = S.make_dba_problem(5000, 5, 1)
+    for name, pp, ee in (("bench_window", p, e), ("reference_window_5kf", p5, None)):
+        t0 = time.perf_counter()
+        e2 = nrs.dba_build_edges(pp["kf_points"], pp["nbr"])
+        t_edges = time.perf_counter() - t0
+        ee = ee or e2
+        cm = nrs.make_camera(pp["model"], pp["prm"])
+        q = np.concatenate([pp["poses_q"], pp["poses_t"]], 1)
+        c = nrs.Context(device=device)
+        c.dba_solve(cm, q, pp["lm_xyz"], pp["lm_kf"], pp["lm_uv"], ee, pp["scale"], 5)         # first call: arena allocation, code objects
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            c.dba_solve(cm, q, pp["lm_xyz"], pp["lm_kf"], pp["lm_uv"], ee, pp["scale"], 5)
+            ts.append(time.perf_counter() - t0)
+        c.dba_upload(cm, q, pp["lm_xyz"], pp["lm_kf"], pp["lm_uv"], ee, pp["scale"])
+        c.dba_optimize(5)
+        tr_ = []
+        for _ in range(reps):
+            c.dba_reset()
+            t0 = time.perf_counter()
+            c.dba_optimize(5)
+            tr_.append(time.perf_counter() - t0)
+        c.close()
+        out[name] = {"landmarks": int(len(pp["lm_kf"])), "keyframes": int(len(q)), "oneshot_ms": 1e3 * min(ts), "resident_optimize_ms": 1e3 * min(tr_),
+                     "build_edges_ms": 1e3 * t_edges}
+    return out
+
+
 def triangulation_bench():
     """f2: every triangulation candidate of a frame in one call (21 buffered snapshots, host buffers in, points out),
     next to the NumPy restatement (oracle/triang_oracle.py, 1 core) on the first 10 candidates."""
@@ -468,6 +535,7 @@ def main():
     ap.add_argument("--sharded-points", type=int, default=0, help="override the sharded window's map points (tests)")
     ap.add_argument("--sharded-kf", type=int, default=0, help="override the sharded window's keyframes (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the bounded C4 leg (operator + lineariser in the HBM regime)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: independent windows only")
     ap.add_argument("--sharded-timeout", type=float, default=900.0)
     args = ap.parse_args()
@@ -540,14 +608,19 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {})
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
         lin_gbs = lin_b / (lin_us * 1e-6) / 1e9
+        tsrc = "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile_r03.sh, not this run; lower bound: profiles/README.md)"
         out["roofline"] = {"kernel": "k_spmv_f (PCG operator apply, dominant: see profiles/)", "bound": "hbm",
                            "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                           "traffic": (traffic or {}).get("k_spmv"), "avg_us": spmv_us,
-                           "algorithmic_bytes": spmv_b, "launches": prof["spmv_launches"]}
-        out["roofline_linearize"] = {"kernel": "k_reg<T, true, true> (residuals + Jacobians + Huber + per-incidence factors + row blocks, one fused pass)",
+                           "traffic": (traffic or {}).get("k_spmv"), "traffic_source": tsrc, "avg_us": spmv_us,
+                           "algorithmic_bytes": spmv_b, "launches": prof["spmv_launches"],
+                           "regime": "%s's working set (~150 MB at C2) sits in the 256 MB Infinity Cache: see roofline_hbm_regime for the HBM-resident window" % args.workload}
+        out["roofline_linearize"] = {"kernel": "k_lin_plain<T> (residuals + Jacobians + Huber + per-incidence factors + row blocks, one fused pass; k_reg<T, true, true> specialised for plain BA windows)",
                                      "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"),
+                                     "frac": lin_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get("linearize"), "traffic_source": tsrc,
                                      "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]}
+        if not args.no_hbm_regime:
+            out["roofline_hbm_regime"] = hbm_regime_leg(local_rank)
+        out["oneshot"] = oneshot_leg(local_rank, p, e, cam, qt)
         # the reference's map graph connects every pair of map points (map.cc:148-166): that is the graph `tracked_fps` runs on,
         # resident on the device; the generator's kNN-16 flat graph (what round 1 measured) stays next to it
         out["tracked_fps"] = tracked_fps(dense_graph=True)
@@ -560,6 +633,11 @@ def main():
         out["skinned"] = skinned_bench()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
+            cb = out["cpu_baseline"]
+            if cb.get("gpu_same_sample_exact_trials"):
+                # like for like: the same window, every LM trial solved to 1e-10 on both sides (`value` / cpu is NOT this ratio:
+                # `value` rejects hopeless trials early)
+                out["speedup_exact_vs_cpu"] = cb["gpu_same_sample_exact_trials"] / cb["value"]
         xctx.close()
     ctx.close()
 

@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -179,6 +180,36 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
     if (LIN) { e->d.lin_pose = e->d.pose[which]; e->d.lin_xl = e->d.xl[which]; }   // the PCG kernels re-form factors from it
     const Dev& d = e->d;
     const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
+    if (LIN && d.plain && getenv("NRS_LIN_DBG")) {
+        // phase clocks of one lineariser launch (100 MHz wall clock): where a wave's time goes
+        static bool done = false;
+        if (!done) {
+            done = true;
+            const size_t ns = (size_t)d.n_rows / (64 / d.T);
+            long long* buf = nullptr;
+            NRS_HIP(c, hipMalloc((void**)&buf, sizeof(long long) * 8 * ns));
+            NRS_HIP(c, hipMemsetAsync(buf, 0, sizeof(long long) * 8 * ns, c->stream));
+            Dev dd = d;
+            dd.dbg_clk = buf;
+            launch_reg<LIN>(c, dd, d.xl[which]);
+            NRS_HIP(c, hipStreamSynchronize(c->stream));
+            std::vector<long long> h(8 * ns);
+            NRS_HIP(c, hipMemcpy(h.data(), buf, sizeof(long long) * 8 * ns, hipMemcpyDeviceToHost));
+            (void)hipFree(buf);
+            double acc[5] = {0, 0, 0, 0, 0};
+            long long t_min = LLONG_MAX, t_max = 0;
+            size_t n = 0;
+            for (size_t i = 0; i < ns; ++i) {
+                const long long* q = &h[8 * i];
+                if (!q[0] || !q[5]) continue;
+                for (int k = 0; k < 5; ++k) acc[k] += (double)(q[k + 1] - q[k]);
+                t_min = std::min(t_min, q[0]); t_max = std::max(t_max, q[5]);
+                ++n;
+            }
+            fprintf(stderr, "[nrs] k_lin_plain phases (us per wave, mean over %zu waves): stage %.2f springs %.2f dampers %.2f reproj %.2f tail %.2f | launch span %.1f us\n",
+                    n, acc[0] / n / 100.0, acc[1] / n / 100.0, acc[2] / n / 100.0, acc[3] / n / 100.0, acc[4] / n / 100.0, (double)(t_max - t_min) / 100.0);
+        }
+    }
     if (LIN) {
         // LDS path: one fused pass (reprojection + springs + dampers per row); gather path: two
         const int reps = c->opt.profile ? PROFILE_REPS : 1;

@@ -564,68 +564,79 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
 
 template <int T, int OCC = 4>
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
-    __shared__ double lds[4 * 2];
-    __shared__ double lds28[4 * 28];
+    __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
+    __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
-    constexpr int U = 2;
+    constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
     int b = xcd_tile(blockIdx.x, P.sh_nt[cls]);
     if (b >= P.sh_nt[cls]) return;
     b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + b];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: slice bounds and loop conditions are scalar)
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
+    auto stamp = [&](int k) { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)slice * 8 + k] = wall_clock64(); };
+    stamp(0);
     const int rf = P.rflag[row];
+    const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];     // (requested up front: nothing behind the loops waits on memory)
+    if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
     const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
-    uint2 shA[U], shB[U], dhA[U], dhB[U];
-    float dwA[U], dwB[U];
-    auto load_sh = [&](uint2* h, int idx) {
+    // Record prefetch.  The loads of a chunk are UNCONDITIONAL (slots past the slice's end read a clamped index and are
+    // treated as padding when they are consumed) and nothing touches the loaded registers before the chunk is processed:
+    // with a predicated load the compiler sinks the unpacking (u32 -> fields, f32 -> f64) into the predicated block, right
+    // behind the load, and the wave then waits out the full memory latency of every chunk it has just requested -- which
+    // is what bounded this pass (and the operator) in rounds 1 and 2.  sched_barrier keeps the phases apart.
+    const int s_last = s_end > 0 ? s_end - 1 : 0, d_last = d_end > 0 ? d_end - 1 : 0;
+    uint32_t somA[U], somB[U], sd0A[U], sd0B[U], dwA[U], dwB[U];
+    uint2 dhA[U], dhB[U];
+    auto load_sh = [&](uint32_t* om, uint32_t* d0, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int j = idx + 64 * q;
-            h[q] = make_uint2(0xFFFFu, 0x3F800000u);                // padding: no neighbour, rest length 1
-            if (j < s_end) h[q] = make_uint2(P.s_om[j], __float_as_uint(P.s_d0[j]));
+            const int j = min(idx + 64 * q, s_last);
+            om[q] = P.s_om[j];
+            d0[q] = __float_as_uint(P.s_d0[j]);
         }
     };
-    auto load_dh = [&](uint2* h, float* w, int idx) {
+    auto load_dh = [&](uint2* h, uint32_t* w, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int j = idx + 64 * q;
-            h[q] = make_uint2(0u, 0xFFFF0000u);
-            w[q] = 0.f;
-            if (j < d_end) { h[q] = P.d_hdr[j]; w[q] = P.d_w[j]; }
+            const int j = min(idx + 64 * q, d_last);
+            h[q] = P.d_hdr[j];
+            w[q] = __float_as_uint(P.d_w[j]);
         }
     };
-    load_sh(shA, s_beg + lane);
+    load_sh(somA, sd0A, s_beg + lane);
     load_dh(dhA, dwA, d_beg + lane);
+    __builtin_amdgcn_sched_barrier(0);
     double* lx = dyn;
     stage_rows(P, b, tid, xl_g, nullptr, lx);
     __syncthreads();
+    stamp(1);
     const int self = row - b * P.tile_rows;
     const double xo0 = lx[3 * self], xo1 = lx[3 * self + 1], xo2 = lx[3 * self + 2];
     double D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0, D5 = 0, bb0 = 0, bb1 = 0, bb2 = 0, chi = 0;
     // ---- springs: r = k (d - d0) / d0, J = cg (x_i - x_j)^T with cg = (k / d0) 2 / sqrt(d) as the reference writes it
     // (position_regularizer.cc:51-60) or k / (d0 d) (tracking form); information info_pos, no kernel
     const double ks = P.k_spring, ip = P.info_pos;
-    const bool ba_form = P.spring_form == 0;
-    auto do_sh = [&](const uint2* hdr, int idx) {
+    auto do_sh = [&](const uint32_t* omv, const uint32_t* d0v, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const uint32_t om = hdr[q].x;
+            const uint32_t om = consume(omv[q]);
             const int o16 = (int)(om & 0xFFFFu);
-            const bool pad = o16 == REC_NONE;                       // (slots past the slice's end were loaded as padding)
-            const int o = pad ? self : o16;
+            const bool live = idx + 64 * q < s_end;
+            const bool pad = !live || o16 == REC_NONE;
+            const int o = (pad ? self : o16) & 0xFFFF;              // (16 bits: the LDS offset is then one v_mad_u32_u24)
             const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
             double d2 = v0 * v0 + v1 * v1 + v2 * v2;
             d2 = pad ? 1.0 : d2;
-            const double d0 = pad ? 1.0 : (double)__uint_as_float(hdr[q].y);
+            const double d0 = pad ? 1.0 : (double)__uint_as_float(consume(d0v[q]));
             const double rs = fast_rsqrt_pos(d2), id0 = fast_rcp_pos(d0);
             const double r = ks * fma(d2, rs, -d0) * id0;
-            const double cg = ba_form ? 2.0 * ks * id0 * fast_sqrt_pos(rs) : ks * id0 * rs;
+            const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);   // (plain windows are BA windows: spring_form 0, checked by engine_create)
             const double qc = pad ? 0.0 : ip * cg * cg;
-            if (idx + 64 * q < s_end) P.s_qc[idx + 64 * q] = qc;
+            if (live) P.s_qc[idx + 64 * q] = qc;
             chi += (om & ((uint32_t)SR_COUNT << 16)) && !pad ? ip * r * r : 0.0;
             const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
             D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
@@ -635,43 +646,55 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         }
     };
     for (int base = s_beg; base < s_end; base += 128 * U) {        // wave-uniform trip count
-        load_sh(shB, base + 64 * U + lane);
-        do_sh(shA, base + lane);
-        load_sh(shA, base + 128 * U + lane);
-        do_sh(shB, base + 64 * U + lane);
+        load_sh(somB, sd0B, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_sh(somA, sd0A, base + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        load_sh(somA, sd0A, base + 128 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_sh(somB, sd0B, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(2);
     // ---- dampers: r = w ((x1n - x1c) - (x2n - x2c)); the records list the three others in canonical order
     // (engine_create), so that sg_i * sum_k sg_k x_k = (x_i - x[o1]) - (x[o0] - x[o2]) for every role
     const double isp = P.info_spatial, dsp = P.delta_spatial;
-    auto do_dh = [&](const uint2* hdr, const float* ww, int idx) {
+    auto do_dh = [&](const uint2* hdr, const uint32_t* ww, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const uint32_t m16 = hdr[q].y >> 16;
-            const bool pad = m16 == REC_NONE;
-            const int o0 = pad ? self : (int)(hdr[q].x & 0xFFFFu), o1 = pad ? self : (int)(hdr[q].x >> 16), o2 = pad ? self : (int)(hdr[q].y & 0xFFFFu);
+            const uint32_t hx = consume(hdr[q].x), hy = consume(hdr[q].y);
+            const uint32_t m16 = hy >> 16;
+            const bool live = idx + 64 * q < d_end;
+            const bool pad = !live || m16 == REC_NONE;
+            const int o0 = (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
             const double g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
             const double g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
             const double g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
-            const double w = pad ? 0.0 : (double)ww[q];
+            const double w = pad ? 0.0 : (double)__uint_as_float(consume(ww[q]));
             const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
             double rho0, rho1;
             huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
             chi += (m16 & DM_COUNT) ? rho0 : 0.0;                  // (padding: rho0 = 0)
             const double sfac = rho1 * isp * w * w;
-            if (idx + 64 * q < d_end) P.d_s[idx + 64 * q] = sfac;
+            if (live) P.d_s[idx + 64 * q] = sfac;
             D0 += sfac; D3 += sfac; D5 += sfac;
             bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
         }
     };
     for (int base = d_beg; base < d_end; base += 128 * U) {
         load_dh(dhB, dwB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
         do_dh(dhA, dwA, base + lane);
+        __builtin_amdgcn_sched_barrier(0);
         load_dh(dhA, dwA, base + 128 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
         do_dh(dhB, dwB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- reprojection edge of the row (as in k_reg: the first two lanes of a row take one residual component each)
+    stamp(3);
+    // ---- reprojection edge of the row (as in k_reg: the first two lanes of a row take one residual component each).
+    // The pose is the tile's (a tile never straddles keyframes): scalar loads, nothing waits on a per-lane gather.
     constexpr int NRR = T == 1 ? 2 : 1;
-    const int kf = P.grp_pose[row / ROW_ALIGN];
     const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE);
     RowRec rc;
 #pragma unroll
@@ -685,7 +708,11 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         for (int q = 0; q < 6; ++q) Jp[a][q] = 0;
     }
     if (active && t < (T == 1 ? 1 : 2)) {
-        const Pose Tcw = P.lin_pose[kf];
+        Pose Tcw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Tcw.q[q] = spose[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Tcw.t[q] = spose[4 + q];
         double Rm[9];
         quat_to_R(Tcw.q, Rm);
         const double px = Rm[0] * xo0 + Rm[1] * xo1 + Rm[2] * xo2 + Tcw.t[0];
@@ -694,7 +721,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         float u, v, Jf[6];
         project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
         projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
-        const double r2[2] = {(double)P.uv[2 * row] - (double)u, (double)P.uv[2 * row + 1] - (double)v};
+        const double r2[2] = {(double)uvx - (double)u, (double)uvy - (double)v};
         double rho0, rho1;
         huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);
         if (t == 0) chi_r = rho0;
@@ -723,46 +750,51 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         }
     }
     if (t == 0) P.rowrec[row] = rc;
-    // [H_pp | b_p] partials of the tile on the matrix cores (see k_reg)
+    stamp(4);
+    // [H_pp | b_p] partials of the SLICE on the matrix cores (the product of k_reg: sixteen v_mfma_f64_16x16x4 per wave),
+    // operands through a 1 KB region of the wave's own, sixteen lanes at a time: no workgroup barrier anywhere behind the
+    // staging one -- the four waves of a tile carry different incidence counts (rows are sorted by them) and finish apart.
+    // Every wave leaves its own partial slot: [0..27) H_pp / b_p, [27] chi2 of the reprojection edges, [28] chi2 of the
+    // regularisers, [29] max |diagonal| of its rows; k_pose_sums adds the slices of a pose up in a fixed order.
+    double* slot = P.part_lin + (size_t)slice * 32;
     {
         typedef double v4d __attribute__((ext_vector_type(4)));
-        __syncthreads();                                           // every wave is done with the staged positions
-        double* mb = dyn + wave * 512;                             // [64 lanes][8], the wave's own
+        double* mb = mfb + wave * 128;                             // [16 lanes][8]
         const int e = lane & 15, kk = lane >> 4;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int a = 0; a < NRR; ++a) {
-            if (a > 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) mb[lane * 8 + q] = Jp[a][q];
-            mb[lane * 8 + 6] = -rres[a];
-            mb[lane * 8 + 7] = w;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-            for (int m = 0; m < 16; ++m) {
-                const int kq = 4 * m + kk;
-                const double val = e < 7 ? mb[kq * 8 + e] : 0.0;
-                const double av = e < 6 ? mb[kq * 8 + 7] * val : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, val, acc, 0, 0, 0);
+            for (int c4 = 0; c4 < 4; ++c4) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();                   // (the previous group's reads are done)
+                if (kk == c4) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) mb[e * 8 + q] = Jp[a][q];
+                    mb[e * 8 + 6] = -rres[a];
+                    mb[e * 8 + 7] = w;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {                      // MFMA 4 c4 + m: k index 4 m + kk of this group of sixteen lanes
+                    const int kq = 4 * m + kk;
+                    const double val = e < 7 ? mb[kq * 8 + e] : 0.0;
+                    const double av = e < 6 ? mb[kq * 8 + 7] * val : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, val, acc, 0, 0, 0);
+                }
             }
         }
         auto put = [&](int prow, double c) {
             if (prow < 6) {
-                if (e >= prow && e < 6) lds28[wave * 28 + prow * 6 - (prow * (prow - 1)) / 2 + (e - prow)] = c;
-                if (e == 6) lds28[wave * 28 + 21 + prow] = c;
+                if (e >= prow && e < 6) slot[prow * 6 - (prow * (prow - 1)) / 2 + (e - prow)] = c;
+                if (e == 6) slot[21 + prow] = c;
             }
         };
         put(kk, acc.x);
         put(4 + kk, acc.y);
     }
-    {
-        const double sm = wave_sum(chi_r);
-        if (lane == 0) lds28[wave * 28 + 27] = sm;
-    }
-    __syncthreads();
-    if (tid < 28) P.part_lin[(size_t)b * 32 + tid] = lds28[tid] + lds28[28 + tid] + lds28[56 + tid] + lds28[84 + tid];
     D0 = sub_sum_t<T>(D0); D1 = sub_sum_t<T>(D1); D2 = sub_sum_t<T>(D2);
     D3 = sub_sum_t<T>(D3); D4 = sub_sum_t<T>(D4); D5 = sub_sum_t<T>(D5);
     bb0 = sub_sum_t<T>(bb0); bb1 = sub_sum_t<T>(bb1); bb2 = sub_sum_t<T>(bb2);
@@ -773,15 +805,11 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         P.bl[3 * row] = bb0; P.bl[3 * row + 1] = bb1; P.bl[3 * row + 2] = bb2;
         md = fmax(fabs(D0), fmax(fabs(D3), fabs(D5)));
     }
-    const double c = wave_sum(chi);
+    const double cr = wave_sum(chi_r), cg2 = wave_sum(chi);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
-    if (lane == 0) { lds[wave * 2] = c; lds[wave * 2 + 1] = md; }
-    __syncthreads();
-    if (tid == 0) {
-        P.part_reg[2 * (size_t)b] = lds[0] + lds[2] + lds[4] + lds[6];
-        P.part_reg[2 * (size_t)b + 1] = fmax(fmax(lds[1], lds[3]), fmax(lds[5], lds[7]));
-    }
+    if (lane == 0) { slot[27] = cr; slot[28] = cg2; slot[29] = md; }
+    stamp(5);
 }
 
 // =====================================================================================
@@ -847,18 +875,19 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
     double chi = 0, md = 0, sc = 0;
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
-    if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    if (LIN && P.plain) { for (int k = tid; k < P.K; k += BLK) chi += P.part_pchi[k]; }      // k_pose_sums: chi2 per pose (reprojection + regularisers)
+    else if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
     else for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_rchi[g];
     if (!LIN && P.ec_on) {
         for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
-    } else {
+    } else if (!(LIN && P.plain)) {
         for (int b = tid; b < P.n_regblk; b += BLK) {
             chi += P.part_reg[2 * (size_t)b];
             md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
         }
     }
     if (LIN)
-        for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp|
+        for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp| (plain: and of the rows' blocks)
     double c = wave_sum(chi);
     sc = wave_sum(sc);
 #pragma unroll
@@ -891,11 +920,12 @@ __global__ __launch_bounds__(BLK) void k_finalize_pack(Dev P) {
     double chi = 0, md = 0, sc = 0;
     if (!LIN)
         for (int b = tid; b < P.n_vecblk; b += BLK) sc += P.part_apply[b];
-    if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
+    if (LIN && P.plain) { for (int k = P.sh_k0 + tid; k < P.sh_k0 + P.sh_nk; k += BLK) chi += P.part_pchi[k]; }   // this rank's poses
+    else if (LIN) for (int g = tid; g < P.n_groups * P.lin_rb; g += BLK) chi += P.part_lin[(size_t)g * 32 + 27];
     else for (int g = tid; g < P.n_groups; g += BLK) chi += P.part_rchi[g];
     if (!LIN && P.ec_on) {
         for (int b = tid; b < P.ec_nblk; b += BLK) chi += P.part_ec[b];     // trial states: edge-parallel chi2
-    } else {
+    } else if (!(LIN && P.plain)) {
         for (int b = tid; b < P.n_regblk; b += BLK) {
             chi += P.part_reg[2 * (size_t)b];
             md = fmax(md, P.part_reg[2 * (size_t)b + 1]);
@@ -955,25 +985,34 @@ __global__ __launch_bounds__(BLK) void k_pose_sums(Dev P) {
     __shared__ double lds[8][32];
     __shared__ double mdl[32];
     const int k = P.sh_k0 + blockIdx.x, tid = threadIdx.x, c = tid & 31, gl = tid >> 5;
+    // plain windows (k_lin_plain): slots are per slice and also carry the regularisers' chi2 [28] and the rows' max |diagonal| [29]
+    const int nsum = P.plain ? 29 : 27;
     double s = 0;
-    if (c < 27)
+    if (c < nsum)
         for (int g = P.pose_grp_ptr[k] * P.lin_rb + gl; g < P.pose_grp_ptr[k + 1] * P.lin_rb; g += 8) s += P.part_lin[(size_t)g * 32 + c];
+    if (P.plain && c == 29)
+        for (int g = P.pose_grp_ptr[k] * P.lin_rb + gl; g < P.pose_grp_ptr[k + 1] * P.lin_rb; g += 8) s = fmax(s, P.part_lin[(size_t)g * 32 + c]);
     lds[gl][c] = s;
     __syncthreads();
     if (tid < 32) {
         double t = 0;
-        if (c < 27) {
+        if (c < nsum) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += lds[q][c];
-            if (c < 21) P.Hpp[k * 21 + c] = t; else P.bp[k * 6 + (c - 21)] = t;
+            if (c < 21) P.Hpp[k * 21 + c] = t; else if (c < 27) P.bp[k * 6 + (c - 21)] = t;
+        }
+        if (P.plain && c == 29) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t = fmax(t, lds[q][c]);
         }
         // diagonal entries of the packed upper triangle: 0,6,11,15,18,20
-        mdl[c] = (c == 0 || c == 6 || c == 11 || c == 15 || c == 18 || c == 20) ? fabs(t) : 0.0;
+        mdl[c] = (c == 0 || c == 6 || c == 11 || c == 15 || c == 18 || c == 20 || (P.plain && c == 29)) ? fabs(t) : ((P.plain && (c == 27 || c == 28)) ? t : 0.0);
     }
     __syncthreads();
     if (tid == 0) {
         double m = 0;
         for (int q = 0; q < 21; ++q) m = fmax(m, mdl[q]);
+        if (P.plain) { m = fmax(m, mdl[29]); P.part_pchi[k] = mdl[27] + mdl[28]; }
         (P.sh_on ? P.red_loc : P.red)[3 + k] = m;
     }
 }

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const int bi = xcd_tile(blockIdx.x, P.sh_nt[cls] + P.sh_ntb[cls]);
     if (bi >= P.sh_nt[cls] + P.sh_ntb[cls]) return;
     const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + (bi < P.sh_nt[cls] ? P.sh_t0[cls] + bi : P.sh_t0b[cls] + bi - P.sh_nt[cls])];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: slice bounds and loop conditions are scalar)
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
@@ -244,34 +244,36 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         rc = P.rowrec[row];
         if (!P.ecd) { rv0 = P.rv[3 * row]; rv1 = P.rv[3 * row + 1]; rv2 = P.rv[3 * row + 2]; }
     }
-    // records are double-buffered: chunk k+1 is requested before chunk k is consumed (with ~3 waves
-    // per SIMD the loops are bound by the latency of their own loads otherwise)
-    SpringRec srA[U], srB[U];
-    DamperRec drA[U], drB[U];
-    auto load_springs = [&](SpringRec* sr, int idx) {
+    // Records are double-buffered: chunk k+1 is requested before chunk k is consumed.  The loads are UNCONDITIONAL (slots
+    // past the slice's end read a clamped index and count as padding when they are consumed) and the raw words are not
+    // touched before the chunk is processed: with a predicated load the compiler sinks the unpacking into the predicated
+    // block, right behind the load, and the wave waits out the full memory latency of every chunk it has just requested
+    // (rounds 1 and 2: ~80 serialised round trips per tile).  sched_barrier keeps request and consumption apart.
+    const int send_u = P.ss_ptr[slice + 1], dend_u = P.sd_ptr[slice + 1];   // (send / dend: empty for a fixed row)
+    const int s_last = max(send_u - 1, 0), d_last = max(dend_u - 1, 0);
+    uint32_t somA[U], somB[U];
+    double sqcA[U], sqcB[U], dsA[U], dsB[U];
+    uint2 dhA[U], dhB[U];
+    auto load_springs = [&](uint32_t* om, double* qc, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int j = idx + 64 * q;
-            sr[q].other = REC_NONE; sr[q].qc = 0;
-            if (j < send) sr[q] = load_spring(P, j);
+            const int j = min(idx + 64 * q, s_last);
+            om[q] = P.s_om[j];
+            qc[q] = P.s_qc[j];
         }
     };
-    auto load_dampers = [&](DamperRec* dr, int idx) {
+    auto load_dampers = [&](uint2* h, double* sv, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int j = idx + 64 * q;
-            dr[q].meta = 0; dr[q].s = 0; dr[q].o0 = dr[q].o1 = dr[q].o2 = REC_NONE;
-            if (j < dend) {
-                if (DF) {                                          // {partner | meta << 16} + s: 12 bytes
-                    const uint32_t om = P.d_om[j];
-                    dr[q].s = P.d_s[j];
-                    dr[q].o0 = (uint16_t)(om & 0xFFFFu); dr[q].meta = (uint16_t)(om >> 16);
-                } else dr[q] = load_damper(P, j);
-            }
+            const int j = min(idx + 64 * q, d_last);
+            if (DF) h[q] = make_uint2(P.d_om[j], 0u);              // {partner | meta << 16} + s: 12 bytes
+            else h[q] = P.d_hdr[j];
+            sv[q] = P.d_s[j];                                      // (0 for padding slots and for edges at level != 0)
         }
     };
-    load_springs(srA, sbeg + lane);
-    load_dampers(drA, dbeg + lane);
+    load_springs(somA, sqcA, sbeg + lane);
+    load_dampers(dhA, dsA, dbeg + lane);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (done_flag) return;
     if (P.ecd && it > 0) {
@@ -292,27 +294,32 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
     double a0 = 0, a1 = 0, a2 = 0;
-    auto do_springs = [&](const SpringRec* sr) {
+    auto do_springs = [&](const uint32_t* om, const double* qcv, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int o = sr[q].other == REC_NONE ? ZROW : (int)sr[q].other;     // padding: qc = 0
-            const int ox = sr[q].other == REC_NONE ? ZROWX : (int)sr[q].other;
+            const int o16 = (int)(consume(om[q]) & 0xFFFFu);
+            const bool pad = idx + 64 * q >= send || o16 == REC_NONE;
+            const int o = pad ? ZROW : o16, ox = pad ? ZROWX : o16;
+            const double qc = pad ? 0.0 : consume(qcv[q]);
             const double v0 = xs[0] - lx[3 * ox], v1 = xs[1] - lx[3 * ox + 1], v2 = xs[2] - lx[3 * ox + 2];
-            const double dot = sr[q].qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
+            const double dot = qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
             a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
         }
     };
     const double gfo[3] = {DF ? lgf[3 * self] : 0.0, DF ? lgf[3 * self + 1] : 0.0, DF ? lgf[3 * self + 2] : 0.0};
     const double gbo[3] = {DF ? lgb[3 * self] : 0.0, DF ? lgb[3 * self + 1] : 0.0, DF ? lgb[3 * self + 2] : 0.0};
-    auto do_dampers = [&](const DamperRec* dr) {
+    auto do_dampers = [&](const uint2* hd, const double* dsv, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
+            const bool live = idx + 64 * q < dend;
             if (DF) {
                 // a_i += s (G^d_i - G^d_o): forward differences for roles 1c / 2c, backward for 1n / 2n
-                const bool pad = dr[q].meta == REC_NONE || dr[q].o0 == REC_NONE;
-                const int o = pad ? ZROW : (int)dr[q].o0;
-                const double sv = pad ? 0.0 : dr[q].s;
-                const bool bw = (dr[q].meta & 2) != 0;
+                const uint32_t hx = consume(hd[q].x);
+                const int p16 = (int)(hx & 0xFFFFu), m16 = (int)(hx >> 16);
+                const bool pad = !live || m16 == REC_NONE || p16 == REC_NONE;
+                const int o = pad ? ZROW : p16;
+                const double sv = pad ? 0.0 : consume(dsv[q]);
+                const bool bw = (m16 & 2) != 0;
                 const double* lg = bw ? lgb : lgf;
                 const double g0 = (bw ? gbo[0] : gfo[0]) - lg[3 * o], g1 = (bw ? gbo[1] : gfo[1]) - lg[3 * o + 1], g2 = (bw ? gbo[2] : gfo[2]) - lg[3 * o + 2];
                 a0 += sv * g0; a1 += sv * g1; a2 += sv * g2;
@@ -320,12 +327,14 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             }
             // padding records carry s = 0; a unary damper (the other vertex is a value) and absent
             // vertices read the zero row, which leaves the diagonal term s u_i
-            const int meta = dr[q].meta == REC_NONE ? 0 : (int)dr[q].meta;
-            const double sv = dr[q].meta == REC_NONE ? 0.0 : dr[q].s;
-            const bool un = (meta & DM_UNARY) != 0;
-            const int o0 = (un || dr[q].o0 == REC_NONE) ? ZROW : (int)dr[q].o0;
-            const int o1 = (un || dr[q].o1 == REC_NONE) ? ZROW : (int)dr[q].o1;
-            const int o2 = (un || dr[q].o2 == REC_NONE) ? ZROW : (int)dr[q].o2;
+            const uint32_t hx = consume(hd[q].x), hy = consume(hd[q].y);
+            const int r0 = (int)(hx & 0xFFFFu), r1 = (int)(hx >> 16), r2 = (int)(hy & 0xFFFFu), m16 = (int)(hy >> 16);
+            const bool pad = !live || m16 == REC_NONE;
+            const double sv = pad ? 0.0 : consume(dsv[q]);
+            const bool un = pad || (m16 & DM_UNARY) != 0;
+            const int o0 = (un || r0 == REC_NONE) ? ZROW : r0;
+            const int o1 = (un || r1 == REC_NONE) ? ZROW : r1;
+            const int o2 = (un || r2 == REC_NONE) ? ZROW : r2;
             // the others come in canonical order (engine_create): a_i += s ((u_i - u[o1]) - (u[o0] - u[o2])) for every role
             const double g0 = (ul[0] - lu[3 * o1]) - (lu[3 * o0] - lu[3 * o2]);
             const double g1 = (ul[1] - lu[3 * o1 + 1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
@@ -333,17 +342,25 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             a0 += sv * g0; a1 += sv * g1; a2 += sv * g2;
         }
     };
-    for (int base = sbeg; base < send; base += 128 * U) {          // wave-uniform trip count
-        load_springs(srB, base + 64 * U + lane);
-        do_springs(srA);
-        load_springs(srA, base + 128 * U + lane);
-        do_springs(srB);
+    for (int base = sbeg; base < send_u; base += 128 * U) {        // wave-uniform trip count
+        load_springs(somB, sqcB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_springs(somA, sqcA, base + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        load_springs(somA, sqcA, base + 128 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_springs(somB, sqcB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    for (int base = dbeg; base < dend; base += 128 * U) {
-        load_dampers(drB, base + 64 * U + lane);
-        do_dampers(drA);
-        load_dampers(drA, base + 128 * U + lane);
-        do_dampers(drB);
+    for (int base = dbeg; base < dend_u; base += 128 * U) {
+        load_dampers(dhB, dsB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_dampers(dhA, dsA, base + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        load_dampers(dhA, dsA, base + 128 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
+        do_dampers(dhB, dsB, base + 64 * U + lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // the row's own terms come last: their temporaries then never coexist with the record registers
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -92,6 +92,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.part_ru = A.get<double>(d.ecd ? 2 * (size_t)d.n_vecblk : 1);
     d.part_lin = A.get<double>(32 * (size_t)d.n_groups * (size_t)d.lin_rb);
     d.part_rchi = A.get<double>((size_t)d.n_groups);
+    d.part_pchi = A.get<double>(K);
     d.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
     d.part_spmv = A.get<double>(NPART * (size_t)d.n_regblk);
     d.part_apply = A.get<double>((size_t)d.n_vecblk);
@@ -710,9 +711,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
         d.ec_on = plain ? 1 : 0;
         {   // the specialised lineariser additionally wants every damper with its four vertices and springs without a kernel
-            bool p4 = plain && d.use_lds && !d.dform && !(s.delta_pos > 0) && !getenv("NRS_NO_PLAIN");
+            bool p4 = plain && d.use_lds && !d.dform && !(s.delta_pos > 0) && s.spring_form == 0 && !getenv("NRS_NO_PLAIN");
             for (int64_t q = 0; q < 4 * (int64_t)s.n_dm && p4; ++q) p4 = s.dm_idx[q] >= 0;
             d.plain = p4 ? 1 : 0;
+            if (d.plain) d.lin_rb = ROW_ALIGN / (64 / T);          // k_lin_plain leaves one partial slot per SLICE (no workgroup barrier behind its loops)
         }
         if (plain) {
             const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
@@ -960,7 +962,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
         for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
     if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
     e->d.ec_on = 0;                                                // masks / fixed vertices: chi2 comes from the incidence records
-    e->d.plain = 0;
+    if (e->d.plain) return c->fail(NRS_ERR_STATE, "masks on a plain BA window: not supported (its partial slots are per slice)");
     NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;

@@ -126,6 +126,7 @@ struct Dev {
     // partials / scalars
     double* part_lin;                // lin_slots x 32  (lineariser: 27 pose sums + chi; per tile on the LDS path, else per group)
     double* part_rchi;               // n_groups        (chi2-only reprojection pass)
+    double* part_pchi;               // K               (plain windows: chi2 of a pose's slices, written by k_pose_sums)
     int lin_rb;                      // part_lin slots per ROW_ALIGN group (tiles per group on the LDS path, else 1)
     double* part_reg;                // n_regblk x 2    (chi, maxdiag)
     double* part_spmv;               // n_regblk x NPART
@@ -134,6 +135,7 @@ struct Dev {
     // chi2 of a trial state, edge-parallel (BA windows without masks: every spring / damper is evaluated
     // once from these lists instead of from the incidence records of the row that counts it)
     int ec_on, ec_nsp, ec_ndm, ec_nblk;
+    long long* dbg_clk;              // NRS_LIN_DBG: per-wave phase clocks of one k_lin_plain launch (8 per slice), else null
     int plain;                       // plain BA window on the LDS path: the lineariser is k_lin_plain (nrs_engine_linearize.hpp)
     EcSpring* ec_sp; EcDamper* ec_dm; float* ec_w; double* part_ec;
     double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
@@ -376,6 +378,12 @@ __device__ inline void row_factored(const RowRec& rc, const Pose& Tcw, const dou
 #pragma unroll
     for (int p = 0; p < 6; ++p) part[3 + p] = w * (Jp[0][p] * tl[0] + Jp[1][p] * tl[1]);
 }
+
+// A prefetched record word is consumed through one of these: the empty asm defines a new value at the point of
+// consumption, so no pass can move the unpacking (mask, shift, conversion) back up behind the load that produced the word
+// -- where it would make the wave wait for a chunk it has only just requested.
+__device__ inline uint32_t consume(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ inline double consume(double v) { asm volatile("" : "+v"(v)); return v; }
 
 // register views of one incidence (see the stream layout at the top)
 __device__ inline SpringRec load_spring(const Dev& P, int j) {

@@ -11,7 +11,9 @@ test budget (tens of seconds per frame), which is why the golden is committed.
 
     python tests/golden/make_c1_golden.py [n_frames]      ->  tests/golden/c1_standin_1000x50.npz
 """
+import functools
 import os
+import pickle
 import sys
 import time
 
@@ -31,14 +33,27 @@ OPTS = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)      
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else N_FRAMES
     sq = S.make_frame_sequence(N_POINTS, n_frames, SEED, S.PINHOLE)
-    proj = lambda pc: FL.project_f32(sq["model"], sq["prm"], pc)
-    loop = FL.FrameLoop(OracleBackend(sq["model"], sq["prm"], OPTS, dense_graph=True), proj, sq["wh"], sq["scale"], sq["kp0"],
-                        sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0], images_to_insert_keyframe=KF_EVERY)
+    proj = functools.partial(FL.project_f32, sq["model"], sq["prm"])
+    # the run takes ~40 minutes: the loop object is checkpointed after every frame (NRS_C1_CKPT=path) so that an interrupted
+    # run resumes; the state after frame f is a deterministic function of the sequence, so a resumed run writes the same file
+    ckpt = os.environ.get("NRS_C1_CKPT")
+    loop, f0 = None, 1
+    if ckpt and os.path.exists(ckpt):
+        with open(ckpt, "rb") as fh:
+            loop, f0 = pickle.load(fh)
+        print("resuming after frame", f0 - 1, flush=True)
+    if loop is None:
+        loop = FL.FrameLoop(OracleBackend(sq["model"], sq["prm"], OPTS, dense_graph=True), proj, sq["wh"], sq["scale"], sq["kp0"],
+                            sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0], images_to_insert_keyframe=KF_EVERY)
     t0 = time.time()
-    for f in range(1, n_frames):
+    for f in range(f0, n_frames):
         assert loop.track_image(sq["images"][f])
         L = loop.log[-1]
         print("frame %d: tracked %d, lost %d, reused %d, keyframe %d  (%.0f s)" % (f, L["n_tracked"], len(L["lost"]), L["reused"], L["keyframe"], time.time() - t0), flush=True)
+        if ckpt:
+            with open(ckpt + ".tmp", "wb") as fh:
+                pickle.dump((loop, f + 1), fh)
+            os.replace(ckpt + ".tmp", ckpt)
     log = loop.log
     out = dict(n_points=N_POINTS, n_frames=n_frames, seed=SEED, kf_every=KF_EVERY,
                pose_q=np.stack([L["pose_q"] for L in log]), pose_t=np.stack([L["pose_t"] for L in log]),
