@@ -131,6 +131,45 @@ def cpu_baseline(p2, e2, ctx=None, ctx_exact=None):
     if ctx is not None:
         out["sparse_cholesky"]["gpu_same_sample"] = gpu_iters_per_s(ctx, p1, e1)
     out["tracked_fps"] = cpu_tracked_fps(ctx is not None)
+    out["tracked_fps"]["compiled"] = cpu_tracked_fps_compiled(lib, ctx is not None)
+    return out
+
+
+def cpu_tracked_fps_compiled(lib, with_gpu):
+    """The two solves of a tracked frame -- a1 CameraPoseOptimization + a2 CameraPoseAndDeformationOptimization (with its
+    graph walks and graph update) -- in the C++ restatement (oracle/nrs_cpu_track.hpp, kind "port": g2o's LM with a full
+    AMD-ordered sparse Cholesky per trial, which is what the reference runs; 1 core, as the reference) on single synthetic
+    frames of 600 / 1150 / 5000 map points, next to the product's two calls on the same inputs (flat kNN-16 graph, host
+    buffers in and out).  LK is not part of this figure on either side (the compiled port covers the solves, > 95 % of the
+    CPU frame); `value` of the enclosing object is the NumPy-driven whole loop."""
+    import nrs
+    import nrs_cpu as CPU
+    import nrs_synth as S
+    out = []
+    for n in (600, 1150, 5000):
+        tp = S.make_tracking_problem(n, 5)
+        m = tp["status"] == 0
+        fm = np.arange(n)
+        t0 = time.perf_counter()
+        q, t, _, _, _ = CPU.pose_only_solve(tp["model"], tp["prm"], tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"], lib)
+        r = CPU.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], q, t, tp["scale"], lib)
+        dt = time.perf_counter() - t0
+        st = r["stats"]
+        row = dict(map_points=n, tracked=int(m.sum()), cpu_ms=1e3 * dt, cpu_frames_per_s=1.0 / dt, cores=1, kind="port",
+                   lm_trials=st["n_trials"], factorisations=st["n_factor"], gflop_per_factorisation=st["chol_flops"] / 1e9,
+                   cpu_factor_ms=1e3 * st["t_factor"])
+        if with_gpu:
+            c = nrs.Context()
+            cam = nrs.make_camera(tp["model"], tp["prm"])
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                gq, gt, _ = c.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
+                c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], gq, gt, tp["scale"])
+                ts.append(time.perf_counter() - t0)
+            c.close()
+            row.update(gpu_ms=1e3 * min(ts), gpu_frames_per_s=1.0 / min(ts), gpu_over_cpu=dt / min(ts))
+        out.append(row)
     return out
 
 

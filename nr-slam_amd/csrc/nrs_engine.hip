@@ -95,8 +95,13 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                 case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
                 default: {
                     static const int occ = getenv("NRS_LIN_OCC") ? atoi(getenv("NRS_LIN_OCC")) : 4;
-                    if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3>), g, b, shm, c->stream, d, xl, cls);
-                    else hipLaunchKernelGGL((k_lin_plain<2, 4>), g, b, shm, c->stream, d, xl, cls);
+                    if (d.cam.model == 0) {
+                        if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3, 0>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 0>), g, b, shm, c->stream, d, xl, cls);
+                    } else {
+                        if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3, 1>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 1>), g, b, shm, c->stream, d, xl, cls);
+                    }
                     break;
                 }
             }

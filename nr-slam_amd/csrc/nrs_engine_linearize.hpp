@@ -562,13 +562,12 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
     return fma(e2, h, g);
 }
 
-template <int T, int OCC = 4>
+template <int T, int OCC = 4, int CAM = -1>
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
-    constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
     int b = xcd_tile(blockIdx.x, P.sh_nt[cls]);
     if (b >= P.sh_nt[cls]) return;
     b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + P.sh_t0[cls] + b];
@@ -583,32 +582,24 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
     const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
-    // Record prefetch.  The loads of a chunk are UNCONDITIONAL (slots past the slice's end read a clamped index and are
-    // treated as padding when they are consumed) and nothing touches the loaded registers before the chunk is processed:
-    // with a predicated load the compiler sinks the unpacking (u32 -> fields, f32 -> f64) into the predicated block, right
-    // behind the load, and the wave then waits out the full memory latency of every chunk it has just requested -- which
-    // is what bounded this pass (and the operator) in rounds 1 and 2.  sched_barrier keeps the phases apart.
+    // Record requests go out in BATCHES of NB slots per lane and stream: all NB requests of a batch are in flight together,
+    // then the slots are consumed one by one -- a wave waits out one memory round trip per batch instead of one per pair of
+    // slots (two-slot double buffering spent ~85 % of the loops waiting: 13.6 us of a 28.6 us wave at C4), and with four
+    // waves per SIMD the others compute meanwhile.  Nothing is carried across loop iterations in registers: software
+    // pipelining across the back edge makes the compiler park register copies behind a vmcnt(0) there.  The loads are
+    // UNCONDITIONAL (slots past the slice's end read a clamped index and count as padding when consumed) and nothing
+    // touches the loaded registers before consume(): with a predicated load the compiler sinks the unpacking behind the
+    // load and the wave waits out the full latency of every single request (rounds 1 and 2).
+    constexpr int NB = 4;
     const int s_last = s_end > 0 ? s_end - 1 : 0, d_last = d_end > 0 ? d_end - 1 : 0;
-    uint32_t somA[U], somB[U], sd0A[U], sd0B[U], dwA[U], dwB[U];
-    uint2 dhA[U], dhB[U];
-    auto load_sh = [&](uint32_t* om, uint32_t* d0, int idx) {
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int j = min(idx + 64 * q, s_last);
-            om[q] = P.s_om[j];
-            d0[q] = __float_as_uint(P.s_d0[j]);
-        }
+    uint32_t rs_om[NB], rs_d0[NB];
+    auto req_s = [&](int q, int idx) {
+        const int j = min(idx, s_last);
+        rs_om[q] = P.s_om[j];
+        rs_d0[q] = __float_as_uint(P.s_d0[j]);
     };
-    auto load_dh = [&](uint2* h, uint32_t* w, int idx) {
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const int j = min(idx + 64 * q, d_last);
-            h[q] = P.d_hdr[j];
-            w[q] = __float_as_uint(P.d_w[j]);
-        }
-    };
-    load_sh(somA, sd0A, s_beg + lane);
-    load_dh(dhA, dwA, d_beg + lane);
+    for (int q = 0; q < NB; ++q) req_s(q, s_beg + lane + 64 * q);  // the first spring batch rides on the staging loads
     __builtin_amdgcn_sched_barrier(0);
     double* lx = dyn;
     stage_rows(P, b, tid, xl_g, nullptr, lx);
@@ -620,75 +611,82 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // ---- springs: r = k (d - d0) / d0, J = cg (x_i - x_j)^T with cg = (k / d0) 2 / sqrt(d) as the reference writes it
     // (position_regularizer.cc:51-60) or k / (d0 d) (tracking form); information info_pos, no kernel
     const double ks = P.k_spring, ip = P.info_pos;
-    auto do_sh = [&](const uint32_t* omv, const uint32_t* d0v, int idx) {
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const uint32_t om = consume(omv[q]);
-            const int o16 = (int)(om & 0xFFFFu);
-            const bool live = idx + 64 * q < s_end;
-            const bool pad = !live || o16 == REC_NONE;
-            const int o = (pad ? self : o16) & 0xFFFF;              // (16 bits: the LDS offset is then one v_mad_u32_u24)
-            const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
-            double d2 = v0 * v0 + v1 * v1 + v2 * v2;
-            d2 = pad ? 1.0 : d2;
-            const double d0 = pad ? 1.0 : (double)__uint_as_float(consume(d0v[q]));
-            const double rs = fast_rsqrt_pos(d2), id0 = fast_rcp_pos(d0);
-            const double r = ks * fma(d2, rs, -d0) * id0;
-            const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);   // (plain windows are BA windows: spring_form 0, checked by engine_create)
-            const double qc = pad ? 0.0 : ip * cg * cg;
-            if (live) P.s_qc[idx + 64 * q] = qc;
-            chi += (om & ((uint32_t)SR_COUNT << 16)) && !pad ? ip * r * r : 0.0;
-            const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
-            D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
-            D3 = fma(t1, v1, D3); D4 = fma(t1, v2, D4); D5 = fma(t2, v2, D5);
-            const double qr = ip * r * cg;                          // (v = 0 on padding slots)
-            bb0 = fma(-qr, v0, bb0); bb1 = fma(-qr, v1, bb1); bb2 = fma(-qr, v2, bb2);
-        }
+    // (a slot's raw words are unpacked BEFORE its successor is requested into the same registers -- the raw value is dead
+    // by then, so the ring needs no register copies, which the compiler otherwise parks behind a vmcnt(0) at the loop's end)
+    auto do_s = [&](int o16, bool live, bool count, float d0f, int idx) {
+        const bool pad = !live || o16 == REC_NONE;
+        const int o = (pad ? self : o16) & 0xFFFF;                  // (16 bits: the LDS offset is then one v_mad_u32_u24)
+        const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
+        double d2 = v0 * v0 + v1 * v1 + v2 * v2;
+        d2 = pad ? 1.0 : d2;
+        const double d0 = pad ? 1.0 : (double)d0f;
+        const double rs = fast_rsqrt_pos(d2), id0 = fast_rcp_pos(d0);
+        const double r = ks * fma(d2, rs, -d0) * id0;
+        const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);       // (plain windows are BA windows: spring_form 0, checked by engine_create)
+        const double qc = pad ? 0.0 : ip * cg * cg;
+        if (live) P.s_qc[idx] = qc;
+        chi += count && !pad ? ip * r * r : 0.0;
+        const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
+        D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
+        D3 = fma(t1, v1, D3); D4 = fma(t1, v2, D4); D5 = fma(t2, v2, D5);
+        const double qr = ip * r * cg;                              // (v = 0 on padding slots)
+        bb0 = fma(-qr, v0, bb0); bb1 = fma(-qr, v1, bb1); bb2 = fma(-qr, v2, bb2);
     };
-    for (int base = s_beg; base < s_end; base += 128 * U) {        // wave-uniform trip count
-        load_sh(somB, sd0B, base + 64 * U + lane);
+    for (int ub = s_beg; ub < s_end; ub += 64 * NB) {              // wave-uniform trip count
+        const int base = ub + lane;
+        if (ub != s_beg) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) req_s(q, base + 64 * q);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        do_sh(somA, sd0A, base + lane);
-        __builtin_amdgcn_sched_barrier(0);
-        load_sh(somA, sd0A, base + 128 * U + lane);
-        __builtin_amdgcn_sched_barrier(0);
-        do_sh(somB, sd0B, base + 64 * U + lane);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const uint32_t om = consume(rs_om[q]);
+            const float d0f = __uint_as_float(consume(rs_d0[q]));
+            do_s((int)(om & 0xFFFFu), base + 64 * q < s_end, (om & ((uint32_t)SR_COUNT << 16)) != 0, d0f, base + 64 * q);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     stamp(2);
     // ---- dampers: r = w ((x1n - x1c) - (x2n - x2c)); the records list the three others in canonical order
     // (engine_create), so that sg_i * sum_k sg_k x_k = (x_i - x[o1]) - (x[o0] - x[o2]) for every role
     const double isp = P.info_spatial, dsp = P.delta_spatial;
-    auto do_dh = [&](const uint2* hdr, const uint32_t* ww, int idx) {
-#pragma unroll
-        for (int q = 0; q < U; ++q) {
-            const uint32_t hx = consume(hdr[q].x), hy = consume(hdr[q].y);
-            const uint32_t m16 = hy >> 16;
-            const bool live = idx + 64 * q < d_end;
-            const bool pad = !live || m16 == REC_NONE;
-            const int o0 = (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
-            const double g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
-            const double g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
-            const double g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
-            const double w = pad ? 0.0 : (double)__uint_as_float(consume(ww[q]));
-            const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
-            double rho0, rho1;
-            huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
-            chi += (m16 & DM_COUNT) ? rho0 : 0.0;                  // (padding: rho0 = 0)
-            const double sfac = rho1 * isp * w * w;
-            if (live) P.d_s[idx + 64 * q] = sfac;
-            D0 += sfac; D3 += sfac; D5 += sfac;
-            bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
-        }
+    uint32_t rd_w[NB];
+    uint2 rd_h[NB];
+    auto req_d = [&](int q, int idx) {
+        const int j = min(idx, d_last);
+        rd_h[q] = P.d_hdr[j];
+        rd_w[q] = __float_as_uint(P.d_w[j]);
     };
-    for (int base = d_beg; base < d_end; base += 128 * U) {
-        load_dh(dhB, dwB, base + 64 * U + lane);
+    auto do_d = [&](uint32_t hx, uint32_t hy, float wf, int idx) {
+        const uint32_t m16 = hy >> 16;
+        const bool live = idx < d_end;
+        const bool pad = !live || m16 == REC_NONE;
+        const int o0 = (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
+        const double g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
+        const double g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
+        const double g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+        const double w = pad ? 0.0 : (double)wf;
+        const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
+        double rho0, rho1;
+        huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
+        chi += (m16 & DM_COUNT) ? rho0 : 0.0;                      // (padding: rho0 = 0)
+        const double sfac = rho1 * isp * w * w;
+        if (live) P.d_s[idx] = sfac;
+        D0 += sfac; D3 += sfac; D5 += sfac;
+        bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
+    };
+    for (int ub = d_beg; ub < d_end; ub += 64 * NB) {
+        const int base = ub + lane;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) req_d(q, base + 64 * q);
         __builtin_amdgcn_sched_barrier(0);
-        do_dh(dhA, dwA, base + lane);
-        __builtin_amdgcn_sched_barrier(0);
-        load_dh(dhA, dwA, base + 128 * U + lane);
-        __builtin_amdgcn_sched_barrier(0);
-        do_dh(dhB, dwB, base + 64 * U + lane);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const uint32_t hx = consume(rd_h[q].x), hy = consume(rd_h[q].y);
+            const float wf = __uint_as_float(consume(rd_w[q]));
+            do_d(hx, hy, wf, base + 64 * q);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     stamp(3);
@@ -719,8 +717,10 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const double py = Rm[3] * xo0 + Rm[4] * xo1 + Rm[5] * xo2 + Tcw.t[1];
         const double pz = Rm[6] * xo0 + Rm[7] * xo1 + Rm[8] * xo2 + Tcw.t[2];
         float u, v, Jf[6];
-        project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
-        projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
+        Cam cam = P.cam;
+        if (CAM >= 0) cam.model = CAM;                             // (one instance per camera model: the pinhole one carries no fisheye code or registers)
+        project_f32(cam, (float)px, (float)py, (float)pz, u, v);
+        projection_jacobian_f32(cam, (float)px, (float)py, (float)pz, Jf);
         const double r2[2] = {(double)uvx - (double)u, (double)uvy - (double)v};
         double rho0, rho1;
         huber(P.info_reproj * (r2[0] * r2[0] + r2[1] * r2[1]), P.delta_reproj, rho0, rho1);

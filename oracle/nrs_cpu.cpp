@@ -318,7 +318,7 @@ struct BlockChol {
     bool factor(const BlockMat& A, double lam) {
         vector<int> s(n), w(n, -1);
         vector<double> x(9 * (size_t)n, 0.0);
-        if (rowi.size() != (size_t)nnz_blocks) {
+        if (rowi.size() != (size_t)nnz_blocks || Ld.size() != 9 * (size_t)n) {           // (a block-diagonal matrix has no off-diagonal block at all)
             rowi.assign((size_t)nnz_blocks, 0);
             Lx.assign(9 * (size_t)nnz_blocks, 0.0);
             Ld.assign(9 * (size_t)n, 0.0);
@@ -919,6 +919,8 @@ struct Pcg {
     }
 };
 
+#include "nrs_cpu_track.hpp"
+
 }  // namespace
 
 extern "C" {
@@ -1122,6 +1124,227 @@ int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* pos
     if (trace_n) *trace_n = n_tr;
     S.n_trials = n_tr;
     S.n_iters = done_iters;
+    S.t_total = now_s() - t_begin;
+    if (st) *st = S;
+    return 0;
+}
+
+// a1: CameraPoseOptimization (g2o_optimization.cc:50-146).  uv n x 2, X n x 3 (float, as the boundary hands them over),
+// pose_qt in/out, inlier out (n bytes).
+int nrs_cpu_pose_only_solve(int32_t model, const float* prm, int32_t n, const float* uv, const float* X, double* pose_qt,
+                            uint8_t* inlier, Trial* trace, int32_t trace_cap, int32_t* trace_n, TStats* st) {
+    const double t_begin = now_s();
+    TStats S;
+    std::memset(&S, 0, sizeof(S));
+    TGraph G;
+    G.st = &S;
+    G.model = model;
+    std::memcpy(G.prm, prm, sizeof(float) * 8);
+    Pose seed;
+    for (int i = 0; i < 4; ++i) seed.q[i] = pose_qt[i];
+    for (int i = 0; i < 3; ++i) seed.t[i] = pose_qt[4 + i];
+    quat_normalize(seed.q);
+    G.N = 0; G.rep_pt = false; G.n_rep = n;
+    G.X0.resize(3 * (size_t)n); G.uv.resize(2 * (size_t)n); G.rep_err.assign(2 * (size_t)n, 0.0); G.rep_level.assign(n, 0);
+    for (size_t i = 0; i < 3 * (size_t)n; ++i) G.X0[i] = (double)X[i];
+    for (size_t i = 0; i < 2 * (size_t)n; ++i) G.uv[i] = (double)uv[i];
+    const float th2_sq = 5.99f, th2 = std::sqrt(th2_sq);
+    G.info_rep = 1.0; G.delta_rep = (double)th2;
+    vector<uint8_t> inl(n, 1);
+    int n_tr = 0;
+    for (int rnd = 0; rnd < 3; ++rnd) {
+        G.pose = seed;
+        G.optimize(10, rnd, trace, trace_cap, &n_tr);
+        // OPT:115-140: outliers get a fresh error, inliers keep the one the last computeActiveErrors stored
+        for (int i = 0; i < n; ++i) {
+            if (!inl[i]) G.rep_residual(i, &G.rep_err[2 * (size_t)i]);
+            const double* r = &G.rep_err[2 * (size_t)i];
+            const float chi = (float)(G.info_rep * (r[0] * r[0] + r[1] * r[1]));
+            inl[i] = !(chi > th2_sq);
+            G.rep_level[i] = inl[i] ? 0 : 1;
+        }
+        if (rnd == 2) G.delta_rep = 0;                               // setRobustKernel(0) after the last optimize(): no effect on the solve
+    }
+    for (int i = 0; i < 4; ++i) pose_qt[i] = G.pose.q[i];
+    for (int i = 0; i < 3; ++i) pose_qt[4 + i] = G.pose.t[i];
+    if (inlier) std::memcpy(inlier, inl.data(), n);
+    if (trace_n) *trace_n = n_tr;
+    S.t_total = now_s() - t_begin;
+    if (st) *st = S;
+    return 0;
+}
+
+// a2: CameraPoseAndDeformationOptimization (g2o_optimization.cc:148-557) on the flat graph of include/nrs.h (nrs_graph):
+// f_* = the frame's landmarks in index order, map_pos = MapPoint::GetLastWorldPosition of every map point; graph edge state,
+// map_pos, f_status, f_pos, pose_qt are updated in place; lost (room for n_points ids) = the re-located lost map points.
+int nrs_cpu_track_deform_solve(int32_t model, const float* prm, int32_t n_points, const int32_t* rowptr, const int32_t* col,
+                               const int32_t* eid, float* e_w, const float* e_d0, float* e_max, float* e_min, int32_t* e_status,
+                               float sigma, float stretch_th, float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status,
+                               const float* f_uv, float* f_pos, double* pose_qt, float scale, float* deform_median, int32_t* n_lost,
+                               int32_t* lost_out, Trial* trace, int32_t trace_cap, int32_t* trace_n, TStats* st) {
+    const double t_begin = now_s();
+    TStats S;
+    std::memset(&S, 0, sizeof(S));
+    FlatGraph g{n_points, rowptr, col, eid, e_w, e_max, e_min, e_d0, e_status, sigma, stretch_th, 0.f};
+    g.min_w = FlatGraph::weight((float)((double)sigma * 1.5), sigma);                 // regularization_graph.cc:28-36
+    if (n_lost) *n_lost = 0;
+    if (deform_median) *deform_median = 0.f;
+    if (trace_n) *trace_n = 0;
+    vector<int> map_to_frame(n_points, -1), opt_f, ids;
+    for (int i = 0; i < n_f; ++i) if (f_map[i] >= 0) map_to_frame[f_map[i]] = i;
+    for (int i = 0; i < n_f; ++i) if (f_status[i] == 0 && f_map[i] >= 0) { opt_f.push_back(i); ids.push_back(f_map[i]); }
+    const int N = (int)opt_f.size();
+    if (N == 0) return 0;
+    vector<int> id_to_idx(n_points, -1);
+    for (int i = 0; i < N; ++i) id_to_idx[ids[i]] = i;
+    TGraph G;
+    G.st = &S;
+    G.model = model;
+    std::memcpy(G.prm, prm, sizeof(float) * 8);
+    Pose seed;
+    for (int i = 0; i < 4; ++i) seed.q[i] = pose_qt[i];
+    for (int i = 0; i < 3; ++i) seed.t[i] = pose_qt[4 + i];
+    quat_normalize(seed.q);
+    G.N = N; G.n_rep = N; G.rep_pt = true;
+    G.x.assign(3 * (size_t)N, 0.0); G.pt_fixed.assign(N, 0);
+    G.X0.resize(3 * (size_t)N); G.uv.resize(2 * (size_t)N); G.rep_err.assign(2 * (size_t)N, 0.0); G.rep_level.assign(N, 0);
+    for (int i = 0; i < N; ++i) {
+        for (int a = 0; a < 3; ++a) G.X0[3 * (size_t)i + a] = (double)f_pos[3 * (size_t)opt_f[i] + a];
+        for (int a = 0; a < 2; ++a) G.uv[2 * (size_t)i + a] = (double)f_uv[2 * (size_t)opt_f[i] + a];
+    }
+    {   // OPT:195-210, float arithmetic widened to double
+        const float th2 = std::sqrt(5.99f), th3 = std::sqrt(0.584f);
+        const float sigma_spatial = (float)(0.1 * (double)scale);
+        G.info_rep = (double)(1.0f / (0.5f * 0.5f)); G.delta_rep = (double)th2;
+        G.info_sp = (double)(1.0f / (0.1f * 0.1f)); G.delta_sp = (double)th3;
+        G.info_dm = (double)(1.0f / (sigma_spatial * sigma_spatial)); G.delta_dm = (double)th3;
+        G.k_spring = (double)1.1f;
+    }
+    // ---- edge construction OPT:224-337
+    double t0 = now_s();
+    vector<vector<std::pair<int, int>>> reg(N);
+    vector<uint8_t> lost_flag(n_points, 0);
+    vector<int> walk;
+    for (int idx = 0; idx < N; ++idx) {
+        int n_reg = 0;
+        g.get_edges(ids[idx], walk);
+        for (int a : walk) {
+            const int other = col[a], e = eid[a];
+            if (n_reg > 10 || e_status[e] == 3) break;
+            const int fo = map_to_frame[other];
+            if (fo < 0 || f_status[fo] != 0) {
+                if (fo >= 0 && f_status[fo] != 2) lost_flag[other] = 1;
+                continue;
+            }
+            const int io = id_to_idx[other];
+            bool dup = false;
+            for (auto& pr : reg[idx]) dup = dup || pr.first == io;
+            if (dup) continue;
+            const int k = G.E();
+            G.ei.push_back(idx); G.ej.push_back(io); G.ew.push_back((double)e_w[e]); G.ed0.push_back((double)e_d0[e]);
+            reg[idx].push_back({io, k});
+            reg[io].push_back({idx, k});
+            ++n_reg;
+        }
+    }
+    S.t_graph += now_s() - t0;
+    const int E = G.E();
+    G.dm_level.assign(E, 0); G.dm_err.assign(3 * (size_t)E, 0.0);
+    const float th2_sq = 5.99f, th3_sq = 0.584f;
+    vector<uint8_t> inl(N, 1);
+    int n_tr = 0;
+    vector<float> chi(N);
+    auto reproj_chi = [&]() {
+        for (int i = 0; i < N; ++i) {
+            double* r = &G.rep_err[2 * (size_t)i];
+            G.rep_residual(i, r);
+            chi[i] = (float)(G.info_rep * (r[0] * r[0] + r[1] * r[1]));
+        }
+    };
+    for (int rnd = 0; rnd < 2; ++rnd) {                               // OPT:338-395
+        G.pose = seed;
+        std::fill(G.x.begin(), G.x.end(), 0.0);
+        G.optimize(10, rnd, trace, trace_cap, &n_tr);
+        reproj_chi();
+        for (int idx = 0; idx < N; ++idx) {
+            const bool out = chi[idx] > th2_sq;
+            inl[idx] = !out;
+            G.rep_level[idx] = out ? 1 : 0;
+            for (auto& pr : reg[idx]) G.dm_level[pr.second] = out ? 1 : 0;
+            for (auto& pr : reg[idx]) {
+                double* r = &G.dm_err[3 * (size_t)pr.second];
+                G.dm_residual(pr.second, r);
+                G.dm_level[pr.second] = G.info_dm * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) > (double)th3_sq ? 1 : 0;
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) pose_qt[i] = G.pose.q[i];
+    for (int i = 0; i < 3; ++i) pose_qt[4 + i] = G.pose.t[i];
+    // ---- OPT:401-455
+    vector<float> delta(3 * (size_t)N), mag(N);
+    for (int i = 0; i < N; ++i) {
+        for (int a = 0; a < 3; ++a) delta[3 * (size_t)i + a] = (float)G.x[3 * (size_t)i + a];
+        const float dx = delta[3 * (size_t)i], dy = delta[3 * (size_t)i + 1], dz = delta[3 * (size_t)i + 2];
+        float s = dx * dx;
+        const float sy = dy * dy, sz = dz * dz;
+        s = s + sy;
+        s = s + sz;
+        mag[i] = std::sqrt(s);
+    }
+    vector<float> srt(mag);
+    std::sort(srt.begin(), srt.end());
+    const float q1 = srt[(int)((float)N * 0.25f)], q3 = srt[(int)((float)N * 0.75f)];
+    const float th = 1.5f * (q3 - q1);
+    reproj_chi();
+    for (int idx = 0; idx < N; ++idx) {
+        const int fi = opt_f[idx];
+        if (chi[idx] > th2_sq) { inl[idx] = 0; f_status[fi] = 1; }
+        if (mag[idx] >= q3 + th) { f_status[fi] = 1; continue; }      // (rejected before setFixed: keeps moving in stage 2)
+        G.pt_fixed[idx] = 1;
+        for (int a = 0; a < 3; ++a) {
+            const float cur = delta[3 * (size_t)idx + a] + f_pos[3 * (size_t)fi + a];
+            f_pos[3 * (size_t)fi + a] = cur;
+            map_pos[3 * (size_t)ids[idx] + a] = cur;
+        }
+    }
+    if (deform_median) *deform_median = srt[N / 2];
+    // ---- graph update OPT:457-474
+    t0 = now_s();
+    for (int idx = 0; idx < N; ++idx) {
+        if (!inl[idx]) continue;
+        const int good = g.update_vertex(ids[idx], map_pos);
+        if ((double)good < 10 * 0.5) f_status[opt_f[idx]] = 3;
+    }
+    S.t_graph += now_s() - t0;
+    // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
+    vector<int> lost;
+    for (int p = 0; p < n_points; ++p) if (lost_flag[p]) lost.push_back(p);
+    const int L = (int)lost.size();
+    if (L > 0) {
+        G.N = N + L;
+        G.x.resize(3 * (size_t)(N + L), 0.0);
+        G.pt_fixed.resize(N + L, 0);
+        t0 = now_s();
+        for (int li = 0; li < L; ++li) {
+            int n_reg = 0;
+            g.get_edges(lost[li], walk);
+            for (int a : walk) {
+                if (n_reg > 10) break;
+                const int io = id_to_idx[col[a]];
+                if (io < 0) continue;
+                G.ui.push_back(N + li); G.uj.push_back(io); G.uw.push_back((double)e_w[eid[a]]);
+                ++n_reg;
+            }
+        }
+        S.t_graph += now_s() - t0;
+        G.pose_fixed = true;
+        G.optimize(10, 2, trace, trace_cap, &n_tr);
+        for (int li = 0; li < L; ++li)
+            for (int a = 0; a < 3; ++a) map_pos[3 * (size_t)lost[li] + a] = (float)G.x[3 * (size_t)(N + li) + a] + map_pos[3 * (size_t)lost[li] + a];
+        if (lost_out) std::memcpy(lost_out, lost.data(), sizeof(int32_t) * L);
+    }
+    if (n_lost) *n_lost = L;
+    if (trace_n) *trace_n = n_tr;
     S.t_total = now_s() - t_begin;
     if (st) *st = S;
     return 0;

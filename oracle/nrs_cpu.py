@@ -81,3 +81,66 @@ def dba_solve(model, prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, 
 
 def max_threads(lib=None):
     return (lib or load()).nrs_cpu_max_threads()
+
+
+# ---- per-frame solves (oracle/nrs_cpu_track.hpp): a1 CameraPoseOptimization, a2 CameraPoseAndDeformationOptimization -------
+class TStats(C.Structure):
+    _fields_ = [("t_total", C.c_double), ("t_graph", C.c_double), ("t_structure", C.c_double), ("t_factor", C.c_double),
+                ("t_solve", C.c_double), ("t_linearize", C.c_double), ("chol_flops", C.c_double), ("n_factor", C.c_int32),
+                ("n_trials", C.c_int32), ("n_iters", C.c_int32), ("unknowns_max", C.c_int32)]
+
+
+def _trace_list(tr, n):
+    return [dict(round=t.iter // 100, iter=t.iter % 100, trial=t.trial, accepted=bool(t.accepted), ok=bool(t.ok), lam=t.lam, chi=t.chi,
+                 chi_new=t.chi_new, rho=t.rho) for t in tr[:min(n, len(tr))]]
+
+
+def pose_only_solve(model, prm, uv, X, pose_q, pose_t, lib=None):
+    """returns (pose_q, pose_t, inlier mask, trace, stats)"""
+    lib = lib or load()
+    p8 = np.zeros(8, np.float32)
+    p8[:len(prm)] = np.asarray(prm, np.float32)
+    uv, X = np.ascontiguousarray(uv, np.float32), np.ascontiguousarray(X, np.float32)
+    qt = np.ascontiguousarray(np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)]))
+    inl = np.zeros(len(uv), np.uint8)
+    tr = (Trial * 512)()
+    ntr, st = C.c_int32(0), TStats()
+    rc = lib.nrs_cpu_pose_only_solve(C.c_int32(int(model)), _p(p8, C.c_float), C.c_int32(len(uv)), _p(uv, C.c_float), _p(X, C.c_float),
+                                     _p(qt, C.c_double), _p(inl, C.c_uint8), tr, C.c_int32(512), C.byref(ntr), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("nrs_cpu_pose_only_solve failed: %d" % rc)
+    return qt[:4].copy(), qt[4:].copy(), inl.astype(bool), _trace_list(tr, ntr.value), {k: getattr(st, k) for k, _ in TStats._fields_}
+
+
+def track_deform_solve(model, prm, graph, map_pos, f_map, f_status, f_uv, f_pos, pose_q, pose_t, scale, lib=None):
+    """the flat-graph form of oracle/nrs_oracle.track_deform_solve; the graph dict is copied, the updated copy returned"""
+    lib = lib or load()
+    p8 = np.zeros(8, np.float32)
+    p8[:len(prm)] = np.asarray(prm, np.float32)
+    g = {k: (np.ascontiguousarray(v).copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+    for k in ("rowptr", "col", "eid", "e_status"):
+        g[k] = np.ascontiguousarray(g[k], np.int32)
+    for k in ("e_w", "e_d0", "e_max", "e_min"):
+        g[k] = np.ascontiguousarray(g[k], np.float32)
+    map_pos = np.ascontiguousarray(map_pos, np.float32).copy()
+    f_map = np.ascontiguousarray(f_map, np.int32)
+    f_status = np.ascontiguousarray(f_status, np.int32).copy()
+    f_uv = np.ascontiguousarray(f_uv, np.float32)
+    f_pos = np.ascontiguousarray(f_pos, np.float32).copy()
+    qt = np.ascontiguousarray(np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)]))
+    n_points = len(map_pos)
+    lost = np.zeros(n_points, np.int32)
+    med, nl = C.c_float(0), C.c_int32(0)
+    tr = (Trial * 1024)()
+    ntr, st = C.c_int32(0), TStats()
+    rc = lib.nrs_cpu_track_deform_solve(C.c_int32(int(model)), _p(p8, C.c_float), C.c_int32(n_points), _p(g["rowptr"], C.c_int32),
+                                        _p(g["col"], C.c_int32), _p(g["eid"], C.c_int32), _p(g["e_w"], C.c_float), _p(g["e_d0"], C.c_float),
+                                        _p(g["e_max"], C.c_float), _p(g["e_min"], C.c_float), _p(g["e_status"], C.c_int32),
+                                        C.c_float(float(g["sigma"])), C.c_float(float(g["stretch_th"])), _p(map_pos, C.c_float),
+                                        C.c_int32(len(f_map)), _p(f_map, C.c_int32), _p(f_status, C.c_int32), _p(f_uv, C.c_float),
+                                        _p(f_pos, C.c_float), _p(qt, C.c_double), C.c_float(float(scale)), C.byref(med), C.byref(nl), _p(lost, C.c_int32),
+                                        tr, C.c_int32(1024), C.byref(ntr), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("nrs_cpu_track_deform_solve failed: %d" % rc)
+    return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos, graph=g, median=float(med.value),
+                lost=lost[:nl.value].tolist(), trace=_trace_list(tr, ntr.value), stats={k: getattr(st, k) for k, _ in TStats._fields_})

@@ -1,0 +1,70 @@
+"""The C++ restatement of the per-frame solves (oracle/nrs_cpu_track.hpp: the compiled CPU baseline of the tracked-fps half of
+the metric and a second checker) held to the NumPy oracle: a1 CameraPoseOptimization and a2
+CameraPoseAndDeformationOptimization on the committed goldens and on fresh synthetic frames -- identical LM accept / reject
+sequences, lambda / chi2 of the leading trials, inlier masks, statuses, lost sets and graph state exact, poses 1e-9,
+positions 1e-6 (the two differ in their linear solve only: dense / SuperLU there, AMD-ordered block Cholesky here)."""
+import os
+
+import numpy as np
+import pytest
+
+import nrs_cpu as CPU
+import nrs_oracle as O
+import nrs_synth as S
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cpu_lib():
+    CPU.build()
+    return CPU.load()
+
+
+def _same_leading_trials(a, b, rounds, rtol=1e-7, noise=3e-7):
+    n = 0
+    for rnd in range(rounds):
+        x = [t for t in a if t["round"] == rnd]
+        y = b[rnd]
+        for i, t in enumerate(y):
+            if abs(t["chi"] - t["chi_new"]) <= noise * abs(t["chi"]):
+                break                                    # from here on decisions sit on the fp32-projection noise floor
+            assert i < len(x) and x[i]["accepted"] == t["accepted"], (rnd, i)
+            assert abs(x[i]["chi"] - t["chi"]) <= rtol * abs(t["chi"]) + 1e-9 and abs(x[i]["lam"] - t["lam"]) <= rtol * abs(t["lam"])
+            n += 1
+    return n
+
+
+def test_pose_only_golden_and_fresh(cpu_lib):
+    d = np.load(os.path.join(G, "pose_only_120.npz"))
+    q, t, inl, tr, st = CPU.pose_only_solve(int(d["model"]), d["prm"], d["uv"], d["X"], d["pose_q"], d["pose_t"], cpu_lib)
+    assert np.allclose(q, d["out_q"], atol=1e-9) and np.allclose(t, d["out_t"], atol=1e-8) and np.array_equal(inl, d["out_inlier"])
+    for n, seed, model in ((400, 3, S.PINHOLE), (300, 4, S.KB8)):
+        tp = S.make_tracking_problem(n, seed, model)
+        m = tp["status"] == 0
+        otr = []
+        oq, ot, oinl = O.pose_only_solve(tp["model"], tp["prm"], tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"], otr)
+        q, t, inl, tr, st = CPU.pose_only_solve(tp["model"], tp["prm"], tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"], cpu_lib)
+        assert np.allclose(q, oq, atol=1e-9) and np.allclose(t, ot, atol=1e-8) and np.array_equal(inl, oinl)
+        assert _same_leading_trials(tr, otr, 3) > 6
+
+
+@pytest.mark.parametrize("n,seed,model", [(150, 5, S.PINHOLE), (400, 6, S.PINHOLE), (350, 7, S.KB8)])
+def test_track_deform_matches_numpy_oracle(cpu_lib, n, seed, model):
+    tp = S.make_tracking_problem(n, seed, model)
+    fm = np.arange(n)
+    otr = []
+    o = O.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
+                             tp["pose_q"], tp["pose_t"], tp["scale"], otr)
+    r = CPU.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"],
+                               tp["pose_q"], tp["pose_t"], tp["scale"], cpu_lib)
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == list(o["lost"])
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-9) and np.allclose(r["pose_t"], o["pose_t"], atol=1e-8)
+    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-6) and np.allclose(r["map_pos"], o["map_pos"], atol=1e-6)
+    for k in ("e_status",):
+        assert np.array_equal(r["graph"][k], o["graph"][k])
+    for k in ("e_w", "e_max", "e_min"):
+        assert np.allclose(r["graph"][k], o["graph"][k], atol=1e-6)
+    assert abs(r["median"] - o["median"]) <= 1e-6
+    assert _same_leading_trials(r["trace"], otr, len(otr)) > 10
+    assert r["stats"]["n_factor"] == r["stats"]["n_trials"] > 0

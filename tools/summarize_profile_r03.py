@@ -85,3 +85,15 @@ for W in ("C2", "C4"):
     p = os.path.join(dst, "r03_pmc_summary_%s.csv" % W)
     if os.path.exists(p):
         print(open(p).read()[:3000])
+
+# VALU / LDS instructions per wave of the lineariser (full launches): specialised kernel vs the generic one (NRS_NO_PLAIN=1)
+with open(os.path.join(dst, "r03_lineariser_instructions_C4.txt"), "w") as fo:
+    for tag, label in (("pmc_insts_C4", "k_lin_plain (this round)"), ("pmc_insts_C4_generic", "k_reg<2,true,true> (round 2 kernel, NRS_NO_PLAIN=1)")):
+        for k, cs in counters(tag).items():
+            if "k_lin_plain" not in k and "k_reg<2, true, true" not in k:
+                continue
+            v = {c: full_launch_avg(vals)[1] for c, vals in cs.items()}
+            if v.get("SQ_WAVES"):
+                fo.write("%s: %s\n  per launch: SQ_INSTS_VALU %.4g, SQ_INSTS_LDS %.4g, SQ_WAVES %.4g -> VALU instructions per wave %.0f (x4 waves = per tile %.0f), LDS instructions per wave %.0f\n"
+                         % (label, k, v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_LDS", 0), v["SQ_WAVES"], v.get("SQ_INSTS_VALU", 0) / v["SQ_WAVES"],
+                            4 * v.get("SQ_INSTS_VALU", 0) / v["SQ_WAVES"], v.get("SQ_INSTS_LDS", 0) / v["SQ_WAVES"]))
