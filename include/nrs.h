@@ -161,6 +161,13 @@ int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_s
                       double* r_damper /* n_damper x 3 */);
 int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
 
+/* Parity tap of the problem construction (edge lists -> row layout, sliced-ELL incidence streams, halo lists, chi2 edge lists;
+ * g2o_optimization.cc:927-1137 ends where this starts): FNV-1a checksums of every packed array of the resident problem,
+ * out[0..24).  A plain BA window of >= 32768 padded rows is packed on the device (csrc/nrs_engine_devpack.hpp), everything else
+ * -- and everything under NRS_HOST_PACK=1 -- on the host; the two constructions produce the same bits (out[21] says which one
+ * ran: 1 = device; it is not part of the comparison). */
+int nrs_dba_pack_hash(nrs_ctx* ctx, uint64_t* out /* 24 */);
+
 /* Parity tap for a18 (the linear solve): solves (H + lambda I) x = b for an explicitly given block system with
  * the engine's own PCG kernels (block-Jacobi preconditioner, operator on stored blocks, single-reduction CG),
  * as g2o's linear solvers are handed an explicit SparseBlockMatrix in the reference's known-answer test

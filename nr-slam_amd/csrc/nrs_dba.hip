@@ -148,6 +148,13 @@ extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
     return engine_gradient(c, c->dba, b, diag);
 }
 
+extern "C" int nrs_dba_pack_hash(nrs_ctx* c, uint64_t* out) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if (!out) return c->fail(NRS_ERR_INVALID, "null output");
+    return engine_pack_hash(c, c->dba, out);
+}
+
 // parity tap (include/nrs.h): an explicit one-pose / n-row block system through the engine's PCG kernels
 extern "C" int nrs_debug_pcg_solve(nrs_ctx* c, int32_t n_rows, const double* Hpp21, const double* bp, const double* D6,
                                    const double* Hpl18, const double* bl, double lambda, double* x, int32_t* iters) {

@@ -55,6 +55,7 @@
 #include "nrs_engine_coarse.hpp"
 #include "nrs_engine_pcg.hpp"
 #include "nrs_engine_setup.hpp"
+#include "nrs_engine_devpack.hpp"
 
 namespace nrs {
 
@@ -553,10 +554,15 @@ int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, 
     float *t_d0 = reinterpret_cast<float*>(tb + o_d0), *t_w = reinterpret_cast<float*>(tb + o_w);
     if (c->tap_serial != e->serial) {
         NRS_HIP(c, hipMemcpyAsync(t_vrow, e->vrow.data(), sizeof(int) * (size_t)d.M, hipMemcpyHostToDevice, c->stream));
-        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_sp, e->sp_ij.data(), sizeof(int) * 2 * (size_t)d.n_sp, hipMemcpyHostToDevice, c->stream));
-        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_d0, e->sp_d0.data(), sizeof(float) * (size_t)d.n_sp, hipMemcpyHostToDevice, c->stream));
-        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_dm, e->dm_idx.data(), sizeof(int) * 4 * (size_t)d.n_dm, hipMemcpyHostToDevice, c->stream));
-        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_w, e->dm_w.data(), sizeof(float) * (size_t)d.n_dm, hipMemcpyHostToDevice, c->stream));
+        const hipMemcpyKind kd = e->dev_edges ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        const int* src_sp = e->dev_edges ? e->raw_sp : e->sp_ij.data();
+        const float* src_d0 = e->dev_edges ? e->raw_d0 : e->sp_d0.data();
+        const int* src_dm = e->dev_edges ? e->raw_dm : e->dm_idx.data();
+        const float* src_w = e->dev_edges ? e->raw_w : e->dm_w.data();
+        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_sp, src_sp, sizeof(int) * 2 * (size_t)d.n_sp, kd, c->stream));
+        if (d.n_sp) NRS_HIP(c, hipMemcpyAsync(t_d0, src_d0, sizeof(float) * (size_t)d.n_sp, kd, c->stream));
+        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_dm, src_dm, sizeof(int) * 4 * (size_t)d.n_dm, kd, c->stream));
+        if (d.n_dm) NRS_HIP(c, hipMemcpyAsync(t_w, src_w, sizeof(float) * (size_t)d.n_dm, kd, c->stream));
         c->tap_serial = e->serial;
     }
     double* rr = reinterpret_cast<double*>(tb + o_out);
@@ -586,6 +592,57 @@ int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj, double* spring, doub
     if (damper)
         for (int i = 0; i < d.n_dm; ++i)
             damper[i] = d.info_spatial * (rd[3 * i] * rd[3 * i] + rd[3 * i + 1] * rd[3 * i + 1] + rd[3 * i + 2] * rd[3 * i + 2]);
+    return NRS_OK;
+}
+
+// parity tap of the problem construction: FNV-1a checksums of every packed array of the resident problem (host or device
+// built: the two must agree bit for bit), out[0..24)
+int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out) {
+    const Dev& d = e->d;
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    auto fnv = [](const void* p, size_t n) {
+        uint64_t h = 1469598103934665603ULL;
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ULL; }
+        return h;
+    };
+    std::vector<char> buf;
+    auto dev = [&](const void* p, size_t bytes, uint64_t* o) {
+        buf.resize(std::max<size_t>(bytes, 1));
+        if (bytes && hipMemcpy(buf.data(), p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        *o = fnv(buf.data(), bytes);
+        return true;
+    };
+    for (int i = 0; i < 24; ++i) out[i] = 0;
+    const size_t ns = (size_t)d.n_rows / (64 / d.T), nt = (size_t)d.n_regblk;
+    std::vector<int> hp(nt + 1);
+    NRS_HIP(c, hipMemcpy(hp.data(), d.halo_ptr, sizeof(int) * (nt + 1), hipMemcpyDeviceToHost));
+    const size_t n_halo = (size_t)hp[nt];
+    bool ok = true;
+    out[0] = fnv(e->vrow.data(), sizeof(int) * e->vrow.size());
+    ok = ok && dev(d.ss_ptr, sizeof(int) * (ns + 1), &out[1]) && dev(d.sd_ptr, sizeof(int) * (ns + 1), &out[2]);
+    ok = ok && dev(d.s_om, sizeof(uint32_t) * (size_t)d.ss_nnz, &out[3]) && dev(d.s_d0, sizeof(float) * (size_t)d.ss_nnz, &out[4]);
+    ok = ok && dev(d.d_hdr, sizeof(uint2) * (size_t)d.sd_nnz, &out[5]) && dev(d.d_w, sizeof(float) * (size_t)d.sd_nnz, &out[6]);
+    out[7] = fnv(hp.data(), sizeof(int) * hp.size());
+    ok = ok && dev(d.halo_rows, sizeof(int) * n_halo, &out[8]) && dev(d.halo_ns, sizeof(int) * nt, &out[9]) && dev(d.tile_list, sizeof(int) * nt, &out[10]);
+    if (d.ec_on) {
+        std::vector<EcSpring> es((size_t)d.ec_nsp);
+        std::vector<EcDamper> ed((size_t)d.ec_ndm);
+        if (d.ec_nsp) NRS_HIP(c, hipMemcpy(es.data(), d.ec_sp, sizeof(EcSpring) * es.size(), hipMemcpyDeviceToHost));
+        if (d.ec_ndm) NRS_HIP(c, hipMemcpy(ed.data(), d.ec_dm, sizeof(EcDamper) * ed.size(), hipMemcpyDeviceToHost));
+        for (auto& x : es) x.pad = 0;
+        out[11] = fnv(es.data(), sizeof(EcSpring) * es.size());
+        out[12] = fnv(ed.data(), sizeof(EcDamper) * ed.size());
+        ok = ok && dev(d.ec_w, sizeof(float) * (size_t)d.ec_ndm, &out[13]);
+    }
+    ok = ok && dev(d.rflag, (size_t)d.n_rows, &out[14]) && dev(d.uv, sizeof(float) * 2 * (size_t)d.n_rows, &out[15]);
+    ok = ok && dev(d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, &out[16]) && dev(d.pose_init, sizeof(Pose) * (size_t)d.K, &out[17]);
+    ok = ok && dev(d.grp_pose, sizeof(int) * (size_t)d.n_groups, &out[18]) && dev(d.pose_grp_ptr, sizeof(int) * ((size_t)d.K + 1), &out[19]);
+    const int sc[16] = {d.n_rows, d.T, d.ss_nnz, d.sd_nnz, d.max_halo, d.max_halo_s, d.n_tiles_cls[0], d.n_tiles_cls[1], d.cap_h[0], d.cap_h[1], d.cap_s[0], d.cap_s[1],
+                        d.ec_nblk, d.lin_rb, d.hier, d.plain};
+    out[20] = fnv(sc, sizeof(sc));
+    out[21] = e->dev_edges ? 1 : 0;                                  // (which path built it: not part of the comparison)
+    if (!ok) return c->fail(NRS_ERR_HIP, "pack hash: a device copy failed");
     return NRS_OK;
 }
 

@@ -58,7 +58,8 @@ int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x);      // call
 // fresh computeError() at the current estimate: chi2 = r^T Omega r of every edge
 int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring /*n_sp*/, double* damper /*n_dm*/);
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
-int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);       // solver order, caller vertex order
+int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);
+int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out /*24*/);    // checksums of the packed arrays (host- or device-built)       // solver order, caller vertex order
 // parity tap: (H + lam I) x = b for explicitly given blocks (one pose, M landmark rows, no regularisers) through
 // the engine's own PCG kernels; the engine must have been created with force_gather and K = 1
 int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,

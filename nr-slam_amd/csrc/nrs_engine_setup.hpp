@@ -221,6 +221,9 @@ void shard_plan(int K, const int* grp_ptr, int world, int* kb) {
     kb[world] = K;
 }
 
+static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows);
+static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine* e, bool* done);
+
 int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     *out = nullptr;
     // failures every rank of a sharded upload sees alike (argument validation on identical inputs) are reported
@@ -260,6 +263,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         std::vector<int> cnt(s.K, 0);
         for (int i = 0; i < s.M; ++i) cnt[s.lm_pose[i]]++;
         for (int k = 0; k < s.K; ++k) n_pad_rows += std::max(1, (cnt[k] + ROW_ALIGN - 1) / ROW_ALIGN) * ROW_ALIGN;
+    }
+    if (devpack_eligible(c, s, n_pad_rows)) {                      // plain BA window on the two-kernel path: built on the device
+        bool done = false;
+        NRS_TRY(engine_create_device(c, s, arena, e, &done));
+        if (done) { guard.keep = true; *out = e; return NRS_OK; }
+        *e = Engine();                                             // (did not qualify after all: the host path, from scratch)
+        e->arena = arena;
+        memset(&d, 0, sizeof(d));
     }
     int T = n_pad_rows >= 32768 ? 2 : 8;
     if (const char* ev = getenv("NRS_SELL_T")) {

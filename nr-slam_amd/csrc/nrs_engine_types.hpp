@@ -182,6 +182,10 @@ struct Engine {
     std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
     unsigned long long serial = 0;   // identifies this engine to the context's tap buffer (nrs_ctx::tap)
+    // device-packed engines (nrs_engine_devpack.hpp) keep no host copies of the edges: the taps read the raw device copies
+    bool dev_edges = false;
+    const int *raw_sp = nullptr, *raw_dm = nullptr;
+    const float *raw_d0 = nullptr, *raw_w = nullptr;
 };
 
 // =====================================================================================

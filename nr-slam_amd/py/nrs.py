@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_debug_pcg_solve",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_debug_pcg_solve",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -434,6 +434,12 @@ class Context:
             C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     median=float(med.value), lost=lost[:n_lost.value].tolist())
+
+    def dba_pack_hash(self):
+        """checksums of the packed arrays of the resident BA problem (include/nrs.h nrs_dba_pack_hash); [21] = 1 if device-built"""
+        out = (C.c_uint64 * 24)()
+        self._chk(self.lib.nrs_dba_pack_hash(self.h, out))
+        return list(out)
 
     def dba_stats(self):
         """sizes of the resident BA problem on this rank (include/nrs.h nrs_dba_stats)"""

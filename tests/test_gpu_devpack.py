@@ -1,0 +1,56 @@
+"""Device-side problem construction (csrc/nrs_engine_devpack.hpp) against the host construction it replaces
+(csrc/nrs_engine_setup.hpp): every packed array -- vertex -> row map, sliced-ELL offsets, incidence headers and static data,
+halo lists, tile classes, chi2 edge lists, row data -- bit for bit (FNV checksums through nrs_dba_pack_hash), and the solves on
+top of the two identical to the last bit.  Windows: C2 (BASELINE configs[1]), a ragged window (few keyframes, many points, a
+large share of unobserved points), and C3."""
+import numpy as np
+import pytest
+
+import nrs
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(monkeypatch, host, p, e, cam, qt, iters=3):
+    if host:
+        monkeypatch.setenv("NRS_HOST_PACK", "1")
+    else:
+        monkeypatch.delenv("NRS_HOST_PACK", raising=False)
+    c = nrs.Context()
+    c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    h = c.dba_pack_hash()
+    tr = nrs.Trace(64)
+    c.dba_optimize(iters, tr)
+    pq, xyz = c.dba_download()
+    rr, rs, rd = c.dba_residuals()
+    c.close()
+    return h, tr.trials, pq, xyz, (rr, rs, rd)
+
+
+@pytest.mark.parametrize("name,n,k,seed", [("C2", 5000, 20, 1), ("ragged", 9000, 5, 17), ("C3", 10000, 50, 2)])
+def test_device_pack_is_the_host_pack(monkeypatch, name, n, k, seed):
+    p = S.make_dba_problem(n, k, seed) if name != "ragged" else S.make_dba_problem(n, k, seed, dropout=0.3)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    hd, td, qd, xd, rd = _solve(monkeypatch, False, p, e, cam, qt)
+    hh, th, qh, xh, rh = _solve(monkeypatch, True, p, e, cam, qt)
+    assert hd[21] == 1 and hh[21] == 0, "the two runs must take the two constructions"
+    names = ["vrow", "ss_ptr", "sd_ptr", "s_om", "s_d0", "d_hdr", "d_w", "halo_ptr", "halo_rows", "halo_ns", "tile_list", "ec_sp", "ec_dm", "ec_w",
+             "rflag", "uv", "xl_init", "pose_init", "grp_pose", "pose_grp_ptr", "scalars"]
+    bad = [nm for i, nm in enumerate(names) if hd[i] != hh[i]]
+    assert not bad, bad
+    assert [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in td] == [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in th]
+    assert np.array_equal(qd, qh) and np.array_equal(xd, xh)
+    assert all(np.array_equal(a, b) for a, b in zip(rd, rh))
+
+
+def test_small_and_masked_windows_keep_the_host_path(monkeypatch):
+    monkeypatch.delenv("NRS_HOST_PACK", raising=False)
+    p = S.make_dba_problem(300, 4, 3)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    c = nrs.Context()
+    c.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
+    assert c.dba_pack_hash()[21] == 0                    # fused single-launch path: T = 8 tiles, packed on the host
+    c.close()

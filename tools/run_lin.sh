@@ -1,2 +1,1 @@
-set -x
-NRS_DFORM=1 python tools/lin_probe.py C2 C4 2>&1 | grep "workload"
+NRS_TIMING=1 python -m pytest tests/test_gpu_devpack.py -x -q 2>&1 | grep -v "engine_create\|a2 \|coarse level" | tail -60
