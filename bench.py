@@ -136,12 +136,11 @@ def cpu_baseline(p2, e2, ctx=None, ctx_exact=None):
 
 
 def cpu_tracked_fps_compiled(lib, with_gpu):
-    """The two solves of a tracked frame -- a1 CameraPoseOptimization + a2 CameraPoseAndDeformationOptimization (with its
-    graph walks and graph update) -- in the C++ restatement (oracle/nrs_cpu_track.hpp, kind "port": g2o's LM with a full
-    AMD-ordered sparse Cholesky per trial, which is what the reference runs; 1 core, as the reference) on single synthetic
-    frames of 600 / 1150 / 5000 map points, next to the product's two calls on the same inputs (flat kNN-16 graph, host
-    buffers in and out).  LK is not part of this figure on either side (the compiled port covers the solves, > 95 % of the
-    CPU frame); `value` of the enclosing object is the NumPy-driven whole loop."""
+    """A tracked frame = LK Track + a1 CameraPoseOptimization + a2 CameraPoseAndDeformationOptimization (with its graph walks
+    and graph update), SURVEY.md 8d's unit, in the C++ restatements (oracle/nrs_cpu_lk.hpp, oracle/nrs_cpu_track.hpp, kind
+    "port": g2o's LM with a full AMD-ordered sparse Cholesky per trial, which is what the reference runs; 1 core, as the
+    reference) on single synthetic frames of 600 / 1150 / 5000 map points, next to the product's three calls on the same
+    inputs (flat kNN-16 graph, host buffers in and out).  `value` of the enclosing object is the NumPy-driven whole loop."""
     import nrs
     import nrs_cpu as CPU
     import nrs_synth as S
@@ -155,15 +154,27 @@ def cpu_tracked_fps_compiled(lib, with_gpu):
         r = CPU.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], q, t, tp["scale"], lib)
         dt = time.perf_counter() - t0
         st = r["stats"]
-        row = dict(map_points=n, tracked=int(m.sum()), cpu_ms=1e3 * dt, cpu_frames_per_s=1.0 / dt, cores=1, kind="port",
+        # LK data association of the same number of points on a 640x480 pair (LucasKanadeTracker::Track, templates cached)
+        sq = S.make_lk_sequence(int(m.sum()), 5)
+        lk = CPU.LucasKanadeCpp(lib=lib)
+        lk.set_reference(sq["im0"], sq["pts"])
+        t0 = time.perf_counter()
+        lk.track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
+        dt_lk = time.perf_counter() - t0
+        lk.close()
+        dt += dt_lk
+        row = dict(map_points=n, tracked=int(m.sum()), cpu_ms=1e3 * dt, cpu_lk_track_ms=1e3 * dt_lk, cpu_frames_per_s=1.0 / dt, cores=1, kind="port",
                    lm_trials=st["n_trials"], factorisations=st["n_factor"], gflop_per_factorisation=st["chol_flops"] / 1e9,
                    cpu_factor_ms=1e3 * st["t_factor"])
         if with_gpu:
             c = nrs.Context()
             cam = nrs.make_camera(tp["model"], tp["prm"])
+            c.klt_configure()
+            c.klt_set_reference(sq["im0"], sq["pts"])
             ts = []
             for _ in range(3):
                 t0 = time.perf_counter()
+                c.klt_track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
                 gq, gt, _ = c.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
                 c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], gq, gt, tp["scale"])
                 ts.append(time.perf_counter() - t0)

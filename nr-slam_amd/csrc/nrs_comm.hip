@@ -115,6 +115,10 @@ struct LocalGroup {
         aborted = true;
         cv.notify_all();
     }
+    void clear_abort() {             // a rank (re)joins: a failure of an earlier window no longer poisons the group
+        std::lock_guard<std::mutex> lk(mu);
+        if (waiting == 0) aborted = false;
+    }
 };
 
 // a failing step of a thread rank must not leave its peers in a barrier
@@ -155,7 +159,7 @@ struct LocalComm : Comm {
         hipLaunchKernelGGL(k_local_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pp, world, tmp.as<double>(), n);
         NRS_LOCAL(c, g, hip_rc(c, hipStreamSynchronize(c->stream), "k_local_sum"));
         NRS_LOCAL_BARRIER(c, g);                                   // everybody has read every send buffer
-        NRS_HIP(c, hipMemcpyAsync(recv, tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        NRS_LOCAL(c, g, hip_rc(c, hipMemcpyAsync(recv, tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync"));
         return NRS_OK;
     }
     int exchange(nrs_ctx* c, double* v, const HaloPlan& h, hipStream_t st) override {
@@ -268,6 +272,7 @@ extern "C" int nrs_comm_init_local(nrs_ctx* c, void* group, int32_t rank) {
     LocalComm* lc = new (std::nothrow) LocalComm();
     if (!lc) return c->fail(NRS_ERR_ALLOC, "out of host memory");
     lc->g = g; lc->rank = rank; lc->world = g->world;
+    g->clear_abort();
     c->comm = lc;
     return comm_streams(c);
 }

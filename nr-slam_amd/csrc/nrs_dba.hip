@@ -66,6 +66,9 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     s.shard = true;                     // with a communicator on the context: one window over its ranks (include/nrs.h)
     // rank-local checks and allocations can fail on one rank only: the ranks agree before the first collective
     int rc = engine_create(c, s, &c->arena_dba, &c->dba);
+    // Every failure every rank sees alike (argument validation, more ranks than keyframes: all of them checked BEFORE any
+    // rank-local work) returns without a collective; from there on a failure may be one rank's alone (err_local) and the ranks
+    // agree on the outcome before the first collective of the solve.
     if (rc == NRS_OK || c->err_local) rc = comm_agree(c, rc);
     if (rc != NRS_OK) dba_free(c);
     return rc;

@@ -89,22 +89,24 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
     const dim3 g(((n + 7) / 8) * 8), b(BLK);
     if constexpr (LIN && LDS) {
         if (d.plain) {                                             // plain BA window: the specialised pass
+            const bool tp = d.tp_ok != 0;
             switch (d.T) {
                 case 1: hipLaunchKernelGGL((k_lin_plain<1>), g, b, shm, c->stream, d, xl, cls); break;
                 case 4: hipLaunchKernelGGL((k_lin_plain<4>), g, b, shm, c->stream, d, xl, cls); break;
-                case 8: hipLaunchKernelGGL((k_lin_plain<8>), g, b, shm, c->stream, d, xl, cls); break;
+                case 8:
+                    if (tp) hipLaunchKernelGGL((k_lin_plain<8, 4, -1, true>), g, b, shm, c->stream, d, xl, cls);
+                    else hipLaunchKernelGGL((k_lin_plain<8>), g, b, shm, c->stream, d, xl, cls);
+                    break;
                 case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
-                default: {
-                    static const int occ = getenv("NRS_LIN_OCC") ? atoi(getenv("NRS_LIN_OCC")) : 4;
+                default:
                     if (d.cam.model == 0) {
-                        if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3, 0>), g, b, shm, c->stream, d, xl, cls);
-                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 0>), g, b, shm, c->stream, d, xl, cls);
+                        if (tp) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 0, false>), g, b, shm, c->stream, d, xl, cls);
                     } else {
-                        if (occ == 3) hipLaunchKernelGGL((k_lin_plain<2, 3, 1>), g, b, shm, c->stream, d, xl, cls);
-                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 1>), g, b, shm, c->stream, d, xl, cls);
+                        if (tp) hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, false>), g, b, shm, c->stream, d, xl, cls);
                     }
                     break;
-                }
             }
             return;
         }
@@ -175,7 +177,10 @@ static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol
             case 4: hipLaunchKernelGGL((k_spmv_f<4, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 8: hipLaunchKernelGGL((k_spmv_f<8, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 16: hipLaunchKernelGGL((k_spmv_f<16, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
-            default: hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
+            default:
+                if (d.plain && d.tp_ok) hipLaunchKernelGGL((k_spmv_f<2, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                break;
         }
     }
 }
@@ -639,9 +644,11 @@ int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out) {
     ok = ok && dev(d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, &out[16]) && dev(d.pose_init, sizeof(Pose) * (size_t)d.K, &out[17]);
     ok = ok && dev(d.grp_pose, sizeof(int) * (size_t)d.n_groups, &out[18]) && dev(d.pose_grp_ptr, sizeof(int) * ((size_t)d.K + 1), &out[19]);
     const int sc[16] = {d.n_rows, d.T, d.ss_nnz, d.sd_nnz, d.max_halo, d.max_halo_s, d.n_tiles_cls[0], d.n_tiles_cls[1], d.cap_h[0], d.cap_h[1], d.cap_s[0], d.cap_s[1],
-                        d.ec_nblk, d.lin_rb, d.hier, d.plain};
-    out[20] = fnv(sc, sizeof(sc));
+                        d.ec_nblk, d.lin_rb, d.hier + 2 * d.fused + 4 * d.ecd + 8 * d.use_lds, d.plain + 2 * d.tp_ok};
+    if (d.plain) { uint64_t h = 0; ok = ok && dev(d.row_tp, sizeof(uint32_t) * (size_t)d.n_rows, &h); out[20] ^= h * 31; }
+    out[20] ^= fnv(sc, sizeof(sc));
     out[21] = e->dev_edges ? 1 : 0;                                  // (which path built it: not part of the comparison)
+    if (d.fused) ok = ok && dev(d.tile_desc, sizeof(int) * 8 * nt, &out[22]) && dev(d.halo_fix, sizeof(int) * BLK * nt, &out[23]);
     if (!ok) return c->fail(NRS_ERR_HIP, "pack hash: a device copy failed");
     return NRS_OK;
 }

@@ -21,7 +21,7 @@
 
 namespace nrs {
 
-constexpr int DP_TILE = 128, DP_HCAP = 2048, DP_HASH = 4096;
+constexpr int DP_HCAP = 2048, DP_HASH = 4096;
 
 __device__ inline uint64_t dp_spread(uint64_t v) {                  // 21 bits -> every third bit (as engine_create)
     v &= 0x1fffff;
@@ -114,35 +114,36 @@ __global__ void k_dp_inc(int n_sp, const int* __restrict__ sp_ij, int n_dm, cons
     }
 }
 
-// slice widths (x 64): a slice = 32 rows, T = 2 lanes per row
-__global__ void k_dp_widths(int n_slices, const int* __restrict__ cnt_s, const int* __restrict__ cnt_d, int* ws, int* wd) {
+// slice widths (x 64): a slice = 64 / T rows, T lanes per row
+__global__ void k_dp_widths(int n_slices, int T, const int* __restrict__ cnt_s, const int* __restrict__ cnt_d, int* ws, int* wd) {
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= n_slices) return;
+    const int Rw = 64 / T;
     int a = 0, b = 0;
-    for (int r = 0; r < 32; ++r) { a = max(a, (cnt_s[sl * 32 + r] + 1) / 2); b = max(b, (cnt_d[sl * 32 + r] + 1) / 2); }
+    for (int r = 0; r < Rw; ++r) { a = max(a, (cnt_s[sl * Rw + r] + T - 1) / T); b = max(b, (cnt_d[sl * Rw + r] + T - 1) / T); }
     ws[sl] = a * 64;
     wd[sl] = b * 64;
 }
 
-__device__ inline size_t dp_pos_of(const int* ptr, int row, int k) {  // packed position of the k-th incidence of a row (T = 2)
-    const int sl = row >> 5, r = row & 31;
-    return (size_t)ptr[sl] + (size_t)(k >> 1) * 64 + (size_t)r * 2 + (size_t)(k & 1);
+__device__ inline size_t dp_pos_of(const int* ptr, int T, int row, int k) {  // packed position of the k-th incidence of a row
+    const int Rw = 64 / T, sl = row / Rw, r = row - sl * Rw;
+    return (size_t)ptr[sl] + (size_t)(k / T) * 64 + (size_t)r * T + (size_t)(k % T);
 }
 
 // fill: sorted incidence i of a row -> its sliced-ELL slot (global neighbour rows; the halo pass turns them into tile-local ids)
-__global__ void k_dp_fill_s(int64_t n, const uint64_t* __restrict__ key, const int* __restrict__ row_start, const int* __restrict__ ss_ptr,
+__global__ void k_dp_fill_s(int64_t n, int T, const uint64_t* __restrict__ key, const int* __restrict__ row_start, const int* __restrict__ ss_ptr,
                             const int* __restrict__ sp_ij, const float* __restrict__ sp_d0, const int* __restrict__ vrow,
                             int* S_other, float* S_d0, uint8_t* S_side) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int row = (int)(key[i] >> 32);
     const uint32_t seq = (uint32_t)key[i];
-    const size_t p = dp_pos_of(ss_ptr, row, (int)(i - row_start[row]));
+    const size_t p = dp_pos_of(ss_ptr, T, row, (int)(i - row_start[row]));
     S_other[p] = vrow[sp_ij[seq ^ 1u]];
     S_d0[p] = sp_d0[seq >> 1];
     S_side[p] = (uint8_t)(1 + (seq & 1u));                           // 1: first endpoint (counts the edge's chi2), 2: second
 }
-__global__ void k_dp_fill_d(int64_t n, const uint64_t* __restrict__ key, const int* __restrict__ row_start, const int* __restrict__ sd_ptr,
+__global__ void k_dp_fill_d(int64_t n, int T, const uint64_t* __restrict__ key, const int* __restrict__ row_start, const int* __restrict__ sd_ptr,
                             const int* __restrict__ dm_idx, const float* __restrict__ dm_w, const int* __restrict__ vrow,
                             int* D_o, float* D_w, int8_t* D_role) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,7 +151,7 @@ __global__ void k_dp_fill_d(int64_t n, const uint64_t* __restrict__ key, const i
     const int row = (int)(key[i] >> 32);
     const uint32_t seq = (uint32_t)key[i];
     const int role = (int)(seq & 3u);
-    const size_t q = seq >> 2, p = dp_pos_of(sd_ptr, row, (int)(i - row_start[row]));
+    const size_t q = seq >> 2, p = dp_pos_of(sd_ptr, T, row, (int)(i - row_start[row]));
     int z = 0;
     for (int k = 0; k < 4; ++k)
         if (k != role) D_o[3 * p + z++] = vrow[dm_idx[4 * q + k]];
@@ -162,7 +163,7 @@ __global__ void k_dp_fill_d(int64_t n, const uint64_t* __restrict__ key, const i
 // the lists and the final incidence headers.  LDS: open-addressing hash set (row, seen-by-a-spring flag), then a bitonic sort
 // of (damper-only << 31 | row).
 template <int PASS>
-__global__ __launch_bounds__(256) void k_dp_halo(const int* __restrict__ ss_ptr, const int* __restrict__ sd_ptr, const int* __restrict__ S_other,
+__global__ __launch_bounds__(256) void k_dp_halo(int tile_rows, int T, uint16_t* row_tp16, const int* __restrict__ ss_ptr, const int* __restrict__ sd_ptr, const int* __restrict__ S_other,
                                                  const uint8_t* __restrict__ S_side, const int* __restrict__ D_o, const int8_t* __restrict__ D_role,
                                                  int* hs, int* hns, const int* __restrict__ halo_ptr, int* halo_rows, uint32_t* s_om, uint2* d_hdr,
                                                  int* overflow) {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void k_dp_halo(const int* __restrict__ ss_ptr,
     __shared__ uint32_t keys[DP_HCAP];
     __shared__ int cnt, cnt_s;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int row0 = b * DP_TILE, row1 = row0 + DP_TILE;
+    const int row0 = b * tile_rows, row1 = row0 + tile_rows;
     for (int i = tid; i < DP_HASH; i += 256) { hk[i] = 0; hf[i] = 0; }
     if (tid == 0) { cnt = 0; cnt_s = 0; }
     __syncthreads();
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(256) void k_dp_halo(const int* __restrict__ ss_ptr,
         // spring part [0, ns), damper-only part [ns, n): binary search in both
         int lo = 0, hi = ns;
         while (lo < hi) { const int m = (lo + hi) >> 1; if ((keys[m] & 0x7FFFFFFFu) < (uint32_t)o) lo = m + 1; else hi = m; }
-        if (lo < ns && (keys[lo] & 0x7FFFFFFFu) == (uint32_t)o) return (uint32_t)(DP_TILE + lo);
+        if (lo < ns && (keys[lo] & 0x7FFFFFFFu) == (uint32_t)o) return (uint32_t)(tile_rows + lo);
         lo = ns; hi = n;
         while (lo < hi) { const int m = (lo + hi) >> 1; if ((keys[m] & 0x7FFFFFFFu) < (uint32_t)o) lo = m + 1; else hi = m; }
-        return (uint32_t)(DP_TILE + lo);
+        return (uint32_t)(tile_rows + lo);
     };
     // springs: {other u16 | meta u16 << 16}, meta = SR_ACTIVE | SR_COUNT on the edge's first endpoint; padding: other = REC_NONE, meta 0
     for (int p = s0 + tid; p < s1; p += 256) {
@@ -243,6 +244,18 @@ __global__ __launch_bounds__(256) void k_dp_halo(const int* __restrict__ ss_ptr,
         const uint32_t l0 = loc(D_o[3 * (size_t)p + pm0]), l1 = loc(D_o[3 * (size_t)p + pm1]), l2 = loc(D_o[3 * (size_t)p + pm2]);
         const uint32_t m16 = (uint32_t)(role | DM_ACTIVE | (role == 0 ? DM_COUNT : 0));
         d_hdr[p] = make_uint2(l0 | (l1 << 16), l2 | (m16 << 16));
+        // the row's own temporal partner (l1): next for roles 1c / 2c, previous for 1n / 2n -- the same for all of its dampers
+        const int sl = b * 4 + (p >= sd_ptr[b * 4 + 1]) + (p >= sd_ptr[b * 4 + 2]) + (p >= sd_ptr[b * 4 + 3]);
+        const int row = sl * (64 / T) + ((p - sd_ptr[sl]) & 63) / T;
+        row_tp16[2 * (size_t)row + (role < 2 ? 0 : 1)] = (uint16_t)l1;
+    }
+    __syncthreads();
+    for (int p = d0 + tid; p < d1; p += 256) {                       // ... which is verified, not assumed
+        const int role = D_role[p];
+        if (role < 0) continue;
+        const int sl = b * 4 + (p >= sd_ptr[b * 4 + 1]) + (p >= sd_ptr[b * 4 + 2]) + (p >= sd_ptr[b * 4 + 3]);
+        const int row = sl * (64 / T) + ((p - sd_ptr[sl]) & 63) / T;
+        if (row_tp16[2 * (size_t)row + (role < 2 ? 0 : 1)] != (uint16_t)(d_hdr[p].x >> 16)) atomicExch(overflow + 1, 1);
     }
 }
 
@@ -286,6 +299,14 @@ __global__ void k_dp_rowv(int M, const int* __restrict__ vrow, int* row_v) {
     if (v < M) row_v[vrow[v]] = v;
 }
 
+// fused single-launch path: the first BLK halo rows of every tile at a fixed stride (no pointer chase in k_pcg_fused)
+__global__ void k_dp_halofix(int n_tiles, const int* __restrict__ halo_ptr, const int* __restrict__ halo_rows, int* halo_fix) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (b >= n_tiles) return;
+    const int hb = halo_ptr[b], hn = halo_ptr[b + 1] - hb;
+    halo_fix[(size_t)b * BLK + i] = i < hn ? halo_rows[hb + i] : 0;
+}
+
 // bump allocator over the context's pack scratch
 struct DpScratch {
     char* base;
@@ -302,7 +323,7 @@ static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows) {
         getenv("NRS_SELL_T") || getenv("NRS_FUSED_MAX_ROWS") || getenv("NRS_TILE_CUT_PCT") || getenv("NRS_HIER") || getenv("NRS_NO_ECD"))
         return false;                                                // (test / A-B switches are honoured by the host path)
     if (c->comm || s.X0 || s.n_un || s.sp_active || s.dm_active || s.pose_fixed || s.force_gather) return false;
-    if (n_pad_rows < 32768 || s.delta_pos > 0 || s.spring_form != 0 || s.n_dm <= 0 || s.n_sp <= 0) return false;
+    if (s.K < 2 || n_pad_rows < 2048 || s.delta_pos > 0 || s.spring_form != 0 || s.n_dm <= 0 || s.n_sp <= 0) return false;   // (single-frame problems: a2, host)
     if (4 * (int64_t)s.n_dm >= 0xFFFFFFFFLL || (int64_t)n_pad_rows >= 0x7FFFFFFFLL) return false;
     return true;
 }
@@ -322,7 +343,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         t_prev = now;
     };
     for (int v = 0; v < s.M; ++v) if (s.rflag[v] != (RF_OBS | RF_REPROJ_ACTIVE)) return NRS_OK;
-    const int T = 2, K = s.K, M = s.M, n_sp = s.n_sp, n_dm = s.n_dm;
+    const int K = s.K, M = s.M, n_sp = s.n_sp, n_dm = s.n_dm;
     std::vector<int> pose_ptr(K + 1, 0), pose_grp_ptr(K + 1, 0), grp_pose;
     for (int i = 0; i < M; ++i) pose_ptr[s.lm_pose[i] + 1]++;
     for (int k = 0; k < K; ++k) pose_ptr[k + 1] += pose_ptr[k];
@@ -332,16 +353,18 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         for (int g = 0; g < ng; ++g) grp_pose.push_back(k);
     }
     memset(&d, 0, sizeof(d));
+    const int n_pad = pose_grp_ptr[K] * ROW_ALIGN;
+    const int T = n_pad >= 32768 ? 2 : 8;                          // lanes per row, as engine_create
     d.T = T; d.K = K; d.M = M; d.n_sp = n_sp; d.n_dm = n_dm; d.n_un = 0;
     d.cam = s.cam;
     d.info_reproj = s.info_reproj; d.delta_reproj = s.delta_reproj; d.info_pos = s.info_pos; d.delta_pos = s.delta_pos;
     d.info_spatial = s.info_spatial; d.delta_spatial = s.delta_spatial; d.k_spring = s.k_spring; d.spring_form = s.spring_form;
     d.n_groups = pose_grp_ptr[K];
     d.n_rows = d.n_groups * ROW_ALIGN;
-    d.n_regblk = d.n_rows / DP_TILE;
+    d.tile_rows = BLK / T;
+    d.n_regblk = d.n_rows / d.tile_rows;
     d.n_vecblk = d.n_rows / BLK;
-    d.tile_rows = DP_TILE;
-    const int n_rows = d.n_rows, n_slices = n_rows / 32, n_tiles = d.n_regblk;
+    const int n_rows = d.n_rows, n_slices = n_rows / (64 / T), n_tiles = d.n_regblk;
     const int64_t ni_s = 2 * (int64_t)n_sp, ni_d = 4 * (int64_t)n_dm;
     // ---- scratch: raw inputs + intermediates (sized from the inputs; the packed arrays themselves go into the arena later)
     size_t tmp_bytes = 0;
@@ -397,7 +420,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     NRS_HIP(c, hipMemcpyAsync(d_pgp, pose_grp_ptr.data(), sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
     {
         std::vector<int> to(n_tiles + 1);
-        for (int i = 0; i <= n_tiles; ++i) to[i] = i * DP_TILE;
+        for (int i = 0; i <= n_tiles; ++i) to[i] = i * d.tile_rows;
         NRS_HIP(c, hipMemcpyAsync(tile_off, to.data(), sizeof(int) * (n_tiles + 1), hipMemcpyHostToDevice, st));
         NRS_HIP(c, hipStreamSynchronize(st));                        // (`to` dies here)
     }
@@ -426,7 +449,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     NRS_HIP(c, hipMemsetAsync(cnt_s, 0, sizeof(int) * ((size_t)n_rows + 1), st));
     NRS_HIP(c, hipMemsetAsync(cnt_d, 0, sizeof(int) * ((size_t)n_rows + 1), st));
     hipLaunchKernelGGL(k_dp_inc, nb(std::max(ni_s, ni_d)), dim3(256), 0, st, n_sp, r_sp, n_dm, r_dm, vrow, cnt_s, cnt_d, key_s, key_d);
-    hipLaunchKernelGGL(k_dp_widths, nb(n_slices), dim3(256), 0, st, n_slices, cnt_s, cnt_d, ws, wd);
+    hipLaunchKernelGGL(k_dp_widths, nb(n_slices), dim3(256), 0, st, n_slices, T, cnt_s, cnt_d, ws, wd);
     NRS_HIP(c, hipMemsetAsync(ws + n_slices, 0, sizeof(int), st));
     NRS_HIP(c, hipMemsetAsync(wd + n_slices, 0, sizeof(int), st));
     tb = tmp_bytes; NRS_HIP(c, rocprim::exclusive_scan(tmp, tb, ws, d_ss, 0, (size_t)n_slices + 1, rocprim::plus<int>(), st));
@@ -467,9 +490,9 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     // (S_d0 / D_w are staged too: the arena is carved only once the halo sizes are known)
     NRS_HIP(c, hipMemsetAsync(t_d0, 0, sizeof(float) * nnz_s, st));
     NRS_HIP(c, hipMemsetAsync(t_w, 0, sizeof(float) * nnz_d, st));
-    hipLaunchKernelGGL(k_dp_fill_s, nb(ni_s), dim3(256), 0, st, ni_s, key_s2, rs_s, d_ss, r_sp, r_d0, vrow, S_other, t_d0, S_side);
-    hipLaunchKernelGGL(k_dp_fill_d, nb(ni_d), dim3(256), 0, st, ni_d, key_d2, rs_d, d_sd, r_dm, r_w, vrow, D_o, t_w, D_role);
-    hipLaunchKernelGGL((k_dp_halo<0>), dim3(n_tiles), dim3(256), 0, st, d_ss, d_sd, S_other, S_side, D_o, D_role, hs, hns, (const int*)nullptr,
+    hipLaunchKernelGGL(k_dp_fill_s, nb(ni_s), dim3(256), 0, st, ni_s, T, key_s2, rs_s, d_ss, r_sp, r_d0, vrow, S_other, t_d0, S_side);
+    hipLaunchKernelGGL(k_dp_fill_d, nb(ni_d), dim3(256), 0, st, ni_d, T, key_d2, rs_d, d_sd, r_dm, r_w, vrow, D_o, t_w, D_role);
+    hipLaunchKernelGGL((k_dp_halo<0>), dim3(n_tiles), dim3(256), 0, st, d.tile_rows, T, (uint16_t*)nullptr, d_ss, d_sd, S_other, S_side, D_o, D_role, hs, hns, (const int*)nullptr,
                        (int*)nullptr, (uint32_t*)nullptr, (uint2*)nullptr, d_flag);
     std::vector<int> h_hs(n_tiles), h_hns(n_tiles), h_vrow(M);
     int h_flag = 0;
@@ -493,7 +516,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         std::vector<int> sorted = h_hs;
         std::sort(sorted.begin(), sorted.end());
         int cut = d.max_halo;
-        if (n_tiles >= 1024) {
+        if (n_tiles >= 1024) {                                      // small problems are latency-bound: one launch
             const int p97 = sorted[(size_t)(0.97 * (n_tiles - 1))];
             const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
             if (4 * d.max_halo > 5 * p97 && (n_tiles - (int)(0.97 * n_tiles) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
@@ -516,9 +539,10 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2));
     }
     if (lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) return NRS_OK;     // gather fallback: host path
-    d.use_lds = 1; d.dform = 0; d.fused = 0; d.coarse = 0;
+    d.use_lds = 1; d.dform = 0; d.coarse = 0;
+    d.fused = d.n_rows < 32768 ? 1 : 0;                             // single-launch PCG iteration for latency-bound windows
     d.hier = n_tiles > 4096 ? 1 : 0;
-    d.ecd = c->opt.profile ? 0 : 1;
+    d.ecd = (!d.fused && !c->opt.profile) ? 1 : 0;
     d.co_n = 3 * d.n_groups + 6;
     d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;
     d.sh_k0 = 0; d.sh_nk = K; d.sh_g0 = 0; d.sh_ng = d.n_groups; d.sh_vb0 = 0; d.sh_nvb = d.n_vecblk;
@@ -561,8 +585,22 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     std::vector<Pose> poses(s.poses, s.poses + K);
     NRS_HIP(c, hipMemcpyAsync(d.pose_init, poses.data(), sizeof(Pose) * K, hipMemcpyHostToDevice, st));
     NRS_HIP(c, hipMemsetAsync(d.pose_fixed, 0, K, st));
-    hipLaunchKernelGGL((k_dp_halo<1>), dim3(n_tiles), dim3(256), 0, st, d.ss_ptr, d.sd_ptr, S_other, S_side, D_o, D_role, hs, hns, d.halo_ptr,
+    NRS_HIP(c, hipMemsetAsync(d.row_tp, 0xFF, sizeof(uint32_t) * (size_t)n_rows, st));
+    hipLaunchKernelGGL((k_dp_halo<1>), dim3(n_tiles), dim3(256), 0, st, d.tile_rows, T, reinterpret_cast<uint16_t*>(d.row_tp), d.ss_ptr, d.sd_ptr, S_other, S_side, D_o, D_role, hs, hns, d.halo_ptr,
                        d.halo_rows, d.s_om, d.d_hdr, d_flag);
+    if (d.fused) {
+        std::vector<int> tile_desc(8 * (size_t)n_tiles, 0);
+        const int rb = ROW_ALIGN / d.tile_rows;
+        for (int b = 0; b < n_tiles; ++b) {
+            const int kf = grp_pose[(size_t)b * d.tile_rows / ROW_ALIGN];
+            int* td = &tile_desc[8 * (size_t)b];
+            td[0] = kf; td[1] = pose_grp_ptr[kf] * rb; td[2] = pose_grp_ptr[kf + 1] * rb;
+            td[3] = halo_ptr[b]; td[4] = halo_ptr[b + 1] - halo_ptr[b];
+        }
+        NRS_HIP(c, hipMemcpyAsync(d.tile_desc, tile_desc.data(), sizeof(int) * tile_desc.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_dp_halofix, dim3(n_tiles), dim3(BLK), 0, st, n_tiles, d.halo_ptr, d.halo_rows, d.halo_fix);
+        NRS_HIP(c, hipStreamSynchronize(st));                        // (tile_desc dies here)
+    }
     hipLaunchKernelGGL(k_dp_rowdata, nb(n_rows), dim3(256), 0, st, n_rows, row_v, r_x, r_uv, d.rflag, d.uv, d.xl_init);
     hipLaunchKernelGGL(k_dp_eckeys, nb(std::max(n_sp, n_dm)), dim3(256), 0, st, n_sp, r_sp, n_dm, r_dm, vrow, ek_s, ek_d);
     tb = tmp_bytes; NRS_HIP(c, rocprim::radix_sort_keys(tmp, tb, ek_s, ek_s2, (size_t)n_sp, 0, 32 + row_bits, st));
@@ -590,8 +628,10 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     e->h_scal = c->pin_scal; e->h_flags = c->pin_flags;
     d.h_scal = c->pin_scal; d.h_flags = c->pin_flags;
     NRS_HIP(c, hipStreamSynchronize(st));                            // (host staging vectors die here; the overflow word is final)
-    NRS_HIP(c, hipMemcpy(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (h_flag) return c->fail(NRS_ERR_HIP, "device pack: halo hash overflow in the second pass");
+    int h_fl2[2] = {0, 0};
+    NRS_HIP(c, hipMemcpy(h_fl2, d_flag, sizeof(int) * 2, hipMemcpyDeviceToHost));
+    if (h_fl2[0]) return c->fail(NRS_ERR_HIP, "device pack: halo hash overflow in the second pass");
+    d.tp_ok = h_fl2[1] ? 0 : 1;
     mark("final arrays");
     NRS_TRY(engine_reset(c, e));
     *done = true;

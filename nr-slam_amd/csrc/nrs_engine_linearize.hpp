@@ -562,7 +562,7 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
     return fma(e2, h, g);
 }
 
-template <int T, int OCC = 4, int CAM = -1>
+template <int T, int OCC = 4, int CAM = -1, bool TPC = false>
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     auto stamp = [&](int k) { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)slice * 8 + k] = wall_clock64(); };
     stamp(0);
     const int rf = P.rflag[row];
+    const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // the row's temporal partners (tile-local ids)
     const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];     // (requested up front: nothing behind the loops waits on memory)
     if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
@@ -608,6 +609,14 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     const int self = row - b * P.tile_rows;
     const double xo0 = lx[3 * self], xo1 = lx[3 * self + 1], xo2 = lx[3 * self + 2];
     double D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0, D5 = 0, bb0 = 0, bb1 = 0, bb2 = 0, chi = 0;
+    // x_i - x_next(i) and x_i - x_prev(i): one of the two is the first half of every damper residual of this row (TPC: read
+    // once here instead of once per incidence -- two of the three gathers of a damper were the row's own partners)
+    double en0 = 0, en1 = 0, en2 = 0, ep0 = 0, ep1 = 0, ep2 = 0;
+    if (TPC) {
+        const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? self : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? self : (int)(tp >> 16);
+        en0 = xo0 - lx[3 * tn]; en1 = xo1 - lx[3 * tn + 1]; en2 = xo2 - lx[3 * tn + 2];
+        ep0 = xo0 - lx[3 * tq]; ep1 = xo1 - lx[3 * tq + 1]; ep2 = xo2 - lx[3 * tq + 2];
+    }
     // ---- springs: r = k (d - d0) / d0, J = cg (x_i - x_j)^T with cg = (k / d0) 2 / sqrt(d) as the reference writes it
     // (position_regularizer.cc:51-60) or k / (d0 d) (tracking form); information info_pos, no kernel
     const double ks = P.k_spring, ip = P.info_pos;
@@ -663,9 +672,17 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const bool live = idx < d_end;
         const bool pad = !live || m16 == REC_NONE;
         const int o0 = (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
-        const double g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
-        const double g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
-        const double g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+        double g0, g1, g2;
+        if (TPC) {
+            const bool fwd = (m16 & 2u) == 0;                        // roles 1c / 2c: the partner is in the next keyframe
+            g0 = (fwd ? en0 : ep0) - (lx[3 * o0] - lx[3 * o2]);
+            g1 = (fwd ? en1 : ep1) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
+            g2 = (fwd ? en2 : ep2) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+        } else {
+            g0 = (xo0 - lx[3 * o1]) - (lx[3 * o0] - lx[3 * o2]);
+            g1 = (xo1 - lx[3 * o1 + 1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]);
+            g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+        }
         const double w = pad ? 0.0 : (double)wf;
         const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
         double rho0, rho1;

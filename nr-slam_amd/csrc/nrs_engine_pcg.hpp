@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 //                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
-template <int T, bool DF>
+template <int T, bool DF, bool TPC = false>
 __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
+    const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // plain BA windows: the row's temporal partners (tile-local ids)
     const int kf = P.grp_pose[row / ROW_ALIGN];
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
@@ -294,6 +295,13 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const double ul[3] = {lu[3 * self], lu[3 * self + 1], lu[3 * self + 2]};
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
     double a0 = 0, a1 = 0, a2 = 0;
+    // u_i - u_next(i), u_i - u_prev(i): the first half of every damper term of this row (TPC: read once, not per incidence)
+    double en[3] = {0, 0, 0}, ep[3] = {0, 0, 0};
+    if (TPC) {
+        const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? ZROW : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? ZROW : (int)(tp >> 16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { en[k] = ul[k] - lu[3 * tn + k]; ep[k] = ul[k] - lu[3 * tq + k]; }
+    }
     auto do_springs = [&](const uint32_t* om, const double* qcv, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -336,9 +344,17 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             const int o1 = (un || r1 == REC_NONE) ? ZROW : r1;
             const int o2 = (un || r2 == REC_NONE) ? ZROW : r2;
             // the others come in canonical order (engine_create): a_i += s ((u_i - u[o1]) - (u[o0] - u[o2])) for every role
-            const double g0 = (ul[0] - lu[3 * o1]) - (lu[3 * o0] - lu[3 * o2]);
-            const double g1 = (ul[1] - lu[3 * o1 + 1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
-            const double g2 = (ul[2] - lu[3 * o1 + 2]) - (lu[3 * o0 + 2] - lu[3 * o2 + 2]);
+            double g0, g1, g2;
+            if (TPC) {
+                const bool fwd = (m16 & 2) == 0;                     // roles 1c / 2c: the partner is in the next keyframe
+                g0 = (fwd ? en[0] : ep[0]) - (lu[3 * o0] - lu[3 * o2]);
+                g1 = (fwd ? en[1] : ep[1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
+                g2 = (fwd ? en[2] : ep[2]) - (lu[3 * o0 + 2] - lu[3 * o2 + 2]);
+            } else {
+                g0 = (ul[0] - lu[3 * o1]) - (lu[3 * o0] - lu[3 * o2]);
+                g1 = (ul[1] - lu[3 * o1 + 1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
+                g2 = (ul[2] - lu[3 * o1 + 2]) - (lu[3 * o0 + 2] - lu[3 * o2 + 2]);
+            }
             a0 += sv * g0; a1 += sv * g1; a2 += sv * g2;
         }
     };

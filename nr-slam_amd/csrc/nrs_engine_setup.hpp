@@ -58,6 +58,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.D = A.get<double>(6 * nr);
     d.Hpl = A.get<double>(d.use_lds ? 1 : 18 * nr);
     d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
+    d.row_tp = A.get<uint32_t>(d.plain ? nr : 1);
     d.s_g = A.get<double>(3 * us);
     d.d_s = A.get<double>(nnz_d);
     d.Hpp = A.get<double>(21 * K);
@@ -240,7 +241,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
     for (int64_t i = 0; i < 2 * (int64_t)s.n_un; ++i)
         if (s.un_ij[i] < 0 || s.un_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "unary damper index out of range");
-    c->err_local = true;
+    if (c->comm && s.shard) {                                      // the same on every rank: no collective follows these returns
+        if (c->comm->world > 8) return c->fail(NRS_ERR_INVALID, "sharded solve: at most 8 ranks");
+        if (s.K < c->comm->world) return c->fail(NRS_ERR_INVALID, "sharded solve: %d keyframes cannot be split over %d ranks", s.K, c->comm->world);
+    }
+    c->err_local = true;                                           // from here on a failure may be this rank's alone: the caller lets the ranks agree
     const bool tm = getenv("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -651,11 +656,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     if (c->comm && s.shard) {
         const int W = c->comm->world, rk = c->comm->rank;
-        c->err_local = false;                                      // the same on every rank:
-        if (W > 8) return c->fail(NRS_ERR_INVALID, "sharded solve: at most 8 ranks");
-        if (s.K < W) return c->fail(NRS_ERR_INVALID, "sharded solve: %d keyframes cannot be split over %d ranks", s.K, W);
+        // (a rank packs its own keyframe range only, so the halo sizes -- and with them this decision -- are rank-local)
         if (!d.use_lds) return c->fail(NRS_ERR_INVALID, "sharded solve: the graph's halo does not fit the LDS-staged path");
-        c->err_local = true;
         std::vector<int> kb(W + 1);
         shard_plan(s.K, pose_grp_ptr.data(), W, kb.data());
         d.sh_on = 1; d.sh_rank = rk; d.sh_world = W; d.sh_lead = rk == 0;
@@ -714,6 +716,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     if (tm) fprintf(stderr, "[nrs] coarse level: wanted %d (fused %d, K %d, unknowns %d <= %d), enabled %d\n", d.fused && s.K == 1, d.fused, s.K, 3 * d.n_groups + 6, CO_MAX, d.coarse);
     // ---- edge lists for the chi2-only evaluation of trial states (BA form, nothing masked or fixed): each
     // edge once, ordered by the row that counts it (locality of the gathers); a rank keeps the edges it counts
+    std::vector<uint32_t> row_tp;
     std::vector<EcSpring> ec_sp;
     std::vector<EcDamper> ec_dm;
     std::vector<float> ec_w;
@@ -783,7 +786,26 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                 }
             });
         }
-        d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
+        // temporal partners of every row (plain windows): from the dampers' canonical second vertex; all dampers of a row and
+    // direction must agree (they do for the reference's BA dampers), else the kernels read it per incidence as before
+    d.tp_ok = 0;
+    if (d.plain) {
+        static const int perm1[4] = {1, 2, 0, 1};                  // (perm[role][1] of the canonical order below)
+        row_tp.assign((size_t)d.n_rows, 0xFFFFFFFFu);
+        bool ok = true;
+        for (int r = 0; r < d.n_rows && ok; ++r)
+            for (int k = 0; k < cnt_d[r] && ok; ++k) {
+                const size_t pz = pos_of(sd_ptr, r, k);
+                const int role = D_role[pz];
+                const uint32_t l = (uint32_t)(L_d[3 * pz + perm1[role]] & 0xFFFF);
+                const int sh = role < 2 ? 0 : 16;
+                const uint32_t cur = (row_tp[r] >> sh) & 0xFFFFu;
+                if (cur != 0xFFFFu && cur != l) ok = false;
+                row_tp[r] = (row_tp[r] & ~(0xFFFFu << sh)) | (l << sh);
+            }
+        d.tp_ok = ok ? 1 : 0;
+    }
+    d.ec_nsp = (int)ec_sp.size(); d.ec_ndm = (int)ec_dm.size();
         d.ec_nblk = std::min((d.ec_nsp + d.ec_ndm + BLK - 1) / BLK, 2048);
     }
     mark("edge lists");
@@ -921,6 +943,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_TRY(h2d(c, d.d_o2, d_o2));
     }
     NRS_TRY(h2d(c, d.d_w, d_w));
+    if (d.plain) NRS_TRY(h2d(c, d.row_tp, row_tp));
     if (d.ec_on) {
         NRS_TRY(h2d(c, d.ec_sp, ec_sp));
         NRS_TRY(h2d(c, d.ec_dm, ec_dm));

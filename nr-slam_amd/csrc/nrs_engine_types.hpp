@@ -82,6 +82,10 @@ struct Dev {
     uint32_t* d_om;                  // dform: {partner u16 | meta u16 << 16} per damper incidence
     int* nxt_row; int* prv_row;      // dform: row of the same map point in the next / previous keyframe (-1: none)
     int* halo_nxt; int* halo_prv;    // dform: the same for the halo rows (indexed like halo_rows)
+    // plain BA windows: a damper's second vertex in canonical order (o1) is the row's OWN temporal partner -- the same map point in
+    // the next (roles 1c / 2c) or previous (1n / 2n) keyframe, OPT:1076-1136 -- hence the same for all dampers of a row and
+    // direction: row_tp[row] = {tile-local id of next | of prev << 16} (REC_NONE: none) lets the kernels read it once per row
+    uint32_t* row_tp; int tp_ok;
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
     Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
     // state (two copies: current / trial, swapped on accept)

@@ -920,6 +920,7 @@ struct Pcg {
 };
 
 #include "nrs_cpu_track.hpp"
+#include "nrs_cpu_lk.hpp"
 
 }  // namespace
 
@@ -1347,6 +1348,24 @@ int nrs_cpu_track_deform_solve(int32_t model, const float* prm, int32_t n_points
     if (trace_n) *trace_n = n_tr;
     S.t_total = now_s() - t_begin;
     if (st) *st = S;
+    return 0;
+}
+
+// LucasKanadeTracker (modules/matching/lucas_kanade_tracker.cc:47-596): create / SetReferenceImage / Track / destroy
+void* nrs_cpu_lk_create(int32_t win, int32_t max_level, int32_t max_iters, float eps, float min_eig) {
+    LkTracker* t = new LkTracker();
+    t->win = win; t->max_level = max_level; t->max_iters = max_iters; t->eps = eps; t->min_eig = min_eig;
+    return t;
+}
+void nrs_cpu_lk_destroy(void* h) { delete static_cast<LkTracker*>(h); }
+int nrs_cpu_lk_set_reference(void* h, const uint8_t* img, int32_t w, int32_t hgt, int32_t stride, int32_t n, const float* pts) {
+    static_cast<LkTracker*>(h)->set_reference(img, w, hgt, stride, n, pts);
+    return 0;
+}
+int nrs_cpu_lk_track(void* h, const uint8_t* img, int32_t w, int32_t hgt, int32_t stride, float* pts, int32_t* status, int32_t initial_flow,
+                     float min_ssim, int32_t* n_good, float* ssim) {
+    const int g = static_cast<LkTracker*>(h)->track(img, w, hgt, stride, pts, status, initial_flow, min_ssim, ssim);
+    if (n_good) *n_good = g;
     return 0;
 }
 

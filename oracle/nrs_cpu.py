@@ -144,3 +144,37 @@ def track_deform_solve(model, prm, graph, map_pos, f_map, f_status, f_uv, f_pos,
         raise RuntimeError("nrs_cpu_track_deform_solve failed: %d" % rc)
     return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos, graph=g, median=float(med.value),
                 lost=lost[:nl.value].tolist(), trace=_trace_list(tr, ntr.value), stats={k: getattr(st, k) for k, _ in TStats._fields_})
+
+
+class LucasKanadeCpp:
+    """oracle/nrs_cpu_lk.hpp behind the interface of lk_oracle.LucasKanadeOracle (no mask)"""
+
+    def __init__(self, win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4, lib=None):
+        self.lib = lib or load()
+        self.lib.nrs_cpu_lk_create.restype = C.c_void_p
+        self.h = C.c_void_p(self.lib.nrs_cpu_lk_create(C.c_int32(win), C.c_int32(max_level), C.c_int32(max_iters), C.c_float(epsilon), C.c_float(min_eig)))
+        self.n = 0
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_cpu_lk_destroy(self.h)
+            self.h = None
+
+    def set_reference(self, img, pts):
+        img = np.ascontiguousarray(img, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        self.n = len(pts)
+        self.lib.nrs_cpu_lk_set_reference(self.h, _p(img, C.c_uint8), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]), C.c_int32(img.strides[0]),
+                                          C.c_int32(self.n), _p(pts, C.c_float))
+
+    def track(self, img, pts, status, initial_flow=True, min_ssim=0.7):
+        img = np.ascontiguousarray(img, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2).copy()
+        status = np.ascontiguousarray(status, np.int32).copy()
+        assert len(pts) == self.n
+        good = C.c_int32(0)
+        ssim = np.zeros(self.n, np.float32)
+        self.lib.nrs_cpu_lk_track(self.h, _p(img, C.c_uint8), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]), C.c_int32(img.strides[0]),
+                                  _p(pts, C.c_float), _p(status, C.c_int32), C.c_int32(1 if initial_flow else 0), C.c_float(min_ssim), C.byref(good),
+                                  _p(ssim, C.c_float))
+        return pts, status, good.value, ssim

@@ -28,7 +28,8 @@ def _solve(monkeypatch, host, p, e, cam, qt, iters=3):
     return h, tr.trials, pq, xyz, (rr, rs, rd)
 
 
-@pytest.mark.parametrize("name,n,k,seed", [("C2", 5000, 20, 1), ("ragged", 9000, 5, 17), ("C3", 10000, 50, 2)])
+@pytest.mark.parametrize("name,n,k,seed", [("C2", 5000, 20, 1), ("ragged", 16000, 5, 17), ("C3", 10000, 50, 2),
+                                            ("reference window (fused path, T = 8)", 5000, 5, 1), ("small fused", 300, 4, 3)])
 def test_device_pack_is_the_host_pack(monkeypatch, name, n, k, seed):
     p = S.make_dba_problem(n, k, seed) if name != "ragged" else S.make_dba_problem(n, k, seed, dropout=0.3)
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
@@ -38,19 +39,19 @@ def test_device_pack_is_the_host_pack(monkeypatch, name, n, k, seed):
     hh, th, qh, xh, rh = _solve(monkeypatch, True, p, e, cam, qt)
     assert hd[21] == 1 and hh[21] == 0, "the two runs must take the two constructions"
     names = ["vrow", "ss_ptr", "sd_ptr", "s_om", "s_d0", "d_hdr", "d_w", "halo_ptr", "halo_rows", "halo_ns", "tile_list", "ec_sp", "ec_dm", "ec_w",
-             "rflag", "uv", "xl_init", "pose_init", "grp_pose", "pose_grp_ptr", "scalars"]
-    bad = [nm for i, nm in enumerate(names) if hd[i] != hh[i]]
+             "rflag", "uv", "xl_init", "pose_init", "grp_pose", "pose_grp_ptr", "scalars", "(path)", "tile_desc", "halo_fix"]
+    bad = [nm for i, nm in enumerate(names) if hd[i] != hh[i] and i != 21]
     assert not bad, bad
     assert [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in td] == [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in th]
     assert np.array_equal(qd, qh) and np.array_equal(xd, xh)
     assert all(np.array_equal(a, b) for a, b in zip(rd, rh))
 
 
-def test_small_and_masked_windows_keep_the_host_path(monkeypatch):
+def test_tiny_windows_keep_the_host_path(monkeypatch):
     monkeypatch.delenv("NRS_HOST_PACK", raising=False)
-    p = S.make_dba_problem(300, 4, 3)
+    p = S.make_dba_problem(100, 2, 3)
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     c = nrs.Context()
     c.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-    assert c.dba_pack_hash()[21] == 0                    # fused single-launch path: T = 8 tiles, packed on the host
+    assert c.dba_pack_hash()[21] == 0                    # a few hundred rows: not worth the device round trips
     c.close()

@@ -68,3 +68,27 @@ def test_track_deform_matches_numpy_oracle(cpu_lib, n, seed, model):
     assert abs(r["median"] - o["median"]) <= 1e-6
     assert _same_leading_trials(r["trace"], otr, len(otr)) > 10
     assert r["stats"]["n_factor"] == r["stats"]["n_trials"] > 0
+
+
+def test_lk_cpp_is_the_numpy_lk_bit_for_bit(cpu_lib):
+    """LucasKanadeTracker::SetReferenceImage + Track: the committed golden (240 x 180, 2 levels) and a fresh 640 x 480 pair with
+    five levels: positions, statuses, good count and SSIM values identical"""
+    import lk_oracle as LK
+    d = np.load(os.path.join(G, "lk_240x180.npz"))
+    lk = CPU.LucasKanadeCpp(max_level=2, lib=cpu_lib)
+    lk.set_reference(d["im0"], d["pts"])
+    xy, st, good, _ = lk.track(d["im1"], d["pts"] + np.float32(0.5), np.zeros(len(d["pts"]), np.int32))
+    lk.close()
+    assert np.array_equal(xy, d["out_xy"]) and np.array_equal(st, d["out_status"]) and good == int(d["out_good"])
+    sq = S.make_lk_sequence(120, 9)
+    o = LK.LucasKanadeOracle()
+    o.set_reference(sq["im0"], sq["pts"])
+    st0 = np.zeros(len(sq["pts"]), np.int32)
+    oxy, ost, ogood, ossim = o.track(sq["im1"], sq["pts"], st0)
+    lk = CPU.LucasKanadeCpp(lib=cpu_lib)
+    lk.set_reference(sq["im0"], sq["pts"])
+    xy, st, good, ssim = lk.track(sq["im1"], sq["pts"], st0)
+    lk.close()
+    assert np.array_equal(xy, oxy) and np.array_equal(st, ost) and good == ogood
+    m = ~np.isnan(ossim)
+    assert np.array_equal(np.isnan(ssim), np.isnan(ossim)) and np.array_equal(ssim[m], ossim[m])
