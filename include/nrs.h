@@ -146,6 +146,19 @@ int nrs_dba_solve(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, double* pos
                   int32_t n_damper, const int32_t* dm_idx, const float* dm_w,
                   float scale, int32_t iters, nrs_lm_trace* trace);
 
+/* The whole of LocalDeformableBundleAdjustment in one call, as mapping.cc:57 makes it: flattened keyframes (kf_rowptr / kf_pt as in
+ * nrs_dba_build_edges; lm_xyz / lm_uv per landmark = position in that concatenation, lm_xyz in/out) + the ordered neighbour lists
+ * RegularizationGraph::GetEdges returns (a19).  The edge construction of OPT:927-1137 runs on the device as well (index for index
+ * the lists nrs_dba_build_edges returns), followed by the device-side problem construction and optimize(iters).  Windows that do
+ * not qualify for the device path (a single keyframe, tiny windows, a communicator on the context) take nrs_dba_build_edges +
+ * nrs_dba_solve internally: the result is the same.  nrs_dba_window_edges (parity tap): the edge lists of the resident window
+ * when they were built on the device (two-call pattern: null arrays return the counts). */
+int nrs_dba_solve_window(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, double* poses_qt, const int32_t* kf_rowptr,
+                         const int32_t* kf_pt, float* lm_xyz, const float* lm_uv, int32_t n_points, const int32_t* nbr_rowptr,
+                         const int32_t* nbr_col, const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status, float scale,
+                         int32_t iters, nrs_lm_trace* trace);
+int nrs_dba_window_edges(nrs_ctx* ctx, int32_t* n_spring, int32_t* sp_ij, float* sp_d0, int32_t* n_damper, int32_t* dm_idx, float* dm_w);
+
 /* Device-resident form of the same solve (used by bench.py so that the timed region starts with
  * the inputs already in HBM): upload once, then any number of {reset, optimize}. */
 int nrs_dba_upload(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,

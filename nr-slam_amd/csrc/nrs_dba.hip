@@ -1,6 +1,7 @@
 // a3: LocalDeformableBundleAdjustment C-ABI entry points (reference
 // modules/optimization/g2o_optimization.cc:880-1161) on top of the graph LM engine.
 #include <algorithm>
+#include <vector>
 #include "nrs_engine.hpp"
 
 namespace nrs {
@@ -135,6 +136,92 @@ extern "C" int nrs_dba_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, do
     NRS_TRY(download(c, n_kf, poses_qt, xyz.data()));
     for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
     return NRS_OK;
+}
+
+// LocalDeformableBundleAdjustment in ONE call, as mapping.cc:57 makes it: the edge construction of OPT:927-1137 on the device,
+// then the device-side problem construction and the solve.  Windows that do not qualify take nrs_dba_build_edges + nrs_dba_solve.
+static int window_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt, const int32_t* kf_rowptr, const int32_t* kf_pt,
+                         const float* lm_xyz, const float* lm_uv, int32_t n_points, const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_w,
+                         const float* nbr_d0, const int32_t* nbr_status, float scale, std::vector<int32_t>& lm_kf) {
+    if (!cam || n_kf <= 0 || !poses_qt || !kf_rowptr || !kf_pt || !lm_xyz || !lm_uv || n_points <= 0 || !nbr_rowptr || !nbr_col || !nbr_w || !nbr_d0 || !nbr_status)
+        return c->fail(NRS_ERR_INVALID, "nrs_dba_solve_window: bad argument");
+    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    const int32_t n_lm = kf_rowptr[n_kf];
+    if (kf_rowptr[0] != 0 || n_lm <= 0) return c->fail(NRS_ERR_INVALID, "nrs_dba_solve_window: empty window");
+    for (int k = 0; k < n_kf; ++k) if (kf_rowptr[k + 1] < kf_rowptr[k]) return c->fail(NRS_ERR_INVALID, "kf_rowptr must be non-decreasing");
+    for (int32_t i = 0; i < n_lm; ++i) if (kf_pt[i] < 0 || kf_pt[i] >= n_points) return c->fail(NRS_ERR_INVALID, "map point index out of range");
+    if (nbr_rowptr[0] != 0) return c->fail(NRS_ERR_INVALID, "nbr_rowptr must start at 0");
+    for (int32_t p = 0; p < n_points; ++p) if (nbr_rowptr[p + 1] < nbr_rowptr[p]) return c->fail(NRS_ERR_INVALID, "nbr_rowptr must be non-decreasing");
+    for (int32_t i = 0; i < nbr_rowptr[n_points]; ++i) if (nbr_col[i] < 0 || nbr_col[i] >= n_points) return c->fail(NRS_ERR_INVALID, "neighbour index out of range");
+    lm_kf.resize(n_lm);
+    for (int k = 0; k < n_kf; ++k) for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) lm_kf[i] = k;
+    dba_free(c);
+    EngineSpec s;
+    s.K = n_kf; s.M = n_lm;
+    std::vector<Pose> poses(n_kf);
+    for (int k = 0; k < n_kf; ++k) {
+        for (int i = 0; i < 4; ++i) poses[k].q[i] = poses_qt[7 * k + i];
+        for (int i = 0; i < 3; ++i) poses[k].t[i] = poses_qt[7 * k + 4 + i];
+        quat_normalize(poses[k].q);
+    }
+    std::vector<double> x(3 * (size_t)n_lm);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (double)lm_xyz[i];
+    std::vector<uint8_t> rflag(n_lm, RF_OBS | RF_REPROJ_ACTIVE);
+    s.poses = poses.data(); s.x = x.data(); s.lm_pose = lm_kf.data(); s.uv = lm_uv; s.rflag = rflag.data();
+    s.cam.model = cam->model;
+    for (int i = 0; i < 8; ++i) s.cam.p[i] = cam->params[i];
+    ba_constants(s, scale);
+    s.delta_pos = 0.0; s.spring_form = 0; s.shard = true;
+    s.n_sp = 1; s.n_dm = 1;                                          // (placeholders for the eligibility test: counts follow)
+    if (!c->comm && engine_device_pack_ok(c, s)) {
+        DevEdges de;
+        NRS_HIP(c, hipSetDevice(c->device));
+        NRS_TRY(engine_build_edges_device(c, n_kf, kf_rowptr, kf_pt, lm_kf.data(), n_points, nbr_rowptr, nbr_col, nbr_w, nbr_d0, nbr_status, &de));
+        if (de.n_sp > 0 && de.n_dm > 0) {
+            s.n_sp = de.n_sp; s.sp_ij = de.sp_ij; s.sp_d0 = de.sp_d0;
+            s.n_dm = de.n_dm; s.dm_idx = de.dm_idx; s.dm_w = de.dm_w;
+            s.edges_on_device = true;
+            const int rc = engine_create(c, s, &c->arena_dba, &c->dba);
+            if (rc == NRS_OK) return NRS_OK;
+            dba_free(c);
+            if (rc != NRS_ERR_STATE) return rc;                      // (NRS_ERR_STATE: the window's halos exceed the device path's limits)
+        }
+    }
+    // host path: nrs_dba_build_edges, then the upload as nrs_dba_upload makes it
+    int32_t ns = 0, nd = 0;
+    int rc = nrs_dba_build_edges(n_kf, kf_rowptr, kf_pt, n_points, nbr_rowptr, nbr_col, nbr_w, nbr_d0, nbr_status, &ns, nullptr, nullptr, &nd, nullptr, nullptr);
+    if (rc != NRS_OK) return c->fail(rc, "nrs_dba_build_edges failed");
+    std::vector<int32_t> sp((size_t)2 * ns + 2), dm((size_t)4 * nd + 4);          // (+ slack: empty lists still need non-null arrays)
+    std::vector<float> d0((size_t)ns + 1), dw((size_t)nd + 1);
+    rc = nrs_dba_build_edges(n_kf, kf_rowptr, kf_pt, n_points, nbr_rowptr, nbr_col, nbr_w, nbr_d0, nbr_status, &ns, sp.data(), d0.data(), &nd, dm.data(), dw.data());
+    if (rc != NRS_OK) return c->fail(rc, "nrs_dba_build_edges failed");
+    return nrs_dba_upload(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf.data(), lm_uv, ns, sp.data(), d0.data(), nd, dm.data(), dw.data(), scale);
+}
+
+extern "C" int nrs_dba_solve_window(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, double* poses_qt, const int32_t* kf_rowptr, const int32_t* kf_pt,
+                                    float* lm_xyz, const float* lm_uv, int32_t n_points, const int32_t* nbr_rowptr, const int32_t* nbr_col,
+                                    const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status, float scale, int32_t iters, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    std::vector<int32_t> lm_kf;
+    NRS_TRY(window_upload(c, cam, n_kf, poses_qt, kf_rowptr, kf_pt, lm_xyz, lm_uv, n_points, nbr_rowptr, nbr_col, nbr_w, nbr_d0, nbr_status, scale, lm_kf));
+    NRS_TRY(nrs_dba_optimize(c, iters, trace));
+    const size_t n_lm = lm_kf.size();
+    std::vector<double> xyz(n_lm * 3);
+    NRS_TRY(download(c, n_kf, poses_qt, xyz.data()));
+    for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
+    return NRS_OK;
+}
+
+// parity tap of the device edge builder: the edge lists of the resident window (built by nrs_dba_solve_window on the device)
+extern "C" int nrs_dba_window_edges(nrs_ctx* c, int32_t* n_spring, int32_t* sp_ij, float* sp_d0, int32_t* n_damper, int32_t* dm_idx, float* dm_w) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    int ns = 0, nd = 0;
+    engine_edge_counts(c->dba, &ns, &nd);
+    if (n_spring) *n_spring = ns;
+    if (n_damper) *n_damper = nd;
+    if (!sp_ij && !sp_d0 && !dm_idx && !dm_w) return NRS_OK;
+    return engine_edges_to_host(c, c->dba, sp_ij, sp_d0, dm_idx, dm_w);
 }
 
 extern "C" int nrs_dba_residuals(nrs_ctx* c, double* r_reproj, double* r_spring, double* r_damper) {

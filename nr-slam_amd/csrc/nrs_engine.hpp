@@ -44,9 +44,11 @@ struct EngineSpec {
     int spring_form = 0;                  // 0: BA Jacobian as written, 1: tracking form
     bool shard = false;                   // split the poses over the ranks of the context's communicator (BA windows only)
     bool force_gather = false;            // stored-block operator (k_spmv gather path) instead of the LDS-staged factored one
+    bool edges_on_device = false;         // sp_ij / sp_d0 / dm_idx / dm_w are DEVICE pointers (engine_build_edges_device): plain BA windows only
 };
 
 struct Engine;
+struct DevEdges { int n_sp = 0, n_dm = 0; const int *sp_ij = nullptr, *dm_idx = nullptr; const float *sp_d0 = nullptr, *dm_w = nullptr; };
 
 int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out);
 void engine_destroy(nrs_ctx* c, Engine* e);
@@ -59,7 +61,12 @@ int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x);      // call
 int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring /*n_sp*/, double* damper /*n_dm*/);
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
 int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);
-int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out /*24*/);    // checksums of the packed arrays (host- or device-built)       // solver order, caller vertex order
+int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out /*24*/);
+// OPT:927-1137's edge construction on the device (index for index what nrs_dba_build_edges returns); arrays live in ctx scratch
+int engine_build_edges_device(nrs_ctx* c, int n_kf, const int* kf_rowptr, const int* kf_pt, const int* lm_kf, int n_points, const int* nbr_rowptr,
+                              const int* nbr_col, const float* nbr_w, const float* nbr_d0, const int* nbr_status, DevEdges* out);
+bool engine_device_pack_ok(nrs_ctx* c, const EngineSpec& s);      // would engine_create build this window on the device?
+int engine_edges_to_host(nrs_ctx* c, Engine* e, int* sp_ij, float* sp_d0, int* dm_idx, float* dm_w);   // parity tap of the device edge builder    // checksums of the packed arrays (host- or device-built)       // solver order, caller vertex order
 // parity tap: (H + lam I) x = b for explicitly given blocks (one pose, M landmark rows, no regularisers) through
 // the engine's own PCG kernels; the engine must have been created with force_gather and K = 1
 int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,
@@ -68,6 +75,7 @@ void arena_release(Arena* a);
 void engine_stats(const Engine* e, int64_t stats[5]);              // rows, rows packed here, spring / damper incidence slots, device bytes
 void shard_plan(int K, const int* grp_ptr, int world, int* kb);     // contiguous keyframe ranges, balanced by rows
 int engine_num_poses(const Engine* e);
+void engine_edge_counts(const Engine* e, int* n_sp, int* n_dm);
 void ba_constants(EngineSpec& s, float scale);            // thresholds / informations of OPT:195-210,958-973
 
 }  // namespace nrs

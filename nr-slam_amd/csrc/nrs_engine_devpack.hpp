@@ -318,6 +318,136 @@ struct DpScratch {
     }
 };
 
+// ---- edge construction of LocalDeformableBundleAdjustment on the device (OPT:927-1137; the host form is nrs_dba_build_edges,
+// csrc/nrs_host_build.cpp, whose output this reproduces index for index).  One thread per landmark l = (keyframe k, map point p):
+// it walks p's ordered neighbour list as the reference does (stop after more than 10 regularisers or at the first BAD
+// connection, OPT:1033-1050; a duplicate counts as a regulariser too, so the walked prefix of a point does not depend on any
+// other point).  The reference's per-keyframe hash sets (SpatialPoint / TemporalPoint, OPT:980-981) keep the FIRST of the two
+// walks that propose a pair: the pair {p, o} is a duplicate here iff o comes earlier in the keyframe and o's own walk reaches p.
+struct WinDev {
+    int n_kf, n_points;
+    const int *kf_rowptr, *kf_pt, *lm_k;                             // lm_k[l] = keyframe of landmark l
+    const int *nbr_rowptr, *nbr_col, *nbr_status;
+    const float *nbr_w, *nbr_d0;
+    const int* cur;                                                  // n_kf x n_points: landmark of (k, p) or -1
+};
+
+__device__ inline bool win_walk_reaches(const WinDev& W, int k, int o, int p, bool damper) {
+    const int* cur = W.cur + (size_t)k * W.n_points;
+    const int* nxt = damper ? W.cur + (size_t)(k + 1) * W.n_points : nullptr;
+    int n_reg = 0;
+    for (int e = W.nbr_rowptr[o]; e < W.nbr_rowptr[o + 1]; ++e) {
+        if (n_reg > 10 || W.nbr_status[e] == NRS_GRAPH_BAD) return false;
+        const int x = W.nbr_col[e];
+        if (cur[x] < 0 || (damper && nxt[x] < 0)) continue;
+        if (x == p) return true;
+        ++n_reg;
+    }
+    return false;
+}
+
+// EMIT = false: counts per landmark; true: writes at the scanned offsets
+template <bool EMIT>
+__global__ void k_win_edges(WinDev W, int n_lm, int* cnt_s, int* cnt_d, const int* __restrict__ off_s, const int* __restrict__ off_d,
+                            int* sp_ij, float* sp_d0, int* dm_idx, float* dm_w) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lm) return;
+    const int k = W.lm_k[l], p = W.kf_pt[l];
+    const int* cur = W.cur + (size_t)k * W.n_points;
+    const int lo = W.nbr_rowptr[p], hi = W.nbr_rowptr[p + 1];
+    int ns = 0, nd = 0, n_reg = 0;
+    for (int e = lo; e < hi; ++e) {                                  // springs (OPT:1033-1074)
+        if (n_reg > 10 || W.nbr_status[e] == NRS_GRAPH_BAD) break;
+        const int o = W.nbr_col[e];
+        if (cur[o] < 0) continue;
+        ++n_reg;
+        if (cur[o] < l && win_walk_reaches(W, k, o, p, false)) continue;        // inserted by o's walk already
+        if (EMIT) { const int q = off_s[l] + ns; sp_ij[2 * (size_t)q] = l; sp_ij[2 * (size_t)q + 1] = cur[o]; sp_d0[q] = W.nbr_d0[e]; }
+        ++ns;
+    }
+    if (k + 1 < W.n_kf) {                                            // dampers with the next keyframe (OPT:1076-1136)
+        const int* nxt = W.cur + (size_t)(k + 1) * W.n_points;
+        if (nxt[p] >= 0) {
+            n_reg = 0;
+            for (int e = lo; e < hi; ++e) {
+                if (n_reg > 10 || W.nbr_status[e] == NRS_GRAPH_BAD) break;
+                const int o = W.nbr_col[e];
+                if (cur[o] < 0 || nxt[o] < 0) continue;
+                ++n_reg;
+                if (cur[o] < l && win_walk_reaches(W, k, o, p, true)) continue;
+                if (EMIT) {
+                    const int q = off_d[l] + nd;
+                    dm_idx[4 * (size_t)q] = l; dm_idx[4 * (size_t)q + 1] = cur[o]; dm_idx[4 * (size_t)q + 2] = nxt[p]; dm_idx[4 * (size_t)q + 3] = nxt[o];
+                    dm_w[q] = W.nbr_w[e];
+                }
+                ++nd;
+            }
+        }
+    }
+    if (!EMIT) { cnt_s[l] = ns; cnt_d[l] = nd; }
+}
+__global__ void k_win_cur(int n_lm, const int* __restrict__ lm_k, const int* __restrict__ kf_pt, int n_points, int* cur) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < n_lm) cur[(size_t)lm_k[l] * n_points + kf_pt[l]] = l;
+}
+
+// Builds the edge lists of a window on the device; the arrays live in the context's third scratch buffer until the next call.
+int engine_build_edges_device(nrs_ctx* c, int n_kf, const int* kf_rowptr, const int* kf_pt, const int* lm_kf, int n_points, const int* nbr_rowptr,
+                              const int* nbr_col, const float* nbr_w, const float* nbr_d0, const int* nbr_status, DevEdges* out) {
+    const int n_lm = kf_rowptr[n_kf], nnz = nbr_rowptr[n_points];
+    hipStream_t st = c->stream;
+    size_t tb = 0;
+    (void)rocprim::exclusive_scan(nullptr, tb, (int*)nullptr, (int*)nullptr, 0, (size_t)n_lm + 1, rocprim::plus<int>(), st);
+    int *d_rowptr, *d_pt, *d_k, *d_nrp, *d_col, *d_st, *d_cur, *d_cs, *d_cd, *d_os, *d_od;
+    float *d_w, *d_d0;
+    void* tmp;
+    auto layout = [&](DpScratch& W) {
+        d_rowptr = W.get<int>(n_kf + 1); d_pt = W.get<int>(n_lm); d_k = W.get<int>(n_lm);
+        d_nrp = W.get<int>(n_points + 1); d_col = W.get<int>(nnz); d_st = W.get<int>(nnz); d_w = W.get<float>(nnz); d_d0 = W.get<float>(nnz);
+        d_cur = W.get<int>((size_t)n_kf * n_points);
+        d_cs = W.get<int>((size_t)n_lm + 1); d_cd = W.get<int>((size_t)n_lm + 1); d_os = W.get<int>((size_t)n_lm + 1); d_od = W.get<int>((size_t)n_lm + 1);
+        tmp = W.get<char>(tb + 256);
+    };
+    DpScratch dry{nullptr, 0, 0};
+    layout(dry);
+    NRS_TRY(c->ensure(c->pack_ws3, dry.off + 4096));
+    DpScratch W{c->pack_ws3.as<char>(), 0, c->pack_ws3.cap};
+    layout(W);
+    NRS_HIP(c, hipMemcpyAsync(d_rowptr, kf_rowptr, sizeof(int) * (n_kf + 1), hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_pt, kf_pt, sizeof(int) * (size_t)n_lm, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_k, lm_kf, sizeof(int) * (size_t)n_lm, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_nrp, nbr_rowptr, sizeof(int) * ((size_t)n_points + 1), hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_col, nbr_col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_st, nbr_status, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_w, nbr_w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemcpyAsync(d_d0, nbr_d0, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    NRS_HIP(c, hipMemsetAsync(d_cur, 0xFF, sizeof(int) * (size_t)n_kf * n_points, st));
+    NRS_HIP(c, hipMemsetAsync(d_cs + n_lm, 0, sizeof(int), st));
+    NRS_HIP(c, hipMemsetAsync(d_cd + n_lm, 0, sizeof(int), st));
+    const dim3 g((unsigned)((n_lm + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_win_cur, g, b, 0, st, n_lm, d_k, d_pt, n_points, d_cur);
+    WinDev wd{n_kf, n_points, d_rowptr, d_pt, d_k, d_nrp, d_col, d_st, d_w, d_d0, d_cur};
+    hipLaunchKernelGGL((k_win_edges<false>), g, b, 0, st, wd, n_lm, d_cs, d_cd, (const int*)nullptr, (const int*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr);
+    size_t t2 = tb + 256;
+    NRS_HIP(c, rocprim::exclusive_scan(tmp, t2, d_cs, d_os, 0, (size_t)n_lm + 1, rocprim::plus<int>(), st));
+    t2 = tb + 256;
+    NRS_HIP(c, rocprim::exclusive_scan(tmp, t2, d_cd, d_od, 0, (size_t)n_lm + 1, rocprim::plus<int>(), st));
+    int tot[2] = {0, 0};
+    NRS_HIP(c, hipMemcpyAsync(&tot[0], d_os + n_lm, sizeof(int), hipMemcpyDeviceToHost, st));
+    NRS_HIP(c, hipMemcpyAsync(&tot[1], d_od + n_lm, sizeof(int), hipMemcpyDeviceToHost, st));
+    NRS_HIP(c, hipStreamSynchronize(st));
+    auto al = [](size_t x) { return ((x + 255) / 256) * 256 + 256; };
+    NRS_TRY(c->ensure(c->pack_ws4, al(8 * (size_t)tot[0]) + al(4 * (size_t)tot[0]) + al(16 * (size_t)tot[1]) + al(4 * (size_t)tot[1]) + 4096));
+    DpScratch W4{c->pack_ws4.as<char>(), 0, c->pack_ws4.cap};
+    int* sp_ij = W4.get<int>(2 * (size_t)tot[0]); float* sp_d0 = W4.get<float>(tot[0]);
+    int* dm_idx = W4.get<int>(4 * (size_t)tot[1]); float* dm_w = W4.get<float>(tot[1]);
+    hipLaunchKernelGGL((k_win_edges<true>), g, b, 0, st, wd, n_lm, (int*)nullptr, (int*)nullptr, d_os, d_od, sp_ij, sp_d0, dm_idx, dm_w);
+    NRS_HIP(c, hipGetLastError());
+    out->n_sp = tot[0]; out->n_dm = tot[1];
+    out->sp_ij = sp_ij; out->sp_d0 = sp_d0; out->dm_idx = dm_idx; out->dm_w = dm_w;
+    return NRS_OK;
+}
+
 static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows) {
     if (getenv("NRS_HOST_PACK") || getenv("NRS_NO_PLAIN") || getenv("NRS_NO_LDS") || getenv("NRS_DFORM") || getenv("NRS_NO_EDGE_CHI") || getenv("NRS_NO_FUSED") ||
         getenv("NRS_SELL_T") || getenv("NRS_FUSED_MAX_ROWS") || getenv("NRS_TILE_CUT_PCT") || getenv("NRS_HIER") || getenv("NRS_NO_ECD"))
@@ -326,6 +456,25 @@ static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows) {
     if (s.K < 2 || n_pad_rows < 2048 || s.delta_pos > 0 || s.spring_form != 0 || s.n_dm <= 0 || s.n_sp <= 0) return false;   // (single-frame problems: a2, host)
     if (4 * (int64_t)s.n_dm >= 0xFFFFFFFFLL || (int64_t)n_pad_rows >= 0x7FFFFFFFLL) return false;
     return true;
+}
+
+bool engine_device_pack_ok(nrs_ctx* c, const EngineSpec& s) {
+    std::vector<int> cnt(s.K, 0);
+    for (int i = 0; i < s.M; ++i) cnt[s.lm_pose[i]]++;
+    int n_pad = 0;
+    for (int k = 0; k < s.K; ++k) n_pad += std::max(1, (cnt[k] + ROW_ALIGN - 1) / ROW_ALIGN) * ROW_ALIGN;
+    return devpack_eligible(c, s, n_pad);
+}
+
+int engine_edges_to_host(nrs_ctx* c, Engine* e, int* sp_ij, float* sp_d0, int* dm_idx, float* dm_w) {
+    if (!e->dev_edges) return c->fail(NRS_ERR_STATE, "the resident problem keeps its edges on the host");
+    const Dev& d = e->d;
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    if (sp_ij) NRS_HIP(c, hipMemcpy(sp_ij, e->raw_sp, sizeof(int) * 2 * (size_t)d.n_sp, hipMemcpyDeviceToHost));
+    if (sp_d0) NRS_HIP(c, hipMemcpy(sp_d0, e->raw_d0, sizeof(float) * (size_t)d.n_sp, hipMemcpyDeviceToHost));
+    if (dm_idx) NRS_HIP(c, hipMemcpy(dm_idx, e->raw_dm, sizeof(int) * 4 * (size_t)d.n_dm, hipMemcpyDeviceToHost));
+    if (dm_w) NRS_HIP(c, hipMemcpy(dm_w, e->raw_w, sizeof(float) * (size_t)d.n_dm, hipMemcpyDeviceToHost));
+    return NRS_OK;
 }
 
 // Returns NRS_OK with *done = true when the engine was built here; *done = false (and NRS_OK) when the window turned out not to
@@ -412,10 +561,11 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     NRS_HIP(c, hipMemcpyAsync(r_x, s.x, sizeof(double) * 3 * (size_t)M, hipMemcpyHostToDevice, st));
     NRS_HIP(c, hipMemcpyAsync(r_kf, s.lm_pose, sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
     NRS_HIP(c, hipMemcpyAsync(r_uv, s.uv, sizeof(float) * 2 * (size_t)M, hipMemcpyHostToDevice, st));
-    NRS_HIP(c, hipMemcpyAsync(r_sp, s.sp_ij, sizeof(int) * 2 * (size_t)n_sp, hipMemcpyHostToDevice, st));
-    NRS_HIP(c, hipMemcpyAsync(r_d0, s.sp_d0, sizeof(float) * (size_t)n_sp, hipMemcpyHostToDevice, st));
-    NRS_HIP(c, hipMemcpyAsync(r_dm, s.dm_idx, sizeof(int) * 4 * (size_t)n_dm, hipMemcpyHostToDevice, st));
-    NRS_HIP(c, hipMemcpyAsync(r_w, s.dm_w, sizeof(float) * (size_t)n_dm, hipMemcpyHostToDevice, st));
+    const hipMemcpyKind ek = s.edges_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;      // (nrs_dba_solve_window builds them there)
+    NRS_HIP(c, hipMemcpyAsync(r_sp, s.sp_ij, sizeof(int) * 2 * (size_t)n_sp, ek, st));
+    NRS_HIP(c, hipMemcpyAsync(r_d0, s.sp_d0, sizeof(float) * (size_t)n_sp, ek, st));
+    NRS_HIP(c, hipMemcpyAsync(r_dm, s.dm_idx, sizeof(int) * 4 * (size_t)n_dm, ek, st));
+    NRS_HIP(c, hipMemcpyAsync(r_w, s.dm_w, sizeof(float) * (size_t)n_dm, ek, st));
     NRS_HIP(c, hipMemcpyAsync(d_pose_ptr, pose_ptr.data(), sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
     NRS_HIP(c, hipMemcpyAsync(d_pgp, pose_grp_ptr.data(), sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
     {
@@ -632,6 +782,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     NRS_HIP(c, hipMemcpy(h_fl2, d_flag, sizeof(int) * 2, hipMemcpyDeviceToHost));
     if (h_fl2[0]) return c->fail(NRS_ERR_HIP, "device pack: halo hash overflow in the second pass");
     d.tp_ok = h_fl2[1] ? 0 : 1;
+    if (c->pack_ws2.cap > ((size_t)512 << 20)) c->release(c->pack_ws2);      // intermediates of a large window: not worth keeping resident
     mark("final arrays");
     NRS_TRY(engine_reset(c, e));
     *done = true;

@@ -609,14 +609,6 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     const int self = row - b * P.tile_rows;
     const double xo0 = lx[3 * self], xo1 = lx[3 * self + 1], xo2 = lx[3 * self + 2];
     double D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0, D5 = 0, bb0 = 0, bb1 = 0, bb2 = 0, chi = 0;
-    // x_i - x_next(i) and x_i - x_prev(i): one of the two is the first half of every damper residual of this row (TPC: read
-    // once here instead of once per incidence -- two of the three gathers of a damper were the row's own partners)
-    double en0 = 0, en1 = 0, en2 = 0, ep0 = 0, ep1 = 0, ep2 = 0;
-    if (TPC) {
-        const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? self : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? self : (int)(tp >> 16);
-        en0 = xo0 - lx[3 * tn]; en1 = xo1 - lx[3 * tn + 1]; en2 = xo2 - lx[3 * tn + 2];
-        ep0 = xo0 - lx[3 * tq]; ep1 = xo1 - lx[3 * tq + 1]; ep2 = xo2 - lx[3 * tq + 2];
-    }
     // ---- springs: r = k (d - d0) / d0, J = cg (x_i - x_j)^T with cg = (k / d0) 2 / sqrt(d) as the reference writes it
     // (position_regularizer.cc:51-60) or k / (d0 d) (tracking form); information info_pos, no kernel
     const double ks = P.k_spring, ip = P.info_pos;
@@ -659,6 +651,14 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     stamp(2);
     // ---- dampers: r = w ((x1n - x1c) - (x2n - x2c)); the records list the three others in canonical order
     // (engine_create), so that sg_i * sum_k sg_k x_k = (x_i - x[o1]) - (x[o0] - x[o2]) for every role
+    // x_i - x_next(i) and x_i - x_prev(i): one of the two is the first half of every damper residual of this row (TPC: read
+    // once here, behind the spring loop whose registers are free by now, instead of once per incidence -- two of the three gathers of a damper were the row's own partners)
+    double en0 = 0, en1 = 0, en2 = 0, ep0 = 0, ep1 = 0, ep2 = 0;
+    if (TPC) {
+        const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? self : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? self : (int)(tp >> 16);
+        en0 = xo0 - lx[3 * tn]; en1 = xo1 - lx[3 * tn + 1]; en2 = xo2 - lx[3 * tn + 2];
+        ep0 = xo0 - lx[3 * tq]; ep1 = xo1 - lx[3 * tq + 1]; ep2 = xo2 - lx[3 * tq + 2];
+    }
     const double isp = P.info_spatial, dsp = P.delta_spatial;
     uint32_t rd_w[NB];
     uint2 rd_h[NB];

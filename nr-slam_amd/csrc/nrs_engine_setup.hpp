@@ -8,6 +8,7 @@ namespace nrs {
 // host side
 // =====================================================================================
 int engine_num_poses(const Engine* e) { return e->d.K; }
+void engine_edge_counts(const Engine* e, int* n_sp, int* n_dm) { *n_sp = e->d.n_sp; *n_dm = e->d.n_dm; }
 
 void arena_release(Arena* a) {
     if (a->base) (void)hipFree(a->base);
@@ -235,10 +236,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     for (int i = 0; i < s.M; ++i)
         if (s.lm_pose[i] < 0 || s.lm_pose[i] >= s.K || (i > 0 && s.lm_pose[i] < s.lm_pose[i - 1]))
             return c->fail(NRS_ERR_INVALID, "vertex pose index must be non-decreasing and in [0, n_poses)");
-    for (int64_t i = 0; i < 2 * (int64_t)s.n_sp; ++i)
-        if (s.sp_ij[i] < 0 || s.sp_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "spring index out of range");
-    for (int64_t i = 0; i < 4 * (int64_t)s.n_dm; ++i)
-        if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+    if (!s.edges_on_device) {                                      // (device-built edge lists are valid by construction)
+        for (int64_t i = 0; i < 2 * (int64_t)s.n_sp; ++i)
+            if (s.sp_ij[i] < 0 || s.sp_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "spring index out of range");
+        for (int64_t i = 0; i < 4 * (int64_t)s.n_dm; ++i)
+            if (s.dm_idx[i] < -1 || s.dm_idx[i] >= s.M) return c->fail(NRS_ERR_INVALID, "damper index out of range");
+    }
     for (int64_t i = 0; i < 2 * (int64_t)s.n_un; ++i)
         if (s.un_ij[i] < 0 || s.un_ij[i] >= s.M) return c->fail(NRS_ERR_INVALID, "unary damper index out of range");
     if (c->comm && s.shard) {                                      // the same on every rank: no collective follows these returns
@@ -277,6 +280,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         e->arena = arena;
         memset(&d, 0, sizeof(d));
     }
+    if (s.edges_on_device) return c->fail(NRS_ERR_STATE, "device-built edge lists need the device-side construction, which this window does not qualify for");
     int T = n_pad_rows >= 32768 ? 2 : 8;
     if (const char* ev = getenv("NRS_SELL_T")) {
         const int v = atoi(ev);

@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_debug_pcg_solve",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -541,6 +541,34 @@ class Context:
                               lm_kf, lm_uv, edges, scale)
         self._chk(self.lib.nrs_dba_solve(*args, C.c_int32(iters), C.byref(trace.c) if trace else None))
         return self._keep[0].copy(), self._keep[1].copy()
+
+    def dba_solve_window(self, cam, poses_qt, kf_points, lm_xyz, lm_uv, graph, scale, iters=5, trace=None):
+        """LocalDeformableBundleAdjustment in one call (include/nrs.h nrs_dba_solve_window): edge construction included"""
+        n_kf = len(kf_points)
+        kf_rowptr = np.zeros(n_kf + 1, np.int32)
+        kf_rowptr[1:] = np.cumsum([len(k) for k in kf_points])
+        kf_pt = _i32(np.concatenate(kf_points))
+        pq = np.ascontiguousarray(np.array(poses_qt, np.float64)).reshape(-1, 7)
+        xyz = np.array(lm_xyz, np.float32).reshape(-1, 3).copy()
+        uv = _f32(lm_uv).reshape(-1, 2)
+        rp, col, w, d0, st = (_i32(graph["rowptr"]), _i32(graph["col"]), _f32(graph["w"]), _f32(graph["d0"]), _i32(graph["status"]))
+        self._chk(self.lib.nrs_dba_solve_window(self.h, C.byref(cam), C.c_int32(n_kf), _p(pq, C.c_double), _p(kf_rowptr, C.c_int32), _p(kf_pt, C.c_int32),
+                                                _p(xyz, C.c_float), _p(uv, C.c_float), C.c_int32(len(rp) - 1), _p(rp, C.c_int32), _p(col, C.c_int32),
+                                                _p(w, C.c_float), _p(d0, C.c_float), _p(st, C.c_int32), C.c_float(scale), C.c_int32(iters),
+                                                C.byref(trace.c) if trace else None))
+        return pq, xyz
+
+    def dba_window_edges(self):
+        """edge lists of the resident window as the device built them (None if they were built on the host)"""
+        ns, nd = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.nrs_dba_window_edges(self.h, C.byref(ns), None, None, C.byref(nd), None, None))
+        sp_ij, sp_d0 = np.zeros((ns.value, 2), np.int32), np.zeros(ns.value, np.float32)
+        dm_idx, dm_w = np.zeros((nd.value, 4), np.int32), np.zeros(nd.value, np.float32)
+        rc = self.lib.nrs_dba_window_edges(self.h, C.byref(ns), _p(sp_ij, C.c_int32), _p(sp_d0, C.c_float), C.byref(nd), _p(dm_idx, C.c_int32), _p(dm_w, C.c_float))
+        if rc == -5:
+            return None
+        self._chk(rc)
+        return dict(sp_ij=sp_ij, sp_d0=sp_d0, dm_idx=dm_idx, dm_w=dm_w)
 
     def dba_upload(self, cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale):
         args = self._dba_args(cam, poses_qt, lm_xyz, lm_kf, lm_uv, edges, scale)

@@ -55,3 +55,27 @@ def test_tiny_windows_keep_the_host_path(monkeypatch):
     c.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
     assert c.dba_pack_hash()[21] == 0                    # a few hundred rows: not worth the device round trips
     c.close()
+
+
+@pytest.mark.parametrize("n,k,seed,model", [(5000, 20, 1, S.PINHOLE), (5000, 5, 1, S.PINHOLE), (900, 6, 8, S.KB8), (200, 1, 4, S.PINHOLE)])
+def test_solve_window_builds_the_same_edges_and_result(n, k, seed, model):
+    """nrs_dba_solve_window: the edge construction of OPT:927-1137 on the device is index for index nrs_dba_build_edges (host),
+    and the one-call solve returns what nrs_dba_build_edges + nrs_dba_solve return, to the last bit"""
+    p = S.make_dba_problem(n, k, seed, model)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    c = nrs.Context()
+    tr = nrs.Trace(64)
+    pq, xyz = c.dba_solve_window(cam, qt, p["kf_points"], p["lm_xyz"], p["lm_uv"], p["nbr"], p["scale"], 5, tr)
+    ed = c.dba_window_edges()
+    if k >= 2:
+        assert ed is not None, "this window should have taken the device path"
+        for key in ("sp_ij", "sp_d0", "dm_idx", "dm_w"):
+            assert np.array_equal(ed[key], e[key]), key
+    c2 = nrs.Context()
+    tr2 = nrs.Trace(64)
+    pq2, xyz2 = c2.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr2)
+    assert [(t["accepted"], t["lam"], t["chi_new"]) for t in tr.trials] == [(t["accepted"], t["lam"], t["chi_new"]) for t in tr2.trials]
+    assert np.array_equal(pq, pq2) and np.array_equal(xyz, xyz2)
+    c.close(); c2.close()
