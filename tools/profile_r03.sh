@@ -26,3 +26,5 @@ timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 200 python tools/lin_probe.py C2 C3 C4 2>&1 | grep workload > $OUT/lin_probe.jsonl
 find $OUT -name "*.csv" -size +20M -delete
 ls -R $OUT | head -60
+# launch-latency probe: kernel arguments in device memory or not (a2 = 2.2k single-launch PCG iterations per frame)
+for v in 0 1; do HIP_FORCE_DEV_KERNARG=$v timeout 200 python tools/frame_probe.py 5000 2>&1 | grep "points" | tail -1 | sed "s/^/HIP_FORCE_DEV_KERNARG=$v /" >> $OUT/kernarg_probe.txt; done
