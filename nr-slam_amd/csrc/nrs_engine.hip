@@ -99,6 +99,15 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                     break;
                 case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
                 default:
+                    if (d.cam.model == 0 && tp && getenv("NRS_LIN_EXP")) {     // timing experiments (wrong results): a piece of the pass removed
+                        switch (atoi(getenv("NRS_LIN_EXP"))) {
+                            case 1: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 1>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 2: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 2>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 3: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 3>), g, b, shm, c->stream, d, xl, cls); break;
+                            default: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 4>), g, b, shm, c->stream, d, xl, cls); break;
+                        }
+                        break;
+                    }
                     if (d.cam.model == 0) {
                         if (tp) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true>), g, b, shm, c->stream, d, xl, cls);
                         else hipLaunchKernelGGL((k_lin_plain<2, 4, 0, false>), g, b, shm, c->stream, d, xl, cls);
@@ -646,9 +655,11 @@ int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out) {
     const int sc[16] = {d.n_rows, d.T, d.ss_nnz, d.sd_nnz, d.max_halo, d.max_halo_s, d.n_tiles_cls[0], d.n_tiles_cls[1], d.cap_h[0], d.cap_h[1], d.cap_s[0], d.cap_s[1],
                         d.ec_nblk, d.lin_rb, d.hier + 2 * d.fused + 4 * d.ecd + 8 * d.use_lds, d.plain + 2 * d.tp_ok};
     if (d.plain) { uint64_t h = 0; ok = ok && dev(d.row_tp, sizeof(uint32_t) * (size_t)d.n_rows, &h); out[20] ^= h * 31; }
+    if (d.plain) { uint64_t h = 0; ok = ok && dev(d.row_cnt, sizeof(uint32_t) * (size_t)d.n_rows, &h); out[20] ^= h * 131; }
     out[20] ^= fnv(sc, sizeof(sc));
     out[21] = e->dev_edges ? 1 : 0;                                  // (which path built it: not part of the comparison)
     if (d.fused) ok = ok && dev(d.tile_desc, sizeof(int) * 8 * nt, &out[22]) && dev(d.halo_fix, sizeof(int) * BLK * nt, &out[23]);
+    else if (d.plain && d.use_lds) ok = ok && dev(d.halo_fix, sizeof(int) * HALO_FIX * nt, &out[23]);
     if (!ok) return c->fail(NRS_ERR_HIP, "pack hash: a device copy failed");
     return NRS_OK;
 }

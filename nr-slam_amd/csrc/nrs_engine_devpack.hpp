@@ -294,17 +294,22 @@ __global__ void k_dp_rowdata(int n_rows, const int* __restrict__ row_v, const do
     uv[2 * (size_t)r + 1] = v < 0 ? 0.f : uv_in[2 * (size_t)v + 1];
     for (int a = 0; a < 3; ++a) xl[3 * (size_t)r + a] = v < 0 ? 0.0 : xyz[3 * (size_t)v + a];
 }
+__global__ void k_dp_rowcnt(int n_rows, const int* __restrict__ cnt_s, const int* __restrict__ cnt_d, uint32_t* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) out[r] = (uint32_t)cnt_s[r] | ((uint32_t)cnt_d[r] << 16);
+}
 __global__ void k_dp_rowv(int M, const int* __restrict__ vrow, int* row_v) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < M) row_v[vrow[v]] = v;
 }
 
 // fused single-launch path: the first BLK halo rows of every tile at a fixed stride (no pointer chase in k_pcg_fused)
-__global__ void k_dp_halofix(int n_tiles, const int* __restrict__ halo_ptr, const int* __restrict__ halo_rows, int* halo_fix) {
-    const int b = blockIdx.x, i = threadIdx.x;
+// (plain two-kernel path: the first HALO_FIX rows, -1 behind the list's end -- stage_rows<true>)
+__global__ void k_dp_halofix(int n_tiles, const int* __restrict__ halo_ptr, const int* __restrict__ halo_rows, int* halo_fix, int stride, int pad) {
+    const int b = blockIdx.x;
     if (b >= n_tiles) return;
     const int hb = halo_ptr[b], hn = halo_ptr[b + 1] - hb;
-    halo_fix[(size_t)b * BLK + i] = i < hn ? halo_rows[hb + i] : 0;
+    for (int i = threadIdx.x; i < stride; i += blockDim.x) halo_fix[(size_t)b * stride + i] = i < hn ? halo_rows[hb + i] : pad;
 }
 
 // bump allocator over the context's pack scratch
@@ -748,10 +753,12 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
             td[3] = halo_ptr[b]; td[4] = halo_ptr[b + 1] - halo_ptr[b];
         }
         NRS_HIP(c, hipMemcpyAsync(d.tile_desc, tile_desc.data(), sizeof(int) * tile_desc.size(), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_dp_halofix, dim3(n_tiles), dim3(BLK), 0, st, n_tiles, d.halo_ptr, d.halo_rows, d.halo_fix);
+        hipLaunchKernelGGL(k_dp_halofix, dim3(n_tiles), dim3(BLK), 0, st, n_tiles, d.halo_ptr, d.halo_rows, d.halo_fix, BLK, 0);
         NRS_HIP(c, hipStreamSynchronize(st));                        // (tile_desc dies here)
-    }
+    } else if (d.use_lds)
+        hipLaunchKernelGGL(k_dp_halofix, dim3(n_tiles), dim3(BLK), 0, st, n_tiles, d.halo_ptr, d.halo_rows, d.halo_fix, HALO_FIX, -1);
     hipLaunchKernelGGL(k_dp_rowdata, nb(n_rows), dim3(256), 0, st, n_rows, row_v, r_x, r_uv, d.rflag, d.uv, d.xl_init);
+    hipLaunchKernelGGL(k_dp_rowcnt, nb(n_rows), dim3(256), 0, st, n_rows, cnt_s, cnt_d, d.row_cnt);
     hipLaunchKernelGGL(k_dp_eckeys, nb(std::max(n_sp, n_dm)), dim3(256), 0, st, n_sp, r_sp, n_dm, r_dm, vrow, ek_s, ek_d);
     tb = tmp_bytes; NRS_HIP(c, rocprim::radix_sort_keys(tmp, tb, ek_s, ek_s2, (size_t)n_sp, 0, 32 + row_bits, st));
     tb = tmp_bytes; NRS_HIP(c, rocprim::radix_sort_keys(tmp, tb, ek_d, ek_d2, (size_t)n_dm, 0, 32 + row_bits, st));

@@ -562,7 +562,7 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
     return fma(e2, h, g);
 }
 
-template <int T, int OCC = 4, int CAM = -1, bool TPC = false>
+template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0>   // EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results)
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
@@ -579,6 +579,9 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     stamp(0);
     const int rf = P.rflag[row];
     const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // the row's temporal partners (tile-local ids)
+    // this lane's share of its row's incidences (k = t, t + T, ...): slots beyond it are padding -- not requested, not stored
+    const uint32_t rcn = P.row_cnt[row];
+    const int my_s = ((int)(rcn & 0xFFFFu) + T - 1 - t) / T, my_d = ((int)(rcn >> 16) + T - 1 - t) / T;
     const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];     // (requested up front: nothing behind the loops waits on memory)
     if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
@@ -592,18 +595,18 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // touches the loaded registers before consume(): with a predicated load the compiler sinks the unpacking behind the
     // load and the wave waits out the full latency of every single request (rounds 1 and 2).
     constexpr int NB = 4;
-    const int s_last = s_end > 0 ? s_end - 1 : 0, d_last = d_end > 0 ? d_end - 1 : 0;
     uint32_t rs_om[NB], rs_d0[NB];
     auto req_s = [&](int q, int idx) {
-        const int j = min(idx, s_last);
-        rs_om[q] = P.s_om[j];
-        rs_d0[q] = __float_as_uint(P.s_d0[j]);
+        if (EXP == 3) { rs_om[q] = (uint32_t)(idx & 63) | 0x10000u; rs_d0[q] = 0x3F800000u; return; }
+        rs_om[q] = 0xFFFFu; rs_d0[q] = 0x3F800000u;                  // padding: no neighbour, rest length 1
+        if ((idx - s_beg - lane) / 64 < my_s) { rs_om[q] = P.s_om[idx]; rs_d0[q] = __float_as_uint(P.s_d0[idx]); }
     };
 #pragma unroll
     for (int q = 0; q < NB; ++q) req_s(q, s_beg + lane + 64 * q);  // the first spring batch rides on the staging loads
     __builtin_amdgcn_sched_barrier(0);
     double* lx = dyn;
-    stage_rows(P, b, tid, xl_g, nullptr, lx);
+    if (P.fused) stage_rows(P, b, tid, xl_g, nullptr, lx);          // (the fused path keeps its own fixed-stride list)
+    else stage_rows<true>(P, b, tid, xl_g, nullptr, lx);
     __syncthreads();
     stamp(1);
     const int self = row - b * P.tile_rows;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // by then, so the ring needs no register copies, which the compiler otherwise parks behind a vmcnt(0) at the loop's end)
     auto do_s = [&](int o16, bool live, bool count, float d0f, int idx) {
         const bool pad = !live || o16 == REC_NONE;
-        const int o = (pad ? self : o16) & 0xFFFF;                  // (16 bits: the LDS offset is then one v_mad_u32_u24)
+        const int o = EXP == 2 ? self : (pad ? self : o16) & 0xFFFF;   // (16 bits: the LDS offset is then one v_mad_u32_u24)
         const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
         double d2 = v0 * v0 + v1 * v1 + v2 * v2;
         d2 = pad ? 1.0 : d2;
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const double r = ks * fma(d2, rs, -d0) * id0;
         const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);       // (plain windows are BA windows: spring_form 0, checked by engine_create)
         const double qc = pad ? 0.0 : ip * cg * cg;
-        if (live) P.s_qc[idx] = qc;
+        if (!pad && EXP != 1) P.s_qc[idx] = qc;                     // (padding slots keep the zero of the set-up)
         chi += count && !pad ? ip * r * r : 0.0;
         const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
         D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const double qr = ip * r * cg;                              // (v = 0 on padding slots)
         bb0 = fma(-qr, v0, bb0); bb1 = fma(-qr, v1, bb1); bb2 = fma(-qr, v2, bb2);
     };
-    for (int ub = s_beg; ub < s_end; ub += 64 * NB) {              // wave-uniform trip count
+    for (int ub = s_beg; ub < (EXP == 4 ? s_beg : s_end); ub += 64 * NB) {   // wave-uniform trip count
         const int base = ub + lane;
         if (ub != s_beg) {
 #pragma unroll
@@ -663,15 +666,15 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     uint32_t rd_w[NB];
     uint2 rd_h[NB];
     auto req_d = [&](int q, int idx) {
-        const int j = min(idx, d_last);
-        rd_h[q] = P.d_hdr[j];
-        rd_w[q] = __float_as_uint(P.d_w[j]);
+        if (EXP == 3) { rd_h[q] = make_uint2((uint32_t)(idx & 63) | ((uint32_t)((idx + 1) & 63) << 16), (uint32_t)((idx + 2) & 63) | 0x80000u); rd_w[q] = 0x3F800000u; return; }
+        rd_h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); rd_w[q] = 0u;
+        if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q] = P.d_hdr[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); }
     };
     auto do_d = [&](uint32_t hx, uint32_t hy, float wf, int idx) {
         const uint32_t m16 = hy >> 16;
         const bool live = idx < d_end;
         const bool pad = !live || m16 == REC_NONE;
-        const int o0 = (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
+        const int o0 = EXP == 2 ? self : (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = EXP == 2 ? self : (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = EXP == 2 ? self : (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
         double g0, g1, g2;
         if (TPC) {
             const bool fwd = (m16 & 2u) == 0;                        // roles 1c / 2c: the partner is in the next keyframe
@@ -689,11 +692,11 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
         chi += (m16 & DM_COUNT) ? rho0 : 0.0;                      // (padding: rho0 = 0)
         const double sfac = rho1 * isp * w * w;
-        if (live) P.d_s[idx] = sfac;
+        if (!pad && EXP != 1) P.d_s[idx] = sfac;
         D0 += sfac; D3 += sfac; D5 += sfac;
         bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
     };
-    for (int ub = d_beg; ub < d_end; ub += 64 * NB) {
+    for (int ub = d_beg; ub < (EXP == 4 ? d_beg : d_end); ub += 64 * NB) {
         const int base = ub + lane;
 #pragma unroll
         for (int q = 0; q < NB; ++q) req_d(q, base + 64 * q);

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const int t = lane % T;
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // plain BA windows: the row's temporal partners (tile-local ids)
+    // ... and this lane's share of the row's incidences: slots beyond it are padding and are not requested
+    const uint32_t rcn = TPC ? P.row_cnt[row] : 0u;
+    const int my_s = ((int)(rcn & 0xFFFFu) + T - 1 - t) / T, my_d = ((int)(rcn >> 16) + T - 1 - t) / T;
     const int kf = P.grp_pose[row / ROW_ALIGN];
     const int sbeg = P.ss_ptr[slice], send = rfix ? sbeg : P.ss_ptr[slice + 1];
     const int dbeg = P.sd_ptr[slice], dend = rfix ? dbeg : P.sd_ptr[slice + 1];
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             const size_t r = 3 * (size_t)(i < P.tile_rows ? row0 + i : P.halo_rows[hb + i - P.tile_rows]);
             lx[3 * i] = P.lin_xl[r]; lx[3 * i + 1] = P.lin_xl[r + 1]; lx[3 * i + 2] = P.lin_xl[r + 2];
         }
-    } else stage_rows2(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);
+    } else stage_rows2<TPC>(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);   // (TPC: plain windows, whose halo lists also sit at a fixed stride)
     // row factors and the first record chunks are requested while the staging loads are in flight
     RowRec rc;
     rc.w = 0;
@@ -258,6 +261,11 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     auto load_springs = [&](uint32_t* om, double* qc, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
+            if (TPC) {
+                om[q] = 0xFFFFu; qc[q] = 0.0;
+                if ((idx + 64 * q - sbeg - lane) / 64 < my_s) { om[q] = P.s_om[idx + 64 * q]; qc[q] = P.s_qc[idx + 64 * q]; }
+                continue;
+            }
             const int j = min(idx + 64 * q, s_last);
             om[q] = P.s_om[j];
             qc[q] = P.s_qc[j];
@@ -266,6 +274,11 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     auto load_dampers = [&](uint2* h, double* sv, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
+            if (TPC) {
+                h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); sv[q] = 0.0;
+                if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q] = P.d_hdr[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; }
+                continue;
+            }
             const int j = min(idx + 64 * q, d_last);
             if (DF) h[q] = make_uint2(P.d_om[j], 0u);              // {partner | meta << 16} + s: 12 bytes
             else h[q] = P.d_hdr[j];

@@ -60,6 +60,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.Hpl = A.get<double>(d.use_lds ? 1 : 18 * nr);
     d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
     d.row_tp = A.get<uint32_t>(d.plain ? nr : 1);
+    d.row_cnt = A.get<uint32_t>(d.plain ? nr : 1);
     d.s_g = A.get<double>(3 * us);
     d.d_s = A.get<double>(nnz_d);
     d.Hpp = A.get<double>(21 * K);
@@ -86,7 +87,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
         d.co_inv = A.get<double>(nc * nc); d.co_y0 = A.get<double>(nc);
     }
     d.tile_desc = A.get<int>(d.fused ? 8 * (size_t)d.n_regblk : 4);
-    d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : 4);
+    d.halo_fix = A.get<int>(d.fused ? BLK * (size_t)d.n_regblk : d.plain && d.use_lds ? HALO_FIX * (size_t)d.n_regblk : 4);
     d.red = A.get<double>(4 + 6 * K);
     d.red_loc = A.get<double>(4 + 6 * K);
     d.pk = A.get<double>(2 + 8 + 27 * K);
@@ -934,6 +935,13 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         }
         NRS_TRY(h2d(c, d.tile_desc, tile_desc));
         NRS_TRY(h2d(c, d.halo_fix, halo_fix));
+    } else if (d.plain && d.use_lds) {                             // stage_rows<true>: the first HALO_FIX halo rows at a fixed stride
+        std::vector<int> halo_fix((size_t)HALO_FIX * d.n_regblk, -1);
+        for (int b = 0; b < d.n_regblk; ++b) {
+            const int hn = std::min(halo_ptr[b + 1] - halo_ptr[b], HALO_FIX);
+            for (int i = 0; i < hn; ++i) halo_fix[(size_t)b * HALO_FIX + i] = halo_rows[halo_ptr[b] + i];
+        }
+        NRS_TRY(h2d(c, d.halo_fix, halo_fix));
     }
     NRS_TRY(h2d(c, d.s_d0, s_d0));
     if (d.use_lds) {                                               // padding slots stay zero
@@ -948,6 +956,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     NRS_TRY(h2d(c, d.d_w, d_w));
     if (d.plain) NRS_TRY(h2d(c, d.row_tp, row_tp));
+    if (d.plain) {
+        std::vector<uint32_t> rc((size_t)d.n_rows);
+        for (int r = 0; r < d.n_rows; ++r) rc[r] = (uint32_t)cnt_s[r] | ((uint32_t)cnt_d[r] << 16);
+        NRS_TRY(h2d(c, d.row_cnt, rc));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));               // (rc dies here)
+    }
     if (d.ec_on) {
         NRS_TRY(h2d(c, d.ec_sp, ec_sp));
         NRS_TRY(h2d(c, d.ec_dm, ec_dm));

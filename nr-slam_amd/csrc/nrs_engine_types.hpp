@@ -86,6 +86,8 @@ struct Dev {
     // the next (roles 1c / 2c) or previous (1n / 2n) keyframe, OPT:1076-1136 -- hence the same for all dampers of a row and
     // direction: row_tp[row] = {tile-local id of next | of prev << 16} (REC_NONE: none) lets the kernels read it once per row
     uint32_t* row_tp; int tp_ok;
+    uint32_t* row_cnt;               // plain windows: {spring incidences | damper incidences << 16} of every row: a lane's slots beyond its share are padding
+                                     // and are neither requested nor stored (a fifth of all slots on the benchmark windows)
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
     Pose* lin_pose; double* lin_xl;  // the linearisation point itself (= pose[cur], xl[cur])
     // state (two copies: current / trial, swapped on accept)
@@ -119,7 +121,8 @@ struct Dev {
     double* co_inv;                  // co_n x co_n: (C0 + lambda N)^-1 of the current trial
     double* co_y0;                   // co_n: its product with Z^T b (start vector of the trial)
     int* tile_desc;                  // fused path: 8 ints per tile {pose, first tile of pose, end tile of pose, halo begin, halo count, 0,0,0}
-    int* halo_fix;                   // fused path: BLK ints per tile = the first BLK halo rows (fixed stride: no pointer chase)
+    int* halo_fix;                   // fused path: BLK ints per tile = the first BLK halo rows (fixed stride: no pointer chase);
+                                     // plain two-kernel path: HALO_FIX ints per tile, -1 behind the list's end (stage_rows<true>)
     // large problems: the SpMV partials are pre-reduced by k_reduce_partials (one launch) instead of
     // being re-summed by every workgroup of the update kernel (which is O(workgroups^2) reads)
     int hier;
@@ -249,14 +252,24 @@ __device__ inline void tile_level(const double* Bi /*6*/, const double* rc, doub
 // stage 3-vectors of the tile's own rows and of its halo rows into LDS (optionally adding X0).
 // The halo is a gather through an index list: all indices of a thread are requested first, then all
 // rows, so that a thread has its 2-4 gathers in flight together instead of one dependent pair at a time.
+// FIX (plain BA windows): the first HALO_FIX halo rows of every tile also sit at a fixed stride (halo_fix, -1 behind the
+// list's end), so their index loads depend on the tile number only and go out TOGETHER with the halo_ptr loads instead of
+// behind them -- one memory round trip less on the chain tile -> list bounds -> indices -> rows -> LDS that every wave
+// of the tile waits out at the staging barrier (C4: the chain was 9.7 us of a 29.5 us wave of the lineariser).
 constexpr int STAGE_K = 4;
+constexpr int HALO_FIX = 2 * BLK;
+template <bool FIX = false>
 __device__ inline void stage_rows(const Dev& P, int b, int tid, const double* __restrict__ v, const double* __restrict__ add,
                                   double* lds) {
     const int row0 = b * P.tile_rows;
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
     int idx[STAGE_K];
+    if (FIX) {
 #pragma unroll
-    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
+        for (int k = 0; k < HALO_FIX / BLK; ++k) idx[k] = P.halo_fix[(size_t)b * HALO_FIX + k * BLK + tid];
+    }
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb;
+#pragma unroll
+    for (int k = FIX ? HALO_FIX / BLK : 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
     for (int i = tid; i < 3 * P.tile_rows; i += BLK) lds[i] = v[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);
     double val[STAGE_K][3];
 #pragma unroll
@@ -302,13 +315,18 @@ __device__ inline void stage_rows_d(const Dev& P, int b, int tid, const double* 
 }
 
 // u and the (spring) positions of the linearisation point, one pass over the halo list
+template <bool FIX = false>
 __device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* __restrict__ u, const double* __restrict__ x,
                                    const double* __restrict__ add, double* lu, double* lx) {
     const int row0 = b * P.tile_rows;
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
     int idx[STAGE_K];
+    if (FIX) {
 #pragma unroll
-    for (int k = 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
+        for (int k = 0; k < HALO_FIX / BLK; ++k) idx[k] = P.halo_fix[(size_t)b * HALO_FIX + k * BLK + tid];
+    }
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
+#pragma unroll
+    for (int k = FIX ? HALO_FIX / BLK : 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
     for (int i = tid; i < 3 * P.tile_rows; i += BLK) {
         lu[i] = u[3 * (size_t)row0 + i];
         lx[i] = x[3 * (size_t)row0 + i] + (add ? add[3 * (size_t)row0 + i] : 0.0);

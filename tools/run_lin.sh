@@ -1,4 +1,4 @@
-timeout 600 python -m pytest tests/test_gpu_devpack.py -x -q 2>&1 | tail -5
+timeout 1200 python -m pytest tests/test_gpu_devpack.py tests/test_gpu_dba.py tests/test_gpu_sharded.py tests/test_gpu_edge_cases.py tests/test_gpu_scale_large.py -x -q > gpurun_out/run_lin_tests.log 2>&1
+grep -E "passed|failed|error" gpurun_out/run_lin_tests.log | tail -3
 NRS_LIN_DBG=1 timeout 300 python tools/lin_probe.py C4 2>&1 | grep "workload\|phases"
 timeout 300 python tools/lin_probe.py C2 C3 2>&1 | grep "workload"
-timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -8
