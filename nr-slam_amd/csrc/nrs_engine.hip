@@ -108,7 +108,10 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                         }
                         break;
                     }
-                    if (d.cam.model == 0) {
+                    if (d.h4) {                                     // (implies tp)
+                        if (d.cam.model == 0) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
+                    } else if (d.cam.model == 0) {
                         if (tp) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true>), g, b, shm, c->stream, d, xl, cls);
                         else hipLaunchKernelGGL((k_lin_plain<2, 4, 0, false>), g, b, shm, c->stream, d, xl, cls);
                     } else {
@@ -187,7 +190,8 @@ static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol
             case 8: hipLaunchKernelGGL((k_spmv_f<8, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 16: hipLaunchKernelGGL((k_spmv_f<16, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             default:
-                if (d.plain && d.tp_ok) hipLaunchKernelGGL((k_spmv_f<2, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                if (d.plain && d.tp_ok && d.h4) hipLaunchKernelGGL((k_spmv_f<2, false, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else if (d.plain && d.tp_ok) hipLaunchKernelGGL((k_spmv_f<2, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 break;
         }
@@ -653,7 +657,7 @@ int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out) {
     ok = ok && dev(d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, &out[16]) && dev(d.pose_init, sizeof(Pose) * (size_t)d.K, &out[17]);
     ok = ok && dev(d.grp_pose, sizeof(int) * (size_t)d.n_groups, &out[18]) && dev(d.pose_grp_ptr, sizeof(int) * ((size_t)d.K + 1), &out[19]);
     const int sc[16] = {d.n_rows, d.T, d.ss_nnz, d.sd_nnz, d.max_halo, d.max_halo_s, d.n_tiles_cls[0], d.n_tiles_cls[1], d.cap_h[0], d.cap_h[1], d.cap_s[0], d.cap_s[1],
-                        d.ec_nblk, d.lin_rb, d.hier + 2 * d.fused + 4 * d.ecd + 8 * d.use_lds, d.plain + 2 * d.tp_ok};
+                        d.ec_nblk, d.lin_rb, d.hier + 2 * d.fused + 4 * d.ecd + 8 * d.use_lds, d.plain + 2 * d.tp_ok + 4 * d.h4};
     if (d.plain) { uint64_t h = 0; ok = ok && dev(d.row_tp, sizeof(uint32_t) * (size_t)d.n_rows, &h); out[20] ^= h * 31; }
     if (d.plain) { uint64_t h = 0; ok = ok && dev(d.row_cnt, sizeof(uint32_t) * (size_t)d.n_rows, &h); out[20] ^= h * 131; }
     out[20] ^= fnv(sc, sizeof(sc));

@@ -791,6 +791,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     d.tp_ok = h_fl2[1] ? 0 : 1;
     if (c->pack_ws2.cap > ((size_t)512 << 20)) c->release(c->pack_ws2);      // intermediates of a large window: not worth keeping resident
     mark("final arrays");
+    engine_compact_headers(c, e);
     NRS_TRY(engine_reset(c, e));
     *done = true;
     return NRS_OK;

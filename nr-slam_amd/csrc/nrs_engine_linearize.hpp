@@ -562,7 +562,7 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
     return fma(e2, h, g);
 }
 
-template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0>   // EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results)
+template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0, bool H4 = false>   // EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results); H4: 4-byte damper headers (Dev::d_h4)
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
@@ -668,13 +668,15 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     auto req_d = [&](int q, int idx) {
         if (EXP == 3) { rd_h[q] = make_uint2((uint32_t)(idx & 63) | ((uint32_t)((idx + 1) & 63) << 16), (uint32_t)((idx + 2) & 63) | 0x80000u); rd_w[q] = 0x3F800000u; return; }
         rd_h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); rd_w[q] = 0u;
-        if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q] = P.d_hdr[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); }
+        if (H4) { if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q].x = P.d_h4[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); } }
+        else if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q] = P.d_hdr[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); }
     };
     auto do_d = [&](uint32_t hx, uint32_t hy, float wf, int idx) {
-        const uint32_t m16 = hy >> 16;
+        const uint32_t m16 = H4 ? (hx == 0xFFFFFFFFu ? (uint32_t)REC_NONE : hx >> 24) : hy >> 16;
         const bool live = idx < d_end;
         const bool pad = !live || m16 == REC_NONE;
-        const int o0 = EXP == 2 ? self : (pad ? self : (int)(hx & 0xFFFFu)) & 0xFFFF, o1 = EXP == 2 ? self : (pad ? self : (int)(hx >> 16)) & 0xFFFF, o2 = EXP == 2 ? self : (pad ? self : (int)(hy & 0xFFFFu)) & 0xFFFF;
+        const int o0 = EXP == 2 ? self : (pad ? self : (int)(hx & (H4 ? 0xFFFu : 0xFFFFu))) & 0xFFFF, o1 = EXP == 2 || H4 ? self : (pad ? self : (int)(hx >> 16)) & 0xFFFF,
+                  o2 = EXP == 2 ? self : (pad ? self : (int)(H4 ? (hx >> 12) & 0xFFFu : hy & 0xFFFFu)) & 0xFFFF;
         double g0, g1, g2;
         if (TPC) {
             const bool fwd = (m16 & 2u) == 0;                        // roles 1c / 2c: the partner is in the next keyframe
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            const uint32_t hx = consume(rd_h[q].x), hy = consume(rd_h[q].y);
+            const uint32_t hx = consume(rd_h[q].x), hy = H4 ? 0u : consume(rd_h[q].y);
             const float wf = __uint_as_float(consume(rd_w[q]));
             do_d(hx, hy, wf, base + 64 * q);
         }

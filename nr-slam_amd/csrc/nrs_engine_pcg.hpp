@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 //                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
-template <int T, bool DF, bool TPC = false>
+template <int T, bool DF, bool TPC = false, bool H4 = false>   // H4: 4-byte damper headers (Dev::d_h4; needs TPC)
 __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         for (int q = 0; q < U; ++q) {
             if (TPC) {
                 h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); sv[q] = 0.0;
-                if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q] = P.d_hdr[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; }
+                if (H4) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; } }
+                else if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q] = P.d_hdr[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; }
                 continue;
             }
             const int j = min(idx + 64 * q, d_last);
@@ -348,14 +349,15 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             }
             // padding records carry s = 0; a unary damper (the other vertex is a value) and absent
             // vertices read the zero row, which leaves the diagonal term s u_i
-            const uint32_t hx = consume(hd[q].x), hy = consume(hd[q].y);
-            const int r0 = (int)(hx & 0xFFFFu), r1 = (int)(hx >> 16), r2 = (int)(hy & 0xFFFFu), m16 = (int)(hy >> 16);
+            const uint32_t hx = consume(hd[q].x), hy = H4 ? 0u : consume(hd[q].y);
+            const int r0 = (int)(hx & (H4 ? 0xFFFu : 0xFFFFu)), r1 = H4 ? 0 : (int)(hx >> 16), r2 = (int)(H4 ? (hx >> 12) & 0xFFFu : hy & 0xFFFFu),
+                      m16 = H4 ? (hx == 0xFFFFFFFFu ? (int)REC_NONE : (int)(hx >> 24)) : (int)(hy >> 16);
             const bool pad = !live || m16 == REC_NONE;
             const double sv = pad ? 0.0 : consume(dsv[q]);
             const bool un = pad || (m16 & DM_UNARY) != 0;
-            const int o0 = (un || r0 == REC_NONE) ? ZROW : r0;
+            const int o0 = H4 ? (pad ? ZROW : r0) : (un || r0 == REC_NONE) ? ZROW : r0;      // (H4: plain windows, every damper with its four vertices)
             const int o1 = (un || r1 == REC_NONE) ? ZROW : r1;
-            const int o2 = (un || r2 == REC_NONE) ? ZROW : r2;
+            const int o2 = H4 ? (pad ? ZROW : r2) : (un || r2 == REC_NONE) ? ZROW : r2;
             // the others come in canonical order (engine_create): a_i += s ((u_i - u[o1]) - (u[o0] - u[o2])) for every role
             double g0, g1, g2;
             if (TPC) {

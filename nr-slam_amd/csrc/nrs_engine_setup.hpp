@@ -61,6 +61,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
     d.row_tp = A.get<uint32_t>(d.plain ? nr : 1);
     d.row_cnt = A.get<uint32_t>(d.plain ? nr : 1);
+    d.d_h4 = A.get<uint32_t>(d.plain && d.use_lds && !d.fused ? nnz_d : 1);
     d.s_g = A.get<double>(3 * us);
     d.d_s = A.get<double>(nnz_d);
     d.Hpp = A.get<double>(21 * K);
@@ -123,6 +124,25 @@ static int host_threads(size_t work) {
     if (const char* ev = getenv("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
     return n;
 }
+// plain two-kernel windows whose rows all know their temporal partners: the dampers' 8-byte headers {o0, o1, o2, meta} shrink
+// to 4 bytes {o0 : 12, o2 : 12, meta : 8} -- o1 is the row's own partner (row_tp) and tile-local ids stay below 4096.  Derived
+// on the device from d_hdr, whichever packer built that.
+__global__ void k_compact_headers(size_t n, const uint2* __restrict__ hdr, uint32_t* __restrict__ h4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 h = hdr[i];
+    const uint32_t m16 = h.y >> 16;
+    h4[i] = m16 == REC_NONE ? 0xFFFFFFFFu : ((h.x & 0xFFFu) | ((h.y & 0xFFFu) << 12) | ((m16 & 0xFFu) << 24));
+}
+static void engine_compact_headers(nrs_ctx* c, Engine* e) {
+    Dev& d = e->d;
+    d.h4 = 0;
+    if (!(d.plain && d.tp_ok && d.use_lds && !d.fused && d.T == 2) || getenv("NRS_NO_H4")) return;
+    if (d.tile_rows + std::max(d.cap_h[0], d.cap_h[1]) + 2 >= 4096 || d.sd_nnz <= 0) return;
+    hipLaunchKernelGGL(k_compact_headers, dim3((unsigned)(((size_t)d.sd_nnz + 255) / 256)), dim3(256), 0, c->stream, (size_t)d.sd_nnz, d.d_hdr, d.d_h4);
+    d.h4 = 1;
+}
+
 template <class F>
 static void parallel_for(int nt, F&& fn) {                         // fn(thread index, thread count)
     if (nt <= 1) { fn(0, 1); return; }
@@ -793,7 +813,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         }
         // temporal partners of every row (plain windows): from the dampers' canonical second vertex; all dampers of a row and
     // direction must agree (they do for the reference's BA dampers), else the kernels read it per incidence as before
-    d.tp_ok = 0;
+    d.tp_ok = 0; d.h4 = 0;
     if (d.plain) {
         static const int perm1[4] = {1, 2, 0, 1};                  // (perm[role][1] of the canonical order below)
         row_tp.assign((size_t)d.n_rows, 0xFFFFFFFFu);
@@ -990,6 +1010,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->h_flags = c->pin_flags;
     e->d.h_scal = c->pin_scal;          // hipHostMalloc memory is mapped: same pointer on the device
     e->d.h_flags = c->pin_flags;
+    engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
     NRS_TRY(engine_reset(c, e));

@@ -86,6 +86,8 @@ struct Dev {
     // the next (roles 1c / 2c) or previous (1n / 2n) keyframe, OPT:1076-1136 -- hence the same for all dampers of a row and
     // direction: row_tp[row] = {tile-local id of next | of prev << 16} (REC_NONE: none) lets the kernels read it once per row
     uint32_t* row_tp; int tp_ok;
+    uint32_t* d_h4; int h4;          // plain two-kernel path with cached temporal partners: 4-byte damper headers {o0 : 12 | o2 : 12 | meta : 8} derived from d_hdr
+                                     // (the partner o1 is the row's own and tile-local ids stay below 4096): 8 instead of 12 bytes per damper incidence in both kernels
     uint32_t* row_cnt;               // plain windows: {spring incidences | damper incidences << 16} of every row: a lane's slots beyond its share are padding
                                      // and are neither requested nor stored (a fifth of all slots on the benchmark windows)
     RowRec* rowrec;                  // n_rows (LDS path): reprojection factors of the linearisation point
