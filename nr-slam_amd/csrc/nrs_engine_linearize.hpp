@@ -628,7 +628,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const double r = ks * fma(d2, rs, -d0) * id0;
         const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);       // (plain windows are BA windows: spring_form 0, checked by engine_create)
         const double qc = pad ? 0.0 : ip * cg * cg;
-        if (!pad && EXP != 1) P.s_qc[idx] = qc;                     // (padding slots keep the zero of the set-up)
+        if (live && EXP != 1) P.s_qc[idx] = qc;                     // (whole lines: padding slots inside the slice are written too -- a lane-masked store leaves partial lines, which cost the memory side a read-modify-write)
         chi += count && !pad ? ip * r * r : 0.0;
         const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
         D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
         chi += (m16 & DM_COUNT) ? rho0 : 0.0;                      // (padding: rho0 = 0)
         const double sfac = rho1 * isp * w * w;
-        if (!pad && EXP != 1) P.d_s[idx] = sfac;
+        if (live && EXP != 1) P.d_s[idx] = sfac;
         D0 += sfac; D3 += sfac; D5 += sfac;
         bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
     };
