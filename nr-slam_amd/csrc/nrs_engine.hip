@@ -166,8 +166,38 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
     }
 }
 
-static void launch_spmv(nrs_ctx* c, const Dev& d, double lam, int it, double tol2) {
-    if (!d.use_lds) { launch_spmv2<false>(c, d, lam, 0, it); return; }
+static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double tol2) {
+    if (!d0.use_lds) { launch_spmv2<false>(c, d0, lam, 0, it); return; }
+    Dev d = d0;
+    long long* dbg = nullptr;
+    static bool dbg_done = false;
+    if (d.h4 && it == 3 && !dbg_done && getenv("NRS_SPMV_DBG")) {  // phase clocks of one operator launch (100 MHz wall clock)
+        dbg_done = true;
+        const size_t ns = (size_t)d.n_rows / (64 / d.T);
+        if (hipMalloc((void**)&dbg, sizeof(long long) * 8 * ns) == hipSuccess) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * ns, c->stream); d.dbg_clk = dbg; }
+    }
+    struct Dump {
+        nrs_ctx* c; long long* buf; size_t ns;
+        ~Dump() {
+            if (!buf) return;
+            (void)hipStreamSynchronize(c->stream);
+            std::vector<long long> h(8 * ns);
+            (void)hipMemcpy(h.data(), buf, sizeof(long long) * 8 * ns, hipMemcpyDeviceToHost);
+            (void)hipFree(buf);
+            double acc[5] = {0, 0, 0, 0, 0};
+            long long t_min = LLONG_MAX, t_max = 0;
+            size_t n = 0;
+            for (size_t i = 0; i < ns; ++i) {
+                const long long* q = &h[8 * i];
+                if (!q[0] || !q[5]) continue;
+                for (int k = 0; k < 5; ++k) acc[k] += (double)(q[k + 1] - q[k]);
+                t_min = std::min(t_min, q[0]); t_max = std::max(t_max, q[5]);
+                ++n;
+            }
+            if (n) fprintf(stderr, "[nrs] k_spmv_f phases (us per wave, mean over %zu waves): stage %.2f springs %.2f dampers %.2f row %.2f reduce %.2f | launch span %.1f us\n",
+                           n, acc[0] / n / 100.0, acc[1] / n / 100.0, acc[2] / n / 100.0, acc[3] / n / 100.0, acc[4] / n / 100.0, (double)(t_max - t_min) / 100.0);
+        }
+    } dump{c, dbg, dbg ? (size_t)d.n_rows / (64 / d.T) : 0};
     for (int cls = 0; cls < 2; ++cls) {
         const int n = d.sh_nt[cls] + d.sh_ntb[cls];
         if (n == 0) continue;

@@ -196,6 +196,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const int slice = b * 4 + wave;
     const int row = slice * R + lane / T;
     const int t = lane % T;
+    auto stamp = [&](int k) { if (H4 && P.dbg_clk && lane == 0) P.dbg_clk[(size_t)slice * 8 + k] = wall_clock64(); };   // (NRS_SPMV_DBG: phase clocks of one launch)
+    stamp(0);
     const bool rfix = (P.rflag[row] & RF_FIXED) != 0;
     const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // plain BA windows: the row's temporal partners (tile-local ids)
     // ... and this lane's share of the row's incidences: slots beyond it are padding and are not requested
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     load_dampers(dhA, dsA, dbeg + lane);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    if (done_flag) return;
+    stamp(1);
+    if (done_flag && !(H4 && P.dbg_clk)) return;
     if (P.ecd && it > 0) {
         const double gamma = lds[0] + lds[1] + lds[2] + lds[3];
         const bool bad = !isfinite(gamma);
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         do_springs(somB, sqcB, base + 64 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(2);
     for (int base = dbeg; base < dend_u; base += 128 * U) {
         load_dampers(dhB, dsB, base + 64 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         do_dampers(dhB, dsB, base + 64 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(3);
     // the row's own terms come last: their temporaries then never coexist with the record registers
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (t == 0) {
@@ -410,7 +415,9 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         part[0] = P.ecd ? 0.0 : rv0 * ul[0] + rv1 * ul[1] + rv2 * ul[2];
         part[1] = a0 * ul[0] + a1 * ul[1] + a2 * ul[2];
     }
+    stamp(4);
     block_sum_store<9>(part, lds, tid, P.part_spmv + (size_t)b * NPART);
+    stamp(5);
 }
 
 // =====================================================================================
