@@ -47,6 +47,26 @@ def test_device_pack_is_the_host_pack(monkeypatch, name, n, k, seed):
     assert all(np.array_equal(a, b) for a, b in zip(rd, rh))
 
 
+@pytest.mark.parametrize("model", [S.PINHOLE, S.KB8])
+def test_compact_damper_headers_change_nothing(monkeypatch, model):
+    """Two-kernel windows whose rows all know their temporal partners read 4-byte damper headers {o0:12, o2:12, meta:8} derived
+    from the 8-byte ones (nrs_engine_setup.hpp engine_compact_headers).  It is an encoding only: with NRS_NO_H4=1 the kernels
+    read the 8-byte headers, and every trial and every output must be the same to the last bit."""
+    p = S.make_dba_problem(5000, 8, 21, model)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    monkeypatch.delenv("NRS_NO_H4", raising=False)
+    h4, t4, q4, x4, r4 = _solve(monkeypatch, False, p, e, cam, qt, iters=4)
+    monkeypatch.setenv("NRS_NO_H4", "1")
+    h8, t8, q8, x8, r8 = _solve(monkeypatch, False, p, e, cam, qt, iters=4)
+    assert h4[20] != h8[20], "the two runs must take the two encodings (the flag is part of the scalar checksum)"
+    assert [h4[i] for i in range(24) if i != 20] == [h8[i] for i in range(24) if i != 20]
+    assert [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in t4] == [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in t8]
+    assert np.array_equal(q4, q8) and np.array_equal(x4, x8)
+    assert all(np.array_equal(a, b) for a, b in zip(r4, r8))
+
+
 def test_tiny_windows_keep_the_host_path(monkeypatch):
     monkeypatch.delenv("NRS_HOST_PACK", raising=False)
     p = S.make_dba_problem(100, 2, 3)

@@ -20,4 +20,4 @@ for rep in range(4):
     r = ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr); t4 = time.perf_counter()
     print("points %d/%d: set_ref %.2f ms, klt_track %.2f ms (good %d), pose_only %.2f ms, track_deform %.2f ms (trials %d, pcg %d, lost %d)" % (
         len(sq["pts"]), m.sum(), 1e3*(t1-t0), 1e3*(t2-t1), good, 1e3*(t3-t2), 1e3*(t4-t3), len(tr.trials), sum(x["inner"] for x in tr.trials), len(r["lost"])))
-print([ (x["round"], x["iter"], x["trial"], x["inner"], x["accepted"]) for x in tr.trials][:60])
+print([ (x["round"], x["iter"], x["trial"], x["inner"], x["accepted"]) for x in tr.trials])
