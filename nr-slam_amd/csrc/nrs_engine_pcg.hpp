@@ -700,7 +700,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     constexpr int U = 4;
-    const int b = xcd_tile(blockIdx.x, P.n_regblk);
+    if (P.one_xcd && (blockIdx.x & 7)) return;                     // (small frames: one workgroup in eight works, so that all of them sit on one XCD)
+    const int b = P.one_xcd ? (int)(blockIdx.x >> 3) : xcd_tile(blockIdx.x, P.n_regblk);
     if (b >= P.n_regblk) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // read half / write half of the ping-pong pairs.  Launch 0 only applies the operator: the state
@@ -720,6 +721,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     const int row = slice * R + lane / T;
     const int t = lane % T;
     const int row0 = b * P.tile_rows;
+    auto stamp = [&](int k) { if (P.dbg_clk && tid == 0) P.dbg_clk[(size_t)b * 8 + k] = wall_clock64(); };   // (NRS_PCG_DBG: phase clocks of one launch)
+    stamp(0);
     // The launch is a chain of dependent memory round trips unless everything is requested at once:
     // level 1 = whatever is addressed by the tile index alone (tile descriptor, flags, scalars, all
     // partials, own rows, fixed-stride halo list, slice pointers), level 2 = what those address
@@ -905,6 +908,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             for (int c = 0; c < 6; ++c) w_pose += q_H[c] * q_up[c];
         }
     }
+    stamp(1);
     // ================= coarse level: y = A_c^-1 Z^T r_new with r_new = r - alpha w - alpha beta s, i.e.
     // y = yR - alpha yW - alpha beta yS; the three products are formed before alpha, beta are known
     double* c_ts = dyn + 6 * (size_t)(P.tile_rows + P.max_halo);  // n_regblk x 9 tile sums
@@ -948,6 +952,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             dst[co_r] = yr; dst[CO_MAX + co_r] = ys; dst[2 * CO_MAX + co_r] = yw;
         }
     }
+    stamp(2);
     // ================= phase 2: scalars of iteration it-1 (k_pcg_update prologue)
     double alpha = 0, beta = 0;
     if (it > 0) {
@@ -999,6 +1004,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         }
         __syncthreads();
     }
+    stamp(3);
     const double* ycor = c_v + 15 * CO_MAX;
     // ================= phase 3: pose vector of this tile's pose (wave 0; every workgroup recomputes
     // it, the first workgroup of the pose also stores the pose part of the state)
@@ -1093,6 +1099,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
         dst[0] = x_h[0]; dst[1] = x_h[1]; dst[2] = x_h[2];
     }
     __syncthreads();
+    stamp(4);
     // ================= phase 5: operator apply on the staged u (k_spmv_f)
     double a0 = 0, a1 = 0, a2 = 0;
     double part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1141,6 +1148,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             a2 += sv * ((ul[2] - v[1][2]) - (v[0][2] - v[2][2]));
         }
     }
+    stamp(5);
     a0 = sub_sum_t<T>(a0); a1 = sub_sum_t<T>(a1); a2 = sub_sum_t<T>(a2);
     if (t == 0) {
         w_out[3 * row] = a0; w_out[3 * row + 1] = a1; w_out[3 * row + 2] = a2;
@@ -1170,6 +1178,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
             else ts_out[(size_t)(tid - 9) * P.n_regblk + b] = tot;
         }
     }
+    stamp(6);
 }
 
 // =====================================================================================

@@ -144,7 +144,7 @@ struct Dev {
     // chi2 of a trial state, edge-parallel (BA windows without masks: every spring / damper is evaluated
     // once from these lists instead of from the incidence records of the row that counts it)
     int ec_on, ec_nsp, ec_ndm, ec_nblk;
-    long long* dbg_clk;              // NRS_LIN_DBG: per-wave phase clocks of one k_lin_plain launch (8 per slice), else null
+    long long* dbg_clk; int one_xcd;   // (one_xcd: every tile of a small fused problem on the workgroups of one XCD: pcg_enqueue_batch)              // NRS_LIN_DBG: per-wave phase clocks of one k_lin_plain launch (8 per slice), else null
     int plain;                       // plain BA window on the LDS path: the lineariser is k_lin_plain (nrs_engine_linearize.hpp)
     EcSpring* ec_sp; EcDamper* ec_dm; float* ec_w; double* part_ec;
     double* h_scal; int* h_flags;     // host-mapped mirrors, written by k_finalize / k_publish (no copy kernels)
