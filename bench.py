@@ -451,7 +451,9 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     ctx.dba_upload(camw, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
     rr = timed_steps(ctx, 20, 3, lambda: None)
     out["ba_window"] = dict(nodes=m, keyframes=n_kf, landmarks=int(len(p["lm_kf"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
-                            ms_per_step=1e3 * rr["dt"] / 20)
+                            ms_per_step=1e3 * rr["dt"] / 20,
+                            note="a window over the NODES only (landmarks = nodes x keyframes they are seen in): a problem ~10x smaller than C2, "
+                                 "not C2 with 500 nodes -- the skinned points carry no observations into this window (DESIGN.md section 1, N2)")
     ctx.close()
     return out
 
