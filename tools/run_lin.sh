@@ -1,3 +1,3 @@
-NRS_PERSIST=1 timeout 120 python tools/small_frame_probe.py 600 1150 2>&1 | grep "^n \|rror"
-NRS_PERSIST=1 timeout 600 python -m pytest tests/test_gpu_track.py tests/test_gpu_goldens.py -x -q > gpurun_out/run_lin_tests.log 2>&1
-grep -E "passed|failed|error" gpurun_out/run_lin_tests.log | tail -3
+for t in "oracle_sweep.py 24" "early_reject_sweep.py 40" "sharded_sweep.py 60" "devpack_sweep.py 60" "dense_sweep.py 16" "lk_graph_sweep.py" "shi_sweep.py"; do
+  echo "== $t"; timeout 1200 python tools/$t 2>&1 | grep -v "^HIP\|^ROCm\|^Host\|^Librccl" | tail -3
+done
