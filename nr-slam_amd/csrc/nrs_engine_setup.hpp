@@ -670,7 +670,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // fixed and few free rows, converges in a few dozen block-Jacobi iterations anyway)
     const bool pose_free = !(s.pose_fixed && s.pose_fixed[0]);
     const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 12 * (size_t)d.n_regblk + 16 * CO_MAX);
-    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && fused_shm <= 63 * 1024 &&
+    // (and only from ~1.5k rows on: below, its per-iteration cost outweighs the iterations it saves -- 1013 points 31.3 ms with it,
+    // 29.2 without; 2220 points 47.4 / 51.8; 4525 points 76.7 / 94.1, tools/small_frame_probe.py)
+    const int co_min_tiles = getenv("NRS_COARSE_MIN_TILES") ? atoi(getenv("NRS_COARSE_MIN_TILES")) : 48;
+    d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && d.n_regblk >= co_min_tiles && fused_shm <= 63 * 1024 &&
                 !getenv("NRS_NO_COARSE")) ? 1 : 0;
     // ---- shard window: the whole problem, or this rank's contiguous range of poses (balanced by rows)
     d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;

@@ -84,8 +84,14 @@ def _track_compare(ctx, n, seed, model=S.PINHOLE, **kw):
     return tp, r, o, tr.trials, otr
 
 
-@pytest.mark.parametrize("n,seed", [(150, 11), (400, 12), (900, 13)])
-def test_track_deform_matches_oracle(ctx, n, seed):
+@pytest.mark.parametrize("n,seed,coarse", [(150, 11, False), (400, 12, False), (400, 12, True), (900, 13, False), (900, 13, True)])
+def test_track_deform_matches_oracle(ctx, monkeypatch, n, seed, coarse):
+    # frames below ~1.5k rows run the block-Jacobi PCG, larger ones add the two-level preconditioner (nrs_engine_setup.hpp);
+    # NRS_COARSE_MIN_TILES=0 puts a small frame on the two-level path so that both are held to the oracle here
+    if coarse:
+        monkeypatch.setenv("NRS_COARSE_MIN_TILES", "0")
+    else:
+        monkeypatch.delenv("NRS_COARSE_MIN_TILES", raising=False)
     tp, r, o, tr, otr = _track_compare(ctx, n, seed)
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
     assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
