@@ -74,6 +74,12 @@ typedef struct {
                                  discarded and accepted steps are always solved to pcg_rtol, so the iterates
                                  are the reference's as long as no rejection is mispredicted.
                                  1: every trial is solved to pcg_rtol (g2o's behaviour; use it to verify). */
+    int32_t direct_solve;     /* linear solver of the single-frame problems (nrs_track_deform_solve[_rg]):
+                                 0 (default): by size -- a sparse direct solve (nested dissection, multifrontal
+                                 Cholesky on the matrix cores: what LinearSolverEigen does, linear_solver_eigen.h:92-173)
+                                 for frames whose free rows lie in [48, 2600], PCG otherwise; 1: direct whenever the
+                                 problem has the single-frame structure; 2: always PCG.  Same LM iterates either way
+                                 (both are held to the oracle).  BA windows always use PCG. */
 } nrs_options;
 
 /* One Levenberg-Marquardt trial as executed by g2o
@@ -190,6 +196,21 @@ int nrs_dba_pack_hash(nrs_ctx* ctx, uint64_t* out /* 24 */);
  * Not used by any solve entry point. */
 int nrs_debug_pcg_solve(nrs_ctx* ctx, int32_t n_rows, const double* Hpp21, const double* bp /*6*/, const double* D6,
                         const double* Hpl18, const double* bl /*3 n_rows*/, double lambda, double* x, int32_t* iters);
+
+/* ---- N1 parity taps: the direct (nested-dissection, multifrontal Cholesky) solve of a2's system on an explicitly given
+ * block system -- what replaces LinearSolverEigen::solve (third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-173:
+ * ordering + symbolic step once, numeric sparse Cholesky per LM trial) when nrs_track_deform_solve[_rg] runs a frame on the
+ * direct path.  n_nodes unknown blocks of 3 scalars at positions pos (n x 3, used for the
+ * dissection only), `last` (n, may be null) marks blocks that are eliminated at the root whatever their position (the two
+ * halves of a pose block), n_pairs unique couplings (a, b) with their 3x3 blocks Vp (row-major, rows = a's components),
+ * diagonal blocks Dn (9 per node), right-hand side bn (3 per node): solves (A + lambda I) x = b.  Returns
+ * NRS_ERR_NUMERIC when a pivot is not positive (linear_solver_eigen.h:124-136: the LM trial then counts as failed).
+ * stats (8, may be null): fronts, levels, largest own / boundary size, L and U doubles, factorisation flops, workgroups.
+ * Runs the device kernels (k_nd_level / k_nd_back) `repeats` times (timing: ms_per_solve, may be null).  Not used by any solve
+ * entry point; the host reference it is held to lives in oracle/nd_host.cpp. */
+int nrs_debug_nd_solve(nrs_ctx* ctx, int32_t n_nodes, const double* pos, const uint8_t* last, int32_t n_pairs, const int32_t* pairs,
+                       const double* Dn, const double* Vp, const double* bn, double lambda, int32_t repeats, double* x, int64_t* stats,
+                       double* ms_per_solve);
 
 /* ---- f3: ShiTomasi (modules/features/shi_tomasi.{h,cc}) + Tracking::ExtractFeatures (tracking.cc:118-134) --
  * nrs_shi_configure = ShiTomasi::ShiTomasi(Options) (shi_tomasi.cc:29-31): a fresh extractor (zeroed

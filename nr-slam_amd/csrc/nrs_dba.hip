@@ -278,3 +278,12 @@ extern "C" int nrs_debug_pcg_solve(nrs_ctx* c, int32_t n_rows, const double* Hpp
     if (rc == NRS_OK && !ok) return c->fail(NRS_ERR_NUMERIC, "debug solve: not positive definite or not converged after %d iterations", it);
     return rc;
 }
+
+extern "C" int nrs_debug_nd_solve(nrs_ctx* c, int32_t n_nodes, const double* pos, const uint8_t* last, int32_t n_pairs, const int32_t* pairs,
+                                  const double* Dn, const double* Vp, const double* bn, double lambda, int32_t repeats, double* x, int64_t* stats,
+                                  double* ms_per_solve) {
+    if (!c) return NRS_ERR_INVALID;
+    if (n_nodes <= 0 || n_pairs < 0 || !pos || (n_pairs > 0 && (!pairs || !Vp)) || !Dn || !bn || !x || repeats < 0)
+        return c->fail(NRS_ERR_INVALID, "nrs_debug_nd_solve: bad argument");
+    return engine_nd_debug_solve(c, n_nodes, pos, last, n_pairs, pairs, Dn, Vp, bn, lambda, repeats, x, stats, ms_per_solve);
+}

@@ -54,6 +54,7 @@
 #include "nrs_engine_linearize.hpp"
 #include "nrs_engine_coarse.hpp"
 #include "nrs_engine_pcg.hpp"
+#include "nrs_engine_nd.hpp"
 #include "nrs_engine_setup.hpp"
 #include "nrs_engine_devpack.hpp"
 
@@ -291,6 +292,8 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         }
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
+    if (LIN && e->nd && e->nd->on)                                 // the direct solver's explicit blocks of this linearisation
+        hipLaunchKernelGGL(k_nd_values, dim3((std::max(e->nd->vals.n_nodes, e->nd->vals.n_pairs) + 255) / 256), dim3(256), 0, c->stream, d, e->nd->vals);
     if (d.sh_on) {
         // local sums -> packet -> all-reduce over the ranks (pose blocks of the normal equations, chi2,
         // scale, one max-diagonal slot per rank) -> every rank publishes the same scalars
@@ -515,7 +518,9 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             const int trial = 1 - e->cur;
             double temp = 0, scale = 0;
             bool ok = true;
-            NRS_TRY(pcg_begin(c, e, lam, &pit));
+            const bool direct = e->nd && e->nd->on;                  // nested-dissection Cholesky instead of PCG (nrs_engine_nd.hpp)
+            if (direct) NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
+            else NRS_TRY(pcg_begin(c, e, lam, &pit));
             auto eval_trial = [&]() -> int {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
                 hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
@@ -529,7 +534,13 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             // size is what the previous trial needed to reach the first milestone (the kernels record
             // it), so a trial that is going to be rejected costs a handful of iterations.
             int seen = 0;                                  // peek levels already evaluated
-            {
+            if (direct) {
+                // g2o's own sequence: factorise (H + lambda I), solve, evaluate (linear_solver_eigen.h:92-136); a pivot that is not
+                // positive raises flags[2] and the trial counts as failed below
+                NRS_TRY(nd_solve_enqueue(c, e->nd->S, lam));
+                NRS_TRY(eval_trial());
+                done = true;
+            } else {
                 int first = 0;
                 // (after an iteration whose first trial was accepted, the next first trial usually is too:
                 // short solves then go out whole, without the intermediate look)

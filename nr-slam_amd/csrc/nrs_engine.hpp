@@ -71,6 +71,9 @@ int engine_edges_to_host(nrs_ctx* c, Engine* e, int* sp_ij, float* sp_d0, int* d
 // the engine's own PCG kernels; the engine must have been created with force_gather and K = 1
 int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double* bp, const double* D6, const double* Hpl18,
                        const double* bl, double lam, double* xp, double* xl, int* iters, int* ok);
+// parity tap of the direct (nested-dissection) solver on an explicit block system: include/nrs.h nrs_debug_nd_solve
+int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint8_t* last, int n_pairs, const int* pairs, const double* Dn, const double* Vp,
+                          const double* bn, double lam, int repeats, double* x, int64_t* stats, double* ms_per_solve);
 void arena_release(Arena* a);
 void engine_stats(const Engine* e, int64_t stats[5]);              // rows, rows packed here, spring / damper incidence slots, device bytes
 void shard_plan(int K, const int* grp_ptr, int world, int* kb);     // contiguous keyframe ranges, balanced by rows

@@ -1016,6 +1016,15 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
+    if (arena == &c->arena_trk && s.K == 1) {          // a2's single-frame engines: direct solve when the frame is small enough to gain from it
+        e->nd = new (std::nothrow) NdEngine();
+        if (!e->nd) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+        e->nd->pos.assign(3 * (size_t)d.n_rows, 0.0);
+        for (int v = 0; v < s.M; ++v)
+            for (int k = 0; k < 3; ++k) e->nd->pos[3 * (size_t)e->vrow[v] + k] = s.x[3 * (size_t)v + k] + (s.X0 ? s.X0[3 * (size_t)v + k] : 0.0);
+        NRS_TRY(nd_engine_setup(c, e, e->nd));
+        mark("direct solve plan");
+    }
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
     *out = e;
@@ -1029,6 +1038,7 @@ void engine_stats(const Engine* e, int64_t stats[5]) {
 void engine_destroy(nrs_ctx* c, Engine* e) {
     if (!e) return;
     (void)hipStreamSynchronize(c->stream);
+    nd_engine_free(e->nd);
     delete e;
 }
 
@@ -1041,6 +1051,11 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
     if (e->d.plain) return c->fail(NRS_ERR_STATE, "masks on a plain BA window: not supported (its partial slots are per slice)");
     NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
+    if (e->nd) {                                                   // the direct solver's plan is built on the free rows: a changed fixed set needs a new one
+        bool same = e->nd->sig.size() == (size_t)e->d.M + 1 && e->nd->sig[e->d.M] == e->h_pose_fixed[0];
+        for (int v = 0; v < e->d.M && same; ++v) same = e->nd->sig[v] == (e->h_rflag[e->vrow[v]] & RF_FIXED);
+        if (!same) NRS_TRY(nd_engine_setup(c, e, e->nd));
+    }
     return NRS_OK;
 }
 

@@ -168,8 +168,10 @@ struct Dev {
 
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
 
+struct NdEngine;                     // nrs_engine_nd.hpp: the direct solver of a single-frame engine
 struct Engine {
     Dev d;
+    NdEngine* nd = nullptr;
     Arena* arena = nullptr;
     int cur = 0;
     int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)

@@ -186,3 +186,24 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
     *n_damper = (int32_t)nd;
     return NRS_OK;
 }
+
+// ---- N1 (include/nrs.h nrs_debug_nd_solve): helpers of the nested-dissection plan shared with the engine
+#include "nrs_nd_plan.hpp"
+
+namespace nrs {
+// pair blocks as the caller gives them (rows = first node of the pair) -> the plan's orientation (rows = the later-eliminated node)
+void nd_orient_pairs(const NdPlan& P, const int32_t* pairs, const double* Vp, std::vector<double>& out) {
+    out.resize(9 * (size_t)P.n_pairs);
+    for (int q = 0; q < P.n_pairs; ++q) {
+        const bool flip = P.pair_hi[q] != pairs[2 * q];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) out[9 * (size_t)q + 3 * a + b] = flip ? Vp[9 * (size_t)q + 3 * b + a] : Vp[9 * (size_t)q + 3 * a + b];
+    }
+}
+void nd_stats(const NdPlan& P, int64_t* stats) {
+    if (!stats) return;
+    stats[0] = P.n_fronts; stats[1] = P.n_levels; stats[2] = P.max_s; stats[3] = P.max_b;
+    stats[4] = (int64_t)P.L_doubles; stats[5] = (int64_t)P.U_doubles; stats[6] = (int64_t)P.flops; stats[7] = (int64_t)P.wg.size() / 3;
+}
+}  // namespace nrs
+

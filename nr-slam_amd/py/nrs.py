@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -45,7 +45,7 @@ class Camera(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
-                ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32)]
+                ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32), ("direct_solve", C.c_int32)]
 
 
 class LmTrial(C.Structure):
@@ -281,9 +281,9 @@ class RGraph:
 
 
 class Context:
-    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0):
+    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0, direct_solve=0):
         self.lib = load_library()
-        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials)
+        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials, direct_solve)
         self.h = C.c_void_p()
         rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
         if rc != OK:
@@ -607,6 +607,25 @@ class Context:
         self._chk(self.lib.nrs_debug_pcg_solve(self.h, C.c_int32(n), _p(Hpp21, C.c_double), _p(bp, C.c_double), _p(D6, C.c_double),
                                                _p(Hpl18, C.c_double), _p(bl, C.c_double), C.c_double(lam), _p(x, C.c_double), C.byref(it)))
         return x, it.value
+
+    def debug_nd_solve(self, pos, last, pairs, Dn, Vp, bn, lam=0.0, repeats=0):
+        """include/nrs.h nrs_debug_nd_solve: the direct (nested-dissection) solver's device kernels on an explicit block system.
+        Returns (ok, x [n,3], stats dict, ms per solve)."""
+        pos = np.ascontiguousarray(pos, np.float64)
+        n = len(pos)
+        last = None if last is None else np.ascontiguousarray(last, np.uint8)
+        pairs = _i32(np.asarray(pairs).reshape(-1, 2))
+        Dn, Vp, bn = (np.ascontiguousarray(a, np.float64) for a in (Dn, Vp, bn))
+        x = np.zeros((n, 3))
+        st = np.zeros(8, np.int64)
+        ms = C.c_double(0)
+        rc = self.lib.nrs_debug_nd_solve(self.h, C.c_int32(n), _p(pos, C.c_double), None if last is None else _p(last, C.c_uint8), C.c_int32(len(pairs)),
+                                         _p(pairs, C.c_int32), _p(Dn, C.c_double), _p(Vp, C.c_double), _p(bn, C.c_double), C.c_double(lam),
+                                         C.c_int32(repeats), _p(x, C.c_double), _p(st, C.c_int64), C.byref(ms))
+        if rc not in (0, -6):
+            self._chk(rc)
+        keys = ("fronts", "levels", "max_s", "max_b", "L_doubles", "U_doubles", "flops", "workgroups")
+        return rc == 0, x, dict(zip(keys, st.tolist())), ms.value
 
     def dba_gradient(self):
         n = 6 * self._n_kf + 3 * self._n_lm

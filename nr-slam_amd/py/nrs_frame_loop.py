@@ -82,11 +82,11 @@ def project_f32(model, prm, p):
 class GpuBackend:
     """The product path: two nrs contexts (each owns one LucasKanadeTracker state)."""
 
-    def __init__(self, nrs, model, prm, klt_opts, dense_graph=False, cap_per_point=64):
+    def __init__(self, nrs, model, prm, klt_opts, dense_graph=False, cap_per_point=64, direct_solve=0):
         self.nrs = nrs
         self.dense, self.cap, self.rg = dense_graph, cap_per_point, None
         self.cam = nrs.make_camera(model, prm)
-        self.ctx = nrs.Context()
+        self.ctx = nrs.Context(direct_solve=direct_solve)      # (nrs_options.direct_solve: the linear solver of the pose-and-deformation solve)
         self.ctx_reuse = nrs.Context()
         self.klt_opts = klt_opts
         self.ctx.klt_configure(klt_opts["win"], klt_opts["max_level"], klt_opts["max_iters"], klt_opts["epsilon"], klt_opts["min_eig"])

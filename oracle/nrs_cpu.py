@@ -178,3 +178,23 @@ class LucasKanadeCpp:
                                   _p(pts, C.c_float), _p(status, C.c_int32), C.c_int32(1 if initial_flow else 0), C.c_float(min_ssim), C.byref(good),
                                   _p(ssim, C.c_float))
         return pts, status, good.value, ssim
+
+
+def nd_solve(pos, last, pairs, Dn, Vp, bn, lam=0.0, lib=None):
+    """oracle/nd_host.cpp: the nested-dissection plan of nr-slam_amd/csrc/nrs_nd_plan.hpp + its host reference solve of
+    (A + lam I) x = b (A: diagonal blocks Dn [n,3,3], pair blocks Vp [p,3,3] with rows = pairs[:,0]'s components).
+    Returns (ok, x [n,3], stats dict)."""
+    lib = lib or load()
+    pos = np.ascontiguousarray(pos, np.float64)
+    n = len(pos)
+    last = None if last is None else np.ascontiguousarray(last, np.uint8)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    Dn, Vp, bn = (np.ascontiguousarray(a, np.float64) for a in (Dn, Vp, bn))
+    x = np.zeros((n, 3))
+    st = np.zeros(8, np.int64)
+    rc = lib.nrs_cpu_nd_solve(C.c_int32(n), _p(pos, C.c_double), _p(last, C.c_uint8), C.c_int32(len(pairs)), _p(pairs, C.c_int32),
+                              _p(Dn, C.c_double), _p(Vp, C.c_double), _p(bn, C.c_double), C.c_double(lam), _p(x, C.c_double), _p(st, C.c_int64))
+    if rc not in (0, -6):
+        raise RuntimeError("nrs_cpu_nd_solve: the plan could not be built (rc %d)" % rc)
+    keys = ("fronts", "levels", "max_s", "max_b", "L_doubles", "U_doubles", "flops", "workgroups")
+    return rc == 0, x, dict(zip(keys, st.tolist()))

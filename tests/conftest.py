@@ -41,6 +41,24 @@ def ctx_exact():
     c.close()
 
 
+@pytest.fixture(scope="session")
+def ctx_direct():
+    """nrs_options.direct_solve = 1: single-frame problems on the nested-dissection Cholesky whatever their size."""
+    import nrs
+    c = nrs.Context(direct_solve=1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_pcg():
+    """nrs_options.direct_solve = 2: single-frame problems on the PCG path whatever their size."""
+    import nrs
+    c = nrs.Context(direct_solve=2)
+    yield c
+    c.close()
+
+
 def compare_lm_traces(dev, ora, rounds, rtol=1e-6, noise=3e-7):
     """Every LM trial of every round against the oracle's, up to the point where the oracle's own decision sits on the
     fp32-projection noise floor: a trial whose chi2 change is below `noise` * chi2 is decided by the last bits of 4.5k

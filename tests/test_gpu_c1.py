@@ -23,13 +23,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_st
 OPTS = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)      # SLAM/system.cc:77-84
 
 
-def test_c1_standin_50_frames_match_oracle_golden():
+@pytest.mark.parametrize("direct_solve", [1, 2])        # both linear solvers of the pose-and-deformation solve: nested-dissection Cholesky, PCG
+def test_c1_standin_50_frames_match_oracle_golden(direct_solve):
     g = np.load(GOLD)
     n_frames = int(g["n_frames"])
     assert n_frames == 50 and int(g["keyframe"].sum()) >= 8
     sq = S.make_frame_sequence(int(g["n_points"]), n_frames, int(g["seed"]), S.PINHOLE)
     assert np.allclose(sq["prm"][:4], [766.380279, 766.380279, 304.8638, 258.3344], atol=1e-3) and sq["wh"] == (640, 480)
-    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS, dense_graph=True)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS, dense_graph=True, direct_solve=direct_solve)
     try:
         proj = lambda pc: FL.project_f32(sq["model"], sq["prm"], pc)
         loop = FL.FrameLoop(gb, proj, sq["wh"], sq["scale"], sq["kp0"], sq["X0"], sq["graph"], sq["pose_q"][0], sq["pose_t"][0],

@@ -84,15 +84,18 @@ def _track_compare(ctx, n, seed, model=S.PINHOLE, **kw):
     return tp, r, o, tr.trials, otr
 
 
-@pytest.mark.parametrize("n,seed,coarse", [(150, 11, False), (400, 12, False), (400, 12, True), (900, 13, False), (900, 13, True)])
-def test_track_deform_matches_oracle(ctx, monkeypatch, n, seed, coarse):
-    # frames below ~1.5k rows run the block-Jacobi PCG, larger ones add the two-level preconditioner (nrs_engine_setup.hpp);
-    # NRS_COARSE_MIN_TILES=0 puts a small frame on the two-level path so that both are held to the oracle here
-    if coarse:
+@pytest.mark.parametrize("n,seed,solver", [(150, 11, "direct"), (150, 11, "pcg"), (400, 12, "direct"), (400, 12, "pcg"), (400, 12, "pcg-coarse"),
+                                           (900, 13, "direct"), (900, 13, "pcg"), (900, 13, "pcg-coarse")])
+def test_track_deform_matches_oracle(ctx_direct, ctx_pcg, monkeypatch, n, seed, solver):
+    # BOTH linear solvers are held to the oracle: the nested-dissection Cholesky (nrs_options.direct_solve = 1; what frames of
+    # 48..2600 free rows run by default) and the PCG (direct_solve = 2) -- the latter with block-Jacobi alone, as frames below
+    # ~1.5k rows run it, and with the two-level preconditioner larger frames add (NRS_COARSE_MIN_TILES=0 puts a small one on it)
+    if solver == "pcg-coarse":
         monkeypatch.setenv("NRS_COARSE_MIN_TILES", "0")
     else:
         monkeypatch.delenv("NRS_COARSE_MIN_TILES", raising=False)
-    tp, r, o, tr, otr = _track_compare(ctx, n, seed)
+    tp, r, o, tr, otr = _track_compare(ctx_direct if solver == "direct" else ctx_pcg, n, seed)
+    assert all(t["inner"] == 1 for t in tr) == (solver == "direct")          # (the direct path reports one "iteration" per trial)
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
     assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
     assert np.array_equal(r["f_status"], o["f_status"])
@@ -107,8 +110,9 @@ def test_track_deform_matches_oracle(ctx, monkeypatch, n, seed, coarse):
     assert compare_lm_traces(tr, otr, 3) >= 9
 
 
-def test_track_deform_kb8(ctx):
-    tp, r, o, tr, otr = _track_compare(ctx, 400, 21, S.KB8)
+@pytest.mark.parametrize("solver", ["direct", "pcg"])
+def test_track_deform_kb8(ctx_direct, ctx_pcg, solver):
+    tp, r, o, tr, otr = _track_compare(ctx_direct if solver == "direct" else ctx_pcg, 400, 21, S.KB8)
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)
     assert np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
     # KB8 trigonometry is defined on both sides as the double routine rounded to float: the

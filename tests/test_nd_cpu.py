@@ -1,0 +1,75 @@
+"""CPU tests of the direct solver's symbolic phase (nr-slam_amd/csrc/nrs_nd_plan.hpp: nested dissection, fronts, child maps,
+entry lists -- host logic of the product) through its host reference solve (oracle/nd_host.cpp) against a dense NumPy solve.
+What the solve stands for: LinearSolverEigen::solve, third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-136."""
+import numpy as np
+import pytest
+
+import nrs_cpu as CPU
+
+
+def block_system(n, seed, pose=True, knn=8, disconnected=False):
+    """An SPD block system with a2's structure: n points on a surface, each coupled to its nearest neighbours (3x3 blocks),
+    optionally two `last` blocks (a pose) coupled to every point."""
+    rng = np.random.default_rng(seed)
+    pts = np.c_[rng.uniform(-20, 20, n), rng.uniform(-15, 15, n), 60 + rng.normal(0, 1, n)]
+    if disconnected:
+        pts[: n // 2, 0] -= 200.0
+    d = np.linalg.norm(pts[:, None, :2] - pts[None, :, :2], axis=2)
+    np.fill_diagonal(d, 1e9)
+    pairs = set()
+    for i in range(n):
+        for j in np.argsort(d[i])[:knn]:
+            if d[i, j] < 50:
+                pairs.add((min(i, int(j)), max(i, int(j))))
+    pairs = np.array(sorted(pairs), np.int32).reshape(-1, 2)
+    flip = rng.uniform(size=len(pairs)) < 0.5                      # either node may come first in a pair
+    pairs[flip] = pairs[flip][:, ::-1]
+    nn = n + (2 if pose else 0)
+    if pose:
+        pp = np.array([(n + h, i) if (i + h) % 2 else (i, n + h) for i in range(n) for h in range(2)] + [(n, n + 1)], np.int32)
+        pairs = np.r_[pairs, pp]
+    pos = np.r_[pts, np.zeros((nn - n, 3))]
+    last = np.zeros(nn, np.uint8)
+    last[n:] = 1
+    Vp = rng.normal(0, 1, (len(pairs), 3, 3)) * 0.3
+    A = np.zeros((3 * nn, 3 * nn))
+    for (a, b), V in zip(pairs, Vp):
+        A[3 * a:3 * a + 3, 3 * b:3 * b + 3] += V
+        A[3 * b:3 * b + 3, 3 * a:3 * a + 3] += V.T
+    rowsum = np.abs(A).sum(1)
+    Dn = np.zeros((nn, 3, 3))
+    for i in range(nn):
+        S = rng.normal(0, 0.2, (3, 3))
+        Dn[i] = S @ S.T + np.eye(3) * (rowsum[3 * i:3 * i + 3].max() + 0.5)
+        A[3 * i:3 * i + 3, 3 * i:3 * i + 3] = Dn[i]
+    bn = rng.normal(0, 1, (nn, 3))
+    return pos, last, pairs, Dn, Vp, bn, A
+
+
+@pytest.mark.parametrize("n,seed,pose", [(5, 1, True), (40, 2, True), (300, 3, True), (300, 4, False), (1200, 5, True)])
+def test_host_reference_matches_dense(n, seed, pose):
+    pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, pose)
+    lam = 0.37
+    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, lam)
+    assert ok
+    ref = np.linalg.solve(A + lam * np.eye(len(A)), bn.ravel())
+    assert np.allclose(x.ravel(), ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    assert st["max_s"] <= 96 and st["fronts"] >= 1
+    if n >= 300:
+        assert st["levels"] >= 4 and st["fronts"] > 8
+
+
+def test_disconnected_graph_and_single_front():
+    pos, last, pairs, Dn, Vp, bn, A = block_system(200, 7, pose=False, disconnected=True)     # a forest: several roots
+    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
+    assert ok and np.allclose(x.ravel(), np.linalg.solve(A, bn.ravel()), atol=1e-10)
+    pos, last, pairs, Dn, Vp, bn, A = block_system(3, 8, pose=True)
+    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
+    assert ok and st["fronts"] == 1 and np.allclose(x.ravel(), np.linalg.solve(A, bn.ravel()), atol=1e-12)
+
+
+def test_not_positive_definite_is_reported():
+    pos, last, pairs, Dn, Vp, bn, A = block_system(60, 9, pose=True)
+    Dn[17] = -Dn[17]                                               # linear_solver_eigen.h:124-136: the solve reports failure
+    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
+    assert not ok
