@@ -293,7 +293,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
     if (LIN && e->nd && e->nd->on)                                 // the direct solver's explicit blocks of this linearisation
-        hipLaunchKernelGGL(k_nd_values, dim3((std::max(e->nd->vals.n_nodes, e->nd->vals.n_pairs) + 255) / 256), dim3(256), 0, c->stream, d, e->nd->vals);
+        hipLaunchKernelGGL(k_nd_values, dim3((e->nd->vals.n_ent + 255) / 256), dim3(256), 0, c->stream, d, e->nd->vals);
     if (d.sh_on) {
         // local sums -> packet -> all-reduce over the ranks (pose blocks of the normal equations, chi2,
         // scale, one max-diagonal slot per rank) -> every rank publishes the same scalars

@@ -23,9 +23,10 @@ constexpr int ND_S16 = 96;
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 struct NdDev {
-    const NdFrontD* fr; const int* own; const int* bnd; const int* child; const int16_t* cmap; const NdEnt* ent; const int* wg; const int* lvl_fronts;
-    const double* Dn; const double* Vp; const double* bn;          // blocks of the current linearisation (diagonal 9 / node, pairs 9, rhs 3)
-    double* Lp; double* U; double* xn;
+    const NdFrontD* fr; const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const int* wg; const int* lvl_fronts;
+    const double* ev;                // 9 doubles per original entry (plan order): the blocks of the current linearisation
+    double* A;                       // assembly areas: every front's Schur complement lands in its parent's index space
+    double* Lp; double* xn;
     const int* node_out;             // engine: node -> 3 doubles at out_rows + o (o >= 0) or out_pose - 1 - o (o < 0); null: xn only
     double* out_rows; double* out_pose;
     int* flags;                      // [0] done [1] iterations [2] not positive definite (the engine's PCG flags, or a scratch word block)
@@ -36,12 +37,87 @@ __device__ inline double nd_readlane(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-__device__ inline double nd_rsqrt(double a) {                       // a > 0: v_rsq_f64 + two Newton steps
-    double r = __builtin_amdgcn_rsq(a);
-    const double h = 0.5 * a;
-    r = r * (1.5 - h * r * r);
-    r = r * (1.5 - h * r * r);
-    return r;
+// value of lane K of the caller's 16-lane row, in every lane of the row: DPP row_newbcast (a plain VALU move, no SGPR round trip)
+template <int K>
+__device__ inline double nd_rowbcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false); }
+// a += (lane K's nl of this 16-lane row) * l in ONE instruction: the DPP form of v_fmac_f64 (gfx90a+ encode row_newbcast on the
+// fp64 ALU).  Measured on gfx950 (tools/micro/diag_probe.hip), per 16 x 16 block: v_readlane + FMA 5100 cycles, v_mov_b64_dpp +
+// FMA 4480, this form 3350.
+template <int K>
+__device__ inline void nd_fmac_bcast(double& a, double nl, double l) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(nl), "v"(l), "n"(K));
+}
+
+// Cholesky of one 16 x 16 diagonal block of the panel, one wave: lane (i = lane & 15) of every 16-lane row holds row i (the four
+// rows of the wave work redundantly, so every broadcast stays inside a row).  Column j: the pivot reaches the lanes by a row
+// broadcast, a[k] -= l_ij l_kj by the DPP FMA.  Leaves the block in W (lower triangle), its transpose in Lt and 1 / diag in dinv.
+template <int J, int K>
+__device__ inline void nd_diag_cols_upd(double (&a)[16], double nl, double l) {
+    if constexpr (K < 16) {
+        nd_fmac_bcast<K>(a[K], nl, l);
+        nd_diag_cols_upd<J, K + 1>(a, nl, l);
+    }
+}
+template <int J>
+__device__ inline void nd_diag_cols(double (&a)[16], double (&rr)[16], int& bad) {
+    if constexpr (J < 16) {
+        double ajj = nd_rowbcast<J>(a[J]);
+        const bool ok = ajj > 0.0;
+        bad |= !ok;
+        ajj = ok ? ajj : 1.0;
+        const double r = fast_rsqrt_pos(ajj);
+        const double l = a[J] * r;                                 // (lane J: a_jj r = sqrt(a_jj))
+        a[J] = l; rr[J] = r;
+        double nl = -l;
+        asm volatile("s_nop 1" : "+v"(nl));                        // (a VALU result read through DPP needs two wait states)
+        nd_diag_cols_upd<J, J + 1>(a, nl, l);
+        nd_diag_cols<J + 1>(a, rr, bad);
+    }
+}
+
+__device__ __forceinline__ void nd_diag_factor(double* W, double* Lt, double* dinv, int k0, int lane, int& bad) {
+    const int i = lane & 15;
+    double a[16], rr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = W[(k0 + i) * ND_LD + k0 + j];
+    nd_diag_cols<0>(a, rr, bad);
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j <= i) W[(k0 + i) * ND_LD + k0 + j] = a[j];
+            Lt[j * 16 + i] = j <= i ? a[j] : 0.0;                  // column j of the block, contiguous over the rows: what step B reads
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dinv[k0 + j] = rr[j];
+    }
+}
+
+// trailing update of the panel factorisation on the matrix cores: C_rb,cb -= P_rb P_cb^T for the block columns cb in [cb_lo, cb_hi) and
+// the row blocks rb >= cb, P = the 16 columns at k0; the tiles are dealt round-robin to the waves w0 .. w0 + nw - 1 (this wave: widx)
+__device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo, int cb_hi, int nrt, int widx, int nw) {
+    if (widx < 0 || widx >= nw) return;
+    int cnt = 0;
+#pragma unroll 1
+    for (int cb = cb_lo; cb < cb_hi; ++cb)
+#pragma unroll 1
+        for (int rb = cb; rb < nrt; ++rb, ++cnt) {
+            if (cnt % nw != widx) continue;
+            nd_v4d c;
+            double av[4], bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) c[g] = W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                av[kk] = -W[(16 * rb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
+                bv[kk] = W[(16 * cb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)] = c[g];
+        }
 }
 
 __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) {
@@ -50,7 +126,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     const int* wd = N.wg + 3 * (size_t)(wg0 + blockIdx.x);
     const int f = wd[0], I = wd[1], J = wd[2];
     const NdFrontD F = N.fr[f];
-    const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b, sn = s / 3, mn = m / 3;
+    const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b;
     const int rI = min(ND_TB, b1 - ND_TB * I);                      // rows of block I (the last block is partial; J < I is always full)
     const bool two = J != I;
     const int cJ = two ? ND_TB : rI;
@@ -58,183 +134,235 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     const int rowI0 = s16, rowJ0 = two ? s16 + ND_TB : s16;
     double* W = sm;
     double* dinv = W + (size_t)nrow * ND_LD;
-    int16_t* cmo = reinterpret_cast<int16_t*>(dinv + ND_S16);
-    int16_t* cmi = cmo + 32;
-    int16_t* cmj = cmi + 16;
-    const int tx = tid & 31, ty = tid >> 5;
+    double* Lt = dinv + ND_S16;                                    // [16][16]: the current diagonal block, transposed
+    int16_t* pmi = reinterpret_cast<int16_t*>(Lt + 256);           // parent node positions of the nodes of blocks I and J
+    int16_t* pmj = pmi + 16;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
-    // ---- assemble: zero, original entries, children (fixed order)
-    for (int i = tid; i < nrow * ND_LD; i += 256) W[i] = 0.0;
-    __syncthreads();
-    if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;       // padding columns: unit diagonal
-    for (int e = tid; e < F.n_ent; e += 256) {
-        const NdEnt E = N.ent[F.ent_off + e];
-        const uint32_t kind = E.src >> ND_KIND_SHIFT, src = E.src & ND_SRC_MASK;
+    // ---- requests first: this thread's original entries (descriptor and values: one round trip) and the Schur complements the
+    // children left in this front's assembly slots (dense, in this front's own index space: contiguous 16-byte loads)
+    auto entry_row = [&](const NdEnt& E) {                         // W row of an entry's first row, -1: not in this workgroup's blocks
         const int fr_row = 3 * (int)E.r;
-        int wr;
-        if (fr_row < s) wr = fr_row;
-        else {
-            const int rb = fr_row - s;
-            if (rb >= ND_TB * I && rb < ND_TB * I + ND_TB) wr = rowI0 + rb - ND_TB * I;
-            else if (two && rb >= ND_TB * J && rb < ND_TB * J + ND_TB) wr = rowJ0 + rb - ND_TB * J;
-            else continue;
-        }
-        double* dst = W + (size_t)wr * ND_LD + 3 * (int)E.c;
-        if (kind == 2) {
-            const double* v = N.bn + 3 * (size_t)src;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
-        } else {
-            const double* v = (kind == 0 ? N.Dn : N.Vp) + 9 * (size_t)src;
+        if (fr_row < s) return fr_row;
+        const int rb = fr_row - s;
+        if (rb >= ND_TB * I && rb < ND_TB * I + ND_TB) return rowI0 + rb - ND_TB * I;
+        if (two && rb >= ND_TB * J && rb < ND_TB * J + ND_TB) return rowJ0 + rb - ND_TB * J;
+        return -1;
+    };
+    constexpr int NE = 2;
+    NdEnt En[NE];
+    double ev[NE][9];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+    for (int u = 0; u < NE; ++u) {
+        const int e = F.ent_off + min(tid + 256 * u, F.n_ent - 1);
+        En[u] = N.ent[e];
+        const double* v = N.ev + 9 * (size_t)e;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) dst[a * ND_LD + j] = v[3 * a + j] + ((kind == 0 && a == j) ? lam : 0.0);
-        }
+        for (int a = 0; a < 9; ++a) ev[u][a] = v[a];
     }
-    stamp(1);
+    if (tid < 16) { const int np = 16 * I + tid; pmi[tid] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
+    else if (tid < 32) { const int np = 16 * J + tid - 16; pmj[tid - 16] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
+    const size_t slot = (size_t)(m + 1) * F.ldA;
+    const double* A0 = N.A + F.A_off;
     nd_v4d acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; k < F.n_ch; ++k) {
-        const NdFrontD C = N.fr[N.child[F.ch_off + k]];
-        const int16_t* cm = N.cmap + F.cmap_off + (size_t)k * (mn + 1);
-        __syncthreads();
-        if (tid < sn) cmo[tid] = cm[tid];
-        if (tid >= 64 && tid < 80) { const int np = sn + 16 * I + (tid - 64); cmi[tid - 64] = np <= mn ? cm[np] : (int16_t)-1; }
-        if (tid >= 128 && tid < 144) { const int np = sn + 16 * J + (tid - 128); cmj[tid - 128] = np <= mn ? cm[np] : (int16_t)-1; }
-        __syncthreads();
-        const double* Uc = N.U + C.U_off;
-        const int ldc = C.ldU;
-        for (int p = ty; p < s; p += 8) {                          // F11, lower triangle
-            const int a = cmo[p / 3];
-            if (a < 0) continue;
-            const double* ur = Uc + (size_t)(3 * a + p % 3) * ldc;
-            for (int q = tx; q <= p; q += 32) { const int bq = cmo[q / 3]; if (bq >= 0) W[p * ND_LD + q] += ur[3 * bq + q % 3]; }
-        }
-        for (int r = ty; r < rI; r += 8) {                         // F21, block I
-            const int a = cmi[r / 3];
-            if (a < 0) continue;
-            const double* ur = Uc + (size_t)(3 * a + r % 3) * ldc;
-            for (int q = tx; q < s; q += 32) { const int bq = cmo[q / 3]; if (bq >= 0) W[(rowI0 + r) * ND_LD + q] += ur[3 * bq + q % 3]; }
-        }
-        if (two)
-            for (int r = ty; r < ND_TB; r += 8) {                  // F21, block J
-                const int a = cmj[r / 3];
-                if (a < 0) continue;
-                const double* ur = Uc + (size_t)(3 * a + r % 3) * ldc;
-                for (int q = tx; q < s; q += 32) { const int bq = cmo[q / 3]; if (bq >= 0) W[(rowJ0 + r) * ND_LD + q] += ur[3 * bq + q % 3]; }
-            }
-        const int16_t* cmc = two ? cmj : cmi;                      // F22 tile (I, J): straight into the accumulators
+    if (F.n_ch > 0) {                                              // F22 tile (I, J): straight into the accumulators of the matrix cores
+        double tv[2][3][4];
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) {
-            const int t = wave + 4 * t3;
-            if (t >= 9) break;
-            const int ti = t / 3, tj = t % 3;
+            const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
-                if (r < rI && cc < cJ && ND_TB * J + cc < F.b) {
-                    const int a = cmi[r / 3], bq = cmc[cc / 3];
-                    if (a >= 0 && bq >= 0) acc[t3][g] += Uc[(size_t)(3 * a + r % 3) * ldc + 3 * bq + cc % 3];
+                const bool in = t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b;
+                const size_t o = in ? (size_t)(s + ND_TB * I + r) * F.ldA + s + ND_TB * J + cc : 0;
+                tv[0][t3][g] = A0[o];
+                tv[1][t3][g] = A0[(F.n_ch > 1 ? slot : 0) + o];
+                if (!in) { tv[0][t3][g] = 0.0; tv[1][t3][g] = 0.0; }
+            }
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t3][g] = tv[0][t3][g] + (F.n_ch > 1 ? tv[1][t3][g] : 0.0);
+        for (int k = 2; k < F.n_ch; ++k)                           // (more than two children: a separator whose halves fell apart)
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
+                    if (t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b) acc[t3][g] += A0[k * slot + (size_t)(s + ND_TB * I + r) * F.ldA + s + ND_TB * J + cc];
                 }
             }
+    }
+    {
+        double2* W2 = reinterpret_cast<double2*>(W);
+        for (int i = tid; i < (nrow * ND_LD) >> 1; i += 256) W2[i] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;       // padding columns: unit diagonal
+    if (F.n_ch > 0) {
+        // panel rows of this workgroup <- sum of the slots: W row wr = ty + 16 i is front row fr; thread (tx, ty) takes the column pairs 2 tx + 32 j
+        const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll 1
+        for (int i0 = 0; 16 * i0 < nrow; i0 += 6) {
+            double2 v0[6][3], v1[6][3];
+            bool ok[6][3], ok2[6][3];                               // (second column of the pair: only below the row's limit)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int wr = ty + 16 * (i0 + i);
+                int fr = -1, lim = s;                              // columns [0, lim) of front row fr
+                if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
+                else if (wr < s16 + ND_TB) { if (wr - s16 < rI) fr = s + ND_TB * I + wr - s16; }
+                else if (wr < nrow) fr = s + ND_TB * J + wr - s16 - ND_TB;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int q = 2 * tx + 32 * j;
+                    ok[i][j] = fr >= 0 && q < lim;
+                    ok2[i][j] = fr >= 0 && q + 1 < lim;
+                    const size_t o = ok[i][j] ? (size_t)fr * F.ldA + q : 0;
+                    v0[i][j] = *reinterpret_cast<const double2*>(A0 + o);
+                    v1[i][j] = *reinterpret_cast<const double2*>(A0 + (F.n_ch > 1 ? slot : 0) + o);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (ok[i][j]) {
+                        double* d = W + (ty + 16 * (i0 + i)) * ND_LD + 2 * tx + 32 * j;
+                        d[0] = v0[i][j].x + (F.n_ch > 1 ? v1[i][j].x : 0.0);
+                        if (ok2[i][j]) d[1] = v0[i][j].y + (F.n_ch > 1 ? v1[i][j].y : 0.0);
+                    }
+        }
+        for (int k = 2; k < F.n_ch; ++k) {
+            __syncthreads();
+            for (int idx = tid; idx < nrow * 48; idx += 256) {
+                const int wr = idx / 48, q = 2 * (idx - 48 * wr);
+                int fr = -1, lim = s;
+                if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
+                else if (wr < s16 + ND_TB) { if (wr - s16 < rI) fr = s + ND_TB * I + wr - s16; }
+                else fr = s + ND_TB * J + wr - s16 - ND_TB;
+                if (fr < 0 || q >= lim) continue;
+                const double2 v = *reinterpret_cast<const double2*>(A0 + k * slot + (size_t)fr * F.ldA + q);
+                W[wr * ND_LD + q] += v.x;
+                if (q + 1 < lim) W[wr * ND_LD + q + 1] += v.y;
+            }
+        }
+        __syncthreads();
+    }
+    stamp(1);
+    {
+        auto put_entry = [&](const NdEnt& E, const double* v, int wr) {
+            const uint32_t kind = E.src >> ND_KIND_SHIFT;
+            double* dst = W + (size_t)wr * ND_LD + 3 * (int)E.c;
+            if (kind == 2) { dst[0] += v[0]; dst[1] += v[1]; dst[2] += v[2]; return; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dst[a * ND_LD + j] += v[3 * a + j] + ((kind == 0 && a == j) ? lam : 0.0);
+        };
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int wr = tid + 256 * u < F.n_ent ? entry_row(En[u]) : -1;
+            if (wr >= 0) put_entry(En[u], ev[u], wr);
+        }
+        for (int e = tid + 256 * NE; e < F.n_ent; e += 256) {      // (fronts with more than 512 entries)
+            const NdEnt E = N.ent[F.ent_off + e];
+            const int wr = entry_row(E);
+            if (wr < 0) continue;
+            double t9[9];
+            for (int a = 0; a < 9; ++a) t9[a] = N.ev[9 * (size_t)(F.ent_off + e) + a];
+            put_entry(E, t9, wr);
         }
     }
     __syncthreads();
     stamp(2);
-    // ---- panel factorisation of [F11; F21_I; F21_J] by 16-column steps
+    // ---- panel factorisation of [F11; F21_I; F21_J] by 16-column steps.  Per step: (A) wave 0 factorises the diagonal block
+    // while waves 1..3 apply the PREVIOUS panel to the block columns behind the next one; (B) every thread solves one panel row
+    // against the block; (C) the next step's block column is updated by all four waves.  Every piece of code appears once.
     const int nb = s16 >> 4, nrt = nrow >> 4;
     int bad = 0;
+    long long tA = 0, tB = 0, tq = 0;                              // (NRS_ND_DBG: time of wave 0 in steps A and B)
+#pragma unroll 1
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 16 * kb;
-        if (wave == 0) {                                           // diagonal block: lane i (< 16) holds row i
-            const int i = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = W[(k0 + i) * ND_LD + k0 + j];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double ajj = nd_readlane(a[j], j);
-                if (!(ajj > 0.0)) { bad = 1; ajj = 1.0; }
-                const double r = nd_rsqrt(ajj);
-                const double lij = (i == j) ? ajj * r : a[j] * r;
-                a[j] = lij;
-                if (lane == 0) dinv[k0 + j] = r;
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) a[k] -= lij * nd_readlane(lij, k);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) if (j <= i) W[(k0 + i) * ND_LD + k0 + j] = a[j];
-            }
-        }
+        if (N.clk) tq = wall_clock64();
+        if (wave == 0) nd_diag_factor(W, Lt, dinv, k0, lane, bad);
+        else if (kb > 0) nd_update(W, lane, k0 - 16, kb + 1, nb, nrt, wave - 1, 3);
         __syncthreads();
-        {                                                          // panel: one row per thread, forward substitution against the block
+        if (N.clk) { const long long t = wall_clock64(); tA += t - tq; tq = t; }
+        {                                                          // (B) one row per thread: x L_kk^T = a, column by column (short dependency chains)
             const int row = k0 + 16 + tid;
             if (row < nrow) {
                 double x[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) x[q] = W[row * ND_LD + k0 + q];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    double v = x[q];
+                for (int p = 0; p < 16; ++p) {
+                    x[p] *= dinv[k0 + p];
 #pragma unroll
-                    for (int p = 0; p < q; ++p) v -= x[p] * W[(k0 + q) * ND_LD + k0 + p];
-                    x[q] = v * dinv[k0 + q];
+                    for (int q = p + 1; q < 16; ++q) x[q] -= x[p] * Lt[p * 16 + q];
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) W[row * ND_LD + k0 + q] = x[q];
             }
         }
         __syncthreads();
-        {                                                          // trailing update on the matrix cores: C_rb,cb -= P_rb P_cb^T
-            int cnt = 0;
-            for (int cb = kb + 1; cb < nb; ++cb)
-                for (int rb = cb; rb < nrt; ++rb, ++cnt) {
-                    if ((cnt & 3) != wave) continue;
-                    nd_v4d c;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) c[g] = W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double av = -W[(16 * rb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
-                        const double bv = W[(16 * cb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)] = c[g];
-                }
+        if (N.clk) tB += wall_clock64() - tq;
+        if (kb + 1 < nb) {                                         // (C)
+            nd_update(W, lane, k0, kb + 1, kb + 2, nrt, wave, 4);
+            __syncthreads();
         }
-        __syncthreads();
     }
     stamp(3);
-    // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T
+    if (N.clk && tid == 0) { N.clk[8 * (size_t)(wg0 + blockIdx.x) + 6] = tA; N.clk[8 * (size_t)(wg0 + blockIdx.x) + 7] = tB; }
+    // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
+    // written into the parent's assembly slot at the parent's positions of its rows and columns (both triangles)
+    if (F.par >= 0) {
+        int ti[3], tj[3];
 #pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3) {
-        const int t = wave + 4 * t3;
-        if (t >= 9) break;
-        const int ti = t / 3, tj = t % 3;
-        nd_v4d c = acc[t3];
-        for (int kk = 0; kk < (s16 >> 2); ++kk) {
-            const double av = -W[(rowI0 + 16 * ti + (lane & 15)) * ND_LD + 4 * kk + (lane >> 4)];
-            const double bv = W[(rowJ0 + 16 * tj + (lane & 15)) * ND_LD + 4 * kk + (lane >> 4)];
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+        for (int t3 = 0; t3 < 3; ++t3) { const int t = min(wave + 4 * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
+        const bool third = wave == 0;                              // (tiles 0..8 over four waves: wave 0 has three, the others two)
+#pragma unroll 1
+        for (int k4 = 0; k4 < (s16 >> 4); ++k4) {
+            double av[3][4], bv[3][4];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    av[t3][kk] = -W[(rowI0 + 16 * ti[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
+                    bv[t3][kk] = W[(rowJ0 + 16 * tj[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
+                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc[1], 0, 0, 0);
+                if (third) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2][kk], bv[2][kk], acc[2], 0, 0, 0);
+            }
         }
-        double* Uf = N.U + F.U_off;
+        double* Ap = N.A + F.pA_off;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
-            const int R = ND_TB * I + r, Cc = ND_TB * J + cc;
-            if (r < rI && cc < cJ && Cc < F.b) {
-                Uf[(size_t)R * F.ldU + Cc] = c[g];
-                if (two && R < F.b) Uf[(size_t)Cc * F.ldU + R] = c[g];
+        for (int t3 = 0; t3 < 3; ++t3) {
+            if (wave + 4 * t3 >= 9) break;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * ti[t3] + (lane >> 4) + 4 * g, cc = 16 * tj[t3] + (lane & 15);
+                const int R = ND_TB * I + r, Cc = ND_TB * J + cc;
+                if (r < rI && cc < cJ && Cc < F.b) {
+                    const int PR = 3 * (int)pmi[r / 3] + r % 3, PC = 3 * (int)(two ? pmj : pmi)[cc / 3] + cc % 3;
+                    Ap[(size_t)PR * F.pldA + PC] = acc[t3][g];
+                    if (two && R < F.b) Ap[(size_t)PC * F.pldA + PR] = acc[t3][g];
+                }
             }
         }
     }
     stamp(4);
     // ---- the factor: block I's rows of L21 (and y^T) by the workgroups of column 0, L11 and 1 / diag by (0, 0)
     if (J == 0) {
+        const int tx = tid & 31, ty = tid >> 5;
         double* L = N.Lp + F.L_off;
         for (int r = ty; r < rI; r += 8)
             for (int q = tx; q < s; q += 32) L[(size_t)(s + ND_TB * I + r) * s + q] = W[(rowI0 + r) * ND_LD + q];
@@ -255,35 +383,73 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
     const NdFrontD F = N.fr[N.lvl_fronts[lf0 + blockIdx.x]];
     const int s = F.s, b = F.b, m = s + b;
     double* Ls = sm;                                               // L11, [s][ND_LD]
-    double* part = Ls + ND_S16 * ND_LD;                            // [2][128]
-    double* di = part + 256;                                       // [96]
+    double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
+    double* di = part + 512;                                       // [96]
     double* xb = di + ND_S16;                                      // [b]
     const double* L = N.Lp + F.L_off;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(clk0 + lf0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
     for (int i = tid; i < b; i += 256) xb[i] = N.xn[3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3];
-    for (int i = tid; i < s * s; i += 256) { const int p = i / s, q = i - p * s; Ls[p * ND_LD + q] = L[i]; }
+    {
+        const int tx = tid & 31, ty = tid >> 5;
+        for (int p = ty; p < s; p += 8)
+            for (int q = tx; q <= p; q += 32) Ls[p * ND_LD + q] = L[(size_t)p * s + q];
+    }
     if (tid < s) di[tid] = L[(size_t)(m + 1) * s + tid];
     __syncthreads();
     stamp(1);
     {
-        const int q = tid & 127, h = tid >> 7;
-        double acc = 0;
-        if (q < s)
-            for (int r = h; r < b; r += 2) acc += L[(size_t)(s + r) * s + q] * xb[r];
-        part[h * 128 + q] = acc;
+        // L21^T x_bnd: column q per thread, the boundary rows dealt to 256 / SQ thread groups, eight loads in flight per thread
+        const int SQ = s <= 64 ? 64 : 128, ng = 256 / SQ;
+        const int q = tid & (SQ - 1), g = tid / SQ;
+        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q < s) {
+            const double* Lq = L + (size_t)s * s + q;
+            int r = g;
+            for (; r + 7 * ng < b; r += 8 * ng) {
+                double l8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)(r + u * ng) * s];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] += l8[u] * xb[r + u * ng];
+            }
+            for (; r < b; r += ng) a8[0] += Lq[(size_t)r * s] * xb[r];
+        }
+        const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        if (q < 128) {
+            for (int gg = g; gg < 4; gg += ng) part[gg * 128 + q] = gg == g ? acc : 0.0;    // (unused group slots: zero)
+        }
     }
     __syncthreads();
     stamp(2);
     if (wave == 0) {
-        double t0 = lane < s ? L[(size_t)m * s + lane] - part[lane] - part[128 + lane] : 0.0;
-        double t1 = lane + 64 < s ? L[(size_t)m * s + lane + 64] - part[lane + 64] - part[192 + lane] : 0.0;
+        auto tsum = [&](int q) { return L[(size_t)m * s + q] - ((part[q] + part[128 + q]) + (part[256 + q] + part[384 + q])); };
+        double t0 = lane < s ? tsum(lane) : 0.0;                   // unknowns 0..63 and 64..127 of the front, two per lane
+        double t1 = lane + 64 < s ? tsum(lane + 64) : 0.0;
         double x0 = 0, x1 = 0;
-        for (int p = s - 1; p >= 0; --p) {
-            const double xp = (p < 64 ? nd_readlane(t0, p) : nd_readlane(t1, p - 64)) * di[p];
-            if (lane == (p & 63)) { if (p < 64) x0 = xp; else x1 = xp; }
-            if (lane < p) t0 -= Ls[p * ND_LD + lane] * xp;
-            if (lane + 64 < p) t1 -= Ls[p * ND_LD + lane + 64] * xp;
+        // two branch-free loops (the high unknowns first); the next row of L11 is requested before this one is used
+        {
+            double l0n = Ls[(s - 1) * ND_LD + lane], l1n = Ls[(s - 1) * ND_LD + lane + 64], dn = di[s - 1];
+            for (int p = s - 1; p >= 64; --p) {
+                const double l0 = l0n, l1 = l1n, d = dn;
+                l0n = Ls[(p - 1) * ND_LD + lane]; l1n = Ls[(p - 1) * ND_LD + lane + 64]; dn = di[p - 1];
+                const double xp = nd_readlane(t1, p - 64) * d;
+                if (lane == p - 64) x1 = xp;
+                t0 -= l0 * xp;
+                if (lane + 64 < p) t1 -= l1 * xp;
+            }
+        }
+        {
+            const int p0 = min(s, 64) - 1;
+            double l0n = Ls[p0 * ND_LD + lane], dn = di[p0];
+            for (int p = p0; p >= 0; --p) {
+                const double l0 = l0n, d = dn;
+                const int pn = max(p - 1, 0);
+                l0n = Ls[pn * ND_LD + lane]; dn = di[pn];
+                const double xp = nd_readlane(t0, p) * d;
+                if (lane == p) x0 = xp;
+                if (lane < p) t0 -= l0 * xp;
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -306,11 +472,12 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
 struct NdSolver {
     NdPlan plan;
     NdDev dev;
-    DevBuf own;                      // everything the kernels read: plan arrays, value blocks, L, U, x ...
+    DevBuf own;                      // everything the kernels read: plan arrays, entry values, assembly areas, L, x ...
     DevBuf* buf = &own;              // ... in the solver's own buffer (the tap) or in the context's (engines: reused from frame to frame)
     std::vector<size_t> lvl_shm_fac, lvl_shm_back;
     bool attr_set = false;
-    double* d_Dn = nullptr; double* d_Vp = nullptr; double* d_bn = nullptr;
+    double* d_ev = nullptr;
+    const NdEnt* d_ent = nullptr;
 };
 
 static int nd_upload(nrs_ctx* c, NdSolver& S) {
@@ -319,10 +486,9 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_fr = take(sizeof(NdFrontD) * P.fr.size()), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
-                 o_ch = take(4 * std::max<size_t>(1, P.child.size())), o_cm = take(2 * std::max<size_t>(1, P.cmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
-                 o_wg = take(4 * P.wg.size()), o_lf = take(4 * P.lvl_fronts.size()), o_Dn = take(72 * (size_t)P.n_nodes), o_Vp = take(72 * std::max(1, P.n_pairs)),
-                 o_bn = take(24 * (size_t)P.n_nodes), o_L = take(8 * P.L_doubles), o_U = take(8 * P.U_doubles), o_x = take(24 * (size_t)P.n_nodes),
-                 o_fl = take(64);
+                 o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
+                 o_wg = take(4 * P.wg.size()), o_lf = take(4 * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
+                 o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64);
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
     auto up = [&](size_t o, const void* src, size_t bytes) -> int {
@@ -332,29 +498,30 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     NRS_TRY(up(o_fr, P.fr.data(), sizeof(NdFrontD) * P.fr.size()));
     NRS_TRY(up(o_own, P.own.data(), 4 * P.own.size()));
     NRS_TRY(up(o_bnd, P.bnd.data(), 4 * P.bnd.size()));
-    NRS_TRY(up(o_ch, P.child.data(), 4 * P.child.size()));
-    NRS_TRY(up(o_cm, P.cmap.data(), 2 * P.cmap.size()));
+    NRS_TRY(up(o_pm, P.pmap.data(), 2 * P.pmap.size()));
     NRS_TRY(up(o_ent, P.ent.data(), sizeof(NdEnt) * P.ent.size()));
     NRS_TRY(up(o_wg, P.wg.data(), 4 * P.wg.size()));
     NRS_TRY(up(o_lf, P.lvl_fronts.data(), 4 * P.lvl_fronts.size()));
     NdDev& D = S.dev;
     memset(&D, 0, sizeof(D));
     D.fr = reinterpret_cast<const NdFrontD*>(base + o_fr); D.own = reinterpret_cast<const int*>(base + o_own); D.bnd = reinterpret_cast<const int*>(base + o_bnd);
-    D.child = reinterpret_cast<const int*>(base + o_ch); D.cmap = reinterpret_cast<const int16_t*>(base + o_cm); D.ent = reinterpret_cast<const NdEnt*>(base + o_ent);
+    D.pmap = reinterpret_cast<const int16_t*>(base + o_pm); D.ent = reinterpret_cast<const NdEnt*>(base + o_ent);
     D.wg = reinterpret_cast<const int*>(base + o_wg); D.lvl_fronts = reinterpret_cast<const int*>(base + o_lf);
-    S.d_Dn = reinterpret_cast<double*>(base + o_Dn); S.d_Vp = reinterpret_cast<double*>(base + o_Vp); S.d_bn = reinterpret_cast<double*>(base + o_bn);
-    D.Dn = S.d_Dn; D.Vp = S.d_Vp; D.bn = S.d_bn;
-    D.Lp = reinterpret_cast<double*>(base + o_L); D.U = reinterpret_cast<double*>(base + o_U); D.xn = reinterpret_cast<double*>(base + o_x);
+    S.d_ev = reinterpret_cast<double*>(base + o_ev); S.d_ent = D.ent;
+    D.ev = S.d_ev;
+    D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
     D.flags = reinterpret_cast<int*>(base + o_fl);
     NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, 64, c->stream));
+    // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
+    NRS_HIP(c, hipMemsetAsync(base + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
     // dynamic LDS per level: the largest panel / boundary of its fronts
     S.lvl_shm_fac.assign(P.n_levels, 0); S.lvl_shm_back.assign(P.n_levels, 0);
     for (int l = 0; l < P.n_levels; ++l)
         for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) {
             const NdFrontD& F = P.fr[P.lvl_fronts[i]];
             const int s16 = (F.s + 15) & ~15, nrow = s16 + ND_TB + (F.nR > 1 ? ND_TB : 0);
-            S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)nrow * ND_LD + ND_S16) + 2 * 64);
-            S.lvl_shm_back[l] = std::max(S.lvl_shm_back[l], sizeof(double) * ((size_t)ND_S16 * ND_LD + 256 + ND_S16 + (size_t)F.b));
+            S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)nrow * ND_LD + ND_S16 + 256) + 2 * 32);
+            S.lvl_shm_back[l] = std::max(S.lvl_shm_back[l], sizeof(double) * ((size_t)ND_S16 * ND_LD + 512 + ND_S16 + (size_t)F.b));
         }
     if (!S.attr_set) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -362,7 +529,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         S.attr_set = true;
     }
     for (int l = 0; l < P.n_levels; ++l)
-        if (S.lvl_shm_back[l] > 160 * 1024) return c->fail(NRS_ERR_INVALID, "direct solve: a front's boundary does not fit the back substitution's LDS");
+        if (S.lvl_shm_back[l] > 160 * 1024 || S.lvl_shm_fac[l] > 160 * 1024) return c->fail(NRS_ERR_INVALID, "direct solve: a front does not fit the LDS");
     return NRS_OK;
 }
 
@@ -392,11 +559,14 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
     nd_stats(S.plan, stats);
     struct Rel { nrs_ctx* c; NdSolver* s; ~Rel() { (void)hipStreamSynchronize(c->stream); c->release(s->own); } } rel{c, &S};
     NRS_TRY(nd_upload(c, S));
-    std::vector<double> V;
+    std::vector<double> V, ev(9 * S.plan.ent.size(), 0.0);
     nd_orient_pairs(S.plan, pairs, Vp, V);
-    NRS_HIP(c, hipMemcpyAsync(S.d_Dn, Dn, 72 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
-    if (n_pairs) NRS_HIP(c, hipMemcpyAsync(S.d_Vp, V.data(), 72 * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(S.d_bn, bn, 24 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
+    for (size_t e = 0; e < S.plan.ent.size(); ++e) {                // the blocks in entry order (what k_nd_values writes for an engine)
+        const uint32_t kind = S.plan.ent[e].src >> ND_KIND_SHIFT, src = S.plan.ent[e].src & ND_SRC_MASK;
+        const double* v = kind == 0 ? Dn + 9 * (size_t)src : kind == 1 ? V.data() + 9 * (size_t)src : bn + 3 * (size_t)src;
+        for (int a = 0; a < (kind == 2 ? 3 : 9); ++a) ev[9 * e + a] = v[a];
+    }
+    NRS_HIP(c, hipMemcpyAsync(S.d_ev, ev.data(), 8 * ev.size(), hipMemcpyHostToDevice, c->stream));
     NRS_TRY(nd_solve_enqueue(c, S, lam));                          // (warm-up and the result)
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     if (repeats > 0) {
@@ -423,16 +593,17 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
         const NdPlan& P = S.plan;
         const long long t00 = h[0];
         for (int l = 0; l < P.n_levels; ++l) {
-            double mean[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+            double mean[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, mA = 0, mB = 0;
             long long lo = LLONG_MAX, hi = 0;
             const int a = P.lvl_wg_ptr[l], b2 = P.lvl_wg_ptr[l + 1];
             for (int w = a; w < b2; ++w) {
                 const long long* q = &h[8 * (size_t)w];
+                mA += (double)q[6] / 100.0 / (b2 - a); mB += (double)q[7] / 100.0 / (b2 - a);
                 for (int k = 0; k < 5; ++k) { const double d = (double)(q[k + 1] - q[k]) / 100.0; mean[k] += d / (b2 - a); mx[k] = std::max(mx[k], d); }
                 lo = std::min(lo, q[0]); hi = std::max(hi, q[5]);
             }
-            fprintf(stderr, "[nrs] nd level %2d: %4d wg, span %6.1f us (from %7.1f) | mean / max us: entries %.1f/%.1f gather %.1f/%.1f factor %.1f/%.1f schur %.1f/%.1f store %.1f/%.1f\n", l, b2 - a,
-                    (double)(hi - lo) / 100.0, (double)(lo - t00) / 100.0, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2], mean[3], mx[3], mean[4], mx[4]);
+            fprintf(stderr, "[nrs] nd level %2d: %4d wg, span %6.1f us (from %7.1f) | mean / max us: entries %.1f/%.1f gather %.1f/%.1f factor %.1f/%.1f (A %.1f B %.1f) schur %.1f/%.1f store %.1f/%.1f\n", l, b2 - a,
+                    (double)(hi - lo) / 100.0, (double)(lo - t00) / 100.0, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2], mA, mB, mean[3], mx[3], mean[4], mx[4]);
         }
         for (int l = P.n_levels - 1; l >= 0; --l) {
             double mean[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
@@ -466,83 +637,86 @@ struct NdVals {
     const int* node_row;             // node -> row (>= 0) or -1 - half
     const NdPairD* pair;
     const int* src;                  // (incidence slot << 1) | (0 spring, 1 damper)
-    double* Dn; double* Vp; double* bn;
-    int n_nodes, n_pairs;
+    const NdEnt* ent;                // the plan's original entries; ev: 9 doubles each
+    double* ev;
+    int n_ent;
 };
 
+// one thread per original entry of the plan: its 3 x 3 block (or its 3 right-hand-side values) of the current linearisation
 __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < V.n_nodes) {
-        const int row = V.node_row[i];
-        double* d = V.Dn + 9 * (size_t)i;
-        double* g = V.bn + 3 * (size_t)i;
+    if (i >= V.n_ent) return;
+    const NdEnt E = V.ent[i];
+    const uint32_t kind = E.src >> ND_KIND_SHIFT, idx = E.src & ND_SRC_MASK;
+    double* o = V.ev + 9 * (size_t)i;
+    if (kind != 1) {
+        const int row = V.node_row[idx];
         if (row >= 0) {
+            if (kind == 2) { o[0] = P.bl[3 * (size_t)row]; o[1] = P.bl[3 * (size_t)row + 1]; o[2] = P.bl[3 * (size_t)row + 2]; return; }
             const double* D = P.D + 6 * (size_t)row;
-            d[0] = D[0]; d[1] = D[1]; d[2] = D[2]; d[3] = D[1]; d[4] = D[3]; d[5] = D[4]; d[6] = D[2]; d[7] = D[4]; d[8] = D[5];
-            g[0] = P.bl[3 * (size_t)row]; g[1] = P.bl[3 * (size_t)row + 1]; g[2] = P.bl[3 * (size_t)row + 2];
-        } else {
-            const int h = -1 - row;                                // H_pp is packed upper-triangular, 21 entries (pose 0)
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int r = 3 * h + min(a, b), cc = 3 * h + max(a, b);
-                    d[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)];
-                }
-            g[0] = P.bp[3 * h]; g[1] = P.bp[3 * h + 1]; g[2] = P.bp[3 * h + 2];
+            o[0] = D[0]; o[1] = D[1]; o[2] = D[2]; o[3] = D[1]; o[4] = D[3]; o[5] = D[4]; o[6] = D[2]; o[7] = D[4]; o[8] = D[5];
+            return;
         }
+        const int h = -1 - row;                                    // half of the pose block; H_pp is packed upper-triangular, 21 entries (pose 0)
+        if (kind == 2) { o[0] = P.bp[3 * h]; o[1] = P.bp[3 * h + 1]; o[2] = P.bp[3 * h + 2]; return; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = 3 * h + min(a, b), cc = 3 * h + max(a, b);
+                o[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)];
+            }
+        return;
     }
-    if (i < V.n_pairs) {
-        const NdPairD q = V.pair[i];
-        double* o = V.Vp + 9 * (size_t)i;
-        if (q.kind == 0) {
-            double v[3];
+    const NdPairD q = V.pair[idx];
+    if (q.kind == 0) {
+        double v[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v[k] = P.lin_xl[3 * (size_t)q.a + k] - P.lin_xl[3 * (size_t)q.b + k];
-                if (P.X0) v[k] = (P.lin_xl[3 * (size_t)q.a + k] + P.X0[3 * (size_t)q.a + k]) - (P.lin_xl[3 * (size_t)q.b + k] + P.X0[3 * (size_t)q.b + k]);
-            }
-            double qc = 0, sd = 0;
-            for (int k = 0; k < q.nsrc; ++k) {
-                const int sv = V.src[q.src0 + k];
-                if (sv & 1) sd += P.d_s[sv >> 1]; else qc += P.s_qc[sv >> 1];
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) o[3 * a + b] = -(qc * v[a] * v[b] + (a == b ? sd : 0.0));
-        } else if (q.kind == 1) {
-            // H_{pose half, row} = J_p^T w J_l, J_l = -J R, J_p = -J [-[X_c]x | I] (reprojection_error_with_deformation.cc:52-68), as row_factored() forms them
-            const RowRec rc = P.rowrec[q.b];
-            const Pose Tcw = P.lin_pose[0];
-            double R[9];
-            quat_to_R(Tcw.q, R);
-            double xs[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) xs[k] = P.lin_xl[3 * (size_t)q.b + k] + (P.X0 ? P.X0[3 * (size_t)q.b + k] : 0.0);
-            const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
-            const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
-            const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
-            double Jl[2][3], Jp[2][3];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
-                if (q.a == 0) { Jp[rr][0] = -j1 * pz + j2 * py; Jp[rr][1] = j0 * pz - j2 * px; Jp[rr][2] = -j0 * py + j1 * px; }
-                else { Jp[rr][0] = j0; Jp[rr][1] = j1; Jp[rr][2] = j2; }
-                Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
-                Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
-                Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) o[3 * a + b] = rc.w * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) { const int r = b, cc = 3 + a; o[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)]; }   // rows: the second half
+        for (int k = 0; k < 3; ++k) {
+            v[k] = P.lin_xl[3 * (size_t)q.a + k] - P.lin_xl[3 * (size_t)q.b + k];
+            if (P.X0) v[k] = (P.lin_xl[3 * (size_t)q.a + k] + P.X0[3 * (size_t)q.a + k]) - (P.lin_xl[3 * (size_t)q.b + k] + P.X0[3 * (size_t)q.b + k]);
         }
+        double qc = 0, sd = 0;
+        for (int k = 0; k < q.nsrc; ++k) {
+            const int sv = V.src[q.src0 + k];
+            if (sv & 1) sd += P.d_s[sv >> 1]; else qc += P.s_qc[sv >> 1];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) o[3 * a + b] = -(qc * v[a] * v[b] + (a == b ? sd : 0.0));     // (symmetric: either orientation)
+    } else if (q.kind == 1) {
+        // H_{pose half, row} = J_p^T w J_l, J_l = -J R, J_p = -J [-[X_c]x | I] (reprojection_error_with_deformation.cc:52-68), as row_factored() forms them;
+        // the pose is eliminated last, so the block's rows are the pose half's components
+        const RowRec rc = P.rowrec[q.b];
+        const Pose Tcw = P.lin_pose[0];
+        double R[9];
+        quat_to_R(Tcw.q, R);
+        double xs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xs[k] = P.lin_xl[3 * (size_t)q.b + k] + (P.X0 ? P.X0[3 * (size_t)q.b + k] : 0.0);
+        const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
+        const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
+        const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
+        double Jl[2][3], Jp[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+            if (q.a == 0) { Jp[rr][0] = -j1 * pz + j2 * py; Jp[rr][1] = j0 * pz - j2 * px; Jp[rr][2] = -j0 * py + j1 * px; }
+            else { Jp[rr][0] = j0; Jp[rr][1] = j1; Jp[rr][2] = j2; }
+            Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+            Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+            Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) o[3 * a + b] = rc.w * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { const int r = b, cc = 3 + a; o[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)]; }   // rows: the second half
     }
 }
 
@@ -637,8 +811,7 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     nd->vals.node_row = reinterpret_cast<const int*>(vb + o_nr);
     nd->vals.pair = reinterpret_cast<const NdPairD*>(vb + o_pd);
     nd->vals.src = reinterpret_cast<const int*>(vb + o_src);
-    nd->vals.Dn = nd->S.d_Dn; nd->vals.Vp = nd->S.d_Vp; nd->vals.bn = nd->S.d_bn;
-    nd->vals.n_nodes = n_nodes; nd->vals.n_pairs = n_pairs;
+    nd->vals.ent = nd->S.d_ent; nd->vals.ev = nd->S.d_ev; nd->vals.n_ent = (int)nd->S.plan.ent.size();
     nd->S.dev.node_out = reinterpret_cast<const int*>(vb + o_no);
     nd->S.dev.out_rows = d.xv; nd->S.dev.out_pose = d.xp;
     nd->S.dev.flags = d.flags;

@@ -37,6 +37,12 @@ struct NdFrontD {                   // one front, as the kernels read it
     int cmap_off;
     int nR;                         // boundary row blocks: ceil((b + 1) / ND_TB)
     int level;
+    // device data flow: a front's Schur complement is WRITTEN INTO ITS PARENT'S INDEX SPACE (slot `pslot` of the parent's
+    // assembly area, through pmap), so that a parent assembles by dense, contiguous reads -- no index maps on the reading side
+    int par, pslot;                 // parent front (-1: a root), which of its assembly slots this front writes
+    int pmap_off;                   // pmap[pmap_off + i]: position of boundary node i in the parent's node list; [.. + b / 3]: the parent's rhs slot
+    int A_off, ldA;                 // doubles: assembly area, n_ch slots of [(s + b + 1) x ldA] (zero where no child writes: zeroed once at upload)
+    int pA_off, pldA;               // this front's slot in the parent's assembly area (doubles) and the parent's ldA
 };
 // an original entry: 3 x 3 block (kind 0: diagonal block of node `src`, + lambda I; kind 1: pair `src`, rows = the later node)
 // or 1 x 3 (kind 2: right-hand side of node `src`) at node positions (r, c) of the front; c is an own column
@@ -47,13 +53,14 @@ struct NdPlan {
     int n_nodes = 0, n_pairs = 0, n_fronts = 0, n_levels = 0;
     std::vector<NdFrontD> fr;
     std::vector<int> own, bnd, child;
-    std::vector<int16_t> cmap;      // per (front, child): front node position (and the rhs slot) -> child boundary position, -1
+    std::vector<int16_t> cmap;      // per (front, child): front node position (and the rhs slot) -> child boundary position, -1 (host reference)
+    std::vector<int16_t> pmap;      // per front: boundary node (and the rhs slot) -> node position in the parent front (device)
     std::vector<NdEnt> ent;
     std::vector<int> lvl_ptr, lvl_fronts;       // fronts of every level (leaves first)
     std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I)
     std::vector<int> pair_hi, pair_lo;          // every pair oriented by elimination order (block rows = hi)
     std::vector<int> elim;                      // node -> elimination position
-    size_t L_doubles = 0, U_doubles = 0;
+    size_t L_doubles = 0, U_doubles = 0, A_doubles = 0;
     int max_s = 0, max_b = 0, max_ch = 0;
     double flops = 0, flops_crit = 0;
 };
@@ -214,21 +221,32 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         P.U_doubles += (size_t)(D.b + 1) * D.ldU;
         if (P.L_doubles > (size_t)1 << 30 || P.U_doubles > (size_t)1 << 30) return fail("factor too large");
         D.nR = (D.b + 1 + ND_TB - 1) / ND_TB;
+        D.par = parent[f]; D.pslot = 0;
+        D.pmap_off = (int)P.pmap.size();
+        P.pmap.resize(P.pmap.size() + nbn + 1, (int16_t)-1);
+        D.ldA = (D.s + D.b + 2) & ~1;
+        D.A_off = (int)P.A_doubles;
+        P.A_doubles += (size_t)F[f].ch.size() * (D.s + D.b + 1) * D.ldA;
+        if (P.A_doubles > (size_t)1 << 30) return fail("assembly areas too large");
         D.ch_off = (int)P.child.size(); D.n_ch = (int)F[f].ch.size();
         P.child.insert(P.child.end(), F[f].ch.begin(), F[f].ch.end());
         for (int i = 0; i < ns; ++i) where[F[f].own[i]] = i;
         for (int i = 0; i < nbn; ++i) where[bnd[f][i]] = ns + i;
         // child maps: front node position (then the rhs slot) -> position in the child's boundary
         D.cmap_off = (int)P.cmap.size();
-        for (int ch : F[f].ch) {
+        for (size_t k = 0; k < F[f].ch.size(); ++k) {
+            const int ch = F[f].ch[k];
             const size_t base = P.cmap.size();
             P.cmap.resize(base + mn + 1, (int16_t)-1);
+            P.fr[ch].pslot = (int)k;                               // (children are laid out before their parents)
             for (size_t i = 0; i < bnd[ch].size(); ++i) {
                 const int w = where[bnd[ch][i]];
                 if (w < 0) return fail("a child's boundary node is missing from the parent front");
                 P.cmap[base + w] = (int16_t)i;
+                P.pmap[P.fr[ch].pmap_off + i] = (int16_t)w;
             }
             P.cmap[base + mn] = (int16_t)bnd[ch].size();
+            P.pmap[P.fr[ch].pmap_off + bnd[ch].size()] = (int16_t)mn;
         }
         // original entries of the own columns
         D.ent_off = (int)P.ent.size();
@@ -249,6 +267,11 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         P.max_s = std::max(P.max_s, D.s); P.max_b = std::max(P.max_b, D.b); P.max_ch = std::max(P.max_ch, D.n_ch);
         const double s = D.s, b = D.b + 1;
         P.flops += s * s * s / 3 + s * s * b + s * b * b;
+    }
+    for (int f = 0; f < nf; ++f) {
+        NdFrontD& D = P.fr[f];
+        D.pA_off = 0; D.pldA = 0;
+        if (D.par >= 0) { const NdFrontD& Q = P.fr[D.par]; D.pldA = Q.ldA; D.pA_off = Q.A_off + D.pslot * (Q.s + Q.b + 1) * Q.ldA; }
     }
     // ---- levels and their workgroups
     P.n_levels = 1 + *std::max_element(level.begin(), level.end());
