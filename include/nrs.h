@@ -75,11 +75,12 @@ typedef struct {
                                  are the reference's as long as no rejection is mispredicted.
                                  1: every trial is solved to pcg_rtol (g2o's behaviour; use it to verify). */
     int32_t direct_solve;     /* linear solver of the single-frame problems (nrs_track_deform_solve[_rg]):
-                                 0 (default): by size -- a sparse direct solve (nested dissection, multifrontal
-                                 Cholesky on the matrix cores: what LinearSolverEigen does, linear_solver_eigen.h:92-173)
-                                 for frames whose free rows lie in [48, 2600], PCG otherwise; 1: direct whenever the
-                                 problem has the single-frame structure; 2: always PCG.  Same LM iterates either way
-                                 (both are held to the oracle).  BA windows always use PCG. */
+                                 0 (default): a sparse direct solve (nested dissection, multifrontal Cholesky on the
+                                 matrix cores: what LinearSolverEigen does, linear_solver_eigen.h:92-173) for frames of
+                                 up to 8000 free rows -- it beats the PCG at every measured size, DESIGN.md section 1 --
+                                 PCG beyond; 1: direct whenever the problem has the single-frame structure; 2: always
+                                 PCG.  Same LM iterates either way (both are held to the oracle).  BA windows always
+                                 use PCG. */
 } nrs_options;
 
 /* One Levenberg-Marquardt trial as executed by g2o

@@ -94,6 +94,82 @@ __device__ __forceinline__ void nd_diag_factor(double* W, double* Lt, double* di
     }
 }
 
+// Wave-level back substitution L^T x = t, L lower triangular (s x s in LDS, leading dimension ND_LD, reciprocal diagonal in di): lane l
+// holds the unknowns l (t0) and l + 64 (t1).  By blocks of 16 unknowns, the last block first: inside a block (one 16-lane row of
+// the wave) the 16 dependent steps are x_p = t_p d_p, t_q -= L[p][q] x_p on DPP row broadcasts (no SGPR round trip); the block's
+// x then updates the unknowns below it from whole rows of L (v_readlane + one conflict-free LDS read per lane and step).
+template <int P>
+__device__ inline void nd_bs_steps(double& T, const double (&Lr)[16], double d) {
+    if constexpr (P >= 0) {
+        double nx = -(T * d);
+        asm volatile("s_nop 1" : "+v"(nx));
+        nd_fmac_bcast<P>(T, nx, Lr[P]);
+        nd_bs_steps<P - 1>(T, Lr, d);
+    }
+}
+__device__ __forceinline__ void nd_back_solve(const double* Ls, const double* di, int s, int lane, double& t0, double& t1) {
+    const int nb = (s + 15) >> 4, ql = lane & 15, myrow = lane >> 4;
+    const double d0 = lane < s ? di[lane] : 0.0, d1 = lane + 64 < s ? di[lane + 64] : 0.0;
+#pragma unroll 1
+    for (int k = nb - 1; k >= 0; --k) {
+        const bool hi = k >= 4;
+        const int row = k & 3;
+        double Lr[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int pr = 16 * k + p;
+            Lr[p] = (myrow == row && ql < p && pr < s) ? Ls[pr * ND_LD + 16 * k + ql] : 0.0;
+        }
+        double T = hi ? t1 : t0;
+        const double d = hi ? d1 : d0;
+        nd_bs_steps<15>(T, Lr, d);
+        if (hi) t1 = T; else t0 = T;
+        const double X = T * d;                                    // the block's solution, in the lanes of its row
+        const int below = 16 * k;                                  // unknowns [0, below) still wait for this block
+        if (below > 0) {
+            double l0[16], l1[16];                                 // the block's 16 rows of L for this lane's unknowns: requested together
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int pr = min(16 * k + p, s - 1);
+                l0[p] = Ls[pr * ND_LD + lane];
+                l1[p] = hi ? Ls[pr * ND_LD + lane + 64] : 0.0;
+            }
+            double a0 = 0, a1 = 0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const double xp = 16 * k + p < s ? nd_readlane(X, 16 * row + p) : 0.0;
+                a0 += l0[p] * xp; a1 += l1[p] * xp;
+            }
+            if (lane < below) t0 -= a0;
+            if (lane + 64 < below) t1 -= a1;
+        }
+    }
+    t0 *= d0; t1 *= d1;
+}
+// the solved unknowns of a front go to the node vector and, for an engine, straight into its step vectors; the two index loads
+// (node of the unknown, its output slot) are requested at kernel start (NdOut) so that no memory round trip follows the solve
+struct NdOut { int node[2], o[2]; };
+__device__ __forceinline__ NdOut nd_out_request(const NdDev& N, const NdFrontD& F, int lane) {
+    NdOut r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h;
+        r.node[h] = N.own[F.own_off + (q < F.s ? q / 3 : 0)];
+        r.o[h] = N.node_out ? N.node_out[r.node[h]] : 0;
+    }
+    return r;
+}
+__device__ __forceinline__ void nd_store_x(const NdDev& N, const NdFrontD& F, const NdOut& r, int lane, double x0, double x1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h;
+        if (q >= F.s) continue;
+        const double xv = h ? x1 : x0;
+        N.xn[3 * (size_t)r.node[h] + q % 3] = xv;
+        if (N.node_out) { if (r.o[h] >= 0) N.out_rows[r.o[h] + q % 3] = xv; else N.out_pose[-1 - r.o[h] + q % 3] = xv; }
+    }
+}
+
 // trailing update of the panel factorisation on the matrix cores: C_rb,cb -= P_rb P_cb^T for the block columns cb in [cb_lo, cb_hi) and
 // the row blocks rb >= cb, P = the 16 columns at k0; the tiles are dealt round-robin to the waves w0 .. w0 + nw - 1 (this wave: widx)
 __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo, int cb_hi, int nrt, int widx, int nw) {
@@ -139,6 +215,8 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     int16_t* pmj = pmi + 16;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
+    NdOut xo = {};
+    if (F.par < 0 && wave == 0) xo = nd_out_request(N, F, lane);
     // ---- requests first: this thread's original entries (descriptor and values: one round trip) and the Schur complements the
     // children left in this front's assembly slots (dense, in this front's own index space: contiguous 16-byte loads)
     auto entry_row = [&](const NdEnt& E) {                         // W row of an entry's first row, -1: not in this workgroup's blocks
@@ -319,6 +397,13 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     }
     stamp(3);
     if (N.clk && tid == 0) { N.clk[8 * (size_t)(wg0 + blockIdx.x) + 6] = tA; N.clk[8 * (size_t)(wg0 + blockIdx.x) + 7] = tB; }
+    if (F.par < 0 && wave == 0) {
+        // a root has no boundary: its unknowns follow at once from the factor and the forward-substituted right-hand side in LDS
+        // (the back-substitution pass starts one level further down)
+        double t0 = lane < s ? W[rowI0 * ND_LD + lane] : 0.0, t1 = lane + 64 < s ? W[rowI0 * ND_LD + lane + 64] : 0.0;
+        nd_back_solve(W, dinv, s, lane, t0, t1);
+        nd_store_x(N, F, xo, lane, t0, t1);
+    }
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
     // written into the parent's assembly slot at the parent's positions of its rows and columns (both triangles)
     if (F.par >= 0) {
@@ -382,6 +467,10 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const NdFrontD F = N.fr[N.lvl_fronts[lf0 + blockIdx.x]];
     const int s = F.s, b = F.b, m = s + b;
+    if (F.par < 0) {                                               // a root: solved by the factorisation kernel
+        if (fin && blockIdx.x == 0 && threadIdx.x == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }
+        return;
+    }
     double* Ls = sm;                                               // L11, [s][ND_LD]
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
     double* di = part + 512;                                       // [96]
@@ -389,6 +478,12 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
     const double* L = N.Lp + F.L_off;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(clk0 + lf0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
+    NdOut xo = {};
+    double y0 = 0, y1 = 0;
+    if (wave == 0) {                                               // needed last, requested first
+        xo = nd_out_request(N, F, lane);
+        y0 = L[(size_t)m * s + min(lane, s - 1)]; y1 = L[(size_t)m * s + min(lane + 64, s - 1)];
+    }
     for (int i = tid; i < b; i += 256) xb[i] = N.xn[3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3];
     {
         const int tx = tid & 31, ty = tid >> 5;
@@ -423,46 +518,11 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
     __syncthreads();
     stamp(2);
     if (wave == 0) {
-        auto tsum = [&](int q) { return L[(size_t)m * s + q] - ((part[q] + part[128 + q]) + (part[256 + q] + part[384 + q])); };
-        double t0 = lane < s ? tsum(lane) : 0.0;                   // unknowns 0..63 and 64..127 of the front, two per lane
-        double t1 = lane + 64 < s ? tsum(lane + 64) : 0.0;
-        double x0 = 0, x1 = 0;
-        // two branch-free loops (the high unknowns first); the next row of L11 is requested before this one is used
-        {
-            double l0n = Ls[(s - 1) * ND_LD + lane], l1n = Ls[(s - 1) * ND_LD + lane + 64], dn = di[s - 1];
-            for (int p = s - 1; p >= 64; --p) {
-                const double l0 = l0n, l1 = l1n, d = dn;
-                l0n = Ls[(p - 1) * ND_LD + lane]; l1n = Ls[(p - 1) * ND_LD + lane + 64]; dn = di[p - 1];
-                const double xp = nd_readlane(t1, p - 64) * d;
-                if (lane == p - 64) x1 = xp;
-                t0 -= l0 * xp;
-                if (lane + 64 < p) t1 -= l1 * xp;
-            }
-        }
-        {
-            const int p0 = min(s, 64) - 1;
-            double l0n = Ls[p0 * ND_LD + lane], dn = di[p0];
-            for (int p = p0; p >= 0; --p) {
-                const double l0 = l0n, d = dn;
-                const int pn = max(p - 1, 0);
-                l0n = Ls[pn * ND_LD + lane]; dn = di[pn];
-                const double xp = nd_readlane(t0, p) * d;
-                if (lane == p) x0 = xp;
-                if (lane < p) t0 -= l0 * xp;
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = lane + 64 * h;
-            if (q >= s) continue;
-            const double xv = h ? x1 : x0;
-            const int node = N.own[F.own_off + q / 3];
-            N.xn[3 * (size_t)node + q % 3] = xv;
-            if (N.node_out) {
-                const int o = N.node_out[node];
-                if (o >= 0) N.out_rows[o + q % 3] = xv; else N.out_pose[-1 - o + q % 3] = xv;
-            }
-        }
+        auto psum = [&](int q) { return (part[q] + part[128 + q]) + (part[256 + q] + part[384 + q]); };
+        double t0 = lane < s ? y0 - psum(lane) : 0.0;              // unknowns 0..63 and 64..127 of the front, two per lane
+        double t1 = lane + 64 < s ? y1 - psum(lane + 64) : 0.0;
+        nd_back_solve(Ls, di, s, lane, t0, t1);
+        nd_store_x(N, F, xo, lane, t0, t1);
     }
     stamp(3);
     if (fin && blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }
@@ -540,8 +600,12 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
         hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam);
     }
-    for (int l = P.n_levels - 1; l >= 0; --l)
+    for (int l = P.n_levels - 1; l >= 0; --l) {
+        bool work = l == 0;                                        // (level 0 always: its launch reports completion; roots are solved by k_nd_level)
+        for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1] && !work; ++i) work = P.fr[P.lvl_fronts[i]].par >= 0;
+        if (!work) continue;
         hipLaunchKernelGGL(k_nd_back, dim3(P.lvl_ptr[l + 1] - P.lvl_ptr[l]), dim3(256), S.lvl_shm_back[l], c->stream, S.dev, P.lvl_ptr[l], l == 0 ? 1 : 0, (int)P.wg.size() / 3);
+    }
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
@@ -729,13 +793,14 @@ struct NdEngine {
 };
 
 static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
-    // nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments
+    // nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments.
+    // Measured (tools/nd_crossover.py, a2 per frame, direct / PCG ms): 129 points 8.7 / 34.2, 543: 18.2 / 53.5, 1013: 22.4 / 29.1,
+    // 2220: 41.9 / 46.6, 4525: 66.2 / 76.4 -- the direct solve wins at every size the fused PCG path covers
     int mode = c->opt.direct_solve;
     if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
-    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 2600;
-    if (mode == 2 || d.K != 1 || !d.use_lds || d.dform || d.sh_on) return false;
-    if (mode == 1) return n_free > 0;
-    return n_free >= 48 && n_free <= nmax;
+    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 8000;
+    if (mode == 2 || d.K != 1 || !d.use_lds || d.dform || d.sh_on || n_free <= 0) return false;
+    return mode == 1 || n_free <= nmax;
 }
 
 // builds (or rebuilds) the plan for the engine's current fixed set; leaves nd->on = false if the problem does not qualify
@@ -790,7 +855,7 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     std::string err;
     const int n_pairs = (int)pd.size();
     nd->S.buf = &c->nd_ws;
-    if (!nd_build_plan(n_nodes, pos.data(), last.data(), n_pairs, pairs.data(), nd->S.plan, &err)) {
+    if (!nd_build_plan(n_nodes, pos.data(), last.data(), n_pairs, pairs.data(), nd->S.plan, &err, ND_LEAFN, ND_SMAXN, false)) {
         if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", err.c_str());
         return NRS_OK;
     }

@@ -68,7 +68,7 @@ struct NdPlan {
 // n_nodes nodes at pos (geometry of the dissection), `last` nodes (the pose halves) are eliminated at the root whatever
 // their position; pairs: unique unordered couplings (a, b), a != b.  Returns false (err set) if the plan cannot be built.
 inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, int n_pairs, const int* pairs, NdPlan& P, std::string* err,
-                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN) {
+                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN, bool with_cmap = true) {
     auto fail = [&](const char* m) { if (err) *err = m; return false; };
     P = NdPlan();
     P.n_nodes = n_nodes; P.n_pairs = n_pairs;
@@ -96,6 +96,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     std::vector<int> side(n_nodes, 0);
     int stamp = 0;
     auto new_front = [&](std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; };
+    std::vector<std::pair<double, int>> keyed;
     auto axis_sort = [&](std::vector<int>& v, int skip_axis) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int u : v)
@@ -103,10 +104,10 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         int ax = -1;
         for (int a = 0; a < 3; ++a)
             if (a != skip_axis && (ax < 0 || hi[a] - lo[a] > hi[ax] - lo[ax])) ax = a;
-        std::sort(v.begin(), v.end(), [&](int x, int y) {
-            const double px = pos[3 * (size_t)x + ax], py = pos[3 * (size_t)y + ax];
-            return px != py ? px < py : x < y;
-        });
+        keyed.resize(v.size());                                    // (coordinate, id) pairs: the sort touches no indirect memory
+        for (size_t i = 0; i < v.size(); ++i) keyed[i] = {pos[3 * (size_t)v[i] + ax], v[i]};
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
         return ax;
     };
     // chain of fronts over one separator (or leaf) that is longer than a front may own
@@ -175,6 +176,8 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         if (k != n_nodes) return fail("node not owned");
     }
     const std::vector<int>& elim = P.elim;
+    std::vector<int> node_at(n_nodes);
+    for (int u = 0; u < n_nodes; ++u) node_at[elim[u]] = u;
     P.pair_hi.resize(n_pairs); P.pair_lo.resize(n_pairs);
     for (int q = 0; q < n_pairs; ++q) {
         const int a = pairs[2 * q], b = pairs[2 * q + 1];
@@ -197,8 +200,10 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
                 else if (elim[u] < pmin) return fail("a child's boundary node is not in its parent");
             }
         }
-        std::sort(c.begin(), c.end(), [&](int x, int y) { return elim[x] < elim[y]; });
+        for (int& u : c) u = elim[u];                              // (sorted as elimination positions: plain integer keys)
+        std::sort(c.begin(), c.end());
         c.erase(std::unique(c.begin(), c.end()), c.end());
+        for (int& u : c) u = node_at[u];
         if (c.size() * 3 + 1 > 30000 || F[f].own.size() > (size_t)smax_n) return fail("front too large");
     }
     for (int f = 0; f < nf; ++f)
@@ -206,6 +211,8 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     // ---- flat arrays
     P.n_fronts = nf;
     P.fr.resize(nf);
+    P.ent.reserve(2 * (size_t)n_nodes + (size_t)n_pairs);
+    P.own.reserve(n_nodes);
     std::vector<int> where(n_nodes, -1);                           // node -> position in the front being laid out
     for (int f = 0; f < nf; ++f) {
         NdFrontD& D = P.fr[f];
@@ -237,15 +244,15 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         for (size_t k = 0; k < F[f].ch.size(); ++k) {
             const int ch = F[f].ch[k];
             const size_t base = P.cmap.size();
-            P.cmap.resize(base + mn + 1, (int16_t)-1);
+            if (with_cmap) P.cmap.resize(base + mn + 1, (int16_t)-1);   // (the host reference's gather maps: the device writes through pmap)
             P.fr[ch].pslot = (int)k;                               // (children are laid out before their parents)
             for (size_t i = 0; i < bnd[ch].size(); ++i) {
                 const int w = where[bnd[ch][i]];
                 if (w < 0) return fail("a child's boundary node is missing from the parent front");
-                P.cmap[base + w] = (int16_t)i;
+                if (with_cmap) P.cmap[base + w] = (int16_t)i;
                 P.pmap[P.fr[ch].pmap_off + i] = (int16_t)w;
             }
-            P.cmap[base + mn] = (int16_t)bnd[ch].size();
+            if (with_cmap) P.cmap[base + mn] = (int16_t)bnd[ch].size();
             P.pmap[P.fr[ch].pmap_off + bnd[ch].size()] = (int16_t)mn;
         }
         // original entries of the own columns

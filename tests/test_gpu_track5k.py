@@ -65,3 +65,9 @@ def test_track5k_default_mode(ctx, name, model, seed):
 def test_track5k_exact_trials(ctx_exact, name, model, seed):
     tr = _run(ctx_exact, name, model, seed)
     assert not any(t["early"] for t in tr.trials)
+
+
+def test_track5k_direct_solver(ctx_direct):
+    """the same frame on the nested-dissection Cholesky (nrs_options.direct_solve = 1; by default frames of this size run the PCG)"""
+    tr = _run(ctx_direct, *CASES[0])
+    assert all(t["inner"] == 1 for t in tr.trials)
