@@ -130,8 +130,12 @@ def cpu_baseline(p2, e2, ctx=None, ctx_exact=None):
                                             st["chol_flops"] * st["n_factor"] / max(1e-9, st["t_factor"]) / 1e9, dt))
     if ctx is not None:
         out["sparse_cholesky"]["gpu_same_sample"] = gpu_iters_per_s(ctx, p1, e1)
-    out["tracked_fps"] = cpu_tracked_fps(ctx is not None)
-    out["tracked_fps"]["compiled"] = cpu_tracked_fps_compiled(lib, ctx is not None)
+    comp = cpu_tracked_fps_compiled(lib, ctx is not None)
+    big = comp[-1]                                               # the frame at the bench's point count (5000 map points, ~4.5k tracked)
+    out["tracked_fps"] = dict(value=big["cpu_frames_per_s"], unit="frames/s", cores=1, kind="port",
+                              sample="1 tracked frame of %d tracked points (LK Track + a1 + a2), C++ restatement with a full sparse Cholesky per LM trial "
+                                     "(oracle/nrs_cpu_track.hpp, oracle/nrs_cpu_lk.hpp), %.0f ms" % (big["tracked"], big["cpu_ms"]),
+                              gpu_same_sample=big.get("gpu_frames_per_s"), compiled=comp, oracle_numpy=cpu_tracked_fps(ctx is not None))
     return out
 
 
@@ -180,6 +184,18 @@ def cpu_tracked_fps_compiled(lib, with_gpu):
                 ts.append(time.perf_counter() - t0)
             c.close()
             row.update(gpu_ms=1e3 * min(ts), gpu_frames_per_s=1.0 / min(ts), gpu_over_cpu=dt / min(ts))
+            c = nrs.Context(direct_solve=2)                         # the same three calls with the PCG as a2's linear solver
+            c.klt_configure()
+            c.klt_set_reference(sq["im0"], sq["pts"])
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                c.klt_track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
+                gq, gt, _ = c.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
+                c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], gq, gt, tp["scale"])
+                ts.append(time.perf_counter() - t0)
+            c.close()
+            row.update(gpu_ms_pcg_solver=1e3 * min(ts))
         out.append(row)
     return out
 
@@ -228,7 +244,7 @@ def reduce_over_ranks(dist, dt, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def tracked_fps(n_points=5000, frames=7, dense_graph=False):
+def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
     """Secondary figure of BASELINE.json's metric: tracked frames/s, end to end through the frame-loop
     harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode and
     feature extraction) on a consistent synthetic 640x480 sequence with n_points map points: LK data
@@ -240,7 +256,7 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False):
     sq = S.make_frame_sequence(n_points, frames + 1, 21)
     opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
     # dense_graph: the map's graph at the reference's density (all pairs, resident on the device) instead of the generator's kNN-16
-    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts, dense_graph=dense_graph, cap_per_point=128)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts, dense_graph=dense_graph, cap_per_point=128, direct_solve=direct_solve)
     stage = {}
 
     def wrap(name):
@@ -268,13 +284,15 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False):
             inner += sum(t["inner"] for t in gb.last_trace.trials)
     gb.close()
     nf = len(ts)
-    # the pose-and-deformation solve is one single-launch PCG iteration after another: bounded by launch latency, not by
-    # traffic.  Its "roofline" is the cost of such a launch with the arithmetic removed (launch + two dependent fetch levels of
-    # what the previous launch wrote + one block reduction: 6.9 us) against the all-in time per iteration.
-    us_iter = 1e6 * stage.get("track_deform", 0) / max(1, inner)
-    latency = dict(kernel="k_pcg_fused (one launch per PCG iteration)", launches_per_frame=inner / nf, us_per_iteration_all_in=us_iter,
-                   floor_us=6.9, frac=6.9 / us_iter if us_iter > 0 else None)
-    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf, pcg_latency=latency,
+    # the pose-and-deformation solve: per LM trial one linear solve -- the nested-dissection Cholesky (default, `inner` = 1 per trial) or,
+    # with direct_solve=2, a run of single-launch PCG iterations bounded by launch latency (6.9 us floor per iteration)
+    direct = inner <= trials
+    us_unit = 1e6 * stage.get("track_deform", 0) / max(1, trials if direct else inner)
+    latency = dict(linear_solver="nested-dissection multifrontal Cholesky (k_nd_level / k_nd_back, fronts on v_mfma_f64_16x16x4)" if direct
+                   else "block-Jacobi / two-level PCG, one launch per iteration (k_pcg_fused)",
+                   solves_per_frame=trials / nf, inner_iterations_per_frame=inner / nf,
+                   us_all_in_per_lm_trial=us_unit if direct else None, us_all_in_per_pcg_iteration=None if direct else us_unit)
+    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf, a2_solver=latency,
                 tracked_last_frame=int(loop.log[-1]["n_tracked"]),
                 ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,
                 ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * stage.get("reuse_track", 0) / nf,
@@ -480,7 +498,12 @@ def hbm_regime_leg(device, workload="C4"):
     lin_b, spmv_b = algorithmic_bytes(n_lm, n_sp, n_dm, unique_blocks(n_lm, e["sp_ij"], e["dm_idx"]))
     spmv_us = 1e3 * prof["spmv_ms"] / max(1, prof["spmv_launches"])
     lin_us = 1e3 * prof["linearize_ms"] / max(1, prof["linearize_launches"])
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC passes (tools/profile_r0x.sh), not this run: lower bounds, profiles/README.md
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(workload, {})
     return {"workload": "%s: %d landmarks, %d springs, %d dampers, %.1f GB resident" % (workload, n_lm, n_sp, n_dm, st["device_bytes"] / 1e9),
+            "traffic": {"k_spmv_f": traffic.get("k_spmv"), "linearize": traffic.get("linearize"), "source": "profiles/traffic.json (rocprofv3 --pmc, bytes per full launch)"},
             "operator": {"kernel": "k_spmv_f", "avg_us": spmv_us, "algorithmic_bytes": spmv_b, "achieved": spmv_b / (spmv_us * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_b / (spmv_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches": prof["spmv_launches"]},
             "linearize": {"kernel": "k_lin_plain", "avg_us": lin_us, "algorithmic_bytes": lin_b, "achieved": lin_b / (lin_us * 1e-6) / 1e9,
@@ -640,6 +663,17 @@ def main():
                           "landmarks": n_lm, "springs": n_sp, "dampers": n_dm, "lm_trials_per_step": r["trials"] / args.steps,
                           "pcg_iters_per_step": r["inner"] / args.steps,
                           "parallelism": "independent BA window per GPU" if world > 1 else "1 GPU"}}
+    if rank == 0:
+        # which library ran: the in-tree build (gitignored, travels with the snapshot) and how __graft_entry__.build() last produced it
+        import hashlib
+        bm = None
+        try:
+            bm = json.load(open(os.path.join(ROOT, "nr-slam_amd", "build", "build_mode.json")))
+        except Exception:
+            pass
+        with open(nrs.LIB_PATH, "rb") as fh:
+            out["build"] = {"library": os.path.relpath(nrs.LIB_PATH, ROOT), "sha256_16": hashlib.sha256(fh.read()).hexdigest()[:16],
+                            "last_build": bm or "no record: the library travelled prebuilt with the snapshot"}
     if not multi and rank == 0:
         # ---- the same steps with every LM trial solved to pcg_rtol (g2o's behaviour; `value` rejects hopeless trials early)
         xctx = nrs.Context(device=local_rank, exact_trials=1)
@@ -684,8 +718,13 @@ def main():
         # resident on the device; the generator's kNN-16 flat graph (what round 1 measured) stays next to it
         out["tracked_fps"] = tracked_fps(dense_graph=True)
         out["tracked_fps"]["graph"] = "all pairs (4999 connections per point), device resident"
+        keys = ("value", "unit", "points", "frames", "ms_pose_and_deformation", "lm_trials_per_frame", "pcg_iters_per_frame", "tracked_last_frame")
+        tf = tracked_fps(dense_graph=True, direct_solve=2)           # the same frames with the PCG as linear solver (round 3's path)
+        out["tracked_fps_pcg_solver"] = {k: tf[k] for k in keys}
+        tf = tracked_fps(n_points=1150, dense_graph=True)            # the reference's own scale (C1: ~1k tracked points)
+        out["tracked_fps_1k_points"] = {k: tf[k] for k in keys}
         tf = tracked_fps(dense_graph=False)
-        out["tracked_fps_flat_knn16_graph"] = {k: tf[k] for k in ("value", "unit", "points", "frames", "ms_pose_and_deformation", "pcg_iters_per_frame", "tracked_last_frame")}
+        out["tracked_fps_flat_knn16_graph"] = {k: tf[k] for k in keys}
         out["shi_extract"] = shi_extract_bench()
         out["graph_dense"] = rgraph_bench()
         out["triangulation"] = triangulation_bench()

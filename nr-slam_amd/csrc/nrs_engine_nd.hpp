@@ -794,11 +794,13 @@ struct NdEngine {
 
 static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
     // nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments.
-    // Measured (tools/nd_crossover.py, a2 per frame, direct / PCG ms): 129 points 8.7 / 34.2, 543: 18.2 / 53.5, 1013: 22.4 / 29.1,
-    // 2220: 41.9 / 46.6, 4525: 66.2 / 76.4 -- the direct solve wins at every size the fused PCG path covers
+    // Measured (tools/nd_crossover.py, a2 per frame, direct / PCG ms; flat kNN-16 graph): 129 points 8.7 / 34.2, 543: 18.2 / 53.5,
+    // 1013: 22.4 / 29.1, 2220: 41.9 / 46.6, 3165: 51.1 / 61.3, 4525: 66.2 / 76.4; on the all-pairs graph (22 neighbours per point
+    // instead of 13: heavier fronts) 543: 21.2 / 52.9, 1013: 31.6 / 62.6, 2220: 38.7 / 62.0, 3165: 48.0 / 68.2, 4525: 91.1 / 87.3.
+    // The default window ends where the two meet on the denser graph.
     int mode = c->opt.direct_solve;
     if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
-    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 8000;
+    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 3500;
     if (mode == 2 || d.K != 1 || !d.use_lds || d.dform || d.sh_on || n_free <= 0) return false;
     return mode == 1 || n_free <= nmax;
 }

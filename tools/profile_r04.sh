@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-4 profiling recipe (run on the GPU box through gpurun from the repo root):
+#   1) rocprofv3 --kernel-trace --stats of the default bench command                 -> per-kernel durations (C2 + the tracked-fps legs)
+#   2) the direct solver (N1): kernel trace of a2 on 543 / 1013-point frames and of the solver tap, and -- in their own passes, no
+#      other trace domain -- the matrix-core counters of its kernels (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES)
+#   3) optional (PROFILE_C4=1): FETCH_SIZE / WRITE_SIZE / SQ passes on C2 and C4 for the lineariser and the operator
+# Raw output goes to gpurun_out/r04 (scratch); tools/summarize_profile_r04.py copies the summaries into profiles/.
+set -u
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/r04
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hbm-regime > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/nd_a2 -o a2 -- python $R/tools/small_frame_probe.py 600 1150 > $OUT/nd_a2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/nd_tap -o tap -- python $R/tools/nd_kernel_probe.py 543 1013 2220 > $OUT/nd_tap.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -f csv -d $OUT/pmc_mfma_nd -o p -- python $R/tools/nd_kernel_probe.py 1013 > $OUT/pmc_mfma_nd.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $OUT/pmc_sq_nd -o p -- python $R/tools/nd_kernel_probe.py 1013 > $OUT/pmc_sq_nd.log 2>&1
+if [ "${PROFILE_C4:-0}" = "1" ]; then
+for W in C2 C4; do
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch_$W -o p -- python $R/tools/c4_probe.py $W 2 > $OUT/pmc_fetch_$W.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write_$W -o p -- python $R/tools/c4_probe.py $W 2 > $OUT/pmc_write_$W.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $OUT/pmc_sq_$W -o p -- python $R/tools/c4_probe.py $W 2 > $OUT/pmc_sq_$W.log 2>&1
+done
+fi
+cd $R
+NRS_TIMING=1 timeout 200 python tools/small_frame_probe.py 600 1150 2500 5000 2>&1 | grep -E "^n |direct solve:" > $OUT/small_frames.txt
+timeout 300 python tools/nd_crossover.py > $OUT/nd_crossover.txt 2>&1
+NRS_ND_DBG=1 timeout 100 python tools/nd_kernel_probe.py 1013 > $OUT/nd_phases_1013.txt 2>&1
+timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 200 python tools/lin_probe.py C2 C3 C4 2>&1 | grep workload > $OUT/lin_probe.jsonl
+find $OUT -name "*.csv" -size +20M -delete
+ls -R $OUT | head -60
