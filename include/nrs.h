@@ -183,9 +183,12 @@ int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag
 
 /* Parity tap of the problem construction (edge lists -> row layout, sliced-ELL incidence streams, halo lists, chi2 edge lists;
  * g2o_optimization.cc:927-1137 ends where this starts): FNV-1a checksums of every packed array of the resident problem,
- * out[0..24).  A plain BA window of >= 32768 padded rows is packed on the device (csrc/nrs_engine_devpack.hpp), everything else
- * -- and everything under NRS_HOST_PACK=1 -- on the host; the two constructions produce the same bits (out[21] says which one
- * ran: 1 = device; it is not part of the comparison). */
+ * out[0..24).  A plain BA window (>= 2 keyframes, >= 2048 padded rows, nothing fixed, no masks / offsets / unary or incomplete
+ * dampers, no communicator: both the two-kernel path, T = 2, and the fused one, T = 8) is packed on the device
+ * (csrc/nrs_engine_devpack.hpp), everything else on the host -- as is everything under NRS_HOST_PACK=1 or any of the A/B switches
+ * the host path honours (NRS_SELL_T, NRS_NO_FUSED, NRS_FUSED_MAX_ROWS, NRS_NO_PLAIN, NRS_NO_LDS, NRS_DFORM, NRS_NO_EDGE_CHI,
+ * NRS_TILE_CUT_PCT, NRS_HIER, NRS_NO_ECD); the two constructions produce the same bits (out[21] says which one ran: 1 = device;
+ * it is not part of the comparison). */
 int nrs_dba_pack_hash(nrs_ctx* ctx, uint64_t* out /* 24 */);
 
 /* Parity tap for a18 (the linear solve): solves (H + lambda I) x = b for an explicitly given block system with

@@ -101,23 +101,34 @@ struct LocalGroup {
     int waiting = 0;
     uint64_t generation = 0;
     const double* slot[LOCAL_MAX] = {};
-    bool aborted = false;            // a rank failed between two barriers: every waiter is released with an error
+    // A rank that fails between two barriers poisons the group: every waiter is released with an error and every later barrier
+    // fails at once.  The poison is STICKY: it is lifted only when all `world` ranks have re-joined (nrs_comm_init_local) after
+    // it -- a rank that re-joins early and starts a collective while a peer is still inside the failed window gets NRS_ERR_COMM
+    // instead of pairing its barriers with that peer's (different buffer lengths: k_local_sum would read past the shorter one).
+    bool aborted = false;
+    bool rejoined[LOCAL_MAX] = {};   // ranks that have re-joined since the abort
     bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
         const uint64_t g = generation;
-        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g || aborted; });
-        return !aborted;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != g || aborted; });
+        if (generation == g) { --waiting; return false; }          // released by an abort: this waiter leaves the barrier it never completed
+        return true;
     }
     void abort() {
         std::lock_guard<std::mutex> lk(mu);
+        if (!aborted) for (bool& r : rejoined) r = false;
         aborted = true;
         cv.notify_all();
     }
-    void clear_abort() {             // a rank (re)joins: a failure of an earlier window no longer poisons the group
+    void join(int rank) {            // nrs_comm_init_local: a rank (re)joins
         std::lock_guard<std::mutex> lk(mu);
-        if (waiting == 0) aborted = false;
+        if (!aborted) return;
+        rejoined[rank] = true;
+        bool all = waiting == 0;
+        for (int r = 0; r < world; ++r) all = all && rejoined[r];
+        if (all) { aborted = false; ++generation; }
     }
 };
 
@@ -272,7 +283,7 @@ extern "C" int nrs_comm_init_local(nrs_ctx* c, void* group, int32_t rank) {
     LocalComm* lc = new (std::nothrow) LocalComm();
     if (!lc) return c->fail(NRS_ERR_ALLOC, "out of host memory");
     lc->g = g; lc->rank = rank; lc->world = g->world;
-    g->clear_abort();
+    g->join(rank);
     c->comm = lc;
     return comm_streams(c);
 }

@@ -100,6 +100,7 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                     break;
                 case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
                 default:
+#ifdef NRS_DEBUG_PROBES
                     if (d.cam.model == 0 && tp && getenv("NRS_LIN_EXP")) {     // timing experiments (wrong results): a piece of the pass removed
                         switch (atoi(getenv("NRS_LIN_EXP"))) {
                             case 1: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 1>), g, b, shm, c->stream, d, xl, cls); break;
@@ -109,6 +110,7 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                         }
                         break;
                     }
+#endif
                     if (d.h4) {                                     // (implies tp)
                         if (d.cam.model == 0) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
                         else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
@@ -170,6 +172,7 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
 static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double tol2) {
     if (!d0.use_lds) { launch_spmv2<false>(c, d0, lam, 0, it); return; }
     Dev d = d0;
+#ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one operator launch: make PROBES=1, then NRS_SPMV_DBG=1)
     long long* dbg = nullptr;
     static bool dbg_done = false;
     if (d.h4 && it == 3 && !dbg_done && getenv("NRS_SPMV_DBG")) {  // phase clocks of one operator launch (100 MHz wall clock)
@@ -199,6 +202,7 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
                            n, acc[0] / n / 100.0, acc[1] / n / 100.0, acc[2] / n / 100.0, acc[3] / n / 100.0, acc[4] / n / 100.0, (double)(t_max - t_min) / 100.0);
         }
     } dump{c, dbg, dbg ? (size_t)d.n_rows / (64 / d.T) : 0};
+#endif
     for (int cls = 0; cls < 2; ++cls) {
         const int n = d.sh_nt[cls] + d.sh_ntb[cls];
         if (n == 0) continue;
@@ -235,6 +239,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
     if (LIN) { e->d.lin_pose = e->d.pose[which]; e->d.lin_xl = e->d.xl[which]; }   // the PCG kernels re-form factors from it
     const Dev& d = e->d;
     const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
+#ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one lineariser launch: make PROBES=1, then NRS_LIN_DBG=1)
     if (LIN && d.plain && getenv("NRS_LIN_DBG")) {
         // phase clocks of one lineariser launch (100 MHz wall clock): where a wave's time goes
         static bool done = false;
@@ -265,6 +270,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
                     n, acc[0] / n / 100.0, acc[1] / n / 100.0, acc[2] / n / 100.0, acc[3] / n / 100.0, acc[4] / n / 100.0, (double)(t_max - t_min) / 100.0);
         }
     }
+#endif
     if (LIN) {
         // LDS path: one fused pass (reprojection + springs + dampers per row); gather path: two
         const int reps = c->opt.profile ? PROFILE_REPS : 1;
@@ -359,6 +365,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
     const int stop = std::min(it + (c->opt.profile ? 1 : count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
     for (; it < stop; ++it) {
         const int pub = it + 1 == stop ? pub_seq : 0;
+#ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one fused PCG launch: make PROBES=1, then NRS_PCG_DBG=1)
         if (d.fused && it == 20 && d.coarse && getenv("NRS_PCG_DBG")) {   // phase clocks of one fused launch (100 MHz wall clock), once
             static bool dbg_done = false;
             if (!dbg_done) {
@@ -395,6 +402,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
                 }
             }
         }
+#endif
         if (d.fused) {
             // frames of <= 32 tiles: every tile on a workgroup of ONE XCD (workgroups are dealt to the XCDs round-robin; the other seven
             // of every eight return at once) -- the vectors then stay in one L2 instead of being written through eight: 19.0 -> 18.0 us

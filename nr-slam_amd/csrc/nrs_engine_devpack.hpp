@@ -14,8 +14,9 @@
 //   chi2 edge lists edges ordered by the row that counts them (stable): radix sort of (row, edge) keys
 // The host keeps what it needs to drive the solve: the vertex -> row map (download), the tile classes (from the halo sizes).
 // Conditions (otherwise engine_create takes the host path): a plain BA window (nothing fixed, no masks, offsets or unary
-// dampers, every damper with four vertices, springs without kernel), the two-kernel path (>= 32768 padded rows, T = 2), no
-// communicator, halos that fit the LDS budget, at most 2048 halo rows per tile.  NRS_HOST_PACK=1 forces the host path.
+// dampers, every damper with four vertices, springs without kernel) of >= 2 keyframes and >= 2048 padded rows -- the two-kernel
+// path (>= 32768 rows, T = 2) and the fused one (T = 8) alike -- no communicator, halos that fit the LDS budget, at most 2048 halo
+// rows per tile.  NRS_HOST_PACK=1 forces the host path, and so does every A/B switch that path honours (devpack_eligible).
 #pragma once
 #include <rocprim/rocprim.hpp>
 
@@ -393,7 +394,7 @@ __global__ void k_win_edges(WinDev W, int n_lm, int* cnt_s, int* cnt_d, const in
 }
 __global__ void k_win_cur(int n_lm, const int* __restrict__ lm_k, const int* __restrict__ kf_pt, int n_points, int* cur) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n_lm) cur[(size_t)lm_k[l] * n_points + kf_pt[l]] = l;
+    if (l < n_lm) atomicMax(&cur[(size_t)lm_k[l] * n_points + kf_pt[l]], l);   // (a map point listed twice in a keyframe: the last entry wins, as on the host)
 }
 
 // Builds the edge lists of a window on the device; the arrays live in the context's third scratch buffer until the next call.
@@ -497,6 +498,9 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         t_prev = now;
     };
     for (int v = 0; v < s.M; ++v) if (s.rflag[v] != (RF_OBS | RF_REPROJ_ACTIVE)) return NRS_OK;
+    if (!s.edges_on_device)                                        // an incomplete damper (-1: absent vertex, valid for engine_create): the device
+        for (int64_t q = 0; q < 4 * (int64_t)s.n_dm; ++q)          // kernels index by these values, so such a window takes the host path
+            if (s.dm_idx[q] < 0) return NRS_OK;
     const int K = s.K, M = s.M, n_sp = s.n_sp, n_dm = s.n_dm;
     std::vector<int> pose_ptr(K + 1, 0), pose_grp_ptr(K + 1, 0), grp_pose;
     for (int i = 0; i < M; ++i) pose_ptr[s.lm_pose[i] + 1]++;

@@ -1044,11 +1044,12 @@ void engine_destroy(nrs_ctx* c, Engine* e) {
 
 int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8_t* pose_fixed,
                         const uint8_t* sp_active, const uint8_t* dm_active) {
+    // (checked before anything is touched: a rejected call leaves the engine as it was)
+    if (e->d.plain) return c->fail(NRS_ERR_STATE, "masks on a plain BA window: not supported (its partial slots are per slice)");
     if (rflag)
         for (int v = 0; v < e->d.M; ++v) e->h_rflag[e->vrow[v]] = rflag[v];
     if (pose_fixed) e->h_pose_fixed.assign(pose_fixed, pose_fixed + e->d.K);
     e->d.ec_on = 0;                                                // masks / fixed vertices: chi2 comes from the incidence records
-    if (e->d.plain) return c->fail(NRS_ERR_STATE, "masks on a plain BA window: not supported (its partial slots are per slice)");
     NRS_TRY(push_masks(c, e, sp_active, dm_active));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     if (e->nd) {                                                   // the direct solver's plan is built on the free rows: a changed fixed set needs a new one
