@@ -460,6 +460,22 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     out = dict(points=n, nodes=m, tracked_points=int((tp["status"] == 0).sum()), ms_select_nodes=1e3 * t_sel,
                ms_pose_and_deformation=float(np.median(ms[1:])), skinned_points=len(r["lost"]),
                lm_trials=len(tr.trials), pcg_iters=int(sum(x["inner"] for x in tr.trials)))
+    # ---- the same frame in the EMBEDDED-DEFORMATION mode (N2 as SURVEY.md 8d words it; include/nrs.h nrs_track_deform_solve_embedded): the m
+    # nodes carry the free variables, the observations of all other tracked points constrain them through <= 11 nodes each
+    node = np.zeros(n, np.uint8)
+    node[nodes] = 1
+    ms2, r2, tr2 = [], None, None
+    for rep in range(4):
+        g.add_edges(tp["X_prev"], fm, fm)
+        tr2 = nrs.Trace(1024)
+        t0 = time.perf_counter()
+        r2 = ctx.track_deform_solve_embedded(cam, g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr2, 512)
+        ms2.append(1e3 * (time.perf_counter() - t0))
+    out["embedded"] = dict(points=n, nodes=m, tracked_points=int((tp["status"] == 0).sum()), ms_pose_and_deformation=float(np.median(ms2[1:])),
+                           frames_per_s_of_this_call=1e3 / float(np.median(ms2[1:])), lm_trials=len(tr2.trials),
+                           linear_solver="nested-dissection Cholesky over %d node blocks + pose (k_nd_level / k_nd_back)" % m,
+                           note="every tracked point's reprojection edge is in the problem (skinned to <= 11 nodes, normalised weights); "
+                                "unknowns 6 + 3 x %d; held to oracle/embedded_oracle.py (tests/test_gpu_embedded.py)" % m)
     g.close()
     # the BA window over the nodes
     p = S.make_dba_problem(m, n_kf, 11, 0)

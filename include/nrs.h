@@ -201,7 +201,7 @@ int nrs_dba_pack_hash(nrs_ctx* ctx, uint64_t* out /* 24 */);
 int nrs_debug_pcg_solve(nrs_ctx* ctx, int32_t n_rows, const double* Hpp21, const double* bp /*6*/, const double* D6,
                         const double* Hpl18, const double* bl /*3 n_rows*/, double lambda, double* x, int32_t* iters);
 
-/* ---- N1 parity taps: the direct (nested-dissection, multifrontal Cholesky) solve of a2's system on an explicitly given
+/* ---- N1 parity tap: the direct (nested-dissection, multifrontal Cholesky) solve of a2's system on an explicitly given
  * block system -- what replaces LinearSolverEigen::solve (third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-173:
  * ordering + symbolic step once, numeric sparse Cholesky per LM trial) when nrs_track_deform_solve[_rg] runs a frame on the
  * direct path.  n_nodes unknown blocks of 3 scalars at positions pos (n x 3, used for the
@@ -372,6 +372,23 @@ int nrs_track_deform_solve_rg(nrs_ctx* ctx, const nrs_camera* cam, nrs_rgraph* g
                               float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
                               float* f_pos, double pose_qt[7], float scale, float* deform_median, int32_t* n_lost,
                               int32_t* lost, nrs_lm_trace* trace);
+
+/* ---- N2: embedded deformation -- "points x graph nodes" as SURVEY.md 8(d) words it ------------------------------------
+ * nrs_track_deform_solve_rg with a node set: f_node[i] != 0 marks the frame landmarks (among the TRACKED_WITH_3D ones) that carry
+ * a free deformation; the regularisers of g2o_optimization.cc:255-335 are built between nodes only.  Every other TRACKED_WITH_3D
+ * landmark is SKINNED: its deformation is sum_k omega_k delta_{n_k} over the <= 11 nodes its own GetEdges walk accepts (the walk of
+ * OPT:255-279: stop after more than 10 accepted or at the first BAD connection; omega = connection weight / their sum), and its
+ * reprojection edge (reprojection_error_with_deformation.cc:37-68: same residual, information, Huber kernel) constrains those nodes
+ * and the pose with the Jacobian omega_k x the reference's block.  Rounds, inlier levels, IQR rejection, write-back and graph
+ * update treat all optimised landmarks alike; the lost-point stage (OPT:476-553) follows nodes and skinned landmarks (the latter as
+ * constants).  The reference has no such estimator -- its only skinning is that second stage -- so this mode is this build's,
+ * stated in oracle/embedded_oracle.py; with every landmark a node it IS nrs_track_deform_solve_rg, bit for bit (tests).  Runs on
+ * the direct solver (nrs_options.direct_solve != 2). */
+int nrs_track_deform_solve_embedded(nrs_ctx* ctx, const nrs_camera* cam, nrs_rgraph* graph, int32_t n_points, int32_t cap_per_point,
+                                    float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                                    float* f_pos, const uint8_t* f_node, double pose_qt[7], float scale, float* deform_median,
+                                    int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
+
 
 /* ---- a21-a23: LucasKanadeTracker (modules/matching/lucas_kanade_tracker.{h,cc}) ----------------
  * The context holds what the reference's tracker object holds: the reference points and, per point

@@ -56,6 +56,7 @@ struct nrs_ctx {
     nrs::DevBuf tap;                 // residual taps (edge lists by vertex + outputs) of the engine `tap_serial`: built on first use
     unsigned long long tap_serial = 0, engine_serial = 0;
     nrs::DevBuf pack_ws, pack_ws2, pack_ws3, pack_ws4;   // device-side problem construction (nrs_engine_devpack.hpp): raw inputs + intermediates
+    nrs::DevBuf nd_skin;             // embedded mode (nrs_engine_skin.hpp): the skinned observations of the tracking engine
     nrs::DevBuf nd_ws, nd_vals;      // direct solver of the tracking engines (nrs_engine_nd.hpp): plan + factor storage, value descriptors; reused across frames
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
     bool err_local = true;           // last set-up failure may be specific to this rank (allocation, HIP, rank-dependent checks)

@@ -54,6 +54,7 @@
 #include "nrs_engine_linearize.hpp"
 #include "nrs_engine_coarse.hpp"
 #include "nrs_engine_pcg.hpp"
+#include "nrs_engine_skin.hpp"
 #include "nrs_engine_nd.hpp"
 #include "nrs_engine_setup.hpp"
 #include "nrs_engine_devpack.hpp"
@@ -298,6 +299,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
         }
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
+    if (d.sk_n > 0) hipLaunchKernelGGL((k_skin<LIN>), dim3(d.sk_nblk), b, 0, c->stream, d, d.pose[which], d.xl[which]);   // embedded mode: the skinned observations
     if (LIN && e->nd && e->nd->on)                                 // the direct solver's explicit blocks of this linearisation
         hipLaunchKernelGGL(k_nd_values, dim3((e->nd->vals.n_ent + 255) / 256), dim3(256), 0, c->stream, d, e->nd->vals);
     if (d.sh_on) {

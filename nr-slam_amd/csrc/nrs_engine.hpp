@@ -42,6 +42,13 @@ struct EngineSpec {
     double info_reproj = 0, delta_reproj = 0, info_pos = 0, delta_pos = 0, info_spatial = 0, delta_spatial = 0;
     double k_spring = 0;
     int spring_form = 0;                  // 0: BA Jacobian as written, 1: tracking form
+    // embedded-deformation mode (N2, nrs_engine_skin.hpp; single-frame engines on the direct solver only): observations of points
+    // WITHOUT a vertex, placed at X0 + sum_k om[k] x[node[k]] over <= 11 vertices (nodes); they constrain those vertices and the pose
+    int n_skin = 0;
+    const float* sk_uv = nullptr;         // n_skin x 2
+    const double* sk_X0 = nullptr;        // n_skin x 3
+    const int* sk_node = nullptr;         // n_skin x 11 vertex indices, -1 pads
+    const double* sk_om = nullptr;        // n_skin x 11 normalised weights
     bool shard = false;                   // split the poses over the ranks of the context's communicator (BA windows only)
     bool force_gather = false;            // stored-block operator (k_spmv gather path) instead of the LDS-staged factored one
     bool edges_on_device = false;         // sp_ij / sp_d0 / dm_idx / dm_w are DEVICE pointers (engine_build_edges_device): plain BA windows only
@@ -62,6 +69,9 @@ int engine_edge_chi2(nrs_ctx* c, Engine* e, double* reproj /*M*/, double* spring
 int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, double* r_damper);
 int engine_gradient(nrs_ctx* c, Engine* e, double* b, double* diag);
 int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out /*24*/);
+// embedded mode: levels of the skinned observations (1 = level 0) / their chi2 = r^T Omega r at the current estimate
+int engine_skin_set_active(nrs_ctx* c, Engine* e, const uint8_t* active);
+int engine_skin_chi2(nrs_ctx* c, Engine* e, double* chi /*n_skin*/);
 // OPT:927-1137's edge construction on the device (index for index what nrs_dba_build_edges returns); arrays live in ctx scratch
 int engine_build_edges_device(nrs_ctx* c, int n_kf, const int* kf_rowptr, const int* kf_pt, const int* lm_kf, int n_points, const int* nbr_rowptr,
                               const int* nbr_col, const float* nbr_w, const float* nbr_d0, const int* nbr_status, DevEdges* out);

@@ -910,6 +910,10 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
     }
     if (LIN)
         for (int k = tid; k < P.K; k += BLK) md = fmax(md, P.red[3 + k]);      // k_pose_sums: max |diag H_pp| (plain: and of the rows' blocks)
+    if (P.sk_n > 0) {                                              // embedded mode: the skinned observations' chi2 (and what they add to the diagonal)
+        for (int b = tid; b < P.sk_nblk; b += BLK) chi += P.sk_part[(size_t)b * 32 + 27];
+        if (LIN && tid == 0) md = fmax(md, *P.sk_maxdiag);
+    }
     double c = wave_sum(chi);
     sc = wave_sum(sc);
 #pragma unroll

@@ -704,7 +704,11 @@ struct NdVals {
     const NdEnt* ent;                // the plan's original entries; ev: 9 doubles each
     double* ev;
     int n_ent;
+    // embedded mode: per entry the skinned observations that add to it (fixed order) with their weight products
+    const int* ske_ptr; const int* ske_pt; const double* ske_coef;
 };
+
+__device__ inline int nd_hpp_idx(int r, int cc) { return r * 6 - (r * (r - 1)) / 2 + (cc - r); }   // H_pp packed upper-triangular (r <= cc)
 
 // one thread per original entry of the plan: its 3 x 3 block (or its 3 right-hand-side values) of the current linearisation
 __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
@@ -712,76 +716,124 @@ __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
     if (i >= V.n_ent) return;
     const NdEnt E = V.ent[i];
     const uint32_t kind = E.src >> ND_KIND_SHIFT, idx = E.src & ND_SRC_MASK;
-    double* o = V.ev + 9 * (size_t)i;
+    double o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int form = 0;                    // how the skinned observations add to this entry: 0 symmetric block (A), 1 gradient (c), 2 pose-row block (B_p), 3 none
+    int half = 0;
     if (kind != 1) {
         const int row = V.node_row[idx];
+        form = kind == 2 ? 1 : 0;
         if (row >= 0) {
-            if (kind == 2) { o[0] = P.bl[3 * (size_t)row]; o[1] = P.bl[3 * (size_t)row + 1]; o[2] = P.bl[3 * (size_t)row + 2]; return; }
-            const double* D = P.D + 6 * (size_t)row;
-            o[0] = D[0]; o[1] = D[1]; o[2] = D[2]; o[3] = D[1]; o[4] = D[3]; o[5] = D[4]; o[6] = D[2]; o[7] = D[4]; o[8] = D[5];
-            return;
-        }
-        const int h = -1 - row;                                    // half of the pose block; H_pp is packed upper-triangular, 21 entries (pose 0)
-        if (kind == 2) { o[0] = P.bp[3 * h]; o[1] = P.bp[3 * h + 1]; o[2] = P.bp[3 * h + 2]; return; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int r = 3 * h + min(a, b), cc = 3 * h + max(a, b);
-                o[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)];
+            if (kind == 2) { o[0] = P.bl[3 * (size_t)row]; o[1] = P.bl[3 * (size_t)row + 1]; o[2] = P.bl[3 * (size_t)row + 2]; }
+            else {
+                const double* D = P.D + 6 * (size_t)row;
+                o[0] = D[0]; o[1] = D[1]; o[2] = D[2]; o[3] = D[1]; o[4] = D[3]; o[5] = D[4]; o[6] = D[2]; o[7] = D[4]; o[8] = D[5];
             }
-        return;
-    }
-    const NdPairD q = V.pair[idx];
-    if (q.kind == 0) {
-        double v[3];
+        } else {
+            const int h = -1 - row;                                // half of the pose block (pose 0)
+            form = 3;
+            if (kind == 2) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            v[k] = P.lin_xl[3 * (size_t)q.a + k] - P.lin_xl[3 * (size_t)q.b + k];
-            if (P.X0) v[k] = (P.lin_xl[3 * (size_t)q.a + k] + P.X0[3 * (size_t)q.a + k]) - (P.lin_xl[3 * (size_t)q.b + k] + P.X0[3 * (size_t)q.b + k]);
+                for (int a = 0; a < 3; ++a) {
+                    o[a] = P.bp[3 * h + a];
+                    for (int b = 0; b < P.sk_nblk; ++b) o[a] += P.sk_part[(size_t)b * 32 + 21 + 3 * h + a];
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const int k = nd_hpp_idx(3 * h + min(a, b), 3 * h + max(a, b));
+                        o[3 * a + b] = P.Hpp[k];
+                        for (int q = 0; q < P.sk_nblk; ++q) o[3 * a + b] += P.sk_part[(size_t)q * 32 + k];
+                    }
+            }
         }
-        double qc = 0, sd = 0;
-        for (int k = 0; k < q.nsrc; ++k) {
-            const int sv = V.src[q.src0 + k];
-            if (sv & 1) sd += P.d_s[sv >> 1]; else qc += P.s_qc[sv >> 1];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) o[3 * a + b] = -(qc * v[a] * v[b] + (a == b ? sd : 0.0));     // (symmetric: either orientation)
-    } else if (q.kind == 1) {
-        // H_{pose half, row} = J_p^T w J_l, J_l = -J R, J_p = -J [-[X_c]x | I] (reprojection_error_with_deformation.cc:52-68), as row_factored() forms them;
-        // the pose is eliminated last, so the block's rows are the pose half's components
-        const RowRec rc = P.rowrec[q.b];
-        const Pose Tcw = P.lin_pose[0];
-        double R[9];
-        quat_to_R(Tcw.q, R);
-        double xs[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) xs[k] = P.lin_xl[3 * (size_t)q.b + k] + (P.X0 ? P.X0[3 * (size_t)q.b + k] : 0.0);
-        const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
-        const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
-        const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
-        double Jl[2][3], Jp[2][3];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
-            if (q.a == 0) { Jp[rr][0] = -j1 * pz + j2 * py; Jp[rr][1] = j0 * pz - j2 * px; Jp[rr][2] = -j0 * py + j1 * px; }
-            else { Jp[rr][0] = j0; Jp[rr][1] = j1; Jp[rr][2] = j2; }
-            Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
-            Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
-            Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) o[3 * a + b] = rc.w * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
     } else {
+        const NdPairD q = V.pair[idx];
+        if (q.kind == 0) {
+            double v[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) {
+                v[k] = P.lin_xl[3 * (size_t)q.a + k] - P.lin_xl[3 * (size_t)q.b + k];
+                if (P.X0) v[k] = (P.lin_xl[3 * (size_t)q.a + k] + P.X0[3 * (size_t)q.a + k]) - (P.lin_xl[3 * (size_t)q.b + k] + P.X0[3 * (size_t)q.b + k]);
+            }
+            double qc = 0, sd = 0;
+            for (int k = 0; k < q.nsrc; ++k) {
+                const int sv = V.src[q.src0 + k];
+                if (sv & 1) sd += P.d_s[sv >> 1]; else qc += P.s_qc[sv >> 1];
+            }
 #pragma unroll
-            for (int b = 0; b < 3; ++b) { const int r = b, cc = 3 + a; o[3 * a + b] = P.Hpp[r * 6 - (r * (r - 1)) / 2 + (cc - r)]; }   // rows: the second half
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) o[3 * a + b] = -(qc * v[a] * v[b] + (a == b ? sd : 0.0));     // (symmetric: either orientation)
+        } else if (q.kind == 1) {
+            // H_{pose half, row} = J_p^T w J_l, J_l = -J R, J_p = -J [-[X_c]x | I] (reprojection_error_with_deformation.cc:52-68), as row_factored() forms them;
+            // the pose is eliminated last, so the block's rows are the pose half's components
+            form = 2; half = q.a;
+            const RowRec rc = P.rowrec[q.b];
+            const Pose Tcw = P.lin_pose[0];
+            double R[9];
+            quat_to_R(Tcw.q, R);
+            double xs[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xs[k] = P.lin_xl[3 * (size_t)q.b + k] + (P.X0 ? P.X0[3 * (size_t)q.b + k] : 0.0);
+            const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
+            const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
+            const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
+            double Jl[2][3], Jp[2][3];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+                if (q.a == 0) { Jp[rr][0] = -j1 * pz + j2 * py; Jp[rr][1] = j0 * pz - j2 * px; Jp[rr][2] = -j0 * py + j1 * px; }
+                else { Jp[rr][0] = j0; Jp[rr][1] = j1; Jp[rr][2] = j2; }
+                Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+                Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+                Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) o[3 * a + b] = rc.w * (Jp[0][a] * Jl[0][b] + Jp[1][a] * Jl[1][b]);
+        } else {
+            form = 3;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {                       // rows: the second half of the pose block
+                    const int k = nd_hpp_idx(b, 3 + a);
+                    o[3 * a + b] = P.Hpp[k];
+                    for (int q2 = 0; q2 < P.sk_nblk; ++q2) o[3 * a + b] += P.sk_part[(size_t)q2 * 32 + k];
+                }
+        }
     }
+    if (V.ske_ptr && form != 3) {                                  // the skinned observations that reach this entry, in list order
+        for (int t = V.ske_ptr[i]; t < V.ske_ptr[i + 1]; ++t) {
+            const double* rec = P.sk_rec + 27 * (size_t)V.ske_pt[t];
+            const double cf = V.ske_coef[t];
+            if (form == 0) {
+                o[0] += cf * rec[0]; o[1] += cf * rec[1]; o[2] += cf * rec[2]; o[3] += cf * rec[1]; o[4] += cf * rec[3]; o[5] += cf * rec[4];
+                o[6] += cf * rec[2]; o[7] += cf * rec[4]; o[8] += cf * rec[5];
+            } else if (form == 1) { o[0] += cf * rec[6]; o[1] += cf * rec[7]; o[2] += cf * rec[8]; }
+            else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) o[3 * a + b] += cf * rec[9 + 3 * (3 * half + a) + b];
+            }
+        }
+    }
+    double* out = V.ev + 9 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) out[a] = o[a];
+    if (P.sk_n > 0 && kind == 2) {
+        // the gradient with the skinned observations' part goes back into the engine's vectors: computeScale = x . (lambda x + b)
+        // (optimization_algorithm_levenberg.cpp:167-174, k_apply) is over the whole b
+        const int row = V.node_row[idx];
+        double* g = row >= 0 ? P.bl + 3 * (size_t)row : P.bp + 3 * (-1 - row);
+        g[0] = o[0]; g[1] = o[1]; g[2] = o[2];
+    }
+    if (P.sk_n > 0 && kind == 0)                                   // lambda_0 = 1e-5 max |diag H| (optimization_algorithm_levenberg.cpp:153-165) sees the added blocks
+        atomicMax(reinterpret_cast<unsigned long long*>(P.sk_maxdiag), (unsigned long long)__double_as_longlong(fmax(fabs(o[0]), fmax(fabs(o[4]), fabs(o[8])))));
 }
 
 struct NdEngine {
@@ -830,18 +882,71 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     // (the factor of an edge sits in both endpoints' incidence slots with the same value when both are free: the first one is read)
     for (size_t q = 0; q < e->sp_ij.size() / 2; ++q) add(e->sp_ij[2 * q], e->sp_ij[2 * q + 1], e->sp_pos[2 * q], 0);
     for (size_t q = 0; q < e->dm_idx.size() / 4; ++q) add(e->dm_idx[4 * q + 2], e->dm_idx[4 * q + 3], e->dm_pos[4 * q + 2], 1);
+    // embedded mode: the node pairs every skinned observation couples (all pairs of its <= 11 free nodes), with the products of
+    // its weights, and per free node the observations that reach it; everything in observation order (fixed summation order)
+    struct SkT { uint64_t k; int pt; double cf; };
+    std::vector<SkT> skt;
+    std::vector<int> nl_ptr(n_free + 1, 0), nl_pt;
+    std::vector<double> nl_om;
+    if (d.sk_n > 0) {
+        size_t n_pairs_sk = 0;
+        for (int i = 0; i < d.sk_n; ++i) {
+            int cnt = 0;
+            for (int a = 0; a < SK_MAX; ++a) {
+                const int va = e->sk_vert[(size_t)SK_MAX * i + a];
+                if (va >= 0 && node_of[va] >= 0) { nl_ptr[node_of[va] + 1]++; ++cnt; }
+            }
+            n_pairs_sk += (size_t)cnt * (cnt - 1) / 2;
+        }
+        for (int u = 0; u < n_free; ++u) nl_ptr[u + 1] += nl_ptr[u];
+        nl_pt.resize(nl_ptr[n_free]); nl_om.resize(nl_ptr[n_free]);
+        std::vector<int> fill(nl_ptr.begin(), nl_ptr.end() - 1);
+        std::vector<SkT> raw;
+        raw.reserve(n_pairs_sk);
+        for (int i = 0; i < d.sk_n; ++i)
+            for (int a = 0; a < SK_MAX; ++a) {
+                const int va = e->sk_vert[(size_t)SK_MAX * i + a];
+                if (va < 0 || node_of[va] < 0) continue;
+                const int na = node_of[va];
+                nl_pt[fill[na]] = i; nl_om[fill[na]++] = e->sk_om[(size_t)SK_MAX * i + a];
+                for (int b = a + 1; b < SK_MAX; ++b) {
+                    const int vb = e->sk_vert[(size_t)SK_MAX * i + b];
+                    if (vb < 0 || node_of[vb] < 0 || node_of[vb] == na) continue;
+                    const int nb2 = node_of[vb];
+                    raw.push_back(SkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), i, e->sk_om[(size_t)SK_MAX * i + a] * e->sk_om[(size_t)SK_MAX * i + b]});
+                }
+            }
+        // by (low node, high node), observation order inside: two stable counting passes (least significant key first)
+        skt.resize(raw.size());
+        std::vector<int> cnt(n_free + 1);
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<SkT>& in = pass == 0 ? raw : skt;
+            std::vector<SkT>& outv = pass == 0 ? skt : raw;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            auto dig = [&](const SkT& t) { return pass == 0 ? (int)(t.k & 0xFFFFFFFFu) : (int)(t.k >> 32); };
+            for (const SkT& t : in) cnt[dig(t) + 1]++;
+            for (int u = 0; u < n_free; ++u) cnt[u + 1] += cnt[u];
+            for (const SkT& t : in) outv[cnt[dig(t)]++] = t;
+        }
+        skt.swap(raw);
+    }
     std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; });
     std::vector<int> pairs, src;
     std::vector<NdPairD> pd;
-    for (size_t i = 0; i < keys.size();) {
-        size_t j = i;
-        const int a = (int)(keys[i].k >> 32), b = (int)(keys[i].k & 0xFFFFFFFFu);
+    std::vector<int> pair_sk0, pair_sk1;                           // per row-row pair: its range in skt
+    pairs.reserve(2 * (keys.size() + skt.size() / 4)); pd.reserve(keys.size() + skt.size() / 4);
+    // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
+    for (size_t i = 0, st = 0; i < keys.size() || st < skt.size();) {
+        const uint64_t kk = i < keys.size() && (st >= skt.size() || keys[i].k <= skt[st].k) ? keys[i].k : skt[st].k;
+        const int a = (int)(kk >> 32), b = (int)(kk & 0xFFFFFFFFu);
         NdPairD p{0, node_row[a], node_row[b], (int)src.size(), 0};
-        for (; j < keys.size() && keys[j].k == keys[i].k; ++j) src.push_back(keys[j].src);
-        p.nsrc = (int)(j - i);
+        for (; i < keys.size() && keys[i].k == kk; ++i) src.push_back(keys[i].src);
+        p.nsrc = (int)src.size() - p.src0;
         pd.push_back(p);
         pairs.push_back(a); pairs.push_back(b);
-        i = j;
+        pair_sk0.push_back((int)st);
+        while (st < skt.size() && skt[st].k == kk) ++st;
+        pair_sk1.push_back((int)st);
     }
     std::vector<uint8_t> last(n_nodes, 0);
     if (pose_free) {
@@ -866,15 +971,44 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     std::vector<int> node_out(n_nodes);
     for (int a = 0; a < n_free; ++a) node_out[a] = 3 * node_row[a];
     if (pose_free) { nrow.push_back(-1); nrow.push_back(-2); node_out[n_free] = -1; node_out[n_free + 1] = -1 - 3; }
+    // embedded mode: per plan entry the observations that add to it
+    std::vector<int> ske_ptr, ske_pt;
+    std::vector<double> ske_cf;
+    if (d.sk_n > 0) {
+        const NdPlan& P = nd->S.plan;
+        ske_ptr.assign(P.ent.size() + 1, 0);
+        ske_pt.reserve(4 * nl_pt.size() + skt.size()); ske_cf.reserve(4 * nl_pt.size() + skt.size());
+        for (size_t q = 0; q < P.ent.size(); ++q) {
+            const uint32_t kind = P.ent[q].src >> ND_KIND_SHIFT, idx = P.ent[q].src & ND_SRC_MASK;
+            auto node_list = [&](int u, bool squared) {
+                if (u >= n_free) return;
+                for (int t = nl_ptr[u]; t < nl_ptr[u + 1]; ++t) { ske_pt.push_back(nl_pt[t]); ske_cf.push_back(squared ? nl_om[t] * nl_om[t] : nl_om[t]); }
+            };
+            if (kind == 0) node_list((int)idx, true);
+            else if (kind == 2) node_list((int)idx, false);
+            else if (pd[idx].kind == 0) { for (int t = pair_sk0[idx]; t < pair_sk1[idx]; ++t) { ske_pt.push_back(skt[t].pt); ske_cf.push_back(skt[t].cf); } }
+            else if (pd[idx].kind == 1) node_list(pairs[2 * (size_t)idx + 1], false);
+            ske_ptr[q + 1] = (int)ske_pt.size();
+        }
+    }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_nr = 0, o_no = o_nr + al(4 * (size_t)n_nodes), o_pd = o_no + al(4 * (size_t)n_nodes), o_src = o_pd + al(sizeof(NdPairD) * (size_t)n_pairs),
-                 total = o_src + al(4 * std::max<size_t>(1, src.size()));
+                 o_sp = o_src + al(4 * std::max<size_t>(1, src.size())), o_st = o_sp + al(4 * std::max<size_t>(1, ske_ptr.size())),
+                 o_sc = o_st + al(4 * std::max<size_t>(1, ske_pt.size())), total = o_sc + al(8 * std::max<size_t>(1, ske_cf.size()));
     NRS_TRY(c->ensure(c->nd_vals, total));
     char* vb = c->nd_vals.as<char>();
     NRS_HIP(c, hipMemcpyAsync(vb + o_nr, nrow.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(vb + o_no, node_out.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(vb + o_pd, pd.data(), sizeof(NdPairD) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_src, src.data(), 4 * src.size(), hipMemcpyHostToDevice, c->stream));
+    nd->vals.ske_ptr = nullptr; nd->vals.ske_pt = nullptr; nd->vals.ske_coef = nullptr;
+    if (d.sk_n > 0) {
+        NRS_HIP(c, hipMemcpyAsync(vb + o_sp, ske_ptr.data(), 4 * ske_ptr.size(), hipMemcpyHostToDevice, c->stream));
+        if (!ske_pt.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_st, ske_pt.data(), 4 * ske_pt.size(), hipMemcpyHostToDevice, c->stream));
+        if (!ske_cf.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_sc, ske_cf.data(), 8 * ske_cf.size(), hipMemcpyHostToDevice, c->stream));
+        nd->vals.ske_ptr = reinterpret_cast<const int*>(vb + o_sp); nd->vals.ske_pt = reinterpret_cast<const int*>(vb + o_st);
+        nd->vals.ske_coef = reinterpret_cast<const double*>(vb + o_sc);
+    }
     nd->vals.node_row = reinterpret_cast<const int*>(vb + o_nr);
     nd->vals.pair = reinterpret_cast<const NdPairD*>(vb + o_pd);
     nd->vals.src = reinterpret_cast<const int*>(vb + o_src);

@@ -1016,6 +1016,37 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
+    if (s.n_skin > 0) {                                // embedded mode: the skinned observations (device arrays in the context's buffer)
+        if (!(arena == &c->arena_trk && s.K == 1) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
+            return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines only");
+        const size_t n = (size_t)s.n_skin, nblk = (n + BLK - 1) / BLK;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_uv = 0, o_X0 = o_uv + al(8 * n), o_row = o_X0 + al(24 * n), o_om = o_row + al(4 * SK_MAX * n), o_act = o_om + al(8 * SK_MAX * n),
+                     o_rec = o_act + al(n), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk), o_md = o_chi + al(8 * n), total = o_md + 256;
+        NRS_TRY(c->ensure(c->nd_skin, total));
+        char* sb = c->nd_skin.as<char>();
+        e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n);
+        e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n);
+        std::vector<int> rows(SK_MAX * n);
+        for (size_t q = 0; q < rows.size(); ++q) {
+            if (e->sk_vert[q] >= s.M) return c->fail(NRS_ERR_INVALID, "skinned observation: node index out of range");
+            rows[q] = e->sk_vert[q] >= 0 ? e->vrow[e->sk_vert[q]] : -1;
+        }
+        std::vector<uint8_t> act(n, 1);
+        NRS_HIP(c, hipMemcpyAsync(sb + o_uv, s.sk_uv, 8 * n, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(sb + o_X0, s.sk_X0, 24 * n, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(sb + o_row, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(sb + o_om, s.sk_om, 8 * SK_MAX * n, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(sb + o_act, act.data(), n, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemsetAsync(sb + o_rec, 0, total - o_rec, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        d.sk_n = s.n_skin; d.sk_nblk = (int)nblk;
+        d.sk_uv = reinterpret_cast<const float*>(sb + o_uv); d.sk_X0 = reinterpret_cast<const double*>(sb + o_X0);
+        d.sk_row = reinterpret_cast<const int*>(sb + o_row); d.sk_om = reinterpret_cast<const double*>(sb + o_om);
+        d.sk_active = reinterpret_cast<const uint8_t*>(sb + o_act);
+        d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
+        d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
+    }
     if (arena == &c->arena_trk && s.K == 1) {          // a2's single-frame engines: direct solve when the frame is small enough to gain from it
         e->nd = new (std::nothrow) NdEngine();
         if (!e->nd) return c->fail(NRS_ERR_ALLOC, "out of host memory");
@@ -1024,6 +1055,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             for (int k = 0; k < 3; ++k) e->nd->pos[3 * (size_t)e->vrow[v] + k] = s.x[3 * (size_t)v + k] + (s.X0 ? s.X0[3 * (size_t)v + k] : 0.0);
         NRS_TRY(nd_engine_setup(c, e, e->nd));
         mark("direct solve plan");
+        if (s.n_skin > 0 && !e->nd->on) return c->fail(NRS_ERR_STATE, "skinned observations need the direct solver (nrs_options.direct_solve = 2 or a problem it does not take)");
     }
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
@@ -1056,6 +1088,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
         bool same = e->nd->sig.size() == (size_t)e->d.M + 1 && e->nd->sig[e->d.M] == e->h_pose_fixed[0];
         for (int v = 0; v < e->d.M && same; ++v) same = e->nd->sig[v] == (e->h_rflag[e->vrow[v]] & RF_FIXED);
         if (!same) NRS_TRY(nd_engine_setup(c, e, e->nd));
+        if (e->d.sk_n > 0 && !e->nd->on) return c->fail(NRS_ERR_STATE, "skinned observations need the direct solver");
     }
     return NRS_OK;
 }
@@ -1070,4 +1103,22 @@ int engine_reset(nrs_ctx* c, Engine* e) {
     return NRS_OK;
 }
 
+}  // namespace nrs
+
+namespace nrs {
+int engine_skin_set_active(nrs_ctx* c, Engine* e, const uint8_t* active) {
+    if (e->d.sk_n <= 0) return NRS_OK;
+    NRS_HIP(c, hipMemcpyAsync(const_cast<uint8_t*>(e->d.sk_active), active, (size_t)e->d.sk_n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
+int engine_skin_chi2(nrs_ctx* c, Engine* e, double* chi) {
+    const Dev& d = e->d;
+    if (d.sk_n <= 0) return NRS_OK;
+    hipLaunchKernelGGL((k_skin<false>), dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, d.pose[e->cur], d.xl[e->cur]);
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipMemcpyAsync(chi, d.sk_chi, sizeof(double) * (size_t)d.sk_n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    return NRS_OK;
+}
 }  // namespace nrs

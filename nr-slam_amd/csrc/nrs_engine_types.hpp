@@ -163,6 +163,14 @@ struct Dev {
     // of the rank's own tiles in each class: the first sh_front and the last sh_back read rows of other ranks
     int sh_front[2], sh_back[2];
     double* red_loc;                 // this rank's SpMV sums before the all-reduce into red
+    // embedded-deformation mode (N2, nrs_engine_skin.hpp): sk_n SKINNED observations -- points without a vertex whose position is
+    // X0 + sum_k om[k] x[row[k]] over <= 11 node rows; their reprojection edges constrain those rows and the pose (direct solver only)
+    int sk_n, sk_nblk;
+    const float* sk_uv; const double* sk_X0; const int* sk_row; const double* sk_om; const uint8_t* sk_active;
+    double* sk_rec;                  // sk_n x 27: per observation J_l^T w J_l (6), -J_l^T w r (3), J_p^T w J_l (18) of the linearisation point
+    double* sk_part;                 // sk_nblk x 32: H_pp (21), b_p (6), chi2 partials of the observations' workgroups
+    double* sk_chi;                  // sk_n: r^T Omega r at the evaluated state (the drivers' inlier classification)
+    double* sk_maxdiag;              // largest diagonal entry of the blocks the observations add to (joins SC_MAXDIAG)
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 
@@ -192,6 +200,8 @@ struct Engine {
     std::vector<uint2> h_d_hdr;
     std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
+    std::vector<int> sk_vert;        // embedded mode: the skinned observations' node vertices (n_skin x 11, -1 pads) and weights
+    std::vector<double> sk_om;
     unsigned long long serial = 0;   // identifies this engine to the context's tap buffer (nrs_ctx::tap)
     // device-packed engines (nrs_engine_devpack.hpp) keep no host copies of the edges: the taps read the raw device copies
     bool dev_edges = false;

@@ -272,7 +272,7 @@ struct DenseSource : NeighbourSource {
 
 static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
                       int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
-                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace);
+                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace, const uint8_t* f_node = nullptr);
 
 }  // namespace nrs
 
@@ -343,10 +343,30 @@ extern "C" int nrs_track_deform_solve_rg(nrs_ctx* c, const nrs_camera* cam, nrs_
     return track_core(c, cam, src, map_pos, n_f, f_map, f_status, f_uv, f_pos, pose_qt, scale, deform_median, n_lost, lost, trace);
 }
 
+// N2 (include/nrs.h): the embedded-deformation mode on the device-resident dense graph
+extern "C" int nrs_track_deform_solve_embedded(nrs_ctx* c, const nrs_camera* cam, nrs_rgraph* g, int32_t n_points, int32_t cap_per_point,
+                                               float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
+                                               float* f_pos, const uint8_t* f_node, double pose_qt[7], float scale, float* deform_median,
+                                               int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!cam || !g || !map_pos || n_points <= 0 || cap_per_point <= 0 || n_f < 0 || !pose_qt || !n_lost || (n_f > 0 && (!f_map || !f_status || !f_uv || !f_pos || !f_node)))
+        return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve_embedded: bad argument");
+    if (cam->model != NRS_CAM_PINHOLE && cam->model != NRS_CAM_KB8) return c->fail(NRS_ERR_INVALID, "unknown camera model %d", cam->model);
+    if (n_points != rg_capacity(g))
+        return c->fail(NRS_ERR_INVALID, "nrs_track_deform_solve_embedded: n_points %d is not the graph's capacity %d", n_points, rg_capacity(g));
+    NRS_HIP(c, hipSetDevice(c->device));
+    DenseSource src;
+    src.c = c; src.g = g; src.cap = std::min(cap_per_point, rg_max_cap_per_point(g)); src.n_points = n_points;
+    return track_core(c, cam, src, map_pos, n_f, f_map, f_status, f_uv, f_pos, pose_qt, scale, deform_median, n_lost, lost, trace, f_node);
+}
+
 namespace nrs {
+// f_node (may be null: every optimised point is a node = the reference function): the EMBEDDED-DEFORMATION mode (N2, SURVEY.md 8d;
+// stated in oracle/embedded_oracle.py).  Nodes carry the vertices and the regularisers of OPT:255-335; every other optimised point is
+// skinned to the <= 11 nodes its own GetEdges walk accepts (normalised connection weights) and its reprojection edge constrains them.
 static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
                       int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
-                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace) {
+                      int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace, const uint8_t* f_node) {
     const bool tm = getenv("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -364,14 +384,19 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         if (f_map[i] >= n_map) return c->fail(NRS_ERR_INVALID, "f_map out of range");
         if (f_map[i] >= 0) map_to_frame[f_map[i]] = i;
     }
-    // points in the optimisation: TRACKED_WITH_3D in frame index order (OPT:174-192)
+    // points in the optimisation: TRACKED_WITH_3D in frame index order (OPT:174-192); the nodes among them carry the vertices
     std::vector<int> opt_f, ids;
     for (int i = 0; i < n_f; ++i)
         if (f_status[i] == NRS_TRACKED_WITH_3D && f_map[i] >= 0) { opt_f.push_back(i); ids.push_back(f_map[i]); }
     const int N = (int)opt_f.size();
     if (N == 0) return NRS_OK;                       // nothing to optimise (g2o: empty graph)
-    std::vector<int> id_to_idx(n_map, -1);
-    for (int i = 0; i < N; ++i) id_to_idx[ids[i]] = i;
+    std::vector<int> id_to_idx(n_map, -1), node_of(N, -1), node_idx;
+    for (int i = 0; i < N; ++i) {
+        id_to_idx[ids[i]] = i;
+        if (!f_node || f_node[opt_f[i]]) { node_of[i] = (int)node_idx.size(); node_idx.push_back(i); }
+    }
+    const int M = (int)node_idx.size();
+    if (M == 0) return c->fail(NRS_ERR_INVALID, "embedded mode: no node among the optimised points");
 
     std::vector<int> orp, ocol, ost;
     std::vector<float> ow, od0;
@@ -380,16 +405,22 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     for (auto& v : reg) v.reserve(24);                            // (one allocation per point: <= 11 own + the neighbours' entries)
     std::vector<int> dm_idx, sp_ij;
     std::vector<float> dm_w, sp_d0;
-    dm_idx.reserve(48 * (size_t)N); sp_ij.reserve(24 * (size_t)N); dm_w.reserve(12 * (size_t)N); sp_d0.reserve(12 * (size_t)N);
+    dm_idx.reserve(48 * (size_t)M); sp_ij.reserve(24 * (size_t)M); dm_w.reserve(12 * (size_t)M); sp_d0.reserve(12 * (size_t)M);
+    std::vector<int> sk_node((size_t)(N - M) * 11, -1), sk_of(N, -1), sk_idx;     // skinned observations: nodes (vertex indices), weights
+    std::vector<double> sk_om((size_t)(N - M) * 11, 0.0);
     std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
     again = false;
     NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
     for (auto& v : reg) v.clear();
     dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); lost_set.clear();
+    sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
     for (int idx = 0; idx < N && !again; ++idx) {
         const int p = ids[idx];
+        const bool is_node = node_of[idx] >= 0;
+        const size_t slot = sk_idx.size();                        // (a skinned observation's slot, kept only if it meets a node)
         int n_reg = 0;
+        double wsum = 0;
         bool ended = false;
         for (int a = orp[p]; a < orp[p + 1]; ++a) {
             const int other = ocol[a];
@@ -400,17 +431,31 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
                 continue;
             }
             const int io = id_to_idx[other];
-            bool dup = false;
-            for (auto& pr : reg[idx]) dup = dup || pr.first == io;
-            if (dup) continue;
-            const int k = (int)dm_w.size();
-            dm_idx.insert(dm_idx.end(), {-1, -1, idx, io});      // r = w (delta_idx - delta_io)
-            dm_w.push_back(ow[a]);
-            sp_ij.insert(sp_ij.end(), {idx, io});
-            sp_d0.push_back(od0[a]);
-            reg[idx].push_back({io, k});
-            reg[io].push_back({idx, k});
+            if (node_of[io] < 0) continue;                        // an optimised point without a vertex: passed over
+            if (is_node) {
+                bool dup = false;
+                for (auto& pr : reg[idx]) dup = dup || pr.first == io;
+                if (dup) continue;
+                const int k = (int)dm_w.size();
+                dm_idx.insert(dm_idx.end(), {-1, -1, node_of[idx], node_of[io]});      // r = w (delta_idx - delta_io)
+                dm_w.push_back(ow[a]);
+                sp_ij.insert(sp_ij.end(), {node_of[idx], node_of[io]});
+                sp_d0.push_back(od0[a]);
+                reg[idx].push_back({io, k});
+                reg[io].push_back({idx, k});
+            } else {
+                sk_node[11 * slot + n_reg] = node_of[io];
+                sk_om[11 * slot + n_reg] = (double)ow[a];
+                wsum += (double)ow[a];
+            }
             ++n_reg;
+        }
+        if (!is_node && n_reg > 0) {                              // omega = w / sum w (float weights, double arithmetic)
+            for (int k = 0; k < n_reg; ++k) sk_om[11 * slot + k] /= wsum;
+            sk_of[idx] = (int)slot;
+            sk_idx.push_back(idx);
+        } else if (!is_node) {
+            for (int k = 0; k < 11; ++k) { sk_node[11 * slot + k] = -1; sk_om[11 * slot + k] = 0.0; }
         }
         if (!ended && !src.truncated.empty() && src.truncated[p]) {
             if (!src.grow()) return c->fail(NRS_ERR_INVALID, "the neighbour walk of map point %d ran off its list", p);
@@ -419,29 +464,37 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     }
     }
     mark("GetEdges + edge construction");
-    const int E = (int)dm_w.size();
+    const int E = (int)dm_w.size(), S = (int)sk_idx.size();
 
-    // ---- engine for the two inlier rounds
+    // ---- engine for the two inlier rounds: one vertex per node
     EngineSpec s;
     Pose seed;
     for (int i = 0; i < 4; ++i) seed.q[i] = pose_qt[i];
     for (int i = 0; i < 3; ++i) seed.t[i] = pose_qt[4 + i];
     quat_normalize(seed.q);
-    std::vector<double> X0(3 * (size_t)N), zeros(3 * (size_t)N, 0.0);
-    std::vector<float> uv(2 * (size_t)N);
-    std::vector<int> lm_pose(N, 0);
-    for (int i = 0; i < N; ++i) {
-        for (int k = 0; k < 3; ++k) X0[3 * (size_t)i + k] = (double)f_pos[3 * (size_t)opt_f[i] + k];
-        uv[2 * (size_t)i] = f_uv[2 * (size_t)opt_f[i]];
-        uv[2 * (size_t)i + 1] = f_uv[2 * (size_t)opt_f[i] + 1];
+    std::vector<double> X0(3 * (size_t)M), zeros(3 * (size_t)M, 0.0), skX0(3 * (size_t)S);
+    std::vector<float> uv(2 * (size_t)M), skuv(2 * (size_t)S);
+    std::vector<int> lm_pose(M, 0);
+    for (int v = 0; v < M; ++v) {
+        const int fi = opt_f[node_idx[v]];
+        for (int k = 0; k < 3; ++k) X0[3 * (size_t)v + k] = (double)f_pos[3 * (size_t)fi + k];
+        uv[2 * (size_t)v] = f_uv[2 * (size_t)fi];
+        uv[2 * (size_t)v + 1] = f_uv[2 * (size_t)fi + 1];
     }
-    std::vector<uint8_t> rflag(N, RF_OBS | RF_REPROJ_ACTIVE), dm_active(E, 1);
-    s.K = 1; s.M = N;
+    for (int q = 0; q < S; ++q) {
+        const int fi = opt_f[sk_idx[q]];
+        for (int k = 0; k < 3; ++k) skX0[3 * (size_t)q + k] = (double)f_pos[3 * (size_t)fi + k];
+        skuv[2 * (size_t)q] = f_uv[2 * (size_t)fi];
+        skuv[2 * (size_t)q + 1] = f_uv[2 * (size_t)fi + 1];
+    }
+    std::vector<uint8_t> rflag(M, RF_OBS | RF_REPROJ_ACTIVE), dm_active(E, 1), sk_active(S, 1);
+    s.K = 1; s.M = M;
     s.poses = &seed;
     s.x = zeros.data(); s.X0 = X0.data();
     s.lm_pose = lm_pose.data(); s.uv = uv.data(); s.rflag = rflag.data();
     s.n_sp = E; s.sp_ij = sp_ij.data(); s.sp_d0 = sp_d0.data();
     s.n_dm = E; s.dm_idx = dm_idx.data(); s.dm_w = dm_w.data(); s.dm_active = dm_active.data();
+    s.n_skin = S; s.sk_uv = skuv.data(); s.sk_X0 = skX0.data(); s.sk_node = sk_node.data(); s.sk_om = sk_om.data();
     s.cam.model = cam->model;
     for (int i = 0; i < 8; ++i) s.cam.p[i] = cam->params[i];
     ba_constants(s, scale);
@@ -454,28 +507,43 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     mark("engine 1");
     const float th2_sq = 5.99f, th3_sq = 0.584f;
     std::vector<char> inl(N, 1);
-    std::vector<double> chi_r(N), chi_d(E);
+    std::vector<double> chi_r(M), chi_d(E), chi_s(S);
     for (int rnd = 0; rnd < 2; ++rnd) {                          // OPT:338-395
         NRS_TRY(engine_reset(c, eng));
         NRS_TRY(engine_optimize(c, eng, 10, rnd, trace));
         NRS_TRY(engine_edge_chi2(c, eng, chi_r.data(), nullptr, chi_d.data()));
-        for (int idx = 0; idx < N; ++idx) {
-            const bool out = (float)chi_r[idx] > th2_sq;
+        for (int v = 0; v < M; ++v) {
+            const int idx = node_idx[v];
+            const bool out = (float)chi_r[v] > th2_sq;
             inl[idx] = !out;
-            rflag[idx] = RF_OBS | (out ? 0 : RF_REPROJ_ACTIVE);
+            rflag[v] = RF_OBS | (out ? 0 : RF_REPROJ_ACTIVE);
             for (auto& pr : reg[idx]) dm_active[pr.second] = out ? 0 : 1;
             for (auto& pr : reg[idx]) dm_active[pr.second] = chi_d[pr.second] > (double)th3_sq ? 0 : 1;
         }
         NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
+        if (S) {                                                  // the skinned observations' levels, by the same gate
+            NRS_TRY(engine_skin_chi2(c, eng, chi_s.data()));
+            for (int q = 0; q < S; ++q) { const bool out = (float)chi_s[q] > th2_sq; inl[sk_idx[q]] = !out; sk_active[q] = out ? 0 : 1; }
+            NRS_TRY(engine_skin_set_active(c, eng, sk_active.data()));
+        }
     }
     mark("two rounds");
     Pose pose_out;
-    std::vector<double> delta(3 * (size_t)N);
-    NRS_TRY(engine_download(c, eng, &pose_out, delta.data()));
+    std::vector<double> delta_v(3 * (size_t)M), delta(3 * (size_t)N, 0.0);
+    NRS_TRY(engine_download(c, eng, &pose_out, delta_v.data()));
     for (int i = 0; i < 4; ++i) pose_qt[i] = pose_out.q[i];
     for (int i = 0; i < 3; ++i) pose_qt[4 + i] = pose_out.t[i];
+    for (int v = 0; v < M; ++v)
+        for (int k = 0; k < 3; ++k) delta[3 * (size_t)node_idx[v] + k] = delta_v[3 * (size_t)v + k];
+    for (int q = 0; q < S; ++q)                                   // a skinned point's deformation: the interpolated one
+        for (int k = 0; k < 3; ++k) {
+            double a = 0;
+            for (int j = 0; j < 11; ++j)
+                if (sk_node[11 * (size_t)q + j] >= 0) a += sk_om[11 * (size_t)q + j] * delta_v[3 * (size_t)sk_node[11 * (size_t)q + j] + k];
+            delta[3 * (size_t)sk_idx[q] + k] = a;
+        }
 
-    // ---- OPT:401-455: deformation statistics, status / position updates
+    // ---- OPT:401-455: deformation statistics, status / position updates (all optimised points alike)
     std::vector<float> mag(N), dfl(3 * (size_t)N);
     for (int i = 0; i < N; ++i) {
         const float d0 = (float)delta[3 * (size_t)i], d1 = (float)delta[3 * (size_t)i + 1], d2 = (float)delta[3 * (size_t)i + 2];
@@ -488,9 +556,10 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     const float th = 1.5f * (q3 - q1);
     for (int idx = 0; idx < N; ++idx) {
         const int fi = opt_f[idx];
-        if ((float)chi_r[idx] > th2_sq) { inl[idx] = 0; f_status[fi] = NRS_TRACKED; }
+        const double chi = node_of[idx] >= 0 ? chi_r[node_of[idx]] : (sk_of[idx] >= 0 ? chi_s[sk_of[idx]] : 0.0);
+        if ((float)chi > th2_sq) { inl[idx] = 0; f_status[fi] = NRS_TRACKED; }
         if (mag[idx] >= q3 + th) { f_status[fi] = NRS_TRACKED; continue; }
-        rflag[idx] |= RF_FIXED;
+        if (node_of[idx] >= 0) rflag[node_of[idx]] |= RF_FIXED;
         for (int k = 0; k < 3; ++k) {
             const float cur = dfl[3 * (size_t)idx + k] + f_pos[3 * (size_t)fi + k];
             f_pos[3 * (size_t)fi + k] = cur;
@@ -516,9 +585,15 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     mark("UpdateVertex");
     if (lost_set.empty()) return NRS_OK;
 
-    // ---- stage 2 OPT:476-553: lost points follow their (fixed) neighbours
+    // ---- stage 2 OPT:476-553: lost points follow their (fixed) optimised neighbours.  Vertices: the nodes, then the optimised points
+    // without a vertex as constants (their interpolated deformation), then the lost points
     std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
     const int L = (int)lost_ids.size();
+    std::vector<int> vert_of(N, -1), others;
+    for (int v = 0; v < M; ++v) vert_of[node_idx[v]] = v;
+    for (int idx = 0; idx < N; ++idx)
+        if (node_of[idx] < 0) { vert_of[idx] = M + (int)others.size(); others.push_back(idx); }
+    const int NV = M + (int)others.size();
     std::vector<int> un_ij;
     std::vector<float> un_w;
     for (bool again = true; again;) {
@@ -533,7 +608,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             if (n_reg > 10) { ended = true; break; }
             const int io = id_to_idx[ocol[a]];
             if (io < 0) continue;
-            un_ij.insert(un_ij.end(), {N + li, io});
+            un_ij.insert(un_ij.end(), {NV + li, vert_of[io]});
             un_w.push_back(ow[a]);
             ++n_reg;
         }
@@ -544,15 +619,18 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     }
     }
     mark("GetEdges 2 + walk");
-    const int M2 = N + L;
+    const int M2 = NV + L;
     std::vector<double> x2(3 * (size_t)M2, 0.0), X02(3 * (size_t)M2, 0.0);
-    std::copy(delta.begin(), delta.end(), x2.begin());
+    std::copy(delta_v.begin(), delta_v.end(), x2.begin());
     std::copy(X0.begin(), X0.end(), X02.begin());
+    for (size_t o = 0; o < others.size(); ++o)
+        for (int k = 0; k < 3; ++k) x2[3 * ((size_t)M + o) + k] = delta[3 * (size_t)others[o] + k];
     std::vector<float> uv2(2 * (size_t)M2, 0.f);
     std::copy(uv.begin(), uv.end(), uv2.begin());
     std::vector<int> lm_pose2(M2, 0);
     std::vector<uint8_t> rflag2(M2, 0);
     std::copy(rflag.begin(), rflag.end(), rflag2.begin());
+    for (size_t o = 0; o < others.size(); ++o) rflag2[M + o] = RF_FIXED;
     const uint8_t pose_fixed = 1;
     EngineSpec s2 = s;
     s2.M = M2;
@@ -562,6 +640,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     s2.lm_pose = lm_pose2.data(); s2.uv = uv2.data(); s2.rflag = rflag2.data();
     s2.dm_active = dm_active.data();
     s2.n_un = (int)un_w.size(); s2.un_ij = un_ij.data(); s2.un_w = un_w.data();
+    s2.n_skin = 0;                                                // (the skinned observations take part in the two rounds only)
     engine_destroy(c, eng);
     eg.e = nullptr;
     Engine* eng2 = nullptr;
@@ -574,7 +653,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     NRS_TRY(engine_download(c, eng2, nullptr, x_out.data()));
     for (int li = 0; li < L; ++li) {
         for (int k = 0; k < 3; ++k)
-            map_pos[3 * (size_t)lost_ids[li] + k] = (float)x_out[3 * (size_t)(N + li) + k] + map_pos[3 * (size_t)lost_ids[li] + k];
+            map_pos[3 * (size_t)lost_ids[li] + k] = (float)x_out[3 * (size_t)(NV + li) + k] + map_pos[3 * (size_t)lost_ids[li] + k];
         if (lost) lost[li] = lost_ids[li];
     }
     *n_lost = L;

@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_track_deform_solve_embedded",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -432,6 +432,24 @@ class Context:
             self.h, C.byref(cam), rg.h, C.c_int32(rg.cap), C.c_int32(cap_per_point), _p(map_pos, C.c_float), C.c_int32(len(f_map)),
             _p(f_map, C.c_int32), _p(f_status, C.c_int32), _p(f_uv, C.c_float), _p(f_pos, C.c_float), _p(qt, C.c_double), C.c_float(scale),
             C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
+        return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
+                    median=float(med.value), lost=lost[:n_lost.value].tolist())
+
+    def track_deform_solve_embedded(self, cam, rg, map_pos, f_map, f_status, f_uv, f_pos, f_node, pose_q, pose_t, scale, trace=None, cap_per_point=128):
+        """N2 (include/nrs.h nrs_track_deform_solve_embedded): a2 with a node set; the other optimised landmarks are skinned to their nodes"""
+        map_pos = _f32(map_pos).reshape(-1, 3).copy()
+        assert len(map_pos) == rg.cap
+        f_map, f_status = _i32(f_map), _i32(f_status).copy()
+        f_uv, f_pos = _f32(f_uv).reshape(-1, 2), _f32(f_pos).reshape(-1, 3).copy()
+        f_node = np.ascontiguousarray(f_node, np.uint8)
+        assert len(f_node) == len(f_map)
+        qt = np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)])
+        med, n_lost = C.c_float(0), C.c_int32(0)
+        lost = np.zeros(len(map_pos), np.int32)
+        self._chk(self.lib.nrs_track_deform_solve_embedded(
+            self.h, C.byref(cam), rg.h, C.c_int32(rg.cap), C.c_int32(cap_per_point), _p(map_pos, C.c_float), C.c_int32(len(f_map)),
+            _p(f_map, C.c_int32), _p(f_status, C.c_int32), _p(f_uv, C.c_float), _p(f_pos, C.c_float), _p(f_node, C.c_uint8), _p(qt, C.c_double),
+            C.c_float(scale), C.byref(med), C.byref(n_lost), _p(lost, C.c_int32), C.byref(trace.c) if trace else None))
         return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos,
                     median=float(med.value), lost=lost[:n_lost.value].tolist())
 
