@@ -57,7 +57,7 @@ struct nrs_ctx {
     unsigned long long tap_serial = 0, engine_serial = 0;
     nrs::DevBuf pack_ws, pack_ws2, pack_ws3, pack_ws4;   // device-side problem construction (nrs_engine_devpack.hpp): raw inputs + intermediates
     nrs::DevBuf nd_skin;             // embedded mode (nrs_engine_skin.hpp): the skinned observations of the tracking engine
-    nrs::DevBuf nd_ws, nd_vals;      // direct solver of the tracking engines (nrs_engine_nd.hpp): plan + factor storage, value descriptors; reused across frames
+    void* nd_cache = nullptr;        // direct solver of the tracking engines (nrs_engine_nd.hpp NdCache): the last few plans with their device arrays
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
     bool err_local = true;           // last set-up failure may be specific to this rank (allocation, HIP, rank-dependent checks)
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
@@ -105,6 +105,7 @@ struct nrs_ctx {
 
 namespace nrs {
 void dba_free(nrs_ctx* ctx);
+void nd_cache_free(nrs_ctx* ctx);
 void comm_free(nrs_ctx* ctx);
 int comm_agree(nrs_ctx* ctx, int rc);    // collective: 0 if every rank passed 0, else an error on every rank
 void klt_free(nrs_ctx* ctx);

@@ -301,7 +301,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
     }
     if (d.sk_n > 0) hipLaunchKernelGGL((k_skin<LIN>), dim3(d.sk_nblk), b, 0, c->stream, d, d.pose[which], d.xl[which]);   // embedded mode: the skinned observations
     if (LIN && e->nd && e->nd->on)                                 // the direct solver's explicit blocks of this linearisation
-        hipLaunchKernelGGL(k_nd_values, dim3((e->nd->vals.n_ent + 255) / 256), dim3(256), 0, c->stream, d, e->nd->vals);
+        hipLaunchKernelGGL(k_nd_values, dim3((e->nd->slot->vals.n_ent + 255) / 256), dim3(256), 0, c->stream, d, e->nd->slot->vals);
     if (d.sh_on) {
         // local sums -> packet -> all-reduce over the ranks (pose blocks of the normal equations, chi2,
         // scale, one max-diagonal slot per rank) -> every rank publishes the same scalars
@@ -547,7 +547,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             if (direct) {
                 // g2o's own sequence: factorise (H + lambda I), solve, evaluate (linear_solver_eigen.h:92-136); a pivot that is not
                 // positive raises flags[2] and the trial counts as failed below
-                NRS_TRY(nd_solve_enqueue(c, e->nd->S, lam));
+                NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam));
                 NRS_TRY(eval_trial());
                 done = true;
             } else {

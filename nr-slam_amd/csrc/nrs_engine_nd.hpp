@@ -22,8 +22,9 @@ constexpr int ND_LD = 97;            // LDS leading dimension (doubles): odd, so
 constexpr int ND_S16 = 96;
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
+struct NdWgD { NdFrontD F; int I, J, pad; };          // one workgroup of k_nd_level: its front and its (I >= J) pair of row blocks
 struct NdDev {
-    const NdFrontD* fr; const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const int* wg; const int* lvl_fronts;
+    const NdFrontD* fr; const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const NdWgD* wg; const NdFrontD* lvl_fr;
     const double* ev;                // 9 doubles per original entry (plan order): the blocks of the current linearisation
     double* A;                       // assembly areas: every front's Schur complement lands in its parent's index space
     double* Lp; double* xn;
@@ -199,9 +200,9 @@ __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo
 __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int* wd = N.wg + 3 * (size_t)(wg0 + blockIdx.x);
-    const int f = wd[0], I = wd[1], J = wd[2];
-    const NdFrontD F = N.fr[f];
+    const NdWgD wd = N.wg[wg0 + blockIdx.x];                        // (front descriptor inlined: one scalar round trip)
+    const int I = wd.I, J = wd.J;
+    const NdFrontD& F = wd.F;
     const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b;
     const int rI = min(ND_TB, b1 - ND_TB * I);                      // rows of block I (the last block is partial; J < I is always full)
     const bool two = J != I;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
 __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int clk0) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const NdFrontD F = N.fr[N.lvl_fronts[lf0 + blockIdx.x]];
+    const NdFrontD F = N.lvl_fr[lf0 + blockIdx.x];                  // (descriptors in level order)
     const int s = F.s, b = F.b, m = s + b;
     if (F.par < 0) {                                               // a root: solved by the factorisation kernel
         if (fin && blockIdx.x == 0 && threadIdx.x == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }
@@ -484,6 +485,14 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
         xo = nd_out_request(N, F, lane);
         y0 = L[(size_t)m * s + min(lane, s - 1)]; y1 = L[(size_t)m * s + min(lane + 64, s - 1)];
     }
+    // L21^T x_bnd: column q per thread, the boundary rows dealt to 256 / SQ thread groups, eight loads in flight per thread (the first
+    // eight requested here, with everything else this workgroup reads)
+    const int SQ = s <= 64 ? 64 : 128, ng = 256 / SQ;
+    const int q = tid & (SQ - 1), g = tid / SQ;
+    const double* Lq = L + (size_t)s * s + min(q, s - 1);
+    double l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)min(g + u * ng, b - 1) * s];
     for (int i = tid; i < b; i += 256) xb[i] = N.xn[3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3];
     {
         const int tx = tid & 31, ty = tid >> 5;
@@ -494,15 +503,12 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
     __syncthreads();
     stamp(1);
     {
-        // L21^T x_bnd: column q per thread, the boundary rows dealt to 256 / SQ thread groups, eight loads in flight per thread
-        const int SQ = s <= 64 ? 64 : 128, ng = 256 / SQ;
-        const int q = tid & (SQ - 1), g = tid / SQ;
         double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (q < s) {
-            const double* Lq = L + (size_t)s * s + q;
-            int r = g;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (g + u * ng < b) a8[u] = l8[u] * xb[g + u * ng];
+            int r = g + 8 * ng;
             for (; r + 7 * ng < b; r += 8 * ng) {
-                double l8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)(r + u * ng) * s];
 #pragma unroll
@@ -535,6 +541,8 @@ struct NdSolver {
     DevBuf own;                      // everything the kernels read: plan arrays, entry values, assembly areas, L, x ...
     DevBuf* buf = &own;              // ... in the solver's own buffer (the tap) or in the context's (engines: reused from frame to frame)
     std::vector<size_t> lvl_shm_fac, lvl_shm_back;
+    std::vector<NdWgD> h_wg;
+    std::vector<NdFrontD> h_lf;
     bool attr_set = false;
     double* d_ev = nullptr;
     const NdEnt* d_ent = nullptr;
@@ -547,7 +555,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_fr = take(sizeof(NdFrontD) * P.fr.size()), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
-                 o_wg = take(4 * P.wg.size()), o_lf = take(4 * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
+                 o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
                  o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64);
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
@@ -560,13 +568,16 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     NRS_TRY(up(o_bnd, P.bnd.data(), 4 * P.bnd.size()));
     NRS_TRY(up(o_pm, P.pmap.data(), 2 * P.pmap.size()));
     NRS_TRY(up(o_ent, P.ent.data(), sizeof(NdEnt) * P.ent.size()));
-    NRS_TRY(up(o_wg, P.wg.data(), 4 * P.wg.size()));
-    NRS_TRY(up(o_lf, P.lvl_fronts.data(), 4 * P.lvl_fronts.size()));
+    S.h_wg.resize(P.wg.size() / 3); S.h_lf.resize(P.lvl_fronts.size());       // (kept: the copies are asynchronous)
+    for (size_t w = 0; w < S.h_wg.size(); ++w) S.h_wg[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0};
+    for (size_t i = 0; i < S.h_lf.size(); ++i) S.h_lf[i] = P.fr[P.lvl_fronts[i]];
+    NRS_TRY(up(o_wg, S.h_wg.data(), sizeof(NdWgD) * S.h_wg.size()));
+    NRS_TRY(up(o_lf, S.h_lf.data(), sizeof(NdFrontD) * S.h_lf.size()));
     NdDev& D = S.dev;
     memset(&D, 0, sizeof(D));
     D.fr = reinterpret_cast<const NdFrontD*>(base + o_fr); D.own = reinterpret_cast<const int*>(base + o_own); D.bnd = reinterpret_cast<const int*>(base + o_bnd);
     D.pmap = reinterpret_cast<const int16_t*>(base + o_pm); D.ent = reinterpret_cast<const NdEnt*>(base + o_ent);
-    D.wg = reinterpret_cast<const int*>(base + o_wg); D.lvl_fronts = reinterpret_cast<const int*>(base + o_lf);
+    D.wg = reinterpret_cast<const NdWgD*>(base + o_wg); D.lvl_fr = reinterpret_cast<const NdFrontD*>(base + o_lf);
     S.d_ev = reinterpret_cast<double*>(base + o_ev); S.d_ent = D.ent;
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
@@ -836,13 +847,55 @@ __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
         atomicMax(reinterpret_cast<unsigned long long*>(P.sk_maxdiag), (unsigned long long)__double_as_longlong(fmax(fabs(o[0]), fmax(fabs(o[4]), fabs(o[8])))));
 }
 
-struct NdEngine {
+// One symbolic factorisation with everything the device needs for it (plan arrays, value descriptors, assembly areas, factor
+// storage).  The context keeps the last few (nd_cache): a frame whose optimised set, edges and fixed flags equal an earlier frame's
+// -- tracking in steady state: points are lost and edges added every few frames, not every frame -- takes the slot as it is, no
+// plan build (1.0 ms at 1k points, 5 ms at 4.5k) and no upload.  The key is the complete input of nd_engine_setup except the
+// positions the dissection bisects (they only steer its quality), compared byte for byte.
+struct NdSlot {
     NdSolver S;
     NdVals vals;
+    DevBuf ws, vb;                   // S.buf = &ws (plan + factor storage), value descriptors
+    std::vector<uint8_t> key;
+    uint64_t hash = 0, used = 0;     // (used: LRU stamp)
+    bool busy = false, cached = false;
+    int n_free = 0, n_pairs = 0;
+};
+struct NdCache { std::vector<NdSlot*> slots; uint64_t clock = 0, hits = 0, misses = 0; };
+constexpr int ND_CACHE_SLOTS = 4;
+
+struct NdEngine {
+    NdSlot* slot = nullptr;
+    NdSolver& S() { return slot->S; }
     std::vector<double> pos;         // row positions the dissection was built on (rebuilt when the fixed set changes)
     std::vector<uint8_t> sig;        // RF_FIXED of every vertex + the pose's flag at set-up
     bool on = false;
 };
+
+static void nd_slot_free(nrs_ctx* c, NdSlot* sl) {
+    if (!sl) return;
+    c->release(sl->ws); c->release(sl->vb);
+    delete sl;
+}
+void nd_cache_free(nrs_ctx* c) {
+    NdCache* nc = static_cast<NdCache*>(c->nd_cache);
+    if (!nc) return;
+    for (NdSlot* sl : nc->slots) nd_slot_free(c, sl);
+    delete nc;
+    c->nd_cache = nullptr;
+}
+static void nd_slot_release(nrs_ctx* c, NdEngine* nd) {            // the engine lets go of its slot: cached ones stay for later frames
+    if (!nd || !nd->slot) return;
+    if (nd->slot->cached) nd->slot->busy = false; else nd_slot_free(c, nd->slot);
+    nd->slot = nullptr; nd->on = false;
+}
+static inline uint64_t nd_hash(const uint8_t* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+    for (; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
 
 static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
     // nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments.
@@ -860,7 +913,7 @@ static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
 // builds (or rebuilds) the plan for the engine's current fixed set; leaves nd->on = false if the problem does not qualify
 static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     Dev& d = e->d;
-    nd->on = false;
+    nd_slot_release(c, nd);                                        // (a rebuild after the fixed set changed: the old plan goes back to the cache)
     std::vector<int> node_of(d.M, -1), node_row;
     for (int v = 0; v < d.M; ++v)
         if (!(e->h_rflag[e->vrow[v]] & RF_FIXED)) { node_of[v] = (int)node_row.size(); node_row.push_back(e->vrow[v]); }
@@ -870,6 +923,47 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
         if (e->dm_idx[q] >= 0 || e->dm_idx[q + 1] >= 0) return NRS_OK;           // four-vertex dampers: a BA window, not this solver's problem
     const bool pose_free = !e->h_pose_fixed[0];
     const int n_nodes = n_free + (pose_free ? 2 : 0);
+    // ---- the key: everything below depends on these arrays only (and on the positions, which may be an earlier frame's)
+    NdCache* nc = static_cast<NdCache*>(c->nd_cache);
+    if (!nc) { nc = new (std::nothrow) NdCache(); if (!nc) return c->fail(NRS_ERR_ALLOC, "out of host memory"); c->nd_cache = nc; }
+    std::vector<uint8_t> key;
+    {
+        std::vector<uint8_t> obs(n_free);
+        for (int a = 0; a < n_free; ++a) obs[a] = e->h_rflag[node_row[a]] & RF_OBS;
+        const int hdr[8] = {n_free, pose_free ? 1 : 0, d.M, d.n_rows, d.sk_n, ND_LEAFN, ND_SMAXN, (int)e->sp_ij.size()};
+        auto put = [&](const void* p, size_t bytes) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + bytes); };
+        key.reserve(sizeof(hdr) + 4 * (node_row.size() + e->sp_ij.size() + e->sp_pos.size() + e->dm_idx.size() + e->dm_pos.size()) + obs.size() +
+                    (d.sk_n > 0 ? (size_t)SK_MAX * d.sk_n * 12 : 0));
+        put(hdr, sizeof(hdr)); put(node_row.data(), 4 * node_row.size()); put(obs.data(), obs.size());
+        put(e->sp_ij.data(), 4 * e->sp_ij.size()); put(e->sp_pos.data(), 4 * e->sp_pos.size());
+        put(e->dm_idx.data(), 4 * e->dm_idx.size()); put(e->dm_pos.data(), 4 * e->dm_pos.size());
+        if (d.sk_n > 0) { put(e->sk_vert.data(), 4 * (size_t)SK_MAX * d.sk_n); put(e->sk_om.data(), 8 * (size_t)SK_MAX * d.sk_n); }
+    }
+    const uint64_t hash = nd_hash(key.data(), key.size());
+    const bool use_cache = !getenv("NRS_ND_NO_CACHE");
+    auto bind = [&](NdSlot* sl) -> int {                            // the engine's own vectors: where the solved step goes, the status words
+        sl->S.dev.out_rows = d.xv; sl->S.dev.out_pose = d.xp; sl->S.dev.flags = d.flags;
+        // rows the solver never writes (fixed, padding) keep a zero step; so does a fixed pose
+        NRS_HIP(c, hipMemsetAsync(d.xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
+        NRS_HIP(c, hipMemsetAsync(d.xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
+        nd->sig.assign((size_t)d.M + 1, 0);
+        for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
+        nd->sig[d.M] = e->h_pose_fixed[0];
+        sl->busy = true; sl->used = ++nc->clock;
+        nd->slot = sl; nd->on = true;
+        if (getenv("NRS_TIMING"))
+            fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", sl->n_free,
+                    sl->n_pairs, sl->S.plan.n_fronts, sl->S.plan.n_levels, (int)sl->S.plan.wg.size() / 3, sl->S.plan.flops / 1e6);
+        return NRS_OK;
+    };
+    if (use_cache)
+        for (NdSlot* sl : nc->slots)
+            if (!sl->busy && sl->hash == hash && sl->key == key) {
+                ++nc->hits;
+                if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve: plan of an earlier frame reused (%llu hits, %llu built)\n", (unsigned long long)nc->hits, (unsigned long long)nc->misses);
+                return bind(sl);
+            }
+    ++nc->misses;
     // unique row-row couplings with the incidence slots that contribute to them
     struct Key { uint64_t k; int src; };
     std::vector<Key> keys;
@@ -961,12 +1055,31 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = nd->pos[3 * (size_t)node_row[a] + k];
     std::string err;
     const int n_pairs = (int)pd.size();
-    nd->S.buf = &c->nd_ws;
-    if (!nd_build_plan(n_nodes, pos.data(), last.data(), n_pairs, pairs.data(), nd->S.plan, &err, ND_LEAFN, ND_SMAXN, false)) {
+    // a slot for the new plan: a free cached one (the least recently used is overwritten) or, if every cached slot is held by a
+    // live engine, one that lives as long as this engine
+    NdSlot* sl = nullptr;
+    if (use_cache) {
+        if ((int)nc->slots.size() < ND_CACHE_SLOTS) {
+            sl = new (std::nothrow) NdSlot();
+            if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+            sl->cached = true;
+            nc->slots.push_back(sl);
+        } else
+            for (NdSlot* q : nc->slots)
+                if (!q->busy && (!sl || q->used < sl->used)) sl = q;
+    }
+    if (!sl) { sl = new (std::nothrow) NdSlot(); if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory"); }
+    struct SlotGuard {                                             // a slot whose set-up fails holds nothing valid
+        nrs_ctx* c; NdSlot* sl; bool keep = false;
+        ~SlotGuard() { if (keep) return; if (sl->cached) { sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF); sl->used = 0; } else nd_slot_free(c, sl); }
+    } sguard{c, sl};
+    sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF);          // (matches no key while it is rebuilt)
+    sl->S.buf = &sl->ws;
+    if (!nd_build_plan(n_nodes, pos.data(), last.data(), n_pairs, pairs.data(), sl->S.plan, &err, ND_LEAFN, ND_SMAXN, false)) {
         if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", err.c_str());
         return NRS_OK;
     }
-    NRS_TRY(nd_upload(c, nd->S));
+    NRS_TRY(nd_upload(c, sl->S));
     std::vector<int> nrow(node_row);
     std::vector<int> node_out(n_nodes);
     for (int a = 0; a < n_free; ++a) node_out[a] = 3 * node_row[a];
@@ -975,7 +1088,7 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     std::vector<int> ske_ptr, ske_pt;
     std::vector<double> ske_cf;
     if (d.sk_n > 0) {
-        const NdPlan& P = nd->S.plan;
+        const NdPlan& P = sl->S.plan;
         ske_ptr.assign(P.ent.size() + 1, 0);
         ske_pt.reserve(4 * nl_pt.size() + skt.size()); ske_cf.reserve(4 * nl_pt.size() + skt.size());
         for (size_t q = 0; q < P.ent.size(); ++q) {
@@ -995,41 +1108,33 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     const size_t o_nr = 0, o_no = o_nr + al(4 * (size_t)n_nodes), o_pd = o_no + al(4 * (size_t)n_nodes), o_src = o_pd + al(sizeof(NdPairD) * (size_t)n_pairs),
                  o_sp = o_src + al(4 * std::max<size_t>(1, src.size())), o_st = o_sp + al(4 * std::max<size_t>(1, ske_ptr.size())),
                  o_sc = o_st + al(4 * std::max<size_t>(1, ske_pt.size())), total = o_sc + al(8 * std::max<size_t>(1, ske_cf.size()));
-    NRS_TRY(c->ensure(c->nd_vals, total));
-    char* vb = c->nd_vals.as<char>();
+    NRS_TRY(c->ensure(sl->vb, total));
+    char* vb = sl->vb.as<char>();
     NRS_HIP(c, hipMemcpyAsync(vb + o_nr, nrow.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(vb + o_no, node_out.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(vb + o_pd, pd.data(), sizeof(NdPairD) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_src, src.data(), 4 * src.size(), hipMemcpyHostToDevice, c->stream));
-    nd->vals.ske_ptr = nullptr; nd->vals.ske_pt = nullptr; nd->vals.ske_coef = nullptr;
+    sl->vals.ske_ptr = nullptr; sl->vals.ske_pt = nullptr; sl->vals.ske_coef = nullptr;
     if (d.sk_n > 0) {
         NRS_HIP(c, hipMemcpyAsync(vb + o_sp, ske_ptr.data(), 4 * ske_ptr.size(), hipMemcpyHostToDevice, c->stream));
         if (!ske_pt.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_st, ske_pt.data(), 4 * ske_pt.size(), hipMemcpyHostToDevice, c->stream));
         if (!ske_cf.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_sc, ske_cf.data(), 8 * ske_cf.size(), hipMemcpyHostToDevice, c->stream));
-        nd->vals.ske_ptr = reinterpret_cast<const int*>(vb + o_sp); nd->vals.ske_pt = reinterpret_cast<const int*>(vb + o_st);
-        nd->vals.ske_coef = reinterpret_cast<const double*>(vb + o_sc);
+        sl->vals.ske_ptr = reinterpret_cast<const int*>(vb + o_sp); sl->vals.ske_pt = reinterpret_cast<const int*>(vb + o_st);
+        sl->vals.ske_coef = reinterpret_cast<const double*>(vb + o_sc);
     }
-    nd->vals.node_row = reinterpret_cast<const int*>(vb + o_nr);
-    nd->vals.pair = reinterpret_cast<const NdPairD*>(vb + o_pd);
-    nd->vals.src = reinterpret_cast<const int*>(vb + o_src);
-    nd->vals.ent = nd->S.d_ent; nd->vals.ev = nd->S.d_ev; nd->vals.n_ent = (int)nd->S.plan.ent.size();
-    nd->S.dev.node_out = reinterpret_cast<const int*>(vb + o_no);
-    nd->S.dev.out_rows = d.xv; nd->S.dev.out_pose = d.xp;
-    nd->S.dev.flags = d.flags;
-    // rows the solver never writes (fixed, padding) keep a zero step; so does a fixed pose
-    NRS_HIP(c, hipMemsetAsync(d.xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
-    NRS_HIP(c, hipMemsetAsync(d.xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
+    sl->vals.node_row = reinterpret_cast<const int*>(vb + o_nr);
+    sl->vals.pair = reinterpret_cast<const NdPairD*>(vb + o_pd);
+    sl->vals.src = reinterpret_cast<const int*>(vb + o_src);
+    sl->vals.ent = sl->S.d_ent; sl->vals.ev = sl->S.d_ev; sl->vals.n_ent = (int)sl->S.plan.ent.size();
+    sl->S.dev.node_out = reinterpret_cast<const int*>(vb + o_no);
+    sl->n_free = n_free; sl->n_pairs = n_pairs;
+    NRS_TRY(bind(sl));
     NRS_HIP(c, hipStreamSynchronize(c->stream));                   // the staging vectors die here
-    nd->sig.assign((size_t)d.M + 1, 0);
-    for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
-    nd->sig[d.M] = e->h_pose_fixed[0];
-    nd->on = true;
-    if (getenv("NRS_TIMING"))
-        fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", n_free, n_pairs,
-                nd->S.plan.n_fronts, nd->S.plan.n_levels, (int)nd->S.plan.wg.size() / 3, nd->S.plan.flops / 1e6);
+    sl->key.swap(key); sl->hash = hash;
+    sguard.keep = true;
     return NRS_OK;
 }
 
-static void nd_engine_free(NdEngine* nd) { delete nd; }          // (its device arrays live in the context's buffers)
+static void nd_engine_free(nrs_ctx* c, NdEngine* nd) { nd_slot_release(c, nd); delete nd; }
 
 }  // namespace nrs

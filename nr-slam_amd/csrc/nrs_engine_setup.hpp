@@ -1070,7 +1070,7 @@ void engine_stats(const Engine* e, int64_t stats[5]) {
 void engine_destroy(nrs_ctx* c, Engine* e) {
     if (!e) return;
     (void)hipStreamSynchronize(c->stream);
-    nd_engine_free(e->nd);
+    nd_engine_free(c, e->nd);
     delete e;
 }
 

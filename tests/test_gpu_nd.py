@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import nrs_cpu as CPU
-from test_nd_cpu import block_system
+from test_nd_cpu import block_system, g2o_block_system
 
 pytestmark = pytest.mark.gpu
 
@@ -37,3 +37,67 @@ def test_forest_and_not_positive_definite(ctx):
     Dn[17] = -Dn[17]                                               # linear_solver_eigen.h:124-136: reported, not hidden
     ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
     assert not ok
+
+
+def test_g2o_known_answer_through_the_device_solver(ctx):
+    """a18's reference-held vector through the direct solver's KERNELS: g2o's 36 x 36 known-answer system
+    (third_party/g2o/unit_test/solver/linear_solver_test.cpp:72-85, tolerance 1e-6) -- as one front, as 20 side-by-side copies
+    (a forest of fronts on several levels), and columns of its dense inverse as unit right-hand sides."""
+    pos, pairs, Dn, Vp, bn, x, inv, tol = g2o_block_system()
+    ok, xs, st, _ = ctx.debug_nd_solve(pos, None, pairs, Dn, Vp, bn, 0.0)
+    assert ok and np.linalg.norm(xs.ravel() - x) <= tol * min(np.linalg.norm(xs), np.linalg.norm(x))
+    k = 20
+    posk = np.concatenate([pos + [40.0 * i, 0, 0] for i in range(k)])
+    pairsk = np.concatenate([pairs + 12 * i for i in range(k)])
+    ok, xs, st, _ = ctx.debug_nd_solve(posk, None, pairsk, np.tile(Dn, (k, 1, 1)), np.tile(Vp, (k, 1, 1)), np.tile(bn, (k, 1)), 0.0)
+    assert ok and st["fronts"] > 4
+    for row in xs.reshape(k, 36)[[0, 7, 19]]:
+        assert np.linalg.norm(row - x) <= tol * np.linalg.norm(x)
+    for col in (0, 13, 35):
+        e = np.zeros(36); e[col] = 1.0
+        ok, xs, st, _ = ctx.debug_nd_solve(pos, None, pairs, Dn, Vp, e.reshape(12, 3), 0.0)
+        assert ok and np.allclose(xs.ravel(), inv[:, col], atol=1e-6 * np.abs(inv[:, col]).max())
+
+
+def test_plan_cache_reuse_is_invisible():
+    """the context keeps the symbolic factorisation of the last few frames (nrs_engine_nd.hpp NdCache): a frame with the same
+    optimised set, edges and fixed flags as an earlier one reuses it -- same result to the last bit as the call that built it,
+    also after other frames have used (and evicted) slots in between, and within the parity tolerances of a context that never
+    caches (the plan of the first frame bisects that frame's positions; a later hit keeps it)"""
+    import os
+    import nrs
+    import nrs_synth as S
+
+    def run(c, n, seed, shift=0.0):
+        tp = S.make_tracking_problem(n, seed, S.PINHOLE)
+        cam = nrs.make_camera(tp["model"], tp["prm"])
+        fm = np.arange(n, dtype=np.int32)
+        uv = tp["uv"] + np.float32(shift)
+        return c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], uv, tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], nrs.Trace(1024))
+
+    c = nrs.Context(direct_solve=1)
+    try:
+        a0 = run(c, 600, 11)
+        a1 = run(c, 600, 11)                                        # hit
+        for k in range(6):                                          # more distinct problems than slots
+            run(c, 200 + 40 * k, 20 + k)
+        a2 = run(c, 600, 11)                                        # rebuilt after eviction: the same plan again
+        b0 = run(c, 600, 11, shift=0.25)                            # same structure, other values: hit, and a different answer
+        for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
+            assert np.array_equal(a0[k], a1[k]) and np.array_equal(a0[k], a2[k]), k
+        assert a0["lost"] == a1["lost"] == a2["lost"]
+        assert not np.array_equal(a0["pose_t"], b0["pose_t"])
+    finally:
+        c.close()
+    os.environ["NRS_ND_NO_CACHE"] = "1"
+    try:
+        c = nrs.Context(direct_solve=1)
+        n0 = run(c, 600, 11)
+        nb = run(c, 600, 11, shift=0.25)
+        c.close()
+    finally:
+        del os.environ["NRS_ND_NO_CACHE"]
+    for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
+        assert np.array_equal(a0[k], n0[k]), k
+    assert np.allclose(b0["pose_t"], nb["pose_t"], atol=1e-5, rtol=0) and np.allclose(b0["f_pos"], nb["f_pos"], atol=1e-4, rtol=0)
+    assert np.array_equal(b0["f_status"], nb["f_status"])

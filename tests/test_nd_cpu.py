@@ -73,3 +73,38 @@ def test_not_positive_definite_is_reported():
     Dn[17] = -Dn[17]                                               # linear_solver_eigen.h:124-136: the solve reports failure
     ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
     assert not ok
+
+
+def g2o_block_system():
+    """g2o's own solver fixture (third_party/g2o/unit_test/solver/sparse_system_helper.cpp:52-149,255,298; extracted numbers in
+    tests/golden/g2o_sparse_system.json) as the direct solver's input: 12 blocks of 3, the upper block triangle as pairs."""
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2o_sparse_system.json")))
+    Dn, pairs, Vp = np.zeros((12, 3, 3)), [], []
+    for blk in d["blocks"]:
+        r, c, v = blk["r"], blk["c"], np.array(blk["v"], float)
+        if r == c:
+            Dn[r] = v
+        else:
+            pairs.append((r, c)); Vp.append(v)                     # rows = r's components
+    pos = np.c_[np.arange(12.0), np.zeros(12), np.zeros(12)]        # (geometry only steers the dissection)
+    return pos, np.array(pairs, np.int32), Dn, np.array(Vp), np.array(d["b"]).reshape(12, 3), np.array(d["x"]), np.array(d["inverse"]), d["tol"]
+
+
+def test_g2o_known_answer_through_the_plan_and_host_reference():
+    # reference: third_party/g2o/unit_test/solver/linear_solver_test.cpp:72-85 (isApprox 1e-6); leaf / chunk sizes of 32 nodes make this
+    # ONE front -- the multi-front path on the same numbers: 20 copies of the system side by side as one block-diagonal problem
+    pos, pairs, Dn, Vp, bn, x, inv, tol = g2o_block_system()
+    ok, xs, st = CPU.nd_solve(pos, None, pairs, Dn, Vp, bn, 0.0)
+    assert ok and np.linalg.norm(xs.ravel() - x) <= tol * min(np.linalg.norm(xs), np.linalg.norm(x))
+    k = 20
+    posk = np.concatenate([pos + [40.0 * i, 0, 0] for i in range(k)])
+    pairsk = np.concatenate([pairs + 12 * i for i in range(k)])
+    ok, xs, st = CPU.nd_solve(posk, None, pairsk, np.tile(Dn, (k, 1, 1)), np.tile(Vp, (k, 1, 1)), np.tile(bn, (k, 1)), 0.0)
+    assert ok and st["fronts"] > 4
+    for row in xs.reshape(k, 36)[[0, 7, 19]]:
+        assert np.linalg.norm(row - x) <= tol * np.linalg.norm(x)
+    # a column of g2o's dense inverse as a unit right-hand side
+    e = np.zeros((12, 3)); e[4, 1] = 1.0
+    ok, xs, st = CPU.nd_solve(pos, None, pairs, Dn, Vp, e, 0.0)
+    assert ok and np.allclose(xs.ravel(), inv[:, 13], atol=1e-6 * np.abs(inv[:, 13]).max())
