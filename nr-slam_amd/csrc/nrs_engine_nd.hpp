@@ -30,6 +30,7 @@ struct NdDev {
     double* Lp; double* xn;
     const int* node_out;             // engine: node -> 3 doubles at out_rows + o (o >= 0) or out_pose - 1 - o (o < 0); null: xn only
     double* out_rows; double* out_pose;
+    int* done;                       // per front: the solve (epoch) whose back substitution has written its unknowns (single-launch back pass)
     int* flags;                      // [0] done [1] iterations [2] not positive definite (the engine's PCG flags, or a scratch word block)
     long long* clk;                  // NRS_ND_DBG: 8 phase clocks (100 MHz) per workgroup of the factorisation, then per front of the back substitution; else null
 };
@@ -197,17 +198,20 @@ __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo
         }
 }
 
-__global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) {
+__global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, int epoch) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NdWgD wd = N.wg[wg0 + blockIdx.x];                        // (front descriptor inlined: one scalar round trip)
     const int I = wd.I, J = wd.J;
     const NdFrontD& F = wd.F;
     const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b;
-    const int rI = min(ND_TB, b1 - ND_TB * I);                      // rows of block I (the last block is partial; J < I is always full)
-    const bool two = J != I;
+    // I < 0: the front's INVERSE workgroup.  Its panel is [F11; identity]: the factorisation leaves e_j^T L11^-T = row j of
+    // (L11^-1)^T under F11, which the back pass multiplies with instead of substituting (no dependent chain on its critical path)
+    const bool inv = I < 0;
+    const int rI = inv ? 0 : min(ND_TB, b1 - ND_TB * I);           // rows of block I (the last block is partial; J < I is always full)
+    const bool two = !inv && J != I;
     const int cJ = two ? ND_TB : rI;
-    const int nrow = s16 + ND_TB + (two ? ND_TB : 0);
+    const int nrow = inv ? 2 * s16 : s16 + ND_TB + (two ? ND_TB : 0);
     const int rowI0 = s16, rowJ0 = two ? s16 + ND_TB : s16;
     double* W = sm;
     double* dinv = W + (size_t)nrow * ND_LD;
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     auto entry_row = [&](const NdEnt& E) {                         // W row of an entry's first row, -1: not in this workgroup's blocks
         const int fr_row = 3 * (int)E.r;
         if (fr_row < s) return fr_row;
+        if (inv) return -1;
         const int rb = fr_row - s;
         if (rb >= ND_TB * I && rb < ND_TB * I + ND_TB) return rowI0 + rb - ND_TB * I;
         if (two && rb >= ND_TB * J && rb < ND_TB * J + ND_TB) return rowJ0 + rb - ND_TB * J;
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
 #pragma unroll
         for (int a = 0; a < 9; ++a) ev[u][a] = v[a];
     }
-    if (tid < 16) { const int np = 16 * I + tid; pmi[tid] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
+    if (inv) { if (tid < 32) pmi[tid] = -1; }
+    else if (tid < 16) { const int np = 16 * I + tid; pmi[tid] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
     else if (tid < 32) { const int np = 16 * J + tid - 16; pmj[tid - 16] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
     const size_t slot = (size_t)(m + 1) * F.ldA;
     const double* A0 = N.A + F.A_off;
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     }
     __syncthreads();
     if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;       // padding columns: unit diagonal
+    if (inv && tid < s) W[(s16 + tid) * ND_LD + tid] = 1.0;
     if (F.n_ch > 0) {
         // panel rows of this workgroup <- sum of the slots: W row wr = ty + 16 i is front row fr; thread (tx, ty) takes the column pairs 2 tx + 32 j
         const int tx = tid & 15, ty = tid >> 4;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
                 int fr = -1, lim = s;                              // columns [0, lim) of front row fr
                 if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
                 else if (wr < s16 + ND_TB) { if (wr - s16 < rI) fr = s + ND_TB * I + wr - s16; }
-                else if (wr < nrow) fr = s + ND_TB * J + wr - s16 - ND_TB;
+                else if (two && wr < nrow) fr = s + ND_TB * J + wr - s16 - ND_TB;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int q = 2 * tx + 32 * j;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
                 int fr = -1, lim = s;
                 if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
                 else if (wr < s16 + ND_TB) { if (wr - s16 < rI) fr = s + ND_TB * I + wr - s16; }
-                else fr = s + ND_TB * J + wr - s16 - ND_TB;
+                else if (two) fr = s + ND_TB * J + wr - s16 - ND_TB;
                 if (fr < 0 || q >= lim) continue;
                 const double2 v = *reinterpret_cast<const double2*>(A0 + k * slot + (size_t)fr * F.ldA + q);
                 W[wr * ND_LD + q] += v.x;
@@ -404,10 +411,11 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
         double t0 = lane < s ? W[rowI0 * ND_LD + lane] : 0.0, t1 = lane + 64 < s ? W[rowI0 * ND_LD + lane + 64] : 0.0;
         nd_back_solve(W, dinv, s, lane, t0, t1);
         nd_store_x(N, F, xo, lane, t0, t1);
+        if (lane == 0) N.done[F.cmap_off] = epoch;                 // (device copies of the descriptor: cmap_off = the front's own index)
     }
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
     // written into the parent's assembly slot at the parent's positions of its rows and columns (both triangles)
-    if (F.par >= 0) {
+    if (F.par >= 0 && !inv) {
         int ti[3], tj[3];
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) { const int t = min(wave + 4 * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
@@ -446,6 +454,12 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
         }
     }
     stamp(4);
+    if (inv) {                                                     // (L11^-1)^T, upper triangular, behind the panel
+        const int tx = tid & 31, ty = tid >> 5;
+        double* LT = N.Lp + F.L_off + (size_t)(m + 2) * s;
+        for (int r = ty; r < s; r += 8)
+            for (int q = tx; q < s; q += 32) LT[(size_t)r * s + q] = q >= r ? W[(s16 + r) * ND_LD + q] : 0.0;
+    }
     // ---- the factor: block I's rows of L21 (and y^T) by the workgroups of column 0, L11 and 1 / diag by (0, 0)
     if (J == 0) {
         const int tx = tid & 31, ty = tid >> 5;
@@ -462,53 +476,82 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam) 
     stamp(5);
 }
 
-// back substitution of one level (the root's first): L11^T x_own = y - L21^T x_bnd, one workgroup per front
-__global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int clk0) {
+// back substitution, x_own = L11^-T (y - L21^T x_bnd), all levels in ONE launch: one workgroup per front, top-down in block
+// order.  A workgroup first brings everything that does not depend on the unknowns above it on chip -- (L11^-1)^T into LDS, L21
+// into registers (the first 32 rows per thread group) and LDS (as many further rows as fit), y, output indices -- then waits for
+// its parent's flag (release / acquire at agent scope; the boundary values are read past the caches).  Per level the critical
+// path is the flag, the boundary gather, two matrix-vector products from registers / LDS and the publication of the result: no
+// triangular solve, no global read of the factor.  A workgroup only waits for one with a smaller block index (dispatched before
+// it), so a full chip cannot deadlock; the wait is bounded all the same.
+constexpr int ND_BACK_UR = 32;
+__host__ __device__ inline int nd_back_fixed_doubles(int b) { return ND_S16 * ND_LD + 512 + 128 + ((b + 1) & ~1); }
+__global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts, int epoch, int lds_doubles) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const NdFrontD F = N.lvl_fr[lf0 + blockIdx.x];                  // (descriptors in level order)
+    const int li = n_fronts - 1 - (int)blockIdx.x;
+    const NdFrontD F = N.lvl_fr[li];                                // (descriptors in level order)
     const int s = F.s, b = F.b, m = s + b;
-    if (F.par < 0) {                                               // a root: solved by the factorisation kernel
-        if (fin && blockIdx.x == 0 && threadIdx.x == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }
-        return;
-    }
-    double* Ls = sm;                                               // L11, [s][ND_LD]
+    if (blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }   // (read by the host after the launch has completed)
+    if (F.par < 0) return;                                         // a root: solved by the factorisation kernel
+    double* Ls = sm;                                               // (L11^-1)^T, [s][ND_LD]
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
-    double* di = part + 512;                                       // [96]
-    double* xb = di + ND_S16;                                      // [b]
+    double* tv = part + 512;                                       // [128]: y - L21^T x_bnd
+    double* xb = tv + 128;                                         // [b]
+    double* L21s = xb + ((b + 1) & ~1);
     const double* L = N.Lp + F.L_off;
-    auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(clk0 + lf0 + blockIdx.x) + k] = wall_clock64(); };
+    auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(clk0 + li) + k] = wall_clock64(); };
     stamp(0);
-    NdOut xo = {};
-    double y0 = 0, y1 = 0;
-    if (wave == 0) {                                               // needed last, requested first
-        xo = nd_out_request(N, F, lane);
-        y0 = L[(size_t)m * s + min(lane, s - 1)]; y1 = L[(size_t)m * s + min(lane + 64, s - 1)];
-    }
-    // L21^T x_bnd: column q per thread, the boundary rows dealt to 256 / SQ thread groups, eight loads in flight per thread (the first
-    // eight requested here, with everything else this workgroup reads)
+    // column q of L21 per thread, its rows dealt to 256 / SQ thread groups
     const int SQ = s <= 64 ? 64 : 128, ng = 256 / SQ;
     const int q = tid & (SQ - 1), g = tid / SQ;
-    const double* Lq = L + (size_t)s * s + min(q, s - 1);
-    double l8[8];
+    const int nreg = min(b, ng * ND_BACK_UR);                       // rows [0, nreg): registers; [nreg, nreg + nl): LDS; the rest (huge boundaries): global
+    const int nl = max(0, min(b - nreg, (lds_doubles - nd_back_fixed_doubles(b)) / s));
+    NdOut xo = {};
+    if (wave == 0) xo = nd_out_request(N, F, lane);
+    const double yq = tid < s ? L[(size_t)m * s + tid] : 0.0;
+    int bn[2];                                                     // nodes of this thread's boundary unknowns (the first 512: requested now)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)min(g + u * ng, b - 1) * s];
-    for (int i = tid; i < b; i += 256) xb[i] = N.xn[3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3];
+    for (int u = 0; u < 2; ++u) bn[u] = tid + 256 * u < b ? N.bnd[F.bnd_off + (tid + 256 * u) / 3] : 0;
+    const double* Lq = L + (size_t)s * s + min(q, s - 1);
+    double lr[ND_BACK_UR];
+#pragma unroll
+    for (int u = 0; u < ND_BACK_UR; ++u) lr[u] = Lq[(size_t)min(g + u * ng, b - 1) * s];
     {
         const int tx = tid & 31, ty = tid >> 5;
-        for (int p = ty; p < s; p += 8)
-            for (int q = tx; q <= p; q += 32) Ls[p * ND_LD + q] = L[(size_t)p * s + q];
+        const double* LT = L + (size_t)(m + 2) * s;
+        for (int r = ty; r < s; r += 8)
+            for (int p = tx; p < s; p += 32) Ls[r * ND_LD + p] = p >= r ? LT[(size_t)r * s + p] : 0.0;
+        const double* L2 = L + (size_t)(s + nreg) * s;              // (rows are contiguous)
+        for (int i = tid; i < nl * s; i += 256) L21s[i] = L2[i];
     }
-    if (tid < s) di[tid] = L[(size_t)(m + 1) * s + tid];
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(N.done + F.par, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { N.flags[2] = 2; break; }      // (cannot happen: parents are dispatched first; never hang the device)
+        }
+    }
+    __syncthreads();
+    stamp(4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (tid + 256 * u < b) xb[tid + 256 * u] = __hip_atomic_load(N.xn + 3 * (size_t)bn[u] + (tid + 256 * u) % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid + 512; i < b; i += 256) xb[i] = __hip_atomic_load(N.xn + 3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     stamp(1);
     {
         double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (q < s) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (g + u * ng < b) a8[u] = l8[u] * xb[g + u * ng];
-            int r = g + 8 * ng;
+            for (int u = 0; u < ND_BACK_UR; ++u) if (g + u * ng < b) a8[u & 7] += lr[u] * xb[g + u * ng];
+            int r = nreg + g;
+            for (; r + 3 * ng < nreg + nl; r += 4 * ng) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a8[u] += L21s[(r + u * ng - nreg) * s + q] * xb[r + u * ng];
+            }
+            for (; r < nreg + nl; r += ng) a8[0] += L21s[(r - nreg) * s + q] * xb[r];
             for (; r + 7 * ng < b; r += 8 * ng) {
+                double l8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)(r + u * ng) * s];
 #pragma unroll
@@ -522,16 +565,31 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int lf0, int fin, int 
         }
     }
     __syncthreads();
+    if (tid < s) tv[tid] = yq - ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]));
+    __syncthreads();
     stamp(2);
+    {
+        // x = (L11^-1)^T t: row q2 per thread, the columns split over two thread halves (stride ND_LD: conflict-free)
+        const int q2 = tid & 127, h = tid >> 7;
+        double a0 = 0, a1 = 0;
+        if (q2 < s) {
+            const double* row = Ls + q2 * ND_LD;
+            int p = h;
+            for (; p + 2 < s; p += 4) { a0 += row[p] * tv[p]; a1 += row[p + 2] * tv[p + 2]; }
+            for (; p < s; p += 2) a0 += row[p] * tv[p];
+        }
+        __syncthreads();                                           // (part is reused)
+        part[h * 128 + q2] = a0 + a1;
+    }
+    __syncthreads();
     if (wave == 0) {
-        auto psum = [&](int q) { return (part[q] + part[128 + q]) + (part[256 + q] + part[384 + q]); };
-        double t0 = lane < s ? y0 - psum(lane) : 0.0;              // unknowns 0..63 and 64..127 of the front, two per lane
-        double t1 = lane + 64 < s ? y1 - psum(lane + 64) : 0.0;
-        nd_back_solve(Ls, di, s, lane, t0, t1);
-        nd_store_x(N, F, xo, lane, t0, t1);
+        const double x0 = lane < s ? part[lane] + part[128 + lane] : 0.0;          // unknowns 0..63 and 64..127 of the front, two per lane
+        const double x1 = lane + 64 < s ? part[lane + 64] + part[128 + lane + 64] : 0.0;
+        nd_store_x(N, F, xo, lane, x0, x1);
+        __threadfence();                                           // (this wave wrote the unknowns: its release publishes them)
+        if (lane == 0) __hip_atomic_store(N.done + F.cmap_off, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(3);
-    if (fin && blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -540,9 +598,11 @@ struct NdSolver {
     NdDev dev;
     DevBuf own;                      // everything the kernels read: plan arrays, entry values, assembly areas, L, x ...
     DevBuf* buf = &own;              // ... in the solver's own buffer (the tap) or in the context's (engines: reused from frame to frame)
-    std::vector<size_t> lvl_shm_fac, lvl_shm_back;
+    std::vector<size_t> lvl_shm_fac;
     std::vector<NdWgD> h_wg;
     std::vector<NdFrontD> h_lf;
+    int epoch = 0;                   // solves so far (the flags of the single-launch back pass count them)
+    size_t shm_back_all = 0;
     bool attr_set = false;
     double* d_ev = nullptr;
     const NdEnt* d_ent = nullptr;
@@ -556,7 +616,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     const size_t o_fr = take(sizeof(NdFrontD) * P.fr.size()), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
                  o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
-                 o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64);
+                 o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size());
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
     auto up = [&](size_t o, const void* src, size_t bytes) -> int {
@@ -569,8 +629,8 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     NRS_TRY(up(o_pm, P.pmap.data(), 2 * P.pmap.size()));
     NRS_TRY(up(o_ent, P.ent.data(), sizeof(NdEnt) * P.ent.size()));
     S.h_wg.resize(P.wg.size() / 3); S.h_lf.resize(P.lvl_fronts.size());       // (kept: the copies are asynchronous)
-    for (size_t w = 0; w < S.h_wg.size(); ++w) S.h_wg[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0};
-    for (size_t i = 0; i < S.h_lf.size(); ++i) S.h_lf[i] = P.fr[P.lvl_fronts[i]];
+    for (size_t w = 0; w < S.h_wg.size(); ++w) { S.h_wg[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0}; S.h_wg[w].F.cmap_off = P.wg[3 * w]; }
+    for (size_t i = 0; i < S.h_lf.size(); ++i) { S.h_lf[i] = P.fr[P.lvl_fronts[i]]; S.h_lf[i].cmap_off = P.lvl_fronts[i]; }   // (cmap_off is the host reference's: here the front's index)
     NRS_TRY(up(o_wg, S.h_wg.data(), sizeof(NdWgD) * S.h_wg.size()));
     NRS_TRY(up(o_lf, S.h_lf.data(), sizeof(NdFrontD) * S.h_lf.size()));
     NdDev& D = S.dev;
@@ -581,18 +641,26 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     S.d_ev = reinterpret_cast<double*>(base + o_ev); S.d_ent = D.ent;
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
-    D.flags = reinterpret_cast<int*>(base + o_fl);
+    D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn);
     NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, 64, c->stream));
+    NRS_HIP(c, hipMemsetAsync(base + o_dn, 0, 4 * P.fr.size(), c->stream));
+    S.epoch = 0;
     // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
     NRS_HIP(c, hipMemsetAsync(base + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
     // dynamic LDS per level: the largest panel / boundary of its fronts
-    S.lvl_shm_fac.assign(P.n_levels, 0); S.lvl_shm_back.assign(P.n_levels, 0);
+    S.lvl_shm_fac.assign(P.n_levels, 0); S.shm_back_all = 8 * (size_t)nd_back_fixed_doubles(0);
     for (int l = 0; l < P.n_levels; ++l)
         for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) {
             const NdFrontD& F = P.fr[P.lvl_fronts[i]];
             const int s16 = (F.s + 15) & ~15, nrow = s16 + ND_TB + (F.nR > 1 ? ND_TB : 0);
             S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)nrow * ND_LD + ND_S16 + 256) + 2 * 32);
-            S.lvl_shm_back[l] = std::max(S.lvl_shm_back[l], sizeof(double) * ((size_t)ND_S16 * ND_LD + 512 + ND_S16 + (size_t)F.b));
+            if (F.par >= 0) {
+                S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)2 * s16 * ND_LD + ND_S16 + 256) + 2 * 32);      // (the inverse workgroup)
+                const int ngb = F.s <= 64 ? 4 : 2;
+                const size_t want = sizeof(double) * ((size_t)nd_back_fixed_doubles(F.b) + (size_t)std::max(0, F.b - ngb * ND_BACK_UR) * F.s);
+                S.shm_back_all = std::max(S.shm_back_all, std::min(want, (size_t)160 * 1024));
+                if (sizeof(double) * (size_t)nd_back_fixed_doubles(F.b) > 160 * 1024) return c->fail(NRS_ERR_INVALID, "direct solve: a front's boundary does not fit the LDS");
+            }
         }
     if (!S.attr_set) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -600,23 +668,19 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         S.attr_set = true;
     }
     for (int l = 0; l < P.n_levels; ++l)
-        if (S.lvl_shm_back[l] > 160 * 1024 || S.lvl_shm_fac[l] > 160 * 1024) return c->fail(NRS_ERR_INVALID, "direct solve: a front does not fit the LDS");
+        if (S.lvl_shm_fac[l] > 160 * 1024) return c->fail(NRS_ERR_INVALID, "direct solve: a front does not fit the LDS");
     return NRS_OK;
 }
 
 // factorise (H + lam I) and solve: 2 x levels launches on the context's stream, no host synchronisation
 static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     const NdPlan& P = S.plan;
+    const int epoch = ++S.epoch;
     for (int l = 0; l < P.n_levels; ++l) {
         const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
-        hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam);
+        hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch);
     }
-    for (int l = P.n_levels - 1; l >= 0; --l) {
-        bool work = l == 0;                                        // (level 0 always: its launch reports completion; roots are solved by k_nd_level)
-        for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1] && !work; ++i) work = P.fr[P.lvl_fronts[i]].par >= 0;
-        if (!work) continue;
-        hipLaunchKernelGGL(k_nd_back, dim3(P.lvl_ptr[l + 1] - P.lvl_ptr[l]), dim3(256), S.lvl_shm_back[l], c->stream, S.dev, P.lvl_ptr[l], l == 0 ? 1 : 0, (int)P.wg.size() / 3);
-    }
+    hipLaunchKernelGGL(k_nd_back, dim3(P.n_fronts), dim3(256), S.shm_back_all, c->stream, S.dev, (int)P.wg.size() / 3, P.n_fronts, epoch, (int)(S.shm_back_all / 8));
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
@@ -686,9 +750,12 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
             const int a = P.lvl_ptr[l], b2 = P.lvl_ptr[l + 1];
             for (int w = a; w < b2; ++w) {
                 const long long* q = &h[8 * (P.wg.size() / 3 + (size_t)w)];
-                for (int k = 0; k < 3; ++k) { const double d = (double)(q[k + 1] - q[k]) / 100.0; mean[k] += d / (b2 - a); mx[k] = std::max(mx[k], d); }
-                lo = std::min(lo, q[0]); hi = std::max(hi, q[3]);
+                if (q[3] == 0) continue;                            // (a root)
+                // (single launch: [4] = released by the parent; "loads" is then the gather of the boundary values only)
+                for (int k = 0; k < 3; ++k) { const double d = (double)(q[k + 1] - (k == 0 && q[4] ? q[4] : q[k])) / 100.0; mean[k] += d / (b2 - a); mx[k] = std::max(mx[k], d); }
+                lo = std::min(lo, q[4] ? q[4] : q[0]); hi = std::max(hi, q[3]);
             }
+            if (hi == 0) continue;
             fprintf(stderr, "[nrs] nd back  %2d: %4d wg, span %6.1f us (from %7.1f) | mean / max us: loads %.1f/%.1f gemv %.1f/%.1f solve %.1f/%.1f\n", l, b2 - a,
                     (double)(hi - lo) / 100.0, (double)(lo - t00) / 100.0, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2]);
         }

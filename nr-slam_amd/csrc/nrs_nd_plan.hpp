@@ -29,7 +29,7 @@ constexpr int ND_TB = 48;           // boundary rows per row block (16 nodes)
 
 struct NdFrontD {                   // one front, as the kernels read it
     int s, b;                       // own / boundary unknowns (b without the right-hand-side row)
-    int L_off;                      // doubles: panel [(s + b + 2) x s]: L11, L21, y^T, 1 / diag(L11)
+    int L_off;                      // doubles: panel [(s + b + 2 + s) x s]: L11, L21, y^T, 1 / diag(L11), (L11^-1)^T (device solver: its back pass multiplies)
     int U_off, ldU;                 // doubles: Schur complement [(b + 1) x ldU] handed to the parent (last row: rhs)
     int own_off, bnd_off;           // node lists (own: s / 3 entries, bnd: b / 3)
     int ent_off, n_ent;             // original entries of the own columns
@@ -57,7 +57,7 @@ struct NdPlan {
     std::vector<int16_t> pmap;      // per front: boundary node (and the rhs slot) -> node position in the parent front (device)
     std::vector<NdEnt> ent;
     std::vector<int> lvl_ptr, lvl_fronts;       // fronts of every level (leaves first)
-    std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I)
+    std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I), and (front, -1, -1) for every non-root front
     std::vector<int> pair_hi, pair_lo;          // every pair oriented by elimination order (block rows = hi)
     std::vector<int> elim;                      // node -> elimination position
     size_t L_doubles = 0, U_doubles = 0, A_doubles = 0;
@@ -222,7 +222,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         P.own.insert(P.own.end(), F[f].own.begin(), F[f].own.end());
         P.bnd.insert(P.bnd.end(), bnd[f].begin(), bnd[f].end());
         D.L_off = (int)P.L_doubles;
-        P.L_doubles += (size_t)(D.s + D.b + 2) * D.s;
+        P.L_doubles += (size_t)(D.s + D.b + 2 + D.s) * D.s;
         D.ldU = (D.b + 1 + 3) & ~3;
         D.U_off = (int)P.U_doubles;
         P.U_doubles += (size_t)(D.b + 1) * D.ldU;
@@ -297,6 +297,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             const int f = P.lvl_fronts[i];
             for (int I = 0; I < P.fr[f].nR; ++I)
                 for (int J = 0; J <= I; ++J) { P.wg.push_back(f); P.wg.push_back(I); P.wg.push_back(J); }
+            if (P.fr[f].par >= 0) { P.wg.push_back(f); P.wg.push_back(-1); P.wg.push_back(-1); }   // the inverse of L11 (device back pass)
             const double s = P.fr[f].s, tb = std::min(ND_TB, P.fr[f].b + 1);
             worst = std::max(worst, s * s * s / 3 + 2 * s * s * tb + s * tb * tb);
         }
