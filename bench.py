@@ -175,15 +175,27 @@ def cpu_tracked_fps_compiled(lib, with_gpu):
             cam = nrs.make_camera(tp["model"], tp["prm"])
             c.klt_configure()
             c.klt_set_reference(sq["im0"], sq["pts"])
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                c.klt_track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
-                gq, gt, _ = c.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
-                c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], gq, gt, tp["scale"])
-                ts.append(time.perf_counter() - t0)
+            def three_calls(reps):
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    c.klt_track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
+                    gq, gt, _ = c.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
+                    c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], gq, gt, tp["scale"])
+                    ts.append(time.perf_counter() - t0)
+                return ts
+            # the same frame is repeated: without the switch every repeat after the first would take the direct solver's symbolic
+            # factorisation from the context's cache.  gpu_ms is a frame that builds it (what the CPU side does per frame, too);
+            # gpu_ms_plan_reused a frame whose structure equals an earlier one's
+            os.environ["NRS_ND_NO_CACHE"] = "1"
+            try:
+                ts = three_calls(3)
+            finally:
+                del os.environ["NRS_ND_NO_CACHE"]
+            ts_hit = three_calls(3)[1:]
             c.close()
-            row.update(gpu_ms=1e3 * min(ts), gpu_frames_per_s=1.0 / min(ts), gpu_over_cpu=dt / min(ts))
+            row.update(gpu_ms=1e3 * min(ts), gpu_frames_per_s=1.0 / min(ts), gpu_over_cpu=dt / min(ts), gpu_ms_plan_reused=1e3 * min(ts_hit),
+                       gpu_over_cpu_plan_reused=dt / min(ts_hit))
             c = nrs.Context(direct_solve=2)                         # the same three calls with the PCG as a2's linear solver
             c.klt_configure()
             c.klt_set_reference(sq["im0"], sq["pts"])
@@ -282,6 +294,7 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
             ts.append(time.perf_counter() - t0)
             trials += len(gb.last_trace.trials)
             inner += sum(t["inner"] for t in gb.last_trace.trials)
+    nd_reused, nd_built = gb.ctx.nd_cache_stats()
     gb.close()
     nf = len(ts)
     # the pose-and-deformation solve: per LM trial one linear solve -- the nested-dissection Cholesky (default, `inner` = 1 per trial) or,
@@ -291,7 +304,10 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
     latency = dict(linear_solver="nested-dissection multifrontal Cholesky (k_nd_level / k_nd_back, fronts on v_mfma_f64_16x16x4)" if direct
                    else "block-Jacobi / two-level PCG, one launch per iteration (k_pcg_fused)",
                    solves_per_frame=trials / nf, inner_iterations_per_frame=inner / nf,
-                   us_all_in_per_lm_trial=us_unit if direct else None, us_all_in_per_pcg_iteration=None if direct else us_unit)
+                   us_all_in_per_lm_trial=us_unit if direct else None, us_all_in_per_pcg_iteration=None if direct else us_unit,
+                   # symbolic factorisations over the whole sequence (two single-frame problems per frame): built anew / taken from the
+                   # context's cache because the frame's optimised set, edges and fixed flags equalled an earlier frame's
+                   symbolic_plans=dict(built=nd_built, reused=nd_reused))
     return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf, a2_solver=latency,
                 tracked_last_frame=int(loop.log[-1]["n_tracked"]),
                 ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,

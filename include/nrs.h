@@ -215,6 +215,11 @@ int nrs_debug_pcg_solve(nrs_ctx* ctx, int32_t n_rows, const double* Hpp21, const
 int nrs_debug_nd_solve(nrs_ctx* ctx, int32_t n_nodes, const double* pos, const uint8_t* last, int32_t n_pairs, const int32_t* pairs,
                        const double* Dn, const double* Vp, const double* bn, double lambda, int32_t repeats, double* x, int64_t* stats,
                        double* ms_per_solve);
+/* The context keeps the symbolic factorisation (ordering, fronts, device arrays) of the last few single-frame problems and reuses
+ * it when a later problem has the same structure -- as a caller of linear_solver_eigen.h:144-169 does who does not request a new
+ * ordering (the symbolic step runs once, then only numeric factorisations).  out[0] = problems that reused a plan, out[1] = plans
+ * built, since the context was created. */
+int nrs_debug_nd_cache_stats(nrs_ctx* ctx, int64_t out[2]);
 
 /* ---- f3: ShiTomasi (modules/features/shi_tomasi.{h,cc}) + Tracking::ExtractFeatures (tracking.cc:118-134) --
  * nrs_shi_configure = ShiTomasi::ShiTomasi(Options) (shi_tomasi.cc:29-31): a fresh extractor (zeroed

@@ -287,3 +287,9 @@ extern "C" int nrs_debug_nd_solve(nrs_ctx* c, int32_t n_nodes, const double* pos
         return c->fail(NRS_ERR_INVALID, "nrs_debug_nd_solve: bad argument");
     return engine_nd_debug_solve(c, n_nodes, pos, last, n_pairs, pairs, Dn, Vp, bn, lambda, repeats, x, stats, ms_per_solve);
 }
+
+extern "C" int nrs_debug_nd_cache_stats(nrs_ctx* c, int64_t out[2]) {
+    if (!c || !out) return NRS_ERR_INVALID;
+    nd_cache_stats(c, out);
+    return NRS_OK;
+}

@@ -951,6 +951,10 @@ void nd_cache_free(nrs_ctx* c) {
     delete nc;
     c->nd_cache = nullptr;
 }
+void nd_cache_stats(nrs_ctx* c, int64_t out[2]) {
+    const NdCache* nc = static_cast<const NdCache*>(c->nd_cache);
+    out[0] = nc ? (int64_t)nc->hits : 0; out[1] = nc ? (int64_t)nc->misses : 0;
+}
 static void nd_slot_release(nrs_ctx* c, NdEngine* nd) {            // the engine lets go of its slot: cached ones stay for later frames
     if (!nd || !nd->slot) return;
     if (nd->slot->cached) nd->slot->busy = false; else nd_slot_free(c, nd->slot);

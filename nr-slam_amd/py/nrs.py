@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_track_deform_solve_embedded",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -625,6 +625,12 @@ class Context:
         self._chk(self.lib.nrs_debug_pcg_solve(self.h, C.c_int32(n), _p(Hpp21, C.c_double), _p(bp, C.c_double), _p(D6, C.c_double),
                                                _p(Hpl18, C.c_double), _p(bl, C.c_double), C.c_double(lam), _p(x, C.c_double), C.byref(it)))
         return x, it.value
+
+    def nd_cache_stats(self):
+        """include/nrs.h nrs_debug_nd_cache_stats: (problems that reused a cached plan, plans built)"""
+        out = np.zeros(2, np.int64)
+        self._chk(self.lib.nrs_debug_nd_cache_stats(self.h, _p(out, C.c_int64)))
+        return int(out[0]), int(out[1])
 
     def debug_nd_solve(self, pos, last, pairs, Dn, Vp, bn, lam=0.0, repeats=0):
         """include/nrs.h nrs_debug_nd_solve: the direct (nested-dissection) solver's device kernels on an explicit block system.

@@ -87,6 +87,8 @@ def test_plan_cache_reuse_is_invisible():
             assert np.array_equal(a0[k], a1[k]) and np.array_equal(a0[k], a2[k]), k
         assert a0["lost"] == a1["lost"] == a2["lost"]
         assert not np.array_equal(a0["pose_t"], b0["pose_t"])
+        reused, built = c.nd_cache_stats()
+        assert reused >= 2 and built >= 8                           # (two problems per frame: both of a1 and b0 hit, every first sight builds)
     finally:
         c.close()
     os.environ["NRS_ND_NO_CACHE"] = "1"
