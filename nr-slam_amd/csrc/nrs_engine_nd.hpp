@@ -24,7 +24,7 @@ typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 struct NdWgD { NdFrontD F; int I, J, pad; };          // one workgroup of k_nd_level: its front and its (I >= J) pair of row blocks
 struct NdDev {
-    const NdFrontD* fr; const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const NdWgD* wg; const NdFrontD* lvl_fr;
+    const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const NdWgD* wg; const NdFrontD* lvl_fr;
     const double* ev;                // 9 doubles per original entry (plan order): the blocks of the current linearisation
     double* A;                       // assembly areas: every front's Schur complement lands in its parent's index space
     double* Lp; double* xn;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         double t0 = lane < s ? W[rowI0 * ND_LD + lane] : 0.0, t1 = lane + 64 < s ? W[rowI0 * ND_LD + lane + 64] : 0.0;
         nd_back_solve(W, dinv, s, lane, t0, t1);
         nd_store_x(N, F, xo, lane, t0, t1);
-        if (lane == 0) N.done[F.cmap_off] = epoch;                 // (device copies of the descriptor: cmap_off = the front's own index)
+        if (lane == 0) N.done[F.cmap_off] = epoch;                 // (cmap_off of a device descriptor: the front's own index; published by the end of the launch)
     }
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
     // written into the parent's assembly slot at the parent's positions of its rows and columns (both triangles)
@@ -599,8 +599,7 @@ struct NdSolver {
     DevBuf own;                      // everything the kernels read: plan arrays, entry values, assembly areas, L, x ...
     DevBuf* buf = &own;              // ... in the solver's own buffer (the tap) or in the context's (engines: reused from frame to frame)
     std::vector<size_t> lvl_shm_fac;
-    std::vector<NdWgD> h_wg;
-    std::vector<NdFrontD> h_lf;
+    std::vector<char> h_stage;       // host image of the plan arrays (one upload)
     int epoch = 0;                   // solves so far (the flags of the single-launch back pass count them)
     size_t shm_back_all = 0;
     bool attr_set = false;
@@ -613,37 +612,37 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_fr = take(sizeof(NdFrontD) * P.fr.size()), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
+    const size_t o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
                  o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
                  o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size());
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
-    auto up = [&](size_t o, const void* src, size_t bytes) -> int {
-        if (bytes) NRS_HIP(c, hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, c->stream));
-        return NRS_OK;
-    };
-    NRS_TRY(up(o_fr, P.fr.data(), sizeof(NdFrontD) * P.fr.size()));
-    NRS_TRY(up(o_own, P.own.data(), 4 * P.own.size()));
-    NRS_TRY(up(o_bnd, P.bnd.data(), 4 * P.bnd.size()));
-    NRS_TRY(up(o_pm, P.pmap.data(), 2 * P.pmap.size()));
-    NRS_TRY(up(o_ent, P.ent.data(), sizeof(NdEnt) * P.ent.size()));
-    S.h_wg.resize(P.wg.size() / 3); S.h_lf.resize(P.lvl_fronts.size());       // (kept: the copies are asynchronous)
-    for (size_t w = 0; w < S.h_wg.size(); ++w) { S.h_wg[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0}; S.h_wg[w].F.cmap_off = P.wg[3 * w]; }
-    for (size_t i = 0; i < S.h_lf.size(); ++i) { S.h_lf[i] = P.fr[P.lvl_fronts[i]]; S.h_lf[i].cmap_off = P.lvl_fronts[i]; }   // (cmap_off is the host reference's: here the front's index)
-    NRS_TRY(up(o_wg, S.h_wg.data(), sizeof(NdWgD) * S.h_wg.size()));
-    NRS_TRY(up(o_lf, S.h_lf.data(), sizeof(NdFrontD) * S.h_lf.size()));
+    // the plan's arrays go up in ONE copy from a staging image that lives as long as the solver (the copy is asynchronous)
+    S.h_stage.assign(o_ev, 0);
+    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) memcpy(S.h_stage.data() + o, src, bytes); };
+    put(o_own, P.own.data(), 4 * P.own.size());
+    put(o_bnd, P.bnd.data(), 4 * P.bnd.size());
+    put(o_pm, P.pmap.data(), 2 * P.pmap.size());
+    put(o_ent, P.ent.data(), sizeof(NdEnt) * P.ent.size());
+    {
+        NdWgD* hw = reinterpret_cast<NdWgD*>(S.h_stage.data() + o_wg);
+        NdFrontD* hl = reinterpret_cast<NdFrontD*>(S.h_stage.data() + o_lf);
+        // (device copies of the descriptor: cmap_off, the host reference's gather map, holds the front's own index)
+        for (size_t w = 0; w < P.wg.size() / 3; ++w) { hw[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0}; hw[w].F.cmap_off = P.wg[3 * w]; }
+        for (size_t i = 0; i < P.lvl_fronts.size(); ++i) { hl[i] = P.fr[P.lvl_fronts[i]]; hl[i].cmap_off = P.lvl_fronts[i]; }
+    }
+    NRS_HIP(c, hipMemcpyAsync(base, S.h_stage.data(), o_ev, hipMemcpyHostToDevice, c->stream));
     NdDev& D = S.dev;
     memset(&D, 0, sizeof(D));
-    D.fr = reinterpret_cast<const NdFrontD*>(base + o_fr); D.own = reinterpret_cast<const int*>(base + o_own); D.bnd = reinterpret_cast<const int*>(base + o_bnd);
+    D.own = reinterpret_cast<const int*>(base + o_own); D.bnd = reinterpret_cast<const int*>(base + o_bnd);
     D.pmap = reinterpret_cast<const int16_t*>(base + o_pm); D.ent = reinterpret_cast<const NdEnt*>(base + o_ent);
     D.wg = reinterpret_cast<const NdWgD*>(base + o_wg); D.lvl_fr = reinterpret_cast<const NdFrontD*>(base + o_lf);
     S.d_ev = reinterpret_cast<double*>(base + o_ev); S.d_ent = D.ent;
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
     D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn);
-    NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, 64, c->stream));
-    NRS_HIP(c, hipMemsetAsync(base + o_dn, 0, 4 * P.fr.size(), c->stream));
+    NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, off - o_fl, c->stream));            // (status words and the fronts' flags)
     S.epoch = 0;
     // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
     NRS_HIP(c, hipMemsetAsync(base + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
@@ -680,6 +679,9 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
         hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch);
     }
+    // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that
+    // its workgroups stage their factors while the root is busy.  The two event waits cost more than the ~10 us of staging they hide:
+    // 224 -> 245 us per solve at 543 points, 503 -> 525 at 2220.)
     hipLaunchKernelGGL(k_nd_back, dim3(P.n_fronts), dim3(256), S.shm_back_all, c->stream, S.dev, (int)P.wg.size() / 3, P.n_fronts, epoch, (int)(S.shm_back_all / 8));
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
@@ -924,6 +926,7 @@ struct NdSlot {
     NdVals vals;
     DevBuf ws, vb;                   // S.buf = &ws (plan + factor storage), value descriptors
     std::vector<uint8_t> key;
+    std::vector<char> h_vals;        // host image of the value descriptors (one upload)
     uint64_t hash = 0, used = 0;     // (used: LRU stamp)
     bool busy = false, cached = false;
     int n_free = 0, n_pairs = 0;
@@ -1181,18 +1184,21 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
                  o_sc = o_st + al(4 * std::max<size_t>(1, ske_pt.size())), total = o_sc + al(8 * std::max<size_t>(1, ske_cf.size()));
     NRS_TRY(c->ensure(sl->vb, total));
     char* vb = sl->vb.as<char>();
-    NRS_HIP(c, hipMemcpyAsync(vb + o_nr, nrow.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(vb + o_no, node_out.data(), 4 * (size_t)n_nodes, hipMemcpyHostToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(vb + o_pd, pd.data(), sizeof(NdPairD) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_src, src.data(), 4 * src.size(), hipMemcpyHostToDevice, c->stream));
+    sl->h_vals.assign(total, 0);                                   // one upload from a staging image the slot keeps (no synchronisation)
+    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) memcpy(sl->h_vals.data() + o, src, bytes); };
+    put(o_nr, nrow.data(), 4 * (size_t)n_nodes);
+    put(o_no, node_out.data(), 4 * (size_t)n_nodes);
+    put(o_pd, pd.data(), sizeof(NdPairD) * (size_t)n_pairs);
+    put(o_src, src.data(), 4 * src.size());
     sl->vals.ske_ptr = nullptr; sl->vals.ske_pt = nullptr; sl->vals.ske_coef = nullptr;
     if (d.sk_n > 0) {
-        NRS_HIP(c, hipMemcpyAsync(vb + o_sp, ske_ptr.data(), 4 * ske_ptr.size(), hipMemcpyHostToDevice, c->stream));
-        if (!ske_pt.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_st, ske_pt.data(), 4 * ske_pt.size(), hipMemcpyHostToDevice, c->stream));
-        if (!ske_cf.empty()) NRS_HIP(c, hipMemcpyAsync(vb + o_sc, ske_cf.data(), 8 * ske_cf.size(), hipMemcpyHostToDevice, c->stream));
+        put(o_sp, ske_ptr.data(), 4 * ske_ptr.size());
+        put(o_st, ske_pt.data(), 4 * ske_pt.size());
+        put(o_sc, ske_cf.data(), 8 * ske_cf.size());
         sl->vals.ske_ptr = reinterpret_cast<const int*>(vb + o_sp); sl->vals.ske_pt = reinterpret_cast<const int*>(vb + o_st);
         sl->vals.ske_coef = reinterpret_cast<const double*>(vb + o_sc);
     }
+    NRS_HIP(c, hipMemcpyAsync(vb, sl->h_vals.data(), total, hipMemcpyHostToDevice, c->stream));
     sl->vals.node_row = reinterpret_cast<const int*>(vb + o_nr);
     sl->vals.pair = reinterpret_cast<const NdPairD*>(vb + o_pd);
     sl->vals.src = reinterpret_cast<const int*>(vb + o_src);
@@ -1200,7 +1206,6 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     sl->S.dev.node_out = reinterpret_cast<const int*>(vb + o_no);
     sl->n_free = n_free; sl->n_pairs = n_pairs;
     NRS_TRY(bind(sl));
-    NRS_HIP(c, hipStreamSynchronize(c->stream));                   // the staging vectors die here
     sl->key.swap(key); sl->hash = hash;
     sguard.keep = true;
     return NRS_OK;

@@ -97,7 +97,8 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     int stamp = 0;
     auto new_front = [&](std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; };
     std::vector<std::pair<double, int>> keyed;
-    auto axis_sort = [&](std::vector<int>& v, int skip_axis) {
+    // orders v along its longest axis (not skip_axis): completely (split < 0), or only so far that the `split` smallest come first
+    auto axis_sort = [&](std::vector<int>& v, int skip_axis, int split = -1) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int u : v)
             for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos[3 * (size_t)u + a]); hi[a] = std::max(hi[a], pos[3 * (size_t)u + a]); }
@@ -106,7 +107,8 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             if (a != skip_axis && (ax < 0 || hi[a] - lo[a] > hi[ax] - lo[ax])) ax = a;
         keyed.resize(v.size());                                    // (coordinate, id) pairs: the sort touches no indirect memory
         for (size_t i = 0; i < v.size(); ++i) keyed[i] = {pos[3 * (size_t)v[i] + ax], v[i]};
-        std::sort(keyed.begin(), keyed.end());
+        if (split < 0) std::sort(keyed.begin(), keyed.end());
+        else std::nth_element(keyed.begin(), keyed.begin() + split, keyed.end());       // (pairs are distinct: the two halves are determined)
         for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
         return ax;
     };
@@ -127,9 +129,10 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         std::vector<int> run(std::vector<int> v) {
             if (v.empty()) return {};
             if ((int)v.size() <= leaf_n) { asort(v, -1); return {mk_chain(v, {})}; }
-            const int ax = asort(v, -1);
             const size_t half = v.size() / 2;
+            const int ax = asort(v, -1, (int)half);
             std::vector<int> L(v.begin(), v.begin() + half), R(v.begin() + half, v.end());
+            std::sort(L.begin(), L.end()); std::sort(R.begin(), R.end());    // (a defined order inside the halves: node index)
             // the thinner of the two candidate separators: the L nodes that touch R, or the R nodes that touch L
             const int sl = ++stamp;
             for (int u : L) side[u] = sl;
@@ -185,24 +188,23 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     }
     // ---- boundaries (bottom-up), levels
     std::vector<std::vector<int>> bnd(nf);
-    std::vector<int> level(nf, 0), parent(nf, -1);
+    std::vector<int> level(nf, 0), parent(nf, -1), seen(n_nodes, -1);
     for (int f = 0; f < nf; ++f) {
         const int pmin = elim[F[f].own.front()], pmax = elim[F[f].own.back()];
         std::vector<int>& c = bnd[f];
+        auto take = [&](int u) { if (seen[u] != f) { seen[u] = f; c.push_back(elim[u]); } };   // (each node once: elimination positions, plain integer keys)
         for (int u : F[f].own)
-            for (int e = ap[u]; e < ap[u + 1]; ++e) if (elim[an[e]] > pmax) c.push_back(an[e]);
+            for (int e = ap[u]; e < ap[u + 1]; ++e) if (elim[an[e]] > pmax) take(an[e]);
         for (int ch : F[f].ch) {
             if (ch >= f) return fail("child created after its parent");
             parent[ch] = f;
             level[f] = std::max(level[f], level[ch] + 1);
             for (int u : bnd[ch]) {
-                if (elim[u] > pmax) c.push_back(u);
+                if (elim[u] > pmax) take(u);
                 else if (elim[u] < pmin) return fail("a child's boundary node is not in its parent");
             }
         }
-        for (int& u : c) u = elim[u];                              // (sorted as elimination positions: plain integer keys)
         std::sort(c.begin(), c.end());
-        c.erase(std::unique(c.begin(), c.end()), c.end());
         for (int& u : c) u = node_at[u];
         if (c.size() * 3 + 1 > 30000 || F[f].own.size() > (size_t)smax_n) return fail("front too large");
     }
