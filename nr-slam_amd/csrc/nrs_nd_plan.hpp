@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace nrs {
@@ -93,7 +94,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     // ---- separator tree by recursive coordinate bisection
     struct FH { std::vector<int> own, ch; };
     std::vector<FH> F;
-    std::vector<int> side(n_nodes, 0);
+    std::vector<int> side(n_nodes, 0), slot(n_nodes, 0);
     int stamp = 0;
     auto new_front = [&](std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; };
     std::vector<std::pair<double, int>> keyed;
@@ -125,7 +126,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     };
     struct Rec {
         std::vector<FH>& F; std::vector<int>& side; int& stamp; const std::vector<int>&ap, &an; const uint8_t* last;
-        decltype(axis_sort)& asort; decltype(chain)& mk_chain; int leaf_n;
+        decltype(axis_sort)& asort; decltype(chain)& mk_chain; int leaf_n; std::vector<int>& slot; bool vertex_cover;
         std::vector<int> run(std::vector<int> v) {
             if (v.empty()) return {};
             if ((int)v.size() <= leaf_n) { asort(v, -1); return {mk_chain(v, {})}; }
@@ -148,8 +149,50 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
                 return s;
             };
             std::vector<int> sepL = touching(L, sr), sepR = touching(R, sl);
-            const bool useL = sepL.size() <= sepR.size();
-            std::vector<int>& sep = useL ? sepL : sepR;
+            // the smallest set of nodes that covers every edge of the cut: a minimum vertex cover of the bipartite graph (sepL, sepR, cut
+            // edges), from a maximum matching (Koenig).  Never larger than the thinner side; on kNN graphs 10-25 % smaller, which takes
+            // chain links -- whole levels -- off the top of the tree
+            std::vector<int> sep;
+            if (!vertex_cover) sep = sepL.size() <= sepR.size() ? sepL : sepR;
+            else {
+                const int nl = (int)sepL.size(), nr = (int)sepR.size();
+                for (int j = 0; j < nr; ++j) slot[sepR[j]] = j;
+                std::vector<int> eptr(nl + 1, 0), eadj;
+                for (int i = 0; i < nl; ++i) {
+                    const int u = sepL[i];
+                    for (int e = ap[u]; e < ap[u + 1]; ++e) if (side[an[e]] == sr) eadj.push_back(slot[an[e]]);
+                    eptr[i + 1] = (int)eadj.size();
+                }
+                std::vector<int> ml(nl, -1), mr(nr, -1), seen(nr, -1);
+                // Kuhn's augmenting paths (a few dozen to a few hundred nodes a side)
+                int cur = 0;
+                std::function<bool(int)> augment = [&](int i) {
+                    for (int e = eptr[i]; e < eptr[i + 1]; ++e) {
+                        const int j = eadj[e];
+                        if (seen[j] == cur) continue;
+                        seen[j] = cur;
+                        if (mr[j] < 0 || augment(mr[j])) { ml[i] = j; mr[j] = i; return true; }
+                    }
+                    return false;
+                };
+                for (int i = 0; i < nl; ++i) { cur = i; augment(i); }
+                std::vector<int> stk;
+                // Z: reachable from the unmatched left nodes along alternating paths; cover = (left \ Z) + (right in Z)
+                std::vector<char> zl(nl, 0), zr(nr, 0);
+                stk.clear();
+                for (int i = 0; i < nl; ++i) if (ml[i] < 0) { zl[i] = 1; stk.push_back(i); }
+                while (!stk.empty()) {
+                    const int i = stk.back(); stk.pop_back();
+                    for (int e = eptr[i]; e < eptr[i + 1]; ++e) {
+                        const int j = eadj[e];
+                        if (zr[j] || ml[i] == j) continue;
+                        zr[j] = 1;
+                        if (mr[j] >= 0 && !zl[mr[j]]) { zl[mr[j]] = 1; stk.push_back(mr[j]); }
+                    }
+                }
+                for (int i = 0; i < nl; ++i) if (!zl[i]) sep.push_back(sepL[i]);
+                for (int j = 0; j < nr; ++j) if (zr[j]) sep.push_back(sepR[j]);
+            }
             const int ss = ++stamp;
             for (int u : sep) side[u] = ss;
             std::vector<int> A, B;
@@ -161,7 +204,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             asort(sep, ax);                                        // along the cut, so that the chunks of a long separator are contiguous
             return {mk_chain(sep, std::move(ra))};
         }
-    } rec{F, side, stamp, ap, an, last, axis_sort, chain, leaf_n};
+    } rec{F, side, stamp, ap, an, last, axis_sort, chain, leaf_n, slot, getenv("NRS_ND_NO_COVER") == nullptr};
     std::vector<int> regular, tail;
     for (int i = 0; i < n_nodes; ++i) (last && last[i] ? tail : regular).push_back(i);
     std::vector<int> roots = rec.run(std::move(regular));
