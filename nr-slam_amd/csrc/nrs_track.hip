@@ -620,26 +620,61 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     }
     mark("GetEdges 2 + walk");
     const int M2 = NV + L;
-    std::vector<double> x2(3 * (size_t)M2, 0.0), X02(3 * (size_t)M2, 0.0);
-    std::copy(delta_v.begin(), delta_v.end(), x2.begin());
-    std::copy(X0.begin(), X0.end(), X02.begin());
-    for (size_t o = 0; o < others.size(); ++o)
-        for (int k = 0; k < 3; ++k) x2[3 * ((size_t)M + o) + k] = delta[3 * (size_t)others[o] + k];
-    std::vector<float> uv2(2 * (size_t)M2, 0.f);
-    std::copy(uv.begin(), uv.end(), uv2.begin());
-    std::vector<int> lm_pose2(M2, 0);
-    std::vector<uint8_t> rflag2(M2, 0);
-    std::copy(rflag.begin(), rflag.end(), rflag2.begin());
-    for (size_t o = 0; o < others.size(); ++o) rflag2[M + o] = RF_FIXED;
+    // Only the free vertices (nodes the statistics left free, lost points) and what an edge ties them to take part: an edge between
+    // two fixed vertices is not in the problem (g2o skips allVerticesFixed edges; the engine masks them) and a fixed vertex no
+    // kept edge touches is read by nothing.  The engine is built on that part -- a few hundred vertices instead of all of them.
+    std::vector<uint8_t> rflag_all(M2, 0);
+    std::copy(rflag.begin(), rflag.end(), rflag_all.begin());
+    for (size_t o = 0; o < others.size(); ++o) rflag_all[M + o] = RF_FIXED;
+    std::vector<int> newid(M2, -1);
+    std::vector<uint8_t> keep_v(M2, 0), keep_e(E, 0);
+    for (int v = 0; v < M2; ++v) keep_v[v] = !(rflag_all[v] & RF_FIXED);
+    for (int k = 0; k < E; ++k) {
+        const int a = sp_ij[2 * (size_t)k], b = sp_ij[2 * (size_t)k + 1];
+        if (!(rflag_all[a] & RF_FIXED) || !(rflag_all[b] & RF_FIXED)) keep_e[k] = 1;
+    }
+    for (int k = 0; k < E; ++k) if (keep_e[k]) { keep_v[sp_ij[2 * (size_t)k]] = 1; keep_v[sp_ij[2 * (size_t)k + 1]] = 1; }
+    for (size_t q = 0; q < un_w.size(); ++q) { keep_v[un_ij[2 * q]] = 1; keep_v[un_ij[2 * q + 1]] = 1; }
+    int M2k = 0;
+    for (int v = 0; v < M2; ++v) if (keep_v[v]) newid[v] = M2k++;
+    std::vector<double> x2(3 * (size_t)M2k, 0.0), X02(3 * (size_t)M2k, 0.0);
+    std::vector<float> uv2(2 * (size_t)M2k, 0.f);
+    std::vector<int> lm_pose2(M2k, 0);
+    std::vector<uint8_t> rflag2(M2k, 0);
+    for (int v = 0; v < M2; ++v) {
+        const int nv = newid[v];
+        if (nv < 0) continue;
+        rflag2[nv] = rflag_all[v];
+        if (v < M) {
+            for (int k = 0; k < 3; ++k) { x2[3 * (size_t)nv + k] = delta_v[3 * (size_t)v + k]; X02[3 * (size_t)nv + k] = X0[3 * (size_t)v + k]; }
+            uv2[2 * (size_t)nv] = uv[2 * (size_t)v]; uv2[2 * (size_t)nv + 1] = uv[2 * (size_t)v + 1];
+        } else if (v < NV) {
+            for (int k = 0; k < 3; ++k) x2[3 * (size_t)nv + k] = delta[3 * (size_t)others[v - M] + k];
+        }
+    }
+    std::vector<int> sp_ij2, dm_idx2, un_ij2(un_ij.size());
+    std::vector<float> sp_d02, dm_w2;
+    std::vector<uint8_t> dm_active2;
+    for (int k = 0; k < E; ++k) {
+        if (!keep_e[k]) continue;
+        const int a = newid[sp_ij[2 * (size_t)k]], b = newid[sp_ij[2 * (size_t)k + 1]];
+        sp_ij2.insert(sp_ij2.end(), {a, b});
+        sp_d02.push_back(sp_d0[k]);
+        dm_idx2.insert(dm_idx2.end(), {-1, -1, newid[dm_idx[4 * (size_t)k + 2]], newid[dm_idx[4 * (size_t)k + 3]]});
+        dm_w2.push_back(dm_w[k]);
+        dm_active2.push_back(dm_active[k]);
+    }
+    for (size_t q = 0; q < un_ij.size(); ++q) un_ij2[q] = newid[un_ij[q]];
     const uint8_t pose_fixed = 1;
     EngineSpec s2 = s;
-    s2.M = M2;
+    s2.M = M2k;
     s2.poses = &pose_out;
     s2.pose_fixed = &pose_fixed;
     s2.x = x2.data(); s2.X0 = X02.data();
     s2.lm_pose = lm_pose2.data(); s2.uv = uv2.data(); s2.rflag = rflag2.data();
-    s2.dm_active = dm_active.data();
-    s2.n_un = (int)un_w.size(); s2.un_ij = un_ij.data(); s2.un_w = un_w.data();
+    s2.n_sp = (int)sp_d02.size(); s2.sp_ij = sp_ij2.data(); s2.sp_d0 = sp_d02.data();
+    s2.n_dm = (int)dm_w2.size(); s2.dm_idx = dm_idx2.data(); s2.dm_w = dm_w2.data(); s2.dm_active = dm_active2.data();
+    s2.n_un = (int)un_w.size(); s2.un_ij = un_ij2.data(); s2.un_w = un_w.data();
     s2.n_skin = 0;                                                // (the skinned observations take part in the two rounds only)
     engine_destroy(c, eng);
     eg.e = nullptr;
@@ -649,11 +684,11 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     mark("engine 2");
     NRS_TRY(engine_optimize(c, eng2, 10, 2, trace));
     mark("stage 2 solve");
-    std::vector<double> x_out(3 * (size_t)M2);
+    std::vector<double> x_out(3 * (size_t)M2k);
     NRS_TRY(engine_download(c, eng2, nullptr, x_out.data()));
     for (int li = 0; li < L; ++li) {
         for (int k = 0; k < 3; ++k)
-            map_pos[3 * (size_t)lost_ids[li] + k] = (float)x_out[3 * (size_t)(NV + li) + k] + map_pos[3 * (size_t)lost_ids[li] + k];
+            map_pos[3 * (size_t)lost_ids[li] + k] = (float)x_out[3 * (size_t)newid[NV + li] + k] + map_pos[3 * (size_t)lost_ids[li] + k];
         if (lost) lost[li] = lost_ids[li];
     }
     *n_lost = L;
