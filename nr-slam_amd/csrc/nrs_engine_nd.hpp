@@ -14,6 +14,7 @@
 // boundary then spread over the CUs without a second launch.  The right-hand side is one more boundary row, so the forward
 // substitution rides along; k_nd_back walks the levels back down (L11^T x = y - L21^T x_bnd).
 #pragma once
+#include <thread>
 #include "nrs_nd_plan.hpp"
 
 namespace nrs {
@@ -937,7 +938,7 @@ constexpr int ND_CACHE_SLOTS = 4;
 struct NdEngine {
     NdSlot* slot = nullptr;
     NdSolver& S() { return slot->S; }
-    std::vector<double> pos;         // row positions the dissection was built on (rebuilt when the fixed set changes)
+    std::vector<double> pos;         // vertex positions the dissection bisects (M x 3, the caller's vertex order)
     std::vector<uint8_t> sig;        // RF_FIXED of every vertex + the pose's flag at set-up
     bool on = false;
 };
@@ -984,197 +985,262 @@ static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
     return mode == 1 || n_free <= nmax;
 }
 
-// builds (or rebuilds) the plan for the engine's current fixed set; leaves nd->on = false if the problem does not qualify
-static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
-    Dev& d = e->d;
-    nd_slot_release(c, nd);                                        // (a rebuild after the fixed set changed: the old plan goes back to the cache)
-    std::vector<int> node_of(d.M, -1), node_row;
-    for (int v = 0; v < d.M; ++v)
-        if (!(e->h_rflag[e->vrow[v]] & RF_FIXED)) { node_of[v] = (int)node_row.size(); node_row.push_back(e->vrow[v]); }
-    const int n_free = (int)node_row.size();
-    if (!nd_wanted(c, d, n_free)) return NRS_OK;
-    for (size_t q = 0; q < e->dm_idx.size(); q += 4)
-        if (e->dm_idx[q] >= 0 || e->dm_idx[q + 1] >= 0) return NRS_OK;           // four-vertex dampers: a BA window, not this solver's problem
-    const bool pose_free = !e->h_pose_fixed[0];
-    const int n_nodes = n_free + (pose_free ? 2 : 0);
-    // ---- the key: everything below depends on these arrays only (and on the positions, which may be an earlier frame's)
-    NdCache* nc = static_cast<NdCache*>(c->nd_cache);
-    if (!nc) { nc = new (std::nothrow) NdCache(); if (!nc) return c->fail(NRS_ERR_ALLOC, "out of host memory"); c->nd_cache = nc; }
+// ---- set-up in two phases.  Phase A (nd_prep_run) needs the problem's STRUCTURE only -- which vertices are free, which pairs of
+// them an edge or a skinned observation couples -- in the caller's vertex order: it builds the pair lists and the cache key, looks
+// the key up and, on a miss, builds the plan.  engine_create runs it on a helper thread next to its own packing of the incidence
+// streams (both are host work: a 1k-point frame's 0.8 ms plan build disappears behind the 0.9 ms of packing).  Phase B
+// (nd_engine_finish) ties the plan to the engine's row layout: value descriptors (rows, incidence slots), uploads, the slot.
+struct NdIn {
+    int M = 0;
+    const uint8_t* rflag = nullptr;      // M, RF_* bits
+    bool pose_fixed = false;
+    int n_sp = 0; const int* sp_ij = nullptr;
+    int n_dm = 0; const int* dm_idx = nullptr;
+    int n_skin = 0; const int* sk_vert = nullptr; const double* sk_om = nullptr;
+    const double* vpos = nullptr;        // M x 3: where the dissection bisects
+};
+struct NdSkT { uint64_t k; int pt; double cf; };
+struct NdPrep {
+    bool wanted = false, plan_ok = false;
+    std::string err;
+    int n_free = 0, n_nodes = 0;
+    bool pose_free = false;
+    std::vector<int> node_of, node_vtx;                            // vertex -> node (-1: fixed), node -> vertex
+    std::vector<int> pairs;                                        // node pairs: row-row couplings (sorted, unique), then the pose's
+    std::vector<uint8_t> pkind;                                    // 0 row-row, 1 pose half (first node) - row, 2 pose - pose
+    std::vector<int> eptr, eid;                                    // row-row pair -> its edges in edge order: (index << 1) | (0 spring, 1 damper)
+    std::vector<uint8_t> last;
+    std::vector<NdSkT> skt;                                        // embedded mode: (pair, observation, weight product), sorted by pair
+    std::vector<int> nl_ptr, nl_pt, pair_sk0, pair_sk1;
+    std::vector<double> nl_om;
     std::vector<uint8_t> key;
+    uint64_t hash = 0;
+    NdSlot* hit = nullptr;
+    NdPlan plan;
+    std::thread th;
+    ~NdPrep() { if (th.joinable()) th.join(); }
+};
+
+static bool nd_mode_allows(nrs_ctx* c, int n_free) {
+    int mode = c->opt.direct_solve;
+    if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
+    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 3500;
+    return mode != 2 && n_free > 0 && (mode == 1 || n_free <= nmax);
+}
+
+static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
+    P.wanted = false; P.plan_ok = false; P.hit = nullptr;
+    P.node_of.assign(in.M, -1); P.node_vtx.clear();
+    for (int v = 0; v < in.M; ++v)
+        if (!(in.rflag[v] & RF_FIXED)) { P.node_of[v] = (int)P.node_vtx.size(); P.node_vtx.push_back(v); }
+    const int n_free = P.n_free = (int)P.node_vtx.size();
+    if (!nd_mode_allows(c, n_free)) return;
+    for (int q = 0; q < in.n_dm; ++q)
+        if (in.dm_idx[4 * (size_t)q] >= 0 || in.dm_idx[4 * (size_t)q + 1] >= 0) return;     // four-vertex dampers: a BA window, not this solver's problem
+    P.pose_free = !in.pose_fixed;
+    const int n_nodes = P.n_nodes = n_free + (P.pose_free ? 2 : 0);
+    const std::vector<int>& node_of = P.node_of;
+    // ---- the key: everything below (and the plan) depends on these arrays only -- and on the positions, which may be an earlier frame's
     {
-        std::vector<uint8_t> obs(n_free);
-        for (int a = 0; a < n_free; ++a) obs[a] = e->h_rflag[node_row[a]] & RF_OBS;
-        const int hdr[8] = {n_free, pose_free ? 1 : 0, d.M, d.n_rows, d.sk_n, ND_LEAFN, ND_SMAXN, (int)e->sp_ij.size()};
+        std::vector<uint8_t> bits(in.M);
+        for (int v = 0; v < in.M; ++v) bits[v] = in.rflag[v] & (RF_FIXED | RF_OBS);
+        const int hdr[8] = {n_free, P.pose_free ? 1 : 0, in.M, in.n_skin, ND_LEAFN, ND_SMAXN, in.n_sp, in.n_dm};
+        std::vector<uint8_t>& key = P.key;
+        key.clear();
         auto put = [&](const void* p, size_t bytes) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + bytes); };
-        key.reserve(sizeof(hdr) + 4 * (node_row.size() + e->sp_ij.size() + e->sp_pos.size() + e->dm_idx.size() + e->dm_pos.size()) + obs.size() +
-                    (d.sk_n > 0 ? (size_t)SK_MAX * d.sk_n * 12 : 0));
-        put(hdr, sizeof(hdr)); put(node_row.data(), 4 * node_row.size()); put(obs.data(), obs.size());
-        put(e->sp_ij.data(), 4 * e->sp_ij.size()); put(e->sp_pos.data(), 4 * e->sp_pos.size());
-        put(e->dm_idx.data(), 4 * e->dm_idx.size()); put(e->dm_pos.data(), 4 * e->dm_pos.size());
-        if (d.sk_n > 0) { put(e->sk_vert.data(), 4 * (size_t)SK_MAX * d.sk_n); put(e->sk_om.data(), 8 * (size_t)SK_MAX * d.sk_n); }
+        key.reserve(sizeof(hdr) + bits.size() + 8 * (size_t)in.n_sp + 16 * (size_t)in.n_dm + (size_t)SK_MAX * in.n_skin * 4);
+        put(hdr, sizeof(hdr)); put(bits.data(), bits.size());
+        put(in.sp_ij, 8 * (size_t)in.n_sp); put(in.dm_idx, 16 * (size_t)in.n_dm);
+        if (in.n_skin > 0) put(in.sk_vert, 4 * (size_t)SK_MAX * in.n_skin);
+        P.hash = nd_hash(key.data(), key.size());
     }
-    const uint64_t hash = nd_hash(key.data(), key.size());
-    const bool use_cache = !getenv("NRS_ND_NO_CACHE");
-    auto bind = [&](NdSlot* sl) -> int {                            // the engine's own vectors: where the solved step goes, the status words
-        sl->S.dev.out_rows = d.xv; sl->S.dev.out_pose = d.xp; sl->S.dev.flags = d.flags;
-        // rows the solver never writes (fixed, padding) keep a zero step; so does a fixed pose
-        NRS_HIP(c, hipMemsetAsync(d.xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
-        NRS_HIP(c, hipMemsetAsync(d.xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
-        nd->sig.assign((size_t)d.M + 1, 0);
-        for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
-        nd->sig[d.M] = e->h_pose_fixed[0];
-        sl->busy = true; sl->used = ++nc->clock;
-        nd->slot = sl; nd->on = true;
-        if (getenv("NRS_TIMING"))
-            fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", sl->n_free,
-                    sl->n_pairs, sl->S.plan.n_fronts, sl->S.plan.n_levels, (int)sl->S.plan.wg.size() / 3, sl->S.plan.flops / 1e6);
-        return NRS_OK;
-    };
-    if (use_cache)
-        for (NdSlot* sl : nc->slots)
-            if (!sl->busy && sl->hash == hash && sl->key == key) {
-                ++nc->hits;
-                if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve: plan of an earlier frame reused (%llu hits, %llu built)\n", (unsigned long long)nc->hits, (unsigned long long)nc->misses);
-                return bind(sl);
-            }
-    ++nc->misses;
-    // unique row-row couplings with the incidence slots that contribute to them
-    struct Key { uint64_t k; int src; };
+    // unique row-row couplings with the edges that contribute to them
+    struct Key { uint64_t k; int id; };
     std::vector<Key> keys;
-    keys.reserve(e->sp_ij.size() / 2 + e->dm_idx.size() / 4);
-    auto add = [&](int va, int vb, int slot, int kind) {
+    keys.reserve((size_t)in.n_sp + in.n_dm);
+    auto add = [&](int va, int vb, int id) {
         const int a = node_of[va], b = node_of[vb];
-        if (a < 0 || b < 0 || a == b || slot < 0) return;
-        keys.push_back(Key{((uint64_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), (slot << 1) | kind});
+        if (a < 0 || b < 0 || a == b) return;
+        keys.push_back(Key{((uint64_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), id});
     };
-    // (the factor of an edge sits in both endpoints' incidence slots with the same value when both are free: the first one is read)
-    for (size_t q = 0; q < e->sp_ij.size() / 2; ++q) add(e->sp_ij[2 * q], e->sp_ij[2 * q + 1], e->sp_pos[2 * q], 0);
-    for (size_t q = 0; q < e->dm_idx.size() / 4; ++q) add(e->dm_idx[4 * q + 2], e->dm_idx[4 * q + 3], e->dm_pos[4 * q + 2], 1);
+    for (int q = 0; q < in.n_sp; ++q) add(in.sp_ij[2 * (size_t)q], in.sp_ij[2 * (size_t)q + 1], q << 1);
+    for (int q = 0; q < in.n_dm; ++q) add(in.dm_idx[4 * (size_t)q + 2], in.dm_idx[4 * (size_t)q + 3], (q << 1) | 1);
     // embedded mode: the node pairs every skinned observation couples (all pairs of its <= 11 free nodes), with the products of
     // its weights, and per free node the observations that reach it; everything in observation order (fixed summation order)
-    struct SkT { uint64_t k; int pt; double cf; };
-    std::vector<SkT> skt;
-    std::vector<int> nl_ptr(n_free + 1, 0), nl_pt;
-    std::vector<double> nl_om;
-    if (d.sk_n > 0) {
+    std::vector<NdSkT>& skt = P.skt;
+    skt.clear();
+    P.nl_ptr.assign(n_free + 1, 0); P.nl_pt.clear(); P.nl_om.clear();
+    if (in.n_skin > 0) {
+        std::vector<int>& nl_ptr = P.nl_ptr;
         size_t n_pairs_sk = 0;
-        for (int i = 0; i < d.sk_n; ++i) {
+        for (int i = 0; i < in.n_skin; ++i) {
             int cnt = 0;
             for (int a = 0; a < SK_MAX; ++a) {
-                const int va = e->sk_vert[(size_t)SK_MAX * i + a];
+                const int va = in.sk_vert[(size_t)SK_MAX * i + a];
                 if (va >= 0 && node_of[va] >= 0) { nl_ptr[node_of[va] + 1]++; ++cnt; }
             }
             n_pairs_sk += (size_t)cnt * (cnt - 1) / 2;
         }
         for (int u = 0; u < n_free; ++u) nl_ptr[u + 1] += nl_ptr[u];
-        nl_pt.resize(nl_ptr[n_free]); nl_om.resize(nl_ptr[n_free]);
+        P.nl_pt.resize(nl_ptr[n_free]); P.nl_om.resize(nl_ptr[n_free]);
         std::vector<int> fill(nl_ptr.begin(), nl_ptr.end() - 1);
-        std::vector<SkT> raw;
+        std::vector<NdSkT> raw;
         raw.reserve(n_pairs_sk);
-        for (int i = 0; i < d.sk_n; ++i)
+        for (int i = 0; i < in.n_skin; ++i)
             for (int a = 0; a < SK_MAX; ++a) {
-                const int va = e->sk_vert[(size_t)SK_MAX * i + a];
+                const int va = in.sk_vert[(size_t)SK_MAX * i + a];
                 if (va < 0 || node_of[va] < 0) continue;
                 const int na = node_of[va];
-                nl_pt[fill[na]] = i; nl_om[fill[na]++] = e->sk_om[(size_t)SK_MAX * i + a];
+                P.nl_pt[fill[na]] = i; P.nl_om[fill[na]++] = in.sk_om[(size_t)SK_MAX * i + a];
                 for (int b = a + 1; b < SK_MAX; ++b) {
-                    const int vb = e->sk_vert[(size_t)SK_MAX * i + b];
+                    const int vb = in.sk_vert[(size_t)SK_MAX * i + b];
                     if (vb < 0 || node_of[vb] < 0 || node_of[vb] == na) continue;
                     const int nb2 = node_of[vb];
-                    raw.push_back(SkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), i, e->sk_om[(size_t)SK_MAX * i + a] * e->sk_om[(size_t)SK_MAX * i + b]});
+                    raw.push_back(NdSkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), i, in.sk_om[(size_t)SK_MAX * i + a] * in.sk_om[(size_t)SK_MAX * i + b]});
                 }
             }
         // by (low node, high node), observation order inside: two stable counting passes (least significant key first)
         skt.resize(raw.size());
         std::vector<int> cnt(n_free + 1);
         for (int pass = 0; pass < 2; ++pass) {
-            const std::vector<SkT>& in = pass == 0 ? raw : skt;
-            std::vector<SkT>& outv = pass == 0 ? skt : raw;
+            const std::vector<NdSkT>& inv = pass == 0 ? raw : skt;
+            std::vector<NdSkT>& outv = pass == 0 ? skt : raw;
             std::fill(cnt.begin(), cnt.end(), 0);
-            auto dig = [&](const SkT& t) { return pass == 0 ? (int)(t.k & 0xFFFFFFFFu) : (int)(t.k >> 32); };
-            for (const SkT& t : in) cnt[dig(t) + 1]++;
+            auto dig = [&](const NdSkT& t) { return pass == 0 ? (int)(t.k & 0xFFFFFFFFu) : (int)(t.k >> 32); };
+            for (const NdSkT& t : inv) cnt[dig(t) + 1]++;
             for (int u = 0; u < n_free; ++u) cnt[u + 1] += cnt[u];
-            for (const SkT& t : in) outv[cnt[dig(t)]++] = t;
+            for (const NdSkT& t : inv) outv[cnt[dig(t)]++] = t;
         }
         skt.swap(raw);
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; });
-    std::vector<int> pairs, src;
-    std::vector<NdPairD> pd;
-    std::vector<int> pair_sk0, pair_sk1;                           // per row-row pair: its range in skt
-    pairs.reserve(2 * (keys.size() + skt.size() / 4)); pd.reserve(keys.size() + skt.size() / 4);
+    P.pairs.clear(); P.pkind.clear(); P.eptr.assign(1, 0); P.eid.clear(); P.pair_sk0.clear(); P.pair_sk1.clear();
+    P.pairs.reserve(2 * (keys.size() + skt.size() / 4));
     // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
     for (size_t i = 0, st = 0; i < keys.size() || st < skt.size();) {
         const uint64_t kk = i < keys.size() && (st >= skt.size() || keys[i].k <= skt[st].k) ? keys[i].k : skt[st].k;
-        const int a = (int)(kk >> 32), b = (int)(kk & 0xFFFFFFFFu);
-        NdPairD p{0, node_row[a], node_row[b], (int)src.size(), 0};
-        for (; i < keys.size() && keys[i].k == kk; ++i) src.push_back(keys[i].src);
-        p.nsrc = (int)src.size() - p.src0;
-        pd.push_back(p);
-        pairs.push_back(a); pairs.push_back(b);
-        pair_sk0.push_back((int)st);
+        for (; i < keys.size() && keys[i].k == kk; ++i) P.eid.push_back(keys[i].id);
+        P.eptr.push_back((int)P.eid.size());
+        P.pairs.push_back((int)(kk >> 32)); P.pairs.push_back((int)(kk & 0xFFFFFFFFu));
+        P.pkind.push_back(0);
+        P.pair_sk0.push_back((int)st);
         while (st < skt.size() && skt[st].k == kk) ++st;
-        pair_sk1.push_back((int)st);
+        P.pair_sk1.push_back((int)st);
     }
-    std::vector<uint8_t> last(n_nodes, 0);
-    if (pose_free) {
-        last[n_free] = last[n_free + 1] = 1;
+    P.last.assign(n_nodes, 0);
+    if (P.pose_free) {
+        P.last[n_free] = P.last[n_free + 1] = 1;
         for (int a = 0; a < n_free; ++a)
-            if (e->h_rflag[node_row[a]] & RF_OBS)
-                for (int h = 0; h < 2; ++h) { pd.push_back(NdPairD{1, h, node_row[a], 0, 0}); pairs.push_back(n_free + h); pairs.push_back(a); }
-        pd.push_back(NdPairD{2, 0, 0, 0, 0}); pairs.push_back(n_free + 1); pairs.push_back(n_free);
+            if (in.rflag[P.node_vtx[a]] & RF_OBS)
+                for (int h = 0; h < 2; ++h) { P.pkind.push_back(1); P.pairs.push_back(n_free + h); P.pairs.push_back(a); }
+        P.pkind.push_back(2); P.pairs.push_back(n_free + 1); P.pairs.push_back(n_free);
     }
+    P.wanted = true;
+    // the cache (read only here: nobody changes it while an engine is being set up)
+    const NdCache* nc = static_cast<const NdCache*>(c->nd_cache);
+    if (nc && !getenv("NRS_ND_NO_CACHE"))
+        for (NdSlot* sl : nc->slots)
+            if (!sl->busy && sl->hash == P.hash && sl->key == P.key) { P.hit = sl; return; }
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
-        for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = nd->pos[3 * (size_t)node_row[a] + k];
-    std::string err;
-    const int n_pairs = (int)pd.size();
-    // a slot for the new plan: a free cached one (the least recently used is overwritten) or, if every cached slot is held by a
-    // live engine, one that lives as long as this engine
-    NdSlot* sl = nullptr;
-    if (use_cache) {
-        if ((int)nc->slots.size() < ND_CACHE_SLOTS) {
-            sl = new (std::nothrow) NdSlot();
-            if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory");
-            sl->cached = true;
-            nc->slots.push_back(sl);
-        } else
-            for (NdSlot* q : nc->slots)
-                if (!q->busy && (!sl || q->used < sl->used)) sl = q;
+        for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
+    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)P.pkind.size(), P.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
+}
+
+// phase B: leaves nd->on = false if the problem does not qualify
+static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
+    Dev& d = e->d;
+    if (P.th.joinable()) P.th.join();
+    nd_slot_release(c, nd);                                        // (a rebuild after the fixed set changed: the old plan goes back to the cache)
+    if (!P.wanted || !nd_wanted(c, d, P.n_free)) return NRS_OK;
+    const int n_free = P.n_free, n_nodes = P.n_nodes, n_pairs = (int)P.pkind.size();
+    NdCache* nc = static_cast<NdCache*>(c->nd_cache);
+    if (!nc) { nc = new (std::nothrow) NdCache(); if (!nc) return c->fail(NRS_ERR_ALLOC, "out of host memory"); c->nd_cache = nc; }
+    const bool use_cache = !getenv("NRS_ND_NO_CACHE");
+    NdSlot* sl = P.hit && !P.hit->busy ? P.hit : nullptr;
+    const bool hit = sl != nullptr;
+    if (!hit) {
+        if (!P.plan_ok) {
+            if (P.hit) {                                           // (cannot happen: the slot it found was taken meanwhile)
+                std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
+                for (int a = 0; a < n_free; ++a)
+                    for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = nd->pos[3 * (size_t)P.node_vtx[a] + k];
+                P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), n_pairs, P.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
+            }
+            if (!P.plan_ok) {
+                if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", P.err.c_str());
+                return NRS_OK;
+            }
+        }
+        ++nc->misses;
+        // a slot for the new plan: a free cached one (the least recently used is overwritten) or, if every cached slot is held by a
+        // live engine, one that lives as long as this engine
+        if (use_cache) {
+            if ((int)nc->slots.size() < ND_CACHE_SLOTS) {
+                sl = new (std::nothrow) NdSlot();
+                if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+                sl->cached = true;
+                nc->slots.push_back(sl);
+            } else
+                for (NdSlot* q : nc->slots)
+                    if (!q->busy && (!sl || q->used < sl->used)) sl = q;
+        }
+        if (!sl) { sl = new (std::nothrow) NdSlot(); if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory"); }
+    } else {
+        ++nc->hits;
+        if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve: plan of an earlier frame reused (%llu reused, %llu built)\n", (unsigned long long)nc->hits, (unsigned long long)nc->misses);
     }
-    if (!sl) { sl = new (std::nothrow) NdSlot(); if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory"); }
     struct SlotGuard {                                             // a slot whose set-up fails holds nothing valid
         nrs_ctx* c; NdSlot* sl; bool keep = false;
         ~SlotGuard() { if (keep) return; if (sl->cached) { sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF); sl->used = 0; } else nd_slot_free(c, sl); }
     } sguard{c, sl};
-    sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF);          // (matches no key while it is rebuilt)
-    sl->S.buf = &sl->ws;
-    if (!nd_build_plan(n_nodes, pos.data(), last.data(), n_pairs, pairs.data(), sl->S.plan, &err, ND_LEAFN, ND_SMAXN, false)) {
-        if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", err.c_str());
-        return NRS_OK;
+    if (!hit) {
+        sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF);      // (matches no key while it is rebuilt)
+        sl->S.buf = &sl->ws;
+        sl->S.plan = std::move(P.plan);
+        NRS_TRY(nd_upload(c, sl->S));
     }
-    NRS_TRY(nd_upload(c, sl->S));
-    std::vector<int> nrow(node_row);
-    std::vector<int> node_out(n_nodes);
-    for (int a = 0; a < n_free; ++a) node_out[a] = 3 * node_row[a];
-    if (pose_free) { nrow.push_back(-1); nrow.push_back(-2); node_out[n_free] = -1; node_out[n_free + 1] = -1 - 3; }
+    // ---- value descriptors: the plan's nodes and pairs in terms of this engine's rows and incidence slots
+    std::vector<int> nrow(n_nodes), node_out(n_nodes);
+    for (int a = 0; a < n_free; ++a) { nrow[a] = e->vrow[P.node_vtx[a]]; node_out[a] = 3 * nrow[a]; }
+    if (P.pose_free) { nrow[n_free] = -1; nrow[n_free + 1] = -2; node_out[n_free] = -1; node_out[n_free + 1] = -1 - 3; }
+    std::vector<NdPairD> pd(n_pairs);
+    std::vector<int> src;
+    src.reserve(P.eid.size());
+    const int n_rr = (int)P.eptr.size() - 1;
+    for (int i = 0; i < n_pairs; ++i) {
+        const int a = P.pairs[2 * (size_t)i], b = P.pairs[2 * (size_t)i + 1];
+        if (P.pkind[i] == 0) {
+            // (the factor of an edge sits in both endpoints' incidence slots with the same value when both are free: the first one is read)
+            pd[i] = NdPairD{0, nrow[a], nrow[b], (int)src.size(), 0};
+            for (int t = P.eptr[i]; t < P.eptr[i + 1]; ++t) {
+                const int id = P.eid[t] >> 1, kind = P.eid[t] & 1;
+                const int slot = kind ? e->dm_pos[4 * (size_t)id + 2] : e->sp_pos[2 * (size_t)id];
+                if (slot < 0) return NRS_OK;                       // (an incidence of another rank: not a single-frame engine)
+                src.push_back((slot << 1) | kind);
+            }
+            pd[i].nsrc = (int)src.size() - pd[i].src0;
+        } else if (P.pkind[i] == 1) pd[i] = NdPairD{1, a - n_free, nrow[b], 0, 0};
+        else pd[i] = NdPairD{2, 0, 0, 0, 0};
+    }
+    (void)n_rr;
     // embedded mode: per plan entry the observations that add to it
     std::vector<int> ske_ptr, ske_pt;
     std::vector<double> ske_cf;
     if (d.sk_n > 0) {
-        const NdPlan& P = sl->S.plan;
-        ske_ptr.assign(P.ent.size() + 1, 0);
-        ske_pt.reserve(4 * nl_pt.size() + skt.size()); ske_cf.reserve(4 * nl_pt.size() + skt.size());
-        for (size_t q = 0; q < P.ent.size(); ++q) {
-            const uint32_t kind = P.ent[q].src >> ND_KIND_SHIFT, idx = P.ent[q].src & ND_SRC_MASK;
+        const NdPlan& PL = sl->S.plan;
+        ske_ptr.assign(PL.ent.size() + 1, 0);
+        ske_pt.reserve(4 * P.nl_pt.size() + P.skt.size()); ske_cf.reserve(4 * P.nl_pt.size() + P.skt.size());
+        for (size_t q = 0; q < PL.ent.size(); ++q) {
+            const uint32_t kind = PL.ent[q].src >> ND_KIND_SHIFT, idx = PL.ent[q].src & ND_SRC_MASK;
             auto node_list = [&](int u, bool squared) {
                 if (u >= n_free) return;
-                for (int t = nl_ptr[u]; t < nl_ptr[u + 1]; ++t) { ske_pt.push_back(nl_pt[t]); ske_cf.push_back(squared ? nl_om[t] * nl_om[t] : nl_om[t]); }
+                for (int t = P.nl_ptr[u]; t < P.nl_ptr[u + 1]; ++t) { ske_pt.push_back(P.nl_pt[t]); ske_cf.push_back(squared ? P.nl_om[t] * P.nl_om[t] : P.nl_om[t]); }
             };
             if (kind == 0) node_list((int)idx, true);
             else if (kind == 2) node_list((int)idx, false);
-            else if (pd[idx].kind == 0) { for (int t = pair_sk0[idx]; t < pair_sk1[idx]; ++t) { ske_pt.push_back(skt[t].pt); ske_cf.push_back(skt[t].cf); } }
-            else if (pd[idx].kind == 1) node_list(pairs[2 * (size_t)idx + 1], false);
+            else if (P.pkind[idx] == 0) { for (int t = P.pair_sk0[idx]; t < P.pair_sk1[idx]; ++t) { ske_pt.push_back(P.skt[t].pt); ske_cf.push_back(P.skt[t].cf); } }
+            else if (P.pkind[idx] == 1) node_list(P.pairs[2 * (size_t)idx + 1], false);
             ske_ptr[q + 1] = (int)ske_pt.size();
         }
     }
@@ -1185,7 +1251,7 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     NRS_TRY(c->ensure(sl->vb, total));
     char* vb = sl->vb.as<char>();
     sl->h_vals.assign(total, 0);                                   // one upload from a staging image the slot keeps (no synchronisation)
-    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) memcpy(sl->h_vals.data() + o, src, bytes); };
+    auto put = [&](size_t o, const void* srcp, size_t bytes) { if (bytes) memcpy(sl->h_vals.data() + o, srcp, bytes); };
     put(o_nr, nrow.data(), 4 * (size_t)n_nodes);
     put(o_no, node_out.data(), 4 * (size_t)n_nodes);
     put(o_pd, pd.data(), sizeof(NdPairD) * (size_t)n_pairs);
@@ -1205,10 +1271,38 @@ static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
     sl->vals.ent = sl->S.d_ent; sl->vals.ev = sl->S.d_ev; sl->vals.n_ent = (int)sl->S.plan.ent.size();
     sl->S.dev.node_out = reinterpret_cast<const int*>(vb + o_no);
     sl->n_free = n_free; sl->n_pairs = n_pairs;
-    NRS_TRY(bind(sl));
-    sl->key.swap(key); sl->hash = hash;
+    // the engine's own vectors: where the solved step goes, the status words
+    sl->S.dev.out_rows = d.xv; sl->S.dev.out_pose = d.xp; sl->S.dev.flags = d.flags;
+    // rows the solver never writes (fixed, padding) keep a zero step; so does a fixed pose
+    NRS_HIP(c, hipMemsetAsync(d.xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
+    NRS_HIP(c, hipMemsetAsync(d.xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
+    nd->sig.assign((size_t)d.M + 1, 0);
+    for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
+    nd->sig[d.M] = e->h_pose_fixed[0];
+    sl->busy = true; sl->used = ++nc->clock;
+    nd->slot = sl; nd->on = true;
+    if (!hit) { sl->key.swap(P.key); sl->hash = P.hash; }
     sguard.keep = true;
+    if (getenv("NRS_TIMING"))
+        fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", sl->n_free,
+                sl->n_pairs, sl->S.plan.n_fronts, sl->S.plan.n_levels, (int)sl->S.plan.wg.size() / 3, sl->S.plan.flops / 1e6);
     return NRS_OK;
+}
+
+// both phases at once, from the engine's own mirrors (a rebuild after the fixed set changed)
+static int nd_engine_setup(nrs_ctx* c, Engine* e, NdEngine* nd) {
+    Dev& d = e->d;
+    std::vector<uint8_t> rf(d.M);
+    for (int v = 0; v < d.M; ++v) rf[v] = e->h_rflag[e->vrow[v]];
+    NdIn in;
+    in.M = d.M; in.rflag = rf.data(); in.pose_fixed = e->h_pose_fixed[0] != 0;
+    in.n_sp = (int)(e->sp_ij.size() / 2); in.sp_ij = e->sp_ij.data();
+    in.n_dm = (int)(e->dm_idx.size() / 4); in.dm_idx = e->dm_idx.data();
+    in.n_skin = d.sk_n; in.sk_vert = e->sk_vert.data(); in.sk_om = e->sk_om.data();
+    in.vpos = nd->pos.data();
+    NdPrep P;
+    nd_prep_run(c, in, P);
+    return nd_engine_finish(c, e, nd, P);
 }
 
 static void nd_engine_free(nrs_ctx* c, NdEngine* nd) { nd_slot_release(c, nd); delete nd; }

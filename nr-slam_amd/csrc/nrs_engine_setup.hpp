@@ -302,6 +302,25 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         memset(&d, 0, sizeof(d));
     }
     if (s.edges_on_device) return c->fail(NRS_ERR_STATE, "device-built edge lists need the device-side construction, which this window does not qualify for");
+    // a2's single-frame engines: the direct solver's symbolic phase needs the structure only and runs next to the packing below
+    NdPrep nd_prep;                                                // (declared after `guard`: joined before the engine can go away)
+    NdIn nd_in;
+    if (arena == &c->arena_trk && s.K == 1) {
+        e->nd = new (std::nothrow) NdEngine();
+        if (!e->nd) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+        e->nd->pos.resize(3 * (size_t)s.M);
+        for (size_t i = 0; i < 3 * (size_t)s.M; ++i) e->nd->pos[i] = s.x[i] + (s.X0 ? s.X0[i] : 0.0);
+        nd_in.M = s.M; nd_in.rflag = s.rflag; nd_in.pose_fixed = s.pose_fixed && s.pose_fixed[0];
+        nd_in.n_sp = s.n_sp; nd_in.sp_ij = s.sp_ij; nd_in.n_dm = s.n_dm; nd_in.dm_idx = s.dm_idx;
+        nd_in.n_skin = s.n_skin; nd_in.sk_vert = s.sk_node; nd_in.sk_om = s.sk_om;
+        nd_in.vpos = e->nd->pos.data();
+        bool inline_run = getenv("NRS_HOST_THREADS") && atoi(getenv("NRS_HOST_THREADS")) <= 1;
+        if (!inline_run) {
+            try { nd_prep.th = std::thread([c, &nd_in, &nd_prep] { nd_prep_run(c, nd_in, nd_prep); }); }
+            catch (const std::system_error&) { inline_run = true; }
+        }
+        if (inline_run) nd_prep_run(c, nd_in, nd_prep);
+    }
     int T = n_pad_rows >= 32768 ? 2 : 8;
     if (const char* ev = getenv("NRS_SELL_T")) {
         const int v = atoi(ev);
@@ -1047,13 +1066,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
         d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
     }
-    if (arena == &c->arena_trk && s.K == 1) {          // a2's single-frame engines: direct solve when the frame is small enough to gain from it
-        e->nd = new (std::nothrow) NdEngine();
-        if (!e->nd) return c->fail(NRS_ERR_ALLOC, "out of host memory");
-        e->nd->pos.assign(3 * (size_t)d.n_rows, 0.0);
-        for (int v = 0; v < s.M; ++v)
-            for (int k = 0; k < 3; ++k) e->nd->pos[3 * (size_t)e->vrow[v] + k] = s.x[3 * (size_t)v + k] + (s.X0 ? s.X0[3 * (size_t)v + k] : 0.0);
-        NRS_TRY(nd_engine_setup(c, e, e->nd));
+    if (e->nd) {                                                   // direct solve when the frame is small enough to gain from it
+        NRS_TRY(nd_engine_finish(c, e, e->nd, nd_prep));
         mark("direct solve plan");
         if (s.n_skin > 0 && !e->nd->on) return c->fail(NRS_ERR_STATE, "skinned observations need the direct solver (nrs_options.direct_solve = 2 or a problem it does not take)");
     }
