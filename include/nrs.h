@@ -77,8 +77,9 @@ typedef struct {
     int32_t direct_solve;     /* linear solver of the single-frame problems (nrs_track_deform_solve[_rg]):
                                  0 (default): a sparse direct solve (nested dissection, multifrontal Cholesky on the
                                  matrix cores: what LinearSolverEigen does, linear_solver_eigen.h:92-173) for frames of
-                                 up to 3500 free rows (1.4 .. 3.9 x faster than the PCG there, level beyond ~4.5k on
-                                 the all-pairs graph: DESIGN.md section 1), PCG beyond; 1: direct whenever the problem has the single-frame structure; 2: always
+                                 up to 8000 free rows (1.1 .. 4.4 x faster than the PCG at every measured size, 129 ..
+                                 4525 points: DESIGN.md section 1), PCG beyond; 1: direct whenever the problem has the
+                                 single-frame structure; 2: always
                                  PCG.  Same LM iterates either way (both are held to the oracle).  BA windows always
                                  use PCG. */
 } nrs_options;

@@ -972,17 +972,19 @@ static inline uint64_t nd_hash(const uint8_t* p, size_t n) {
     return h;
 }
 
-static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
-    // nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments.
-    // Measured (tools/nd_crossover.py, a2 per frame, direct / PCG ms; flat kNN-16 graph): 129 points 8.7 / 34.2, 543: 18.2 / 53.5,
-    // 1013: 22.4 / 29.1, 2220: 41.9 / 46.6, 3165: 51.1 / 61.3, 4525: 66.2 / 76.4; on the all-pairs graph (22 neighbours per point
-    // instead of 13: heavier fronts) 543: 21.2 / 52.9, 1013: 31.6 / 62.6, 2220: 38.7 / 62.0, 3165: 48.0 / 68.2, 4525: 91.1 / 87.3.
-    // The default window ends where the two meet on the denser graph.
+// nrs_options.direct_solve (0: by size, 1: whenever possible, 2: never); NRS_ND / NRS_ND_MAX_ROWS override it for experiments.
+// Measured (tools/nd_crossover.py, a2 per frame with a fresh plan per call, direct / PCG ms; flat kNN-16 graph): 129 points 7.9 / 34.6,
+// 543: 13.1 / 52.8, 1013: 17.3 / 28.3, 2220: 32.7 / 45.6, 3165: 40.7 / 60.3, 4525: 58.3 / 75.1; on the all-pairs graph (22 neighbours
+// per point instead of 13: heavier fronts) 543: 15.5 / 51.7, 1013: 22.4 / 61.8, 2220: 28.3 / 59.7, 3165: 39.8 / 66.3, 4525: 76.3 / 85.0.
+// Ahead at every measured size; the default window ends where nothing has been measured.
+static bool nd_mode_allows(nrs_ctx* c, int n_free) {
     int mode = c->opt.direct_solve;
     if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
-    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 3500;
-    if (mode == 2 || d.K != 1 || !d.use_lds || d.dform || d.sh_on || n_free <= 0) return false;
-    return mode == 1 || n_free <= nmax;
+    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 8000;
+    return mode != 2 && n_free > 0 && (mode == 1 || n_free <= nmax);
+}
+static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
+    return nd_mode_allows(c, n_free) && d.K == 1 && d.use_lds && !d.dform && !d.sh_on;
 }
 
 // ---- set-up in two phases.  Phase A (nd_prep_run) needs the problem's STRUCTURE only -- which vertices are free, which pairs of
@@ -1021,12 +1023,6 @@ struct NdPrep {
     ~NdPrep() { if (th.joinable()) th.join(); }
 };
 
-static bool nd_mode_allows(nrs_ctx* c, int n_free) {
-    int mode = c->opt.direct_solve;
-    if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
-    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 3500;
-    return mode != 2 && n_free > 0 && (mode == 1 || n_free <= nmax);
-}
 
 static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     P.wanted = false; P.plan_ok = false; P.hit = nullptr;

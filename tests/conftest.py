@@ -34,9 +34,10 @@ def ctx():
 
 @pytest.fixture(scope="session")
 def ctx_exact():
-    """Context with nrs_options.exact_trials = 1: every LM trial is solved to pcg_rtol."""
+    """Context with nrs_options.exact_trials = 1: every LM trial is solved to pcg_rtol (on the PCG: direct_solve = 2 -- the
+    direct solver, the default for single-frame problems, has no inexact trials to switch off)."""
     import nrs
-    c = nrs.Context(exact_trials=1)
+    c = nrs.Context(exact_trials=1, direct_solve=2)
     yield c
     c.close()
 

@@ -1,6 +1,6 @@
 """GPU parity: a2 (CameraPoseAndDeformationOptimization, reference modules/optimization/g2o_optimization.cc:148-557) at the
 size bench.py's tracked-fps figure is measured on -- ~4.4k points of one frame, the map's graph at the reference's all-pairs
-density, the two-level preconditioner / the solver selection on their natural paths -- against the oracle's output committed
+density, on the default solver (the direct one) and on the PCG with its two-level preconditioner -- against the oracle's output committed
 in tests/golden/track5k_{pinhole,kb8}.npz (tests/golden/make_track5k_golden.py ran oracle/nrs_oracle.track_deform_solve on
 oracle/rgraph_oracle.DenseGraph once in the build container: minutes per frame).  The inputs are regenerated here from the
 same seeds (nrs_synth is deterministic; the fixture carries a checksum of them).
@@ -67,7 +67,14 @@ def test_track5k_exact_trials(ctx_exact, name, model, seed):
     assert not any(t["early"] for t in tr.trials)
 
 
-def test_track5k_direct_solver(ctx_direct):
-    """the same frame on the nested-dissection Cholesky (nrs_options.direct_solve = 1; by default frames of this size run the PCG)"""
-    tr = _run(ctx_direct, *CASES[0])
+def test_track5k_default_is_the_direct_solver(ctx):
+    """by default a frame of this size runs on the nested-dissection Cholesky (nrs_options.direct_solve = 0: up to 8000 free rows)"""
+    tr = _run(ctx, *CASES[0])
     assert all(t["inner"] == 1 for t in tr.trials)
+
+
+@pytest.mark.parametrize("name,model,seed", CASES)
+def test_track5k_pcg_solver(ctx_pcg, name, model, seed):
+    """the same frames on the PCG with the two-level preconditioner and early trial rejection (nrs_options.direct_solve = 2)"""
+    tr = _run(ctx_pcg, name, model, seed)
+    assert max(t["inner"] for t in tr.trials) > 1

@@ -2,6 +2,7 @@
 PCG (= 2); decides the size window of the default (direct_solve = 0).   python tools/nd_crossover.py [--dense] [n ...]
 (--dense: on the device-resident all-pairs graph, nrs_track_deform_solve_rg, as bench.py's tracked_fps)"""
 import os, sys, time
+os.environ["NRS_ND_NO_CACHE"] = "1"          # the frame is repeated: every call builds its symbolic factorisation, as a new frame does
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nr-slam_amd/py"))
 import numpy as np, nrs, nrs_synth as S
