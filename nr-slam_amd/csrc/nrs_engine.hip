@@ -236,7 +236,7 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
 
 // errors (+ linearisation) at a given state; leaves chi2 (and max diag) in scal[]
 template <bool LIN>
-static int evaluate(nrs_ctx* c, Engine* e, int which) {
+static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) {
     if (LIN) { e->d.lin_pose = e->d.pose[which]; e->d.lin_xl = e->d.xl[which]; }   // the PCG kernels re-form factors from it
     const Dev& d = e->d;
     const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
@@ -281,7 +281,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which) {
             launch_reg<LIN>(c, d, d.xl[which]);
         }
     } else {
-        hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
+        if (!reproj_done) hipLaunchKernelGGL((k_reproj<LIN>), gg, b, 0, c->stream, d, d.pose[which], d.xl[which]);
         if (d.ec_on) hipLaunchKernelGGL(k_chi_edges, dim3(std::max(1, d.ec_nblk)), b, 0, c->stream, d, d.xl[which]);
         else launch_reg<LIN>(c, d, d.xl[which]);
     }
@@ -533,9 +533,13 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             else NRS_TRY(pcg_begin(c, e, lam, &pit));
             auto eval_trial = [&]() -> int {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
-                hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                const bool one_pose = d.K == 1 && !d.sh_on;      // a2's engines: trial state and reprojection chi2 in one launch
+                if (one_pose)
+                    hipLaunchKernelGGL(k_apply_reproj, dim3(((d.sh_ng + 7) / 8) * 8), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
+                else
+                    hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
                 if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo, c->stream));   // the regularisers read the neighbours' boundary keyframes
-                NRS_TRY(evaluate<false>(c, e, trial));
+                NRS_TRY(evaluate<false>(c, e, trial, one_pose));
                 return read_scalars(c, e);                 // one synchronisation: chi2, scale and the PCG flags
             };
             const bool peeking = !c->opt.exact_trials;

@@ -1188,21 +1188,21 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         // a slot for the new plan: a free cached one (the least recently used is overwritten) or, if every cached slot is held by a
         // live engine, one that lives as long as this engine
         if (use_cache) {
-            // (device memory: a free slot whose buffer already holds this plan is taken before a new or smaller one -- the factor and
-            // assembly storage of a 4.5k-point frame is ~100 MB, and a hipMalloc per frame costs milliseconds)
-            const size_t need = 8 * (P.plan.L_doubles + P.plan.A_doubles);
-            NdSlot* fits = nullptr;
-            for (NdSlot* q : nc->slots)
-                if (!q->busy && q->ws.cap >= need + need / 16 && (!fits || q->used < fits->used)) fits = q;
-            if (fits) sl = fits;
-            else if ((int)nc->slots.size() < ND_CACHE_SLOTS) {
+            // a new slot while there is room; then the least recently used one among those whose buffer already holds this plan (the
+            // factor and assembly storage of a 4.5k-point frame is ~100 MB: a hipMalloc per frame costs milliseconds); else the largest
+            if ((int)nc->slots.size() < ND_CACHE_SLOTS) {
                 sl = new (std::nothrow) NdSlot();
                 if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory");
                 sl->cached = true;
                 nc->slots.push_back(sl);
-            } else
+            } else {
+                const size_t need = 8 * (P.plan.L_doubles + P.plan.A_doubles);
                 for (NdSlot* q : nc->slots)
-                    if (!q->busy && (!sl || q->ws.cap > sl->ws.cap)) sl = q;       // (the largest buffer grows)
+                    if (!q->busy && q->ws.cap >= need + need / 16 && (!sl || q->used < sl->used)) sl = q;
+                if (!sl)
+                    for (NdSlot* q : nc->slots)
+                        if (!q->busy && (!sl || q->ws.cap > sl->ws.cap)) sl = q;
+            }
         }
         if (!sl) { sl = new (std::nothrow) NdSlot(); if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory"); }
     } else {

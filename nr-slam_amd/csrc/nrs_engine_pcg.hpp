@@ -1217,6 +1217,64 @@ __global__ __launch_bounds__(BLK) void k_apply(Dev P, double lam, const Pose* __
     if (tid == 0) P.part_apply[P.sh_vb0 + blockIdx.x] = sc[0];
 }
 
+// k_apply and k_reproj<false> in one launch for single-pose problems (a2's per-frame engines, where an LM trial is a handful of
+// launch-bound kernels behind the direct solve): the trial state and, from it, the chi2 of the reprojection edges, with the
+// expressions -- and so the bits -- of the two kernels it stands for.  One workgroup per row group, as both of them.
+__global__ __launch_bounds__(BLK) void k_apply_reproj(Dev P, double lam, const Pose* __restrict__ pose_in, const double* __restrict__ xl_in,
+                                                      Pose* pose_out, double* xl_out) {
+    __shared__ double lds[4];
+    const int gi = xcd_tile(blockIdx.x, P.sh_ng);
+    if (gi >= P.sh_ng) return;
+    const int g = P.sh_g0 + gi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = g * ROW_ALIGN + tid;
+    Pose Tcw = pose_in[0];
+    const bool pfix = P.pose_fixed[0] != 0;
+    double sc[1] = {0};
+    {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t j = 3 * (size_t)row + k;
+            const double x = P.xv[j];
+            xl_out[j] = xl_in[j] + x;
+            sc[0] += x * (lam * x + P.bl[j]);
+        }
+    }
+    if (!pfix) {                                                   // (every workgroup: the pose is six numbers)
+        double upd[6];
+        for (int a = 0; a < 6; ++a) {
+            upd[a] = P.xp[a];
+            if (g == 0 && tid == 0) sc[0] += upd[a] * (lam * upd[a] + P.bp[a]);
+        }
+        pose_oplus(Tcw, upd);
+    }
+    if (g == 0 && tid == 0) pose_out[0] = Tcw;
+    block_sum<1>(sc, lds, lane, wave);
+    if (tid == 0) P.part_apply[g] = sc[0];
+    __syncthreads();                                               // (lds is reused)
+    double R[9];
+    quat_to_R(Tcw.q, R);
+    const int rf = P.rflag[row];
+    const bool rfix = (rf & RF_FIXED) != 0;
+    const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE) && !(pfix && rfix);
+    double c1[1] = {0};
+    if (active) {
+        double x0 = xl_in[3 * row] + P.xv[3 * row], x1 = xl_in[3 * row + 1] + P.xv[3 * row + 1], x2 = xl_in[3 * row + 2] + P.xv[3 * row + 2];
+        if (P.X0) { x0 += P.X0[3 * row]; x1 += P.X0[3 * row + 1]; x2 += P.X0[3 * row + 2]; }
+        const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + Tcw.t[0];
+        const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + Tcw.t[1];
+        const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + Tcw.t[2];
+        float u, v;
+        project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
+        const double r0 = (double)P.uv[2 * row] - (double)u, r1 = (double)P.uv[2 * row + 1] - (double)v;
+        double rho0, rho1;
+        huber(P.info_reproj * (r0 * r0 + r1 * r1), P.delta_reproj, rho0, rho1);
+        c1[0] = rho0;
+    }
+    block_sum<1>(c1, lds, lane, wave);
+    if (tid == 0) P.part_rchi[g] = c1[0];
+}
+
 // sharded download: a rank's own rows, zeros elsewhere (summed over the ranks afterwards)
 __global__ void k_mask_rows(Dev P, const double* __restrict__ in, double* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
