@@ -25,7 +25,7 @@ typedef double nd_v4d __attribute__((ext_vector_type(4)));
 
 struct NdWgD { NdFrontD F; int I, J, pad; };          // one workgroup of k_nd_level: its front and its (I >= J) pair of row blocks
 struct NdDev {
-    const int* own; const int* bnd; const int16_t* pmap; const NdEnt* ent; const NdWgD* wg; const NdFrontD* lvl_fr;
+    const int* own; const int* bnd; const int* seg; const int16_t* pmap; const NdEnt* ent; const NdWgD* wg; const NdFrontD* lvl_fr;
     const double* ev;                // 9 doubles per original entry (plan order): the blocks of the current linearisation
     double* A;                       // assembly areas: every front's Schur complement lands in its parent's index space
     double* Lp; double* xn;
@@ -495,13 +495,16 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
 
 // back substitution, x_own = L11^-T (y - L21^T x_bnd), all levels in ONE launch: one workgroup per front, top-down in block
 // order.  A workgroup first brings everything that does not depend on the unknowns above it on chip -- (L11^-1)^T into LDS, L21
-// into registers (the first 32 rows per thread group) and LDS (as many further rows as fit), y, output indices -- then waits for
-// its parent's flag (release / acquire at agent scope; the boundary values are read past the caches).  Per level the critical
-// path is the flag, the boundary gather, two matrix-vector products from registers / LDS and the publication of the result: no
-// triangular solve, no global read of the factor.  A workgroup only waits for one with a smaller block index (dispatched before
-// it), so a full chip cannot deadlock; the wait is bounded all the same.
+// into registers (the first 32 rows per thread group) and LDS (as many further rows as fit), y, output indices.  Its boundary is
+// sorted by owner (NdFrontD::seg_off: the parent's unknowns first, the root's last), and the owners finish root first: the
+// workgroup takes the segments from the far end, waits for each owner's flag (release / acquire at agent scope; the values are
+// read past the caches) and adds that owner's part of L21^T x_bnd -- so whatever does not fit on chip (the tail of a large
+// boundary: the oldest ancestors) is read from global memory while the nearer ancestors are still busy, and what is left when the
+// parent publishes is its own segment out of registers / LDS, the product with (L11^-1)^T and the publication: ~5 us per level,
+// no triangular solve, no global read of the factor on the critical path.  A workgroup only waits for one with a smaller block
+// index (dispatched before it), so a full chip cannot deadlock; the wait is bounded all the same.
 constexpr int ND_BACK_UR = 32;
-__host__ __device__ inline int nd_back_fixed_doubles(int b) { return ND_S16 * ND_LD + 512 + 128 + ((b + 1) & ~1); }
+__host__ __device__ inline int nd_back_fixed_doubles(int b) { return ND_S16 * ND_LD + 512 + 128 + ((b + 1) & ~1) + ((b / 3 + 2) >> 1); }
 __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts, int epoch, int lds_doubles) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -514,7 +517,8 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
     double* tv = part + 512;                                       // [128]: y - L21^T x_bnd
     double* xb = tv + 128;                                         // [b]
-    double* L21s = xb + ((b + 1) & ~1);
+    int* bnode = reinterpret_cast<int*>(xb + ((b + 1) & ~1));      // [b / 3]: nodes of the boundary
+    double* L21s = xb + ((b + 1) & ~1) + ((b / 3 + 2) >> 1);
     const double* L = N.Lp + F.L_off;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(clk0 + li) + k] = wall_clock64(); };
     stamp(0);
@@ -526,56 +530,86 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     NdOut xo = {};
     if (wave == 0) xo = nd_out_request(N, F, lane);
     const double yq = tid < s ? L[(size_t)m * s + tid] : 0.0;
-    int bn[2];                                                     // nodes of this thread's boundary unknowns (the first 512: requested now)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) bn[u] = tid + 256 * u < b ? N.bnd[F.bnd_off + (tid + 256 * u) / 3] : 0;
+    for (int i = tid; i < b / 3; i += 256) bnode[i] = N.bnd[F.bnd_off + i];
     const double* Lq = L + (size_t)s * s + min(q, s - 1);
     double lr[ND_BACK_UR];
 #pragma unroll
     for (int u = 0; u < ND_BACK_UR; ++u) lr[u] = Lq[(size_t)min(g + u * ng, b - 1) * s];
     {
+        // (all requests of a staging step in flight together: a plain copy loop waits for every load before the next goes out --
+        // 36 + 40 dependent round trips, 70 us for a front with a boundary of 70 nodes)
         const int tx = tid & 31, ty = tid >> 5;
         const double* LT = L + (size_t)(m + 2) * s;
-        for (int r = ty; r < s; r += 8)
-            for (int p = tx; p < s; p += 32) Ls[r * ND_LD + p] = p >= r ? LT[(size_t)r * s + p] : 0.0;
-        const double* L2 = L + (size_t)(s + nreg) * s;              // (rows are contiguous)
-        for (int i = tid; i < nl * s; i += 256) L21s[i] = L2[i];
-    }
-    if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(N.done + F.par, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { N.flags[2] = 2; break; }      // (cannot happen: parents are dispatched first; never hang the device)
+        double v[12][3];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int r = ty + 8 * i, p = tx + 32 * j;
+                v[i][j] = (r < s && p < s && p >= r) ? LT[(size_t)r * s + p] : 0.0;
+            }
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int r = ty + 8 * i, p = tx + 32 * j;
+                if (r < s && p < s) Ls[r * ND_LD + p] = v[i][j];
+            }
+        const double* L2 = L + (size_t)(s + nreg) * s;              // (rows are contiguous; s is a multiple of 3, the panel offset of 2 doubles: 8-byte accesses)
+        const int n = nl * s;
+#pragma unroll 1
+        for (int i0 = tid; i0 < n; i0 += 256 * 20) {
+            double w[20];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) w[u] = L2[min(i0 + 256 * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) if (i0 + 256 * u < n) L21s[i0 + 256 * u] = w[u];
         }
     }
-    __syncthreads();
-    stamp(4);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (tid + 256 * u < b) xb[tid + 256 * u] = __hip_atomic_load(N.xn + 3 * (size_t)bn[u] + (tid + 256 * u) % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid + 512; i < b; i += 256) xb[i] = __hip_atomic_load(N.xn + 3 * (size_t)N.bnd[F.bnd_off + i / 3] + i % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    stamp(1);
-    {
-        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    stamp(5);
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int2* seg = reinterpret_cast<const int2*>(N.seg) + F.seg_off;
+#pragma unroll 1
+    for (int sg = F.n_seg - 1; sg >= 0; --sg) {
+        const int2 S2 = seg[sg];
+        const int r0 = sg > 0 ? seg[sg - 1].y : 0, r1 = S2.y;
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(N.done + S2.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {   // (plain polls: one acquire at the end)
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 23)) { N.flags[2] = 2; break; }  // (cannot happen: ancestors are dispatched first; never hang the device)
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+        if (sg == 0) stamp(4);
+        for (int i = r0 + tid; i < r1; i += 256) xb[i] = __hip_atomic_load(N.xn + 3 * (size_t)bnode[i / 3] + i % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sg == 0) stamp(1);
         if (q < s) {
+            if (r0 < nreg) {
 #pragma unroll
-            for (int u = 0; u < ND_BACK_UR; ++u) if (g + u * ng < b) a8[u & 7] += lr[u] * xb[g + u * ng];
-            int r = nreg + g;
-            for (; r + 3 * ng < nreg + nl; r += 4 * ng) {
+                for (int u = 0; u < ND_BACK_UR; ++u) { const int r = g + u * ng; if (r >= r0 && r < r1) a8[u & 7] += lr[u] * xb[r]; }
+            }
+            // this thread's rows in [max(r0, nreg), r1): r = g (mod ng)
+            int r = max(r0, nreg);
+            r += (g - r % ng + ng) % ng;
+            const int e1 = min(r1, nreg + nl);
+            for (; r + 3 * ng < e1; r += 4 * ng) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a8[u] += L21s[(r + u * ng - nreg) * s + q] * xb[r + u * ng];
             }
-            for (; r < nreg + nl; r += ng) a8[0] += L21s[(r - nreg) * s + q] * xb[r];
-            for (; r + 7 * ng < b; r += 8 * ng) {
-                double l8[8];
+            for (; r < e1; r += ng) a8[0] += L21s[(r - nreg) * s + q] * xb[r];
+            for (; r < r1; r += 24 * ng) {                         // (rows beyond the chip: 24 requests in flight per thread)
+                double l24[24];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) l8[u] = Lq[(size_t)(r + u * ng) * s];
+                for (int u = 0; u < 24; ++u) l24[u] = Lq[(size_t)min(r + u * ng, b - 1) * s];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a8[u] += l8[u] * xb[r + u * ng];
+                for (int u = 0; u < 24; ++u) if (r + u * ng < r1) a8[u & 7] += l24[u] * xb[r + u * ng];
             }
-            for (; r < b; r += ng) a8[0] += Lq[(size_t)r * s] * xb[r];
         }
+    }
+    {
         const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         if (q < 128) {
             for (int gg = g; gg < 4; gg += ng) part[gg * 128 + q] = gg == g ? acc : 0.0;    // (unused group slots: zero)
@@ -629,7 +663,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
+    const size_t o_seg = take(4 * std::max<size_t>(2, P.seg.size())), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
                  o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
                  o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size());
@@ -638,6 +672,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     // the plan's arrays go up in ONE copy from a staging image that lives as long as the solver (the copy is asynchronous)
     S.h_stage.assign(o_ev, 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) memcpy(S.h_stage.data() + o, src, bytes); };
+    put(o_seg, P.seg.data(), 4 * P.seg.size());
     put(o_own, P.own.data(), 4 * P.own.size());
     put(o_bnd, P.bnd.data(), 4 * P.bnd.size());
     put(o_pm, P.pmap.data(), 2 * P.pmap.size());
@@ -652,6 +687,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     NRS_HIP(c, hipMemcpyAsync(base, S.h_stage.data(), o_ev, hipMemcpyHostToDevice, c->stream));
     NdDev& D = S.dev;
     memset(&D, 0, sizeof(D));
+    D.seg = reinterpret_cast<const int*>(base + o_seg);
     D.own = reinterpret_cast<const int*>(base + o_own); D.bnd = reinterpret_cast<const int*>(base + o_bnd);
     D.pmap = reinterpret_cast<const int16_t*>(base + o_pm); D.ent = reinterpret_cast<const NdEnt*>(base + o_ent);
     D.wg = reinterpret_cast<const NdWgD*>(base + o_wg); D.lvl_fr = reinterpret_cast<const NdFrontD*>(base + o_lf);
@@ -770,6 +806,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
             for (int w = a; w < b2; ++w) {
                 const long long* q = &h[8 * (P.wg.size() / 3 + (size_t)w)];
                 if (q[3] == 0) continue;                            // (a root)
+                if (b2 - a <= 2 && getenv("NRS_ND_DBG2")) fprintf(stderr, "   front %d (s %d b %d nseg %d): start %.1f seg-loop-begin %.1f released %.1f gathered %.1f gemv %.1f end %.1f\n", w, P.fr[P.lvl_fronts[w]].s, P.fr[P.lvl_fronts[w]].b, P.fr[P.lvl_fronts[w]].n_seg, (q[0]-t00)/100.0, (q[5]-t00)/100.0, (q[4]-t00)/100.0, (q[1]-t00)/100.0, (q[2]-t00)/100.0, (q[3]-t00)/100.0);
                 // (single launch: [4] = released by the parent; "loads" is then the gather of the boundary values only)
                 for (int k = 0; k < 3; ++k) { const double d = (double)(q[k + 1] - (k == 0 && q[4] ? q[4] : q[k])) / 100.0; mean[k] += d / (b2 - a); mx[k] = std::max(mx[k], d); }
                 lo = std::min(lo, q[4] ? q[4] : q[0]); hi = std::max(hi, q[3]);

@@ -44,6 +44,9 @@ struct NdFrontD {                   // one front, as the kernels read it
     int pmap_off;                   // pmap[pmap_off + i]: position of boundary node i in the parent's node list; [.. + b / 3]: the parent's rhs slot
     int A_off, ldA;                 // doubles: assembly area, n_ch slots of [(s + b + 1) x ldA] (zero where no child writes: zeroed once at upload)
     int pA_off, pldA;               // this front's slot in the parent's assembly area (doubles) and the parent's ldA
+    // the boundary by owner: seg[seg_off + i] = (ancestor front, end row of its unknowns in the boundary), i = 0 the parent, then
+    // its parent, ...: the boundary is sorted by elimination position and a front's own nodes are contiguous there
+    int seg_off, n_seg;
 };
 // an original entry: 3 x 3 block (kind 0: diagonal block of node `src`, + lambda I; kind 1: pair `src`, rows = the later node)
 // or 1 x 3 (kind 2: right-hand side of node `src`) at node positions (r, c) of the front; c is an own column
@@ -58,6 +61,7 @@ struct NdPlan {
     std::vector<int16_t> pmap;      // per front: boundary node (and the rhs slot) -> node position in the parent front (device)
     std::vector<NdEnt> ent;
     std::vector<int> lvl_ptr, lvl_fronts;       // fronts of every level (leaves first)
+    std::vector<int> seg;                       // (front, end row) pairs: NdFrontD::seg_off
     std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I), and (front, -1, -1) for every non-root front
     std::vector<int> pair_hi, pair_lo;          // every pair oriented by elimination order (block rows = hi)
     std::vector<int> elim;                      // node -> elimination position
@@ -259,6 +263,8 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     P.ent.reserve(2 * (size_t)n_nodes + (size_t)n_pairs);
     P.own.reserve(n_nodes);
     std::vector<int> where(n_nodes, -1);                           // node -> position in the front being laid out
+    std::vector<int> owner(n_nodes, -1);                           // node -> the front that eliminates it
+    for (int f = 0; f < nf; ++f) for (int u : F[f].own) owner[u] = f;
     for (int f = 0; f < nf; ++f) {
         NdFrontD& D = P.fr[f];
         const int ns = (int)F[f].own.size(), nbn = (int)bnd[f].size(), mn = ns + nbn;
@@ -280,6 +286,12 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         D.A_off = (int)P.A_doubles;
         P.A_doubles += (size_t)F[f].ch.size() * (D.s + D.b + 1) * D.ldA;
         if (P.A_doubles > (size_t)1 << 30) return fail("assembly areas too large");
+        D.seg_off = (int)P.seg.size() / 2; D.n_seg = 0;
+        for (int i = 0; i < nbn; ++i) {
+            const int o = owner[bnd[f][i]];
+            if (i == 0 || o != owner[bnd[f][i - 1]]) { P.seg.push_back(o); P.seg.push_back(0); ++D.n_seg; }
+            P.seg.back() = 3 * (i + 1);
+        }
         D.ch_off = (int)P.child.size(); D.n_ch = (int)F[f].ch.size();
         P.child.insert(P.child.end(), F[f].ch.begin(), F[f].ch.end());
         for (int i = 0; i < ns; ++i) where[F[f].own[i]] = i;
