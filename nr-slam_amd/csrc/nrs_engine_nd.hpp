@@ -191,13 +191,13 @@ __device__ __forceinline__ void nd_store_x(const NdDev& N, const NdFrontD& F, co
 
 // trailing update of the panel factorisation on the matrix cores: C_rb,cb -= P_rb P_cb^T for the block columns cb in [cb_lo, cb_hi) and
 // the row blocks rb >= cb, P = the 16 columns at k0; the tiles are dealt round-robin to the waves w0 .. w0 + nw - 1 (this wave: widx)
-__device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo, int cb_hi, int nrt, int widx, int nw) {
+__device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo, int cb_hi, int nrt, int widx, int nw, int skip_first = 0) {
     if (widx < 0 || widx >= nw) return;
     int cnt = 0;
 #pragma unroll 1
     for (int cb = cb_lo; cb < cb_hi; ++cb)
 #pragma unroll 1
-        for (int rb = cb; rb < nrt; ++rb, ++cnt) {
+        for (int rb = cb + (cb == cb_lo ? skip_first : 0); rb < nrt; ++rb, ++cnt) {      // (skip_first: the diagonal tile of the first column is somebody else's)
             if (cnt % nw != widx) continue;
             nd_v4d c;
             double av[4], bv[4];
@@ -392,8 +392,12 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 16 * kb;
         if (N.clk) tq = wall_clock64();
-        if (wave == 0) nd_diag_factor(W, dinv, k0, lane, bad);
-        else if (kb > 0) nd_update(W, lane, k0 - 16, kb + 1, nb, nrt, wave - 1, 3);
+        // (wave 0: the previous panel's update of THIS diagonal block, then its factorisation (A); waves 1..3 meanwhile apply the
+        // previous panel to everything else right of it -- the rest of this block column included: only B is done by all four)
+        if (wave == 0) {
+            if (kb > 0) nd_update(W, lane, k0 - 16, kb, kb + 1, kb + 1, 0, 1);
+            nd_diag_factor(W, dinv, k0, lane, bad);
+        } else if (kb > 0) nd_update(W, lane, k0 - 16, kb, nb, nrt, wave - 1, 3, 1);
         __syncthreads();
         if (N.clk) { const long long t = wall_clock64(); tA += t - tq; tq = t; }
         {
@@ -415,10 +419,6 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         }
         __syncthreads();
         if (N.clk) tB += wall_clock64() - tq;
-        if (kb + 1 < nb) {                                         // (C)
-            nd_update(W, lane, k0, kb + 1, kb + 2, nrt, wave, 4);
-            __syncthreads();
-        }
     }
     stamp(3);
     if (N.clk && tid == 0) { N.clk[8 * (size_t)(wg0 + blockIdx.x) + 6] = tA; N.clk[8 * (size_t)(wg0 + blockIdx.x) + 7] = tB; }
