@@ -5,14 +5,19 @@
 // the whole system per LM trial, `not positive definite` reported as a failed solve -- as CameraPoseAndDeformationOptimization
 // drives it (modules/optimization/g2o_optimization.cc:148-557, block_solver.hpp:329-341: no Schur ordering, nothing marginalised).
 //
-// One launch per tree level (leaves first).  A workgroup is (front f, boundary row blocks I >= J): it assembles the front's
-// own block F11 (<= 96 x 96) and the two 48-row blocks of F21 in LDS -- original entries, then the children's Schur
-// complements through the plan's maps, in a fixed order (no atomics: bit-reproducible) -- factorises the tall panel
-// [F11; F21_I; F21_J] by 16-column steps (diagonal block in one wave on cross-lane reads, panel rows one per thread, trailing
-// update on the matrix cores), and leaves the tile U_IJ = F22_IJ - L21_I L21_J^T (matrix cores) for the parent.  F11 is
-// factorised redundantly by every workgroup of a front: it is the latency of the level either way, and the tiles of a large
-// boundary then spread over the CUs without a second launch.  The right-hand side is one more boundary row, so the forward
-// substitution rides along; k_nd_back walks the levels back down (L11^T x = y - L21^T x_bnd).
+// Factorisation: one launch per tree level (leaves first).  A workgroup is (front f, boundary row blocks I >= J): it assembles
+// the front's own block F11 (<= 96 x 96) and the two 48-row blocks of F21 in LDS -- original entries, then the children's Schur
+// complements by dense reads of the slots they wrote in THIS front's index space, in a fixed order (no atomics:
+// bit-reproducible) -- factorises the tall panel [F11; F21_I; F21_J] by 16-column steps (diagonal block in one wave and panel
+// rows one per thread, both on DPP row broadcasts; trailing update on the matrix cores), and leaves the tile
+// U_IJ = F22_IJ - L21_I L21_J^T (matrix cores) in the parent's slot.  F11 is factorised redundantly by every workgroup of a
+// front: it is the latency of the level either way, and the tiles of a large boundary then spread over the CUs without a second
+// launch.  The right-hand side is one more boundary row, so the forward substitution rides along.  One more workgroup per front
+// factorises [F11; I] and leaves (L11^-1)^T behind the factor.
+// Back pass: ONE launch (k_nd_back), a workgroup per front, top-down: factors staged on chip, then ancestor by ancestor
+// (agent-scope flags) x_own = (L11^-1)^T (y - L21^T x_bnd) as two matrix-vector products.
+// Set-up: nd_prep_run (structure only: pair lists, cache key, plan; on a helper thread of engine_create) and nd_engine_finish
+// (value descriptors in the engine's row layout, uploads); the context caches the last plans (NdCache).
 #pragma once
 #include <thread>
 #include "nrs_nd_plan.hpp"
