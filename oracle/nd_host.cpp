@@ -105,3 +105,72 @@ extern "C" int nrs_cpu_nd_solve(int32_t n_nodes, const double* pos, const uint8_
     }
     return nrs::nd_host_solve(P, Dn, V.data(), bn, lambda, x) ? 0 : -6;
 }
+
+// Structural invariants of a plan the device kernels rely on (tests/test_nd_cpu.py): returns 0, or the number of the first
+// violated check.  (1) every node is owned by exactly one front; (2) both ends of every pair sit in the front that owns the
+// earlier-eliminated one (own or boundary): the separators separate; (3) a front's boundary is sorted by elimination position and
+// all of it lies in the parent's front; (4) the boundary's owner segments (NdFrontD::seg_off) tile it in order, parent side first,
+// every owner a proper ancestor, each ancestor at most once; (5) a front owns at most ND_SMAXN nodes; (6) workgroups: every
+// (I >= J) pair of row blocks once, one inverse workgroup per front with a parent, levels ascending.
+extern "C" int nrs_cpu_nd_plan_check(int32_t n_nodes, const double* pos, const uint8_t* last, int32_t n_pairs, const int32_t* pairs) {
+    nrs::NdPlan P;
+    std::string err;
+    if (n_nodes <= 0 || n_pairs < 0 || !nrs::nd_build_plan(n_nodes, pos, last, n_pairs, pairs, P, &err)) return -1;
+    const int nf = P.n_fronts;
+    std::vector<int> owner(n_nodes, -1);
+    for (int f = 0; f < nf; ++f) {
+        const nrs::NdFrontD& D = P.fr[f];
+        if (D.s / 3 > nrs::ND_SMAXN || D.s % 3 || D.b % 3) return 5;
+        for (int i = 0; i < D.s / 3; ++i) { const int u = P.own[D.own_off + i]; if (owner[u] >= 0) return 1; owner[u] = f; }
+    }
+    for (int u = 0; u < n_nodes; ++u) if (owner[u] < 0) return 1;
+    auto in_front = [&](int f, int u) {
+        const nrs::NdFrontD& D = P.fr[f];
+        for (int i = 0; i < D.s / 3; ++i) if (P.own[D.own_off + i] == u) return true;
+        for (int i = 0; i < D.b / 3; ++i) if (P.bnd[D.bnd_off + i] == u) return true;
+        return false;
+    };
+    for (int q = 0; q < n_pairs; ++q) {
+        const int a = pairs[2 * q], b = pairs[2 * q + 1];
+        const int lo = P.elim[a] < P.elim[b] ? a : b, hi = lo == a ? b : a;
+        if (!in_front(owner[lo], hi)) return 2;
+    }
+    for (int f = 0; f < nf; ++f) {
+        const nrs::NdFrontD& D = P.fr[f];
+        for (int i = 0; i < D.b / 3; ++i) {
+            const int u = P.bnd[D.bnd_off + i];
+            if (i > 0 && P.elim[u] <= P.elim[P.bnd[D.bnd_off + i - 1]]) return 3;
+            if (D.par < 0 || !in_front(D.par, u)) return 3;
+        }
+        if ((D.par < 0) != (D.b == 0 && D.par < 0)) return 3;
+        int row = 0, prev_owner = f;
+        std::vector<int> seen;
+        for (int k = 0; k < D.n_seg; ++k) {
+            const int o = P.seg[2 * (size_t)(D.seg_off + k)], end = P.seg[2 * (size_t)(D.seg_off + k) + 1];
+            if (end <= row || end % 3) return 4;
+            bool anc = false;                                     // o is a proper ancestor of f, above the previous owner
+            for (int g = P.fr[prev_owner].par; g >= 0; g = P.fr[g].par) if (g == o) { anc = true; break; }
+            if (!anc) return 4;
+            for (int i = row / 3; i < end / 3; ++i) if (owner[P.bnd[D.bnd_off + i]] != o) return 4;
+            for (int s2 : seen) if (s2 == o) return 4;
+            seen.push_back(o);
+            prev_owner = o;
+            row = end;
+        }
+        if (row != D.b) return 4;
+    }
+    std::vector<int> n_inv(nf, 0), n_reg(nf, 0);
+    for (int l = 0; l < P.n_levels; ++l)
+        for (int w = P.lvl_wg_ptr[l]; w < P.lvl_wg_ptr[l + 1]; ++w) {
+            const int f = P.wg[3 * w], I = P.wg[3 * w + 1], J = P.wg[3 * w + 2];
+            if (P.fr[f].level != l) return 6;
+            if (I < 0) { if (J >= 0 || P.fr[f].par < 0) return 6; n_inv[f]++; }
+            else { if (J < 0 || J > I || I >= P.fr[f].nR) return 6; n_reg[f]++; }
+        }
+    for (int f = 0; f < nf; ++f) {
+        const int nR = P.fr[f].nR;
+        if (n_reg[f] != nR * (nR + 1) / 2 || n_inv[f] != (P.fr[f].par >= 0 ? 1 : 0)) return 6;
+        if (P.fr[f].par >= 0 && P.fr[P.fr[f].par].level <= P.fr[f].level) return 6;
+    }
+    return 0;
+}

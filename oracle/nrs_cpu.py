@@ -180,6 +180,15 @@ class LucasKanadeCpp:
         return pts, status, good.value, ssim
 
 
+def nd_plan_check(pos, last, pairs, lib=None):
+    """oracle/nd_host.cpp nrs_cpu_nd_plan_check: the structural invariants of the nested-dissection plan (0 = all hold)"""
+    lib = lib or load()
+    pos = np.ascontiguousarray(pos, np.float64)
+    last = None if last is None else np.ascontiguousarray(last, np.uint8)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    return int(lib.nrs_cpu_nd_plan_check(C.c_int32(len(pos)), _p(pos, C.c_double), _p(last, C.c_uint8), C.c_int32(len(pairs)), _p(pairs, C.c_int32)))
+
+
 def nd_solve(pos, last, pairs, Dn, Vp, bn, lam=0.0, lib=None):
     """oracle/nd_host.cpp: the nested-dissection plan of nr-slam_amd/csrc/nrs_nd_plan.hpp + its host reference solve of
     (A + lam I) x = b (A: diagonal blocks Dn [n,3,3], pair blocks Vp [p,3,3] with rows = pairs[:,0]'s components).

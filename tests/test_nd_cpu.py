@@ -108,3 +108,14 @@ def test_g2o_known_answer_through_the_plan_and_host_reference():
     e = np.zeros((12, 3)); e[4, 1] = 1.0
     ok, xs, st = CPU.nd_solve(pos, None, pairs, Dn, Vp, e, 0.0)
     assert ok and np.allclose(xs.ravel(), inv[:, 13], atol=1e-6 * np.abs(inv[:, 13]).max())
+
+
+@pytest.mark.parametrize("n,seed,pose,knn", [(7, 1, True, 3), (90, 2, True, 11), (700, 3, True, 11), (700, 4, False, 22), (2500, 5, True, 16)])
+def test_plan_invariants(n, seed, pose, knn):
+    """what the device kernels take for granted about a plan (oracle/nd_host.cpp nrs_cpu_nd_plan_check): one owner per node, the
+    separators separate (both ends of every coupling in the earlier node's front), boundaries sorted and inside the parent's front,
+    the boundary's owner segments tile it parent-first with proper ancestors only, front sizes, the workgroup lists"""
+    pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, pose, knn=knn)
+    assert CPU.nd_plan_check(pos, last, pairs) == 0
+    pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, pose, knn=knn, disconnected=True)     # a forest (without a pose): several roots
+    assert CPU.nd_plan_check(pos, last, pairs) == 0
