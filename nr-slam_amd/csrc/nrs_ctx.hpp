@@ -80,6 +80,7 @@ struct nrs_ctx {
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) return fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         b.cap = want;
+        if (getenv("NRS_POISON")) { (void)hipMemset(b.p, 0xFF, want); (void)hipDeviceSynchronize(); }     // (debug: a read of memory nobody wrote shows up as NaN)
         return NRS_OK;
     }
     void release(nrs::DevBuf& b) {

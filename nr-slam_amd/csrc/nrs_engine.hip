@@ -540,7 +540,16 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     hipLaunchKernelGGL(k_apply, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam, d.pose[e->cur], d.xl[e->cur], d.pose[trial], d.xl[trial]);
                 if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo, c->stream));   // the regularisers read the neighbours' boundary keyframes
                 NRS_TRY(evaluate<false>(c, e, trial, one_pose));
-                return read_scalars(c, e);                 // one synchronisation: chi2, scale and the PCG flags
+                NRS_TRY(read_scalars(c, e));               // one synchronisation: chi2, scale and the PCG flags
+                static const bool check_eval = getenv("NRS_CHECK_EVAL") != nullptr;
+                if (check_eval) {                          // (debug: the same evaluation again on the same state must give the same bits)
+                    const double chi1 = e->h_scal[SC_CHI], sc1 = e->h_scal[SC_SCALE];
+                    NRS_TRY(evaluate<false>(c, e, trial, false));
+                    NRS_TRY(read_scalars(c, e));
+                    if (e->h_scal[SC_CHI] != chi1 || e->h_scal[SC_SCALE] != sc1)
+                        fprintf(stderr, "[nrs] evaluation not reproducible: chi2 %.17g / %.17g, scale %.17g / %.17g\n", chi1, e->h_scal[SC_CHI], sc1, e->h_scal[SC_SCALE]);
+                }
+                return NRS_OK;
             };
             const bool peeking = !c->opt.exact_trials;
             // The first batch of PCG iterations and a speculative evaluation of its result go out

@@ -726,6 +726,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         hipError_t he = hipMalloc((void**)&arena->base, want);
         if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
         arena->cap = want;
+        if (getenv("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
     }
     ArenaPlan real{arena, false};
     carve(real, d, false, nnz_s, nnz_d, (size_t)n_slices, n_halo, e);

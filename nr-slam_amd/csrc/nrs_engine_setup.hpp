@@ -870,6 +870,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         hipError_t he = hipMalloc((void**)&arena->base, want);
         if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
         arena->cap = want;
+        if (getenv("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
     }
     ArenaPlan real{arena, false};
     carve(real, d, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), e);
