@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
     if (F.n_ch > 0) {                                              // F22 tile (I, J): straight into the accumulators of the matrix cores
+        // (the children wrote every element once, at (larger, smaller) of its two positions here: a diagonal tile's upper half is
+        // read at its mirror position)
+        auto tile_off = [&](int r, int cc) {
+            const int fr = s + ND_TB * I + r, fc = s + ND_TB * J + cc;
+            return (size_t)max(fr, fc) * F.ldA + min(fr, fc);
+        };
         double tv[2][3][4];
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
                 const bool in = t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b;
-                const size_t o = in ? (size_t)(s + ND_TB * I + r) * F.ldA + s + ND_TB * J + cc : 0;
+                const size_t o = in ? tile_off(r, cc) : 0;
                 tv[0][t3][g] = A0[o];
                 tv[1][t3][g] = A0[(F.n_ch > 1 ? slot : 0) + o];
                 if (!in) { tv[0][t3][g] = 0.0; tv[1][t3][g] = 0.0; }
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
-                    if (t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b) acc[t3][g] += A0[k * slot + (size_t)(s + ND_TB * I + r) * F.ldA + s + ND_TB * J + cc];
+                    if (t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b) acc[t3][g] += A0[k * slot + tile_off(r, cc)];
                 }
             }
     }
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         if (lane == 0) N.done[F.cmap_off] = epoch;                 // (cmap_off of a device descriptor: the front's own index; published by the end of the launch)
     }
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
-    // written into the parent's assembly slot at the parent's positions of its rows and columns (both triangles)
+    // written into the parent's assembly slot at the parent's positions of its rows and columns (the lower one of the two)
     if (F.par >= 0 && !inv) {
         int ti[3], tj[3];
 #pragma unroll
@@ -466,11 +472,10 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti[t3] + (lane >> 4) + 4 * g, cc = 16 * tj[t3] + (lane & 15);
-                const int R = ND_TB * I + r, Cc = ND_TB * J + cc;
-                if (r < rI && cc < cJ && Cc < F.b) {
+                const int Cc = ND_TB * J + cc;
+                if (r < rI && cc < cJ && Cc < F.b && (two || r >= cc)) {         // (a diagonal tile: its lower half)
                     const int PR = 3 * (int)pmi[r / 3] + r % 3, PC = 3 * (int)(two ? pmj : pmi)[cc / 3] + cc % 3;
-                    Ap[(size_t)PR * F.pldA + PC] = acc[t3][g];
-                    if (two && R < F.b) Ap[(size_t)PC * F.pldA + PR] = acc[t3][g];
+                    Ap[(size_t)max(PR, PC) * F.pldA + min(PR, PC)] = acc[t3][g];  // ONE store per element: the parent reads lower positions only
                 }
             }
         }
