@@ -41,10 +41,6 @@ struct NdDev {
     long long* clk;                  // NRS_ND_DBG: 8 phase clocks (100 MHz) per workgroup of the factorisation, then per front of the back substitution; else null
 };
 
-__device__ inline double nd_readlane(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
 // value of lane K of the caller's 16-lane row, in every lane of the row: DPP row_newbcast (a plain VALU move, no SGPR round trip)
 template <int K>
 __device__ inline double nd_rowbcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false); }
@@ -118,58 +114,6 @@ __device__ inline void nd_b_cols(double (&x)[16], const double (&lk)[16], const 
     }
 }
 
-// Wave-level back substitution L^T x = t, L lower triangular (s x s in LDS, leading dimension ND_LD, reciprocal diagonal in di): lane l
-// holds the unknowns l (t0) and l + 64 (t1).  By blocks of 16 unknowns, the last block first: inside a block (one 16-lane row of
-// the wave) the 16 dependent steps are x_p = t_p d_p, t_q -= L[p][q] x_p on DPP row broadcasts (no SGPR round trip); the block's
-// x then updates the unknowns below it from whole rows of L (v_readlane + one conflict-free LDS read per lane and step).
-template <int P>
-__device__ inline void nd_bs_steps(double& T, const double (&Lr)[16], double d) {
-    if constexpr (P >= 0) {
-        double nx = -(T * d);
-        asm volatile("s_nop 1" : "+v"(nx));
-        nd_fmac_bcast<P>(T, nx, Lr[P]);
-        nd_bs_steps<P - 1>(T, Lr, d);
-    }
-}
-__device__ __forceinline__ void nd_back_solve(const double* Ls, const double* di, int s, int lane, double& t0, double& t1) {
-    const int nb = (s + 15) >> 4, ql = lane & 15, myrow = lane >> 4;
-    const double d0 = lane < s ? di[lane] : 0.0, d1 = lane + 64 < s ? di[lane + 64] : 0.0;
-#pragma unroll 1
-    for (int k = nb - 1; k >= 0; --k) {
-        const bool hi = k >= 4;
-        const int row = k & 3;
-        double Lr[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int pr = 16 * k + p;
-            Lr[p] = (myrow == row && ql < p && pr < s) ? Ls[pr * ND_LD + 16 * k + ql] : 0.0;
-        }
-        double T = hi ? t1 : t0;
-        const double d = hi ? d1 : d0;
-        nd_bs_steps<15>(T, Lr, d);
-        if (hi) t1 = T; else t0 = T;
-        const double X = T * d;                                    // the block's solution, in the lanes of its row
-        const int below = 16 * k;                                  // unknowns [0, below) still wait for this block
-        if (below > 0) {
-            double l0[16], l1[16];                                 // the block's 16 rows of L for this lane's unknowns: requested together
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int pr = min(16 * k + p, s - 1);
-                l0[p] = Ls[pr * ND_LD + lane];
-                l1[p] = hi ? Ls[pr * ND_LD + lane + 64] : 0.0;
-            }
-            double a0 = 0, a1 = 0;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const double xp = 16 * k + p < s ? nd_readlane(X, 16 * row + p) : 0.0;
-                a0 += l0[p] * xp; a1 += l1[p] * xp;
-            }
-            if (lane < below) t0 -= a0;
-            if (lane + 64 < below) t1 -= a1;
-        }
-    }
-    t0 *= d0; t1 *= d1;
-}
 // the solved unknowns of a front go to the node vector and, for an engine, straight into its step vectors; the two index loads
 // (node of the unknown, its output slot) are requested at kernel start (NdOut) so that no memory round trip follows the solve
 struct NdOut { int node[2], o[2]; };
@@ -241,8 +185,6 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     int16_t* pmj = pmi + 16;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
-    NdOut xo = {};
-    if (F.par < 0 && wave == 0) xo = nd_out_request(N, F, lane);
     // ---- requests first: this thread's original entries (descriptor and values: one round trip) and the Schur complements the
     // children left in this front's assembly slots (dense, in this front's own index space: contiguous 16-byte loads)
     auto entry_row = [&](const NdEnt& E) {                         // W row of an entry's first row, -1: not in this workgroup's blocks
@@ -433,14 +375,6 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     }
     stamp(3);
     if (N.clk && tid == 0) { N.clk[8 * (size_t)(wg0 + blockIdx.x) + 6] = tA; N.clk[8 * (size_t)(wg0 + blockIdx.x) + 7] = tB; }
-    if (F.par < 0 && wave == 0) {
-        // a root has no boundary: its unknowns follow at once from the factor and the forward-substituted right-hand side in LDS
-        // (the back-substitution pass starts one level further down)
-        double t0 = lane < s ? W[rowI0 * ND_LD + lane] : 0.0, t1 = lane + 64 < s ? W[rowI0 * ND_LD + lane + 64] : 0.0;
-        nd_back_solve(W, dinv, s, lane, t0, t1);
-        nd_store_x(N, F, xo, lane, t0, t1);
-        if (lane == 0) N.done[F.cmap_off] = epoch;                 // (cmap_off of a device descriptor: the front's own index; published by the end of the launch)
-    }
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
     // written into the parent's assembly slot at the parent's positions of its rows and columns (the lower one of the two)
     if (F.par >= 0 && !inv) {
@@ -503,8 +437,8 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     stamp(5);
 }
 
-// back substitution, x_own = L11^-T (y - L21^T x_bnd), all levels in ONE launch: one workgroup per front, top-down in block
-// order.  A workgroup first brings everything that does not depend on the unknowns above it on chip -- (L11^-1)^T into LDS, L21
+// back substitution, x_own = L11^-T (y - L21^T x_bnd), all levels in ONE launch: one workgroup per front (roots included: no
+// boundary, nothing to wait for), top-down in block order.  A workgroup first brings everything that does not depend on the unknowns above it on chip -- (L11^-1)^T into LDS, L21
 // into registers (the first 32 rows per thread group) and LDS (as many further rows as fit), y, output indices.  Its boundary is
 // sorted by owner (NdFrontD::seg_off: the parent's unknowns first, the root's last), and the owners finish root first: the
 // workgroup takes the segments from the far end, waits for each owner's flag (release / acquire at agent scope; the values are
@@ -522,7 +456,6 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     const NdFrontD F = N.lvl_fr[li];                                // (descriptors in level order)
     const int s = F.s, b = F.b, m = s + b;
     if (blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }   // (read by the host after the launch has completed)
-    if (F.par < 0) return;                                         // a root: solved by the factorisation kernel
     double* Ls = sm;                                               // (L11^-1)^T, [s][ND_LD]
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
     double* tv = part + 512;                                       // [128]: y - L21^T x_bnd
@@ -544,7 +477,7 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     const double* Lq = L + (size_t)s * s + min(q, s - 1);
     double lr[ND_BACK_UR];
 #pragma unroll
-    for (int u = 0; u < ND_BACK_UR; ++u) lr[u] = Lq[(size_t)min(g + u * ng, b - 1) * s];
+    for (int u = 0; u < ND_BACK_UR; ++u) lr[u] = Lq[(size_t)max(min(g + u * ng, b - 1), 0) * s];     // (a root has no boundary: the value is not used)
     {
         // (all requests of a staging step in flight together: a plain copy loop waits for every load before the next goes out --
         // 36 + 40 dependent round trips, 70 us for a front with a boundary of 70 nodes)
@@ -716,8 +649,8 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
             const NdFrontD& F = P.fr[P.lvl_fronts[i]];
             const int s16 = (F.s + 15) & ~15, nrow = s16 + ND_TB + (F.nR > 1 ? ND_TB : 0);
             S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)nrow * ND_LD + ND_S16 + 256) + 2 * 32);
-            if (F.par >= 0) {
-                S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)2 * s16 * ND_LD + ND_S16 + 256) + 2 * 32);      // (the inverse workgroup)
+            S.lvl_shm_fac[l] = std::max(S.lvl_shm_fac[l], sizeof(double) * ((size_t)2 * s16 * ND_LD + ND_S16 + 256) + 2 * 32);          // (the inverse workgroup)
+            {
                 const int ngb = F.s <= 64 ? 4 : 2;
                 const size_t want = sizeof(double) * ((size_t)nd_back_fixed_doubles(F.b) + (size_t)std::max(0, F.b - ngb * ND_BACK_UR) * F.s);
                 S.shm_back_all = std::max(S.shm_back_all, std::min(want, (size_t)160 * 1024));

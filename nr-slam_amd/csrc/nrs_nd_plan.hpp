@@ -62,7 +62,7 @@ struct NdPlan {
     std::vector<NdEnt> ent;
     std::vector<int> lvl_ptr, lvl_fronts;       // fronts of every level (leaves first)
     std::vector<int> seg;                       // (front, end row) pairs: NdFrontD::seg_off
-    std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I), and (front, -1, -1) for every non-root front
+    std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I), and (front, -1, -1) for every front
     std::vector<int> pair_hi, pair_lo;          // every pair oriented by elimination order (block rows = hi)
     std::vector<int> elim;                      // node -> elimination position
     size_t L_doubles = 0, U_doubles = 0, A_doubles = 0;
@@ -354,7 +354,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             const int f = P.lvl_fronts[i];
             for (int I = 0; I < P.fr[f].nR; ++I)
                 for (int J = 0; J <= I; ++J) { P.wg.push_back(f); P.wg.push_back(I); P.wg.push_back(J); }
-            if (P.fr[f].par >= 0) { P.wg.push_back(f); P.wg.push_back(-1); P.wg.push_back(-1); }   // the inverse of L11 (device back pass)
+            P.wg.push_back(f); P.wg.push_back(-1); P.wg.push_back(-1);                               // the inverse of L11 (device back pass)
             const double s = P.fr[f].s, tb = std::min(ND_TB, P.fr[f].b + 1);
             worst = std::max(worst, s * s * s / 3 + 2 * s * s * tb + s * tb * tb);
         }

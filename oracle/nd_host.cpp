@@ -111,7 +111,7 @@ extern "C" int nrs_cpu_nd_solve(int32_t n_nodes, const double* pos, const uint8_
 // earlier-eliminated one (own or boundary): the separators separate; (3) a front's boundary is sorted by elimination position and
 // all of it lies in the parent's front; (4) the boundary's owner segments (NdFrontD::seg_off) tile it in order, parent side first,
 // every owner a proper ancestor, each ancestor at most once; (5) a front owns at most ND_SMAXN nodes; (6) workgroups: every
-// (I >= J) pair of row blocks once, one inverse workgroup per front with a parent, levels ascending.
+// (I >= J) pair of row blocks once, one inverse workgroup per front, levels ascending.
 extern "C" int nrs_cpu_nd_plan_check(int32_t n_nodes, const double* pos, const uint8_t* last, int32_t n_pairs, const int32_t* pairs) {
     nrs::NdPlan P;
     std::string err;
@@ -164,12 +164,12 @@ extern "C" int nrs_cpu_nd_plan_check(int32_t n_nodes, const double* pos, const u
         for (int w = P.lvl_wg_ptr[l]; w < P.lvl_wg_ptr[l + 1]; ++w) {
             const int f = P.wg[3 * w], I = P.wg[3 * w + 1], J = P.wg[3 * w + 2];
             if (P.fr[f].level != l) return 6;
-            if (I < 0) { if (J >= 0 || P.fr[f].par < 0) return 6; n_inv[f]++; }
+            if (I < 0) { if (J >= 0) return 6; n_inv[f]++; }
             else { if (J < 0 || J > I || I >= P.fr[f].nR) return 6; n_reg[f]++; }
         }
     for (int f = 0; f < nf; ++f) {
         const int nR = P.fr[f].nR;
-        if (n_reg[f] != nR * (nR + 1) / 2 || n_inv[f] != (P.fr[f].par >= 0 ? 1 : 0)) return 6;
+        if (n_reg[f] != nR * (nR + 1) / 2 || n_inv[f] != 1) return 6;
         if (P.fr[f].par >= 0 && P.fr[P.fr[f].par].level <= P.fr[f].level) return 6;
     }
     return 0;
