@@ -1148,7 +1148,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     const int n_free = P.n_free, n_nodes = P.n_nodes, n_pairs = (int)P.pkind.size();
     NdCache* nc = static_cast<NdCache*>(c->nd_cache);
     if (!nc) { nc = new (std::nothrow) NdCache(); if (!nc) return c->fail(NRS_ERR_ALLOC, "out of host memory"); c->nd_cache = nc; }
-    const bool use_cache = !getenv("NRS_ND_NO_CACHE");
+    const bool use_cache = true;                                  // (NRS_ND_NO_CACHE=1 only stops plans from being REUSED -- nd_prep_run -- the slots' buffers are)
     NdSlot* sl = P.hit && !P.hit->busy ? P.hit : nullptr;
     const bool hit = sl != nullptr;
     if (!hit) {
