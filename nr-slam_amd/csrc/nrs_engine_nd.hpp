@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
             }
         }
     }
+    if (F.n_seg == 0) { stamp(4); stamp(1); }                      // (a root: nothing to wait for)
     {
         const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         if (q < 128) {
