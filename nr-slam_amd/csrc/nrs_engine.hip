@@ -416,6 +416,60 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             const Dev& d = d1;
             const dim3 g(one_xcd ? 8 * d.n_regblk : ((d.n_regblk + 7) / 8) * 8), bb(BLK);
             const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 12 * (size_t)d.n_regblk + 16 * CO_MAX : 0));
+            static const bool check_fused = getenv("NRS_CHECK_FUSED") != nullptr;
+            if (check_fused && !d.coarse && d.T == 8) {
+                // debug: the same launch twice from the same state must leave the same bits in every array it writes
+                // (tools/flake_probe.py: run-to-run variation of the single-launch iteration)
+                struct Arr { void* p; size_t bytes; const char* name; };
+                const size_t nv = sizeof(double) * 3 * (size_t)d.n_rows, np6 = sizeof(double) * 6 * (size_t)d.K, npart = sizeof(double) * NPART * (size_t)d.n_regblk;
+                const Arr arr[] = {{d.rv, nv, "r0"}, {d.rv2, nv, "r1"}, {d.sv, nv, "s0"}, {d.sv2, nv, "s1"}, {d.wv, nv, "w0"}, {d.wv2, nv, "w1"}, {d.xv, nv, "x"},
+                                   {d.pv, nv, "p"}, {d.uv3, nv, "u"}, {d.rp, np6, "rp0"}, {d.rp2, np6, "rp1"}, {d.sp, np6, "sp0"}, {d.sp2, np6, "sp1"},
+                                   {d.up, np6, "up0"}, {d.up2, np6, "up1"}, {d.pp, np6, "pp"}, {d.xp, np6, "xp"}, {d.part_spmv, npart, "part0"},
+                                   {d.part_spmv2, npart, "part1"}, {d.scal, sizeof(double) * SC_N, "scal"}, {d.flags, sizeof(int) * 8, "flags"}};
+                size_t total = 0;
+                for (const Arr& a : arr) total += (a.bytes + 255) & ~(size_t)255;
+                static char* snap = nullptr; static size_t snap_cap = 0;
+                if (snap_cap < total) { if (snap) (void)hipFree(snap); NRS_HIP(c, hipMalloc((void**)&snap, total)); snap_cap = total; }
+                std::vector<char> h1(total), h2(total);
+                auto gather = [&](char* dst, hipMemcpyKind kind) -> int {
+                    size_t o = 0;
+                    for (const Arr& a : arr) { NRS_HIP(c, hipMemcpyAsync(dst + o, a.p, a.bytes, kind, c->stream)); o += (a.bytes + 255) & ~(size_t)255; }
+                    NRS_HIP(c, hipStreamSynchronize(c->stream));
+                    return NRS_OK;
+                };
+                NRS_TRY(gather(snap, hipMemcpyDeviceToDevice));
+                hipLaunchKernelGGL((k_pcg_fused<8, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                NRS_TRY(gather(h1.data(), hipMemcpyDeviceToHost));
+                { size_t o = 0; for (const Arr& a : arr) { NRS_HIP(c, hipMemcpyAsync(a.p, snap + o, a.bytes, hipMemcpyDeviceToDevice, c->stream)); o += (a.bytes + 255) & ~(size_t)255; } }
+                hipLaunchKernelGGL((k_pcg_fused<8, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+                NRS_TRY(gather(h2.data(), hipMemcpyDeviceToHost));
+                size_t o = 0;
+                bool any = false;
+                for (const Arr& a : arr) {
+                    if (memcmp(h1.data() + o, h2.data() + o, a.bytes) != 0) {
+                        any = true;
+                        const size_t nel = a.bytes / 8;
+                        size_t ndiff = 0, first = 0, last = 0;
+                        for (size_t el = 0; el < nel; ++el)
+                            if (memcmp(h1.data() + o + 8 * el, h2.data() + o + 8 * el, 8) != 0) { if (!ndiff) first = el; last = el; ++ndiff; }
+                        double v1, v2; memcpy(&v1, h1.data() + o + 8 * first, 8); memcpy(&v2, h2.data() + o + 8 * first, 8);
+                        fprintf(stderr, "[nrs] fused launch it %d: array %s differs in %zu elements, first %zu (tile %zu) last %zu (tile %zu): %.6g / %.6g\n", it, a.name, ndiff, first,
+                                first / 3 / (size_t)d.tile_rows, last, last / 3 / (size_t)d.tile_rows, v1, v2);
+                    }
+                    o += (a.bytes + 255) & ~(size_t)255;
+                }
+                if (any) {
+                    const size_t o_fl = total - 256, o_sc = o_fl - ((sizeof(double) * SC_N + 255) & ~(size_t)255);
+                    const int* f1 = reinterpret_cast<const int*>(h1.data() + o_fl); const int* f2 = reinterpret_cast<const int*>(h2.data() + o_fl);
+                    const int* f0 = nullptr; (void)f0;
+                    fprintf(stderr, "[nrs]    flags after run 1: %d %d %d %d | run 2: %d %d %d %d ; scal gamma0 %.6g/%.6g slot0 %.6g %.6g / %.6g %.6g slot1 %.6g %.6g / %.6g %.6g\n", f1[0], f1[1], f1[2], f1[3], f2[0], f2[1], f2[2], f2[3],
+                            reinterpret_cast<const double*>(h1.data() + o_sc)[SC_GAMMA0], reinterpret_cast<const double*>(h2.data() + o_sc)[SC_GAMMA0],
+                            reinterpret_cast<const double*>(h1.data() + o_sc)[SC_SLOT0], reinterpret_cast<const double*>(h1.data() + o_sc)[SC_SLOT0 + 1],
+                            reinterpret_cast<const double*>(h2.data() + o_sc)[SC_SLOT0], reinterpret_cast<const double*>(h2.data() + o_sc)[SC_SLOT0 + 1],
+                            reinterpret_cast<const double*>(h1.data() + o_sc)[SC_SLOT1], reinterpret_cast<const double*>(h1.data() + o_sc)[SC_SLOT1 + 1],
+                            reinterpret_cast<const double*>(h2.data() + o_sc)[SC_SLOT1], reinterpret_cast<const double*>(h2.data() + o_sc)[SC_SLOT1 + 1]);
+                }
+            } else
             switch (d.T) {
                 case 1: if (d.coarse) hipLaunchKernelGGL((k_pcg_fused<1, true>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
                         else hipLaunchKernelGGL((k_pcg_fused<1, false>), g, bb, shm, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);

@@ -291,9 +291,11 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     load_springs(somA, sqcA, sbeg + lane);
     load_dampers(dhA, dsA, dbeg + lane);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    // (one decision per workgroup: the flag can be raised -- by workgroup 0 of this very launch, or of k_pcg_update's -- between
+    // the loads of two waves of a workgroup that starts late; see k_pcg_fused)
+    const int done_wg = __syncthreads_or(done_flag);
     stamp(1);
-    if (done_flag && !(H4 && P.dbg_clk)) return;
+    if (done_wg && !(H4 && P.dbg_clk)) return;
     if (P.ecd && it > 0) {
         const double gamma = lds[0] + lds[1] + lds[2] + lds[3];
         const bool bad = !isfinite(gamma);
@@ -568,7 +570,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     // pub_seq != 0: this is the last launch of a batch the host is waiting for -- the thread that owns the
     // flags publishes them (mapped host memory + sequence word) as soon as they are final
     const bool publisher = pub_seq != 0 && blockIdx.x == 0 && tid == 0;
-    if (done_flag) {
+    // (one decision per workgroup: workgroup 0 raises the flag in the launch that finds the solve converged, while workgroups of
+    // that launch are still starting -- with a per-thread test the waves that loaded the word after the store left, the sums below
+    // lost their shares and the remaining rows were updated with garbage scalars; found on the single-launch form, k_pcg_fused)
+    if (__syncthreads_or(done_flag)) {
         if (publisher) publish_flags(P, pub_seq);
         return;
     }
@@ -880,7 +885,12 @@ __global__ __launch_bounds__(BLK) void k_pcg_fused(Dev P, double lam, int it, do
     load_springs(sbeg + lane);
     load_dampers(dbeg + lane);
 
-    if (done_flag) {
+    // The flag is raised by workgroup 0 of the launch that finds the solve converged -- while other workgroups of that very launch
+    // are still starting.  The decision has to be ONE per workgroup: with a per-thread test, waves that loaded the word before
+    // the store went on and waves that loaded it after left, the block sums below lost the leavers' shares, and the tile ran an
+    // update with garbage scalars behind the converged solve (seen as run-to-run differences of 1e-14 in chi2: tools/flake_probe.py,
+    // NRS_CHECK_FUSED=1).
+    if (__syncthreads_or(done_flag)) {
         if (pub_seq != 0 && blockIdx.x == 0 && tid == 0) publish_flags(P, pub_seq);      // (see k_pcg_update)
         return;
     }

@@ -215,3 +215,27 @@ def test_bad_arguments(ctx):
     kf[0] = 2
     with pytest.raises(nrs.NrsError):
         ctx.dba_solve(cam, qt, p["lm_xyz"], kf, p["lm_uv"], e, p["scale"], 5)
+
+
+def test_reference_window_is_bit_reproducible_between_runs():
+    """Fresh context per run, same inputs, the 5 keyframe x 5000 point window on the single-launch PCG iteration: every trial of
+    every run to the last bit.  (This configuration used to differ in 2-18 % of the runs: workgroup 0 raises the `converged` flag
+    while other workgroups of the same launch are still starting, and a per-thread test of it let some waves of a late workgroup
+    leave and the others go on with block sums that lacked the leavers' shares -- an update with garbage scalars behind the
+    converged solve.  k_pcg_fused / k_pcg_update / k_spmv_f take one decision per workgroup now; tools/flake_probe.py.)"""
+    p = S.make_dba_problem(5000, 5, 1, S.PINHOLE)
+    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    ref = None
+    for rep in range(40):
+        c = nrs.Context()
+        tr = nrs.Trace(64)
+        pq, xyz = c.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr)
+        c.close()
+        t = [(x["accepted"], x["inner"], x["lam"], x["chi"], x["chi_new"]) for x in tr.trials]
+        if ref is None:
+            ref = (t, pq, xyz)
+        else:
+            assert t == ref[0], "run %d" % rep
+            assert np.array_equal(pq, ref[1]) and np.array_equal(xyz, ref[2])

@@ -12,24 +12,6 @@ import nrs_synth as S
 pytestmark = pytest.mark.gpu
 
 
-def _same_trials(a, b, with_inner=True):
-    """decisions, iteration counts and lambda to the last bit; chi2 to 1e-12 relative.  (The single-launch PCG iteration is not
-    bit-reproducible from run to run on ONE configuration seen so far -- the 5-keyframe x 5000-point window: 2-18 % of the runs,
-    depending on launch timing, end an accepted solve a few ulps away, 1e-14 relative in chi2, 1 ulp in a pose, nothing in the fp32
-    positions; K = 2, 3, 4 and the two-kernel path: 0 of 250.  tools/flake_probe.py reproduces it)"""
-    ka = [(t["accepted"], t["inner"] if with_inner else 0, t["lam"]) for t in a]
-    kb = [(t["accepted"], t["inner"] if with_inner else 0, t["lam"]) for t in b]
-    if ka != kb:
-        # (a chi2 a few ulps off moves lambda of the NEXT iteration by an ulp: decisions and counts must still agree)
-        assert [(x[0], x[1]) for x in ka] == [(x[0], x[1]) for x in kb]
-        assert all(abs(x[2] - y[2]) <= 1e-12 * abs(y[2]) for x, y in zip(ka, kb))
-    for x, y in zip(a, b):
-        for key in ("chi", "chi_new"):
-            if key in x and np.isfinite(y[key]):
-                assert abs(x[key] - y[key]) <= 1e-12 * abs(y[key]), (key, x[key], y[key])
-    return True
-
-
 def _solve(monkeypatch, host, p, e, cam, qt, iters=3):
     if host:
         monkeypatch.setenv("NRS_HOST_PACK", "1")
@@ -60,9 +42,9 @@ def test_device_pack_is_the_host_pack(monkeypatch, name, n, k, seed):
              "rflag", "uv", "xl_init", "pose_init", "grp_pose", "pose_grp_ptr", "scalars", "(path)", "tile_desc", "halo_fix"]
     bad = [nm for i, nm in enumerate(names) if hd[i] != hh[i] and i != 21]
     assert not bad, bad
-    assert _same_trials(td, th)
-    assert np.allclose(qd, qh, rtol=0, atol=1e-14) and np.array_equal(xd, xh)
-    assert all(np.allclose(a, b, rtol=0, atol=1e-9) for a, b in zip(rd, rh))
+    assert [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in td] == [(t["accepted"], t["inner"], t["lam"], t["chi"], t["chi_new"]) for t in th]
+    assert np.array_equal(qd, qh) and np.array_equal(xd, xh)
+    assert all(np.array_equal(a, b) for a, b in zip(rd, rh))
 
 
 @pytest.mark.parametrize("model", [S.PINHOLE, S.KB8])
@@ -114,6 +96,6 @@ def test_solve_window_builds_the_same_edges_and_result(n, k, seed, model):
     c2 = nrs.Context()
     tr2 = nrs.Trace(64)
     pq2, xyz2 = c2.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr2)
-    assert _same_trials(tr.trials, tr2.trials, with_inner=False)
-    assert np.allclose(pq, pq2, rtol=0, atol=1e-14) and np.array_equal(xyz, xyz2)
+    assert [(t["accepted"], t["lam"], t["chi_new"]) for t in tr.trials] == [(t["accepted"], t["lam"], t["chi_new"]) for t in tr2.trials]
+    assert np.array_equal(pq, pq2) and np.array_equal(xyz, xyz2)
     c.close(); c2.close()
