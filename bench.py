@@ -485,7 +485,7 @@ def skinned_bench(n=5000, m=500, n_kf=20):
         g.add_edges(tp["X_prev"], fm, fm)
         tr2 = nrs.Trace(1024)
         t0 = time.perf_counter()
-        r2 = ctx.track_deform_solve_embedded(cam, g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr2, 512)
+        r2 = ctx.track_deform_solve_embedded(cam, g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr2)
         ms2.append(1e3 * (time.perf_counter() - t0))
     out["embedded"] = dict(points=n, nodes=m, tracked_points=int((tp["status"] == 0).sum()), ms_pose_and_deformation=float(np.median(ms2[1:])),
                            frames_per_s_of_this_call=1e3 / float(np.median(ms2[1:])), lm_trials=len(tr2.trials),

@@ -19,6 +19,7 @@
 // Set-up: nd_prep_run (structure only: pair lists, cache key, plan; on a helper thread of engine_create) and nd_engine_finish
 // (value descriptors in the engine's row layout, uploads); the context caches the last plans (NdCache).
 #pragma once
+#include <memory>
 #include <thread>
 #include "nrs_nd_plan.hpp"
 
@@ -919,8 +920,19 @@ __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
 // -- tracking in steady state: points are lost and edges added every few frames, not every frame -- takes the slot as it is, no
 // plan build (1.0 ms at 1k points, 5 ms at 4.5k) and no upload.  The key is the complete input of nd_engine_setup except the
 // positions the dissection bisects (they only steer its quality), compared byte for byte.
+// what a plan's key determines besides the plan itself: the node pairs with their edges and, in the embedded mode, which
+// observations add to which plan entry.  Built once per plan; a frame that reuses the plan only fills in its own weights.
+struct NdStruct {
+    std::vector<int> pairs;                                        // node pairs: row-row couplings (sorted, unique), then the pose's
+    std::vector<uint8_t> pkind;                                    // 0 row-row, 1 pose half (first node) - row, 2 pose - pose
+    std::vector<int> eptr, eid;                                    // row-row pair -> its edges in edge order: (index << 1) | (0 spring, 1 damper)
+    // embedded mode, per plan entry: the observations that add to it (ske_pt) and their coefficient as a product of skinning weights,
+    // w[ske_ia] * w[ske_ib] (ske_ib < 0: w[ske_ia] alone); indices into the frame's SK_MAX-wide weight table
+    std::vector<int> ske_ptr, ske_pt, ske_ia, ske_ib;
+};
 struct NdSlot {
     NdSolver S;
+    std::shared_ptr<NdStruct> st;
     NdVals vals;
     DevBuf ws, vb;                   // S.buf = &ws (plan + factor storage), value descriptors
     std::vector<uint8_t> key;
@@ -998,20 +1010,18 @@ struct NdIn {
     int n_skin = 0; const int* sk_vert = nullptr; const double* sk_om = nullptr;
     const double* vpos = nullptr;        // M x 3: where the dissection bisects
 };
-struct NdSkT { uint64_t k; int pt; double cf; };
+struct NdSkT { uint64_t k; int ia, ib; };                       // (pair key, the two weights' places in the weight table)
 struct NdPrep {
     bool wanted = false, plan_ok = false;
     std::string err;
     int n_free = 0, n_nodes = 0;
     bool pose_free = false;
     std::vector<int> node_of, node_vtx;                            // vertex -> node (-1: fixed), node -> vertex
-    std::vector<int> pairs;                                        // node pairs: row-row couplings (sorted, unique), then the pose's
-    std::vector<uint8_t> pkind;                                    // 0 row-row, 1 pose half (first node) - row, 2 pose - pose
-    std::vector<int> eptr, eid;                                    // row-row pair -> its edges in edge order: (index << 1) | (0 spring, 1 damper)
+    std::shared_ptr<NdStruct> st;                                  // this engine's, or the reused slot's
     std::vector<uint8_t> last;
-    std::vector<NdSkT> skt;                                        // embedded mode: (pair, observation, weight product), sorted by pair
-    std::vector<int> nl_ptr, nl_pt, pair_sk0, pair_sk1;
-    std::vector<double> nl_om;
+    std::vector<NdSkT> skt;                                        // embedded mode: (pair, weight places), sorted by pair
+    std::vector<int> nl_ptr, nl_ix, pair_sk0, pair_sk1;            // per free node: the weight-table places of the observations that reach it
+    std::vector<double> ske_cf;                                    // this frame's coefficients for st->ske_*
     std::vector<uint8_t> key;
     uint64_t hash = 0;
     NdSlot* hit = nullptr;
@@ -1021,8 +1031,41 @@ struct NdPrep {
 };
 
 
+// embedded mode: the observation lists of a plan's entries
+static void nd_prep_ske(NdPrep& P, const NdPlan& PL) {
+    NdStruct& T = *P.st;
+    const int n_free = P.n_free;
+    T.ske_ptr.assign(PL.ent.size() + 1, 0);
+    T.ske_pt.clear(); T.ske_ia.clear(); T.ske_ib.clear();
+    const size_t guess = 4 * P.nl_ix.size() + P.skt.size();
+    T.ske_pt.reserve(guess); T.ske_ia.reserve(guess); T.ske_ib.reserve(guess);
+    auto push = [&](int ia, int ib) { T.ske_pt.push_back(ia / SK_MAX); T.ske_ia.push_back(ia); T.ske_ib.push_back(ib); };
+    for (size_t q = 0; q < PL.ent.size(); ++q) {
+        const uint32_t kind = PL.ent[q].src >> ND_KIND_SHIFT, idx = PL.ent[q].src & ND_SRC_MASK;
+        auto node_list = [&](int u, bool squared) {
+            if (u >= n_free) return;
+            for (int t = P.nl_ptr[u]; t < P.nl_ptr[u + 1]; ++t) push(P.nl_ix[t], squared ? P.nl_ix[t] : -1);
+        };
+        if (kind == 0) node_list((int)idx, true);
+        else if (kind == 2) node_list((int)idx, false);
+        else if (T.pkind[idx] == 0) { for (int t = P.pair_sk0[idx]; t < P.pair_sk1[idx]; ++t) push(P.skt[t].ia, P.skt[t].ib); }
+        else if (T.pkind[idx] == 1) node_list(T.pairs[2 * (size_t)idx + 1], false);
+        T.ske_ptr[q + 1] = (int)T.ske_pt.size();
+    }
+}
+// ... and this frame's coefficients for them
+static void nd_prep_ske_values(NdPrep& P, const double* sk_om) {
+    const NdStruct& T = *P.st;
+    const size_t n = T.ske_pt.size();
+    P.ske_cf.resize(n);
+    for (size_t t = 0; t < n; ++t) {
+        const double a = sk_om[T.ske_ia[t]];
+        P.ske_cf[t] = T.ske_ib[t] < 0 ? a : a * sk_om[T.ske_ib[t]];
+    }
+}
+
 static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
-    P.wanted = false; P.plan_ok = false; P.hit = nullptr;
+    P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.st.reset();
     P.node_of.assign(in.M, -1); P.node_vtx.clear();
     for (int v = 0; v < in.M; ++v)
         if (!(in.rflag[v] & RF_FIXED)) { P.node_of[v] = (int)P.node_vtx.size(); P.node_vtx.push_back(v); }
@@ -1047,6 +1090,19 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         if (in.n_skin > 0) put(in.sk_vert, 4 * (size_t)SK_MAX * in.n_skin);
         P.hash = nd_hash(key.data(), key.size());
     }
+    // the cache (read only here: nobody changes it while an engine is being set up).  A frame whose key an earlier one had takes
+    // that one's plan and structure as they are; only the skinning weights are its own.
+    const NdCache* nc = static_cast<const NdCache*>(c->nd_cache);
+    if (nc && !getenv("NRS_ND_NO_CACHE"))
+        for (NdSlot* sl : nc->slots)
+            if (!sl->busy && sl->st && sl->hash == P.hash && sl->key == P.key) {
+                P.hit = sl; P.st = sl->st;
+                if (in.n_skin > 0) nd_prep_ske_values(P, in.sk_om);
+                P.wanted = true;
+                return;
+            }
+    P.st = std::make_shared<NdStruct>();
+    NdStruct& T = *P.st;
     // unique row-row couplings with the edges that contribute to them
     struct Key { uint64_t k; int id; };
     std::vector<Key> keys;
@@ -1062,7 +1118,7 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     // its weights, and per free node the observations that reach it; everything in observation order (fixed summation order)
     std::vector<NdSkT>& skt = P.skt;
     skt.clear();
-    P.nl_ptr.assign(n_free + 1, 0); P.nl_pt.clear(); P.nl_om.clear();
+    P.nl_ptr.assign(n_free + 1, 0); P.nl_ix.clear();
     if (in.n_skin > 0) {
         std::vector<int>& nl_ptr = P.nl_ptr;
         size_t n_pairs_sk = 0;
@@ -1075,7 +1131,7 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
             n_pairs_sk += (size_t)cnt * (cnt - 1) / 2;
         }
         for (int u = 0; u < n_free; ++u) nl_ptr[u + 1] += nl_ptr[u];
-        P.nl_pt.resize(nl_ptr[n_free]); P.nl_om.resize(nl_ptr[n_free]);
+        P.nl_ix.resize(nl_ptr[n_free]);
         std::vector<int> fill(nl_ptr.begin(), nl_ptr.end() - 1);
         std::vector<NdSkT> raw;
         raw.reserve(n_pairs_sk);
@@ -1084,12 +1140,12 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
                 const int va = in.sk_vert[(size_t)SK_MAX * i + a];
                 if (va < 0 || node_of[va] < 0) continue;
                 const int na = node_of[va];
-                P.nl_pt[fill[na]] = i; P.nl_om[fill[na]++] = in.sk_om[(size_t)SK_MAX * i + a];
+                P.nl_ix[fill[na]++] = SK_MAX * i + a;
                 for (int b = a + 1; b < SK_MAX; ++b) {
                     const int vb = in.sk_vert[(size_t)SK_MAX * i + b];
                     if (vb < 0 || node_of[vb] < 0 || node_of[vb] == na) continue;
                     const int nb2 = node_of[vb];
-                    raw.push_back(NdSkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), i, in.sk_om[(size_t)SK_MAX * i + a] * in.sk_om[(size_t)SK_MAX * i + b]});
+                    raw.push_back(NdSkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), SK_MAX * i + a, SK_MAX * i + b});
                 }
             }
         // by (low node, high node), observation order inside: two stable counting passes (least significant key first)
@@ -1107,15 +1163,15 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         skt.swap(raw);
     }
     std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; });
-    P.pairs.clear(); P.pkind.clear(); P.eptr.assign(1, 0); P.eid.clear(); P.pair_sk0.clear(); P.pair_sk1.clear();
-    P.pairs.reserve(2 * (keys.size() + skt.size() / 4));
+    T.pairs.clear(); T.pkind.clear(); T.eptr.assign(1, 0); T.eid.clear(); P.pair_sk0.clear(); P.pair_sk1.clear();
+    T.pairs.reserve(2 * (keys.size() + skt.size() / 4));
     // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
     for (size_t i = 0, st = 0; i < keys.size() || st < skt.size();) {
         const uint64_t kk = i < keys.size() && (st >= skt.size() || keys[i].k <= skt[st].k) ? keys[i].k : skt[st].k;
-        for (; i < keys.size() && keys[i].k == kk; ++i) P.eid.push_back(keys[i].id);
-        P.eptr.push_back((int)P.eid.size());
-        P.pairs.push_back((int)(kk >> 32)); P.pairs.push_back((int)(kk & 0xFFFFFFFFu));
-        P.pkind.push_back(0);
+        for (; i < keys.size() && keys[i].k == kk; ++i) T.eid.push_back(keys[i].id);
+        T.eptr.push_back((int)T.eid.size());
+        T.pairs.push_back((int)(kk >> 32)); T.pairs.push_back((int)(kk & 0xFFFFFFFFu));
+        T.pkind.push_back(0);
         P.pair_sk0.push_back((int)st);
         while (st < skt.size() && skt[st].k == kk) ++st;
         P.pair_sk1.push_back((int)st);
@@ -1125,45 +1181,40 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         P.last[n_free] = P.last[n_free + 1] = 1;
         for (int a = 0; a < n_free; ++a)
             if (in.rflag[P.node_vtx[a]] & RF_OBS)
-                for (int h = 0; h < 2; ++h) { P.pkind.push_back(1); P.pairs.push_back(n_free + h); P.pairs.push_back(a); }
-        P.pkind.push_back(2); P.pairs.push_back(n_free + 1); P.pairs.push_back(n_free);
+                for (int h = 0; h < 2; ++h) { T.pkind.push_back(1); T.pairs.push_back(n_free + h); T.pairs.push_back(a); }
+        T.pkind.push_back(2); T.pairs.push_back(n_free + 1); T.pairs.push_back(n_free);
     }
     P.wanted = true;
-    // the cache (read only here: nobody changes it while an engine is being set up)
-    const NdCache* nc = static_cast<const NdCache*>(c->nd_cache);
-    if (nc && !getenv("NRS_ND_NO_CACHE"))
-        for (NdSlot* sl : nc->slots)
-            if (!sl->busy && sl->hash == P.hash && sl->key == P.key) { P.hit = sl; return; }
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
-    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)P.pkind.size(), P.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
+    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
+    if (P.plan_ok && in.n_skin > 0) { nd_prep_ske(P, P.plan); nd_prep_ske_values(P, in.sk_om); }
 }
 
 // phase B: leaves nd->on = false if the problem does not qualify
 static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     Dev& d = e->d;
-    if (P.th.joinable()) P.th.join();
+    {
+        const bool tm = getenv("NRS_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (P.th.joinable()) P.th.join();
+        if (tm) fprintf(stderr, "[nrs] direct solve: waited %.2f ms for the plan thread\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     nd_slot_release(c, nd);                                        // (a rebuild after the fixed set changed: the old plan goes back to the cache)
     if (!P.wanted || !nd_wanted(c, d, P.n_free)) return NRS_OK;
-    const int n_free = P.n_free, n_nodes = P.n_nodes, n_pairs = (int)P.pkind.size();
+    const NdStruct& T = *P.st;
+    const int n_free = P.n_free, n_nodes = P.n_nodes, n_pairs = (int)T.pkind.size();
     NdCache* nc = static_cast<NdCache*>(c->nd_cache);
     if (!nc) { nc = new (std::nothrow) NdCache(); if (!nc) return c->fail(NRS_ERR_ALLOC, "out of host memory"); c->nd_cache = nc; }
     const bool use_cache = true;                                  // (NRS_ND_NO_CACHE=1 only stops plans from being REUSED -- nd_prep_run -- the slots' buffers are)
     NdSlot* sl = P.hit && !P.hit->busy ? P.hit : nullptr;
     const bool hit = sl != nullptr;
     if (!hit) {
+        if (P.hit) return c->fail(NRS_ERR_STATE, "direct solve: the plan this engine was set up on was taken by another engine meanwhile (engines of one context are created one at a time)");
         if (!P.plan_ok) {
-            if (P.hit) {                                           // (cannot happen: the slot it found was taken meanwhile)
-                std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
-                for (int a = 0; a < n_free; ++a)
-                    for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = nd->pos[3 * (size_t)P.node_vtx[a] + k];
-                P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), n_pairs, P.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
-            }
-            if (!P.plan_ok) {
-                if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", P.err.c_str());
-                return NRS_OK;
-            }
+            if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", P.err.c_str());
+            return NRS_OK;
         }
         ++nc->misses;
         // a slot for the new plan: a free cached one (the least recently used is overwritten) or, if every cached slot is held by a
@@ -1206,44 +1257,25 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     if (P.pose_free) { nrow[n_free] = -1; nrow[n_free + 1] = -2; node_out[n_free] = -1; node_out[n_free + 1] = -1 - 3; }
     std::vector<NdPairD> pd(n_pairs);
     std::vector<int> src;
-    src.reserve(P.eid.size());
-    const int n_rr = (int)P.eptr.size() - 1;
+    src.reserve(T.eid.size());
     for (int i = 0; i < n_pairs; ++i) {
-        const int a = P.pairs[2 * (size_t)i], b = P.pairs[2 * (size_t)i + 1];
-        if (P.pkind[i] == 0) {
+        const int a = T.pairs[2 * (size_t)i], b = T.pairs[2 * (size_t)i + 1];
+        if (T.pkind[i] == 0) {
             // (the factor of an edge sits in both endpoints' incidence slots with the same value when both are free: the first one is read)
             pd[i] = NdPairD{0, nrow[a], nrow[b], (int)src.size(), 0};
-            for (int t = P.eptr[i]; t < P.eptr[i + 1]; ++t) {
-                const int id = P.eid[t] >> 1, kind = P.eid[t] & 1;
+            for (int t = T.eptr[i]; t < T.eptr[i + 1]; ++t) {
+                const int id = T.eid[t] >> 1, kind = T.eid[t] & 1;
                 const int slot = kind ? e->dm_pos[4 * (size_t)id + 2] : e->sp_pos[2 * (size_t)id];
                 if (slot < 0) return NRS_OK;                       // (an incidence of another rank: not a single-frame engine)
                 src.push_back((slot << 1) | kind);
             }
             pd[i].nsrc = (int)src.size() - pd[i].src0;
-        } else if (P.pkind[i] == 1) pd[i] = NdPairD{1, a - n_free, nrow[b], 0, 0};
+        } else if (T.pkind[i] == 1) pd[i] = NdPairD{1, a - n_free, nrow[b], 0, 0};
         else pd[i] = NdPairD{2, 0, 0, 0, 0};
     }
-    (void)n_rr;
-    // embedded mode: per plan entry the observations that add to it
-    std::vector<int> ske_ptr, ske_pt;
-    std::vector<double> ske_cf;
-    if (d.sk_n > 0) {
-        const NdPlan& PL = sl->S.plan;
-        ske_ptr.assign(PL.ent.size() + 1, 0);
-        ske_pt.reserve(4 * P.nl_pt.size() + P.skt.size()); ske_cf.reserve(4 * P.nl_pt.size() + P.skt.size());
-        for (size_t q = 0; q < PL.ent.size(); ++q) {
-            const uint32_t kind = PL.ent[q].src >> ND_KIND_SHIFT, idx = PL.ent[q].src & ND_SRC_MASK;
-            auto node_list = [&](int u, bool squared) {
-                if (u >= n_free) return;
-                for (int t = P.nl_ptr[u]; t < P.nl_ptr[u + 1]; ++t) { ske_pt.push_back(P.nl_pt[t]); ske_cf.push_back(squared ? P.nl_om[t] * P.nl_om[t] : P.nl_om[t]); }
-            };
-            if (kind == 0) node_list((int)idx, true);
-            else if (kind == 2) node_list((int)idx, false);
-            else if (P.pkind[idx] == 0) { for (int t = P.pair_sk0[idx]; t < P.pair_sk1[idx]; ++t) { ske_pt.push_back(P.skt[t].pt); ske_cf.push_back(P.skt[t].cf); } }
-            else if (P.pkind[idx] == 1) node_list(P.pairs[2 * (size_t)idx + 1], false);
-            ske_ptr[q + 1] = (int)ske_pt.size();
-        }
-    }
+    // embedded mode: per plan entry the observations that add to it (built beside the plan, nd_prep_run)
+    const std::vector<int>&ske_ptr = T.ske_ptr, &ske_pt = T.ske_pt;
+    const std::vector<double>& ske_cf = P.ske_cf;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_nr = 0, o_no = o_nr + al(4 * (size_t)n_nodes), o_pd = o_no + al(4 * (size_t)n_nodes), o_src = o_pd + al(sizeof(NdPairD) * (size_t)n_pairs),
                  o_sp = o_src + al(4 * std::max<size_t>(1, src.size())), o_st = o_sp + al(4 * std::max<size_t>(1, ske_ptr.size())),
@@ -1281,7 +1313,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     nd->sig[d.M] = e->h_pose_fixed[0];
     sl->busy = true; sl->used = ++nc->clock;
     nd->slot = sl; nd->on = true;
-    if (!hit) { sl->key.swap(P.key); sl->hash = P.hash; }
+    if (!hit) { sl->key.swap(P.key); sl->hash = P.hash; sl->st = P.st; }
     sguard.keep = true;
     if (getenv("NRS_TIMING"))
         fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", sl->n_free,

@@ -29,7 +29,7 @@ struct nrs_rgraph {
     float sigma = 1.f, stretch_th = 1.1f, min_w = 0.f;
     float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
     uint8_t* st = nullptr;
-    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good;
+    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip;
     char* pin = nullptr;             // pinned staging area of the GetEdges results (page-faulting pageable targets cost more than the kernel)
     size_t pin_cap = 0;
 };
@@ -112,9 +112,12 @@ constexpr int RG_SLACK = 1024;   // candidates staged beyond out_cap (the popula
 // of the surviving weights per status class, from which the (class, bin) at which the first out_cap entries end is
 // known; pass 2 stages only the entries up to that bin (<= out_cap + one bin's population) and those are put in order.
 // `select_all`: stage every survivor (the fallback when a bin holds more than RG_SLACK entries: many equal distances).
+// `skip` (may be null): points the caller's walk passes over without any effect (the embedded mode's optimised points that
+// carry no vertex, OPT:255-279 as restated in oracle/embedded_oracle.py): their connections are left out of the list unless
+// BAD (a BAD connection ends the walk whoever it leads to).  They still count for s*: the list ends where the reference's ends.
 __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __restrict__ ids, int cap, const float* __restrict__ maxd,
                                                      const float* __restrict__ d0, const uint8_t* __restrict__ st, float sigma,
-                                                     float min_w, float d_hi, int cand_cap, int out_cap, int select_all, int* o_count,
+                                                     float min_w, float d_hi, int cand_cap, int out_cap, int select_all, const uint8_t* __restrict__ skip, int* o_count,
                                                      int* o_col, float* o_w, float* o_d0, int* o_st, int* overflow) {
     extern __shared__ unsigned long long cand[];              // keys of the staged connections (padded to a power of two for the sort)
     __shared__ int hist[RG_CLASSES][RG_BINS];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
         float w; int s;
         const bool keep = entry(j0 + lane, w, s);
         if (!keep && s != 255) s_star = min(s_star, s);
-        if (keep) atomicAdd(&hist[min(s, RG_CLASSES - 1)][bin_of(w)], 1);
+        if (keep && !(skip && s != NRS_GRAPH_BAD && skip[j0 + lane])) atomicAdd(&hist[min(s, RG_CLASSES - 1)][bin_of(w)], 1);
     }
     for (int off = 32; off > 0; off >>= 1) s_star = min(s_star, __shfl_xor(s_star, off, 64));
     __syncthreads();
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
     for (int j0 = 0; j0 < cap; j0 += 64) {
         float w; int s;
         bool keep = entry(j0 + lane, w, s);
+        if (keep && skip && s != NRS_GRAPH_BAD && skip[j0 + lane]) keep = false;
         if (keep) {
             const int c = min(s, RG_CLASSES - 1);
             int cc = cut[0];
@@ -287,7 +291,7 @@ extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
     if (g->pin) (void)hipHostFree(g->pin);
-    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good);
+    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip);
     delete g;
 }
 
@@ -364,7 +368,7 @@ int rg_max_cap_per_point(const nrs_rgraph* g) {
     return std::min(g->cap, (int)cand_max - RG_SLACK);
 }
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
-                        const int** status, const float** w, const float** d0) {
+                        const int** status, const float** w, const float** d0, const uint8_t* pass_over) {
     nrs_ctx* c = g->c;
     NRS_TRY(rg_check_ids(g, n_ids, ids, "GetEdges"));               // (also the a2 driver's entry: ids index the dense state)
     if (cap_per_point <= 0) return c->fail(NRS_ERR_INVALID, "GetEdges: cap_per_point must be positive");
@@ -396,6 +400,10 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
         g->pin_cap = want;
     }
     NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
+    if (pass_over) {                                               // (one byte per point of the dense state)
+        NRS_TRY(c->ensure(g->skip, (size_t)g->cap));
+        NRS_HIP(c, hipMemcpyAsync(g->skip.p, pass_over, (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
+    }
     const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
     // first the selecting form (stages <= cap_per_point + one histogram bin per row); if a bin overflows the staging area
     // (many equal distances), once more with every survivor of a row staged
@@ -409,7 +417,7 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
         const size_t shm = sizeof(unsigned long long) * pad;
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), shm, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
-                           g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
+                           g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, pass_over ? g->skip.as<uint8_t>() : nullptr, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
         NRS_HIP(c, hipGetLastError());
         NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -434,7 +442,7 @@ extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t*
     if (n_ids == 0) return NRS_OK;
     const int *h_cnt, *h_col, *h_st;
     const float *h_w, *h_d0;
-    NRS_TRY(rg_get_edges_staged(g, n_ids, ids, cap_per_point, &h_cnt, &h_col, &h_st, &h_w, &h_d0));
+    NRS_TRY(rg_get_edges_staged(g, n_ids, ids, cap_per_point, &h_cnt, &h_col, &h_st, &h_w, &h_d0, nullptr));
     const size_t no = (size_t)n_ids * cap_per_point;
     memcpy(count, h_cnt, sizeof(int) * (size_t)n_ids);
     memcpy(col, h_col, sizeof(int) * no);

@@ -225,6 +225,9 @@ struct NeighbourSource {
     // UpdateVertex of the listed points from the last world positions; good[i] = its return value
     virtual int update(const float* map_pos, int n, const int* ids, int* good) = 0;
     std::vector<char> truncated;      // per point: select() returned only a prefix of its list
+    // per map point, may be null: 1 = the caller's walk passes over this point's connections without any effect unless they are
+    // BAD; a source may leave them out of the lists (the dense one does: an embedded-mode walk would read ~N/M entries per node found)
+    const std::vector<uint8_t>* pass_over = nullptr;
     virtual bool grow() { return false; }                          // fetch longer prefixes next time (false: there is nothing longer)
 };
 
@@ -243,7 +246,7 @@ struct FlatSource : NeighbourSource {
 };
 
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
-                        const int** status, const float** w, const float** d0);   // nrs_rgraph.hip
+                        const int** status, const float** w, const float** d0, const uint8_t* pass_over);   // nrs_rgraph.hip
 int rg_capacity(const nrs_rgraph* g);
 int rg_max_cap_per_point(const nrs_rgraph* g);
 
@@ -258,7 +261,7 @@ struct DenseSource : NeighbourSource {
         if (m == 0) return NRS_OK;
         const int *cnt, *fc, *fs;
         const float *fw, *fd;
-        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &fc, &fs, &fw, &fd));   // pinned staging area, read in place
+        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &fc, &fs, &fw, &fd, pass_over ? pass_over->data() : nullptr));   // pinned staging area, read in place
         for (size_t r = 0; r < m; ++r) { truncated[want[r]] = cnt[r] > cap; rp[(size_t)want[r] + 1] = std::min(cnt[r], cap); }
         for (size_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
         col.resize(rp[n]); w.resize(rp[n]); d0.resize(rp[n]); st.resize(rp[n]);
@@ -420,6 +423,12 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     std::vector<int> sk_node((size_t)(N - M) * 11, -1), sk_of(N, -1), sk_idx;     // skinned observations: nodes (vertex indices), weights
     std::vector<double> sk_om((size_t)(N - M) * 11, 0.0);
     std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
+    std::vector<uint8_t> no_vertex;                               // embedded mode: optimised points without a vertex (passed over below)
+    if (M < N) {
+        no_vertex.assign(n_map, 0);
+        for (int i = 0; i < N; ++i) no_vertex[ids[i]] = node_of[i] < 0;
+        src.pass_over = &no_vertex;
+    }
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
     again = false;
     NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
@@ -474,6 +483,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         }
     }
     }
+    src.pass_over = nullptr;
     mark("GetEdges + edge construction");
     const int E = (int)dm_w.size(), S = (int)sk_idx.size();
 

@@ -62,3 +62,45 @@ def test_embedded_mode_matches_its_oracle(ctx, n, m, seed, model):
     probe = np.arange(0, n, max(1, n // 25), dtype=np.int32)
     assert np.array_equal(g.rows(probe)[3], D.st[probe])
     g.close()
+
+
+def test_reused_plan_takes_the_new_frames_skinning_weights():
+    """a frame whose structure (optimised set, nodes, which nodes every point is skinned to) an earlier frame had reuses that frame's
+    plan and observation lists (nrs_engine_nd.hpp NdStruct) -- with its OWN skinning weights: the same bits as a context that
+    builds everything for it"""
+    import os
+    n, m = 700, 90
+    tp = S.make_tracking_problem(n, 47, S.PINHOLE)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    ids = np.arange(n, dtype=np.int32)
+
+    def run(c, sigma, node):
+        g = nrs.RGraph(c, n, sigma, tp["graph"]["stretch_th"])
+        g.add_edges(tp["X_prev"], ids, ids)
+        r = c.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], nrs.Trace(1024), 256)
+        g.close()
+        return r
+
+    sig = tp["graph"]["sigma"]
+    c = nrs.Context()
+    try:
+        nodes = c.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0)
+        node = np.zeros(n, np.uint8)
+        node[nodes] = 1
+        a = run(c, sig, node)
+        h0 = c.nd_cache_stats()[0]
+        b = run(c, sig * 1.02, node)                                # the same neighbours in the same order, other weights
+        assert c.nd_cache_stats()[0] > h0, "the second frame was expected to reuse the first one's plan"
+    finally:
+        c.close()
+    os.environ["NRS_ND_NO_CACHE"] = "1"
+    try:
+        c = nrs.Context()
+        fresh = run(c, sig * 1.02, node)
+        c.close()
+    finally:
+        del os.environ["NRS_ND_NO_CACHE"]
+    assert not np.array_equal(a["f_pos"], b["f_pos"])
+    for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
+        assert np.array_equal(b[k], fresh[k]), k
+    assert b["lost"] == fresh["lost"] and b["median"] == fresh["median"]
