@@ -229,6 +229,7 @@ struct NeighbourSource {
     // BAD; a source may leave them out of the lists (the dense one does: an embedded-mode walk would read ~N/M entries per node found)
     const std::vector<uint8_t>* pass_over = nullptr;
     virtual bool grow() { return false; }                          // fetch longer prefixes next time (false: there is nothing longer)
+    virtual void prefix_hint(int) {}                               // the next walks read about this many entries (grow() still applies)
 };
 
 struct FlatSource : NeighbourSource {
@@ -281,6 +282,7 @@ struct DenseSource : NeighbourSource {
         cap = std::min(lim, 4 * cap);
         return true;
     }
+    void prefix_hint(int n) override { cap = std::min(cap, std::max(n, 16)); }
     int update(const float* map_pos, int n, const int* ids, int* good) override { return n ? nrs_rgraph_update(g, map_pos, n, ids, good) : NRS_OK; }
 };
 
@@ -617,6 +619,11 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     const int NV = M + (int)others.size();
     std::vector<int> un_ij;
     std::vector<float> un_w;
+    // the walk below counts optimised neighbours only and stops after 11: everything else may stay out of the lists
+    std::vector<uint8_t> not_optimised(n_map);
+    for (int i = 0; i < n_map; ++i) not_optimised[i] = id_to_idx[i] < 0;
+    src.pass_over = &not_optimised;
+    src.prefix_hint(32);
     for (bool again = true; again;) {
     again = false;
     NRS_TRY(src.select(lost_ids, orp, ocol, ow, od0, ost));       // GetEdges sees the updated graph
@@ -639,6 +646,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         }
     }
     }
+    src.pass_over = nullptr;
     mark("GetEdges 2 + walk");
     const int M2 = NV + L;
     // Only the free vertices (nodes the statistics left free, lost points) and what an edge ties them to take part: an edge between
