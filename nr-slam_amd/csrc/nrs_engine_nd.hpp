@@ -915,11 +915,6 @@ __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
         atomicMax(reinterpret_cast<unsigned long long*>(P.sk_maxdiag), (unsigned long long)__double_as_longlong(fmax(fabs(o[0]), fmax(fabs(o[4]), fabs(o[8])))));
 }
 
-// One symbolic factorisation with everything the device needs for it (plan arrays, value descriptors, assembly areas, factor
-// storage).  The context keeps the last few (nd_cache): a frame whose optimised set, edges and fixed flags equal an earlier frame's
-// -- tracking in steady state: points are lost and edges added every few frames, not every frame -- takes the slot as it is, no
-// plan build (1.0 ms at 1k points, 5 ms at 4.5k) and no upload.  The key is the complete input of nd_engine_setup except the
-// positions the dissection bisects (they only steer its quality), compared byte for byte.
 // what a plan's key determines besides the plan itself: the node pairs with their edges and, in the embedded mode, which
 // observations add to which plan entry.  Built once per plan; a frame that reuses the plan only fills in its own weights.
 struct NdStruct {
@@ -930,6 +925,11 @@ struct NdStruct {
     // w[ske_ia] * w[ske_ib] (ske_ib < 0: w[ske_ia] alone); indices into the frame's SK_MAX-wide weight table
     std::vector<int> ske_ptr, ske_pt, ske_ia, ske_ib;
 };
+// One symbolic factorisation with everything the device needs for it (plan arrays, value descriptors, assembly areas, factor
+// storage).  The context keeps the last few (nd_cache): a frame whose optimised set, edges and fixed flags equal an earlier frame's
+// -- tracking in steady state: points are lost and edges added every few frames, not every frame -- takes the slot as it is, no
+// plan build (1.0 ms at 1k points, 5 ms at 4.5k) and no upload.  The key is the complete input of nd_engine_setup except the
+// positions the dissection bisects (they only steer its quality), compared byte for byte.
 struct NdSlot {
     NdSolver S;
     std::shared_ptr<NdStruct> st;
@@ -1031,6 +1031,23 @@ struct NdPrep {
 };
 
 
+// records with a key k = (low node << 32) | high node into key order, equal keys in their order of arrival: two stable counting
+// passes (least significant half first) -- a comparison sort of the ~10^5 records of a 4.5k-point frame took longer than its plan
+template <class T>
+static void nd_sort_by_pair(std::vector<T>& v, int n_free) {
+    std::vector<T> tmp(v.size());
+    std::vector<int> cnt(n_free + 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<T>& inv = pass == 0 ? v : tmp;
+        std::vector<T>& outv = pass == 0 ? tmp : v;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        auto dig = [&](const T& t) { return pass == 0 ? (int)(t.k & 0xFFFFFFFFu) : (int)(t.k >> 32); };
+        for (const T& t : inv) cnt[dig(t) + 1]++;
+        for (int u = 0; u < n_free; ++u) cnt[u + 1] += cnt[u];
+        for (const T& t : inv) outv[cnt[dig(t)]++] = t;
+    }
+}
+
 // embedded mode: the observation lists of a plan's entries
 static void nd_prep_ske(NdPrep& P, const NdPlan& PL) {
     NdStruct& T = *P.st;
@@ -1066,6 +1083,10 @@ static void nd_prep_ske_values(NdPrep& P, const double* sk_om) {
 
 static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.st.reset();
+    const bool tm = getenv("NRS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_ms[3] = {0, 0, 0};                                    // key + look-up, pairs, plan
+    auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); t_ms[k] = std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
     P.node_of.assign(in.M, -1); P.node_vtx.clear();
     for (int v = 0; v < in.M; ++v)
         if (!(in.rflag[v] & RF_FIXED)) { P.node_of[v] = (int)P.node_vtx.size(); P.node_vtx.push_back(v); }
@@ -1101,6 +1122,7 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
                 P.wanted = true;
                 return;
             }
+    lap(0);
     P.st = std::make_shared<NdStruct>();
     NdStruct& T = *P.st;
     // unique row-row couplings with the edges that contribute to them
@@ -1148,21 +1170,10 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
                     raw.push_back(NdSkT{((uint64_t)std::min(na, nb2) << 32) | (uint32_t)std::max(na, nb2), SK_MAX * i + a, SK_MAX * i + b});
                 }
             }
-        // by (low node, high node), observation order inside: two stable counting passes (least significant key first)
-        skt.resize(raw.size());
-        std::vector<int> cnt(n_free + 1);
-        for (int pass = 0; pass < 2; ++pass) {
-            const std::vector<NdSkT>& inv = pass == 0 ? raw : skt;
-            std::vector<NdSkT>& outv = pass == 0 ? skt : raw;
-            std::fill(cnt.begin(), cnt.end(), 0);
-            auto dig = [&](const NdSkT& t) { return pass == 0 ? (int)(t.k & 0xFFFFFFFFu) : (int)(t.k >> 32); };
-            for (const NdSkT& t : inv) cnt[dig(t) + 1]++;
-            for (int u = 0; u < n_free; ++u) cnt[u + 1] += cnt[u];
-            for (const NdSkT& t : inv) outv[cnt[dig(t)]++] = t;
-        }
+        nd_sort_by_pair(raw, n_free);                               // by (low node, high node), observation order inside
         skt.swap(raw);
     }
-    std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; });
+    nd_sort_by_pair(keys, n_free);                                 // (edge order inside a pair)
     T.pairs.clear(); T.pkind.clear(); T.eptr.assign(1, 0); T.eid.clear(); P.pair_sk0.clear(); P.pair_sk1.clear();
     T.pairs.reserve(2 * (keys.size() + skt.size() / 4));
     // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
@@ -1185,11 +1196,14 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         T.pkind.push_back(2); T.pairs.push_back(n_free + 1); T.pairs.push_back(n_free);
     }
     P.wanted = true;
+    lap(1);
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
     P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
     if (P.plan_ok && in.n_skin > 0) { nd_prep_ske(P, P.plan); nd_prep_ske_values(P, in.sk_om); }
+    lap(2);
+    if (tm) fprintf(stderr, "[nrs] direct solve set-up thread: key %.2f ms, pairs %.2f ms, plan %.2f ms\n", t_ms[0], t_ms[1], t_ms[2]);
 }
 
 // phase B: leaves nd->on = false if the problem does not qualify

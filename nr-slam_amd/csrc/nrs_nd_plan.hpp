@@ -98,7 +98,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     // ---- separator tree by recursive coordinate bisection
     struct FH { std::vector<int> own, ch; };
     std::vector<FH> F;
-    std::vector<int> side(n_nodes, 0), slot(n_nodes, 0);
+    std::vector<int> side(n_nodes, 0), slot(n_nodes, 0), mark(n_nodes, 0);
     int stamp = 0;
     auto new_front = [&](std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; };
     std::vector<std::pair<double, int>> keyed;
@@ -112,9 +112,10 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             if (a != skip_axis && (ax < 0 || hi[a] - lo[a] > hi[ax] - lo[ax])) ax = a;
         keyed.resize(v.size());                                    // (coordinate, id) pairs: the sort touches no indirect memory
         for (size_t i = 0; i < v.size(); ++i) keyed[i] = {pos[3 * (size_t)v[i] + ax], v[i]};
-        if (split < 0) std::sort(keyed.begin(), keyed.end());
-        else std::nth_element(keyed.begin(), keyed.begin() + split, keyed.end());       // (pairs are distinct: the two halves are determined)
-        for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
+        if (split < 0) {
+            std::sort(keyed.begin(), keyed.end());
+            for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
+        } else std::nth_element(keyed.begin(), keyed.begin() + split, keyed.end());     // (pairs are distinct: the two halves are determined; v stays as it is)
         return ax;
     };
     // chain of fronts over one separator (or leaf) that is longer than a front may own
@@ -131,28 +132,29 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
     struct Rec {
         std::vector<FH>& F; std::vector<int>& side; int& stamp; const std::vector<int>&ap, &an; const uint8_t* last;
         decltype(axis_sort)& asort; decltype(chain)& mk_chain; int leaf_n; std::vector<int>& slot; bool vertex_cover;
-        std::vector<int> run(std::vector<int> v) {
+        const std::vector<std::pair<double, int>>& keyed; std::vector<int>& mark;
+        std::vector<int> run(std::vector<int> v) {                   // (v ascending by node index, here and in every call below)
             if (v.empty()) return {};
             if ((int)v.size() <= leaf_n) { asort(v, -1); return {mk_chain(v, {})}; }
             const size_t half = v.size() / 2;
             const int ax = asort(v, -1, (int)half);
-            std::vector<int> L(v.begin(), v.begin() + half), R(v.begin() + half, v.end());
-            std::sort(L.begin(), L.end()); std::sort(R.begin(), R.end());    // (a defined order inside the halves: node index)
+            // the halves in a defined order (node index): v is, and is read in that order
+            const int sl = ++stamp, sr = ++stamp;
+            for (size_t i = 0; i < v.size(); ++i) side[keyed[i].second] = i < half ? sl : sr;
+            std::vector<int> L, R;
+            L.reserve(half); R.reserve(v.size() - half);
+            for (int u : v) (side[u] == sl ? L : R).push_back(u);
             // the thinner of the two candidate separators: the L nodes that touch R, or the R nodes that touch L
-            const int sl = ++stamp;
-            for (int u : L) side[u] = sl;
-            const int sr = ++stamp;
-            for (int u : R) side[u] = sr;
-            auto touching = [&](const std::vector<int>& from, int other) {
-                std::vector<int> s;
-                for (int u : from) {
-                    bool t = false;
-                    for (int e = ap[u]; e < ap[u + 1] && !t; ++e) t = side[an[e]] == other;
-                    if (t) s.push_back(u);
-                }
-                return s;
-            };
-            std::vector<int> sepL = touching(L, sr), sepR = touching(R, sl);
+            // (one pass over L's connections finds both: the graph is symmetric)
+            std::vector<int> sepL, sepR;
+            const int sm = ++stamp;
+            for (int u : L) {
+                bool t = false;
+                for (int e = ap[u]; e < ap[u + 1]; ++e)
+                    if (side[an[e]] == sr) { t = true; mark[an[e]] = sm; }
+                if (t) sepL.push_back(u);
+            }
+            for (int u : R) if (mark[u] == sm) sepR.push_back(u);
             // the smallest set of nodes that covers every edge of the cut: a minimum vertex cover of the bipartite graph (sepL, sepR, cut
             // edges), from a maximum matching (Koenig).  Never larger than the thinner side; on kNN graphs 10-25 % smaller, which takes
             // chain links -- whole levels -- off the top of the tree
@@ -208,7 +210,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             asort(sep, ax);                                        // along the cut, so that the chunks of a long separator are contiguous
             return {mk_chain(sep, std::move(ra))};
         }
-    } rec{F, side, stamp, ap, an, last, axis_sort, chain, leaf_n, slot, getenv("NRS_ND_NO_COVER") == nullptr};
+    } rec{F, side, stamp, ap, an, last, axis_sort, chain, leaf_n, slot, getenv("NRS_ND_NO_COVER") == nullptr, keyed, mark};
     std::vector<int> regular, tail;
     for (int i = 0; i < n_nodes; ++i) (last && last[i] ? tail : regular).push_back(i);
     std::vector<int> roots = rec.run(std::move(regular));
