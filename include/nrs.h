@@ -373,7 +373,9 @@ int nrs_track_deform_solve(nrs_ctx* ctx, const nrs_camera* cam, nrs_graph* g, fl
  * taken over all of its N - 1 connections as in the reference (the "fewer than 5 -> BAD" rule, OPT:470-473).
  * n_points = the graph's capacity = rows of map_pos; cap_per_point = how much of each point's GetEdges list is fetched at
  * first (if a walk of OPT:255-279 reaches the end of a truncated list, four times as much is fetched and the walks start
- * over: the result does not depend on cap_per_point, the time does). */
+ * over: the result does not depend on cap_per_point, the time does).  Connections a walk passes over without any effect
+ * are left out of the fetched lists on the device: in the lost-point stage (OPT:483-520) those to points that were not
+ * optimised, in the embedded mode below those to optimised points that carry no vertex (BAD ones stay: they end a walk). */
 int nrs_track_deform_solve_rg(nrs_ctx* ctx, const nrs_camera* cam, nrs_rgraph* g, int32_t n_points, int32_t cap_per_point,
                               float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status, const float* f_uv,
                               float* f_pos, double pose_qt[7], float scale, float* deform_median, int32_t* n_lost,

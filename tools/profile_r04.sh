@@ -24,11 +24,13 @@ for W in C2 C4; do
 done
 fi
 cd $R
-NRS_TIMING=1 timeout 200 python tools/small_frame_probe.py 600 1150 2500 5000 2>&1 | grep -E "^n |direct solve:" > $OUT/small_frames.txt
+NRS_TIMING=1 timeout 200 python tools/small_frame_probe.py 600 1150 2500 5000 2>&1 | grep -E "^n |direct solve: [0-9p]" > $OUT/small_frames.txt
 timeout 300 python tools/nd_crossover.py > $OUT/nd_crossover.txt 2>&1
 timeout 600 python tools/nd_crossover.py --dense 600 1150 2500 3500 5000 > $OUT/nd_crossover_dense.txt 2>&1
 timeout 300 python tools/tracked_fps_probe.py 5000 7 > $OUT/tracked_fps_probe.txt 2>&1
 NRS_ND_DBG=1 timeout 100 python tools/nd_kernel_probe.py 1013 > $OUT/nd_phases_1013.txt 2>&1
+# the embedded-deformation frame (5k points x 500 nodes) and the 500-node / 4500-lost-point frame: host phases of the last call of each, then the probe's line
+NRS_TIMING=1 timeout 200 python tools/skinned_probe.py > $OUT/skinned_raw.txt 2>&1; (grep -E "\] a2 |set-up thread|waited" $OUT/skinned_raw.txt | tail -24; tail -1 $OUT/skinned_raw.txt) > $OUT/embedded_phases.txt
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 200 python tools/lin_probe.py C2 C3 C4 2>&1 | grep workload > $OUT/lin_probe.jsonl
 find $OUT -name "*.csv" -size +20M -delete

@@ -14,7 +14,7 @@ def first(pattern):
 f = first("stats/**/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, "r04_bench_kernel_stats.csv"))
-for name in ("bench.json", "lin_probe.jsonl", "small_frames.txt", "nd_crossover.txt", "nd_crossover_dense.txt", "tracked_fps_probe.txt", "nd_phases_1013.txt"):
+for name in ("bench.json", "lin_probe.jsonl", "small_frames.txt", "nd_crossover.txt", "nd_crossover_dense.txt", "tracked_fps_probe.txt", "nd_phases_1013.txt", "embedded_phases.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "r04_" + name))
 
