@@ -300,8 +300,11 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
     if (d.sk_n > 0) hipLaunchKernelGGL((k_skin<LIN>), dim3(d.sk_nblk), b, 0, c->stream, d, d.pose[which], d.xl[which]);   // embedded mode: the skinned observations
-    if (LIN && e->nd && e->nd->on)                                 // the direct solver's explicit blocks of this linearisation
-        hipLaunchKernelGGL(k_nd_values, dim3((e->nd->slot->vals.n_ent + 255) / 256), dim3(256), 0, c->stream, d, e->nd->slot->vals);
+    if (LIN && e->nd && e->nd->on) {                               // the direct solver's explicit blocks of this linearisation
+        const NdVals& nv = e->nd->slot->vals;
+        if (nv.ske_ptr) hipLaunchKernelGGL(k_nd_values<true>, dim3((nv.n_ent * ND_SKL + 255) / 256), dim3(256), 0, c->stream, d, nv);
+        else hipLaunchKernelGGL(k_nd_values<false>, dim3((nv.n_ent + 255) / 256), dim3(256), 0, c->stream, d, nv);
+    }
     if (d.sh_on) {
         // local sums -> packet -> all-reduce over the ranks (pose blocks of the normal equations, chi2,
         // scale, one max-diagonal slot per rank) -> every rank publishes the same scalars

@@ -789,9 +789,15 @@ struct NdVals {
 
 __device__ inline int nd_hpp_idx(int r, int cc) { return r * 6 - (r * (r - 1)) / 2 + (cc - r); }   // H_pp packed upper-triangular (r <= cc)
 
-// one thread per original entry of the plan: its 3 x 3 block (or its 3 right-hand-side values) of the current linearisation
+// one thread per original entry of the plan: its 3 x 3 block (or its 3 right-hand-side values) of the current linearisation.
+// SK (embedded mode): ND_SKL lanes per entry -- all of them form the entry's own part (same addresses: one fetch), each adds up
+// every ND_SKL-th skinned observation of the entry's list (a node is reached by ~N * 11 / M observations: ~100 at 5k x 500, a
+// serial chain of dependent fetches for one thread) and the partial sums meet in a fixed butterfly: bit-reproducible
+constexpr int ND_SKL = 8;
+template <bool SK>
 __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int i = SK ? tid / ND_SKL : tid, sub = SK ? tid % ND_SKL : 0;
     if (i >= V.n_ent) return;
     const NdEnt E = V.ent[i];
     const uint32_t kind = E.src >> ND_KIND_SHIFT, idx = E.src & ND_SRC_MASK;
@@ -885,21 +891,30 @@ __global__ __launch_bounds__(256) void k_nd_values(Dev P, NdVals V) {
                 }
         }
     }
-    if (V.ske_ptr && form != 3) {                                  // the skinned observations that reach this entry, in list order
-        for (int t = V.ske_ptr[i]; t < V.ske_ptr[i + 1]; ++t) {
+    if (SK) {                                                      // the skinned observations that reach this entry: every ND_SKL-th, in list order
+        double p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int t1 = form != 3 ? V.ske_ptr[i + 1] : 0;
+        for (int t = form != 3 ? V.ske_ptr[i] + sub : 0; t < t1; t += ND_SKL) {
             const double* rec = P.sk_rec + 27 * (size_t)V.ske_pt[t];
             const double cf = V.ske_coef[t];
             if (form == 0) {
-                o[0] += cf * rec[0]; o[1] += cf * rec[1]; o[2] += cf * rec[2]; o[3] += cf * rec[1]; o[4] += cf * rec[3]; o[5] += cf * rec[4];
-                o[6] += cf * rec[2]; o[7] += cf * rec[4]; o[8] += cf * rec[5];
-            } else if (form == 1) { o[0] += cf * rec[6]; o[1] += cf * rec[7]; o[2] += cf * rec[8]; }
+                p[0] += cf * rec[0]; p[1] += cf * rec[1]; p[2] += cf * rec[2]; p[3] += cf * rec[1]; p[4] += cf * rec[3]; p[5] += cf * rec[4];
+                p[6] += cf * rec[2]; p[7] += cf * rec[4]; p[8] += cf * rec[5];
+            } else if (form == 1) { p[0] += cf * rec[6]; p[1] += cf * rec[7]; p[2] += cf * rec[8]; }
             else {
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) o[3 * a + b] += cf * rec[9 + 3 * (3 * half + a) + b];
+                    for (int b = 0; b < 3; ++b) p[3 * a + b] += cf * rec[9 + 3 * (3 * half + a) + b];
             }
         }
+#pragma unroll
+        for (int off = 1; off < ND_SKL; off <<= 1)                  // (x + y on both partners: every lane ends with the same bits)
+#pragma unroll
+            for (int a = 0; a < 9; ++a) p[a] += __shfl_xor(p[a], off, 64);
+#pragma unroll
+        for (int a = 0; a < 9; ++a) o[a] += p[a];
+        if (sub != 0) return;
     }
     double* out = V.ev + 9 * (size_t)i;
 #pragma unroll
