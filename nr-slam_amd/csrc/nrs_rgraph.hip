@@ -29,7 +29,8 @@ struct nrs_rgraph {
     float sigma = 1.f, stretch_th = 1.1f, min_w = 0.f;
     float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
     uint8_t* st = nullptr;
-    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip;
+    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip, slot;
+    std::vector<int> h_slot;
     char* pin = nullptr;             // pinned staging area of the GetEdges results (page-faulting pageable targets cost more than the kernel)
     size_t pin_cap = 0;
 };
@@ -91,6 +92,59 @@ __global__ __launch_bounds__(256) void k_rg_update(int n_ids, const int* __restr
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = n_good;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&good[blockIdx.y], lds[0] + lds[1] + lds[2] + lds[3]);      // integer: order-free
+}
+
+// The same update when a large part of the points is listed (a frame's inliers: most of the map): one pass over the stored
+// upper triangle, 64-row x 256-column tiles, a thread per column -- every pair that has a listed end is updated ONCE, by row-wise
+// (coalesced) accesses; the kernel above reads the j < i part of a vertex's connections down a column (one 4-byte word per
+// 4 * cap bytes) and updates a pair of two listed vertices twice.  slot[v] = place of v in the id list (-1: not listed, no
+// duplicates); the counts are integer sums: order-free.  Same values: the distance is symmetric to the last bit.
+constexpr int RG_TR = 64, RG_TC = 256;
+__global__ __launch_bounds__(RG_TC) void k_rg_update_tri(const int* __restrict__ slot, const float* __restrict__ pos, int cap, float* maxd,
+                                                         float* mind, uint8_t* st, float stretch_th, int* good) {
+#pragma clang fp contract(off)
+    __shared__ float rpos[RG_TR][3];
+    __shared__ int rslot[RG_TR], rcnt[RG_TR];
+    const int r0 = blockIdx.y * RG_TR, c0 = blockIdx.x * RG_TC, t = threadIdx.x;
+    if (c0 + RG_TC - 1 <= r0) return;                               // (all of the tile is at or below the diagonal)
+    if (t < RG_TR) {
+        const int r = r0 + t;
+        rslot[t] = r < cap ? slot[r] : -1;
+        rcnt[t] = 0;
+        for (int k = 0; k < 3; ++k) rpos[t][k] = r < cap ? pos[3 * r + k] : 0.f;
+    }
+    __syncthreads();
+    const int j = c0 + t;
+    const bool jin = j < cap;
+    const int uj = jin ? slot[j] : -1;
+    const float px = jin ? pos[3 * j] : 0.f, py = jin ? pos[3 * j + 1] : 0.f, pz = jin ? pos[3 * j + 2] : 0.f;
+    int ccnt = 0;
+    const int nr = min(RG_TR, cap - r0);
+    for (int rr = 0; rr < nr; ++rr) {
+        const int r = r0 + rr, ur = rslot[rr];
+        bool pass = false;
+        if (jin && j > r && (ur >= 0 || uj >= 0)) {
+            const size_t k = (size_t)r * cap + j;
+            if (st[k] != RG_NONE) {
+                const float dx = rpos[rr][0] - px, dy = rpos[rr][1] - py, dz = rpos[rr][2] - pz;
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+                float mx = maxd[k], mn = mind[k];
+                if (d > mx) mx = d;
+                if (d < mn) mn = d;
+                maxd[k] = mx; mind[k] = mn;
+                if (fabsf((mx - mn) / mn) > stretch_th) st[k] = (uint8_t)NRS_GRAPH_BAD;
+                else pass = true;
+            }
+        }
+        if (pass && uj >= 0) ++ccnt;
+        if (ur >= 0) {                                              // (block-uniform)
+            const unsigned long long m = __ballot(pass);
+            if ((t & 63) == 0 && m) atomicAdd(&rcnt[rr], __popcll(m));
+        }
+    }
+    if (uj >= 0 && ccnt) atomicAdd(&good[uj], ccnt);
+    __syncthreads();
+    if (t < RG_TR && rslot[t] >= 0 && rcnt[t]) atomicAdd(&good[rslot[t]], rcnt[t]);
 }
 
 // GetEdges (regularization_graph.cc:71-87) for one listed vertex per wave.  The sorted list is
@@ -291,7 +345,7 @@ extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
     if (g->pin) (void)hipHostFree(g->pin);
-    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip);
+    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip); c->release(g->slot);
     delete g;
 }
 
@@ -343,8 +397,20 @@ extern "C" int nrs_rgraph_update(nrs_rgraph* g, const float* pos, int32_t n_ids,
     NRS_HIP(c, hipMemcpyAsync(g->pos.p, pos, sizeof(float) * 3 * (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemcpyAsync(g->ids_a.p, ids, sizeof(int) * (size_t)n_ids, hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipMemsetAsync(g->good.p, 0, sizeof(int) * (size_t)n_ids, c->stream));
+    // most of the points listed, each once: the one-pass form
+    bool tri = (size_t)n_ids * 4 >= (size_t)g->cap;
+    if (tri) {
+        g->h_slot.assign(g->cap, -1);
+        for (int a = 0; a < n_ids && tri; ++a) { if (g->h_slot[ids[a]] >= 0) tri = false; g->h_slot[ids[a]] = a; }
+    }
+    if (tri) {
+        NRS_TRY(c->ensure(g->slot, sizeof(int) * (size_t)g->cap));
+        NRS_HIP(c, hipMemcpyAsync(g->slot.p, g->h_slot.data(), sizeof(int) * (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_rg_update_tri, dim3((g->cap + RG_TC - 1) / RG_TC, (g->cap + RG_TR - 1) / RG_TR), dim3(RG_TC), 0, c->stream,
+                           g->slot.as<int>(), g->pos.as<float>(), g->cap, g->maxd, g->mind, g->st, g->stretch_th, g->good.as<int>());
+    }
     const int bx = std::max(1, std::min(8, (g->cap + 1023) / 1024));
-    for (int a0 = 0; a0 < n_ids; a0 += 32768) {
+    for (int a0 = 0; a0 < n_ids && !tri; a0 += 32768) {
         const int na = std::min(32768, n_ids - a0);
         hipLaunchKernelGGL(k_rg_update, dim3(bx, na), dim3(256), 0, c->stream, na, g->ids_a.as<int>() + a0, g->pos.as<float>(), g->cap,
                            g->maxd, g->mind, g->st, g->stretch_th, g->good.as<int>() + a0);
