@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
-#include <set>
 #include "nrs_engine.hpp"
 
 namespace nrs {
@@ -418,13 +417,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     std::vector<float> ow, od0;
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
-    for (auto& v : reg) v.reserve(24);                            // (one allocation per point: <= 11 own + the neighbours' entries)
+    for (int i = 0; i < N; ++i) if (node_of[i] >= 0) reg[i].reserve(24);   // (one allocation per node: <= 11 own + the neighbours' entries)
     std::vector<int> dm_idx, sp_ij;
     std::vector<float> dm_w, sp_d0;
     dm_idx.reserve(48 * (size_t)M); sp_ij.reserve(24 * (size_t)M); dm_w.reserve(12 * (size_t)M); sp_d0.reserve(12 * (size_t)M);
     std::vector<int> sk_node((size_t)(N - M) * 11, -1), sk_of(N, -1), sk_idx;     // skinned observations: nodes (vertex indices), weights
     std::vector<double> sk_om((size_t)(N - M) * 11, 0.0);
-    std::set<int> lost_set;                                       // btree_set<ID>: ascending ids (OPT:222)
+    std::vector<uint8_t> lost_flag(n_map, 0);                     // btree_set<ID> (OPT:222) as a flag per id: read out in ascending order below
     std::vector<uint8_t> no_vertex;                               // embedded mode: optimised points without a vertex (passed over below)
     if (M < N) {
         no_vertex.assign(n_map, 0);
@@ -434,8 +433,9 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
     again = false;
     NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
+    mark("GetEdges");
     for (auto& v : reg) v.clear();
-    dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); lost_set.clear();
+    dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); std::fill(lost_flag.begin(), lost_flag.end(), 0);
     sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
     for (int idx = 0; idx < N && !again; ++idx) {
         const int p = ids[idx];
@@ -449,7 +449,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             if (n_reg > 10 || ost[a] == NRS_GRAPH_BAD) { ended = true; break; }
             const int fo = map_to_frame[other];
             if (fo < 0 || f_status[fo] != NRS_TRACKED_WITH_3D) {
-                if (fo >= 0 && f_status[fo] != NRS_JUST_TRIANGULATED) lost_set.insert(other);
+                if (fo >= 0 && f_status[fo] != NRS_JUST_TRIANGULATED) lost_flag[other] = 1;
                 continue;
             }
             const int io = id_to_idx[other];
@@ -606,11 +606,12 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             if (good[i] < 10 * 0.5) f_status[opt_f[upd_idx[i]]] = NRS_BAD;
     }
     mark("UpdateVertex");
-    if (lost_set.empty()) return NRS_OK;
+    std::vector<int> lost_ids;
+    for (int i = 0; i < n_map; ++i) if (lost_flag[i]) lost_ids.push_back(i);
+    if (lost_ids.empty()) return NRS_OK;
 
     // ---- stage 2 OPT:476-553: lost points follow their (fixed) optimised neighbours.  Vertices: the nodes, then the optimised points
     // without a vertex as constants (their interpolated deformation), then the lost points
-    std::vector<int> lost_ids(lost_set.begin(), lost_set.end());
     const int L = (int)lost_ids.size();
     std::vector<int> vert_of(N, -1), others;
     for (int v = 0; v < M; ++v) vert_of[node_idx[v]] = v;
