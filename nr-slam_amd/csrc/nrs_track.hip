@@ -217,10 +217,12 @@ static int graph_update(nrs_ctx* c, GraphDevice& G, nrs_graph* g, const float* p
 struct NeighbourSource {
     int n_points = 0;
     virtual ~NeighbourSource() {}
-    // GetEdges of the map points in `want` (a source may serve every point), in the reference's order: CSR over ALL map
-    // points of (other, weight, first_distance, status); rows that were not asked for may be empty
-    virtual int select(const std::vector<int>& want, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
-                       std::vector<int>& st) = 0;
+    // GetEdges of the map points in `want` (a source may serve every point), in the reference's order: entries beg[p] .. end[p] of
+    // (col = other, w = weight, d0 = first distance, st = status) for a map point p that was asked for; the arrays are the source's
+    // (valid until its next select)
+    virtual int select(const std::vector<int>& want) = 0;
+    std::vector<int> beg, end;
+    const int* col = nullptr; const float* w = nullptr; const float* d0 = nullptr; const int* st = nullptr;
     // UpdateVertex of the listed points from the last world positions; good[i] = its return value
     virtual int update(const float* map_pos, int n, const int* ids, int* good) = 0;
     std::vector<char> truncated;      // per point: select() returned only a prefix of its list
@@ -234,12 +236,15 @@ struct NeighbourSource {
 struct FlatSource : NeighbourSource {
     nrs_ctx* c; nrs_graph* g; GraphDevice G;
     int init() { n_points = g->n_points; return graph_upload(c, G, g); }
-    int select(const std::vector<int>&, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
-               std::vector<int>& st) override {
+    std::vector<int> rp_, col_, st_;
+    std::vector<float> w_, d0_;
+    int select(const std::vector<int>&) override {
         std::vector<int> eid;
-        NRS_TRY(graph_select(c, G, g->sigma, rp, col, eid));
-        w.resize(eid.size()); d0.resize(eid.size()); st.resize(eid.size());
-        for (size_t a = 0; a < eid.size(); ++a) { w[a] = g->e_w[eid[a]]; d0[a] = g->e_d0[eid[a]]; st[a] = g->e_status[eid[a]]; }
+        NRS_TRY(graph_select(c, G, g->sigma, rp_, col_, eid));
+        w_.resize(eid.size()); d0_.resize(eid.size()); st_.resize(eid.size());
+        for (size_t a = 0; a < eid.size(); ++a) { w_[a] = g->e_w[eid[a]]; d0_[a] = g->e_d0[eid[a]]; st_[a] = g->e_status[eid[a]]; }
+        beg.assign(rp_.begin(), rp_.end() - 1); end.assign(rp_.begin() + 1, rp_.end());
+        col = col_.data(); w = w_.data(); d0 = d0_.data(); st = st_.data();
         return NRS_OK;
     }
     int update(const float* map_pos, int n, const int* ids, int* good) override { return graph_update(c, G, g, map_pos, n, ids, good); }
@@ -252,25 +257,18 @@ int rg_max_cap_per_point(const nrs_rgraph* g);
 
 struct DenseSource : NeighbourSource {
     nrs_ctx* c; nrs_rgraph* g; int cap;
-    int select(const std::vector<int>& want, std::vector<int>& rp, std::vector<int>& col, std::vector<float>& w, std::vector<float>& d0,
-               std::vector<int>& st) override {
+    int select(const std::vector<int>& want) override {           // (the lists are read where they land: the graph's pinned staging area)
         const size_t n = (size_t)n_points, m = want.size();
-        rp.assign(n + 1, 0);
+        beg.assign(n, 0); end.assign(n, 0);
         truncated.assign(n, 0);
-        col.clear(); w.clear(); d0.clear(); st.clear();
+        col = nullptr; w = nullptr; d0 = nullptr; st = nullptr;
         if (m == 0) return NRS_OK;
-        const int *cnt, *fc, *fs;
-        const float *fw, *fd;
-        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &fc, &fs, &fw, &fd, pass_over ? pass_over->data() : nullptr));   // pinned staging area, read in place
-        for (size_t r = 0; r < m; ++r) { truncated[want[r]] = cnt[r] > cap; rp[(size_t)want[r] + 1] = std::min(cnt[r], cap); }
-        for (size_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
-        col.resize(rp[n]); w.resize(rp[n]); d0.resize(rp[n]); st.resize(rp[n]);
+        const int* cnt;
+        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &col, &st, &w, &d0, pass_over ? pass_over->data() : nullptr));
         for (size_t r = 0; r < m; ++r) {
-            const size_t a = (size_t)rp[want[r]], b = r * (size_t)cap, len = (size_t)(rp[(size_t)want[r] + 1] - rp[want[r]]);
-            std::copy(fc + b, fc + b + len, col.begin() + a);
-            std::copy(fw + b, fw + b + len, w.begin() + a);
-            std::copy(fd + b, fd + b + len, d0.begin() + a);
-            std::copy(fs + b, fs + b + len, st.begin() + a);
+            const int p = want[r];
+            truncated[p] = cnt[r] > cap;
+            beg[p] = (int)(r * (size_t)cap); end[p] = beg[p] + std::min(cnt[r], cap);
         }
         return NRS_OK;
     }
@@ -413,8 +411,6 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     const int M = (int)node_idx.size();
     if (M == 0) return c->fail(NRS_ERR_INVALID, "embedded mode: no node among the optimised points");
 
-    std::vector<int> orp, ocol, ost;
-    std::vector<float> ow, od0;
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
     std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
     for (int i = 0; i < N; ++i) if (node_of[i] >= 0) reg[i].reserve(24);   // (one allocation per node: <= 11 own + the neighbours' entries)
@@ -432,7 +428,9 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     }
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
     again = false;
-    NRS_TRY(src.select(ids, orp, ocol, ow, od0, ost));             // the walks below start from the optimised points only
+    NRS_TRY(src.select(ids));                                      // the walks below start from the optimised points only
+    const int *ocol = src.col, *ost = src.st;
+    const float *ow = src.w, *od0 = src.d0;
     mark("GetEdges");
     for (auto& v : reg) v.clear();
     dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); std::fill(lost_flag.begin(), lost_flag.end(), 0);
@@ -444,7 +442,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         int n_reg = 0;
         double wsum = 0;
         bool ended = false;
-        for (int a = orp[p]; a < orp[p + 1]; ++a) {
+        for (int a = src.beg[p]; a < src.end[p]; ++a) {
             const int other = ocol[a];
             if (n_reg > 10 || ost[a] == NRS_GRAPH_BAD) { ended = true; break; }
             const int fo = map_to_frame[other];
@@ -627,13 +625,15 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     src.prefix_hint(32);
     for (bool again = true; again;) {
     again = false;
-    NRS_TRY(src.select(lost_ids, orp, ocol, ow, od0, ost));       // GetEdges sees the updated graph
+    NRS_TRY(src.select(lost_ids));                                 // GetEdges sees the updated graph
+    const int* ocol = src.col;
+    const float* ow = src.w;
     un_ij.clear(); un_w.clear();
     for (int li = 0; li < L && !again; ++li) {
         const int p = lost_ids[li];
         int n_reg = 0;
         bool ended = false;
-        for (int a = orp[p]; a < orp[p + 1]; ++a) {
+        for (int a = src.beg[p]; a < src.end[p]; ++a) {
             if (n_reg > 10) { ended = true; break; }
             const int io = id_to_idx[ocol[a]];
             if (io < 0) continue;
