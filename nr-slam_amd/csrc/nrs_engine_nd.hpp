@@ -38,6 +38,7 @@ struct NdDev {
     const int* node_out;             // engine: node -> 3 doubles at out_rows + o (o >= 0) or out_pose - 1 - o (o < 0); null: xn only
     double* out_rows; double* out_pose;
     int* done;                       // per front: the solve (epoch) whose back substitution has written its unknowns (single-launch back pass)
+    int* fcnt;                       // per front: Schur tiles its children have delivered, over all solves (single-launch factorisation)
     int* flags;                      // [0] done [1] iterations [2] not positive definite (the engine's PCG flags, or a scratch word block)
     long long* clk;                  // NRS_ND_DBG: 8 phase clocks (100 MHz) per workgroup of the factorisation, then per front of the back substitution; else null
 };
@@ -165,7 +166,7 @@ __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo
         }
 }
 
-__global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, int epoch) {
+__global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained) {   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NdWgD wd = N.wg[wg0 + blockIdx.x];                        // (front descriptor inlined: one scalar round trip)
@@ -216,6 +217,20 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     nd_v4d acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
+    if (chained && F.n_ch > 0) {
+        // every level in one launch: wait until the children's workgroups (smaller block indices: dispatched before this one, so a full
+        // chip cannot deadlock; bounded all the same) have delivered their tiles -- wd.pad of them per solve -- then read past stale lines
+        if (tid == 0) {
+            const int want = chained * wd.pad;
+            int spins = 0;
+            while (__hip_atomic_load(N.fcnt + F.cmap_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 23)) { N.flags[2] = 2; break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     if (F.n_ch > 0) {                                              // F22 tile (I, J): straight into the accumulators of the matrix cores
         // (the children wrote every element once, at (larger, smaller) of its two positions here: a diagonal tile's upper half is
         // read at its mirror position)
@@ -416,6 +431,11 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         }
     }
     stamp(4);
+    if (chained && !inv && F.par >= 0) {                           // this tile is in the parent's slot: count it (release: the stores first)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(N.fcnt + F.par, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (inv) {                                                     // (L11^-1)^T, upper triangular, behind the panel
         const int tx = tid & 31, ty = tid >> 5;
         double* LT = N.Lp + F.L_off + (size_t)(m + 2) * s;
@@ -597,6 +617,7 @@ struct NdSolver {
     std::vector<size_t> lvl_shm_fac;
     std::vector<char> h_stage;       // host image of the plan arrays (one upload)
     int epoch = 0;                   // solves so far (the flags of the single-launch back pass count them)
+    int chained = 0;                 // ... of which with the single-launch factorisation (its per-front counters count those)
     size_t shm_back_all = 0;
     bool attr_set = false;
     double* d_ev = nullptr;
@@ -611,7 +632,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     const size_t o_seg = take(4 * std::max<size_t>(2, P.seg.size())), o_own = take(4 * P.own.size()), o_bnd = take(4 * std::max<size_t>(1, P.bnd.size())),
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
                  o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
-                 o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size());
+                 o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size()), o_fc = take(4 * P.fr.size());
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
     // the plan's arrays go up in ONE copy from a staging image that lives as long as the solver (the copy is asynchronous)
@@ -626,7 +647,10 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         NdWgD* hw = reinterpret_cast<NdWgD*>(S.h_stage.data() + o_wg);
         NdFrontD* hl = reinterpret_cast<NdFrontD*>(S.h_stage.data() + o_lf);
         // (device copies of the descriptor: cmap_off, the host reference's gather map, holds the front's own index)
-        for (size_t w = 0; w < P.wg.size() / 3; ++w) { hw[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], 0}; hw[w].F.cmap_off = P.wg[3 * w]; }
+        // (pad: how many workgroups write into this front's assembly slots in one factorisation -- its children's (I, J) pairs)
+        std::vector<int> need(P.fr.size(), 0);
+        for (const NdFrontD& f : P.fr) if (f.par >= 0) need[f.par] += f.nR * (f.nR + 1) / 2;
+        for (size_t w = 0; w < P.wg.size() / 3; ++w) { hw[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], need[P.wg[3 * w]]}; hw[w].F.cmap_off = P.wg[3 * w]; }
         for (size_t i = 0; i < P.lvl_fronts.size(); ++i) { hl[i] = P.fr[P.lvl_fronts[i]]; hl[i].cmap_off = P.lvl_fronts[i]; }
     }
     NRS_HIP(c, hipMemcpyAsync(base, S.h_stage.data(), o_ev, hipMemcpyHostToDevice, c->stream));
@@ -639,9 +663,9 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     S.d_ev = reinterpret_cast<double*>(base + o_ev); S.d_ent = D.ent;
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
-    D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn);
+    D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn); D.fcnt = reinterpret_cast<int*>(base + o_fc);
     NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, off - o_fl, c->stream));            // (status words and the fronts' flags)
-    S.epoch = 0;
+    S.epoch = 0; S.chained = 0;
     // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
     NRS_HIP(c, hipMemsetAsync(base + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
     // dynamic LDS per level: the largest panel / boundary of its fronts
@@ -673,9 +697,20 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
 static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     const NdPlan& P = S.plan;
     const int epoch = ++S.epoch;
-    for (int l = 0; l < P.n_levels; ++l) {
-        const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
-        hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch);
+    // all levels in ONE launch, a front's workgroups waiting for its children's tiles (no launch boundaries: 176 -> 165 us per
+    // factorise + solve at 543 points), when every workgroup of the factorisation is resident at once (one per CU).  Beyond that the
+    // release / acquire pair of every workgroup costs more than the boundaries it replaces (231 -> 228 us at 1013 points, 329 -> 329
+    // at 2220, 547 -> 569 at 4525): one launch per level (also with NRS_ND_LEVELS=1, and whenever the phase clocks are on)
+    static const bool per_level = getenv("NRS_ND_LEVELS") != nullptr;
+    if (!per_level && !S.dev.clk && P.lvl_wg_ptr[P.n_levels] <= 256) {
+        size_t shm = 0;
+        for (int l = 0; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
+        hipLaunchKernelGGL(k_nd_level, dim3(P.lvl_wg_ptr[P.n_levels]), dim3(256), shm, c->stream, S.dev, 0, lam, epoch, ++S.chained);
+    } else {
+        for (int l = 0; l < P.n_levels; ++l) {
+            const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
+            hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
+        }
     }
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that
     // its workgroups stage their factors while the root is busy.  The two event waits cost more than the ~10 us of staging they hide:
