@@ -119,3 +119,17 @@ def test_plan_invariants(n, seed, pose, knn):
     assert CPU.nd_plan_check(pos, last, pairs) == 0
     pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, pose, knn=knn, disconnected=True)     # a forest (without a pose): several roots
     assert CPU.nd_plan_check(pos, last, pairs) == 0
+
+
+@pytest.mark.parametrize("n,seed,pose,knn,shape", [
+    (700, 3, True, 11, dict(fronts=46, levels=7, max_s=96, max_b=132, L_doubles=415368, U_doubles=311424, flops=26193024, workgroups=214)),
+    (2500, 5, True, 16, dict(fronts=131, levels=11, max_s=96, max_b=354, L_doubles=2142594, U_doubles=3868500, flops=305143704, workgroups=1448)),
+    (300, 4, False, 8, dict(fronts=19, levels=5, max_s=93, max_b=66, L_doubles=151587, U_doubles=40336, flops=5480208, workgroups=52)),
+])
+def test_plan_shape_is_pinned(n, seed, pose, knn, shape):
+    """the dissection is deterministic (coordinate bisection by (coordinate, index), minimum vertex cover by Kuhn's paths in a fixed
+    order): the shape of the plan of a seeded system is a known answer -- a change of the builder that is meant to leave the plans
+    alone (round 4: no sort per level, one pass for both separator candidates) must reproduce it"""
+    pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, pose, knn=knn)
+    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
+    assert ok and st == shape
