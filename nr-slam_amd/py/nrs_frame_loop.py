@@ -227,11 +227,13 @@ class FrameLoop:
         pc = se3f_act(self.pose, self.map_pos)
         uv = self.project(pc) if len(pc) else np.zeros((0, 2), F32)
         inside = (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
-        for mp in range(len(self.map_pos)):
-            i = in_frame[mp]
-            present = i >= 0 and self.status[i] in (TRACKED_WITH_3D, JUST_TRIANGULATED)
-            if not present and pc[mp, 2] >= 0 and inside[mp]:
-                cand.add(mp)
+        # map points the frame does not hold (tracking.cc:404-420), in front of the camera and inside the image: one pass over the map
+        present = np.zeros(len(self.map_pos), bool)
+        held = np.nonzero(in_frame >= 0)[0]
+        st_held = self.status[in_frame[held]]
+        present[held] = (st_held == TRACKED_WITH_3D) | (st_held == JUST_TRIANGULATED)
+        if len(pc):
+            cand.update(int(mp) for mp in np.nonzero(~present & (pc[:, 2] >= 0) & inside)[0])
         cand = [mp for mp in sorted(cand) if inside[mp] and not np.isnan(uv[mp]).any()]
         if not cand:
             return 0
