@@ -57,8 +57,13 @@ typedef struct {
     float params[8];
 } nrs_camera;
 
+ /* nrs_options grows at its END only and says how long the caller's version of it is: nrs_create reads struct_size bytes and takes
+ * the defaults for everything behind them, so a binding compiled against an older header keeps working.  Fill it with
+ * nrs_options_init() (device = -1, everything else 0 = default, struct_size = sizeof) or set struct_size = sizeof(nrs_options) by
+ * hand; struct_size = 0 is read as the first published layout (fields up to exact_trials, 32 bytes). */
 typedef struct {
     int32_t device;           /* HIP device ordinal; -1 = current device                         */
+    uint32_t struct_size;     /* sizeof(nrs_options) as the CALLER was compiled (sits where the layout had padding) */
     double pcg_rtol;          /* relative residual ||b-Ax||/||b|| at which the inner solve stops;
                                  0 = default 1e-10 (SURVEY.md 7.2 hard part 1)                    */
     int32_t pcg_max_iters;    /* 0 = default 2000                                                */
@@ -81,8 +86,9 @@ typedef struct {
                                  4525 points: DESIGN.md section 1), PCG beyond; 1: direct whenever the problem has the
                                  single-frame structure; 2: always
                                  PCG.  Same LM iterates either way (both are held to the oracle).  BA windows always
-                                 use PCG. */
+                                 use PCG.  Values outside 0..2 are read as 0. */
 } nrs_options;
+void nrs_options_init(nrs_options* opt);
 
 /* One Levenberg-Marquardt trial as executed by g2o
  * (third_party/g2o/g2o/core/optimization_algorithm_levenberg.cpp:94-145). */

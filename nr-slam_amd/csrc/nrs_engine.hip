@@ -112,7 +112,14 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                         break;
                     }
 #endif
-                    if (d.h4) {                                     // (implies tp)
+                    if (d.h4 && rc_of(d, cls)) {                             // the operator re-forms the factors: nothing stored per incidence
+#define NRS_LIN_RC(CAMV) switch (rc_of(d, cls)) { \
+    case 1: hipLaunchKernelGGL((k_lin_plain<2, 4, CAMV, true, 0, true, true, false>), g, b, shm, c->stream, d, xl, cls); break; \
+    case 2: hipLaunchKernelGGL((k_lin_plain<2, 4, CAMV, true, 0, true, false, true>), g, b, shm, c->stream, d, xl, cls); break; \
+    default: hipLaunchKernelGGL((k_lin_plain<2, 4, CAMV, true, 0, true, true, true>), g, b, shm, c->stream, d, xl, cls); break; }
+                        if (d.cam.model == 0) { NRS_LIN_RC(0) } else { NRS_LIN_RC(1) }
+#undef NRS_LIN_RC
+                    } else if (d.h4) {                              // (implies tp)
                         if (d.cam.model == 0) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
                         else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
                     } else if (d.cam.model == 0) {
@@ -219,14 +226,17 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
             }
             continue;
         }
-        const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2);
+        const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + ((rc_of(d, cls) & 2) ? d.cap_h[cls] : d.cap_s[cls]) + 2);
         switch (d.T) {
             case 1: hipLaunchKernelGGL((k_spmv_f<1, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 4: hipLaunchKernelGGL((k_spmv_f<4, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 8: hipLaunchKernelGGL((k_spmv_f<8, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 16: hipLaunchKernelGGL((k_spmv_f<16, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             default:
-                if (d.plain && d.tp_ok && d.h4) hipLaunchKernelGGL((k_spmv_f<2, false, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 1) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, true, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 2) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 3) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else if (d.plain && d.tp_ok && d.h4) hipLaunchKernelGGL((k_spmv_f<2, false, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else if (d.plain && d.tp_ok) hipLaunchKernelGGL((k_spmv_f<2, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 break;
@@ -655,6 +665,9 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                 NRS_TRY(pcg_advance(c, e, lam, peeking && seen < peek_levels ? seen + 1 : 0, &pit, &done));
                 NRS_TRY(eval_trial());
             }
+            // (flags[2] == 2: a bounded wait of the direct solver ran out -- a synchronisation fault, not a matrix that is not positive
+            // definite: the factor and the assembly areas hold partial data, so this is an error, never a rejected trial)
+            if (e->h_flags[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out");
             ok = e->h_flags[2] == 0;
             if (!early && !ok) temp = 1.7976931348623157e308;
             if (!early) e->pred_iters = e->h_flags[1];

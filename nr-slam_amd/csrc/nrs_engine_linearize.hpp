@@ -562,7 +562,28 @@ __device__ inline double fast_sqrt_pos(double a) {                  // a^1/2, a 
     return fma(e2, h, g);
 }
 
-template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0, bool H4 = false>   // EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results); H4: 4-byte damper headers (Dev::d_h4)
+// The two per-incidence factors of a plain BA window, in ONE place: k_lin_plain forms them for the diagonal blocks and (unless
+// Dev::rc says otherwise) stores them for the operator; with Dev::rc the operator (k_spmv_f<.., RCS / RCD>) re-forms them from the
+// staged linearisation point with these very operation sequences (explicit fma, contraction off: the same bits in either kernel).
+//   spring (BA form, position_regularizer.cc:51-60, no kernel): qc = info (2 k / (d0 sqrt(d)))^2 = info (2 k / d0)^2 / d
+//   damper (spatial_regularizer.cc:32-59 + Huber): s = rho'(e) info w^2, e = info |w g|^2
+__device__ inline double sq3(double a, double b, double c) { return fma(c, c, fma(b, b, a * a)); }
+__device__ inline double spring_qc(double d2, double d0, double ks, double ip) {
+#pragma clang fp contract(off)
+    const double c = 2.0 * ks * fast_rcp_pos(d0);
+    return ip * (c * c) * fast_rsqrt_pos(d2);
+}
+__device__ inline double damper_s(double g0, double g1, double g2, double w, double isp, double dsp, double& rho0) {
+#pragma clang fp contract(off)
+    const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
+    const double e = isp * sq3(r0, r1, r2), dsqr = dsp * dsp;
+    const bool act = dsp > 0 && e > dsqr;                          // Huber active: rho' = delta / sqrt(e), rho = 2 delta sqrt(e) - delta^2
+    const double ea = act ? e : 1.0, y = fast_rsqrt_pos(ea);
+    rho0 = act ? 2.0 * (ea * y) * dsp - dsqr : e;
+    return (act ? dsp * y : 1.0) * isp * w * w;
+}
+
+template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0, bool H4 = false, bool RCS = false, bool RCD = false>   // RCS / RCD: the spring / damper factors are not stored (Dev::rc: the operator re-forms them); EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results); H4: 4-byte damper headers (Dev::d_h4)
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // UNCONDITIONAL (slots past the slice's end read a clamped index and count as padding when consumed) and nothing
     // touches the loaded registers before consume(): with a predicated load the compiler sinks the unpacking behind the
     // load and the wave waits out the full latency of every single request (rounds 1 and 2).
-    constexpr int NB = 4;
+    constexpr int NB = 4;                                          // (6 or 8 slots per lane and batch: 111 / 238 spilled VGPRs at 4 waves per SIMD, round 5)
     uint32_t rs_om[NB], rs_d0[NB];
     auto req_s = [&](int q, int idx) {
         if (EXP == 3) { rs_om[q] = (uint32_t)(idx & 63) | 0x10000u; rs_d0[q] = 0x3F800000u; return; }
@@ -621,14 +642,14 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const bool pad = !live || o16 == REC_NONE;
         const int o = EXP == 2 ? self : (pad ? self : o16) & 0xFFFF;   // (16 bits: the LDS offset is then one v_mad_u32_u24)
         const double v0 = xo0 - lx[3 * o], v1 = xo1 - lx[3 * o + 1], v2 = xo2 - lx[3 * o + 2];
-        double d2 = v0 * v0 + v1 * v1 + v2 * v2;
+        double d2 = sq3(v0, v1, v2);
         d2 = pad ? 1.0 : d2;
         const double d0 = pad ? 1.0 : (double)d0f;
         const double rs = fast_rsqrt_pos(d2), id0 = fast_rcp_pos(d0);
         const double r = ks * fma(d2, rs, -d0) * id0;
         const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);       // (plain windows are BA windows: spring_form 0, checked by engine_create)
-        const double qc = pad ? 0.0 : ip * cg * cg;
-        if (live && EXP != 1) P.s_qc[idx] = qc;                     // (whole lines: padding slots inside the slice are written too -- a lane-masked store leaves partial lines, which cost the memory side a read-modify-write)
+        const double qc = pad ? 0.0 : spring_qc(d2, d0, ks, ip);
+        if (live && EXP != 1 && !RCS) P.s_qc[idx] = qc;                     // (whole lines: padding slots inside the slice are written too -- a lane-masked store leaves partial lines, which cost the memory side a read-modify-write)
         chi += count && !pad ? ip * r * r : 0.0;
         const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
         D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
@@ -689,12 +710,10 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
             g2 = (xo2 - lx[3 * o1 + 2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
         }
         const double w = pad ? 0.0 : (double)wf;
-        const double r0 = w * g0, r1 = w * g1, r2 = w * g2;
-        double rho0, rho1;
-        huber(isp * (r0 * r0 + r1 * r1 + r2 * r2), dsp, rho0, rho1);
+        double rho0;
+        const double sfac = damper_s(g0, g1, g2, w, isp, dsp, rho0);
         chi += (m16 & DM_COUNT) ? rho0 : 0.0;                      // (padding: rho0 = 0)
-        const double sfac = rho1 * isp * w * w;
-        if (live && EXP != 1) P.d_s[idx] = sfac;
+        if (live && EXP != 1 && !RCD) P.d_s[idx] = sfac;
         D0 += sfac; D3 += sfac; D5 += sfac;
         bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
     };

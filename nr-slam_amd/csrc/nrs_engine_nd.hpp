@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 23)) { N.flags[2] = 2; break; }  // (cannot happen: ancestors are dispatched first; never hang the device)
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // (every thread, behind the barrier, as in k_nd_level: what the ancestor published is visible to all of them)
         if (sg == 0) stamp(4);
         for (int i = r0 + tid; i < r1; i += 256) xb[i] = __hip_atomic_load(N.xn + 3 * (size_t)bnode[i / 3] + i % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -701,8 +701,14 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // factorise + solve at 543 points), when every workgroup of the factorisation is resident at once (one per CU).  Beyond that the
     // release / acquire pair of every workgroup costs more than the boundaries it replaces (231 -> 228 us at 1013 points, 329 -> 329
     // at 2220, 547 -> 569 at 4525): one launch per level (also with NRS_ND_LEVELS=1, and whenever the phase clocks are on)
-    static const bool per_level = getenv("NRS_ND_LEVELS") != nullptr;
-    if (!per_level && !S.dev.clk && P.lvl_wg_ptr[P.n_levels] <= 256) {
+    // "Resident at once" is what makes the waits safe and is a property of the device, not a constant: one workgroup per CU (a panel
+    // fills most of a CU's LDS), so the bound is the CU count of THIS device (256 on a whole MI355X, fewer in a partition mode).  The
+    // no-deadlock argument: a front's workgroups wait only for workgroups of its children, which sit at SMALLER block indices, and the
+    // dispatcher hands workgroups of a launch out in block-index order -- observed on every CDNA part, not promised by HIP; hence the
+    // bounded spins in k_nd_level / k_nd_back (a wait that runs out raises flags[2] = 2 -> NRS_ERR_HIP, never a hang) and the
+    // resident-at-once condition, under which the order does not matter at all.
+    const bool per_level = getenv("NRS_ND_LEVELS") != nullptr;     // (read per call: the tests switch it between solves)
+    if (!per_level && !S.dev.clk && P.lvl_wg_ptr[P.n_levels] <= c->prop.multiProcessorCount) {
         size_t shm = 0;
         for (int l = 0; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
         hipLaunchKernelGGL(k_nd_level, dim3(P.lvl_wg_ptr[P.n_levels]), dim3(256), shm, c->stream, S.dev, 0, lam, epoch, ++S.chained);
@@ -801,6 +807,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
     NRS_HIP(c, hipMemcpyAsync(x, S.dev.xn, 24 * (size_t)n_nodes, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     if (!fl[0]) return c->fail(NRS_ERR_HIP, "direct solve: the last level did not report completion");
+    if (fl[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out");
     return fl[2] ? c->fail(NRS_ERR_NUMERIC, "direct solve: the matrix is not positive definite") : NRS_OK;
 }
 
@@ -1131,7 +1138,14 @@ static void nd_prep_ske_values(NdPrep& P, const double* sk_om) {
     }
 }
 
+static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P);
+// (runs on a helper thread of engine_create: nothing may escape it -- an exception there would end the process)
 static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
+    try { nd_prep_run_body(c, in, P); }
+    catch (const std::exception& ex) { P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.err = ex.what(); }
+    catch (...) { P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.err = "unknown exception in the plan thread"; }
+}
+static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.st.reset();
     const bool tm = getenv("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -1313,7 +1327,12 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF);      // (matches no key while it is rebuilt)
         sl->S.buf = &sl->ws;
         sl->S.plan = std::move(P.plan);
-        NRS_TRY(nd_upload(c, sl->S));
+        const int up = nd_upload(c, sl->S);
+        if (up == NRS_ERR_INVALID) {                               // a front or a boundary beyond the LDS: like a plan that could not be built -- the PCG takes the problem
+            if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", c->err);
+            return NRS_OK;                                         // (sguard leaves the slot empty; nd->on stays false; the embedded mode reports it, engine_create)
+        }
+        if (up != NRS_OK) return up;
     }
     // ---- value descriptors: the plan's nodes and pairs in terms of this engine's rows and incidence slots
     std::vector<int> nrow(n_nodes), node_out(n_nodes);

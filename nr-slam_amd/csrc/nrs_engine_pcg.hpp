@@ -183,8 +183,9 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 //                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
-template <int T, bool DF, bool TPC = false, bool H4 = false>   // H4: 4-byte damper headers (Dev::d_h4; needs TPC)
-__global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
+template <int T, bool DF, bool TPC = false, bool H4 = false, bool RCS = false, bool RCD = false>   // H4: 4-byte damper headers (Dev::d_h4; needs TPC); RCS / RCD: spring / damper factors re-formed from the staged linearisation point (Dev::rc)
+__global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
+    static_assert(!(RCS || RCD) || (TPC && H4 && !DF), "factor recomputation: plain windows with cached partners and 4-byte headers");
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     double* lx = dyn + (DF ? 9 : 3) * nst;
     // row ZROW of the arrays is zero: padding records and absent damper vertices point at it, so the
     // incidence loops are branch-free and the LDS reads of a whole chunk can be in flight together
-    const int ZROW = P.tile_rows + P.cap_h[cls], ZROWX = P.tile_rows + P.cap_s[cls];
+    const int ZROW = P.tile_rows + P.cap_h[cls], ZROWX = RCD ? ZROW : P.tile_rows + P.cap_s[cls];   // (RCD: positions of the whole halo)
     if (tid < 3) {
         lu[3 * ZROW + tid] = 0; lx[3 * ZROWX + tid] = 0;
         if (DF) { lgf[3 * ZROW + tid] = 0; lgb[3 * ZROW + tid] = 0; }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             const size_t r = 3 * (size_t)(i < P.tile_rows ? row0 + i : P.halo_rows[hb + i - P.tile_rows]);
             lx[3 * i] = P.lin_xl[r]; lx[3 * i + 1] = P.lin_xl[r + 1]; lx[3 * i + 2] = P.lin_xl[r + 2];
         }
-    } else stage_rows2<TPC>(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);   // (TPC: plain windows, whose halo lists also sit at a fixed stride)
+    } else stage_rows2<TPC, RCD>(P, b, tid, P.uv3, P.lin_xl, P.X0, lu, lx);   // (TPC: plain windows, whose halo lists also sit at a fixed stride)
     // row factors and the first record chunks are requested while the staging loads are in flight
     RowRec rc;
     rc.w = 0;
@@ -257,14 +258,15 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     // (rounds 1 and 2: ~80 serialised round trips per tile).  sched_barrier keeps request and consumption apart.
     const int send_u = P.ss_ptr[slice + 1], dend_u = P.sd_ptr[slice + 1];   // (send / dend: empty for a fixed row)
     const int s_last = max(send_u - 1, 0), d_last = max(dend_u - 1, 0);
-    uint32_t somA[U], somB[U];
+    uint32_t somA[U], somB[U], sd0A[U], sd0B[U];                   // (sd0: the rest length's bits, RCS)
     double sqcA[U], sqcB[U], dsA[U], dsB[U];
     uint2 dhA[U], dhB[U];
-    auto load_springs = [&](uint32_t* om, double* qc, int idx) {
+    auto load_springs = [&](uint32_t* om, double* qc, uint32_t* d0w, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             if (TPC) {
                 om[q] = 0xFFFFu; qc[q] = 0.0;
+                if (RCS) { d0w[q] = 0x3F800000u; if ((idx + 64 * q - sbeg - lane) / 64 < my_s) { om[q] = P.s_om[idx + 64 * q]; d0w[q] = __float_as_uint(P.s_d0[idx + 64 * q]); } continue; }
                 if ((idx + 64 * q - sbeg - lane) / 64 < my_s) { om[q] = P.s_om[idx + 64 * q]; qc[q] = P.s_qc[idx + 64 * q]; }
                 continue;
             }
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         for (int q = 0; q < U; ++q) {
             if (TPC) {
                 h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); sv[q] = 0.0;
-                if (H4) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; } }
+                if (H4 && RCD) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; h[q].y = __float_as_uint(P.d_w[idx + 64 * q]); } }
+                else if (H4) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; } }
                 else if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q] = P.d_hdr[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; }
                 continue;
             }
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             sv[q] = P.d_s[j];                                      // (0 for padding slots and for edges at level != 0)
         }
     };
-    load_springs(somA, sqcA, sbeg + lane);
+    load_springs(somA, sqcA, sd0A, sbeg + lane);
     load_dampers(dhA, dsA, dbeg + lane);
     __builtin_amdgcn_sched_barrier(0);
     // (one decision per workgroup: the flag can be raised -- by workgroup 0 of this very launch, or of k_pcg_update's -- between
@@ -315,20 +318,27 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
     const double xs[3] = {lx[3 * self], lx[3 * self + 1], lx[3 * self + 2]};
     double a0 = 0, a1 = 0, a2 = 0;
     // u_i - u_next(i), u_i - u_prev(i): the first half of every damper term of this row (TPC: read once, not per incidence)
-    double en[3] = {0, 0, 0}, ep[3] = {0, 0, 0};
+    double en[3] = {0, 0, 0}, ep[3] = {0, 0, 0}, exn[3] = {0, 0, 0}, exq[3] = {0, 0, 0};   // (exn / exq: the same differences of the linearisation point, RCD)
+    const double ks = P.k_spring, ip = P.info_pos, isp = P.info_spatial;
     if (TPC) {
         const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? ZROW : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? ZROW : (int)(tp >> 16);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { en[k] = ul[k] - lu[3 * tn + k]; ep[k] = ul[k] - lu[3 * tq + k]; }
+        if (RCD) {
+            const int xn = (int)(tp & 0xFFFFu) == REC_NONE ? self : (int)(tp & 0xFFFFu), xq = (int)(tp >> 16) == REC_NONE ? self : (int)(tp >> 16);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { exn[k] = xs[k] - lx[3 * xn + k]; exq[k] = xs[k] - lx[3 * xq + k]; }
+        }
     }
-    auto do_springs = [&](const uint32_t* om, const double* qcv, int idx) {
+    auto do_springs = [&](const uint32_t* om, const double* qcv, const uint32_t* d0w, int idx) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             const int o16 = (int)(consume(om[q]) & 0xFFFFu);
             const bool pad = idx + 64 * q >= send || o16 == REC_NONE;
             const int o = pad ? ZROW : o16, ox = pad ? ZROWX : o16;
-            const double qc = pad ? 0.0 : consume(qcv[q]);
+            double qc = pad || RCS ? 0.0 : consume(qcv[q]);
             const double v0 = xs[0] - lx[3 * ox], v1 = xs[1] - lx[3 * ox + 1], v2 = xs[2] - lx[3 * ox + 2];
+            if (RCS) { const double d2 = sq3(v0, v1, v2); qc = pad ? 0.0 : spring_qc(pad ? 1.0 : d2, (double)__uint_as_float(consume(d0w[q])), ks, ip); }
             const double dot = qc * (v0 * (ul[0] - lu[3 * o]) + v1 * (ul[1] - lu[3 * o + 1]) + v2 * (ul[2] - lu[3 * o + 2]));
             a0 += dot * v0; a1 += dot * v1; a2 += dot * v2;
         }
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
             const int r0 = (int)(hx & (H4 ? 0xFFFu : 0xFFFFu)), r1 = H4 ? 0 : (int)(hx >> 16), r2 = (int)(H4 ? (hx >> 12) & 0xFFFu : hy & 0xFFFFu),
                       m16 = H4 ? (hx == 0xFFFFFFFFu ? (int)REC_NONE : (int)(hx >> 24)) : (int)(hy >> 16);
             const bool pad = !live || m16 == REC_NONE;
-            const double sv = pad ? 0.0 : consume(dsv[q]);
+            double sv = pad || RCD ? 0.0 : consume(dsv[q]);
             const bool un = pad || (m16 & DM_UNARY) != 0;
             const int o0 = H4 ? (pad ? ZROW : r0) : (un || r0 == REC_NONE) ? ZROW : r0;      // (H4: plain windows, every damper with its four vertices)
             const int o1 = (un || r1 == REC_NONE) ? ZROW : r1;
@@ -370,6 +380,12 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
                 g0 = (fwd ? en[0] : ep[0]) - (lu[3 * o0] - lu[3 * o2]);
                 g1 = (fwd ? en[1] : ep[1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
                 g2 = (fwd ? en[2] : ep[2]) - (lu[3 * o0 + 2] - lu[3 * o2 + 2]);
+                if (RCD) {                                           // the factor of the linearisation point, as k_lin_plain forms it
+                    const double x0 = (fwd ? exn[0] : exq[0]) - (lx[3 * o0] - lx[3 * o2]), x1 = (fwd ? exn[1] : exq[1]) - (lx[3 * o0 + 1] - lx[3 * o2 + 1]),
+                                 x2 = (fwd ? exn[2] : exq[2]) - (lx[3 * o0 + 2] - lx[3 * o2 + 2]);
+                    double rho0;
+                    sv = pad ? 0.0 : damper_s(x0, x1, x2, (double)__uint_as_float(consume(hd[q].y)), isp, P.delta_spatial, rho0);
+                }
             } else {
                 g0 = (ul[0] - lu[3 * o1]) - (lu[3 * o0] - lu[3 * o2]);
                 g1 = (ul[1] - lu[3 * o1 + 1]) - (lu[3 * o0 + 1] - lu[3 * o2 + 1]);
@@ -379,13 +395,13 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f(Dev P, double lam, int cls, i
         }
     };
     for (int base = sbeg; base < send_u; base += 128 * U) {        // wave-uniform trip count
-        load_springs(somB, sqcB, base + 64 * U + lane);
+        load_springs(somB, sqcB, sd0B, base + 64 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
-        do_springs(somA, sqcA, base + lane);
+        do_springs(somA, sqcA, sd0A, base + lane);
         __builtin_amdgcn_sched_barrier(0);
-        load_springs(somA, sqcA, base + 128 * U + lane);
+        load_springs(somA, sqcA, sd0A, base + 128 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
-        do_springs(somB, sqcB, base + 64 * U + lane);
+        do_springs(somB, sqcB, sd0B, base + 64 * U + lane);
         __builtin_amdgcn_sched_barrier(0);
     }
     stamp(2);

@@ -136,11 +136,12 @@ __global__ void k_compact_headers(size_t n, const uint2* __restrict__ hdr, uint3
 }
 static void engine_compact_headers(nrs_ctx* c, Engine* e) {
     Dev& d = e->d;
-    d.h4 = 0;
+    d.h4 = 0; d.rc = 0;
     if (!(d.plain && d.tp_ok && d.use_lds && !d.fused && d.T == 2) || getenv("NRS_NO_H4")) return;
     if (d.tile_rows + std::max(d.cap_h[0], d.cap_h[1]) + 2 >= 4096 || d.sd_nnz <= 0) return;
     hipLaunchKernelGGL(k_compact_headers, dim3((unsigned)(((size_t)d.sd_nnz + 255) / 256)), dim3(256), 0, c->stream, (size_t)d.sd_nnz, d.d_hdr, d.d_h4);
     d.h4 = 1;
+    if (const char* v = getenv("NRS_RC")) d.rc = atoi(v) & 3;
 }
 
 template <class F>
@@ -303,6 +304,12 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     if (s.edges_on_device) return c->fail(NRS_ERR_STATE, "device-built edge lists need the device-side construction, which this window does not qualify for");
     // a2's single-frame engines: the direct solver's symbolic phase needs the structure only and runs next to the packing below
+    if (s.n_skin > 0) {                                            // (checked HERE: the plan thread below indexes by these)
+        if (!(arena == &c->arena_trk && s.K == 1) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
+            return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines only");
+        for (size_t q = 0; q < (size_t)SK_MAX * s.n_skin; ++q)
+            if (s.sk_node[q] >= s.M || s.sk_node[q] < -1) return c->fail(NRS_ERR_INVALID, "skinned observation: node index out of range");
+    }
     NdPrep nd_prep;                                                // (declared after `guard`: joined before the engine can go away)
     NdIn nd_in;
     if (arena == &c->arena_trk && s.K == 1) {

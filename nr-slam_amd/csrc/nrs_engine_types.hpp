@@ -86,6 +86,8 @@ struct Dev {
     // the next (roles 1c / 2c) or previous (1n / 2n) keyframe, OPT:1076-1136 -- hence the same for all dampers of a row and
     // direction: row_tp[row] = {tile-local id of next | of prev << 16} (REC_NONE: none) lets the kernels read it once per row
     uint32_t* row_tp; int tp_ok;
+    int rc;                          // plain two-kernel path with h4: bit 0 / bit 1 = the spring / damper factors are not stored -- the operator re-forms them from the
+                                     // staged linearisation point (spring_qc / damper_s, nrs_engine_linearize.hpp): 8 instead of 12 bytes per incidence there, no factor stores in the lineariser
     uint32_t* d_h4; int h4;          // plain two-kernel path with cached temporal partners: 4-byte damper headers {o0 : 12 | o2 : 12 | meta : 8} derived from d_hdr
                                      // (the partner o1 is the row's own and tile-local ids stay below 4096): 8 instead of 12 bytes per damper incidence in both kernels
     uint32_t* row_cnt;               // plain windows: {spring incidences | damper incidences << 16} of every row: a lane's slots beyond its share are padding
@@ -173,6 +175,13 @@ struct Dev {
     double* sk_maxdiag;              // largest diagonal entry of the blocks the observations add to (joins SC_MAXDIAG)
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
+
+// factor recomputation of a tile class (Dev::rc): with the damper part on, the operator stages the positions of the whole halo,
+// which has to fit a workgroup's 64 KB -- a class of outlier halos keeps its dampers' factors stored
+inline int rc_of(const Dev& d, int cls) {
+    if (!(d.rc & 2)) return d.rc;
+    return sizeof(double) * 3 * (size_t)(2 * (d.tile_rows + d.cap_h[cls]) + 2) > 64 * 1024 - 512 ? (d.rc & 1) : d.rc;
+}
 
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
 
@@ -329,7 +338,7 @@ __device__ inline void stage_rows_d(const Dev& P, int b, int tid, const double* 
 }
 
 // u and the (spring) positions of the linearisation point, one pass over the halo list
-template <bool FIX = false>
+template <bool FIX = false, bool ALLX = false>                     // ALLX: positions of every halo row (the operator re-forms the damper factors, Dev::rc)
 __device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* __restrict__ u, const double* __restrict__ x,
                                    const double* __restrict__ add, double* lu, double* lx) {
     const int row0 = b * P.tile_rows;
@@ -338,7 +347,7 @@ __device__ inline void stage_rows2(const Dev& P, int b, int tid, const double* _
 #pragma unroll
         for (int k = 0; k < HALO_FIX / BLK; ++k) idx[k] = P.halo_fix[(size_t)b * HALO_FIX + k * BLK + tid];
     }
-    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = P.halo_ns[b];
+    const int hb = P.halo_ptr[b], hn = P.halo_ptr[b + 1] - hb, ns = ALLX ? hn : P.halo_ns[b];
 #pragma unroll
     for (int k = FIX ? HALO_FIX / BLK : 0; k < STAGE_K; ++k) { const int i = tid + k * BLK; idx[k] = i < hn ? P.halo_rows[hb + i] : -1; }
     for (int i = tid; i < 3 * P.tile_rows; i += BLK) {

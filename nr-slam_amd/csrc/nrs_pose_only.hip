@@ -8,7 +8,9 @@
 // loads that stay in L1/L2: 20 B/point), reduce with wave butterflies + LDS, and lane 0 runs
 // the LM control flow, the Cholesky of H+lambda*I and the SE(3) retraction.  No host round trips,
 // no inter-workgroup hand-offs; latency per trial is a few microseconds.
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include "nrs_ctx.hpp"
 #include "nrs_device.hpp"
 
@@ -324,6 +326,13 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
 
 using namespace nrs;
 
+extern "C" void nrs_options_init(nrs_options* opt) {
+    if (!opt) return;
+    memset(opt, 0, sizeof(*opt));
+    opt->device = -1;
+    opt->struct_size = (uint32_t)sizeof(*opt);
+}
+
 extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     if (!out) return NRS_ERR_INVALID;
     *out = nullptr;
@@ -333,7 +342,14 @@ extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     if (!c) return NRS_ERR_ALLOC;
     memset(&c->opt, 0, sizeof(c->opt));
     c->opt.device = -1;
-    if (opt) c->opt = *opt;
+    if (opt) {
+        // the caller's struct may be shorter than this build's (an older header): its bytes only, defaults behind them
+        size_t n = opt->struct_size ? opt->struct_size : offsetof(nrs_options, direct_solve);
+        if (n < offsetof(nrs_options, pcg_rtol)) { delete c; return NRS_ERR_INVALID; }
+        memcpy(&c->opt, opt, std::min(n, sizeof(c->opt)));
+        c->opt.struct_size = (uint32_t)sizeof(c->opt);
+    }
+    if (c->opt.direct_solve < 0 || c->opt.direct_solve > 2) c->opt.direct_solve = 0;
     if (c->opt.pcg_rtol <= 0) c->opt.pcg_rtol = 1e-10;
     if (const char* e = getenv("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
     if (c->opt.pcg_max_iters <= 0) c->opt.pcg_max_iters = 2000;

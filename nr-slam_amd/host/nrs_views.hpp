@@ -90,7 +90,8 @@ struct KeyFrameView {
 class Engine {                            // owns one nrs_ctx; not thread-safe, like the reference's callers
 public:
     explicit Engine(int device = -1) {
-        nrs_options opt{};
+        nrs_options opt;
+        nrs_options_init(&opt);
         opt.device = device;
         if (nrs_create(&ctx_, &opt) != NRS_OK) throw std::runtime_error("nrs_create: no usable HIP device");
     }

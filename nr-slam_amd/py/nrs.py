@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "NRS_OK", -1: "NRS_ERR_INVALID", -2: "NRS_ERR_NO_DEVICE", -3:
 COMM_ID_BYTES = 128
 
 # every symbol include/nrs.h declares (tests check that the library exports all of them)
-SYMBOLS = ["nrs_create", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
+SYMBOLS = ["nrs_create", "nrs_options_init", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
            "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
@@ -44,7 +44,7 @@ class Camera(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
+    _fields_ = [("device", C.c_int32), ("struct_size", C.c_uint32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
                 ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32), ("direct_solve", C.c_int32)]
 
 
@@ -283,7 +283,7 @@ class RGraph:
 class Context:
     def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0, direct_solve=0):
         self.lib = load_library()
-        opt = Options(device, pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials, direct_solve)
+        opt = Options(device, C.sizeof(Options), pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials, direct_solve)
         self.h = C.c_void_p()
         rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
         if rc != OK:

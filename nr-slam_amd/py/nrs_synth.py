@@ -500,3 +500,29 @@ def _rot_to_quat(R):
     """unit quaternion (x y z w) of a rotation matrix, w >= 0"""
     w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
     return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+
+def pick_nodes(points_xyz, n_nodes, start=0):
+    """Farthest-point sampling of n_nodes map points (float64, ties to the lowest index): the node set of the synthetic
+    embedded-deformation windows.  Returns a uint8 flag per map point."""
+    X = np.asarray(points_xyz, np.float64)
+    flag = np.zeros(len(X), np.uint8)
+    if n_nodes >= len(X):
+        flag[:] = 1
+        return flag
+    d = np.full(len(X), np.inf)
+    cur = start
+    for _ in range(n_nodes):
+        flag[cur] = 1
+        d = np.minimum(d, np.sum((X - X[cur]) ** 2, axis=1))
+        d[flag == 1] = -1.0
+        cur = int(np.argmax(d))
+    return flag
+
+
+def embedded_window(p, e):
+    """Inputs of nrs_dba_*_embedded from a plain window p (make_dba_problem) and the embedded edge lists e (dba_build_embedded /
+    nrs_dba_build_edges_embedded: node copies lm_obs, skinned observations sk_obs as indices into the window's observations)."""
+    lo, so = e["lm_obs"], e["sk_obs"]
+    return dict(lm_xyz=p["lm_xyz"][lo], lm_kf=p["lm_kf"][lo], lm_uv=p["lm_uv"][lo],
+                sk_kf=p["lm_kf"][so], sk_uv=p["lm_uv"][so], sk_xyz=p["lm_xyz"][so])

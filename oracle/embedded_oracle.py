@@ -263,3 +263,171 @@ def track_deform_solve_embedded(cam_model, cam_prm, graph, map_pos, f_map, f_sta
         map_pos[lid] = G.pts[nv + li].astype(F32) + map_pos[lid]
     res.update(lost=lost_sorted, map_pos=map_pos)
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# N2b: the embedded form of LocalDeformableBundleAdjustment (OPT:880-1161) -- BASELINE configs[1] as written, "5k map points x
+# 500 deformation-graph nodes x 20 keyframes".  The window's VERTICES are the keyframe copies of the NODES (LandmarkVertex per
+# (keyframe, node), OPT:985-1004) and the poses; springs (PositionRegularizer, OPT:1031-1072) and dampers (SpatialRegularizer,
+# OPT:1076-1132) are built between node copies only, by the reference's own walks with every non-node passed over; every other
+# observed point is SKINNED in its keyframe to the <= 11 node copies its walk accepts:
+#       x = X0 + sum_k omega_k (x_{n_k} - x0_{n_k}),   omega = w / sum w  (float32 connection weights, summed in float64)
+# (X0, x0: the estimates the window starts from), and its ReprojectionError edge (reprojection_error.cc:32-64: residual,
+# information 1 / 0.5^2, Huber sqrt(5.99)) constrains those node copies and the keyframe pose -- Jacobian omega_k x the
+# reference's 2 x 3 block.  With every point a node the lists are dba_build's and the solve is nrs_oracle.dba_solve, bit for bit
+# (tests/test_oracle_embedded_cpu.py): the only pin this mode can have; beyond M = N it is "parity unpinned".
+# ----------------------------------------------------------------------------------------------------------------------------
+def dba_build_embedded(kf_points, is_node, nbr_rowptr, nbr_col, nbr_w, nbr_d0, nbr_status):
+    """kf_points / nbr_* as nrs_oracle.dba_build; is_node[p] != 0: map point p is a node.  Observation o = position in the
+    concatenation of kf_points (= landmark index of the plain form).  Returns the node copies (lm_obs: their observation index,
+    kf-major; lm_kf, lm_pt), springs / dampers over node-copy indices in reference insertion order, and the skinned observations
+    (sk_obs, sk_kf, sk_node [n x 11] node-copy indices with -1 pads, sk_omega [n x 11])."""
+    is_node = np.asarray(is_node).astype(bool)
+    K = len(kf_points)
+    lm_obs, lm_kf, lm_pt = [], [], []
+    inserted, observed = [], []
+    o = 0
+    for k, pts in enumerate(kf_points):
+        d = {}
+        ob = set()
+        for p in pts:
+            p = int(p)
+            ob.add(p)
+            if is_node[p]:
+                d[p] = len(lm_kf)
+                lm_obs.append(o); lm_kf.append(k); lm_pt.append(p)
+            o += 1
+        inserted.append(d)
+        observed.append(ob)
+    sp_i, sp_j, sp_d0, dm, dm_w = [], [], [], [], []
+    sk_obs, sk_kf, sk_node, sk_omega = [], [], [], []
+    spring_seen, damper_seen = set(), set()
+    o = 0
+    for k, pts in enumerate(kf_points):
+        cur = inserted[k]
+        nxt = inserted[k + 1] if k + 1 < K else None
+        for p in pts:
+            p = int(p)
+            lo, hi = nbr_rowptr[p], nbr_rowptr[p + 1]
+            if not is_node[p]:
+                nodes, ws = [], []
+                n_reg = 0
+                for e in range(lo, hi):                            # the walk of OPT:1035-1072, nodes accepted, others passed over
+                    if n_reg > O.REGULARIZERS_PER_POINT or nbr_status[e] == O.GRAPH_BAD:
+                        break
+                    q = int(nbr_col[e])
+                    if q not in cur:                               # (not observed by the keyframe, or not a node)
+                        continue
+                    nodes.append(cur[q]); ws.append(float(np.float64(F32(nbr_w[e]))))
+                    n_reg += 1
+                if nodes:
+                    tot = 0.0
+                    for w in ws:
+                        tot += w
+                    sk_obs.append(o); sk_kf.append(k)
+                    sk_node.append(nodes + [-1] * (MAX_NODES - len(nodes)))
+                    sk_omega.append([w / tot for w in ws] + [0.0] * (MAX_NODES - len(ws)))
+                o += 1
+                continue
+            l = cur[p]
+            n_reg = 0
+            for e in range(lo, hi):
+                if n_reg > O.REGULARIZERS_PER_POINT or nbr_status[e] == O.GRAPH_BAD:
+                    break
+                q = int(nbr_col[e])
+                if q not in cur:
+                    continue
+                key = (min(p, q), max(p, q), k)
+                if key in spring_seen:
+                    n_reg += 1
+                    continue
+                spring_seen.add(key)
+                sp_i.append(l); sp_j.append(cur[q]); sp_d0.append(nbr_d0[e])
+                n_reg += 1
+            if nxt is not None and p in nxt:
+                ln = nxt[p]
+                n_reg = 0
+                for e in range(lo, hi):
+                    if n_reg > O.REGULARIZERS_PER_POINT or nbr_status[e] == O.GRAPH_BAD:
+                        break
+                    q = int(nbr_col[e])
+                    if q not in cur or q not in nxt:
+                        continue
+                    key = (min(p, q), max(p, q), k)
+                    if key in damper_seen:
+                        n_reg += 1
+                        continue
+                    damper_seen.add(key)
+                    dm.append((l, cur[q], ln, nxt[q])); dm_w.append(nbr_w[e])
+                    n_reg += 1
+            o += 1
+    return dict(lm_obs=np.array(lm_obs, np.int32), lm_kf=np.array(lm_kf, np.int32), lm_pt=np.array(lm_pt, np.int32),
+                sp_ij=np.array(list(zip(sp_i, sp_j)), np.int32).reshape(-1, 2), sp_d0=np.array(sp_d0, F32),
+                dm_idx=np.array(dm, np.int32).reshape(-1, 4), dm_w=np.array(dm_w, F32),
+                sk_obs=np.array(sk_obs, np.int32), sk_kf=np.array(sk_kf, np.int32),
+                sk_node=np.array(sk_node, np.int32).reshape(-1, MAX_NODES), sk_omega=np.array(sk_omega, np.float64).reshape(-1, MAX_NODES))
+
+
+class SkinnedBAReprojEdges(O.EdgeGroup):
+    """ReprojectionError (reprojection_error.cc:32-64) of a point without a vertex: x = X0 + sum_k omega_k (pts[node_k] - P0[node_k])."""
+    dim = 2
+
+    def __init__(self, uv, pose_idx, X0, nodes, omega, P0, info, delta):
+        n = len(uv)
+        super().__init__(n, info, delta)
+        self.uv = np.asarray(uv, np.float64).reshape(n, 2)
+        self.pose_idx = np.asarray(pose_idx, np.int64)
+        self.X0 = np.asarray(X0, np.float64).reshape(n, 3)
+        nodes = np.asarray(nodes, np.int64).reshape(n, MAX_NODES)
+        self.omega = np.where(nodes >= 0, np.asarray(omega, np.float64).reshape(n, MAX_NODES), 0.0)
+        self.nodes = np.where(nodes >= 0, nodes, 0)
+        self.P0 = np.asarray(P0, np.float64)
+        self.slots = [('pose', self.pose_idx)] + [('pt', self.nodes[:, k].copy()) for k in range(MAX_NODES)]
+
+    def world(self, G, idx):
+        d = np.zeros((len(idx), 3))
+        for k in range(MAX_NODES):                                 # (sequential over the nodes)
+            nk = self.nodes[idx, k]
+            d += self.omega[idx, k, None] * (G.pts[nk] - self.P0[nk])
+        return self.X0[idx] + d
+
+    def _cam(self, G, idx):
+        k = self.pose_idx[idx]
+        return O._reproj_core(G, G.pose_q[k], G.pose_t[k], self.world(G, idx))
+
+    def residual(self, G, idx):
+        p = self._cam(G, idx)
+        return self.uv[idx] - O.project_f32(G.cam_model, G.cam_prm, p.astype(F32)).astype(np.float64)
+
+    def jacobians(self, G, idx):
+        p = self._cam(G, idx)
+        Jp = -O.projection_jacobian_f32(G.cam_model, G.cam_prm, p.astype(F32)).astype(np.float64)
+        k = self.pose_idx[idx]
+        uk = np.unique(k)
+        R = np.stack([O.quat_to_R(G.pose_q[kk]) for kk in uk])
+        Rn = R[np.searchsorted(uk, k)]
+        Jl = np.einsum('nij,njk->nik', Jp, Rn)
+        return [np.einsum('nij,njk->nik', Jp, O._expmap_jac(p))] + [self.omega[idx, q, None, None] * Jl for q in range(MAX_NODES)]
+
+
+def dba_graph_embedded(cam_model, cam_prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w,
+                       sk_kf, sk_uv, sk_xyz, sk_node, sk_omega, scale):
+    """lm_*: the node copies (vertices); sk_*: the skinned observations (sk_xyz: their positions at the start = X0)."""
+    G = O.dba_graph(cam_model, cam_prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w, scale)
+    skn = None
+    if len(sk_kf):
+        skn = SkinnedBAReprojEdges(np.asarray(sk_uv, F32), sk_kf, np.asarray(sk_xyz, F32).astype(np.float64), sk_node, sk_omega,
+                                   G.pts.copy(), float(O.INFO_REPROJ), O.TH2)
+        G.groups.append(skn)
+    return G, skn
+
+
+def dba_solve_embedded(cam_model, cam_prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w,
+                       sk_kf, sk_uv, sk_xyz, sk_node, sk_omega, scale, iters=5, trace=None, solver=O.solve_spd):
+    """optimize(iters) on the embedded window.  Returns poses (q, t), node copies fp64, skinned positions fp64, LM iterations."""
+    G, skn = dba_graph_embedded(cam_model, cam_prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w,
+                                sk_kf, sk_uv, sk_xyz, sk_node, sk_omega, scale)
+    G.initialize(0)
+    n_it = O.lm_optimize(G, iters, trace, solver)
+    sk_out = skn.world(G, np.arange(skn.n)) if skn is not None else np.zeros((0, 3))
+    return G.pose_q.copy(), G.pose_t.copy(), G.pts.copy(), sk_out, n_it

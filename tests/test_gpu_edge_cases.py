@@ -147,8 +147,9 @@ def test_ba_two_tile_classes_bit_identical(ctx, monkeypatch):
 def test_ba_trial_chi2_paths_agree(exact, monkeypatch):
     """Trial states of a BA window are evaluated edge-parallel (one thread per spring / damper); the
     switch NRS_NO_EDGE_CHI=1 evaluates them from the incidence records of the counting rows instead.
-    Same residuals and Huber, another order of the sum: identical decisions, chi2 to 1e-12 relative,
-    same result."""
+    Same residuals and Huber, another order of the sum: identical decisions, chi2 to 1e-11 relative,
+    same result.  (A spring residual k (d - d0) / d0 amplifies the last bit of d by d / (d - d0): the two kernels form d in
+    differently contracted expressions, so the sums agree to ~1e-12, not to the 1e-14 of a pure reordering.)"""
     p = S.make_dba_problem(900, 6, 76)
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
@@ -165,7 +166,7 @@ def test_ba_trial_chi2_paths_agree(exact, monkeypatch):
     a, b = res
     assert [(t["accepted"], t["early"], t["inner"]) for t in a[2]] == [(t["accepted"], t["early"], t["inner"]) for t in b[2]]
     for s, t in zip(a[2], b[2]):
-        assert abs(s["chi_new"] - t["chi_new"]) <= 1e-12 * abs(t["chi_new"]) and abs(s["chi"] - t["chi"]) <= 1e-12 * abs(t["chi"])
+        assert abs(s["chi_new"] - t["chi_new"]) <= 1e-11 * abs(t["chi_new"]) and abs(s["chi"] - t["chi"]) <= 1e-11 * abs(t["chi"])
     assert np.allclose(a[0], b[0], atol=1e-9, rtol=0) and np.allclose(a[1], b[1], atol=1e-6, rtol=0)
 
 
