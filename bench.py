@@ -256,7 +256,7 @@ def reduce_over_ranks(dist, dt, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
+def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0, n_nodes=0):
     """Secondary figure of BASELINE.json's metric: tracked frames/s, end to end through the frame-loop
     harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode and
     feature extraction) on a consistent synthetic 640x480 sequence with n_points map points: LK data
@@ -268,7 +268,8 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
     sq = S.make_frame_sequence(n_points, frames + 1, 21)
     opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
     # dense_graph: the map's graph at the reference's density (all pairs, resident on the device) instead of the generator's kNN-16
-    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts, dense_graph=dense_graph, cap_per_point=128, direct_solve=direct_solve)
+    # n_nodes > 0: the embedded-deformation mode of the pose-and-deformation solve (n_nodes map points carry the vertices, N2a)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], opts, dense_graph=dense_graph, cap_per_point=128, direct_solve=direct_solve, n_nodes=n_nodes)
     stage = {}
 
     def wrap(name):
@@ -308,7 +309,7 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0):
                    # symbolic factorisations over the whole sequence (two single-frame problems per frame): built anew / taken from the
                    # context's cache because the frame's optimised set, edges and fixed flags equalled an earlier frame's
                    symbolic_plans=dict(built=nd_built, reused=nd_reused))
-    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), frames=nf, a2_solver=latency,
+    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), nodes=int(n_nodes) if n_nodes else int(sq["n_points"]), frames=nf, a2_solver=latency,
                 tracked_last_frame=int(loop.log[-1]["n_tracked"]),
                 ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,
                 ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * stage.get("reuse_track", 0) / nf,
@@ -491,19 +492,28 @@ def skinned_bench(n=5000, m=500, n_kf=20):
                            frames_per_s_of_this_call=1e3 / float(np.median(ms2[1:])), lm_trials=len(tr2.trials),
                            linear_solver="nested-dissection Cholesky over %d node blocks + pose (k_nd_level / k_nd_back)" % m,
                            note="every tracked point's reprojection edge is in the problem (skinned to <= 11 nodes, normalised weights); "
-                                "unknowns 6 + 3 x %d; held to oracle/embedded_oracle.py (tests/test_gpu_embedded.py)" % m)
+                                "unknowns 6 + 3 x %d; held to oracle/embedded_oracle.py at 600 x 80, 1500 x 200, 900 x 120 KB8 (tests/test_gpu_embedded.py) "
+                                "and at 5000 x 500 pinhole + KB8 by committed goldens (tests/test_gpu_embedded5k.py)" % m)
     g.close()
-    # the BA window over the nodes
-    p = S.make_dba_problem(m, n_kf, 11, 0)
-    e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
+    # ---- N2b: BASELINE configs[1] AS WRITTEN -- the C2 window (5k points x 20 keyframes) with m nodes: the node copies carry the
+    # vertices, every other observation is skinned to <= 11 node copies of its keyframe and constrains them and the pose
+    # (include/nrs.h nrs_dba_*_embedded; PCG with the observations' blocks as hyper-edges, csrc/nrs_engine_skin.hpp)
+    p = S.make_dba_problem("C2")
+    flag, nb = S.embedded_problem(p, m)
+    e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
+    w = S.embedded_window(p, e)
     camw = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-    ctx.dba_upload(camw, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
-    rr = timed_steps(ctx, 20, 3, lambda: None)
-    out["ba_window"] = dict(nodes=m, keyframes=n_kf, landmarks=int(len(p["lm_kf"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
-                            ms_per_step=1e3 * rr["dt"] / 20,
-                            note="a window over the NODES only (landmarks = nodes x keyframes they are seen in): a problem ~10x smaller than C2, "
-                                 "not C2 with 500 nodes -- the skinned points carry no observations into this window (DESIGN.md section 1, N2)")
+    ctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
+    rr = timed_steps(ctx, 10, 2, lambda: None)
+    out["ba_window"] = dict(workload="C2 embedded: %d points x %d nodes x %d keyframes" % (p["n_points"], m, p["n_kf"]), node_copies=int(len(e["lm_obs"])),
+                            skinned_observations=int(len(e["sk_obs"])), springs=int(len(e["sp_ij"])), dampers=int(len(e["dm_idx"])),
+                            unknowns=int(6 * p["n_kf"] + 3 * len(e["lm_obs"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
+                            ms_per_step=1e3 * rr["dt"] / 10, lm_trials_per_step=rr["trials"] / 10, pcg_iters_per_step=rr["inner"] / 10,
+                            linear_solver="block-Jacobi PCG, the skinned observations applied as hyper-edges (k_skin_op / k_skin_op_rows)",
+                            note="every observation of the window is in the problem; held to oracle/embedded_oracle.py dba_solve_embedded at 300 x 40 x 4 .. "
+                                 "600 x 80 x 6 (tests/test_gpu_embedded_ba.py) and at this size by the golden tests/golden/dba_C2_embedded%d_trace.npz; "
+                                 "the mode has no reference counterpart beyond every-point-a-node (there it is the plain window, bit for bit)" % m)
     ctx.close()
     return out
 
@@ -757,6 +767,12 @@ def main():
         out["tracked_fps_1k_points"] = {k: tf[k] for k in keys}
         tf = tracked_fps(dense_graph=False)
         out["tracked_fps_flat_knn16_graph"] = {k: tf[k] for k in keys}
+        # the metric's "tracked fps, 5k pts x 500 graph nodes" end to end: the same frame loop with the pose-and-deformation solve in the
+        # embedded-deformation mode (500 map points carry the vertices, every other tracked point is skinned to <= 11 of them; N2a)
+        tf = tracked_fps(dense_graph=True, n_nodes=500)
+        out["tracked_fps_5k_x_500"] = dict({k: tf[k] for k in keys}, nodes=500, mode="embedded deformation (nrs_track_deform_solve_embedded)",
+                                           note="held to oracle/embedded_oracle.py at 600 x 80 .. 1500 x 200 (tests/test_gpu_embedded.py) and at 5000 x 500, pinhole + KB8 "
+                                                "(tests/test_gpu_embedded5k.py, committed goldens); no reference counterpart beyond every-point-a-node")
         out["shi_extract"] = shi_extract_bench()
         out["graph_dense"] = rgraph_bench()
         out["triangulation"] = triangulation_bench()

@@ -160,6 +160,43 @@ int nrs_dba_solve(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, double* pos
                   int32_t n_damper, const int32_t* dm_idx, const float* dm_w,
                   float scale, int32_t iters, nrs_lm_trace* trace);
 
+/* ---- N2b: the EMBEDDED form of the window -- BASELINE configs[1] as written, "5k map points x 500 deformation-graph nodes x 20
+ * keyframes".  The reference has no such estimator (its graph has a vertex per map point); this is
+ * LocalDeformableBundleAdjustment (g2o_optimization.cc:880-1161) with the vertices restricted to the keyframe copies of a NODE set:
+ * springs (OPT:1031-1072) and dampers (OPT:1076-1132) by the reference's walks between node copies only, and every other observed
+ * point SKINNED in its keyframe to the <= 11 node copies its walk accepts, x = X0 + sum_k omega_k (x_{n_k} - x_start_{n_k}) with the
+ * connection weights normalised; its ReprojectionError edge (reprojection_error.cc:32-64) keeps residual, information and Huber
+ * kernel and constrains those node copies and the keyframe pose (Jacobian omega_k x the reference's block).  With every point a
+ * node all of it IS the plain window (same lists, same bits); beyond that it is held to oracle/embedded_oracle.py
+ * (dba_build_embedded / dba_solve_embedded), "parity unpinned".  Observation o = position in the concatenation kf_pt.
+ *   nrs_dba_build_edges_embedded  host: node copies (lm_obs[n_lm]: their observation, keyframe-major), springs / dampers over
+ *                                 node-copy indices, skinned observations (sk_obs, sk_node [n x 11, -1 pads], sk_omega [n x 11]);
+ *                                 two-call pattern: lm_obs = NULL returns the four counts
+ *   nrs_dba_upload_embedded       the window resident: lm_* of the node copies, sk_kf / sk_uv / sk_xyz of the skinned observations
+ *                                 (sk_xyz = X0, their positions at the start); then nrs_dba_reset / optimize / download as before
+ *   nrs_dba_download_skinned      the skinned points at the current estimate (n_skin x 3, fp64)
+ *   nrs_dba_solve_embedded        one shot: upload, optimize(iters), download (poses_qt, lm_xyz, sk_xyz in/out)
+ * One GPU (no communicator); the linear solve is the PCG with the observations' blocks applied as hyper-edges
+ * (csrc/nrs_engine_skin.hpp). */
+int nrs_dba_build_edges_embedded(int32_t n_kf, const int32_t* kf_rowptr, const int32_t* kf_pt, int32_t n_points, const uint8_t* is_node,
+                                 const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status,
+                                 int32_t* n_lm, int32_t* lm_obs, int32_t* n_spring, int32_t* sp_ij, float* sp_d0,
+                                 int32_t* n_damper, int32_t* dm_idx, float* dm_w,
+                                 int32_t* n_skin, int32_t* sk_obs, int32_t* sk_node, double* sk_omega);
+int nrs_dba_upload_embedded(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                            int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                            int32_t n_spring, const int32_t* sp_ij, const float* sp_d0,
+                            int32_t n_damper, const int32_t* dm_idx, const float* dm_w,
+                            int32_t n_skin, const int32_t* sk_kf, const float* sk_uv, const float* sk_xyz,
+                            const int32_t* sk_node, const double* sk_omega, float scale);
+int nrs_dba_download_skinned(nrs_ctx* ctx, double* sk_xyz /* n_skin x 3, fp64 */);
+int nrs_dba_solve_embedded(nrs_ctx* ctx, const nrs_camera* cam, int32_t n_kf, double* poses_qt,
+                           int32_t n_lm, float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                           int32_t n_spring, const int32_t* sp_ij, const float* sp_d0,
+                           int32_t n_damper, const int32_t* dm_idx, const float* dm_w,
+                           int32_t n_skin, const int32_t* sk_kf, const float* sk_uv, float* sk_xyz,
+                           const int32_t* sk_node, const double* sk_omega, float scale, int32_t iters, nrs_lm_trace* trace);
+
 /* The whole of LocalDeformableBundleAdjustment in one call, as mapping.cc:57 makes it: flattened keyframes (kf_rowptr / kf_pt as in
  * nrs_dba_build_edges; lm_xyz / lm_uv per landmark = position in that concatenation, lm_xyz in/out) + the ordered neighbour lists
  * RegularizationGraph::GetEdges returns (a19).  The edge construction of OPT:927-1137 runs on the device as well (index for index

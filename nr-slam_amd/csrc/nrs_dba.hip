@@ -28,10 +28,12 @@ void ba_constants(EngineSpec& s, float scale) {
 
 using namespace nrs;
 
-extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
-                              int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
-                              int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
-                              int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale) {
+struct SkinIn { int32_t n = 0; const int32_t* kf = nullptr; const float* uv = nullptr; const float* xyz = nullptr; const int32_t* node = nullptr; const double* omega = nullptr; };
+
+static int dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                      int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                      int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                      int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale, const SkinIn& sk) {
     if (!c) return NRS_ERR_INVALID;
     if (!cam || n_kf <= 0 || n_lm <= 0 || !poses_qt || !lm_xyz || !lm_kf || !lm_uv || n_sp < 0 || n_dm < 0 ||
         (n_sp > 0 && (!sp_ij || !sp_d0)) || (n_dm > 0 && (!dm_idx || !dm_w)))
@@ -65,6 +67,13 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     s.delta_pos = 0.0;                  // no robust kernel on the BA springs (OPT:1057-1071)
     s.spring_form = 0;                  // PositionRegularizer Jacobian as written (position_regularizer.cc:51-60)
     s.shard = true;                     // with a communicator on the context: one window over its ranks (include/nrs.h)
+    std::vector<double> sk_X0;
+    if (sk.n > 0) {                     // embedded window (N2b): observations of points without a vertex
+        if (c->comm) return c->fail(NRS_ERR_STATE, "embedded BA windows are not sharded over a communicator");
+        sk_X0.resize(3 * (size_t)sk.n);
+        for (size_t i = 0; i < sk_X0.size(); ++i) sk_X0[i] = (double)sk.xyz[i];
+        s.n_skin = sk.n; s.sk_uv = sk.uv; s.sk_X0 = sk_X0.data(); s.sk_node = sk.node; s.sk_om = sk.omega; s.sk_pose = sk.kf;
+    }
     // rank-local checks and allocations can fail on one rank only: the ranks agree before the first collective
     int rc = engine_create(c, s, &c->arena_dba, &c->dba);
     // Every failure every rank sees alike (argument validation, more ranks than keyframes: all of them checked BEFORE any
@@ -73,6 +82,36 @@ extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, c
     if (rc == NRS_OK || c->err_local) rc = comm_agree(c, rc);
     if (rc != NRS_OK) dba_free(c);
     return rc;
+}
+
+extern "C" int nrs_dba_upload(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                              int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                              int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                              int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale) {
+    return dba_upload(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale, SkinIn());
+}
+
+// ---- N2b: the embedded form of the window (include/nrs.h) -- vertices = the node copies, every other observation skinned
+extern "C" int nrs_dba_upload_embedded(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, const double* poses_qt,
+                                       int32_t n_lm, const float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                                       int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                                       int32_t n_dm, const int32_t* dm_idx, const float* dm_w,
+                                       int32_t n_skin, const int32_t* sk_kf, const float* sk_uv, const float* sk_xyz,
+                                       const int32_t* sk_node, const double* sk_omega, float scale) {
+    if (!c) return NRS_ERR_INVALID;
+    if (n_skin < 0 || (n_skin > 0 && (!sk_kf || !sk_uv || !sk_xyz || !sk_node || !sk_omega))) return c->fail(NRS_ERR_INVALID, "nrs_dba_upload_embedded: bad argument");
+    for (int64_t i = 0; i < (int64_t)11 * n_skin; ++i)
+        if (sk_node[i] < -1 || sk_node[i] >= n_lm) return c->fail(NRS_ERR_INVALID, "skinned observation: node copy out of range");
+    SkinIn sk;
+    sk.n = n_skin; sk.kf = sk_kf; sk.uv = sk_uv; sk.xyz = sk_xyz; sk.node = sk_node; sk.omega = sk_omega;
+    return dba_upload(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale, sk);
+}
+
+extern "C" int nrs_dba_download_skinned(nrs_ctx* c, double* sk_xyz) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if (!sk_xyz) return c->fail(NRS_ERR_INVALID, "null output");
+    return engine_skin_positions(c, c->dba, sk_xyz);
 }
 
 extern "C" int nrs_dba_stats(nrs_ctx* c, int64_t stats[5]) {
@@ -135,6 +174,24 @@ extern "C" int nrs_dba_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, do
     std::vector<double> xyz((size_t)n_lm * 3);
     NRS_TRY(download(c, n_kf, poses_qt, xyz.data()));
     for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
+    return NRS_OK;
+}
+
+extern "C" int nrs_dba_solve_embedded(nrs_ctx* c, const nrs_camera* cam, int32_t n_kf, double* poses_qt,
+                                      int32_t n_lm, float* lm_xyz, const int32_t* lm_kf, const float* lm_uv,
+                                      int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                                      int32_t n_dm, const int32_t* dm_idx, const float* dm_w,
+                                      int32_t n_skin, const int32_t* sk_kf, const float* sk_uv, float* sk_xyz,
+                                      const int32_t* sk_node, const double* sk_omega, float scale, int32_t iters, nrs_lm_trace* trace) {
+    if (!c) return NRS_ERR_INVALID;
+    NRS_TRY(nrs_dba_upload_embedded(c, cam, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, n_skin, sk_kf, sk_uv, sk_xyz,
+                                    sk_node, sk_omega, scale));
+    NRS_TRY(nrs_dba_optimize(c, iters, trace));
+    std::vector<double> xyz((size_t)n_lm * 3), sk((size_t)n_skin * 3);
+    NRS_TRY(download(c, n_kf, poses_qt, xyz.data()));
+    if (n_skin > 0) NRS_TRY(engine_skin_positions(c, c->dba, sk.data()));
+    for (size_t i = 0; i < xyz.size(); ++i) lm_xyz[i] = (float)xyz[i];      // OPT:1158 cast<float>
+    for (size_t i = 0; i < sk.size(); ++i) sk_xyz[i] = (float)sk[i];
     return NRS_OK;
 }
 

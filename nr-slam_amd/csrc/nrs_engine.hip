@@ -310,6 +310,10 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
         hipLaunchKernelGGL(k_coarse_reduce, dim3(1), b, 0, c->stream, d);
     }
     if (d.sk_n > 0) hipLaunchKernelGGL((k_skin<LIN>), dim3(d.sk_nblk), b, 0, c->stream, d, d.pose[which], d.xl[which]);   // embedded mode: the skinned observations
+    if (LIN && d.sk_pcg) {                                         // embedded BA window: their blocks join D / b_l / H_pp / b_p (the PCG path reads those)
+        hipLaunchKernelGGL(k_skin_rows, dim3((d.sk_nrl + SK_RPB - 1) / SK_RPB), b, 0, c->stream, d);
+        hipLaunchKernelGGL(k_skin_pose, dim3((27 * d.K + BLK - 1) / BLK), b, 0, c->stream, d);
+    }
     if (LIN && e->nd && e->nd->on) {                               // the direct solver's explicit blocks of this linearisation
         const NdVals& nv = e->nd->slot->vals;
         if (nv.ske_ptr) hipLaunchKernelGGL(k_nd_values<true>, dim3((nv.n_ent * ND_SKL + 255) / 256), dim3(256), 0, c->stream, d, nv);
@@ -525,6 +529,10 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches, reps);
             if (d.hier && d.ecd) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(BLK), 0, c->stream, d, it);
             for (int r = 0; r < reps; ++r) launch_spmv(c, d, lam, it, tol2);
+        }
+        if (d.sk_pcg) {                                            // embedded BA window: H u of the skinned observations' blocks (nrs_engine_skin.hpp)
+            hipLaunchKernelGGL(k_skin_op, dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, it);
+            hipLaunchKernelGGL(k_skin_op_rows, dim3((d.sk_nrl + SK_RPB - 1) / SK_RPB), dim3(BLK), 0, c->stream, d);
         }
         if (d.sh_on) {
             // this rank's dot products and pose sums (other ranks' slots are zero), then the sum over the

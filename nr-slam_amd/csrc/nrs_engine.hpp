@@ -49,6 +49,8 @@ struct EngineSpec {
     const double* sk_X0 = nullptr;        // n_skin x 3
     const int* sk_node = nullptr;         // n_skin x 11 vertex indices, -1 pads
     const double* sk_om = nullptr;        // n_skin x 11 normalised weights
+    const int* sk_pose = nullptr;         // n_skin pose index of every observation (null: pose 0); BA windows (K >= 1, PCG path): the point sits at
+                                          // X0 + sum_k om[k] (x[node[k]] - x_start[node[k]]) -- N2b, oracle/embedded_oracle.py dba_solve_embedded
     bool shard = false;                   // split the poses over the ranks of the context's communicator (BA windows only)
     bool force_gather = false;            // stored-block operator (k_spmv gather path) instead of the LDS-staged factored one
     bool edges_on_device = false;         // sp_ij / sp_d0 / dm_idx / dm_w are DEVICE pointers (engine_build_edges_device): plain BA windows only
@@ -72,6 +74,7 @@ int engine_pack_hash(nrs_ctx* c, Engine* e, uint64_t* out /*24*/);
 // embedded mode: levels of the skinned observations (1 = level 0) / their chi2 = r^T Omega r at the current estimate
 int engine_skin_set_active(nrs_ctx* c, Engine* e, const uint8_t* active);
 int engine_skin_chi2(nrs_ctx* c, Engine* e, double* chi /*n_skin*/);
+int engine_skin_positions(nrs_ctx* c, Engine* e, double* xyz /*n_skin x 3*/);   // embedded BA windows: the skinned points at the current estimate
 // OPT:927-1137's edge construction on the device (index for index what nrs_dba_build_edges returns); arrays live in ctx scratch
 int engine_build_edges_device(nrs_ctx* c, int n_kf, const int* kf_rowptr, const int* kf_pt, const int* lm_kf, int n_points, const int* nbr_rowptr,
                               const int* nbr_col, const float* nbr_w, const float* nbr_d0, const int* nbr_status, DevEdges* out);

@@ -458,7 +458,7 @@ static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows) {
     if (getenv("NRS_HOST_PACK") || getenv("NRS_NO_PLAIN") || getenv("NRS_NO_LDS") || getenv("NRS_DFORM") || getenv("NRS_NO_EDGE_CHI") || getenv("NRS_NO_FUSED") ||
         getenv("NRS_SELL_T") || getenv("NRS_FUSED_MAX_ROWS") || getenv("NRS_TILE_CUT_PCT") || getenv("NRS_HIER") || getenv("NRS_NO_ECD"))
         return false;                                                // (test / A-B switches are honoured by the host path)
-    if (c->comm || s.X0 || s.n_un || s.sp_active || s.dm_active || s.pose_fixed || s.force_gather) return false;
+    if (c->comm || s.X0 || s.n_un || s.sp_active || s.dm_active || s.pose_fixed || s.force_gather || s.n_skin > 0) return false;
     if (s.K < 2 || n_pad_rows < 2048 || s.delta_pos > 0 || s.spring_form != 0 || s.n_dm <= 0 || s.n_sp <= 0) return false;   // (single-frame problems: a2, host)
     if (4 * (int64_t)s.n_dm >= 0xFFFFFFFFLL || (int64_t)n_pad_rows >= 0x7FFFFFFFLL) return false;
     return true;

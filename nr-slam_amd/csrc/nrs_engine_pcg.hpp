@@ -465,6 +465,8 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
             v[1] += P.part_spmv[(size_t)b * NPART + 1];
             v[2] += P.part_spmv[(size_t)b * NPART + 2];
         }
+        if (P.sk_pcg)                                              // embedded BA window: what the skinned observations' row pass added
+            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) { v[1] += P.sk_rpart[2 * (size_t)b]; v[2] += P.sk_rpart[2 * (size_t)b + 1]; }
         block_sum<3>(v, lds, lane, wave);
         if (tid == 0) { P.red[0] = v[0]; P.red[1] = v[1]; P.red[2] = v[2]; }
     } else {
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
         }
+        if (P.sk_pcg)
+            for (int b = P.sk_pose_blk[k] + tid; b < P.sk_pose_blk[k + 1]; b += BLK) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[a] += P.sk_opart[(size_t)b * 8 + a];
+            }
         block_sum<6>(acc, lds, lane, wave);
         if (tid == 0) {
 #pragma unroll
@@ -569,6 +576,8 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
             for (int b = tid; b < P.n_vecblk; b += BLK) v[0] += pr[b];
         }
+        if (P.sk_pcg)                                              // embedded BA window: the skinned observations' shares of w.u and of the cross term
+            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) { v[1] += P.sk_rpart[2 * (size_t)b]; v[2] += P.sk_rpart[2 * (size_t)b + 1]; }
     }
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
     for (int i = tid; i < 6 * P.K; i += BLK) {
@@ -675,6 +684,11 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
 #pragma unroll
                     for (int a = 0; a < 6; ++a) acc[a] += P.part_spmv[(size_t)g * NPART + 3 + a];
                 }
+                if (P.sk_pcg)                                      // ... and of the pose rows: sum of B s over the pose's observation blocks
+                    for (int b = P.sk_pose_blk[k] + lane; b < P.sk_pose_blk[k + 1]; b += 64) {
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) acc[a] += P.sk_opart[(size_t)b * 8 + a];
+                    }
 #pragma unroll
                 for (int a = 0; a < 6; ++a) acc[a] = wave_sum(acc[a]);
             }

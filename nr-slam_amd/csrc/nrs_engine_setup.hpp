@@ -305,8 +305,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     if (s.edges_on_device) return c->fail(NRS_ERR_STATE, "device-built edge lists need the device-side construction, which this window does not qualify for");
     // a2's single-frame engines: the direct solver's symbolic phase needs the structure only and runs next to the packing below
     if (s.n_skin > 0) {                                            // (checked HERE: the plan thread below indexes by these)
-        if (!(arena == &c->arena_trk && s.K == 1) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
-            return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines only");
+        if ((!(arena == &c->arena_trk && s.K == 1) && !s.sk_pose) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
+            return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines, or BA windows with a pose per observation");
         for (size_t q = 0; q < (size_t)SK_MAX * s.n_skin; ++q)
             if (s.sk_node[q] >= s.M || s.sk_node[q] < -1) return c->fail(NRS_ERR_INVALID, "skinned observation: node index out of range");
     }
@@ -687,6 +687,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
+    if (s.n_skin > 0 && s.sk_pose) d.fused = 0;                    // embedded BA window: the skinned observations' operator kernels sit between the two launches of an iteration
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     // (a profiling context times full operator launches only: no convergence-detecting early exits)
     d.ecd = (d.use_lds && !d.fused && !c->opt.profile && !getenv("NRS_NO_ECD")) ? 1 : 0;
@@ -1043,6 +1044,85 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
+    if (s.n_skin > 0 && s.sk_pose) {
+        // ---- embedded BA window (N2b): K poses, the skinned observations act through the PCG operator (nrs_engine_skin.hpp).
+        // Slots: observations grouped by pose (caller order inside a pose), every pose's padded to BLK; per node row the list of the
+        // observations that reach it, in slot order.
+        if (d.fused || d.sh_on || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om) return c->fail(NRS_ERR_INVALID, "skinned observations of a BA window: two-kernel PCG path, one GPU");
+        const size_t n_in = (size_t)s.n_skin;
+        std::vector<int> cnt(s.K + 1, 0), pose_blk(s.K + 1, 0);
+        for (size_t i = 0; i < n_in; ++i) {
+            if (s.sk_pose[i] < 0 || s.sk_pose[i] >= s.K) return c->fail(NRS_ERR_INVALID, "skinned observation: pose index out of range");
+            cnt[s.sk_pose[i] + 1]++;
+        }
+        for (int k = 0; k < s.K; ++k) pose_blk[k + 1] = pose_blk[k] + (cnt[k + 1] + BLK - 1) / BLK;
+        const size_t nblk = (size_t)pose_blk[s.K], n = nblk * BLK;
+        std::vector<int> next(s.K), blk_pose(nblk);
+        for (int k = 0; k < s.K; ++k) { next[k] = pose_blk[k] * BLK; for (int b2 = pose_blk[k]; b2 < pose_blk[k + 1]; ++b2) blk_pose[b2] = k; }
+        e->sk_slot.resize(n_in);
+        std::vector<float> uv(2 * n, 0.f);
+        std::vector<double> X0(3 * n, 0.0), om(SK_MAX * n, 0.0);
+        std::vector<int> rows(SK_MAX * n, -1);
+        std::vector<uint8_t> act(n, 0);
+        std::vector<int> rl_cnt(d.n_rows + 1, 0);
+        for (size_t i = 0; i < n_in; ++i) {
+            const size_t sl = (size_t)next[s.sk_pose[i]]++;
+            e->sk_slot[i] = (int)sl;
+            uv[2 * sl] = s.sk_uv[2 * i]; uv[2 * sl + 1] = s.sk_uv[2 * i + 1];
+            for (int k = 0; k < 3; ++k) X0[3 * sl + k] = s.sk_X0[3 * i + k];
+            act[sl] = 1;
+            for (int k = 0; k < SK_MAX; ++k) {
+                const int v = s.sk_node[SK_MAX * i + k];
+                if (v < 0) continue;
+                if (s.lm_pose[v] != s.sk_pose[i]) return c->fail(NRS_ERR_INVALID, "skinned observation: a node copy of another keyframe");
+                rows[SK_MAX * sl + k] = e->vrow[v];
+                om[SK_MAX * sl + k] = s.sk_om[SK_MAX * i + k];
+                rl_cnt[e->vrow[v] + 1]++;
+            }
+        }
+        // row lists (CSR over the rows that are reached), entries in slot order
+        std::vector<int> rl_row, rl_ptr(1, 0), row_list(d.n_rows, -1);
+        for (int r = 0; r < d.n_rows; ++r)
+            if (rl_cnt[r + 1] > 0) { row_list[r] = (int)rl_row.size(); rl_row.push_back(r); rl_ptr.push_back(rl_ptr.back() + rl_cnt[r + 1]); }
+        const size_t n_ent = (size_t)rl_ptr.back(), nrl = rl_row.size(), nrlblk = (nrl + SK_RPB - 1) / SK_RPB;
+        std::vector<int> rl_obs(n_ent + 1), fill(rl_ptr.begin(), rl_ptr.end() - 1);
+        std::vector<double> rl_om(n_ent + 1);
+        for (size_t sl = 0; sl < n; ++sl)
+            for (int k = 0; k < SK_MAX; ++k) {
+                const int r = rows[SK_MAX * sl + k];
+                if (r < 0) continue;
+                const int q = fill[row_list[r]]++;
+                rl_obs[q] = (int)sl; rl_om[q] = om[SK_MAX * sl + k];
+            }
+        auto al = [](size_t b2) { return (b2 + 255) & ~(size_t)255; };
+        const size_t o_uv = 0, o_X0 = o_uv + al(8 * n), o_row = o_X0 + al(24 * n), o_om = o_row + al(4 * SK_MAX * n), o_act = o_om + al(8 * SK_MAX * n),
+                     o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
+                     o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
+                     o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 6 * n), o_rpart = o_op + al(8 * 8 * nblk), total = o_rpart + al(8 * 2 * (nrlblk + 1));
+        NRS_TRY(c->ensure(c->dba_skin, total));
+        char* sb = c->dba_skin.as<char>();
+        auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(sb + off, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess; };
+        NRS_HIP(c, up(o_uv, uv.data(), 8 * n)); NRS_HIP(c, up(o_X0, X0.data(), 24 * n)); NRS_HIP(c, up(o_row, rows.data(), 4 * SK_MAX * n));
+        NRS_HIP(c, up(o_om, om.data(), 8 * SK_MAX * n)); NRS_HIP(c, up(o_act, act.data(), n)); NRS_HIP(c, up(o_bp, blk_pose.data(), 4 * nblk));
+        NRS_HIP(c, up(o_pb, pose_blk.data(), 4 * (size_t)(s.K + 1))); NRS_HIP(c, up(o_rr, rl_row.data(), 4 * nrl)); NRS_HIP(c, up(o_rp, rl_ptr.data(), 4 * (nrl + 1)));
+        NRS_HIP(c, up(o_ro, rl_obs.data(), 4 * n_ent)); NRS_HIP(c, up(o_rw, rl_om.data(), 8 * n_ent));
+        NRS_HIP(c, hipMemsetAsync(sb + o_rec, 0, total - o_rec, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        d.sk_n = (int)n; d.sk_nblk = (int)nblk; d.sk_pcg = 1;
+        d.sk_uv = reinterpret_cast<const float*>(sb + o_uv); d.sk_X0 = reinterpret_cast<const double*>(sb + o_X0);
+        d.sk_row = reinterpret_cast<const int*>(sb + o_row); d.sk_om = reinterpret_cast<const double*>(sb + o_om);
+        d.sk_active = reinterpret_cast<const uint8_t*>(sb + o_act);
+        d.sk_blk_pose = reinterpret_cast<const int*>(sb + o_bp); d.sk_pose_blk = reinterpret_cast<const int*>(sb + o_pb);
+        d.sk_nrl = (int)nrl; d.sk_rl_row = reinterpret_cast<const int*>(sb + o_rr); d.sk_rl_ptr = reinterpret_cast<const int*>(sb + o_rp);
+        d.sk_rl_obs = reinterpret_cast<const int*>(sb + o_ro); d.sk_rl_om = reinterpret_cast<const double*>(sb + o_rw);
+        d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
+        d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
+        d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_rpart = reinterpret_cast<double*>(sb + o_rpart);
+        d.sk_base = d.xl_init;
+        e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
+        e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n_in);
+        e->sk_X0.assign(s.sk_X0, s.sk_X0 + 3 * n_in);
+    } else
     if (s.n_skin > 0) {                                // embedded mode: the skinned observations (device arrays in the context's buffer)
         if (!(arena == &c->arena_trk && s.K == 1) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
             return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines only");
@@ -1134,11 +1214,41 @@ int engine_skin_set_active(nrs_ctx* c, Engine* e, const uint8_t* active) {
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
+// embedded BA window: the skinned points at the current estimate, X0 + sum_k om_k (x_{n_k} - x_start_{n_k}), summed over k in order
+// (caller order of the observations; host arithmetic on the downloaded rows -- the same expression k_skin evaluates)
+int engine_skin_positions(nrs_ctx* c, Engine* e, double* xyz) {
+    const Dev& d = e->d;
+    if (!d.sk_pcg) return c->fail(NRS_ERR_STATE, "no skinned observations on this window");
+    const size_t nr = 3 * (size_t)d.n_rows, n = e->sk_slot.size();
+    std::vector<double> cur(nr), ini(nr);
+    NRS_HIP(c, hipMemcpyAsync(cur.data(), d.xl[e->cur], 8 * nr, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(ini.data(), d.xl_init, 8 * nr, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) {
+        double x[3] = {e->sk_X0[3 * i], e->sk_X0[3 * i + 1], e->sk_X0[3 * i + 2]};
+        for (int k = 0; k < SK_MAX; ++k) {
+            const int v = e->sk_vert[SK_MAX * i + k];
+            if (v < 0) continue;
+            const size_t r = 3 * (size_t)e->vrow[v];
+            const double om = e->sk_om[SK_MAX * i + k];
+            for (int a = 0; a < 3; ++a) x[a] += om * (cur[r + a] - ini[r + a]);
+        }
+        xyz[3 * i] = x[0]; xyz[3 * i + 1] = x[1]; xyz[3 * i + 2] = x[2];
+    }
+    return NRS_OK;
+}
 int engine_skin_chi2(nrs_ctx* c, Engine* e, double* chi) {
     const Dev& d = e->d;
     if (d.sk_n <= 0) return NRS_OK;
     hipLaunchKernelGGL((k_skin<false>), dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, d.pose[e->cur], d.xl[e->cur]);
     NRS_HIP(c, hipGetLastError());
+    if (d.sk_pcg) {                                                // (slots are pose-grouped and padded: back to the caller's order)
+        std::vector<double> h((size_t)d.sk_n);
+        NRS_HIP(c, hipMemcpyAsync(h.data(), d.sk_chi, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < e->sk_slot.size(); ++i) chi[i] = h[e->sk_slot[i]];
+        return NRS_OK;
+    }
     NRS_HIP(c, hipMemcpyAsync(chi, d.sk_chi, sizeof(double) * (size_t)d.sk_n, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;

@@ -15,7 +15,6 @@
 
 namespace nrs {
 
-constexpr int SK_MAX = 11;           // nodes per skinned observation (the walk of OPT:255-279 accepts 11)
 
 template <bool LIN>
 __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ poses, const double* __restrict__ xl) {
@@ -25,8 +24,9 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0;
     if (LIN && i == 0) *P.sk_maxdiag = 0.0;
+    const int kp = P.sk_blk_pose ? P.sk_blk_pose[blockIdx.x] : 0;  // (a workgroup's observations share a pose)
     if (i < P.sk_n) {
-        const Pose Tcw = poses[0];
+        const Pose Tcw = poses[kp];
         double R[9];
         quat_to_R(Tcw.q, R);
         double x0 = P.sk_X0[3 * (size_t)i], x1 = P.sk_X0[3 * (size_t)i + 1], x2 = P.sk_X0[3 * (size_t)i + 2];
@@ -34,7 +34,10 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
         for (int k = 0; k < SK_MAX; ++k) {
             const int row = P.sk_row[SK_MAX * (size_t)i + k];
             const double om = P.sk_om[SK_MAX * (size_t)i + k];
-            if (row >= 0) { x0 += om * xl[3 * (size_t)row]; x1 += om * xl[3 * (size_t)row + 1]; x2 += om * xl[3 * (size_t)row + 2]; }
+            if (row >= 0 && P.sk_base) {                           // BA form: the node's displacement from where the window started
+                x0 += om * (xl[3 * (size_t)row] - P.sk_base[3 * (size_t)row]); x1 += om * (xl[3 * (size_t)row + 1] - P.sk_base[3 * (size_t)row + 1]);
+                x2 += om * (xl[3 * (size_t)row + 2] - P.sk_base[3 * (size_t)row + 2]);
+            } else if (row >= 0) { x0 += om * xl[3 * (size_t)row]; x1 += om * xl[3 * (size_t)row + 1]; x2 += om * xl[3 * (size_t)row + 2]; }
         }
         const double px = R[0] * x0 + R[1] * x1 + R[2] * x2 + Tcw.t[0];
         const double py = R[3] * x0 + R[4] * x1 + R[5] * x2 + Tcw.t[1];
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
             if (active) {
                 float Jf[6];
                 projection_jacobian_f32(P.cam, (float)px, (float)py, (float)pz, Jf);
-                const double w = rho1 * P.info_reproj, pm = P.pose_fixed[0] ? 0.0 : 1.0;
+                const double w = rho1 * P.info_reproj, pm = P.pose_fixed[kp] ? 0.0 : 1.0;
                 double Jp[2][6], Jl[2][3];
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
@@ -92,6 +95,120 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
         }
     }
     block_sum_store<28>(acc, lds, tid, P.sk_part + (size_t)blockIdx.x * 32);
+}
+
+// ---- embedded BA windows (N2b): K poses, the skinned observations act through the PCG path -------------------------------------------
+// Per linearisation, behind the lineariser and k_pose_sums (which WRITE D, b_l, H_pp, b_p): what the observations add to them.
+//   k_skin_rows : a node row's diagonal block += sum om^2 J_l^T w J_l, its gradient += sum om (-J_l^T w r) over its list
+//   k_skin_pose : H_pp / b_p of a pose += the block sums k_skin left (its blocks in order)
+// Per PCG iteration, behind k_spmv_f:  H u of the observations' blocks, with s_o = sum_k om_k u_{n_k}:
+//   k_skin_op      (per observation): g_o = A_o s_o + B_o^T u_p, gB_o = B_o^T u_p; block sums of B_o s_o (pose rows)
+//   k_skin_op_rows (per node row)   : w_row += sum om g_o; partials of what that adds to w.u and to the cross term
+// k_pcg_update / k_reduce_partials add the partials in (fixed order).  8 lanes per list, combined by the fixed butterfly of sub_sum_t.
+
+__device__ inline void sk_atomic_max(double* addr, double v) {     // v >= 0: the bit patterns of non-negative doubles order like integers
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ __launch_bounds__(BLK) void k_skin_rows(Dev P) {
+    const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
+    double D[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    const bool live = j < P.sk_nrl;
+    if (live)
+        for (int q = P.sk_rl_ptr[j] + t; q < P.sk_rl_ptr[j + 1]; q += SK_RL) {
+            const double om = P.sk_rl_om[q];
+            const double* rec = P.sk_rec + 27 * (size_t)P.sk_rl_obs[q];
+            const double o2 = om * om;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) D[k] += o2 * rec[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) b[k] += om * rec[6 + k];
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) D[k] = sub_sum_t<SK_RL>(D[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = sub_sum_t<SK_RL>(b[k]);
+    if (live && t == 0) {
+        const size_t row = (size_t)P.sk_rl_row[j];
+        double* Dr = P.D + 6 * row;
+        double dd[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { dd[k] = Dr[k] + D[k]; Dr[k] = dd[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.bl[3 * row + k] += b[k];
+        sk_atomic_max(P.sk_maxdiag, fmax(fabs(dd[0]), fmax(fabs(dd[3]), fabs(dd[5]))));
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_skin_pose(Dev P) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= 27 * P.K) return;
+    const int k = i / 27, cc = i % 27;
+    double s = 0;
+    for (int b = P.sk_pose_blk[k]; b < P.sk_pose_blk[k + 1]; ++b) s += P.sk_part[(size_t)b * 32 + cc];
+    if (cc < 21) {
+        const double v = P.Hpp[21 * k + cc] + s;
+        P.Hpp[21 * k + cc] = v;
+        if (cc == 0 || cc == 6 || cc == 11 || cc == 15 || cc == 18 || cc == 20) sk_atomic_max(P.sk_maxdiag, fabs(v));
+    } else P.bp[6 * k + (cc - 21)] += s;
+}
+
+__global__ __launch_bounds__(BLK) void k_skin_op(Dev P, int it) {
+    __shared__ double lds[4 * 6];
+    const int tid = threadIdx.x, i = blockIdx.x * BLK + tid;
+    double q[6] = {0, 0, 0, 0, 0, 0};
+    if (i < P.sk_n && !P.flags[0]) {
+        const int kp = P.sk_blk_pose[blockIdx.x];
+        const double* up = ((it & 1) ? P.up2 : P.up) + 6 * kp;
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < SK_MAX; ++k) {
+            const int row = P.sk_row[SK_MAX * (size_t)i + k];
+            const double om = P.sk_om[SK_MAX * (size_t)i + k];
+            if (row >= 0) { s0 += om * P.uv3[3 * (size_t)row]; s1 += om * P.uv3[3 * (size_t)row + 1]; s2 += om * P.uv3[3 * (size_t)row + 2]; }
+        }
+        const double* rec = P.sk_rec + 27 * (size_t)i;
+        const double a0 = rec[0] * s0 + rec[1] * s1 + rec[2] * s2, a1 = rec[1] * s0 + rec[3] * s1 + rec[4] * s2, a2 = rec[2] * s0 + rec[4] * s1 + rec[5] * s2;
+        double g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const double b0 = rec[9 + 3 * p], b1 = rec[9 + 3 * p + 1], b2 = rec[9 + 3 * p + 2], u = up[p];
+            g0 += b0 * u; g1 += b1 * u; g2 += b2 * u;
+            q[p] = b0 * s0 + b1 * s1 + b2 * s2;
+        }
+        double* g = P.sk_g + 6 * (size_t)i;
+        g[0] = a0 + g0; g[1] = a1 + g1; g[2] = a2 + g2; g[3] = g0; g[4] = g1; g[5] = g2;
+    }
+    block_sum<6>(q, lds, tid & 63, tid >> 6);
+    if (tid == 0) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) P.sk_opart[(size_t)blockIdx.x * 8 + p] = q[p];
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_skin_op_rows(Dev P) {
+    __shared__ double lds[4 * 2];
+    const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
+    double a[3] = {0, 0, 0}, c[3] = {0, 0, 0}, part[2] = {0, 0};
+    const bool live = j < P.sk_nrl && !P.flags[0];
+    if (live)
+        for (int q = P.sk_rl_ptr[j] + t; q < P.sk_rl_ptr[j + 1]; q += SK_RL) {
+            const double om = P.sk_rl_om[q];
+            const double* g = P.sk_g + 6 * (size_t)P.sk_rl_obs[q];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a[k] += om * g[k]; c[k] += om * g[3 + k]; }
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a[k] = sub_sum_t<SK_RL>(a[k]); c[k] = sub_sum_t<SK_RL>(c[k]); }
+    if (live && t == 0) {
+        const size_t row = (size_t)P.sk_rl_row[j];
+        const double u0 = P.uv3[3 * row], u1 = P.uv3[3 * row + 1], u2 = P.uv3[3 * row + 2];
+        P.wv[3 * row] += a[0]; P.wv[3 * row + 1] += a[1]; P.wv[3 * row + 2] += a[2];
+        part[0] = u0 * a[0] + u1 * a[1] + u2 * a[2];
+        part[1] = u0 * c[0] + u1 * c[1] + u2 * c[2];
+    }
+    block_sum<2>(part, lds, tid & 63, tid >> 6);
+    if (tid == 0) { P.sk_rpart[2 * (size_t)blockIdx.x] = part[0]; P.sk_rpart[2 * (size_t)blockIdx.x + 1] = part[1]; }
 }
 
 }  // namespace nrs

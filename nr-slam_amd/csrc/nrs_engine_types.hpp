@@ -7,6 +7,9 @@ namespace nrs {
 constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj workgroup
 constexpr int BLK = 256;             // threads per workgroup everywhere
 constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel: [0..2] dots, [3..8] pose sums
+constexpr int SK_MAX = 11;           // embedded mode (nrs_engine_skin.hpp): nodes per skinned observation (the walk of OPT:255-279 accepts 11)
+constexpr int SK_RL = 8;             // ... lanes per node-row list of the PCG form, lists per workgroup
+constexpr int SK_RPB = BLK / SK_RL;
 constexpr int CO_MAX = 84;           // largest coarse system of the two-level preconditioner (fits one workgroup's LDS)
 constexpr int CO_GMAX = (CO_MAX - 6) / 3;   // row groups of the coarse level
 static_assert(CO_GMAX <= 32, "k_coarse_tile keeps the reached groups in a 32-bit mask");
@@ -173,6 +176,18 @@ struct Dev {
     double* sk_part;                 // sk_nblk x 32: H_pp (21), b_p (6), chi2 partials of the observations' workgroups
     double* sk_chi;                  // sk_n: r^T Omega r at the evaluated state (the drivers' inlier classification)
     double* sk_maxdiag;              // largest diagonal entry of the blocks the observations add to (joins SC_MAXDIAG)
+    // embedded BA windows (N2b: K poses, PCG path -- k_skin_rows / k_skin_pose / k_skin_op / k_skin_op_rows).  Observations are grouped by
+    // pose, every pose's padded to BLK slots (a workgroup of k_skin / k_skin_op serves ONE pose); per node row the observations that
+    // reach it in slot order with their weights (fixed-order gathers: no atomics on values, bit-reproducible)
+    int sk_pcg;                      // 1: the observations act through the PCG operator (not through the direct solver's blocks)
+    const int* sk_blk_pose;          // sk_nblk: pose of a block's observations (null: pose 0 -- the single-frame engines)
+    const int* sk_pose_blk;          // K + 1: block range of every pose
+    const double* sk_base;           // BA form: a skinned point sits at X0 + sum om (x - x_start), x_start = xl_init (null: X0 + sum om x)
+    int sk_nrl;                      // node rows with a list
+    const int* sk_rl_row; const int* sk_rl_ptr; const int* sk_rl_obs; const double* sk_rl_om;   // list j: row, entries [ptr[j], ptr[j+1]): observation slot, weight
+    double* sk_g;                    // sk_n x 6: per observation A s + B^T u_p (3) and B^T u_p alone (3) of the current PCG direction u
+    double* sk_opart;                // sk_nblk x 8: sum over a block's observations of B s (what they add to the pose rows of H u)
+    double* sk_rpart;                // ceil(sk_nrl / 32) x 2: what the row pass adds to w.u and to the cross term u_l.(H_lp u_p)
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 
@@ -209,8 +224,9 @@ struct Engine {
     std::vector<uint2> h_d_hdr;
     std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
+    std::vector<int> sk_slot;        // embedded BA windows: observation (caller order) -> slot (pose-grouped, padded)
     std::vector<int> sk_vert;        // embedded mode: the skinned observations' node vertices (n_skin x 11, -1 pads) and weights
-    std::vector<double> sk_om;
+    std::vector<double> sk_om, sk_X0;
     unsigned long long serial = 0;   // identifies this engine to the context's tap buffer (nrs_ctx::tap)
     // device-packed engines (nrs_engine_devpack.hpp) keep no host copies of the edges: the taps read the raw device copies
     bool dev_edges = false;

@@ -187,6 +187,109 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
     return NRS_OK;
 }
 
+// ---- N2b: the embedded form of the window (include/nrs.h).  Vertices = the keyframe copies of the NODES; the walks of OPT:1033-1136
+// run between node copies only (an observed point that is not a node is passed over like one the keyframe does not observe), and
+// every other observed point is bound, by the same walk, to the <= 11 node copies of its keyframe it accepts, with the connection
+// weights normalised (float32 weights widened, summed and divided in float64, in walk order).  oracle/embedded_oracle.py
+// dba_build_embedded states it; with every point a node the lists are nrs_dba_build_edges', index for index.
+extern "C" int nrs_dba_build_edges_embedded(int32_t n_kf, const int32_t* kf_rowptr, const int32_t* kf_pt, int32_t n_points, const uint8_t* is_node,
+                                            const int32_t* nbr_rowptr, const int32_t* nbr_col, const float* nbr_w, const float* nbr_d0, const int32_t* nbr_status,
+                                            int32_t* n_lm, int32_t* lm_obs, int32_t* n_spring, int32_t* sp_ij, float* sp_d0,
+                                            int32_t* n_damper, int32_t* dm_idx, float* dm_w,
+                                            int32_t* n_skin, int32_t* sk_obs, int32_t* sk_node, double* sk_omega) {
+    if (n_kf < 0 || n_points < 0 || !kf_rowptr || !nbr_rowptr || !is_node || !n_lm || !n_spring || !n_damper || !n_skin) return NRS_ERR_INVALID;
+    if (n_kf > 0 && kf_rowptr[n_kf] > 0 && !kf_pt) return NRS_ERR_INVALID;
+    if (n_points > 0 && nbr_rowptr[n_points] > 0 && (!nbr_col || !nbr_w || !nbr_d0 || !nbr_status)) return NRS_ERR_INVALID;
+    const bool fill = lm_obs != nullptr;
+    if (fill && (!sp_ij || !sp_d0 || !dm_idx || !dm_w || !sk_obs || !sk_node || !sk_omega)) return NRS_ERR_INVALID;
+    const int64_t cap_l = *n_lm, cap_s = *n_spring, cap_d = *n_damper, cap_k = *n_skin;
+    for (int32_t i = 0; i < kf_rowptr[n_kf]; ++i)
+        if (kf_pt[i] < 0 || kf_pt[i] >= n_points) return NRS_ERR_INVALID;
+    for (int32_t i = 0; i < (n_points > 0 ? nbr_rowptr[n_points] : 0); ++i)
+        if (nbr_col[i] < 0 || nbr_col[i] >= n_points) return NRS_ERR_INVALID;
+    // node copies are numbered keyframe by keyframe in observation order: first offsets per keyframe
+    std::vector<int32_t> first((size_t)n_kf + 1, 0);
+    for (int k = 0; k < n_kf; ++k) {
+        int32_t m = 0;
+        for (int32_t i = kf_rowptr[k]; i < kf_rowptr[k + 1]; ++i) m += is_node[kf_pt[i]] ? 1 : 0;
+        first[k + 1] = first[k] + m;
+    }
+    std::vector<int32_t> cur(n_points, -1), nxt(n_points, -1);
+    auto load = [&](std::vector<int32_t>& row, int kk) {
+        int32_t l = first[kk];
+        for (int32_t i = kf_rowptr[kk]; i < kf_rowptr[kk + 1]; ++i) if (is_node[kf_pt[i]]) row[kf_pt[i]] = l++;
+    };
+    auto clear = [&](std::vector<int32_t>& row, int kk) {
+        for (int32_t i = kf_rowptr[kk]; i < kf_rowptr[kk + 1]; ++i) row[kf_pt[i]] = -1;
+    };
+    PairSet spring_seen, damper_seen;
+    int64_t nl = 0, ns = 0, nd = 0, nk = 0;
+    bool overflow = false;
+    for (int k = 0; k < n_kf; ++k) {
+        const bool has_next = k + 1 < n_kf;
+        load(cur, k);
+        if (has_next) load(nxt, k + 1);
+        spring_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        damper_seen.reset((std::size_t)(kf_rowptr[k + 1] - kf_rowptr[k]) * 12);
+        for (int32_t ob = kf_rowptr[k]; ob < kf_rowptr[k + 1]; ++ob) {
+            const int32_t p = kf_pt[ob];
+            const int32_t lo = nbr_rowptr[p], hi = nbr_rowptr[p + 1];
+            if (!is_node[p]) {                                                       // a skinned observation: its walk accepts node copies
+                int n_reg = 0;
+                int32_t nodes[11];
+                double w[11], tot = 0.0;
+                for (int32_t e = lo; e < hi; ++e) {
+                    if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
+                    const int32_t o = nbr_col[e];
+                    if (cur[o] < 0) continue;
+                    nodes[n_reg] = cur[o]; w[n_reg] = (double)nbr_w[e];
+                    ++n_reg;
+                }
+                if (n_reg == 0) continue;                                            // (no node copy within reach: the observation constrains nothing)
+                for (int q = 0; q < n_reg; ++q) tot += w[q];
+                if (fill && nk >= cap_k) overflow = true;
+                else if (fill) {
+                    sk_obs[nk] = ob;
+                    for (int q = 0; q < 11; ++q) { sk_node[11 * nk + q] = q < n_reg ? nodes[q] : -1; sk_omega[11 * nk + q] = q < n_reg ? w[q] / tot : 0.0; }
+                }
+                ++nk;
+                continue;
+            }
+            const int32_t l = cur[p];
+            if (fill && nl >= cap_l) overflow = true; else if (fill) lm_obs[nl] = ob;
+            ++nl;
+            int n_reg = 0;
+            for (int32_t e = lo; e < hi; ++e) {                                     // OPT:1033-1074 between node copies
+                if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
+                const int32_t o = nbr_col[e];
+                if (cur[o] < 0) continue;
+                if (!spring_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
+                if (fill && ns >= cap_s) overflow = true;
+                else if (fill) { sp_ij[2 * ns] = l; sp_ij[2 * ns + 1] = cur[o]; sp_d0[ns] = nbr_d0[e]; }
+                ++ns; ++n_reg;
+            }
+            if (has_next && nxt[p] >= 0) {                                           // OPT:1076-1136
+                const int32_t ln = nxt[p];
+                n_reg = 0;
+                for (int32_t e = lo; e < hi; ++e) {
+                    if (n_reg > kRegularizersPerPoint || nbr_status[e] == NRS_GRAPH_BAD) break;
+                    const int32_t o = nbr_col[e];
+                    if (cur[o] < 0 || nxt[o] < 0) continue;
+                    if (!damper_seen.insert(pair_key(p, o))) { ++n_reg; continue; }
+                    if (fill && nd >= cap_d) overflow = true;
+                    else if (fill) { dm_idx[4 * nd] = l; dm_idx[4 * nd + 1] = cur[o]; dm_idx[4 * nd + 2] = ln; dm_idx[4 * nd + 3] = nxt[o]; dm_w[nd] = nbr_w[e]; }
+                    ++nd; ++n_reg;
+                }
+            }
+        }
+        clear(cur, k);
+        if (has_next) clear(nxt, k + 1);
+    }
+    if (overflow || nl > INT32_MAX || ns > INT32_MAX || nd > INT32_MAX || nk > INT32_MAX) return NRS_ERR_INVALID;
+    *n_lm = (int32_t)nl; *n_spring = (int32_t)ns; *n_damper = (int32_t)nd; *n_skin = (int32_t)nk;
+    return NRS_OK;
+}
+
 // ---- N1 (include/nrs.h nrs_debug_nd_solve): helpers of the nested-dissection plan shared with the engine
 #include "nrs_nd_plan.hpp"
 

@@ -19,7 +19,7 @@ COMM_ID_BYTES = 128
 # every symbol include/nrs.h declares (tests check that the library exports all of them)
 SYMBOLS = ["nrs_create", "nrs_options_init", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
-           "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_reset", "nrs_dba_optimize",
+           "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_build_edges_embedded", "nrs_dba_upload_embedded", "nrs_dba_download_skinned", "nrs_dba_solve_embedded", "nrs_dba_reset", "nrs_dba_optimize",
            "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
@@ -218,6 +218,36 @@ def dba_build_edges(kf_points, graph, lib=None):
     if rc != OK:
         raise NrsError(rc, "nrs_dba_build_edges (fill)")
     return dict(sp_ij=sp_ij, sp_d0=sp_d0, dm_idx=dm_idx, dm_w=dm_w)
+
+
+def dba_build_edges_embedded(kf_points, is_node, graph, lib=None):
+    """Host-side edge construction of the EMBEDDED window (include/nrs.h nrs_dba_build_edges_embedded, N2b): node copies, springs /
+    dampers between them, skinned observations with their node copies and normalised weights."""
+    lib = lib or load_library()
+    n_kf = len(kf_points)
+    kf_rowptr = np.zeros(n_kf + 1, np.int32)
+    kf_rowptr[1:] = np.cumsum([len(k) for k in kf_points])
+    kf_pt = _i32(np.concatenate(kf_points)) if n_kf else np.zeros(0, np.int32)
+    n_points = len(graph["rowptr"]) - 1
+    node = np.ascontiguousarray(is_node, np.uint8)
+    assert len(node) == n_points
+    rp, col, w, d0, st = (_i32(graph["rowptr"]), _i32(graph["col"]), _f32(graph["w"]), _f32(graph["d0"]), _i32(graph["status"]))
+    nl, ns, nd, nk = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    args = [C.c_int32(n_kf), _p(kf_rowptr, C.c_int32), _p(kf_pt, C.c_int32), C.c_int32(n_points), _p(node, C.c_uint8),
+            _p(rp, C.c_int32), _p(col, C.c_int32), _p(w, C.c_float), _p(d0, C.c_float), _p(st, C.c_int32)]
+    rc = lib.nrs_dba_build_edges_embedded(*args, C.byref(nl), None, C.byref(ns), None, None, C.byref(nd), None, None, C.byref(nk), None, None, None)
+    if rc != OK:
+        raise NrsError(rc, "nrs_dba_build_edges_embedded (count)")
+    lm_obs = np.zeros(nl.value, np.int32)
+    sp_ij, sp_d0 = np.zeros((ns.value, 2), np.int32), np.zeros(ns.value, np.float32)
+    dm_idx, dm_w = np.zeros((nd.value, 4), np.int32), np.zeros(nd.value, np.float32)
+    sk_obs, sk_node, sk_omega = np.zeros(nk.value, np.int32), np.zeros((nk.value, 11), np.int32), np.zeros((nk.value, 11), np.float64)
+    rc = lib.nrs_dba_build_edges_embedded(*args, C.byref(nl), _p(lm_obs, C.c_int32), C.byref(ns), _p(sp_ij, C.c_int32), _p(sp_d0, C.c_float),
+                                          C.byref(nd), _p(dm_idx, C.c_int32), _p(dm_w, C.c_float), C.byref(nk), _p(sk_obs, C.c_int32),
+                                          _p(sk_node, C.c_int32), _p(sk_omega, C.c_double))
+    if rc != OK:
+        raise NrsError(rc, "nrs_dba_build_edges_embedded (fill)")
+    return dict(lm_obs=lm_obs, sp_ij=sp_ij, sp_d0=sp_d0, dm_idx=dm_idx, dm_w=dm_w, sk_obs=sk_obs, sk_node=sk_node, sk_omega=sk_omega)
 
 
 class RGraph:
@@ -593,6 +623,32 @@ class Context:
         self._n_kf, self._n_lm = len(self._keep[0]), len(self._keep[1])
         self._n_sp, self._n_dm = len(self._keep[4]), len(self._keep[6])
         self._chk(self.lib.nrs_dba_upload(*args))
+
+    # ---- N2b: the embedded window (nrs_dba_*_embedded): w = nrs_synth.embedded_window(p, e), e = dba_build_edges_embedded(...)
+    def _dba_args_embedded(self, cam, poses_qt, w, e, scale):
+        args = self._dba_args(cam, poses_qt, w["lm_xyz"], w["lm_kf"], w["lm_uv"], e, scale)
+        self._keep_sk = (_i32(w["sk_kf"]), _f32(w["sk_uv"]).reshape(-1, 2), np.array(w["sk_xyz"], np.float32).reshape(-1, 3).copy(),
+                         _i32(e["sk_node"]).reshape(-1, 11), np.ascontiguousarray(e["sk_omega"], np.float64).reshape(-1, 11))
+        kf, uv, xyz, node, om = self._keep_sk
+        self._n_skin = len(kf)
+        return args[:-1] + [C.c_int32(len(kf)), _p(kf, C.c_int32), _p(uv, C.c_float), _p(xyz, C.c_float), _p(node, C.c_int32), _p(om, C.c_double), args[-1]]
+
+    def dba_upload_embedded(self, cam, poses_qt, w, e, scale):
+        args = self._dba_args_embedded(cam, poses_qt, w, e, scale)
+        self._n_kf, self._n_lm = len(self._keep[0]), len(self._keep[1])
+        self._n_sp, self._n_dm = len(self._keep[4]), len(self._keep[6])
+        self._chk(self.lib.nrs_dba_upload_embedded(*args))
+
+    def dba_download_skinned(self):
+        xyz = np.zeros((self._n_skin, 3), np.float64)
+        self._chk(self.lib.nrs_dba_download_skinned(self.h, _p(xyz, C.c_double)))
+        return xyz
+
+    def dba_solve_embedded(self, cam, poses_qt, w, e, scale, iters=5, trace=None):
+        """one shot; returns (poses_qt, node copies fp32, skinned points fp32)"""
+        args = self._dba_args_embedded(cam, np.array(poses_qt, np.float64), dict(w, lm_xyz=np.array(w["lm_xyz"], np.float32)), e, scale)
+        self._chk(self.lib.nrs_dba_solve_embedded(*args, C.c_int32(iters), C.byref(trace.c) if trace else None))
+        return self._keep[0].copy(), self._keep[1].copy(), self._keep_sk[2].copy()
 
     def dba_reset(self):
         self._chk(self.lib.nrs_dba_reset(self.h))

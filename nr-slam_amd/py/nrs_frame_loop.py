@@ -82,9 +82,13 @@ def project_f32(model, prm, p):
 class GpuBackend:
     """The product path: two nrs contexts (each owns one LucasKanadeTracker state)."""
 
-    def __init__(self, nrs, model, prm, klt_opts, dense_graph=False, cap_per_point=64, direct_solve=0):
+    def __init__(self, nrs, model, prm, klt_opts, dense_graph=False, cap_per_point=64, direct_solve=0, n_nodes=0):
+        """n_nodes > 0: EMBEDDED-DEFORMATION mode (include/nrs.h nrs_track_deform_solve_embedded; needs the dense graph): n_nodes map points
+        (farthest-point sampling on the initial map, nrs_skin_select_nodes) carry the deformation vertices for the whole sequence, every
+        other tracked point is skinned to <= 11 of them in the pose-and-deformation solve of each frame (tracking.cc:321-333's call)"""
         self.nrs = nrs
-        self.dense, self.cap, self.rg = dense_graph, cap_per_point, None
+        self.dense, self.cap, self.rg = dense_graph or n_nodes > 0, cap_per_point, None
+        self.n_nodes, self.node_flag = n_nodes, None
         self.cam = nrs.make_camera(model, prm)
         self.ctx = nrs.Context(direct_solve=direct_solve)      # (nrs_options.direct_solve: the linear solver of the pose-and-deformation solve)
         self.ctx_reuse = nrs.Context()
@@ -130,10 +134,19 @@ class GpuBackend:
         ids = np.arange(len(X0), dtype=np.int32)
         self.rg = self.nrs.RGraph(self.ctx, len(X0), graph["sigma"], graph["stretch_th"])
         self.rg.add_edges(np.asarray(X0, F32), ids, ids)
+        if self.n_nodes > 0:                                       # the node set of the sequence: fixed map points
+            nodes = self.ctx.skin_select_nodes(np.asarray(X0, F32), min(self.n_nodes, len(X0)), np.ones(len(X0), bool))
+            self.node_flag = np.zeros(len(X0), np.uint8)
+            self.node_flag[nodes] = 1
         return self.rg
 
     def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
         self.last_trace = self.nrs.Trace(1024)
+        if self.node_flag is not None:
+            r = self.ctx.track_deform_solve_embedded(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, self.node_flag[np.asarray(f_map)], q, t, scale,
+                                                     self.last_trace, max(self.cap, 128))
+            r["graph"] = graph
+            return r
         if self.dense:
             r = self.ctx.track_deform_solve_rg(self.cam, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale, self.last_trace, self.cap)
             r["graph"] = graph                                     # updated in place on the device

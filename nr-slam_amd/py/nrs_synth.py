@@ -520,6 +520,42 @@ def pick_nodes(points_xyz, n_nodes, start=0):
     return flag
 
 
+def node_lists(X, sigma, flag, k=24):
+    """Ordered neighbour lists for the EMBEDDED windows: per map point the k nearest NODES (itself excluded) whose weight reaches
+    min_weight, by (weight desc, index asc), status NEUTRAL -- the prefix a GetEdges list of the reference's all-pairs graph
+    (map.cc:148-166, regularization_graph.cc:61-87) shows once everything but the nodes is passed over; the walks of the embedded
+    mode accept <= 11 of them.  Same wire form as ordered_view()."""
+    X = np.asarray(X, F32)
+    sigma = F32(sigma)
+    nodes = np.where(np.asarray(flag) != 0)[0]
+    min_w = _weight(F32(float(sigma) * 1.5), sigma)
+    kk = min(k + 1, len(nodes))
+    tree = cKDTree(X[nodes].astype(np.float64))
+    _, nn = tree.query(X.astype(np.float64), k=kk)
+    nn = nn.reshape(len(X), kk)
+    rowptr = np.zeros(len(X) + 1, np.int32)
+    col, w, d0 = [], [], []
+    for p in range(len(X)):
+        c = nodes[nn[p]]
+        c = c[c != p]
+        rel = X[c] - X[p]
+        d = np.sqrt((rel[:, 0] * rel[:, 0] + rel[:, 1] * rel[:, 1] + rel[:, 2] * rel[:, 2]).astype(F32)).astype(F32)
+        ww = _weight(d, sigma)
+        keep = ww >= min_w
+        c, d, ww = c[keep], d[keep], ww[keep]
+        o = np.lexsort((c, -ww.astype(np.float64)))
+        col.append(c[o]); w.append(ww[o]); d0.append(d[o])
+        rowptr[p + 1] = rowptr[p] + len(o)
+    col = np.concatenate(col).astype(np.int32)
+    return dict(rowptr=rowptr, col=col, w=np.concatenate(w).astype(F32), d0=np.concatenate(d0).astype(F32), status=np.full(len(col), GRAPH_NEUTRAL, np.int32))
+
+
+def embedded_problem(p, n_nodes, k=24):
+    """node flags (farthest-point sampling on the rest shape) and the node lists of a window p (make_dba_problem)"""
+    flag = pick_nodes(p["scene"]["X0"], n_nodes)
+    return flag, node_lists(p["scene"]["X0"], p["scene"]["sigma"], flag, k)
+
+
 def embedded_window(p, e):
     """Inputs of nrs_dba_*_embedded from a plain window p (make_dba_problem) and the embedded edge lists e (dba_build_embedded /
     nrs_dba_build_edges_embedded: node copies lm_obs, skinned observations sk_obs as indices into the window's observations)."""

@@ -40,8 +40,11 @@ def _insert_template(lk, t):
 
 
 class OracleBackend:
-    def __init__(self, model, prm, klt_opts, dense_graph=False):
-        self.model, self.prm, self.o, self.dense = model, prm, klt_opts, dense_graph
+    def __init__(self, model, prm, klt_opts, dense_graph=False, n_nodes=0):
+        """n_nodes > 0: the embedded-deformation mode (embedded_oracle.track_deform_solve_embedded) on the dense graph, nodes chosen once on the
+        initial map by skin_oracle.select_nodes -- the twin of nrs_frame_loop.GpuBackend(n_nodes=...)"""
+        self.model, self.prm, self.o, self.dense = model, prm, klt_opts, dense_graph or n_nodes > 0
+        self.n_nodes, self.node_flag = n_nodes, None
         self.lk = LK.LucasKanadeOracle(klt_opts["win"], klt_opts["max_level"], klt_opts["max_iters"], klt_opts["epsilon"], klt_opts["min_eig"])
 
     def klt_set_reference(self, im, pts):
@@ -81,9 +84,16 @@ class OracleBackend:
         g = RG.DenseGraph(len(X0), graph["sigma"], graph["stretch_th"])
         ids = np.arange(len(X0))
         g.add_edges(np.asarray(X0, F32), ids, ids)
+        if self.n_nodes > 0:
+            import skin_oracle as K
+            self.node_flag = np.zeros(len(X0), np.uint8)
+            self.node_flag[K.select_nodes(np.asarray(X0, F32), min(self.n_nodes, len(X0)))] = 1
         return g
 
     def track_deform(self, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale):
+        if self.node_flag is not None:
+            import embedded_oracle as E
+            return E.track_deform_solve_embedded(self.model, self.prm, graph, map_pos, f_map, f_status, f_uv, f_pos, self.node_flag[np.asarray(f_map)], q, t, scale)
         return O.track_deform_solve(self.model, self.prm, graph, map_pos, f_map, f_status, f_uv, f_pos, q, t, scale)
 
     def close(self):

@@ -1,0 +1,117 @@
+"""GPU parity: N2b, the EMBEDDED form of LocalDeformableBundleAdjustment (BASELINE configs[1] as written: points x graph nodes x
+keyframes) through the C ABI (nrs_dba_*_embedded) against oracle/embedded_oracle.py dba_solve_embedded.
+
+The reference has no such estimator; the mode has one pin: with every point a node the window IS the plain one (same lists --
+tests/test_host_cpu.py -- and the same bits out of the solve, here), and the oracle is nrs_oracle.dba_solve bit for bit
+(tests/test_oracle_embedded_cpu.py).  Beyond M = N ("parity unpinned") the GPU is held to that oracle at the a3 tolerances
+(tests/test_gpu_dba.py): gradient / Hessian diagonal 1e-6 relative, per-trial chi2 1e-6 relative, identical accept / reject
+sequence, rotation 1e-6, translation 1e-5, node copies and skinned points 1e-4 map units."""
+import numpy as np
+import pytest
+
+import embedded_oracle as E
+import nrs
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, k, m, seed, model=S.PINHOLE):
+    p = S.make_dba_problem(n, k, seed, model)
+    flag, nb = S.embedded_problem(p, m)
+    p["nbr_nodes"] = nb
+    e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
+    w = S.embedded_window(p, e)
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    return p, e, w, cam, qt
+
+
+def _oracle(p, e, w, iters=5, trace=None):
+    return E.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], iters, trace)
+
+
+def test_every_point_a_node_is_the_plain_window_bit_for_bit(ctx):
+    p, e, w, cam, qt = _setup(300, 4, 300, 51)
+    assert len(e["sk_obs"]) == 0
+    ta, tb = nrs.Trace(), nrs.Trace()
+    pa, xa, _ = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, ta)
+    pb, xb = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], nrs.dba_build_edges(p["kf_points"], p["nbr_nodes"]), p["scale"], 5, tb)
+    assert np.array_equal(pa, pb) and np.array_equal(xa, xb)
+    assert [(t["accepted"], t["chi"], t["chi_new"], t["lam"]) for t in ta.trials] == [(t["accepted"], t["chi"], t["chi_new"], t["lam"]) for t in tb.trials]
+
+
+@pytest.mark.parametrize("model", [S.PINHOLE, S.KB8])
+def test_gradient_and_diagonal_include_the_skinned_observations(ctx, model):
+    p, e, w, cam, qt = _setup(300, 4, 40, 52, model)
+    ctx.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    b, d = ctx.dba_gradient()
+    G, skn = E.dba_graph_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                  e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"])
+    G.initialize(0)
+    G.compute_active_errors()
+    H, bo = G.build_system()
+    assert np.max(np.abs(b - bo)) <= 1e-6 * np.max(np.abs(bo))
+    assert np.max(np.abs(d - H.diagonal())) <= 1e-6 * np.max(np.abs(H.diagonal()))
+    # (and they matter: without the skinned observations the gradient is another one)
+    G0, _ = E.dba_graph_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                 e["dm_idx"], e["dm_w"], w["sk_kf"][:0], w["sk_uv"][:0], w["sk_xyz"][:0], e["sk_node"][:0], e["sk_omega"][:0], p["scale"])
+    G0.initialize(0)
+    G0.compute_active_errors()
+    assert np.max(np.abs(G0.build_system()[1] - bo)) > 0.1 * np.max(np.abs(bo))
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("n,k,m,seed,model", [(300, 4, 40, 53, S.PINHOLE), (600, 6, 80, 54, S.PINHOLE), (400, 5, 60, 55, S.KB8)])
+def test_solve_matches_oracle(ctx, ctx_exact, n, k, m, seed, model, exact):
+    ctx = ctx_exact if exact else ctx
+    p, e, w, cam, qt = _setup(n, k, m, seed, model)
+    assert len(e["sk_obs"]) > 0.7 * len(p["lm_kf"])
+    tr = nrs.Trace()
+    pq, xyz, sk = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tr)
+    otr = []
+    oq, ot, opts, osk, nit = _oracle(p, e, w, 5, otr)
+    assert tr.iterations == nit
+    assert [t["accepted"] for t in tr.trials] == [t["accepted"] for t in otr]
+    for a, b in zip(tr.trials, otr):
+        assert (a["iter"], a["trial"]) == (b["iter"], b["trial"])
+        assert abs(a["lam"] - b["lam"]) <= 1e-6 * b["lam"]
+        assert abs(a["chi"] - b["chi"]) <= 1e-6 * b["chi"]
+        if a["early"]:
+            assert not exact and not a["accepted"] and not b["accepted"] and b["rho"] < -0.02
+        else:
+            assert abs(a["chi_new"] - b["chi_new"]) <= 1e-6 * b["chi_new"]
+    assert np.allclose(pq[:, :4], oq, atol=1e-6, rtol=0)
+    assert np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
+    assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
+    assert np.allclose(sk, osk, atol=1e-4, rtol=0)
+
+
+def test_resident_form_reset_and_determinism(ctx):
+    p, e, w, cam, qt = _setup(500, 5, 70, 56)
+    ctx.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    out = []
+    for _ in range(3):
+        ctx.dba_reset()
+        tr = nrs.Trace()
+        ctx.dba_optimize(5, tr)
+        pq, xyz = ctx.dba_download()
+        out.append((pq, xyz, ctx.dba_download_skinned(), [(t["accepted"], t["chi"], t["chi_new"], t["inner"]) for t in tr.trials]))
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
+    osk = _oracle(p, e, w)[3]
+    assert np.allclose(out[0][2], osk, atol=1e-4, rtol=0)
+
+
+def test_bad_inputs_are_rejected(ctx):
+    p, e, w, cam, qt = _setup(200, 3, 30, 57)
+    bad = dict(e, sk_node=e["sk_node"].copy())
+    bad["sk_node"][0, 0] = len(w["lm_kf"])                        # node copy out of range
+    with pytest.raises(nrs.NrsError):
+        ctx.dba_upload_embedded(cam, qt, w, bad, p["scale"])
+    bad = dict(e, sk_node=e["sk_node"].copy())
+    other = np.where(w["lm_kf"] != w["sk_kf"][0])[0][0]           # a node copy of another keyframe
+    bad["sk_node"][0, 0] = other
+    with pytest.raises(nrs.NrsError):
+        ctx.dba_upload_embedded(cam, qt, w, bad, p["scale"])

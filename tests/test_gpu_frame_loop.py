@@ -53,3 +53,32 @@ def test_frame_loop_matches_oracle_loop(n, frames, seed, model, dense):
     pc = FL.se3f_act((last["pose_q"], last["pose_t"]), last["pos_by_map"][ok])
     uv = FL.project_f32(sq["model"], sq["prm"], pc)
     assert np.median(np.linalg.norm(uv - sq["uv_true"][frames - 1][ok], axis=1)) < 1.0
+
+
+def test_frame_loop_in_the_embedded_mode_matches_the_oracle_loop():
+    """the same loop with the pose-and-deformation solve of every frame in the embedded-deformation mode (40 of 260 map points carry the
+    vertices for the whole sequence, everything else is skinned: include/nrs.h nrs_track_deform_solve_embedded), device against
+    oracle/embedded_oracle.py behind the same harness"""
+    n, frames, m = 260, 5, 40
+    sq = S.make_frame_sequence(n, frames, 19, S.PINHOLE)
+    gb = FL.GpuBackend(nrs, sq["model"], sq["prm"], OPTS, n_nodes=m)
+    try:
+        glog = _run(gb, sq, frames, 2)
+        assert gb.node_flag.sum() == m
+    finally:
+        gb.close()
+    ob = OracleBackend(sq["model"], sq["prm"], OPTS, n_nodes=m)
+    olog = _run(ob, sq, frames, 2)
+    assert np.array_equal(ob.node_flag, gb.node_flag)
+    for f, (g, o) in enumerate(zip(glog, olog), 1):
+        assert np.allclose(g["pose_q"], o["pose_q"], atol=2e-6, rtol=0), f
+        assert np.allclose(g["pose_t"], o["pose_t"], atol=2e-5, rtol=0), f
+        assert g["lost"] == o["lost"] and g["reused"] == o["reused"] and g["keyframe"] == o["keyframe"], f
+        assert np.array_equal(g["status_by_map"], o["status_by_map"]), f
+        assert np.allclose(g["pos_by_map"], o["pos_by_map"], atol=2e-4, rtol=0), f
+        assert g["n_tracked"] == o["n_tracked"] and g["n_tracked"] > 0.8 * sq["n_points"]
+    last = glog[-1]
+    ok = last["status_by_map"] == FL.TRACKED_WITH_3D
+    pc = FL.se3f_act((last["pose_q"], last["pose_t"]), last["pos_by_map"][ok])
+    uv = FL.project_f32(sq["model"], sq["prm"], pc)
+    assert np.median(np.linalg.norm(uv - sq["uv_true"][frames - 1][ok], axis=1)) < 1.5

@@ -103,3 +103,60 @@ def test_plan_cache_reuse_is_invisible():
         assert np.array_equal(a0[k], n0[k]), k
     assert np.allclose(b0["pose_t"], nb["pose_t"], atol=1e-5, rtol=0) and np.allclose(b0["f_pos"], nb["f_pos"], atol=1e-4, rtol=0)
     assert np.array_equal(b0["f_status"], nb["f_status"])
+
+
+def test_chained_and_per_level_factorisation_give_the_same_bits(ctx, monkeypatch):
+    """One launch for all levels (fronts waiting for their children's tiles on agent-scope counters: taken when every workgroup of the
+    factorisation is resident at once, <= the device's CU count) against one launch per level (NRS_ND_LEVELS=1): the same arithmetic in
+    the same order, hence the same bits -- on systems small enough for the chained form (40 / 120 nodes) and on one that is not (1200)."""
+    for n, seed in ((40, 21), (120, 22), (1200, 23)):
+        pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, True)
+        monkeypatch.delenv("NRS_ND_LEVELS", raising=False)
+        ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.setenv("NRS_ND_LEVELS", "1")
+        ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.delenv("NRS_ND_LEVELS", raising=False)
+        assert ok and ok2 and st == st2 and np.array_equal(x, x2), n
+
+
+def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypatch):
+    """nrs_options.direct_solve = 0 takes the direct solver up to 8000 free rows and the PCG beyond.  (i) With the window lowered
+    (NRS_ND_MAX_ROWS=300) a 600-point frame is handed over and still matches the oracle like every other a2 frame; (ii) a 10 000-point
+    frame (C5-sized single frame) runs on the PCG by default (inner iterations > 1) and agrees with the same frame forced onto the
+    direct solver (direct_solve = 1) within the a2 tolerances: same statuses and lost set, pose 1e-6 / 1e-5, positions 1e-4."""
+    import nrs
+    import nrs_oracle as O
+    import nrs_synth as S
+    from conftest import compare_lm_traces
+
+    def run(c, tp, tr):
+        cam = nrs.make_camera(tp["model"], tp["prm"])
+        fm = np.arange(len(tp["status"]), dtype=np.int32)
+        return c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
+
+    tp = S.make_tracking_problem(600, 61)
+    monkeypatch.setenv("NRS_ND_MAX_ROWS", "300")
+    c = nrs.Context()
+    try:
+        tr = nrs.Trace(1024)
+        r = run(c, tp, tr)
+    finally:
+        c.close()
+        monkeypatch.delenv("NRS_ND_MAX_ROWS", raising=False)
+    assert max(t["inner"] for t in tr.trials) > 1                   # PCG iterations: the direct solver reports 1 per trial
+    otr = []
+    o = O.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], np.arange(600), tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"],
+                             tp["scale"], otr)
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0) and np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == o["lost"] and np.allclose(r["f_pos"], o["f_pos"], atol=1e-4, rtol=0)
+    assert compare_lm_traces(tr.trials, otr, len(otr)) >= 6
+    big = S.make_tracking_problem(10000, 62)
+    a, b = nrs.Context(), nrs.Context(direct_solve=1)
+    try:
+        ta, tb = nrs.Trace(1024), nrs.Trace(1024)
+        ra, rb = run(a, big, ta), run(b, big, tb)
+    finally:
+        a.close(); b.close()
+    assert (big["status"] == 0).sum() > 8000 and max(t["inner"] for t in ta.trials) > 1 and all(t["inner"] == 1 for t in tb.trials)
+    assert np.allclose(ra["pose_q"], rb["pose_q"], atol=1e-6, rtol=0) and np.allclose(ra["pose_t"], rb["pose_t"], atol=1e-5, rtol=0)
+    assert np.array_equal(ra["f_status"], rb["f_status"]) and ra["lost"] == rb["lost"] and np.allclose(ra["f_pos"], rb["f_pos"], atol=1e-4, rtol=0)

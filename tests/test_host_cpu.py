@@ -179,3 +179,21 @@ def test_skinned_status_demotes_everything_but_the_nodes():
     st = nrs.skinned_status(f_status, f_map, [2, 4])
     assert st.tolist() == [1, 0, 1, 1, 3, 0, 2, 0]
     assert f_status.tolist() == [0, 0, 0, 1, 3, 0, 2, 0]                      # the input is not modified
+
+
+def test_embedded_window_builder_matches_the_oracle(lib_built):
+    """nrs_dba_build_edges_embedded (N2b) against oracle/embedded_oracle.py dba_build_embedded: node copies, springs / dampers
+    between them, skinned observations with their node copies and normalised weights -- index for index, weights to the last bit;
+    with every point a node: the lists of nrs_dba_build_edges."""
+    import embedded_oracle as E
+    nrs = lib_built
+    for n, k, m, seed in ((300, 4, 40, 9), (500, 6, 77, 10), (200, 3, 200, 11)):
+        p = S.make_dba_problem(n, k, seed)
+        flag, nb = S.embedded_problem(p, m)
+        a = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
+        b = E.dba_build_embedded(p["kf_points"], flag, nb["rowptr"], nb["col"], nb["w"], nb["d0"], nb["status"])
+        for key in ("lm_obs", "sp_ij", "sp_d0", "dm_idx", "dm_w", "sk_obs", "sk_node", "sk_omega"):
+            assert np.array_equal(a[key], b[key]), key
+        if m == n:
+            e = nrs.dba_build_edges(p["kf_points"], nb)
+            assert len(a["sk_obs"]) == 0 and all(np.array_equal(a[key], e[key]) for key in ("sp_ij", "sp_d0", "dm_idx", "dm_w"))
