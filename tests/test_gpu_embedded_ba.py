@@ -115,3 +115,42 @@ def test_bad_inputs_are_rejected(ctx):
     bad["sk_node"][0, 0] = other
     with pytest.raises(nrs.NrsError):
         ctx.dba_upload_embedded(cam, qt, w, bad, p["scale"])
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, exact):
+    """BASELINE configs[1] as written -- 5k points x 500 nodes x 20 keyframes -- against tests/golden/dba_C2_embedded500_trace.npz: the
+    oracle's LM on the complete embedded window (tests/golden/make_embedded_ba_golden.py: 443 s in the build container, sparse LU per
+    trial), on the oracle's own lists (checksums in the fixture; the product's host builder must reproduce them).  Tolerances of the
+    small cases."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_embedded_ba_golden import skin_checksum
+    g = np.load(os.path.join(here, "golden", "dba_C2_embedded500_trace.npz"))
+    c = ctx_exact if exact else ctx
+    p = S.make_dba_problem("C2")
+    flag, nb = S.embedded_problem(p, int(g["n_nodes"]))
+    e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
+    assert (int(g["n_lm"]), int(g["n_skin"]), int(g["n_sp"]), int(g["n_dm"])) == (len(e["lm_obs"]), len(e["sk_obs"]), len(e["sp_ij"]), len(e["dm_idx"]))
+    assert int(g["edge_checksum"]) == S.edge_checksum(e) and int(g["skin_checksum"]) == skin_checksum(e)
+    w = S.embedded_window(p, e)
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    c.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    tr = nrs.Trace()
+    c.dba_optimize(5, tr)
+    pq, xyz = c.dba_download()
+    sk = c.dba_download_skinned()
+    t = tr.trials
+    assert tr.iterations == int(g["out_iters"])
+    assert [x["accepted"] for x in t] == g["out_accepted"].tolist()
+    for x, chi, chi_new, lam in zip(t, g["out_chi"], g["out_chi_new"], g["out_lam"]):
+        assert abs(x["lam"] - lam) <= 1e-6 * lam and abs(x["chi"] - chi) <= 1e-6 * chi
+        if not x["early"]:
+            assert abs(x["chi_new"] - chi_new) <= 1e-6 * chi_new
+    assert np.allclose(pq[:, :4], g["out_q"], atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], g["out_t"], atol=1e-5, rtol=0)
+    assert np.allclose(xyz[g["sel"]], g["out_pts_sel"], atol=1e-4, rtol=0) and np.allclose(sk[g["ssel"]], g["out_sk_sel"], atol=1e-4, rtol=0)
+    assert np.allclose(xyz.sum(0), g["out_pts_sum"], atol=1e-4 * np.sqrt(len(xyz)), rtol=0)
+    assert np.allclose(sk.sum(0), g["out_sk_sum"], atol=1e-4 * np.sqrt(len(sk)), rtol=0)
