@@ -518,6 +518,36 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     return out
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6        # dense fp64 matrix peak of MI355X (MI355X_MICROARCH.md: 32 flop / clk / SIMD x 1024 SIMDs x 2.4 GHz)
+
+
+def direct_solver_leg(sizes=(1013, 4446)):
+    """Roofline entry of the kernel pair that decides tracked fps: the nested-dissection multifrontal Cholesky of a2's system
+    (k_nd_level: one launch per tree level, k_nd_back: one launch), timed with HIP events over 50 back-to-back factorise + solve
+    sequences on a2-like block systems (nrs_synth.nd_block_system: kNN-11 couplings + the pose, the flat graph's structure) through
+    the tap nrs_debug_nd_solve.  It is a CRITICAL-PATH kernel, not a throughput one: `frac` of the fp64 matrix peak is reported
+    because the contract asks for it, the model that explains the time is levels x per-level latency."""
+    import nrs
+    import nrs_synth as S
+    ctx = nrs.Context()
+    out = {}
+    for n in sizes:
+        pos, last, pairs, Dn, Vp, bn = S.nd_block_system(n)
+        ok, x, st, ms = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1, repeats=50)
+        tf = st["flops"] / (ms * 1e-3) / 1e12
+        out["%d_points" % n] = dict(ok=bool(ok), plan_flops=int(st["flops"]), fronts=int(st["fronts"]), levels=int(st["levels"]), workgroups=int(st["workgroups"]),
+                                    largest_front=int(st["max_s"]), largest_boundary=int(st["max_b"]), us_per_factorise_and_solve=1e3 * ms,
+                                    achieved=tf, frac=tf / FP64_MFMA_PEAK_TFLOPS,
+                                    critical_path=dict(levels=int(st["levels"]), us_per_level_all_in=1e3 * ms / max(1, st["levels"]),
+                                                       note="one launch per level (a level's latency = one workgroup's panel factorisation of <= 96 columns + its Schur tile) "
+                                                            "+ one back-pass launch; the time is levels x latency, not flops / peak"))
+    ctx.close()
+    big = out["%d_points" % sizes[-1]]
+    return {"kernel": "k_nd_level + k_nd_back (multifrontal Cholesky of a2's system on the nested-dissection plan, fronts on v_mfma_f64_16x16x4)",
+            "bound": "mfma", "achieved": big["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": big["frac"], "traffic": None,
+            "workload": "a2-like block system, %d points + pose, kNN-11 couplings" % sizes[-1], "regime": "latency (critical path): see critical_path", "sizes": out}
+
+
 def hbm_regime_leg(device, workload="C4"):
     """The two roofline kernels on a window that does NOT fit the 256 MB Infinity Cache (C4: 50k points x 200 keyframes,
     ~14 GB resident): HIP events on the context's own stream around back-to-back full launches (nrs_options.profile), one
@@ -755,6 +785,7 @@ def main():
                                      "avg_us": lin_us, "algorithmic_bytes": lin_b, "launches": prof["linearize_launches"]}
         if not args.no_hbm_regime:
             out["roofline_hbm_regime"] = hbm_regime_leg(local_rank)
+        out["roofline_direct_solver"] = direct_solver_leg()
         out["oneshot"] = oneshot_leg(local_rank, p, e, cam, qt)
         # the reference's map graph connects every pair of map points (map.cc:148-166): that is the graph `tracked_fps` runs on,
         # resident on the device; the generator's kNN-16 flat graph (what round 1 measured) stays next to it

@@ -687,7 +687,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
     const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
     d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
-    if (s.n_skin > 0 && s.sk_pose) d.fused = 0;                    // embedded BA window: the skinned observations' operator kernels sit between the two launches of an iteration
+    if (s.n_skin > 0) d.fused = 0;                                 // embedded mode: the skinned observations' operator kernels sit between the two launches of an iteration
     d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
     // (a profiling context times full operator launches only: no convergence-detecting early exits)
     d.ecd = (d.use_lds && !d.fused && !c->opt.profile && !getenv("NRS_NO_ECD")) ? 1 : 0;
@@ -1044,16 +1044,23 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
-    if (s.n_skin > 0 && s.sk_pose) {
-        // ---- embedded BA window (N2b): K poses, the skinned observations act through the PCG operator (nrs_engine_skin.hpp).
-        // Slots: observations grouped by pose (caller order inside a pose), every pose's padded to BLK; per node row the list of the
-        // observations that reach it, in slot order.
-        if (d.fused || d.sh_on || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om) return c->fail(NRS_ERR_INVALID, "skinned observations of a BA window: two-kernel PCG path, one GPU");
+    if (s.n_skin > 0) {
+        // ---- embedded mode: the skinned observations (nrs_engine_skin.hpp; device arrays in a buffer of the context).  A BA window (N2b:
+        // sk_pose given, K poses) solves by the PCG with the observations applied as hyper-edges; a single-frame engine (N2a) by the direct
+        // solver when it takes the frame (k_nd_values folds them into its blocks) and by the same PCG form when it does not.
+        // Slots: observations grouped by pose (caller order inside a pose: K = 1 keeps the caller's order), every pose's padded to BLK;
+        // per node row the list of the observations that reach it, in slot order.
+        const bool ba_form = s.sk_pose != nullptr;
+        if (d.fused || d.sh_on || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om) return c->fail(NRS_ERR_INVALID, "skinned observations: two-kernel PCG path, one GPU");
+        if (!ba_form && !(arena == &c->arena_trk && s.K == 1)) return c->fail(NRS_ERR_INVALID, "skinned observations without a pose index: single-frame tracking engines only");
         const size_t n_in = (size_t)s.n_skin;
+        std::vector<int> pose0;
+        if (!ba_form) pose0.assign(n_in, 0);
+        const int* sk_pose = ba_form ? s.sk_pose : pose0.data();
         std::vector<int> cnt(s.K + 1, 0), pose_blk(s.K + 1, 0);
         for (size_t i = 0; i < n_in; ++i) {
-            if (s.sk_pose[i] < 0 || s.sk_pose[i] >= s.K) return c->fail(NRS_ERR_INVALID, "skinned observation: pose index out of range");
-            cnt[s.sk_pose[i] + 1]++;
+            if (sk_pose[i] < 0 || sk_pose[i] >= s.K) return c->fail(NRS_ERR_INVALID, "skinned observation: pose index out of range");
+            cnt[sk_pose[i] + 1]++;
         }
         for (int k = 0; k < s.K; ++k) pose_blk[k + 1] = pose_blk[k] + (cnt[k + 1] + BLK - 1) / BLK;
         const size_t nblk = (size_t)pose_blk[s.K], n = nblk * BLK;
@@ -1066,7 +1073,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         std::vector<uint8_t> act(n, 0);
         std::vector<int> rl_cnt(d.n_rows + 1, 0);
         for (size_t i = 0; i < n_in; ++i) {
-            const size_t sl = (size_t)next[s.sk_pose[i]]++;
+            const size_t sl = (size_t)next[sk_pose[i]]++;
             e->sk_slot[i] = (int)sl;
             uv[2 * sl] = s.sk_uv[2 * i]; uv[2 * sl + 1] = s.sk_uv[2 * i + 1];
             for (int k = 0; k < 3; ++k) X0[3 * sl + k] = s.sk_X0[3 * i + k];
@@ -1074,7 +1081,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             for (int k = 0; k < SK_MAX; ++k) {
                 const int v = s.sk_node[SK_MAX * i + k];
                 if (v < 0) continue;
-                if (s.lm_pose[v] != s.sk_pose[i]) return c->fail(NRS_ERR_INVALID, "skinned observation: a node copy of another keyframe");
+                if (s.lm_pose[v] != sk_pose[i]) return c->fail(NRS_ERR_INVALID, "skinned observation: a node copy of another keyframe");
                 rows[SK_MAX * sl + k] = e->vrow[v];
                 om[SK_MAX * sl + k] = s.sk_om[SK_MAX * i + k];
                 rl_cnt[e->vrow[v] + 1]++;
@@ -1099,8 +1106,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                      o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
                      o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
                      o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 6 * n), o_rpart = o_op + al(8 * 8 * nblk), total = o_rpart + al(8 * 2 * (nrlblk + 1));
-        NRS_TRY(c->ensure(c->dba_skin, total));
-        char* sb = c->dba_skin.as<char>();
+        DevBuf& buf = arena == &c->arena_trk ? c->nd_skin : c->dba_skin;
+        NRS_TRY(c->ensure(buf, total));
+        char* sb = buf.as<char>();
         auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(sb + off, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess; };
         NRS_HIP(c, up(o_uv, uv.data(), 8 * n)); NRS_HIP(c, up(o_X0, X0.data(), 24 * n)); NRS_HIP(c, up(o_row, rows.data(), 4 * SK_MAX * n));
         NRS_HIP(c, up(o_om, om.data(), 8 * SK_MAX * n)); NRS_HIP(c, up(o_act, act.data(), n)); NRS_HIP(c, up(o_bp, blk_pose.data(), 4 * nblk));
@@ -1108,7 +1116,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_HIP(c, up(o_ro, rl_obs.data(), 4 * n_ent)); NRS_HIP(c, up(o_rw, rl_om.data(), 8 * n_ent));
         NRS_HIP(c, hipMemsetAsync(sb + o_rec, 0, total - o_rec, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
-        d.sk_n = (int)n; d.sk_nblk = (int)nblk; d.sk_pcg = 1;
+        d.sk_n = (int)n; d.sk_nblk = (int)nblk; d.sk_pcg = 1;      // (a single-frame engine on the direct solver switches sk_pcg off below)
         d.sk_uv = reinterpret_cast<const float*>(sb + o_uv); d.sk_X0 = reinterpret_cast<const double*>(sb + o_X0);
         d.sk_row = reinterpret_cast<const int*>(sb + o_row); d.sk_om = reinterpret_cast<const double*>(sb + o_om);
         d.sk_active = reinterpret_cast<const uint8_t*>(sb + o_act);
@@ -1118,47 +1126,16 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
         d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
         d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_rpart = reinterpret_cast<double*>(sb + o_rpart);
-        d.sk_base = d.xl_init;
+        d.sk_base = ba_form ? d.xl_init : nullptr;                 // (tracking form: the rows ARE the deformations, X0 + sum om x)
         e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
         e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n_in);
         e->sk_X0.assign(s.sk_X0, s.sk_X0 + 3 * n_in);
-    } else
-    if (s.n_skin > 0) {                                // embedded mode: the skinned observations (device arrays in the context's buffer)
-        if (!(arena == &c->arena_trk && s.K == 1) || !s.sk_uv || !s.sk_X0 || !s.sk_node || !s.sk_om)
-            return c->fail(NRS_ERR_INVALID, "skinned observations: single-frame tracking engines only");
-        const size_t n = (size_t)s.n_skin, nblk = (n + BLK - 1) / BLK;
-        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t o_uv = 0, o_X0 = o_uv + al(8 * n), o_row = o_X0 + al(24 * n), o_om = o_row + al(4 * SK_MAX * n), o_act = o_om + al(8 * SK_MAX * n),
-                     o_rec = o_act + al(n), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk), o_md = o_chi + al(8 * n), total = o_md + 256;
-        NRS_TRY(c->ensure(c->nd_skin, total));
-        char* sb = c->nd_skin.as<char>();
-        e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n);
-        e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n);
-        std::vector<int> rows(SK_MAX * n);
-        for (size_t q = 0; q < rows.size(); ++q) {
-            if (e->sk_vert[q] >= s.M) return c->fail(NRS_ERR_INVALID, "skinned observation: node index out of range");
-            rows[q] = e->sk_vert[q] >= 0 ? e->vrow[e->sk_vert[q]] : -1;
-        }
-        std::vector<uint8_t> act(n, 1);
-        NRS_HIP(c, hipMemcpyAsync(sb + o_uv, s.sk_uv, 8 * n, hipMemcpyHostToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(sb + o_X0, s.sk_X0, 24 * n, hipMemcpyHostToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(sb + o_row, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(sb + o_om, s.sk_om, 8 * SK_MAX * n, hipMemcpyHostToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(sb + o_act, act.data(), n, hipMemcpyHostToDevice, c->stream));
-        NRS_HIP(c, hipMemsetAsync(sb + o_rec, 0, total - o_rec, c->stream));
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
-        d.sk_n = s.n_skin; d.sk_nblk = (int)nblk;
-        d.sk_uv = reinterpret_cast<const float*>(sb + o_uv); d.sk_X0 = reinterpret_cast<const double*>(sb + o_X0);
-        d.sk_row = reinterpret_cast<const int*>(sb + o_row); d.sk_om = reinterpret_cast<const double*>(sb + o_om);
-        d.sk_active = reinterpret_cast<const uint8_t*>(sb + o_act);
-        d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
-        d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
     }
     if (e->nd) {                                                   // direct solve when the frame is small enough to gain from it
         NRS_TRY(nd_engine_finish(c, e, e->nd, nd_prep));
         mark("direct solve plan");
-        if (s.n_skin > 0 && !e->nd->on) return c->fail(NRS_ERR_STATE, "skinned observations need the direct solver (nrs_options.direct_solve = 2 or a problem it does not take)");
     }
+    d.sk_pcg = (d.sk_n > 0 && !(e->nd && e->nd->on)) ? 1 : 0;      // (on the direct solver k_nd_values folds the observations into its blocks)
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
     *out = e;
@@ -1190,7 +1167,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
         bool same = e->nd->sig.size() == (size_t)e->d.M + 1 && e->nd->sig[e->d.M] == e->h_pose_fixed[0];
         for (int v = 0; v < e->d.M && same; ++v) same = e->nd->sig[v] == (e->h_rflag[e->vrow[v]] & RF_FIXED);
         if (!same) NRS_TRY(nd_engine_setup(c, e, e->nd));
-        if (e->d.sk_n > 0 && !e->nd->on) return c->fail(NRS_ERR_STATE, "skinned observations need the direct solver");
+        e->d.sk_pcg = (e->d.sk_n > 0 && !e->nd->on) ? 1 : 0;
     }
     return NRS_OK;
 }
@@ -1210,7 +1187,9 @@ int engine_reset(nrs_ctx* c, Engine* e) {
 namespace nrs {
 int engine_skin_set_active(nrs_ctx* c, Engine* e, const uint8_t* active) {
     if (e->d.sk_n <= 0) return NRS_OK;
-    NRS_HIP(c, hipMemcpyAsync(const_cast<uint8_t*>(e->d.sk_active), active, (size_t)e->d.sk_n, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint8_t> act((size_t)e->d.sk_n, 0);                // (slots are pose-grouped and padded: padding stays inactive)
+    for (size_t i = 0; i < e->sk_slot.size(); ++i) act[e->sk_slot[i]] = active[i];
+    NRS_HIP(c, hipMemcpyAsync(const_cast<uint8_t*>(e->d.sk_active), act.data(), act.size(), hipMemcpyHostToDevice, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
@@ -1242,15 +1221,12 @@ int engine_skin_chi2(nrs_ctx* c, Engine* e, double* chi) {
     if (d.sk_n <= 0) return NRS_OK;
     hipLaunchKernelGGL((k_skin<false>), dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, d.pose[e->cur], d.xl[e->cur]);
     NRS_HIP(c, hipGetLastError());
-    if (d.sk_pcg) {                                                // (slots are pose-grouped and padded: back to the caller's order)
+    {                                                              // (slots are pose-grouped and padded: back to the caller's order)
         std::vector<double> h((size_t)d.sk_n);
         NRS_HIP(c, hipMemcpyAsync(h.data(), d.sk_chi, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
         for (size_t i = 0; i < e->sk_slot.size(); ++i) chi[i] = h[e->sk_slot[i]];
-        return NRS_OK;
     }
-    NRS_HIP(c, hipMemcpyAsync(chi, d.sk_chi, sizeof(double) * (size_t)d.sk_n, hipMemcpyDeviceToHost, c->stream));
-    NRS_HIP(c, hipStreamSynchronize(c->stream));
     return NRS_OK;
 }
 }  // namespace nrs

@@ -113,7 +113,7 @@ __device__ inline void sk_atomic_max(double* addr, double v) {     // v >= 0: th
 __global__ __launch_bounds__(BLK) void k_skin_rows(Dev P) {
     const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
     double D[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    const bool live = j < P.sk_nrl;
+    const bool live = j < P.sk_nrl && !(P.rflag[P.sk_rl_row[min(j, P.sk_nrl - 1)]] & RF_FIXED);   // (a fixed row is an identity row: nothing is added to it)
     if (live)
         for (int q = P.sk_rl_ptr[j] + t; q < P.sk_rl_ptr[j + 1]; q += SK_RL) {
             const double om = P.sk_rl_om[q];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BLK) void k_skin_op_rows(Dev P) {
     __shared__ double lds[4 * 2];
     const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
     double a[3] = {0, 0, 0}, c[3] = {0, 0, 0}, part[2] = {0, 0};
-    const bool live = j < P.sk_nrl && !P.flags[0];
+    const bool live = j < P.sk_nrl && !P.flags[0] && !(P.rflag[P.sk_rl_row[min(j, P.sk_nrl - 1)]] & RF_FIXED);
     if (live)
         for (int q = P.sk_rl_ptr[j] + t; q < P.sk_rl_ptr[j + 1]; q += SK_RL) {
             const double om = P.sk_rl_om[q];

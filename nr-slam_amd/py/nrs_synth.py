@@ -562,3 +562,29 @@ def embedded_window(p, e):
     lo, so = e["lm_obs"], e["sk_obs"]
     return dict(lm_xyz=p["lm_xyz"][lo], lm_kf=p["lm_kf"][lo], lm_uv=p["lm_uv"][lo],
                 sk_kf=p["lm_kf"][so], sk_uv=p["lm_uv"][so], sk_xyz=p["lm_xyz"][so])
+
+
+def nd_block_system(n, seed=3, knn=11):
+    """An SPD block system with the structure of a2's single-frame problem (input of nrs_debug_nd_solve): n points on a surface, 3 x 3
+    couplings to the knn nearest neighbours, two `last` blocks (the halves of the pose) coupled to every point, block-diagonally dominant.
+    Returns pos, last, pairs, Dn, Vp, bn (no dense copy: usable at 5k points)."""
+    rng = np.random.default_rng(seed)
+    pts = np.c_[rng.uniform(-20, 20, n), rng.uniform(-15, 15, n), 60 + rng.normal(0, 1, n)]
+    _, nn = cKDTree(pts[:, :2]).query(pts[:, :2], k=min(knn + 1, n))
+    a = np.repeat(np.arange(n), nn.shape[1] - 1)
+    b = nn[:, 1:].ravel()
+    pr = np.unique(np.stack([np.minimum(a, b), np.maximum(a, b)], 1), axis=0)
+    pr = pr[pr[:, 0] != pr[:, 1]]
+    pp = np.array([(n + h, i) if (i + h) % 2 else (i, n + h) for i in range(n) for h in range(2)] + [(n, n + 1)], np.int64)
+    pairs = np.r_[pr, pp].astype(np.int32)
+    N = n + 2
+    Vp = rng.normal(0, 1, (len(pairs), 3, 3)) * 0.3
+    rs = np.zeros((N, 3))
+    np.add.at(rs, pairs[:, 0], np.abs(Vp).sum(2))
+    np.add.at(rs, pairs[:, 1], np.abs(Vp).sum(1))
+    S_ = rng.normal(0, 0.2, (N, 3, 3))
+    Dn = np.einsum('nij,nkj->nik', S_, S_) + np.eye(3)[None] * (rs.max(1)[:, None, None] + 0.5)
+    pos = np.r_[pts, np.zeros((2, 3))]
+    last = np.zeros(N, np.uint8)
+    last[n:] = 1
+    return pos, last, pairs, Dn, Vp, rng.normal(0, 1, (N, 3))

@@ -3,6 +3,8 @@
 // the plan (child maps, entry lists, offsets) without a GPU (tests/test_nd_cpu.py) and is the yardstick of the device
 // kernels (tests/test_gpu_nd.py).  The algorithm it stands for on the reference side: LinearSolverEigen::solve
 // (third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-136), a sparse Cholesky of (H + lambda I).
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -92,7 +94,10 @@ extern "C" int nrs_cpu_nd_solve(int32_t n_nodes, const double* pos, const uint8_
                                 const double* Dn, const double* Vp, const double* bn, double lambda, double* x, int64_t* stats) {
     nrs::NdPlan P;
     std::string err;
-    if (n_nodes <= 0 || n_pairs < 0 || !nrs::nd_build_plan(n_nodes, pos, last, n_pairs, pairs, P, &err)) return -1;
+    if (n_nodes <= 0 || n_pairs < 0 || !nrs::nd_build_plan(n_nodes, pos, last, n_pairs, pairs, P, &err)) {
+        if (getenv("NRS_ND_ERR")) fprintf(stderr, "[nd_host] no plan: %s\n", err.c_str());
+        return -1;
+    }
     if (stats) {
         stats[0] = P.n_fronts; stats[1] = P.n_levels; stats[2] = P.max_s; stats[3] = P.max_b;
         stats[4] = (int64_t)P.L_doubles; stats[5] = (int64_t)P.U_doubles; stats[6] = (int64_t)P.flops; stats[7] = (int64_t)P.wg.size() / 3;

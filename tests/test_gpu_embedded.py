@@ -104,3 +104,28 @@ def test_reused_plan_takes_the_new_frames_skinning_weights():
     for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
         assert np.array_equal(b[k], fresh[k]), k
     assert b["lost"] == fresh["lost"] and b["median"] == fresh["median"]
+
+
+@pytest.mark.parametrize("n,m,seed,model", [(600, 80, 41, S.PINHOLE), (900, 120, 43, S.KB8)])
+def test_embedded_mode_on_the_pcg_matches_its_oracle(ctx_pcg, n, m, seed, model):
+    """nrs_options.direct_solve = 2 (or a frame beyond the direct solver's window): the embedded mode runs on the PCG, the skinned
+    observations applied as hyper-edges (k_skin_op / k_skin_op_rows, the operator form of the embedded BA window) -- same oracle,
+    same tolerances as on the direct solver."""
+    from conftest import compare_lm_traces
+    tp = S.make_tracking_problem(n, seed, model)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    g, D, ids = _graphs(ctx_pcg, tp, n)
+    nodes = ctx_pcg.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0)
+    node = np.zeros(n, np.uint8)
+    node[nodes] = 1
+    tr, otr = nrs.Trace(1024), []
+    r = ctx_pcg.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, 256)
+    o = E.track_deform_solve_embedded(tp["model"], tp["prm"], D, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"],
+                                      tp["scale"], otr)
+    assert max(t["inner"] for t in tr.trials) > 1                   # PCG iterations (the direct solver reports 1 per trial)
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0) and np.allclose(r["pose_t"], o["pose_t"], atol=1e-5, rtol=0)
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == o["lost"]
+    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-4, rtol=0) and np.allclose(r["map_pos"], o["map_pos"], atol=1e-4, rtol=0)
+    assert abs(r["median"] - o["median"]) < 1e-5
+    assert compare_lm_traces(tr.trials, otr, len(otr)) >= 6
+    g.close()
