@@ -44,7 +44,7 @@ struct nrs_ctx {
     nrs_profile prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for a1
-    nrs::DevBuf po_uv, po_X, po_err, po_level, po_out, po_trace;
+    nrs::DevBuf po_uv, po_X, po_err, po_level, po_out, po_trace, po_multi;   // (po_multi: state + partial slots of the multi-workgroup form)
     // resident BA problem (a3) and per-call tracking problems (a2): one reusable arena each
     nrs::Engine* dba = nullptr;
     nrs::Arena arena_dba, arena_trk;

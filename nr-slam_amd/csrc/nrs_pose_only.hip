@@ -8,6 +8,7 @@
 // loads that stay in L1/L2: 20 B/point), reduce with wave butterflies + LDS, and lane 0 runs
 // the LM control flow, the Cholesky of H+lambda*I and the SE(3) retraction.  No host round trips,
 // no inter-workgroup hand-offs; latency per trial is a few microseconds.
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -94,40 +95,192 @@ __device__ inline bool chol6_solve(const double* Hu /*21 upper, row-major packed
     return true;
 }
 
+// sums of 29 values over a 256-thread workgroup, totals to out[0..29): wave butterflies, then the four waves in order
+__device__ inline void block_sum_29(const double* v, double* lds /* 4 x 29 */, int tid, double* out) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 29; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) lds[wave * 29 + k] = s;
+    }
+    __syncthreads();
+    if (tid < 29) out[tid] = lds[tid] + lds[29 + tid] + lds[58 + tid] + lds[87 + tid];
+}
+
 enum { PH_EVAL = 0, PH_CLASSIFY = 1, PH_DONE = 2 };
+
+// State of the serial part: g2o's Levenberg-Marquardt control flow (optimization_algorithm_levenberg.cpp:57-174) and the three rounds of
+// OPT:103-141.  One thread runs it: in LDS for the single-workgroup kernel, in global memory for the multi-workgroup form.
+struct PoState {
+    Pose cur, bak;
+    double H[21], b[6], x[6];
+    double chi, lam, ni, rho;
+    double R[9], t[3];                   // the pose the next pass evaluates at
+    int round, it, qmax, ok, ntrials, niters, have_base, phase;
+};
+
+__device__ inline void po_publish_pose(PoState& S) {
+    quat_to_R(S.cur.q, S.R);
+    S.t[0] = S.cur.t[0]; S.t[1] = S.cur.t[1]; S.t[2] = S.cur.t[2];
+}
+__device__ inline void po_init(PoState& S, const PoseOnlyArgs& a) {
+    S.cur = a.seed; S.bak = a.seed;
+    for (int k = 0; k < 6; ++k) S.x[k] = 0;
+    S.chi = 0; S.lam = -1; S.ni = 2; S.rho = 0;
+    S.round = 0; S.it = 0; S.qmax = 0; S.ok = 1; S.ntrials = 0; S.niters = 0;
+    S.have_base = 0;                     // 0: the coming eval is the iteration-0 linearisation
+    po_publish_pose(S);
+    S.phase = PH_EVAL;
+}
+// behind an evaluation pass (tot: 21 upper H, 6 b, chi2 of the active edges): the LM decision and, if the loop goes on, the next trial
+__device__ inline void po_after_eval(PoState& S, const double* tot, int nactive, const PoseOnlyArgs& a) {
+    int next = PH_EVAL;
+    if (!S.have_base) {
+        if (nactive == 0) {
+            next = PH_CLASSIFY;          // optimize() returns -1: nothing to optimise
+        } else {
+            S.chi = tot[27];
+            for (int k = 0; k < 21; ++k) S.H[k] = tot[k];
+            for (int k = 0; k < 6; ++k) S.b[k] = tot[21 + k];
+            S.have_base = 1;
+            S.it = 0;
+            // computeLambdaInit: tau * max diag
+            double md = 0;
+            int k = 0;
+            for (int p = 0; p < 6; ++p) { md = fmax(md, fabs(S.H[k])); k += 6 - p; }
+            S.lam = 1e-5 * md;
+            S.ni = 2;
+            S.qmax = 0;
+        }
+    } else {
+        const double tempChi = S.ok ? tot[27] : 1.7976931348623157e308;
+        double scale = 0;
+        for (int k = 0; k < 6; ++k) scale += S.x[k] * (S.lam * S.x[k] + S.b[k]);
+        scale += 1e-3;
+        S.rho = (S.chi - tempChi) / scale;
+        const bool accepted = (S.rho > 0) && isfinite(tempChi);
+        if (S.ntrials < a.trace_cap) {
+            nrs_lm_trial& T = a.trace[S.ntrials];
+            T.round = S.round; T.iter = S.it; T.trial = S.qmax; T.accepted = accepted; T.solver_ok = S.ok;
+            T.inner_iters = 0; T.early_rejected = 0; T.reserved = 0; T.lambda = S.lam; T.chi2 = S.chi; T.chi2_new = tempChi; T.rho = S.rho;
+        }
+        ++S.ntrials;
+        bool lam_bad = false;
+        if (accepted) {
+            double alpha = 1.0 - (2 * S.rho - 1) * (2 * S.rho - 1) * (2 * S.rho - 1);
+            alpha = fmin(alpha, 2.0 / 3.0);
+            S.lam *= fmax(1.0 / 3.0, alpha);
+            S.ni = 2;
+            S.chi = tempChi;
+            for (int k = 0; k < 21; ++k) S.H[k] = tot[k];
+            for (int k = 0; k < 6; ++k) S.b[k] = tot[21 + k];
+        } else {
+            S.lam *= S.ni;
+            S.ni *= 2;
+            S.cur = S.bak;
+            if (!isfinite(S.lam)) lam_bad = true;
+        }
+        if (!lam_bad) ++S.qmax;
+        const bool again = !lam_bad && (S.rho < 0) && (S.qmax < 10);
+        if (!again) {
+            ++S.niters;
+            const bool terminate = (S.qmax == 10) || (S.rho == 0) || !isfinite(S.lam);
+            ++S.it;
+            if (terminate || S.it == 10) next = PH_CLASSIFY;
+            else S.qmax = 0;
+        }
+    }
+    if (next == PH_EVAL) {
+        // one trial: push, solve (H + lam I) x = b, update
+        S.bak = S.cur;
+        S.ok = chol6_solve(S.H, S.lam, S.b, S.x) ? 1 : 0;
+        pose_oplus(S.cur, S.x);
+    }
+    po_publish_pose(S);
+    S.phase = next;
+}
+// behind a classification pass (OPT:115-140): next round from the seed, or the end
+__device__ inline void po_after_classify(PoState& S, const PoseOnlyArgs& a) {
+    ++S.round;
+    if (S.round == 3) {
+        *a.pose_out = S.cur;
+        a.counters[0] = S.ntrials;
+        a.counters[1] = S.niters;
+        S.phase = PH_DONE;
+    } else {
+        S.cur = a.seed;                  // OPT:108-110 restart from the seed
+        S.have_base = 0;
+        po_publish_pose(S);
+        S.phase = PH_EVAL;
+    }
+}
+
+// one point of an evaluation pass: residual, Huber, its share of the 6 x 6 normal equations (reprojection_error_only_pose.cc:50-75)
+__device__ inline void po_eval_point(const PoseOnlyArgs& a, const double* R, const double* t, const float* pX, const float* pU, int i, double* acc) {
+    const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
+    const double px = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0];
+    const double py = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1];
+    const double pz = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
+    float u, v, Jf[6];
+    project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
+    projection_jacobian_f32(a.cam, (float)px, (float)py, (float)pz, Jf);
+    const double r0 = (double)pU[2 * i] - (double)u, r1 = (double)pU[2 * i + 1] - (double)v;
+    a.err[2 * i] = r0;
+    a.err[2 * i + 1] = r1;
+    double rho0, rho1;
+    huber(a.info * (r0 * r0 + r1 * r1), a.delta, rho0, rho1);
+    acc[27] += rho0;
+    const double w = rho1 * a.info;
+    // J = -Jpi * [ -[p]x | I ]   (reprojection_error_only_pose.cc:60-74)
+    double J[2][6];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
+        J[rr][0] = -j1 * pz + j2 * py;
+        J[rr][1] = j0 * pz - j2 * px;
+        J[rr][2] = -j0 * py + j1 * px;
+        J[rr][3] = j0; J[rr][4] = j1; J[rr][5] = j2;
+    }
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = p; q < 6; ++q) { acc[k] += w * (J[0][p] * J[0][q] + J[1][p] * J[1][q]); ++k; }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) acc[21 + p] -= w * (J[0][p] * r0 + J[1][p] * r1);
+}
+// one point of a classification pass: inliers keep the error stored by the last computeActiveErrors, outliers are re-evaluated at the
+// final pose of the round (OPT:115-140)
+__device__ inline void po_classify_point(const PoseOnlyArgs& a, const double* R, const double* t, const float* pX, const float* pU, int i) {
+    double r0, r1;
+    if (a.level[i] != 0) {
+        const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
+        const double px = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0];
+        const double py = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1];
+        const double pz = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
+        float u, v;
+        project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
+        r0 = (double)pU[2 * i] - (double)u;
+        r1 = (double)pU[2 * i + 1] - (double)v;
+        a.err[2 * i] = r0;
+        a.err[2 * i + 1] = r1;
+    } else {
+        r0 = a.err[2 * i];
+        r1 = a.err[2 * i + 1];
+    }
+    const float chi2 = (float)(a.info * (r0 * r0 + r1 * r1));
+    const bool out = chi2 > a.th_sq;
+    a.level[i] = out ? 1 : 0;
+    a.inlier[i] = out ? 0 : 1;
+}
 
 __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
     __shared__ double s_red[PO_WAVES][PO_NACC];
     __shared__ double s_tot[PO_NACC];
-    __shared__ double s_R[9], s_t[3];
-    __shared__ int s_phase;
     __shared__ int s_nactive;
-
+    __shared__ PoState S;                // (the serial lane's state lives in LDS so that it does not cost VGPRs in the other lanes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // lane-0 LM state lives in LDS so that it does not cost VGPRs in the 1023 other lanes
-    __shared__ Pose s_cur, s_bak;
-    __shared__ double s_H[21], s_b[6], s_x[6];
-    __shared__ double s_lm[4];           // chi, lam, ni, rho
-    __shared__ int s_ctl[8];             // round, it, qmax, ok, ntrials, niters, have_base
-    Pose& cur = s_cur; Pose& bak = s_bak;
-    double* H = s_H; double* b = s_b; double* x = s_x;
-    double& chi = s_lm[0]; double& lam = s_lm[1]; double& ni = s_lm[2]; double& rho = s_lm[3];
-    int& round = s_ctl[0]; int& it = s_ctl[1]; int& qmax = s_ctl[2]; int& ok = s_ctl[3];
-    int& ntrials = s_ctl[4]; int& niters = s_ctl[5]; int& have_base = s_ctl[6];
-    if (tid == 0) {
-        cur = a.seed; bak = a.seed;
-        for (int k = 0; k < 6; ++k) x[k] = 0;
-        chi = 0; lam = -1; ni = 2; rho = 0;
-        round = 0; it = 0; qmax = 0; ok = 1; ntrials = 0; niters = 0;
-        have_base = 0;                   // 0: the coming eval is the iteration-0 linearisation
-    }
-
-    if (tid == 0) {
-        quat_to_R(cur.q, s_R);
-        s_t[0] = cur.t[0]; s_t[1] = cur.t[1]; s_t[2] = cur.t[2];
-        s_phase = PH_EVAL;
-    }
+    if (tid == 0) po_init(S, a);
     // the points are constant over all ~40 passes: keep them in LDS when they fit (the passes are
     // otherwise a chain of dependent L2 round trips per point)
     extern __shared__ float s_pts[];
@@ -143,51 +296,23 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
     __syncthreads();
 
     while (true) {
-        const int phase = s_phase;
+        const int phase = S.phase;
         if (phase == PH_DONE) break;
-
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = S.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = S.t[k];
         if (phase == PH_EVAL) {
             // ---- computeActiveErrors + linearise + quadratic form over the active edges ----------
             double acc[PO_NACC];
 #pragma unroll
             for (int k = 0; k < PO_NACC; ++k) acc[k] = 0;
             int nact = 0;
-            const double R0 = s_R[0], R1 = s_R[1], R2 = s_R[2], R3 = s_R[3], R4 = s_R[4], R5 = s_R[5],
-                         R6 = s_R[6], R7 = s_R[7], R8 = s_R[8], t0 = s_t[0], t1 = s_t[1], t2 = s_t[2];
             for (int i = tid; i < a.n; i += PO_THREADS) {
                 if (a.level[i] != 0) continue;
                 ++nact;
-                const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
-                const double px = R0 * X0 + R1 * X1 + R2 * X2 + t0;
-                const double py = R3 * X0 + R4 * X1 + R5 * X2 + t1;
-                const double pz = R6 * X0 + R7 * X1 + R8 * X2 + t2;
-                float u, v, Jf[6];
-                project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
-                projection_jacobian_f32(a.cam, (float)px, (float)py, (float)pz, Jf);
-                const double r0 = (double)pU[2 * i] - (double)u, r1 = (double)pU[2 * i + 1] - (double)v;
-                a.err[2 * i] = r0;
-                a.err[2 * i + 1] = r1;
-                double rho0, rho1;
-                huber(a.info * (r0 * r0 + r1 * r1), a.delta, rho0, rho1);
-                acc[27] += rho0;
-                const double w = rho1 * a.info;
-                // J = -Jpi * [ -[p]x | I ]   (reprojection_error_only_pose.cc:60-74)
-                double J[2][6];
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
-                    J[rr][0] = -j1 * pz + j2 * py;
-                    J[rr][1] = j0 * pz - j2 * px;
-                    J[rr][2] = -j0 * py + j1 * px;
-                    J[rr][3] = j0; J[rr][4] = j1; J[rr][5] = j2;
-                }
-                int k = 0;
-#pragma unroll
-                for (int p = 0; p < 6; ++p)
-#pragma unroll
-                    for (int q = p; q < 6; ++q) { acc[k] += w * (J[0][p] * J[0][q] + J[1][p] * J[1][q]); ++k; }
-#pragma unroll
-                for (int p = 0; p < 6; ++p) acc[21 + p] -= w * (J[0][p] * r0 + J[1][p] * r1);
+                po_eval_point(a, R, t, pX, pU, i, acc);
             }
 #pragma unroll
             for (int k = 0; k < PO_NACC; ++k) {
@@ -204,122 +329,68 @@ __global__ __launch_bounds__(PO_THREADS) void pose_only_kernel(PoseOnlyArgs a) {
                 s_tot[tid] = s;
             }
             __syncthreads();
-
-            if (tid == 0) {
-                // ---- g2o Levenberg-Marquardt control flow -------------------------------------
-                int next = PH_EVAL;
-                if (!have_base) {
-                    if (s_nactive == 0) {
-                        next = PH_CLASSIFY;          // optimize() returns -1: nothing to optimise
-                    } else {
-                        chi = s_tot[27];
-                        for (int k = 0; k < 21; ++k) H[k] = s_tot[k];
-                        for (int k = 0; k < 6; ++k) b[k] = s_tot[21 + k];
-                        have_base = 1;
-                        it = 0;
-                        // computeLambdaInit: tau * max diag
-                        double md = 0;
-                        int k = 0;
-                        for (int p = 0; p < 6; ++p) { md = fmax(md, fabs(H[k])); k += 6 - p; }
-                        lam = 1e-5 * md;
-                        ni = 2;
-                        qmax = 0;
-                    }
-                } else {
-                    const double tempChi = ok ? s_tot[27] : 1.7976931348623157e308;
-                    double scale = 0;
-                    for (int k = 0; k < 6; ++k) scale += x[k] * (lam * x[k] + b[k]);
-                    scale += 1e-3;
-                    rho = (chi - tempChi) / scale;
-                    const bool accepted = (rho > 0) && isfinite(tempChi);
-                    if (ntrials < a.trace_cap) {
-                        nrs_lm_trial& T = a.trace[ntrials];
-                        T.round = round; T.iter = it; T.trial = qmax; T.accepted = accepted; T.solver_ok = ok;
-                        T.inner_iters = 0; T.early_rejected = 0; T.reserved = 0; T.lambda = lam; T.chi2 = chi; T.chi2_new = tempChi; T.rho = rho;
-                    }
-                    ++ntrials;
-                    bool lam_bad = false;
-                    if (accepted) {
-                        double alpha = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-                        alpha = fmin(alpha, 2.0 / 3.0);
-                        lam *= fmax(1.0 / 3.0, alpha);
-                        ni = 2;
-                        chi = tempChi;
-                        for (int k = 0; k < 21; ++k) H[k] = s_tot[k];
-                        for (int k = 0; k < 6; ++k) b[k] = s_tot[21 + k];
-                    } else {
-                        lam *= ni;
-                        ni *= 2;
-                        cur = bak;
-                        if (!isfinite(lam)) lam_bad = true;
-                    }
-                    if (!lam_bad) ++qmax;
-                    const bool again = !lam_bad && (rho < 0) && (qmax < 10);
-                    if (!again) {
-                        ++niters;
-                        const bool terminate = (qmax == 10) || (rho == 0) || !isfinite(lam);
-                        ++it;
-                        if (terminate || it == 10) next = PH_CLASSIFY;
-                        else qmax = 0;
-                    }
-                }
-                if (next == PH_EVAL) {
-                    // one trial: push, solve (H + lam I) x = b, update
-                    bak = cur;
-                    ok = chol6_solve(H, lam, b, x) ? 1 : 0;
-                    pose_oplus(cur, x);
-                }
-                quat_to_R(cur.q, s_R);
-                s_t[0] = cur.t[0]; s_t[1] = cur.t[1]; s_t[2] = cur.t[2];
-                s_phase = next;
-            }
+            if (tid == 0) po_after_eval(S, s_tot, s_nactive, a);       // g2o's Levenberg-Marquardt control flow
             __syncthreads();
         } else {
-            // ---- PH_CLASSIFY: OPT:115-140.  Inliers keep the error stored by the last
-            //      computeActiveErrors; outliers are re-evaluated at the final pose of the round.
-            const double R0 = s_R[0], R1 = s_R[1], R2 = s_R[2], R3 = s_R[3], R4 = s_R[4], R5 = s_R[5],
-                         R6 = s_R[6], R7 = s_R[7], R8 = s_R[8], t0 = s_t[0], t1 = s_t[1], t2 = s_t[2];
-            for (int i = tid; i < a.n; i += PO_THREADS) {
-                double r0, r1;
-                if (a.level[i] != 0) {
-                    const double X0 = pX[3 * i], X1 = pX[3 * i + 1], X2 = pX[3 * i + 2];
-                    const double px = R0 * X0 + R1 * X1 + R2 * X2 + t0;
-                    const double py = R3 * X0 + R4 * X1 + R5 * X2 + t1;
-                    const double pz = R6 * X0 + R7 * X1 + R8 * X2 + t2;
-                    float u, v;
-                    project_f32(a.cam, (float)px, (float)py, (float)pz, u, v);
-                    r0 = (double)pU[2 * i] - (double)u;
-                    r1 = (double)pU[2 * i + 1] - (double)v;
-                    a.err[2 * i] = r0;
-                    a.err[2 * i + 1] = r1;
-                } else {
-                    r0 = a.err[2 * i];
-                    r1 = a.err[2 * i + 1];
-                }
-                const float chi2 = (float)(a.info * (r0 * r0 + r1 * r1));
-                const bool out = chi2 > a.th_sq;
-                a.level[i] = out ? 1 : 0;
-                a.inlier[i] = out ? 0 : 1;
-            }
+            for (int i = tid; i < a.n; i += PO_THREADS) po_classify_point(a, R, t, pX, pU, i);
             __syncthreads();
-            if (tid == 0) {
-                ++round;
-                if (round == 3) {
-                    *a.pose_out = cur;
-                    a.counters[0] = ntrials;
-                    a.counters[1] = niters;
-                    s_phase = PH_DONE;
-                } else {
-                    cur = a.seed;                      // OPT:108-110 restart from the seed
-                    have_base = 0;
-                    quat_to_R(cur.q, s_R);
-                    s_t[0] = cur.t[0]; s_t[1] = cur.t[1]; s_t[2] = cur.t[2];
-                    s_phase = PH_EVAL;
-                }
-            }
+            if (tid == 0) po_after_classify(S, a);
             __syncthreads();
         }
     }
+}
+
+// ---- the same solve over MANY workgroups, for frames whose passes one workgroup would serialise (a 100k-point map: ~200 points per
+// thread and pass).  A pass (k_po_pass: every workgroup its share of the points, partial sums in a slot of its own) and a step
+// (k_po_step: one workgroup adds the slots up in slot order -- bit-reproducible -- and runs the serial part) alternate on the stream; the
+// state lives in global memory, launches behind PH_DONE are no-ops, the host looks at the phase once per batch of launches.
+constexpr int POM_THREADS = 256;
+__global__ __launch_bounds__(POM_THREADS) void k_po_pass(PoseOnlyArgs a, PoState* S, double* part /* gridDim x 32 */, int first) {
+    __shared__ double lds[4 * 29];
+    const int tid = threadIdx.x, gid = blockIdx.x * POM_THREADS + tid, stride = gridDim.x * POM_THREADS;
+    if (first) { for (int i = gid; i < a.n; i += stride) a.level[i] = 0; }
+    const int phase = first ? (int)PH_EVAL : S->phase;
+    if (phase == PH_DONE) return;
+    double R[9], t[3];
+    if (first) { Pose p = a.seed; quat_to_R(p.q, R); t[0] = p.t[0]; t[1] = p.t[1]; t[2] = p.t[2]; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = S->R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = S->t[k];
+    }
+    if (phase == PH_EVAL) {
+        double acc[29];
+#pragma unroll
+        for (int k = 0; k < 29; ++k) acc[k] = 0;
+        for (int i = gid; i < a.n; i += stride) {
+            if (!first && a.level[i] != 0) continue;
+            acc[28] += 1.0;                                           // active edges (exact in fp64)
+            po_eval_point(a, R, t, a.X, a.uv, i, acc);
+        }
+        block_sum_29(acc, lds, tid, part + (size_t)blockIdx.x * 32);
+    } else {
+        for (int i = gid; i < a.n; i += stride) po_classify_point(a, R, t, a.X, a.uv, i);
+    }
+}
+__global__ __launch_bounds__(64) void k_po_step(PoseOnlyArgs a, PoState* S, const double* part, int n_part, int first, int* h_phase) {
+    __shared__ double tot[32];
+    const int tid = threadIdx.x;
+    if (first && tid == 0) po_init(*S, a);
+    __syncthreads();
+    const int phase = S->phase;
+    if (phase == PH_EVAL) {
+        if (tid < 29) {
+            double s = 0;
+            for (int g = 0; g < n_part; ++g) s += part[(size_t)g * 32 + tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) po_after_eval(*S, tot, (int)tot[28], a);
+    } else if (phase == PH_CLASSIFY) {
+        if (tid == 0) po_after_classify(*S, a);
+    }
+    if (tid == 0 && h_phase) { __threadfence_system(); *reinterpret_cast<volatile int*>(h_phase) = S->phase; }
 }
 
 }  // namespace nrs
@@ -385,7 +456,7 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
     if (c->arena_dba.base) (void)hipFree(c->arena_dba.base);
     if (c->arena_trk.base) (void)hipFree(c->arena_trk.base);
     c->release(c->po_uv); c->release(c->po_X); c->release(c->po_err);
-    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin);
+    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin); c->release(c->po_multi);
     nrs::nd_cache_free(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -455,10 +526,36 @@ extern "C" int nrs_pose_only_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n,
     a.trace_cap = cap;
     const size_t shm = (size_t)n * 20;
     a.cache_pts = shm <= 140 * 1024 ? 1 : 0;                 // 160 KiB of LDS per CU on gfx950
-    if (a.cache_pts && shm > 48 * 1024)
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pose_only_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(PO_THREADS), a.cache_pts ? shm : 0, c->stream, a);
-    NRS_HIP(c, hipGetLastError());
+    // One workgroup runs the whole function in ONE launch while its passes are short (the points then sit in its LDS: <= 7168 points);
+    // beyond that a pass is spread over the chip and the serial part runs in a kernel of its own between passes (k_po_pass / k_po_step:
+    // ~10 us per LM trial whatever the size, where the single workgroup needs n / 512 point evaluations per thread and trial).
+    // NRS_PO_MULTI_MIN moves the hand-over (tests run both forms on the same frames).
+    int multi_min = 32768;                                    // (measured: 13.0 ms on one workgroup, 6.0 ms on many at 90k points; the two meet near 35k)
+    if (const char* ev = getenv("NRS_PO_MULTI_MIN")) multi_min = atoi(ev);
+    if (n >= multi_min && n > 0) {
+        const int G = std::max(1, std::min(2 * c->prop.multiProcessorCount, (n + POM_THREADS - 1) / POM_THREADS));
+        NRS_TRY(c->ensure(c->po_multi, sizeof(PoState) + 256 + sizeof(double) * 32 * (size_t)G));
+        PoState* S = c->po_multi.as<PoState>();
+        double* part = reinterpret_cast<double*>(c->po_multi.as<char>() + ((sizeof(PoState) + 255) & ~(size_t)255));
+        a.cache_pts = 0;
+        int phase = PH_EVAL, launched = 0;
+        // (at most 3 rounds x (1 + 10 iterations x 10 trials) evaluation passes + 3 classification passes)
+        while (phase != PH_DONE && launched < 320) {
+            for (int q = 0; q < 16; ++q, ++launched) {
+                hipLaunchKernelGGL(k_po_pass, dim3(G), dim3(POM_THREADS), 0, c->stream, a, S, part, launched == 0 ? 1 : 0);
+                hipLaunchKernelGGL(k_po_step, dim3(1), dim3(64), 0, c->stream, a, S, part, G, launched == 0 ? 1 : 0, (int*)nullptr);
+            }
+            NRS_HIP(c, hipGetLastError());
+            NRS_HIP(c, hipMemcpyAsync(&phase, &S->phase, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            NRS_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        if (phase != PH_DONE) return c->fail(NRS_ERR_HIP, "pose-only solve: the pass / step sequence did not finish");
+    } else {
+        if (a.cache_pts && shm > 48 * 1024)
+            NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pose_only_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(PO_THREADS), a.cache_pts ? shm : 0, c->stream, a);
+        NRS_HIP(c, hipGetLastError());
+    }
     Pose out;
     int counters[2] = {0, 0};
     NRS_HIP(c, hipMemcpyAsync(&out, a.pose_out, sizeof(Pose), hipMemcpyDeviceToHost, c->stream));
