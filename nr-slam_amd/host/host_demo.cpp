@@ -74,10 +74,16 @@ int main(int argc, char** argv) {
         wr(out, lost.data(), lost.size());
         wr(out, m.last_world_position.data(), m.last_world_position.size());
         wr(out, m.e_status.data(), m.e_status.size());
-        // a3: LocalDeformableBundleAdjustment
+        // a3: LocalDeformableBundleAdjustment, then its embedded form on a copy of the window (every 6th map point a node)
+        nrs_host::KeyFrameWindow we = w;
         eng.LocalDeformableBundleAdjustment(cam, w, mb);
         wr(out, w.poses_qt.data(), w.poses_qt.size());
         wr(out, w.lm_xyz.data(), w.lm_xyz.size());
+        std::vector<uint8_t> is_node(mb.rowptr.size() - 1, 0);
+        for (size_t p = 0; p < is_node.size(); p += 6) is_node[p] = 1;
+        eng.LocalDeformableBundleAdjustmentEmbedded(cam, we, mb, is_node);
+        wr(out, we.poses_qt.data(), we.poses_qt.size());
+        wr(out, we.lm_xyz.data(), we.lm_xyz.size());
         std::printf("host_demo: ok (%zu frame slots, %zu lost, %zu BA landmarks)\n", f.status.size(), lost.size(), w.lm_xyz.size() / 3);
         return 0;
     } catch (const std::exception& e) {

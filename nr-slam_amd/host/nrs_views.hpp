@@ -158,6 +158,46 @@ public:
                             w.lm_uv.data(), ns, sp.data(), d0.data(), nd, dm.data(), dw.data(), m.scale, iterations, nullptr));
     }
 
+    // The EMBEDDED form of the same call (include/nrs.h N2b; BASELINE configs[1] "points x graph nodes x keyframes"): is_node flags the
+    // map points that carry vertices (e.g. SelectGraphNodes once per map); the other observations of the window are skinned to the
+    // <= 11 node copies of their keyframe their walk accepts and keep their reprojection edges.  The walks see GetEdges lists with
+    // everything but the nodes passed over: here they are cut out of the flat graph's ordered lists.  w.lm_xyz comes back with the
+    // node copies' and the skinned points' new positions.
+    void LocalDeformableBundleAdjustmentEmbedded(const CameraView& cam, KeyFrameWindow& w, MapView& m, const std::vector<uint8_t>& is_node, int iterations = 5) {
+        const int32_t n_kf = (int32_t)w.kf_rowptr.size() - 1;
+        if (n_kf < 3) return;                                              // OPT:922-924
+        nrs_graph g = m.c_graph();
+        std::vector<int32_t> orp((size_t)g.n_points + 1), ocol(m.col.size()), oeid(m.col.size());
+        check(nrs_graph_select_neighbours(ctx_, &g, orp.data(), ocol.data(), oeid.data()));
+        std::vector<int32_t> nrp((size_t)g.n_points + 1, 0), ncol, nst;
+        std::vector<float> nw, nd0;
+        for (int32_t p = 0; p < g.n_points; ++p) {                           // node neighbours only, GetEdges order kept
+            for (int32_t a = orp[p]; a < orp[p + 1]; ++a)
+                if (is_node[ocol[a]]) { ncol.push_back(ocol[a]); nw.push_back(m.e_w[oeid[a]]); nd0.push_back(m.e_d0[oeid[a]]); nst.push_back(m.e_status[oeid[a]]); }
+            nrp[p + 1] = (int32_t)ncol.size();
+        }
+        if (ncol.empty()) { ncol.push_back(0); nw.push_back(0.f); nd0.push_back(0.f); nst.push_back(0); }
+        int32_t nl = 0, ns = 0, nd = 0, nk = 0;
+        check(nrs_dba_build_edges_embedded(n_kf, w.kf_rowptr.data(), w.kf_pt.data(), g.n_points, is_node.data(), nrp.data(), ncol.data(), nw.data(), nd0.data(),
+                                           nst.data(), &nl, nullptr, &ns, nullptr, nullptr, &nd, nullptr, nullptr, &nk, nullptr, nullptr, nullptr));
+        std::vector<int32_t> lm_obs((size_t)nl + 1), sp(2 * (size_t)ns + 2), dm(4 * (size_t)nd + 4), sk_obs((size_t)nk + 1), sk_node(11 * (size_t)nk + 11);
+        std::vector<float> d0((size_t)ns + 1), dw((size_t)nd + 1);
+        std::vector<double> sk_om(11 * (size_t)nk + 11);
+        check(nrs_dba_build_edges_embedded(n_kf, w.kf_rowptr.data(), w.kf_pt.data(), g.n_points, is_node.data(), nrp.data(), ncol.data(), nw.data(), nd0.data(),
+                                           nst.data(), &nl, lm_obs.data(), &ns, sp.data(), d0.data(), &nd, dm.data(), dw.data(), &nk, sk_obs.data(), sk_node.data(), sk_om.data()));
+        std::vector<int32_t> obs_kf(w.kf_pt.size());
+        for (int32_t k = 0; k < n_kf; ++k)
+            for (int32_t l = w.kf_rowptr[k]; l < w.kf_rowptr[k + 1]; ++l) obs_kf[l] = k;
+        std::vector<float> lxyz(3 * (size_t)nl + 3), luv(2 * (size_t)nl + 2), sxyz(3 * (size_t)nk + 3), suv(2 * (size_t)nk + 2);
+        std::vector<int32_t> lkf((size_t)nl + 1), skf((size_t)nk + 1);
+        for (int32_t i = 0; i < nl; ++i) { const int32_t o = lm_obs[i]; lkf[i] = obs_kf[o]; for (int c = 0; c < 3; ++c) lxyz[3 * i + c] = w.lm_xyz[3 * o + c]; luv[2 * i] = w.lm_uv[2 * o]; luv[2 * i + 1] = w.lm_uv[2 * o + 1]; }
+        for (int32_t i = 0; i < nk; ++i) { const int32_t o = sk_obs[i]; skf[i] = obs_kf[o]; for (int c = 0; c < 3; ++c) sxyz[3 * i + c] = w.lm_xyz[3 * o + c]; suv[2 * i] = w.lm_uv[2 * o]; suv[2 * i + 1] = w.lm_uv[2 * o + 1]; }
+        check(nrs_dba_solve_embedded(ctx_, &cam.cam, n_kf, w.poses_qt.data(), nl, lxyz.data(), lkf.data(), luv.data(), ns, sp.data(), d0.data(), nd, dm.data(), dw.data(),
+                                     nk, skf.data(), suv.data(), sxyz.data(), sk_node.data(), sk_om.data(), m.scale, iterations, nullptr));
+        for (int32_t i = 0; i < nl; ++i) for (int c = 0; c < 3; ++c) w.lm_xyz[3 * (size_t)lm_obs[i] + c] = lxyz[3 * i + c];      // OPT:1145-1160
+        for (int32_t i = 0; i < nk; ++i) for (int c = 0; c < 3; ++c) w.lm_xyz[3 * (size_t)sk_obs[i] + c] = sxyz[3 * i + c];
+    }
+
     // ShiTomasi::Extract(const cv::Mat&, std::vector<cv::KeyPoint>&)  features/shi_tomasi.h:45 followed by the
     // mask filter of Tracking::ExtractFeatures (tracking.cc:118-134): `keypoints` holds the frame's keypoints on
     // entry and the NEW ones (x, y) on return, `ids` their class ids.  The extractor's buffers live in the context

@@ -59,6 +59,7 @@ def test_cpp_host_mirror_matches_ctypes_path(ctx, tmp_path):
         a1 = _r(f, np.float64)
         a2_qt, a2_pos, a2_st, a2_lost, a2_map, a2_est = _r(f, np.float64), _r(f, np.float32), _r(f, np.int32), _r(f, np.int32), _r(f, np.float32), _r(f, np.int32)
         a3_qt, a3_xyz = _r(f, np.float64), _r(f, np.float32)
+        a3e_qt, a3e_xyz = _r(f, np.float64), _r(f, np.float32)
     cam = nrs.make_camera(tp["model"], tp["prm"])
     m = tp["status"] == 0
     q, t, _ = ctx.pose_only_solve(cam, tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"])
@@ -72,6 +73,22 @@ def test_cpp_host_mirror_matches_ctypes_path(ctx, tmp_path):
     camb = nrs.make_camera(p["model"], p["prm"])
     pq, xyz = ctx.dba_solve(camb, wqt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5)
     assert np.array_equal(a3_qt.reshape(-1, 7), pq) and np.array_equal(a3_xyz.reshape(-1, 3), xyz)
+    # the embedded form of the window (N2b): every 6th map point a node, the ordered lists cut down to nodes -- the mirror's
+    # LocalDeformableBundleAdjustmentEmbedded against the ctypes path, bit for bit
+    flag = np.zeros(p["n_points"], np.uint8)
+    flag[::6] = 1
+    nb = p["nbr"]
+    keep = flag[nb["col"]] != 0
+    rows = np.repeat(np.arange(p["n_points"]), np.diff(nb["rowptr"]))
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=p["n_points"]))]).astype(np.int32)
+    nbn = dict(rowptr=rp, col=nb["col"][keep], w=nb["w"][keep], d0=nb["d0"][keep], status=nb["status"][keep])
+    ee = nrs.dba_build_edges_embedded(p["kf_points"], flag, nbn)
+    we = S.embedded_window(p, ee)
+    pqe, xe, ske = ctx.dba_solve_embedded(camb, wqt, we, ee, p["scale"], 5)
+    full = p["lm_xyz"].astype(np.float32).copy()
+    full[ee["lm_obs"]] = xe
+    full[ee["sk_obs"]] = ske
+    assert len(ee["sk_obs"]) > 100 and np.array_equal(a3e_qt.reshape(-1, 7), pqe) and np.array_equal(a3e_xyz.reshape(-1, 3), full)
 
 
 def test_cpp_tracker_graph_and_triangulation_mirror(tmp_path):
