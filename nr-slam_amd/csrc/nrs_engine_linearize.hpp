@@ -583,7 +583,7 @@ __device__ inline double damper_s(double g0, double g1, double g2, double w, dou
     return (act ? dsp * y : 1.0) * isp * w * w;
 }
 
-template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0, bool H4 = false, bool RCS = false, bool RCD = false>   // RCS / RCD: the spring / damper factors are not stored (Dev::rc: the operator re-forms them); EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results); H4: 4-byte damper headers (Dev::d_h4)
+template <int T, int OCC = 4, int CAM = -1, bool TPC = false, int EXP = 0, bool H4 = false, bool RCS = false, bool RCD = false, int NBT = 4, bool NT = false>   // NBT: slots per lane and request batch; NT: non-temporal stream accesses (probe variants); RCS / RCD: the spring / damper factors are not stored (Dev::rc: the operator re-forms them); EXP != 0: timing experiments with a piece removed (NRS_LIN_EXP; wrong results); H4: 4-byte damper headers (Dev::d_h4)
 __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __restrict__ xl_g, int cls) {
     __shared__ double mfb[4 * 128];                                // pose-block operands: 1 KB per wave
     __shared__ double spose[8];                                    // the tile's pose (q, t): fetched during staging, read after the loops
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];     // (requested up front: nothing behind the loops waits on memory)
     if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
-    const int d_beg = P.sd_ptr[slice], d_end = P.sd_ptr[slice + 1];
+    const int d_beg = P.sd_ptr[slice], d_end = EXP == 5 ? P.sd_ptr[slice] + (((P.sd_ptr[slice + 1] - P.sd_ptr[slice]) / 64 + 1) / 2) * 64 : P.sd_ptr[slice + 1];   // (EXP 5: half of the damper slots -- what a two-incidence form of the dampers would stream)
     // Record requests go out in BATCHES of NB slots per lane and stream: all NB requests of a batch are in flight together,
     // then the slots are consumed one by one -- a wave waits out one memory round trip per batch instead of one per pair of
     // slots (two-slot double buffering spent ~85 % of the loops waiting: 13.6 us of a 28.6 us wave at C4), and with four
@@ -615,12 +615,15 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // UNCONDITIONAL (slots past the slice's end read a clamped index and count as padding when consumed) and nothing
     // touches the loaded registers before consume(): with a predicated load the compiler sinks the unpacking behind the
     // load and the wave waits out the full latency of every single request (rounds 1 and 2).
-    constexpr int NB = 4;                                          // (6 or 8 slots per lane and batch: 111 / 238 spilled VGPRs at 4 waves per SIMD, round 5)
+    constexpr int NB = NBT;                                        // (6 or 8 slots per lane and batch: 111 / 238 spilled VGPRs at 4 waves per SIMD, round 5)
     uint32_t rs_om[NB], rs_d0[NB];
     auto req_s = [&](int q, int idx) {
         if (EXP == 3) { rs_om[q] = (uint32_t)(idx & 63) | 0x10000u; rs_d0[q] = 0x3F800000u; return; }
         rs_om[q] = 0xFFFFu; rs_d0[q] = 0x3F800000u;                  // padding: no neighbour, rest length 1
-        if ((idx - s_beg - lane) / 64 < my_s) { rs_om[q] = P.s_om[idx]; rs_d0[q] = __float_as_uint(P.s_d0[idx]); }
+        if ((idx - s_beg - lane) / 64 < my_s) {
+            if (NT) { rs_om[q] = __builtin_nontemporal_load(P.s_om + idx); rs_d0[q] = __float_as_uint(__builtin_nontemporal_load(P.s_d0 + idx)); }
+            else { rs_om[q] = P.s_om[idx]; rs_d0[q] = __float_as_uint(P.s_d0[idx]); }
+        }
     };
 #pragma unroll
     for (int q = 0; q < NB; ++q) req_s(q, s_beg + lane + 64 * q);  // the first spring batch rides on the staging loads
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         const double r = ks * fma(d2, rs, -d0) * id0;
         const double cg = 2.0 * ks * id0 * fast_sqrt_pos(rs);       // (plain windows are BA windows: spring_form 0, checked by engine_create)
         const double qc = pad ? 0.0 : spring_qc(d2, d0, ks, ip);
-        if (live && EXP != 1 && !RCS) P.s_qc[idx] = qc;                     // (whole lines: padding slots inside the slice are written too -- a lane-masked store leaves partial lines, which cost the memory side a read-modify-write)
+        if (live && EXP != 1 && !RCS) { if (NT) __builtin_nontemporal_store(qc, P.s_qc + idx); else P.s_qc[idx] = qc; }                    // (whole lines: padding slots inside the slice are written too -- a lane-masked store leaves partial lines, which cost the memory side a read-modify-write)
         chi += count && !pad ? ip * r * r : 0.0;
         const double t0 = qc * v0, t1 = qc * v1, t2 = qc * v2;
         D0 = fma(t0, v0, D0); D1 = fma(t0, v1, D1); D2 = fma(t0, v2, D2);
@@ -689,7 +692,9 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     auto req_d = [&](int q, int idx) {
         if (EXP == 3) { rd_h[q] = make_uint2((uint32_t)(idx & 63) | ((uint32_t)((idx + 1) & 63) << 16), (uint32_t)((idx + 2) & 63) | 0x80000u); rd_w[q] = 0x3F800000u; return; }
         rd_h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); rd_w[q] = 0u;
-        if (H4) { if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q].x = P.d_h4[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); } }
+        if (H4) { if ((idx - d_beg - lane) / 64 < my_d) {
+            if (NT) { rd_h[q].x = __builtin_nontemporal_load(P.d_h4 + idx); rd_w[q] = __float_as_uint(__builtin_nontemporal_load(P.d_w + idx)); }
+            else { rd_h[q].x = P.d_h4[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); } } }
         else if ((idx - d_beg - lane) / 64 < my_d) { rd_h[q] = P.d_hdr[idx]; rd_w[q] = __float_as_uint(P.d_w[idx]); }
     };
     auto do_d = [&](uint32_t hx, uint32_t hy, float wf, int idx) {
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
         double rho0;
         const double sfac = damper_s(g0, g1, g2, w, isp, dsp, rho0);
         chi += (m16 & DM_COUNT) ? rho0 : 0.0;                      // (padding: rho0 = 0)
-        if (live && EXP != 1 && !RCD) P.d_s[idx] = sfac;
+        if (live && EXP != 1 && !RCD) { if (NT) __builtin_nontemporal_store(sfac, P.d_s + idx); else P.d_s[idx] = sfac; }
         D0 += sfac; D3 += sfac; D5 += sfac;
         bb0 = fma(-sfac, g0, bb0); bb1 = fma(-sfac, g1, bb1); bb2 = fma(-sfac, g2, bb2);
     };

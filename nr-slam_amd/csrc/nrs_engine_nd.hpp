@@ -442,8 +442,9 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         for (int r = ty; r < s; r += 8)
             for (int q = tx; q < s; q += 32) LT[(size_t)r * s + q] = q >= r ? W[(s16 + r) * ND_LD + q] : 0.0;
     }
-    // ---- the factor: block I's rows of L21 (and y^T) by the workgroups of column 0, L11 and 1 / diag by (0, 0)
-    if (J == 0) {
+    // ---- the factor: block I's rows of L21 (and y^T) by the DIAGONAL workgroups (I, I) -- those run in every form of a level, also when its
+    // off-diagonal tiles come from k_nd_tile, which reads these rows back -- L11 and 1 / diag by (0, 0)
+    if (J == I && !inv) {
         const int tx = tid & 31, ty = tid >> 5;
         double* L = N.Lp + F.L_off;
         for (int r = ty; r < rI; r += 8)
@@ -456,6 +457,136 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         }
     }
     stamp(5);
+}
+
+// ---- the off-diagonal Schur tiles of a CROWDED level (more workgroups than CUs) in a launch of their own: U_IJ = F22_IJ - L21_I L21_J^T from the
+// rows of L21 the diagonal workgroups (I, I), (J, J) of the launch before left in the factor -- instead of every (I, J) workgroup factorising
+// the front's panel again for its one tile (13 us of panel for 4.4 us of tile, three rounds of workgroups at one per CU on the lowest level of
+// a 4.4k-point frame).  Same operands, same matrix-core sequence, same accumulation order as k_nd_level's tile: the same bits.  LDS: two
+// 48-row blocks (74 KB), two workgroups per CU.
+constexpr int ND_TILE_LDS = 2 * ND_TB * ND_LD;                     // doubles
+__global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NdWgD wd = N.wg[wg0 + blockIdx.x];
+    const int I = wd.I, J = wd.J;
+    const NdFrontD& F = wd.F;
+    const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b;
+    const int rI = min(ND_TB, b1 - ND_TB * I), cJ = ND_TB;          // (J < I: a full block)
+    double* LI = sm;
+    double* LJ = sm + ND_TB * ND_LD;
+    int16_t* pmi = reinterpret_cast<int16_t*>(sm + ND_TILE_LDS);
+    int16_t* pmj = pmi + 16;
+    auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
+    stamp(0);
+    if (tid < 16) { const int np = 16 * I + tid; pmi[tid] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
+    else if (tid < 32) { const int np = 16 * J + tid - 16; pmj[tid - 16] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
+    // requests first: the two row blocks of the factor (contiguous: rows of s doubles), then the children's slots of this tile
+    const double* L = N.Lp + F.L_off;
+    const double* srcI = L + (size_t)(s + ND_TB * I) * s;
+    const double* srcJ = L + (size_t)(s + ND_TB * J) * s;
+    constexpr int NL = (ND_TB * ND_S16 + 255) / 256;               // 18 values per thread and block at most
+    double vi[NL], vj[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = tid + 256 * u;
+        vi[u] = i < rI * s ? srcI[i] : 0.0;
+        vj[u] = i < cJ * s ? srcJ[i] : 0.0;
+    }
+    const size_t slot = (size_t)(m + 1) * F.ldA;
+    const double* A0 = N.A + F.A_off;
+    nd_v4d acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
+    if (F.n_ch > 0) {                                              // F22 tile (I, J) of the children, as in k_nd_level
+        auto tile_off = [&](int r, int cc) {
+            const int fr = s + ND_TB * I + r, fc = s + ND_TB * J + cc;
+            return (size_t)max(fr, fc) * F.ldA + min(fr, fc);
+        };
+        double tv[2][3][4];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
+                const bool in = t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b;
+                const size_t o = in ? tile_off(r, cc) : 0;
+                tv[0][t3][g] = A0[o];
+                tv[1][t3][g] = A0[(F.n_ch > 1 ? slot : 0) + o];
+                if (!in) { tv[0][t3][g] = 0.0; tv[1][t3][g] = 0.0; }
+            }
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t3][g] = tv[0][t3][g] + (F.n_ch > 1 ? tv[1][t3][g] : 0.0);
+        for (int k = 2; k < F.n_ch; ++k)
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
+                    if (t < 9 && r < rI && cc < cJ && ND_TB * J + cc < F.b) acc[t3][g] += A0[k * slot + tile_off(r, cc)];
+                }
+            }
+    }
+    // into LDS at the panel's leading dimension; what the matrix cores read beyond the blocks (columns s .. s16, rows rI .. 48 of a partial
+    // block I) is zero.  (row = i / s by a float reciprocal: (i + 0.5) / s is never closer than 0.5 / 96 to an integer)
+    const float invs = 1.0f / (float)s;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = tid + 256 * u;
+        const int r = __float2int_rz(((float)i + 0.5f) * invs), q = i - r * s;
+        if (i < rI * s) LI[r * ND_LD + q] = vi[u];
+        if (i < cJ * s) LJ[r * ND_LD + q] = vj[u];
+    }
+    for (int i = tid; i < ND_TB * (s16 - s); i += 256) {            // pad columns of both blocks
+        const int r = i / (s16 - s), q = s + i % (s16 - s);
+        LI[r * ND_LD + q] = 0.0; LJ[r * ND_LD + q] = 0.0;
+    }
+    for (int i = tid; i < (ND_TB - rI) * s; i += 256) LI[(rI + i / s) * ND_LD + i % s] = 0.0;   // rows below a partial block I
+    __syncthreads();
+    stamp(1); stamp(2); stamp(3);
+    if (F.par >= 0) {
+        int ti[3], tj[3];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) { const int t = min(wave + 4 * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
+        const bool third = wave == 0;
+#pragma unroll 1
+        for (int k4 = 0; k4 < (s16 >> 4); ++k4) {
+            double av[3][4], bv[3][4];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    av[t3][kk] = -LI[(16 * ti[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
+                    bv[t3][kk] = LJ[(16 * tj[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
+                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc[1], 0, 0, 0);
+                if (third) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2][kk], bv[2][kk], acc[2], 0, 0, 0);
+            }
+        }
+        double* Ap = N.A + F.pA_off;
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            if (wave + 4 * t3 >= 9) break;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * ti[t3] + (lane >> 4) + 4 * g, cc = 16 * tj[t3] + (lane & 15);
+                const int Cc = ND_TB * J + cc;
+                if (r < rI && cc < cJ && Cc < F.b) {
+                    const int PR = 3 * (int)pmi[r / 3] + r % 3, PC = 3 * (int)pmj[cc / 3] + cc % 3;
+                    Ap[(size_t)max(PR, PC) * F.pldA + min(PR, PC)] = acc[t3][g];
+                }
+            }
+        }
+    }
+    stamp(4); stamp(5);
 }
 
 // back substitution, x_own = L11^-T (y - L21^T x_bnd), all levels in ONE launch: one workgroup per front (roots included: no
@@ -686,6 +817,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     if (!S.attr_set) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         S.attr_set = true;
     }
     for (int l = 0; l < P.n_levels; ++l)
@@ -713,9 +845,16 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         for (int l = 0; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
         hipLaunchKernelGGL(k_nd_level, dim3(P.lvl_wg_ptr[P.n_levels]), dim3(256), shm, c->stream, S.dev, 0, lam, epoch, ++S.chained);
     } else {
+        // a CROWDED level (more workgroups than CUs: they would run in rounds, one per CU, each factorising its front's panel for one
+        // tile) runs as two launches: the diagonal and inverse workgroups factorise and leave their rows of L21, k_nd_tile makes the
+        // off-diagonal tiles from them (NRS_ND_NO_SPLIT=1: one launch per level throughout; the bits are the same)
+        const bool no_split = getenv("NRS_ND_NO_SPLIT") != nullptr;
         for (int l = 0; l < P.n_levels; ++l) {
-            const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l];
-            hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
+            const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
+            if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
+                hipLaunchKernelGGL(k_nd_level, dim3(nA), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
+                hipLaunchKernelGGL(k_nd_tile, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
+            } else hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
         }
     }
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that

@@ -63,6 +63,8 @@ struct NdPlan {
     std::vector<int> lvl_ptr, lvl_fronts;       // fronts of every level (leaves first)
     std::vector<int> seg;                       // (front, end row) pairs: NdFrontD::seg_off
     std::vector<int> lvl_wg_ptr, wg;            // workgroups of every level: (front, row block I, row block J <= I), and (front, -1, -1) for every front
+    std::vector<int> lvl_wg_split;              // per level: where its off-diagonal workgroups (I > J) start -- the diagonal (I, I) and inverse
+                                                // ones come first, so a crowded level can run as two launches (nrs_engine_nd.hpp k_nd_tile)
     std::vector<int> pair_hi, pair_lo;          // every pair oriented by elimination order (block rows = hi)
     std::vector<int> elim;                      // node -> elimination position
     size_t L_doubles = 0, U_doubles = 0, A_doubles = 0;
@@ -350,15 +352,21 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         for (int f = 0; f < nf; ++f) P.lvl_fronts[fill[level[f]]++] = f;
     }
     P.lvl_wg_ptr.assign(P.n_levels + 1, 0);
+    P.lvl_wg_split.assign(P.n_levels, 0);
     for (int l = 0; l < P.n_levels; ++l) {
         double worst = 0;
-        for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) {
+        for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) {                                     // the workgroups that factorise a panel of their own
             const int f = P.lvl_fronts[i];
-            for (int I = 0; I < P.fr[f].nR; ++I)
-                for (int J = 0; J <= I; ++J) { P.wg.push_back(f); P.wg.push_back(I); P.wg.push_back(J); }
+            for (int I = 0; I < P.fr[f].nR; ++I) { P.wg.push_back(f); P.wg.push_back(I); P.wg.push_back(I); }
             P.wg.push_back(f); P.wg.push_back(-1); P.wg.push_back(-1);                               // the inverse of L11 (device back pass)
             const double s = P.fr[f].s, tb = std::min(ND_TB, P.fr[f].b + 1);
             worst = std::max(worst, s * s * s / 3 + 2 * s * s * tb + s * tb * tb);
+        }
+        P.lvl_wg_split[l] = (int)P.wg.size() / 3;
+        for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) {                                     // ... and the off-diagonal Schur tiles
+            const int f = P.lvl_fronts[i];
+            for (int I = 0; I < P.fr[f].nR; ++I)
+                for (int J = 0; J < I; ++J) { P.wg.push_back(f); P.wg.push_back(I); P.wg.push_back(J); }
         }
         P.flops_crit += worst;
         P.lvl_wg_ptr[l + 1] = (int)P.wg.size() / 3;

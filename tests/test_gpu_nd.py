@@ -160,3 +160,20 @@ def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypat
     assert (big["status"] == 0).sum() > 8000 and max(t["inner"] for t in ta.trials) > 1 and all(t["inner"] == 1 for t in tb.trials)
     assert np.allclose(ra["pose_q"], rb["pose_q"], atol=1e-6, rtol=0) and np.allclose(ra["pose_t"], rb["pose_t"], atol=1e-5, rtol=0)
     assert np.array_equal(ra["f_status"], rb["f_status"]) and ra["lost"] == rb["lost"] and np.allclose(ra["f_pos"], rb["f_pos"], atol=1e-4, rtol=0)
+
+
+def test_crowded_levels_in_two_launches_give_the_same_bits(ctx, monkeypatch):
+    """A level with more workgroups than CUs runs as two launches -- diagonal / inverse workgroups (k_nd_level), then the off-diagonal
+    Schur tiles from the rows of L21 those left (k_nd_tile) -- against one launch per level (NRS_ND_NO_SPLIT=1): same operands, same
+    matrix-core sequence, hence the same bits (systems whose lowest levels are crowded: 2500 and 4446 points)."""
+    import nrs_synth as S
+    for n in (2500, 4446):
+        pos, last, pairs, Dn, Vp, bn = S.nd_block_system(n)
+        monkeypatch.delenv("NRS_ND_NO_SPLIT", raising=False)
+        ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
+        monkeypatch.setenv("NRS_ND_NO_SPLIT", "1")
+        ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
+        monkeypatch.delenv("NRS_ND_NO_SPLIT", raising=False)
+        assert ok and ok2 and st == st2 and st["workgroups"] > 800 and np.array_equal(x, x2), n
+        okh, xh, sth = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
+        assert okh and np.allclose(x, xh, rtol=0, atol=1e-11 * np.abs(xh).max())
