@@ -107,7 +107,16 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                             case 1: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 1>), g, b, shm, c->stream, d, xl, cls); break;
                             case 2: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 2>), g, b, shm, c->stream, d, xl, cls); break;
                             case 3: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 3>), g, b, shm, c->stream, d, xl, cls); break;
-                            default: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 4>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 4: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 4>), g, b, shm, c->stream, d, xl, cls); break;
+                            // round 5 (4-byte damper headers throughout; 6..9 compute right results): 5 half the damper slots,
+                            // 6 non-temporal streams, 7 two waves per SIMD with 8-slot batches, 8 the same with 10, 9 three waves with 6
+                            case 5: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 5, true>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 6: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true, false, false, 4, true>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 7: hipLaunchKernelGGL((k_lin_plain<2, 2, 0, true, 0, true, false, false, 8>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 8: hipLaunchKernelGGL((k_lin_plain<2, 2, 0, true, 0, true, false, false, 10>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 9: hipLaunchKernelGGL((k_lin_plain<2, 3, 0, true, 0, true, false, false, 6>), g, b, shm, c->stream, d, xl, cls); break;
+                            case 10: hipLaunchKernelGGL((k_lin_plain<2, 2, 0, true, 0, true, false, false, 8, true>), g, b, shm, c->stream, d, xl, cls); break;
+                            default: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true>), g, b, shm, c->stream, d, xl, cls); break;
                         }
                         break;
                     }
@@ -119,6 +128,9 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
     default: hipLaunchKernelGGL((k_lin_plain<2, 4, CAMV, true, 0, true, true, true>), g, b, shm, c->stream, d, xl, cls); break; }
                         if (d.cam.model == 0) { NRS_LIN_RC(0) } else { NRS_LIN_RC(1) }
 #undef NRS_LIN_RC
+                    } else if (d.h4 && d.nt) {                      // (streams beyond the Infinity Cache: non-temporal accesses)
+                        if (d.cam.model == 0) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true, false, false, 4, true>), g, b, shm, c->stream, d, xl, cls);
+                        else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true, 0, true, false, false, 4, true>), g, b, shm, c->stream, d, xl, cls);
                     } else if (d.h4) {                              // (implies tp)
                         if (d.cam.model == 0) hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
                         else hipLaunchKernelGGL((k_lin_plain<2, 4, 1, true, 0, true>), g, b, shm, c->stream, d, xl, cls);
@@ -236,6 +248,7 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
                 if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 1) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, true, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 2) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else if (d.plain && d.tp_ok && d.h4 && rc_of(d, cls) == 3) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
+                else if (d.plain && d.tp_ok && d.h4 && d.nt) hipLaunchKernelGGL((k_spmv_f<2, false, true, true, false, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else if (d.plain && d.tp_ok && d.h4) hipLaunchKernelGGL((k_spmv_f<2, false, true, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else if (d.plain && d.tp_ok) hipLaunchKernelGGL((k_spmv_f<2, false, true>), g, b, shm, c->stream, d, lam, cls, it, tol2);
                 else hipLaunchKernelGGL((k_spmv_f<2, false>), g, b, shm, c->stream, d, lam, cls, it, tol2);

@@ -166,8 +166,12 @@ __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo
         }
 }
 
-__global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained) {   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
+// NTH threads per workgroup: 256, or 512 (two waves per SIMD: seven waves instead of three on the trailing updates next to the diagonal
+// block, one pass over the children's slots instead of two, a Schur tile per wave); which wave computes a tile does not change its bits
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained) {   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
     extern __shared__ double sm[];
+    constexpr int NW = NTH / 64, NT3 = (9 + NW - 1) / NW;          // waves; Schur tiles (of nine) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NdWgD wd = N.wg[wg0 + blockIdx.x];                        // (front descriptor inlined: one scalar round trip)
     const int I = wd.I, J = wd.J;
@@ -198,12 +202,12 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         if (two && rb >= ND_TB * J && rb < ND_TB * J + ND_TB) return rowJ0 + rb - ND_TB * J;
         return -1;
     };
-    constexpr int NE = 2;
+    constexpr int NE = 512 / NTH;
     NdEnt En[NE];
     double ev[NE][9];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-        const int e = F.ent_off + min(tid + 256 * u, F.n_ent - 1);
+        const int e = F.ent_off + min(tid + NTH * u, F.n_ent - 1);
         En[u] = N.ent[e];
         const double* v = N.ev + 9 * (size_t)e;
 #pragma unroll
@@ -214,9 +218,9 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     else if (tid < 32) { const int np = 16 * J + tid - 16; pmj[tid - 16] = np <= F.b / 3 ? N.pmap[F.pmap_off + np] : (int16_t)-1; }
     const size_t slot = (size_t)(m + 1) * F.ldA;
     const double* A0 = N.A + F.A_off;
-    nd_v4d acc[3];
+    nd_v4d acc[NT3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NT3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
     if (chained && F.n_ch > 0) {
         // every level in one launch: wait until the children's workgroups (smaller block indices: dispatched before this one, so a full
         // chip cannot deadlock; bounded all the same) have delivered their tiles -- wd.pad of them per solve -- then read past stale lines
@@ -238,10 +242,10 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
             const int fr = s + ND_TB * I + r, fc = s + ND_TB * J + cc;
             return (size_t)max(fr, fc) * F.ldA + min(fr, fc);
         };
-        double tv[2][3][4];
+        double tv[2][NT3][4];
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+        for (int t3 = 0; t3 < NT3; ++t3) {
+            const int t = wave + NW * t3, ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
@@ -253,13 +257,13 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
             }
         }
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3)
+        for (int t3 = 0; t3 < NT3; ++t3)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[t3][g] = tv[0][t3][g] + (F.n_ch > 1 ? tv[1][t3][g] : 0.0);
         for (int k = 2; k < F.n_ch; ++k)                           // (more than two children: a separator whose halves fell apart)
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+            for (int t3 = 0; t3 < NT3; ++t3) {
+                const int t = wave + NW * t3, ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
@@ -269,21 +273,22 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     }
     {
         double2* W2 = reinterpret_cast<double2*>(W);
-        for (int i = tid; i < (nrow * ND_LD) >> 1; i += 256) W2[i] = make_double2(0.0, 0.0);
+        for (int i = tid; i < (nrow * ND_LD) >> 1; i += NTH) W2[i] = make_double2(0.0, 0.0);
     }
     __syncthreads();
     if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;       // padding columns: unit diagonal
     if (inv && tid < s) W[(s16 + tid) * ND_LD + tid] = 1.0;
     if (F.n_ch > 0) {
-        // panel rows of this workgroup <- sum of the slots: W row wr = ty + 16 i is front row fr; thread (tx, ty) takes the column pairs 2 tx + 32 j
+        // panel rows of this workgroup <- sum of the slots: W row wr = ty + RG i is front row fr; thread (tx, ty) takes the column pairs 2 tx + 32 j
+        constexpr int RG = NTH / 16;
         const int tx = tid & 15, ty = tid >> 4;
 #pragma unroll 1
-        for (int i0 = 0; 16 * i0 < nrow; i0 += 6) {
+        for (int i0 = 0; RG * i0 < nrow; i0 += 6) {
             double2 v0[6][3], v1[6][3];
             bool ok[6][3], ok2[6][3];                               // (second column of the pair: only below the row's limit)
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int wr = ty + 16 * (i0 + i);
+                const int wr = ty + RG * (i0 + i);
                 int fr = -1, lim = s;                              // columns [0, lim) of front row fr
                 if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
                 else if (wr < s16 + ND_TB) { if (wr - s16 < rI) fr = s + ND_TB * I + wr - s16; }
@@ -303,14 +308,14 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (ok[i][j]) {
-                        double* d = W + (ty + 16 * (i0 + i)) * ND_LD + 2 * tx + 32 * j;
+                        double* d = W + (ty + RG * (i0 + i)) * ND_LD + 2 * tx + 32 * j;
                         d[0] = v0[i][j].x + (F.n_ch > 1 ? v1[i][j].x : 0.0);
                         if (ok2[i][j]) d[1] = v0[i][j].y + (F.n_ch > 1 ? v1[i][j].y : 0.0);
                     }
         }
         for (int k = 2; k < F.n_ch; ++k) {
             __syncthreads();
-            for (int idx = tid; idx < nrow * 48; idx += 256) {
+            for (int idx = tid; idx < nrow * 48; idx += NTH) {
                 const int wr = idx / 48, q = 2 * (idx - 48 * wr);
                 int fr = -1, lim = s;
                 if (wr < s16) { if (wr < s) { fr = wr; lim = wr + 1; } }
@@ -337,10 +342,10 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         };
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
-            const int wr = tid + 256 * u < F.n_ent ? entry_row(En[u]) : -1;
+            const int wr = tid + NTH * u < F.n_ent ? entry_row(En[u]) : -1;
             if (wr >= 0) put_entry(En[u], ev[u], wr);
         }
-        for (int e = tid + 256 * NE; e < F.n_ent; e += 256) {      // (fronts with more than 512 entries)
+        for (int e = tid + NTH * NE; e < F.n_ent; e += NTH) {      // (fronts with more than 512 entries)
             const NdEnt E = N.ent[F.ent_off + e];
             const int wr = entry_row(E);
             if (wr < 0) continue;
@@ -366,10 +371,10 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
         if (wave == 0) {
             if (kb > 0) nd_update(W, lane, k0 - 16, kb, kb + 1, kb + 1, 0, 1);
             nd_diag_factor(W, dinv, k0, lane, bad);
-        } else if (kb > 0) nd_update(W, lane, k0 - 16, kb, nb, nrt, wave - 1, 3, 1);
+        } else if (kb > 0) nd_update(W, lane, k0 - 16, kb, nb, nrt, wave - 1, NW - 1, 1);
         __syncthreads();
         if (N.clk) { const long long t = wall_clock64(); tA += t - tq; tq = t; }
-        {
+        if (k0 + 16 + 64 * wave < nrow) {                          // (wave-uniform: the waves beyond the panel's rows stay out of the VALU's way)
             // (B) one panel row per thread: x L_kk^T = a, column by column.  L_kk sits in registers, row (lane & 15) in every 16-lane
             // row of the wave, and L[q][p] reaches the FMA through a DPP row broadcast: no LDS read inside the substitution
             // (it was 136 broadcast reads per thread: 1.07 -> 0.4 us per step).  Every lane computes; only the store is predicated.
@@ -394,15 +399,15 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     // ---- Schur tile: U_IJ = F22_IJ - L21_I L21_J^T (k outermost: the wave's tiles advance together, operands of four k-steps in flight),
     // written into the parent's assembly slot at the parent's positions of its rows and columns (the lower one of the two)
     if (F.par >= 0 && !inv) {
-        int ti[3], tj[3];
+        int ti[NT3], tj[NT3];
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) { const int t = min(wave + 4 * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
-        const bool third = wave == 0;                              // (tiles 0..8 over four waves: wave 0 has three, the others two)
+        for (int t3 = 0; t3 < NT3; ++t3) { const int t = min(wave + NW * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
+        const bool last = wave + NW * (NT3 - 1) < 9;                // (tiles 0..8 over the waves: wave 0 has one more than the others)
 #pragma unroll 1
         for (int k4 = 0; k4 < (s16 >> 4); ++k4) {
-            double av[3][4], bv[3][4];
+            double av[NT3][4], bv[NT3][4];
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3)
+            for (int t3 = 0; t3 < NT3; ++t3)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     av[t3][kk] = -W[(rowI0 + 16 * ti[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
@@ -410,15 +415,15 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
                 }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc[1], 0, 0, 0);
-                if (third) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2][kk], bv[2][kk], acc[2], 0, 0, 0);
+#pragma unroll
+                for (int t3 = 0; t3 < NT3 - 1; ++t3) acc[t3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t3][kk], bv[t3][kk], acc[t3], 0, 0, 0);
+                if (last) acc[NT3 - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[NT3 - 1][kk], bv[NT3 - 1][kk], acc[NT3 - 1], 0, 0, 0);
             }
         }
         double* Ap = N.A + F.pA_off;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            if (wave + 4 * t3 >= 9) break;
+        for (int t3 = 0; t3 < NT3; ++t3) {
+            if (wave + NW * t3 >= 9) break;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti[t3] + (lane >> 4) + 4 * g, cc = 16 * tj[t3] + (lane & 15);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     if (inv) {                                                     // (L11^-1)^T, upper triangular, behind the panel
         const int tx = tid & 31, ty = tid >> 5;
         double* LT = N.Lp + F.L_off + (size_t)(m + 2) * s;
-        for (int r = ty; r < s; r += 8)
+        for (int r = ty; r < s; r += NTH / 32)
             for (int q = tx; q < s; q += 32) LT[(size_t)r * s + q] = q >= r ? W[(s16 + r) * ND_LD + q] : 0.0;
     }
     // ---- the factor: block I's rows of L21 (and y^T) by the DIAGONAL workgroups (I, I) -- those run in every form of a level, also when its
@@ -447,10 +452,10 @@ __global__ __launch_bounds__(256) void k_nd_level(NdDev N, int wg0, double lam, 
     if (J == I && !inv) {
         const int tx = tid & 31, ty = tid >> 5;
         double* L = N.Lp + F.L_off;
-        for (int r = ty; r < rI; r += 8)
+        for (int r = ty; r < rI; r += NTH / 32)
             for (int q = tx; q < s; q += 32) L[(size_t)(s + ND_TB * I + r) * s + q] = W[(rowI0 + r) * ND_LD + q];
         if (I == 0) {
-            for (int p = ty; p < s; p += 8)
+            for (int p = ty; p < s; p += NTH / 32)
                 for (int q = tx; q < s; q += 32) L[(size_t)p * s + q] = q <= p ? W[p * ND_LD + q] : 0.0;
             if (tid < s) L[(size_t)(m + 1) * s + tid] = dinv[tid];
             if (bad && lane == 0) N.flags[2] = 1;                  // (wave 0 saw the pivots)
@@ -815,7 +820,8 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
             }
         }
     if (!S.attr_set) {
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         S.attr_set = true;
@@ -840,10 +846,18 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // bounded spins in k_nd_level / k_nd_back (a wait that runs out raises flags[2] = 2 -> NRS_ERR_HIP, never a hang) and the
     // resident-at-once condition, under which the order does not matter at all.
     const bool per_level = getenv("NRS_ND_LEVELS") != nullptr;     // (read per call: the tests switch it between solves)
+    // 512 threads per workgroup unless NRS_ND_THREADS=256 (a level is one workgroup's latency: eight waves shorten its trailing updates,
+    // its reads of the children's slots and its Schur tiles; same bits either way)
+    const char* nth_env = getenv("NRS_ND_THREADS");
+    const bool wide = !(nth_env && atoi(nth_env) == 256);
+    auto level = [&](int n, size_t shm, int wg0, int chained) {
+        if (wide) hipLaunchKernelGGL(k_nd_level<512>, dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        else hipLaunchKernelGGL(k_nd_level<256>, dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+    };
     if (!per_level && !S.dev.clk && P.lvl_wg_ptr[P.n_levels] <= c->prop.multiProcessorCount) {
         size_t shm = 0;
         for (int l = 0; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
-        hipLaunchKernelGGL(k_nd_level, dim3(P.lvl_wg_ptr[P.n_levels]), dim3(256), shm, c->stream, S.dev, 0, lam, epoch, ++S.chained);
+        level(P.lvl_wg_ptr[P.n_levels], shm, 0, ++S.chained);
     } else {
         // a CROWDED level (more workgroups than CUs: they would run in rounds, one per CU, each factorising its front's panel for one
         // tile) runs as two launches: the diagonal and inverse workgroups factorise and leave their rows of L21, k_nd_tile makes the
@@ -852,9 +866,9 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         for (int l = 0; l < P.n_levels; ++l) {
             const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
             if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
-                hipLaunchKernelGGL(k_nd_level, dim3(nA), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
+                level(nA, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
                 hipLaunchKernelGGL(k_nd_tile, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
-            } else hipLaunchKernelGGL(k_nd_level, dim3(n), dim3(256), S.lvl_shm_fac[l], c->stream, S.dev, P.lvl_wg_ptr[l], lam, epoch, 0);
+            } else level(n, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
         }
     }
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 //                 included), s re-formed from the weight unless the edge's Huber kernel is active;
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
-template <int T, bool DF, bool TPC = false, bool H4 = false, bool RCS = false, bool RCD = false>   // H4: 4-byte damper headers (Dev::d_h4; needs TPC); RCS / RCD: spring / damper factors re-formed from the staged linearisation point (Dev::rc)
+template <int T, bool DF, bool TPC = false, bool H4 = false, bool RCS = false, bool RCD = false, bool NT = false>   // NT: non-temporal stream loads (Dev::nt); H4: 4-byte damper headers (Dev::d_h4; needs TPC); RCS / RCD: spring / damper factors re-formed from the staged linearisation point (Dev::rc)
 __global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
     static_assert(!(RCS || RCD) || (TPC && H4 && !DF), "factor recomputation: plain windows with cached partners and 4-byte headers");
     __shared__ double lds[4 * 9];
@@ -267,7 +267,10 @@ __global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, 
             if (TPC) {
                 om[q] = 0xFFFFu; qc[q] = 0.0;
                 if (RCS) { d0w[q] = 0x3F800000u; if ((idx + 64 * q - sbeg - lane) / 64 < my_s) { om[q] = P.s_om[idx + 64 * q]; d0w[q] = __float_as_uint(P.s_d0[idx + 64 * q]); } continue; }
-                if ((idx + 64 * q - sbeg - lane) / 64 < my_s) { om[q] = P.s_om[idx + 64 * q]; qc[q] = P.s_qc[idx + 64 * q]; }
+                if ((idx + 64 * q - sbeg - lane) / 64 < my_s) {
+                    if (NT) { om[q] = __builtin_nontemporal_load(P.s_om + idx + 64 * q); qc[q] = __builtin_nontemporal_load(P.s_qc + idx + 64 * q); }
+                    else { om[q] = P.s_om[idx + 64 * q]; qc[q] = P.s_qc[idx + 64 * q]; }
+                }
                 continue;
             }
             const int j = min(idx + 64 * q, s_last);
@@ -281,7 +284,9 @@ __global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, 
             if (TPC) {
                 h[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); sv[q] = 0.0;
                 if (H4 && RCD) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; h[q].y = __float_as_uint(P.d_w[idx + 64 * q]); } }
-                else if (H4) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q].x = P.d_h4[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; } }
+                else if (H4) { if ((idx + 64 * q - dbeg - lane) / 64 < my_d) {
+                    if (NT) { h[q].x = __builtin_nontemporal_load(P.d_h4 + idx + 64 * q); sv[q] = __builtin_nontemporal_load(P.d_s + idx + 64 * q); }
+                    else { h[q].x = P.d_h4[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; } } }
                 else if ((idx + 64 * q - dbeg - lane) / 64 < my_d) { h[q] = P.d_hdr[idx + 64 * q]; sv[q] = P.d_s[idx + 64 * q]; }
                 continue;
             }

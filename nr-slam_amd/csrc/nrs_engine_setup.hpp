@@ -136,12 +136,14 @@ __global__ void k_compact_headers(size_t n, const uint2* __restrict__ hdr, uint3
 }
 static void engine_compact_headers(nrs_ctx* c, Engine* e) {
     Dev& d = e->d;
-    d.h4 = 0; d.rc = 0;
+    d.h4 = 0; d.rc = 0; d.nt = 0;
     if (!(d.plain && d.tp_ok && d.use_lds && !d.fused && d.T == 2) || getenv("NRS_NO_H4")) return;
     if (d.tile_rows + std::max(d.cap_h[0], d.cap_h[1]) + 2 >= 4096 || d.sd_nnz <= 0) return;
     hipLaunchKernelGGL(k_compact_headers, dim3((unsigned)(((size_t)d.sd_nnz + 255) / 256)), dim3(256), 0, c->stream, (size_t)d.sd_nnz, d.d_hdr, d.d_h4);
     d.h4 = 1;
     if (const char* v = getenv("NRS_RC")) d.rc = atoi(v) & 3;
+    d.nt = 12 * ((size_t)d.ss_nnz + (size_t)d.sd_nnz) > ((size_t)128 << 20);   // the streams (with the vectors next to them) do not stay in the 256 MB Infinity Cache between launches
+    if (const char* v = getenv("NRS_NT")) d.nt = atoi(v) != 0;
 }
 
 template <class F>

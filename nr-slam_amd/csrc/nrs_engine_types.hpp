@@ -91,6 +91,8 @@ struct Dev {
     uint32_t* row_tp; int tp_ok;
     int rc;                          // plain two-kernel path with h4: bit 0 / bit 1 = the spring / damper factors are not stored -- the operator re-forms them from the
                                      // staged linearisation point (spring_qc / damper_s, nrs_engine_linearize.hpp): 8 instead of 12 bytes per incidence there, no factor stores in the lineariser
+    int nt;                          // h4 path: the incidence streams (12 bytes per slot) exceed the Infinity Cache -- read / written once per launch with the non-temporal hint
+                                     // (k_lin_plain C4 2.19 -> 2.10 ms; NRS_NT=0 / 1 overrides)
     uint32_t* d_h4; int h4;          // plain two-kernel path with cached temporal partners: 4-byte damper headers {o0 : 12 | o2 : 12 | meta : 8} derived from d_hdr
                                      // (the partner o1 is the row's own and tile-local ids stay below 4096): 8 instead of 12 bytes per damper incidence in both kernels
     uint32_t* row_cnt;               // plain windows: {spring incidences | damper incidences << 16} of every row: a lane's slots beyond its share are padding
