@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
     nd_v4d acc[NT3];
 #pragma unroll
     for (int q = 0; q < NT3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
-    if (chained && F.n_ch > 0) {
+    if (chained && wd.pad > 0) {                                   // (pad: the tiles this front's children deliver INSIDE this launch, per solve)
         // every level in one launch: wait until the children's workgroups (smaller block indices: dispatched before this one, so a full
         // chip cannot deadlock; bounded all the same) have delivered their tiles -- wd.pad of them per solve -- then read past stale lines
         if (tid == 0) {
@@ -271,15 +271,17 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
                 }
             }
     }
-    {
+    if (F.n_ch == 0) {                                             // a leaf: the panel starts from zero (and the unit diagonals below)
         double2* W2 = reinterpret_cast<double2*>(W);
         for (int i = tid; i < (nrow * ND_LD) >> 1; i += NTH) W2[i] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;       // padding columns: unit diagonal
-    if (inv && tid < s) W[(s16 + tid) * ND_LD + tid] = 1.0;
-    if (F.n_ch > 0) {
-        // panel rows of this workgroup <- sum of the slots: W row wr = ty + RG i is front row fr; thread (tx, ty) takes the column pairs 2 tx + 32 j
+        __syncthreads();
+        if (tid < s16 - s) W[(s + tid) * ND_LD + s + tid] = 1.0;   // padding columns: unit diagonal
+        if (inv && tid < s) W[(s16 + tid) * ND_LD + tid] = 1.0;
+    } else {
+        // panel rows of this workgroup <- sum of the children's slots: W row wr = ty + RG i is front row fr; thread (tx, ty) takes the column
+        // pairs 2 tx + 32 j.  The pass writes EVERY element of the panel (rows < nrow, columns < 96) -- zero where no slot element
+        // belongs, one on the unit diagonals of the padding columns and of the inverse workgroup's identity -- so nothing is zeroed
+        // first and no barrier stands between these loads and the requests above: one memory round trip for entries, tile and panel
         constexpr int RG = NTH / 16;
         const int tx = tid & 15, ty = tid >> 4;
 #pragma unroll 1
@@ -304,14 +306,19 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 6; ++i) {
+                const int wr = ty + RG * (i0 + i);
+                if (wr >= nrow) continue;
+                // the one of this row: padding columns' unit diagonal (rows s .. s16), the identity under F11 (inverse workgroup)
+                const int one = wr >= s && wr < s16 ? wr : (inv && wr >= s16 && wr - s16 < s ? wr - s16 : -1);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (ok[i][j]) {
-                        double* d = W + (ty + RG * (i0 + i)) * ND_LD + 2 * tx + 32 * j;
-                        d[0] = v0[i][j].x + (F.n_ch > 1 ? v1[i][j].x : 0.0);
-                        if (ok2[i][j]) d[1] = v0[i][j].y + (F.n_ch > 1 ? v1[i][j].y : 0.0);
-                    }
+                for (int j = 0; j < 3; ++j) {
+                    const int q = 2 * tx + 32 * j;
+                    double* d = W + wr * ND_LD + q;
+                    d[0] = ok[i][j] ? v0[i][j].x + (F.n_ch > 1 ? v1[i][j].x : 0.0) : (q == one ? 1.0 : 0.0);
+                    d[1] = ok2[i][j] ? v0[i][j].y + (F.n_ch > 1 ? v1[i][j].y : 0.0) : (q + 1 == one ? 1.0 : 0.0);
+                }
+            }
         }
         for (int k = 2; k < F.n_ch; ++k) {
             __syncthreads();
@@ -754,6 +761,7 @@ struct NdSolver {
     std::vector<char> h_stage;       // host image of the plan arrays (one upload)
     int epoch = 0;                   // solves so far (the flags of the single-launch back pass count them)
     int chained = 0;                 // ... of which with the single-launch factorisation (its per-front counters count those)
+    int chain_from = 0;              // the levels from here up run as ONE launch (their workgroups are resident at once); n_levels: none
     size_t shm_back_all = 0;
     bool attr_set = false;
     double* d_ev = nullptr;
@@ -784,8 +792,19 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         NdFrontD* hl = reinterpret_cast<NdFrontD*>(S.h_stage.data() + o_lf);
         // (device copies of the descriptor: cmap_off, the host reference's gather map, holds the front's own index)
         // (pad: how many workgroups write into this front's assembly slots in one factorisation -- its children's (I, J) pairs)
-        std::vector<int> need(P.fr.size(), 0);
-        for (const NdFrontD& f : P.fr) if (f.par >= 0) need[f.par] += f.nR * (f.nR + 1) / 2;
+        // the top of the tree in one launch: the highest levels whose workgroups are resident at once (one per CU), when that spares at
+        // least one launch; a front's counter then counts the tiles of its children INSIDE that launch (the others are complete before it)
+        std::vector<int> need(P.fr.size(), 0), lvl_of(P.fr.size(), 0);
+        for (int l = 0; l < P.n_levels; ++l)
+            for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) lvl_of[P.lvl_fronts[i]] = l;
+        S.chain_from = P.n_levels;
+        while (S.chain_from > 0 && P.lvl_wg_ptr[P.n_levels] - P.lvl_wg_ptr[S.chain_from - 1] <= c->prop.multiProcessorCount) --S.chain_from;
+        // Measured with 512-thread workgroups (round 5): the launch boundaries are the cheaper hand-over at every size -- 155 us per factorise +
+        // solve against 163 chained at 543 points (everything resident), 201 / 223 at 1013, 480 / 501 at 4446 (top seven levels chained) -- so
+        // the chained form is opt-in (NRS_ND_CHAIN=1, read when a plan is uploaded; the tests hold it to the per-level form bit for bit)
+        if (P.n_levels - S.chain_from < 2 || !getenv("NRS_ND_CHAIN")) S.chain_from = P.n_levels;
+        for (size_t f = 0; f < P.fr.size(); ++f)
+            if (P.fr[f].par >= 0 && lvl_of[f] >= S.chain_from) need[P.fr[f].par] += P.fr[f].nR * (P.fr[f].nR + 1) / 2;
         for (size_t w = 0; w < P.wg.size() / 3; ++w) { hw[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], need[P.wg[3 * w]]}; hw[w].F.cmap_off = P.wg[3 * w]; }
         for (size_t i = 0; i < P.lvl_fronts.size(); ++i) { hl[i] = P.fr[P.lvl_fronts[i]]; hl[i].cmap_off = P.lvl_fronts[i]; }
     }
@@ -835,10 +854,10 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
 static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     const NdPlan& P = S.plan;
     const int epoch = ++S.epoch;
-    // all levels in ONE launch, a front's workgroups waiting for its children's tiles (no launch boundaries: 176 -> 165 us per
-    // factorise + solve at 543 points), when every workgroup of the factorisation is resident at once (one per CU).  Beyond that the
-    // release / acquire pair of every workgroup costs more than the boundaries it replaces (231 -> 228 us at 1013 points, 329 -> 329
-    // at 2220, 547 -> 569 at 4525): one launch per level (also with NRS_ND_LEVELS=1, and whenever the phase clocks are on)
+    // One launch per level.  Opt-in (NRS_ND_CHAIN=1): the TOP of the tree in ONE launch, a front's workgroups waiting for the tiles of its
+    // children inside that launch -- the highest levels whose workgroups are all resident at once (one per CU), the whole factorisation
+    // for frames of <= ~800 points.  It paid with 256-thread workgroups at 543 points (176 -> 165 us per factorise + solve, round 4) and
+    // does not with 512-thread ones (nd_upload); NRS_ND_LEVELS=1, and the phase clocks, put every level in a launch of its own regardless.
     // "Resident at once" is what makes the waits safe and is a property of the device, not a constant: one workgroup per CU (a panel
     // fills most of a CU's LDS), so the bound is the CU count of THIS device (256 on a whole MI355X, fewer in a partition mode).  The
     // no-deadlock argument: a front's workgroups wait only for workgroups of its children, which sit at SMALLER block indices, and the
@@ -854,21 +873,23 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         if (wide) hipLaunchKernelGGL(k_nd_level<512>, dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
         else hipLaunchKernelGGL(k_nd_level<256>, dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
     };
-    if (!per_level && !S.dev.clk && P.lvl_wg_ptr[P.n_levels] <= c->prop.multiProcessorCount) {
-        size_t shm = 0;
-        for (int l = 0; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
-        level(P.lvl_wg_ptr[P.n_levels], shm, 0, ++S.chained);
-    } else {
+    const int chain_from = per_level || S.dev.clk ? P.n_levels : S.chain_from;
+    {
         // a CROWDED level (more workgroups than CUs: they would run in rounds, one per CU, each factorising its front's panel for one
         // tile) runs as two launches: the diagonal and inverse workgroups factorise and leave their rows of L21, k_nd_tile makes the
         // off-diagonal tiles from them (NRS_ND_NO_SPLIT=1: one launch per level throughout; the bits are the same)
         const bool no_split = getenv("NRS_ND_NO_SPLIT") != nullptr;
-        for (int l = 0; l < P.n_levels; ++l) {
+        for (int l = 0; l < chain_from; ++l) {
             const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
             if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
                 level(nA, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
                 hipLaunchKernelGGL(k_nd_tile, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
             } else level(n, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
+        }
+        if (chain_from < P.n_levels) {                             // the levels above in one launch (all of them when the whole factorisation is resident at once)
+            size_t shm = 0;
+            for (int l = chain_from; l < P.n_levels; ++l) shm = std::max(shm, S.lvl_shm_fac[l]);
+            level(P.lvl_wg_ptr[P.n_levels] - P.lvl_wg_ptr[chain_from], shm, P.lvl_wg_ptr[chain_from], ++S.chained);
         }
     }
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that

@@ -106,17 +106,23 @@ def test_plan_cache_reuse_is_invisible():
 
 
 def test_chained_and_per_level_factorisation_give_the_same_bits(ctx, monkeypatch):
-    """One launch for all levels (fronts waiting for their children's tiles on agent-scope counters: taken when every workgroup of the
-    factorisation is resident at once, <= the device's CU count) against one launch per level (NRS_ND_LEVELS=1): the same arithmetic in
-    the same order, hence the same bits -- on systems small enough for the chained form (40 / 120 nodes) and on one that is not (1200)."""
-    for n, seed in ((40, 21), (120, 22), (1200, 23)):
+    """The top of the tree in one launch (NRS_ND_CHAIN=1: fronts waiting for their children's tiles on agent-scope counters, for the
+    highest levels whose workgroups are all resident at once -- every level of the small systems, the top ones of the large) against one
+    launch per level (the default since the levels run on 512-thread workgroups): the same arithmetic in the same order, hence the
+    same bits; 256-thread workgroups (NRS_ND_THREADS=256) likewise."""
+    for n, seed in ((40, 21), (120, 22), (1200, 23), (3000, 24)):
         pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, True)
-        monkeypatch.delenv("NRS_ND_LEVELS", raising=False)
+        monkeypatch.setenv("NRS_ND_CHAIN", "1")
         ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
         monkeypatch.setenv("NRS_ND_LEVELS", "1")
-        ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        ok1, x1, st1, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
         monkeypatch.delenv("NRS_ND_LEVELS", raising=False)
-        assert ok and ok2 and st == st2 and np.array_equal(x, x2), n
+        monkeypatch.delenv("NRS_ND_CHAIN", raising=False)
+        ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.setenv("NRS_ND_THREADS", "256")
+        ok3, x3, st3, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.delenv("NRS_ND_THREADS", raising=False)
+        assert ok and ok1 and ok2 and ok3 and st == st2 and np.array_equal(x, x1) and np.array_equal(x, x2) and np.array_equal(x, x3), n
 
 
 def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypatch):

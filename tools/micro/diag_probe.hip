@@ -23,6 +23,56 @@ template <int V, int J> __device__ inline void cols(double (&a)[16], double (&rr
         cols<V, J + 1>(a, rr, i, bad);
     }
 }
+
+// variant 2 (round 5): column J's pivot chain (broadcast, rsq + Newton step, scaling) INTERLEAVED with the pending updates of column
+// J - 1 -- the wave issues in order, so in the recursive form above a column's ~15 independent FMAs and the next column's ~10 dependent
+// chain operations run one after the other; here the order is pinned by scheduling barriers
+#define SB __builtin_amdgcn_sched_barrier(0)
+template <int J, int K> __device__ inline void pend(double (&a)[16], double pnl, double pl) {
+    if constexpr (J > 0 && K < 16) fmac_bc<K>(a[K], pnl, pl);
+}
+template <int J> __device__ inline void colp(double (&a)[16], double (&rr)[16], int& bad, double pl, double pnl) {
+    if constexpr (J < 16) {
+        pend<J, J>(a, pnl, pl);                                    // a[J] is final
+        SB;
+        pend<J, J + 1>(a, pnl, pl); pend<J, J + 2>(a, pnl, pl);
+        SB;
+        double ajj = bc<J>(a[J]);
+        SB;
+        pend<J, J + 3>(a, pnl, pl);
+        SB;
+        const bool ok = ajj > 0.0; bad |= !ok; ajj = ok ? ajj : 1.0;
+        SB;
+        pend<J, J + 4>(a, pnl, pl);
+        SB;
+        const double y = __builtin_amdgcn_rsq(ajj);
+        SB;
+        pend<J, J + 5>(a, pnl, pl); pend<J, J + 6>(a, pnl, pl); pend<J, J + 7>(a, pnl, pl);
+        SB;
+        const double t = -ajj * y;
+        SB;
+        pend<J, J + 8>(a, pnl, pl); pend<J, J + 9>(a, pnl, pl);
+        SB;
+        const double e = fma(t, y, 1.0);
+        SB;
+        pend<J, J + 10>(a, pnl, pl); pend<J, J + 11>(a, pnl, pl);
+        SB;
+        const double ye = y * e, f = fma(e, 0.375, 0.5);
+        SB;
+        pend<J, J + 12>(a, pnl, pl); pend<J, J + 13>(a, pnl, pl);
+        SB;
+        const double r = fma(ye, f, y);
+        SB;
+        pend<J, J + 14>(a, pnl, pl); pend<J, J + 15>(a, pnl, pl);
+        SB;
+        const double l = a[J] * r;
+        double nl = -l;
+        asm volatile("s_nop 1" : "+v"(nl));
+        a[J] = l; rr[J] = r;
+        SB;
+        colp<J + 1>(a, rr, bad, l, nl);
+    }
+}
 template <int V> __global__ void k(double* out, const double* in, long long* t, int reps) {
     __shared__ double W[16 * 17], dinv[16];
     const int lane = threadIdx.x & 63, i = lane & 15;
@@ -35,7 +85,7 @@ template <int V> __global__ void k(double* out, const double* in, long long* t, 
         const long long c0 = clock64();
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = W[i * 17 + j];
-        cols<V, 0>(a, rr, i, bad);
+        if constexpr (V == 2) colp<0>(a, rr, bad, 0.0, 0.0); else cols<V, 0>(a, rr, i, bad);
         if (lane < 16) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) if (j <= i) out[i * 16 + j] = a[j];
@@ -54,8 +104,9 @@ int main() {
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) h[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + abs(i - j));
     hipMalloc(&in, 2048); hipMalloc(&out, 4096); hipMalloc(&t, 64);
     hipMemcpy(in, h, 2048, hipMemcpyHostToDevice);
-    for (int v = 0; v < 2; ++v) for (int rep = 0; rep < 2; ++rep) {
-        if (v == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, out, in, t, 100); else hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, out, in, t, 100);
+    for (int v = 0; v < 3; ++v) for (int rep = 0; rep < 2; ++rep) {
+        if (v == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, out, in, t, 100); else if (v == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, out, in, t, 100);
+        else hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, out, in, t, 100);
         long long ht[2]; double ho[256];
         hipMemcpy(ht, t, 16, hipMemcpyDeviceToHost); hipMemcpy(ho, out, 2048, hipMemcpyDeviceToHost);
         double L[16][16] = {}, err = 0;                                // host check
