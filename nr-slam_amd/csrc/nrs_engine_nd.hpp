@@ -1319,6 +1319,12 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     catch (const std::exception& ex) { P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.err = ex.what(); }
     catch (...) { P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.err = "unknown exception in the plan thread"; }
 }
+// halves of a dissection of this many nodes go to threads of their own (first two levels; NRS_ND_PLAN_PAR=0: never; NRS_HOST_THREADS=1 likewise)
+static int nd_plan_par_min() {
+    if (const char* v = getenv("NRS_ND_PLAN_PAR")) return atoi(v);
+    if (const char* v = getenv("NRS_HOST_THREADS")) if (atoi(v) <= 1) return 0;
+    return std::thread::hardware_concurrency() >= 4 ? 700 : 0;
+}
 static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.st.reset();
     const bool tm = getenv("NRS_TIMING") != nullptr;
@@ -1372,8 +1378,13 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         if (a < 0 || b < 0 || a == b) return;
         keys.push_back(Key{((uint64_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), id});
     };
+    // (a2 gives every regulariser as a spring AND a damper over the same two vertices, index for index, OPT:281-335: one key per edge
+    // then stands for both -- half the records to sort; inside a pair the springs come first and the dampers after them, as they arrive)
+    bool twin = in.n_sp == in.n_dm;
+    for (int q = 0; twin && q < in.n_sp; ++q)
+        twin = in.sp_ij[2 * (size_t)q] == in.dm_idx[4 * (size_t)q + 2] && in.sp_ij[2 * (size_t)q + 1] == in.dm_idx[4 * (size_t)q + 3];
     for (int q = 0; q < in.n_sp; ++q) add(in.sp_ij[2 * (size_t)q], in.sp_ij[2 * (size_t)q + 1], q << 1);
-    for (int q = 0; q < in.n_dm; ++q) add(in.dm_idx[4 * (size_t)q + 2], in.dm_idx[4 * (size_t)q + 3], (q << 1) | 1);
+    if (!twin) for (int q = 0; q < in.n_dm; ++q) add(in.dm_idx[4 * (size_t)q + 2], in.dm_idx[4 * (size_t)q + 3], (q << 1) | 1);
     // embedded mode: the node pairs every skinned observation couples (all pairs of its <= 11 free nodes), with the products of
     // its weights, and per free node the observations that reach it; everything in observation order (fixed summation order)
     std::vector<NdSkT>& skt = P.skt;
@@ -1417,7 +1428,9 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
     for (size_t i = 0, st = 0; i < keys.size() || st < skt.size();) {
         const uint64_t kk = i < keys.size() && (st >= skt.size() || keys[i].k <= skt[st].k) ? keys[i].k : skt[st].k;
+        const size_t i0 = i;
         for (; i < keys.size() && keys[i].k == kk; ++i) T.eid.push_back(keys[i].id);
+        if (twin) for (size_t j = i0; j < i; ++j) T.eid.push_back(keys[j].id | 1);
         T.eptr.push_back((int)T.eid.size());
         T.pairs.push_back((int)(kk >> 32)); T.pairs.push_back((int)(kk & 0xFFFFFFFFu));
         T.pkind.push_back(0);
@@ -1438,7 +1451,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
-    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false);
+    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false, nd_plan_par_min());
     if (P.plan_ok && in.n_skin > 0) { nd_prep_ske(P, P.plan); nd_prep_ske_values(P, in.sk_om); }
     lap(2);
     if (tm) fprintf(stderr, "[nrs] direct solve set-up thread: key %.2f ms, pairs %.2f ms, plan %.2f ms\n", t_ms[0], t_ms[1], t_ms[2]);

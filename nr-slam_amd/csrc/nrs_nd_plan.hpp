@@ -19,7 +19,10 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <exception>
 #include <functional>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace nrs {
@@ -75,7 +78,7 @@ struct NdPlan {
 // n_nodes nodes at pos (geometry of the dissection), `last` nodes (the pose halves) are eliminated at the root whatever
 // their position; pairs: unique unordered couplings (a, b), a != b.  Returns false (err set) if the plan cannot be built.
 inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, int n_pairs, const int* pairs, NdPlan& P, std::string* err,
-                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN, bool with_cmap = true) {
+                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN, bool with_cmap = true, int par_min = 0) {
     auto fail = [&](const char* m) { if (err) *err = m; return false; };
     P = NdPlan();
     P.n_nodes = n_nodes; P.n_pairs = n_pairs;
@@ -98,44 +101,54 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
         }
     }
     // ---- separator tree by recursive coordinate bisection
+    // The two halves of a bisection are independent problems: with par_min > 0 the first two levels of the recursion hand one half each to a
+    // thread of its own when a half has that many nodes (a worker keeps its fronts in a list of its own; the lists are joined in the order a
+    // single thread creates the fronts in -- left subtree, right subtree, separator -- so the plan is the same, index for index)
     struct FH { std::vector<int> own, ch; };
-    std::vector<FH> F;
-    std::vector<int> side(n_nodes, 0), slot(n_nodes, 0), mark(n_nodes, 0);
-    int stamp = 0;
-    auto new_front = [&](std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; };
-    std::vector<std::pair<double, int>> keyed;
-    // orders v along its longest axis (not skip_axis): completely (split < 0), or only so far that the `split` smallest come first
-    auto axis_sort = [&](std::vector<int>& v, int skip_axis, int split = -1) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int u : v)
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos[3 * (size_t)u + a]); hi[a] = std::max(hi[a], pos[3 * (size_t)u + a]); }
-        int ax = -1;
-        for (int a = 0; a < 3; ++a)
-            if (a != skip_axis && (ax < 0 || hi[a] - lo[a] > hi[ax] - lo[ax])) ax = a;
-        keyed.resize(v.size());                                    // (coordinate, id) pairs: the sort touches no indirect memory
-        for (size_t i = 0; i < v.size(); ++i) keyed[i] = {pos[3 * (size_t)v[i] + ax], v[i]};
-        if (split < 0) {
-            std::sort(keyed.begin(), keyed.end());
-            for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
-        } else std::nth_element(keyed.begin(), keyed.begin() + split, keyed.end());     // (pairs are distinct: the two halves are determined; v stays as it is)
-        return ax;
-    };
-    // chain of fronts over one separator (or leaf) that is longer than a front may own
-    auto chain = [&](std::vector<int>& nodes, std::vector<int> ch) {
-        const int n = (int)nodes.size(), nc = (n + smax_n - 1) / smax_n;
-        int prev = -1;
-        for (int k = 0; k < nc; ++k) {
-            const int a = (int)((int64_t)n * k / nc), b = (int)((int64_t)n * (k + 1) / nc);
-            std::vector<int> own(nodes.begin() + a, nodes.begin() + b);
-            prev = new_front(std::move(own), k == 0 ? std::move(ch) : std::vector<int>{prev});
-        }
-        return prev;
-    };
     struct Rec {
-        std::vector<FH>& F; std::vector<int>& side; int& stamp; const std::vector<int>&ap, &an; const uint8_t* last;
-        decltype(axis_sort)& asort; decltype(chain)& mk_chain; int leaf_n; std::vector<int>& slot; bool vertex_cover;
-        const std::vector<std::pair<double, int>>& keyed; std::vector<int>& mark;
-        std::vector<int> run(std::vector<int> v) {                   // (v ascending by node index, here and in every call below)
+        const double* pos; const std::vector<int>&ap, &an; int leaf_n, smax_n; bool vertex_cover; int par_min;
+        std::vector<FH> F;                                         // this worker's fronts (children: indices into this list)
+        std::vector<int> side, slot, mark;
+        int stamp = 0;
+        std::vector<std::pair<double, int>> keyed;
+        int new_front(std::vector<int> own, std::vector<int> ch) { F.push_back(FH{std::move(own), std::move(ch)}); return (int)F.size() - 1; }
+        // orders v along its longest axis (not skip_axis): completely (split < 0), or only so far that the `split` smallest come first
+        int asort(std::vector<int>& v, int skip_axis, int split = -1) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int u : v)
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos[3 * (size_t)u + a]); hi[a] = std::max(hi[a], pos[3 * (size_t)u + a]); }
+            int ax = -1;
+            for (int a = 0; a < 3; ++a)
+                if (a != skip_axis && (ax < 0 || hi[a] - lo[a] > hi[ax] - lo[ax])) ax = a;
+            keyed.resize(v.size());                                    // (coordinate, id) pairs: the sort touches no indirect memory
+            for (size_t i = 0; i < v.size(); ++i) keyed[i] = {pos[3 * (size_t)v[i] + ax], v[i]};
+            if (split < 0) {
+                std::sort(keyed.begin(), keyed.end());
+                for (size_t i = 0; i < v.size(); ++i) v[i] = keyed[i].second;
+            } else std::nth_element(keyed.begin(), keyed.begin() + split, keyed.end());     // (pairs are distinct: the two halves are determined; v stays as it is)
+            return ax;
+        }
+        // chain of fronts over one separator (or leaf) that is longer than a front may own
+        int mk_chain(std::vector<int>& nodes, std::vector<int> ch) {
+            const int n = (int)nodes.size(), nc = (n + smax_n - 1) / smax_n;
+            int prev = -1;
+            for (int k = 0; k < nc; ++k) {
+                const int a = (int)((int64_t)n * k / nc), b = (int)((int64_t)n * (k + 1) / nc);
+                std::vector<int> own(nodes.begin() + a, nodes.begin() + b);
+                prev = new_front(std::move(own), k == 0 ? std::move(ch) : std::vector<int>{prev});
+            }
+            return prev;
+        }
+        // a worker for one half: the marks as they stand (what it reads of nodes outside its half never equals a stamp it hands out)
+        Rec fork() const { Rec r{pos, ap, an, leaf_n, smax_n, vertex_cover, par_min, {}, side, std::vector<int>(slot.size(), 0), mark, stamp, {}}; return r; }
+        // its fronts behind this worker's, its roots in this worker's numbering
+        std::vector<int> adopt(Rec& w, std::vector<int> roots) {
+            const int off = (int)F.size();
+            for (FH& f : w.F) { for (int& c : f.ch) c += off; F.push_back(std::move(f)); }
+            for (int& r : roots) r += off;
+            return roots;
+        }
+        std::vector<int> run(std::vector<int> v, int depth) {        // (v ascending by node index, here and in every call below)
             if (v.empty()) return {};
             if ((int)v.size() <= leaf_n) { asort(v, -1); return {mk_chain(v, {})}; }
             const size_t half = v.size() / 2;
@@ -206,19 +219,38 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             std::vector<int> A, B;
             for (int u : L) if (side[u] != ss) A.push_back(u);
             for (int u : R) if (side[u] != ss) B.push_back(u);
-            std::vector<int> ra = run(std::move(A)), rb = run(std::move(B));
+            std::vector<int> ra, rb;
+            if (par_min > 0 && depth < 2 && (int)std::min(A.size(), B.size()) >= par_min) {
+                Rec wa = fork(), wb = fork();
+                std::exception_ptr ex;
+                bool threaded = true;
+                std::thread th;
+                try { th = std::thread([&] { try { ra = wa.run(std::move(A), depth + 1); } catch (...) { ex = std::current_exception(); } }); }
+                catch (const std::system_error&) { threaded = false; }
+                if (!threaded) ra = wa.run(std::move(A), depth + 1);
+                try { rb = wb.run(std::move(B), depth + 1); }
+                catch (...) { if (th.joinable()) th.join(); throw; }
+                if (th.joinable()) th.join();
+                if (ex) std::rethrow_exception(ex);
+                ra = adopt(wa, std::move(ra));
+                rb = adopt(wb, std::move(rb));
+            } else {
+                ra = run(std::move(A), depth + 1);
+                rb = run(std::move(B), depth + 1);
+            }
             ra.insert(ra.end(), rb.begin(), rb.end());
             if (sep.empty()) return ra;                            // the halves do not touch: two independent subtrees
             asort(sep, ax);                                        // along the cut, so that the chunks of a long separator are contiguous
             return {mk_chain(sep, std::move(ra))};
         }
-    } rec{F, side, stamp, ap, an, last, axis_sort, chain, leaf_n, slot, getenv("NRS_ND_NO_COVER") == nullptr, keyed, mark};
+    } rec{pos, ap, an, leaf_n, smax_n, getenv("NRS_ND_NO_COVER") == nullptr, par_min, {}, std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), 0, {}};
     std::vector<int> regular, tail;
     for (int i = 0; i < n_nodes; ++i) (last && last[i] ? tail : regular).push_back(i);
-    std::vector<int> roots = rec.run(std::move(regular));
+    std::vector<int> roots = rec.run(std::move(regular), 0);
+    std::vector<FH>& F = rec.F;
     if (!tail.empty()) {
         if (roots.size() == 1 && F[roots[0]].own.size() + tail.size() <= (size_t)smax_n) F[roots[0]].own.insert(F[roots[0]].own.end(), tail.begin(), tail.end());
-        else { const int r = chain(tail, std::move(roots)); roots = {r}; }
+        else { const int r = rec.mk_chain(tail, std::move(roots)); roots = {r}; }
     }
     const int nf = (int)F.size();
     if (nf == 0) return fail("empty tree");

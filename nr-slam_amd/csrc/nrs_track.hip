@@ -412,8 +412,11 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     if (M == 0) return c->fail(NRS_ERR_INVALID, "embedded mode: no node among the optimised points");
 
     // ---- edge construction OPT:224-337 (container walk on the host, order as in the reference)
-    std::vector<std::vector<std::pair<int, int>>> reg(N);       // reg[idx] = {(idx_other, edge)}
-    for (int i = 0; i < N; ++i) if (node_of[i] >= 0) reg[i].reserve(24);   // (one allocation per node: <= 11 own + the neighbours' entries)
+    // The reference keeps per vertex the (other, edge) pairs it is part of and skips a neighbour it is already paired with (OPT:268-272).
+    // A pair {idx, io} exists when idx's walk reaches io iff io was walked EARLIER (io < idx) and accepted idx (a list holds a connection
+    // once): the test reads io's accepted neighbours -- at most 11, one cache line -- instead of a container per vertex
+    std::vector<int> acc(11 * (size_t)N, -1);
+    std::vector<uint8_t> n_acc(N, 0);
     std::vector<int> dm_idx, sp_ij;
     std::vector<float> dm_w, sp_d0;
     dm_idx.reserve(48 * (size_t)M); sp_ij.reserve(24 * (size_t)M); dm_w.reserve(12 * (size_t)M); sp_d0.reserve(12 * (size_t)M);
@@ -432,7 +435,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     const int *ocol = src.col, *ost = src.st;
     const float *ow = src.w, *od0 = src.d0;
     mark("GetEdges");
-    for (auto& v : reg) v.clear();
+    std::fill(n_acc.begin(), n_acc.end(), 0);
     dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); std::fill(lost_flag.begin(), lost_flag.end(), 0);
     sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
     for (int idx = 0; idx < N && !again; ++idx) {
@@ -454,15 +457,15 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             if (node_of[io] < 0) continue;                        // an optimised point without a vertex: passed over
             if (is_node) {
                 bool dup = false;
-                for (auto& pr : reg[idx]) dup = dup || pr.first == io;
+                if (io < idx) { const int* al = &acc[11 * (size_t)io]; for (int k = 0, nk = n_acc[io]; k < nk; ++k) dup = dup || al[k] == idx; }
                 if (dup) continue;
                 const int k = (int)dm_w.size();
                 dm_idx.insert(dm_idx.end(), {-1, -1, node_of[idx], node_of[io]});      // r = w (delta_idx - delta_io)
                 dm_w.push_back(ow[a]);
                 sp_ij.insert(sp_ij.end(), {node_of[idx], node_of[io]});
                 sp_d0.push_back(od0[a]);
-                reg[idx].push_back({io, k});
-                reg[io].push_back({idx, k});
+                (void)k;
+                acc[11 * (size_t)idx + n_acc[idx]++] = io;           // (n_reg <= 10 here: at most 11 per walk)
             } else {
                 sk_node[11 * slot + n_reg] = node_of[io];
                 sk_om[11 * slot + n_reg] = (double)ow[a];
@@ -538,9 +541,10 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             const bool out = (float)chi_r[v] > th2_sq;
             inl[idx] = !out;
             rflag[v] = RF_OBS | (out ? 0 : RF_REPROJ_ACTIVE);
-            for (auto& pr : reg[idx]) dm_active[pr.second] = out ? 0 : 1;
-            for (auto& pr : reg[idx]) dm_active[pr.second] = chi_d[pr.second] > (double)th3_sq ? 0 : 1;
         }
+        // OPT:365-383 sets the level of every regulariser of a vertex twice -- by the vertex's reprojection gate, then by the edge's own
+        // chi2 -- and the second assignment stands: every edge (each has a vertex) ends at its own gate
+        for (int k = 0; k < E; ++k) dm_active[k] = chi_d[k] > (double)th3_sq ? 0 : 1;
         NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
         if (S) {                                                  // the skinned observations' levels, by the same gate
             NRS_TRY(engine_skin_chi2(c, eng, chi_s.data()));
