@@ -309,7 +309,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
         else launch_reg<LIN>(c, d, d.xl[which]);
     }
     if (LIN) hipLaunchKernelGGL(k_pose_sums, dim3(d.sh_nk), b, 0, c->stream, d);
-    if (LIN && d.coarse) {
+    if (LIN && d.coarse && !(e->nd && e->nd->on)) {                // (the coarse level is the PCG's: a directly solved engine never reads it -- 50 us per linearisation at 4.4k points)
         const size_t rows = (size_t)(d.tile_rows + d.max_halo);
         const size_t shm = sizeof(double) * 3 * rows + 3 * (rows + 8) + 16;
         const dim3 g(d.n_regblk);

@@ -440,6 +440,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
     for (int idx = 0; idx < N && !again; ++idx) {
         const int p = ids[idx];
+        if (idx + 6 < N) {                                        // (the lists have just arrived from the device: every walk would start on lines that are in no cache)
+            const int pb = src.beg[ids[idx + 6]];
+            for (int o = 0; o < 32; o += 16) {
+                __builtin_prefetch(ocol + pb + o); __builtin_prefetch(ost + pb + o);
+                __builtin_prefetch(ow + pb + o); __builtin_prefetch(od0 + pb + o);
+            }
+        }
         const bool is_node = node_of[idx] >= 0;
         const size_t slot = sk_idx.size();                        // (a skinned observation's slot, kept only if it meets a node)
         int n_reg = 0;
@@ -635,6 +642,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     un_ij.clear(); un_w.clear();
     for (int li = 0; li < L && !again; ++li) {
         const int p = lost_ids[li];
+        if (li + 6 < L) { const int pb = src.beg[lost_ids[li + 6]]; __builtin_prefetch(ocol + pb); __builtin_prefetch(ow + pb); __builtin_prefetch(ocol + pb + 16); __builtin_prefetch(ow + pb + 16); }
         int n_reg = 0;
         bool ended = false;
         for (int a = src.beg[p]; a < src.end[p]; ++a) {
