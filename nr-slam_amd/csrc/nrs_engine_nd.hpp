@@ -54,14 +54,23 @@ __device__ inline void nd_fmac_bcast(double& a, double nl, double l) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(nl), "v"(l), "n"(K));
 }
 
+// a -= (lane K's ls of this 16-lane row) * l: the negation rides on the DPP operand (src0 neg modifier), so no negated copy is made
+template <int K>
+__device__ inline void nd_fmacn_bcast(double& a, double ls, double l) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(ls), "v"(l), "n"(K));
+}
+
 // Cholesky of one 16 x 16 diagonal block of the panel, one wave: lane (i = lane & 15) of every 16-lane row holds row i (the four
 // rows of the wave work redundantly, so every broadcast stays inside a row).  Column j: the pivot reaches the lanes by a row
-// broadcast, a[k] -= l_ij l_kj by the DPP FMA.  Leaves the block in W (lower triangle) and 1 / diag in dinv.
+// broadcast, a[k] -= l_ij l_kj by the DPP FMA.  Leaves the block in W (lower triangle) and 1 / diag in dinv.  The wave is ISSUE-bound
+// here (tools/micro/diag_probe.hip: pinning the next column's pivot chain between this column's independent updates buys 8 %, a
+// shorter chain 13 %): ten VALU operations per pivot -- a bad pivot is replaced by changing its high word only (any value in
+// [1, 2) will do: one select instead of two), no negated copy of the column -- 3350 -> 2900 cycles per block.
 template <int J, int K>
-__device__ inline void nd_diag_cols_upd(double (&a)[16], double nl, double l) {
+__device__ inline void nd_diag_cols_upd(double (&a)[16], double l) {
     if constexpr (K < 16) {
-        nd_fmac_bcast<K>(a[K], nl, l);
-        nd_diag_cols_upd<J, K + 1>(a, nl, l);
+        nd_fmacn_bcast<K>(a[K], l, l);
+        nd_diag_cols_upd<J, K + 1>(a, l);
     }
 }
 template <int J>
@@ -70,13 +79,12 @@ __device__ inline void nd_diag_cols(double (&a)[16], double (&rr)[16], int& bad)
         double ajj = nd_rowbcast<J>(a[J]);
         const bool ok = ajj > 0.0;
         bad |= !ok;
-        ajj = ok ? ajj : 1.0;
+        ajj = __hiloint2double(ok ? __double2hiint(ajj) : 0x3FF00000, __double2loint(ajj));
         const double r = fast_rsqrt_pos(ajj);
-        const double l = a[J] * r;                                 // (lane J: a_jj r = sqrt(a_jj))
+        double l = a[J] * r;                                       // (lane J: a_jj r = sqrt(a_jj))
+        asm volatile("s_nop 1" : "+v"(l));                         // (a VALU result read through DPP needs two wait states)
         a[J] = l; rr[J] = r;
-        double nl = -l;
-        asm volatile("s_nop 1" : "+v"(nl));                        // (a VALU result read through DPP needs two wait states)
-        nd_diag_cols_upd<J, J + 1>(a, nl, l);
+        nd_diag_cols_upd<J, J + 1>(a, l);
         nd_diag_cols<J + 1>(a, rr, bad);
     }
 }
@@ -100,18 +108,17 @@ __device__ __forceinline__ void nd_diag_factor(double* W, double* dinv, int k0, 
 
 // step B of the panel factorisation for one row held in x: x <- x L_kk^-T, L_kk row (lane & 15) in lk (see k_nd_level)
 template <int P, int Q>
-__device__ inline void nd_b_upd(double (&x)[16], const double (&lk)[16], double nx) {
+__device__ inline void nd_b_upd(double (&x)[16], const double (&lk)[16], double xp) {
     if constexpr (Q < 16) {
-        nd_fmac_bcast<Q>(x[Q], lk[P], nx);                         // x[Q] += (lane Q's L[Q][P]) * (-x[P])
-        nd_b_upd<P, Q + 1>(x, lk, nx);
+        nd_fmacn_bcast<Q>(x[Q], lk[P], xp);                        // x[Q] -= (lane Q's L[Q][P]) * x[P]
+        nd_b_upd<P, Q + 1>(x, lk, xp);
     }
 }
 template <int P>
 __device__ inline void nd_b_cols(double (&x)[16], const double (&lk)[16], const double (&di)[16]) {
     if constexpr (P < 16) {
         x[P] *= di[P];
-        const double nx = -x[P];
-        nd_b_upd<P, P + 1>(x, lk, nx);
+        nd_b_upd<P, P + 1>(x, lk, x[P]);
         nd_b_cols<P + 1>(x, lk, di);
     }
 }
