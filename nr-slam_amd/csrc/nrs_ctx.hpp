@@ -60,6 +60,7 @@ struct nrs_ctx {
     nrs::DevBuf nd_skin;             // embedded mode (nrs_engine_skin.hpp): the skinned observations of the tracking engine
     void* nd_cache = nullptr;        // direct solver of the tracking engines (nrs_engine_nd.hpp NdCache): the last few plans with their device arrays
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
+    nrs::DevBuf gather_ws;           // sharded download / taps: two full-length row vectors for the gather (a rank holds its own rows only); released after use
     bool err_local = true;           // last set-up failure may be specific to this rank (allocation, HIP, rank-dependent checks)
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;

@@ -730,15 +730,20 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
 
 // sharded: the current estimates of all rows on every rank (each rank contributes its own rows, zeros
 // elsewhere, summed over the ranks); uses the PCG vectors w and s as scratch
-static int gather_state(nrs_ctx* c, Engine* e, const double** xl_full) {
+static int gather_state(nrs_ctx* c, Engine* e, const double** xl_full, size_t extra_bytes = 0) {   // extra_bytes: room behind the two vectors (row-limited ranks: the taps' full-length flags / observations)
     Dev& d = e->d;
     *xl_full = d.xl[e->cur];
     if (!d.sh_on) return NRS_OK;
     const size_t n = 3 * (size_t)d.n_rows;
-    hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d, d.xl[e->cur], d.wv);
+    double *in = d.wv, *out = d.sv;
+    if (d.row_hi - d.row_lo < d.n_rows) {                         // the rank holds its own rows of the vectors only: full-length scratch for the duration of the call
+        NRS_TRY(c->ensure(c->gather_ws, 2 * sizeof(double) * n + extra_bytes));
+        in = c->gather_ws.as<double>(); out = in + n;
+    }
+    hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d, d.xl[e->cur], in);
     NRS_HIP(c, hipGetLastError());
-    NRS_TRY(c->comm->allreduce(c, d.wv, d.sv, n));
-    *xl_full = d.sv;
+    NRS_TRY(c->comm->allreduce(c, in, out, n));
+    *xl_full = out;
     return NRS_OK;
 }
 
@@ -750,6 +755,7 @@ int engine_download(nrs_ctx* c, Engine* e, Pose* poses, double* x) {
     if (poses) NRS_HIP(c, hipMemcpyAsync(poses, d.pose[e->cur], sizeof(Pose) * d.K, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipMemcpyAsync(xl.data(), src, sizeof(double) * xl.size(), hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
+    c->release(c->gather_ws);
     if (x)
         for (int v = 0; v < d.M; ++v)
             for (int k = 0; k < 3; ++k) x[3 * (size_t)v + k] = xl[3 * (size_t)e->vrow[v] + k];
@@ -787,14 +793,27 @@ int engine_residuals(nrs_ctx* c, Engine* e, double* r_reproj, double* r_spring, 
     double* rd = rs + (size_t)d.n_sp;
     const int n = std::max(d.M, std::max(d.n_sp, d.n_dm));
     const double* xl_full = nullptr;
-    NRS_TRY(gather_state(c, e, &xl_full));
-    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], xl_full,
+    const bool limited = d.row_hi - d.row_lo < d.n_rows;           // a rank of a sharded window holds its own rows only: the tap reads every row's flag and observation
+    if (limited && d.X0) return c->fail(NRS_ERR_STATE, "residual taps: a sharded window with offsets is not supported");
+    NRS_TRY(gather_state(c, e, &xl_full, limited ? 9 * (size_t)d.n_rows + 256 : 0));
+    const uint8_t* t_rflag = d.rflag;
+    const float* t_uv = d.uv;
+    if (limited) {
+        char* xb = c->gather_ws.as<char>() + 2 * sizeof(double) * 3 * (size_t)d.n_rows;
+        float* fu = reinterpret_cast<float*>(xb);
+        uint8_t* fr = reinterpret_cast<uint8_t*>(xb + 8 * (size_t)d.n_rows);
+        NRS_HIP(c, hipMemcpyAsync(fu, e->h_uv.data(), sizeof(float) * 2 * (size_t)d.n_rows, hipMemcpyHostToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(fr, e->h_rflag.data(), (size_t)d.n_rows, hipMemcpyHostToDevice, c->stream));
+        t_rflag = fr; t_uv = fu;
+    }
+    hipLaunchKernelGGL(k_tap_residuals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, d.pose[e->cur], xl_full, t_rflag, t_uv,
                        t_vrow, t_sp, t_d0, t_dm, t_w, rr, rs, rd);
     NRS_HIP(c, hipGetLastError());
     if (r_reproj) NRS_HIP(c, hipMemcpyAsync(r_reproj, rr, sizeof(double) * 2 * (size_t)d.M, hipMemcpyDeviceToHost, c->stream));
     if (r_spring && d.n_sp) NRS_HIP(c, hipMemcpyAsync(r_spring, rs, sizeof(double) * (size_t)d.n_sp, hipMemcpyDeviceToHost, c->stream));
     if (r_damper && d.n_dm) NRS_HIP(c, hipMemcpyAsync(r_damper, rd, sizeof(double) * 3 * (size_t)d.n_dm, hipMemcpyDeviceToHost, c->stream));
     NRS_HIP(c, hipStreamSynchronize(c->stream));
+    c->release(c->gather_ws);
     return NRS_OK;
 }
 

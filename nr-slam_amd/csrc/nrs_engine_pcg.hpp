@@ -1331,14 +1331,14 @@ __global__ void k_mask_rows(Dev P, const double* __restrict__ in, double* __rest
 // =====================================================================================
 // edge taps (edge-parallel, not on the timed path): residuals of every edge at a given state
 // =====================================================================================
-__global__ void k_tap_residuals(Dev P, const Pose* poses, const double* xl, const int* vrow,
+__global__ void k_tap_residuals(Dev P, const Pose* poses, const double* xl, const uint8_t* rflag, const float* uvs, const int* vrow,   // (rflag / uvs: the engine's, or full-length copies on a rank that holds its own rows only)
                                 const int* sp_ij, const float* sp_d0, const int* dm_idx, const float* dm_w,
                                 double* r_reproj, double* r_spring, double* r_damper) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.M) {
         const int row = vrow[i];
         r_reproj[2 * i] = r_reproj[2 * i + 1] = 0;
-        if (P.rflag[row] & RF_OBS) {
+        if (rflag[row] & RF_OBS) {
             const Pose Tcw = poses[P.grp_pose[row / ROW_ALIGN]];
             double R[9];
             quat_to_R(Tcw.q, R);
@@ -1349,8 +1349,8 @@ __global__ void k_tap_residuals(Dev P, const Pose* poses, const double* xl, cons
             const double pz = R[6] * x0 + R[7] * x1 + R[8] * x2 + Tcw.t[2];
             float u, v;
             project_f32(P.cam, (float)px, (float)py, (float)pz, u, v);
-            r_reproj[2 * i] = (double)P.uv[2 * row] - (double)u;
-            r_reproj[2 * i + 1] = (double)P.uv[2 * row + 1] - (double)v;
+            r_reproj[2 * i] = (double)uvs[2 * row] - (double)u;
+            r_reproj[2 * i + 1] = (double)uvs[2 * row + 1] - (double)v;
         }
     }
     if (i < P.n_sp) {

@@ -20,22 +20,33 @@ struct ArenaPlan {                   // two passes: size, then carve
     Arena* a;
     bool dry;
     size_t off = 0;
+    size_t row_lo = 0, row_n = 0;    // the rows this engine holds of every per-row array (a rank of a sharded window: its keyframes and one ghost keyframe either side)
     template <class Tp> Tp* get(size_t n) {
         const size_t bytes = ((n * sizeof(Tp) + 255) / 256) * 256 + 256;
         Tp* p = dry ? nullptr : reinterpret_cast<Tp*>(a->base + off);
         off += bytes;
         return p;
     }
+    // a per-row array (per_row elements a row): storage for rows [row_lo, row_lo + row_n) only, addressed by the GLOBAL row index --
+    // the pointer handed out is the storage's start minus row_lo rows, so every kernel and every exchange indexes as on one GPU and
+    // nothing outside the held rows is ever touched (engine_create: the launches of a rank cover its own tiles, whose halos end one
+    // keyframe away)
+    template <class Tp> Tp* get_rows(size_t per_row) {
+        Tp* p = get<Tp>(row_n * per_row);
+        return dry ? nullptr : p - row_lo * per_row;
+    }
 };
 
 static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, size_t n_halo, Engine* e) {
     const size_t nr = (size_t)d.n_rows, K = (size_t)d.K;
+    if (d.row_hi <= 0) { d.row_lo = 0; d.row_hi = d.n_rows; }     // (callers that never shard leave the range unset: every row)
+    A.row_lo = (size_t)d.row_lo; A.row_n = (size_t)(d.row_hi - d.row_lo);
     d.grp_pose = A.get<int>(d.n_groups);
     d.pose_grp_ptr = A.get<int>(K + 1);
-    d.rflag = A.get<uint8_t>(nr);
+    d.rflag = A.get_rows<uint8_t>(1);
     d.pose_fixed = A.get<uint8_t>(K);
-    d.uv = A.get<float>(2 * nr);
-    double* X0 = A.get<double>(has_X0 ? 3 * nr : 1);
+    d.uv = A.get_rows<float>(2);
+    double* X0 = has_X0 ? A.get_rows<double>(3) : A.get<double>(1);
     d.X0 = has_X0 ? X0 : nullptr;
     d.ss_ptr = A.get<int>(n_slices + 1);
     d.sd_ptr = A.get<int>(n_slices + 1);
@@ -53,26 +64,26 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.s_other = A.get<int>(us); d.s_d0 = A.get<float>(nnz_s); d.s_meta = A.get<int>(us);
     d.d_o0 = A.get<int>(ud); d.d_o1 = A.get<int>(ud); d.d_o2 = A.get<int>(ud);
     d.d_w = A.get<float>(nnz_d); d.d_meta = A.get<int>(ud);
-    for (int s = 0; s < 2; ++s) { d.pose[s] = A.get<Pose>(K); d.xl[s] = A.get<double>(3 * nr); }
+    for (int s = 0; s < 2; ++s) { d.pose[s] = A.get<Pose>(K); d.xl[s] = A.get_rows<double>(3); }
     d.pose_init = A.get<Pose>(K);
-    d.xl_init = A.get<double>(3 * nr);
-    d.D = A.get<double>(6 * nr);
+    d.xl_init = A.get_rows<double>(3);
+    d.D = A.get_rows<double>(6);
     d.Hpl = A.get<double>(d.use_lds ? 1 : 18 * nr);
-    d.rowrec = A.get<RowRec>(d.use_lds ? nr : 1);
-    d.row_tp = A.get<uint32_t>(d.plain ? nr : 1);
-    d.row_cnt = A.get<uint32_t>(d.plain ? nr : 1);
+    d.rowrec = d.use_lds ? A.get_rows<RowRec>(1) : A.get<RowRec>(1);
+    d.row_tp = d.plain ? A.get_rows<uint32_t>(1) : A.get<uint32_t>(1);
+    d.row_cnt = d.plain ? A.get_rows<uint32_t>(1) : A.get<uint32_t>(1);
     d.d_h4 = A.get<uint32_t>(d.plain && d.use_lds && !d.fused ? nnz_d : 1);
     d.s_g = A.get<double>(3 * us);
     d.d_s = A.get<double>(nnz_d);
     d.Hpp = A.get<double>(21 * K);
     d.bp = A.get<double>(6 * K);
-    d.bl = A.get<double>(3 * nr);
-    d.Dinv = A.get<double>(6 * nr);
+    d.bl = A.get_rows<double>(3);
+    d.Dinv = A.get_rows<double>(6);
     d.Hppinv = A.get<double>(36 * K);
     double** pv[] = {&d.xp, &d.rp, &d.up, &d.pp, &d.sp, &d.wp};
     for (auto p : pv) *p = A.get<double>(6 * K);
     double** rvv[] = {&d.xv, &d.rv, &d.uv3, &d.pv, &d.sv, &d.wv};
-    for (auto p : rvv) *p = A.get<double>(3 * nr);
+    for (auto p : rvv) *p = A.get_rows<double>(3);
     d.rp2 = A.get<double>(6 * K); d.sp2 = A.get<double>(6 * K); d.up2 = A.get<double>(6 * K);
     d.rv2 = A.get<double>(d.fused ? 3 * nr : 1); d.sv2 = A.get<double>(d.fused ? 3 * nr : 1); d.wv2 = A.get<double>(d.fused ? 3 * nr : 1);
     d.part_spmv2 = A.get<double>(d.fused ? NPART * (size_t)d.n_regblk : 1);
@@ -112,6 +123,14 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
 template <class Tp>
 static int h2d(nrs_ctx* c, Tp* dst, const std::vector<Tp>& src) {
     if (!src.empty()) NRS_HIP(c, hipMemcpyAsync(dst, src.data(), sizeof(Tp) * src.size(), hipMemcpyHostToDevice, c->stream));
+    return NRS_OK;
+}
+
+// a full-length host image of a per-row array (per_row elements a row) into the rows this engine holds of it
+template <class Tp>
+static int h2d_rows(nrs_ctx* c, const Dev& d, Tp* dst, const std::vector<Tp>& src, size_t per_row) {
+    const size_t o = (size_t)d.row_lo * per_row, n = (size_t)(d.row_hi - d.row_lo) * per_row;
+    if (n) NRS_HIP(c, hipMemcpyAsync(dst + o, src.data() + o, sizeof(Tp) * n, hipMemcpyHostToDevice, c->stream));
     return NRS_OK;
 }
 
@@ -226,7 +245,7 @@ static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uin
         NRS_TRY(h2d(c, d.s_meta, e->h_s_meta));
         NRS_TRY(h2d(c, d.d_meta, e->h_d_meta));
     }
-    NRS_TRY(h2d(c, d.rflag, e->h_rflag));
+    NRS_TRY(h2d_rows(c, d, d.rflag, e->h_rflag, 1));
     NRS_TRY(h2d(c, d.pose_fixed, e->h_pose_fixed));
     return NRS_OK;
 }
@@ -736,6 +755,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             for (int i = halo_ptr[b]; i < halo_ptr[b + 1]; ++i)
                 if (halo_rows[i] < r_lo || halo_rows[i] >= r_hi)
                     return c->fail(NRS_ERR_INVALID, "sharded solve: an edge of keyframe range [%d, %d) reaches beyond the adjacent keyframes", kb[rk], kb[rk + 1]);
+        // ... so the rank holds the per-row arrays (state, vectors, diagonal blocks: ~410 bytes a row) of its own keyframes and of ONE ghost
+        // keyframe either side only: its tiles' halos end there (just checked), the boundary exchange fills the ghosts, and no launch of
+        // this rank touches a row beyond them (ArenaPlan::get_rows).  NRS_SHARD_FULL_VECTORS=1: every row, the round-1..4 form.
+        if (W > 1 && !d.dform && !getenv("NRS_SHARD_FULL_VECTORS")) { d.row_lo = r_lo; d.row_hi = r_hi; }
         // boundary tiles (their halo holds rows of another rank) sit at the two ends of the rank's tile range:
         // they run after the interior tiles, once the neighbours' rows have arrived
         const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
@@ -957,9 +980,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<Pose> poses(s.poses, s.poses + s.K);
     NRS_TRY(h2d(c, d.grp_pose, grp_pose));
     NRS_TRY(h2d(c, d.pose_grp_ptr, pose_grp_ptr));
-    NRS_TRY(h2d(c, d.uv, uv));
-    NRS_TRY(h2d(c, d.xl_init, xl));
-    if (s.X0) NRS_TRY(h2d(c, d.X0, X0));
+    NRS_TRY(h2d_rows(c, d, d.uv, uv, 2));
+    if (d.row_hi - d.row_lo < d.n_rows) e->h_uv = uv;              // (a row-limited rank: the residual taps stage the observations of every row from here)
+    NRS_TRY(h2d_rows(c, d, d.xl_init, xl, 3));
+    if (s.X0) NRS_TRY(h2d_rows(c, d, d.X0, X0, 3));
     NRS_TRY(h2d(c, d.pose_init, poses));
     NRS_TRY(h2d(c, d.ss_ptr, ss_ptr));
     NRS_TRY(h2d(c, d.sd_ptr, sd_ptr));
@@ -1008,11 +1032,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_TRY(h2d(c, d.d_o2, d_o2));
     }
     NRS_TRY(h2d(c, d.d_w, d_w));
-    if (d.plain) NRS_TRY(h2d(c, d.row_tp, row_tp));
+    if (d.plain) NRS_TRY(h2d_rows(c, d, d.row_tp, row_tp, 1));
     if (d.plain) {
         std::vector<uint32_t> rc((size_t)d.n_rows);
         for (int r = 0; r < d.n_rows; ++r) rc[r] = (uint32_t)cnt_s[r] | ((uint32_t)cnt_d[r] << 16);
-        NRS_TRY(h2d(c, d.row_cnt, rc));
+        NRS_TRY(h2d_rows(c, d, d.row_cnt, rc, 1));
         NRS_HIP(c, hipStreamSynchronize(c->stream));               // (rc dies here)
     }
     if (d.ec_on) {
@@ -1179,8 +1203,9 @@ int engine_reset(nrs_ctx* c, Engine* e) {
     e->cur = 0;
     e->pred_iters = 0; e->pred_peek = 0; e->first_trial_accepted = false;   // batch-size predictors start fresh, as in a new engine
     NRS_HIP(c, hipMemcpyAsync(d.pose[0], d.pose_init, sizeof(Pose) * d.K, hipMemcpyDeviceToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(d.xl[0], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(d.xl[1], d.xl_init, sizeof(double) * 3 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));
+    const size_t o = 3 * (size_t)d.row_lo, n = 3 * (size_t)(d.row_hi - d.row_lo);                  // (the rows this engine holds: all of them on one GPU)
+    NRS_HIP(c, hipMemcpyAsync(d.xl[0] + o, d.xl_init + o, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d.xl[1] + o, d.xl_init + o, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     return NRS_OK;
 }
 

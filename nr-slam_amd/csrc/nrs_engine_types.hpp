@@ -48,6 +48,8 @@ struct __attribute__((aligned(16))) EcDamper { int r[4]; };         // roles 1c 
 
 struct Dev {
     int K, M, n_rows, n_groups;      // poses, vertices, padded rows, ROW_ALIGN groups
+    int row_lo, row_hi;              // the rows whose per-row arrays this engine holds ([0, n_rows) on one GPU; a rank of a sharded window: its own keyframes
+                                     // and one ghost keyframe either side -- the arrays are addressed by the global row index all the same, see ArenaPlan::get_rows)
     int T;                           // lanes per row
     int n_sp, n_dm, n_un;
     int n_regblk, n_vecblk;
@@ -226,6 +228,7 @@ struct Engine {
     std::vector<uint2> h_d_hdr;
     std::vector<uint32_t> h_d_om;
     std::vector<uint8_t> h_rflag, h_pose_fixed;
+    std::vector<float> h_uv;         // observations by row, kept by a rank that holds its own rows only (residual taps)
     std::vector<int> sk_slot;        // embedded BA windows: observation (caller order) -> slot (pose-grouped, padded)
     std::vector<int> sk_vert;        // embedded mode: the skinned observations' node vertices (n_skin x 11, -1 pads) and weights
     std::vector<double> sk_om, sk_X0;

@@ -456,7 +456,7 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
     if (c->arena_dba.base) (void)hipFree(c->arena_dba.base);
     if (c->arena_trk.base) (void)hipFree(c->arena_trk.base);
     c->release(c->po_uv); c->release(c->po_X); c->release(c->po_err);
-    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin); c->release(c->po_multi);
+    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->gather_ws); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin); c->release(c->po_multi);
     nrs::nd_cache_free(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -141,6 +141,7 @@ def test_c4_sharded_8_thread_ranks(ctx, big):
         pytest.skip("configs[3] is the sharded configuration")
     iters, world = 2, 8
     ref = _run(ctx, big, iters)                      # plain solve of the same window
+    plain_bytes = ctx.dba_stats()["device_bytes"]
     ctx.dba_upload(cam, qt[:3], p["lm_xyz"][:3], np.arange(3, dtype=np.int32), p["lm_uv"][:3],
                    dict(sp_ij=np.zeros((0, 2), np.int32), sp_d0=np.zeros(0, np.float32),
                         dm_idx=np.zeros((0, 4), np.int32), dm_w=np.zeros(0, np.float32)), p["scale"])   # frees its 14 GB
@@ -185,4 +186,5 @@ def test_c4_sharded_8_thread_ranks(ctx, big):
     assert np.allclose(xyz0, ref[1], atol=1e-4, rtol=0)
     # a rank holds the records of its own keyframe range: the ranges tile the window
     assert sum(o[3]["packed_rows"] for o in out) == out[0][3]["rows"]
-    assert max(o[3]["device_bytes"] for o in out) < 0.45 * 16.5e9  # device bytes per rank against the replicated window
+    # ... and the rows of its own keyframes + one ghost keyframe either side of every per-row array: an eighth of the window and a bit
+    assert max(o[3]["device_bytes"] for o in out) <= 1.3 * plain_bytes / world, ([o[3]["device_bytes"] for o in out], plain_bytes)

@@ -207,3 +207,23 @@ def test_every_rank_packs_only_its_keyframe_range(ctx):
         own_kf = np.isin(p["lm_kf"], np.arange(kb[r], kb[r + 1]))
         assert st[r]["rows"] == whole["rows"] and own_kf.sum() <= st[r]["packed_rows"] < own_kf.sum() + 256 * (kb[r + 1] - kb[r])
         assert st[r]["spring_slots"] < 0.45 * whole["spring_slots"] and st[r]["device_bytes"] < 0.6 * whole["device_bytes"]
+
+
+def test_a_rank_holds_the_rows_of_its_own_keyframes_and_two_ghosts_only(monkeypatch):
+    """The per-row arrays (state, PCG vectors, diagonal blocks: ~410 bytes a row) of a rank cover its own keyframes and one ghost
+    keyframe either side -- addressed by the global row index all the same (ArenaPlan::get_rows) -- instead of every row of the window
+    (NRS_SHARD_FULL_VECTORS=1: the round-1..4 form).  Same launches, same exchanges: the two forms agree bit for bit (trials, poses,
+    landmarks, residual taps, after a reset too), and what a rank holds shrinks with the rank count."""
+    p, e, cam, qt = _setup(600, 16, 45)
+    monkeypatch.setenv("NRS_SHARD_FULL_VECTORS", "1")
+    full = _run_sharded(4, p, e, cam, qt, resets=1)
+    full_bytes = [s["device_bytes"] for s in _run_sharded.stats]
+    monkeypatch.delenv("NRS_SHARD_FULL_VECTORS")
+    own = _run_sharded(4, p, e, cam, qt, resets=1)
+    own_bytes = [s["device_bytes"] for s in _run_sharded.stats]
+    for r in range(4):
+        assert [(t["accepted"], t["lam"], t["chi"], t["chi_new"]) for t in own[r][0]] == [(t["accepted"], t["lam"], t["chi"], t["chi_new"]) for t in full[r][0]]
+        for a, b in zip(own[r][1:], full[r][1:]):
+            assert np.array_equal(a, b)
+    # 16 keyframes over 4 ranks: 4 own + <= 2 ghost keyframes of 16 -> the row arrays are <= 6 / 16 of the full-length ones
+    assert max(own_bytes) < 0.75 * min(full_bytes), (own_bytes, full_bytes)
