@@ -543,8 +543,12 @@ def direct_solver_leg(sizes=(1013, 4446)):
                                                             "+ one back-pass launch; the time is levels x latency, not flops / peak"))
     ctx.close()
     big = out["%d_points" % sizes[-1]]
-    return {"kernel": "k_nd_level + k_nd_back (multifrontal Cholesky of a2's system on the nested-dissection plan, fronts on v_mfma_f64_16x16x4)",
-            "bound": "mfma", "achieved": big["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": big["frac"], "traffic": None,
+    traffic = None                                             # HBM bytes per launch of the two kernels at 4446 points (own PMC passes: profiles/traffic.json)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("direct_solver_4446_points")
+    return {"kernel": "k_nd_level<512> + k_nd_tile + k_nd_back (multifrontal Cholesky of a2's system on the nested-dissection plan, fronts on v_mfma_f64_16x16x4)",
+            "bound": "mfma", "achieved": big["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": big["frac"], "traffic": traffic,
             "workload": "a2-like block system, %d points + pose, kNN-11 couplings" % sizes[-1], "regime": "latency (critical path): see critical_path", "sizes": out}
 
 
@@ -773,7 +777,8 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {})
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
         lin_gbs = lin_b / (lin_us * 1e-6) / 1e9
-        tsrc = "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile_r03.sh, not this run; lower bound: profiles/README.md)"
+        tsrc = "profiles/traffic.json (rocprofv3 --pmc passes of %s, not this run; lower bound: profiles/README.md)" % (
+            json.load(open(tpath)).get("source", "tools/profile_r03.sh") if os.path.exists(tpath) else "-")
         out["roofline"] = {"kernel": "k_spmv_f (PCG operator apply, dominant: see profiles/)", "bound": "hbm",
                            "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                            "traffic": (traffic or {}).get("k_spmv"), "traffic_source": tsrc, "avg_us": spmv_us,

@@ -340,7 +340,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
         NRS_TRY(c->comm->allreduce(c, d.pk_loc, d.pk, (size_t)(2 + d.sh_world + (LIN ? 27 * d.K : 0))));
         hipLaunchKernelGGL((k_finalize_unpack<LIN>), dim3(1), b, 0, c->stream, d, ++c->seq);
     } else {
-        hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d, ++c->seq);
+        hipLaunchKernelGGL((k_finalize<LIN>), dim3(1), b, 0, c->stream, d, ++c->seq, (e->nd && e->nd->on) ? 1 : 0);
     }
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
@@ -617,8 +617,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             double temp = 0, scale = 0;
             bool ok = true;
             const bool direct = e->nd && e->nd->on;                  // nested-dissection Cholesky instead of PCG (nrs_engine_nd.hpp)
-            if (direct) NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
-            else NRS_TRY(pcg_begin(c, e, lam, &pit));
+            // (a directly solved engine's flag words are cleared by the evaluation that published them: k_finalize, every trial and linearisation)
+            if (!direct) NRS_TRY(pcg_begin(c, e, lam, &pit));
             auto eval_trial = [&]() -> int {
                 Timer t(c, &c->prof.update_ms, &c->prof.update_launches);
                 const bool one_pose = d.K == 1 && !d.sh_on;      // a2's engines: trial state and reprojection chi2 in one launch

@@ -907,15 +907,15 @@ __global__ __launch_bounds__(BLK) void k_chi_edges(Dev P, const double* __restri
 // fence, then the sequence number the host is polling for (h_flags[7]) -- a host round trip is then the
 // latency of that word (measured 9.5 us per {two launches + wait} against 15.2 us with
 // hipStreamSynchronize, tools/micro/sync_latency.hip).
-__device__ inline void publish_flags(const Dev& P, int seq) {
+__device__ inline void publish_flags(const Dev& P, int seq, int zero = 0) {   // zero: leave the device words cleared for the next solve (directly solved engines: no memset launch per LM trial)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) P.h_flags[k] = P.flags[k];
+    for (int k = 0; k < 7; ++k) { P.h_flags[k] = P.flags[k]; if (zero) P.flags[k] = 0; }
     __threadfence_system();
     *reinterpret_cast<volatile int*>(P.h_flags + 7) = seq;
 }
 
 template <bool LIN>
-__global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
+__global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq, int zero_flags) {
     __shared__ double lds[4 * 3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double chi = 0, md = 0, sc = 0;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(BLK) void k_finalize(Dev P, int seq) {
         P.h_scal[SC_CHI] = P.scal[SC_CHI];
         if (LIN) P.h_scal[SC_MAXDIAG] = P.scal[SC_MAXDIAG];
         if (!LIN) P.h_scal[SC_SCALE] = P.scal[SC_SCALE];
-        publish_flags(P, seq);
+        publish_flags(P, seq, zero_flags);
     }
 }
 
