@@ -138,7 +138,12 @@ static int h2d_rows(nrs_ctx* c, const Dev& d, Tp* dst, const std::vector<Tp>& sr
 // reproduces the sequential order (a thread owns a range of ROWS and scans the edges in edge order): the packed problem is
 // the same bits for any thread count (tests/test_gpu_scale.py).
 static int host_threads(size_t work) {
-    if (work < 600000) return 1;                                   // single-frame problems (a 4.5k-point frame: 0.3 M): threads cost 8 ms per frame, they save nothing
+    if (work < 600000) {
+        // single-frame problems (a 4.5k-point frame: 0.3 M incidences): sixteen threads per stage cost more than they save (8 ms per frame,
+        // round 2); NRS_HOST_THREADS_SMALL=<n> tries a few (round 5: see profiles/README.md)
+        if (const char* ev = getenv("NRS_HOST_THREADS_SMALL")) if (work >= 100000) return std::max(1, std::min(8, atoi(ev)));
+        return 1;
+    }
     int n = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* ev = getenv("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
     return n;

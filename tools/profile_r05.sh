@@ -44,5 +44,15 @@ cd $R
 NRS_ND_DBG=1 timeout 100 python tools/nd_kernel_probe.py 4446 > $OUT/nd_phases_4446.txt 2>&1
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 200 python tools/lin_probe.py C2 C3 C4 2>&1 | grep workload > $OUT/lin_probe.jsonl
+# round 5 additions: one LM trial of a2 on the all-pairs frame as a kernel timeline, the sharded window's per-rank footprint (thread ranks),
+# the symbolic phase and the diagonal-block micro-benchmarks, non-temporal streams on / off
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace -f csv -d $OUT/dense_prof -o d -- python $R/tools/tracked_fps_probe.py 5000 3 > $OUT/dense_prof.log 2>&1
+cd $R
+python tools/a2_trial_timeline.py $(find $OUT/dense_prof -name "*kernel_trace.csv" | head -1) 60 > $OUT/a2_trial_timeline.txt 2>&1
+timeout 600 python tools/shard_pack_probe.py C4 8 2>/dev/null | grep -v "^\[" > $OUT/shard_pack_probe.txt
+(nproc; for a in "4221 20" "4221 10" "1013 12"; do tools/micro/bin/plan_probe $a; done) > $OUT/plan_probe.txt 2>&1
+tools/micro/bin/diag_probe > $OUT/diag_probe.txt 2>&1
+for NT in 0 1; do NRS_NT=$NT timeout 400 python tools/lin_probe.py C3 C4 2>&1 | grep workload | sed "s/^{/{\"nt\": $NT, /"; done > $OUT/nt_probe.jsonl
 find $OUT -name "*.csv" -size +20M -delete
 ls -R $OUT | head -60

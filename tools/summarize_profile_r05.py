@@ -15,7 +15,7 @@ f = first("stats/**/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, "r05_bench_kernel_stats.csv"))
 for name in ("bench.json", "lin_probe.jsonl", "small_frames.txt", "nd_crossover.txt", "nd_crossover_dense.txt", "tracked_fps_probe.txt", "nd_phases_1013.txt", "nd_phases_4446.txt",
-             "embedded_phases.txt", "embedded_ba_probe.jsonl", "a1_100k.txt", "kernel_regs.txt"):
+             "embedded_phases.txt", "embedded_ba_probe.jsonl", "a1_100k.txt", "kernel_regs.txt", "a2_trial_timeline.txt", "shard_pack_probe.txt", "plan_probe.txt", "diag_probe.txt", "nt_probe.jsonl"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "r05_" + name))
 
