@@ -29,7 +29,8 @@ struct nrs_rgraph {
     float sigma = 1.f, stretch_th = 1.1f, min_w = 0.f;
     float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
     uint8_t* st = nullptr;
-    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip, slot;
+    nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip, slot, walk;   // (walk: the device-side neighbour walk of a2, rg_walk)
+    int last_n_ids = 0, last_cap = 0;  // shape of the lists out_i holds (the last GetEdges)
     std::vector<int> h_slot;
     char* pin = nullptr;             // pinned staging area of the GetEdges results (page-faulting pageable targets cost more than the kernel)
     size_t pin_cap = 0;
@@ -345,7 +346,7 @@ extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
     if (g->pin) (void)hipHostFree(g->pin);
-    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip); c->release(g->slot);
+    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip); c->release(g->slot); c->release(g->walk);
     delete g;
 }
 
@@ -433,8 +434,130 @@ int rg_max_cap_per_point(const nrs_rgraph* g) {
     while (sizeof(unsigned long long) * (cand_max << 1) + 4096 + 512 <= (size_t)lds_max) cand_max <<= 1;
     return std::min(g->cap, (int)cand_max - RG_SLACK);
 }
+
+// ---- a2's neighbour walk on the device (OPT:252-279 as nrs_track.hip's host loop restates it): optimised point idx (rows of the last
+// GetEdges, in the caller's order) accepts, in list order, up to 11 connections whose other end takes part (code >= 0: its index among
+// the optimised points) and -- for a vertex -- is not already paired with it, i.e. NOT (io < idx and idx among io's accepted): a
+// duplicate does not count, so a point's accepted set depends on those of lower-index points.  The sequential loop is the unique
+// solution of that recursion; the kernel recomputes every point's set from the current sets of the others (one wave per point, 64 list
+// entries at a time) and is repeated until a pass changes nothing (a pass without a change is a fixed point; correct sets never change
+// again, so the passes needed are the longest chain of dependent points + 1).  The last pass (final = 1) also leaves weights, first
+// distances, the lost-point flags of the entries the walk visits and whether it ended before its list did.
+constexpr int RG_WALK_MAX = 11;
+__global__ __launch_bounds__(256) void k_rg_walk(int n, int cap, const int* __restrict__ cnt, const int* __restrict__ col, const int* __restrict__ st,
+                                                 const float* __restrict__ w, const float* __restrict__ d0, const int* __restrict__ code,
+                                                 const uint8_t* __restrict__ is_node, int* acc, int* n_acc, float* acc_w, float* acc_d0,
+                                                 uint8_t* ended, uint8_t* lost, int* changed, int final) {
+    __shared__ int s_new[4][RG_WALK_MAX], s_pos[4][RG_WALK_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wv;
+    if (idx >= n) return;
+    const int c = min(cnt[idx], cap);
+    const size_t base = (size_t)idx * cap;
+    const bool node = !is_node || is_node[idx];
+    int n_reg = 0, brk = -1;                                       // brk: the entry at which the sequential loop breaks (-1: it runs off the list)
+    for (int ch = 0; ch < c && brk < 0; ch += 64) {
+        const int a = ch + lane;
+        const bool valid = a < c;
+        const int other = valid ? col[base + a] : 0;
+        const bool bad = valid && st[base + a] == NRS_GRAPH_BAD;
+        const int io = valid ? code[other] : -1;
+        bool keep = io >= 0;
+        if (keep && node && io < idx) {
+            const int na = min(n_acc[io], RG_WALK_MAX);
+            for (int k = 0; k < na; ++k) keep = keep && acc[(size_t)io * RG_WALK_MAX + k] != idx;
+        }
+        const unsigned long long badm = __ballot(bad), keepm = __ballot(keep);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const int rank = __popcll(keepm & below);                  // kept entries of this chunk before this lane
+        // the loop breaks at the first entry that is BAD or finds eleven accepted before it
+        const bool brk_here = valid && (bad || n_reg + rank >= RG_WALK_MAX);
+        const unsigned long long brkm = __ballot(brk_here);
+        const int first_brk = brkm ? __ffsll((long long)brkm) - 1 : 64;
+        if (keep && lane < first_brk) { s_new[wv][n_reg + rank] = io; s_pos[wv][n_reg + rank] = a; }
+        if (final && valid && lane < first_brk && io == -2) lost[other] = 1;
+        n_reg += __popcll(keepm & (first_brk < 64 ? (~0ull >> (63 - first_brk) >> 1) : ~0ull));
+        if (first_brk < 64) brk = ch + first_brk;
+        (void)badm;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool diff = false;
+    const int old_n = n_acc[idx];
+    if (lane < n_reg) diff = acc[(size_t)idx * RG_WALK_MAX + lane] != s_new[wv][lane];
+    diff = __any(diff) || old_n != n_reg;
+    if (diff) {
+        if (lane < n_reg) acc[(size_t)idx * RG_WALK_MAX + lane] = s_new[wv][lane];
+        __threadfence();
+        if (lane == 0) { n_acc[idx] = n_reg; atomicAdd(changed, 1); }
+    }
+    if (final) {
+        if (lane < n_reg) { acc_w[(size_t)idx * RG_WALK_MAX + lane] = w[base + s_pos[wv][lane]]; acc_d0[(size_t)idx * RG_WALK_MAX + lane] = d0[base + s_pos[wv][lane]]; }
+        if (lane == 0) ended[idx] = brk >= 0;
+    }
+}
+
+// The walk over the lists of the last rg_get_edges_staged(.., lists_to_host = false) call.  code: n_map ints (nrs_track.hip walk_code);
+// is_node: one byte per row or null (every optimised point a vertex).  Outputs (host): n_acc[n], acc[11 n] (indices among the optimised
+// points), acc_w / acc_d0[11 n], ended[n], lost[n_map].  *converged = 0: the passes ran out (the caller walks on the host instead).
+int rg_walk(nrs_rgraph* g, int n_map, const int* code, const uint8_t* is_node, int* n_acc, int* acc, float* acc_w, float* acc_d0,
+            uint8_t* ended, uint8_t* lost, int* converged, int* passes) {
+    nrs_ctx* c = g->c;
+    const int n = g->last_n_ids, cap = g->last_cap;
+    *converged = 0; *passes = 0;
+    if (n <= 0 || n_map > g->cap) return c->fail(NRS_ERR_STATE, "rg_walk: no lists on the device");
+    const size_t no = (size_t)n * cap;
+    const int* d_cnt = g->out_i.as<int>();
+    const int* d_col = d_cnt + n;
+    const int* d_st = d_col + no;
+    const float* d_w = reinterpret_cast<const float*>(d_st + no);
+    const float* d_d0 = d_w + no;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    constexpr int MAXP = 96;
+    const size_t o_code = 0, o_node = o_code + al(4 * (size_t)n_map), o_acc = o_node + al((size_t)n), o_nacc = o_acc + al(4 * (size_t)RG_WALK_MAX * n),
+                 o_w = o_nacc + al(4 * (size_t)n), o_d0 = o_w + al(4 * (size_t)RG_WALK_MAX * n), o_end = o_d0 + al(4 * (size_t)RG_WALK_MAX * n),
+                 o_lost = o_end + al((size_t)n), o_chg = o_lost + al((size_t)n_map), total = o_chg + al(4 * (MAXP + 1));
+    NRS_TRY(c->ensure(g->walk, total));
+    char* b = g->walk.as<char>();
+    NRS_HIP(c, hipMemcpyAsync(b + o_code, code, 4 * (size_t)n_map, hipMemcpyHostToDevice, c->stream));
+    if (is_node) NRS_HIP(c, hipMemcpyAsync(b + o_node, is_node, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemsetAsync(b + o_nacc, 0, 4 * (size_t)n, c->stream));
+    NRS_HIP(c, hipMemsetAsync(b + o_lost, 0, o_chg - o_lost + 4 * (MAXP + 1), c->stream));
+    int* chg = reinterpret_cast<int*>(b + o_chg);
+    auto pass = [&](int slot, int final) {
+        hipLaunchKernelGGL(k_rg_walk, dim3((n + 3) / 4), dim3(256), 0, c->stream, n, cap, d_cnt, d_col, d_st, d_w, d_d0, reinterpret_cast<const int*>(b + o_code),
+                           is_node ? reinterpret_cast<const uint8_t*>(b + o_node) : nullptr, reinterpret_cast<int*>(b + o_acc), reinterpret_cast<int*>(b + o_nacc),
+                           reinterpret_cast<float*>(b + o_w), reinterpret_cast<float*>(b + o_d0), reinterpret_cast<uint8_t*>(b + o_end),
+                           reinterpret_cast<uint8_t*>(b + o_lost), chg + slot, final);
+    };
+    int done = 0, hc[MAXP];
+    while (done < MAXP && !*converged) {                           // batches of passes, one look at their change counts per batch
+        const int batch = std::min(done == 0 ? 6 : 8, MAXP - done);
+        for (int q = 0; q < batch; ++q) pass(done + q, 0);
+        NRS_HIP(c, hipGetLastError());
+        NRS_HIP(c, hipMemcpyAsync(hc + done, chg + done, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        for (int q = 0; q < batch; ++q) if (hc[done + q] == 0) *converged = 1;
+        done += batch;
+    }
+    *passes = done;
+    if (!*converged) return NRS_OK;
+    pass(MAXP, 1);                                                 // (the sets are final: this pass changes nothing and leaves the outputs)
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipMemcpyAsync(n_acc, b + o_nacc, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(acc, b + o_acc, 4 * (size_t)RG_WALK_MAX * n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(acc_w, b + o_w, 4 * (size_t)RG_WALK_MAX * n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(acc_d0, b + o_d0, 4 * (size_t)RG_WALK_MAX * n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(ended, b + o_end, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(lost, b + o_lost, (size_t)n_map, hipMemcpyDeviceToHost, c->stream));
+    int last = 0;
+    NRS_HIP(c, hipMemcpyAsync(&last, chg + MAXP, 4, hipMemcpyDeviceToHost, c->stream));
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    if (last != 0) *converged = 0;                                 // (cannot happen: the fixed point was reached)
+    return NRS_OK;
+}
+
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
-                        const int** status, const float** w, const float** d0, const uint8_t* pass_over) {
+                        const int** status, const float** w, const float** d0, const uint8_t* pass_over, bool lists_to_host) {   // lists_to_host = false: the lists stay on the device (rg_walk reads them there); only the counts come back
     nrs_ctx* c = g->c;
     NRS_TRY(rg_check_ids(g, n_ids, ids, "GetEdges"));               // (also the a2 driver's entry: ids index the dense state)
     if (cap_per_point <= 0) return c->fail(NRS_ERR_INVALID, "GetEdges: cap_per_point must be positive");
@@ -485,8 +608,13 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
         hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), shm, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
                            g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, pass_over ? g->skip.as<uint8_t>() : nullptr, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
         NRS_HIP(c, hipGetLastError());
-        NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (lists_to_host) NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
+        else {
+            NRS_HIP(c, hipMemcpyAsync(h, d_cnt, sizeof(int) * (size_t)n_ids, hipMemcpyDeviceToHost, c->stream));
+            NRS_HIP(c, hipMemcpyAsync(h + 4 * no + (size_t)n_ids, d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
         NRS_HIP(c, hipStreamSynchronize(c->stream));
+        g->last_n_ids = n_ids; g->last_cap = cap_per_point;
         if (h[4 * no + (size_t)n_ids] == 0) break;
         if (pass == 1) return c->fail(NRS_ERR_INVALID, "nrs_rgraph_get_edges: a point has %d connections at or above min_weight: more than this build stages per row (%d)", h[4 * no + (size_t)n_ids], cand_cap);
     }
@@ -508,7 +636,7 @@ extern "C" int nrs_rgraph_get_edges(nrs_rgraph* g, int32_t n_ids, const int32_t*
     if (n_ids == 0) return NRS_OK;
     const int *h_cnt, *h_col, *h_st;
     const float *h_w, *h_d0;
-    NRS_TRY(rg_get_edges_staged(g, n_ids, ids, cap_per_point, &h_cnt, &h_col, &h_st, &h_w, &h_d0, nullptr));
+    NRS_TRY(rg_get_edges_staged(g, n_ids, ids, cap_per_point, &h_cnt, &h_col, &h_st, &h_w, &h_d0, nullptr, true));
     const size_t no = (size_t)n_ids * cap_per_point;
     memcpy(count, h_cnt, sizeof(int) * (size_t)n_ids);
     memcpy(col, h_col, sizeof(int) * no);

@@ -230,6 +230,11 @@ struct NeighbourSource {
     // BAD; a source may leave them out of the lists (the dense one does: an embedded-mode walk would read ~N/M entries per node found)
     const std::vector<uint8_t>* pass_over = nullptr;
     virtual bool grow() { return false; }                          // fetch longer prefixes next time (false: there is nothing longer)
+    // GetEdges of `want` AND the walk of OPT:252-279 over the lists where they are (a source that holds them on the device): per
+    // wanted point (in order) the connections its walk accepts -- indices among `want` -- with weight and first distance, whether the
+    // walk ended before its list did, and the lost-point flags.  *done = false: not available (the caller selects and walks itself).
+    struct WalkOut { std::vector<int> n_acc, acc; std::vector<float> w, d0; std::vector<uint8_t> ended, lost; int passes = 0; };
+    virtual int device_walk(const std::vector<int>&, const std::vector<int>&, const uint8_t*, WalkOut&, bool* done) { *done = false; return NRS_OK; }
     virtual void prefix_hint(int) {}                               // the next walks read about this many entries (grow() still applies)
 };
 
@@ -251,7 +256,9 @@ struct FlatSource : NeighbourSource {
 };
 
 int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_t cap_per_point, const int** count, const int** col,
-                        const int** status, const float** w, const float** d0, const uint8_t* pass_over);   // nrs_rgraph.hip
+                        const int** status, const float** w, const float** d0, const uint8_t* pass_over, bool lists_to_host = true);   // nrs_rgraph.hip
+int rg_walk(nrs_rgraph* g, int n_map, const int* code, const uint8_t* is_node, int* n_acc, int* acc, float* acc_w, float* acc_d0,
+            uint8_t* ended, uint8_t* lost, int* converged, int* passes);
 int rg_capacity(const nrs_rgraph* g);
 int rg_max_cap_per_point(const nrs_rgraph* g);
 
@@ -270,6 +277,20 @@ struct DenseSource : NeighbourSource {
             truncated[p] = cnt[r] > cap;
             beg[p] = (int)(r * (size_t)cap); end[p] = beg[p] + std::min(cnt[r], cap);
         }
+        return NRS_OK;
+    }
+    int device_walk(const std::vector<int>& want, const std::vector<int>& code, const uint8_t* is_node, WalkOut& o, bool* done) override {
+        *done = false;
+        const size_t n = (size_t)n_points, m = want.size();
+        if (m == 0 || code.size() != n) return NRS_OK;
+        const int *cnt, *c1, *c2; const float *f1, *f2;
+        NRS_TRY(rg_get_edges_staged(g, (int32_t)m, want.data(), cap, &cnt, &c1, &c2, &f1, &f2, pass_over ? pass_over->data() : nullptr, false));
+        truncated.assign(n, 0);
+        for (size_t r = 0; r < m; ++r) truncated[want[r]] = cnt[r] > cap;
+        o.n_acc.resize(m); o.acc.resize(11 * m); o.w.resize(11 * m); o.d0.resize(11 * m); o.ended.resize(m); o.lost.resize(n);
+        int conv = 0;
+        NRS_TRY(rg_walk(g, (int)n, code.data(), is_node, o.n_acc.data(), o.acc.data(), o.w.data(), o.d0.data(), o.ended.data(), o.lost.data(), &conv, &o.passes));
+        *done = conv != 0;
         return NRS_OK;
     }
     // (longer prefixes up to what one row's sort buffer holds in LDS; a walk that needs more than that is reported, not cut)
@@ -439,8 +460,58 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         const int io = id_to_idx[o];
         if (io >= 0 && node_of[io] >= 0) walk_code[o] = io;
     }
+    const bool host_walk = getenv("NRS_HOST_WALK") != nullptr;     // (A/B switch: the walk on the host, as before round 5)
+    std::vector<uint8_t> is_node_b;
+    if (M < N) { is_node_b.resize(N); for (int i = 0; i < N; ++i) is_node_b[i] = node_of[i] >= 0; }
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)
     again = false;
+    if (!host_walk) {
+        // the dense graph walks on the device (nrs_rgraph.hip k_rg_walk): the lists never leave it, what comes back are the <= 11 accepted
+        // connections per point; the edges are made from them here in the order the sequential walk makes them
+        NeighbourSource::WalkOut wo;
+        bool dev = false;
+        const auto tw0 = std::chrono::steady_clock::now();
+        NRS_TRY(src.device_walk(ids, walk_code, M < N ? is_node_b.data() : nullptr, wo, &dev));
+        if (tm) fprintf(stderr, "[nrs] a2 device_walk call %.2f ms (N %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), N);
+        if (tm) fprintf(stderr, "[nrs] a2 device walk: %d passes, %s\n", wo.passes, dev ? "converged" : "not taken");
+        if (dev) {
+            mark("GetEdges + device walk");
+            dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear();
+            std::copy(wo.lost.begin(), wo.lost.end(), lost_flag.begin());
+            sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
+            for (int idx = 0; idx < N && !again; ++idx) {
+                const bool is_node = node_of[idx] >= 0;
+                const size_t slot = sk_idx.size();
+                const int nr = wo.n_acc[idx];
+                double wsum = 0;
+                for (int k = 0; k < nr; ++k) {
+                    const int io = wo.acc[11 * (size_t)idx + k];
+                    const float wk = wo.w[11 * (size_t)idx + k];
+                    if (is_node) {
+                        dm_idx.insert(dm_idx.end(), {-1, -1, node_of[idx], node_of[io]});
+                        dm_w.push_back(wk);
+                        sp_ij.insert(sp_ij.end(), {node_of[idx], node_of[io]});
+                        sp_d0.push_back(wo.d0[11 * (size_t)idx + k]);
+                    } else {
+                        sk_node[11 * slot + k] = node_of[io];
+                        sk_om[11 * slot + k] = (double)wk;
+                        wsum += (double)wk;
+                    }
+                }
+                if (!is_node && nr > 0) {
+                    for (int k = 0; k < nr; ++k) sk_om[11 * slot + k] /= wsum;
+                    sk_of[idx] = (int)slot;
+                    sk_idx.push_back(idx);
+                }
+                if (!wo.ended[idx] && !src.truncated.empty() && src.truncated[ids[idx]]) {
+                    if (!src.grow()) return c->fail(NRS_ERR_INVALID, "the neighbour walk of map point %d ran off its list", ids[idx]);
+                    again = true;
+                    if (tm) fprintf(stderr, "[nrs] a2 device walk: point %d ran off its list: longer prefixes\n", idx);
+                }
+            }
+            continue;
+        }
+    }
     NRS_TRY(src.select(ids));                                      // the walks below start from the optimised points only
     const int *ocol = src.col, *ost = src.st;
     const float *ow = src.w, *od0 = src.d0;

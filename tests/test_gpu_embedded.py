@@ -129,3 +129,35 @@ def test_embedded_mode_on_the_pcg_matches_its_oracle(ctx_pcg, n, m, seed, model)
     assert abs(r["median"] - o["median"]) < 1e-5
     assert compare_lm_traces(tr.trials, otr, len(otr)) >= 6
     g.close()
+
+
+@pytest.mark.parametrize("n,m,seed,cap", [(700, 0, 51, 64), (2500, 0, 52, 128), (1500, 200, 53, 256), (900, 0, 54, 8)])
+def test_device_walk_builds_the_same_problem_as_the_host_walk(ctx_direct, monkeypatch, n, m, seed, cap):
+    """The neighbour walk of OPT:252-279 runs on the device for the dense graph (nrs_rgraph.hip k_rg_walk: the sequential loop's sets as the
+    fixed point of a parallel pass, the lists never leave the device) -- against the host loop over the downloaded lists
+    (NRS_HOST_WALK=1): the same edges in the same order, hence the same bits everywhere: parity mode (m = 0: every point a node),
+    embedded mode (m nodes), and a prefix so short (cap 8) that walks run off their lists and the driver has to fetch longer ones."""
+    tp = S.make_tracking_problem(n, seed)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    node = np.ones(n, np.uint8)
+    if m:
+        node[:] = 0
+        node[ctx_direct.skin_select_nodes(tp["X_prev"], m, tp["status"] == 0)] = 1
+    out = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("NRS_HOST_WALK", "1")
+        else:
+            monkeypatch.delenv("NRS_HOST_WALK", raising=False)
+        g, _, ids = _graphs(ctx_direct, tp, n)
+        tr = nrs.Trace(1024)
+        r = ctx_direct.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, cap)
+        st = g.edge_statuses(ids[:200], ids[:200]) if hasattr(g, "edge_statuses") else None
+        out.append((r, tr.trials, st))
+        g.close()
+    monkeypatch.delenv("NRS_HOST_WALK", raising=False)
+    (a, ta, sa), (b, tb, sb) = out
+    for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["lost"] == b["lost"] and a["median"] == b["median"] and len(ta) > 10
+    assert [(t["lam"], t["chi"], t["chi_new"], t["accepted"]) for t in ta] == [(t["lam"], t["chi"], t["chi_new"], t["accepted"]) for t in tb]

@@ -47,5 +47,8 @@ for tscale in (0.0, 0.25, 1.0, 4.0):
     n = len(pos)
     Dn = np.tile(np.eye(3) * 1e3, (n, 1, 1)); Vp = np.zeros((len(pairs), 3, 3)); bn = np.ones((n, 3))
     t0 = time.time()
-    ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
+    try:
+        ok, x, st = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.0)
+    except RuntimeError as ex:
+        print("tscale %.2f: %s" % (tscale, ex), flush=True); continue
     print("tscale %.2f: %d nodes, %d pairs -> %s  (%.1f GFLOP per factorisation; host plan + reference solve %.1f s)" % (tscale, n, len(pairs), st, st["flops"] / 1e9, time.time() - t0), flush=True)
