@@ -530,8 +530,10 @@ int rg_walk(nrs_rgraph* g, int n_map, const int* code, const uint8_t* is_node, i
                            reinterpret_cast<uint8_t*>(b + o_lost), chg + slot, final);
     };
     int done = 0, hc[MAXP];
-    while (done < MAXP && !*converged) {                           // batches of passes, one look at their change counts per batch
-        const int batch = std::min(done == 0 ? 6 : 8, MAXP - done);
+    int max_p = MAXP;                                              // (NRS_WALK_MAX_PASSES: a lower cap, so that the tests reach the caller's host fallback)
+    if (const char* v = getenv("NRS_WALK_MAX_PASSES")) max_p = std::max(1, std::min(MAXP, atoi(v)));
+    while (done < max_p && !*converged) {                          // batches of passes, one look at their change counts per batch
+        const int batch = std::min(done == 0 ? 6 : 8, max_p - done);
         for (int q = 0; q < batch; ++q) pass(done + q, 0);
         NRS_HIP(c, hipGetLastError());
         NRS_HIP(c, hipMemcpyAsync(hc + done, chg + done, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream));

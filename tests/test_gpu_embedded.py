@@ -156,6 +156,15 @@ def test_device_walk_builds_the_same_problem_as_the_host_walk(ctx_direct, monkey
         out.append((r, tr.trials, st))
         g.close()
     monkeypatch.delenv("NRS_HOST_WALK", raising=False)
+    if cap == 64:                                     # the passes run out (capped at 2): the driver falls back to the host walk, same result
+        monkeypatch.setenv("NRS_WALK_MAX_PASSES", "2")
+        g, _, ids = _graphs(ctx_direct, tp, n)
+        tr = nrs.Trace(1024)
+        r = ctx_direct.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, cap)
+        g.close()
+        monkeypatch.delenv("NRS_WALK_MAX_PASSES", raising=False)
+        for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+            assert np.array_equal(r[k], out[0][0][k]), k
     (a, ta, sa), (b, tb, sb) = out
     for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
         assert np.array_equal(a[k], b[k]), k
