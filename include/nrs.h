@@ -304,8 +304,9 @@ int nrs_comm_init_rccl(nrs_ctx* ctx, int32_t world, int32_t rank, const uint8_t*
 int nrs_comm_rank(const nrs_ctx* ctx, int32_t* rank, int32_t* world);
 /* Sizes of the BA problem resident on THIS rank: stats[0] padded landmark rows of the window, [1] rows whose incidence
  * records this rank packed and holds (sharded: the rows of its keyframe range), [2] / [3] spring / damper incidence
- * slots held, [4] device bytes of the problem.  (Vectors stay full length on every rank: the replicated row layout is
- * what the boundary exchange and the final gather address.) */
+ * slots held, [4] device bytes of the problem.  (A rank also holds the per-row arrays -- state, PCG vectors, diagonal blocks --
+ * of its own keyframes and one ghost keyframe either side only; they are addressed by the window's row index all the same.
+ * nrs_dba_download and the residual taps gather through transient full-length scratch that is released when they return.) */
 int nrs_dba_stats(nrs_ctx* ctx, int64_t stats[5]);
 /* keyframe ranges: rank r owns keyframes kf_begin[r] .. kf_begin[r+1]-1 (balanced by padded landmark
  * rows, every rank at least one keyframe).  Host only, needs no device. */
