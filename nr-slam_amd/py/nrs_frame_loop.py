@@ -109,6 +109,9 @@ class GpuBackend:
     def klt_insert_template(self, t):
         self.ctx.klt_insert_template(t)
 
+    def klt_insert_templates(self, ts):                  # (one call, one upload: PointReuse's new slots of a frame)
+        self.ctx.klt_insert_templates(ts)
+
     # the tracker PointReuse builds for its candidates (maxLevel 1, tracking.cc:422-424)
     def reuse_track(self, im, pts, templates, min_ssim):
         o = self.klt_opts
@@ -253,6 +256,7 @@ class FrameLoop:
         seeds = uv[cand].astype(F32)
         xy, st = self.b.reuse_track(im, seeds, [self.templates[mp] for mp in cand], 0.75)
         reused = 0
+        new_k, new_mp = [], []                          # candidates that enter the frame as new slots, in candidate order (one append below)
         for k, mp in enumerate(cand):
             if st[k] != TRACKED_WITH_3D:
                 continue
@@ -263,13 +267,21 @@ class FrameLoop:
             if i >= 0:
                 self.kp[i], self.pos[i], self.status[i] = xy[k], self.map_pos[mp], TRACKED_WITH_3D
             else:
-                self.kp = np.vstack([self.kp, xy[k][None]]).astype(F32)
-                self.pos = np.vstack([self.pos, self.map_pos[mp][None]]).astype(F32)
-                self.status = np.append(self.status, TRACKED_WITH_3D).astype(np.int32)
-                self.map_index = np.append(self.map_index, mp).astype(np.int32)
-                in_frame[mp] = len(self.map_index) - 1
-                self.b.klt_insert_template(dict(self.templates[mp], xy=xy[k].astype(F32)))
+                in_frame[mp] = len(self.map_index) + len(new_mp)
+                new_k.append(k); new_mp.append(mp)
             reused += 1
+        if new_mp:                                      # (the slots and their photometric information, appended in the loop's order)
+            nk, nm = np.asarray(new_k), np.asarray(new_mp)
+            self.kp = np.vstack([self.kp, xy[nk]]).astype(F32)
+            self.pos = np.vstack([self.pos, self.map_pos[nm]]).astype(F32)
+            self.status = np.concatenate([self.status, np.full(len(nm), TRACKED_WITH_3D, np.int32)]).astype(np.int32)
+            self.map_index = np.concatenate([self.map_index, nm]).astype(np.int32)
+            tpl = [dict(self.templates[mp], xy=xy[k].astype(F32)) for k, mp in zip(new_k, new_mp)]
+            if hasattr(self.b, "klt_insert_templates"):
+                self.b.klt_insert_templates(tpl)
+            else:
+                for t in tpl:
+                    self.b.klt_insert_template(t)
         return reused
 
     # ---- tracking.cc:336-392
