@@ -489,6 +489,17 @@ int nrs_klt_get_templates(nrs_ctx* ctx, int32_t first, int32_t count, float* xy,
 int nrs_klt_insert_templates(nrs_ctx* ctx, int32_t count, const float* xy, const int16_t* gray,
                              const int16_t* grad, const float* mean, const uint8_t* valid);
 
+/* The same hand-over without the host in between.  The reference keeps a map point's photometric information in its Map
+ * (GetPhotometricInformation at keyframes, tracking.cc:383-391) and inserts it into a tracker when the point is reused
+ * (InsertPhotometricInformation, tracking.cc:457-460; PointReuse's own tracker, :422-448).  Here the context keeps an ARCHIVE in
+ * device memory: nrs_klt_archive_templates copies the templates of tracker slots `slots[i]` into the archive entries `keys[i]`
+ * (the caller's ids, e.g. map point ids; an entry is overwritten when archived again), nrs_klt_insert_archived appends the entries
+ * `keys[i]` of context `src`'s archive to THIS context's tracker with the positions xy (n x 2).  Both contexts on one device; a
+ * tracker with fewer pyramid levels than the archive takes the levels it has (PointReuse's tracker: maxLevel 1).  Byte for
+ * byte what nrs_klt_get_templates + nrs_klt_insert_templates hand over (tests/test_gpu_klt.py). */
+int nrs_klt_archive_templates(nrs_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* keys);
+int nrs_klt_insert_archived(nrs_ctx* ctx, nrs_ctx* src, int32_t n, const int32_t* keys, const float* xy);
+
 /* ---- N2: the skinned mode ("5k points x 500 graph nodes") --------------------------------------------------------
  * The reference has no separate node set; its skinning is stage 2 of CameraPoseAndDeformationOptimization
  * (modules/optimization/g2o_optimization.cc:476-553, spatial_regularizer_fixed.cc:32-43): points of the frame that are not

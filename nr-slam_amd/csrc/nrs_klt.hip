@@ -45,6 +45,12 @@ struct KltState {
     Pyr pyr;
     int pyr_w = 0, pyr_h = 0;
     DevBuf tI, tD, tMean, tValid, prev, pts, status, misc;
+    // the archive: photometric information kept by a caller's key (the map point id) -- what the reference keeps in its Map per map
+    // point (GetPhotometricInformation at keyframes, InsertPhotometricInformation when a point is reused: tracking.cc:383-391,457-460)
+    // -- in HBM, so that templates never travel to the host and back (nrs_klt_archive_templates / nrs_klt_insert_archived)
+    DevBuf aI, aD, aMean, aValid, a_idx;
+    int a_cap = 0, a_levels = 0;
+    std::vector<uint8_t> a_has;
 };
 
 __device__ __host__ inline int reflect101(int i, int n) {
@@ -399,7 +405,7 @@ static KltState* klt(nrs_ctx* c) {
 void klt_free(nrs_ctx* c) {
     if (!c->klt) return;
     KltState* k = c->klt;
-    DevBuf* bufs[] = {&k->pyr_buf, &k->img_in, &k->mask_in, &k->tI, &k->tD, &k->tMean, &k->tValid, &k->prev, &k->pts, &k->status, &k->misc};
+    DevBuf* bufs[] = {&k->pyr_buf, &k->img_in, &k->mask_in, &k->tI, &k->tD, &k->tMean, &k->tValid, &k->prev, &k->pts, &k->status, &k->misc, &k->aI, &k->aD, &k->aMean, &k->aValid, &k->a_idx};
     for (auto b : bufs) c->release(*b);
     delete k;
     c->klt = nullptr;
@@ -632,5 +638,107 @@ extern "C" int nrs_klt_insert_templates(nrs_ctx* c, int32_t count, const float* 
     NRS_HIP(c, hipMemcpy(k->tMean.as<float>() + 2 * s, mean, sizeof(float) * 2 * L * n, hipMemcpyHostToDevice));
     NRS_HIP(c, hipMemcpy(k->tValid.as<uint8_t>() + s, valid, L * n, hipMemcpyHostToDevice));
     k->n += count;
+    return NRS_OK;
+}
+
+
+// ---- the template archive (device to device) ----------------------------------------------------------------------------------
+// one workgroup per template: `lv` levels of entry src_idx[i] (src_levels levels an entry) into entry dst_idx[i] (dst_levels)
+__global__ __launch_bounds__(256) void k_klt_copy_templates(int n, const int* __restrict__ src_idx, const int* __restrict__ dst_idx, int lv, int src_levels,
+                                                            int dst_levels, const short* __restrict__ sI, const short2* __restrict__ sD, const float* __restrict__ sM,
+                                                            const uint8_t* __restrict__ sV, short* dI, short2* dD, float* dM, uint8_t* dV) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const size_t so = (size_t)src_idx[i] * src_levels, d_o = (size_t)dst_idx[i] * dst_levels;
+    for (int e = threadIdx.x; e < lv * KA; e += 256) { dI[d_o * KA + e] = sI[so * KA + e]; dD[d_o * KA + e] = sD[so * KA + e]; }
+    for (int e = threadIdx.x; e < 2 * lv; e += 256) dM[2 * d_o + e] = sM[2 * so + e];
+    for (int e = threadIdx.x; e < lv; e += 256) dV[d_o + e] = sV[so + e];
+}
+
+static int klt_archive_reserve(nrs_ctx* c, KltState* k, int cap_want) {
+    if (k->a_levels != k->levels && k->a_cap > 0) {                // (another level count: the archive starts over)
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        c->release(k->aI); c->release(k->aD); c->release(k->aMean); c->release(k->aValid);
+        k->a_cap = 0; k->a_has.clear();
+    }
+    k->a_levels = k->levels;
+    if (cap_want <= k->a_cap) return NRS_OK;
+    const int cap = std::max(cap_want + cap_want / 2, 256);
+    const size_t L = (size_t)k->a_levels;
+    DevBuf nI, nD, nM, nV;
+    int rc = c->ensure(nI, sizeof(short) * KA * L * cap);
+    if (rc == NRS_OK) rc = c->ensure(nD, sizeof(short2) * KA * L * cap);
+    if (rc == NRS_OK) rc = c->ensure(nM, sizeof(float) * 2 * L * cap);
+    if (rc == NRS_OK) rc = c->ensure(nV, L * cap);
+    if (rc != NRS_OK) { c->release(nI); c->release(nD); c->release(nM); c->release(nV); return rc; }
+    if (k->a_cap > 0) {
+        const size_t m = (size_t)k->a_cap;
+        NRS_HIP(c, hipMemcpyAsync(nI.p, k->aI.p, sizeof(short) * KA * L * m, hipMemcpyDeviceToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(nD.p, k->aD.p, sizeof(short2) * KA * L * m, hipMemcpyDeviceToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(nM.p, k->aMean.p, sizeof(float) * 2 * L * m, hipMemcpyDeviceToDevice, c->stream));
+        NRS_HIP(c, hipMemcpyAsync(nV.p, k->aValid.p, L * m, hipMemcpyDeviceToDevice, c->stream));
+        NRS_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->release(k->aI); c->release(k->aD); c->release(k->aMean); c->release(k->aValid);
+    k->aI = nI; k->aD = nD; k->aMean = nM; k->aValid = nV;
+    k->a_cap = cap;
+    k->a_has.resize((size_t)cap, 0);
+    return NRS_OK;
+}
+
+extern "C" int nrs_klt_archive_templates(nrs_ctx* c, int32_t n, const int32_t* slots, const int32_t* keys) {
+    if (!c) return NRS_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!slots || !keys))) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: bad argument");
+    if (n == 0) return NRS_OK;
+    KltState* k = c->klt;
+    if (!k) return c->fail(NRS_ERR_STATE, "nrs_klt_archive_templates: no tracker state");
+    int kmax = -1;
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= k->n) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: slot %d out of range", slots[i]);
+        if (keys[i] < 0 || keys[i] > (1 << 26)) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: key %d out of range", keys[i]);
+        kmax = std::max(kmax, keys[i]);
+    }
+    NRS_HIP(c, hipSetDevice(c->device));
+    NRS_TRY(klt_archive_reserve(c, k, kmax + 1));
+    NRS_TRY(c->ensure(k->a_idx, sizeof(int) * 2 * (size_t)n));
+    int* d_idx = k->a_idx.as<int>();
+    NRS_HIP(c, hipMemcpyAsync(d_idx, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d_idx + n, keys, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_klt_copy_templates, dim3(n), dim3(256), 0, c->stream, n, d_idx, d_idx + n, k->levels, k->levels, k->a_levels,
+                       k->tI.as<short>(), k->tD.as<short2>(), k->tMean.as<float>(), k->tValid.as<uint8_t>(),
+                       k->aI.as<short>(), k->aD.as<short2>(), k->aMean.as<float>(), k->aValid.as<uint8_t>());
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipStreamSynchronize(c->stream));                   // (the caller's index arrays are free again; the archive is complete for any stream)
+    for (int i = 0; i < n; ++i) k->a_has[keys[i]] = 1;
+    return NRS_OK;
+}
+
+extern "C" int nrs_klt_insert_archived(nrs_ctx* c, nrs_ctx* src, int32_t n, const int32_t* keys, const float* xy) {
+    if (!c || !src) return NRS_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!keys || !xy))) return c->fail(NRS_ERR_INVALID, "nrs_klt_insert_archived: bad argument");
+    if (n == 0) return NRS_OK;
+    if (c->device != src->device) return c->fail(NRS_ERR_INVALID, "nrs_klt_insert_archived: the two contexts are on different devices");
+    KltState* ks = src->klt;
+    if (!ks || ks->a_cap == 0) return c->fail(NRS_ERR_STATE, "nrs_klt_insert_archived: the source context holds no archive");
+    KltState* k = klt(c);
+    if (!k) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    if (k->levels > ks->a_levels) return c->fail(NRS_ERR_INVALID, "nrs_klt_insert_archived: the archive holds %d levels, this tracker needs %d", ks->a_levels, k->levels);
+    for (int i = 0; i < n; ++i)
+        if (keys[i] < 0 || keys[i] >= ks->a_cap || !ks->a_has[keys[i]]) return c->fail(NRS_ERR_INVALID, "nrs_klt_insert_archived: nothing archived under key %d", keys[i]);
+    NRS_HIP(c, hipSetDevice(c->device));
+    NRS_TRY(reserve_points(c, k, k->n + n, true));
+    NRS_TRY(c->ensure(k->a_idx, sizeof(int) * 2 * (size_t)n));
+    std::vector<int> dst((size_t)n);
+    for (int i = 0; i < n; ++i) dst[i] = k->n + i;
+    int* d_idx = k->a_idx.as<int>();
+    NRS_HIP(c, hipMemcpyAsync(d_idx, keys, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d_idx + n, dst.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(k->prev.as<float>() + 2 * (size_t)k->n, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_klt_copy_templates, dim3(n), dim3(256), 0, c->stream, n, d_idx, d_idx + n, k->levels, ks->a_levels, k->levels,
+                       ks->aI.as<short>(), ks->aD.as<short2>(), ks->aMean.as<float>(), ks->aValid.as<uint8_t>(),
+                       k->tI.as<short>(), k->tD.as<short2>(), k->tMean.as<float>(), k->tValid.as<uint8_t>());
+    NRS_HIP(c, hipGetLastError());
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    k->n += n;
     return NRS_OK;
 }

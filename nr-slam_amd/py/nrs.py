@@ -560,6 +560,18 @@ class Context:
                                                  _p(grad, C.c_int16), _p(mean, C.c_float), _p(valid, C.c_uint8)))
         return [dict(xy=xy[i], gray=gray[i], grad=grad[i], mean=mean[i], valid=valid[i]) for i in range(count)]
 
+    def klt_archive_templates(self, slots, keys):
+        """copy the templates of tracker slots into this context's device-side archive under `keys` (include/nrs.h nrs_klt_archive_templates)"""
+        slots, keys = _i32(slots), _i32(keys)
+        assert len(slots) == len(keys)
+        self._chk(self.lib.nrs_klt_archive_templates(self.h, C.c_int32(len(slots)), _p(slots, C.c_int32), _p(keys, C.c_int32)))
+
+    def klt_insert_archived(self, src, keys, xy):
+        """append the archive entries `keys` of context `src` to this context's tracker at positions xy (nrs_klt_insert_archived)"""
+        keys, xy = _i32(keys), _f32(xy).reshape(-1, 2)
+        assert len(keys) == len(xy)
+        self._chk(self.lib.nrs_klt_insert_archived(self.h, src.h, C.c_int32(len(keys)), _p(keys, C.c_int32), _p(xy, C.c_float)))
+
     def klt_insert_templates(self, ts):
         """append several templates (each as returned by klt_get_template; levels beyond this tracker's are ignored)."""
         L = getattr(self, "_klt_levels", 5)

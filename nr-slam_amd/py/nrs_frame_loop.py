@@ -112,6 +112,22 @@ class GpuBackend:
     def klt_insert_templates(self, ts):                  # (one call, one upload: PointReuse's new slots of a frame)
         self.ctx.klt_insert_templates(ts)
 
+    # The map's photometric information stays on the device (include/nrs.h nrs_klt_archive_templates): archived by map point id at
+    # keyframes, inserted from there when a point is reused.  (NRS_FRAME_LOOP_HOST_TEMPLATES=1: through the host, as before round 5.)
+    def archive_templates(self, slots, mps):
+        self.ctx.klt_archive_templates(slots, mps)
+
+    def insert_archived(self, mps, xy):
+        self.ctx.klt_insert_archived(self.ctx, mps, xy)
+
+    def reuse_track_archived(self, im, pts, mps, min_ssim):
+        o = self.klt_opts
+        self.ctx_reuse.klt_clear()
+        self.ctx_reuse.klt_configure(o["win"], 1, o["max_iters"], o["epsilon"], o["min_eig"])
+        self.ctx_reuse.klt_insert_archived(self.ctx, mps, pts)
+        xy, st, good, _ = self.ctx_reuse.klt_track(im, pts, np.zeros(len(pts), np.int32), initial_flow=True, min_ssim=min_ssim)
+        return xy, st
+
     # the tracker PointReuse builds for its candidates (maxLevel 1, tracking.cc:422-424)
     def reuse_track(self, im, pts, templates, min_ssim):
         o = self.klt_opts
@@ -187,7 +203,13 @@ class FrameLoop:
         self.extract = extract_on_keyframes
         # initial keyframe: klt reference + photometric information of every map point (tracking.cc:201-209)
         self.b.klt_set_reference(im0, self.kp)
-        self.templates = self.b.klt_get_templates(n)
+        import os
+        self.dev_templates = hasattr(self.b, "archive_templates") and not os.environ.get("NRS_FRAME_LOOP_HOST_TEMPLATES")
+        if self.dev_templates:
+            self.templates = None
+            self.b.archive_templates(np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32))
+        else:
+            self.templates = self.b.klt_get_templates(n)
         self.log = []
 
     # ---- tracking.cc:72-112 (tracked branch)
@@ -254,7 +276,10 @@ class FrameLoop:
         if not cand:
             return 0
         seeds = uv[cand].astype(F32)
-        xy, st = self.b.reuse_track(im, seeds, [self.templates[mp] for mp in cand], 0.75)
+        if self.dev_templates:
+            xy, st = self.b.reuse_track_archived(im, seeds, np.asarray(cand, np.int32), 0.75)
+        else:
+            xy, st = self.b.reuse_track(im, seeds, [self.templates[mp] for mp in cand], 0.75)
         reused = 0
         new_k, new_mp = [], []                          # candidates that enter the frame as new slots, in candidate order (one append below)
         for k, mp in enumerate(cand):
@@ -276,6 +301,9 @@ class FrameLoop:
             self.pos = np.vstack([self.pos, self.map_pos[nm]]).astype(F32)
             self.status = np.concatenate([self.status, np.full(len(nm), TRACKED_WITH_3D, np.int32)]).astype(np.int32)
             self.map_index = np.concatenate([self.map_index, nm]).astype(np.int32)
+            if self.dev_templates:
+                self.b.insert_archived(nm.astype(np.int32), xy[nk].astype(F32))
+                return reused
             tpl = [dict(self.templates[mp], xy=xy[k].astype(F32)) for k, mp in zip(new_k, new_mp)]
             if hasattr(self.b, "klt_insert_templates"):
                 self.b.klt_insert_templates(tpl)
@@ -307,8 +335,12 @@ class FrameLoop:
         self.pos[self.status == TRACKED] = 0
         self.map_index[self.status == TRACKED] = -1               # only the 3D slots keep their map point (frame.cc:56-62)
         self.b.klt_set_reference(im, self.kp)
+        if self.dev_templates:                                     # Frame::MapPointIdToIndex: slots that have a map point
+            slots = np.nonzero(self.map_index >= 0)[0].astype(np.int32)
+            self.b.archive_templates(slots, self.map_index[slots].astype(np.int32))
+            return True
         tpl = self.b.klt_get_templates(len(self.map_index))
-        for i, mp in enumerate(self.map_index):                    # Frame::MapPointIdToIndex: slots that have a map point
+        for i, mp in enumerate(self.map_index):
             if mp >= 0:
                 self.templates[mp] = tpl[i]
         return True

@@ -146,3 +146,56 @@ def test_batched_templates_equal_single_point_calls(ctx):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     ctx.klt_clear()
     ctx.klt_configure()
+
+
+def test_archived_templates_equal_the_host_hand_over(ctx):
+    """nrs_klt_archive_templates / nrs_klt_insert_archived: the map's photometric information kept in device memory by map point id.
+    Archive some slots under arbitrary keys, overwrite one entry, then insert from the archive into (i) a fresh two-level tracker of
+    ANOTHER context (PointReuse's tracker) and (ii) the archiving tracker itself -- byte for byte what get_templates + insert_templates
+    hand over, and the same track results.  Unknown keys, bad slots and a tracker with more levels than the archive are refused."""
+    sq, lk = _setup(ctx, 40, 13)
+    n = ctx.klt_num_points()
+    host = ctx.klt_get_templates(0, n)
+    slots, keys = np.array([3, 7, 20, 11], np.int32), np.array([900, 2, 57, 900], np.int32)     # (key 900 is archived twice: the later slot stands)
+    ctx.klt_archive_templates(slots, keys)
+    other = nrs.Context()
+    try:
+        use_keys, use_slots = [2, 900, 57], [7, 11, 20]
+        xy = np.stack([host[s]["xy"] for s in use_slots]) + np.float32(0.5)
+        res = []
+        for archived in (True, False):
+            other.klt_clear()
+            other.klt_configure(21, 1)
+            if archived:
+                other.klt_insert_archived(ctx, use_keys, xy)
+            else:
+                other.klt_insert_templates([dict(host[s], xy=xy[i]) for i, s in enumerate(use_slots)])
+            assert other.klt_num_points() == 3
+            got = other.klt_get_templates(0, 3)
+            res.append((got, other.klt_track(sq["im1"], xy, np.zeros(3, np.int32))))
+        for a, b in zip(res[0][0], res[1][0]):
+            for k in ("xy", "gray", "grad", "mean", "valid"):
+                assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
+        # into the archiving tracker itself (a reused point becomes a new slot of the frame's tracker): all five levels
+        ctx.klt_insert_archived(ctx, [57], host[20]["xy"][None])
+        t = ctx.klt_get_template(n)
+        for k in ("xy", "gray", "grad", "mean", "valid"):
+            assert np.array_equal(t[k], host[20][k]), k
+        with pytest.raises(nrs.NrsError):
+            other.klt_insert_archived(ctx, [5], xy[:1])              # nothing archived under key 5
+        with pytest.raises(nrs.NrsError):
+            ctx.klt_archive_templates([n + 5], [1])                 # no such slot
+        two = nrs.Context()
+        try:
+            two.klt_configure(21, 1)
+            two.klt_set_reference(sq["im0"], sq["pts"][:4])
+            two.klt_archive_templates([0], [0])
+            with pytest.raises(nrs.NrsError):
+                ctx.klt_insert_archived(two, [0], xy[:1])           # a five-level tracker cannot take a two-level entry
+        finally:
+            two.close()
+    finally:
+        other.close()
+    ctx.klt_clear()
+    ctx.klt_configure()
