@@ -292,6 +292,14 @@ public:
     void InsertPhotometricInformation(const PhotometricInformation& p) {
         e_.check_rc(nrs_klt_insert_template(e_.raw(), p.xy, p.gray.data(), p.grad.data(), p.mean.data(), p.valid.data()));
     }
+    // (no reference counterpart: the photometric information of map points kept in device memory by id instead of in MapPoint --
+    // ArchivePhotometricInformation at a keyframe, InsertArchived where the reference inserts a stored PhotometricInformation)
+    void ArchivePhotometricInformation(const std::vector<int32_t>& slots, const std::vector<int32_t>& ids) {
+        e_.check_rc(nrs_klt_archive_templates(e_.raw(), (int32_t)slots.size(), slots.data(), ids.data()));
+    }
+    void InsertArchived(LucasKanadeTracker& from, const std::vector<int32_t>& ids, const std::vector<float>& xy) {
+        e_.check_rc(nrs_klt_insert_archived(e_.raw(), from.e_.raw(), (int32_t)ids.size(), ids.data(), xy.data()));
+    }
     void clear() { e_.check_rc(nrs_klt_clear(e_.raw())); }
     int size() { return nrs_klt_num_points(e_.raw()); }
 
