@@ -149,6 +149,9 @@ __device__ __forceinline__ void nd_store_x(const NdDev& N, const NdFrontD& F, co
 
 // trailing update of the panel factorisation on the matrix cores: C_rb,cb -= P_rb P_cb^T for the block columns cb in [cb_lo, cb_hi) and
 // the row blocks rb >= cb, P = the 16 columns at k0; the tiles are dealt round-robin to the waves w0 .. w0 + nw - 1 (this wave: widx)
+// (KB: the panel is KB consecutive 16-column blocks at k0 -- two of them in the 32-column steps, applied in column order: the same
+// sequence of matrix-core operations on a tile as two single-block updates one after the other)
+template <int KB = 1>
 __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo, int cb_hi, int nrt, int widx, int nw, int skip_first = 0) {
     if (widx < 0 || widx >= nw) return;
     int cnt = 0;
@@ -158,24 +161,41 @@ __device__ __forceinline__ void nd_update(double* W, int lane, int k0, int cb_lo
         for (int rb = cb + (cb == cb_lo ? skip_first : 0); rb < nrt; ++rb, ++cnt) {      // (skip_first: the diagonal tile of the first column is somebody else's)
             if (cnt % nw != widx) continue;
             nd_v4d c;
-            double av[4], bv[4];
+            double av[4 * KB], bv[4 * KB];
 #pragma unroll
             for (int g = 0; g < 4; ++g) c[g] = W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < 4 * KB; ++kk) {
                 av[kk] = -W[(16 * rb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
                 bv[kk] = W[(16 * cb + (lane & 15)) * ND_LD + k0 + 4 * kk + (lane >> 4)];
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
+            for (int kk = 0; kk < 4 * KB; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) W[(16 * rb + (lane >> 4) + 4 * g) * ND_LD + 16 * cb + (lane & 15)] = c[g];
         }
 }
 
+// step B of the panel factorisation for the panel row `row` against the diagonal block at k0 (one row per calling thread; the store is
+// predicated by `live`): see k_nd_level
+__device__ __forceinline__ void nd_b_row(double* W, const double* dinv, int k0, int row, bool live, int lane) {
+    const int li = lane & 15;
+    double x[16], lk[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { x[q] = W[row * ND_LD + k0 + q]; lk[q] = W[(k0 + li) * ND_LD + k0 + q]; }
+    double di[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) di[q] = dinv[k0 + q];
+    nd_b_cols<0>(x, lk, di);
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) W[row * ND_LD + k0 + q] = x[q];
+    }
+}
+
 // NTH threads per workgroup: 256, or 512 (two waves per SIMD: seven waves instead of three on the trailing updates next to the diagonal
 // block, one pass over the children's slots instead of two, a Schur tile per wave); which wave computes a tile does not change its bits
-template <int NTH>
+template <int NTH, bool W32 = false>
 __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained) {   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
     extern __shared__ double sm[];
     constexpr int NW = NTH / 64, NT3 = (9 + NW - 1) / NW;          // waves; Schur tiles (of nine) per wave
@@ -376,6 +396,54 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
     const int nb = s16 >> 4, nrt = nrow >> 4;
     int bad = 0;
     long long tA = 0, tB = 0, tq = 0;                              // (NRS_ND_DBG: time of wave 0 in steps A and B)
+    if constexpr (W32) {
+        // 32-column steps (round 5): blocks a and b = a + 1 per step.  Wave 0 runs the chain that cannot be shortened -- the diagonal block
+        // of a, the sixteen panel rows of block b against it, their product into the diagonal block of b, the diagonal block of b --
+        // and the other waves do everything else next to it: (P1) the two panels of the step before into block columns a and b, (P2) the
+        // rows below block b against block a, (P3) those rows' product into block column b and the two panels of the step before into
+        // the columns behind b, (P4, all waves) the rows against block b.  Four barriers per 32 columns as before, but the chain no longer waits for the rows and their products between its
+        // two diagonal blocks.  Every tile sees the same operations in the same order as in the 16-column form: the same bits.
+#pragma unroll 1
+        for (int a = 0; a < nb; a += 2) {
+            const int ka = 16 * a, b = a + 1, kbb = 16 * b;
+            const bool pair = b < nb;
+            if (N.clk) tq = wall_clock64();
+            if (wave == 0) {                                       // P1
+                if (a > 0) nd_update<2>(W, lane, ka - 32, a, a + 1, a + 1, 0, 1);
+                nd_diag_factor(W, dinv, ka, lane, bad);
+            } else if (a > 0) nd_update<2>(W, lane, ka - 32, a, min(a + 2, nb), nrt, wave - 1, NW - 1, 1);   // (block columns a and b only: the columns behind them get theirs in P3, next to the chain's second diagonal block)
+            __syncthreads();
+            if (N.clk) { const long long t = wall_clock64(); tA += t - tq; tq = t; }
+            if (!pair) {                                           // (an odd last block: its rows, and done)
+                if (ka + 16 + 64 * wave < nrow) nd_b_row(W, dinv, ka, min(ka + 16 + tid, nrow - 1), ka + 16 + tid < nrow, lane);
+                __syncthreads();
+                if (N.clk) tB += wall_clock64() - tq;
+                break;
+            }
+            if (wave == 0) {                                       // P2: rows of block b against block a, then their product into (b, b)
+                nd_b_row(W, dinv, ka, kbb + (lane & 15), lane < 16, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                nd_update<1>(W, lane, ka, b, b + 1, b + 1, 0, 1);
+            } else {
+                const int row = kbb + 16 + (tid - 64);
+                if (kbb + 16 + 64 * (wave - 1) < nrow) nd_b_row(W, dinv, ka, min(row, nrow - 1), row < nrow, lane);
+            }
+            __syncthreads();
+            if (N.clk) { const long long t = wall_clock64(); tB += t - tq; tq = t; }
+            if (wave == 0) nd_diag_factor(W, dinv, kbb, lane, bad);                                   // P3
+            else {
+                nd_update<1>(W, lane, ka, b, b + 1, nrt, wave - 1, NW - 1, 1);
+                if (a > 0) nd_update<2>(W, lane, ka - 32, a + 2, nb, nrt, wave - 1, NW - 1, 0);
+            }
+            __syncthreads();
+            if (N.clk) { const long long t = wall_clock64(); tA += t - tq; tq = t; }
+            if (kbb + 16 + 64 * wave < nrow) nd_b_row(W, dinv, kbb, min(kbb + 16 + tid, nrow - 1), kbb + 16 + tid < nrow, lane);   // P4
+            __syncthreads();
+            if (N.clk) tB += wall_clock64() - tq;
+        }
+    } else
 #pragma unroll 1
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 16 * kb;
@@ -846,8 +914,10 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
             }
         }
     if (!S.attr_set) {
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         S.attr_set = true;
@@ -876,9 +946,14 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // its reads of the children's slots and its Schur tiles; same bits either way)
     const char* nth_env = getenv("NRS_ND_THREADS");
     const bool wide = !(nth_env && atoi(nth_env) == 256);
+    // 32-column panel steps (k_nd_level<.., true>) unless NRS_ND_STEP32=0; same bits as the 16-column form
+    const char* s32_env = getenv("NRS_ND_STEP32");
+    const bool step32 = !(s32_env && atoi(s32_env) == 0);
     auto level = [&](int n, size_t shm, int wg0, int chained) {
-        if (wide) hipLaunchKernelGGL(k_nd_level<512>, dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
-        else hipLaunchKernelGGL(k_nd_level<256>, dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        if (wide && step32) hipLaunchKernelGGL((k_nd_level<512, true>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        else if (wide) hipLaunchKernelGGL((k_nd_level<512, false>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        else if (step32) hipLaunchKernelGGL((k_nd_level<256, true>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        else hipLaunchKernelGGL((k_nd_level<256, false>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
     };
     const int chain_from = per_level || S.dev.clk ? P.n_levels : S.chain_from;
     {

@@ -121,8 +121,13 @@ def test_chained_and_per_level_factorisation_give_the_same_bits(ctx, monkeypatch
         ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
         monkeypatch.setenv("NRS_ND_THREADS", "256")
         ok3, x3, st3, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.setenv("NRS_ND_STEP32", "0")                       # ... and the panel by 16-column steps (the round-4 form), on 256 and 512 threads
+        ok4, x4, st4, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
         monkeypatch.delenv("NRS_ND_THREADS", raising=False)
+        ok5, x5, st5, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.delenv("NRS_ND_STEP32", raising=False)
         assert ok and ok1 and ok2 and ok3 and st == st2 and np.array_equal(x, x1) and np.array_equal(x, x2) and np.array_equal(x, x3), n
+        assert ok4 and ok5 and np.array_equal(x, x4) and np.array_equal(x, x5), n
 
 
 def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypatch):
