@@ -982,6 +982,11 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     return NRS_OK;
 }
 
+// leaf size of the dissection (nodes): ND_LEAFN unless NRS_ND_LEAF says otherwise (a tuning knob: part of the plan cache's key)
+static int nd_leaf_n() {
+    if (const char* v = getenv("NRS_ND_LEAF")) return std::max(4, std::min(ND_LEAFN, atoi(v)));
+    return ND_LEAFN;
+}
 void nd_orient_pairs(const NdPlan& P, const int32_t* pairs, const double* Vp, std::vector<double>& out);   // nrs_host_build.cpp
 void nd_stats(const NdPlan& P, int64_t* stats);
 
@@ -991,7 +996,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
     NRS_HIP(c, hipSetDevice(c->device));
     NdSolver S;
     std::string err;
-    if (!nd_build_plan(n_nodes, pos, last, n_pairs, pairs, S.plan, &err)) return c->fail(NRS_ERR_INVALID, "direct solve: %s", err.c_str());
+    if (!nd_build_plan(n_nodes, pos, last, n_pairs, pairs, S.plan, &err, nd_leaf_n())) return c->fail(NRS_ERR_INVALID, "direct solve: %s", err.c_str());
     nd_stats(S.plan, stats);
     struct Rel { nrs_ctx* c; NdSolver* s; ~Rel() { (void)hipStreamSynchronize(c->stream); c->release(s->own); } } rel{c, &S};
     NRS_TRY(nd_upload(c, S));
@@ -1427,7 +1432,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     {
         std::vector<uint8_t> bits(in.M);
         for (int v = 0; v < in.M; ++v) bits[v] = in.rflag[v] & (RF_FIXED | RF_OBS);
-        const int hdr[8] = {n_free, P.pose_free ? 1 : 0, in.M, in.n_skin, ND_LEAFN, ND_SMAXN, in.n_sp, in.n_dm};
+        const int hdr[8] = {n_free, P.pose_free ? 1 : 0, in.M, in.n_skin, nd_leaf_n(), ND_SMAXN, in.n_sp, in.n_dm};
         std::vector<uint8_t>& key = P.key;
         key.clear();
         auto put = [&](const void* p, size_t bytes) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + bytes); };
@@ -1533,7 +1538,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
-    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, ND_LEAFN, ND_SMAXN, false, nd_plan_par_min());
+    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, nd_leaf_n(), ND_SMAXN, false, nd_plan_par_min());
     if (P.plan_ok && in.n_skin > 0) { nd_prep_ske(P, P.plan); nd_prep_ske_values(P, in.sk_om); }
     lap(2);
     if (tm) fprintf(stderr, "[nrs] direct solve set-up thread: key %.2f ms, pairs %.2f ms, plan %.2f ms\n", t_ms[0], t_ms[1], t_ms[2]);
