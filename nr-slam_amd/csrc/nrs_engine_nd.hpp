@@ -552,8 +552,10 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
 // a 4.4k-point frame).  Same operands, same matrix-core sequence, same accumulation order as k_nd_level's tile: the same bits.  LDS: two
 // 48-row blocks (74 KB), two workgroups per CU.
 constexpr int ND_TILE_LDS = 2 * ND_TB * ND_LD;                     // doubles
-__global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_nd_tile(NdDev N, int wg0) {
     extern __shared__ double sm[];
+    constexpr int NW = NTH / 64, NT3 = (9 + NW - 1) / NW;          // waves; tiles (of nine) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NdWgD wd = N.wg[wg0 + blockIdx.x];
     const int I = wd.I, J = wd.J;
@@ -572,28 +574,28 @@ __global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
     const double* L = N.Lp + F.L_off;
     const double* srcI = L + (size_t)(s + ND_TB * I) * s;
     const double* srcJ = L + (size_t)(s + ND_TB * J) * s;
-    constexpr int NL = (ND_TB * ND_S16 + 255) / 256;               // 18 values per thread and block at most
+    constexpr int NL = (ND_TB * ND_S16 + NTH - 1) / NTH;           // values per thread and block at most (18 on 256 threads)
     double vi[NL], vj[NL];
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NTH * u;
         vi[u] = i < rI * s ? srcI[i] : 0.0;
         vj[u] = i < cJ * s ? srcJ[i] : 0.0;
     }
     const size_t slot = (size_t)(m + 1) * F.ldA;
     const double* A0 = N.A + F.A_off;
-    nd_v4d acc[3];
+    nd_v4d acc[NT3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NT3; ++q) acc[q] = nd_v4d{0.0, 0.0, 0.0, 0.0};
     if (F.n_ch > 0) {                                              // F22 tile (I, J) of the children, as in k_nd_level
         auto tile_off = [&](int r, int cc) {
             const int fr = s + ND_TB * I + r, fc = s + ND_TB * J + cc;
             return (size_t)max(fr, fc) * F.ldA + min(fr, fc);
         };
-        double tv[2][3][4];
+        double tv[2][NT3][4];
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+        for (int t3 = 0; t3 < NT3; ++t3) {
+            const int t = wave + NW * t3, ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
@@ -605,13 +607,13 @@ __global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
             }
         }
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3)
+        for (int t3 = 0; t3 < NT3; ++t3)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[t3][g] = tv[0][t3][g] + (F.n_ch > 1 ? tv[1][t3][g] : 0.0);
         for (int k = 2; k < F.n_ch; ++k)
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int t = wave + 4 * t3, ti = t / 3, tj = t - 3 * ti;
+            for (int t3 = 0; t3 < NT3; ++t3) {
+                const int t = wave + NW * t3, ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * ti + (lane >> 4) + 4 * g, cc = 16 * tj + (lane & 15);
@@ -624,28 +626,28 @@ __global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
     const float invs = 1.0f / (float)s;
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NTH * u;
         const int r = __float2int_rz(((float)i + 0.5f) * invs), q = i - r * s;
         if (i < rI * s) LI[r * ND_LD + q] = vi[u];
         if (i < cJ * s) LJ[r * ND_LD + q] = vj[u];
     }
-    for (int i = tid; i < ND_TB * (s16 - s); i += 256) {            // pad columns of both blocks
+    for (int i = tid; i < ND_TB * (s16 - s); i += NTH) {            // pad columns of both blocks
         const int r = i / (s16 - s), q = s + i % (s16 - s);
         LI[r * ND_LD + q] = 0.0; LJ[r * ND_LD + q] = 0.0;
     }
-    for (int i = tid; i < (ND_TB - rI) * s; i += 256) LI[(rI + i / s) * ND_LD + i % s] = 0.0;   // rows below a partial block I
+    for (int i = tid; i < (ND_TB - rI) * s; i += NTH) LI[(rI + i / s) * ND_LD + i % s] = 0.0;   // rows below a partial block I
     __syncthreads();
     stamp(1); stamp(2); stamp(3);
     if (F.par >= 0) {
-        int ti[3], tj[3];
+        int ti[NT3], tj[NT3];
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) { const int t = min(wave + 4 * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
-        const bool third = wave == 0;
+        for (int t3 = 0; t3 < NT3; ++t3) { const int t = min(wave + NW * t3, 8); ti[t3] = t / 3; tj[t3] = t - 3 * ti[t3]; }
+        const bool last = wave + NW * (NT3 - 1) < 9;
 #pragma unroll 1
         for (int k4 = 0; k4 < (s16 >> 4); ++k4) {
-            double av[3][4], bv[3][4];
+            double av[NT3][4], bv[NT3][4];
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3)
+            for (int t3 = 0; t3 < NT3; ++t3)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     av[t3][kk] = -LI[(16 * ti[t3] + (lane & 15)) * ND_LD + 16 * k4 + 4 * kk + (lane >> 4)];
@@ -653,15 +655,15 @@ __global__ __launch_bounds__(256) void k_nd_tile(NdDev N, int wg0) {
                 }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc[1], 0, 0, 0);
-                if (third) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2][kk], bv[2][kk], acc[2], 0, 0, 0);
+#pragma unroll
+                for (int t3 = 0; t3 < NT3 - 1; ++t3) acc[t3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t3][kk], bv[t3][kk], acc[t3], 0, 0, 0);
+                if (last) acc[NT3 - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[NT3 - 1][kk], bv[NT3 - 1][kk], acc[NT3 - 1], 0, 0, 0);
             }
         }
         double* Ap = N.A + F.pA_off;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            if (wave + 4 * t3 >= 9) break;
+        for (int t3 = 0; t3 < NT3; ++t3) {
+            if (wave + NW * t3 >= 9) break;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * ti[t3] + (lane >> 4) + 4 * g, cc = 16 * tj[t3] + (lane & 15);
@@ -919,7 +921,8 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_level<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_nd_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         S.attr_set = true;
     }
     for (int l = 0; l < P.n_levels; ++l)
@@ -965,7 +968,8 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
             const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
             if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
                 level(nA, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
-                hipLaunchKernelGGL(k_nd_tile, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
+                if (wide) hipLaunchKernelGGL(k_nd_tile<512>, dim3(n - nA), dim3(512), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
+                else hipLaunchKernelGGL(k_nd_tile<256>, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
             } else level(n, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
         }
         if (chain_from < P.n_levels) {                             // the levels above in one launch (all of them when the whole factorisation is resident at once)
