@@ -700,11 +700,19 @@ extern "C" int nrs_klt_archive_templates(nrs_ctx* c, int32_t n, const int32_t* s
     }
     NRS_HIP(c, hipSetDevice(c->device));
     NRS_TRY(klt_archive_reserve(c, k, kmax + 1));
-    NRS_TRY(c->ensure(k->a_idx, sizeof(int) * 2 * (size_t)n));
+    // a key listed more than once: its LAST occurrence stands (the copies run side by side: two of them must not share a destination)
+    std::vector<int> u_slot, u_key;
+    {
+        std::vector<int> last((size_t)kmax + 1, -1);
+        for (int i = 0; i < n; ++i) last[keys[i]] = i;
+        for (int i = 0; i < n; ++i) if (last[keys[i]] == i) { u_slot.push_back(slots[i]); u_key.push_back(keys[i]); }
+    }
+    const int m = (int)u_key.size();
+    NRS_TRY(c->ensure(k->a_idx, sizeof(int) * 2 * (size_t)m));
     int* d_idx = k->a_idx.as<int>();
-    NRS_HIP(c, hipMemcpyAsync(d_idx, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    NRS_HIP(c, hipMemcpyAsync(d_idx + n, keys, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_klt_copy_templates, dim3(n), dim3(256), 0, c->stream, n, d_idx, d_idx + n, k->levels, k->levels, k->a_levels,
+    NRS_HIP(c, hipMemcpyAsync(d_idx, u_slot.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    NRS_HIP(c, hipMemcpyAsync(d_idx + m, u_key.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_klt_copy_templates, dim3(m), dim3(256), 0, c->stream, m, d_idx, d_idx + m, k->levels, k->levels, k->a_levels,
                        k->tI.as<short>(), k->tD.as<short2>(), k->tMean.as<float>(), k->tValid.as<uint8_t>(),
                        k->aI.as<short>(), k->aD.as<short2>(), k->aMean.as<float>(), k->aValid.as<uint8_t>());
     NRS_HIP(c, hipGetLastError());
