@@ -28,6 +28,7 @@ namespace nrs {
 constexpr int ND_LD = 97;            // LDS leading dimension (doubles): odd, so the column-strided operand reads of the MFMAs are conflict-free
 constexpr int ND_S16 = 96;
 typedef double nd_v4d __attribute__((ext_vector_type(4)));
+constexpr unsigned long long ND_POISON = 0x7FF8A5A5DEADBEEFull;   // "not written yet" in xn: a NaN payload no arithmetic produces
 
 struct NdWgD { NdFrontD F; int I, J, pad; };          // one workgroup of k_nd_level: its front and its (I >= J) pair of row blocks
 struct NdDev {
@@ -40,6 +41,9 @@ struct NdDev {
     int* done;                       // per front: the solve (epoch) whose back substitution has written its unknowns (single-launch back pass)
     int* fcnt;                       // per front: Schur tiles its children have delivered, over all solves (single-launch factorisation)
     int* flags;                      // [0] done [1] iterations [2] not positive definite (the engine's PCG flags, or a scratch word block)
+    int n_x3;                        // 3 x nodes: the length of xn
+    int x_poll;                      // back pass: 1 = a front reads its boundary's unknowns by polling the VALUES (xn is poisoned when a solve starts and every
+                                     // unknown is written once), 0 = by its ancestors' done flags (NRS_ND_BACK_FLAGS=1: the round-4 hand-over)
     long long* clk;                  // NRS_ND_DBG: 8 phase clocks (100 MHz) per workgroup of the factorisation, then per front of the back substitution; else null
 };
 
@@ -142,7 +146,8 @@ __device__ __forceinline__ void nd_store_x(const NdDev& N, const NdFrontD& F, co
         const int q = lane + 64 * h;
         if (q >= F.s) continue;
         const double xv = h ? x1 : x0;
-        N.xn[3 * (size_t)r.node[h] + q % 3] = xv;
+        if (N.x_poll) __hip_atomic_store(N.xn + 3 * (size_t)r.node[h] + q % 3, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a reader polls this very word)
+        else N.xn[3 * (size_t)r.node[h] + q % 3] = xv;
         if (N.node_out) { if (r.o[h] >= 0) N.out_rows[r.o[h] + q % 3] = xv; else N.out_pose[-1 - r.o[h] + q % 3] = xv; }
     }
 }
@@ -196,7 +201,7 @@ __device__ __forceinline__ void nd_b_row(double* W, const double* dinv, int k0, 
 // NTH threads per workgroup: 256, or 512 (two waves per SIMD: seven waves instead of three on the trailing updates next to the diagonal
 // block, one pass over the children's slots instead of two, a Schur tile per wave); which wave computes a tile does not change its bits
 template <int NTH, bool W32 = false>
-__global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained) {   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
+__global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, int epoch, int chained, int first) {   // first: the first launch of a solve (poisons xn for the back pass)   // chained: 0 = one launch per level, else the count of single-launch factorisations so far
     extern __shared__ double sm[];
     constexpr int NW = NTH / 64, NT3 = (9 + NW - 1) / NW;          // waves; Schur tiles (of nine) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,6 +223,8 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
     int16_t* pmj = pmi + 16;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
+    if (first && N.x_poll)                                         // (nothing reads xn before the back pass of this solve, launches later)
+        for (int i = blockIdx.x * NTH + tid; i < N.n_x3; i += gridDim.x * NTH) reinterpret_cast<unsigned long long*>(N.xn)[i] = ND_POISON;
     // ---- requests first: this thread's original entries (descriptor and values: one round trip) and the Schur complements the
     // children left in this front's assembly slots (dense, in this front's own index space: contiguous 16-byte loads)
     auto entry_row = [&](const NdEnt& E) {                         // W row of an entry's first row, -1: not in this workgroup's blocks
@@ -757,6 +764,23 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     for (int sg = F.n_seg - 1; sg >= 0; --sg) {
         const int2 S2 = seg[sg];
         const int r0 = sg > 0 ? seg[sg - 1].y : 0, r1 = S2.y;
+        if (N.x_poll) {
+            // every thread polls the unknowns it stages until they are there: no flag, no fence -- one memory round trip between an
+            // ancestor's store and this front's products instead of three (its fence + flag, this front's poll, then the loads)
+            if (sg == 0) stamp(4);
+            for (int i = r0 + tid; i < r1; i += 256) {
+                const double* src = N.xn + 3 * (size_t)bnode[i / 3] + i % 3;
+                double v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while ((unsigned long long)__double_as_longlong(v) == ND_POISON) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { N.flags[2] = 2; break; }   // (cannot happen: ancestors are dispatched first; never hang the device)
+                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                xb[i] = v;
+            }
+            __syncthreads();
+        } else {
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(N.done + S2.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {   // (plain polls: one acquire at the end)
@@ -769,6 +793,7 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
         if (sg == 0) stamp(4);
         for (int i = r0 + tid; i < r1; i += 256) xb[i] = __hip_atomic_load(N.xn + 3 * (size_t)bnode[i / 3] + i % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        }
         if (sg == 0) stamp(1);
         if (q < s) {
             if (r0 < nreg) {
@@ -822,8 +847,10 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
         const double x0 = lane < s ? part[lane] + part[128 + lane] : 0.0;          // unknowns 0..63 and 64..127 of the front, two per lane
         const double x1 = lane + 64 < s ? part[lane + 64] + part[128 + lane + 64] : 0.0;
         nd_store_x(N, F, xo, lane, x0, x1);
-        __threadfence();                                           // (this wave wrote the unknowns: its release publishes them)
-        if (lane == 0) __hip_atomic_store(N.done + F.cmap_off, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!N.x_poll) {
+            __threadfence();                                       // (this wave wrote the unknowns: its release publishes them)
+            if (lane == 0) __hip_atomic_store(N.done + F.cmap_off, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     stamp(3);
 }
@@ -896,6 +923,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
     D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn); D.fcnt = reinterpret_cast<int*>(base + o_fc);
+    D.n_x3 = 3 * P.n_nodes; D.x_poll = getenv("NRS_ND_BACK_FLAGS") ? 0 : 1;
     NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, off - o_fl, c->stream));            // (status words and the fronts' flags)
     S.epoch = 0; S.chained = 0;
     // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
@@ -952,11 +980,13 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // 32-column panel steps (k_nd_level<.., true>) unless NRS_ND_STEP32=0; same bits as the 16-column form
     const char* s32_env = getenv("NRS_ND_STEP32");
     const bool step32 = !(s32_env && atoi(s32_env) == 0);
+    int first = 1;                                                 // (the first launch of the solve poisons xn)
     auto level = [&](int n, size_t shm, int wg0, int chained) {
-        if (wide && step32) hipLaunchKernelGGL((k_nd_level<512, true>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
-        else if (wide) hipLaunchKernelGGL((k_nd_level<512, false>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained);
-        else if (step32) hipLaunchKernelGGL((k_nd_level<256, true>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
-        else hipLaunchKernelGGL((k_nd_level<256, false>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained);
+        if (wide && step32) hipLaunchKernelGGL((k_nd_level<512, true>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
+        else if (wide) hipLaunchKernelGGL((k_nd_level<512, false>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
+        else if (step32) hipLaunchKernelGGL((k_nd_level<256, true>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
+        else hipLaunchKernelGGL((k_nd_level<256, false>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
+        first = 0;
     };
     const int chain_from = per_level || S.dev.clk ? P.n_levels : S.chain_from;
     {

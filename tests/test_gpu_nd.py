@@ -128,6 +128,10 @@ def test_chained_and_per_level_factorisation_give_the_same_bits(ctx, monkeypatch
         monkeypatch.delenv("NRS_ND_STEP32", raising=False)
         assert ok and ok1 and ok2 and ok3 and st == st2 and np.array_equal(x, x1) and np.array_equal(x, x2) and np.array_equal(x, x3), n
         assert ok4 and ok5 and np.array_equal(x, x4) and np.array_equal(x, x5), n
+        monkeypatch.setenv("NRS_ND_BACK_FLAGS", "1")                    # ... and the back pass handing over by flags instead of by the values themselves
+        ok6, x6, st6, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
+        monkeypatch.delenv("NRS_ND_BACK_FLAGS", raising=False)
+        assert ok6 and np.array_equal(x, x6), n
 
 
 def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypatch):
