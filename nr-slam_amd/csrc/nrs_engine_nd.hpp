@@ -15,7 +15,8 @@
 // launch.  The right-hand side is one more boundary row, so the forward substitution rides along.  One more workgroup per front
 // factorises [F11; I] and leaves (L11^-1)^T behind the factor.
 // Back pass: ONE launch (k_nd_back), a workgroup per front, top-down: factors staged on chip, then ancestor by ancestor
-// (agent-scope flags) x_own = (L11^-1)^T (y - L21^T x_bnd) as two matrix-vector products.
+// (the unknowns above are polled where they land: xn is poisoned at the start of a solve) x_own = (L11^-1)^T (y - L21^T x_bnd) as
+// two matrix-vector products.
 // Set-up: nd_prep_run (structure only: pair lists, cache key, plan; on a helper thread of engine_create) and nd_engine_finish
 // (value descriptors in the engine's row layout, uploads); the context caches the last plans (NdCache).
 #pragma once
@@ -689,8 +690,9 @@ __global__ __launch_bounds__(NTH) void k_nd_tile(NdDev N, int wg0) {
 // boundary, nothing to wait for), top-down in block order.  A workgroup first brings everything that does not depend on the unknowns above it on chip -- (L11^-1)^T into LDS, L21
 // into registers (the first 32 rows per thread group) and LDS (as many further rows as fit), y, output indices.  Its boundary is
 // sorted by owner (NdFrontD::seg_off: the parent's unknowns first, the root's last), and the owners finish root first: the
-// workgroup takes the segments from the far end, waits for each owner's flag (release / acquire at agent scope; the values are
-// read past the caches) and adds that owner's part of L21^T x_bnd -- so whatever does not fit on chip (the tail of a large
+// workgroup takes the segments from the far end, waits for each owner's unknowns (round 5: every thread polls the values it stages --
+// agent-scope atomic loads past the caches -- until they are no longer the poison of this solve; NRS_ND_BACK_FLAGS=1: the owner's
+// flag, release / acquire at agent scope) and adds that owner's part of L21^T x_bnd -- so whatever does not fit on chip (the tail of a large
 // boundary: the oldest ancestors) is read from global memory while the nearer ancestors are still busy, and what is left when the
 // parent publishes is its own segment out of registers / LDS, the product with (L11^-1)^T and the publication: ~5 us per level,
 // no triangular solve, no global read of the factor on the critical path.  A workgroup only waits for one with a smaller block
