@@ -24,7 +24,7 @@ SYMBOLS = ["nrs_create", "nrs_options_init", "nrs_destroy", "nrs_last_error", "n
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
-           "nrs_klt_insert_templates",
+           "nrs_klt_insert_templates", "nrs_klt_archive_templates", "nrs_klt_insert_archived",
            "nrs_shi_configure", "nrs_shi_extract", "nrs_shi_buffers",
            "nrs_comm_unique_id", "nrs_comm_init_rccl", "nrs_comm_rank", "nrs_shard_plan",
            "nrs_local_group_create", "nrs_local_group_destroy", "nrs_comm_init_local",
