@@ -661,9 +661,11 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         dfl[3 * (size_t)i] = d0; dfl[3 * (size_t)i + 1] = d1; dfl[3 * (size_t)i + 2] = d2;
         mag[i] = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
     }
-    std::vector<float> srt = mag;
-    std::sort(srt.begin(), srt.end());
-    const float q1 = srt[(int)(N * 0.25f)], q3 = srt[(int)(N * 0.75f)];
+    std::vector<float> srt = mag;                                 // (the two order statistics of the sorted magnitudes, without sorting all of them)
+    const int i1 = (int)(N * 0.25f), i3 = (int)(N * 0.75f);
+    std::nth_element(srt.begin(), srt.begin() + i3, srt.end());
+    std::nth_element(srt.begin(), srt.begin() + i1, srt.begin() + i3);
+    const float q1 = srt[i1], q3 = srt[i3];
     const float th = 1.5f * (q3 - q1);
     for (int idx = 0; idx < N; ++idx) {
         const int fi = opt_f[idx];
