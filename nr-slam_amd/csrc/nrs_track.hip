@@ -621,7 +621,9 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     for (int rnd = 0; rnd < 2; ++rnd) {                          // OPT:338-395
         NRS_TRY(engine_reset(c, eng));
         NRS_TRY(engine_optimize(c, eng, 10, rnd, trace));
+        mark("  round: optimize");
         NRS_TRY(engine_edge_chi2(c, eng, chi_r.data(), nullptr, chi_d.data()));
+        mark("  round: edge chi2");
         for (int v = 0; v < M; ++v) {
             const int idx = node_idx[v];
             const bool out = (float)chi_r[v] > th2_sq;
@@ -631,11 +633,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         // OPT:365-383 sets the level of every regulariser of a vertex twice -- by the vertex's reprojection gate, then by the edge's own
         // chi2 -- and the second assignment stands: every edge (each has a vertex) ends at its own gate
         for (int k = 0; k < E; ++k) dm_active[k] = chi_d[k] > (double)th3_sq ? 0 : 1;
-        NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
+        // (the levels decide what the NEXT round optimises: after the last round only their host copies are read -- by stage 2 -- and this engine is not optimised again)
+        if (rnd < 1) NRS_TRY(engine_update_flags(c, eng, rflag.data(), nullptr, nullptr, dm_active.data()));
+        mark("  round: levels");
         if (S) {                                                  // the skinned observations' levels, by the same gate
             NRS_TRY(engine_skin_chi2(c, eng, chi_s.data()));
             for (int q = 0; q < S; ++q) { const bool out = (float)chi_s[q] > th2_sq; inl[sk_idx[q]] = !out; sk_active[q] = out ? 0 : 1; }
-            NRS_TRY(engine_skin_set_active(c, eng, sk_active.data()));
+            if (rnd < 1) NRS_TRY(engine_skin_set_active(c, eng, sk_active.data()));
         }
     }
     mark("two rounds");
