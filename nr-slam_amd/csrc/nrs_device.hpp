@@ -216,13 +216,15 @@ __device__ inline double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// sum over aligned groups of T lanes (T = 1, 2, 4, 8, 16); every lane of a group receives its sum
+// sum over aligned groups of T lanes (T = 1, 2, 4, 8, 16, 32, 64); every lane of a group receives its sum
 template <int T>
 __device__ inline double group_sum(double v) {
     if (T >= 2) v += dpp_mov<DPP_QUAD_1032>(v);
     if (T >= 4) v += dpp_mov<DPP_QUAD_2301>(v);
     if (T >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
     if (T >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
+    if (T >= 32) v += __shfl_xor(v, 16, 64);                       // (across DPP rows)
+    if (T >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 

@@ -189,8 +189,11 @@ static void launch_spmv2(nrs_ctx* c, const Dev& d, double lam, size_t shm, int i
     }
 }
 
-static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double tol2) {
-    if (!d0.use_lds) { launch_spmv2<false>(c, d0, lam, 0, it); return; }
+// with_skin_op (embedded BA window): k_skin_op's workgroups ride behind the operator's in the same launch (k_spmv_f_skin) where the
+// operator is the generic k_spmv_f<T, false>; returns whether they did (the caller launches k_skin_op on its own otherwise)
+static bool launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double tol2, bool with_skin_op = false) {
+    if (!d0.use_lds) { launch_spmv2<false>(c, d0, lam, 0, it); return false; }
+    bool merged = false;
     Dev d = d0;
 #ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one operator launch: make PROBES=1, then NRS_SPMV_DBG=1)
     long long* dbg = nullptr;
@@ -239,6 +242,19 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
             continue;
         }
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + ((rc_of(d, cls) & 2) ? d.cap_h[cls] : d.cap_s[cls]) + 2);
+        const bool last_cls = cls == 1 || d.sh_nt[1] + d.sh_ntb[1] == 0;
+        if (with_skin_op && last_cls && !(d.T == 2 && d.plain && d.tp_ok) && !getenv("NRS_SKIN_OP_OWN_LAUNCH")) {
+            const dim3 g2(g.x + d.sk_nblk);
+            switch (d.T) {
+                case 1: hipLaunchKernelGGL((k_spmv_f_skin<1>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
+                case 2: hipLaunchKernelGGL((k_spmv_f_skin<2>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
+                case 4: hipLaunchKernelGGL((k_spmv_f_skin<4>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
+                case 16: hipLaunchKernelGGL((k_spmv_f_skin<16>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
+                default: hipLaunchKernelGGL((k_spmv_f_skin<8>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
+            }
+            merged = true;
+            continue;
+        }
         switch (d.T) {
             case 1: hipLaunchKernelGGL((k_spmv_f<1, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
             case 4: hipLaunchKernelGGL((k_spmv_f<4, false>), g, b, shm, c->stream, d, lam, cls, it, tol2); break;
@@ -255,6 +271,7 @@ static void launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
                 break;
         }
     }
+    return merged;
 }
 
 // errors (+ linearisation) at a given state; leaves chi2 (and max diag) in scal[]
@@ -519,6 +536,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             }
             continue;
         }
+        bool skin_op_done = false;                                 // (k_skin_op's workgroups went with the operator's launch)
         if (d.sh_on && d.sh_world > 1) {
             // sharded: the operator reads u of the neighbouring ranks' boundary keyframes (dampers).  The rows
             // travel on the second stream while the interior tiles run; the boundary tiles follow them.
@@ -541,10 +559,10 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             const int reps = c->opt.profile ? PROFILE_REPS : 1;    // (a profiling context has no convergence look-ahead: the launch is idempotent)
             Timer t(c, &c->prof.spmv_ms, &c->prof.spmv_launches, reps);
             if (d.hier && d.ecd) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(BLK), 0, c->stream, d, it);
-            for (int r = 0; r < reps; ++r) launch_spmv(c, d, lam, it, tol2);
+            for (int r = 0; r < reps; ++r) skin_op_done = launch_spmv(c, d, lam, it, tol2, d.sk_pcg != 0);
         }
         if (d.sk_pcg) {                                            // embedded BA window: H u of the skinned observations' blocks (nrs_engine_skin.hpp)
-            hipLaunchKernelGGL(k_skin_op, dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, it);
+            if (!skin_op_done) hipLaunchKernelGGL(k_skin_op, dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, it);
             hipLaunchKernelGGL(k_skin_op_rows, dim3((d.sk_nrl + SK_RPB - 1) / SK_RPB), dim3(BLK), 0, c->stream, d);
         }
         if (d.sh_on) {

@@ -184,13 +184,13 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
 // per row 32 bytes of reprojection factors instead of the 6x3 H_pl block and the 3x3 diagonal.
 // =====================================================================================
 template <int T, bool DF, bool TPC = false, bool H4 = false, bool RCS = false, bool RCD = false, bool NT = false>   // NT: non-temporal stream loads (Dev::nt); H4: 4-byte damper headers (Dev::d_h4; needs TPC); RCS / RCD: spring / damper factors re-formed from the staged linearisation point (Dev::rc)
-__global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
+__device__ __forceinline__ void spmv_f_body(const Dev& P, const double lam, const int cls, const int it, const double tol2, const int blk) {   // blk: the workgroup's index among the operator's (k_spmv_f_skin launches others behind them)
     static_assert(!(RCS || RCD) || (TPC && H4 && !DF), "factor recomputation: plain windows with cached partners and 4-byte headers");
     __shared__ double lds[4 * 9];
     extern __shared__ double dyn[];
     constexpr int R = 64 / T;
     constexpr int U = 2;                                           // records per lane and buffer (two buffers per stream)
-    const int bi = xcd_tile(blockIdx.x, P.sh_nt[cls] + P.sh_ntb[cls]);
+    const int bi = xcd_tile(blk, P.sh_nt[cls] + P.sh_ntb[cls]);
     if (bi >= P.sh_nt[cls] + P.sh_ntb[cls]) return;
     const int b = P.tile_list[(cls ? P.n_tiles_cls[0] : 0) + (bi < P.sh_nt[cls] ? P.sh_t0[cls] + bi : P.sh_t0b[cls] + bi - P.sh_nt[cls])];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: slice bounds and loop conditions are scalar)
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, 
         const double gamma = lds[0] + lds[1] + lds[2] + lds[3];
         const bool bad = !isfinite(gamma);
         if (gamma <= tol2 * gamma0 || bad || gamma == 0.0) {       // converged: the operator is not applied again
-            if (blockIdx.x == 0 && tid == 0 && cls == 0) {
+            if (blk == 0 && tid == 0 && cls == 0) {
                 if (bad) P.flags[2] = 1;
                 P.flags[1] = it;
                 __threadfence();
@@ -442,6 +442,10 @@ __global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, 
     block_sum_store<9>(part, lds, tid, P.part_spmv + (size_t)b * NPART);
     stamp(5);
 }
+template <int T, bool DF, bool TPC = false, bool H4 = false, bool RCS = false, bool RCD = false, bool NT = false>
+__global__ __launch_bounds__(BLK, RCD ? 3 : 4) void k_spmv_f(Dev P, double lam, int cls, int it, double tol2) {
+    spmv_f_body<T, DF, TPC, H4, RCS, RCD, NT>(P, lam, cls, it, tol2, (int)blockIdx.x);
+}
 
 // =====================================================================================
 // large problems only: fixed-order reduction of the SpMV partials.  Workgroup 0: the three dot
@@ -470,8 +474,10 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
             v[1] += P.part_spmv[(size_t)b * NPART + 1];
             v[2] += P.part_spmv[(size_t)b * NPART + 2];
         }
-        if (P.sk_pcg)                                              // embedded BA window: what the skinned observations' row pass added
-            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) { v[1] += P.sk_rpart[2 * (size_t)b]; v[2] += P.sk_rpart[2 * (size_t)b + 1]; }
+        if (P.sk_pcg) {                                            // embedded BA window: what the skinned observations add to w.u (row pass) and to the cross term
+            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) v[1] += P.sk_rpart[b];
+            for (int b = tid; b < P.sk_nblk; b += BLK) v[2] += P.sk_opart[(size_t)b * 8 + 6];
+        }
         block_sum<3>(v, lds, lane, wave);
         if (tid == 0) { P.red[0] = v[0]; P.red[1] = v[1]; P.red[2] = v[2]; }
     } else {
@@ -581,8 +587,10 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             const double* pr = P.part_ru + (size_t)(it & 1) * P.n_vecblk;
             for (int b = tid; b < P.n_vecblk; b += BLK) v[0] += pr[b];
         }
-        if (P.sk_pcg)                                              // embedded BA window: the skinned observations' shares of w.u and of the cross term
-            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) { v[1] += P.sk_rpart[2 * (size_t)b]; v[2] += P.sk_rpart[2 * (size_t)b + 1]; }
+        if (P.sk_pcg) {                                            // embedded BA window: the skinned observations' shares of w.u and of the cross term
+            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) v[1] += P.sk_rpart[b];
+            for (int b = tid; b < P.sk_nblk; b += BLK) v[2] += P.sk_opart[(size_t)b * 8 + 6];
+        }
     }
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
     for (int i = tid; i < 6 * P.K; i += BLK) {

@@ -1113,8 +1113,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                 const int v = s.sk_node[SK_MAX * i + k];
                 if (v < 0) continue;
                 if (s.lm_pose[v] != sk_pose[i]) return c->fail(NRS_ERR_INVALID, "skinned observation: a node copy of another keyframe");
-                rows[SK_MAX * sl + k] = e->vrow[v];
-                om[SK_MAX * sl + k] = s.sk_om[SK_MAX * i + k];
+                rows[(size_t)k * n + sl] = e->vrow[v];              // (11 x n, node-slot-major: the kernels read them coalesced)
+                om[(size_t)k * n + sl] = s.sk_om[SK_MAX * i + k];
                 rl_cnt[e->vrow[v] + 1]++;
             }
         }
@@ -1127,16 +1127,17 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         std::vector<double> rl_om(n_ent + 1);
         for (size_t sl = 0; sl < n; ++sl)
             for (int k = 0; k < SK_MAX; ++k) {
-                const int r = rows[SK_MAX * sl + k];
+                const int r = rows[(size_t)k * n + sl];
                 if (r < 0) continue;
                 const int q = fill[row_list[r]]++;
-                rl_obs[q] = (int)sl; rl_om[q] = om[SK_MAX * sl + k];
+                rl_obs[q] = (int)sl; rl_om[q] = om[(size_t)k * n + sl];
             }
         auto al = [](size_t b2) { return (b2 + 255) & ~(size_t)255; };
         const size_t o_uv = 0, o_X0 = o_uv + al(8 * n), o_row = o_X0 + al(24 * n), o_om = o_row + al(4 * SK_MAX * n), o_act = o_om + al(8 * SK_MAX * n),
                      o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
                      o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
-                     o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 6 * n), o_rpart = o_op + al(8 * 8 * nblk), total = o_rpart + al(8 * 2 * (nrlblk + 1));
+                     o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 4 * n), o_rpart = o_op + al(8 * 8 * nblk), o_recT = o_rpart + al(8 * (nrlblk + 1)),
+                     total = o_recT + al(8 * 24 * n);
         DevBuf& buf = arena == &c->arena_trk ? c->nd_skin : c->dba_skin;
         NRS_TRY(c->ensure(buf, total));
         char* sb = buf.as<char>();
@@ -1157,6 +1158,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
         d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
         d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_rpart = reinterpret_cast<double*>(sb + o_rpart);
+        d.sk_recT = reinterpret_cast<double*>(sb + o_recT);
         d.sk_base = ba_form ? d.xl_init : nullptr;                 // (tracking form: the rows ARE the deformations, X0 + sum om x)
         e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
         e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n_in);

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
         double x0 = P.sk_X0[3 * (size_t)i], x1 = P.sk_X0[3 * (size_t)i + 1], x2 = P.sk_X0[3 * (size_t)i + 2];
 #pragma unroll
         for (int k = 0; k < SK_MAX; ++k) {
-            const int row = P.sk_row[SK_MAX * (size_t)i + k];
-            const double om = P.sk_om[SK_MAX * (size_t)i + k];
+            const int row = P.sk_row[(size_t)k * P.sk_n + i];       // (node lists slot-major inside a k: coalesced)
+            const double om = P.sk_om[(size_t)k * P.sk_n + i];
             if (row >= 0 && P.sk_base) {                           // BA form: the node's displacement from where the window started
                 x0 += om * (xl[3 * (size_t)row] - P.sk_base[3 * (size_t)row]); x1 += om * (xl[3 * (size_t)row + 1] - P.sk_base[3 * (size_t)row + 1]);
                 x2 += om * (xl[3 * (size_t)row + 2] - P.sk_base[3 * (size_t)row + 2]);
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
 #pragma unroll
                 for (int k = 0; k < 27; ++k) rec[k] = 0.0;
             }
+            if (P.sk_pcg) {                                        // PCG form: the operator's 24 values once more, value-major (k_skin_op reads them coalesced)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) P.sk_recT[(size_t)k * P.sk_n + i] = rec[k];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) P.sk_recT[(size_t)(6 + k) * P.sk_n + i] = rec[9 + k];
+            }
         }
     }
     block_sum_store<28>(acc, lds, tid, P.sk_part + (size_t)blockIdx.x * 32);
@@ -102,9 +108,13 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
 //   k_skin_rows : a node row's diagonal block += sum om^2 J_l^T w J_l, its gradient += sum om (-J_l^T w r) over its list
 //   k_skin_pose : H_pp / b_p of a pose += the block sums k_skin left (its blocks in order)
 // Per PCG iteration, behind k_spmv_f:  H u of the observations' blocks, with s_o = sum_k om_k u_{n_k}:
-//   k_skin_op      (per observation): g_o = A_o s_o + B_o^T u_p, gB_o = B_o^T u_p; block sums of B_o s_o (pose rows)
-//   k_skin_op_rows (per node row)   : w_row += sum om g_o; partials of what that adds to w.u and to the cross term
-// k_pcg_update / k_reduce_partials add the partials in (fixed order).  8 lanes per list, combined by the fixed butterfly of sub_sum_t.
+//   k_skin_op      (per observation): g_o = A_o s_o + B_o^T u_p; block sums of B_o s_o (pose rows) and of (B_o^T u_p) . s_o (the
+//                                     observations' share of the cross term u_l . H_lp u_p)
+//   k_skin_op_rows (per node row)   : w_row += sum om g_o; partials of what that adds to w.u
+// k_pcg_update / k_reduce_partials add the partials in (fixed order).  SK_RL lanes per list, combined by the fixed butterfly of
+// sub_sum_t.  Both kernels are bound by the number of cache lines a wave's loads touch (one wave per SIMD at this size): the
+// per-observation operands are value-major (sk_recT, sk_row, sk_om: a load instruction of 64 observations touches 4 lines, not 64),
+// g_o is 3 values in a 32-byte slot (two 16-byte loads per list entry).
 
 __device__ inline void sk_atomic_max(double* addr, double v) {     // v >= 0: the bit patterns of non-negative doubles order like integers
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
@@ -153,62 +163,85 @@ __global__ __launch_bounds__(BLK) void k_skin_pose(Dev P) {
     } else P.bp[6 * k + (cc - 21)] += s;
 }
 
-__global__ __launch_bounds__(BLK) void k_skin_op(Dev P, int it) {
-    __shared__ double lds[4 * 6];
-    const int tid = threadIdx.x, i = blockIdx.x * BLK + tid;
-    double q[6] = {0, 0, 0, 0, 0, 0};
-    if (i < P.sk_n && !P.flags[0]) {
-        const int kp = P.sk_blk_pose[blockIdx.x];
+__device__ __forceinline__ void skin_op_body(const Dev& P, const int it, const int blk) {
+    __shared__ double lds[4 * 7];
+    const int tid = threadIdx.x, i = blk * BLK + tid;
+    double q[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int done = P.flags[0];                                   // (read beside the first operands, not before them)
+    if (i < P.sk_n) {
+        const int kp = P.sk_blk_pose[blk];
         const double* up = ((it & 1) ? P.up2 : P.up) + 6 * kp;
+        const size_t n = (size_t)P.sk_n;
         double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
         for (int k = 0; k < SK_MAX; ++k) {
-            const int row = P.sk_row[SK_MAX * (size_t)i + k];
-            const double om = P.sk_om[SK_MAX * (size_t)i + k];
+            const int row = P.sk_row[k * n + i];
+            const double om = P.sk_om[k * n + i];
             if (row >= 0) { s0 += om * P.uv3[3 * (size_t)row]; s1 += om * P.uv3[3 * (size_t)row + 1]; s2 += om * P.uv3[3 * (size_t)row + 2]; }
         }
-        const double* rec = P.sk_rec + 27 * (size_t)i;
-        const double a0 = rec[0] * s0 + rec[1] * s1 + rec[2] * s2, a1 = rec[1] * s0 + rec[3] * s1 + rec[4] * s2, a2 = rec[2] * s0 + rec[4] * s1 + rec[5] * s2;
+        const double* rec = P.sk_recT + i;                         // A_o (6), B_o (18), value-major
+        const double A0 = rec[0], A1 = rec[n], A2 = rec[2 * n], A3 = rec[3 * n], A4 = rec[4 * n], A5 = rec[5 * n];
+        const double a0 = A0 * s0 + A1 * s1 + A2 * s2, a1 = A1 * s0 + A3 * s1 + A4 * s2, a2 = A2 * s0 + A4 * s1 + A5 * s2;
         double g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-            const double b0 = rec[9 + 3 * p], b1 = rec[9 + 3 * p + 1], b2 = rec[9 + 3 * p + 2], u = up[p];
+            const double b0 = rec[(6 + 3 * p) * n], b1 = rec[(7 + 3 * p) * n], b2 = rec[(8 + 3 * p) * n], u = up[p];
             g0 += b0 * u; g1 += b1 * u; g2 += b2 * u;
             q[p] = b0 * s0 + b1 * s1 + b2 * s2;
         }
-        double* g = P.sk_g + 6 * (size_t)i;
-        g[0] = a0 + g0; g[1] = a1 + g1; g[2] = a2 + g2; g[3] = g0; g[4] = g1; g[5] = g2;
+        q[6] = g0 * s0 + g1 * s1 + g2 * s2;                        // (B_o^T u_p) . s_o
+        if (!done) {
+            double* g = P.sk_g + 4 * (size_t)i;
+            g[0] = a0 + g0; g[1] = a1 + g1; g[2] = a2 + g2;
+        } else {                                                   // (the solve has finished: nothing is added any more)
+#pragma unroll
+            for (int p = 0; p < 7; ++p) q[p] = 0;
+        }
     }
-    block_sum<6>(q, lds, tid & 63, tid >> 6);
+    block_sum<7>(q, lds, tid & 63, tid >> 6);
     if (tid == 0) {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) P.sk_opart[(size_t)blockIdx.x * 8 + p] = q[p];
+        for (int p = 0; p < 7; ++p) P.sk_opart[(size_t)blk * 8 + p] = q[p];
     }
 }
+__global__ __launch_bounds__(BLK) void k_skin_op(Dev P, int it) { skin_op_body(P, it, (int)blockIdx.x); }
+// The operator of the regularisers and the observations' pass in ONE launch: the two read u and write different things (w's rows /
+// sk_g and the block sums), so the first n_op workgroups are k_spmv_f's and the rest k_skin_op's -- one launch and one kernel's
+// chain of dependent loads less per PCG iteration (both are latency-bound at a BA window's size).  Same bodies, same bits.
+template <int T>
+__global__ __launch_bounds__(BLK, 4) void k_spmv_f_skin(Dev P, double lam, int cls, int it, double tol2, int n_op) {
+    if ((int)blockIdx.x < n_op) spmv_f_body<T, false>(P, lam, cls, it, tol2, (int)blockIdx.x);
+    else skin_op_body(P, it, (int)blockIdx.x - n_op);
+}
 
+// (a short kernel is as long as its chain of dependent loads: the list bounds, the row and the flag are fetched side by side, then
+// the first entries together with the row's own values, then the observations' g)
 __global__ __launch_bounds__(BLK) void k_skin_op_rows(Dev P) {
-    __shared__ double lds[4 * 2];
+    __shared__ double lds[4];
     const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
-    double a[3] = {0, 0, 0}, c[3] = {0, 0, 0}, part[2] = {0, 0};
-    const bool live = j < P.sk_nrl && !P.flags[0] && !(P.rflag[P.sk_rl_row[min(j, P.sk_nrl - 1)]] & RF_FIXED);
+    const int jj = min(j, P.sk_nrl - 1);
+    const int done = P.flags[0], q0 = P.sk_rl_ptr[jj], q1 = P.sk_rl_ptr[jj + 1];
+    const size_t row = (size_t)P.sk_rl_row[jj];
+    const uint8_t rf = P.rflag[row];
+    const double u0 = P.uv3[3 * row], u1 = P.uv3[3 * row + 1], u2 = P.uv3[3 * row + 2];
+    const double w0 = P.wv[3 * row], w1 = P.wv[3 * row + 1], w2 = P.wv[3 * row + 2];
+    const bool live = j < P.sk_nrl && !done && !(rf & RF_FIXED);
+    double a[3] = {0, 0, 0}, part[1] = {0};
     if (live)
-        for (int q = P.sk_rl_ptr[j] + t; q < P.sk_rl_ptr[j + 1]; q += SK_RL) {
+        for (int q = q0 + t; q < q1; q += SK_RL) {
             const double om = P.sk_rl_om[q];
-            const double* g = P.sk_g + 6 * (size_t)P.sk_rl_obs[q];
+            const double* g = P.sk_g + 4 * (size_t)P.sk_rl_obs[q];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { a[k] += om * g[k]; c[k] += om * g[3 + k]; }
+            for (int k = 0; k < 3; ++k) a[k] += om * g[k];
         }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { a[k] = sub_sum_t<SK_RL>(a[k]); c[k] = sub_sum_t<SK_RL>(c[k]); }
+    for (int k = 0; k < 3; ++k) a[k] = sub_sum_t<SK_RL>(a[k]);
     if (live && t == 0) {
-        const size_t row = (size_t)P.sk_rl_row[j];
-        const double u0 = P.uv3[3 * row], u1 = P.uv3[3 * row + 1], u2 = P.uv3[3 * row + 2];
-        P.wv[3 * row] += a[0]; P.wv[3 * row + 1] += a[1]; P.wv[3 * row + 2] += a[2];
+        P.wv[3 * row] = w0 + a[0]; P.wv[3 * row + 1] = w1 + a[1]; P.wv[3 * row + 2] = w2 + a[2];
         part[0] = u0 * a[0] + u1 * a[1] + u2 * a[2];
-        part[1] = u0 * c[0] + u1 * c[1] + u2 * c[2];
     }
-    block_sum<2>(part, lds, tid & 63, tid >> 6);
-    if (tid == 0) { P.sk_rpart[2 * (size_t)blockIdx.x] = part[0]; P.sk_rpart[2 * (size_t)blockIdx.x + 1] = part[1]; }
+    block_sum<1>(part, lds, tid & 63, tid >> 6);
+    if (tid == 0) P.sk_rpart[blockIdx.x] = part[0];
 }
 
 }  // namespace nrs

@@ -8,7 +8,7 @@ constexpr int ROW_ALIGN = 256;       // pose row padding; also rows per k_reproj
 constexpr int BLK = 256;             // threads per workgroup everywhere
 constexpr int NPART = 12;            // per-block partial slots of the SpMV kernel: [0..2] dots, [3..8] pose sums
 constexpr int SK_MAX = 11;           // embedded mode (nrs_engine_skin.hpp): nodes per skinned observation (the walk of OPT:255-279 accepts 11)
-constexpr int SK_RL = 8;             // ... lanes per node-row list of the PCG form, lists per workgroup
+constexpr int SK_RL = 16;            // ... lanes per node-row list of the PCG form, lists per workgroup
 constexpr int SK_RPB = BLK / SK_RL;
 constexpr int CO_MAX = 84;           // largest coarse system of the two-level preconditioner (fits one workgroup's LDS)
 constexpr int CO_GMAX = (CO_MAX - 6) / 3;   // row groups of the coarse level
@@ -175,7 +175,7 @@ struct Dev {
     // embedded-deformation mode (N2, nrs_engine_skin.hpp): sk_n SKINNED observations -- points without a vertex whose position is
     // X0 + sum_k om[k] x[row[k]] over <= 11 node rows; their reprojection edges constrain those rows and the pose (direct solver only)
     int sk_n, sk_nblk;
-    const float* sk_uv; const double* sk_X0; const int* sk_row; const double* sk_om; const uint8_t* sk_active;
+    const float* sk_uv; const double* sk_X0; const int* sk_row; const double* sk_om; const uint8_t* sk_active;   // (sk_row / sk_om: 11 x sk_n, node-slot-major)
     double* sk_rec;                  // sk_n x 27: per observation J_l^T w J_l (6), -J_l^T w r (3), J_p^T w J_l (18) of the linearisation point
     double* sk_part;                 // sk_nblk x 32: H_pp (21), b_p (6), chi2 partials of the observations' workgroups
     double* sk_chi;                  // sk_n: r^T Omega r at the evaluated state (the drivers' inlier classification)
@@ -189,9 +189,10 @@ struct Dev {
     const double* sk_base;           // BA form: a skinned point sits at X0 + sum om (x - x_start), x_start = xl_init (null: X0 + sum om x)
     int sk_nrl;                      // node rows with a list
     const int* sk_rl_row; const int* sk_rl_ptr; const int* sk_rl_obs; const double* sk_rl_om;   // list j: row, entries [ptr[j], ptr[j+1]): observation slot, weight
-    double* sk_g;                    // sk_n x 6: per observation A s + B^T u_p (3) and B^T u_p alone (3) of the current PCG direction u
-    double* sk_opart;                // sk_nblk x 8: sum over a block's observations of B s (what they add to the pose rows of H u)
-    double* sk_rpart;                // ceil(sk_nrl / 32) x 2: what the row pass adds to w.u and to the cross term u_l.(H_lp u_p)
+    double* sk_recT;                 // 24 x sk_n: the operator's part of sk_rec (A: 6, B: 18), value-major (written when sk_pcg)
+    double* sk_g;                    // sk_n x 4: per observation A s + B^T u_p (3 values in a 32-byte slot) of the current PCG direction u
+    double* sk_opart;                // sk_nblk x 8: sums over a block's observations of B s (6: the pose rows of H u) and of (B^T u_p).s (the cross term u_l.(H_lp u_p))
+    double* sk_rpart;                // ceil(sk_nrl / SK_RPB): what the row pass adds to w.u
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 
