@@ -104,6 +104,23 @@ def test_resident_form_reset_and_determinism(ctx):
     assert np.allclose(out[0][2], osk, atol=1e-4, rtol=0)
 
 
+def test_operator_halves_in_one_launch_give_the_bits_of_two(ctx, monkeypatch):
+    """k_spmv_f_skin (the regularisers' operator and k_skin_op as one launch) against the two launches (NRS_SKIN_OP_OWN_LAUNCH=1:
+    the env is read per launch): the same bodies on the same data -- every trial and every output bit for bit."""
+    p, e, w, cam, qt = _setup(500, 5, 70, 58)
+    out = []
+    for own in (False, True):
+        if own:
+            monkeypatch.setenv("NRS_SKIN_OP_OWN_LAUNCH", "1")
+        tr = nrs.Trace()
+        pq, xyz, sk = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tr)
+        out.append((pq, xyz, sk, [(t["accepted"], t["chi"], t["chi_new"], t["lam"], t["inner"]) for t in tr.trials]))
+    monkeypatch.delenv("NRS_SKIN_OP_OWN_LAUNCH")
+    assert sum(t[4] for t in out[0][3]) > 50
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3]
+
+
 def test_bad_inputs_are_rejected(ctx):
     p, e, w, cam, qt = _setup(200, 3, 30, 57)
     bad = dict(e, sk_node=e["sk_node"].copy())
