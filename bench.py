@@ -510,7 +510,7 @@ def skinned_bench(n=5000, m=500, n_kf=20):
                             skinned_observations=int(len(e["sk_obs"])), springs=int(len(e["sp_ij"])), dampers=int(len(e["dm_idx"])),
                             unknowns=int(6 * p["n_kf"] + 3 * len(e["lm_obs"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
                             ms_per_step=1e3 * rr["dt"] / 10, lm_trials_per_step=rr["trials"] / 10, pcg_iters_per_step=rr["inner"] / 10,
-                            linear_solver="block-Jacobi PCG, the skinned observations applied as hyper-edges (k_skin_op / k_skin_op_rows)",
+                            linear_solver="block-Jacobi PCG, the skinned observations applied as hyper-edges (k_spmv_f_skin / k_pcg_update<true>: two launches per iteration)",
                             note="every observation of the window is in the problem; held to oracle/embedded_oracle.py dba_solve_embedded at 300 x 40 x 4 .. "
                                  "600 x 80 x 6 (tests/test_gpu_embedded_ba.py) and at this size by the golden tests/golden/dba_C2_embedded%d_trace.npz; "
                                  "the mode has no reference counterpart beyond every-point-a-node (there it is the plain window, bit for bit)" % m)

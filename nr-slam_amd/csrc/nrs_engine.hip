@@ -537,6 +537,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             continue;
         }
         bool skin_op_done = false;                                 // (k_skin_op's workgroups went with the operator's launch)
+        bool skin_rows_fused = false;                              // (... and the row pass goes with the vector update's)
         if (d.sh_on && d.sh_world > 1) {
             // sharded: the operator reads u of the neighbouring ranks' boundary keyframes (dampers).  The rows
             // travel on the second stream while the interior tiles run; the boundary tiles follow them.
@@ -563,7 +564,9 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
         }
         if (d.sk_pcg) {                                            // embedded BA window: H u of the skinned observations' blocks (nrs_engine_skin.hpp)
             if (!skin_op_done) hipLaunchKernelGGL(k_skin_op, dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, it);
-            hipLaunchKernelGGL(k_skin_op_rows, dim3((d.sk_nrl + SK_RPB - 1) / SK_RPB), dim3(BLK), 0, c->stream, d);
+            // the row pass: inside k_pcg_update<true> (for the rows it updates) unless the update is the generic kernel's
+            skin_rows_fused = !d.sh_on && !d.hier && !d.ecd && !getenv("NRS_SKIN_ROWS_OWN_LAUNCH");
+            if (!skin_rows_fused) hipLaunchKernelGGL(k_skin_op_rows, dim3(d.n_rows / SK_RPB), dim3(BLK), 0, c->stream, d);
         }
         if (d.sh_on) {
             // this rank's dot products and pose sums (other ranks' slots are zero), then the sum over the
@@ -575,8 +578,9 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
         } else if (d.hier) hipLaunchKernelGGL(k_reduce_partials, dim3(1 + d.K), dim3(BLK), 0, c->stream, d);
         {
             Timer t(c, &c->prof.vec_ms, &c->prof.vec_launches);
-            hipLaunchKernelGGL(k_pcg_update, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
-                               d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+            if (skin_rows_fused) hipLaunchKernelGGL(k_pcg_update<true>, dim3(d.n_rows / SK_RPB + n_poseblk), dim3(BLK), 0, c->stream, d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
+            else hipLaunchKernelGGL(k_pcg_update<false>, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
+                                    d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
         }
     }
     *it_io = it;

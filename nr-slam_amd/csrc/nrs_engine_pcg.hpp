@@ -475,8 +475,7 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
             v[2] += P.part_spmv[(size_t)b * NPART + 2];
         }
         if (P.sk_pcg) {                                            // embedded BA window: what the skinned observations add to w.u (row pass) and to the cross term
-            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) v[1] += P.sk_rpart[b];
-            for (int b = tid; b < P.sk_nblk; b += BLK) v[2] += P.sk_opart[(size_t)b * 8 + 6];
+            for (int b = tid; b < P.sk_nblk; b += BLK) { v[1] += P.sk_opart[(size_t)b * 8 + 7]; v[2] += P.sk_opart[(size_t)b * 8 + 6]; }
         }
         block_sum<3>(v, lds, lane, wave);
         if (tid == 0) { P.red[0] = v[0]; P.red[1] = v[1]; P.red[2] = v[2]; }
@@ -509,6 +508,28 @@ __global__ __launch_bounds__(BLK) void k_reduce_partials(Dev P) {
 //   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = M^-1 r
 // Workgroups >= n_vec8 own the pose rows (w_p = (H_pp + lambda) u_p + sum_l H_pl u_l).
 // =====================================================================================
+// a node row's list, SK_RL lanes: a += om g_o over the entries this lane takes (the lanes are combined by sub_sum_t<SK_RL>)
+__device__ __forceinline__ void skin_row_gather(const Dev& P, const int q0, const int q1, const int t, double a[3]) {
+    int q = q0 + t;
+    for (; q + SK_RL < q1; q += 2 * SK_RL) {                       // two entries in flight (added in list order: the same sums)
+        const double om0 = P.sk_rl_om[q], om1 = P.sk_rl_om[q + SK_RL];
+        const double* g0 = P.sk_g + 4 * (size_t)P.sk_rl_obs[q];
+        const double* g1 = P.sk_g + 4 * (size_t)P.sk_rl_obs[q + SK_RL];
+        const double x0 = g0[0], x1 = g0[1], x2 = g0[2], y0 = g1[0], y1 = g1[1], y2 = g1[2];
+        a[0] += om0 * x0; a[1] += om0 * x1; a[2] += om0 * x2;
+        a[0] += om1 * y0; a[1] += om1 * y1; a[2] += om1 * y2;
+    }
+    if (q < q1) {
+        const double om = P.sk_rl_om[q];
+        const double* g = P.sk_g + 4 * (size_t)P.sk_rl_obs[q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[k] += om * g[k];
+    }
+}
+
+// SKR (embedded BA window, nrs_engine_skin.hpp): a row workgroup owns SK_RPB rows with SK_RL lanes each and first completes their w
+// with the observations' row pass (w_row += sum om g_o, the gather in flight while the scalars are derived); lane 0 of a row updates it.
+template <bool SKR = false>
 __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, double tol2, double peek_tol2, int pub_seq) {
     __shared__ double lds[4 * 3];
     const int n_vecblk = P.sh_nvb;                                 // own row range (the whole problem when not sharded)
@@ -523,13 +544,32 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     const double sc_gamma0 = P.scal[SC_GAMMA0];
     const double sc_slot0 = P.scal[(it & 1) ? SC_SLOT1 : SC_SLOT0], sc_slot1 = P.scal[((it & 1) ? SC_SLOT1 : SC_SLOT0) + 1];
     const int n_vec2 = (n_vecblk + 1) >> 1;
-    const int n_vec8 = ((n_vec2 + 7) >> 3) << 3;
+    const int n_vec8 = SKR ? P.n_rows / SK_RPB : ((n_vec2 + 7) >> 3) << 3;          // (row workgroups of this launch)
     const bool row_wg = (int)blockIdx.x < n_vec8;
-    const int pair = row_wg ? P.sh_vb0 * (BLK / 2) + xcd_tile(blockIdx.x, n_vec2) * BLK + tid : 0;
-    const bool has_rows = row_wg && 2 * pair < (P.sh_vb0 + n_vecblk) * BLK;
-    const size_t o = 6 * (size_t)pair;
+    const int pair = (row_wg && !SKR) ? P.sh_vb0 * (BLK / 2) + xcd_tile(blockIdx.x, n_vec2) * BLK + tid : 0;
+    const int sk_r = (int)blockIdx.x * SK_RPB + tid / SK_RL, sk_t = tid % SK_RL;   // SKR: this lane's row and its place in the row's group
+    const bool has_rows = SKR ? row_wg && sk_t == 0 : row_wg && 2 * pair < (P.sh_vb0 + n_vecblk) * BLK;
+    const size_t o = SKR ? 3 * (size_t)sk_r : 6 * (size_t)pair;
     double uu[6], pp[6], ww[6], ss[6], rr[6], xx[6], Di[12];
-    if (has_rows) {
+    double ska[3] = {0, 0, 0};
+    bool sk_add = false;
+    if (SKR) {
+        if (row_wg) {
+            const int q0 = P.sk_row_q[2 * (size_t)sk_r], q1 = P.sk_row_q[2 * (size_t)sk_r + 1];
+            sk_add = q1 > q0 && !(P.rflag[sk_r] & RF_FIXED);      // (a fixed row is an identity row: nothing is added to it)
+            if (has_rows) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uu[k] = P.uv3[o + k]; pp[k] = P.pv[o + k]; ww[k] = P.wv[o + k]; ss[k] = P.sv[o + k]; rr[k] = P.rv[o + k]; xx[k] = P.xv[o + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Di[k] = P.Dinv[2 * o + k];
+            }
+            if (sk_add) skin_row_gather(P, q0, q1, sk_t, ska);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ska[k] = sub_sum_t<SK_RL>(ska[k]);
+        }
+    } else if (has_rows) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double2 a = *reinterpret_cast<const double2*>(P.uv3 + o + 2 * k);
@@ -588,8 +628,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             for (int b = tid; b < P.n_vecblk; b += BLK) v[0] += pr[b];
         }
         if (P.sk_pcg) {                                            // embedded BA window: the skinned observations' shares of w.u and of the cross term
-            for (int b = tid; b < (P.sk_nrl + SK_RPB - 1) / SK_RPB; b += BLK) v[1] += P.sk_rpart[b];
-            for (int b = tid; b < P.sk_nblk; b += BLK) v[2] += P.sk_opart[(size_t)b * 8 + 6];
+            for (int b = tid; b < P.sk_nblk; b += BLK) { v[1] += P.sk_opart[(size_t)b * 8 + 7]; v[2] += P.sk_opart[(size_t)b * 8 + 6]; }
         }
     }
     // pose rows: gamma_p = r_p.u_p ; delta_p = u_p.(H_pp + lam)u_p + cross (cross is v[2])
@@ -647,7 +686,24 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
     }
     // row workgroups: every thread updates TWO consecutive rows (6 doubles = three 16-byte
     // accesses per vector); n_rows is a multiple of 256, so pairs never straddle anything
-    if (row_wg) {
+    if (SKR) {
+        if (has_rows) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (sk_add) ww[k] += ska[k];
+                pp[k] = uu[k] + beta * pp[k];
+                ss[k] = ww[k] + beta * ss[k];
+                xx[k] += alpha * pp[k];
+                rr[k] -= alpha * ss[k];
+            }
+            uu[0] = Di[0] * rr[0] + Di[1] * rr[1] + Di[2] * rr[2];
+            uu[1] = Di[1] * rr[0] + Di[3] * rr[1] + Di[4] * rr[2];
+            uu[2] = Di[2] * rr[0] + Di[4] * rr[1] + Di[5] * rr[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { P.pv[o + k] = pp[k]; P.sv[o + k] = ss[k]; P.xv[o + k] = xx[k]; P.rv[o + k] = rr[k]; P.uv3[o + k] = uu[k]; }
+        }
+    }
+    if (row_wg && !SKR) {
         if (has_rows) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -685,7 +741,7 @@ __global__ __launch_bounds__(BLK) void k_pcg_update(Dev P, double lam, int it, d
             if (tid == 0 && w2 < P.n_vecblk) pw[w2] = ru[0];
             if (tid == 1 && w2 + 1 < P.n_vecblk) pw[w2 + 1] = 0.0;
         }
-    } else {
+    } else if (!row_wg) {
         // pose workgroups: one wave per pose; its 64 lanes split the pose's SpMV partials
         if (has_pose) {
             const int k = pk_pose;

@@ -1122,7 +1122,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         std::vector<int> rl_row, rl_ptr(1, 0), row_list(d.n_rows, -1);
         for (int r = 0; r < d.n_rows; ++r)
             if (rl_cnt[r + 1] > 0) { row_list[r] = (int)rl_row.size(); rl_row.push_back(r); rl_ptr.push_back(rl_ptr.back() + rl_cnt[r + 1]); }
-        const size_t n_ent = (size_t)rl_ptr.back(), nrl = rl_row.size(), nrlblk = (nrl + SK_RPB - 1) / SK_RPB;
+        const size_t n_ent = (size_t)rl_ptr.back(), nrl = rl_row.size();
         std::vector<int> rl_obs(n_ent + 1), fill(rl_ptr.begin(), rl_ptr.end() - 1);
         std::vector<double> rl_om(n_ent + 1);
         for (size_t sl = 0; sl < n; ++sl)
@@ -1136,7 +1136,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         const size_t o_uv = 0, o_X0 = o_uv + al(8 * n), o_row = o_X0 + al(24 * n), o_om = o_row + al(4 * SK_MAX * n), o_act = o_om + al(8 * SK_MAX * n),
                      o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
                      o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
-                     o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 4 * n), o_rpart = o_op + al(8 * 8 * nblk), o_recT = o_rpart + al(8 * (nrlblk + 1)),
+                     o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 4 * n), o_rq = o_op + al(8 * 8 * nblk), o_recT = o_rq + al(8 * (size_t)d.n_rows),
                      total = o_recT + al(8 * 24 * n);
         DevBuf& buf = arena == &c->arena_trk ? c->nd_skin : c->dba_skin;
         NRS_TRY(c->ensure(buf, total));
@@ -1147,6 +1147,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         NRS_HIP(c, up(o_pb, pose_blk.data(), 4 * (size_t)(s.K + 1))); NRS_HIP(c, up(o_rr, rl_row.data(), 4 * nrl)); NRS_HIP(c, up(o_rp, rl_ptr.data(), 4 * (nrl + 1)));
         NRS_HIP(c, up(o_ro, rl_obs.data(), 4 * n_ent)); NRS_HIP(c, up(o_rw, rl_om.data(), 8 * n_ent));
         NRS_HIP(c, hipMemsetAsync(sb + o_rec, 0, total - o_rec, c->stream));
+        std::vector<int> row_q(2 * (size_t)d.n_rows, 0);           // per row: its list's range (k_pcg_update<true> / k_skin_op_rows go by rows)
+        for (size_t l = 0; l < nrl; ++l) { row_q[2 * (size_t)rl_row[l]] = rl_ptr[l]; row_q[2 * (size_t)rl_row[l] + 1] = rl_ptr[l + 1]; }
+        NRS_HIP(c, up(o_rq, row_q.data(), 8 * (size_t)d.n_rows));
         NRS_HIP(c, hipStreamSynchronize(c->stream));
         d.sk_n = (int)n; d.sk_nblk = (int)nblk; d.sk_pcg = 1;      // (a single-frame engine on the direct solver switches sk_pcg off below)
         d.sk_uv = reinterpret_cast<const float*>(sb + o_uv); d.sk_X0 = reinterpret_cast<const double*>(sb + o_X0);
@@ -1157,7 +1160,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_rl_obs = reinterpret_cast<const int*>(sb + o_ro); d.sk_rl_om = reinterpret_cast<const double*>(sb + o_rw);
         d.sk_rec = reinterpret_cast<double*>(sb + o_rec); d.sk_part = reinterpret_cast<double*>(sb + o_part);
         d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
-        d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_rpart = reinterpret_cast<double*>(sb + o_rpart);
+        d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_row_q = reinterpret_cast<const int*>(sb + o_rq);
         d.sk_recT = reinterpret_cast<double*>(sb + o_recT);
         d.sk_base = ba_form ? d.xl_init : nullptr;                 // (tracking form: the rows ARE the deformations, X0 + sum om x)
         e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
@@ -1169,6 +1172,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         mark("direct solve plan");
     }
     d.sk_pcg = (d.sk_n > 0 && !(e->nd && e->nd->on)) ? 1 : 0;      // (on the direct solver k_nd_values folds the observations into its blocks)
+    if (d.sk_pcg) d.ecd = 0;                                       // (k_pcg_update<true> owns 16 rows a workgroup: no r.u partials per 256 rows for the operator's early test -- one launch in hundreds)
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
     *out = e;
@@ -1201,6 +1205,7 @@ int engine_update_flags(nrs_ctx* c, Engine* e, const uint8_t* rflag, const uint8
         for (int v = 0; v < e->d.M && same; ++v) same = e->nd->sig[v] == (e->h_rflag[e->vrow[v]] & RF_FIXED);
         if (!same) NRS_TRY(nd_engine_setup(c, e, e->nd));
         e->d.sk_pcg = (e->d.sk_n > 0 && !e->nd->on) ? 1 : 0;
+        if (e->d.sk_pcg) e->d.ecd = 0;
     }
     return NRS_OK;
 }

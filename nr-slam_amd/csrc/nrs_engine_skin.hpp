@@ -108,10 +108,12 @@ __global__ __launch_bounds__(BLK) void k_skin(Dev P, const Pose* __restrict__ po
 //   k_skin_rows : a node row's diagonal block += sum om^2 J_l^T w J_l, its gradient += sum om (-J_l^T w r) over its list
 //   k_skin_pose : H_pp / b_p of a pose += the block sums k_skin left (its blocks in order)
 // Per PCG iteration, behind k_spmv_f:  H u of the observations' blocks, with s_o = sum_k om_k u_{n_k}:
-//   k_skin_op      (per observation): g_o = A_o s_o + B_o^T u_p; block sums of B_o s_o (pose rows) and of (B_o^T u_p) . s_o (the
-//                                     observations' share of the cross term u_l . H_lp u_p)
-//   k_skin_op_rows (per node row)   : w_row += sum om g_o; partials of what that adds to w.u
-// k_pcg_update / k_reduce_partials add the partials in (fixed order).  SK_RL lanes per list, combined by the fixed butterfly of
+//   k_skin_op      (per observation): g_o = A_o s_o + B_o^T u_p; block sums of B_o s_o (pose rows), of (B_o^T u_p) . s_o (the
+//                                     observations' share of the cross term u_l . H_lp u_p) and of g_o . s_o (their share of w.u)
+//   per node row                    : w_row += sum om g_o -- by k_pcg_update<true> for the rows it updates (k_skin_op_rows where the
+//                                     update is the generic kernel)
+// k_pcg_update / k_reduce_partials add the block sums in (fixed order): every scalar of the iteration is known after the FIRST launch
+// (k_spmv_f_skin), so the row pass needs no reduction of its own and the iteration is two launches.  SK_RL lanes per list, combined by the fixed butterfly of
 // sub_sum_t.  Both kernels are bound by the number of cache lines a wave's loads touch (one wave per SIMD at this size): the
 // per-observation operands are value-major (sk_recT, sk_row, sk_om: a load instruction of 64 observations touches 4 lines, not 64),
 // g_o is 3 values in a 32-byte slot (two 16-byte loads per list entry).
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(BLK) void k_skin_pose(Dev P) {
 }
 
 __device__ __forceinline__ void skin_op_body(const Dev& P, const int it, const int blk) {
-    __shared__ double lds[4 * 7];
+    __shared__ double lds[4 * 8];
     const int tid = threadIdx.x, i = blk * BLK + tid;
-    double q[7] = {0, 0, 0, 0, 0, 0, 0};
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int done = P.flags[0];                                   // (read beside the first operands, not before them)
     if (i < P.sk_n) {
         const int kp = P.sk_blk_pose[blk];
@@ -190,18 +192,19 @@ __device__ __forceinline__ void skin_op_body(const Dev& P, const int it, const i
             q[p] = b0 * s0 + b1 * s1 + b2 * s2;
         }
         q[6] = g0 * s0 + g1 * s1 + g2 * s2;                        // (B_o^T u_p) . s_o
+        q[7] = (a0 + g0) * s0 + (a1 + g1) * s1 + (a2 + g2) * s2;   // g_o . s_o = sum over the observation's rows of u_row . (om g_o): its share of w.u
         if (!done) {
             double* g = P.sk_g + 4 * (size_t)i;
             g[0] = a0 + g0; g[1] = a1 + g1; g[2] = a2 + g2;
         } else {                                                   // (the solve has finished: nothing is added any more)
 #pragma unroll
-            for (int p = 0; p < 7; ++p) q[p] = 0;
+            for (int p = 0; p < 8; ++p) q[p] = 0;
         }
     }
-    block_sum<7>(q, lds, tid & 63, tid >> 6);
+    block_sum<8>(q, lds, tid & 63, tid >> 6);
     if (tid == 0) {
 #pragma unroll
-        for (int p = 0; p < 7; ++p) P.sk_opart[(size_t)blk * 8 + p] = q[p];
+        for (int p = 0; p < 8; ++p) P.sk_opart[(size_t)blk * 8 + p] = q[p];
     }
 }
 __global__ __launch_bounds__(BLK) void k_skin_op(Dev P, int it) { skin_op_body(P, it, (int)blockIdx.x); }
@@ -214,34 +217,19 @@ __global__ __launch_bounds__(BLK, 4) void k_spmv_f_skin(Dev P, double lam, int c
     else skin_op_body(P, it, (int)blockIdx.x - n_op);
 }
 
-// (a short kernel is as long as its chain of dependent loads: the list bounds, the row and the flag are fetched side by side, then
-// the first entries together with the row's own values, then the observations' g)
+// The row pass in a launch of its own (large windows on the hierarchical reduction, NRS_SKIN_ROWS_OWN_LAUNCH=1): w_row += sum om g_o.
+// Otherwise k_pcg_update<true> does it for the rows it is about to update.  The rows' shares of the dot products are k_skin_op's.
 __global__ __launch_bounds__(BLK) void k_skin_op_rows(Dev P) {
-    __shared__ double lds[4];
-    const int tid = threadIdx.x, j = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
-    const int jj = min(j, P.sk_nrl - 1);
-    const int done = P.flags[0], q0 = P.sk_rl_ptr[jj], q1 = P.sk_rl_ptr[jj + 1];
-    const size_t row = (size_t)P.sk_rl_row[jj];
-    const uint8_t rf = P.rflag[row];
-    const double u0 = P.uv3[3 * row], u1 = P.uv3[3 * row + 1], u2 = P.uv3[3 * row + 2];
-    const double w0 = P.wv[3 * row], w1 = P.wv[3 * row + 1], w2 = P.wv[3 * row + 2];
-    const bool live = j < P.sk_nrl && !done && !(rf & RF_FIXED);
-    double a[3] = {0, 0, 0}, part[1] = {0};
-    if (live)
-        for (int q = q0 + t; q < q1; q += SK_RL) {
-            const double om = P.sk_rl_om[q];
-            const double* g = P.sk_g + 4 * (size_t)P.sk_rl_obs[q];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a[k] += om * g[k];
-        }
+    const int tid = threadIdx.x, r = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;     // (n_rows is a multiple of BLK)
+    const int done = P.flags[0], q0 = P.sk_row_q[2 * (size_t)r], q1 = P.sk_row_q[2 * (size_t)r + 1];
+    const uint8_t rf = P.rflag[r];
+    const double w0 = P.wv[3 * (size_t)r], w1 = P.wv[3 * (size_t)r + 1], w2 = P.wv[3 * (size_t)r + 2];
+    const bool live = !done && q1 > q0 && !(rf & RF_FIXED);       // (a fixed row is an identity row: nothing is added to it)
+    double a[3] = {0, 0, 0};
+    if (live) skin_row_gather(P, q0, q1, t, a);
 #pragma unroll
     for (int k = 0; k < 3; ++k) a[k] = sub_sum_t<SK_RL>(a[k]);
-    if (live && t == 0) {
-        P.wv[3 * row] = w0 + a[0]; P.wv[3 * row + 1] = w1 + a[1]; P.wv[3 * row + 2] = w2 + a[2];
-        part[0] = u0 * a[0] + u1 * a[1] + u2 * a[2];
-    }
-    block_sum<1>(part, lds, tid & 63, tid >> 6);
-    if (tid == 0) P.sk_rpart[blockIdx.x] = part[0];
+    if (live && t == 0) { P.wv[3 * (size_t)r] = w0 + a[0]; P.wv[3 * (size_t)r + 1] = w1 + a[1]; P.wv[3 * (size_t)r + 2] = w2 + a[2]; }
 }
 
 }  // namespace nrs

@@ -191,8 +191,8 @@ struct Dev {
     const int* sk_rl_row; const int* sk_rl_ptr; const int* sk_rl_obs; const double* sk_rl_om;   // list j: row, entries [ptr[j], ptr[j+1]): observation slot, weight
     double* sk_recT;                 // 24 x sk_n: the operator's part of sk_rec (A: 6, B: 18), value-major (written when sk_pcg)
     double* sk_g;                    // sk_n x 4: per observation A s + B^T u_p (3 values in a 32-byte slot) of the current PCG direction u
-    double* sk_opart;                // sk_nblk x 8: sums over a block's observations of B s (6: the pose rows of H u) and of (B^T u_p).s (the cross term u_l.(H_lp u_p))
-    double* sk_rpart;                // ceil(sk_nrl / SK_RPB): what the row pass adds to w.u
+    double* sk_opart;                // sk_nblk x 8: sums over a block's observations of B s (6: the pose rows of H u), of (B^T u_p).s (the cross term u_l.(H_lp u_p)) and of g.s (their share of w.u)
+    const int* sk_row_q;             // n_rows x 2: a row's range in sk_rl_obs / sk_rl_om (empty: no observation reaches it)
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 

@@ -104,18 +104,21 @@ def test_resident_form_reset_and_determinism(ctx):
     assert np.allclose(out[0][2], osk, atol=1e-4, rtol=0)
 
 
-def test_operator_halves_in_one_launch_give_the_bits_of_two(ctx, monkeypatch):
-    """k_spmv_f_skin (the regularisers' operator and k_skin_op as one launch) against the two launches (NRS_SKIN_OP_OWN_LAUNCH=1:
-    the env is read per launch): the same bodies on the same data -- every trial and every output bit for bit."""
+@pytest.mark.parametrize("switch", ["NRS_SKIN_OP_OWN_LAUNCH", "NRS_SKIN_ROWS_OWN_LAUNCH"])
+def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx, monkeypatch, switch):
+    """A PCG iteration of the embedded window is two launches: k_spmv_f_skin (the regularisers' operator and k_skin_op) and
+    k_pcg_update<true> (the observations' row pass and the vector update).  NRS_SKIN_OP_OWN_LAUNCH=1 / NRS_SKIN_ROWS_OWN_LAUNCH=1 give
+    k_skin_op / the row pass (k_skin_op_rows, then the generic update) launches of their own (the env is read per launch): the same
+    arithmetic on the same data -- every trial and every output bit for bit."""
     p, e, w, cam, qt = _setup(500, 5, 70, 58)
     out = []
     for own in (False, True):
         if own:
-            monkeypatch.setenv("NRS_SKIN_OP_OWN_LAUNCH", "1")
+            monkeypatch.setenv(switch, "1")
         tr = nrs.Trace()
         pq, xyz, sk = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tr)
         out.append((pq, xyz, sk, [(t["accepted"], t["chi"], t["chi_new"], t["lam"], t["inner"]) for t in tr.trials]))
-    monkeypatch.delenv("NRS_SKIN_OP_OWN_LAUNCH")
+    monkeypatch.delenv(switch)
     assert sum(t[4] for t in out[0][3]) > 50
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert out[0][3] == out[1][3]
