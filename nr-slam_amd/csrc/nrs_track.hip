@@ -476,7 +476,10 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         if (tm) fprintf(stderr, "[nrs] a2 device walk: %d passes, %s\n", wo.passes, dev ? "converged" : "not taken");
         if (dev) {
             mark("GetEdges + device walk");
-            dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear();
+            size_t n_e = 0;                                        // (the edge arrays are sized once and written by index: ~50 ns an edge with four vector appends)
+            for (int idx = 0; idx < N; ++idx) if (node_of[idx] >= 0) n_e += wo.n_acc[idx];
+            dm_idx.resize(4 * n_e); sp_ij.resize(2 * n_e); dm_w.resize(n_e); sp_d0.resize(n_e);
+            size_t ne = 0;
             std::copy(wo.lost.begin(), wo.lost.end(), lost_flag.begin());
             sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
             for (int idx = 0; idx < N && !again; ++idx) {
@@ -488,10 +491,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
                     const int io = wo.acc[11 * (size_t)idx + k];
                     const float wk = wo.w[11 * (size_t)idx + k];
                     if (is_node) {
-                        dm_idx.insert(dm_idx.end(), {-1, -1, node_of[idx], node_of[io]});
-                        dm_w.push_back(wk);
-                        sp_ij.insert(sp_ij.end(), {node_of[idx], node_of[io]});
-                        sp_d0.push_back(wo.d0[11 * (size_t)idx + k]);
+                        const int a = node_of[idx], b = node_of[io];
+                        int* dq = &dm_idx[4 * ne];
+                        dq[0] = -1; dq[1] = -1; dq[2] = a; dq[3] = b;        // r = w (delta_idx - delta_io)
+                        dm_w[ne] = wk;
+                        sp_ij[2 * ne] = a; sp_ij[2 * ne + 1] = b;
+                        sp_d0[ne] = wo.d0[11 * (size_t)idx + k];
+                        ++ne;
                     } else {
                         sk_node[11 * slot + k] = node_of[io];
                         sk_om[11 * slot + k] = (double)wk;
@@ -517,7 +523,9 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
     const float *ow = src.w, *od0 = src.d0;
     mark("GetEdges");
     std::fill(n_acc.begin(), n_acc.end(), 0);
-    dm_idx.clear(); sp_ij.clear(); dm_w.clear(); sp_d0.clear(); std::fill(lost_flag.begin(), lost_flag.end(), 0);
+    size_t ne = 0;                                                 // (at most 11 edges a walk: sized for that, written by index, cut to size below)
+    dm_idx.resize(44 * (size_t)M); sp_ij.resize(22 * (size_t)M); dm_w.resize(11 * (size_t)M); sp_d0.resize(11 * (size_t)M);
+    std::fill(lost_flag.begin(), lost_flag.end(), 0);
     sk_idx.clear(); std::fill(sk_of.begin(), sk_of.end(), -1); std::fill(sk_node.begin(), sk_node.end(), -1); std::fill(sk_om.begin(), sk_om.end(), 0.0);
     for (int idx = 0; idx < N && !again; ++idx) {
         const int p = ids[idx];
@@ -545,12 +553,13 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
                 bool dup = false;
                 if (io < idx) { const int* al = &acc[11 * (size_t)io]; for (int k = 0, nk = n_acc[io]; k < nk; ++k) dup = dup || al[k] == idx; }
                 if (dup) continue;
-                const int k = (int)dm_w.size();
-                dm_idx.insert(dm_idx.end(), {-1, -1, node_of[idx], node_of[io]});      // r = w (delta_idx - delta_io)
-                dm_w.push_back(ow[a]);
-                sp_ij.insert(sp_ij.end(), {node_of[idx], node_of[io]});
-                sp_d0.push_back(od0[a]);
-                (void)k;
+                const int va = node_of[idx], vb = node_of[io];
+                int* dq = &dm_idx[4 * ne];
+                dq[0] = -1; dq[1] = -1; dq[2] = va; dq[3] = vb;       // r = w (delta_idx - delta_io)
+                dm_w[ne] = ow[a];
+                sp_ij[2 * ne] = va; sp_ij[2 * ne + 1] = vb;
+                sp_d0[ne] = od0[a];
+                ++ne;
                 acc[11 * (size_t)idx + n_acc[idx]++] = io;           // (n_reg <= 10 here: at most 11 per walk)
             } else {
                 sk_node[11 * slot + n_reg] = node_of[io];
@@ -571,6 +580,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
             again = true;
         }
     }
+    dm_idx.resize(4 * ne); sp_ij.resize(2 * ne); dm_w.resize(ne); sp_d0.resize(ne);
     }
     src.pass_over = nullptr;
     mark("GetEdges + edge construction");
