@@ -1546,29 +1546,36 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
         skt.swap(raw);
     }
     nd_sort_by_pair(keys, n_free);                                 // (edge order inside a pair)
-    T.pairs.clear(); T.pkind.clear(); T.eptr.assign(1, 0); T.eid.clear(); P.pair_sk0.clear(); P.pair_sk1.clear();
-    T.pairs.reserve(2 * (keys.size() + skt.size() / 4));
-    // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences
+    // the union of the regularisers' couplings and the observations': a merge of the two sorted key sequences (the arrays are sized for
+    // the most there can be and written by index -- seven vector appends a pair were a third of this phase -- then cut to size)
+    const size_t pairs_max = keys.size() + skt.size() + (P.pose_free ? 2 * (size_t)n_free + 1 : 0);
+    T.pairs.resize(2 * pairs_max); T.pkind.resize(pairs_max); T.eptr.resize(pairs_max + 1); T.eid.resize(keys.size() * (twin ? 2 : 1));
+    P.pair_sk0.resize(pairs_max); P.pair_sk1.resize(pairs_max);
+    size_t np = 0, ne = 0;
+    T.eptr[0] = 0;
     for (size_t i = 0, st = 0; i < keys.size() || st < skt.size();) {
         const uint64_t kk = i < keys.size() && (st >= skt.size() || keys[i].k <= skt[st].k) ? keys[i].k : skt[st].k;
         const size_t i0 = i;
-        for (; i < keys.size() && keys[i].k == kk; ++i) T.eid.push_back(keys[i].id);
-        if (twin) for (size_t j = i0; j < i; ++j) T.eid.push_back(keys[j].id | 1);
-        T.eptr.push_back((int)T.eid.size());
-        T.pairs.push_back((int)(kk >> 32)); T.pairs.push_back((int)(kk & 0xFFFFFFFFu));
-        T.pkind.push_back(0);
-        P.pair_sk0.push_back((int)st);
+        for (; i < keys.size() && keys[i].k == kk; ++i) T.eid[ne++] = keys[i].id;
+        if (twin) for (size_t j = i0; j < i; ++j) T.eid[ne++] = keys[j].id | 1;
+        T.eptr[np + 1] = (int)ne;
+        T.pairs[2 * np] = (int)(kk >> 32); T.pairs[2 * np + 1] = (int)(kk & 0xFFFFFFFFu);
+        T.pkind[np] = 0;
+        P.pair_sk0[np] = (int)st;
         while (st < skt.size() && skt[st].k == kk) ++st;
-        P.pair_sk1.push_back((int)st);
+        P.pair_sk1[np] = (int)st;
+        ++np;
     }
+    const size_t n_coupl = np;                                     // (the pose's pairs below carry no edge list and no observation range)
     P.last.assign(n_nodes, 0);
     if (P.pose_free) {
         P.last[n_free] = P.last[n_free + 1] = 1;
         for (int a = 0; a < n_free; ++a)
             if (in.rflag[P.node_vtx[a]] & RF_OBS)
-                for (int h = 0; h < 2; ++h) { T.pkind.push_back(1); T.pairs.push_back(n_free + h); T.pairs.push_back(a); }
-        T.pkind.push_back(2); T.pairs.push_back(n_free + 1); T.pairs.push_back(n_free);
+                for (int h = 0; h < 2; ++h) { T.pkind[np] = 1; T.pairs[2 * np] = n_free + h; T.pairs[2 * np + 1] = a; ++np; }
+        T.pkind[np] = 2; T.pairs[2 * np] = n_free + 1; T.pairs[2 * np + 1] = n_free; ++np;
     }
+    T.pairs.resize(2 * np); T.pkind.resize(np); T.eptr.resize(n_coupl + 1); T.eid.resize(ne); P.pair_sk0.resize(n_coupl); P.pair_sk1.resize(n_coupl);
     P.wanted = true;
     lap(1);
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
