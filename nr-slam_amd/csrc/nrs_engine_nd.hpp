@@ -1596,6 +1596,14 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         if (P.th.joinable()) P.th.join();
         if (tm) fprintf(stderr, "[nrs] direct solve: waited %.2f ms for the plan thread\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
+    const bool tmf = getenv("NRS_TIMING") != nullptr;
+    auto tf_prev = std::chrono::steady_clock::now();
+    auto lapf = [&](const char* what) {
+        if (!tmf) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nrs] direct solve finish: %-18s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tf_prev).count());
+        tf_prev = now;
+    };
     nd_slot_release(c, nd);                                        // (a rebuild after the fixed set changed: the old plan goes back to the cache)
     if (!P.wanted || !nd_wanted(c, d, P.n_free)) return NRS_OK;
     const NdStruct& T = *P.st;
@@ -1651,25 +1659,26 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         }
         if (up != NRS_OK) return up;
     }
+    lapf("plan upload");
     // ---- value descriptors: the plan's nodes and pairs in terms of this engine's rows and incidence slots
     std::vector<int> nrow(n_nodes), node_out(n_nodes);
     for (int a = 0; a < n_free; ++a) { nrow[a] = e->vrow[P.node_vtx[a]]; node_out[a] = 3 * nrow[a]; }
     if (P.pose_free) { nrow[n_free] = -1; nrow[n_free + 1] = -2; node_out[n_free] = -1; node_out[n_free + 1] = -1 - 3; }
     std::vector<NdPairD> pd(n_pairs);
-    std::vector<int> src;
-    src.reserve(T.eid.size());
+    std::vector<int> src(T.eid.size());                             // (one source per edge of a pair, written by index)
+    size_t n_src = 0;
     for (int i = 0; i < n_pairs; ++i) {
         const int a = T.pairs[2 * (size_t)i], b = T.pairs[2 * (size_t)i + 1];
         if (T.pkind[i] == 0) {
             // (the factor of an edge sits in both endpoints' incidence slots with the same value when both are free: the first one is read)
-            pd[i] = NdPairD{0, nrow[a], nrow[b], (int)src.size(), 0};
+            pd[i] = NdPairD{0, nrow[a], nrow[b], (int)n_src, 0};
             for (int t = T.eptr[i]; t < T.eptr[i + 1]; ++t) {
                 const int id = T.eid[t] >> 1, kind = T.eid[t] & 1;
                 const int slot = kind ? e->dm_pos[4 * (size_t)id + 2] : e->sp_pos[2 * (size_t)id];
                 if (slot < 0) return NRS_OK;                       // (an incidence of another rank: not a single-frame engine)
-                src.push_back((slot << 1) | kind);
+                src[n_src++] = (slot << 1) | kind;
             }
-            pd[i].nsrc = (int)src.size() - pd[i].src0;
+            pd[i].nsrc = (int)n_src - pd[i].src0;
         } else if (T.pkind[i] == 1) pd[i] = NdPairD{1, a - n_free, nrow[b], 0, 0};
         else pd[i] = NdPairD{2, 0, 0, 0, 0};
     }
@@ -1680,6 +1689,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     const size_t o_nr = 0, o_no = o_nr + al(4 * (size_t)n_nodes), o_pd = o_no + al(4 * (size_t)n_nodes), o_src = o_pd + al(sizeof(NdPairD) * (size_t)n_pairs),
                  o_sp = o_src + al(4 * std::max<size_t>(1, src.size())), o_st = o_sp + al(4 * std::max<size_t>(1, ske_ptr.size())),
                  o_sc = o_st + al(4 * std::max<size_t>(1, ske_pt.size())), total = o_sc + al(8 * std::max<size_t>(1, ske_cf.size()));
+    lapf("descriptors");
     NRS_TRY(c->ensure(sl->vb, total));
     char* vb = sl->vb.as<char>();
     sl->h_vals.assign(total, 0);                                   // one upload from a staging image the slot keeps (no synchronisation)
@@ -1711,6 +1721,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     nd->sig.assign((size_t)d.M + 1, 0);
     for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
     nd->sig[d.M] = e->h_pose_fixed[0];
+    lapf("values upload");
     sl->busy = true; sl->used = ++nc->clock;
     nd->slot = sl; nd->on = true;
     if (!hit) { sl->key.swap(P.key); sl->hash = P.hash; sl->st = P.st; }
