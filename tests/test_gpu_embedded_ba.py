@@ -124,6 +124,24 @@ def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx, monkeyp
     assert out[0][3] == out[1][3]
 
 
+def test_hierarchical_reduction_path_matches(ctx, monkeypatch):
+    """Large windows reduce the partials in a kernel of their own (k_reduce_partials, from 4096 tiles on); NRS_HIER=1 forces that form
+    on a small window: the row pass is then k_skin_op_rows and the update the generic kernel.  Same problem, same LM decisions, results
+    within the oracle tolerances of the default form (the sums are grouped differently)."""
+    p, e, w, cam, qt = _setup(400, 4, 50, 59)
+    ta = nrs.Trace()
+    pa, xa, ska = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, ta)
+    monkeypatch.setenv("NRS_HIER", "1")
+    tb = nrs.Trace()
+    pb, xb, skb = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tb)
+    monkeypatch.delenv("NRS_HIER")
+    assert [t["accepted"] for t in ta.trials] == [t["accepted"] for t in tb.trials]
+    for a, b in zip(ta.trials, tb.trials):
+        assert abs(a["chi"] - b["chi"]) <= 1e-6 * b["chi"]
+    assert np.allclose(pa[:, :4], pb[:, :4], atol=1e-6, rtol=0) and np.allclose(pa[:, 4:], pb[:, 4:], atol=1e-5, rtol=0)
+    assert np.allclose(xa, xb, atol=1e-4, rtol=0) and np.allclose(ska, skb, atol=1e-4, rtol=0)
+
+
 def test_bad_inputs_are_rejected(ctx):
     p, e, w, cam, qt = _setup(200, 3, 30, 57)
     bad = dict(e, sk_node=e["sk_node"].copy())
