@@ -30,6 +30,7 @@ struct nrs_rgraph {
     float *maxd = nullptr, *mind = nullptr, *d0 = nullptr;
     uint8_t* st = nullptr;
     nrs::DevBuf pos, ids_a, ids_b, out_i, out_f, good, skip, slot, walk;   // (walk: the device-side neighbour walk of a2, rg_walk)
+    nrs::DevBuf mir;                 // status + longest distance once more as FULL matrices (k_rg_mirror), for GetEdges over many rows
     int last_n_ids = 0, last_cap = 0;  // shape of the lists out_i holds (the last GetEdges)
     std::vector<int> h_slot;
     char* pin = nullptr;             // pinned staging area of the GetEdges results (page-faulting pageable targets cost more than the kernel)
@@ -158,6 +159,30 @@ __global__ __launch_bounds__(RG_TC) void k_rg_update_tri(const int* __restrict__
 __device__ inline unsigned long long rg_key(int s, float w, int j) {
     return ((unsigned long long)s << 56) | ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(w)) << 24) | (unsigned long long)j;
 }
+// The state is the upper triangle of cap x cap arrays (rg_at): row i of the graph is a contiguous run for j > i and a COLUMN for
+// j < i (one cache line per entry).  GetEdges of most rows (a2's first call: every tracked point) read that column part at a tenth of
+// the memory system's rate (0.55 ms at 4.4k points), so the two arrays it scans are first written out as full symmetric matrices:
+// 64 x 64 tiles, the transposed half through LDS, both halves stored as rows (~5 bytes x cap^2 read and written once).
+__global__ __launch_bounds__(256) void k_rg_mirror(int cap, const uint8_t* __restrict__ st, const float* __restrict__ maxd, uint8_t* __restrict__ st_f, float* __restrict__ maxd_f) {
+    __shared__ float tm[64][65];
+    __shared__ uint8_t ts[64][68];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bi > bj) return;                                           // (tiles of the upper triangle, the diagonal ones included)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int i = bi * 64 + r, j = bj * 64 + tx;
+        float v = 0.f; uint8_t q = RG_NONE;
+        if (i < cap && j < cap && i < j) { v = maxd[(size_t)i * cap + j]; q = st[(size_t)i * cap + j]; }
+        tm[r][tx] = v; ts[r][tx] = q;
+        if (i < cap && j < cap && (bi < bj || i < j)) { maxd_f[(size_t)i * cap + j] = v; st_f[(size_t)i * cap + j] = q; }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {                             // the transposed tile: rows of the lower triangle
+        const int j = bj * 64 + r, i = bi * 64 + tx;               // (element (j, i) of the full matrix = element (i, j) of the state, i < j)
+        if (i < cap && j < cap && i < j) { maxd_f[(size_t)j * cap + i] = tm[tx][r]; st_f[(size_t)j * cap + i] = ts[tx][r]; }
+    }
+}
+
 constexpr int RG_BINS = 256;     // weight histogram bins per status class (selection of the first out_cap entries)
 constexpr int RG_CLASSES = 4;    // NRS_GRAPH_VERIFIED .. NRS_GRAPH_BAD
 constexpr int RG_SLACK = 1024;   // candidates staged beyond out_cap (the population of the bin the cut falls into)
@@ -173,7 +198,8 @@ constexpr int RG_SLACK = 1024;   // candidates staged beyond out_cap (the popula
 __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __restrict__ ids, int cap, const float* __restrict__ maxd,
                                                      const float* __restrict__ d0, const uint8_t* __restrict__ st, float sigma,
                                                      float min_w, float d_hi, int cand_cap, int out_cap, int select_all, const uint8_t* __restrict__ skip, int* o_count,
-                                                     int* o_col, float* o_w, float* o_d0, int* o_st, int* overflow) {
+                                                     int* o_col, float* o_w, float* o_d0, int* o_st, int* overflow,
+                                                     const uint8_t* __restrict__ st_f, const float* __restrict__ maxd_f) {   // st_f / maxd_f: the full matrices of k_rg_mirror, or null
     extern __shared__ unsigned long long cand[];              // keys of the staged connections (padded to a power of two for the sort)
     __shared__ int hist[RG_CLASSES][RG_BINS];
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -185,10 +211,10 @@ __global__ __launch_bounds__(64) void k_rg_get_edges(int n_ids, const int* __res
     auto entry = [&](int j, float& w, int& s) -> bool {         // does connection (i, j) survive the min_weight cut?
         s = 255; w = 0.f;
         if (j >= cap || j == i) return false;
-        const size_t k = rg_at(i, j, cap);
-        s = st[k];
+        const size_t k = st_f ? (size_t)i * cap + j : rg_at(i, j, cap);
+        s = st_f ? st_f[k] : st[k];
         if (s == RG_NONE) { s = 255; return false; }
-        const float mx = maxd[k];
+        const float mx = st_f ? maxd_f[k] : maxd[k];
         // beyond d_hi = 1.5 sigma (1 + 1e-4) the weight is below min_weight for sure; inside, the exact value decides
         if (mx <= d_hi) { w = rg_weight(mx, sigma); return !(w < min_w); }
         return false;
@@ -346,7 +372,7 @@ extern "C" void nrs_rgraph_destroy(nrs_rgraph* g) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(g->maxd); (void)hipFree(g->mind); (void)hipFree(g->d0); (void)hipFree(g->st);
     if (g->pin) (void)hipHostFree(g->pin);
-    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip); c->release(g->slot); c->release(g->walk);
+    c->release(g->pos); c->release(g->ids_a); c->release(g->ids_b); c->release(g->out_i); c->release(g->out_f); c->release(g->good); c->release(g->skip); c->release(g->slot); c->release(g->walk); c->release(g->mir);
     delete g;
 }
 
@@ -596,6 +622,17 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
         NRS_HIP(c, hipMemcpyAsync(g->skip.p, pass_over, (size_t)g->cap, hipMemcpyHostToDevice, c->stream));
     }
     const float d_hi = (float)((double)g->sigma * 1.5 * (1.0 + 1e-4));
+    // many rows (a2's first GetEdges of a frame: every tracked point): the kernel scans full symmetric copies of the two arrays it reads
+    const uint8_t* st_f = nullptr;
+    const float* maxd_f = nullptr;
+    if ((int64_t)n_ids * 8 >= g->cap && g->cap >= 512 && !getenv("NRS_RG_NO_MIRROR")) {
+        const size_t cc = (size_t)g->cap * g->cap, o_m = (cc + 255) & ~(size_t)255;
+        NRS_TRY(c->ensure(g->mir, o_m + 4 * cc));
+        const int nt = (g->cap + 63) / 64;
+        hipLaunchKernelGGL(k_rg_mirror, dim3(nt, nt), dim3(256), 0, c->stream, g->cap, g->st, g->maxd, g->mir.as<uint8_t>(), reinterpret_cast<float*>(g->mir.as<char>() + o_m));
+        NRS_HIP(c, hipGetLastError());
+        st_f = g->mir.as<uint8_t>(); maxd_f = reinterpret_cast<const float*>(g->mir.as<char>() + o_m);
+    }
     // first the selecting form (stages <= cap_per_point + one histogram bin per row); if a bin overflows the staging area
     // (many equal distances), once more with every survivor of a row staged
     int* h = reinterpret_cast<int*>(g->pin);
@@ -608,7 +645,7 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
         const size_t shm = sizeof(unsigned long long) * pad;
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rg_get_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         hipLaunchKernelGGL(k_rg_get_edges, dim3(n_ids), dim3(64), shm, c->stream, n_ids, g->ids_a.as<int>(), g->cap,
-                           g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, pass_over ? g->skip.as<uint8_t>() : nullptr, d_cnt, d_col, d_w, d_d0, d_st, d_ovf);
+                           g->maxd, g->d0, g->st, g->sigma, g->min_w, d_hi, cand_cap, cap_per_point, pass, pass_over ? g->skip.as<uint8_t>() : nullptr, d_cnt, d_col, d_w, d_d0, d_st, d_ovf, st_f, maxd_f);
         NRS_HIP(c, hipGetLastError());
         if (lists_to_host) NRS_HIP(c, hipMemcpyAsync(h, d_cnt, bytes, hipMemcpyDeviceToHost, c->stream));
         else {
