@@ -256,16 +256,31 @@ def reduce_over_ranks(dist, dt, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0, n_nodes=0):
+_SEQ_CACHE = {}
+
+
+def frame_sequence(n_points, n_frames, seed=21):
+    """the synthetic 640x480 sequence of a tracked-fps leg (nrs_synth.make_frame_sequence), generated once per (points, frames): the legs
+    that differ in graph / solver / node set run on the very same images"""
+    import nrs_synth as S
+    key = (n_points, n_frames, seed)
+    if key not in _SEQ_CACHE:
+        _SEQ_CACHE[key] = S.make_frame_sequence(n_points, n_frames, seed)
+    return _SEQ_CACHE[key]
+
+
+def tracked_fps(n_points=5000, frames=31, dense_graph=False, direct_solve=0, n_nodes=0):
     """Secondary figure of BASELINE.json's metric: tracked frames/s, end to end through the frame-loop
-    harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode and
-    feature extraction) on a consistent synthetic 640x480 sequence with n_points map points: LK data
-    association, motion-model seed, pose-only solve, pose-and-deformation solve (with its graph
-    update), point reuse.  Every call takes host buffers (a frame arrives from the host): PCIe-inclusive."""
+    harness (nr-slam_amd/py/nrs_frame_loop.py = reference tracking.cc:72-112 minus image decode) on a consistent
+    synthetic 640x480 sequence with n_points map points: LK data association, motion-model seed, pose-only solve,
+    pose-and-deformation solve (with its graph update), PointReuse (tracking.cc:394-506: moving occluders hide points,
+    which fail the tracker's SSIM gate and are re-found once the patch has moved on), keyframe insertion every sixth
+    frame (Shi-Tomasi extraction, new LK reference, template archive).  frames - 1 frames are timed (the first warms the
+    code objects up): `value` is their mean rate; median / p95 frame times and the per-stage means sit next to it.
+    Every call takes host buffers (a frame arrives from the host): PCIe-inclusive."""
     import nrs
     import nrs_frame_loop as FL
-    import nrs_synth as S
-    sq = S.make_frame_sequence(n_points, frames + 1, 21)
+    sq = frame_sequence(n_points, frames + 1)
     opts = dict(win=21, max_level=4, max_iters=10, epsilon=1e-4, min_eig=1e-4)
     # dense_graph: the map's graph at the reference's density (all pairs, resident on the device) instead of the generator's kNN-16
     # n_nodes > 0: the embedded-deformation mode of the pose-and-deformation solve (n_nodes map points carry the vertices, N2a)
@@ -281,7 +296,10 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0, n_no
             stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
             return r
         setattr(gb, name, w)
-    for nme in ("klt_track", "pose_only", "track_deform", "reuse_track", "extract_features"):
+    # (PointReuse tracks its candidates from the device-side template archive: reuse_track_archived + insert_archived; a keyframe is
+    # extract_features + klt_set_reference + archive_templates)
+    for nme in ("klt_track", "pose_only", "track_deform", "reuse_track", "reuse_track_archived", "insert_archived", "extract_features",
+                "klt_set_reference", "archive_templates"):
         wrap(nme)
     loop = FL.FrameLoop(gb, lambda pc: FL.project_f32(sq["model"], sq["prm"], pc), sq["wh"], sq["scale"], sq["kp0"], sq["X0"],
                         sq["graph"], sq["pose_q"][0], sq["pose_t"][0], sq["images"][0])
@@ -298,6 +316,7 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0, n_no
     nd_reused, nd_built = gb.ctx.nd_cache_stats()
     gb.close()
     nf = len(ts)
+    log = loop.log[1:]
     # the pose-and-deformation solve: per LM trial one linear solve -- the nested-dissection Cholesky (default, `inner` = 1 per trial) or,
     # with direct_solve=2, a run of single-launch PCG iterations bounded by launch latency (6.9 us floor per iteration)
     direct = inner <= trials
@@ -309,11 +328,19 @@ def tracked_fps(n_points=5000, frames=7, dense_graph=False, direct_solve=0, n_no
                    # symbolic factorisations over the whole sequence (two single-frame problems per frame): built anew / taken from the
                    # context's cache because the frame's optimised set, edges and fixed flags equalled an earlier frame's
                    symbolic_plans=dict(built=nd_built, reused=nd_reused))
-    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), nodes=int(n_nodes) if n_nodes else int(sq["n_points"]), frames=nf, a2_solver=latency,
-                tracked_last_frame=int(loop.log[-1]["n_tracked"]),
+    ms = 1e3 * np.sort(np.asarray(ts))
+    reuse_s = stage.get("reuse_track", 0) + stage.get("reuse_track_archived", 0) + stage.get("insert_archived", 0)
+    kf_s = stage.get("extract_features", 0) + stage.get("klt_set_reference", 0) + stage.get("archive_templates", 0)
+    return dict(value=nf / sum(ts), unit="frames/s", points=int(sq["n_points"]), nodes=int(n_nodes) if n_nodes else int(sq["n_points"]), frames=nf,
+                ms_per_frame_mean=float(ms.mean()), ms_per_frame_median=float(np.median(ms)), ms_per_frame_p95=float(ms[min(nf - 1, int(np.ceil(0.95 * nf)) - 1)]),
+                ms_per_frame_max=float(ms[-1]), keyframes=int(sum(1 for l in log if l["keyframe"])),
+                frames_with_point_reuse=int(sum(1 for l in log if l["reused"] > 0)), points_reused=int(sum(l["reused"] for l in log)),
+                points_lost=int(sum(len(l["lost"]) for l in log)), a2_solver=latency,
+                tracked_last_frame=int(loop.log[-1]["n_tracked"]), tracked_min=int(min(l["n_tracked"] for l in log)),
                 ms_klt_track=1e3 * stage.get("klt_track", 0) / nf, ms_pose_only=1e3 * stage.get("pose_only", 0) / nf,
-                ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * stage.get("reuse_track", 0) / nf,
-                ms_keyframe_extract=1e3 * stage.get("extract_features", 0) / nf, features_2d_last_frame=int(loop.log[-1]["n_2d"]),
+                ms_pose_and_deformation=1e3 * stage.get("track_deform", 0) / nf, ms_point_reuse=1e3 * reuse_s / nf,
+                ms_keyframe_work=1e3 * kf_s / nf, ms_keyframe_extract=1e3 * stage.get("extract_features", 0) / nf,
+                ms_host_harness=1e3 * (sum(ts) - sum(stage.values())) / nf, features_2d_last_frame=int(loop.log[-1]["n_2d"]),
                 lm_trials_per_frame=trials / nf, pcg_iters_per_frame=inner / nf)
 
 
@@ -514,7 +541,64 @@ def skinned_bench(n=5000, m=500, n_kf=20):
                             note="every observation of the window is in the problem; held to oracle/embedded_oracle.py dba_solve_embedded at 300 x 40 x 4 .. "
                                  "600 x 80 x 6 (tests/test_gpu_embedded_ba.py) and at this size by the golden tests/golden/dba_C2_embedded%d_trace.npz; "
                                  "the mode has no reference counterpart beyond every-point-a-node (there it is the plain window, bit for bit)" % m)
+    # ---- its roofline entry: the two launches of a PCG iteration (k_spmv_f_skin<8>: the regularisers' operator + the observations' pass;
+    # k_pcg_update<true>: the observations' row pass + the vector update), HIP events on the context's stream (nrs_options.profile).
+    # Algorithmic bytes per iteration: operator -- per skinned observation A_o (6) + B_o (18) doubles, its 11 (row, weight)
+    # pairs and the 24-byte g_o it leaves = 348 B; per node row u, w, the linearisation point and the 32-byte reprojection factors = 104 B;
+    # 12 B per spring incidence, 16 B per damper incidence.  Update -- per node row 6 vectors read, 5 written, M^-1 = 312 B; per (row, observation)
+    # list entry weight + index + g_o = 36 B.  Both stay in the 256 MB Infinity Cache at this size: the fraction is of the HBM peak all the same.
+    pctx = nrs.Context(profile=1)
+    pctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
+    pctx.dba_optimize(2)
+    pctx.reset_profile()
+    pctx.dba_reset()
+    pctx.dba_optimize(2)
+    prof = pctx.profile()
+    pctx.close()
+    n_obs, n_rows, n_ent = int(len(e["sk_obs"])), int(len(e["lm_obs"])), int((np.asarray(e["sk_node"]) >= 0).sum())
+    op_b = 348 * n_obs + 104 * n_rows + 12 * 2 * len(e["sp_ij"]) + 16 * 4 * len(e["dm_idx"])
+    up_b = 312 * n_rows + 36 * n_ent
+    op_us = 1e3 * prof["spmv_ms"] / max(1, prof["spmv_launches"])
+    up_us = 1e3 * prof["vec_ms"] / max(1, prof["vec_launches"])
+    out["ba_window"]["roofline"] = dict(kernel="k_spmv_f_skin<8> (operator of the regularisers + the skinned observations' pass, one launch)", bound="hbm",
+                                        achieved=op_b / (op_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=op_b / (op_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        traffic=None, avg_us=op_us, algorithmic_bytes=int(op_b), launches=int(prof["spmv_launches"]),
+                                        regime="27 MB of operands per launch: Infinity-Cache resident, bound by the chains of dependent loads (latency), not by bytes")
+    out["ba_window"]["roofline_update"] = dict(kernel="k_pcg_update<true> (the observations' row pass + the PCG vector update)", bound="hbm",
+                                               achieved=up_b / (up_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=up_b / (up_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                               traffic=None, avg_us=up_us, algorithmic_bytes=int(up_b), launches=int(prof["vec_launches"]))
+    out["ba_window"]["pcg_iterations_per_lm_trial"] = rr["inner"] / max(1, rr["trials"])
+    out["ba_window_inputs"] = (p, e, w)                            # (the CPU leg of main() runs the same window; removed before printing)
     ctx.close()
+    return out
+
+
+def cpu_baseline_embedded(p, e, w, gpu_value):
+    """cpu_baseline of the embedded C2 window: the C++ restatement of the embedded form (oracle/nrs_cpu.cpp nrs_cpu_dba_solve_embedded, held to
+    oracle/embedded_oracle.py by tests/test_oracle_cpp_cpu.py), the whole optimize(5) with the block-Jacobi PCG on all host threads (the faster
+    CPU algorithm), one thread next to it, and ONE trial of the reference's own linear solve (sparse Cholesky: 146 GFLOP per factorisation)."""
+    import nrs_cpu as CPU
+    CPU.build(native=True)
+    lib = CPU.load(native=True)
+    nt = CPU.max_threads(lib)
+
+    def run(solver, threads, max_trials):
+        t0 = time.perf_counter()
+        r = CPU.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"],
+                                   w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], 5, solver, 1e-10, threads, max_trials, lib)
+        return time.perf_counter() - t0, r[5]
+    dt, st = run(1, nt, 0)
+    out = dict(value=st["n_iters"] / (st["t_total"] - st["t_structure"]), unit="LM iters/s", cores=nt, kind="port",
+               sample="the whole optimize(5) of the embedded C2 window, block-Jacobi PCG to 1e-10 on %d threads: %d LM iterations, %d PCG iterations, %.1f s "
+                      "(+ %.1f s structure, once per window)" % (nt, st["n_iters"], st["n_pcg_iters"], st["t_total"] - st["t_structure"], st["t_structure"]),
+               gpu_over_cpu=gpu_value / (st["n_iters"] / (st["t_total"] - st["t_structure"])))
+    dt1, st1 = run(1, 1, 2)
+    out["one_core"] = dict(value=st1["n_iters"] / (st1["t_total"] - st1["t_structure"]), unit="LM iters/s", cores=1,
+                           sample="the first 2 LM trials (%d PCG iterations), %.1f s" % (st1["n_pcg_iters"], st1["t_total"] - st1["t_structure"]))
+    dt0, st0 = run(0, 1, 1)
+    out["sparse_cholesky_one_trial"] = dict(value=st0["n_trials"] / max(1e-9, st0["t_factor"] + st0["t_solve"] + st0["t_linearize"] + st0["t_errors"]), unit="LM trials/s", cores=1,
+                                            gflop_per_factorisation=st0["chol_flops"] / 1e9, seconds_factorisation=st0["t_factor"],
+                                            note="what the reference runs per LM trial (linear_solver_eigen.h:92-173), here the oracle's own AMD-ordered up-looking block Cholesky")
     return out
 
 
@@ -796,7 +880,9 @@ def main():
         # resident on the device; the generator's kNN-16 flat graph (what round 1 measured) stays next to it
         out["tracked_fps"] = tracked_fps(dense_graph=True)
         out["tracked_fps"]["graph"] = "all pairs (4999 connections per point), device resident"
-        keys = ("value", "unit", "points", "frames", "ms_pose_and_deformation", "lm_trials_per_frame", "pcg_iters_per_frame", "tracked_last_frame")
+        keys = ("value", "unit", "points", "frames", "ms_per_frame_median", "ms_per_frame_p95", "keyframes", "frames_with_point_reuse", "points_reused",
+                "ms_klt_track", "ms_pose_only", "ms_pose_and_deformation", "ms_point_reuse", "ms_keyframe_work", "lm_trials_per_frame", "pcg_iters_per_frame",
+                "tracked_last_frame")
         tf = tracked_fps(dense_graph=True, direct_solve=2)           # the same frames with the PCG as linear solver (round 3's path)
         out["tracked_fps_pcg_solver"] = {k: tf[k] for k in keys}
         tf = tracked_fps(n_points=1150, dense_graph=True)            # the reference's own scale (C1: ~1k tracked points)
@@ -813,6 +899,10 @@ def main():
         out["graph_dense"] = rgraph_bench()
         out["triangulation"] = triangulation_bench()
         out["skinned"] = skinned_bench()
+        emb_inputs = out["skinned"].pop("ba_window_inputs")
+        out["value_5k_x_500"] = out["skinned"]["ba_window"]["value"]      # BASELINE.json's config as written (5k points x 500 nodes x 20 keyframes), LM iters/s
+        if not args.no_cpu_baseline:
+            out["skinned"]["ba_window"]["cpu_baseline"] = cpu_baseline_embedded(*emb_inputs, out["value_5k_x_500"])
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
             cb = out["cpu_baseline"]

@@ -341,6 +341,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
     }
     if (d.sk_n > 0) hipLaunchKernelGGL((k_skin<LIN>), dim3(d.sk_nblk), b, 0, c->stream, d, d.pose[which], d.xl[which]);   // embedded mode: the skinned observations
     if (LIN && d.sk_pcg) {                                         // embedded BA window: their blocks join D / b_l / H_pp / b_p (the PCG path reads those)
+        if (d.D_op) NRS_HIP(c, hipMemcpyAsync(d.D_op, d.D, sizeof(double) * 6 * (size_t)d.n_rows, hipMemcpyDeviceToDevice, c->stream));   // (gather path: the operator's copy)
         hipLaunchKernelGGL(k_skin_rows, dim3((d.sk_nrl + SK_RPB - 1) / SK_RPB), b, 0, c->stream, d);
         hipLaunchKernelGGL(k_skin_pose, dim3((27 * d.K + BLK - 1) / BLK), b, 0, c->stream, d);
     }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLK) void k_spmv(Dev P, double lam, int it) {
         // row part: the T lanes of a row share the 6 pose components of H_pl
         const int kf = P.grp_pose[row / ROW_ALIGN];
         if (t == 0) {
-            const double* D = P.D + 6 * (size_t)row;
+            const double* D = (P.D_op ? P.D_op : P.D) + 6 * (size_t)row;
             a0 = (D[0] + lam) * ul0 + D[1] * ul1 + D[2] * ul2;
             a1 = D[1] * ul0 + (D[3] + lam) * ul1 + D[4] * ul2;
             a2 = D[2] * ul0 + D[4] * ul1 + (D[5] + lam) * ul2;

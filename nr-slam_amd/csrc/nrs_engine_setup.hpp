@@ -1137,7 +1137,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                      o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
                      o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
                      o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 4 * n), o_rq = o_op + al(8 * 8 * nblk), o_recT = o_rq + al(8 * (size_t)d.n_rows),
-                     total = o_recT + al(8 * 24 * n);
+                     o_dop = o_recT + al(8 * 24 * n), total = o_dop + (d.use_lds ? 0 : al(8 * 6 * (size_t)d.n_rows));
         DevBuf& buf = arena == &c->arena_trk ? c->nd_skin : c->dba_skin;
         NRS_TRY(c->ensure(buf, total));
         char* sb = buf.as<char>();
@@ -1162,6 +1162,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_chi = reinterpret_cast<double*>(sb + o_chi); d.sk_maxdiag = reinterpret_cast<double*>(sb + o_md);
         d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_row_q = reinterpret_cast<const int*>(sb + o_rq);
         d.sk_recT = reinterpret_cast<double*>(sb + o_recT);
+        d.D_op = d.use_lds ? nullptr : reinterpret_cast<double*>(sb + o_dop);
         d.sk_base = ba_form ? d.xl_init : nullptr;                 // (tracking form: the rows ARE the deformations, X0 + sum om x)
         e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
         e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n_in);

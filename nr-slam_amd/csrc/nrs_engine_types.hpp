@@ -193,6 +193,8 @@ struct Dev {
     double* sk_g;                    // sk_n x 4: per observation A s + B^T u_p (3 values in a 32-byte slot) of the current PCG direction u
     double* sk_opart;                // sk_nblk x 8: sums over a block's observations of B s (6: the pose rows of H u), of (B^T u_p).s (the cross term u_l.(H_lp u_p)) and of g.s (their share of w.u)
     const int* sk_row_q;             // n_rows x 2: a row's range in sk_rl_obs / sk_rl_om (empty: no observation reaches it)
+    double* D_op;                    // gather path (use_lds = 0) of an embedded problem: the rows' diagonal blocks as the lineariser left them, WITHOUT the observations'
+                                     // share k_skin_rows adds to D for the preconditioner -- k_spmv applies these (k_skin_op / the row pass apply A_o whole); null: D
     double* pk; double* pk_loc;      // evaluation packet: [0] chi2 [1] scale [2..2+world) max diag per rank, then K x 27 (H_pp, b_p)
 };
 

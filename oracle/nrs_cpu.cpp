@@ -444,6 +444,27 @@ struct Graph {
     vector<int64_t> slot_s;           // per spring: (i,i) (i,j) (j,i) (j,j)
     vector<int64_t> slot_d;           // per damper: 16 = (va, vb) row-major over the 4 vertices
     int threads = 1;
+    // embedded form (N2b; oracle/embedded_oracle.py dba_graph_embedded, SkinnedBAReprojEdges): observations of points WITHOUT a vertex.
+    // Observation i of keyframe sk_kf[i] sees the point X0_i + sum_k om_ik (x[n_ik] - P0[n_ik]) over <= 11 node copies of that keyframe
+    // (P0: the estimates the window starts from); it is a ReprojectionError edge (reprojection_error.cc:32-64: residual, information,
+    // Huber) whose Jacobian with respect to node copy n_ik is om_ik times the landmark block; its vertices are the pose and those copies.
+    static constexpr int SKN = 11, SKV = SKN + 2;
+    int n_sk = 0;
+    const int32_t* sk_kf = nullptr; const int32_t* sk_node = nullptr;   // n_sk ; n_sk x 11, -1 pads
+    const double* sk_om = nullptr;                                      // n_sk x 11
+    vector<double> sk_uv, sk_X0, P0;                                     // 2 n_sk, 3 n_sk, 3 M
+    vector<int32_t> slot_k;           // per skinned observation: (v1, v2) row-major over its SKV vertices (pose halves a, c, then the node copies), -1: absent
+
+    void sk_world(int i, double* o) const {                             // (sequential over the nodes, then X0 + d: as SkinnedBAReprojEdges.world)
+        double d[3] = {0, 0, 0};
+        for (int k = 0; k < SKN; ++k) {
+            const int nk = sk_node[SKN * (size_t)i + k];
+            if (nk < 0) continue;
+            const double om = sk_om[SKN * (size_t)i + k];
+            for (int a = 0; a < 3; ++a) d[a] += om * (x[3 * (size_t)nk + a] - P0[3 * (size_t)nk + a]);
+        }
+        for (int a = 0; a < 3; ++a) o[a] = sk_X0[3 * (size_t)i + a] + d[a];
+    }
 
     double chi2() const {
         double chi = 0;
@@ -481,6 +502,19 @@ struct Graph {
             huber(info_spatial * e, delta_spatial, rho0, rho1);
             chi += rho0;
         }
+#pragma omp parallel for reduction(+ : chi) schedule(static) num_threads(threads)
+        for (int i = 0; i < n_sk; ++i) {
+            const Pose& T = pose[sk_kf[i]];
+            double xw[3], pc[3];
+            sk_world(i, xw);
+            quat_rotate(T.q, xw, pc);
+            float u, v;
+            project_f32(model, prm, (float)(pc[0] + T.t[0]), (float)(pc[1] + T.t[1]), (float)(pc[2] + T.t[2]), u, v);
+            const double r0 = sk_uv[2 * (size_t)i] - (double)u, r1 = sk_uv[2 * (size_t)i + 1] - (double)v;
+            double rho0, rho1;
+            huber(info_reproj * (r0 * r0 + r1 * r1), delta_reproj, rho0, rho1);
+            chi += rho0;
+        }
         return chi;
     }
 
@@ -507,6 +541,15 @@ struct Graph {
             int v[4];
             for (int k = 0; k < 4; ++k) v[k] = P(2 * K + dm_idx[4 * (size_t)s + k]);
             for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) pr.emplace_back(v[p], v[q]);
+        }
+        auto sk_verts = [&](int i, int* v) {                        // the vertices of a skinned observation in the permuted order, -1: absent
+            v[0] = P(2 * sk_kf[i]); v[1] = P(2 * sk_kf[i] + 1);
+            for (int k = 0; k < SKN; ++k) { const int nk = sk_node[SKN * (size_t)i + k]; v[2 + k] = nk < 0 ? -1 : P(2 * K + nk); }
+        };
+        for (int i = 0; i < n_sk; ++i) {
+            int v[SKV];
+            sk_verts(i, v);
+            for (int p = 0; p < SKV; ++p) for (int q = 0; q < SKV; ++q) if (v[p] >= 0 && v[q] >= 0) pr.emplace_back(v[p], v[q]);
         }
         std::sort(pr.begin(), pr.end());
         pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
@@ -537,6 +580,14 @@ struct Graph {
             int v[4];
             for (int k = 0; k < 4; ++k) v[k] = P(2 * K + dm_idx[4 * (size_t)s + k]);
             for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) slot_d[16 * (size_t)s + 4 * p + q] = H.find(v[p], v[q]);
+        }
+        slot_k.assign((size_t)SKV * SKV * n_sk, -1);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < n_sk; ++i) {
+            int v[SKV];
+            sk_verts(i, v);
+            for (int p = 0; p < SKV; ++p) for (int q = 0; q < SKV; ++q)
+                if (v[p] >= 0 && v[q] >= 0) slot_k[((size_t)i * SKV + p) * SKV + q] = (int32_t)H.find(v[p], v[q]);
         }
         b.assign(3 * (size_t)nb, 0.0);
     }
@@ -653,6 +704,62 @@ struct Graph {
                 const int bv = pinv[2 * K + v[p]];
                 for (int k = 0; k < 3; ++k) b[3 * (size_t)bv + k] -= sg[p] * w * wi * r[k];
             }
+        }
+        // skinned observations (embedded form): J_pose as above, J_node_k = om_k J_l.  An observation touches its keyframe's pose and node
+        // copies only, so the keyframes are added in parallel (each in observation order: fixed sums)
+        if (n_sk > 0) {
+            vector<int> kf_ptr(K + 1, 0);
+            for (int i = 0; i < n_sk; ++i) kf_ptr[sk_kf[i] + 1]++;
+            for (int k = 0; k < K; ++k) kf_ptr[k + 1] += kf_ptr[k];
+            vector<int> kf_obs(n_sk), fill(kf_ptr.begin(), kf_ptr.end() - 1);
+            for (int i = 0; i < n_sk; ++i) kf_obs[fill[sk_kf[i]]++] = i;
+            vector<double> chi_k(K, 0.0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+            for (int k = 0; k < K; ++k) {
+                const Pose& T = pose[k];
+                const double* R = &Rk[9 * (size_t)k];
+                for (int e = kf_ptr[k]; e < kf_ptr[k + 1]; ++e) {
+                    const int i = kf_obs[e];
+                    double xw[3], pc[3];
+                    sk_world(i, xw);
+                    quat_rotate(T.q, xw, pc);
+                    const double px = pc[0] + T.t[0], py = pc[1] + T.t[1], pz = pc[2] + T.t[2];
+                    float u, v, Jf[6];
+                    project_f32(model, prm, (float)px, (float)py, (float)pz, u, v);
+                    projjac_f32(model, prm, (float)px, (float)py, (float)pz, Jf);
+                    const double r[2] = {sk_uv[2 * (size_t)i] - (double)u, sk_uv[2 * (size_t)i + 1] - (double)v};
+                    double rho0, rho1;
+                    huber(info_reproj * (r[0] * r[0] + r[1] * r[1]), delta_reproj, rho0, rho1);
+                    chi_k[k] += rho0;
+                    const double w = rho1 * info_reproj;
+                    double J[SKV][6];                                  // per vertex: 2 x 3, row-major
+                    double Jl[6];
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
+                        J[0][3 * rr] = -j1 * pz + j2 * py; J[0][3 * rr + 1] = j0 * pz - j2 * px; J[0][3 * rr + 2] = -j0 * py + j1 * px;
+                        J[1][3 * rr] = j0; J[1][3 * rr + 1] = j1; J[1][3 * rr + 2] = j2;
+                        Jl[3 * rr] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+                        Jl[3 * rr + 1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+                        Jl[3 * rr + 2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+                    }
+                    int vb[SKV];
+                    vb[0] = pinv[2 * k]; vb[1] = pinv[2 * k + 1];
+                    for (int q = 0; q < SKN; ++q) {
+                        const int nk = sk_node[SKN * (size_t)i + q];
+                        vb[2 + q] = nk < 0 ? -1 : pinv[2 * K + nk];
+                        const double om = nk < 0 ? 0.0 : sk_om[SKN * (size_t)i + q];
+                        for (int c = 0; c < 6; ++c) J[2 + q][c] = om * Jl[c];
+                    }
+                    const int32_t* sl = &slot_k[(size_t)i * SKV * SKV];
+                    for (int p = 0; p < SKV; ++p) {
+                        if (vb[p] < 0) continue;
+                        for (int q = 0; q < SKV; ++q)
+                            if (vb[q] >= 0) add_outer(&H.val[9 * (size_t)sl[p * SKV + q]], J[p], J[q], 2, w);
+                        for (int c = 0; c < 3; ++c) b[3 * (size_t)vb[p] + c] -= w * (J[p][c] * r[0] + J[p][3 + c] * r[1]);
+                    }
+                }
+            }
+            for (int k = 0; k < K; ++k) chi += chi_k[k];
         }
         return chi;
     }
@@ -985,11 +1092,13 @@ int nrs_cpu_block_cholesky_solve(int32_t nb, int32_t n_blocks, const int32_t* br
 // solver: 0 = sparse block Cholesky (reference-equivalent), 1 = block-Jacobi PCG to pcg_rtol, 2 = the same PCG on the
 // pose-eliminated (Schur) landmark system -- a measurement variant (natural block order: poses first).
 // max_trials_total > 0 stops after that many LM trials (bounded timing samples on large windows).
-int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
+struct SkinIn { int32_t n; const int32_t* kf; const float* uv; const float* xyz; const int32_t* node; const double* omega; };
+static int dba_solve_impl(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
                       const int32_t* lm_kf, const float* lm_uv, int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
                       int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale, int32_t iters,
                       int32_t solver, double pcg_rtol, int32_t threads, int32_t max_trials_total,
-                      Trial* trace, int32_t trace_cap, int32_t* trace_n, double* lm_xyz64, Stats* st) {
+                      Trial* trace, int32_t trace_cap, int32_t* trace_n, double* lm_xyz64, Stats* st,
+                      const SkinIn* sk, double* sk_xyz64) {
     const double t_begin = now_s();
     Graph G;
     G.model = model;
@@ -1013,6 +1122,15 @@ int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* pos
     G.lm_kf = lm_kf;
     G.n_sp = n_sp; G.sp_ij = sp_ij; G.sp_d0 = sp_d0;
     G.n_dm = n_dm; G.dm_idx = dm_idx; G.dm_w = dm_w;
+    if (sk && sk->n > 0) {                                           // embedded form: the skinned observations (float inputs widened as the landmarks' are)
+        for (int64_t q = 0; q < (int64_t)Graph::SKN * sk->n; ++q) if (sk->node[q] < -1 || sk->node[q] >= n_lm) return 2;
+        for (int32_t i = 0; i < sk->n; ++i) if (sk->kf[i] < 0 || sk->kf[i] >= n_kf) return 2;
+        G.n_sk = sk->n; G.sk_kf = sk->kf; G.sk_node = sk->node; G.sk_om = sk->omega;
+        G.sk_uv.resize(2 * (size_t)sk->n); G.sk_X0.resize(3 * (size_t)sk->n);
+        for (size_t i = 0; i < G.sk_uv.size(); ++i) G.sk_uv[i] = (double)sk->uv[i];
+        for (size_t i = 0; i < G.sk_X0.size(); ++i) G.sk_X0[i] = (double)sk->xyz[i];
+        G.P0 = G.x;
+    }
     {   // OPT:958-973, float arithmetic widened to double
         const float th2 = std::sqrt(5.99f), th3 = std::sqrt(0.584f);
         const float sigma_spatial = (float)(0.1 * (double)scale);
@@ -1122,12 +1240,36 @@ int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* pos
     }
     for (size_t i = 0; i < G.x.size(); ++i) lm_xyz[i] = (float)G.x[i];              // OPT:1158
     if (lm_xyz64) std::memcpy(lm_xyz64, G.x.data(), sizeof(double) * G.x.size());
+    if (sk_xyz64) for (int i = 0; i < G.n_sk; ++i) G.sk_world(i, sk_xyz64 + 3 * (size_t)i);
     if (trace_n) *trace_n = n_tr;
     S.n_trials = n_tr;
     S.n_iters = done_iters;
     S.t_total = now_s() - t_begin;
     if (st) *st = S;
     return 0;
+}
+
+int nrs_cpu_dba_solve(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
+                      const int32_t* lm_kf, const float* lm_uv, int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                      int32_t n_dm, const int32_t* dm_idx, const float* dm_w, float scale, int32_t iters,
+                      int32_t solver, double pcg_rtol, int32_t threads, int32_t max_trials_total,
+                      Trial* trace, int32_t trace_cap, int32_t* trace_n, double* lm_xyz64, Stats* st) {
+    return dba_solve_impl(model, prm, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale, iters, solver, pcg_rtol,
+                          threads, max_trials_total, trace, trace_cap, trace_n, lm_xyz64, st, nullptr, nullptr);
+}
+
+// The embedded form of the window (N2b: include/nrs.h nrs_dba_solve_embedded, oracle/embedded_oracle.py dba_solve_embedded): lm_* are the
+// node copies (the vertices), sk_* the observations of the points without a vertex -- keyframe, keypoint, position at the start,
+// <= 11 node copies (-1 pads) with their normalised weights.  sk_xyz64 (out, may be NULL): the skinned points at the final estimate.
+int nrs_cpu_dba_solve_embedded(int32_t model, const float* prm, int32_t n_kf, double* poses_qt, int32_t n_lm, float* lm_xyz,
+                               const int32_t* lm_kf, const float* lm_uv, int32_t n_sp, const int32_t* sp_ij, const float* sp_d0,
+                               int32_t n_dm, const int32_t* dm_idx, const float* dm_w,
+                               int32_t n_skin, const int32_t* sk_kf, const float* sk_uv, const float* sk_xyz, const int32_t* sk_node, const double* sk_omega,
+                               float scale, int32_t iters, int32_t solver, double pcg_rtol, int32_t threads, int32_t max_trials_total,
+                               Trial* trace, int32_t trace_cap, int32_t* trace_n, double* lm_xyz64, double* sk_xyz64, Stats* st) {
+    const SkinIn sk{n_skin, sk_kf, sk_uv, sk_xyz, sk_node, sk_omega};
+    return dba_solve_impl(model, prm, n_kf, poses_qt, n_lm, lm_xyz, lm_kf, lm_uv, n_sp, sp_ij, sp_d0, n_dm, dm_idx, dm_w, scale, iters, solver, pcg_rtol,
+                          threads, max_trials_total, trace, trace_cap, trace_n, lm_xyz64, st, &sk, sk_xyz64);
 }
 
 // a1: CameraPoseOptimization (g2o_optimization.cc:50-146).  uv n x 2, X n x 3 (float, as the boundary hands them over),

@@ -79,6 +79,37 @@ def dba_solve(model, prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, 
     return qt[:, :4].copy(), qt[:, 4:].copy(), x64, trace, stats
 
 
+def dba_solve_embedded(model, prm, poses_q, poses_t, lm_xyz, lm_kf, lm_uv, sp_ij, sp_d0, dm_idx, dm_w, sk_kf, sk_uv, sk_xyz, sk_node, sk_omega,
+                       scale, iters=5, solver=0, pcg_rtol=1e-10, threads=1, max_trials=0, lib=None):
+    """the embedded form of the window (oracle/embedded_oracle.py dba_solve_embedded): returns (poses_q, poses_t, node copies fp64,
+    skinned positions fp64, trace list, stats dict)"""
+    lib = lib or load()
+    p8 = np.zeros(8, np.float32)
+    p8[:len(prm)] = np.asarray(prm, np.float32)
+    qt = np.ascontiguousarray(np.concatenate([np.asarray(poses_q, np.float64), np.asarray(poses_t, np.float64)], 1))
+    xyz = np.ascontiguousarray(lm_xyz, np.float32).copy()
+    kf, uv = np.ascontiguousarray(lm_kf, np.int32), np.ascontiguousarray(lm_uv, np.float32)
+    sp, d0 = np.ascontiguousarray(sp_ij, np.int32).reshape(-1, 2), np.ascontiguousarray(sp_d0, np.float32)
+    dm, dw = np.ascontiguousarray(dm_idx, np.int32).reshape(-1, 4), np.ascontiguousarray(dm_w, np.float32)
+    skf, suv, sx = np.ascontiguousarray(sk_kf, np.int32), np.ascontiguousarray(sk_uv, np.float32), np.ascontiguousarray(sk_xyz, np.float32)
+    snode, som = np.ascontiguousarray(sk_node, np.int32).reshape(-1, 11), np.ascontiguousarray(sk_omega, np.float64).reshape(-1, 11)
+    tr = (Trial * 256)()
+    ntr = C.c_int32(0)
+    x64, s64 = np.zeros((len(xyz), 3), np.float64), np.zeros((len(skf), 3), np.float64)
+    st = Stats()
+    rc = lib.nrs_cpu_dba_solve_embedded(C.c_int32(int(model)), _p(p8, C.c_float), C.c_int32(len(qt)), _p(qt, C.c_double), C.c_int32(len(xyz)),
+                                        _p(xyz, C.c_float), _p(kf, C.c_int32), _p(uv, C.c_float), C.c_int32(len(sp)), _p(sp, C.c_int32),
+                                        _p(d0, C.c_float), C.c_int32(len(dm)), _p(dm, C.c_int32), _p(dw, C.c_float),
+                                        C.c_int32(len(skf)), _p(skf, C.c_int32), _p(suv, C.c_float), _p(sx, C.c_float), _p(snode, C.c_int32), _p(som, C.c_double),
+                                        C.c_float(scale), C.c_int32(iters), C.c_int32(solver), C.c_double(pcg_rtol), C.c_int32(threads), C.c_int32(max_trials),
+                                        tr, C.c_int32(256), C.byref(ntr), _p(x64, C.c_double), _p(s64, C.c_double), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("nrs_cpu_dba_solve_embedded failed: %d" % rc)
+    trace = [dict(iter=t.iter, trial=t.trial, accepted=bool(t.accepted), ok=bool(t.ok), inner=t.inner, lam=t.lam, chi=t.chi,
+                  chi_new=t.chi_new, rho=t.rho) for t in tr[:min(ntr.value, 256)]]
+    return qt[:, :4].copy(), qt[:, 4:].copy(), x64, s64, trace, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+
 def max_threads(lib=None):
     return (lib or load()).nrs_cpu_max_threads()
 

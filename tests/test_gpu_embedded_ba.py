@@ -192,3 +192,25 @@ def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, e
     assert np.allclose(xyz[g["sel"]], g["out_pts_sel"], atol=1e-4, rtol=0) and np.allclose(sk[g["ssel"]], g["out_sk_sel"], atol=1e-4, rtol=0)
     assert np.allclose(xyz.sum(0), g["out_pts_sum"], atol=1e-4 * np.sqrt(len(xyz)), rtol=0)
     assert np.allclose(sk.sum(0), g["out_sk_sum"], atol=1e-4 * np.sqrt(len(sk)), rtol=0)
+
+
+def test_gather_path_applies_the_observations_diagonal_blocks_once(ctx_exact, monkeypatch):
+    """on the stored-block operator (use_lds = 0: NRS_NO_LDS, an irregular graph whose halo does not fit the LDS) the
+    skinned observations' diagonal blocks sat in D (for the preconditioner) AND were applied by k_skin_op / the row pass -- H u counted
+    them twice and the PCG converged to another system's solution.  The operator now reads the lineariser's own D (Dev::D_op): the
+    gather path is held to the oracle like the LDS path, and to the LDS path's own result."""
+    p, e, w, cam, qt = _setup(300, 4, 40, 57)
+    tl = nrs.Trace()
+    pl, xl, sl = ctx_exact.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tl)
+    monkeypatch.setenv("NRS_NO_LDS", "1")
+    tg = nrs.Trace()
+    pg, xg, sg = ctx_exact.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tg)
+    monkeypatch.delenv("NRS_NO_LDS")
+    otr = []
+    oq, ot, opts, osk, nit = _oracle(p, e, w, 5, otr)
+    assert tg.iterations == nit and [t["accepted"] for t in tg.trials] == [t["accepted"] for t in otr]
+    for a, b in zip(tg.trials, otr):
+        assert abs(a["lam"] - b["lam"]) <= 1e-6 * b["lam"] and abs(a["chi"] - b["chi"]) <= 1e-6 * b["chi"] and abs(a["chi_new"] - b["chi_new"]) <= 1e-6 * b["chi_new"]
+    assert np.allclose(pg[:, :4], oq, atol=1e-6, rtol=0) and np.allclose(pg[:, 4:], ot, atol=1e-5, rtol=0)
+    assert np.allclose(xg, opts, atol=1e-4, rtol=0) and np.allclose(sg, osk, atol=1e-4, rtol=0)
+    assert np.allclose(xg, xl, atol=1e-6, rtol=0) and np.allclose(sg, sl, atol=1e-6, rtol=0)

@@ -80,3 +80,45 @@ def test_cpp_restatement_matches_c2_golden(cpu_lib):
         assert abs(a["lam"] - lam) <= 1e-6 * lam and abs(a["chi"] - chi) <= 1e-6 * chi and abs(a["chi_new"] - chi_new) <= 1e-6 * chi_new
     assert np.allclose(q, g["out_q"], atol=1e-6, rtol=0) and np.allclose(t, g["out_t"], atol=1e-5, rtol=0)
     assert np.allclose(x[g["sel"]], g["out_pts_sel"], atol=1e-4, rtol=0)
+
+
+# ---- N2b: the embedded form of the window (oracle/nrs_cpu.cpp nrs_cpu_dba_solve_embedded) against oracle/embedded_oracle.py
+def _embedded(p, n_nodes):
+    import embedded_oracle as E
+    flag = S.pick_nodes(p["scene"]["X0"], n_nodes) if n_nodes else np.ones(p["n_points"], np.uint8)
+    nb = S.node_lists(p["scene"]["X0"], p["scene"]["sigma"], flag)
+    e = E.dba_build_embedded(p["kf_points"], flag, nb["rowptr"], nb["col"], nb["w"], nb["d0"], nb["status"])
+    return E, e, S.embedded_window(p, e)
+
+
+def test_cpp_embedded_window_with_every_point_a_node_is_the_plain_window_bit_for_bit(cpu_lib):
+    p = S.make_dba_problem(90, 3, 5)
+    E, e, w = _embedded(p, 0)
+    assert len(e["sk_obs"]) == 0
+    for solver in (0, 1):
+        a = CPU.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"],
+                                   w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], 5, solver, 1e-11, 1, 0, cpu_lib)
+        b = CPU.dba_solve(p["model"], p["prm"], p["poses_q"], p["poses_t"], p["lm_xyz"], p["lm_kf"], p["lm_uv"], e["sp_ij"], e["sp_d0"], e["dm_idx"], e["dm_w"],
+                          p["scale"], 5, solver, 1e-11, 1, 0, cpu_lib)       # (one thread: the OpenMP reductions of chi2 are order-dependent)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[3]
+
+
+@pytest.mark.parametrize("n,m,k,seed,model", [(300, 40, 4, 9, S.PINHOLE), (400, 60, 5, 14, S.KB8), (500, 70, 6, 15, S.PINHOLE)])
+def test_cpp_embedded_window_matches_numpy_oracle(cpu_lib, n, m, k, seed, model):
+    """identical LM decisions, lambda / chi2 of every trial, poses, node copies and skinned points: the sparse Cholesky to 1e-10, the PCG variant to 1e-7"""
+    p = S.make_dba_problem(n, k, seed, model)
+    E, e, w = _embedded(p, m)
+    assert len(e["sk_obs"]) > 0.6 * len(p["lm_kf"])
+    otr = []
+    oq, ot, ox, osk, nit = E.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                                e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], 5, otr)
+    for solver, tol in ((0, 1e-10), (1, 1e-7)):
+        q, t, x, sk, tr, st = CPU.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                                     e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], 5,
+                                                     solver, 1e-11, 2, 0, cpu_lib)
+        assert st["n_iters"] == nit and [a["accepted"] for a in tr] == [b["accepted"] for b in otr]
+        for a, b in zip(tr, otr):
+            assert abs(a["lam"] - b["lam"]) <= max(tol, 1e-9) * b["lam"]
+            assert abs(a["chi"] - b["chi"]) <= tol * b["chi"] and abs(a["chi_new"] - b["chi_new"]) <= tol * b["chi_new"]
+        assert np.allclose(q, oq, atol=tol, rtol=0) and np.allclose(t, ot, atol=10 * tol, rtol=0)
+        assert np.allclose(x, ox, atol=100 * tol, rtol=0) and np.allclose(sk, osk, atol=100 * tol, rtol=0)
