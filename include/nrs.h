@@ -60,7 +60,8 @@ typedef struct {
  /* nrs_options grows at its END only and says how long the caller's version of it is: nrs_create reads struct_size bytes and takes
  * the defaults for everything behind them, so a binding compiled against an older header keeps working.  Fill it with
  * nrs_options_init() (device = -1, everything else 0 = default, struct_size = sizeof) or set struct_size = sizeof(nrs_options) by
- * hand; struct_size = 0 is read as the first published layout (fields up to exact_trials, 32 bytes). */
+ * hand; struct_size = 0 is read as the first published layout (fields up to exact_trials, 32 bytes) -- a caller that does not use
+ * nrs_options_init MUST set struct_size or zero the whole struct: a value larger than 4096 is rejected as garbage (NRS_ERR_INVALID). */
 typedef struct {
     int32_t device;           /* HIP device ordinal; -1 = current device                         */
     uint32_t struct_size;     /* sizeof(nrs_options) as the CALLER was compiled (sits where the layout had padding) */
@@ -87,6 +88,19 @@ typedef struct {
                                  single-frame structure; 2: always
                                  PCG.  Same LM iterates either way (both are held to the oracle).  BA windows always
                                  use PCG.  Values outside 0..2 are read as 0. */
+    int32_t embedded_solver;  /* linear solver of the EMBEDDED BA windows (nrs_dba_*_embedded):
+                                 the system of an embedded window is block tridiagonal over the keyframes -- dense keyframe
+                                 blocks (node copies + pose, coupled through the skinned observations), sparse damper
+                                 couplings -- and can be factorised EXACTLY per LM trial (what LinearSolverEigen does for the
+                                 reference, linear_solver_eigen.h:92-173): the keyframe blocks are inverted on the matrix
+                                 cores along two elimination chains, and the factorisation preconditions the PCG, which then
+                                 converges to pcg_rtol in one or two iterations (csrc/nrs_engine_kft.hpp).
+                                 0 (default): that solver when a keyframe block has at most 1280 unknowns (~ 420 nodes per
+                                 keyframe: there it is 1.2 .. 4 x faster than the PCG), block-Jacobi PCG beyond;
+                                 1: always the factorisation (if its K x (3 nodes + 6)^2 x 8 bytes fit 6 GB);
+                                 2: always block-Jacobi PCG (hundreds of iterations per trial).  Same LM iterates either
+                                 way.  Plain (every point a node) and sharded windows use the block-Jacobi PCG.
+                                 (Sits where the 40-byte layout had padding: values outside 0..2 are read as 0.) */
 } nrs_options;
 void nrs_options_init(nrs_options* opt);
 
@@ -224,6 +238,14 @@ int nrs_dba_download(nrs_ctx* ctx, double* poses_qt, double* lm_xyz /* n_lm x 3,
 int nrs_dba_residuals(nrs_ctx* ctx, double* r_reproj /* n_lm x 2 */, double* r_spring /* n_spring */,
                       double* r_damper /* n_damper x 3 */);
 int nrs_dba_gradient(nrs_ctx* ctx, double* b /* 6 n_kf + 3 n_lm */, double* diag /* same size */);
+/* Parity tap of the embedded window's keyframe-block factorisation (nrs_options.embedded_solver = 0; csrc/nrs_engine_kft.hpp) on the resident
+ * window, linearised at the current estimate with damping lam:
+ *   what 0  out_i[0..6) = {in use, keyframes K, block dimension ld, ld / 64, middle keyframe, factor MiB}, then K free-node counts, K pose sizes (6 / 0)
+ *   what 1  out_d = the assembled diagonal block of keyframe k (ld x ld: its free node copies in row order, then its pose)
+ *   what 2  out_d = the coupling of keyframes k and k + 1 as a dense ld x ld matrix (rows: k)
+ *   what 3  out_d = M^-1 in_d, both in solver order (6 per pose, then 3 per node copy): the factorisation applied as the PCG applies it
+ *   what 4  out_i = per node copy its (keyframe, compact index) pair, -1: fixed */
+int nrs_debug_kft(nrs_ctx* ctx, double lam, int32_t what, int32_t k, const double* in_d, double* out_d, int32_t* out_i);
 
 /* Parity tap of the problem construction (edge lists -> row layout, sliced-ELL incidence streams, halo lists, chi2 edge lists;
  * g2o_optimization.cc:927-1137 ends where this starts): FNV-1a checksums of every packed array of the resident problem,

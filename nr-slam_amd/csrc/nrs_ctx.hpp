@@ -57,6 +57,7 @@ struct nrs_ctx {
     unsigned long long tap_serial = 0, engine_serial = 0;
     nrs::DevBuf pack_ws, pack_ws2, pack_ws3, pack_ws4;   // device-side problem construction (nrs_engine_devpack.hpp): raw inputs + intermediates
     nrs::DevBuf dba_skin;            // ... and of the resident BA window (N2b)
+    nrs::DevBuf dba_kft;             // embedded BA window: the keyframe-block factorisation (nrs_engine_kft.hpp)
     nrs::DevBuf nd_skin;             // embedded mode (nrs_engine_skin.hpp): the skinned observations of the tracking engine
     void* nd_cache = nullptr;        // direct solver of the tracking engines (nrs_engine_nd.hpp NdCache): the last few plans with their device arrays
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload

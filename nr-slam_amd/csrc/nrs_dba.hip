@@ -295,6 +295,14 @@ extern "C" int nrs_dba_gradient(nrs_ctx* c, double* b, double* diag) {
     return engine_gradient(c, c->dba, b, diag);
 }
 
+extern "C" int nrs_debug_kft(nrs_ctx* c, double lam, int32_t what, int32_t k, const double* in_d, double* out_d, int32_t* out_i) {
+    if (!c) return NRS_ERR_INVALID;
+    if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");
+    if ((what == 0 || what == 4) ? !out_i : !out_d) return c->fail(NRS_ERR_INVALID, "null output");
+    if (what == 3 && !in_d) return c->fail(NRS_ERR_INVALID, "null input");
+    return engine_kft_debug(c, c->dba, lam, what, k, in_d, out_d, out_i);
+}
+
 extern "C" int nrs_dba_pack_hash(nrs_ctx* c, uint64_t* out) {
     if (!c) return NRS_ERR_INVALID;
     if (!c->dba) return c->fail(NRS_ERR_STATE, "no BA problem uploaded");

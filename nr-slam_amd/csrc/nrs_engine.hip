@@ -56,7 +56,9 @@
 #include "nrs_engine_pcg.hpp"
 #include "nrs_engine_skin.hpp"
 #include "nrs_engine_nd.hpp"
+#include "nrs_engine_kft.hpp"
 #include "nrs_engine_setup.hpp"
+#include "nrs_engine_kft_setup.hpp"
 #include "nrs_engine_devpack.hpp"
 
 namespace nrs {
@@ -400,6 +402,10 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     NRS_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int) * 8, c->stream));
     if (d.coarse) hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(BLK), sizeof(double) * (size_t)d.co_n * d.co_n, c->stream, d, lam);
     hipLaunchKernelGGL(k_trial_setup, dim3(d.sh_nvb), dim3(BLK), 0, c->stream, d, lam);
+    if (e->kft && e->kft->on) {                                    // embedded BA window: factorise H + lambda I by keyframe blocks, u_0 = M^-1 b
+        NRS_TRY(kft_factor(c, e, e->kft, lam));
+        NRS_TRY(kft_apply(c, e->kft, d.rv, d.rp, d.uv3, d.up, d.flags));
+    }
     *it = 0;
     return NRS_OK;
 }
@@ -583,6 +589,8 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             else hipLaunchKernelGGL(k_pcg_update<false>, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
                                     d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
         }
+        if (e->kft && e->kft->on)                                  // u = M^-1 r over the keyframe chains (the update left the block-Jacobi u: overwritten)
+            NRS_TRY(kft_apply(c, e->kft, d.rv, (it & 1) ? d.rp : d.rp2, d.uv3, (it & 1) ? d.up : d.up2, d.flags));
     }
     *it_io = it;
     return NRS_OK;
@@ -979,3 +987,5 @@ int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double*
 }
 
 }  // namespace nrs
+
+#include "nrs_engine_kft_debug.hpp"

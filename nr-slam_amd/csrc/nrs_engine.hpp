@@ -87,6 +87,7 @@ int engine_debug_solve(nrs_ctx* c, Engine* e, const double* Hpp21, const double*
 // parity tap of the direct (nested-dissection) solver on an explicit block system: include/nrs.h nrs_debug_nd_solve
 int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint8_t* last, int n_pairs, const int* pairs, const double* Dn, const double* Vp,
                           const double* bn, double lam, int repeats, double* x, int64_t* stats, double* ms_per_solve);
+int engine_kft_debug(nrs_ctx* c, Engine* e, double lam, int what, int k, const double* in_d, double* out_d, int32_t* out_i);   // include/nrs.h nrs_debug_kft
 void nd_cache_stats(nrs_ctx* c, int64_t out[2]);                   // plans reused / built by the direct solver's cache
 void arena_release(Arena* a);
 void engine_stats(const Engine* e, int64_t stats[5]);              // rows, rows packed here, spring / damper incidence slots, device bytes

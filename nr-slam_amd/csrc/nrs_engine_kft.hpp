@@ -1,0 +1,552 @@
+// Keyframe-block direct solve of an EMBEDDED BA window (N2b, BASELINE configs[1] as written: points x graph nodes x keyframes).
+// Part of nrs_engine.hip (one translation unit).
+//
+// What it replaces: g2o's exact linear solve per LM trial (reference third_party/g2o/g2o/solvers/eigen/linear_solver_eigen.h:92-173,
+// block_solver.hpp:329-341) for LocalDeformableBundleAdjustment (modules/optimization/g2o_optimization.cc:880-1161) in the embedded form.
+// The block-Jacobi PCG needs 110 .. 1000 iterations per LM trial on that window (2371 per optimize(5) at 5000 x 500 x 20): a keyframe's
+// node copies are coupled densely through the shared skinned observations, and the depth components -- which a single view does not
+// constrain -- are held by the temporal dampers only (profiles/r06_embedded_ba_precond_probe.txt: exact keyframe blocks alone still need
+// 28 .. 306 iterations, per-node temporal blocks more than block-Jacobi).  The structure that IS exact:
+//
+//     H + lambda I  =  block tridiagonal over the keyframes,
+//         diagonal block  A_k : the node copies of keyframe k and its pose -- dense (1.4k x 1.4k at 458 nodes): reprojection edges of the
+//                               node copies, the skinned observations' hyper-edges (<= 11 node copies + the pose each), springs
+//                               (OPT:1031-1072) and the same-keyframe halves of the dampers
+//         coupling        T_k : keyframe k x keyframe k + 1 -- SPARSE: a damper (1c, 2c, 1n, 2n) (spatial_regularizer.cc:32-59, OPT:1076-1132)
+//                               couples copies of two map points in consecutive keyframes, every block +- s I_3.
+//
+// Block elimination from BOTH ends of the window towards the middle keyframe m ("twisted"): two chains of K / 2 dependent steps
+//     S_0 = A_0,  S_k = A_k - T_{k-1}^T G_{k-1} T_{k-1},   G_k = S_k^-1      (and mirrored from K - 1 down to m + 1; S_m takes both)
+// with G_k formed EXPLICITLY by a blocked symmetric sweep (Gauss-Jordan on 64 x 64 pivot blocks: panel on the vector units, the rank-64
+// trailing update on v_mfma_f64_16x16x4) -- so that a solve is a chain of dense matrix-vector products instead of triangular sweeps --
+// and the Schur update is sparse x dense x sparse.  20 inversions of 1.4k x 1.4k = 53 GFLOP per LM trial.  The factorisation serves as
+// the PRECONDITIONER of the engine's PCG (u = M^-1 r by one forward and one backward pass over the chains): M is H + lambda I up to the
+// rounding of the explicit inverses, so the PCG converges in two or three iterations to the same pcg_rtol as before -- same LM iterates.
+// Fixed-order sums throughout (no atomics): bit-reproducible.
+#pragma once
+
+namespace nrs {
+
+constexpr int KFT_B = 64;            // pivot block / tile of the sweeps
+
+struct KftDev {
+    int K, ld, nb, m, nfm;           // keyframes; padded block dimension (multiple of KFT_B); ld / KFT_B; middle keyframe; ld / 3 (stride of the per-node tables)
+    double* A;                       // K x ld x ld: A_k, then S_k, then G_k in place (full symmetric squares; rows / columns >= n_k: identity)
+    double* YT;                      // 2 x ld x ld: per chain (G_f C^T)^T of the Schur update
+    double* Bb; double* Cb;          // 2 x nb x 64 x 64: panels of a sweep step, packed [k / 4][row][k % 4] (what the matrix-core operands read)
+    double* Pv;                      // 2 x 64 x 64: the swept pivot block (- P^-1)
+    double* z; double* xs;           // K x ld: G_k y_k of the forward pass; the solution (compact order) for the backward pass
+    double* vb;                      // 2 x ld: the right-hand side of a solve stage (per chain)
+    const int* kf_nf; const int* kf_np;   // K: free node rows of a keyframe; 6 if its pose is free, else 0
+    const int* kf_row;               // K x nfm: compact node -> row
+    const int* row_ci;               // n_rows: row -> compact node of its keyframe (-1: fixed / padding)
+    // diagonal-block assembly: the unique same-keyframe node pairs (hi > lo) with their contributions
+    int n_pp;
+    const uint32_t* pp_id;           // k << 24 | hi << 12 | lo
+    const int* pp_ptr;               // n_pp + 1
+    const uint32_t* pe_src;          // type << 30 | index: 0 spring (s_qc slot), 1 damper (d_s slot), 2 skinned observation (slot)
+    const double* pe_w;              // skinned: om_hi om_lo
+    // temporal couplings: unique pairs (a in keyframe k, b in keyframe k + 1), t = sum +- s
+    int n_tp;
+    const int* tp_ptr;               // n_tp + 1
+    const uint32_t* te_src;          // sign << 31 | d_s slot
+    double* tp_val;
+    // coupling lists by the 'to' node, dir 0: from keyframe to - 1, dir 1: from keyframe to + 1
+    const int* cl_ptr[2];            // K x (nfm + 1)
+    const int* cl_from[2]; const int* cl_tp[2];
+    double* cl_val[2];               // the lists' values (tp_val[cl_tp[.]], refreshed per linearisation: the solve's loops read them in place)
+};
+
+struct KftHost {
+    bool on = false;
+    KftDev d;
+    size_t bytes = 0;
+    int factorisations = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------ assembly
+__global__ __launch_bounds__(256) void k_kft_clear(KftDev F) {
+    const int k = blockIdx.y;
+    const size_t idx = 2 * ((size_t)blockIdx.x * 256 + threadIdx.x), n2 = (size_t)F.ld * F.ld;
+    if (idx >= n2) return;
+    const int i = (int)(idx / F.ld), j = (int)(idx % F.ld), nk = 3 * F.kf_nf[k] + F.kf_np[k];
+    double2 v = make_double2(0.0, 0.0);
+    if (i >= nk && j == i) v.x = 1.0;
+    if (i >= nk && j + 1 == i) v.y = 1.0;
+    *reinterpret_cast<double2*>(F.A + (size_t)k * n2 + idx) = v;
+}
+
+// node diagonal blocks (D + lambda: every edge's share, the skinned observations' included) and the pose-node blocks: the node copy's own
+// reprojection edge (factored form, as row_factored) + sum om B_o over the observations that reach the row (SK_RL lanes a row)
+__global__ __launch_bounds__(BLK) void k_kft_diag(Dev P, KftDev F, double lam) {
+    const int tid = threadIdx.x, r = blockIdx.x * SK_RPB + tid / SK_RL, t = tid % SK_RL;
+    const int ci = F.row_ci[r], k = P.grp_pose[r / ROW_ALIGN];
+    const int nf = F.kf_nf[k], np = F.kf_np[k];
+    double acc[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) acc[q] = 0;
+    if (ci >= 0 && np) {
+        for (int q = P.sk_row_q[2 * (size_t)r] + t; q < P.sk_row_q[2 * (size_t)r + 1]; q += SK_RL) {
+            const double om = P.sk_rl_om[q];
+            const double* rec = P.sk_rec + 27 * (size_t)P.sk_rl_obs[q] + 9;
+#pragma unroll
+            for (int j = 0; j < 18; ++j) acc[j] += om * rec[j];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 18; ++q) acc[q] = sub_sum_t<SK_RL>(acc[q]);
+    if (ci < 0 || t != 0) return;
+    double* A = F.A + (size_t)k * F.ld * F.ld;
+    const double* D = P.D + 6 * (size_t)r;
+    const size_t o = (size_t)(3 * ci) * F.ld + 3 * ci;
+    A[o] = D[0] + lam; A[o + 1] = D[1]; A[o + 2] = D[2];
+    A[o + F.ld] = D[1]; A[o + F.ld + 1] = D[3] + lam; A[o + F.ld + 2] = D[4];
+    A[o + 2 * (size_t)F.ld] = D[2]; A[o + 2 * (size_t)F.ld + 1] = D[4]; A[o + 2 * (size_t)F.ld + 2] = D[5] + lam;
+    if (!np) return;
+    const RowRec rc = P.rowrec[r];
+    if (rc.w != 0.0) {
+        const Pose Tcw = P.lin_pose[k];
+        double R[9], xs[3];
+        quat_to_R(Tcw.q, R);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) xs[a] = P.lin_xl[3 * (size_t)r + a] + (P.X0 ? P.X0[3 * (size_t)r + a] : 0.0);
+        const double px = R[0] * xs[0] + R[1] * xs[1] + R[2] * xs[2] + Tcw.t[0];
+        const double py = R[3] * xs[0] + R[4] * xs[1] + R[5] * xs[2] + Tcw.t[1];
+        const double pz = R[6] * xs[0] + R[7] * xs[1] + R[8] * xs[2] + Tcw.t[2];
+        double Jl[2][3], Jp[2][6];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const double j0 = -(double)rc.J[3 * rr], j1 = -(double)rc.J[3 * rr + 1], j2 = -(double)rc.J[3 * rr + 2];
+            Jp[rr][0] = -j1 * pz + j2 * py; Jp[rr][1] = j0 * pz - j2 * px; Jp[rr][2] = -j0 * py + j1 * px;
+            Jp[rr][3] = j0; Jp[rr][4] = j1; Jp[rr][5] = j2;
+            Jl[rr][0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+            Jl[rr][1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+            Jl[rr][2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) acc[3 * p + cc] += rc.w * (Jp[0][p] * Jl[0][cc] + Jp[1][p] * Jl[1][cc]);
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            A[(size_t)(3 * nf + p) * F.ld + 3 * ci + cc] = acc[3 * p + cc];
+            A[(size_t)(3 * ci + cc) * F.ld + 3 * nf + p] = acc[3 * p + cc];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_kft_pose(Dev P, KftDev F, double lam) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 36 * F.K) return;
+    const int k = i / 36, p = (i % 36) / 6, q = i % 6;
+    if (!F.kf_np[k]) return;
+    const int lo = p < q ? p : q, hi = p < q ? q : p;
+    const int pk = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);       // packed upper index (as k_pcg_update)
+    const int nf = F.kf_nf[k];
+    F.A[(size_t)k * F.ld * F.ld + (size_t)(3 * nf + p) * F.ld + 3 * nf + q] = P.Hpp[21 * k + pk] + (p == q ? lam : 0.0);
+}
+
+// one thread per unique same-keyframe node pair: the sum of its contributions in list order
+__global__ __launch_bounds__(256) void k_kft_pairs(Dev P, KftDev F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F.n_pp) return;
+    const uint32_t id = F.pp_id[i];
+    const int k = (int)(id >> 24), hi = (int)((id >> 12) & 0xFFFu), lo = (int)(id & 0xFFFu);
+    const size_t rh = (size_t)F.kf_row[k * F.nfm + hi], rl = (size_t)F.kf_row[k * F.nfm + lo];
+    double v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] = (P.lin_xl[3 * rh + a] + (P.X0 ? P.X0[3 * rh + a] : 0.0)) - (P.lin_xl[3 * rl + a] + (P.X0 ? P.X0[3 * rl + a] : 0.0));
+    double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = F.pp_ptr[i]; q < F.pp_ptr[i + 1]; ++q) {
+        const uint32_t src = F.pe_src[q];
+        const uint32_t type = src >> 30, idx = src & 0x3FFFFFFFu;
+        if (type == 0) {                                           // spring: - qc v v^T
+            const double qc = P.s_qc[idx];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) b[3 * a + cc] -= qc * v[a] * v[cc];
+        } else if (type == 1) {                                    // damper, the two vertices of one keyframe: - s I
+            const double s = P.d_s[idx];
+            b[0] -= s; b[4] -= s; b[8] -= s;
+        } else {                                                   // skinned observation: om_hi om_lo J_l^T w J_l
+            const double w = F.pe_w[q];
+            const double* rec = P.sk_rec + 27 * (size_t)idx;
+            b[0] += w * rec[0]; b[1] += w * rec[1]; b[2] += w * rec[2];
+            b[3] += w * rec[1]; b[4] += w * rec[3]; b[5] += w * rec[4];
+            b[6] += w * rec[2]; b[7] += w * rec[4]; b[8] += w * rec[5];
+        }
+    }
+    double* A = F.A + (size_t)k * F.ld * F.ld;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            A[(size_t)(3 * hi + a) * F.ld + 3 * lo + cc] = b[3 * a + cc];
+            A[(size_t)(3 * lo + cc) * F.ld + 3 * hi + a] = b[3 * a + cc];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_kft_tvals(Dev P, KftDev F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F.n_tp) return;
+    double t = 0;
+    for (int q = F.tp_ptr[i]; q < F.tp_ptr[i + 1]; ++q) {
+        const uint32_t src = F.te_src[q];
+        const double s = P.d_s[src & 0x7FFFFFFFu];
+        t += (src >> 31) ? -s : s;
+    }
+    F.tp_val[i] = t;
+}
+
+__global__ __launch_bounds__(256) void k_kft_clvals(KftDev F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F.n_tp) return;
+    F.cl_val[0][i] = F.tp_val[F.cl_tp[0][i]];
+    F.cl_val[1][i] = F.tp_val[F.cl_tp[1][i]];
+}
+
+// ------------------------------------------------------------------------------------------------------------------ the sweep
+// SWEEP(j) of a symmetric matrix on 64 x 64 blocks (P = A_jj):  A_jj <- -P^-1,  A_Ij <- A_Ij P^-1 (and its mirror),
+// A_IL <- A_IL - A_Ij P^-1 A_jL for I, L != j; after every block has been swept the matrix is -A^-1.  Two launches per step:
+//   k_kft_panel  (one workgroup per block row I): inverts P in registers (64 scalar sweep steps, the pivot column through LDS),
+//                B_I = C_I P^-1 on the vector units, leaves B_I in the panel (both triangles) and B_I / C_I in the packed buffers
+//   k_kft_update (one workgroup per tile): A_IL -= B_I C_L^T on the matrix cores; the tile (j, j) takes the swept pivot block
+// The final sign is taken off by the last step (k_kft_update with neg = 1 writes -A).  Both launches serve the two chains at once.
+constexpr int KFT_LDP = KFT_B + 1;
+constexpr size_t KFT_PANEL_LDS = sizeof(double) * (2 * (size_t)KFT_B * KFT_LDP + 2 * KFT_B);
+
+__global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int kf1, int* flags) {
+    extern __shared__ double sm[];
+    const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
+    if (kf < 0) return;
+    double* Ps = sm;
+    double* Cs = sm + KFT_B * KFT_LDP;
+    double* colb = sm + 2 * KFT_B * KFT_LDP;
+    const int I = blockIdx.x, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int ld = F.ld;
+    double* A = F.A + (size_t)kf * ld * ld;
+    const double* Pt = A + (size_t)(KFT_B * j) * ld + KFT_B * j;
+    double a[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) a[x][y] = Pt[(size_t)(4 * ti + x) * ld + 4 * tj + y];
+    double cI[4][4];
+    const double* Ct = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
+    if (I != j) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) cI[x][y] = Ct[(size_t)(4 * ti + x) * ld + 4 * tj + y];
+    }
+    bool bad = false;
+    // scalar SWEEP(p), p = 0 .. 63, on the 4 x 4 register blocks: with the pivot column c (= row, by symmetry) and d = c_p,
+    //   a_rc <- a_rc - c_r c_c / d  (r, c != p),  a_rp <- c_r / d,  a_pc <- c_c / d,  a_pp <- -1 / d
+    // -- all four cases are ONE expression once the pivot row / column entries are zeroed and c_p is replaced by -1 (no divergent code)
+#pragma unroll 1
+    for (int pb = 0; pb < KFT_B / 4; ++pb) {                        // (four pivots per trip: the register block's column index is a constant in every copy)
+#pragma unroll
+        for (int y0 = 0; y0 < 4; ++y0) {
+            const int p = 4 * pb + y0;
+            double* cb = colb + (y0 & 1) * KFT_B;
+            if (tj == pb) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) cb[4 * ti + x] = a[x][y0];
+            }
+            __syncthreads();
+            double d = cb[p];
+            const bool ok = d > 0.0 && d < 1e300;
+            bad = bad || !ok;
+            d = ok ? d : 1.0;
+            const double inv = 1.0 / d;
+            double cr[4], cc[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const bool rp = 4 * ti + x == p, cp = 4 * tj + x == p;
+                const double r0 = cb[4 * ti + x], c0 = cb[4 * tj + x];
+                cr[x] = rp ? -1.0 : r0;
+                cc[x] = (cp ? -1.0 : c0) * inv;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const bool piv = (4 * ti + x == p) | (4 * tj + y == p);
+                    const double a0 = piv ? 0.0 : a[x][y];
+                    a[x][y] = a0 - cr[x] * cc[y];
+                }
+        }
+    }
+    if (bad && tid == 0) flags[2] = 1;
+    const size_t tile = (size_t)KFT_B * KFT_B;
+    double* Bb = F.Bb + ((size_t)ch * F.nb + I) * tile;
+    double* Cb = F.Cb + ((size_t)ch * F.nb + I) * tile;
+    if (I == j) {                                                   // the pivot block's own row: nothing to update with it; the swept block for k_kft_update
+        double* Pv = F.Pv + (size_t)ch * tile;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                Pv[(4 * ti + x) * KFT_B + 4 * tj + y] = a[x][y];
+                Bb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = 0.0;
+                Cb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = 0.0;
+            }
+        return;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
+            Cs[(4 * ti + x) * KFT_LDP + 4 * tj + y] = cI[x][y];
+        }
+    __syncthreads();
+    double bI[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) bI[x][y] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < KFT_B; ++q) {
+        double c4[4], p4[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { c4[x] = Cs[(4 * ti + x) * KFT_LDP + q]; p4[x] = Ps[q * KFT_LDP + 4 * tj + x]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) bI[x][y] += c4[x] * p4[y];
+    }
+    double* Bt = A + (size_t)(KFT_B * I) * ld + KFT_B * j;         // A_Ij <- B_I
+    double* Btt = A + (size_t)(KFT_B * j) * ld + KFT_B * I;        // A_jI <- B_I^T
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            Bt[(size_t)(4 * ti + x) * ld + 4 * tj + y] = bI[x][y];
+            Btt[(size_t)(4 * tj + y) * ld + 4 * ti + x] = bI[x][y];
+            Bb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = bI[x][y];
+            Cb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = cI[x][y];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, int kf1, int neg) {
+    const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
+    if (kf < 0) return;
+    const int I = blockIdx.x / F.nb, L = blockIdx.x % F.nb;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ld = F.ld;
+    const size_t tile = (size_t)KFT_B * KFT_B;
+    double* At = F.A + (size_t)kf * ld * ld + (size_t)(KFT_B * I) * ld + KFT_B * L;
+    const double sgn = neg ? -1.0 : 1.0;
+    if (I == j && L == j) {
+        const double* Pv = F.Pv + (size_t)ch * tile;
+        for (int q = tid; q < KFT_B * KFT_B; q += 256) At[(size_t)(q / KFT_B) * ld + q % KFT_B] = sgn * Pv[q];
+        return;
+    }
+    if (I == j || L == j) {
+        if (neg) for (int q = tid; q < KFT_B * KFT_B; q += 256) { double* e = At + (size_t)(q / KFT_B) * ld + q % KFT_B; *e = -*e; }
+        return;
+    }
+    const double* Bb = F.Bb + ((size_t)ch * F.nb + I) * tile;
+    const double* Cb = F.Cb + ((size_t)ch * F.nb + L) * tile;
+    nd_v4d c[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c[n][g] = At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)];
+#pragma unroll 4
+    for (int kq = 0; kq < KFT_B / 4; ++kq) {
+        const double av = -Bb[((size_t)kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
+        double bv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[n] = Cb[((size_t)kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)] = sgn * c[n][g];
+}
+
+// ------------------------------------------------------------------------------------------------------------------ Schur update
+// chain 0: from keyframe f0 to f0 + 1 (dir 0); chain 1: from f1 to f1 - 1 (dir 1).  C = the coupling block (rows: 'to' nodes, columns: 'from'
+// nodes), S_to -= C G_from C^T in two passes through YT = (G_from C^T)^T (G is symmetric: every access runs along a row)
+__global__ __launch_bounds__(256) void k_kft_gct(KftDev F, int f0, int f1) {
+    const int ch = blockIdx.z, f = ch ? f1 : f0;
+    if (f < 0) return;
+    const int t = ch ? f - 1 : f + 1, dir = ch;
+    const int col = blockIdx.y, b = col / 3, comp = col % 3;
+    if (b >= F.kf_nf[t]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F.ld) return;
+    const double* G = F.A + (size_t)f * F.ld * F.ld;
+    const int* ptr = F.cl_ptr[dir] + (size_t)t * (F.nfm + 1);
+    double acc = 0;
+    for (int e = ptr[b]; e < ptr[b + 1]; ++e) acc += F.cl_val[dir][e] * G[(size_t)(3 * F.cl_from[dir][e] + comp) * F.ld + i];
+    F.YT[((size_t)ch * F.ld + col) * F.ld + i] = acc;
+}
+// one workgroup per column of S_to: the YT row in LDS, a thread per 'to' node (its three components share the list)
+__global__ __launch_bounds__(256) void k_kft_tgt(KftDev F, int f0, int f1) {
+    extern __shared__ double yrow[];
+    const int ch = blockIdx.y, f = ch ? f1 : f0;
+    if (f < 0) return;
+    const int t = ch ? f - 1 : f + 1, dir = ch;
+    const int col = blockIdx.x;
+    const int nft = F.kf_nf[t];
+    if (col >= 3 * nft) return;
+    const double* Y = F.YT + ((size_t)ch * F.ld + col) * F.ld;
+    for (int i = threadIdx.x; i < F.ld; i += 256) yrow[i] = Y[i];
+    __syncthreads();
+    const int* ptr = F.cl_ptr[dir] + (size_t)t * (F.nfm + 1);
+    double* S = F.A + (size_t)t * F.ld * F.ld + (size_t)col * F.ld;
+    for (int b = threadIdx.x; b < nft; b += 256) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int e = ptr[b]; e < ptr[b + 1]; ++e) {
+            const double v = F.cl_val[dir][e];
+            const double* y = yrow + 3 * F.cl_from[dir][e];
+            a0 += v * y[0]; a1 += v * y[1]; a2 += v * y[2];
+        }
+        S[3 * b] -= a0; S[3 * b + 1] -= a1; S[3 * b + 2] -= a2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ the solve
+// One stage = one keyframe per chain, two launches: k_kft_vec builds the right-hand side (the residual of the keyframe's unknowns and the
+// sparse coupling with the neighbour's vector, one thread per unknown), k_kft_gemv multiplies by G_k (16 rows per workgroup).
+//   mode 0: forward   z_k = G_k (r_k - C z_prev)
+//   mode 1: middle    x_m = G_m (r_m - C z_{m-1} - C' z_{m+1})
+//   mode 2: backward  x_k = z_k - G_k C x_next
+// x is scattered to the PCG's u (rows / poses).
+__global__ __launch_bounds__(256) void k_kft_vec(KftDev F, int mode, int k0, int k1, const double* __restrict__ rv, const double* __restrict__ rp,
+                                                 const int* __restrict__ flags) {
+    const int ch = blockIdx.y, k = ch ? k1 : k0;
+    if (k < 0 || flags[0]) return;                                  // (launches queued behind a converged solve are no-ops, as the PCG's own)
+    const int jx = blockIdx.x * 256 + threadIdx.x;
+    if (jx >= F.ld) return;
+    const int ld = F.ld, nf = F.kf_nf[k], np = F.kf_np[k], K = F.K;
+    // the neighbours whose vectors enter: forward -- the previous keyframe of the chain; backward -- the next towards the middle
+    int nbr[2] = {-1, -1};
+    if (mode == 0) nbr[0] = ch ? (k + 1 < K ? k + 1 : -1) : k - 1;
+    else if (mode == 2) nbr[0] = ch ? k - 1 : k + 1;
+    else { nbr[0] = k - 1; nbr[1] = k + 1 < K ? k + 1 : -1; }
+    const double* src = mode == 2 ? F.xs : F.z;
+    double v = 0;
+    if (jx < 3 * nf) {
+        const int b = jx / 3, comp = jx % 3;
+        if (mode != 2) v = rv[3 * (size_t)F.kf_row[k * F.nfm + b] + comp];
+        double s = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int o = nbr[h];
+            if (o < 0) continue;
+            const int dir = o < k ? 0 : 1;
+            const int* ptr = F.cl_ptr[dir] + (size_t)k * (F.nfm + 1);
+            const double* ov = src + (size_t)o * ld;
+            for (int e = ptr[b]; e < ptr[b + 1]; ++e) s += F.cl_val[dir][e] * ov[3 * F.cl_from[dir][e] + comp];
+        }
+        v = mode == 2 ? s : v - s;
+    } else if (jx < 3 * nf + np) {
+        if (mode != 2) v = rp[6 * k + (jx - 3 * nf)];
+    }
+    F.vb[(size_t)ch * ld + jx] = v;
+}
+
+__global__ __launch_bounds__(256) void k_kft_gemv(KftDev F, int mode, int k0, int k1, double* __restrict__ uv, double* __restrict__ up, const int* __restrict__ flags) {
+    extern __shared__ double vec[];
+    const int ch = blockIdx.y, k = ch ? k1 : k0;
+    if (k < 0 || flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ld = F.ld, nf = F.kf_nf[k], np = F.kf_np[k];
+    for (int jx = tid; jx < ld; jx += 256) vec[jx] = F.vb[(size_t)ch * ld + jx];
+    const double* G = F.A + (size_t)k * ld * ld;
+    const int row0 = blockIdx.x * 16 + 4 * w;
+    // (the rows of G are requested before the barrier: the two are independent)
+    double acc[4] = {0, 0, 0, 0};
+    __syncthreads();
+    for (int c0 = 2 * lane; c0 < ld; c0 += 128) {
+        const double v0 = vec[c0], v1 = vec[c0 + 1];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double2 g = *reinterpret_cast<const double2*>(G + (size_t)(row0 + a) * ld + c0);
+            acc[a] += g.x * v0 + g.y * v1;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = wave_sum(acc[a]);
+    if (lane < 4) {
+        const int row = row0 + lane;
+        double x = acc[0];
+#pragma unroll
+        for (int a = 1; a < 4; ++a) x = lane == a ? acc[a] : x;
+        if (mode == 0) { F.z[(size_t)k * ld + row] = x; return; }
+        if (mode == 2) x = F.z[(size_t)k * ld + row] - x;
+        F.xs[(size_t)k * ld + row] = x;
+        if (row < 3 * nf) uv[3 * (size_t)F.kf_row[k * F.nfm + row / 3] + row % 3] = x;
+        else if (row < 3 * nf + np) up[6 * k + (row - 3 * nf)] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host
+static int kft_invert(nrs_ctx* c, const KftDev& F, int kf0, int kf1, int* flags) {
+    for (int j = 0; j < F.nb; ++j) {
+        hipLaunchKernelGGL(k_kft_panel, dim3(F.nb, 2), dim3(256), KFT_PANEL_LDS, c->stream, F, j, kf0, kf1, flags);
+        hipLaunchKernelGGL(k_kft_update, dim3(F.nb * F.nb, 2), dim3(256), 0, c->stream, F, j, kf0, kf1, j + 1 == F.nb ? 1 : 0);
+    }
+    return NRS_OK;
+}
+
+// assembly of every A_k and T_k at the current linearisation (after evaluate<true>), then the two elimination chains
+static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
+    const Dev& d = e->d;
+    const KftDev& F = H->d;
+    const size_t n2 = (size_t)F.ld * F.ld;
+    hipLaunchKernelGGL(k_kft_clear, dim3((unsigned)((n2 / 2 + 255) / 256), F.K), dim3(256), 0, c->stream, F);
+    hipLaunchKernelGGL(k_kft_diag, dim3(d.n_rows / SK_RPB), dim3(BLK), 0, c->stream, d, F, lam);
+    hipLaunchKernelGGL(k_kft_pose, dim3((36 * F.K + 255) / 256), dim3(256), 0, c->stream, d, F, lam);
+    if (F.n_pp) hipLaunchKernelGGL(k_kft_pairs, dim3((F.n_pp + 255) / 256), dim3(256), 0, c->stream, d, F);
+    if (F.n_tp) {
+        hipLaunchKernelGGL(k_kft_tvals, dim3((F.n_tp + 255) / 256), dim3(256), 0, c->stream, d, F);
+        hipLaunchKernelGGL(k_kft_clvals, dim3((F.n_tp + 255) / 256), dim3(256), 0, c->stream, F);
+    }
+    const int len0 = F.m, len1 = F.K - 1 - F.m;
+    for (int s = 0; s < std::max(len0, len1); ++s) {
+        const int k0 = s < len0 ? s : -1, k1 = s < len1 ? F.K - 1 - s : -1;
+        NRS_TRY(kft_invert(c, F, k0, k1, d.flags));
+        const dim3 g((F.ld + 255) / 256, F.ld, 2), g2(F.ld, 2);
+        const size_t shy = sizeof(double) * F.ld;
+        hipLaunchKernelGGL(k_kft_gct, g, dim3(256), 0, c->stream, F, k0, k1);
+        if (k0 >= 0 && k1 >= 0 && k0 + 1 == k1 - 1) {              // both chains reach the middle keyframe: one after the other (fixed order)
+            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, -1);
+            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, -1, k1);
+        } else hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, k1);
+    }
+    NRS_TRY(kft_invert(c, F, F.m, -1, d.flags));
+    NRS_HIP(c, hipGetLastError());
+    H->factorisations++;
+    return NRS_OK;
+}
+
+// u = M^-1 r: r in (rv rows, rp poses), u to (uv rows, up poses)
+static int kft_apply(nrs_ctx* c, KftHost* H, const double* rv, const double* rp, double* uv, double* up, const int* flags) {
+    const KftDev& F = H->d;
+    const int len0 = F.m, len1 = F.K - 1 - F.m, ns = std::max(len0, len1);
+    const dim3 b(256);
+    const size_t shm = sizeof(double) * F.ld;
+    auto stage = [&](int mode, int k0, int k1) {
+        const int nch = k1 >= 0 ? 2 : 1;
+        hipLaunchKernelGGL(k_kft_vec, dim3((F.ld + 255) / 256, nch), b, 0, c->stream, F, mode, k0, k1, rv, rp, flags);
+        hipLaunchKernelGGL(k_kft_gemv, dim3(F.ld / 16, nch), b, shm, c->stream, F, mode, k0, k1, uv, up, flags);
+    };
+    for (int s = 0; s < ns; ++s) stage(0, s < len0 ? s : -1, s < len1 ? F.K - 1 - s : -1);
+    stage(1, F.m, -1);
+    for (int s = ns - 1; s >= 0; --s) stage(2, s < len0 ? s : -1, s < len1 ? F.K - 1 - s : -1);
+    return NRS_OK;
+}
+
+static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vector<int>& pose_grp_ptr);   // nrs_engine_kft_setup.hpp
+
+}  // namespace nrs

@@ -1,0 +1,188 @@
+// Set-up of the keyframe-block factorisation (nrs_engine_kft.hpp): host lists, one device buffer.  Part of nrs_engine.hip.
+#pragma once
+
+namespace nrs {
+
+// ---- set-up (once per window): compact indices, the pair / coupling lists in a fixed order, one device buffer
+struct KftEnt { uint64_t key; uint32_t src; double w; };
+static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vector<int>& pose_grp_ptr) {
+    const Dev& d = e->d;
+    const int K = d.K;
+    if (K < 1 || K > 255 || (e->sp_pos.empty() && s.n_sp > 0)) return NRS_OK;
+    std::vector<int> kf_nf(K, 0), kf_np(K, 0), row_ci((size_t)d.n_rows, -1);
+    int nf_max = 0;
+    for (int k = 0; k < K; ++k) {
+        int n = 0;
+        for (int r = pose_grp_ptr[k] * ROW_ALIGN; r < pose_grp_ptr[k + 1] * ROW_ALIGN; ++r)
+            if (!(e->h_rflag[r] & RF_FIXED)) row_ci[r] = n++;
+        kf_nf[k] = n;
+        kf_np[k] = (s.pose_fixed && s.pose_fixed[k]) ? 0 : 6;
+        nf_max = std::max(nf_max, n);
+    }
+    if (nf_max >= 4096 || nf_max < 1) return NRS_OK;
+    // automatic choice (nrs_options.embedded_solver = 0): a factorisation is K / 2 dependent inversions of (3 nodes + 6)^2 blocks, each
+    // ld / 64 dependent pivot steps of ~60 us -- measured against the block-Jacobi PCG on 20-keyframe windows (tools/kft_probe.py,
+    // profiles/r06_kft_crossover.txt): 4.2 x faster at 100 nodes per keyframe, 2.7 x at 200, 1.7 x at 300, 1.2 x at 400, 0.75 x at 458
+    if (c->opt.embedded_solver == 0 && 3 * nf_max + 6 > 1280) return NRS_OK;
+    const int ld = ((3 * nf_max + 6 + KFT_B - 1) / KFT_B) * KFT_B, nb = ld / KFT_B, nfm = ld / 3;
+    const size_t n2 = (size_t)ld * ld;
+    if ((size_t)K * n2 * sizeof(double) > ((size_t)6 << 30)) return NRS_OK;       // (the factor would not be worth its memory: the PCG stays block-Jacobi)
+    std::vector<int> kf_row((size_t)K * nfm, -1);
+    for (int k = 0; k < K; ++k)
+        for (int r = pose_grp_ptr[k] * ROW_ALIGN; r < pose_grp_ptr[k + 1] * ROW_ALIGN; ++r)
+            if (row_ci[r] >= 0) kf_row[(size_t)k * nfm + row_ci[r]] = r;
+    auto vk = [&](int v) { return s.lm_pose[v]; };
+    auto vc = [&](int v) { return row_ci[e->vrow[v]]; };
+    // ---- same-keyframe pairs
+    std::vector<KftEnt> pe;
+    pe.reserve((size_t)s.n_sp + 2 * (size_t)s.n_dm + 55 * (size_t)s.n_skin);
+    auto add_pair = [&](int k, int a, int b, uint32_t src, double w) {
+        if (a < 0 || b < 0 || a == b) return;
+        const int hi = std::max(a, b), lo = std::min(a, b);
+        pe.push_back(KftEnt{((uint64_t)k << 24) | ((uint64_t)hi << 12) | (uint64_t)lo, src, w});
+    };
+    for (int q = 0; q < s.n_sp; ++q) {
+        const int i = s.sp_ij[2 * (size_t)q], j = s.sp_ij[2 * (size_t)q + 1];
+        if (vk(i) != vk(j)) return NRS_OK;                         // (a spring across keyframes: not a BA window's)
+        const int pos = vc(i) >= 0 ? e->sp_pos[2 * (size_t)q] : e->sp_pos[2 * (size_t)q + 1];
+        if (pos >= 0) add_pair(vk(i), vc(i), vc(j), (0u << 30) | (uint32_t)pos, 0.0);
+    }
+    std::vector<KftEnt> te;
+    te.reserve(4 * (size_t)s.n_dm);
+    for (int q = 0; q < s.n_dm; ++q) {
+        const int* v = s.dm_idx + 4 * (size_t)q;                   // (1c, 2c, 1n, 2n), -1: absent
+        int kk[4], cc[4], pos = -1;
+        for (int r = 0; r < 4; ++r) {
+            kk[r] = v[r] >= 0 ? vk(v[r]) : -1; cc[r] = v[r] >= 0 ? vc(v[r]) : -1;
+            if (pos < 0 && cc[r] >= 0) pos = e->dm_pos[4 * (size_t)q + r];
+        }
+        if (pos < 0) continue;
+        // J = (-w, +w, +w, -w) I on (1c, 2c, 1n, 2n): block (p, q) = sg_p sg_q s I
+        if (v[0] >= 0 && v[1] >= 0) { if (kk[0] != kk[1]) return NRS_OK; add_pair(kk[0], cc[0], cc[1], (1u << 30) | (uint32_t)pos, 0.0); }
+        if (v[2] >= 0 && v[3] >= 0) { if (kk[2] != kk[3]) return NRS_OK; add_pair(kk[2], cc[2], cc[3], (1u << 30) | (uint32_t)pos, 0.0); }
+        static const int cur[2] = {0, 1}, nxt[2] = {2, 3};
+        for (int x = 0; x < 2; ++x)
+            for (int y = 0; y < 2; ++y) {
+                const int a = cur[x], b = nxt[y];
+                if (v[a] < 0 || v[b] < 0 || cc[a] < 0 || cc[b] < 0) continue;
+                if (kk[b] != kk[a] + 1) return NRS_OK;             // (a damper that does not join consecutive keyframes)
+                const bool minus = (x == y);                       // (1c,1n), (2c,2n): - s ; (1c,2n), (2c,1n): + s
+                te.push_back(KftEnt{((uint64_t)kk[a] << 24) | ((uint64_t)cc[a] << 12) | (uint64_t)cc[b], (minus ? 0x80000000u : 0u) | (uint32_t)pos, 0.0});
+            }
+    }
+    for (int i = 0; i < s.n_skin; ++i) {
+        const int k = s.sk_pose[i];
+        int cn[SK_MAX];
+        for (int a = 0; a < SK_MAX; ++a) { const int v = s.sk_node[SK_MAX * (size_t)i + a]; cn[a] = v >= 0 ? vc(v) : -1; }
+        for (int a = 0; a < SK_MAX; ++a)
+            for (int b = a + 1; b < SK_MAX; ++b)
+                if (cn[a] >= 0 && cn[b] >= 0) add_pair(k, cn[a], cn[b], (2u << 30) | (uint32_t)e->sk_slot[i], s.sk_om[SK_MAX * (size_t)i + a] * s.sk_om[SK_MAX * (size_t)i + b]);
+    }
+    auto by_key = [](const KftEnt& a, const KftEnt& b) { return a.key < b.key; };
+    {   // (keyframes are independent: sorted in parallel, each stably -- the generation order above is the summation order)
+        std::vector<size_t> kp(K + 1, 0);
+        for (const KftEnt& x : pe) kp[(x.key >> 24) + 1]++;
+        for (int k = 0; k < K; ++k) kp[k + 1] += kp[k];
+        std::vector<KftEnt> tmp(pe.size());
+        std::vector<size_t> fill(kp.begin(), kp.end() - 1);
+        for (const KftEnt& x : pe) tmp[fill[x.key >> 24]++] = x;
+        pe.swap(tmp);
+        const int nt = host_threads(pe.size());
+        parallel_for(std::min(nt, K), [&](int ti, int n) {
+            int64_t a, b;
+            chunk(K, ti, n, a, b);
+            for (int k = (int)a; k < (int)b; ++k) std::stable_sort(pe.begin() + kp[k], pe.begin() + kp[k + 1], by_key);
+        });
+    }
+    std::stable_sort(te.begin(), te.end(), by_key);
+    std::vector<uint32_t> pp_id, pe_src(pe.size()), te_src(te.size());
+    std::vector<int> pp_ptr, tp_ptr;
+    std::vector<double> pe_w(pe.size());
+    for (size_t i = 0; i < pe.size(); ++i) {
+        if (i == 0 || pe[i].key != pe[i - 1].key) { pp_id.push_back((uint32_t)pe[i].key); pp_ptr.push_back((int)i); }
+        pe_src[i] = pe[i].src; pe_w[i] = pe[i].w;
+    }
+    pp_ptr.push_back((int)pe.size());
+    std::vector<uint64_t> tp_key;
+    for (size_t i = 0; i < te.size(); ++i) {
+        if (i == 0 || te[i].key != te[i - 1].key) { tp_key.push_back(te[i].key); tp_ptr.push_back((int)i); }
+        te_src[i] = te[i].src;
+    }
+    tp_ptr.push_back((int)te.size());
+    const size_t n_pp = pp_id.size(), n_tp = tp_key.size();
+    // coupling lists by the 'to' node: dir 0 at keyframe k + 1 by b (from a of k), dir 1 at keyframe k by a (from b of k + 1)
+    std::vector<int> cl_ptr[2], cl_from[2], cl_tp[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        cl_ptr[dir].assign((size_t)K * (nfm + 1), 0);
+        std::vector<int> cnt((size_t)K * nfm, 0);
+        for (size_t i = 0; i < n_tp; ++i) {
+            const int k = (int)(tp_key[i] >> 24), a = (int)((tp_key[i] >> 12) & 0xFFF), b = (int)(tp_key[i] & 0xFFF);
+            cnt[dir == 0 ? (size_t)(k + 1) * nfm + b : (size_t)k * nfm + a]++;
+        }
+        int run = 0;
+        for (int k = 0; k < K; ++k) {
+            for (int n = 0; n < nfm; ++n) { cl_ptr[dir][(size_t)k * (nfm + 1) + n] = run; run += cnt[(size_t)k * nfm + n]; }
+            cl_ptr[dir][(size_t)k * (nfm + 1) + nfm] = run;
+        }
+        cl_from[dir].assign(n_tp + 1, 0); cl_tp[dir].assign(n_tp + 1, 0);
+        std::vector<int> fill((size_t)K * nfm);
+        for (int k = 0; k < K; ++k) for (int n = 0; n < nfm; ++n) fill[(size_t)k * nfm + n] = cl_ptr[dir][(size_t)k * (nfm + 1) + n];
+        for (size_t i = 0; i < n_tp; ++i) {                        // (tp order = ascending (k, a, b): every list in a fixed order)
+            const int k = (int)(tp_key[i] >> 24), a = (int)((tp_key[i] >> 12) & 0xFFF), b = (int)(tp_key[i] & 0xFFF);
+            const int q = fill[dir == 0 ? (size_t)(k + 1) * nfm + b : (size_t)k * nfm + a]++;
+            cl_from[dir][q] = dir == 0 ? a : b; cl_tp[dir][q] = (int)i;
+        }
+    }
+    // ---- one device buffer
+    auto al = [](size_t b2) { return (b2 + 255) & ~(size_t)255; };
+    const size_t tile = (size_t)KFT_B * KFT_B;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t o_A = take(8 * (size_t)K * n2), o_YT = take(8 * 2 * n2), o_Bb = take(8 * 2 * nb * tile), o_Cb = take(8 * 2 * nb * tile), o_Pv = take(8 * 2 * tile),
+                 o_z = take(8 * (size_t)K * ld), o_xs = take(8 * (size_t)K * ld), o_vb = take(8 * 2 * (size_t)ld), o_nf = take(4 * (size_t)K), o_np = take(4 * (size_t)K), o_kr = take(4 * kf_row.size()),
+                 o_rc = take(4 * row_ci.size()), o_ppid = take(4 * (n_pp + 1)), o_ppp = take(4 * (n_pp + 1)), o_pes = take(4 * (pe.size() + 1)), o_pew = take(8 * (pe.size() + 1)),
+                 o_tpp = take(4 * (n_tp + 1)), o_tes = take(4 * (te.size() + 1)), o_tpv = take(8 * (n_tp + 1)),
+                 o_cp0 = take(4 * cl_ptr[0].size()), o_cp1 = take(4 * cl_ptr[1].size()), o_cf0 = take(4 * (n_tp + 1)), o_cf1 = take(4 * (n_tp + 1)),
+                 o_ct0 = take(4 * (n_tp + 1)), o_ct1 = take(4 * (n_tp + 1)), o_cv0 = take(8 * (n_tp + 1)), o_cv1 = take(8 * (n_tp + 1));
+    if (c->ensure(c->dba_kft, off) != NRS_OK) return NRS_OK;      // (no memory for the factor: block-Jacobi PCG)
+    char* base = c->dba_kft.as<char>();
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess; };
+    NRS_HIP(c, up(o_nf, kf_nf.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_np, kf_np.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_kr, kf_row.data(), 4 * kf_row.size()));
+    NRS_HIP(c, up(o_rc, row_ci.data(), 4 * row_ci.size())); NRS_HIP(c, up(o_ppid, pp_id.data(), 4 * n_pp)); NRS_HIP(c, up(o_ppp, pp_ptr.data(), 4 * (n_pp + 1)));
+    NRS_HIP(c, up(o_pes, pe_src.data(), 4 * pe.size())); NRS_HIP(c, up(o_pew, pe_w.data(), 8 * pe.size()));
+    NRS_HIP(c, up(o_tpp, tp_ptr.data(), 4 * (n_tp + 1))); NRS_HIP(c, up(o_tes, te_src.data(), 4 * te.size()));
+    NRS_HIP(c, up(o_cp0, cl_ptr[0].data(), 4 * cl_ptr[0].size())); NRS_HIP(c, up(o_cp1, cl_ptr[1].data(), 4 * cl_ptr[1].size()));
+    NRS_HIP(c, up(o_cf0, cl_from[0].data(), 4 * n_tp)); NRS_HIP(c, up(o_cf1, cl_from[1].data(), 4 * n_tp));
+    NRS_HIP(c, up(o_ct0, cl_tp[0].data(), 4 * n_tp)); NRS_HIP(c, up(o_ct1, cl_tp[1].data(), 4 * n_tp));
+    NRS_HIP(c, hipMemsetAsync(base + o_z, 0, o_nf - o_z, c->stream));     // (z and xs)
+    NRS_HIP(c, hipStreamSynchronize(c->stream));
+    KftHost* H = new (std::nothrow) KftHost();
+    if (!H) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+    KftDev& F = H->d;
+    memset(&F, 0, sizeof(F));
+    F.K = K; F.ld = ld; F.nb = nb; F.m = K / 2; F.nfm = nfm;
+    F.A = reinterpret_cast<double*>(base + o_A); F.YT = reinterpret_cast<double*>(base + o_YT);
+    F.Bb = reinterpret_cast<double*>(base + o_Bb); F.Cb = reinterpret_cast<double*>(base + o_Cb); F.Pv = reinterpret_cast<double*>(base + o_Pv);
+    F.z = reinterpret_cast<double*>(base + o_z); F.xs = reinterpret_cast<double*>(base + o_xs); F.vb = reinterpret_cast<double*>(base + o_vb);
+    F.kf_nf = reinterpret_cast<const int*>(base + o_nf); F.kf_np = reinterpret_cast<const int*>(base + o_np);
+    F.kf_row = reinterpret_cast<const int*>(base + o_kr); F.row_ci = reinterpret_cast<const int*>(base + o_rc);
+    F.n_pp = (int)n_pp; F.pp_id = reinterpret_cast<const uint32_t*>(base + o_ppid); F.pp_ptr = reinterpret_cast<const int*>(base + o_ppp);
+    F.pe_src = reinterpret_cast<const uint32_t*>(base + o_pes); F.pe_w = reinterpret_cast<const double*>(base + o_pew);
+    F.n_tp = (int)n_tp; F.tp_ptr = reinterpret_cast<const int*>(base + o_tpp); F.te_src = reinterpret_cast<const uint32_t*>(base + o_tes);
+    F.tp_val = reinterpret_cast<double*>(base + o_tpv);
+    F.cl_ptr[0] = reinterpret_cast<const int*>(base + o_cp0); F.cl_ptr[1] = reinterpret_cast<const int*>(base + o_cp1);
+    F.cl_from[0] = reinterpret_cast<const int*>(base + o_cf0); F.cl_from[1] = reinterpret_cast<const int*>(base + o_cf1);
+    F.cl_tp[0] = reinterpret_cast<const int*>(base + o_ct0); F.cl_tp[1] = reinterpret_cast<const int*>(base + o_ct1);
+    F.cl_val[0] = reinterpret_cast<double*>(base + o_cv0); F.cl_val[1] = reinterpret_cast<double*>(base + o_cv1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_PANEL_LDS));
+        attr_done = true;
+    }
+    H->bytes = off;
+    H->on = true;
+    e->kft = H;
+    return NRS_OK;
+}
+
+}  // namespace nrs

@@ -1174,6 +1174,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     }
     d.sk_pcg = (d.sk_n > 0 && !(e->nd && e->nd->on)) ? 1 : 0;      // (on the direct solver k_nd_values folds the observations into its blocks)
     if (d.sk_pcg) d.ecd = 0;                                       // (k_pcg_update<true> owns 16 rows a workgroup: no r.u partials per 256 rows for the operator's early test -- one launch in hundreds)
+    if (d.sk_pcg && s.sk_pose && d.use_lds && !d.sh_on && !d.hier && c->opt.embedded_solver != 2) {   // embedded BA window: the keyframe-block factorisation as the PCG's preconditioner
+        NRS_TRY(kft_setup(c, e, s, pose_grp_ptr));
+        mark("keyframe-block factorisation plan");
+    }
     NRS_TRY(engine_reset(c, e));
     guard.keep = true;
     *out = e;
@@ -1188,6 +1192,7 @@ void engine_destroy(nrs_ctx* c, Engine* e) {
     if (!e) return;
     (void)hipStreamSynchronize(c->stream);
     nd_engine_free(c, e->nd);
+    delete e->kft;
     delete e;
 }
 

@@ -208,9 +208,11 @@ inline int rc_of(const Dev& d, int cls) {
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
 
 struct NdEngine;                     // nrs_engine_nd.hpp: the direct solver of a single-frame engine
+struct KftHost;                      // nrs_engine_kft.hpp: the keyframe-block factorisation of an embedded BA window
 struct Engine {
     Dev d;
     NdEngine* nd = nullptr;
+    KftHost* kft = nullptr;
     Arena* arena = nullptr;
     int cur = 0;
     int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)

@@ -416,11 +416,12 @@ extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     if (opt) {
         // the caller's struct may be shorter than this build's (an older header): its bytes only, defaults behind them
         size_t n = opt->struct_size ? opt->struct_size : offsetof(nrs_options, direct_solve);
-        if (n < offsetof(nrs_options, pcg_rtol)) { delete c; return NRS_ERR_INVALID; }
+        if (n < offsetof(nrs_options, pcg_rtol) || n > 4096) { delete c; return NRS_ERR_INVALID; }   // (shorter than the first field / an uninitialised word)
         memcpy(&c->opt, opt, std::min(n, sizeof(c->opt)));
         c->opt.struct_size = (uint32_t)sizeof(c->opt);
     }
     if (c->opt.direct_solve < 0 || c->opt.direct_solve > 2) c->opt.direct_solve = 0;
+    if (c->opt.embedded_solver < 0 || c->opt.embedded_solver > 2) c->opt.embedded_solver = 0;
     if (c->opt.pcg_rtol <= 0) c->opt.pcg_rtol = 1e-10;
     if (const char* e = getenv("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
     if (c->opt.pcg_max_iters <= 0) c->opt.pcg_max_iters = 2000;
@@ -456,7 +457,7 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
     if (c->arena_dba.base) (void)hipFree(c->arena_dba.base);
     if (c->arena_trk.base) (void)hipFree(c->arena_trk.base);
     c->release(c->po_uv); c->release(c->po_X); c->release(c->po_err);
-    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->gather_ws); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin); c->release(c->po_multi);
+    c->release(c->po_level); c->release(c->po_out); c->release(c->po_trace); c->release(c->comm_flag); c->release(c->gather_ws); c->release(c->tap); c->release(c->pack_ws); c->release(c->pack_ws2); c->release(c->pack_ws3); c->release(c->pack_ws4); c->release(c->nd_skin); c->release(c->dba_skin); c->release(c->dba_kft); c->release(c->po_multi);
     nrs::nd_cache_free(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_options_init", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_build_edges_embedded", "nrs_dba_upload_embedded", "nrs_dba_download_skinned", "nrs_dba_solve_embedded", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_kft", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -45,7 +45,8 @@ class Camera(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("struct_size", C.c_uint32), ("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int32),
-                ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32), ("direct_solve", C.c_int32)]
+                ("pcg_batch", C.c_int32), ("profile", C.c_int32), ("exact_trials", C.c_int32), ("direct_solve", C.c_int32),
+                ("embedded_solver", C.c_int32)]
 
 
 class LmTrial(C.Structure):
@@ -311,9 +312,9 @@ class RGraph:
 
 
 class Context:
-    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0, direct_solve=0):
+    def __init__(self, device=-1, pcg_rtol=0.0, pcg_max_iters=0, pcg_batch=0, profile=0, exact_trials=0, direct_solve=0, embedded_solver=0):
         self.lib = load_library()
-        opt = Options(device, C.sizeof(Options), pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials, direct_solve)
+        opt = Options(device, C.sizeof(Options), pcg_rtol, pcg_max_iters, pcg_batch, profile, exact_trials, direct_solve, embedded_solver)
         self.h = C.c_void_p()
         rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
         if rc != OK:
@@ -718,6 +719,30 @@ class Context:
             self._chk(rc)
         keys = ("fronts", "levels", "max_s", "max_b", "L_doubles", "U_doubles", "flops", "workgroups")
         return rc == 0, x, dict(zip(keys, st.tolist())), ms.value
+
+    def debug_kft_info(self):
+        """the keyframe-block factorisation of the resident embedded window: dict(on, K, ld, nb, m, mib, nf[K], np[K])"""
+        o = np.zeros(6 + 2 * max(1, self._n_kf), np.int32)
+        self._chk(self.lib.nrs_debug_kft(self.h, C.c_double(0.0), C.c_int32(0), C.c_int32(0), None, None, _p(o, C.c_int32)))
+        K = self._n_kf
+        return dict(on=bool(o[0]), K=int(o[1]), ld=int(o[2]), nb=int(o[3]), m=int(o[4]), mib=int(o[5]), nf=o[6:6 + K].copy(), np=o[6 + K:6 + 2 * K].copy())
+
+    def debug_kft_block(self, lam, k, coupling=False):
+        ld = self.debug_kft_info()["ld"]
+        a = np.zeros((ld, ld), np.float64)
+        self._chk(self.lib.nrs_debug_kft(self.h, C.c_double(lam), C.c_int32(2 if coupling else 1), C.c_int32(k), None, _p(a, C.c_double), None))
+        return a
+
+    def debug_kft_apply(self, lam, r):
+        r = np.ascontiguousarray(r, np.float64)
+        u = np.zeros_like(r)
+        self._chk(self.lib.nrs_debug_kft(self.h, C.c_double(lam), C.c_int32(3), C.c_int32(0), _p(r, C.c_double), _p(u, C.c_double), None))
+        return u
+
+    def debug_kft_index(self):
+        o = np.zeros((self._n_lm, 2), np.int32)
+        self._chk(self.lib.nrs_debug_kft(self.h, C.c_double(0.0), C.c_int32(4), C.c_int32(0), None, None, _p(o, C.c_int32)))
+        return o
 
     def dba_gradient(self):
         n = 6 * self._n_kf + 3 * self._n_lm

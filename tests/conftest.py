@@ -60,6 +60,33 @@ def ctx_pcg():
     c.close()
 
 
+@pytest.fixture(scope="session")
+def ctx_emb_pcg():
+    """nrs_options.embedded_solver = 2: embedded BA windows on the block-Jacobi PCG (the default takes the keyframe-block factorisation
+    for windows of up to ~420 nodes per keyframe, csrc/nrs_engine_kft.hpp)."""
+    import nrs
+    c = nrs.Context(embedded_solver=2)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_emb_pcg_exact():
+    import nrs
+    c = nrs.Context(embedded_solver=2, exact_trials=1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_emb_direct():
+    """nrs_options.embedded_solver = 1: the keyframe-block factorisation whatever the window's size."""
+    import nrs
+    c = nrs.Context(embedded_solver=1)
+    yield c
+    c.close()
+
+
 def compare_lm_traces(dev, ora, rounds, rtol=1e-6, noise=3e-7):
     """Every LM trial of every round against the oracle's, up to the point where the oracle's own decision sits on the
     fp32-projection noise floor: a trial whose chi2 change is below `noise` * chi2 is decided by the last bits of 4.5k

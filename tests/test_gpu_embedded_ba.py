@@ -62,10 +62,13 @@ def test_gradient_and_diagonal_include_the_skinned_observations(ctx, model):
     assert np.max(np.abs(G0.build_system()[1] - bo)) > 0.1 * np.max(np.abs(bo))
 
 
+@pytest.mark.parametrize("solver", ["factorisation", "pcg"])
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("n,k,m,seed,model", [(300, 4, 40, 53, S.PINHOLE), (600, 6, 80, 54, S.PINHOLE), (400, 5, 60, 55, S.KB8)])
-def test_solve_matches_oracle(ctx, ctx_exact, n, k, m, seed, model, exact):
-    ctx = ctx_exact if exact else ctx
+def test_solve_matches_oracle(ctx, ctx_exact, ctx_emb_pcg, ctx_emb_pcg_exact, n, k, m, seed, model, exact, solver):
+    """both linear solvers of the embedded window (nrs_options.embedded_solver): the keyframe-block factorisation (the default at these
+    sizes: one or two PCG iterations per trial) and the block-Jacobi PCG (hundreds)"""
+    ctx = (ctx_exact if exact else ctx) if solver == "factorisation" else (ctx_emb_pcg_exact if exact else ctx_emb_pcg)
     p, e, w, cam, qt = _setup(n, k, m, seed, model)
     assert len(e["sk_obs"]) > 0.7 * len(p["lm_kf"])
     tr = nrs.Trace()
@@ -86,9 +89,13 @@ def test_solve_matches_oracle(ctx, ctx_exact, n, k, m, seed, model, exact):
     assert np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
     assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
     assert np.allclose(sk, osk, atol=1e-4, rtol=0)
+    inner = sum(t["inner"] for t in tr.trials if not t["early"])
+    assert inner <= 3 * len(tr.trials) if solver == "factorisation" else inner > 20 * len(tr.trials)
 
 
-def test_resident_form_reset_and_determinism(ctx):
+@pytest.mark.parametrize("which", ["factorisation", "pcg"])
+def test_resident_form_reset_and_determinism(ctx, ctx_emb_pcg, which):
+    ctx = ctx if which == "factorisation" else ctx_emb_pcg
     p, e, w, cam, qt = _setup(500, 5, 70, 56)
     ctx.dba_upload_embedded(cam, qt, w, e, p["scale"])
     out = []
@@ -105,7 +112,8 @@ def test_resident_form_reset_and_determinism(ctx):
 
 
 @pytest.mark.parametrize("switch", ["NRS_SKIN_OP_OWN_LAUNCH", "NRS_SKIN_ROWS_OWN_LAUNCH"])
-def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx, monkeypatch, switch):
+def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx_emb_pcg, monkeypatch, switch):
+    ctx = ctx_emb_pcg
     """A PCG iteration of the embedded window is two launches: k_spmv_f_skin (the regularisers' operator and k_skin_op) and
     k_pcg_update<true> (the observations' row pass and the vector update).  NRS_SKIN_OP_OWN_LAUNCH=1 / NRS_SKIN_ROWS_OWN_LAUNCH=1 give
     k_skin_op / the row pass (k_skin_op_rows, then the generic update) launches of their own (the env is read per launch): the same
@@ -124,7 +132,8 @@ def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx, monkeyp
     assert out[0][3] == out[1][3]
 
 
-def test_hierarchical_reduction_path_matches(ctx, monkeypatch):
+def test_hierarchical_reduction_path_matches(ctx_emb_pcg, monkeypatch):
+    ctx = ctx_emb_pcg
     """Large windows reduce the partials in a kernel of their own (k_reduce_partials, from 4096 tiles on); NRS_HIER=1 forces that form
     on a small window: the row pass is then k_skin_op_rows and the update the generic kernel.  Same problem, same LM decisions, results
     within the oracle tolerances of the default form (the sums are grouped differently)."""
@@ -155,9 +164,11 @@ def test_bad_inputs_are_rejected(ctx):
         ctx.dba_upload_embedded(cam, qt, w, bad, p["scale"])
 
 
-@pytest.mark.parametrize("exact", [True, False])
-def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, exact):
-    """BASELINE configs[1] as written -- 5k points x 500 nodes x 20 keyframes -- against tests/golden/dba_C2_embedded500_trace.npz: the
+@pytest.mark.parametrize("mode", ["exact", "early-rejection", "factorisation"])
+def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, ctx_emb_direct, mode):
+    """(mode: the block-Jacobi PCG with every trial solved to pcg_rtol / with early trial rejection -- the default at this size -- and the
+    keyframe-block factorisation forced, nrs_options.embedded_solver = 1: 20 blocks of 1408 x 1408)
+    BASELINE configs[1] as written -- 5k points x 500 nodes x 20 keyframes -- against tests/golden/dba_C2_embedded500_trace.npz: the
     oracle's LM on the complete embedded window (tests/golden/make_embedded_ba_golden.py: 443 s in the build container, sparse LU per
     trial), on the oracle's own lists (checksums in the fixture; the product's host builder must reproduce them).  Tolerances of the
     small cases."""
@@ -167,7 +178,7 @@ def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, e
     sys.path.insert(0, os.path.join(here, "golden"))
     from make_embedded_ba_golden import skin_checksum
     g = np.load(os.path.join(here, "golden", "dba_C2_embedded500_trace.npz"))
-    c = ctx_exact if exact else ctx
+    c = {"exact": ctx_exact, "early-rejection": ctx, "factorisation": ctx_emb_direct}[mode]
     p = S.make_dba_problem("C2")
     flag, nb = S.embedded_problem(p, int(g["n_nodes"]))
     e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
@@ -177,11 +188,14 @@ def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, e
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     c.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    assert c.debug_kft_info()["on"] == (mode == "factorisation")
     tr = nrs.Trace()
     c.dba_optimize(5, tr)
     pq, xyz = c.dba_download()
     sk = c.dba_download_skinned()
     t = tr.trials
+    if mode == "factorisation":
+        assert sum(x["inner"] for x in t) <= 3 * len(t)
     assert tr.iterations == int(g["out_iters"])
     assert [x["accepted"] for x in t] == g["out_accepted"].tolist()
     for x, chi, chi_new, lam in zip(t, g["out_chi"], g["out_chi_new"], g["out_lam"]):

@@ -1,0 +1,76 @@
+"""GPU parity of the embedded BA window's keyframe-block factorisation (nrs_options.embedded_solver = 0; nr-slam_amd/csrc/nrs_engine_kft.hpp) --
+the GPU counterpart of g2o's exact solve per LM trial (linear_solver_eigen.h:92-173) -- against the oracle's assembled system
+(oracle/embedded_oracle.py dba_graph_embedded -> Graph.build_system): every diagonal block A_k, every coupling T_k, and the factorisation
+applied to a vector, M^-1 (H + lambda I) x = x."""
+import numpy as np
+import pytest
+
+import embedded_oracle as E
+import nrs
+import nrs_synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, k, m, seed, model=S.PINHOLE):
+    p = S.make_dba_problem(n, k, seed, model)
+    flag, nb = S.embedded_problem(p, m)
+    e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
+    w = S.embedded_window(p, e)
+    cam = nrs.make_camera(p["model"], p["prm"])
+    qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
+    G, _ = E.dba_graph_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"])
+    G.initialize(0)
+    G.compute_active_errors()
+    H, b = G.build_system()
+    return p, e, w, cam, qt, H.tocsr(), b
+
+
+@pytest.mark.parametrize("n,k,m,seed,model", [(300, 4, 40, 61, S.PINHOLE), (500, 5, 70, 62, S.KB8), (600, 7, 90, 63, S.PINHOLE)])
+def test_blocks_couplings_and_the_applied_factorisation_match_the_oracle_system(ctx, n, k, m, seed, model):
+    p, e, w, cam, qt, H, b = _setup(n, k, m, seed, model)
+    ctx.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    info = ctx.debug_kft_info()
+    assert info["on"] and info["K"] == k and info["ld"] % 64 == 0
+    idx = ctx.debug_kft_index()                                    # node copy -> (keyframe, compact node)
+    assert (idx[:, 0] == w["lm_kf"]).all() and (idx[:, 1] >= 0).all()
+    lam = 1e-5 * np.abs(H.diagonal()).max()
+    K6 = 6 * k
+    scale = np.abs(H.diagonal()).max()
+    for kf in range(k):
+        nf = int(info["nf"][kf])
+        mine = np.where(idx[:, 0] == kf)[0]
+        assert len(mine) == nf
+        # unknowns of keyframe kf in the device's compact order -> the oracle's indices (6 per pose, then 3 per node copy)
+        cols = np.zeros(3 * nf + 6, np.int64)
+        for v in mine:
+            cols[3 * idx[v, 1]:3 * idx[v, 1] + 3] = K6 + 3 * v + np.arange(3)
+        cols[3 * nf:] = 6 * kf + np.arange(6)
+        A = ctx.debug_kft_block(lam, kf)
+        ref = H[cols][:, cols].toarray() + lam * np.eye(len(cols))
+        nk = len(cols)
+        assert np.abs(A[:nk, :nk] - ref).max() <= 1e-9 * scale, kf
+        assert np.array_equal(A[nk:, nk:], np.eye(info["ld"] - nk)) and not A[:nk, nk:].any() and not A[nk:, :nk].any()
+        if kf + 1 < k:
+            nxt = np.where(idx[:, 0] == kf + 1)[0]
+            cn = np.zeros(3 * len(nxt), np.int64)
+            for v in nxt:
+                cn[3 * idx[v, 1]:3 * idx[v, 1] + 3] = K6 + 3 * v + np.arange(3)
+            T = ctx.debug_kft_block(lam, kf, coupling=True)
+            reft = H[cols[:3 * nf]][:, cn].toarray()
+            assert np.abs(T[:3 * nf, :len(cn)] - reft).max() <= 1e-9 * scale, kf
+            assert not T[3 * nf:].any() and not T[:, len(cn):].any()
+            assert not H[cols[3 * nf:]][:, cn].nnz                 # (poses do not couple across keyframes)
+    # the factorisation applied to a vector: M^-1 (H + lam I) x = x
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1, H.shape[0])
+    r = H @ x + lam * x
+    u = ctx.debug_kft_apply(lam, r)
+    assert np.linalg.norm(u - x) <= 1e-7 * np.linalg.norm(x)
+    # ... and to the window's own right-hand side: the LM step of the oracle
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    step = spla.spsolve((H + lam * sp.identity(H.shape[0])).tocsc(), b)
+    u = ctx.debug_kft_apply(lam, b)
+    assert np.linalg.norm(u - step) <= 1e-7 * np.linalg.norm(step)
