@@ -187,11 +187,11 @@ def cpu_tracked_fps_compiled(lib, with_gpu):
             # the same frame is repeated: without the switch every repeat after the first would take the direct solver's symbolic
             # factorisation from the context's cache.  gpu_ms is a frame that builds it (what the CPU side does per frame, too);
             # gpu_ms_plan_reused a frame whose structure equals an earlier one's
-            os.environ["NRS_ND_NO_CACHE"] = "1"
+            nrs.debug_set("NRS_ND_NO_CACHE", "1")
             try:
                 ts = three_calls(3)
             finally:
-                del os.environ["NRS_ND_NO_CACHE"]
+                nrs.debug_set("NRS_ND_NO_CACHE", None)
             ts_hit = three_calls(3)[1:]
             c.close()
             row.update(gpu_ms=1e3 * min(ts), gpu_frames_per_s=1.0 / min(ts), gpu_over_cpu=dt / min(ts), gpu_ms_plan_reused=1e3 * min(ts_hit),

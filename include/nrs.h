@@ -137,6 +137,27 @@ typedef struct {
 } nrs_profile;
 
 int nrs_create(nrs_ctx** out, const nrs_options* opt);
+
+/* ---- Debug switches -----------------------------------------------------------------------------------------------------
+ * None is needed in normal use.  A context reads the NRS_* variables of the environment ONCE, in nrs_create (also
+ * NRS_DEBUG="NAME=VALUE,NAME2=VALUE2", names without the prefix); afterwards the library never looks at the environment again --
+ * a host application may call setenv at any time -- and a switch is changed through nrs_debug_set only (value NULL: unset;
+ * takes effect at the next problem upload / solve of that context).  The host edge builders, which take no context, read
+ * NRS_HOST_THREADS from a process-wide snapshot taken at their first call.
+ *   measurement   NRS_TIMING (stage marks of engine_create and the a2 driver on stderr), NRS_ND_DBG / NRS_ND_DBG2 (phase clocks of one
+ *                 direct solve through nrs_debug_nd_solve), NRS_PEEK_DEBUG (gain ratios at the early-rejection looks)
+ *   checks        NRS_POISON (fresh device allocations filled with NaN patterns), NRS_CHECK_EVAL / NRS_CHECK_FUSED / NRS_CHECK_CHI (an
+ *                 evaluation / a single-launch PCG iteration / the carried chi2 computed twice and compared)
+ *   direct solver NRS_ND=0|1, NRS_ND_MAX_ROWS, NRS_ND_NO_CACHE, NRS_ND_NO_COVER, NRS_ND_CHAIN, NRS_ND_LEVELS, NRS_ND_THREADS=256,
+ *                 NRS_ND_STEP32=0, NRS_ND_BACK_FLAGS, NRS_ND_LEAF=<n>, NRS_ND_NO_SPLIT, NRS_ND_PLAN_PAR=<n>
+ *   PCG / packing NRS_NO_LDS, NRS_NO_FUSED, NRS_FUSED_MAX_ROWS=<n>, NRS_NO_COARSE, NRS_COARSE_MIN_TILES=<n>, NRS_NO_ONE_XCD, NRS_NO_ECD, NRS_HIER,
+ *                 NRS_NO_PLAIN, NRS_NO_H4, NRS_RC=<0..3>, NRS_NT=0|1, NRS_DFORM, NRS_NO_EDGE_CHI, NRS_SELL_T=<lanes>, NRS_NO_MORTON,
+ *                 NRS_NO_TILE_SORT, NRS_ONE_CLASS, NRS_TILE_CUT_PCT=<p>, NRS_HOST_PACK, NRS_HOST_THREADS=<n>, NRS_HOST_THREADS_SMALL=<n>,
+ *                 NRS_SKIN_OP_OWN_LAUNCH, NRS_SKIN_ROWS_OWN_LAUNCH, NRS_PCG_RTOL=<r> (experiments)
+ *   sharding      NRS_SHARD_PACK_ALL, NRS_SHARD_FULL_VECTORS
+ *   a1 / graph    NRS_PO_MULTI_MIN=<n>, NRS_HOST_WALK, NRS_WALK_MAX_PASSES=<n>, NRS_RG_NO_MIRROR
+ * (what each selects: README.md "Debug switches"; the A/B tests drive every launch form through nrs_debug_set). */
+int nrs_debug_set(nrs_ctx* ctx, const char* name /* "NRS_..." */, const char* value /* NULL: unset */);
 void nrs_destroy(nrs_ctx* ctx);
 const char* nrs_last_error(const nrs_ctx* ctx);
 int nrs_device_name(const nrs_ctx* ctx, char* buf, int32_t buf_len);
@@ -518,7 +539,9 @@ int nrs_klt_insert_templates(nrs_ctx* ctx, int32_t count, const float* xy, const
  * (the caller's ids, e.g. map point ids; an entry is overwritten when archived again), nrs_klt_insert_archived appends the entries
  * `keys[i]` of context `src`'s archive to THIS context's tracker with the positions xy (n x 2).  Both contexts on one device; a
  * tracker with fewer pyramid levels than the archive takes the levels it has (PointReuse's tracker: maxLevel 1).  Byte for
- * byte what nrs_klt_get_templates + nrs_klt_insert_templates hand over (tests/test_gpu_klt.py). */
+ * byte what nrs_klt_get_templates + nrs_klt_insert_templates hand over (tests/test_gpu_klt.py).  The archive is DENSE by key (the key
+ * indexes its entry: no lookup on the device), window^2 x levels x 6 bytes per key up to the largest key seen: keys must be
+ * below 2^20 (NRS_ERR_INVALID otherwise); an archive that was built with another pyramid level count is dropped and starts over. */
 int nrs_klt_archive_templates(nrs_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* keys);
 int nrs_klt_insert_archived(nrs_ctx* ctx, nrs_ctx* src, int32_t n, const int32_t* keys, const float* xy);
 

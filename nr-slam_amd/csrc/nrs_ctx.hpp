@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/nrs.h"
 
@@ -33,6 +34,25 @@ struct Comm {
 };
 struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 
+// Debug / A-B switches (include/nrs.h "Debug switches").  A context takes the NRS_* variables of the environment ONCE, when it is created
+// (plus NRS_DEBUG="NAME=VALUE,NAME2=VALUE2", names without the prefix), and is changed afterwards through nrs_debug_set only: the library
+// never looks at the environment again -- a host application may call setenv at any time, and no launch path pays for a lookup (the list
+// is empty in normal use).  Entry points without a context (the host edge builder) read a process-wide snapshot taken on first use.
+struct DebugOpts {
+    std::vector<std::pair<std::string, std::string>> kv;
+    const char* get(const char* name) const {
+        for (const auto& p : kv) if (p.first == name) return p.second.c_str();
+        return nullptr;
+    }
+    void set(const char* name, const char* value) {
+        for (size_t i = 0; i < kv.size(); ++i)
+            if (kv[i].first == name) { if (value) kv[i].second = value; else kv.erase(kv.begin() + i); return; }
+        if (value) kv.emplace_back(name, value);
+    }
+    void load_environment();         // nrs_pose_only.hip: the one place that reads the environment
+    static const DebugOpts& process();
+};
+
 }  // namespace nrs
 
 struct nrs_ctx {
@@ -40,6 +60,8 @@ struct nrs_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     nrs_options opt;
+    nrs::DebugOpts dbg;              // debug / A-B switches: read once at nrs_create, changed by nrs_debug_set only
+    const char* env(const char* name) const { return dbg.get(name); }
     char err[512];
     nrs_profile prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -83,7 +105,7 @@ struct nrs_ctx {
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) return fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         b.cap = want;
-        if (getenv("NRS_POISON")) { (void)hipMemset(b.p, 0xFF, want); (void)hipDeviceSynchronize(); }     // (debug: a read of memory nobody wrote shows up as NaN)
+        if (env("NRS_POISON")) { (void)hipMemset(b.p, 0xFF, want); (void)hipDeviceSynchronize(); }     // (debug: a read of memory nobody wrote shows up as NaN)
         return NRS_OK;
     }
     void release(nrs::DevBuf& b) {

@@ -104,8 +104,8 @@ static void launch_reg2(nrs_ctx* c, const Dev& d, const double* xl, size_t shm, 
                 case 16: hipLaunchKernelGGL((k_lin_plain<16>), g, b, shm, c->stream, d, xl, cls); break;
                 default:
 #ifdef NRS_DEBUG_PROBES
-                    if (d.cam.model == 0 && tp && getenv("NRS_LIN_EXP")) {     // timing experiments (wrong results): a piece of the pass removed
-                        switch (atoi(getenv("NRS_LIN_EXP"))) {
+                    if (d.cam.model == 0 && tp && c->env("NRS_LIN_EXP")) {     // timing experiments (wrong results): a piece of the pass removed
+                        switch (atoi(c->env("NRS_LIN_EXP"))) {
                             case 1: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 1>), g, b, shm, c->stream, d, xl, cls); break;
                             case 2: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 2>), g, b, shm, c->stream, d, xl, cls); break;
                             case 3: hipLaunchKernelGGL((k_lin_plain<2, 4, 0, true, 3>), g, b, shm, c->stream, d, xl, cls); break;
@@ -200,7 +200,7 @@ static bool launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
 #ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one operator launch: make PROBES=1, then NRS_SPMV_DBG=1)
     long long* dbg = nullptr;
     static bool dbg_done = false;
-    if (d.h4 && it == 3 && !dbg_done && getenv("NRS_SPMV_DBG")) {  // phase clocks of one operator launch (100 MHz wall clock)
+    if (d.h4 && it == 3 && !dbg_done && c->env("NRS_SPMV_DBG")) {  // phase clocks of one operator launch (100 MHz wall clock)
         dbg_done = true;
         const size_t ns = (size_t)d.n_rows / (64 / d.T);
         if (hipMalloc((void**)&dbg, sizeof(long long) * 8 * ns) == hipSuccess) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * ns, c->stream); d.dbg_clk = dbg; }
@@ -245,7 +245,7 @@ static bool launch_spmv(nrs_ctx* c, const Dev& d0, double lam, int it, double to
         }
         const size_t shm = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + ((rc_of(d, cls) & 2) ? d.cap_h[cls] : d.cap_s[cls]) + 2);
         const bool last_cls = cls == 1 || d.sh_nt[1] + d.sh_ntb[1] == 0;
-        if (with_skin_op && last_cls && !(d.T == 2 && d.plain && d.tp_ok) && !getenv("NRS_SKIN_OP_OWN_LAUNCH")) {
+        if (with_skin_op && last_cls && !(d.T == 2 && d.plain && d.tp_ok) && !c->env("NRS_SKIN_OP_OWN_LAUNCH")) {
             const dim3 g2(g.x + d.sk_nblk);
             switch (d.T) {
                 case 1: hipLaunchKernelGGL((k_spmv_f_skin<1>), g2, b, shm, c->stream, d, lam, cls, it, tol2, (int)g.x); break;
@@ -283,7 +283,7 @@ static int evaluate(nrs_ctx* c, Engine* e, int which, bool reproj_done = false) 
     const Dev& d = e->d;
     const dim3 gg(((d.sh_ng + 7) / 8) * 8), b(BLK);
 #ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one lineariser launch: make PROBES=1, then NRS_LIN_DBG=1)
-    if (LIN && d.plain && getenv("NRS_LIN_DBG")) {
+    if (LIN && d.plain && c->env("NRS_LIN_DBG")) {
         // phase clocks of one lineariser launch (100 MHz wall clock): where a wave's time goes
         static bool done = false;
         if (!done) {
@@ -422,7 +422,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
     for (; it < stop; ++it) {
         const int pub = it + 1 == stop ? pub_seq : 0;
 #ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one fused PCG launch: make PROBES=1, then NRS_PCG_DBG=1)
-        if (d.fused && it == 20 && d.coarse && getenv("NRS_PCG_DBG")) {   // phase clocks of one fused launch (100 MHz wall clock), once
+        if (d.fused && it == 20 && d.coarse && c->env("NRS_PCG_DBG")) {   // phase clocks of one fused launch (100 MHz wall clock), once
             static bool dbg_done = false;
             if (!dbg_done) {
                 dbg_done = true;
@@ -463,14 +463,14 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             // frames of <= 32 tiles: every tile on a workgroup of ONE XCD (workgroups are dealt to the XCDs round-robin; the other seven
             // of every eight return at once) -- the vectors then stay in one L2 instead of being written through eight: 19.0 -> 18.0 us
             // per iteration all-in at 543 points, 22.8 -> 21.9 at 1013.  Placement only: the result does not depend on where a workgroup lands.
-            static const bool one_xcd_off = getenv("NRS_NO_ONE_XCD") != nullptr;
+            const bool one_xcd_off = c->env("NRS_NO_ONE_XCD") != nullptr;
             const bool one_xcd = !one_xcd_off && d.n_regblk <= 32;
             Dev d1 = d;
             d1.one_xcd = one_xcd ? 1 : 0;
             const Dev& d = d1;
             const dim3 g(one_xcd ? 8 * d.n_regblk : ((d.n_regblk + 7) / 8) * 8), bb(BLK);
             const size_t shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + (d.coarse ? 12 * (size_t)d.n_regblk + 16 * CO_MAX : 0));
-            static const bool check_fused = getenv("NRS_CHECK_FUSED") != nullptr;
+            const bool check_fused = c->env("NRS_CHECK_FUSED") != nullptr;
             if (check_fused && !d.coarse && d.T == 8) {
                 // debug: the same launch twice from the same state must leave the same bits in every array it writes
                 // (tools/flake_probe.py: run-to-run variation of the single-launch iteration)
@@ -572,7 +572,7 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
         if (d.sk_pcg) {                                            // embedded BA window: H u of the skinned observations' blocks (nrs_engine_skin.hpp)
             if (!skin_op_done) hipLaunchKernelGGL(k_skin_op, dim3(d.sk_nblk), dim3(BLK), 0, c->stream, d, it);
             // the row pass: inside k_pcg_update<true> (for the rows it updates) unless the update is the generic kernel's
-            skin_rows_fused = !d.sh_on && !d.hier && !d.ecd && !getenv("NRS_SKIN_ROWS_OWN_LAUNCH");
+            skin_rows_fused = !d.sh_on && !d.hier && !d.ecd && !c->env("NRS_SKIN_ROWS_OWN_LAUNCH");
             if (!skin_rows_fused) hipLaunchKernelGGL(k_skin_op_rows, dim3(d.n_rows / SK_RPB), dim3(BLK), 0, c->stream, d);
         }
         if (d.sh_on) {
@@ -621,8 +621,8 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     NRS_HIP(c, hipSetDevice(c->device));
     Dev& d = e->d;
     double lam = -1, ni = 2;
-    const bool peek_debug = getenv("NRS_PEEK_DEBUG") != nullptr;
-    const bool check_chi = getenv("NRS_CHECK_CHI") != nullptr;
+    const bool peek_debug = c->env("NRS_PEEK_DEBUG") != nullptr;
+    const bool check_chi = c->env("NRS_CHECK_CHI") != nullptr;
     double chi_carry = 0;
     const int peek_levels = peek_debug ? 4 : PEEK_LEVELS;
     for (int it = 0; it < iters; ++it) {
@@ -660,7 +660,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                 if (d.sh_on) NRS_TRY(c->comm->exchange(c, d.xl[trial], e->halo, c->stream));   // the regularisers read the neighbours' boundary keyframes
                 NRS_TRY(evaluate<false>(c, e, trial, one_pose));
                 NRS_TRY(read_scalars(c, e));               // one synchronisation: chi2, scale and the PCG flags
-                static const bool check_eval = getenv("NRS_CHECK_EVAL") != nullptr;
+                const bool check_eval = c->env("NRS_CHECK_EVAL") != nullptr;
                 if (check_eval) {                          // (debug: the same evaluation again on the same state must give the same bits)
                     const double chi1 = e->h_scal[SC_CHI], sc1 = e->h_scal[SC_SCALE];
                     NRS_TRY(evaluate<false>(c, e, trial, false));

@@ -455,8 +455,8 @@ int engine_build_edges_device(nrs_ctx* c, int n_kf, const int* kf_rowptr, const 
 }
 
 static bool devpack_eligible(nrs_ctx* c, const EngineSpec& s, int n_pad_rows) {
-    if (getenv("NRS_HOST_PACK") || getenv("NRS_NO_PLAIN") || getenv("NRS_NO_LDS") || getenv("NRS_DFORM") || getenv("NRS_NO_EDGE_CHI") || getenv("NRS_NO_FUSED") ||
-        getenv("NRS_SELL_T") || getenv("NRS_FUSED_MAX_ROWS") || getenv("NRS_TILE_CUT_PCT") || getenv("NRS_HIER") || getenv("NRS_NO_ECD"))
+    if (c->env("NRS_HOST_PACK") || c->env("NRS_NO_PLAIN") || c->env("NRS_NO_LDS") || c->env("NRS_DFORM") || c->env("NRS_NO_EDGE_CHI") || c->env("NRS_NO_FUSED") ||
+        c->env("NRS_SELL_T") || c->env("NRS_FUSED_MAX_ROWS") || c->env("NRS_TILE_CUT_PCT") || c->env("NRS_HIER") || c->env("NRS_NO_ECD"))
         return false;                                                // (test / A-B switches are honoured by the host path)
     if (c->comm || s.X0 || s.n_un || s.sp_active || s.dm_active || s.pose_fixed || s.force_gather || s.n_skin > 0) return false;
     if (s.K < 2 || n_pad_rows < 2048 || s.delta_pos > 0 || s.spring_form != 0 || s.n_dm <= 0 || s.n_sp <= 0) return false;   // (single-frame problems: a2, host)
@@ -488,7 +488,7 @@ int engine_edges_to_host(nrs_ctx* c, Engine* e, int* sp_ij, float* sp_d0, int* d
 static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine* e, bool* done) {
     *done = false;
     Dev& d = e->d;
-    const bool tm = getenv("NRS_TIMING") != nullptr;
+    const bool tm = c->env("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (!tm) return;
@@ -587,12 +587,12 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
     auto nb = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     // ---- row layout
     hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(1024), 0, st, M, r_x, mm);
-    hipLaunchKernelGGL(k_dp_morton, nb(M), dim3(256), 0, st, M, r_x, mm, getenv("NRS_NO_MORTON") ? 0 : 1, code_a, val_a);
+    hipLaunchKernelGGL(k_dp_morton, nb(M), dim3(256), 0, st, M, r_x, mm, c->env("NRS_NO_MORTON") ? 0 : 1, code_a, val_a);
     size_t tb = tmp_bytes;
     NRS_HIP(c, rocprim::segmented_radix_sort_pairs(tmp, tb, code_a, code_b, val_a, val_b, (size_t)M, (unsigned)K, d_pose_ptr, d_pose_ptr + 1, 0, 64, st));
     NRS_HIP(c, hipMemsetAsync(row_v, 0xFF, sizeof(int) * (size_t)n_rows, st));
     hipLaunchKernelGGL(k_dp_rows0, nb(M), dim3(256), 0, st, M, val_b, r_kf, d_pose_ptr, d_pgp, vrow, row_v);
-    if (!getenv("NRS_NO_TILE_SORT")) {
+    if (!c->env("NRS_NO_TILE_SORT")) {
         NRS_HIP(c, hipMemsetAsync(cs, 0, sizeof(int) * (size_t)M, st));
         NRS_HIP(c, hipMemsetAsync(cd, 0, sizeof(int) * (size_t)M, st));
         hipLaunchKernelGGL(k_dp_vcounts, nb(std::max(ni_s, ni_d)), dim3(256), 0, st, n_sp, r_sp, n_dm, r_dm, cs, cd);
@@ -678,7 +678,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         if (n_tiles >= 1024) {                                      // small problems are latency-bound: one launch
             const int p97 = sorted[(size_t)(0.97 * (n_tiles - 1))];
             const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
-            if (4 * d.max_halo > 5 * p97 && (n_tiles - (int)(0.97 * n_tiles) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
+            if (4 * d.max_halo > 5 * p97 && (n_tiles - (int)(0.97 * n_tiles) >= 1024 || !fits) && !c->env("NRS_ONE_CLASS")) cut = p97;
         }
         int n0 = 0;
         for (int b = 0; b < n_tiles; ++b) if (h_hs[b] <= cut) tile_list[n0++] = b;
@@ -726,7 +726,7 @@ static int engine_create_device(nrs_ctx* c, const EngineSpec& s, Arena* arena, E
         hipError_t he = hipMalloc((void**)&arena->base, want);
         if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
         arena->cap = want;
-        if (getenv("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
+        if (c->env("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
     }
     ArenaPlan real{arena, false};
     carve(real, d, false, nnz_s, nnz_d, (size_t)n_slices, n_halo, e);

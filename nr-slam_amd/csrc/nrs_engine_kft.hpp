@@ -225,27 +225,26 @@ __global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int
     double* Ps = sm;
     double* Cs = sm + KFT_B * KFT_LDP;
     double* colb = sm + 2 * KFT_B * KFT_LDP;
-    const int I = blockIdx.x, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int I = blockIdx.x, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15, lane = tid & 63, w = tid >> 6;
     const int ld = F.ld;
     double* A = F.A + (size_t)kf * ld * ld;
     const double* Pt = A + (size_t)(KFT_B * j) * ld + KFT_B * j;
+    const double* Ct = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
+    // both tiles through LDS: whole 512-byte rows per request (the register blocks and the matrix-core operands are read from there)
+    for (int q = tid; q < KFT_B * KFT_B; q += 256) {
+        const int r = q >> 6, cidx = q & 63;
+        Ps[r * KFT_LDP + cidx] = Pt[(size_t)r * ld + cidx];
+        Cs[r * KFT_LDP + cidx] = I != j ? Ct[(size_t)r * ld + cidx] : 0.0;
+    }
+    __syncthreads();
     double a[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) a[x][y] = Pt[(size_t)(4 * ti + x) * ld + 4 * tj + y];
-    double cI[4][4];
-    const double* Ct = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
-    if (I != j) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) cI[x][y] = Ct[(size_t)(4 * ti + x) * ld + 4 * tj + y];
-    }
+        for (int y = 0; y < 4; ++y) a[x][y] = Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y];
     bool bad = false;
     // scalar SWEEP(p), p = 0 .. 63, on the 4 x 4 register blocks: with the pivot column c (= row, by symmetry) and d = c_p,
     //   a_rc <- a_rc - c_r c_c / d  (r, c != p),  a_rp <- c_r / d,  a_pc <- c_c / d,  a_pp <- -1 / d
-    // -- all four cases are ONE expression once the pivot row / column entries are zeroed and c_p is replaced by -1 (no divergent code)
 #pragma unroll 1
     for (int pb = 0; pb < KFT_B / 4; ++pb) {                        // (four pivots per trip: the register block's column index is a constant in every copy)
 #pragma unroll
@@ -261,23 +260,22 @@ __global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int
             const bool ok = d > 0.0 && d < 1e300;
             bad = bad || !ok;
             d = ok ? d : 1.0;
-            const double inv = 1.0 / d;
+            double inv = __builtin_amdgcn_rcp(d);                  // (v_rcp_f64 + one Newton step: the division's ten dependent operations are on every thread's chain)
+            inv = fma(fma(-d, inv, 1.0), inv, inv);
             double cr[4], cc[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const bool rp = 4 * ti + x == p, cp = 4 * tj + x == p;
-                const double r0 = cb[4 * ti + x], c0 = cb[4 * tj + x];
-                cr[x] = rp ? -1.0 : r0;
-                cc[x] = (cp ? -1.0 : c0) * inv;
-            }
+            for (int x = 0; x < 4; ++x) { cr[x] = cb[4 * ti + x]; cc[x] = cb[4 * tj + x] * inv; }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    const bool piv = (4 * ti + x == p) | (4 * tj + y == p);
-                    const double a0 = piv ? 0.0 : a[x][y];
-                    a[x][y] = a0 - cr[x] * cc[y];
-                }
+                for (int y = 0; y < 4; ++y) a[x][y] -= cr[x] * cc[y];
+            // the pivot row, the pivot column and the pivot itself (the register block's row / column y0 in the threads that hold them)
+            const bool prow = ti == pb, pcol = tj == pb;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) a[y0][y] = prow ? cc[y] : a[y0][y];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[x][y0] = pcol ? cr[x] * inv : a[x][y0];
+            a[y0][y0] = (prow && pcol) ? -inv : a[y0][y0];
         }
     }
     if (bad && tid == 0) flags[2] = 1;
@@ -289,47 +287,47 @@ __global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                Pv[(4 * ti + x) * KFT_B + 4 * tj + y] = a[x][y];
-                Bb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = 0.0;
-                Cb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = 0.0;
-            }
+            for (int y = 0; y < 4; ++y) Pv[(4 * ti + x) * KFT_B + 4 * tj + y] = a[x][y];
+        for (int q = tid; q < KFT_B * KFT_B; q += 256) { Bb[q] = 0.0; Cb[q] = 0.0; }
         return;
     }
+    __syncthreads();                                                // (every register block has been read from Ps)
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
-            Cs[(4 * ti + x) * KFT_LDP + 4 * tj + y] = cI[x][y];
-        }
+        for (int y = 0; y < 4; ++y) Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
+    // C_I in the packed operand layout [k / 4][row][k % 4] (whole lines)
+    for (int q = tid; q < KFT_B * KFT_B; q += 256) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
     __syncthreads();
-    double bI[4][4];
+    // B_I = C_I P^-1 on the matrix cores: wave w its 16 rows, four 16-column tiles (P^-1 is symmetric: read by rows)
+    nd_v4d c[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) bI[x][y] = 0.0;
+        for (int g = 0; g < 4; ++g) c[n][g] = 0.0;
 #pragma unroll 4
-    for (int q = 0; q < KFT_B; ++q) {
-        double c4[4], p4[4];
+    for (int kq = 0; kq < KFT_B / 4; ++kq) {
+        const double av = Cs[(16 * w + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
+        double bv[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { c4[x] = Cs[(4 * ti + x) * KFT_LDP + q]; p4[x] = Ps[q * KFT_LDP + 4 * tj + x]; }
+        for (int n = 0; n < 4; ++n) bv[n] = Ps[(16 * n + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) bI[x][y] += c4[x] * p4[y];
+        for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
     }
+    // (wave w is the only reader of its rows of Cs: B_I takes their place)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Cs[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
+    __syncthreads();
     double* Bt = A + (size_t)(KFT_B * I) * ld + KFT_B * j;         // A_Ij <- B_I
     double* Btt = A + (size_t)(KFT_B * j) * ld + KFT_B * I;        // A_jI <- B_I^T
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            Bt[(size_t)(4 * ti + x) * ld + 4 * tj + y] = bI[x][y];
-            Btt[(size_t)(4 * tj + y) * ld + 4 * ti + x] = bI[x][y];
-            Bb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = bI[x][y];
-            Cb[((size_t)tj * KFT_B + 4 * ti + x) * 4 + y] = cI[x][y];
-        }
+    for (int q = tid; q < KFT_B * KFT_B; q += 256) {
+        const int r = q >> 6, cidx = q & 63;
+        Bt[(size_t)r * ld + cidx] = Cs[r * KFT_LDP + cidx];
+        Btt[(size_t)r * ld + cidx] = Cs[cidx * KFT_LDP + r];
+        Bb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, int kf1, int neg) {

@@ -87,7 +87,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         std::vector<size_t> fill(kp.begin(), kp.end() - 1);
         for (const KftEnt& x : pe) tmp[fill[x.key >> 24]++] = x;
         pe.swap(tmp);
-        const int nt = host_threads(pe.size());
+        const int nt = host_threads(c, pe.size());
         parallel_for(std::min(nt, K), [&](int ti, int n) {
             int64_t a, b;
             chunk(K, ti, n, a, b);

@@ -908,7 +908,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
         // Measured with 512-thread workgroups (round 5): the launch boundaries are the cheaper hand-over at every size -- 155 us per factorise +
         // solve against 163 chained at 543 points (everything resident), 201 / 223 at 1013, 480 / 501 at 4446 (top seven levels chained) -- so
         // the chained form is opt-in (NRS_ND_CHAIN=1, read when a plan is uploaded; the tests hold it to the per-level form bit for bit)
-        if (P.n_levels - S.chain_from < 2 || !getenv("NRS_ND_CHAIN")) S.chain_from = P.n_levels;
+        if (P.n_levels - S.chain_from < 2 || !c->env("NRS_ND_CHAIN")) S.chain_from = P.n_levels;
         for (size_t f = 0; f < P.fr.size(); ++f)
             if (P.fr[f].par >= 0 && lvl_of[f] >= S.chain_from) need[P.fr[f].par] += P.fr[f].nR * (P.fr[f].nR + 1) / 2;
         for (size_t w = 0; w < P.wg.size() / 3; ++w) { hw[w] = NdWgD{P.fr[P.wg[3 * w]], P.wg[3 * w + 1], P.wg[3 * w + 2], need[P.wg[3 * w]]}; hw[w].F.cmap_off = P.wg[3 * w]; }
@@ -925,7 +925,7 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     D.ev = S.d_ev;
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
     D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn); D.fcnt = reinterpret_cast<int*>(base + o_fc);
-    D.n_x3 = 3 * P.n_nodes; D.x_poll = getenv("NRS_ND_BACK_FLAGS") ? 0 : 1;
+    D.n_x3 = 3 * P.n_nodes; D.x_poll = c->env("NRS_ND_BACK_FLAGS") ? 0 : 1;
     NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, off - o_fl, c->stream));            // (status words and the fronts' flags)
     S.epoch = 0; S.chained = 0;
     // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
@@ -974,13 +974,13 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // dispatcher hands workgroups of a launch out in block-index order -- observed on every CDNA part, not promised by HIP; hence the
     // bounded spins in k_nd_level / k_nd_back (a wait that runs out raises flags[2] = 2 -> NRS_ERR_HIP, never a hang) and the
     // resident-at-once condition, under which the order does not matter at all.
-    const bool per_level = getenv("NRS_ND_LEVELS") != nullptr;     // (read per call: the tests switch it between solves)
+    const bool per_level = c->env("NRS_ND_LEVELS") != nullptr;     // (read per call: the tests switch it between solves)
     // 512 threads per workgroup unless NRS_ND_THREADS=256 (a level is one workgroup's latency: eight waves shorten its trailing updates,
     // its reads of the children's slots and its Schur tiles; same bits either way)
-    const char* nth_env = getenv("NRS_ND_THREADS");
+    const char* nth_env = c->env("NRS_ND_THREADS");
     const bool wide = !(nth_env && atoi(nth_env) == 256);
     // 32-column panel steps (k_nd_level<.., true>) unless NRS_ND_STEP32=0; same bits as the 16-column form
-    const char* s32_env = getenv("NRS_ND_STEP32");
+    const char* s32_env = c->env("NRS_ND_STEP32");
     const bool step32 = !(s32_env && atoi(s32_env) == 0);
     int first = 1;                                                 // (the first launch of the solve poisons xn)
     auto level = [&](int n, size_t shm, int wg0, int chained) {
@@ -995,7 +995,7 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
         // a CROWDED level (more workgroups than CUs: they would run in rounds, one per CU, each factorising its front's panel for one
         // tile) runs as two launches: the diagonal and inverse workgroups factorise and leave their rows of L21, k_nd_tile makes the
         // off-diagonal tiles from them (NRS_ND_NO_SPLIT=1: one launch per level throughout; the bits are the same)
-        const bool no_split = getenv("NRS_ND_NO_SPLIT") != nullptr;
+        const bool no_split = c->env("NRS_ND_NO_SPLIT") != nullptr;
         for (int l = 0; l < chain_from; ++l) {
             const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
             if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
@@ -1019,8 +1019,8 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
 }
 
 // leaf size of the dissection (nodes): ND_LEAFN unless NRS_ND_LEAF says otherwise (a tuning knob: part of the plan cache's key)
-static int nd_leaf_n() {
-    if (const char* v = getenv("NRS_ND_LEAF")) return std::max(4, std::min(ND_LEAFN, atoi(v)));
+static int nd_leaf_n(const nrs_ctx* c) {
+    if (const char* v = c->env("NRS_ND_LEAF")) return std::max(4, std::min(ND_LEAFN, atoi(v)));
     return ND_LEAFN;
 }
 void nd_orient_pairs(const NdPlan& P, const int32_t* pairs, const double* Vp, std::vector<double>& out);   // nrs_host_build.cpp
@@ -1032,7 +1032,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
     NRS_HIP(c, hipSetDevice(c->device));
     NdSolver S;
     std::string err;
-    if (!nd_build_plan(n_nodes, pos, last, n_pairs, pairs, S.plan, &err, nd_leaf_n())) return c->fail(NRS_ERR_INVALID, "direct solve: %s", err.c_str());
+    if (!nd_build_plan(n_nodes, pos, last, n_pairs, pairs, S.plan, &err, nd_leaf_n(c), ND_SMAXN, true, 0, c->env("NRS_ND_NO_COVER") == nullptr)) return c->fail(NRS_ERR_INVALID, "direct solve: %s", err.c_str());
     nd_stats(S.plan, stats);
     struct Rel { nrs_ctx* c; NdSolver* s; ~Rel() { (void)hipStreamSynchronize(c->stream); c->release(s->own); } } rel{c, &S};
     NRS_TRY(nd_upload(c, S));
@@ -1055,7 +1055,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
         NRS_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         if (ms_per_solve) *ms_per_solve = ms / repeats;
     }
-    if (getenv("NRS_ND_DBG")) {                                    // phase clocks of one solve: mean / max over the workgroups of every launch
+    if (c->env("NRS_ND_DBG")) {                                    // phase clocks of one solve: mean / max over the workgroups of every launch
         const size_t nw = S.plan.wg.size() / 3 + (size_t)S.plan.n_fronts;
         long long* clk = nullptr;
         NRS_HIP(c, hipMalloc((void**)&clk, sizeof(long long) * 8 * nw));
@@ -1089,7 +1089,7 @@ int engine_nd_debug_solve(nrs_ctx* c, int n_nodes, const double* pos, const uint
             for (int w = a; w < b2; ++w) {
                 const long long* q = &h[8 * (P.wg.size() / 3 + (size_t)w)];
                 if (q[3] == 0) continue;                            // (a root)
-                if (b2 - a <= 2 && getenv("NRS_ND_DBG2")) fprintf(stderr, "   front %d (s %d b %d nseg %d): start %.1f seg-loop-begin %.1f released %.1f gathered %.1f gemv %.1f end %.1f\n", w, P.fr[P.lvl_fronts[w]].s, P.fr[P.lvl_fronts[w]].b, P.fr[P.lvl_fronts[w]].n_seg, (q[0]-t00)/100.0, (q[5]-t00)/100.0, (q[4]-t00)/100.0, (q[1]-t00)/100.0, (q[2]-t00)/100.0, (q[3]-t00)/100.0);
+                if (b2 - a <= 2 && c->env("NRS_ND_DBG2")) fprintf(stderr, "   front %d (s %d b %d nseg %d): start %.1f seg-loop-begin %.1f released %.1f gathered %.1f gemv %.1f end %.1f\n", w, P.fr[P.lvl_fronts[w]].s, P.fr[P.lvl_fronts[w]].b, P.fr[P.lvl_fronts[w]].n_seg, (q[0]-t00)/100.0, (q[5]-t00)/100.0, (q[4]-t00)/100.0, (q[1]-t00)/100.0, (q[2]-t00)/100.0, (q[3]-t00)/100.0);
                 // (single launch: [4] = released by the parent; "loads" is then the gather of the boundary values only)
                 for (int k = 0; k < 3; ++k) { const double d = (double)(q[k + 1] - (k == 0 && q[4] ? q[4] : q[k])) / 100.0; mean[k] += d / (b2 - a); mx[k] = std::max(mx[k], d); }
                 lo = std::min(lo, q[4] ? q[4] : q[0]); hi = std::max(hi, q[3]);
@@ -1342,8 +1342,8 @@ static inline uint64_t nd_hash(const uint8_t* p, size_t n) {
 // Ahead at every measured size; the default window ends where nothing has been measured.
 static bool nd_mode_allows(nrs_ctx* c, int n_free) {
     int mode = c->opt.direct_solve;
-    if (const char* ev = getenv("NRS_ND")) mode = atoi(ev) ? 1 : 2;
-    const int nmax = getenv("NRS_ND_MAX_ROWS") ? atoi(getenv("NRS_ND_MAX_ROWS")) : 8000;
+    if (const char* ev = c->env("NRS_ND")) mode = atoi(ev) ? 1 : 2;
+    const int nmax = c->env("NRS_ND_MAX_ROWS") ? atoi(c->env("NRS_ND_MAX_ROWS")) : 8000;
     return mode != 2 && n_free > 0 && (mode == 1 || n_free <= nmax);
 }
 static bool nd_wanted(nrs_ctx* c, const Dev& d, int n_free) {
@@ -1443,14 +1443,14 @@ static void nd_prep_run(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     catch (...) { P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.err = "unknown exception in the plan thread"; }
 }
 // halves of a dissection of this many nodes go to threads of their own (first two levels; NRS_ND_PLAN_PAR=0: never; NRS_HOST_THREADS=1 likewise)
-static int nd_plan_par_min() {
-    if (const char* v = getenv("NRS_ND_PLAN_PAR")) return atoi(v);
-    if (const char* v = getenv("NRS_HOST_THREADS")) if (atoi(v) <= 1) return 0;
+static int nd_plan_par_min(const nrs_ctx* c) {
+    if (const char* v = c->env("NRS_ND_PLAN_PAR")) return atoi(v);
+    if (const char* v = c->env("NRS_HOST_THREADS")) if (atoi(v) <= 1) return 0;
     return std::thread::hardware_concurrency() >= 4 ? 700 : 0;
 }
 static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     P.wanted = false; P.plan_ok = false; P.hit = nullptr; P.st.reset();
-    const bool tm = getenv("NRS_TIMING") != nullptr;
+    const bool tm = c->env("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     double t_ms[3] = {0, 0, 0};                                    // key + look-up, pairs, plan
     auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); t_ms[k] = std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
@@ -1468,7 +1468,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     {
         std::vector<uint8_t> bits(in.M);
         for (int v = 0; v < in.M; ++v) bits[v] = in.rflag[v] & (RF_FIXED | RF_OBS);
-        const int hdr[8] = {n_free, P.pose_free ? 1 : 0, in.M, in.n_skin, nd_leaf_n(), ND_SMAXN, in.n_sp, in.n_dm};
+        const int hdr[8] = {n_free, P.pose_free ? 1 : 0, in.M, in.n_skin, nd_leaf_n(c), ND_SMAXN, in.n_sp, in.n_dm};
         std::vector<uint8_t>& key = P.key;
         key.clear();
         auto put = [&](const void* p, size_t bytes) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + bytes); };
@@ -1481,7 +1481,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     // the cache (read only here: nobody changes it while an engine is being set up).  A frame whose key an earlier one had takes
     // that one's plan and structure as they are; only the skinning weights are its own.
     const NdCache* nc = static_cast<const NdCache*>(c->nd_cache);
-    if (nc && !getenv("NRS_ND_NO_CACHE"))
+    if (nc && !c->env("NRS_ND_NO_CACHE"))
         for (NdSlot* sl : nc->slots)
             if (!sl->busy && sl->st && sl->hash == P.hash && sl->key == P.key) {
                 P.hit = sl; P.st = sl->st;
@@ -1581,7 +1581,7 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
     std::vector<double> pos(3 * (size_t)n_nodes, 0.0);
     for (int a = 0; a < n_free; ++a)
         for (int k = 0; k < 3; ++k) pos[3 * (size_t)a + k] = in.vpos[3 * (size_t)P.node_vtx[a] + k];
-    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, nd_leaf_n(), ND_SMAXN, false, nd_plan_par_min());
+    P.plan_ok = nd_build_plan(n_nodes, pos.data(), P.last.data(), (int)T.pkind.size(), T.pairs.data(), P.plan, &P.err, nd_leaf_n(c), ND_SMAXN, false, nd_plan_par_min(c), c->env("NRS_ND_NO_COVER") == nullptr);
     if (P.plan_ok && in.n_skin > 0) { nd_prep_ske(P, P.plan); nd_prep_ske_values(P, in.sk_om); }
     lap(2);
     if (tm) fprintf(stderr, "[nrs] direct solve set-up thread: key %.2f ms, pairs %.2f ms, plan %.2f ms\n", t_ms[0], t_ms[1], t_ms[2]);
@@ -1591,12 +1591,12 @@ static void nd_prep_run_body(nrs_ctx* c, const NdIn& in, NdPrep& P) {
 static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     Dev& d = e->d;
     {
-        const bool tm = getenv("NRS_TIMING") != nullptr;
+        const bool tm = c->env("NRS_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         if (P.th.joinable()) P.th.join();
         if (tm) fprintf(stderr, "[nrs] direct solve: waited %.2f ms for the plan thread\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
-    const bool tmf = getenv("NRS_TIMING") != nullptr;
+    const bool tmf = c->env("NRS_TIMING") != nullptr;
     auto tf_prev = std::chrono::steady_clock::now();
     auto lapf = [&](const char* what) {
         if (!tmf) return;
@@ -1616,7 +1616,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     if (!hit) {
         if (P.hit) return c->fail(NRS_ERR_STATE, "direct solve: the plan this engine was set up on was taken by another engine meanwhile (engines of one context are created one at a time)");
         if (!P.plan_ok) {
-            if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", P.err.c_str());
+            if (c->env("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", P.err.c_str());
             return NRS_OK;
         }
         ++nc->misses;
@@ -1642,7 +1642,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         if (!sl) { sl = new (std::nothrow) NdSlot(); if (!sl) return c->fail(NRS_ERR_ALLOC, "out of host memory"); }
     } else {
         ++nc->hits;
-        if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve: plan of an earlier frame reused (%llu reused, %llu built)\n", (unsigned long long)nc->hits, (unsigned long long)nc->misses);
+        if (c->env("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve: plan of an earlier frame reused (%llu reused, %llu built)\n", (unsigned long long)nc->hits, (unsigned long long)nc->misses);
     }
     struct SlotGuard {                                             // a slot whose set-up fails holds nothing valid
         nrs_ctx* c; NdSlot* sl; bool keep = false;
@@ -1654,7 +1654,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
         sl->S.plan = std::move(P.plan);
         const int up = nd_upload(c, sl->S);
         if (up == NRS_ERR_INVALID) {                               // a front or a boundary beyond the LDS: like a plan that could not be built -- the PCG takes the problem
-            if (getenv("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", c->err);
+            if (c->env("NRS_TIMING")) fprintf(stderr, "[nrs] direct solve not used: %s\n", c->err);
             return NRS_OK;                                         // (sguard leaves the slot empty; nd->on stays false; the embedded mode reports it, engine_create)
         }
         if (up != NRS_OK) return up;
@@ -1726,7 +1726,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     nd->slot = sl; nd->on = true;
     if (!hit) { sl->key.swap(P.key); sl->hash = P.hash; sl->st = P.st; }
     sguard.keep = true;
-    if (getenv("NRS_TIMING"))
+    if (c->env("NRS_TIMING"))
         fprintf(stderr, "[nrs] direct solve: %d free rows, %d pairs, %d fronts on %d levels, %d workgroups, %.1f MFLOP per factorisation\n", sl->n_free,
                 sl->n_pairs, sl->S.plan.n_fronts, sl->S.plan.n_levels, (int)sl->S.plan.wg.size() / 3, sl->S.plan.flops / 1e6);
     return NRS_OK;

@@ -137,15 +137,15 @@ static int h2d_rows(nrs_ctx* c, const Dev& d, Tp* dst, const std::vector<Tp>& sr
 // Host-side set-up work split over a few threads.  Every use below is order-free (disjoint outputs, or integer counts) or
 // reproduces the sequential order (a thread owns a range of ROWS and scans the edges in edge order): the packed problem is
 // the same bits for any thread count (tests/test_gpu_scale.py).
-static int host_threads(size_t work) {
+static int host_threads(const nrs_ctx* c, size_t work) {
     if (work < 600000) {
         // single-frame problems (a 4.5k-point frame: 0.3 M incidences): sixteen threads per stage cost more than they save (8 ms per frame,
         // round 2); NRS_HOST_THREADS_SMALL=<n> tries a few (round 5: see profiles/README.md)
-        if (const char* ev = getenv("NRS_HOST_THREADS_SMALL")) if (work >= 100000) return std::max(1, std::min(8, atoi(ev)));
+        if (const char* ev = c->env("NRS_HOST_THREADS_SMALL")) if (work >= 100000) return std::max(1, std::min(8, atoi(ev)));
         return 1;
     }
     int n = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* ev = getenv("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
+    if (const char* ev = c->env("NRS_HOST_THREADS")) n = std::max(1, std::min(64, atoi(ev)));
     return n;
 }
 // plain two-kernel windows whose rows all know their temporal partners: the dampers' 8-byte headers {o0, o1, o2, meta} shrink
@@ -161,13 +161,13 @@ __global__ void k_compact_headers(size_t n, const uint2* __restrict__ hdr, uint3
 static void engine_compact_headers(nrs_ctx* c, Engine* e) {
     Dev& d = e->d;
     d.h4 = 0; d.rc = 0; d.nt = 0;
-    if (!(d.plain && d.tp_ok && d.use_lds && !d.fused && d.T == 2) || getenv("NRS_NO_H4")) return;
+    if (!(d.plain && d.tp_ok && d.use_lds && !d.fused && d.T == 2) || c->env("NRS_NO_H4")) return;
     if (d.tile_rows + std::max(d.cap_h[0], d.cap_h[1]) + 2 >= 4096 || d.sd_nnz <= 0) return;
     hipLaunchKernelGGL(k_compact_headers, dim3((unsigned)(((size_t)d.sd_nnz + 255) / 256)), dim3(256), 0, c->stream, (size_t)d.sd_nnz, d.d_hdr, d.d_h4);
     d.h4 = 1;
-    if (const char* v = getenv("NRS_RC")) d.rc = atoi(v) & 3;
+    if (const char* v = c->env("NRS_RC")) d.rc = atoi(v) & 3;
     d.nt = 12 * ((size_t)d.ss_nnz + (size_t)d.sd_nnz) > ((size_t)128 << 20);   // the streams (with the vectors next to them) do not stay in the 256 MB Infinity Cache between launches
-    if (const char* v = getenv("NRS_NT")) d.nt = atoi(v) != 0;
+    if (const char* v = c->env("NRS_NT")) d.nt = atoi(v) != 0;
 }
 
 template <class F>
@@ -191,7 +191,7 @@ static inline void count_up(int* p, int nt) { if (nt == 1) ++*p; else __atomic_f
 static int push_masks(nrs_ctx* c, Engine* e, const uint8_t* sp_active, const uint8_t* dm_active) {
     Dev& d = e->d;
     auto vfixed = [&](int v) { return (e->h_rflag[e->vrow[v]] & RF_FIXED) != 0; };
-    const int nt = host_threads((size_t)d.n_sp + (size_t)d.n_dm);
+    const int nt = host_threads(c, (size_t)d.n_sp + (size_t)d.n_dm);
     parallel_for(nt, [&](int ti, int n_thr) {                     // every edge writes its own incidence slots
     int64_t q0, q1;
     chunk(d.n_sp, ti, n_thr, q0, q1);
@@ -297,7 +297,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         if (s.K < c->comm->world) return c->fail(NRS_ERR_INVALID, "sharded solve: %d keyframes cannot be split over %d ranks", s.K, c->comm->world);
     }
     c->err_local = true;                                           // from here on a failure may be this rank's alone: the caller lets the ranks agree
-    const bool tm = getenv("NRS_TIMING") != nullptr;
+    const bool tm = c->env("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (!tm) return;
@@ -347,7 +347,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         nd_in.n_sp = s.n_sp; nd_in.sp_ij = s.sp_ij; nd_in.n_dm = s.n_dm; nd_in.dm_idx = s.dm_idx;
         nd_in.n_skin = s.n_skin; nd_in.sk_vert = s.sk_node; nd_in.sk_om = s.sk_om;
         nd_in.vpos = e->nd->pos.data();
-        bool inline_run = getenv("NRS_HOST_THREADS") && atoi(getenv("NRS_HOST_THREADS")) <= 1;
+        bool inline_run = c->env("NRS_HOST_THREADS") && atoi(c->env("NRS_HOST_THREADS")) <= 1;
         if (!inline_run) {
             try { nd_prep.th = std::thread([c, &nd_in, &nd_prep] { nd_prep_run(c, nd_in, nd_prep); }); }
             catch (const std::system_error&) { inline_run = true; }
@@ -355,7 +355,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         if (inline_run) nd_prep_run(c, nd_in, nd_prep);
     }
     int T = n_pad_rows >= 32768 ? 2 : 8;
-    if (const char* ev = getenv("NRS_SELL_T")) {
+    if (const char* ev = c->env("NRS_SELL_T")) {
         const int v = atoi(ev);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) T = v;
     }
@@ -367,7 +367,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     d.info_spatial = s.info_spatial; d.delta_spatial = s.delta_spatial;
     d.k_spring = s.k_spring; d.spring_form = s.spring_form;
 
-    const int nt_all = host_threads(2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm + (size_t)s.n_un);   // one decision for every set-up stage
+    const int nt_all = host_threads(c, 2 * (size_t)s.n_sp + 4 * (size_t)s.n_dm + (size_t)s.n_un);   // one decision for every set-up stage
     // ---- row layout: pose-major, each pose padded to ROW_ALIGN rows, Morton order inside
     std::vector<int> pose_ptr(s.K + 1, 0);
     for (int i = 0; i < s.M; ++i) pose_ptr[s.lm_pose[i] + 1]++;
@@ -398,7 +398,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             v = (v | v << 2) & 0x1249249249249249ULL;
             return v;
         };
-        const bool morton = getenv("NRS_NO_MORTON") == nullptr;
+        const bool morton = c->env("NRS_NO_MORTON") == nullptr;
         const int nt_rows = nt_all;
         parallel_for(std::min(nt_rows, s.K), [&](int ti, int nt) {
         std::vector<std::pair<uint64_t, int>> keys;
@@ -424,7 +424,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // Inside a tile the row order is free (neighbour ids are tile-local, the vector kernels stream): rows are sorted
     // by their incidence counts, so that the rows of a slice (64 / T consecutive rows share the slice's width) have
     // similar counts.  C2: sliced-ELL padding 1.34x / 1.37x (springs / dampers) -> 1.22x / 1.15x of the incidences.
-    if (!getenv("NRS_NO_TILE_SORT")) {
+    if (!c->env("NRS_NO_TILE_SORT")) {
         std::vector<int> cs(s.M, 0), cd(s.M, 0);
         const int nt = nt_all;
         parallel_for(nt, [&](int ti, int n) {                      // integer counts: order-free
@@ -465,7 +465,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // Rows of other ranks keep empty lists: their tiles never run here, and what this rank's tiles read of them are
     // vector rows (the boundary-keyframe exchange), not records.  Packing time and record memory scale with 1 / ranks.
     int pack_lo = 0, pack_hi = d.n_rows;
-    if (c->comm && s.shard && c->comm->world <= 8 && s.K >= c->comm->world && !getenv("NRS_SHARD_PACK_ALL")) {
+    if (c->comm && s.shard && c->comm->world <= 8 && s.K >= c->comm->world && !c->env("NRS_SHARD_PACK_ALL")) {
         std::vector<int> kb0(c->comm->world + 1);
         shard_plan(s.K, pose_grp_ptr.data(), c->comm->world, kb0.data());
         pack_lo = pose_grp_ptr[kb0[c->comm->rank]] * ROW_ALIGN;
@@ -588,11 +588,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     // and keeps the generic four-vertex records)
     std::vector<int> nxt_row, prv_row;
     {
-        const int fused_max0 = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
-        bool plain = !s.X0 && s.n_un == 0 && s.n_dm > 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !getenv("NRS_NO_EDGE_CHI") && getenv("NRS_DFORM") &&
-                     !getenv("NRS_NO_LDS") && !s.force_gather;
+        const int fused_max0 = c->env("NRS_FUSED_MAX_ROWS") ? atoi(c->env("NRS_FUSED_MAX_ROWS")) : 32768;
+        bool plain = !s.X0 && s.n_un == 0 && s.n_dm > 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !c->env("NRS_NO_EDGE_CHI") && c->env("NRS_DFORM") &&
+                     !c->env("NRS_NO_LDS") && !s.force_gather;
         for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
-        const bool two_kernel = d.n_rows >= fused_max0 || getenv("NRS_NO_FUSED") || (c->comm && s.shard);
+        const bool two_kernel = d.n_rows >= fused_max0 || c->env("NRS_NO_FUSED") || (c->comm && s.shard);
         if (plain && two_kernel) {
             nxt_row.assign(d.n_rows, -1); prv_row.assign(d.n_rows, -1);
             for (int q = 0; q < s.n_dm && plain; ++q) {
@@ -618,7 +618,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     {
         // tiles are independent: a few host threads each take a contiguous range of tiles
         int nt = std::max(1, std::min({8, (int)std::thread::hardware_concurrency(), d.n_regblk / 32}));   // (a 4.5k-point frame: 4 threads, 1.5 -> 0.5 ms)
-        if (const char* ev = getenv("NRS_HOST_THREADS")) nt = std::max(1, std::min({64, atoi(ev), std::max(1, d.n_regblk)}));
+        if (const char* ev = c->env("NRS_HOST_THREADS")) nt = std::max(1, std::min({64, atoi(ev), std::max(1, d.n_regblk)}));
         std::vector<std::vector<int>> part(nt);
         std::vector<int> cnt(d.n_regblk, 0);
         auto work = [&](int ti) {
@@ -677,10 +677,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
             // for the bulk to fit the LDS budget at all)
             const int p97 = sorted[(size_t)(0.97 * (d.n_regblk - 1))];
             const bool fits = sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.max_halo + d.max_halo_s + 2) <= 48 * 1024;
-            if (4 * d.max_halo > 5 * p97 && (d.n_regblk - (int)(0.97 * d.n_regblk) >= 1024 || !fits) && !getenv("NRS_ONE_CLASS")) cut = p97;
+            if (4 * d.max_halo > 5 * p97 && (d.n_regblk - (int)(0.97 * d.n_regblk) >= 1024 || !fits) && !c->env("NRS_ONE_CLASS")) cut = p97;
         }
-        if (getenv("NRS_TILE_CUT_PCT")) {                          // test switch: force a split at a percentile
-            const double pct = atof(getenv("NRS_TILE_CUT_PCT")) / 100.0;
+        if (c->env("NRS_TILE_CUT_PCT")) {                          // test switch: force a split at a percentile
+            const double pct = atof(c->env("NRS_TILE_CUT_PCT")) / 100.0;
             cut = sorted[(size_t)(pct * (d.n_regblk - 1))];
         }
         int n0 = 0;
@@ -707,16 +707,16 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(d.tile_rows + d.cap_h[cls]) * (s.X0 ? 2 : 1));                          // linearise
         lds_need = std::max(lds_need, sizeof(double) * 3 * (size_t)(2 * d.tile_rows + d.cap_h[cls] + d.cap_s[cls] + 2));                    // operator: u + positions
     }
-    if (getenv("NRS_NO_LDS") || s.force_gather || lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
+    if (c->env("NRS_NO_LDS") || s.force_gather || lds_need > 64 * 1024 - 512 || d.tile_rows + d.max_halo >= 65535) d.use_lds = 0;   // irregular graph / A-B switch
     if (!d.use_lds) d.dform = 0;
     d.lin_rb = d.use_lds ? ROW_ALIGN / d.tile_rows : 1;              // lineariser partials: per tile (LDS path) or per group
     // single-launch PCG iteration for problems that are bound by launch latency, not by traffic
-    const int fused_max = getenv("NRS_FUSED_MAX_ROWS") ? atoi(getenv("NRS_FUSED_MAX_ROWS")) : 32768;
-    d.fused = (d.use_lds && d.n_rows < fused_max && !getenv("NRS_NO_FUSED")) ? 1 : 0;
+    const int fused_max = c->env("NRS_FUSED_MAX_ROWS") ? atoi(c->env("NRS_FUSED_MAX_ROWS")) : 32768;
+    d.fused = (d.use_lds && d.n_rows < fused_max && !c->env("NRS_NO_FUSED")) ? 1 : 0;
     if (s.n_skin > 0) d.fused = 0;                                 // embedded mode: the skinned observations' operator kernels sit between the two launches of an iteration
-    d.hier = (d.n_regblk > 4096 || getenv("NRS_HIER")) ? 1 : 0;
+    d.hier = (d.n_regblk > 4096 || c->env("NRS_HIER")) ? 1 : 0;
     // (a profiling context times full operator launches only: no convergence-detecting early exits)
-    d.ecd = (d.use_lds && !d.fused && !c->opt.profile && !getenv("NRS_NO_ECD")) ? 1 : 0;
+    d.ecd = (d.use_lds && !d.fused && !c->opt.profile && !c->env("NRS_NO_ECD")) ? 1 : 0;
     // two-level preconditioner: fused path, one pose, small enough coarse system
     d.co_n = 3 * d.n_groups + 6;
     // (worth its per-iteration cost on the pose + deformation problems; the lost-point stage, pose
@@ -725,9 +725,9 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     const size_t fused_shm = sizeof(double) * (6 * (size_t)(d.tile_rows + d.max_halo) + 12 * (size_t)d.n_regblk + 16 * CO_MAX);
     // (and only from ~1.5k rows on: below, its per-iteration cost outweighs the iterations it saves -- 1013 points 31.3 ms with it,
     // 29.2 without; 2220 points 47.4 / 51.8; 4525 points 76.7 / 94.1, tools/small_frame_probe.py)
-    const int co_min_tiles = getenv("NRS_COARSE_MIN_TILES") ? atoi(getenv("NRS_COARSE_MIN_TILES")) : 48;
+    const int co_min_tiles = c->env("NRS_COARSE_MIN_TILES") ? atoi(c->env("NRS_COARSE_MIN_TILES")) : 48;
     d.coarse = (d.fused && s.K == 1 && pose_free && d.co_n <= CO_MAX && d.n_regblk <= BLK && d.n_regblk >= co_min_tiles && fused_shm <= 63 * 1024 &&
-                !getenv("NRS_NO_COARSE")) ? 1 : 0;
+                !c->env("NRS_NO_COARSE")) ? 1 : 0;
     // ---- shard window: the whole problem, or this rank's contiguous range of poses (balanced by rows)
     d.sh_on = 0; d.sh_rank = 0; d.sh_world = 1; d.sh_lead = 1;
     d.sh_k0 = 0; d.sh_nk = s.K; d.sh_g0 = 0; d.sh_ng = d.n_groups; d.sh_vb0 = 0; d.sh_nvb = d.n_vecblk;
@@ -763,7 +763,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         // ... so the rank holds the per-row arrays (state, vectors, diagonal blocks: ~410 bytes a row) of its own keyframes and of ONE ghost
         // keyframe either side only: its tiles' halos end there (just checked), the boundary exchange fills the ghosts, and no launch of
         // this rank touches a row beyond them (ArenaPlan::get_rows).  NRS_SHARD_FULL_VECTORS=1: every row, the round-1..4 form.
-        if (W > 1 && !d.dform && !getenv("NRS_SHARD_FULL_VECTORS")) { d.row_lo = r_lo; d.row_hi = r_hi; }
+        if (W > 1 && !d.dform && !c->env("NRS_SHARD_FULL_VECTORS")) { d.row_lo = r_lo; d.row_hi = r_hi; }
         // boundary tiles (their halo holds rows of another rank) sit at the two ends of the rank's tile range:
         // they run after the interior tiles, once the neighbours' rows have arrived
         const int own_lo = d.sh_g0 * ROW_ALIGN, own_hi = (d.sh_g0 + d.sh_ng) * ROW_ALIGN;
@@ -806,11 +806,11 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     std::vector<EcDamper> ec_dm;
     std::vector<float> ec_w;
     {
-        bool plain = !s.X0 && s.n_un == 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !getenv("NRS_NO_EDGE_CHI");
+        bool plain = !s.X0 && s.n_un == 0 && !s.sp_active && !s.dm_active && !s.pose_fixed && !c->env("NRS_NO_EDGE_CHI");
         for (int v = 0; v < s.M && plain; ++v) plain = !(s.rflag[v] & RF_FIXED);
         d.ec_on = plain ? 1 : 0;
         {   // the specialised lineariser additionally wants every damper with its four vertices and springs without a kernel
-            bool p4 = plain && d.use_lds && !d.dform && !(s.delta_pos > 0) && s.spring_form == 0 && !getenv("NRS_NO_PLAIN");
+            bool p4 = plain && d.use_lds && !d.dform && !(s.delta_pos > 0) && s.spring_form == 0 && !c->env("NRS_NO_PLAIN");
             for (int64_t q = 0; q < 4 * (int64_t)s.n_dm && p4; ++q) p4 = s.dm_idx[q] >= 0;
             d.plain = p4 ? 1 : 0;
             if (d.plain) d.lin_rb = ROW_ALIGN / (64 / T);          // k_lin_plain leaves one partial slot per SLICE (no workgroup barrier behind its loops)
@@ -908,7 +908,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         hipError_t he = hipMalloc((void**)&arena->base, want);
         if (he != hipSuccess) return c->fail(NRS_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(he));
         arena->cap = want;
-        if (getenv("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
+        if (c->env("NRS_POISON")) { (void)hipMemset(arena->base, 0xFF, want); (void)hipDeviceSynchronize(); }    // (debug: a read of memory nobody wrote shows up as NaN)
     }
     ArenaPlan real{arena, false};
     carve(real, d, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), e);

@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/nrs.h"
+namespace nrs { const char* process_debug_option(const char* name); }   // nrs_pose_only.hip: the process-wide snapshot of the NRS_* switches
 
 namespace {
 constexpr int kRegularizersPerPoint = 10;      // OPT:958
@@ -135,7 +136,7 @@ extern "C" int nrs_dba_build_edges(int32_t n_kf, const int32_t* kf_rowptr, const
     int nt = 1;
     if (n_kf > 1 && kf_rowptr[n_kf] >= 20000) {
         nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-        if (const char* ev = getenv("NRS_HOST_THREADS")) nt = std::max(1, std::min(64, atoi(ev)));
+        if (const char* ev = nrs::process_debug_option("NRS_HOST_THREADS")) nt = std::max(1, std::min(64, atoi(ev)));
         nt = std::min(nt, n_kf);
     }
     std::vector<int64_t> cs((size_t)n_kf + 1, 0), cd((size_t)n_kf + 1, 0);

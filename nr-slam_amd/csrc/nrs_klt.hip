@@ -655,6 +655,9 @@ __global__ __launch_bounds__(256) void k_klt_copy_templates(int n, const int* __
     for (int e = threadIdx.x; e < lv; e += 256) dV[d_o + e] = sV[so + e];
 }
 
+// The archive is DENSE by key (a map point id indexes its slot: no lookup on the device): KA x levels x 6 bytes per key, so the key range is bounded --
+// 2^20 map points = 2.9 GB at 5 levels; the reference's maps hold thousands (include/nrs.h nrs_klt_archive_templates)
+constexpr int NRS_KLT_ARCHIVE_MAX_KEY = 1 << 20;
 static int klt_archive_reserve(nrs_ctx* c, KltState* k, int cap_want) {
     if (k->a_levels != k->levels && k->a_cap > 0) {                // (another level count: the archive starts over)
         NRS_HIP(c, hipStreamSynchronize(c->stream));
@@ -673,11 +676,15 @@ static int klt_archive_reserve(nrs_ctx* c, KltState* k, int cap_want) {
     if (rc != NRS_OK) { c->release(nI); c->release(nD); c->release(nM); c->release(nV); return rc; }
     if (k->a_cap > 0) {
         const size_t m = (size_t)k->a_cap;
-        NRS_HIP(c, hipMemcpyAsync(nI.p, k->aI.p, sizeof(short) * KA * L * m, hipMemcpyDeviceToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(nD.p, k->aD.p, sizeof(short2) * KA * L * m, hipMemcpyDeviceToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(nM.p, k->aMean.p, sizeof(float) * 2 * L * m, hipMemcpyDeviceToDevice, c->stream));
-        NRS_HIP(c, hipMemcpyAsync(nV.p, k->aValid.p, L * m, hipMemcpyDeviceToDevice, c->stream));
-        NRS_HIP(c, hipStreamSynchronize(c->stream));
+        hipError_t he = hipMemcpyAsync(nI.p, k->aI.p, sizeof(short) * KA * L * m, hipMemcpyDeviceToDevice, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(nD.p, k->aD.p, sizeof(short2) * KA * L * m, hipMemcpyDeviceToDevice, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(nM.p, k->aMean.p, sizeof(float) * 2 * L * m, hipMemcpyDeviceToDevice, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(nV.p, k->aValid.p, L * m, hipMemcpyDeviceToDevice, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) {                                    // (the new buffers do not outlive a failed copy; the archive stays as it was)
+            c->release(nI); c->release(nD); c->release(nM); c->release(nV);
+            return c->fail(NRS_ERR_HIP, "template archive: copy to the grown buffers failed: %s", hipGetErrorString(he));
+        }
     }
     c->release(k->aI); c->release(k->aD); c->release(k->aMean); c->release(k->aValid);
     k->aI = nI; k->aD = nD; k->aMean = nM; k->aValid = nV;
@@ -695,7 +702,7 @@ extern "C" int nrs_klt_archive_templates(nrs_ctx* c, int32_t n, const int32_t* s
     int kmax = -1;
     for (int i = 0; i < n; ++i) {
         if (slots[i] < 0 || slots[i] >= k->n) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: slot %d out of range", slots[i]);
-        if (keys[i] < 0 || keys[i] > (1 << 26)) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: key %d out of range", keys[i]);
+        if (keys[i] < 0 || keys[i] >= NRS_KLT_ARCHIVE_MAX_KEY) return c->fail(NRS_ERR_INVALID, "nrs_klt_archive_templates: key %d out of range (the archive is dense by key: keys below %d)", keys[i], NRS_KLT_ARCHIVE_MAX_KEY);
         kmax = std::max(kmax, keys[i]);
     }
     NRS_HIP(c, hipSetDevice(c->device));

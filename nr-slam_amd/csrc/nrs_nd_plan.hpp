@@ -78,7 +78,7 @@ struct NdPlan {
 // n_nodes nodes at pos (geometry of the dissection), `last` nodes (the pose halves) are eliminated at the root whatever
 // their position; pairs: unique unordered couplings (a, b), a != b.  Returns false (err set) if the plan cannot be built.
 inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, int n_pairs, const int* pairs, NdPlan& P, std::string* err,
-                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN, bool with_cmap = true, int par_min = 0) {
+                          int leaf_n = ND_LEAFN, int smax_n = ND_SMAXN, bool with_cmap = true, int par_min = 0, bool vertex_cover = true) {
     auto fail = [&](const char* m) { if (err) *err = m; return false; };
     P = NdPlan();
     P.n_nodes = n_nodes; P.n_pairs = n_pairs;
@@ -243,7 +243,7 @@ inline bool nd_build_plan(int n_nodes, const double* pos, const uint8_t* last, i
             asort(sep, ax);                                        // along the cut, so that the chunks of a long separator are contiguous
             return {mk_chain(sep, std::move(ra))};
         }
-    } rec{pos, ap, an, leaf_n, smax_n, getenv("NRS_ND_NO_COVER") == nullptr, par_min, {}, std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), 0, {}};
+    } rec{pos, ap, an, leaf_n, smax_n, vertex_cover, par_min, {}, std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), std::vector<int>(n_nodes, 0), 0, {}};
     std::vector<int> regular, tail;
     for (int i = 0; i < n_nodes; ++i) (last && last[i] ? tail : regular).push_back(i);
     std::vector<int> roots = rec.run(std::move(regular), 0);

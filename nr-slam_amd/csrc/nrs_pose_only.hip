@@ -397,6 +397,41 @@ __global__ __launch_bounds__(64) void k_po_step(PoseOnlyArgs a, PoState* S, cons
 
 using namespace nrs;
 
+extern char** environ;
+namespace nrs {
+void DebugOpts::load_environment() {
+    kv.clear();
+    if (!environ) return;
+    const char* list = nullptr;
+    for (char** e = environ; *e; ++e) {
+        if (strncmp(*e, "NRS_", 4) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        if (!eq) continue;
+        const std::string name(*e, eq - *e);
+        if (name == "NRS_DEBUG") { list = eq + 1; continue; }
+        kv.emplace_back(name, eq + 1);
+    }
+    for (const char* p = list; p && *p;) {                          // NRS_DEBUG="ND=0,NO_LDS=1": NAME=VALUE pairs, names without the NRS_ prefix
+        const char* end = strchr(p, ',');
+        const std::string item = end ? std::string(p, end - p) : std::string(p);
+        const size_t eq = item.find('=');
+        if (!item.empty()) set(("NRS_" + (eq == std::string::npos ? item : item.substr(0, eq))).c_str(), eq == std::string::npos ? "1" : item.c_str() + eq + 1);
+        p = end ? end + 1 : nullptr;
+    }
+}
+const char* process_debug_option(const char* name) { return DebugOpts::process().get(name); }
+const DebugOpts& DebugOpts::process() {
+    static const DebugOpts snap = [] { DebugOpts d; d.load_environment(); return d; }();
+    return snap;
+}
+}  // namespace nrs
+
+extern "C" int nrs_debug_set(nrs_ctx* c, const char* name, const char* value) {
+    if (!c || !name || strncmp(name, "NRS_", 4) != 0) return NRS_ERR_INVALID;
+    c->dbg.set(name, value);
+    return NRS_OK;
+}
+
 extern "C" void nrs_options_init(nrs_options* opt) {
     if (!opt) return;
     memset(opt, 0, sizeof(*opt));
@@ -423,7 +458,8 @@ extern "C" int nrs_create(nrs_ctx** out, const nrs_options* opt) {
     if (c->opt.direct_solve < 0 || c->opt.direct_solve > 2) c->opt.direct_solve = 0;
     if (c->opt.embedded_solver < 0 || c->opt.embedded_solver > 2) c->opt.embedded_solver = 0;
     if (c->opt.pcg_rtol <= 0) c->opt.pcg_rtol = 1e-10;
-    if (const char* e = getenv("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
+    c->dbg.load_environment();
+    if (const char* e = c->env("NRS_PCG_RTOL")) { const double v = atof(e); if (v > 0) c->opt.pcg_rtol = v; }   // experiments only
     if (c->opt.pcg_max_iters <= 0) c->opt.pcg_max_iters = 2000;
     if (c->opt.pcg_batch <= 0) c->opt.pcg_batch = 8;
     c->err[0] = 0;
@@ -532,7 +568,7 @@ extern "C" int nrs_pose_only_solve(nrs_ctx* c, const nrs_camera* cam, int32_t n,
     // ~10 us per LM trial whatever the size, where the single workgroup needs n / 512 point evaluations per thread and trial).
     // NRS_PO_MULTI_MIN moves the hand-over (tests run both forms on the same frames).
     int multi_min = 32768;                                    // (measured: 13.0 ms on one workgroup, 6.0 ms on many at 90k points; the two meet near 35k)
-    if (const char* ev = getenv("NRS_PO_MULTI_MIN")) multi_min = atoi(ev);
+    if (const char* ev = c->env("NRS_PO_MULTI_MIN")) multi_min = atoi(ev);
     if (n >= multi_min && n > 0) {
         const int G = std::max(1, std::min(2 * c->prop.multiProcessorCount, (n + POM_THREADS - 1) / POM_THREADS));
         NRS_TRY(c->ensure(c->po_multi, sizeof(PoState) + 256 + sizeof(double) * 32 * (size_t)G));

@@ -557,7 +557,7 @@ int rg_walk(nrs_rgraph* g, int n_map, const int* code, const uint8_t* is_node, i
     };
     int done = 0, hc[MAXP];
     int max_p = MAXP;                                              // (NRS_WALK_MAX_PASSES: a lower cap, so that the tests reach the caller's host fallback)
-    if (const char* v = getenv("NRS_WALK_MAX_PASSES")) max_p = std::max(1, std::min(MAXP, atoi(v)));
+    if (const char* v = c->env("NRS_WALK_MAX_PASSES")) max_p = std::max(1, std::min(MAXP, atoi(v)));
     while (done < max_p && !*converged) {                          // batches of passes, one look at their change counts per batch
         const int batch = std::min(done == 0 ? 6 : 8, max_p - done);
         for (int q = 0; q < batch; ++q) pass(done + q, 0);
@@ -625,13 +625,17 @@ int rg_get_edges_staged(nrs_rgraph* g, int32_t n_ids, const int32_t* ids, int32_
     // many rows (a2's first GetEdges of a frame: every tracked point): the kernel scans full symmetric copies of the two arrays it reads
     const uint8_t* st_f = nullptr;
     const float* maxd_f = nullptr;
-    if ((int64_t)n_ids * 8 >= g->cap && g->cap >= 512 && !getenv("NRS_RG_NO_MIRROR")) {
+    if ((int64_t)n_ids * 8 >= g->cap && g->cap >= 512 && !c->env("NRS_RG_NO_MIRROR")) {
         const size_t cc = (size_t)g->cap * g->cap, o_m = (cc + 255) & ~(size_t)255;
-        NRS_TRY(c->ensure(g->mir, o_m + 4 * cc));
-        const int nt = (g->cap + 63) / 64;
-        hipLaunchKernelGGL(k_rg_mirror, dim3(nt, nt), dim3(256), 0, c->stream, g->cap, g->st, g->maxd, g->mir.as<uint8_t>(), reinterpret_cast<float*>(g->mir.as<char>() + o_m));
-        NRS_HIP(c, hipGetLastError());
-        st_f = g->mir.as<uint8_t>(); maxd_f = reinterpret_cast<const float*>(g->mir.as<char>() + o_m);
+        if (c->ensure(g->mir, o_m + 4 * cc) == NRS_OK) {           // (5 bytes per pair on top of the 13 of the state)
+            const int nt = (g->cap + 63) / 64;
+            hipLaunchKernelGGL(k_rg_mirror, dim3(nt, nt), dim3(256), 0, c->stream, g->cap, g->st, g->maxd, g->mir.as<uint8_t>(), reinterpret_cast<float*>(g->mir.as<char>() + o_m));
+            NRS_HIP(c, hipGetLastError());
+            st_f = g->mir.as<uint8_t>(); maxd_f = reinterpret_cast<const float*>(g->mir.as<char>() + o_m);
+        } else {                                                   // no memory for the copies: the triangular state serves the call (slower, same lists)
+            (void)hipGetLastError();
+            c->err[0] = 0;
+        }
     }
     // first the selecting form (stages <= cap_per_point + one histogram bin per row); if a bin overflows the staging area
     // (many equal distances), once more with every survivor of a row staged

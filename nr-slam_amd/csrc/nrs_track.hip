@@ -401,7 +401,7 @@ namespace nrs {
 static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, float* map_pos, int32_t n_f, const int32_t* f_map,
                       int32_t* f_status, const float* f_uv, float* f_pos, double pose_qt[7], float scale, float* deform_median,
                       int32_t* n_lost, int32_t* lost, nrs_lm_trace* trace, const uint8_t* f_node) {
-    const bool tm = getenv("NRS_TIMING") != nullptr;
+    const bool tm = c->env("NRS_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (!tm) return;
@@ -460,7 +460,7 @@ static int track_core(nrs_ctx* c, const nrs_camera* cam, NeighbourSource& src, f
         const int io = id_to_idx[o];
         if (io >= 0 && node_of[io] >= 0) walk_code[o] = io;
     }
-    const bool host_walk = getenv("NRS_HOST_WALK") != nullptr;     // (A/B switch: the walk on the host, as before round 5)
+    const bool host_walk = c->env("NRS_HOST_WALK") != nullptr;     // (A/B switch: the walk on the host, as before round 5)
     std::vector<uint8_t> is_node_b;
     if (M < N) { is_node_b.resize(N); for (int i = 0; i < N; ++i) is_node_b[i] = node_of[i] >= 0; }
     for (bool again = true; again;) {                             // (again: a walk ran off a truncated list -- longer prefixes, from the start)

@@ -20,7 +20,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = ["nrs_create", "nrs_options_init", "nrs_destroy", "nrs_last_error", "nrs_device_name", "nrs_get_profile",
            "nrs_reset_profile", "nrs_stream", "nrs_pose_only_solve", "nrs_dba_build_edges",
            "nrs_dba_solve", "nrs_dba_upload", "nrs_dba_build_edges_embedded", "nrs_dba_upload_embedded", "nrs_dba_download_skinned", "nrs_dba_solve_embedded", "nrs_dba_reset", "nrs_dba_optimize",
-           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_kft", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
+           "nrs_dba_download", "nrs_dba_residuals", "nrs_dba_gradient", "nrs_dba_pack_hash", "nrs_dba_solve_window", "nrs_dba_window_edges", "nrs_debug_pcg_solve", "nrs_debug_kft", "nrs_debug_set", "nrs_debug_nd_solve", "nrs_debug_nd_cache_stats", "nrs_track_deform_solve_embedded",
            "nrs_graph_select_neighbours", "nrs_graph_update", "nrs_track_deform_solve",
            "nrs_klt_configure", "nrs_klt_clear", "nrs_klt_num_points", "nrs_klt_set_reference",
            "nrs_klt_track", "nrs_klt_get_template", "nrs_klt_insert_template", "nrs_klt_get_templates",
@@ -41,6 +41,28 @@ class NrsError(RuntimeError):
 
 class Camera(C.Structure):
     _fields_ = [("model", C.c_int32), ("params", C.c_float * 8)]
+
+
+# ---- debug / A-B switches (include/nrs.h "Debug switches"): a context reads the NRS_* environment ONCE when it is created; afterwards they are
+# changed through nrs_debug_set only.  debug_set() here applies a switch to every live Context of this process and to the ones created later.
+import weakref
+_DEBUG = {}
+_LIVE = weakref.WeakSet()
+
+
+def debug_set(name, value):
+    """value None: unset.  (tests / probes: the replacement of os.environ[name] = value for a library that no longer reads the environment per call)"""
+    if value is None:
+        _DEBUG.pop(name, None)
+    else:
+        _DEBUG[name] = str(value)
+    for c in list(_LIVE):
+        c.debug_set(name, value)
+
+
+def debug_clear():
+    for k in list(_DEBUG):
+        debug_set(k, None)
 
 
 class Options(C.Structure):
@@ -319,6 +341,9 @@ class Context:
         rc = self.lib.nrs_create(C.byref(self.h), C.byref(opt))
         if rc != OK:
             raise NrsError(rc, "nrs_create failed (no usable HIP device?)")
+        _LIVE.add(self)
+        for k, v in _DEBUG.items():
+            self.debug_set(k, v)
 
     def close(self):
         if self.h:
@@ -719,6 +744,11 @@ class Context:
             self._chk(rc)
         keys = ("fronts", "levels", "max_s", "max_b", "L_doubles", "U_doubles", "flops", "workgroups")
         return rc == 0, x, dict(zip(keys, st.tolist())), ms.value
+
+    def debug_set(self, name, value):
+        """a debug / A-B switch of THIS context (include/nrs.h nrs_debug_set); value None: unset"""
+        if self.h:
+            self._chk(self.lib.nrs_debug_set(self.h, name.encode(), None if value is None else str(value).encode()))
 
     def debug_kft_info(self):
         """the keyframe-block factorisation of the resident embedded window: dict(on, K, ld, nb, m, mib, nf[K], np[K])"""

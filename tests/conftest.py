@@ -32,6 +32,16 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _debug_switches_do_not_leak(request):
+    """A/B switches set with nrs.debug_set during a test are dropped when it ends (the library reads the environment once per context:
+    the tests switch launch forms through nrs_debug_set, include/nrs.h)"""
+    yield
+    if "gpu" in request.keywords:
+        import nrs
+        nrs.debug_clear()
+
+
 @pytest.fixture(scope="session")
 def ctx_exact():
     """Context with nrs_options.exact_trials = 1: every LM trial is solved to pcg_rtol (on the PCG: direct_solve = 2 -- the

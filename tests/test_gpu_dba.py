@@ -103,7 +103,7 @@ def test_two_kernel_path_with_temporal_difference_dampers(ctx, monkeypatch, mode
     out = {}
     for name, env in (("dform", {"NRS_NO_FUSED": "1", "NRS_DFORM": "1"}), ("generic", {"NRS_NO_FUSED": "1"})):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            nrs.debug_set(k, v)
         tr = nrs.Trace()
         pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr)
         ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
@@ -118,7 +118,7 @@ def test_two_kernel_path_with_temporal_difference_dampers(ctx, monkeypatch, mode
         assert np.allclose(pq[:, :4], oq, atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
         assert np.allclose(xyz, opts, atol=1e-4, rtol=0)
         for k in env:
-            monkeypatch.delenv(k)
+            nrs.debug_set(k, None)
     a, g = out["dform"], out["generic"]
     assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)
     assert np.max(np.abs(a[3] - g[3])) <= 1e-10 * np.max(np.abs(g[3])) and np.max(np.abs(a[4] - g[4])) <= 1e-10 * np.max(np.abs(g[4]))

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 
 def _solve(monkeypatch, host, p, e, cam, qt, iters=3):
     if host:
-        monkeypatch.setenv("NRS_HOST_PACK", "1")
+        nrs.debug_set("NRS_HOST_PACK", "1")
     else:
-        monkeypatch.delenv("NRS_HOST_PACK", raising=False)
+        nrs.debug_set("NRS_HOST_PACK", None)
     c = nrs.Context()
     c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
     h = c.dba_pack_hash()
@@ -56,9 +56,9 @@ def test_compact_damper_headers_change_nothing(monkeypatch, model):
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-    monkeypatch.delenv("NRS_NO_H4", raising=False)
+    nrs.debug_set("NRS_NO_H4", None)
     h4, t4, q4, x4, r4 = _solve(monkeypatch, False, p, e, cam, qt, iters=4)
-    monkeypatch.setenv("NRS_NO_H4", "1")
+    nrs.debug_set("NRS_NO_H4", "1")
     h8, t8, q8, x8, r8 = _solve(monkeypatch, False, p, e, cam, qt, iters=4)
     assert h4[20] != h8[20], "the two runs must take the two encodings (the flag is part of the scalar checksum)"
     assert [h4[i] for i in range(24) if i != 20] == [h8[i] for i in range(24) if i != 20]
@@ -68,7 +68,7 @@ def test_compact_damper_headers_change_nothing(monkeypatch, model):
 
 
 def test_tiny_windows_keep_the_host_path(monkeypatch):
-    monkeypatch.delenv("NRS_HOST_PACK", raising=False)
+    nrs.debug_set("NRS_HOST_PACK", None)
     p = S.make_dba_problem(100, 2, 3)
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     c = nrs.Context()

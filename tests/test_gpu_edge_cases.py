@@ -131,11 +131,11 @@ def test_ba_two_tile_classes_bit_identical(ctx, monkeypatch):
     e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
     cam = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
-    monkeypatch.setenv("NRS_FUSED_MAX_ROWS", "0")             # the two-kernel PCG path (as for large windows)
+    nrs.debug_set("NRS_FUSED_MAX_ROWS", "0")             # the two-kernel PCG path (as for large windows)
     res = []
     for cut in (None, "50"):
         if cut:
-            monkeypatch.setenv("NRS_TILE_CUT_PCT", cut)
+            nrs.debug_set("NRS_TILE_CUT_PCT", cut)
         tr = nrs.Trace()
         pq, xyz = ctx.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 3, tr)
         res.append((pq, xyz, [(t["accepted"], t["inner"], t["chi"], t["chi_new"]) for t in tr.trials]))
@@ -157,7 +157,7 @@ def test_ba_trial_chi2_paths_agree(exact, monkeypatch):
     res = []
     for sw in (None, "1"):
         if sw:
-            monkeypatch.setenv("NRS_NO_EDGE_CHI", sw)
+            nrs.debug_set("NRS_NO_EDGE_CHI", sw)
         c = nrs.Context(exact_trials=exact)
         tr = nrs.Trace()
         pq, xyz = c.dba_solve(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"], 5, tr)

@@ -93,13 +93,13 @@ def test_reused_plan_takes_the_new_frames_skinning_weights():
         assert c.nd_cache_stats()[0] > h0, "the second frame was expected to reuse the first one's plan"
     finally:
         c.close()
-    os.environ["NRS_ND_NO_CACHE"] = "1"
+    nrs.debug_set("NRS_ND_NO_CACHE", "1")
     try:
         c = nrs.Context()
         fresh = run(c, sig * 1.02, node)
         c.close()
     finally:
-        del os.environ["NRS_ND_NO_CACHE"]
+        nrs.debug_set("NRS_ND_NO_CACHE", None)
     assert not np.array_equal(a["f_pos"], b["f_pos"])
     for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
         assert np.array_equal(b[k], fresh[k]), k
@@ -146,23 +146,23 @@ def test_device_walk_builds_the_same_problem_as_the_host_walk(ctx_direct, monkey
     out = []
     for host in (False, True):
         if host:
-            monkeypatch.setenv("NRS_HOST_WALK", "1")
+            nrs.debug_set("NRS_HOST_WALK", "1")
         else:
-            monkeypatch.delenv("NRS_HOST_WALK", raising=False)
+            nrs.debug_set("NRS_HOST_WALK", None)
         g, _, ids = _graphs(ctx_direct, tp, n)
         tr = nrs.Trace(1024)
         r = ctx_direct.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, cap)
         st = g.edge_statuses(ids[:200], ids[:200]) if hasattr(g, "edge_statuses") else None
         out.append((r, tr.trials, st))
         g.close()
-    monkeypatch.delenv("NRS_HOST_WALK", raising=False)
+    nrs.debug_set("NRS_HOST_WALK", None)
     if cap == 64:                                     # the passes run out (capped at 2): the driver falls back to the host walk, same result
-        monkeypatch.setenv("NRS_WALK_MAX_PASSES", "2")
+        nrs.debug_set("NRS_WALK_MAX_PASSES", "2")
         g, _, ids = _graphs(ctx_direct, tp, n)
         tr = nrs.Trace(1024)
         r = ctx_direct.track_deform_solve_embedded(cam, g, tp["X_prev"], ids, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, cap)
         g.close()
-        monkeypatch.delenv("NRS_WALK_MAX_PASSES", raising=False)
+        nrs.debug_set("NRS_WALK_MAX_PASSES", None)
         for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
             assert np.array_equal(r[k], out[0][0][k]), k
     (a, ta, sa), (b, tb, sb) = out

@@ -122,11 +122,11 @@ def test_two_launches_per_iteration_give_the_bits_of_three_and_four(ctx_emb_pcg,
     out = []
     for own in (False, True):
         if own:
-            monkeypatch.setenv(switch, "1")
+            nrs.debug_set(switch, "1")
         tr = nrs.Trace()
         pq, xyz, sk = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tr)
         out.append((pq, xyz, sk, [(t["accepted"], t["chi"], t["chi_new"], t["lam"], t["inner"]) for t in tr.trials]))
-    monkeypatch.delenv(switch)
+    nrs.debug_set(switch, None)
     assert sum(t[4] for t in out[0][3]) > 50
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert out[0][3] == out[1][3]
@@ -140,10 +140,10 @@ def test_hierarchical_reduction_path_matches(ctx_emb_pcg, monkeypatch):
     p, e, w, cam, qt = _setup(400, 4, 50, 59)
     ta = nrs.Trace()
     pa, xa, ska = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, ta)
-    monkeypatch.setenv("NRS_HIER", "1")
+    nrs.debug_set("NRS_HIER", "1")
     tb = nrs.Trace()
     pb, xb, skb = ctx.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tb)
-    monkeypatch.delenv("NRS_HIER")
+    nrs.debug_set("NRS_HIER", None)
     assert [t["accepted"] for t in ta.trials] == [t["accepted"] for t in tb.trials]
     for a, b in zip(ta.trials, tb.trials):
         assert abs(a["chi"] - b["chi"]) <= 1e-6 * b["chi"]
@@ -216,10 +216,10 @@ def test_gather_path_applies_the_observations_diagonal_blocks_once(ctx_exact, mo
     p, e, w, cam, qt = _setup(300, 4, 40, 57)
     tl = nrs.Trace()
     pl, xl, sl = ctx_exact.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tl)
-    monkeypatch.setenv("NRS_NO_LDS", "1")
+    nrs.debug_set("NRS_NO_LDS", "1")
     tg = nrs.Trace()
     pg, xg, sg = ctx_exact.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tg)
-    monkeypatch.delenv("NRS_NO_LDS")
+    nrs.debug_set("NRS_NO_LDS", None)
     otr = []
     oq, ot, opts, osk, nit = _oracle(p, e, w, 5, otr)
     assert tg.iterations == nit and [t["accepted"] for t in tg.trials] == [t["accepted"] for t in otr]

@@ -91,14 +91,14 @@ def test_plan_cache_reuse_is_invisible():
         assert reused >= 2 and built >= 8                           # (two problems per frame: both of a1 and b0 hit, every first sight builds)
     finally:
         c.close()
-    os.environ["NRS_ND_NO_CACHE"] = "1"
+    nrs.debug_set("NRS_ND_NO_CACHE", "1")
     try:
         c = nrs.Context(direct_solve=1)
         n0 = run(c, 600, 11)
         nb = run(c, 600, 11, shift=0.25)
         c.close()
     finally:
-        del os.environ["NRS_ND_NO_CACHE"]
+        nrs.debug_set("NRS_ND_NO_CACHE", None)
     for k in ("pose_q", "pose_t", "f_pos", "map_pos", "f_status"):
         assert np.array_equal(a0[k], n0[k]), k
     assert np.allclose(b0["pose_t"], nb["pose_t"], atol=1e-5, rtol=0) and np.allclose(b0["f_pos"], nb["f_pos"], atol=1e-4, rtol=0)
@@ -112,25 +112,25 @@ def test_chained_and_per_level_factorisation_give_the_same_bits(ctx, monkeypatch
     same bits; 256-thread workgroups (NRS_ND_THREADS=256) likewise."""
     for n, seed in ((40, 21), (120, 22), (1200, 23), (3000, 24)):
         pos, last, pairs, Dn, Vp, bn, A = block_system(n, seed, True)
-        monkeypatch.setenv("NRS_ND_CHAIN", "1")
+        nrs.debug_set("NRS_ND_CHAIN", "1")
         ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.setenv("NRS_ND_LEVELS", "1")
+        nrs.debug_set("NRS_ND_LEVELS", "1")
         ok1, x1, st1, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.delenv("NRS_ND_LEVELS", raising=False)
-        monkeypatch.delenv("NRS_ND_CHAIN", raising=False)
+        nrs.debug_set("NRS_ND_LEVELS", None)
+        nrs.debug_set("NRS_ND_CHAIN", None)
         ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.setenv("NRS_ND_THREADS", "256")
+        nrs.debug_set("NRS_ND_THREADS", "256")
         ok3, x3, st3, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.setenv("NRS_ND_STEP32", "0")                       # ... and the panel by 16-column steps (the round-4 form), on 256 and 512 threads
+        nrs.debug_set("NRS_ND_STEP32", "0")                       # ... and the panel by 16-column steps (the round-4 form), on 256 and 512 threads
         ok4, x4, st4, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.delenv("NRS_ND_THREADS", raising=False)
+        nrs.debug_set("NRS_ND_THREADS", None)
         ok5, x5, st5, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.delenv("NRS_ND_STEP32", raising=False)
+        nrs.debug_set("NRS_ND_STEP32", None)
         assert ok and ok1 and ok2 and ok3 and st == st2 and np.array_equal(x, x1) and np.array_equal(x, x2) and np.array_equal(x, x3), n
         assert ok4 and ok5 and np.array_equal(x, x4) and np.array_equal(x, x5), n
-        monkeypatch.setenv("NRS_ND_BACK_FLAGS", "1")                    # ... and the back pass handing over by flags instead of by the values themselves
+        nrs.debug_set("NRS_ND_BACK_FLAGS", "1")                    # ... and the back pass handing over by flags instead of by the values themselves
         ok6, x6, st6, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.21)
-        monkeypatch.delenv("NRS_ND_BACK_FLAGS", raising=False)
+        nrs.debug_set("NRS_ND_BACK_FLAGS", None)
         assert ok6 and np.array_equal(x, x6), n
 
 
@@ -150,14 +150,14 @@ def test_a_frame_beyond_the_direct_solvers_window_is_handed_to_the_pcg(monkeypat
         return c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
 
     tp = S.make_tracking_problem(600, 61)
-    monkeypatch.setenv("NRS_ND_MAX_ROWS", "300")
+    nrs.debug_set("NRS_ND_MAX_ROWS", "300")
     c = nrs.Context()
     try:
         tr = nrs.Trace(1024)
         r = run(c, tp, tr)
     finally:
         c.close()
-        monkeypatch.delenv("NRS_ND_MAX_ROWS", raising=False)
+        nrs.debug_set("NRS_ND_MAX_ROWS", None)
     assert max(t["inner"] for t in tr.trials) > 1                   # PCG iterations: the direct solver reports 1 per trial
     otr = []
     o = O.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], np.arange(600), tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"],
@@ -184,11 +184,11 @@ def test_crowded_levels_in_two_launches_give_the_same_bits(ctx, monkeypatch):
     import nrs_synth as S
     for n in (2500, 4446):
         pos, last, pairs, Dn, Vp, bn = S.nd_block_system(n)
-        monkeypatch.delenv("NRS_ND_NO_SPLIT", raising=False)
+        nrs.debug_set("NRS_ND_NO_SPLIT", None)
         ok, x, st, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
-        monkeypatch.setenv("NRS_ND_NO_SPLIT", "1")
+        nrs.debug_set("NRS_ND_NO_SPLIT", "1")
         ok2, x2, st2, _ = ctx.debug_nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
-        monkeypatch.delenv("NRS_ND_NO_SPLIT", raising=False)
+        nrs.debug_set("NRS_ND_NO_SPLIT", None)
         assert ok and ok2 and st == st2 and st["workgroups"] > 800 and np.array_equal(x, x2), n
         okh, xh, sth = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
         assert okh and np.allclose(x, xh, rtol=0, atol=1e-11 * np.abs(xh).max())

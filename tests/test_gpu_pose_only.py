@@ -80,7 +80,7 @@ def test_pose_only_many_workgroups_matches_oracle(ctx, monkeypatch, n, seed, mod
     """the multi-workgroup form (k_po_pass / k_po_step: what frames of >= 32768 points take) forced onto the frames the single-workgroup
     kernel is held to the oracle on: same tolerances, identical inlier mask, traces to the noise floor; bit-reproducible between calls"""
     from conftest import compare_lm_traces
-    monkeypatch.setenv("NRS_PO_MULTI_MIN", "1")
+    nrs.debug_set("NRS_PO_MULTI_MIN", "1")
     tp, uv, X = _problem(n, seed, model)
     (q, t, inl, tr), (q2, t2, inl2, otr) = _compare(ctx, tp, uv, X)
     assert np.allclose(q, q2, atol=1e-6, rtol=0) and np.allclose(t, t2, atol=1e-5, rtol=0)
@@ -108,7 +108,7 @@ def test_pose_only_on_a_100k_point_frame(ctx, monkeypatch):
             best = min(best, time.perf_counter() - t0)
         return r, best
     (q, t, inl), t_multi = run()
-    monkeypatch.setenv("NRS_PO_MULTI_MIN", "1000000000")
+    nrs.debug_set("NRS_PO_MULTI_MIN", "1000000000")
     (q1, t1, inl1), t_single = run()
     print("a1 at %d points: %.2f ms on many workgroups, %.2f ms on one" % (len(uv), 1e3 * t_multi, 1e3 * t_single))
     assert np.allclose(q, q1, atol=1e-9, rtol=0) and np.allclose(t, t1, atol=1e-8, rtol=0)

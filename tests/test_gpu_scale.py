@@ -43,7 +43,7 @@ def test_c3_reproducible_and_mode_independent(ctx, ctx_exact, c3):
 
 def test_c3_operator_paths_agree(ctx, c3, monkeypatch):
     a = _solve(ctx, c3, 2)
-    monkeypatch.setenv("NRS_NO_LDS", "1")                                            # global-gather operator, stored H blocks
+    nrs.debug_set("NRS_NO_LDS", "1")                                            # global-gather operator, stored H blocks
     g = _solve(ctx, c3, 2)
     assert [t["accepted"] for t in a[2]] == [t["accepted"] for t in g[2]]
     assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)
@@ -92,7 +92,7 @@ def test_host_packing_is_thread_count_independent(ctx, c3, monkeypatch):
     p, e, cam, qt = c3
     runs = []
     for nt in ("1", "7", "16"):
-        monkeypatch.setenv("NRS_HOST_THREADS", nt)
+        nrs.debug_set("NRS_HOST_THREADS", nt)
         ctx.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
         tr = nrs.Trace()
         ctx.dba_optimize(2, tr)

@@ -127,7 +127,7 @@ def test_full_size_operator_paths_agree(ctx, big, monkeypatch):
     tr = nrs.Trace(128)
     ctx.dba_optimize(2, tr)
     a = ctx.dba_download()
-    monkeypatch.setenv("NRS_NO_LDS", "1")
+    nrs.debug_set("NRS_NO_LDS", "1")
     g = _run(ctx, big, 2)
     assert [x["accepted"] for x in tr.trials] == [x["accepted"] for x in g[2]]
     assert np.allclose(a[0], g[0], atol=1e-9, rtol=0) and np.allclose(a[1], g[1], atol=1e-7, rtol=0)

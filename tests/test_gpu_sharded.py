@@ -183,7 +183,7 @@ def test_sharded_with_two_tile_classes(ctx, monkeypatch):
     tr = nrs.Trace()
     ctx.dba_optimize(5, tr)
     pq0, xyz0 = ctx.dba_download()
-    monkeypatch.setenv("NRS_TILE_CUT_PCT", "60")
+    nrs.debug_set("NRS_TILE_CUT_PCT", "60")
     out = _run_sharded(3, p, e, cam, qt)
     trials, pq, xyz = out[0][:3]
     _same_trials(trials, tr.trials)
@@ -215,10 +215,10 @@ def test_a_rank_holds_the_rows_of_its_own_keyframes_and_two_ghosts_only(monkeypa
     (NRS_SHARD_FULL_VECTORS=1: the round-1..4 form).  Same launches, same exchanges: the two forms agree bit for bit (trials, poses,
     landmarks, residual taps, after a reset too), and what a rank holds shrinks with the rank count."""
     p, e, cam, qt = _setup(600, 16, 45)
-    monkeypatch.setenv("NRS_SHARD_FULL_VECTORS", "1")
+    nrs.debug_set("NRS_SHARD_FULL_VECTORS", "1")
     full = _run_sharded(4, p, e, cam, qt, resets=1)
     full_bytes = [s["device_bytes"] for s in _run_sharded.stats]
-    monkeypatch.delenv("NRS_SHARD_FULL_VECTORS")
+    nrs.debug_set("NRS_SHARD_FULL_VECTORS", None)
     own = _run_sharded(4, p, e, cam, qt, resets=1)
     own_bytes = [s["device_bytes"] for s in _run_sharded.stats]
     for r in range(4):

@@ -91,9 +91,9 @@ def test_track_deform_matches_oracle(ctx_direct, ctx_pcg, monkeypatch, n, seed, 
     # 48..2600 free rows run by default) and the PCG (direct_solve = 2) -- the latter with block-Jacobi alone, as frames below
     # ~1.5k rows run it, and with the two-level preconditioner larger frames add (NRS_COARSE_MIN_TILES=0 puts a small one on it)
     if solver == "pcg-coarse":
-        monkeypatch.setenv("NRS_COARSE_MIN_TILES", "0")
+        nrs.debug_set("NRS_COARSE_MIN_TILES", "0")
     else:
-        monkeypatch.delenv("NRS_COARSE_MIN_TILES", raising=False)
+        nrs.debug_set("NRS_COARSE_MIN_TILES", None)
     tp, r, o, tr, otr = _track_compare(ctx_direct if solver == "direct" else ctx_pcg, n, seed)
     assert all(t["inner"] == 1 for t in tr) == (solver == "direct")          # (the direct path reports one "iteration" per trial)
     assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-6, rtol=0)

@@ -16,13 +16,13 @@ for seed in range(n_seeds):
     cam = nrs.make_camera(p["model"], p["prm"]); qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     res = []
     for host in (False, True):
-        if host: os.environ["NRS_HOST_PACK"] = "1"
-        else: os.environ.pop("NRS_HOST_PACK", None)
+        if host: nrs.debug_set("NRS_HOST_PACK", "1")
+        else: nrs.debug_set("NRS_HOST_PACK", None)
         c = nrs.Context()
         c.dba_upload(cam, qt, p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
         h = c.dba_pack_hash(); c.dba_optimize(3); out = c.dba_download(); c.close()
         res.append((h, out))
-    os.environ.pop("NRS_HOST_PACK", None)
+    nrs.debug_set("NRS_HOST_PACK", None)
     c = nrs.Context()
     wq, wx = c.dba_solve_window(cam, qt, p["kf_points"], p["lm_xyz"], p["lm_uv"], p["nbr"], p["scale"], 3)
     ed = c.dba_window_edges(); c.close()

@@ -15,7 +15,7 @@ w = S.embedded_window(p, e)
 cam = nrs.make_camera(p["model"], p["prm"])
 qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
 res = {}
-for mode in (0, 2):
+for mode in (1, 2):
     ctx = nrs.Context(embedded_solver=mode, exact_trials=1)
     t0 = time.perf_counter()
     ctx.dba_upload_embedded(cam, qt, w, e, p["scale"])

@@ -11,8 +11,8 @@ e = nrs.dba_build_edges(p["kf_points"], p["nbr"])
 ctx = nrs.Context(profile=1)
 ctx.dba_upload(nrs.make_camera(p["model"], p["prm"]), np.concatenate([p["poses_q"], p["poses_t"]], 1), p["lm_xyz"], p["lm_kf"], p["lm_uv"], e, p["scale"])
 for exp in (sys.argv[2:] or ("0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11")):
-    if exp == "0": os.environ.pop("NRS_LIN_EXP", None)
-    else: os.environ["NRS_LIN_EXP"] = exp
+    if exp == "0": nrs.debug_set("NRS_LIN_EXP", None)
+    else: nrs.debug_set("NRS_LIN_EXP", exp)
     ctx.dba_reset(); ctx.reset_profile()
     try:
         ctx.dba_optimize(1)

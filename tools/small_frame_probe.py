@@ -17,9 +17,9 @@ for n in [int(a) for a in sys.argv[1:]] or [600, 1150, 2500, 5000]:
             ctx.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
             b = min(b, time.perf_counter() - t0)
         return b
-    os.environ["NRS_ND_NO_CACHE"] = "1"
+    nrs.debug_set("NRS_ND_NO_CACHE", "1")
     best = run(3)
-    del os.environ["NRS_ND_NO_CACHE"]
+    nrs.debug_set("NRS_ND_NO_CACHE", None)
     best_hit = run(3)
     inner = [x["inner"] for x in tr.trials]
     per_round = {}
