@@ -212,6 +212,42 @@ def cpu_tracked_fps_compiled(lib, with_gpu):
     return out
 
 
+def cpu_embedded_frame(gpu_frames_per_s):
+    """cpu_baseline of the embedded frame loop (tracked_fps_5k_x_500): ONE frame of 5000 map points with 500 nodes in the C++ restatement
+    (oracle/nrs_cpu_lk.hpp LK Track, a1, and the embedded a2 of oracle/nrs_cpu.cpp nrs_cpu_track_deform_solve_embedded -- held to
+    oracle/embedded_oracle.py by tests/test_oracle_cpp_track_cpu.py), 1 core, full sparse Cholesky per LM trial.  The CPU side walks a flat
+    kNN-96 graph (~10 nodes among a point's neighbours; the GPU leg's all-pairs graph is 25 M connections on a CPU): the same unknowns
+    (6 + 3 x 500) and the same observations."""
+    import nrs_cpu as CPU
+    import nrs_synth as S
+    import skin_oracle as K
+    lib = CPU.load(native=True)
+    n = 5000
+    tp = S.make_tracking_problem(n, 3)
+    g = S.build_graph(tp["X_prev"], tp["graph"]["sigma"], 96, tp["graph"]["stretch_th"])
+    node = np.zeros(n, np.uint8)
+    node[K.select_nodes(tp["X_prev"], 500, tp["status"] == 0)] = 1
+    m = tp["status"] == 0
+    fm = np.arange(n)
+    t0 = time.perf_counter()
+    q, t, _, _, _ = CPU.pose_only_solve(tp["model"], tp["prm"], tp["uv"][m], tp["X_prev"][m], tp["pose_q"], tp["pose_t"], lib)
+    r = CPU.track_deform_solve_embedded(tp["model"], tp["prm"], g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node, q, t, tp["scale"], lib)
+    dt = time.perf_counter() - t0
+    sq = S.make_lk_sequence(int(m.sum()), 5)
+    lk = CPU.LucasKanadeCpp(lib=lib)
+    lk.set_reference(sq["im0"], sq["pts"])
+    t0 = time.perf_counter()
+    lk.track(sq["im1"], sq["pts"], np.zeros(len(sq["pts"]), np.int32))
+    dt_lk = time.perf_counter() - t0
+    lk.close()
+    st = r["stats"]
+    return dict(value=1.0 / (dt + dt_lk), unit="frames/s", cores=1, kind="port",
+                sample="1 frame, %d tracked points, %d nodes, %d skinned points: LK Track %.0f ms + a1 + embedded a2 %.0f ms (%d LM trials, %d factorisations of "
+                       "%.2f GFLOP, %d unknowns)" % (int(m.sum()), r["n_nodes"], r["n_skinned"], 1e3 * dt_lk, 1e3 * dt, st["n_trials"], st["n_factor"],
+                                                    st["chol_flops"] / 1e9, st["unknowns_max"]),
+                gpu_over_cpu=gpu_frames_per_s * (dt + dt_lk))
+
+
 def cpu_tracked_fps(with_gpu, n_points=600):
     """The frame loop driven by the oracle (1 core) on a bounded sample: ONE tracked frame of a 640x480
     sequence with 600 map points (about 10 s; the metric's 4.4k points take minutes per frame in NumPy),
@@ -908,6 +944,7 @@ def main():
         out["value_5k_x_500"] = out["skinned"]["ba_window"]["value"]      # BASELINE.json's config as written (5k points x 500 nodes x 20 keyframes), LM iters/s
         if not args.no_cpu_baseline:
             out["skinned"]["ba_window"]["cpu_baseline"] = cpu_baseline_embedded(*emb_inputs, out["value_5k_x_500"])
+            out["tracked_fps_5k_x_500"]["cpu_baseline"] = cpu_embedded_frame(out["tracked_fps_5k_x_500"]["value"])
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, e, ctx=ctx, ctx_exact=xctx)
             cb = out["cpu_baseline"]

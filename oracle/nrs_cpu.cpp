@@ -1493,6 +1493,252 @@ int nrs_cpu_track_deform_solve(int32_t model, const float* prm, int32_t n_points
     return 0;
 }
 
+// The EMBEDDED-DEFORMATION form of the pose-and-deformation solve (N2a; include/nrs.h nrs_track_deform_solve_embedded,
+// oracle/embedded_oracle.py track_deform_solve_embedded, statement for statement): f_node[i] != 0 marks the frame landmarks that are NODES --
+// they carry the vertices and the regularisers of OPT:255-335 (the walks pass other optimised points over); every other optimised point is
+// skinned to the <= 11 nodes its own walk accepts, omega = w / sum w (float weights, summed and divided in double), and its
+// ReprojectionErrorWithDeformation edge constrains those nodes and the pose.  Rounds, inlier levels, the IQR rejection, write-back, graph
+// update over all optimised points; stage 2 with the skinned points as constants.  With every optimised point a node this is
+// nrs_cpu_track_deform_solve.  Flat graph, arguments as there.
+int nrs_cpu_track_deform_solve_embedded(int32_t model, const float* prm, int32_t n_points, const int32_t* rowptr, const int32_t* col,
+                                        const int32_t* eid, float* e_w, const float* e_d0, float* e_max, float* e_min, int32_t* e_status,
+                                        float sigma, float stretch_th, float* map_pos, int32_t n_f, const int32_t* f_map, int32_t* f_status,
+                                        const float* f_uv, float* f_pos, const uint8_t* f_node, double* pose_qt, float scale, float* deform_median,
+                                        int32_t* n_lost, int32_t* lost_out, int32_t* n_nodes_out, int32_t* n_skinned_out,
+                                        Trial* trace, int32_t trace_cap, int32_t* trace_n, TStats* st) {
+    const double t_begin = now_s();
+    TStats S;
+    std::memset(&S, 0, sizeof(S));
+    FlatGraph g{n_points, rowptr, col, eid, e_w, e_max, e_min, e_d0, e_status, sigma, stretch_th, 0.f};
+    g.min_w = FlatGraph::weight((float)((double)sigma * 1.5), sigma);
+    if (n_lost) *n_lost = 0;
+    if (deform_median) *deform_median = 0.f;
+    if (trace_n) *trace_n = 0;
+    vector<int> map_to_frame(n_points, -1), opt_f, ids;
+    for (int i = 0; i < n_f; ++i) if (f_map[i] >= 0) map_to_frame[f_map[i]] = i;
+    for (int i = 0; i < n_f; ++i) if (f_status[i] == 0 && f_map[i] >= 0) { opt_f.push_back(i); ids.push_back(f_map[i]); }
+    const int N = (int)opt_f.size();
+    if (N == 0) return 0;
+    vector<int> id_to_idx(n_points, -1);
+    for (int i = 0; i < N; ++i) id_to_idx[ids[i]] = i;
+    vector<uint8_t> is_node(N);
+    vector<int> node_of(N, -1), node_idx;
+    for (int i = 0; i < N; ++i) { is_node[i] = f_node[opt_f[i]] != 0; if (is_node[i]) { node_of[i] = (int)node_idx.size(); node_idx.push_back(i); } }
+    const int M = (int)node_idx.size();
+    if (n_nodes_out) *n_nodes_out = M;
+    vector<double> X0all(3 * (size_t)N);
+    for (int i = 0; i < N; ++i) for (int a = 0; a < 3; ++a) X0all[3 * (size_t)i + a] = (double)f_pos[3 * (size_t)opt_f[i] + a];
+    TGraph G;
+    G.st = &S;
+    G.model = model;
+    std::memcpy(G.prm, prm, sizeof(float) * 8);
+    Pose seed;
+    for (int i = 0; i < 4; ++i) seed.q[i] = pose_qt[i];
+    for (int i = 0; i < 3; ++i) seed.t[i] = pose_qt[4 + i];
+    quat_normalize(seed.q);
+    G.N = M; G.n_rep = M; G.rep_pt = true;
+    G.x.assign(3 * (size_t)M, 0.0); G.pt_fixed.assign(M, 0);
+    G.X0.resize(3 * (size_t)M); G.uv.resize(2 * (size_t)M); G.rep_err.assign(2 * (size_t)M, 0.0); G.rep_level.assign(M, 0);
+    for (int v = 0; v < M; ++v) {
+        for (int a = 0; a < 3; ++a) G.X0[3 * (size_t)v + a] = X0all[3 * (size_t)node_idx[v] + a];
+        for (int a = 0; a < 2; ++a) G.uv[2 * (size_t)v + a] = (double)f_uv[2 * (size_t)opt_f[node_idx[v]] + a];
+    }
+    {
+        const float th2 = std::sqrt(5.99f), th3 = std::sqrt(0.584f);
+        const float sigma_spatial = (float)(0.1 * (double)scale);
+        G.info_rep = (double)(1.0f / (0.5f * 0.5f)); G.delta_rep = (double)th2;
+        G.info_sp = (double)(1.0f / (0.1f * 0.1f)); G.delta_sp = (double)th3;
+        G.info_dm = (double)(1.0f / (sigma_spatial * sigma_spatial)); G.delta_dm = (double)th3;
+        G.k_spring = (double)1.1f;
+    }
+    // ---- edge construction: OPT:224-337 between nodes; the same walk binds a skinned point to its nodes
+    double t0 = now_s();
+    vector<vector<std::pair<int, int>>> reg(N);
+    vector<uint8_t> lost_flag(n_points, 0);
+    vector<int> walk, sk_idx;
+    vector<int> sk_nodes;                                           // per skinned point: 11 vertex ids (pads 0)
+    vector<double> sk_omega;
+    for (int idx = 0; idx < N; ++idx) {
+        int n_reg = 0;
+        int nodes[TGraph::SKN];
+        double ws[TGraph::SKN];
+        g.get_edges(ids[idx], walk);
+        for (int a : walk) {
+            const int other = col[a], e = eid[a];
+            if (n_reg > 10 || e_status[e] == 3) break;
+            const int fo = map_to_frame[other];
+            if (fo < 0 || f_status[fo] != 0) {
+                if (fo >= 0 && f_status[fo] != 2) lost_flag[other] = 1;
+                continue;
+            }
+            const int io = id_to_idx[other];
+            if (!is_node[io]) continue;                               // an optimised point without a vertex: passed over
+            if (is_node[idx]) {
+                bool dup = false;
+                for (auto& pr : reg[idx]) dup = dup || pr.first == io;
+                if (dup) continue;
+                const int k = G.E();
+                G.ei.push_back(node_of[idx]); G.ej.push_back(node_of[io]); G.ew.push_back((double)e_w[e]); G.ed0.push_back((double)e_d0[e]);
+                reg[idx].push_back({io, k});
+                reg[io].push_back({idx, k});
+            } else {
+                nodes[n_reg] = node_of[io];
+                ws[n_reg] = (double)e_w[e];
+            }
+            ++n_reg;
+        }
+        if (!is_node[idx] && n_reg > 0) {
+            double tot = 0.0;
+            for (int k = 0; k < n_reg; ++k) tot += ws[k];            // (sequential: the summation order is part of the statement)
+            sk_idx.push_back(idx);
+            for (int k = 0; k < TGraph::SKN; ++k) { sk_nodes.push_back(k < n_reg ? nodes[k] : 0); sk_omega.push_back(k < n_reg ? ws[k] / tot : 0.0); }
+        }
+    }
+    S.t_graph += now_s() - t0;
+    const int E = G.E(), Sn = (int)sk_idx.size();
+    if (n_skinned_out) *n_skinned_out = Sn;
+    G.dm_level.assign(E, 0); G.dm_err.assign(3 * (size_t)E, 0.0);
+    // (springs read the nodes' own X0: TGraph::sp_residual indexes X0 by vertex)
+    G.n_sk = Sn; G.sk_node = sk_nodes; G.sk_om = sk_omega; G.sk_level.assign(Sn, 0); G.sk_err.assign(2 * (size_t)Sn, 0.0);
+    G.sk_X0.resize(3 * (size_t)Sn); G.sk_uv.resize(2 * (size_t)Sn);
+    for (int j = 0; j < Sn; ++j) {
+        for (int a = 0; a < 3; ++a) G.sk_X0[3 * (size_t)j + a] = X0all[3 * (size_t)sk_idx[j] + a];
+        for (int a = 0; a < 2; ++a) G.sk_uv[2 * (size_t)j + a] = (double)f_uv[2 * (size_t)opt_f[sk_idx[j]] + a];
+    }
+    const float th2_sq = 5.99f, th3_sq = 0.584f;
+    vector<uint8_t> inl(N, 1);
+    int n_tr = 0;
+    vector<float> chi(M), chs(Sn);
+    auto reproj_chi = [&]() {
+        for (int v = 0; v < M; ++v) {
+            double* r = &G.rep_err[2 * (size_t)v];
+            G.rep_residual(v, r);
+            chi[v] = (float)(G.info_rep * (r[0] * r[0] + r[1] * r[1]));
+        }
+    };
+    auto skin_chi = [&]() {
+        for (int j = 0; j < Sn; ++j) {
+            double* r = &G.sk_err[2 * (size_t)j];
+            G.sk_residual(j, r);
+            chs[j] = (float)(G.info_rep * (r[0] * r[0] + r[1] * r[1]));
+        }
+    };
+    for (int rnd = 0; rnd < 2; ++rnd) {                               // OPT:338-395
+        G.pose = seed;
+        std::fill(G.x.begin(), G.x.end(), 0.0);
+        G.optimize(10, rnd, trace, trace_cap, &n_tr);
+        reproj_chi();
+        for (int v = 0; v < M; ++v) {
+            const int idx = node_idx[v];
+            const bool out = chi[v] > th2_sq;
+            inl[idx] = !out;
+            G.rep_level[v] = out ? 1 : 0;
+            for (auto& pr : reg[idx]) G.dm_level[pr.second] = out ? 1 : 0;
+            for (auto& pr : reg[idx]) {
+                double* r = &G.dm_err[3 * (size_t)pr.second];
+                G.dm_residual(pr.second, r);
+                G.dm_level[pr.second] = G.info_dm * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) > (double)th3_sq ? 1 : 0;
+            }
+        }
+        skin_chi();
+        for (int j = 0; j < Sn; ++j) {
+            const bool out = chs[j] > th2_sq;
+            inl[sk_idx[j]] = !out;
+            G.sk_level[j] = out ? 1 : 0;
+        }
+    }
+    for (int i = 0; i < 4; ++i) pose_qt[i] = G.pose.q[i];
+    for (int i = 0; i < 3; ++i) pose_qt[4 + i] = G.pose.t[i];
+    // ---- OPT:401-455 over all optimised points (a skinned point's deformation is its interpolated one)
+    vector<double> delta64(3 * (size_t)N, 0.0);
+    for (int v = 0; v < M; ++v) for (int a = 0; a < 3; ++a) delta64[3 * (size_t)node_idx[v] + a] = G.x[3 * (size_t)v + a];
+    for (int j = 0; j < Sn; ++j) G.sk_deformation(j, &delta64[3 * (size_t)sk_idx[j]]);
+    vector<float> delta(3 * (size_t)N), mag(N);
+    for (int i = 0; i < N; ++i) {
+        for (int a = 0; a < 3; ++a) delta[3 * (size_t)i + a] = (float)delta64[3 * (size_t)i + a];
+        const float dx = delta[3 * (size_t)i], dy = delta[3 * (size_t)i + 1], dz = delta[3 * (size_t)i + 2];
+        float s2 = dx * dx;
+        const float sy = dy * dy, sz = dz * dz;
+        s2 = s2 + sy;
+        s2 = s2 + sz;
+        mag[i] = std::sqrt(s2);
+    }
+    vector<float> srt(mag);
+    std::sort(srt.begin(), srt.end());
+    const float q1 = srt[(int)((float)N * 0.25f)], q3 = srt[(int)((float)N * 0.75f)];
+    const float th = 1.5f * (q3 - q1);
+    reproj_chi();
+    skin_chi();
+    vector<float> chi_all(N, 0.f);
+    for (int v = 0; v < M; ++v) chi_all[node_idx[v]] = chi[v];
+    for (int j = 0; j < Sn; ++j) chi_all[sk_idx[j]] = chs[j];
+    for (int idx = 0; idx < N; ++idx) {
+        const int fi = opt_f[idx];
+        if (chi_all[idx] > th2_sq) { inl[idx] = 0; f_status[fi] = 1; }
+        if (mag[idx] >= q3 + th) { f_status[fi] = 1; continue; }
+        if (is_node[idx]) G.pt_fixed[node_of[idx]] = 1;
+        for (int a = 0; a < 3; ++a) {
+            const float cur = delta[3 * (size_t)idx + a] + f_pos[3 * (size_t)fi + a];
+            f_pos[3 * (size_t)fi + a] = cur;
+            map_pos[3 * (size_t)ids[idx] + a] = cur;
+        }
+    }
+    {
+        vector<float> part(mag);                                     // np.partition(mag, N // 2)[N // 2]: the N // 2-th smallest
+        std::nth_element(part.begin(), part.begin() + N / 2, part.end());
+        if (deform_median) *deform_median = part[N / 2];
+    }
+    t0 = now_s();
+    for (int idx = 0; idx < N; ++idx) {                               // graph update OPT:457-474
+        if (!inl[idx]) continue;
+        const int good = g.update_vertex(ids[idx], map_pos);
+        if ((double)good < 10 * 0.5) f_status[opt_f[idx]] = 3;
+    }
+    S.t_graph += now_s() - t0;
+    // ---- stage 2 OPT:476-553: vertices = nodes, then the other optimised points as constants (their interpolated deformation), then the lost points
+    vector<int> lost;
+    for (int p = 0; p < n_points; ++p) if (lost_flag[p]) lost.push_back(p);
+    const int L = (int)lost.size();
+    if (L > 0) {
+        vector<int> other_idx, vert_of(N, -1);
+        for (int v = 0; v < M; ++v) vert_of[node_idx[v]] = v;
+        for (int i = 0; i < N; ++i) if (!is_node[i]) { vert_of[i] = M + (int)other_idx.size(); other_idx.push_back(i); }
+        const int nv = M + (int)other_idx.size();
+        G.N = nv + L;
+        G.x.resize(3 * (size_t)(nv + L), 0.0);
+        G.pt_fixed.resize(nv + L, 0);
+        for (size_t j = 0; j < other_idx.size(); ++j) {
+            for (int a = 0; a < 3; ++a) G.x[3 * (size_t)(M + j) + a] = delta64[3 * (size_t)other_idx[j] + a];
+            G.pt_fixed[M + j] = 1;
+        }
+        for (int li = 0; li < L; ++li) { for (int a = 0; a < 3; ++a) G.x[3 * (size_t)(nv + li) + a] = 0.0; G.pt_fixed[nv + li] = 0; }
+        t0 = now_s();
+        for (int li = 0; li < L; ++li) {
+            int n_reg = 0;
+            g.get_edges(lost[li], walk);
+            for (int a : walk) {
+                if (n_reg > 10) break;
+                const int io = id_to_idx[col[a]];
+                if (io < 0) continue;
+                G.ui.push_back(nv + li); G.uj.push_back(vert_of[io]); G.uw.push_back((double)e_w[eid[a]]);
+                ++n_reg;
+            }
+        }
+        S.t_graph += now_s() - t0;
+        std::fill(G.sk_level.begin(), G.sk_level.end(), 1);          // the skinned observations take part in the two rounds only
+        G.pose_fixed = true;
+        G.optimize(10, 2, trace, trace_cap, &n_tr);
+        for (int li = 0; li < L; ++li)
+            for (int a = 0; a < 3; ++a) map_pos[3 * (size_t)lost[li] + a] = (float)G.x[3 * (size_t)(nv + li) + a] + map_pos[3 * (size_t)lost[li] + a];
+        if (lost_out) std::memcpy(lost_out, lost.data(), sizeof(int32_t) * L);
+    }
+    if (n_lost) *n_lost = L;
+    if (trace_n) *trace_n = n_tr;
+    S.t_total = now_s() - t_begin;
+    if (st) *st = S;
+    return 0;
+}
+
 // LucasKanadeTracker (modules/matching/lucas_kanade_tracker.cc:47-596): create / SetReferenceImage / Track / destroy
 void* nrs_cpu_lk_create(int32_t win, int32_t max_level, int32_t max_iters, float eps, float min_eig) {
     LkTracker* t = new LkTracker();

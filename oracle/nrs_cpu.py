@@ -177,6 +177,42 @@ def track_deform_solve(model, prm, graph, map_pos, f_map, f_status, f_uv, f_pos,
                 lost=lost[:nl.value].tolist(), trace=_trace_list(tr, ntr.value), stats={k: getattr(st, k) for k, _ in TStats._fields_})
 
 
+def track_deform_solve_embedded(model, prm, graph, map_pos, f_map, f_status, f_uv, f_pos, f_node, pose_q, pose_t, scale, lib=None):
+    """the embedded-deformation form on the flat graph (oracle/embedded_oracle.track_deform_solve_embedded): f_node[i] != 0 marks the nodes"""
+    lib = lib or load()
+    p8 = np.zeros(8, np.float32)
+    p8[:len(prm)] = np.asarray(prm, np.float32)
+    g = {k: (np.ascontiguousarray(v).copy() if isinstance(v, np.ndarray) else v) for k, v in graph.items()}
+    for k in ("rowptr", "col", "eid", "e_status"):
+        g[k] = np.ascontiguousarray(g[k], np.int32)
+    for k in ("e_w", "e_d0", "e_max", "e_min"):
+        g[k] = np.ascontiguousarray(g[k], np.float32)
+    map_pos = np.ascontiguousarray(map_pos, np.float32).copy()
+    f_map = np.ascontiguousarray(f_map, np.int32)
+    f_status = np.ascontiguousarray(f_status, np.int32).copy()
+    f_uv = np.ascontiguousarray(f_uv, np.float32)
+    f_pos = np.ascontiguousarray(f_pos, np.float32).copy()
+    f_node = np.ascontiguousarray(np.asarray(f_node) != 0, np.uint8)
+    qt = np.ascontiguousarray(np.concatenate([np.asarray(pose_q, np.float64), np.asarray(pose_t, np.float64)]))
+    n_points = len(map_pos)
+    lost = np.zeros(n_points, np.int32)
+    med, nl, nn, ns = C.c_float(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    tr = (Trial * 1024)()
+    ntr, st = C.c_int32(0), TStats()
+    rc = lib.nrs_cpu_track_deform_solve_embedded(C.c_int32(int(model)), _p(p8, C.c_float), C.c_int32(n_points), _p(g["rowptr"], C.c_int32),
+                                                 _p(g["col"], C.c_int32), _p(g["eid"], C.c_int32), _p(g["e_w"], C.c_float), _p(g["e_d0"], C.c_float),
+                                                 _p(g["e_max"], C.c_float), _p(g["e_min"], C.c_float), _p(g["e_status"], C.c_int32),
+                                                 C.c_float(float(g["sigma"])), C.c_float(float(g["stretch_th"])), _p(map_pos, C.c_float),
+                                                 C.c_int32(len(f_map)), _p(f_map, C.c_int32), _p(f_status, C.c_int32), _p(f_uv, C.c_float),
+                                                 _p(f_pos, C.c_float), _p(f_node, C.c_uint8), _p(qt, C.c_double), C.c_float(float(scale)), C.byref(med), C.byref(nl),
+                                                 _p(lost, C.c_int32), C.byref(nn), C.byref(ns), tr, C.c_int32(1024), C.byref(ntr), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("nrs_cpu_track_deform_solve_embedded failed: %d" % rc)
+    return dict(pose_q=qt[:4].copy(), pose_t=qt[4:].copy(), f_pos=f_pos, f_status=f_status, map_pos=map_pos, graph=g, median=float(med.value),
+                lost=lost[:nl.value].tolist(), n_nodes=nn.value, n_skinned=ns.value, trace=_trace_list(tr, ntr.value),
+                stats={k: getattr(st, k) for k, _ in TStats._fields_})
+
+
 class LucasKanadeCpp:
     """oracle/nrs_cpu_lk.hpp behind the interface of lk_oracle.LucasKanadeOracle (no mask)"""
 

@@ -42,6 +42,14 @@ struct TGraph {
     // unary dampers against a vertex read live (SpatialRegularizerFixed: raw pointer to the other vertex' estimate)
     vector<int> ui, uj;
     vector<double> uw;
+    // embedded mode (oracle/embedded_oracle.py SkinnedReprojEdges): observations of optimised points WITHOUT a vertex -- the point sits at
+    // X0 + sum_k om_k x[node_k] over <= 11 vertices (pads: vertex 0 with weight 0, as the oracle's arrays), Jacobian om_k J_l per node
+    static constexpr int SKN = 11, SKV = SKN + 2;
+    int n_sk = 0;
+    vector<int> sk_node, sk_level;
+    vector<double> sk_om, sk_X0, sk_uv, sk_err;
+    vector<uint8_t> a_sk;
+    vector<int64_t> s_sk;                        // (v1, v2) row-major over (pose omega, pose upsilon, the 11 nodes), -1: not in the system
     // ---- per optimize(): active sets, index mapping, structure
     vector<uint8_t> a_rep, a_dm, a_sp, a_un;
     vector<int> blk;                             // point vertex -> block (permuted), -1 = not in the system
@@ -66,6 +74,25 @@ struct TGraph {
         float u, v;
         project_f32(model, prm, (float)pc[0], (float)pc[1], (float)pc[2], u, v);
         r[0] = uv[2 * (size_t)i] - (double)u; r[1] = uv[2 * (size_t)i + 1] - (double)v;
+        if (pc_out) { pc_out[0] = pc[0]; pc_out[1] = pc[1]; pc_out[2] = pc[2]; }
+    }
+    void sk_deformation(int i, double* d) const {                    // (sequential over the nodes, as SkinnedReprojEdges.deformation)
+        d[0] = d[1] = d[2] = 0;
+        for (int k = 0; k < SKN; ++k) {
+            const double om = sk_om[SKN * (size_t)i + k];
+            const double* xn = &x[3 * (size_t)sk_node[SKN * (size_t)i + k]];
+            for (int a = 0; a < 3; ++a) d[a] += om * xn[a];
+        }
+    }
+    void sk_residual(int i, double* r, double* pc_out = nullptr) const {
+        double d[3], xw[3], pc[3];
+        sk_deformation(i, d);
+        for (int a = 0; a < 3; ++a) xw[a] = sk_X0[3 * (size_t)i + a] + d[a];
+        quat_rotate(pose.q, xw, pc);
+        for (int a = 0; a < 3; ++a) pc[a] += pose.t[a];
+        float u, v;
+        project_f32(model, prm, (float)pc[0], (float)pc[1], (float)pc[2], u, v);
+        r[0] = sk_uv[2 * (size_t)i] - (double)u; r[1] = sk_uv[2 * (size_t)i + 1] - (double)v;
         if (pc_out) { pc_out[0] = pc[0]; pc_out[1] = pc[1]; pc_out[2] = pc[2]; }
     }
     void dm_residual(int k, double* r) const {
@@ -99,6 +126,13 @@ struct TGraph {
             if (a_dm[k] || a_sp[k]) { used[ei[k]] = 1; used[ej[k]] = 1; }
         }
         for (int k = 0; k < U; ++k) { a_un[k] = !pt_fixed[ui[k]]; if (a_un[k]) used[ui[k]] = 1; }
+        a_sk.assign(n_sk, 0);
+        for (int i = 0; i < n_sk; ++i) {
+            bool allfix = pose_fixed;
+            for (int k = 0; k < SKN; ++k) allfix = allfix && pt_fixed[sk_node[SKN * (size_t)i + k]];
+            a_sk[i] = sk_level[i] == 0 && !allfix;
+            if (a_sk[i]) { pose_used = true; for (int k = 0; k < SKN; ++k) used[sk_node[SKN * (size_t)i + k]] = 1; }
+        }
         // natural order: pose blocks first, then the active non-fixed points by id
         vector<int> nat(N, -1);
         int n = 0;
@@ -126,6 +160,13 @@ struct TGraph {
                 if (i >= 0 && j >= 0) { pr.emplace_back(P(i), P(j)); pr.emplace_back(P(j), P(i)); }
             }
             for (int k = 0; k < U; ++k) if (a_un[k]) { const int i = P(nat[ui[k]]); pr.emplace_back(i, i); }
+            for (int i = 0; i < n_sk; ++i) {
+                if (!a_sk[i]) continue;
+                int v[SKV];
+                v[0] = pose_in ? P(0) : -1; v[1] = pose_in ? P(1) : -1;
+                for (int k = 0; k < SKN; ++k) { const int nt = nat[sk_node[SKN * (size_t)i + k]]; v[2 + k] = nt >= 0 ? P(nt) : -1; }
+                for (int p = 0; p < SKV; ++p) for (int q = 0; q < SKV; ++q) if (v[p] >= 0 && v[q] >= 0) pr.emplace_back(v[p], v[q]);
+            }
             std::sort(pr.begin(), pr.end());
             pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
             M.n = nb;
@@ -174,6 +215,15 @@ struct TGraph {
         }
         s_un.assign(U, -1);
         for (int k = 0; k < U; ++k) if (a_un[k]) s_un[k] = H.find(blk[ui[k]], blk[ui[k]]);
+        s_sk.assign((size_t)SKV * SKV * n_sk, -1);
+        for (int i = 0; i < n_sk; ++i) {
+            if (!a_sk[i]) continue;
+            int v[SKV];
+            v[0] = pb[0]; v[1] = pb[1];
+            for (int k = 0; k < SKN; ++k) v[2 + k] = blk[sk_node[SKN * (size_t)i + k]];
+            for (int p = 0; p < SKV; ++p) for (int q = 0; q < SKV; ++q)
+                if (v[p] >= 0 && v[q] >= 0) s_sk[((size_t)i * SKV + p) * SKV + q] = H.find(v[p], v[q]);
+        }
         b.assign(3 * (size_t)nb, 0.0);
         chol = BlockChol();
         chol.analyze(H);
@@ -206,6 +256,13 @@ struct TGraph {
                 huber(info_sp * r * r, delta_sp, rho0, rho1);
                 chi += rho0;
             }
+        }
+        for (int i = 0; i < n_sk; ++i) {
+            if (!a_sk[i]) continue;
+            double* r = &sk_err[2 * (size_t)i];
+            sk_residual(i, r);
+            huber(info_rep * (r[0] * r[0] + r[1] * r[1]), delta_rep, rho0, rho1);
+            chi += rho0;
         }
         for (size_t k = 0; k < ui.size(); ++k) {
             if (!a_un[k]) continue;
@@ -303,6 +360,38 @@ struct TGraph {
                     if (bi >= 0) b[3 * (size_t)bi + p] -= wi * r * g[p];
                     if (bj >= 0) b[3 * (size_t)bj + p] += wi * r * g[p];
                 }
+            }
+        }
+        for (int i = 0; i < n_sk; ++i) {                                // skinned observations: J_pose as the reprojection edges', J_node_k = om_k J_l
+            if (!a_sk[i]) continue;
+            double r[2], pc[3];
+            sk_residual(i, r, pc);
+            float Jf[6];
+            projjac_f32(model, prm, (float)pc[0], (float)pc[1], (float)pc[2], Jf);
+            huber(info_rep * (r[0] * r[0] + r[1] * r[1]), delta_rep, rho0, rho1);
+            const double w = rho1 * info_rep;
+            double J[SKV][6], Jl[6];
+            for (int rr = 0; rr < 2; ++rr) {
+                const double j0 = -(double)Jf[3 * rr], j1 = -(double)Jf[3 * rr + 1], j2 = -(double)Jf[3 * rr + 2];
+                J[0][3 * rr] = -j1 * pc[2] + j2 * pc[1]; J[0][3 * rr + 1] = j0 * pc[2] - j2 * pc[0]; J[0][3 * rr + 2] = -j0 * pc[1] + j1 * pc[0];
+                J[1][3 * rr] = j0; J[1][3 * rr + 1] = j1; J[1][3 * rr + 2] = j2;
+                Jl[3 * rr] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+                Jl[3 * rr + 1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+                Jl[3 * rr + 2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+            }
+            int vb[SKV];
+            vb[0] = pb[0]; vb[1] = pb[1];
+            for (int k = 0; k < SKN; ++k) {
+                vb[2 + k] = blk[sk_node[SKN * (size_t)i + k]];
+                const double om = sk_om[SKN * (size_t)i + k];
+                for (int cc = 0; cc < 6; ++cc) J[2 + k][cc] = om * Jl[cc];
+            }
+            const int64_t* sl = &s_sk[(size_t)i * SKV * SKV];
+            for (int p = 0; p < SKV; ++p) {
+                if (vb[p] < 0) continue;
+                for (int q = 0; q < SKV; ++q)
+                    if (vb[q] >= 0) add3(&H.val[9 * sl[p * SKV + q]], J[p], J[q], 2, w);
+                for (int cc = 0; cc < 3; ++cc) b[3 * (size_t)vb[p] + cc] -= w * (J[p][cc] * r[0] + J[p][3 + cc] * r[1]);
             }
         }
         for (size_t k = 0; k < ui.size(); ++k) {

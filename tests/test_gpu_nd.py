@@ -6,6 +6,7 @@ NumPy solve and against the host reference of the same plan (oracle/nd_host.cpp)
 import numpy as np
 import pytest
 
+import nrs
 import nrs_cpu as CPU
 from test_nd_cpu import block_system, g2o_block_system
 

@@ -92,3 +92,40 @@ def test_lk_cpp_is_the_numpy_lk_bit_for_bit(cpu_lib):
     assert np.array_equal(xy, oxy) and np.array_equal(st, ost) and good == ogood
     m = ~np.isnan(ossim)
     assert np.array_equal(np.isnan(ssim), np.isnan(ossim)) and np.array_equal(ssim[m], ossim[m])
+
+
+# ---- N2a: the embedded-deformation form (oracle/nrs_cpu.cpp nrs_cpu_track_deform_solve_embedded) against oracle/embedded_oracle.py
+def test_track_deform_embedded_with_every_point_a_node_is_the_parity_solve(cpu_lib):
+    tp = S.make_tracking_problem(300, 8)
+    fm = np.arange(300)
+    a = CPU.track_deform_solve_embedded(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], np.ones(300, np.uint8),
+                                        tp["pose_q"], tp["pose_t"], tp["scale"], cpu_lib)
+    b = CPU.track_deform_solve(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], cpu_lib)
+    assert a["n_skinned"] == 0 and a["lost"] == b["lost"] and a["median"] == b["median"]
+    for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+        assert np.array_equal(a[k], b[k]), k
+    assert [(t["accepted"], t["lam"], t["chi"], t["chi_new"]) for t in a["trace"]] == [(t["accepted"], t["lam"], t["chi"], t["chi_new"]) for t in b["trace"]]
+
+
+@pytest.mark.parametrize("n,m,seed,model", [(400, 60, 21, S.PINHOLE), (600, 150, 22, S.KB8), (500, 100, 23, S.PINHOLE)])
+def test_track_deform_embedded_matches_numpy_oracle(cpu_lib, n, m, seed, model):
+    import embedded_oracle as E
+    import skin_oracle as K
+    tp = S.make_tracking_problem(n, seed, model)
+    fm = np.arange(n)
+    node = np.zeros(n, np.uint8)
+    node[K.select_nodes(tp["X_prev"], m, tp["status"] == 0)] = 1
+    otr = []
+    o = E.track_deform_solve_embedded(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node,
+                                      tp["pose_q"], tp["pose_t"], tp["scale"], otr)
+    r = CPU.track_deform_solve_embedded(tp["model"], tp["prm"], tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node,
+                                        tp["pose_q"], tp["pose_t"], tp["scale"], cpu_lib)
+    assert (r["n_nodes"], r["n_skinned"]) == (o["n_nodes"], o["n_skinned"]) and r["n_skinned"] > 0.3 * n
+    assert np.array_equal(r["f_status"], o["f_status"]) and r["lost"] == list(o["lost"])
+    assert np.allclose(r["pose_q"], o["pose_q"], atol=1e-9) and np.allclose(r["pose_t"], o["pose_t"], atol=1e-8)
+    assert np.allclose(r["f_pos"], o["f_pos"], atol=1e-6) and np.allclose(r["map_pos"], o["map_pos"], atol=1e-6)
+    assert np.array_equal(r["graph"]["e_status"], o["graph"]["e_status"])
+    for k in ("e_w", "e_max", "e_min"):
+        assert np.allclose(r["graph"][k], o["graph"][k], atol=1e-6)
+    assert abs(r["median"] - o["median"]) <= 1e-6
+    assert _same_leading_trials(r["trace"], otr, len(otr)) > 8
