@@ -33,8 +33,8 @@ struct KftDev {
     int K, ld, nb, m, nfm;           // keyframes; padded block dimension (multiple of KFT_B); ld / KFT_B; middle keyframe; ld / 3 (stride of the per-node tables)
     double* A;                       // K x ld x ld: A_k, then S_k, then G_k in place (full symmetric squares; rows / columns >= n_k: identity)
     double* YT;                      // 2 x ld x ld: per chain (G_f C^T)^T of the Schur update
-    double* Bb; double* Cb;          // 2 x nb x 64 x 64: panels of a sweep step, packed [k / 4][row][k % 4] (what the matrix-core operands read)
-    double* Pv;                      // 2 x 64 x 64: the swept pivot block (- P^-1)
+    double* Bb; double* Cb;          // 2 (step parity) x 2 (chains) x nb x 64 x 64: panels of a sweep step, packed [k / 4][row][k % 4] (what the matrix-core operands read)
+    double* Pv;                      // 2 (step parity) x 2 x 64 x 64: the swept pivot block (- P^-1)
     double* z; double* xs;           // K x ld: G_k y_k of the forward pass; the solution (compact order) for the backward pass
     double* vb;                      // 2 x ld: the right-hand side of a solve stage (per chain)
     const int* kf_nf; const int* kf_np;   // K: free node rows of a keyframe; 6 if its pose is free, else 0
@@ -211,12 +211,90 @@ __global__ __launch_bounds__(256) void k_kft_clvals(KftDev F) {
 // ------------------------------------------------------------------------------------------------------------------ the sweep
 // SWEEP(j) of a symmetric matrix on 64 x 64 blocks (P = A_jj):  A_jj <- -P^-1,  A_Ij <- A_Ij P^-1 (and its mirror),
 // A_IL <- A_IL - A_Ij P^-1 A_jL for I, L != j; after every block has been swept the matrix is -A^-1.  Two launches per step:
-//   k_kft_panel  (one workgroup per block row I): inverts P in registers (64 scalar sweep steps, the pivot column through LDS),
+//   k_kft_panel  (one workgroup per block row I): inverts P in registers (kft_sweep64: sixteen 4-pivot steps),
 //                B_I = C_I P^-1 on the vector units, leaves B_I in the panel (both triangles) and B_I / C_I in the packed buffers
 //   k_kft_update (one workgroup per tile): A_IL -= B_I C_L^T on the matrix cores; the tile (j, j) takes the swept pivot block
 // The final sign is taken off by the last step (k_kft_update with neg = 1 writes -A).  Both launches serve the two chains at once.
 constexpr int KFT_LDP = KFT_B + 1;
-constexpr size_t KFT_PANEL_LDS = sizeof(double) * (2 * (size_t)KFT_B * KFT_LDP + 2 * KFT_B);
+// k_kft_step asks for more than half a CU's LDS: a trailing-update workgroup then never shares a CU with a panel workgroup (whose 64-pivot
+// sweep is the launch's critical path and loses ~10 us to a co-resident matrix-core workgroup)
+constexpr size_t KFT_STEP_LDS = 84 * 1024;
+constexpr int KFT_CBS = 18;          // doubles per 4 x 4 block of the sweep's block-column buffer (16 + 2: sixteen lanes reading sixteen blocks hit sixteen bank groups)
+constexpr size_t KFT_PANEL_LDS = sizeof(double) * (2 * (size_t)KFT_B * KFT_LDP + 2 * 16 * KFT_CBS + 16);   // P, C_I (padded rows), the sweep's block-column buffers + its -I block
+// SWEEP of a 64 x 64 symmetric positive definite block held as 4 x 4 register blocks (thread (ti, tj) of 16 x 16 holds rows 4 ti .., columns
+// 4 tj ..): sixteen steps of FOUR pivots each.  A step sweeps the 4 x 4 pivot block P = A_pp (every thread inverts it for itself -- a
+// scalar sweep on sixteen registers), and with C_I = A_Ip (the block column, through LDS: one barrier per step instead of one per pivot)
+//     A_IJ <- A_IJ - C_I P^-1 C_J^T,   A_Ip <- C_I P^-1,   A_pJ <- P^-1 C_J^T,   A_pp <- -P^-1
+// as ONE expression  m a - L (P^-1 R^T):  L = C_I, R = C_J, m = 1 in general; in the pivot row L = -I (read from a constant block: the
+// choice is an LDS ADDRESS, not sixteen selects), in the pivot column R = -I, and m = 0 in both.  345 cycles per pivot against 840 of the
+// pivot-at-a-time form (one LDS round trip, one reciprocal chain and nine selects per pivot).  Leaves -A^-1 in a; colb: 2 x 16 x KFT_CBS + 16 doubles.
+__device__ __forceinline__ bool kft_sweep64(double (&a)[4][4], double* colb, int ti, int tj) {
+    double* negI = colb + 2 * 16 * KFT_CBS;
+    if (ti == 0 && tj < 16) negI[tj] = (tj % 5 == 0) ? -1.0 : 0.0;   // (written before the first barrier below, read after it)
+    bool bad = false;
+#pragma unroll 1
+    for (int pb = 0; pb < KFT_B / 4; ++pb) {
+        double* cb = colb + (pb & 1) * 16 * KFT_CBS;
+        if (tj == pb) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) cb[KFT_CBS * ti + 4 * x + y] = a[x][y];
+        }
+        __syncthreads();
+        const bool prow = ti == pb, pcol = tj == pb;
+        const double* Lp = prow ? negI : cb + KFT_CBS * ti;
+        const double* Rp = pcol ? negI : cb + KFT_CBS * tj;
+        double P[4][4], L[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { P[x][y] = cb[KFT_CBS * pb + 4 * x + y]; L[x][y] = Lp[4 * x + y]; }
+        // - P^-1 by four scalar sweeps (lower triangle computed, mirrored)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double d = P[q][q];
+            const bool ok = d > 0.0 && d < 1e300;
+            bad = bad || !ok;
+            d = ok ? d : 1.0;
+            double inv = __builtin_amdgcn_rcp(d);
+            inv = fma(fma(-d, inv, 1.0), inv, inv);
+            double col[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[r] = P[r][q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    if (r == q || cc == q) continue;
+                    P[r][cc] -= col[r] * col[cc] * inv;
+                    P[cc][r] = P[r][cc];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r != q) { P[r][q] = col[r] * inv; P[q][r] = P[r][q]; }
+            P[q][q] = -inv;
+        }
+        const double m = (prow || pcol) ? 0.0 : 1.0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            double R[4], T[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) R[t] = Rp[4 * y + t];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) T[sidx] = -(P[sidx][0] * R[0] + P[sidx][1] * R[1] + P[sidx][2] * R[2] + P[sidx][3] * R[3]);   // (P holds -P^-1)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[x][y] = m * a[x][y] - (L[x][0] * T[0] + L[x][1] * T[1] + L[x][2] * T[2] + L[x][3] * T[3]);
+        }
+    }
+    return bad;
+}
+
+// SWEEP(j) of a symmetric matrix on 64 x 64 blocks (P = A_jj):  A_jj <- -P^-1,  A_Ij <- A_Ij P^-1 (and its mirror),
+// A_IL <- A_IL - A_Ij P^-1 A_jL for I, L != j; after every block has been swept the matrix is -A^-1.  Two launches per step:
+//   k_kft_panel  (one workgroup per block row I): inverts P in registers (kft_sweep64: sixteen 4-pivot steps),
+//                B_I = C_I P^-1 on the vector units, leaves B_I in the panel (both triangles) and B_I / C_I in the packed buffers
+//   k_kft_update (one workgroup per tile): A_IL -= B_I C_L^T on the matrix cores; the tile (j, j) takes the swept pivot block
+// The final sign is taken off by the last step (k_kft_update with neg = 1 writes -A).  Both launches serve the two chains at once.
 
 __global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int kf1, int* flags) {
     extern __shared__ double sm[];
@@ -242,42 +320,7 @@ __global__ __launch_bounds__(256) void k_kft_panel(KftDev F, int j, int kf0, int
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) a[x][y] = Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y];
-    bool bad = false;
-    // scalar SWEEP(p), p = 0 .. 63, on the 4 x 4 register blocks: with the pivot column c (= row, by symmetry) and d = c_p,
-    //   a_rc <- a_rc - c_r c_c / d  (r, c != p),  a_rp <- c_r / d,  a_pc <- c_c / d,  a_pp <- -1 / d
-#pragma unroll 1
-    for (int pb = 0; pb < KFT_B / 4; ++pb) {                        // (four pivots per trip: the register block's column index is a constant in every copy)
-#pragma unroll
-        for (int y0 = 0; y0 < 4; ++y0) {
-            const int p = 4 * pb + y0;
-            double* cb = colb + (y0 & 1) * KFT_B;
-            if (tj == pb) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) cb[4 * ti + x] = a[x][y0];
-            }
-            __syncthreads();
-            double d = cb[p];
-            const bool ok = d > 0.0 && d < 1e300;
-            bad = bad || !ok;
-            d = ok ? d : 1.0;
-            double inv = __builtin_amdgcn_rcp(d);                  // (v_rcp_f64 + one Newton step: the division's ten dependent operations are on every thread's chain)
-            inv = fma(fma(-d, inv, 1.0), inv, inv);
-            double cr[4], cc[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { cr[x] = cb[4 * ti + x]; cc[x] = cb[4 * tj + x] * inv; }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) a[x][y] -= cr[x] * cc[y];
-            // the pivot row, the pivot column and the pivot itself (the register block's row / column y0 in the threads that hold them)
-            const bool prow = ti == pb, pcol = tj == pb;
-#pragma unroll
-            for (int y = 0; y < 4; ++y) a[y0][y] = prow ? cc[y] : a[y0][y];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) a[x][y0] = pcol ? cr[x] * inv : a[x][y0];
-            a[y0][y0] = (prow && pcol) ? -inv : a[y0][y0];
-        }
-    }
+    const bool bad = kft_sweep64(a, colb, ti, tj);
     if (bad && tid == 0) flags[2] = 1;
     const size_t tile = (size_t)KFT_B * KFT_B;
     double* Bb = F.Bb + ((size_t)ch * F.nb + I) * tile;
@@ -368,6 +411,135 @@ __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, in
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g) At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)] = sgn * c[n][g];
+}
+
+// ---- the two launches of a sweep step as ONE (look-ahead): launch j applies the trailing update of step j - 1 and, next to it, produces
+// the panel of step j.  The panel workgroups (one per block row I: the critical path -- a 64-pivot sweep) bring the two tiles they need up
+// to date themselves -- their own tile (I, j) and the pivot tile (j, j), each minus B C^T of step j - 1 on the matrix cores -- so they do
+// not wait for the trailing update, which the other workgroups run meanwhile.  Nobody writes the pivot tile during the launch (every panel
+// workgroup reads its pre-update value): the swept block travels through Pv and lands with launch j + 1.  Panels B / C / Pv are
+// double-buffered by the parity of j.  nb + 1 launches per inversion instead of 2 nb; same arithmetic as the two-launch form up to the
+// association of the pivot tile's update (NRS_KFT_TWO_LAUNCHES=1 selects that form).
+__global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags) {
+    extern __shared__ double sm[];
+    const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
+    if (kf < 0) return;
+    const int nb = F.nb, ld = F.ld, jp = j - 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t tile = (size_t)KFT_B * KFT_B, pbuf = (size_t)2 * nb * tile;
+    double* A = F.A + (size_t)kf * ld * ld;
+    const double* Bp = F.Bb + (size_t)(jp & 1) * pbuf + (size_t)ch * nb * tile;       // panels of step j - 1
+    const double* Cp = F.Cb + (size_t)(jp & 1) * pbuf + (size_t)ch * nb * tile;
+    const double* Pvp = F.Pv + ((size_t)(jp & 1) * 2 + ch) * tile;
+    const bool last = j == nb;                                      // the closing launch: trailing update of the last step, the sign taken off
+    const double sgn = last ? -1.0 : 1.0;
+    // tile (I, L) <- sgn * (tile - B_I C_L^T) on the matrix cores, to global memory or (row-major, stride KFT_LDP) to LDS
+    auto updated_tile = [&](int I, int L, bool apply, double* lds_out) {
+        const double* At = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
+        nd_v4d c[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) c[n][g] = At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)];
+        if (apply) {
+            const double* Bb = Bp + (size_t)I * tile;
+            const double* Cb = Cp + (size_t)L * tile;
+#pragma unroll 4
+            for (int kq = 0; kq < KFT_B / 4; ++kq) {
+                const double av = -Bb[((size_t)kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
+                double bv[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bv[n] = Cb[((size_t)kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * w + (lane >> 4) + 4 * g, cc = 16 * n + (lane & 15);
+                if (lds_out) lds_out[r * KFT_LDP + cc] = c[n][g];
+                else A[(size_t)(KFT_B * I + r) * ld + KFT_B * L + cc] = sgn * c[n][g];
+            }
+    };
+    if ((int)blockIdx.x >= nb) {
+        // ---- trailing update of step j - 1 (every tile outside its pivot row / column and outside this step's panel)
+        if (jp < 0) return;
+        const int q = blockIdx.x - nb, I = q / nb, L = q % nb;
+        double* At = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
+        if (I == jp && L == jp) {                                   // the swept pivot block of step j - 1 lands
+            for (int e = tid; e < KFT_B * KFT_B; e += 256) At[(size_t)(e / KFT_B) * ld + e % KFT_B] = sgn * Pvp[e];
+            return;
+        }
+        if (I == jp || L == jp) {                                   // its panel: B, already in place
+            if (last) for (int e = tid; e < KFT_B * KFT_B; e += 256) { double* x = At + (size_t)(e / KFT_B) * ld + e % KFT_B; *x = -*x; }
+            return;
+        }
+        if (!last && (I == j || L == j)) return;                    // this step's panel and pivot tile: the panel workgroups'
+        updated_tile(I, L, true, nullptr);
+        return;
+    }
+    if (last) return;
+    // ---- panel of step j: block row I
+    const int I = blockIdx.x, ti = tid >> 4, tj = tid & 15;
+    double* Ps = sm;
+    double* Cs = sm + KFT_B * KFT_LDP;
+    double* colb = sm + 2 * KFT_B * KFT_LDP;
+    updated_tile(j, j, jp >= 0, Ps);                                // P = the pivot tile brought up to date (every panel workgroup its own copy)
+    if (I != j) updated_tile(I, j, jp >= 0 && I != jp, Cs);         // C_I likewise (the previous pivot row holds B already: no update)
+    __syncthreads();
+    double a[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) a[x][y] = Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y];
+    const bool bad = kft_sweep64(a, colb, ti, tj);
+    if (bad && tid == 0) flags[2] = 1;
+    double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
+    double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
+    if (I == j) {
+        double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) Pv[(4 * ti + x) * KFT_B + 4 * tj + y] = a[x][y];
+        return;                                                     // (its own B / C slots are never read: the trailing update skips the pivot row / column)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
+    for (int q = tid; q < KFT_B * KFT_B; q += 256) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
+    __syncthreads();
+    nd_v4d c[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c[n][g] = 0.0;
+#pragma unroll 4
+    for (int kq = 0; kq < KFT_B / 4; ++kq) {
+        const double av = Cs[(16 * w + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
+        double bv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[n] = Ps[(16 * n + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Cs[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
+    __syncthreads();
+    double* Bt = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
+    double* Btt = A + (size_t)(KFT_B * j) * ld + KFT_B * I;
+    for (int q = tid; q < KFT_B * KFT_B; q += 256) {
+        const int r = q >> 6, cidx = q & 63;
+        Bt[(size_t)r * ld + cidx] = Cs[r * KFT_LDP + cidx];
+        Btt[(size_t)r * ld + cidx] = Cs[cidx * KFT_LDP + r];
+        Bb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ Schur update
@@ -490,10 +662,15 @@ __global__ __launch_bounds__(256) void k_kft_gemv(KftDev F, int mode, int k0, in
 
 // ------------------------------------------------------------------------------------------------------------------ host
 static int kft_invert(nrs_ctx* c, const KftDev& F, int kf0, int kf1, int* flags) {
-    for (int j = 0; j < F.nb; ++j) {
-        hipLaunchKernelGGL(k_kft_panel, dim3(F.nb, 2), dim3(256), KFT_PANEL_LDS, c->stream, F, j, kf0, kf1, flags);
-        hipLaunchKernelGGL(k_kft_update, dim3(F.nb * F.nb, 2), dim3(256), 0, c->stream, F, j, kf0, kf1, j + 1 == F.nb ? 1 : 0);
+    if (c->env("NRS_KFT_TWO_LAUNCHES")) {                           // (A/B: the panel and the trailing update of a step as launches of their own)
+        for (int j = 0; j < F.nb; ++j) {
+            hipLaunchKernelGGL(k_kft_panel, dim3(F.nb, 2), dim3(256), KFT_PANEL_LDS, c->stream, F, j, kf0, kf1, flags);
+            hipLaunchKernelGGL(k_kft_update, dim3(F.nb * F.nb, 2), dim3(256), 0, c->stream, F, j, kf0, kf1, j + 1 == F.nb ? 1 : 0);
+        }
+        return NRS_OK;
     }
+    for (int j = 0; j <= F.nb; ++j)
+        hipLaunchKernelGGL(k_kft_step, dim3(F.nb + F.nb * F.nb, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags);
     return NRS_OK;
 }
 

@@ -20,12 +20,16 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         nf_max = std::max(nf_max, n);
     }
     if (nf_max >= 4096 || nf_max < 1) return NRS_OK;
-    // automatic choice (nrs_options.embedded_solver = 0): a factorisation is K / 2 dependent inversions of (3 nodes + 6)^2 blocks, each
-    // ld / 64 dependent pivot steps of ~60 us -- measured against the block-Jacobi PCG on 20-keyframe windows (tools/kft_probe.py,
-    // profiles/r06_kft_crossover.txt): 4.2 x faster at 100 nodes per keyframe, 2.7 x at 200, 1.7 x at 300, 1.2 x at 400, 0.75 x at 458
-    if (c->opt.embedded_solver == 0 && 3 * nf_max + 6 > 1280) return NRS_OK;
     const int ld = ((3 * nf_max + 6 + KFT_B - 1) / KFT_B) * KFT_B, nb = ld / KFT_B, nfm = ld / 3;
     const size_t n2 = (size_t)ld * ld;
+    if (c->opt.embedded_solver == 0) {
+        // automatic choice: the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches each, (30 + 0.035 nb^2) us a launch, + 2.5 ms
+        // per trial; the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count (tools/kft_probe.py on 10 .. 40 keyframes,
+        // 100 .. 600 nodes per keyframe: profiles/r06_kft_crossover.txt -- 5.2 x faster at 100 nodes x 20 keyframes, 2.2 x at 300, 1.24 x at
+        // 440, 0.92 x at 458 (C2), 1.44 x at 458 x 10 keyframes).  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
+        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (30.0 + 0.035 * nb * nb) * 1e-3 + 2.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
+        if (kft_ms > 0.9 * pcg_ms) return NRS_OK;
+    }
     if ((size_t)K * n2 * sizeof(double) > ((size_t)6 << 30)) return NRS_OK;       // (the factor would not be worth its memory: the PCG stays block-Jacobi)
     std::vector<int> kf_row((size_t)K * nfm, -1);
     for (int k = 0; k < K; ++k)
@@ -138,7 +142,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     const size_t tile = (size_t)KFT_B * KFT_B;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_A = take(8 * (size_t)K * n2), o_YT = take(8 * 2 * n2), o_Bb = take(8 * 2 * nb * tile), o_Cb = take(8 * 2 * nb * tile), o_Pv = take(8 * 2 * tile),
+    const size_t o_A = take(8 * (size_t)K * n2), o_YT = take(8 * 2 * n2), o_Bb = take(8 * 4 * nb * tile), o_Cb = take(8 * 4 * nb * tile), o_Pv = take(8 * 4 * tile),
                  o_z = take(8 * (size_t)K * ld), o_xs = take(8 * (size_t)K * ld), o_vb = take(8 * 2 * (size_t)ld), o_nf = take(4 * (size_t)K), o_np = take(4 * (size_t)K), o_kr = take(4 * kf_row.size()),
                  o_rc = take(4 * row_ci.size()), o_ppid = take(4 * (n_pp + 1)), o_ppp = take(4 * (n_pp + 1)), o_pes = take(4 * (pe.size() + 1)), o_pew = take(8 * (pe.size() + 1)),
                  o_tpp = take(4 * (n_tp + 1)), o_tes = take(4 * (te.size() + 1)), o_tpv = take(8 * (n_tp + 1)),
@@ -177,6 +181,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     static bool attr_done = false;
     if (!attr_done) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_PANEL_LDS));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
         attr_done = true;
     }
     H->bytes = off;

@@ -33,4 +33,4 @@ for mode in (1, 2):
     print("embedded_solver %d: upload %.1f ms, optimize(5) %.2f ms (min of %d) = %.1f LM it/s; trials: %s" % (
         mode, 1e3 * t_up, 1e3 * min(ts), reps, tr.iterations / min(ts), [(t["accepted"], t["inner"], "%.6e" % t["chi_new"]) for t in tr.trials]), flush=True)
     ctx.close()
-print("max |pose diff| %.3e  max |node diff| %.3e" % (np.abs(res[0][0] - res[2][0]).max(), np.abs(res[0][1] - res[2][1]).max()))
+print("max |pose diff| %.3e  max |node diff| %.3e" % (np.abs(res[1][0] - res[2][0]).max(), np.abs(res[1][1] - res[2][1]).max()))
