@@ -604,6 +604,24 @@ def skinned_bench(n=5000, m=500, n_kf=20):
                                                achieved=up_b / (up_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=up_b / (up_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                                traffic=None, avg_us=up_us, algorithmic_bytes=int(up_b), launches=int(prof["vec_launches"]))
     out["ba_window"]["pcg_iterations_per_lm_trial"] = rr["inner"] / max(1, rr["trials"])
+    # ---- the same window on the exact keyframe-block factorisation (nrs_options.embedded_solver = 1; the default's cost model keeps the PCG at this size)
+    fctx = nrs.Context(embedded_solver=1)
+    fctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
+    info = fctx.debug_kft_info()
+    rf = timed_steps(fctx, 10, 2, lambda: None)
+    fctx.close()
+    nbk, K = info["nb"], info["K"]
+    flops_trial = K * (nbk ** 3) * 2.0 * 64 ** 3                  # K inversions, nb steps of nb^2 rank-64 tile updates (full squares)
+    tf = flops_trial * rf["trials"] / rf["dt"] / 1e12
+    out["ba_window"]["keyframe_block_factorisation"] = dict(
+        value=rf["lm_iters"] / rf["dt"], unit="LM iters/s", ms_per_step=1e3 * rf["dt"] / 10, pcg_iters_per_step=rf["inner"] / 10, lm_trials_per_step=rf["trials"] / 10,
+        block_dimension=info["ld"], keyframe_blocks=K, factor_mib=info["mib"], gflop_per_trial=flops_trial / 1e9,
+        roofline=dict(kernel="k_kft_step (one launch per 64-pivot sweep step: panel + trailing rank-64 update on v_mfma_f64_16x16x4)", bound="mfma", achieved=tf,
+                      peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                      note="whole-trial rate (assembly, Schur updates, solves included): a CRITICAL-PATH computation -- %d dependent launches per trial, "
+                           "each bounded by a 64-pivot sweep in one workgroup" % (((K + 1) // 2) * (nbk + 1) + nbk + 1)),
+        note="exact solve per LM trial (what the reference's LinearSolverEigen does): block tridiagonal over the keyframes, csrc/nrs_engine_kft.hpp; "
+             "1-2 PCG iterations per trial; faster than the PCG below ~450 nodes x 20 keyframes (profiles/r06_kft_crossover.txt)")
     out["ba_window_inputs"] = (p, e, w)                            # (the CPU leg of main() runs the same window; removed before printing)
     ctx.close()
     return out

@@ -18,4 +18,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_M
 cd $R
 for a in "1000 100 20" "2000 200 20" "3000 300 20" "4000 400 20" "5000 500 20" "5000 500 10" "2500 250 40"; do echo "== points nodes keyframes: $a"; python tools/kft_probe.py $a 3 2>&1 | grep embedded_solver | sed 's/; trials.*//'; done > $OUT/kft_crossover.txt
 python bench.py --steps 200 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
-ls $OUT
+# the merge back takes 64 MiB: the per-launch traces stay on the box (the statistics are what profiles/ keeps)
+find $OUT -name '*kernel_trace.csv' -size +4M -delete
+find $OUT -name '*.db' -delete
+du -sh $OUT
