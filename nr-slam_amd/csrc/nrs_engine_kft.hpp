@@ -216,9 +216,7 @@ __global__ __launch_bounds__(256) void k_kft_clvals(KftDev F) {
 //   k_kft_update (one workgroup per tile): A_IL -= B_I C_L^T on the matrix cores; the tile (j, j) takes the swept pivot block
 // The final sign is taken off by the last step (k_kft_update with neg = 1 writes -A).  Both launches serve the two chains at once.
 constexpr int KFT_LDP = KFT_B + 1;
-// k_kft_step asks for more than half a CU's LDS: a trailing-update workgroup then never shares a CU with a panel workgroup (whose 64-pivot
-// sweep is the launch's critical path and loses ~10 us to a co-resident matrix-core workgroup)
-constexpr size_t KFT_STEP_LDS = 84 * 1024;
+constexpr size_t KFT_STEP_LDS = sizeof(double) * (2 * (size_t)(64 * 65) + 2 * 16 * 18 + 16 + 2 * (size_t)64 * 64) + 1024;   // the panel's buffers + two operand panels of 32 KB (~ 137 KB)
 constexpr int KFT_CBS = 18;          // doubles per 4 x 4 block of the sweep's block-column buffer (16 + 2: sixteen lanes reading sixteen blocks hit sixteen bank groups)
 constexpr size_t KFT_PANEL_LDS = sizeof(double) * (2 * (size_t)KFT_B * KFT_LDP + 2 * 16 * KFT_CBS + 16);   // P, C_I (padded rows), the sweep's block-column buffers + its -I block
 // SWEEP of a 64 x 64 symmetric positive definite block held as 4 x 4 register blocks (thread (ti, tj) of 16 x 16 holds rows 4 ti .., columns
@@ -477,7 +475,18 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
             return;
         }
         if (!last && (I == j || L == j)) return;                    // this step's panel and pivot tile: the panel workgroups'
-        updated_tile(I, L, true, nullptr);
+        if (I < L) return;                                          // the matrix is symmetric: the lower tiles are computed, the upper ones are their mirrors
+        if (I == L) { updated_tile(I, L, true, nullptr); return; }
+        double* Ts = sm;                                            // (row-major, stride KFT_LDP: the transposed copy is read from here, whole rows per store)
+        updated_tile(I, L, true, Ts);
+        __syncthreads();
+        double* Al = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
+        double* Au = A + (size_t)(KFT_B * L) * ld + KFT_B * I;
+        for (int e = tid; e < KFT_B * KFT_B; e += 256) {
+            const int r = e >> 6, cidx = e & 63;
+            Al[(size_t)r * ld + cidx] = sgn * Ts[r * KFT_LDP + cidx];
+            Au[(size_t)r * ld + cidx] = sgn * Ts[cidx * KFT_LDP + r];
+        }
         return;
     }
     if (last) return;
@@ -486,8 +495,51 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     double* Ps = sm;
     double* Cs = sm + KFT_B * KFT_LDP;
     double* colb = sm + 2 * KFT_B * KFT_LDP;
-    updated_tile(j, j, jp >= 0, Ps);                                // P = the pivot tile brought up to date (every panel workgroup its own copy)
-    if (I != j) updated_tile(I, j, jp >= 0 && I != jp, Cs);         // C_I likewise (the previous pivot row holds B already: no update)
+    // The two tiles this workgroup needs, brought up to date with step j - 1: P = tile (j, j) and C_I = tile (I, j), each minus B C^T.  The three
+    // operand panels (B_j, C_j, B_I of step j - 1: 32 KB each) come through LDS in whole lines -- the matrix cores read them from there --
+    // instead of 8-byte global loads per operand (9 us of this workgroup's ~35 before).
+    double* X0 = sm + 2 * KFT_B * KFT_LDP + 2 * 16 * KFT_CBS + 16;  // B panel (packed [k / 4][row][k % 4])
+    double* X1 = X0 + KFT_B * KFT_B;                                // C_j
+    const bool upP = jp >= 0, upC = jp >= 0 && I != j && I != jp;  // (the previous pivot row holds B already: no update)
+    auto tile_lds = [&](int TI, int TL, bool apply, double* out) {  // out (row-major, stride KFT_LDP) = tile (TI, TL) - X0 X1^T
+        const double* At = A + (size_t)(KFT_B * TI) * ld + KFT_B * TL;
+        nd_v4d c[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) c[n][g] = At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)];
+        if (apply) {
+#pragma unroll 4
+            for (int kq = 0; kq < KFT_B / 4; ++kq) {
+                const double av = -X0[(kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
+                double bv[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bv[n] = X1[(kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) out[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
+    };
+    if (upP) {
+        const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)j * tile);
+        const double2* c2 = reinterpret_cast<const double2*>(Cp + (size_t)j * tile);
+        for (int e = tid; e < KFT_B * KFT_B / 2; e += 256) { reinterpret_cast<double2*>(X0)[e] = b2[e]; reinterpret_cast<double2*>(X1)[e] = c2[e]; }
+        __syncthreads();
+    }
+    tile_lds(j, j, upP, Ps);
+    if (I != j) {
+        if (upC) {
+            __syncthreads();                                        // (every wave has read B_j from X0)
+            const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)I * tile);
+            for (int e = tid; e < KFT_B * KFT_B / 2; e += 256) reinterpret_cast<double2*>(X0)[e] = b2[e];
+            __syncthreads();
+        }
+        tile_lds(I, j, upC, Cs);
+    }
     __syncthreads();
     double a[4][4];
 #pragma unroll

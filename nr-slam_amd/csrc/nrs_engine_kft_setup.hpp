@@ -8,6 +8,14 @@ struct KftEnt { uint64_t key; uint32_t src; double w; };
 static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vector<int>& pose_grp_ptr) {
     const Dev& d = e->d;
     const int K = d.K;
+    const bool tm = c->env("NRS_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!tm) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nrs] kft_setup %-18s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (K < 1 || K > 255 || (e->sp_pos.empty() && s.n_sp > 0)) return NRS_OK;
     std::vector<int> kf_nf(K, 0), kf_np(K, 0), row_ci((size_t)d.n_rows, -1);
     int nf_max = 0;
@@ -23,11 +31,12 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     const int ld = ((3 * nf_max + 6 + KFT_B - 1) / KFT_B) * KFT_B, nb = ld / KFT_B, nfm = ld / 3;
     const size_t n2 = (size_t)ld * ld;
     if (c->opt.embedded_solver == 0) {
-        // automatic choice: the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches each, (30 + 0.035 nb^2) us a launch, + 2.5 ms
-        // per trial; the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count (tools/kft_probe.py on 10 .. 40 keyframes,
-        // 100 .. 600 nodes per keyframe: profiles/r06_kft_crossover.txt -- 5.2 x faster at 100 nodes x 20 keyframes, 2.2 x at 300, 1.24 x at
-        // 440, 0.92 x at 458 (C2), 1.44 x at 458 x 10 keyframes).  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
-        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (30.0 + 0.035 * nb * nb) * 1e-3 + 2.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
+        // automatic choice by a cost model of the two solvers, fitted on tools/kft_probe.py runs (10 .. 40 keyframes, 100 .. 600 nodes per keyframe,
+        // profiles/r06_kft_crossover.txt): the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches, (20.6 + 0.066 nb^2) us a launch,
+        // + 1.5 ms per trial; the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count.  Measured on 20 keyframes: 5.2 x
+        // the PCG's rate at 100 nodes per keyframe, 3.3 x at 200, 2.3 x at 300, 1.5 x at 400, 1.24 x at 440, 1.0 x at 458 (C2), 0.87 x at 550;
+        // 1.44 x at 458 x 10 keyframes.  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
+        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (20.6 + 0.066 * nb * nb) * 1e-3 + 1.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
         if (kft_ms > 0.9 * pcg_ms) return NRS_OK;
     }
     if ((size_t)K * n2 * sizeof(double) > ((size_t)6 << 30)) return NRS_OK;       // (the factor would not be worth its memory: the PCG stays block-Jacobi)
@@ -82,6 +91,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
             for (int b = a + 1; b < SK_MAX; ++b)
                 if (cn[a] >= 0 && cn[b] >= 0) add_pair(k, cn[a], cn[b], (2u << 30) | (uint32_t)e->sk_slot[i], s.sk_om[SK_MAX * (size_t)i + a] * s.sk_om[SK_MAX * (size_t)i + b]);
     }
+    mark("entries");
     auto by_key = [](const KftEnt& a, const KftEnt& b) { return a.key < b.key; };
     {   // (keyframes are independent: sorted in parallel, each stably -- the generation order above is the summation order)
         std::vector<size_t> kp(K + 1, 0);
@@ -95,9 +105,23 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         parallel_for(std::min(nt, K), [&](int ti, int n) {
             int64_t a, b;
             chunk(K, ti, n, a, b);
-            for (int k = (int)a; k < (int)b; ++k) std::stable_sort(pe.begin() + kp[k], pe.begin() + kp[k + 1], by_key);
+            std::vector<int> cnt;
+            std::vector<KftEnt> buf;
+            for (int k = (int)a; k < (int)b; ++k) {
+                const size_t n0 = kp[k], n1 = kp[k + 1], nk = (size_t)kf_nf[k];
+                if (nk * nk > ((size_t)4 << 20) || n1 - n0 < 64) { std::stable_sort(pe.begin() + n0, pe.begin() + n1, by_key); continue; }
+                // counting sort by (hi, lo) < nf^2 (stable: equal keys keep the generation order, which is the summation order)
+                cnt.assign(nk * nk + 1, 0);
+                auto kk = [&](const KftEnt& x) { return (size_t)((x.key >> 12) & 0xFFF) * nk + (size_t)(x.key & 0xFFF); };
+                for (size_t i = n0; i < n1; ++i) cnt[kk(pe[i]) + 1]++;
+                for (size_t q = 0; q < nk * nk; ++q) cnt[q + 1] += cnt[q];
+                buf.resize(n1 - n0);
+                for (size_t i = n0; i < n1; ++i) buf[cnt[kk(pe[i])]++] = pe[i];
+                std::copy(buf.begin(), buf.end(), pe.begin() + n0);
+            }
         });
     }
+    mark("pair sort");
     std::stable_sort(te.begin(), te.end(), by_key);
     std::vector<uint32_t> pp_id, pe_src(pe.size()), te_src(te.size());
     std::vector<int> pp_ptr, tp_ptr;
@@ -137,6 +161,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
             cl_from[dir][q] = dir == 0 ? a : b; cl_tp[dir][q] = (int)i;
         }
     }
+    mark("lists");
     // ---- one device buffer
     auto al = [](size_t b2) { return (b2 + 255) & ~(size_t)255; };
     const size_t tile = (size_t)KFT_B * KFT_B;
@@ -149,6 +174,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
                  o_cp0 = take(4 * cl_ptr[0].size()), o_cp1 = take(4 * cl_ptr[1].size()), o_cf0 = take(4 * (n_tp + 1)), o_cf1 = take(4 * (n_tp + 1)),
                  o_ct0 = take(4 * (n_tp + 1)), o_ct1 = take(4 * (n_tp + 1)), o_cv0 = take(8 * (n_tp + 1)), o_cv1 = take(8 * (n_tp + 1));
     if (c->ensure(c->dba_kft, off) != NRS_OK) return NRS_OK;      // (no memory for the factor: block-Jacobi PCG)
+    mark("device buffer");
     char* base = c->dba_kft.as<char>();
     auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess; };
     NRS_HIP(c, up(o_nf, kf_nf.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_np, kf_np.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_kr, kf_row.data(), 4 * kf_row.size()));
@@ -160,6 +186,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     NRS_HIP(c, up(o_ct0, cl_tp[0].data(), 4 * n_tp)); NRS_HIP(c, up(o_ct1, cl_tp[1].data(), 4 * n_tp));
     NRS_HIP(c, hipMemsetAsync(base + o_z, 0, o_nf - o_z, c->stream));     // (z and xs)
     NRS_HIP(c, hipStreamSynchronize(c->stream));
+    mark("uploads");
     KftHost* H = new (std::nothrow) KftHost();
     if (!H) return c->fail(NRS_ERR_ALLOC, "out of host memory");
     KftDev& F = H->d;
