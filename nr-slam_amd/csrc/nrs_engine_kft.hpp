@@ -611,28 +611,39 @@ __global__ __launch_bounds__(256) void k_kft_gct(KftDev F, int f0, int f1) {
     for (int e = ptr[b]; e < ptr[b + 1]; ++e) acc += F.cl_val[dir][e] * G[(size_t)(3 * F.cl_from[dir][e] + comp) * F.ld + i];
     F.YT[((size_t)ch * F.ld + col) * F.ld + i] = acc;
 }
-// one workgroup per column of S_to: the YT row in LDS, a thread per 'to' node (its three components share the list)
+// one workgroup per KFT_TC columns of S_to: their YT rows in LDS, a thread per 'to' node -- its list is read once for all the columns
+// and its three components
+constexpr int KFT_TC = 4;
 __global__ __launch_bounds__(256) void k_kft_tgt(KftDev F, int f0, int f1) {
     extern __shared__ double yrow[];
     const int ch = blockIdx.y, f = ch ? f1 : f0;
     if (f < 0) return;
     const int t = ch ? f - 1 : f + 1, dir = ch;
-    const int col = blockIdx.x;
-    const int nft = F.kf_nf[t];
-    if (col >= 3 * nft) return;
-    const double* Y = F.YT + ((size_t)ch * F.ld + col) * F.ld;
-    for (int i = threadIdx.x; i < F.ld; i += 256) yrow[i] = Y[i];
+    const int col0 = blockIdx.x * KFT_TC;
+    const int nft = F.kf_nf[t], ld = F.ld;
+    if (col0 >= 3 * nft) return;
+    const int nc = min(KFT_TC, 3 * nft - col0);
+    const double* Y = F.YT + ((size_t)ch * ld + col0) * ld;
+    for (int i = threadIdx.x; i < nc * ld; i += 256) yrow[i] = Y[i];
     __syncthreads();
     const int* ptr = F.cl_ptr[dir] + (size_t)t * (F.nfm + 1);
-    double* S = F.A + (size_t)t * F.ld * F.ld + (size_t)col * F.ld;
+    double* S = F.A + (size_t)t * ld * ld + (size_t)col0 * ld;
     for (int b = threadIdx.x; b < nft; b += 256) {
-        double a0 = 0, a1 = 0, a2 = 0;
+        double acc[KFT_TC][3];
+#pragma unroll
+        for (int q = 0; q < KFT_TC; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
         for (int e = ptr[b]; e < ptr[b + 1]; ++e) {
             const double v = F.cl_val[dir][e];
-            const double* y = yrow + 3 * F.cl_from[dir][e];
-            a0 += v * y[0]; a1 += v * y[1]; a2 += v * y[2];
+            const int o = 3 * F.cl_from[dir][e];
+#pragma unroll
+            for (int q = 0; q < KFT_TC; ++q) {
+                const double* y = yrow + q * ld + o;
+                acc[q][0] += v * y[0]; acc[q][1] += v * y[1]; acc[q][2] += v * y[2];
+            }
         }
-        S[3 * b] -= a0; S[3 * b + 1] -= a1; S[3 * b + 2] -= a2;
+#pragma unroll
+        for (int q = 0; q < KFT_TC; ++q)
+            if (q < nc) { double* Sq = S + (size_t)q * ld + 3 * b; Sq[0] -= acc[q][0]; Sq[1] -= acc[q][1]; Sq[2] -= acc[q][2]; }
     }
 }
 
@@ -743,8 +754,8 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
     for (int s = 0; s < std::max(len0, len1); ++s) {
         const int k0 = s < len0 ? s : -1, k1 = s < len1 ? F.K - 1 - s : -1;
         NRS_TRY(kft_invert(c, F, k0, k1, d.flags));
-        const dim3 g((F.ld + 255) / 256, F.ld, 2), g2(F.ld, 2);
-        const size_t shy = sizeof(double) * F.ld;
+        const dim3 g((F.ld + 255) / 256, F.ld, 2), g2((F.ld + KFT_TC - 1) / KFT_TC, 2);
+        const size_t shy = sizeof(double) * KFT_TC * F.ld;
         hipLaunchKernelGGL(k_kft_gct, g, dim3(256), 0, c->stream, F, k0, k1);
         if (k0 >= 0 && k1 >= 0 && k0 + 1 == k1 - 1) {              // both chains reach the middle keyframe: one after the other (fixed order)
             hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, -1);
