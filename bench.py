@@ -568,12 +568,15 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     camw = nrs.make_camera(p["model"], p["prm"])
     qt = np.concatenate([p["poses_q"], p["poses_t"]], 1)
     ctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
+    kft_default = ctx.debug_kft_info()["on"]                      # (nrs_options.embedded_solver = 0: the library's cost model chose)
     rr = timed_steps(ctx, 10, 2, lambda: None)
     out["ba_window"] = dict(workload="C2 embedded: %d points x %d nodes x %d keyframes" % (p["n_points"], m, p["n_kf"]), node_copies=int(len(e["lm_obs"])),
                             skinned_observations=int(len(e["sk_obs"])), springs=int(len(e["sp_ij"])), dampers=int(len(e["dm_idx"])),
                             unknowns=int(6 * p["n_kf"] + 3 * len(e["lm_obs"])), value=rr["lm_iters"] / rr["dt"], unit="LM iters/s",
                             ms_per_step=1e3 * rr["dt"] / 10, lm_trials_per_step=rr["trials"] / 10, pcg_iters_per_step=rr["inner"] / 10,
-                            linear_solver="block-Jacobi PCG, the skinned observations applied as hyper-edges (k_spmv_f_skin / k_pcg_update<true>: two launches per iteration)",
+                            linear_solver=("the default (nrs_options.embedded_solver = 0, cost model): exact keyframe-block factorisation on the matrix cores as the PCG's "
+                                           "preconditioner (csrc/nrs_engine_kft.hpp), 1-2 PCG iterations per LM trial") if kft_default else
+                                          "the default (nrs_options.embedded_solver = 0, cost model): block-Jacobi PCG, the skinned observations applied as hyper-edges",
                             note="every observation of the window is in the problem; held to oracle/embedded_oracle.py dba_solve_embedded at 300 x 40 x 4 .. "
                                  "600 x 80 x 6 (tests/test_gpu_embedded_ba.py) and at this size by the golden tests/golden/dba_C2_embedded%d_trace.npz; "
                                  "the mode has no reference counterpart beyond every-point-a-node (there it is the plain window, bit for bit)" % m)
@@ -583,7 +586,13 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     # pairs and the 24-byte g_o it leaves = 348 B; per node row u, w, the linearisation point and the 32-byte reprojection factors = 104 B;
     # 12 B per spring incidence, 16 B per damper incidence.  Update -- per node row 6 vectors read, 5 written, M^-1 = 312 B; per (row, observation)
     # list entry weight + index + g_o = 36 B.  Both stay in the 256 MB Infinity Cache at this size: the fraction is of the HBM peak all the same.
-    pctx = nrs.Context(profile=1)
+    bctx = nrs.Context(embedded_solver=2)
+    bctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
+    rb = timed_steps(bctx, 10, 2, lambda: None)
+    bctx.close()
+    out["ba_window"]["block_jacobi_pcg"] = dict(value=rb["lm_iters"] / rb["dt"], unit="LM iters/s", ms_per_step=1e3 * rb["dt"] / 10, pcg_iters_per_step=rb["inner"] / 10,
+                                                note="nrs_options.embedded_solver = 2: k_spmv_f_skin / k_pcg_update<true>, two launches per iteration; the two roofline entries below are its kernels")
+    pctx = nrs.Context(profile=1, embedded_solver=2)
     pctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
     pctx.dba_optimize(2)
     pctx.reset_profile()
@@ -604,7 +613,7 @@ def skinned_bench(n=5000, m=500, n_kf=20):
                                                achieved=up_b / (up_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=up_b / (up_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                                traffic=None, avg_us=up_us, algorithmic_bytes=int(up_b), launches=int(prof["vec_launches"]))
     out["ba_window"]["pcg_iterations_per_lm_trial"] = rr["inner"] / max(1, rr["trials"])
-    # ---- the same window on the exact keyframe-block factorisation (nrs_options.embedded_solver = 1; the default's cost model keeps the PCG at this size)
+    # ---- the same window on the exact keyframe-block factorisation forced (nrs_options.embedded_solver = 1)
     fctx = nrs.Context(embedded_solver=1)
     fctx.dba_upload_embedded(camw, qt, w, e, p["scale"])
     info = fctx.debug_kft_info()

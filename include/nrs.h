@@ -96,8 +96,8 @@ typedef struct {
                                  cores along two elimination chains, and the factorisation preconditions the PCG, which then
                                  converges to pcg_rtol in one or two iterations (csrc/nrs_engine_kft.hpp).
                                  0 (default): that solver where a cost model of the two says it is the faster one (measured:
-                                 5 x at 100 nodes x 20 keyframes, 2.2 x at 300, 1.24 x at 440; the PCG wins from ~ 450 nodes
-                                 x 20 keyframes on -- the literal C2 -- and earlier on longer windows), block-Jacobi PCG else;
+                                 5 x at 100 nodes x 20 keyframes, 2.3 x at 300, 1.24 x at 440, break-even at the literal C2 --
+                                 458 node copies x 20 keyframes; the PCG wins beyond), block-Jacobi PCG else;
                                  1: always the factorisation (if its K x (3 nodes + 6)^2 x 8 bytes fit 6 GB);
                                  2: always block-Jacobi PCG (hundreds of iterations per trial).  Same LM iterates either
                                  way.  Plain (every point a node) and sharded windows use the block-Jacobi PCG.

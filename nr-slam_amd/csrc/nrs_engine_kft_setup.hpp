@@ -32,12 +32,12 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     const size_t n2 = (size_t)ld * ld;
     if (c->opt.embedded_solver == 0) {
         // automatic choice by a cost model of the two solvers, fitted on tools/kft_probe.py runs (10 .. 40 keyframes, 100 .. 600 nodes per keyframe,
-        // profiles/r06_kft_crossover.txt): the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches, (20.6 + 0.066 nb^2) us a launch,
+        // profiles/r06_kft_crossover.txt): the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches, (25.3 + 0.045 nb^2) us a launch,
         // + 1.5 ms per trial; the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count.  Measured on 20 keyframes: 5.2 x
-        // the PCG's rate at 100 nodes per keyframe, 3.3 x at 200, 2.3 x at 300, 1.5 x at 400, 1.24 x at 440, 1.0 x at 458 (C2), 0.87 x at 550;
+        // the PCG's rate at 100 nodes per keyframe, 3.3 x at 200, 2.3 x at 300, 1.5 x at 400, 1.24 x at 440, 1.03 x at 458 (C2: 75 against 73 LM iterations / s), 0.87 x at 550;
         // 1.44 x at 458 x 10 keyframes.  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
-        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (20.6 + 0.066 * nb * nb) * 1e-3 + 1.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
-        if (kft_ms > 0.9 * pcg_ms) return NRS_OK;
+        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (25.3 + 0.0447 * nb * nb) * 1e-3 + 1.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
+        if (kft_ms > pcg_ms) return NRS_OK;
     }
     if ((size_t)K * n2 * sizeof(double) > ((size_t)6 << 30)) return NRS_OK;       // (the factor would not be worth its memory: the PCG stays block-Jacobi)
     std::vector<int> kf_row((size_t)K * nfm, -1);
@@ -48,7 +48,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     auto vc = [&](int v) { return row_ci[e->vrow[v]]; };
     // ---- same-keyframe pairs
     std::vector<KftEnt> pe;
-    pe.reserve((size_t)s.n_sp + 2 * (size_t)s.n_dm + 55 * (size_t)s.n_skin);
+    pe.reserve((size_t)s.n_sp + 2 * (size_t)s.n_dm);
     auto add_pair = [&](int k, int a, int b, uint32_t src, double w) {
         if (a < 0 || b < 0 || a == b) return;
         const int hi = std::max(a, b), lo = std::min(a, b);
@@ -83,54 +83,89 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
                 te.push_back(KftEnt{((uint64_t)kk[a] << 24) | ((uint64_t)cc[a] << 12) | (uint64_t)cc[b], (minus ? 0x80000000u : 0u) | (uint32_t)pos, 0.0});
             }
     }
-    for (int i = 0; i < s.n_skin; ++i) {
-        const int k = s.sk_pose[i];
-        int cn[SK_MAX];
-        for (int a = 0; a < SK_MAX; ++a) { const int v = s.sk_node[SK_MAX * (size_t)i + a]; cn[a] = v >= 0 ? vc(v) : -1; }
-        for (int a = 0; a < SK_MAX; ++a)
-            for (int b = a + 1; b < SK_MAX; ++b)
-                if (cn[a] >= 0 && cn[b] >= 0) add_pair(k, cn[a], cn[b], (2u << 30) | (uint32_t)e->sk_slot[i], s.sk_om[SK_MAX * (size_t)i + a] * s.sk_om[SK_MAX * (size_t)i + b]);
+    mark("edge entries");
+    // The skinned observations' pairs (55 per observation: 5 M at C2) are never materialised: per keyframe -- in parallel -- a counting pass
+    // over (hi, lo) < nf^2, then a placing pass straight into the keyframe's sorted source / weight arrays.  Order inside a pair's list:
+    // springs and dampers in edge order, then the observations in caller order (the summation order of k_kft_pairs).
+    std::vector<size_t> small_ptr(K + 1, 0);
+    std::vector<KftEnt> small(pe.size());
+    {
+        for (const KftEnt& x : pe) small_ptr[(x.key >> 24) + 1]++;
+        for (int k = 0; k < K; ++k) small_ptr[k + 1] += small_ptr[k];
+        std::vector<size_t> fill(small_ptr.begin(), small_ptr.end() - 1);
+        for (const KftEnt& x : pe) small[fill[x.key >> 24]++] = x;
     }
-    mark("entries");
-    auto by_key = [](const KftEnt& a, const KftEnt& b) { return a.key < b.key; };
-    {   // (keyframes are independent: sorted in parallel, each stably -- the generation order above is the summation order)
-        std::vector<size_t> kp(K + 1, 0);
-        for (const KftEnt& x : pe) kp[(x.key >> 24) + 1]++;
-        for (int k = 0; k < K; ++k) kp[k + 1] += kp[k];
-        std::vector<KftEnt> tmp(pe.size());
-        std::vector<size_t> fill(kp.begin(), kp.end() - 1);
-        for (const KftEnt& x : pe) tmp[fill[x.key >> 24]++] = x;
-        pe.swap(tmp);
-        const int nt = host_threads(c, pe.size());
+    std::vector<int> sk_ptr(K + 1, 0), sk_of((size_t)s.n_skin);
+    for (int i = 0; i < s.n_skin; ++i) sk_ptr[s.sk_pose[i] + 1]++;
+    for (int k = 0; k < K; ++k) sk_ptr[k + 1] += sk_ptr[k];
+    {
+        std::vector<int> fill(sk_ptr.begin(), sk_ptr.end() - 1);
+        for (int i = 0; i < s.n_skin; ++i) sk_of[fill[s.sk_pose[i]]++] = i;
+    }
+    struct KfLists { std::vector<uint32_t> pp_id, pe_src; std::vector<int> pp_ptr; std::vector<double> pe_w; };
+    std::vector<KfLists> kl(K);
+    {
+        const int nt = host_threads(c, (size_t)s.n_sp + 55 * (size_t)s.n_skin);
         parallel_for(std::min(nt, K), [&](int ti, int n) {
-            int64_t a, b;
-            chunk(K, ti, n, a, b);
+            int64_t ka, kb;
+            chunk(K, ti, n, ka, kb);
             std::vector<int> cnt;
-            std::vector<KftEnt> buf;
-            for (int k = (int)a; k < (int)b; ++k) {
-                const size_t n0 = kp[k], n1 = kp[k + 1], nk = (size_t)kf_nf[k];
-                if (nk * nk > ((size_t)4 << 20) || n1 - n0 < 64) { std::stable_sort(pe.begin() + n0, pe.begin() + n1, by_key); continue; }
-                // counting sort by (hi, lo) < nf^2 (stable: equal keys keep the generation order, which is the summation order)
-                cnt.assign(nk * nk + 1, 0);
-                auto kk = [&](const KftEnt& x) { return (size_t)((x.key >> 12) & 0xFFF) * nk + (size_t)(x.key & 0xFFF); };
-                for (size_t i = n0; i < n1; ++i) cnt[kk(pe[i]) + 1]++;
-                for (size_t q = 0; q < nk * nk; ++q) cnt[q + 1] += cnt[q];
-                buf.resize(n1 - n0);
-                for (size_t i = n0; i < n1; ++i) buf[cnt[kk(pe[i])]++] = pe[i];
-                std::copy(buf.begin(), buf.end(), pe.begin() + n0);
+            std::vector<int> cn((size_t)SK_MAX);
+            for (int k = (int)ka; k < (int)kb; ++k) {
+                const size_t nk = (size_t)kf_nf[k], nkey = nk * nk;
+                cnt.assign(nkey + 1, 0);
+                auto each_skin_pair = [&](auto&& fn) {
+                    for (int q = sk_ptr[k]; q < sk_ptr[k + 1]; ++q) {
+                        const int i = sk_of[q];
+                        for (int a2 = 0; a2 < SK_MAX; ++a2) { const int v = s.sk_node[SK_MAX * (size_t)i + a2]; cn[a2] = v >= 0 ? vc(v) : -1; }
+                        for (int a2 = 0; a2 < SK_MAX; ++a2)
+                            for (int b2 = a2 + 1; b2 < SK_MAX; ++b2) {
+                                if (cn[a2] < 0 || cn[b2] < 0 || cn[a2] == cn[b2]) continue;
+                                const int hi = std::max(cn[a2], cn[b2]), lo = std::min(cn[a2], cn[b2]);
+                                fn((size_t)hi * nk + lo, i, a2, b2);
+                            }
+                    }
+                };
+                for (size_t q = small_ptr[k]; q < small_ptr[k + 1]; ++q) cnt[((small[q].key >> 12) & 0xFFF) * nk + (small[q].key & 0xFFF) + 1]++;
+                each_skin_pair([&](size_t key, int, int, int) { cnt[key + 1]++; });
+                KfLists& o = kl[k];
+                for (size_t key = 0; key < nkey; ++key) {
+                    if (cnt[key + 1] > 0) { o.pp_id.push_back(((uint32_t)k << 24) | ((uint32_t)(key / nk) << 12) | (uint32_t)(key % nk)); o.pp_ptr.push_back(cnt[key]); }
+                    cnt[key + 1] += cnt[key];
+                }
+                const size_t ne = (size_t)cnt[nkey];
+                o.pp_ptr.push_back((int)ne);
+                o.pe_src.resize(ne); o.pe_w.resize(ne);
+                for (size_t q = small_ptr[k]; q < small_ptr[k + 1]; ++q) {
+                    const int at = cnt[((small[q].key >> 12) & 0xFFF) * nk + (small[q].key & 0xFFF)]++;
+                    o.pe_src[at] = small[q].src; o.pe_w[at] = small[q].w;
+                }
+                each_skin_pair([&](size_t key, int i, int a2, int b2) {
+                    const int at = cnt[key]++;
+                    o.pe_src[at] = (2u << 30) | (uint32_t)e->sk_slot[i];
+                    o.pe_w[at] = s.sk_om[SK_MAX * (size_t)i + a2] * s.sk_om[SK_MAX * (size_t)i + b2];
+                });
             }
         });
     }
-    mark("pair sort");
+    mark("pair lists");
+    auto by_key = [](const KftEnt& a, const KftEnt& b) { return a.key < b.key; };
     std::stable_sort(te.begin(), te.end(), by_key);
-    std::vector<uint32_t> pp_id, pe_src(pe.size()), te_src(te.size());
+    std::vector<uint32_t> pp_id, te_src(te.size());
     std::vector<int> pp_ptr, tp_ptr;
-    std::vector<double> pe_w(pe.size());
-    for (size_t i = 0; i < pe.size(); ++i) {
-        if (i == 0 || pe[i].key != pe[i - 1].key) { pp_id.push_back((uint32_t)pe[i].key); pp_ptr.push_back((int)i); }
-        pe_src[i] = pe[i].src; pe_w[i] = pe[i].w;
+    std::vector<size_t> ent_base(K + 1, 0);                          // (the entries themselves go up keyframe by keyframe: no concatenated host copy)
+    {
+        size_t n_pairs = 0;
+        for (int k = 0; k < K; ++k) { n_pairs += kl[k].pp_id.size(); ent_base[k + 1] = ent_base[k] + kl[k].pe_src.size(); }
+        if (ent_base[K] >= ((size_t)1 << 31)) return NRS_OK;
+        pp_id.reserve(n_pairs); pp_ptr.reserve(n_pairs + 1);
+        for (int k = 0; k < K; ++k) {
+            pp_id.insert(pp_id.end(), kl[k].pp_id.begin(), kl[k].pp_id.end());
+            for (size_t q = 0; q + 1 < kl[k].pp_ptr.size(); ++q) pp_ptr.push_back((int)ent_base[k] + kl[k].pp_ptr[q]);
+        }
+        pp_ptr.push_back((int)ent_base[K]);
     }
-    pp_ptr.push_back((int)pe.size());
+    const size_t pe_size = ent_base[K];
     std::vector<uint64_t> tp_key;
     for (size_t i = 0; i < te.size(); ++i) {
         if (i == 0 || te[i].key != te[i - 1].key) { tp_key.push_back(te[i].key); tp_ptr.push_back((int)i); }
@@ -161,7 +196,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
             cl_from[dir][q] = dir == 0 ? a : b; cl_tp[dir][q] = (int)i;
         }
     }
-    mark("lists");
+    mark("coupling lists");
     // ---- one device buffer
     auto al = [](size_t b2) { return (b2 + 255) & ~(size_t)255; };
     const size_t tile = (size_t)KFT_B * KFT_B;
@@ -169,7 +204,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_A = take(8 * (size_t)K * n2), o_YT = take(8 * 2 * n2), o_Bb = take(8 * 4 * nb * tile), o_Cb = take(8 * 4 * nb * tile), o_Pv = take(8 * 4 * tile),
                  o_z = take(8 * (size_t)K * ld), o_xs = take(8 * (size_t)K * ld), o_vb = take(8 * 2 * (size_t)ld), o_nf = take(4 * (size_t)K), o_np = take(4 * (size_t)K), o_kr = take(4 * kf_row.size()),
-                 o_rc = take(4 * row_ci.size()), o_ppid = take(4 * (n_pp + 1)), o_ppp = take(4 * (n_pp + 1)), o_pes = take(4 * (pe.size() + 1)), o_pew = take(8 * (pe.size() + 1)),
+                 o_rc = take(4 * row_ci.size()), o_ppid = take(4 * (n_pp + 1)), o_ppp = take(4 * (n_pp + 1)), o_pes = take(4 * (pe_size + 1)), o_pew = take(8 * (pe_size + 1)),
                  o_tpp = take(4 * (n_tp + 1)), o_tes = take(4 * (te.size() + 1)), o_tpv = take(8 * (n_tp + 1)),
                  o_cp0 = take(4 * cl_ptr[0].size()), o_cp1 = take(4 * cl_ptr[1].size()), o_cf0 = take(4 * (n_tp + 1)), o_cf1 = take(4 * (n_tp + 1)),
                  o_ct0 = take(4 * (n_tp + 1)), o_ct1 = take(4 * (n_tp + 1)), o_cv0 = take(8 * (n_tp + 1)), o_cv1 = take(8 * (n_tp + 1));
@@ -179,7 +214,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess; };
     NRS_HIP(c, up(o_nf, kf_nf.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_np, kf_np.data(), 4 * (size_t)K)); NRS_HIP(c, up(o_kr, kf_row.data(), 4 * kf_row.size()));
     NRS_HIP(c, up(o_rc, row_ci.data(), 4 * row_ci.size())); NRS_HIP(c, up(o_ppid, pp_id.data(), 4 * n_pp)); NRS_HIP(c, up(o_ppp, pp_ptr.data(), 4 * (n_pp + 1)));
-    NRS_HIP(c, up(o_pes, pe_src.data(), 4 * pe.size())); NRS_HIP(c, up(o_pew, pe_w.data(), 8 * pe.size()));
+    for (int k = 0; k < K; ++k) { NRS_HIP(c, up(o_pes + 4 * ent_base[k], kl[k].pe_src.data(), 4 * kl[k].pe_src.size())); NRS_HIP(c, up(o_pew + 8 * ent_base[k], kl[k].pe_w.data(), 8 * kl[k].pe_w.size())); }
     NRS_HIP(c, up(o_tpp, tp_ptr.data(), 4 * (n_tp + 1))); NRS_HIP(c, up(o_tes, te_src.data(), 4 * te.size()));
     NRS_HIP(c, up(o_cp0, cl_ptr[0].data(), 4 * cl_ptr[0].size())); NRS_HIP(c, up(o_cp1, cl_ptr[1].data(), 4 * cl_ptr[1].size()));
     NRS_HIP(c, up(o_cf0, cl_from[0].data(), 4 * n_tp)); NRS_HIP(c, up(o_cf1, cl_from[1].data(), 4 * n_tp));

@@ -164,10 +164,10 @@ def test_bad_inputs_are_rejected(ctx):
         ctx.dba_upload_embedded(cam, qt, w, bad, p["scale"])
 
 
-@pytest.mark.parametrize("mode", ["exact", "early-rejection", "factorisation"])
-def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, ctx_emb_direct, mode):
-    """(mode: the block-Jacobi PCG with every trial solved to pcg_rtol / with early trial rejection -- the default at this size -- and the
-    keyframe-block factorisation forced, nrs_options.embedded_solver = 1: 20 blocks of 1408 x 1408)
+@pytest.mark.parametrize("mode", ["pcg-exact", "pcg-early-rejection", "factorisation"])
+def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_emb_pcg, ctx_emb_pcg_exact, mode):
+    """(mode: the block-Jacobi PCG, nrs_options.embedded_solver = 2, with every trial solved to pcg_rtol / with early trial rejection, and the
+    default context, whose cost model takes the keyframe-block factorisation at this size: 20 blocks of ~1.4k x 1.4k)
     BASELINE configs[1] as written -- 5k points x 500 nodes x 20 keyframes -- against tests/golden/dba_C2_embedded500_trace.npz: the
     oracle's LM on the complete embedded window (tests/golden/make_embedded_ba_golden.py: 443 s in the build container, sparse LU per
     trial), on the oracle's own lists (checksums in the fixture; the product's host builder must reproduce them).  Tolerances of the
@@ -178,7 +178,7 @@ def test_full_size_c2_with_500_nodes_matches_the_oracle_golden(ctx, ctx_exact, c
     sys.path.insert(0, os.path.join(here, "golden"))
     from make_embedded_ba_golden import skin_checksum
     g = np.load(os.path.join(here, "golden", "dba_C2_embedded500_trace.npz"))
-    c = {"exact": ctx_exact, "early-rejection": ctx, "factorisation": ctx_emb_direct}[mode]
+    c = {"pcg-exact": ctx_emb_pcg_exact, "pcg-early-rejection": ctx_emb_pcg, "factorisation": ctx}[mode]
     p = S.make_dba_problem("C2")
     flag, nb = S.embedded_problem(p, int(g["n_nodes"]))
     e = nrs.dba_build_edges_embedded(p["kf_points"], flag, nb)
