@@ -62,6 +62,7 @@ struct KftHost {
     KftDev d;
     size_t bytes = 0;
     int factorisations = 0;
+    std::vector<int> kf_nb;          // per keyframe: 64-blocks that hold unknowns (ceil((3 nodes + 6) / 64))
 };
 
 // ------------------------------------------------------------------------------------------------------------------ assembly
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, in
 // workgroup reads its pre-update value): the swept block travels through Pv and lands with launch j + 1.  Panels B / C / Pv are
 // double-buffered by the parity of j.  nb + 1 launches per inversion instead of 2 nb; same arithmetic as the two-launch form up to the
 // association of the pivot tile's update (NRS_KFT_TWO_LAUNCHES=1 selects that form).
-__global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags) {
+__global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags, int nbu) {   // nbu: blocks in use (the larger of the two keyframes': rows beyond a keyframe's unknowns are identity rows, whole identity blocks need no sweep)
     extern __shared__ double sm[];
     const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
     if (kf < 0) return;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     const double* Bp = F.Bb + (size_t)(jp & 1) * pbuf + (size_t)ch * nb * tile;       // panels of step j - 1
     const double* Cp = F.Cb + (size_t)(jp & 1) * pbuf + (size_t)ch * nb * tile;
     const double* Pvp = F.Pv + ((size_t)(jp & 1) * 2 + ch) * tile;
-    const bool last = j == nb;                                      // the closing launch: trailing update of the last step, the sign taken off
+    const bool last = j == nbu;                                     // the closing launch: trailing update of the last step, the sign taken off
     const double sgn = last ? -1.0 : 1.0;
     // tile (I, L) <- sgn * (tile - B_I C_L^T) on the matrix cores, to global memory or (row-major, stride KFT_LDP) to LDS
     auto updated_tile = [&](int I, int L, bool apply, double* lds_out) {
@@ -461,10 +462,10 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
                 else A[(size_t)(KFT_B * I + r) * ld + KFT_B * L + cc] = sgn * c[n][g];
             }
     };
-    if ((int)blockIdx.x >= nb) {
+    if ((int)blockIdx.x >= nbu) {
         // ---- trailing update of step j - 1 (every tile outside its pivot row / column and outside this step's panel)
         if (jp < 0) return;
-        const int q = blockIdx.x - nb, I = q / nb, L = q % nb;
+        const int q = blockIdx.x - nbu, I = q / nbu, L = q % nbu;
         double* At = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
         if (I == jp && L == jp) {                                   // the swept pivot block of step j - 1 lands
             for (int e = tid; e < KFT_B * KFT_B; e += 256) At[(size_t)(e / KFT_B) * ld + e % KFT_B] = sgn * Pvp[e];
@@ -724,7 +725,8 @@ __global__ __launch_bounds__(256) void k_kft_gemv(KftDev F, int mode, int k0, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
-static int kft_invert(nrs_ctx* c, const KftDev& F, int kf0, int kf1, int* flags) {
+static int kft_invert(nrs_ctx* c, const KftHost& H, int kf0, int kf1, int* flags) {
+    const KftDev& F = H.d;
     if (c->env("NRS_KFT_TWO_LAUNCHES")) {                           // (A/B: the panel and the trailing update of a step as launches of their own)
         for (int j = 0; j < F.nb; ++j) {
             hipLaunchKernelGGL(k_kft_panel, dim3(F.nb, 2), dim3(256), KFT_PANEL_LDS, c->stream, F, j, kf0, kf1, flags);
@@ -732,8 +734,9 @@ static int kft_invert(nrs_ctx* c, const KftDev& F, int kf0, int kf1, int* flags)
         }
         return NRS_OK;
     }
-    for (int j = 0; j <= F.nb; ++j)
-        hipLaunchKernelGGL(k_kft_step, dim3(F.nb + F.nb * F.nb, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags);
+    const int nbu = std::max(kf0 >= 0 ? H.kf_nb[kf0] : 1, kf1 >= 0 ? H.kf_nb[kf1] : 1);
+    for (int j = 0; j <= nbu; ++j)
+        hipLaunchKernelGGL(k_kft_step, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
     return NRS_OK;
 }
 
@@ -753,7 +756,7 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
     const int len0 = F.m, len1 = F.K - 1 - F.m;
     for (int s = 0; s < std::max(len0, len1); ++s) {
         const int k0 = s < len0 ? s : -1, k1 = s < len1 ? F.K - 1 - s : -1;
-        NRS_TRY(kft_invert(c, F, k0, k1, d.flags));
+        NRS_TRY(kft_invert(c, *H, k0, k1, d.flags));
         const dim3 g((F.ld + 255) / 256, F.ld, 2), g2((F.ld + KFT_TC - 1) / KFT_TC, 2);
         const size_t shy = sizeof(double) * KFT_TC * F.ld;
         hipLaunchKernelGGL(k_kft_gct, g, dim3(256), 0, c->stream, F, k0, k1);
@@ -762,7 +765,7 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
             hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, -1, k1);
         } else hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, k1);
     }
-    NRS_TRY(kft_invert(c, F, F.m, -1, d.flags));
+    NRS_TRY(kft_invert(c, *H, F.m, -1, d.flags));
     NRS_HIP(c, hipGetLastError());
     H->factorisations++;
     return NRS_OK;

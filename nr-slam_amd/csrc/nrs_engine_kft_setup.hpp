@@ -247,6 +247,8 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         attr_done = true;
     }
     H->bytes = off;
+    H->kf_nb.resize(K);
+    for (int k = 0; k < K; ++k) H->kf_nb[k] = std::max(1, (3 * kf_nf[k] + kf_np[k] + KFT_B - 1) / KFT_B);
     H->on = true;
     e->kft = H;
     return NRS_OK;
