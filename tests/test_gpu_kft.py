@@ -74,3 +74,39 @@ def test_blocks_couplings_and_the_applied_factorisation_match_the_oracle_system(
     step = spla.spsolve((H + lam * sp.identity(H.shape[0])).tocsc(), b)
     u = ctx.debug_kft_apply(lam, b)
     assert np.linalg.norm(u - step) <= 1e-7 * np.linalg.norm(step)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_short_windows_and_both_launch_forms(ctx_emb_direct, k):
+    """one, two and three keyframes (no chain / one chain / both chains meeting at once) and an odd count: M^-1 (H + lam I) x = x, the
+    solve against the oracle; the two-launch form of a sweep step (NRS_KFT_TWO_LAUNCHES=1) gives the same result up to rounding"""
+    c = ctx_emb_direct
+    p, e, w, cam, qt, H, b = _setup(260, k, 36, 70 + k)
+    c.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    assert c.debug_kft_info()["on"]
+    lam = 1e-5 * np.abs(H.diagonal()).max()
+    rng = np.random.default_rng(k)
+    x = rng.normal(0, 1, H.shape[0])
+    u1 = c.debug_kft_apply(lam, H @ x + lam * x)
+    assert np.linalg.norm(u1 - x) <= 1e-7 * np.linalg.norm(x)
+    nrs.debug_set("NRS_KFT_TWO_LAUNCHES", "1")
+    u2 = c.debug_kft_apply(lam, H @ x + lam * x)
+    nrs.debug_set("NRS_KFT_TWO_LAUNCHES", None)
+    assert np.linalg.norm(u2 - x) <= 1e-7 * np.linalg.norm(x) and np.linalg.norm(u1 - u2) <= 1e-9 * np.linalg.norm(x)
+    tr, otr = nrs.Trace(), []
+    pq, xyz, sk = c.dba_solve_embedded(cam, qt, w, e, p["scale"], 5, tr)
+    oq, ot, opts, osk, nit = E.dba_solve_embedded(p["model"], p["prm"], p["poses_q"], p["poses_t"], w["lm_xyz"], w["lm_kf"], w["lm_uv"], e["sp_ij"], e["sp_d0"],
+                                                  e["dm_idx"], e["dm_w"], w["sk_kf"], w["sk_uv"], w["sk_xyz"], e["sk_node"], e["sk_omega"], p["scale"], 5, otr)
+    assert tr.iterations == nit and [t["accepted"] for t in tr.trials] == [t["accepted"] for t in otr]
+    assert sum(t["inner"] for t in tr.trials) <= 3 * len(tr.trials)
+    assert np.allclose(pq[:, :4], oq, atol=1e-6, rtol=0) and np.allclose(pq[:, 4:], ot, atol=1e-5, rtol=0)
+    assert np.allclose(xyz, opts, atol=1e-4, rtol=0) and np.allclose(sk, osk, atol=1e-4, rtol=0)
+
+
+def test_factorisation_is_bit_reproducible(ctx_emb_direct):
+    c = ctx_emb_direct
+    p, e, w, cam, qt, H, b = _setup(400, 5, 60, 81)
+    c.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    lam = 1e-5 * np.abs(H.diagonal()).max()
+    u = [c.debug_kft_apply(lam, b) for _ in range(3)]
+    assert np.array_equal(u[0], u[1]) and np.array_equal(u[0], u[2])
