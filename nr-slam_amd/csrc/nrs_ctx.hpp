@@ -88,6 +88,11 @@ struct nrs_ctx {
     double* pin_scal = nullptr;      // pinned host mirrors of the engine's scalars / flags
     int* pin_flags = nullptr;
     int seq = 0;                     // sequence number of the last publication the host waited for (pin_flags[7])
+    // speculative LM trials of the single-frame engines (nrs_engine_types.hpp SpecSet): mirrors, streams and events of the shadow sets
+    double* pin_spec_scal = nullptr; int* pin_spec_flags = nullptr;
+    int spec_run = 4;                // rejections of the last completed run of an LM iteration (sizes the next batch)
+    hipStream_t spec_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t spec_fork = nullptr, spec_join[3] = {nullptr, nullptr, nullptr};
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;

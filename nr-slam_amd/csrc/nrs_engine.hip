@@ -386,6 +386,59 @@ static int wait_published(nrs_ctx* c, Engine* e) {
 
 static int read_scalars(nrs_ctx* c, Engine* e) { return wait_published(c, e); }
 
+// the same wait on the mirrors of a shadow set (speculative trials): publication `seq` in flag block hf, enqueued on stream st
+static int wait_published_at(nrs_ctx* c, const int* hf, int seq, hipStream_t st) {
+    const volatile int* w = hf + 7;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *w != seq; ++spins) {
+        if (spins > 200000) std::this_thread::yield();
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            NRS_HIP(c, hipStreamSynchronize(st));
+            if (*w != seq) return c->fail(NRS_ERR_HIP, "device results were not published");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return NRS_OK;
+}
+
+// One LM trial of a directly solved single-pose engine, enqueued whole: factorise (H + lam I), solve, trial state, chi2, publication
+// (sequence number in *seq).  set < 0: on the engine's own arrays and the context's stream -- the launches engine_optimize issues for
+// one trial at a time.  set >= 0: the SAME launches on shadow set `set` (nrs_engine_types.hpp SpecSet, nd_alt_dev) and its stream,
+// behind the fork event the caller recorded; everything a trial writes is the set's own, everything it reads -- the linearisation, the
+// current state -- is shared and read-only while trials are in flight.  Leaves the set's join event recorded behind the publication.
+static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int* seq) {
+    Dev& d = e->d;
+    const int cur = e->cur, trial = 1 - e->cur;
+    const dim3 g(((d.sh_ng + 7) / 8) * 8), b(BLK);
+    if (set < 0) {
+        NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam));
+        hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], d.pose[trial], d.xl[trial]);
+        NRS_TRY(evaluate<false>(c, e, trial, true));
+        *seq = c->seq;
+        return NRS_OK;
+    }
+    const SpecSet& q = e->spec[set];
+    struct Restore {                                               // the engine's view and the context's stream come back on every path
+        nrs_ctx* c; Engine* e; Dev saved; hipStream_t main;
+        ~Restore() { e->d = saved; c->stream = main; }
+    } restore{c, e, d, c->stream};
+    d.xv = q.xv; d.xp = q.xp; d.part_apply = q.part_apply; d.part_rchi = q.part_rchi; d.part_reg = q.part_reg; d.scal = q.scal; d.flags = q.flags;
+    d.h_scal = q.h_scal; d.h_flags = q.h_flags;
+    if (d.sk_n > 0) { d.sk_part = q.sk_part; d.sk_chi = q.sk_chi; }
+    d.pose[trial] = q.pose; d.xl[trial] = q.xl;
+    c->stream = c->spec_stream[set];
+    NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_fork, 0));
+    NdDev nd = nd_alt_dev(e->nd->S(), set);
+    nd.out_rows = q.xv; nd.out_pose = q.xp; nd.flags = q.flags;
+    NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, &nd));
+    hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], q.pose, q.xl);
+    NRS_TRY(evaluate<false>(c, e, trial, true));
+    *seq = c->seq;
+    NRS_HIP(c, hipEventRecord(c->spec_join[set], c->stream));
+    return NRS_OK;
+}
+
 // (H + lam I) x = b by block-Jacobi PCG, resumable: pcg_begin, then pcg_advance until it reports
 // convergence; with stop_at_peek it also returns as soon as the 1e-4 milestone flag is up.
 constexpr double PEEK_RTOL = 1e-1;      // inner-solve accuracy at which a trial is first evaluated
@@ -625,6 +678,20 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     const bool check_chi = c->env("NRS_CHECK_CHI") != nullptr;
     double chi_carry = 0;
     const int peek_levels = peek_debug ? 4 : PEEK_LEVELS;
+    // Speculative trials (directly solved single-pose engines; nrs_engine_types.hpp SpecSet): after a rejected trial the rest of the run
+    // goes out as a batch -- the trial g2o would try next on the engine's own arrays, the ones after it (lam x ni, then x 2 ni, ...) on
+    // the shadow sets -- and the results are read in order.  NRS_SPEC_TRIALS=0: one at a time (the same trials, the same bits).
+    const int n_spec = e->nd && e->nd->on && d.K == 1 && !d.sh_on && !d.ec_on && !c->opt.profile && !c->env("NRS_CHECK_EVAL") ? std::min(e->n_spec, e->nd->S().n_alt) : 0;
+    struct Pending { int set; double lam; int seq; } pend[1 + SPEC_MAX];
+    int n_pend = 0, i_pend = 0;
+    const bool spec_dbg = c->env("NRS_SPEC_DBG") != nullptr;       // (host clocks of a batch on stderr)
+    auto t_batch = std::chrono::steady_clock::now();
+    auto join_batch = [&]() -> int {                              // the context's stream continues behind every shadow trial of the batch (they read the linearisation and the state)
+        for (int j = 0; j < n_pend; ++j)
+            if (pend[j].set >= 0) NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_join[pend[j].set], 0));
+        n_pend = i_pend = 0;
+        return NRS_OK;
+    };
     for (int it = 0; it < iters; ++it) {
         NRS_TRY(evaluate<true>(c, e, e->cur));
         // computeActiveErrors at the start of an iteration re-derives the chi2 the last accepted trial
@@ -676,7 +743,39 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             // size is what the previous trial needed to reach the first milestone (the kernels record
             // it), so a trial that is going to be rejected costs a handful of iterations.
             int seen = 0;                                  // peek levels already evaluated
-            if (direct) {
+            const double* hs = e->h_scal;                            // the mirrors this trial's results arrive in
+            const int* hf = e->h_flags;
+            int won = -1;                                          // the shadow set that holds this trial's state (-1: the engine's own)
+            if (direct && n_spec > 0) {
+                if (i_pend == n_pend) {                            // nothing in flight: this trial and, inside a run of rejections, the ones that would follow it
+                    n_pend = i_pend = 0;
+                    // how many: up to the trial that is expected to be accepted -- runs repeat their length from one LM iteration, round and
+                    // frame to the next (c->spec_run: rejections of the last completed run) -- and two at a time beyond it; a trial of the
+                    // batch that turns out not to be needed holds the next linearisation up until it has drained
+                    int nb = 1;
+                    if (qmax >= 1) nb = std::min(std::min(std::max(c->spec_run - qmax + 1, 2), 1 + n_spec), 10 - qmax);
+                    if (const char* f = c->env("NRS_SPEC_FIXED")) { if (qmax >= 1) nb = std::min(std::min(std::max(1, atoi(f)), 1 + n_spec), 10 - qmax); }
+                    if (nb > 1) NRS_HIP(c, hipEventRecord(c->spec_fork, c->stream));
+                    double l = lam, n = ni;
+                    const auto tq0 = std::chrono::steady_clock::now();
+                    for (int j = 0; j < nb; ++j) {
+                        if (j > 0) { l *= n; n *= 2; if (!std::isfinite(l)) break; }
+                        pend[n_pend].set = j - 1; pend[n_pend].lam = l;
+                        NRS_TRY(direct_trial_enqueue(c, e, j - 1, l, &pend[n_pend].seq));
+                        ++n_pend;
+                        if (spec_dbg) fprintf(stderr, "[spec] it %d trial %d: set %d enqueued at +%.1f us\n", it, qmax, j - 1, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
+                    }
+                    NRS_HIP(c, hipGetLastError());
+                    t_batch = tq0;
+                }
+                const Pending& pp = pend[i_pend++];
+                if (pp.lam != lam) return c->fail(NRS_ERR_STATE, "speculative trial: damping %.17g does not match the sequence (%.17g)", pp.lam, lam);
+                won = pp.set;
+                if (won >= 0) { hs = e->spec[won].h_scal; hf = e->spec[won].h_flags; }
+                NRS_TRY(wait_published_at(c, hf, pp.seq, won >= 0 ? c->spec_stream[won] : c->stream));
+                if (spec_dbg) fprintf(stderr, "[spec] it %d trial %d: result of set %d at +%.1f us\n", it, qmax, won, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_batch).count());
+                done = true;
+            } else if (direct) {
                 // g2o's own sequence: factorise (H + lambda I), solve, evaluate (linear_solver_eigen.h:92-136); a pivot that is not
                 // positive raises flags[2] and the trial counts as failed below
                 NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam));
@@ -694,10 +793,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                 done = e->h_flags[0] != 0 || pit >= c->opt.pcg_max_iters;
             }
             while (true) {
-                temp = e->h_scal[SC_CHI];
-                scale = e->h_scal[SC_SCALE] + 1e-3;
+                temp = hs[SC_CHI];
+                scale = hs[SC_SCALE] + 1e-3;
                 if (done) break;
-                const int lvl = e->h_flags[3];
+                const int lvl = hf[3];
                 if (peeking && lvl > seen) {
                     // peek: a trial that is clearly going to be rejected is not solved any further --
                     // its step is discarded, so the iterate sequence is the reference's either way
@@ -705,7 +804,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     // ... and only when the chi2 increase is well above the noise floor of the fp32
                     // projection (relative 1e-7 per evaluation): near convergence the gain ratio of a
                     // tiny step is noise over the 1e-3 regulariser of its denominator, at any accuracy
-                    early = e->h_flags[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl] && (temp - chi) > PEEK_MIN_REL_INCREASE * chi;
+                    early = hf[2] == 0 && std::isfinite(temp) && rho_peek < PEEK_RHO_LVL[lvl] && (temp - chi) > PEEK_MIN_REL_INCREASE * chi;
                     if (peek_debug) { fprintf(stderr, "[peek] it %d trial %d lvl %d pit %d rho %.4f relinc %.3e\n", it, qmax, lvl, pit, rho_peek, (temp - chi) / chi); early = false; }
                     if (early) break;
                     seen = lvl;
@@ -719,13 +818,13 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             // (flags[2] == 2: a bounded wait of the direct solver ran out -- a synchronisation fault, not a matrix that is not positive
             // definite: the factor and the assembly areas hold partial data, so this is an error, never a rejected trial)
-            if (e->h_flags[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out");
-            ok = e->h_flags[2] == 0;
+            if (hf[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out");
+            ok = hf[2] == 0;
             if (!early && !ok) temp = 1.7976931348623157e308;
-            if (!early) e->pred_iters = e->h_flags[1];
-            if (e->h_flags[4] > 0) e->pred_peek = e->h_flags[4];
+            if (!early) e->pred_iters = hf[1];
+            if (hf[4] > 0) e->pred_peek = hf[4];
             if (qmax == 0) e->first_trial_accepted = !early && (chi - temp) / scale > 0 && std::isfinite(temp);
-            const int inner = e->h_flags[1];
+            const int inner = hf[1];
             rho = (chi - temp) / scale;
             if (peek_debug) fprintf(stderr, "[peek] it %d trial %d FINAL pit %d rho %.4f\n", it, qmax, pit, rho);
             const bool accepted = !early && rho > 0 && std::isfinite(temp);
@@ -744,6 +843,12 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                 lam *= std::max(1.0 / 3.0, alpha);
                 ni = 2;
                 chi = temp;
+                if (won >= 0) {                        // (the state sits in the shadow set's arrays: they become the engine's, the engine's the set's)
+                    std::swap(d.pose[trial], e->spec[won].pose);
+                    std::swap(d.xl[trial], e->spec[won].xl);
+                }
+                NRS_TRY(join_batch());                 // (trials of the batch still in flight are discarded; the next linearisation waits for them)
+                if (n_spec > 0 && qmax > 0) c->spec_run = qmax;   // (a run of qmax rejections ended here)
                 e->cur = trial;                        // discardTop: the trial state becomes current
             } else {
                 lam *= ni;
@@ -752,6 +857,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             ++qmax;
         } while (rho < 0 && qmax < 10);
+        NRS_TRY(join_batch());
         chi_carry = chi;
         if (trace) trace->iterations++;
         if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;

@@ -872,7 +872,20 @@ struct NdSolver {
     bool attr_set = false;
     double* d_ev = nullptr;
     const NdEnt* d_ent = nullptr;
+    int n_alt = 0;                   // further sets of everything a solve WRITES (factor, assembly areas, unknowns, per-front words): speculative LM trials
+    size_t alt_stride = 0;           // ... each this many bytes behind the one before (set before nd_upload; nd_alt_dev)
 };
+
+// the device view of solve set j >= 0 of the alternates (same plan and entry values, its own factor storage); the caller points out_rows /
+// out_pose / flags at its own vectors
+static NdDev nd_alt_dev(const NdSolver& S, int j) {
+    NdDev D = S.dev;
+    const size_t shift = (size_t)(j + 1) * S.alt_stride;
+    D.Lp = reinterpret_cast<double*>(reinterpret_cast<char*>(D.Lp) + shift); D.A = reinterpret_cast<double*>(reinterpret_cast<char*>(D.A) + shift);
+    D.xn = reinterpret_cast<double*>(reinterpret_cast<char*>(D.xn) + shift);
+    D.done = reinterpret_cast<int*>(reinterpret_cast<char*>(D.done) + shift); D.fcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(D.fcnt) + shift);
+    return D;
+}
 
 static int nd_upload(nrs_ctx* c, NdSolver& S) {
     const NdPlan& P = S.plan;
@@ -883,6 +896,9 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
                  o_pm = take(2 * std::max<size_t>(1, P.pmap.size())), o_ent = take(sizeof(NdEnt) * P.ent.size()),
                  o_wg = take(sizeof(NdWgD) * (P.wg.size() / 3)), o_lf = take(sizeof(NdFrontD) * P.lvl_fronts.size()), o_ev = take(72 * P.ent.size() + 64),
                  o_L = take(8 * P.L_doubles), o_A = take(8 * std::max<size_t>(2, P.A_doubles) + 64), o_x = take(24 * (size_t)P.n_nodes), o_fl = take(64), o_dn = take(4 * P.fr.size()), o_fc = take(4 * P.fr.size());
+    const size_t off1 = off;                                       // (one set ends here)
+    S.alt_stride = off1 - o_L;
+    off += (size_t)S.n_alt * S.alt_stride;
     NRS_TRY(c->ensure(*S.buf, off));
     char* base = S.buf->as<char>();
     // the plan's arrays go up in ONE copy from a staging image that lives as long as the solver (the copy is asynchronous)
@@ -926,10 +942,13 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
     D.Lp = reinterpret_cast<double*>(base + o_L); D.A = reinterpret_cast<double*>(base + o_A); D.xn = reinterpret_cast<double*>(base + o_x);
     D.flags = reinterpret_cast<int*>(base + o_fl); D.done = reinterpret_cast<int*>(base + o_dn); D.fcnt = reinterpret_cast<int*>(base + o_fc);
     D.n_x3 = 3 * P.n_nodes; D.x_poll = c->env("NRS_ND_BACK_FLAGS") ? 0 : 1;
-    NRS_HIP(c, hipMemsetAsync(base + o_fl, 0, off - o_fl, c->stream));            // (status words and the fronts' flags)
     S.epoch = 0; S.chained = 0;
-    // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
-    NRS_HIP(c, hipMemsetAsync(base + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
+    for (int j = 0; j <= S.n_alt; ++j) {
+        char* bj = base + (size_t)j * S.alt_stride;
+        NRS_HIP(c, hipMemsetAsync(bj + o_fl, 0, off1 - o_fl, c->stream));          // (status words and the fronts' flags)
+        // the assembly areas are zero wherever no child ever writes (the written pattern is the same in every factorisation)
+        NRS_HIP(c, hipMemsetAsync(bj + o_A, 0, 8 * std::max<size_t>(2, P.A_doubles) + 64, c->stream));
+    }
     // dynamic LDS per level: the largest panel / boundary of its fronts
     S.lvl_shm_fac.assign(P.n_levels, 0); S.shm_back_all = 8 * (size_t)nd_back_fixed_doubles(0);
     for (int l = 0; l < P.n_levels; ++l)
@@ -961,8 +980,9 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
 }
 
 // factorise (H + lam I) and solve: 2 x levels launches on the context's stream, no host synchronisation
-static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
+static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* alt = nullptr) {   // alt: the arrays of another solve set (nd_alt_dev)
     const NdPlan& P = S.plan;
+    const NdDev& dev = alt ? *alt : S.dev;
     const int epoch = ++S.epoch;
     // One launch per level.  Opt-in (NRS_ND_CHAIN=1): the TOP of the tree in ONE launch, a front's workgroups waiting for the tiles of its
     // children inside that launch -- the highest levels whose workgroups are all resident at once (one per CU), the whole factorisation
@@ -984,13 +1004,13 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     const bool step32 = !(s32_env && atoi(s32_env) == 0);
     int first = 1;                                                 // (the first launch of the solve poisons xn)
     auto level = [&](int n, size_t shm, int wg0, int chained) {
-        if (wide && step32) hipLaunchKernelGGL((k_nd_level<512, true>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
-        else if (wide) hipLaunchKernelGGL((k_nd_level<512, false>), dim3(n), dim3(512), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
-        else if (step32) hipLaunchKernelGGL((k_nd_level<256, true>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
-        else hipLaunchKernelGGL((k_nd_level<256, false>), dim3(n), dim3(256), shm, c->stream, S.dev, wg0, lam, epoch, chained, first);
+        if (wide && step32) hipLaunchKernelGGL((k_nd_level<512, true>), dim3(n), dim3(512), shm, c->stream, dev, wg0, lam, epoch, chained, first);
+        else if (wide) hipLaunchKernelGGL((k_nd_level<512, false>), dim3(n), dim3(512), shm, c->stream, dev, wg0, lam, epoch, chained, first);
+        else if (step32) hipLaunchKernelGGL((k_nd_level<256, true>), dim3(n), dim3(256), shm, c->stream, dev, wg0, lam, epoch, chained, first);
+        else hipLaunchKernelGGL((k_nd_level<256, false>), dim3(n), dim3(256), shm, c->stream, dev, wg0, lam, epoch, chained, first);
         first = 0;
     };
-    const int chain_from = per_level || S.dev.clk ? P.n_levels : S.chain_from;
+    const int chain_from = per_level || dev.clk || alt ? P.n_levels : S.chain_from;   // (the per-front counters of the chained form count one set's solves)
     {
         // a CROWDED level (more workgroups than CUs: they would run in rounds, one per CU, each factorising its front's panel for one
         // tile) runs as two launches: the diagonal and inverse workgroups factorise and leave their rows of L21, k_nd_tile makes the
@@ -1000,8 +1020,8 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
             const int n = P.lvl_wg_ptr[l + 1] - P.lvl_wg_ptr[l], nA = P.lvl_wg_split[l] - P.lvl_wg_ptr[l];
             if (!no_split && n > c->prop.multiProcessorCount && n > nA) {
                 level(nA, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
-                if (wide) hipLaunchKernelGGL(k_nd_tile<512>, dim3(n - nA), dim3(512), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
-                else hipLaunchKernelGGL(k_nd_tile<256>, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, S.dev, P.lvl_wg_split[l]);
+                if (wide) hipLaunchKernelGGL(k_nd_tile<512>, dim3(n - nA), dim3(512), sizeof(double) * ND_TILE_LDS + 64, c->stream, dev, P.lvl_wg_split[l]);
+                else hipLaunchKernelGGL(k_nd_tile<256>, dim3(n - nA), dim3(256), sizeof(double) * ND_TILE_LDS + 64, c->stream, dev, P.lvl_wg_split[l]);
             } else level(n, S.lvl_shm_fac[l], P.lvl_wg_ptr[l], 0);
         }
         if (chain_from < P.n_levels) {                             // the levels above in one launch (all of them when the whole factorisation is resident at once)
@@ -1013,7 +1033,7 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam) {
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that
     // its workgroups stage their factors while the root is busy.  The two event waits cost more than the ~10 us of staging they hide:
     // 224 -> 245 us per solve at 543 points, 503 -> 525 at 2220.)
-    hipLaunchKernelGGL(k_nd_back, dim3(P.n_fronts), dim3(256), S.shm_back_all, c->stream, S.dev, (int)P.wg.size() / 3, P.n_fronts, epoch, (int)(S.shm_back_all / 8));
+    hipLaunchKernelGGL(k_nd_back, dim3(P.n_fronts), dim3(256), S.shm_back_all, c->stream, dev, (int)P.wg.size() / 3, P.n_fronts, epoch, (int)(S.shm_back_all / 8));
     NRS_HIP(c, hipGetLastError());
     return NRS_OK;
 }
@@ -1651,6 +1671,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     if (!hit) {
         sl->hash = 0; sl->key.clear(); sl->key.push_back(0xFF);      // (matches no key while it is rebuilt)
         sl->S.buf = &sl->ws;
+        sl->S.n_alt = e->n_spec;                                   // (solve sets for the speculative trials: engine_optimize uses min(e->n_spec, n_alt))
         sl->S.plan = std::move(P.plan);
         const int up = nd_upload(c, sl->S);
         if (up == NRS_ERR_INVALID) {                               // a front or a boundary beyond the LDS: like a plan that could not be built -- the PCG takes the problem
@@ -1718,6 +1739,10 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     // rows the solver never writes (fixed, padding) keep a zero step; so does a fixed pose
     NRS_HIP(c, hipMemsetAsync(d.xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
     NRS_HIP(c, hipMemsetAsync(d.xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
+    for (int j = 0; j < e->n_spec; ++j) {
+        NRS_HIP(c, hipMemsetAsync(e->spec[j].xv, 0, sizeof(double) * 3 * (size_t)d.n_rows, c->stream));
+        NRS_HIP(c, hipMemsetAsync(e->spec[j].xp, 0, sizeof(double) * 6 * (size_t)d.K, c->stream));
+    }
     nd->sig.assign((size_t)d.M + 1, 0);
     for (int v = 0; v < d.M; ++v) nd->sig[v] = e->h_rflag[e->vrow[v]] & RF_FIXED;
     nd->sig[d.M] = e->h_pose_fixed[0];

@@ -37,6 +37,41 @@ struct ArenaPlan {                   // two passes: size, then carve
     }
 };
 
+// the shadow sets' arrays as the engine's own start out (zero partials, scalars and status words), their host mirrors, and the
+// context's streams and events for them (created on first use)
+static int spec_prepare(nrs_ctx* c, Engine* e) {
+    const Dev& d = e->d;
+    if (!c->pin_spec_scal) {
+        NRS_HIP(c, hipHostMalloc((void**)&c->pin_spec_scal, sizeof(double) * SC_N * SPEC_MAX, hipHostMallocMapped | hipHostMallocCoherent));
+        NRS_HIP(c, hipHostMalloc((void**)&c->pin_spec_flags, sizeof(int) * 8 * SPEC_MAX, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->pin_spec_flags, 0, sizeof(int) * 8 * SPEC_MAX);
+        // (measured and dropped: shadow streams at the lowest priority so that they yield to the context's stream -- a level of the
+        // factorisation on such a stream takes 57 us instead of 28 even with the device to itself)
+        for (int j = 0; j < SPEC_MAX; ++j) {
+            NRS_HIP(c, hipStreamCreateWithFlags(&c->spec_stream[j], hipStreamNonBlocking));
+            NRS_HIP(c, hipEventCreateWithFlags(&c->spec_join[j], hipEventDisableTiming));
+        }
+        NRS_HIP(c, hipEventCreateWithFlags(&c->spec_fork, hipEventDisableTiming));
+    }
+    for (int j = 0; j < e->n_spec; ++j) {
+        SpecSet& q = e->spec[j];
+        q.h_scal = c->pin_spec_scal + SC_N * j; q.h_flags = c->pin_spec_flags + 8 * j;
+        NRS_HIP(c, hipMemsetAsync(q.part_apply, 0, sizeof(double) * (size_t)d.n_vecblk, c->stream));
+        NRS_HIP(c, hipMemsetAsync(q.part_rchi, 0, sizeof(double) * (size_t)d.n_groups, c->stream));
+        NRS_HIP(c, hipMemsetAsync(q.part_reg, 0, sizeof(double) * 2 * (size_t)d.n_regblk, c->stream));
+        NRS_HIP(c, hipMemsetAsync(q.scal, 0, sizeof(double) * SC_N, c->stream));
+        NRS_HIP(c, hipMemsetAsync(q.flags, 0, sizeof(int) * 8, c->stream));
+    }
+    return NRS_OK;
+}
+
+// shadow sets of a single-frame engine (speculative LM trials, nrs_engine_types.hpp): NRS_SPEC_TRIALS=<0..3> (0: one trial at a time)
+static int spec_sets(const nrs_ctx* c) {
+    if (c->opt.profile) return 0;                                  // (a profiling context times its launches one by one)
+    if (const char* v = c->env("NRS_SPEC_TRIALS")) return std::max(0, std::min(SPEC_MAX, atoi(v)));
+    return SPEC_MAX;
+}
+
 static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, size_t n_halo, Engine* e) {
     const size_t nr = (size_t)d.n_rows, K = (size_t)d.K;
     if (d.row_hi <= 0) { d.row_lo = 0; d.row_hi = d.n_rows; }     // (callers that never shard leave the range unset: every row)
@@ -117,7 +152,14 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
     d.ec_dm = A.get<EcDamper>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
     d.ec_w = A.get<float>(d.ec_on ? std::max(1, d.ec_ndm) : 1);
     d.part_ec = A.get<double>(d.ec_on ? std::max(1, d.ec_nblk) : 1);
-    (void)e;
+    for (int j = 0; j < e->n_spec; ++j) {                          // shadow sets of what an LM trial writes (speculative trials: nrs_engine_types.hpp)
+        SpecSet& q = e->spec[j];
+        q.xv = A.get_rows<double>(3); q.xp = A.get<double>(6 * K);
+        q.pose = A.get<Pose>(K); q.xl = A.get_rows<double>(3);
+        q.part_apply = A.get<double>((size_t)d.n_vecblk); q.part_rchi = A.get<double>((size_t)d.n_groups); q.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
+        q.scal = A.get<double>(SC_N); q.flags = A.get<int>(8);
+        q.sk_part = q.sk_chi = nullptr;
+    }
 }
 
 template <class Tp>
@@ -341,6 +383,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     if (arena == &c->arena_trk && s.K == 1) {
         e->nd = new (std::nothrow) NdEngine();
         if (!e->nd) return c->fail(NRS_ERR_ALLOC, "out of host memory");
+        e->n_spec = spec_sets(c);                                  // shadow sets for speculative LM trials (carved with the arena below)
         e->nd->pos.resize(3 * (size_t)s.M);
         for (size_t i = 0; i < 3 * (size_t)s.M; ++i) e->nd->pos[i] = s.x[i] + (s.X0 ? s.X0[i] : 0.0);
         nd_in.M = s.M; nd_in.rflag = s.rflag; nd_in.pose_fixed = s.pose_fixed && s.pose_fixed[0];
@@ -899,6 +942,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     {
         Dev tmp = d;
         Engine te;
+        te.n_spec = e->n_spec;
         carve(dry, tmp, s.X0 != nullptr, nnz_s, nnz_d, ss_ptr.size() - 1, halo_rows.size(), &te);
     }
     if (dry.off > arena->cap) {
@@ -1072,6 +1116,7 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
     e->h_flags = c->pin_flags;
     e->d.h_scal = c->pin_scal;          // hipHostMalloc memory is mapped: same pointer on the device
     e->d.h_flags = c->pin_flags;
+    if (e->n_spec > 0) NRS_TRY(spec_prepare(c, e));
     engine_compact_headers(c, e);
     NRS_HIP(c, hipStreamSynchronize(c->stream));       // host staging vectors die here
     mark("pinned+sync");
@@ -1137,7 +1182,8 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
                      o_bp = o_act + al(n), o_pb = o_bp + al(4 * nblk), o_rr = o_pb + al(4 * (s.K + 1)), o_rp = o_rr + al(4 * (nrl + 1)), o_ro = o_rp + al(4 * (nrl + 1)),
                      o_rw = o_ro + al(4 * (n_ent + 1)), o_rec = o_rw + al(8 * (n_ent + 1)), o_part = o_rec + al(8 * 27 * n), o_chi = o_part + al(8 * 32 * nblk),
                      o_md = o_chi + al(8 * n), o_g = o_md + 256, o_op = o_g + al(8 * 4 * n), o_rq = o_op + al(8 * 8 * nblk), o_recT = o_rq + al(8 * (size_t)d.n_rows),
-                     o_dop = o_recT + al(8 * 24 * n), total = o_dop + (d.use_lds ? 0 : al(8 * 6 * (size_t)d.n_rows));
+                     o_dop = o_recT + al(8 * 24 * n), o_spec = o_dop + (d.use_lds ? 0 : al(8 * 6 * (size_t)d.n_rows)),
+                     spec_stride = al(8 * 32 * nblk) + al(8 * n), total = o_spec + (size_t)e->n_spec * spec_stride;   // (shadow sets of sk_part / sk_chi: speculative trials)
         DevBuf& buf = arena == &c->arena_trk ? c->nd_skin : c->dba_skin;
         NRS_TRY(c->ensure(buf, total));
         char* sb = buf.as<char>();
@@ -1163,6 +1209,10 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         d.sk_g = reinterpret_cast<double*>(sb + o_g); d.sk_opart = reinterpret_cast<double*>(sb + o_op); d.sk_row_q = reinterpret_cast<const int*>(sb + o_rq);
         d.sk_recT = reinterpret_cast<double*>(sb + o_recT);
         d.D_op = d.use_lds ? nullptr : reinterpret_cast<double*>(sb + o_dop);
+        for (int j = 0; j < e->n_spec; ++j) {
+            e->spec[j].sk_part = reinterpret_cast<double*>(sb + o_spec + (size_t)j * spec_stride);
+            e->spec[j].sk_chi = reinterpret_cast<double*>(sb + o_spec + (size_t)j * spec_stride + al(8 * 32 * nblk));
+        }
         d.sk_base = ba_form ? d.xl_init : nullptr;                 // (tracking form: the rows ARE the deformations, X0 + sum om x)
         e->sk_vert.assign(s.sk_node, s.sk_node + SK_MAX * n_in);
         e->sk_om.assign(s.sk_om, s.sk_om + SK_MAX * n_in);

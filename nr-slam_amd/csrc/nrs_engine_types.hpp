@@ -207,6 +207,22 @@ inline int rc_of(const Dev& d, int cls) {
 
 enum { SC_CHI = 0, SC_MAXDIAG = 1, SC_SCALE = 2, SC_GAMMA0 = 3, SC_SLOT0 = 4, SC_SLOT1 = 6, SC_N = 16 };
 
+// Speculative LM trials of a directly solved single-frame engine (a2; engine_optimize).  Rejections come in runs there -- the damping
+// grows x 2, x 4, x 8 ... until a step is accepted, four trials in a row as a rule -- and one trial is a chain of a dozen launches that
+// keeps a few dozen workgroups busy.  After a rejected trial the next trials of the run (the same damping sequence g2o would walk)
+// are factorised, solved and evaluated SIDE BY SIDE on streams of their own, each on a shadow set of everything a trial writes: step
+// vectors, trial state, partial sums, scalars, status words and their host mirrors (here) and the solver's factor storage, assembly
+// areas and unknowns (NdSolver).  The host then reads the results in order; the first accepted one becomes the state (pointer swap),
+// the rest are discarded.  Same trials, same arithmetic, same bits as one at a time.
+constexpr int SPEC_MAX = 3;          // shadow sets: up to 1 + SPEC_MAX trials in flight
+struct SpecSet {
+    double *xv, *xp, *part_apply, *part_rchi, *part_reg, *scal;
+    double *sk_part, *sk_chi;        // embedded mode (the context's skin buffer)
+    int* flags;
+    Pose* pose; double* xl;          // the trial state (swapped with the engine's on acceptance)
+    double* h_scal; int* h_flags;    // mapped host mirrors of its own (nrs_ctx::pin_spec_*)
+};
+
 struct NdEngine;                     // nrs_engine_nd.hpp: the direct solver of a single-frame engine
 struct KftHost;                      // nrs_engine_kft.hpp: the keyframe-block factorisation of an embedded BA window
 struct Engine {
@@ -215,6 +231,8 @@ struct Engine {
     KftHost* kft = nullptr;
     Arena* arena = nullptr;
     int cur = 0;
+    int n_spec = 0;                  // shadow sets carved for speculative trials (single-frame engines; 0: none)
+    SpecSet spec[SPEC_MAX];
     int pred_iters = 0;              // inner iterations of the last fully solved LM trial (sizes later batches)
     int pack_rows = 0;               // rows whose incidence records this engine holds (sharded: the rank's keyframe range)
     size_t arena_bytes = 0;          // device bytes carved for it

@@ -490,6 +490,13 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
     nrs::comm_free(c);
     if (c->pin_scal) (void)hipHostFree(c->pin_scal);
     if (c->pin_flags) (void)hipHostFree(c->pin_flags);
+    if (c->pin_spec_scal) (void)hipHostFree(c->pin_spec_scal);
+    if (c->pin_spec_flags) (void)hipHostFree(c->pin_spec_flags);
+    for (int j = 0; j < 3; ++j) {
+        if (c->spec_stream[j]) { (void)hipStreamSynchronize(c->spec_stream[j]); (void)hipStreamDestroy(c->spec_stream[j]); }
+        if (c->spec_join[j]) (void)hipEventDestroy(c->spec_join[j]);
+    }
+    if (c->spec_fork) (void)hipEventDestroy(c->spec_fork);
     if (c->arena_dba.base) (void)hipFree(c->arena_dba.base);
     if (c->arena_trk.base) (void)hipFree(c->arena_trk.base);
     c->release(c->po_uv); c->release(c->po_X); c->release(c->po_err);

@@ -193,3 +193,49 @@ def test_crowded_levels_in_two_launches_give_the_same_bits(ctx, monkeypatch):
         assert ok and ok2 and st == st2 and st["workgroups"] > 800 and np.array_equal(x, x2), n
         okh, xh, sth = CPU.nd_solve(pos, last, pairs, Dn, Vp, bn, 0.1)
         assert okh and np.allclose(x, xh, rtol=0, atol=1e-11 * np.abs(xh).max())
+
+
+def _trace_key(tr):
+    return [(t["round"], t["iter"], t["trial"], t["lam"], t["chi"], t["chi_new"], t["rho"], t["accepted"], t["ok"]) for t in tr]
+
+
+@pytest.mark.parametrize("n,seed,embedded", [(400, 12, False), (2500, 14, False), (1500, 42, True)])
+def test_speculative_trials_walk_the_same_trials_to_the_same_bits(ctx_direct, n, seed, embedded):
+    """a2's LM trials inside a run of rejections go out in batches on shadow sets of the trial state and the factor storage
+    (nrs_engine_types.hpp SpecSet); one at a time (NRS_SPEC_TRIALS=0), with one or three shadow sets, with the batch sized by the
+    last run or fixed at 2 / 4: the same trials (damping, chi2, gain ratio, decision -- exactly) and the same results bit for bit"""
+    import nrs_synth as S
+    c = ctx_direct
+    tp = S.make_tracking_problem(n, seed)
+    cam = nrs.make_camera(tp["model"], tp["prm"])
+    fm = np.arange(n, dtype=np.int32)
+    node = None
+    if embedded:
+        nodes = c.skin_select_nodes(tp["X_prev"], 200, tp["status"] == 0)
+        node = np.zeros(n, np.uint8)
+        node[nodes] = 1
+
+    def run():
+        tr = nrs.Trace(1024)
+        if embedded:
+            g = nrs.RGraph(c, n, tp["graph"]["sigma"], tp["graph"]["stretch_th"])
+            g.add_edges(tp["X_prev"], fm, fm)
+            r = c.track_deform_solve_embedded(cam, g, tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], node, tp["pose_q"], tp["pose_t"], tp["scale"], tr, 256)
+            g.close()
+        else:
+            r = c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
+        return r, tr.trials
+    outs = []
+    for sw in ({"NRS_SPEC_TRIALS": "0"}, {}, {"NRS_SPEC_TRIALS": "1"}, {"NRS_SPEC_FIXED": "4"}, {"NRS_SPEC_FIXED": "2"}, {}):
+        nrs.debug_clear()
+        for k, v in sw.items():
+            nrs.debug_set(k, v)
+        outs.append(run())
+    nrs.debug_clear()
+    r0, t0 = outs[0]
+    assert any(t["trial"] >= 2 for t in t0), "the frame has no run of rejections: nothing speculative ran"
+    for r, t in outs[1:]:
+        assert _trace_key(t) == _trace_key(t0)
+        for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+            assert np.array_equal(r[k], r0[k]), k
+        assert r["lost"] == r0["lost"] and r["median"] == r0["median"]
