@@ -407,12 +407,12 @@ static int wait_published_at(nrs_ctx* c, const int* hf, int seq, hipStream_t st)
 // one trial at a time.  set >= 0: the SAME launches on shadow set `set` (nrs_engine_types.hpp SpecSet, nd_alt_dev) and its stream,
 // behind the fork event the caller recorded; everything a trial writes is the set's own, everything it reads -- the linearisation, the
 // current state -- is shared and read-only while trials are in flight.  Leaves the set's join event recorded behind the publication.
-static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int* seq) {
+static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int* seq, int* solve_id) {
     Dev& d = e->d;
     const int cur = e->cur, trial = 1 - e->cur;
     const dim3 g(((d.sh_ng + 7) / 8) * 8), b(BLK);
     if (set < 0) {
-        NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam));
+        NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, nullptr, solve_id));
         hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], d.pose[trial], d.xl[trial]);
         NRS_TRY(evaluate<false>(c, e, trial, true));
         *seq = c->seq;
@@ -430,8 +430,8 @@ static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int*
     c->stream = c->spec_stream[set];
     NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_fork, 0));
     NdDev nd = nd_alt_dev(e->nd->S(), set);
-    nd.out_rows = q.xv; nd.out_pose = q.xp; nd.flags = q.flags;
-    NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, &nd));
+    nd.out_rows = q.xv; nd.out_pose = q.xp; nd.flags = q.flags; nd.abort = q.abort;
+    NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, &nd, solve_id));
     hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], q.pose, q.xl);
     NRS_TRY(evaluate<false>(c, e, trial, true));
     *seq = c->seq;
@@ -682,11 +682,15 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     // goes out as a batch -- the trial g2o would try next on the engine's own arrays, the ones after it (lam x ni, then x 2 ni, ...) on
     // the shadow sets -- and the results are read in order.  NRS_SPEC_TRIALS=0: one at a time (the same trials, the same bits).
     const int n_spec = e->nd && e->nd->on && d.K == 1 && !d.sh_on && !d.ec_on && !c->opt.profile && !c->env("NRS_CHECK_EVAL") ? std::min(e->n_spec, e->nd->S().n_alt) : 0;
-    struct Pending { int set; double lam; int seq; } pend[1 + SPEC_MAX];
+    struct Pending { int set; double lam; int seq; int solve_id; } pend[1 + SPEC_MAX];
     int n_pend = 0, i_pend = 0;
     const bool spec_dbg = c->env("NRS_SPEC_DBG") != nullptr;       // (host clocks of a batch on stderr)
     auto t_batch = std::chrono::steady_clock::now();
     auto join_batch = [&]() -> int {                              // the context's stream continues behind every shadow trial of the batch (they read the linearisation and the state)
+        // trials of the batch nobody has asked for yet are not needed: their solves drain (the context's stream is idle here -- the
+        // results before them have been read -- so the word is written at once)
+        for (int j = i_pend; j < n_pend; ++j)
+            if (pend[j].set >= 0) NRS_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->spec[pend[j].set].abort), pend[j].solve_id, 1, c->stream));
         for (int j = 0; j < n_pend; ++j)
             if (pend[j].set >= 0) NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_join[pend[j].set], 0));
         n_pend = i_pend = 0;
@@ -761,7 +765,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     for (int j = 0; j < nb; ++j) {
                         if (j > 0) { l *= n; n *= 2; if (!std::isfinite(l)) break; }
                         pend[n_pend].set = j - 1; pend[n_pend].lam = l;
-                        NRS_TRY(direct_trial_enqueue(c, e, j - 1, l, &pend[n_pend].seq));
+                        NRS_TRY(direct_trial_enqueue(c, e, j - 1, l, &pend[n_pend].seq, &pend[n_pend].solve_id));
                         ++n_pend;
                         if (spec_dbg) fprintf(stderr, "[spec] it %d trial %d: set %d enqueued at +%.1f us\n", it, qmax, j - 1, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
                     }

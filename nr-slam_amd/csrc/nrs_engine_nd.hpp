@@ -45,6 +45,8 @@ struct NdDev {
     int n_x3;                        // 3 x nodes: the length of xn
     int x_poll;                      // back pass: 1 = a front reads its boundary's unknowns by polling the VALUES (xn is poisoned when a solve starts and every
                                      // unknown is written once), 0 = by its ancestors' done flags (NRS_ND_BACK_FLAGS=1: the round-4 hand-over)
+    const int* abort; int abort_id;  // speculative trials (engine_optimize): a solve whose id the host has written to *abort is not needed any more -- the
+                                     // remaining workgroups of its FACTORISATION return at once (null: never); they wait for nobody, so a stale read only costs time
     long long* clk;                  // NRS_ND_DBG: 8 phase clocks (100 MHz) per workgroup of the factorisation, then per front of the back substitution; else null
 };
 
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(NTH) void k_nd_level(NdDev N, int wg0, double lam, 
     int16_t* pmj = pmi + 16;
     auto stamp = [&](int k) { if (N.clk && tid == 0) N.clk[8 * (size_t)(wg0 + blockIdx.x) + k] = wall_clock64(); };
     stamp(0);
+    if (N.abort && *N.abort == N.abort_id) return;                 // (a discarded speculative trial drains)
     if (first && N.x_poll)                                         // (nothing reads xn before the back pass of this solve, launches later)
         for (int i = blockIdx.x * NTH + tid; i < N.n_x3; i += gridDim.x * NTH) reinterpret_cast<unsigned long long*>(N.xn)[i] = ND_POISON;
     // ---- requests first: this thread's original entries (descriptor and values: one round trip) and the Schur complements the
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(NTH) void k_nd_tile(NdDev N, int wg0) {
     constexpr int NW = NTH / 64, NT3 = (9 + NW - 1) / NW;          // waves; tiles (of nine) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NdWgD wd = N.wg[wg0 + blockIdx.x];
+    if (N.abort && *N.abort == N.abort_id) return;
     const int I = wd.I, J = wd.J;
     const NdFrontD& F = wd.F;
     const int s = F.s, s16 = (s + 15) & ~15, b1 = F.b + 1, m = s + F.b;
@@ -706,6 +710,9 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     const NdFrontD F = N.lvl_fr[li];                                // (descriptors in level order)
     const int s = F.s, b = F.b, m = s + b;
     if (blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }   // (read by the host after the launch has completed)
+    // (no abort test here: this launch's workgroups wait for each other, and two of them can see the word change in either order --
+    // a descendant that missed it would poll for an ancestor that left until its spin bound runs out: measured, 2 s stalls.  The back
+    // pass of a discarded solve runs to its end on whatever the drained factorisation left: 60 us, nobody reads the result.)
     double* Ls = sm;                                               // (L11^-1)^T, [s][ND_LD]
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
     double* tv = part + 512;                                       // [128]: y - L21^T x_bnd
@@ -980,10 +987,12 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
 }
 
 // factorise (H + lam I) and solve: 2 x levels launches on the context's stream, no host synchronisation
-static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* alt = nullptr) {   // alt: the arrays of another solve set (nd_alt_dev)
+static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* alt = nullptr, int* solve_id = nullptr) {   // alt: the arrays of another solve set (nd_alt_dev)
     const NdPlan& P = S.plan;
-    const NdDev& dev = alt ? *alt : S.dev;
+    NdDev dev = alt ? *alt : S.dev;
     const int epoch = ++S.epoch;
+    dev.abort_id = epoch;
+    if (solve_id) *solve_id = epoch;
     // One launch per level.  Opt-in (NRS_ND_CHAIN=1): the TOP of the tree in ONE launch, a front's workgroups waiting for the tiles of its
     // children inside that launch -- the highest levels whose workgroups are all resident at once (one per CU), the whole factorisation
     // for frames of <= ~800 points.  It paid with 256-thread workgroups at 543 points (176 -> 165 us per factorise + solve, round 4) and

@@ -61,6 +61,7 @@ static int spec_prepare(nrs_ctx* c, Engine* e) {
         NRS_HIP(c, hipMemsetAsync(q.part_reg, 0, sizeof(double) * 2 * (size_t)d.n_regblk, c->stream));
         NRS_HIP(c, hipMemsetAsync(q.scal, 0, sizeof(double) * SC_N, c->stream));
         NRS_HIP(c, hipMemsetAsync(q.flags, 0, sizeof(int) * 8, c->stream));
+        NRS_HIP(c, hipMemsetAsync(q.abort, 0, sizeof(int), c->stream));
     }
     return NRS_OK;
 }
@@ -157,7 +158,7 @@ static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d,
         q.xv = A.get_rows<double>(3); q.xp = A.get<double>(6 * K);
         q.pose = A.get<Pose>(K); q.xl = A.get_rows<double>(3);
         q.part_apply = A.get<double>((size_t)d.n_vecblk); q.part_rchi = A.get<double>((size_t)d.n_groups); q.part_reg = A.get<double>(2 * (size_t)d.n_regblk);
-        q.scal = A.get<double>(SC_N); q.flags = A.get<int>(8);
+        q.scal = A.get<double>(SC_N); q.flags = A.get<int>(8); q.abort = A.get<int>(1);
         q.sk_part = q.sk_chi = nullptr;
     }
 }

@@ -219,6 +219,7 @@ struct SpecSet {
     double *xv, *xp, *part_apply, *part_rchi, *part_reg, *scal;
     double *sk_part, *sk_chi;        // embedded mode (the context's skin buffer)
     int* flags;
+    int* abort;                      // id of the set's solve that is not needed any more (NdDev::abort)
     Pose* pose; double* xl;          // the trial state (swapped with the engine's on acceptance)
     double* h_scal; int* h_flags;    // mapped host mirrors of its own (nrs_ctx::pin_spec_*)
 };
