@@ -70,7 +70,9 @@ static int spec_prepare(nrs_ctx* c, Engine* e) {
 static int spec_sets(const nrs_ctx* c) {
     if (c->opt.profile) return 0;                                  // (a profiling context times its launches one by one)
     if (const char* v = c->env("NRS_SPEC_TRIALS")) return std::max(0, std::min(SPEC_MAX, atoi(v)));
-    return SPEC_MAX;
+    // two shadow sets = three trials in flight: a fourth stream's launches are serialised behind another stream's on this runtime (its result
+    // arrives a whole trial after the third's: 240 / 266 / 298 / 516 us at 1k points), so a third set only adds work that may be discarded
+    return 2;
 }
 
 static void carve(ArenaPlan& A, Dev& d, bool has_X0, size_t nnz_s, size_t nnz_d, size_t n_slices, size_t n_halo, Engine* e) {
