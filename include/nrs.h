@@ -152,7 +152,7 @@ int nrs_create(nrs_ctx** out, const nrs_options* opt);
  *   direct solver NRS_ND=0|1, NRS_ND_MAX_ROWS, NRS_ND_NO_CACHE, NRS_ND_NO_COVER, NRS_ND_CHAIN, NRS_ND_LEVELS, NRS_ND_THREADS=256,
  *                 NRS_ND_STEP32=0, NRS_ND_BACK_FLAGS, NRS_ND_LEAF=<n>, NRS_ND_NO_SPLIT, NRS_ND_PLAN_PAR=<n>
  *   a2 LM trials  NRS_SPEC_TRIALS=<0..3> (shadow sets for the speculative trials of a run of rejections; 0: one at a time; read when an
- *                 engine is created), NRS_SPEC_FIXED=<n>, NRS_SPEC_DBG
+ *                 engine is created), NRS_SPEC_FIXED=<n>, NRS_SPEC_FIRST=<n>, NRS_SPEC_NO_ABORT, NRS_SPEC_DBG
  *   PCG / packing NRS_NO_LDS, NRS_NO_FUSED, NRS_FUSED_MAX_ROWS=<n>, NRS_NO_COARSE, NRS_COARSE_MIN_TILES=<n>, NRS_NO_ONE_XCD, NRS_NO_ECD, NRS_HIER,
  *                 NRS_NO_PLAIN, NRS_NO_H4, NRS_RC=<0..3>, NRS_NT=0|1, NRS_DFORM, NRS_NO_EDGE_CHI, NRS_SELL_T=<lanes>, NRS_NO_MORTON,
  *                 NRS_NO_TILE_SORT, NRS_ONE_CLASS, NRS_TILE_CUT_PCT=<p>, NRS_HOST_PACK, NRS_HOST_THREADS=<n>, NRS_HOST_THREADS_SMALL=<n>,

@@ -93,6 +93,7 @@ struct nrs_ctx {
     int spec_run = 4;                // rejections of the last completed run of an LM iteration (sizes the next batch)
     hipStream_t spec_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t spec_fork = nullptr, spec_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t spec_back[4] = {nullptr, nullptr, nullptr, nullptr};   // behind the back pass of the batch's k-th trial (they run one after the other: nd_solve_enqueue)
 
     int fail(int code, const char* fmt, ...) {
         va_list ap;

@@ -407,12 +407,12 @@ static int wait_published_at(nrs_ctx* c, const int* hf, int seq, hipStream_t st)
 // one trial at a time.  set >= 0: the SAME launches on shadow set `set` (nrs_engine_types.hpp SpecSet, nd_alt_dev) and its stream,
 // behind the fork event the caller recorded; everything a trial writes is the set's own, everything it reads -- the linearisation, the
 // current state -- is shared and read-only while trials are in flight.  Leaves the set's join event recorded behind the publication.
-static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int* seq, int* solve_id) {
+static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int* seq, int* solve_id, bool in_batch) {   // in_batch: further trials share the device: back passes in turn
     Dev& d = e->d;
     const int cur = e->cur, trial = 1 - e->cur;
     const dim3 g(((d.sh_ng + 7) / 8) * 8), b(BLK);
     if (set < 0) {
-        NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, nullptr, solve_id));
+        NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, nullptr, solve_id, nullptr, in_batch ? c->spec_back[0] : nullptr));
         hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], d.pose[trial], d.xl[trial]);
         NRS_TRY(evaluate<false>(c, e, trial, true));
         *seq = c->seq;
@@ -431,7 +431,7 @@ static int direct_trial_enqueue(nrs_ctx* c, Engine* e, int set, double lam, int*
     NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_fork, 0));
     NdDev nd = nd_alt_dev(e->nd->S(), set);
     nd.out_rows = q.xv; nd.out_pose = q.xp; nd.flags = q.flags; nd.abort = q.abort;
-    NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, &nd, solve_id));
+    NRS_TRY(nd_solve_enqueue(c, e->nd->S(), lam, &nd, solve_id, c->spec_back[set], c->spec_back[set + 1]));
     hipLaunchKernelGGL(k_apply_reproj, g, b, 0, c->stream, d, lam, d.pose[cur], d.xl[cur], q.pose, q.xl);
     NRS_TRY(evaluate<false>(c, e, trial, true));
     *seq = c->seq;
@@ -681,15 +681,18 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
     // Speculative trials (directly solved single-pose engines; nrs_engine_types.hpp SpecSet): after a rejected trial the rest of the run
     // goes out as a batch -- the trial g2o would try next on the engine's own arrays, the ones after it (lam x ni, then x 2 ni, ...) on
     // the shadow sets -- and the results are read in order.  NRS_SPEC_TRIALS=0: one at a time (the same trials, the same bits).
-    const int n_spec = e->nd && e->nd->on && d.K == 1 && !d.sh_on && !d.ec_on && !c->opt.profile && !c->env("NRS_CHECK_EVAL") ? std::min(e->n_spec, e->nd->S().n_alt) : 0;
+    const int n_spec = e->nd && e->nd->on && d.K == 1 && !d.sh_on && !d.ec_on && !c->opt.profile && !c->env("NRS_CHECK_EVAL") &&
+                               e->nd->S().chain_from >= e->nd->S().plan.n_levels       // (the chained factorisation's workgroups wait for each other too: one such launch at a time)
+                           ? std::min(e->n_spec, e->nd->S().n_alt) : 0;
     struct Pending { int set; double lam; int seq; int solve_id; } pend[1 + SPEC_MAX];
     int n_pend = 0, i_pend = 0;
+    const int spec_first = c->env("NRS_SPEC_FIRST") ? atoi(c->env("NRS_SPEC_FIRST")) : 0;
     const bool spec_dbg = c->env("NRS_SPEC_DBG") != nullptr;       // (host clocks of a batch on stderr)
     auto t_batch = std::chrono::steady_clock::now();
     auto join_batch = [&]() -> int {                              // the context's stream continues behind every shadow trial of the batch (they read the linearisation and the state)
         // trials of the batch nobody has asked for yet are not needed: their solves drain (the context's stream is idle here -- the
         // results before them have been read -- so the word is written at once)
-        for (int j = i_pend; j < n_pend; ++j)
+        for (int j = i_pend; j < n_pend && !c->env("NRS_SPEC_NO_ABORT"); ++j)
             if (pend[j].set >= 0) NRS_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->spec[pend[j].set].abort), pend[j].solve_id, 1, c->stream));
         for (int j = 0; j < n_pend; ++j)
             if (pend[j].set >= 0) NRS_HIP(c, hipStreamWaitEvent(c->stream, c->spec_join[pend[j].set], 0));
@@ -757,6 +760,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     // frame to the next (c->spec_run: rejections of the last completed run) -- and two at a time beyond it; a trial of the
                     // batch that turns out not to be needed holds the next linearisation up until it has drained
                     int nb = 1;
+                    if (qmax == 0 && spec_first > 0) nb = std::min(1 + n_spec, 1 + spec_first);   // (experiment: NRS_SPEC_FIRST=<n> further trials behind the first of an iteration)
                     if (qmax >= 1) nb = std::min(std::min(std::max(c->spec_run - qmax + 1, 2), 1 + n_spec), 10 - qmax);
                     if (const char* f = c->env("NRS_SPEC_FIXED")) { if (qmax >= 1) nb = std::min(std::min(std::max(1, atoi(f)), 1 + n_spec), 10 - qmax); }
                     if (nb > 1) NRS_HIP(c, hipEventRecord(c->spec_fork, c->stream));
@@ -765,7 +769,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                     for (int j = 0; j < nb; ++j) {
                         if (j > 0) { l *= n; n *= 2; if (!std::isfinite(l)) break; }
                         pend[n_pend].set = j - 1; pend[n_pend].lam = l;
-                        NRS_TRY(direct_trial_enqueue(c, e, j - 1, l, &pend[n_pend].seq, &pend[n_pend].solve_id));
+                        NRS_TRY(direct_trial_enqueue(c, e, j - 1, l, &pend[n_pend].seq, &pend[n_pend].solve_id, nb > 1));
                         ++n_pend;
                         if (spec_dbg) fprintf(stderr, "[spec] it %d trial %d: set %d enqueued at +%.1f us\n", it, qmax, j - 1, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
                     }
@@ -822,7 +826,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
             }
             // (flags[2] == 2: a bounded wait of the direct solver ran out -- a synchronisation fault, not a matrix that is not positive
             // definite: the factor and the assembly areas hold partial data, so this is an error, never a rejected trial)
-            if (hf[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out");
+            if (hf[2] == 2) return c->fail(NRS_ERR_HIP, "direct solve: a wait for another workgroup's result timed out (LM iteration %d, trial %d, solve set %d)", it, qmax, won);
             ok = hf[2] == 0;
             if (!early && !ok) temp = 1.7976931348623157e308;
             if (!early) e->pred_iters = hf[1];

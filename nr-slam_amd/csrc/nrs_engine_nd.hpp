@@ -710,9 +710,8 @@ __global__ __launch_bounds__(256) void k_nd_back(NdDev N, int clk0, int n_fronts
     const NdFrontD F = N.lvl_fr[li];                                // (descriptors in level order)
     const int s = F.s, b = F.b, m = s + b;
     if (blockIdx.x == 0 && tid == 0) { N.flags[1] = 1; __threadfence(); N.flags[0] = 1; }   // (read by the host after the launch has completed)
-    // (no abort test here: this launch's workgroups wait for each other, and two of them can see the word change in either order --
-    // a descendant that missed it would poll for an ancestor that left until its spin bound runs out: measured, 2 s stalls.  The back
-    // pass of a discarded solve runs to its end on whatever the drained factorisation left: 60 us, nobody reads the result.)
+    // (no abort test in this launch: its workgroups wait for each other, and a discarded solve's back pass that lost some of them was measured
+    // to fault; it runs to its end on whatever the drained factorisation left -- 60 us, nobody reads the result)
     double* Ls = sm;                                               // (L11^-1)^T, [s][ND_LD]
     double* part = Ls + ND_S16 * ND_LD;                            // [4][128]
     double* tv = part + 512;                                       // [128]: y - L21^T x_bnd
@@ -987,7 +986,13 @@ static int nd_upload(nrs_ctx* c, NdSolver& S) {
 }
 
 // factorise (H + lam I) and solve: 2 x levels launches on the context's stream, no host synchronisation
-static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* alt = nullptr, int* solve_id = nullptr) {   // alt: the arrays of another solve set (nd_alt_dev)
+// back_wait / back_record (speculative trials, several solves in flight on different streams): the back pass is the one launch whose workgroups
+// wait for each other, which is safe for ONE such launch at a time -- its lowest unfinished workgroup is always resident or next in its XCD's
+// queue -- and not for two: each can fill the CUs of an XCD with waiting workgroups while the workgroup the other's wait for sits in that XCD's
+// queue behind them (measured: a 2 s stall ended by the spin bound, NRS_ERR_HIP).  So the back passes of a batch run one after the other:
+// this one starts behind the event back_wait and records back_record.  The factorisation's launches wait for nobody and overlap freely.
+static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* alt = nullptr, int* solve_id = nullptr, hipEvent_t back_wait = nullptr,
+                            hipEvent_t back_record = nullptr) {   // alt: the arrays of another solve set (nd_alt_dev)
     const NdPlan& P = S.plan;
     NdDev dev = alt ? *alt : S.dev;
     const int epoch = ++S.epoch;
@@ -1042,8 +1047,10 @@ static int nd_solve_enqueue(nrs_ctx* c, NdSolver& S, double lam, const NdDev* al
     // (Measured and dropped: the back pass on a second stream next to the last factorisation level -- only roots live there -- so that
     // its workgroups stage their factors while the root is busy.  The two event waits cost more than the ~10 us of staging they hide:
     // 224 -> 245 us per solve at 543 points, 503 -> 525 at 2220.)
+    if (back_wait) NRS_HIP(c, hipStreamWaitEvent(c->stream, back_wait, 0));
     hipLaunchKernelGGL(k_nd_back, dim3(P.n_fronts), dim3(256), S.shm_back_all, c->stream, dev, (int)P.wg.size() / 3, P.n_fronts, epoch, (int)(S.shm_back_all / 8));
     NRS_HIP(c, hipGetLastError());
+    if (back_record) NRS_HIP(c, hipEventRecord(back_record, c->stream));
     return NRS_OK;
 }
 

@@ -52,6 +52,7 @@ static int spec_prepare(nrs_ctx* c, Engine* e) {
             NRS_HIP(c, hipEventCreateWithFlags(&c->spec_join[j], hipEventDisableTiming));
         }
         NRS_HIP(c, hipEventCreateWithFlags(&c->spec_fork, hipEventDisableTiming));
+        for (int j = 0; j < 1 + SPEC_MAX; ++j) NRS_HIP(c, hipEventCreateWithFlags(&c->spec_back[j], hipEventDisableTiming));
     }
     for (int j = 0; j < e->n_spec; ++j) {
         SpecSet& q = e->spec[j];

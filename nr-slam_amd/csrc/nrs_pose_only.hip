@@ -497,6 +497,7 @@ extern "C" void nrs_destroy(nrs_ctx* c) {
         if (c->spec_join[j]) (void)hipEventDestroy(c->spec_join[j]);
     }
     if (c->spec_fork) (void)hipEventDestroy(c->spec_fork);
+    for (int j = 0; j < 4; ++j) if (c->spec_back[j]) (void)hipEventDestroy(c->spec_back[j]);
     if (c->arena_dba.base) (void)hipFree(c->arena_dba.base);
     if (c->arena_trk.base) (void)hipFree(c->arena_trk.base);
     c->release(c->po_uv); c->release(c->po_X); c->release(c->po_err);

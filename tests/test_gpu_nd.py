@@ -226,7 +226,10 @@ def test_speculative_trials_walk_the_same_trials_to_the_same_bits(ctx_direct, n,
             r = c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
         return r, tr.trials
     outs = []
-    for sw in ({"NRS_SPEC_TRIALS": "0"}, {}, {"NRS_SPEC_TRIALS": "1"}, {"NRS_SPEC_FIXED": "4"}, {"NRS_SPEC_FIXED": "2"}, {}):
+    # (the last two: three trials behind EVERY first trial of an iteration -- most are discarded and drain, the worst case for the back
+    # passes' turn-taking and the abort path -- and the same without the abort word)
+    for sw in ({"NRS_SPEC_TRIALS": "0"}, {}, {"NRS_SPEC_TRIALS": "1"}, {"NRS_SPEC_TRIALS": "3", "NRS_SPEC_FIXED": "4"}, {"NRS_SPEC_FIXED": "2"}, {},
+               {"NRS_SPEC_TRIALS": "3", "NRS_SPEC_FIRST": "3"}, {"NRS_SPEC_TRIALS": "3", "NRS_SPEC_FIRST": "3", "NRS_SPEC_NO_ABORT": "1"}):
         nrs.debug_clear()
         for k, v in sw.items():
             nrs.debug_set(k, v)
