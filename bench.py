@@ -360,6 +360,9 @@ def tracked_fps(n_points=5000, frames=31, dense_graph=False, direct_solve=0, n_n
     latency = dict(linear_solver="nested-dissection multifrontal Cholesky (k_nd_level / k_nd_back, fronts on v_mfma_f64_16x16x4)" if direct
                    else "block-Jacobi / two-level PCG, one launch per iteration (k_pcg_fused)",
                    solves_per_frame=trials / nf, inner_iterations_per_frame=inner / nf,
+                   lm_trials="inside a run of rejections the next trials go out as a batch on two shadow sets and their own streams (same trials, same bits; "
+                             "NRS_SPEC_TRIALS=0: one at a time -- tools/spec_trials_probe.py, profiles/r06_a2_spec_trials.txt)" if direct else "one at a time",
+
                    us_all_in_per_lm_trial=us_unit if direct else None, us_all_in_per_pcg_iteration=None if direct else us_unit,
                    # symbolic factorisations over the whole sequence (two single-frame problems per frame): built anew / taken from the
                    # context's cache because the frame's optimised set, edges and fixed flags equalled an earlier frame's
