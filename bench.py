@@ -603,6 +603,10 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     pctx.dba_optimize(2)
     prof = pctx.profile()
     pctx.close()
+    emb_traffic = {}                                              # HBM bytes per launch from the PMC passes of tools/profile_r06.sh (not this run)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        emb_traffic = {k: v.get("bytes_per_launch") for k, v in json.load(open(tpath)).get("embedded_C2", {}).items()}
     n_obs, n_rows, n_ent = int(len(e["sk_obs"])), int(len(e["lm_obs"])), int((np.asarray(e["sk_node"]) >= 0).sum())
     op_b = 348 * n_obs + 104 * n_rows + 12 * 2 * len(e["sp_ij"]) + 16 * 4 * len(e["dm_idx"])
     up_b = 312 * n_rows + 36 * n_ent
@@ -610,11 +614,12 @@ def skinned_bench(n=5000, m=500, n_kf=20):
     up_us = 1e3 * prof["vec_ms"] / max(1, prof["vec_launches"])
     out["ba_window"]["roofline"] = dict(kernel="k_spmv_f_skin<8> (operator of the regularisers + the skinned observations' pass, one launch)", bound="hbm",
                                         achieved=op_b / (op_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=op_b / (op_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                        traffic=None, avg_us=op_us, algorithmic_bytes=int(op_b), launches=int(prof["spmv_launches"]),
+                                        traffic=emb_traffic.get("k_spmv_f_skin"), avg_us=op_us, algorithmic_bytes=int(op_b), launches=int(prof["spmv_launches"]),
                                         regime="27 MB of operands per launch: Infinity-Cache resident, bound by the chains of dependent loads (latency), not by bytes")
     out["ba_window"]["roofline_update"] = dict(kernel="k_pcg_update<true> (the observations' row pass + the PCG vector update)", bound="hbm",
                                                achieved=up_b / (up_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=up_b / (up_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                               traffic=None, avg_us=up_us, algorithmic_bytes=int(up_b), launches=int(prof["vec_launches"]))
+                                               traffic=emb_traffic.get("k_pcg_update_skin"), avg_us=up_us, algorithmic_bytes=int(up_b), launches=int(prof["vec_launches"]),
+                                               traffic_source="profiles/traffic.json embedded_C2 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r06.sh, 2 * FETCH + WRITE)")
     out["ba_window"]["pcg_iterations_per_lm_trial"] = rr["inner"] / max(1, rr["trials"])
     # ---- the same window on the exact keyframe-block factorisation forced (nrs_options.embedded_solver = 1)
     fctx = nrs.Context(embedded_solver=1)
@@ -629,7 +634,7 @@ def skinned_bench(n=5000, m=500, n_kf=20):
         value=rf["lm_iters"] / rf["dt"], unit="LM iters/s", ms_per_step=1e3 * rf["dt"] / 10, pcg_iters_per_step=rf["inner"] / 10, lm_trials_per_step=rf["trials"] / 10,
         block_dimension=info["ld"], keyframe_blocks=K, factor_mib=info["mib"], gflop_per_trial=flops_trial / 1e9,
         roofline=dict(kernel="k_kft_step (one launch per 64-pivot sweep step: panel + trailing rank-64 update on v_mfma_f64_16x16x4)", bound="mfma", achieved=tf,
-                      peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                      peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TFLOPS, traffic=emb_traffic.get("k_kft_step"),
                       note="whole-trial rate (assembly, Schur updates, solves included): a CRITICAL-PATH computation -- %d dependent launches per trial, "
                            "each bounded by a 64-pivot sweep in one workgroup" % (((K + 1) // 2) * (nbk + 1) + nbk + 1)),
         note="exact solve per LM trial (what the reference's LinearSolverEigen does): block tridiagonal over the keyframes, csrc/nrs_engine_kft.hpp; "
