@@ -81,6 +81,7 @@ struct nrs_ctx {
     nrs::DevBuf dba_skin;            // ... and of the resident BA window (N2b)
     nrs::DevBuf dba_kft;             // embedded BA window: the keyframe-block factorisation (nrs_engine_kft.hpp)
     nrs::DevBuf nd_skin;             // embedded mode (nrs_engine_skin.hpp): the skinned observations of the tracking engine
+    void* plan_worker = nullptr;     // nrs_engine_nd.hpp PlanWorker: the helper thread of the direct solver's symbolic phase (one for the context's lifetime)
     void* nd_cache = nullptr;        // direct solver of the tracking engines (nrs_engine_nd.hpp NdCache): the last few plans with their device arrays
     nrs::DevBuf comm_flag;           // one double: status word the ranks agree on after a sharded upload
     nrs::DevBuf gather_ws;           // sharded download / taps: two full-length row vectors for the gather (a rank holds its own rows only); released after use

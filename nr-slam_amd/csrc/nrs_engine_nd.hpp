@@ -20,7 +20,10 @@
 // Set-up: nd_prep_run (structure only: pair lists, cache key, plan; on a helper thread of engine_create) and nd_engine_finish
 // (value descriptors in the engine's row layout, uploads); the context caches the last plans (NdCache).
 #pragma once
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include "nrs_nd_plan.hpp"
 
@@ -1347,7 +1350,9 @@ static void nd_slot_free(nrs_ctx* c, NdSlot* sl) {
     c->release(sl->ws); c->release(sl->vb);
     delete sl;
 }
+static void plan_worker_free(nrs_ctx* c);
 void nd_cache_free(nrs_ctx* c) {
+    plan_worker_free(c);
     NdCache* nc = static_cast<NdCache*>(c->nd_cache);
     if (!nc) return;
     for (NdSlot* sl : nc->slots) nd_slot_free(c, sl);
@@ -1416,9 +1421,54 @@ struct NdPrep {
     uint64_t hash = 0;
     NdSlot* hit = nullptr;
     NdPlan plan;
-    std::thread th;
-    ~NdPrep() { if (th.joinable()) th.join(); }
+    struct PlanWorker* worker = nullptr;                           // the context's helper thread is running nd_prep_run on this object (joined by wait())
+    void wait();
+    ~NdPrep() { wait(); }
 };
+
+// The context's helper thread for the symbolic phase (nd_prep_run next to engine_create's packing).  ONE thread for the context's lifetime, not one
+// per frame: a fresh thread starts on a fresh malloc arena, and the ~15 MB of vectors a frame's plan builds were page-faulted in again every frame
+// (embedded 500-node frames: pair lists 1.9 ms on a new thread, the whole phase faster inline on the caller's warm heap than next to it on a cold one).
+struct PlanWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+    bool start() {
+        try { th = std::thread([this] { loop(); }); } catch (const std::system_error&) { return false; }
+        return true;
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        while (true) {
+            cv.wait(lk, [this] { return has_job || quit; });
+            if (quit) return;
+            std::function<void()> f = std::move(job);
+            has_job = false;
+            lk.unlock();
+            f();                                                   // (nd_prep_run: lets nothing escape)
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(f); has_job = true; busy = true; }
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return !busy; }); }
+    ~PlanWorker() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+inline void NdPrep::wait() { if (worker) { worker->wait(); worker = nullptr; } }
+static void plan_worker_free(nrs_ctx* c) {                         // (idle: every NdPrep waits for it before it goes away)
+    delete static_cast<PlanWorker*>(c->plan_worker);
+    c->plan_worker = nullptr;
+}
 
 
 // records with a key k = (low node << 32) | high node into key order, equal keys in their order of arrival: two stable counting
@@ -1629,7 +1679,7 @@ static int nd_engine_finish(nrs_ctx* c, Engine* e, NdEngine* nd, NdPrep& P) {
     {
         const bool tm = c->env("NRS_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        if (P.th.joinable()) P.th.join();
+        P.wait();
         if (tm) fprintf(stderr, "[nrs] direct solve: waited %.2f ms for the plan thread\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     const bool tmf = c->env("NRS_TIMING") != nullptr;

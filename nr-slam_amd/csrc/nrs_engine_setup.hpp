@@ -396,8 +396,14 @@ int engine_create(nrs_ctx* c, const EngineSpec& s, Arena* arena, Engine** out) {
         nd_in.vpos = e->nd->pos.data();
         bool inline_run = c->env("NRS_HOST_THREADS") && atoi(c->env("NRS_HOST_THREADS")) <= 1;
         if (!inline_run) {
-            try { nd_prep.th = std::thread([c, &nd_in, &nd_prep] { nd_prep_run(c, nd_in, nd_prep); }); }
-            catch (const std::system_error&) { inline_run = true; }
+            PlanWorker* pw = static_cast<PlanWorker*>(c->plan_worker);
+            if (!pw) {
+                pw = new (std::nothrow) PlanWorker();
+                if (pw && !pw->start()) { delete pw; pw = nullptr; }
+                c->plan_worker = pw;
+            }
+            if (pw) { nd_prep.worker = pw; pw->submit([c, &nd_in, &nd_prep] { nd_prep_run(c, nd_in, nd_prep); }); }
+            else inline_run = true;
         }
         if (inline_run) nd_prep_run(c, nd_in, nd_prep);
     }
