@@ -686,6 +686,10 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
                            ? std::min(e->n_spec, e->nd->S().n_alt) : 0;
     struct Pending { int set; double lam; int seq; int solve_id; } pend[1 + SPEC_MAX];
     int n_pend = 0, i_pend = 0;
+    struct SpecDrain {                                             // an error return with trials in flight: nothing of theirs may outlive the engine the caller is about to drop
+        nrs_ctx* c; int n; bool ok = false;
+        ~SpecDrain() { if (!ok) for (int j = 0; j < n; ++j) if (c->spec_stream[j]) (void)hipStreamSynchronize(c->spec_stream[j]); }
+    } spec_drain{c, n_spec};
     const int spec_first = c->env("NRS_SPEC_FIRST") ? atoi(c->env("NRS_SPEC_FIRST")) : 0;
     const bool spec_dbg = c->env("NRS_SPEC_DBG") != nullptr;       // (host clocks of a batch on stderr)
     auto t_batch = std::chrono::steady_clock::now();
@@ -870,6 +874,7 @@ int engine_optimize(nrs_ctx* c, Engine* e, int iters, int round, nrs_lm_trace* t
         if (trace) trace->iterations++;
         if (qmax == 10 || rho == 0 || !std::isfinite(lam)) break;
     }
+    spec_drain.ok = true;
     return NRS_OK;
 }
 
