@@ -261,40 +261,43 @@ class FrameLoop:
         in_frame = np.full(len(self.map_pos), -1, np.int64)
         has_mp = self.map_index >= 0
         in_frame[self.map_index[has_mp]] = np.nonzero(has_mp)[0]
-        cand = set(lost)
         pc = se3f_act(self.pose, self.map_pos)
         uv = self.project(pc) if len(pc) else np.zeros((0, 2), F32)
         inside = (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
-        # map points the frame does not hold (tracking.cc:404-420), in front of the camera and inside the image: one pass over the map
+        # candidates: the points lost in this frame and the map points the frame does not hold (tracking.cc:404-420), in front of the camera and
+        # inside the image -- one pass over the map, ascending map index (the reference walks a std::set)
         present = np.zeros(len(self.map_pos), bool)
         held = np.nonzero(in_frame >= 0)[0]
         st_held = self.status[in_frame[held]]
         present[held] = (st_held == TRACKED_WITH_3D) | (st_held == JUST_TRIANGULATED)
+        is_cand = np.zeros(len(self.map_pos), bool)
+        if lost:
+            is_cand[np.fromiter((int(x) for x in lost), np.int64, len(lost))] = True
         if len(pc):
-            cand.update(int(mp) for mp in np.nonzero(~present & (pc[:, 2] >= 0) & inside)[0])
-        cand = [mp for mp in sorted(cand) if inside[mp] and not np.isnan(uv[mp]).any()]
-        if not cand:
+            is_cand |= ~present & (pc[:, 2] >= 0) & inside
+            is_cand &= inside & ~np.isnan(uv).any(1)
+        cand = np.nonzero(is_cand)[0]
+        if not len(cand):
             return 0
         seeds = uv[cand].astype(F32)
         if self.dev_templates:
-            xy, st = self.b.reuse_track_archived(im, seeds, np.asarray(cand, np.int32), 0.75)
+            xy, st = self.b.reuse_track_archived(im, seeds, cand.astype(np.int32), 0.75)
         else:
-            xy, st = self.b.reuse_track(im, seeds, [self.templates[mp] for mp in cand], 0.75)
-        reused = 0
-        new_k, new_mp = [], []                          # candidates that enter the frame as new slots, in candidate order (one append below)
-        for k, mp in enumerate(cand):
-            if st[k] != TRACKED_WITH_3D:
-                continue
-            ex, ey = F32(uv[mp, 0]) - F32(xy[k, 0]), F32(uv[mp, 1]) - F32(xy[k, 1])
-            if ex * ex + ey * ey > F32(5.99):
-                continue
-            i = in_frame[mp]
-            if i >= 0:
-                self.kp[i], self.pos[i], self.status[i] = xy[k], self.map_pos[mp], TRACKED_WITH_3D
-            else:
-                in_frame[mp] = len(self.map_index) + len(new_mp)
-                new_k.append(k); new_mp.append(mp)
-            reused += 1
+            xy, st = self.b.reuse_track(im, seeds, [self.templates[int(mp)] for mp in cand], 0.75)
+        # accepted: tracked, and within sqrt(5.99) px of the projection (fp32 arithmetic, element by element as the scalar form)
+        xy = np.asarray(xy)
+        ex = uv[cand, 0].astype(F32) - xy[:, 0].astype(F32)
+        ey = uv[cand, 1].astype(F32) - xy[:, 1].astype(F32)
+        ok = (np.asarray(st) == TRACKED_WITH_3D) & ~(ex * ex + ey * ey > F32(5.99))
+        slot = in_frame[cand]
+        upd = ok & (slot >= 0)                          # the frame holds a slot for the point: it is refreshed
+        if upd.any():
+            self.kp[slot[upd]] = xy[upd]
+            self.pos[slot[upd]] = self.map_pos[cand[upd]]
+            self.status[slot[upd]] = TRACKED_WITH_3D
+        new = ok & (slot < 0)                           # candidates that enter the frame as new slots, in candidate order (one append below)
+        new_k, new_mp = [int(k) for k in np.nonzero(new)[0]], [int(mp) for mp in cand[new]]
+        reused = int(ok.sum())
         if new_mp:                                      # (the slots and their photometric information, appended in the loop's order)
             nk, nm = np.asarray(new_k), np.asarray(new_mp)
             self.kp = np.vstack([self.kp, xy[nk]]).astype(F32)
