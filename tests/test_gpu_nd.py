@@ -242,3 +242,31 @@ def test_speculative_trials_walk_the_same_trials_to_the_same_bits(ctx_direct, n,
         for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
             assert np.array_equal(r[k], r0[k]), k
         assert r["lost"] == r0["lost"] and r["median"] == r0["median"]
+
+
+def test_symbolic_phase_on_the_helper_thread_or_inline_gives_the_same_bits(ctx_direct):
+    """the plan is built on the context's helper thread next to the packing (PlanWorker) or, with NRS_HOST_THREADS=1, inline: same plan,
+    same results; several frames in a row, so that the worker is reused"""
+    import nrs_synth as S
+    c = ctx_direct
+    outs = {}
+    for mode in ("worker", "inline", "worker again"):
+        nrs.debug_clear()
+        nrs.debug_set("NRS_ND_NO_CACHE", "1")
+        if mode == "inline":
+            nrs.debug_set("NRS_HOST_THREADS", "1")
+        res = []
+        for n, seed in ((300, 7), (900, 8), (300, 7)):
+            tp = S.make_tracking_problem(n, seed)
+            cam = nrs.make_camera(tp["model"], tp["prm"])
+            fm = np.arange(n, dtype=np.int32)
+            tr = nrs.Trace(1024)
+            r = c.track_deform_solve(cam, tp["graph"], tp["X_prev"], fm, tp["status"], tp["uv"], tp["X_prev"], tp["pose_q"], tp["pose_t"], tp["scale"], tr)
+            res.append((r, _trace_key(tr.trials)))
+        outs[mode] = res
+    nrs.debug_clear()
+    for mode in ("inline", "worker again"):
+        for (r, t), (r0, t0) in zip(outs[mode], outs["worker"]):
+            assert t == t0
+            for k in ("pose_q", "pose_t", "f_pos", "f_status", "map_pos"):
+                assert np.array_equal(r[k], r0[k]), (mode, k)
