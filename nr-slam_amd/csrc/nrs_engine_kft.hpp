@@ -210,6 +210,8 @@ __global__ __launch_bounds__(256) void k_kft_clvals(KftDev F) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the sweep
+#include "nrs_kft_sweep.hpp"   // kft_sweep64_blk: the pivot block's sweep in 16-pivot steps (DPP broadcasts + matrix cores)
+
 // SWEEP(j) of a symmetric matrix on 64 x 64 blocks (P = A_jj):  A_jj <- -P^-1,  A_Ij <- A_Ij P^-1 (and its mirror),
 // A_IL <- A_IL - A_Ij P^-1 A_jL for I, L != j; after every block has been swept the matrix is -A^-1.  Two launches per step:
 //   k_kft_panel  (one workgroup per block row I): inverts P in registers (kft_sweep64: sixteen 4-pivot steps),
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, in
 // workgroup reads its pre-update value): the swept block travels through Pv and lands with launch j + 1.  Panels B / C / Pv are
 // double-buffered by the parity of j.  nb + 1 launches per inversion instead of 2 nb; same arithmetic as the two-launch form up to the
 // association of the pivot tile's update (NRS_KFT_TWO_LAUNCHES=1 selects that form).
+template <bool MF>                                               // MF: the pivot block's sweep in 16-pivot steps on DPP broadcasts + the matrix cores (kft_sweep64_blk); else the 4-pivot register form
 __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags, int nbu) {   // nbu: blocks in use (the larger of the two keyframes': rows beyond a keyframe's unknowns are identity rows, whole identity blocks need no sweep)
     extern __shared__ double sm[];
     const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
@@ -542,6 +545,30 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
         tile_lds(I, j, upC, Cs);
     }
     __syncthreads();
+    double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
+    double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
+    if constexpr (MF) {
+        nd_v4d pc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pc[n][g] = Ps[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)];
+        const bool bad = kft_sweep64_blk(pc, X0, lane, w);           // (the operand panels are not needed any more)
+        if (bad && lane == 0) flags[2] = 1;
+        if (I == j) {
+            double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Pv[(16 * w + (lane >> 4) + 4 * g) * KFT_B + 16 * n + (lane & 15)] = pc[n][g];
+            return;                                                 // (its own B / C slots are never read: the trailing update skips the pivot row / column)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Ps[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = -pc[n][g];   // P^-1
+    } else {
     double a[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -549,8 +576,6 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
         for (int y = 0; y < 4; ++y) a[x][y] = Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y];
     const bool bad = kft_sweep64(a, colb, ti, tj);
     if (bad && tid == 0) flags[2] = 1;
-    double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
-    double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     if (I == j) {
         double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
 #pragma unroll
@@ -564,6 +589,7 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
+    }
     for (int q = tid; q < KFT_B * KFT_B; q += 256) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
     __syncthreads();
     nd_v4d c[4];
@@ -736,7 +762,8 @@ static int kft_invert(nrs_ctx* c, const KftHost& H, int kf0, int kf1, int* flags
     }
     const int nbu = std::max(kf0 >= 0 ? H.kf_nb[kf0] : 1, kf1 >= 0 ? H.kf_nb[kf1] : 1);
     for (int j = 0; j <= nbu; ++j)
-        hipLaunchKernelGGL(k_kft_step, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        if (c->env("NRS_KFT_SCALAR_SWEEP")) hipLaunchKernelGGL(k_kft_step<false>, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        else hipLaunchKernelGGL(k_kft_step<true>, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
     return NRS_OK;
 }
 

@@ -243,7 +243,8 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
     static bool attr_done = false;
     if (!attr_done) {
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_PANEL_LDS));
-        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
         attr_done = true;
     }
     H->bytes = off;
