@@ -458,6 +458,7 @@ static int pcg_begin(nrs_ctx* c, Engine* e, double lam, int* it) {
     if (e->kft && e->kft->on) {                                    // embedded BA window: factorise H + lambda I by keyframe blocks, u_0 = M^-1 b
         NRS_TRY(kft_factor(c, e, e->kft, lam));
         NRS_TRY(kft_apply(c, e->kft, d.rv, d.rp, d.uv3, d.up, d.flags));
+        e->kft->apply_pending = false;
     }
     *it = 0;
     return NRS_OK;
@@ -471,9 +472,18 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
     const double tol2 = c->opt.pcg_rtol * c->opt.pcg_rtol;
     int it = *it_io;
     // profiling contexts poll after every iteration, so that no launch queued behind a converged solve is timed
-    const int stop = std::min(it + (c->opt.profile ? 1 : count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
+    int stop = std::min(it + (c->opt.profile ? 1 : count > 0 ? count : c->opt.pcg_batch), c->opt.pcg_max_iters);
+    // keyframe-block factorisation: the first step's residual is tested on its own before M^-1 is applied again (k_kft_rnorm,
+    // nrs_engine_kft.hpp): the batch that holds iteration 0 ends with it, and u = M^-1 r is enqueued only when the solve goes on
+    const bool kft_on = e->kft && e->kft->on;
+    const bool kft_lazy = kft_on && it == 0 && stop > 0 && !c->opt.profile && !c->env("NRS_KFT_NO_RESIDUAL_TEST");
+    if (kft_lazy) stop = 1;
+    if (kft_on && e->kft->apply_pending) {
+        NRS_TRY(kft_apply(c, e->kft, d.rv, ((it - 1) & 1) ? d.rp : d.rp2, d.uv3, ((it - 1) & 1) ? d.up : d.up2, d.flags));
+        e->kft->apply_pending = false;
+    }
     for (; it < stop; ++it) {
-        const int pub = it + 1 == stop ? pub_seq : 0;
+        const int pub = it + 1 == stop && !kft_lazy ? pub_seq : 0;     // (kft_lazy: k_kft_rnorm is the batch's last launch and publishes)
 #ifdef NRS_DEBUG_PROBES                                            // (phase clocks of one fused PCG launch: make PROBES=1, then NRS_PCG_DBG=1)
         if (d.fused && it == 20 && d.coarse && c->env("NRS_PCG_DBG")) {   // phase clocks of one fused launch (100 MHz wall clock), once
             static bool dbg_done = false;
@@ -642,7 +652,10 @@ static int pcg_enqueue_batch(nrs_ctx* c, Engine* e, double lam, int* it_io, int 
             else hipLaunchKernelGGL(k_pcg_update<false>, dim3((((d.sh_nvb + 1) / 2 + 7) / 8) * 8 + n_poseblk), dim3(BLK), 0, c->stream,
                                     d, lam, it, tol2, PEEK_RTOL * PEEK_RTOL, pub);
         }
-        if (e->kft && e->kft->on)                                  // u = M^-1 r over the keyframe chains (the update left the block-Jacobi u: overwritten)
+        if (kft_lazy) {
+            hipLaunchKernelGGL(k_kft_rnorm, dim3(1), dim3(1024), 0, c->stream, e->kft->d, d, d.rv, (it & 1) ? d.rp : d.rp2, tol2, pub_seq);
+            e->kft->apply_pending = true;
+        } else if (kft_on)                                         // u = M^-1 r over the keyframe chains (the update left the block-Jacobi u: overwritten)
             NRS_TRY(kft_apply(c, e->kft, d.rv, (it & 1) ? d.rp : d.rp2, d.uv3, (it & 1) ? d.up : d.up2, d.flags));
     }
     *it_io = it;

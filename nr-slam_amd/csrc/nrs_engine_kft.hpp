@@ -62,6 +62,7 @@ struct KftHost {
     KftDev d;
     size_t bytes = 0;
     int factorisations = 0;
+    bool apply_pending = false;      // the PCG's iteration 0 ended with the residual test (k_kft_rnorm): u = M^-1 r is enqueued when the solve goes on
     std::vector<int> kf_nb;          // per keyframe: 64-blocks that hold unknowns (ceil((3 nodes + 6) / 64))
 };
 
@@ -799,6 +800,43 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
 }
 
 // u = M^-1 r: r in (rv rows, rp poses), u to (uv rows, up poses)
+// The factorisation is exact up to rounding, so the first PCG step as a rule IS the solution.  The PCG's own test -- r.u <= rtol^2 r_0.u_0 with
+// u = M^-1 r -- costs a second pass over the keyframe chains (42 launches) and the first two launches of an iteration that only finds r.u
+// small.  This kernel tests the step's residual on its own first, |r| <= rtol |b| over the factorisation's unknowns (fixed-order sums, one
+// workgroup): when it holds the solve is marked converged -- with the iterate the PCG would have returned an iteration later -- and the
+// second pass is never enqueued; when it does not, the PCG carries on as before (pcg_enqueue_batch, nrs_engine.hip).
+__global__ __launch_bounds__(1024) void k_kft_rnorm(KftDev F, Dev P, const double* __restrict__ rv, const double* __restrict__ rp, double tol2, int pub_seq) {
+    __shared__ double lds[2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double sr = 0, sb = 0;
+    const bool live = P.flags[0] == 0;
+    if (live)
+        for (int k = 0; k < F.K; ++k) {
+            const int nf = F.kf_nf[k], np = F.kf_np[k];
+            for (int jx = tid; jx < 3 * nf + np; jx += 1024) {
+                double r, b;
+                if (jx < 3 * nf) {
+                    const size_t o = 3 * (size_t)F.kf_row[k * F.nfm + jx / 3] + jx % 3;
+                    r = rv[o]; b = P.bl[o];
+                } else { r = rp[6 * k + (jx - 3 * nf)]; b = P.bp[6 * k + (jx - 3 * nf)]; }
+                sr += r * r; sb += b * b;
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); sb += __shfl_xor(sb, o, 64); }
+    if (lane == 0) { lds[2 * w] = sr; lds[2 * w + 1] = sb; }
+    __syncthreads();
+    if (tid == 0) {
+        sr = 0; sb = 0;
+        for (int q = 0; q < 16; ++q) { sr += lds[2 * q]; sb += lds[2 * q + 1]; }
+        if (live && sr <= tol2 * sb) {                             // (a NaN fails the test: the PCG's own checks see it)
+            __threadfence();
+            P.flags[0] = 1;
+        }
+        if (pub_seq != 0) publish_flags(P, pub_seq);
+    }
+}
+
 static int kft_apply(nrs_ctx* c, KftHost* H, const double* rv, const double* rp, double* uv, double* up, const int* flags) {
     const KftDev& F = H->d;
     const int len0 = F.m, len1 = F.K - 1 - F.m, ns = std::max(len0, len1);
