@@ -36,7 +36,8 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         // + 1.5 ms per trial; the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count.  Measured on 20 keyframes: 5.2 x
         // the PCG's rate at 100 nodes per keyframe, 3.3 x at 200, 2.3 x at 300, 1.5 x at 400, 1.24 x at 440, 1.03 x at 458 (C2: 75 against 73 LM iterations / s), 0.87 x at 550;
         // 1.44 x at 458 x 10 keyframes.  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
-        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (25.3 + 0.0447 * nb * nb) * 1e-3 + 1.5, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
+        // (later in round 6: the 16-pivot sweep took 2.5 us off a launch and the residual test 0.5 ms off a trial -- the constants below; C2: 87 against 73)
+        const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * (22.8 + 0.0447 * nb * nb) * 1e-3 + 1.0, pcg_ms = 14.0 * std::pow(K / 20.0, 0.45);
         if (kft_ms > pcg_ms) return NRS_OK;
     }
     if ((size_t)K * n2 * sizeof(double) > ((size_t)6 << 30)) return NRS_OK;       // (the factor would not be worth its memory: the PCG stays block-Jacobi)
