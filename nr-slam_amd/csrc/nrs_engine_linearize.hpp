@@ -598,12 +598,9 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     const int t = lane % T;
     auto stamp = [&](int k) { if (P.dbg_clk && lane == 0) P.dbg_clk[(size_t)slice * 8 + k] = wall_clock64(); };
     stamp(0);
-    const int rf = P.rflag[row];
-    const uint32_t tp = TPC ? P.row_tp[row] : 0u;                  // the row's temporal partners (tile-local ids)
     // this lane's share of its row's incidences (k = t, t + T, ...): slots beyond it are padding -- not requested, not stored
     const uint32_t rcn = P.row_cnt[row];
     const int my_s = ((int)(rcn & 0xFFFFu) + T - 1 - t) / T, my_d = ((int)(rcn >> 16) + T - 1 - t) / T;
-    const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];     // (requested up front: nothing behind the loops waits on memory)
     if (tid < 7) spose[tid] = reinterpret_cast<const double*>(P.lin_pose + P.grp_pose[row / ROW_ALIGN])[tid];   // (a tile never straddles keyframes)
     const int s_beg = P.ss_ptr[slice], s_end = P.ss_ptr[slice + 1];
     const int d_beg = P.sd_ptr[slice], d_end = EXP == 5 ? P.sd_ptr[slice] + (((P.sd_ptr[slice + 1] - P.sd_ptr[slice]) / 64 + 1) / 2) * 64 : P.sd_ptr[slice + 1];   // (EXP 5: half of the damper slots -- what a two-incidence form of the dampers would stream)
@@ -682,6 +679,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // once here, behind the spring loop whose registers are free by now, instead of once per incidence -- two of the three gathers of a damper were the row's own partners)
     double en0 = 0, en1 = 0, en2 = 0, ep0 = 0, ep1 = 0, ep2 = 0;
     if (TPC) {
+        const uint32_t tp = P.row_tp[row];                         // the row's temporal partners (tile-local ids); requested here for the same reason as the flag and the keypoint below
         const int tn = (int)(tp & 0xFFFFu) == REC_NONE ? self : (int)(tp & 0xFFFFu), tq = (int)(tp >> 16) == REC_NONE ? self : (int)(tp >> 16);
         en0 = xo0 - lx[3 * tn]; en1 = xo1 - lx[3 * tn + 1]; en2 = xo2 - lx[3 * tn + 2];
         ep0 = xo0 - lx[3 * tq]; ep1 = xo1 - lx[3 * tq + 1]; ep2 = xo2 - lx[3 * tq + 2];
@@ -739,6 +737,10 @@ __global__ __launch_bounds__(BLK, OCC) void k_lin_plain(Dev P, const double* __r
     // ---- reprojection edge of the row (as in k_reg: the first two lanes of a row take one residual component each).
     // The pose is the tile's (a tile never straddles keyframes): scalar loads, nothing waits on a per-lane gather.
     constexpr int NRR = T == 1 ? 2 : 1;
+    // (the row's flag and keypoint are requested HERE, not up front: held across the loops they are spilled at four waves per SIMD -- 20 bytes of
+    // scratch written and read back per lane, which in the HBM regime is traffic; the other waves of the SIMD cover this round trip)
+    const int rf = P.rflag[row];
+    const float uvx = P.uv[2 * row], uvy = P.uv[2 * row + 1];
     const bool active = (rf & RF_OBS) && (rf & RF_REPROJ_ACTIVE);
     RowRec rc;
 #pragma unroll
