@@ -549,26 +549,29 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     if constexpr (MF) {
-        nd_v4d pc[4];
+        KftTiles pc;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pc[n][g] = Ps[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)];
+        for (int g = 0; g < 4; ++g) {
+            const double* pr = Ps + (16 * w + (lane >> 4) + 4 * g) * KFT_LDP + (lane & 15);
+            pc.t0[g] = pr[0]; pc.t1[g] = pr[16]; pc.t2[g] = pr[32]; pc.t3[g] = pr[48];
+        }
         const bool bad = kft_sweep64_blk(pc, X0, lane, w);           // (the operand panels are not needed any more)
         if (bad && lane == 0) flags[2] = 1;
         if (I == j) {
             double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) Pv[(16 * w + (lane >> 4) + 4 * g) * KFT_B + 16 * n + (lane & 15)] = pc[n][g];
+            for (int g = 0; g < 4; ++g) {
+                double* pw = Pv + (16 * w + (lane >> 4) + 4 * g) * KFT_B + (lane & 15);
+                pw[0] = pc.t0[g]; pw[16] = pc.t1[g]; pw[32] = pc.t2[g]; pw[48] = pc.t3[g];
+            }
             return;                                                 // (its own B / C slots are never read: the trailing update skips the pivot row / column)
         }
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Ps[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = -pc[n][g];   // P^-1
+        for (int g = 0; g < 4; ++g) {                               // P^-1
+            double* pw = Ps + (16 * w + (lane >> 4) + 4 * g) * KFT_LDP + (lane & 15);
+            pw[0] = -pc.t0[g]; pw[16] = -pc.t1[g]; pw[32] = -pc.t2[g]; pw[48] = -pc.t3[g];
+        }
     } else {
     double a[4][4];
 #pragma unroll

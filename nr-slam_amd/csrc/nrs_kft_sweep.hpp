@@ -55,26 +55,56 @@ __device__ inline void kft_ldl16(double (&a)[16], double (&wv)[16], double& mine
         kft_ldl16<J + 1>(a, wv, mine, i, bad);
     }
 }
+// the wave's sixteen rows as four accumulator tiles by NAME (a tile array indexed inside the unrolled loops stayed in scratch memory: six
+// 16-byte scratch loads and stores per step)
+struct KftTiles {
+    nd_v4d t0, t1, t2, t3;
+    template <int N> __device__ __forceinline__ nd_v4d& at() {
+        if constexpr (N == 0) return t0; else if constexpr (N == 1) return t1; else if constexpr (N == 2) return t2; else return t3;
+    }
+};
+template <int K, int N>
+__device__ __forceinline__ void kft_blk_panel_out(KftTiles& c, double* R, int lc, int lk) {   // wave K: its rows to the panel
+    if constexpr (N < 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R[(lk + 4 * g) * KFT_RS + 16 * N + lc] = c.at<N>()[g];
+        kft_blk_panel_out<K, N + 1>(c, R, lc, lk);
+    }
+}
+template <int K, int N>
+__device__ __forceinline__ void kft_blk_tiles(KftTiles& c, const double* R, int lc, int lk, const double (&ws)[4], const double (&wt)[4], const nd_v4d& nyw, bool pivot_wave) {
+    if constexpr (N < 4) {
+        if constexpr (N != K) {
+            double b[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[s] = R[(lk + 4 * s) * KFT_RS + 16 * N + lc];
+            nd_v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ws[s], b[s], y, 0, 0, 0);          // Y_N = W R_N
+            if (pivot_wave) {
+                nd_v4d z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[s], y[s], z, 0, 0, 0);      // A[K, N] = W^T Y_N
+                c.at<N>() = z;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) c.at<N>() = __builtin_amdgcn_mfma_f64_16x16x4f64(nyw[s], y[s], c.at<N>(), 0, 0, 0);   // A[w, N] -= Y_w^T Y_N
+            }
+        }
+        kft_blk_tiles<K, N + 1>(c, R, lc, lk, ws, wt, nyw, pivot_wave);
+    }
+}
 template <int K>
-__device__ __forceinline__ void kft_sweep_blk_steps(nd_v4d (&c)[4], double* xb, int lane, int w, int& bad) {
+__device__ __forceinline__ void kft_sweep_blk_steps(KftTiles& c, double* xb, int lane, int w, int& bad) {
     if constexpr (K < 4) {
         double* R = xb + (K & 1) * (16 * KFT_RS);
         double* Wl = xb + 2 * 16 * KFT_RS + w * (16 * KFT_WS);
         const int lc = lane & 15, lk = lane >> 4;
-        if (w == K) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) R[(lk + 4 * g) * KFT_RS + 16 * n + lc] = c[n][g];
-        }
+        if (w == K) kft_blk_panel_out<K, 0>(c, R, lc, lk);
         __syncthreads();
-        double a[16], wv[16], b[4][4], rw[4];
+        double a[16], wv[16], rw[4];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a[q] = R[lc * KFT_RS + 16 * K + q];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) b[n][s] = n == K ? 0.0 : R[(lk + 4 * s) * KFT_RS + 16 * n + lc];
 #pragma unroll
         for (int s = 0; s < 4; ++s) rw[s] = R[(lk + 4 * s) * KFT_RS + 16 * w + lc];
         double mine = 1.0;
@@ -91,47 +121,26 @@ __device__ __forceinline__ void kft_sweep_blk_steps(nd_v4d (&c)[4], double* xb, 
 #pragma unroll
         for (int s = 0; s < 4; ++s) { ws[s] = Wl[lc * KFT_WS + 4 * s + lk]; wt[s] = Wl[(4 * s + lk) * KFT_WS + lc]; }
         const nd_v4d zero = {0.0, 0.0, 0.0, 0.0};
-        nd_v4d y[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            y[n] = zero;
-            if (n == K) continue;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) y[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ws[s], b[n][s], y[n], 0, 0, 0);
-        }
+        nd_v4d nyw = zero;
         if (w == K) {
+            nd_v4d z = zero;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                nd_v4d z = zero;
-                if (n == K) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[s], wt[s], z, 0, 0, 0);
-                    c[n] = -z;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[s], y[n][s], z, 0, 0, 0);
-                    c[n] = z;
-                }
-            }
+            for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[s], wt[s], z, 0, 0, 0);
+            c.at<K>() = -z;                                        // A[K, K] = -W^T W
         } else {
             nd_v4d yw = zero, ck = zero;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) yw = __builtin_amdgcn_mfma_f64_16x16x4f64(ws[s], rw[s], yw, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) yw = __builtin_amdgcn_mfma_f64_16x16x4f64(ws[s], rw[s], yw, 0, 0, 0);       // Y_w
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ck = __builtin_amdgcn_mfma_f64_16x16x4f64(yw[s], wt[s], ck, 0, 0, 0);
-            const nd_v4d nyw = -yw;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (n == K) continue;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(nyw[s], y[n][s], c[n], 0, 0, 0);
-            }
-            c[K] = ck;
+            for (int s = 0; s < 4; ++s) ck = __builtin_amdgcn_mfma_f64_16x16x4f64(yw[s], wt[s], ck, 0, 0, 0);       // A[w, K] = Y_w^T W
+            nyw = -yw;
+            c.at<K>() = ck;
         }
+        kft_blk_tiles<K, 0>(c, R, lc, lk, ws, wt, nyw, w == K);
         kft_sweep_blk_steps<K + 1>(c, xb, lane, w, bad);
     }
 }
-__device__ __forceinline__ bool kft_sweep64_blk(nd_v4d (&c)[4], double* xb, int lane, int w) {
+__device__ __forceinline__ bool kft_sweep64_blk(KftTiles& c, double* xb, int lane, int w) {
     int bad = 0;
     kft_sweep_blk_steps<0>(c, xb, lane, w, bad);
     return bad != 0;

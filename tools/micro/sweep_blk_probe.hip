@@ -21,14 +21,15 @@ using namespace nrs;
 __global__ __launch_bounds__(256) void k_probe(const double* A, double* out, long long* cyc, int* badf, int reps) {
     __shared__ double xb[KFT_SWEEP_XB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    nd_v4d c[4];
+    KftTiles c;
     long long t = 0;
     bool bad = false;
     for (int r = 0; r < reps; ++r) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) c[n][g] = A[(16 * w + (lane >> 4) + 4 * g) * 64 + 16 * n + (lane & 15)];
+        for (int g = 0; g < 4; ++g) {
+            const double* a = A + (16 * w + (lane >> 4) + 4 * g) * 64 + (lane & 15);
+            c.t0[g] = a[0]; c.t1[g] = a[16]; c.t2[g] = a[32]; c.t3[g] = a[48];
+        }
         __syncthreads();
         const long long t0 = clock64();
         bad = kft_sweep64_blk(c, xb, lane, w) || bad;
@@ -36,9 +37,10 @@ __global__ __launch_bounds__(256) void k_probe(const double* A, double* out, lon
         __syncthreads();
     }
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) out[(16 * w + (lane >> 4) + 4 * g) * 64 + 16 * n + (lane & 15)] = c[n][g];
+    for (int g = 0; g < 4; ++g) {
+        double* o = out + (16 * w + (lane >> 4) + 4 * g) * 64 + (lane & 15);
+        o[0] = c.t0[g]; o[16] = c.t1[g]; o[32] = c.t2[g]; o[48] = c.t3[g];
+    }
     if (tid == 0) { *cyc = t / reps; *badf = bad; }
 }
 
