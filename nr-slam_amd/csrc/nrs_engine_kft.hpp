@@ -506,55 +506,78 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     double* X0 = sm + 2 * KFT_B * KFT_LDP + 2 * 16 * KFT_CBS + 16;  // B panel (packed [k / 4][row][k % 4])
     double* X1 = X0 + KFT_B * KFT_B;                                // C_j
     const bool upP = jp >= 0, upC = jp >= 0 && I != j && I != jp;  // (the previous pivot row holds B already: no update)
-    auto tile_lds = [&](int TI, int TL, bool apply, double* out) {  // out (row-major, stride KFT_LDP) = tile (TI, TL) - X0 X1^T
-        const double* At = A + (size_t)(KFT_B * TI) * ld + KFT_B * TL;
-        nd_v4d c[4];
+    // EVERY global request of the look-ahead goes out before the first wait -- the pivot row's two operand panels, this row's B panel (held in
+    // registers until X0 is free again) and both tiles: as four dependent phases (panels, pivot tile, B_I, own tile) the launch paid four
+    // memory round trips under the load of the trailing update's workgroups, ~10 of its 34 us
+    const double* Pt = A + (size_t)(KFT_B * j) * ld + KFT_B * j;
+    const double* Ct = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
+    double rbj[16], rcj[16], rbi[16];                               // (plain doubles: arrays of 16-byte vectors filled in unrolled loops end up in scratch memory)
+    nd_v4d cp[4], cc[4];
+    if (upP) {
+        const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)j * tile);
+        const double2* c2 = reinterpret_cast<const double2*>(Cp + (size_t)j * tile);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) c[n][g] = At[(size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15)];
-        if (apply) {
-#pragma unroll 4
-            for (int kq = 0; kq < KFT_B / 4; ++kq) {
-                const double av = -X0[(kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
-                double bv[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) bv[n] = X1[(kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
-            }
+        for (int q = 0; q < 8; ++q) {
+            const double2 vb = b2[tid + 256 * q], vc = c2[tid + 256 * q];
+            rbj[2 * q] = vb.x; rbj[2 * q + 1] = vb.y; rcj[2 * q] = vc.x; rcj[2 * q + 1] = vc.y;
         }
+    }
+    if (upC) {
+        const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)I * tile);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const double2 vb = b2[tid + 256 * q]; rbi[2 * q] = vb.x; rbi[2 * q + 1] = vb.y; }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t o = (size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15);
+            cp[n][g] = Pt[o];
+            cc[n][g] = I != j ? Ct[o] : 0.0;
+        }
+    auto rank64 = [&](nd_v4d (&c)[4]) {                             // c -= X0 X1^T on the matrix cores
+#pragma unroll 4
+        for (int kq = 0; kq < KFT_B / 4; ++kq) {
+            const double av = -X0[(kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
+            double bv[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bv[n] = X1[(kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+        }
+    };
+    auto to_lds = [&](const nd_v4d (&c)[4], double* out) {          // (row-major, stride KFT_LDP)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) out[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
     };
     if (upP) {
-        const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)j * tile);
-        const double2* c2 = reinterpret_cast<const double2*>(Cp + (size_t)j * tile);
-        for (int e = tid; e < KFT_B * KFT_B / 2; e += 256) { reinterpret_cast<double2*>(X0)[e] = b2[e]; reinterpret_cast<double2*>(X1)[e] = c2[e]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbj[2 * q], rbj[2 * q + 1]);
+            reinterpret_cast<double2*>(X1)[tid + 256 * q] = make_double2(rcj[2 * q], rcj[2 * q + 1]);
+        }
         __syncthreads();
+        rank64(cp);
     }
-    tile_lds(j, j, upP, Ps);
+    if (!MF) to_lds(cp, Ps);                                        // (the 16-pivot sweep takes the block from the registers)
     if (I != j) {
         if (upC) {
             __syncthreads();                                        // (every wave has read B_j from X0)
-            const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)I * tile);
-            for (int e = tid; e < KFT_B * KFT_B / 2; e += 256) reinterpret_cast<double2*>(X0)[e] = b2[e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbi[2 * q], rbi[2 * q + 1]);
             __syncthreads();
+            rank64(cc);
         }
-        tile_lds(I, j, upC, Cs);
+        to_lds(cc, Cs);
     }
     __syncthreads();
     double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     if constexpr (MF) {
         KftTiles pc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const double* pr = Ps + (16 * w + (lane >> 4) + 4 * g) * KFT_LDP + (lane & 15);
-            pc.t0[g] = pr[0]; pc.t1[g] = pr[16]; pc.t2[g] = pr[32]; pc.t3[g] = pr[48];
-        }
+        pc.t0 = cp[0]; pc.t1 = cp[1]; pc.t2 = cp[2]; pc.t3 = cp[3];
         const bool bad = kft_sweep64_blk(pc, X0, lane, w);           // (the operand panels are not needed any more)
         if (bad && lane == 0) flags[2] = 1;
         if (I == j) {
