@@ -425,7 +425,11 @@ __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, in
 template <bool MF>                                               // MF: the pivot block's sweep in 16-pivot steps on DPP broadcasts + the matrix cores (kft_sweep64_blk); else the 4-pivot register form
 __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags, int nbu) {   // nbu: blocks in use (the larger of the two keyframes': rows beyond a keyframe's unknowns are identity rows, whole identity blocks need no sweep)
     extern __shared__ double sm[];
-    const int ch = blockIdx.y, kf = ch ? kf1 : kf0;
+    // (1-D grid: the panel workgroups of BOTH chains come first -- with the chain as the grid's second dimension chain 1's panel workgroups were
+    // dispatched behind chain 0's 500 tiles, a round of tiles late: 40 against 34 us a launch when two chains are in flight)
+    const int ch = (int)blockIdx.x < 2 * nbu ? (int)blockIdx.x / nbu : ((int)blockIdx.x - 2 * nbu) / (nbu * nbu);
+    const int bx = (int)blockIdx.x < 2 * nbu ? (int)blockIdx.x % nbu : nbu + ((int)blockIdx.x - 2 * nbu) % (nbu * nbu);
+    const int kf = ch ? kf1 : kf0;
     if (kf < 0) return;
     const int nb = F.nb, ld = F.ld, jp = j - 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -466,10 +470,10 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
                 else A[(size_t)(KFT_B * I + r) * ld + KFT_B * L + cc] = sgn * c[n][g];
             }
     };
-    if ((int)blockIdx.x >= nbu) {
+    if (bx >= nbu) {
         // ---- trailing update of step j - 1 (every tile outside its pivot row / column and outside this step's panel)
         if (jp < 0) return;
-        const int q = blockIdx.x - nbu, I = q / nbu, L = q % nbu;
+        const int q = bx - nbu, I = q / nbu, L = q % nbu;
         double* At = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
         if (I == jp && L == jp) {                                   // the swept pivot block of step j - 1 lands
             for (int e = tid; e < KFT_B * KFT_B; e += 256) At[(size_t)(e / KFT_B) * ld + e % KFT_B] = sgn * Pvp[e];
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     }
     if (last) return;
     // ---- panel of step j: block row I
-    const int I = blockIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int I = bx, ti = tid >> 4, tj = tid & 15;
     double* Ps = sm;
     double* Cs = sm + KFT_B * KFT_LDP;
     double* colb = sm + 2 * KFT_B * KFT_LDP;
@@ -789,8 +793,8 @@ static int kft_invert(nrs_ctx* c, const KftHost& H, int kf0, int kf1, int* flags
     }
     const int nbu = std::max(kf0 >= 0 ? H.kf_nb[kf0] : 1, kf1 >= 0 ? H.kf_nb[kf1] : 1);
     for (int j = 0; j <= nbu; ++j)
-        if (c->env("NRS_KFT_SCALAR_SWEEP")) hipLaunchKernelGGL(k_kft_step<false>, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
-        else hipLaunchKernelGGL(k_kft_step<true>, dim3(nbu + nbu * nbu, 2), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        if (c->env("NRS_KFT_SCALAR_SWEEP")) hipLaunchKernelGGL(k_kft_step<false>, dim3(2 * (nbu + nbu * nbu)), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        else hipLaunchKernelGGL(k_kft_step<true>, dim3(2 * (nbu + nbu * nbu)), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
     return NRS_OK;
 }
 
