@@ -158,7 +158,7 @@ int nrs_create(nrs_ctx** out, const nrs_options* opt);
  *                 NRS_NO_TILE_SORT, NRS_ONE_CLASS, NRS_TILE_CUT_PCT=<p>, NRS_HOST_PACK, NRS_HOST_THREADS=<n>, NRS_HOST_THREADS_SMALL=<n>,
  *                 NRS_SKIN_OP_OWN_LAUNCH, NRS_SKIN_ROWS_OWN_LAUNCH, NRS_PCG_RTOL=<r> (experiments)
  *   embedded BA   NRS_KFT_TWO_LAUNCHES (a sweep step of the keyframe-block factorisation as two launches), NRS_KFT_SCALAR_SWEEP (the pivot
- *                 block's sweep in the 4-pivot register form), NRS_KFT_NO_RESIDUAL_TEST (M^-1 applied again after the first PCG step
+ *                 block's sweep in the 4-pivot register form), NRS_KFT_FOUR_WAVES (panel workgroups without the four helper waves), NRS_KFT_NO_RESIDUAL_TEST (M^-1 applied again after the first PCG step
  *                 instead of the step's residual tested on its own)
  *   sharding      NRS_SHARD_PACK_ALL, NRS_SHARD_FULL_VECTORS
  *   a1 / graph    NRS_PO_MULTI_MIN=<n>, NRS_HOST_WALK, NRS_WALK_MAX_PASSES=<n>, NRS_RG_NO_MIRROR

@@ -422,8 +422,12 @@ __global__ __launch_bounds__(256) void k_kft_update(KftDev F, int j, int kf0, in
 // workgroup reads its pre-update value): the swept block travels through Pv and lands with launch j + 1.  Panels B / C / Pv are
 // double-buffered by the parity of j.  nb + 1 launches per inversion instead of 2 nb; same arithmetic as the two-launch form up to the
 // association of the pivot tile's update (NRS_KFT_TWO_LAUNCHES=1 selects that form).
-template <bool MF>                                               // MF: the pivot block's sweep in 16-pivot steps on DPP broadcasts + the matrix cores (kft_sweep64_blk); else the 4-pivot register form
-__global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags, int nbu) {   // nbu: blocks in use (the larger of the two keyframes': rows beyond a keyframe's unknowns are identity rows, whole identity blocks need no sweep)
+// HW (with MF): EIGHT waves.  Waves 4 - 7 of a panel workgroup take the C_I half of the look-ahead -- this row's B panel, its tile, the rank-64
+// update, C_I into LDS -- while waves 0 - 3 update and sweep the pivot block: that half (a panel through LDS, two barriers, sixty-four matrix
+// instructions a wave) sat on the panel workgroup's path in front of the sweep.  The helpers meet the sweep's four barriers and the ones behind
+// it, and share the stores; in a tile workgroup they leave at once.
+template <bool MF, bool HW = false>                              // MF: the pivot block's sweep in 16-pivot steps on DPP broadcasts + the matrix cores (kft_sweep64_blk); else the 4-pivot register form
+__global__ __launch_bounds__(HW ? 512 : 256) void k_kft_step(KftDev F, int j, int kf0, int kf1, int* flags, int nbu) {   // nbu: blocks in use (the larger of the two keyframes': rows beyond a keyframe's unknowns are identity rows, whole identity blocks need no sweep)
     extern __shared__ double sm[];
     // (1-D grid: the panel workgroups of BOTH chains come first -- with the chain as the grid's second dimension chain 1's panel workgroups were
     // dispatched behind chain 0's 500 tiles, a round of tiles late: 40 against 34 us a launch when two chains are in flight)
@@ -470,9 +474,11 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
                 else A[(size_t)(KFT_B * I + r) * ld + KFT_B * L + cc] = sgn * c[n][g];
             }
     };
+    static_assert(MF || !HW, "the helper waves go with the 16-pivot sweep");
     if (bx >= nbu) {
         // ---- trailing update of step j - 1 (every tile outside its pivot row / column and outside this step's panel)
         if (jp < 0) return;
+        if (HW && tid >= 256) return;                               // (a tile is four waves' work)
         const int q = bx - nbu, I = q / nbu, L = q % nbu;
         double* At = A + (size_t)(KFT_B * I) * ld + KFT_B * L;
         if (I == jp && L == jp) {                                   // the swept pivot block of step j - 1 lands
@@ -515,34 +521,37 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
     // memory round trips under the load of the trailing update's workgroups, ~10 of its 34 us
     const double* Pt = A + (size_t)(KFT_B * j) * ld + KFT_B * j;
     const double* Ct = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
+    const bool helper = HW && tid >= 256;                           // (HW: waves 4 - 7)
+    const int ht = HW ? (tid & 255) : tid, wr = HW ? (w & 3) : w;   // a thread's place among its four waves; its wave's sixteen rows
+    constexpr int NT = HW ? 512 : 256;
     double rbj[16], rcj[16], rbi[16];                               // (plain doubles: arrays of 16-byte vectors filled in unrolled loops end up in scratch memory)
     nd_v4d cp[4], cc[4];
-    if (upP) {
+    if (upP && !helper) {
         const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)j * tile);
         const double2* c2 = reinterpret_cast<const double2*>(Cp + (size_t)j * tile);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const double2 vb = b2[tid + 256 * q], vc = c2[tid + 256 * q];
+            const double2 vb = b2[ht + 256 * q], vc = c2[ht + 256 * q];
             rbj[2 * q] = vb.x; rbj[2 * q + 1] = vb.y; rcj[2 * q] = vc.x; rcj[2 * q + 1] = vc.y;
         }
     }
-    if (upC) {
+    if (upC && (helper || !HW)) {
         const double2* b2 = reinterpret_cast<const double2*>(Bp + (size_t)I * tile);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const double2 vb = b2[tid + 256 * q]; rbi[2 * q] = vb.x; rbi[2 * q + 1] = vb.y; }
+        for (int q = 0; q < 8; ++q) { const double2 vb = b2[ht + 256 * q]; rbi[2 * q] = vb.x; rbi[2 * q + 1] = vb.y; }
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const size_t o = (size_t)(16 * w + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15);
-            cp[n][g] = Pt[o];
-            cc[n][g] = I != j ? Ct[o] : 0.0;
+            const size_t o = (size_t)(16 * wr + (lane >> 4) + 4 * g) * ld + 16 * n + (lane & 15);
+            cp[n][g] = !helper ? Pt[o] : 0.0;
+            cc[n][g] = I != j && (helper || !HW) ? Ct[o] : 0.0;
         }
-    auto rank64 = [&](nd_v4d (&c)[4]) {                             // c -= X0 X1^T on the matrix cores
+    auto rank64 = [&](nd_v4d (&c)[4], const double* Xl) {           // c -= Xl X1^T on the matrix cores
 #pragma unroll 4
         for (int kq = 0; kq < KFT_B / 4; ++kq) {
-            const double av = -X0[(kq * KFT_B + 16 * w + (lane & 15)) * 4 + (lane >> 4)];
+            const double av = -Xl[(kq * KFT_B + 16 * wr + (lane & 15)) * 4 + (lane >> 4)];
             double bv[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) bv[n] = X1[(kq * KFT_B + 16 * n + (lane & 15)) * 4 + (lane >> 4)];
@@ -554,50 +563,83 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) out[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
+            for (int g = 0; g < 4; ++g) out[(16 * wr + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
     };
-    if (upP) {
+    if constexpr (HW) {
+        if (!helper) {
+            if (upP) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbj[2 * q], rbj[2 * q + 1]);
-            reinterpret_cast<double2*>(X1)[tid + 256 * q] = make_double2(rcj[2 * q], rcj[2 * q + 1]);
+                for (int q = 0; q < 8; ++q) {
+                    reinterpret_cast<double2*>(X0)[ht + 256 * q] = make_double2(rbj[2 * q], rbj[2 * q + 1]);
+                    reinterpret_cast<double2*>(X1)[ht + 256 * q] = make_double2(rcj[2 * q], rcj[2 * q + 1]);
+                }
+            }
+        } else if (upC) {                                           // (P's area is free until the sweep is over: this row's B panel)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) reinterpret_cast<double2*>(Ps)[ht + 256 * q] = make_double2(rbi[2 * q], rbi[2 * q + 1]);
         }
         __syncthreads();
-        rank64(cp);
-    }
-    if (!MF) to_lds(cp, Ps);                                        // (the 16-pivot sweep takes the block from the registers)
-    if (I != j) {
-        if (upC) {
-            __syncthreads();                                        // (every wave has read B_j from X0)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbi[2 * q], rbi[2 * q + 1]);
-            __syncthreads();
-            rank64(cc);
+        if (!helper) { if (upP) rank64(cp, X0); }
+        else {
+            if (upC) rank64(cc, Ps);
+            if (I != j) to_lds(cc, Cs);
         }
-        to_lds(cc, Cs);
+        __syncthreads();                                            // (X0 has been read: the sweep's scratch; C_I is in place)
+    } else {
+        if (upP) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbj[2 * q], rbj[2 * q + 1]);
+                reinterpret_cast<double2*>(X1)[tid + 256 * q] = make_double2(rcj[2 * q], rcj[2 * q + 1]);
+            }
+            __syncthreads();
+            rank64(cp, X0);
+        }
+        if (!MF) to_lds(cp, Ps);                                    // (the 16-pivot sweep takes the block from the registers)
+        if (I != j) {
+            if (upC) {
+                __syncthreads();                                    // (every wave has read B_j from X0)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) reinterpret_cast<double2*>(X0)[tid + 256 * q] = make_double2(rbi[2 * q], rbi[2 * q + 1]);
+                __syncthreads();
+                rank64(cc, X0);
+            }
+            to_lds(cc, Cs);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     double* Bb = F.Bb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     double* Cb = F.Cb + (size_t)(j & 1) * pbuf + ((size_t)ch * nb + I) * tile;
     if constexpr (MF) {
         KftTiles pc;
         pc.t0 = cp[0]; pc.t1 = cp[1]; pc.t2 = cp[2]; pc.t3 = cp[3];
-        const bool bad = kft_sweep64_blk(pc, X0, lane, w);           // (the operand panels are not needed any more)
-        if (bad && lane == 0) flags[2] = 1;
-        if (I == j) {
-            double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
+        if (!helper) {
+            const bool bad = kft_sweep64_blk(pc, X0, lane, w);       // (the operand panels are not needed any more)
+            if (bad && lane == 0) flags[2] = 1;
+        } else {
+            if (I != j)                                             // (C_I's packed copy for the next step's tiles goes out while the others sweep)
+                for (int q = ht; q < KFT_B * KFT_B; q += 256) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                double* pw = Pv + (16 * w + (lane >> 4) + 4 * g) * KFT_B + (lane & 15);
-                pw[0] = pc.t0[g]; pw[16] = pc.t1[g]; pw[32] = pc.t2[g]; pw[48] = pc.t3[g];
+            for (int q = 0; q < 4; ++q) __syncthreads();            // (the sweep's four: one per 16-pivot step)
+        }
+        if (I == j) {
+            if (!helper) {
+                double* Pv = F.Pv + ((size_t)(j & 1) * 2 + ch) * tile;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    double* pw = Pv + (16 * w + (lane >> 4) + 4 * g) * KFT_B + (lane & 15);
+                    pw[0] = pc.t0[g]; pw[16] = pc.t1[g]; pw[32] = pc.t2[g]; pw[48] = pc.t3[g];
+                }
             }
             return;                                                 // (its own B / C slots are never read: the trailing update skips the pivot row / column)
         }
         __syncthreads();
+        if (!helper) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {                               // P^-1
-            double* pw = Ps + (16 * w + (lane >> 4) + 4 * g) * KFT_LDP + (lane & 15);
-            pw[0] = -pc.t0[g]; pw[16] = -pc.t1[g]; pw[32] = -pc.t2[g]; pw[48] = -pc.t3[g];
+            for (int g = 0; g < 4; ++g) {                           // P^-1
+                double* pw = Ps + (16 * w + (lane >> 4) + 4 * g) * KFT_LDP + (lane & 15);
+                pw[0] = -pc.t0[g]; pw[16] = -pc.t1[g]; pw[32] = -pc.t2[g]; pw[48] = -pc.t3[g];
+            }
         }
     } else {
     double a[4][4];
@@ -621,30 +663,33 @@ __global__ __launch_bounds__(256) void k_kft_step(KftDev F, int j, int kf0, int 
 #pragma unroll
         for (int y = 0; y < 4; ++y) Ps[(4 * ti + x) * KFT_LDP + 4 * tj + y] = -a[x][y];   // P^-1
     }
-    for (int q = tid; q < KFT_B * KFT_B; q += 256) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
+    if (!HW)
+        for (int q = tid; q < KFT_B * KFT_B; q += NT) Cb[q] = Cs[((q >> 2) & 63) * KFT_LDP + 4 * (q >> 8) + (q & 3)];
     __syncthreads();
-    nd_v4d c[4];
+    if (!helper) {
+        nd_v4d c[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) c[n][g] = 0.0;
+            for (int g = 0; g < 4; ++g) c[n][g] = 0.0;
 #pragma unroll 4
-    for (int kq = 0; kq < KFT_B / 4; ++kq) {
-        const double av = Cs[(16 * w + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
-        double bv[4];
+        for (int kq = 0; kq < KFT_B / 4; ++kq) {
+            const double av = Cs[(16 * w + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
+            double bv[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bv[n] = Ps[(16 * n + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
+            for (int n = 0; n < 4; ++n) bv[n] = Ps[(16 * n + (lane & 15)) * KFT_LDP + 4 * kq + (lane >> 4)];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], c[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Cs[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];   // (a wave reads and writes its own sixteen rows)
     }
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Cs[(16 * w + (lane >> 4) + 4 * g) * KFT_LDP + 16 * n + (lane & 15)] = c[n][g];
     __syncthreads();
     double* Bt = A + (size_t)(KFT_B * I) * ld + KFT_B * j;
     double* Btt = A + (size_t)(KFT_B * j) * ld + KFT_B * I;
-    for (int q = tid; q < KFT_B * KFT_B; q += 256) {
+    for (int q = tid; q < KFT_B * KFT_B; q += NT) {
         const int r = q >> 6, cidx = q & 63;
         Bt[(size_t)r * ld + cidx] = Cs[r * KFT_LDP + cidx];
         Btt[(size_t)r * ld + cidx] = Cs[cidx * KFT_LDP + r];
@@ -794,7 +839,8 @@ static int kft_invert(nrs_ctx* c, const KftHost& H, int kf0, int kf1, int* flags
     const int nbu = std::max(kf0 >= 0 ? H.kf_nb[kf0] : 1, kf1 >= 0 ? H.kf_nb[kf1] : 1);
     for (int j = 0; j <= nbu; ++j)
         if (c->env("NRS_KFT_SCALAR_SWEEP")) hipLaunchKernelGGL(k_kft_step<false>, dim3(2 * (nbu + nbu * nbu)), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
-        else hipLaunchKernelGGL(k_kft_step<true>, dim3(2 * (nbu + nbu * nbu)), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        else if (c->env("NRS_KFT_FOUR_WAVES")) hipLaunchKernelGGL(k_kft_step<true>, dim3(2 * (nbu + nbu * nbu)), dim3(256), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
+        else hipLaunchKernelGGL((k_kft_step<true, true>), dim3(2 * (nbu + nbu * nbu)), dim3(512), KFT_STEP_LDS, c->stream, F, j, kf0, kf1, flags, nbu);
     return NRS_OK;
 }
 

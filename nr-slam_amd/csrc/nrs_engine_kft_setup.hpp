@@ -249,6 +249,7 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_PANEL_LDS));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
         NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
+        NRS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_kft_step<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KFT_STEP_LDS));
         attr_done = true;
     }
     H->bytes = off;

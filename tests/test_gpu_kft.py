@@ -115,11 +115,12 @@ def test_factorisation_is_bit_reproducible(ctx_emb_direct):
 def test_residual_test_after_the_first_step_gives_the_iterate_of_the_pcgs_own_test(ctx_emb_direct):
     """the PCG's first step with the factorisation as preconditioner is tested by its residual (k_kft_rnorm) instead of by r . M^-1 r an
     iteration later (NRS_KFT_NO_RESIDUAL_TEST=1): the same iterate, bit for bit, the same trials; and the sweep of the pivot block in
-    16-pivot steps against the 4-pivot register form (NRS_KFT_SCALAR_SWEEP=1): the same solve up to rounding"""
+    16-pivot steps against the 4-pivot register form (NRS_KFT_SCALAR_SWEEP=1): the same solve up to rounding; eight-wave panel workgroups
+    against four-wave ones (NRS_KFT_FOUR_WAVES=1): bit-identical"""
     c = ctx_emb_direct
     p, e, w, cam, qt, H, b = _setup(420, 5, 64, 83)
     out = []
-    for name in (None, "NRS_KFT_NO_RESIDUAL_TEST", "NRS_KFT_SCALAR_SWEEP"):
+    for name in (None, "NRS_KFT_NO_RESIDUAL_TEST", "NRS_KFT_SCALAR_SWEEP", "NRS_KFT_FOUR_WAVES"):
         if name:
             nrs.debug_set(name, "1")
         try:
@@ -131,5 +132,7 @@ def test_residual_test_after_the_first_step_gives_the_iterate_of_the_pcgs_own_te
         out.append((pq, xyz, sk, [(t["accepted"], t["chi"], t["chi_new"], t["lam"], t["inner"]) for t in tr.trials]))
     assert all(t[4] == 1 for t in out[0][3])                       # (one step per trial: the factorisation is exact)
     assert out[0][3] == out[1][3] and all(np.array_equal(a, b2) for a, b2 in zip(out[0][:3], out[1][:3]))
+    # a panel workgroup of eight waves (four take the C_I half of the look-ahead) against four: the same arithmetic, the same bits
+    assert out[0][3] == out[3][3] and all(np.array_equal(a, b2) for a, b2 in zip(out[0][:3], out[3][:3]))
     assert [t[0] for t in out[0][3]] == [t[0] for t in out[2][3]]
     assert np.allclose(out[0][0], out[2][0], atol=1e-9, rtol=0) and np.allclose(out[0][1], out[2][1], atol=1e-8, rtol=0)
