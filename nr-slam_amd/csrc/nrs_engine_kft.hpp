@@ -150,10 +150,13 @@ __global__ __launch_bounds__(256) void k_kft_pose(Dev P, KftDev F, double lam) {
     F.A[(size_t)k * F.ld * F.ld + (size_t)(3 * nf + p) * F.ld + 3 * nf + q] = P.Hpp[21 * k + pk] + (p == q ? lam : 0.0);
 }
 
-// one thread per unique same-keyframe node pair: the sum of its contributions in list order
+// KFT_PL lanes per unique same-keyframe node pair: a lane adds up every KFT_PL-th contribution of the pair's list in list order, the partial
+// sums meet in a fixed butterfly (bit-reproducible).  One thread per pair walked lists of ~50 skinned observations with dependent fetches of
+// their 27-double records: 183 us per LM trial at C2.
+constexpr int KFT_PL = 8;
 __global__ __launch_bounds__(256) void k_kft_pairs(Dev P, KftDev F) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= F.n_pp) return;
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t / KFT_PL, sub = t % KFT_PL;
+    if (i >= F.n_pp) return;                                        // (whole groups of KFT_PL lanes leave together: the butterfly below stays inside a group)
     const uint32_t id = F.pp_id[i];
     const int k = (int)(id >> 24), hi = (int)((id >> 12) & 0xFFFu), lo = (int)(id & 0xFFFu);
     const size_t rh = (size_t)F.kf_row[k * F.nfm + hi], rl = (size_t)F.kf_row[k * F.nfm + lo];
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_kft_pairs(Dev P, KftDev F) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) v[a] = (P.lin_xl[3 * rh + a] + (P.X0 ? P.X0[3 * rh + a] : 0.0)) - (P.lin_xl[3 * rl + a] + (P.X0 ? P.X0[3 * rl + a] : 0.0));
     double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = F.pp_ptr[i]; q < F.pp_ptr[i + 1]; ++q) {
+    for (int q = F.pp_ptr[i] + sub; q < F.pp_ptr[i + 1]; q += KFT_PL) {
         const uint32_t src = F.pe_src[q];
         const uint32_t type = src >> 30, idx = src & 0x3FFFFFFFu;
         if (type == 0) {                                           // spring: - qc v v^T
@@ -181,6 +184,11 @@ __global__ __launch_bounds__(256) void k_kft_pairs(Dev P, KftDev F) {
             b[6] += w * rec[2]; b[7] += w * rec[4]; b[8] += w * rec[5];
         }
     }
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int o = 1; o < KFT_PL; o <<= 1) b[a] += __shfl_xor(b[a], o, 64);
+    if (sub) return;
     double* A = F.A + (size_t)k * F.ld * F.ld;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -852,7 +860,7 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
     hipLaunchKernelGGL(k_kft_clear, dim3((unsigned)((n2 / 2 + 255) / 256), F.K), dim3(256), 0, c->stream, F);
     hipLaunchKernelGGL(k_kft_diag, dim3(d.n_rows / SK_RPB), dim3(BLK), 0, c->stream, d, F, lam);
     hipLaunchKernelGGL(k_kft_pose, dim3((36 * F.K + 255) / 256), dim3(256), 0, c->stream, d, F, lam);
-    if (F.n_pp) hipLaunchKernelGGL(k_kft_pairs, dim3((F.n_pp + 255) / 256), dim3(256), 0, c->stream, d, F);
+    if (F.n_pp) hipLaunchKernelGGL(k_kft_pairs, dim3((unsigned)(((size_t)F.n_pp * KFT_PL + 255) / 256)), dim3(256), 0, c->stream, d, F);
     if (F.n_tp) {
         hipLaunchKernelGGL(k_kft_tvals, dim3((F.n_tp + 255) / 256), dim3(256), 0, c->stream, d, F);
         hipLaunchKernelGGL(k_kft_clvals, dim3((F.n_tp + 255) / 256), dim3(256), 0, c->stream, F);

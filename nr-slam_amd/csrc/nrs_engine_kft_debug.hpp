@@ -38,7 +38,7 @@ int engine_kft_debug(nrs_ctx* c, Engine* e, double lam, int what, int k, const d
         hipLaunchKernelGGL(k_kft_clear, dim3((unsigned)((n2 / 2 + 255) / 256), F.K), dim3(256), 0, c->stream, F);
         hipLaunchKernelGGL(k_kft_diag, dim3(d.n_rows / SK_RPB), dim3(BLK), 0, c->stream, d, F, lam);
         hipLaunchKernelGGL(k_kft_pose, dim3((36 * F.K + 255) / 256), dim3(256), 0, c->stream, d, F, lam);
-        if (F.n_pp) hipLaunchKernelGGL(k_kft_pairs, dim3((F.n_pp + 255) / 256), dim3(256), 0, c->stream, d, F);
+        if (F.n_pp) hipLaunchKernelGGL(k_kft_pairs, dim3((unsigned)(((size_t)F.n_pp * KFT_PL + 255) / 256)), dim3(256), 0, c->stream, d, F);
         if (F.n_tp) hipLaunchKernelGGL(k_kft_tvals, dim3((F.n_tp + 255) / 256), dim3(256), 0, c->stream, d, F);
         NRS_HIP(c, hipStreamSynchronize(c->stream));
         if (what == 1) { NRS_HIP(c, hipMemcpy(out_d, F.A + (size_t)k * n2, 8 * n2, hipMemcpyDeviceToHost)); return NRS_OK; }
