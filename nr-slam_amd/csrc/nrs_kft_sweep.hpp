@@ -108,7 +108,12 @@ __device__ __forceinline__ void kft_sweep_blk_steps(KftTiles& c, double* xb, int
 #pragma unroll
         for (int s = 0; s < 4; ++s) rw[s] = R[(lk + 4 * s) * KFT_RS + 16 * w + lc];
         double mine = 1.0;
+#ifndef KFT_EXP_NOLDL                                              // (tools/micro/sweep_blk_probe.hip: the sweep without its chains, timing only)
         kft_ldl16<0>(a, wv, mine, lc, bad);
+#else
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wv[q] = a[q];
+#endif
         const double rs = kft_rsqrt(mine);
 #pragma unroll
         for (int q = 0; q < 16; ++q) wv[q] *= rs;                  // row lc of W

@@ -136,3 +136,20 @@ def test_residual_test_after_the_first_step_gives_the_iterate_of_the_pcgs_own_te
     assert out[0][3] == out[3][3] and all(np.array_equal(a, b2) for a, b2 in zip(out[0][:3], out[3][:3]))
     assert [t[0] for t in out[0][3]] == [t[0] for t in out[2][3]]
     assert np.allclose(out[0][0], out[2][0], atol=1e-9, rtol=0) and np.allclose(out[0][1], out[2][1], atol=1e-8, rtol=0)
+
+
+@pytest.mark.parametrize("n,k,m,seed", [(90, 2, 8, 93), (200, 6, 21, 94), (400, 9, 45, 95)])
+def test_single_block_and_mixed_block_counts(ctx_emb_direct, n, k, m, seed):
+    """keyframe blocks of ONE 64-pivot block (a sweep step without trailing tiles) and windows whose keyframes need different block counts
+    (40 .. 43 node copies: 126 .. 135 unknowns, two or three blocks -- the two chains of a step then sweep different counts): M^-1 (H + lam I) x = x"""
+    c = ctx_emb_direct
+    p, e, w, cam, qt, H, b = _setup(n, k, m, seed)
+    c.dba_upload_embedded(cam, qt, w, e, p["scale"])
+    info = c.debug_kft_info()
+    assert info["on"] and info["K"] == k
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1, H.shape[0])
+    for scl in (1e-5, 1e-7):
+        lam = scl * np.abs(H.diagonal()).max()
+        u = c.debug_kft_apply(lam, H @ x + lam * x)
+        assert np.linalg.norm(u - x) <= (1e-7 if scl == 1e-5 else 1e-5) * np.linalg.norm(x)
