@@ -712,20 +712,39 @@ __global__ __launch_bounds__(256) void k_kft_gct(KftDev F, int f0, int f1) {
     const int ch = blockIdx.z, f = ch ? f1 : f0;
     if (f < 0) return;
     const int t = ch ? f - 1 : f + 1, dir = ch;
-    const int col = blockIdx.y, b = col / 3, comp = col % 3;
+    // a thread takes the three components of a 'to' node at once: the launch is bound by the dependent chain list entry -> row of G, not by
+    // bytes -- one column (node, component) a workgroup: 43 us; three accumulators a thread and two list entries in flight: a third of the workgroups
+    const int b = blockIdx.y;
     if (b >= F.kf_nf[t]) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= F.ld) return;
-    const double* G = F.A + (size_t)f * F.ld * F.ld;
+    const int ld = F.ld;
+    const double* G = F.A + (size_t)f * ld * ld + i;
     const int* ptr = F.cl_ptr[dir] + (size_t)t * (F.nfm + 1);
-    double acc = 0;
-    for (int e = ptr[b]; e < ptr[b + 1]; ++e) acc += F.cl_val[dir][e] * G[(size_t)(3 * F.cl_from[dir][e] + comp) * F.ld + i];
-    F.YT[((size_t)ch * F.ld + col) * F.ld + i] = acc;
+    const int e0 = ptr[b], e1 = ptr[b + 1];
+    double a0 = 0, a1 = 0, a2 = 0;
+    int e = e0;
+    for (; e + 1 < e1; e += 2) {                                    // (sums in list order)
+        const double v0 = F.cl_val[dir][e], v1 = F.cl_val[dir][e + 1];
+        const double* g0 = G + (size_t)(3 * F.cl_from[dir][e]) * ld;
+        const double* g1 = G + (size_t)(3 * F.cl_from[dir][e + 1]) * ld;
+        const double x0 = g0[0], x1 = g0[ld], x2 = g0[2 * (size_t)ld], y0 = g1[0], y1 = g1[ld], y2 = g1[2 * (size_t)ld];
+        a0 += v0 * x0; a1 += v0 * x1; a2 += v0 * x2;
+        a0 += v1 * y0; a1 += v1 * y1; a2 += v1 * y2;
+    }
+    if (e < e1) {
+        const double v0 = F.cl_val[dir][e];
+        const double* g0 = G + (size_t)(3 * F.cl_from[dir][e]) * ld;
+        a0 += v0 * g0[0]; a1 += v0 * g0[ld]; a2 += v0 * g0[2 * (size_t)ld];
+    }
+    double* Y = F.YT + ((size_t)ch * ld + 3 * b) * ld + i;
+    Y[0] = a0; Y[ld] = a1; Y[2 * (size_t)ld] = a2;
 }
 // one workgroup per KFT_TC columns of S_to: their YT rows in LDS, a thread per 'to' node -- its list is read once for all the columns
 // and its three components
 constexpr int KFT_TC = 4;
-__global__ __launch_bounds__(256) void k_kft_tgt(KftDev F, int f0, int f1) {
+constexpr int KFT_TGT_NT = 512;      // (a keyframe's ~460 nodes in one pass)
+__global__ __launch_bounds__(KFT_TGT_NT) void k_kft_tgt(KftDev F, int f0, int f1) {
     extern __shared__ double yrow[];
     const int ch = blockIdx.y, f = ch ? f1 : f0;
     if (f < 0) return;
@@ -735,15 +754,28 @@ __global__ __launch_bounds__(256) void k_kft_tgt(KftDev F, int f0, int f1) {
     if (col0 >= 3 * nft) return;
     const int nc = min(KFT_TC, 3 * nft - col0);
     const double* Y = F.YT + ((size_t)ch * ld + col0) * ld;
-    for (int i = threadIdx.x; i < nc * ld; i += 256) yrow[i] = Y[i];
+    for (int i = threadIdx.x; i < nc * ld; i += KFT_TGT_NT) yrow[i] = Y[i];
     __syncthreads();
     const int* ptr = F.cl_ptr[dir] + (size_t)t * (F.nfm + 1);
     double* S = F.A + (size_t)t * ld * ld + (size_t)col0 * ld;
-    for (int b = threadIdx.x; b < nft; b += 256) {
+    for (int b = threadIdx.x; b < nft; b += KFT_TGT_NT) {
         double acc[KFT_TC][3];
 #pragma unroll
         for (int q = 0; q < KFT_TC; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
-        for (int e = ptr[b]; e < ptr[b + 1]; ++e) {
+        const int e0 = ptr[b], e1 = ptr[b + 1];
+        int e = e0;
+        for (; e + 1 < e1; e += 2) {                                // (two list entries in flight; sums in list order)
+            const double v = F.cl_val[dir][e], v2 = F.cl_val[dir][e + 1];
+            const int o = 3 * F.cl_from[dir][e], o2 = 3 * F.cl_from[dir][e + 1];
+#pragma unroll
+            for (int q = 0; q < KFT_TC; ++q) {
+                const double* y = yrow + q * ld + o;
+                const double* y2 = yrow + q * ld + o2;
+                acc[q][0] += v * y[0]; acc[q][1] += v * y[1]; acc[q][2] += v * y[2];
+                acc[q][0] += v2 * y2[0]; acc[q][1] += v2 * y2[1]; acc[q][2] += v2 * y2[2];
+            }
+        }
+        if (e < e1) {
             const double v = F.cl_val[dir][e];
             const int o = 3 * F.cl_from[dir][e];
 #pragma unroll
@@ -869,13 +901,13 @@ static int kft_factor(nrs_ctx* c, Engine* e, KftHost* H, double lam) {
     for (int s = 0; s < std::max(len0, len1); ++s) {
         const int k0 = s < len0 ? s : -1, k1 = s < len1 ? F.K - 1 - s : -1;
         NRS_TRY(kft_invert(c, *H, k0, k1, d.flags));
-        const dim3 g((F.ld + 255) / 256, F.ld, 2), g2((F.ld + KFT_TC - 1) / KFT_TC, 2);
+        const dim3 g((F.ld + 255) / 256, F.nfm, 2), g2((F.ld + KFT_TC - 1) / KFT_TC, 2);
         const size_t shy = sizeof(double) * KFT_TC * F.ld;
         hipLaunchKernelGGL(k_kft_gct, g, dim3(256), 0, c->stream, F, k0, k1);
         if (k0 >= 0 && k1 >= 0 && k0 + 1 == k1 - 1) {              // both chains reach the middle keyframe: one after the other (fixed order)
-            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, -1);
-            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, -1, k1);
-        } else hipLaunchKernelGGL(k_kft_tgt, g2, dim3(256), shy, c->stream, F, k0, k1);
+            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(KFT_TGT_NT), shy, c->stream, F, k0, -1);
+            hipLaunchKernelGGL(k_kft_tgt, g2, dim3(KFT_TGT_NT), shy, c->stream, F, -1, k1);
+        } else hipLaunchKernelGGL(k_kft_tgt, g2, dim3(KFT_TGT_NT), shy, c->stream, F, k0, k1);
     }
     NRS_TRY(kft_invert(c, *H, F.m, -1, d.flags));
     NRS_HIP(c, hipGetLastError());
