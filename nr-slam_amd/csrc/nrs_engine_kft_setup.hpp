@@ -35,10 +35,10 @@ static int kft_setup(nrs_ctx* c, Engine* e, const EngineSpec& s, const std::vect
         // profiles/r06_kft_crossover.txt): the factorisation is ceil(K / 2) dependent inversions of nb + 1 launches, (16.5 + 0.72 nb) us a launch
         // (the panel workgroup's path: sweep, look-ahead, tile I/O), + 0.05 K ms per trial (assembly, Schur updates,
         // one pass over the chains); the block-Jacobi PCG took 14 ms (K / 20)^0.45 per trial whatever the node count.  Measured on 20 keyframes:
-        // 7.5 x the PCG's rate at 100 nodes per keyframe, 4.7 x at 200, 3.2 x at 300, 2.2 x at 400, 1.55 x at 458 (C2: 114 against 73 LM
-        // iterations / s); 2.2 x at 458 x 10 keyframes.  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
+        // 7.8 x the PCG's rate at 100 nodes per keyframe, 4.8 x at 200, 3.3 x at 300, 2.3 x at 400, 1.6 x at 458 (C2: 118 against 73 LM
+        // iterations / s); 2.3 x at 458 x 10 keyframes.  A heuristic of this scene family: nrs_options.embedded_solver = 1 / 2 decide.
         // Beyond ~550 nodes per keyframe the launch is bound by its nb^2 tiles, (9 + 0.045 nb^2) us, and the PCG's trial grows by 16 us a node:
-        // 600 nodes x 20 keyframes 88.2 against 62.5 LM iterations / s, 700 nodes 58.6 against 58.0 (the crossover), 600 x 10 keyframes 161 against 136.
+        // 600 nodes x 20 keyframes 91.4 against 62.6 LM iterations / s, 700 nodes 60.4 against 57.8 (the crossover), 600 x 10 keyframes 165 against 134.
         const double launch_us = std::max(16.5 + 0.72 * nb, 9.0 + 0.045 * nb * nb);
         const double kft_ms = ((K + 1) / 2) * (nb + 1.0) * launch_us * 1e-3 + 0.05 * K, pcg_ms = (14.0 + 0.016 * std::max(0, nf_max - 500)) * std::pow(K / 20.0, 0.45);
         if (kft_ms > pcg_ms) return NRS_OK;
