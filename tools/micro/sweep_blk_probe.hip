@@ -1,5 +1,5 @@
 // The 64 x 64 pivot-block sweep of the keyframe-block factorisation (csrc/nrs_kft_sweep.hpp) alone: result against a host inverse, cycles per sweep.
-//   hipcc --offload-arch=gfx950 -O3 -I nr-slam_amd/csrc tools/micro/sweep_blk_probe.hip -o /tmp/sweep_probe && /tmp/sweep_probe [scale] [real rows] [decay] [rank] [eps]
+//   hipcc --offload-arch=gfx950 -O3 -I nr-slam_amd/csrc -I tools/micro tools/micro/sweep_blk_probe.hip -o /tmp/sweep_probe && /tmp/sweep_probe [scale] [real rows] [decay] [rank] [eps]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +15,7 @@ __device__ inline void nd_fmacn_bcast(double& a, double ls, double l) {
 }
 constexpr int KFT_B = 64;
 #include "nrs_kft_sweep.hpp"
+#include "kft_sweep_chain_exp.hpp"
 }  // namespace nrs
 using namespace nrs;
 
@@ -40,6 +41,51 @@ __global__ __launch_bounds__(256) void k_probe(const double* A, double* out, lon
     for (int g = 0; g < 4; ++g) {
         double* o = out + (16 * w + (lane >> 4) + 4 * g) * 64 + (lane & 15);
         o[0] = c.t0[g]; o[16] = c.t1[g]; o[32] = c.t2[g]; o[48] = c.t3[g];
+    }
+    if (tid == 0) { *cyc = t / reps; *badf = bad; }
+}
+
+__global__ __launch_bounds__(512) void k_probe_chain(const double* A, double* out, long long* cyc, int* badf, int reps) {
+    __shared__ double xb[KFT_CHAIN_XB + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wphys = tid >> 6;
+#ifdef CHAIN_ALONE                                                 // the chain wave alone on its SIMD: rows 0 on wave 5 (SIMD 1 holds two main waves), wave 0 idle
+    const int w = wphys == 5 ? 0 : wphys == 0 ? 7 : wphys == 7 ? 5 : wphys;
+#else
+    const int w = wphys;
+#endif
+    KftTiles c;
+    long long t = 0;
+    int bad = 0;
+    for (int r = 0; r < reps; ++r) {
+        if (w < 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double* a = A + (16 * w + (lane >> 4) + 4 * g) * 64 + (lane & 15);
+                c.t0[g] = a[0]; c.t1[g] = a[16]; c.t2[g] = a[32]; c.t3[g] = a[48];
+            }
+        }
+        __syncthreads();
+        const long long t0 = clock64();
+        kft_sweep64_chain(c, xb, lane, w);
+        __syncthreads();
+        t += clock64() - t0;
+#ifdef KFT_EXP_STAMPS
+        if (tid == 0 && r == reps - 1) {
+            const long long* st = reinterpret_cast<const long long*>(xb + KFT_CHAIN_XB);
+            printf("chain wave: entry +0, LDL start / end of the four blocks (cycles after entry):");
+            for (int q = 0; q < 8; ++q) printf(" %lld", st[q] - t0);
+            printf(", sweep end %lld\n", clock64() - t0);
+        }
+#endif
+        bad |= kft_chain_bad(xb);
+        __syncthreads();
+    }
+    if (w < 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            double* o = out + (16 * w + (lane >> 4) + 4 * g) * 64 + (lane & 15);
+            o[0] = c.t0[g]; o[16] = c.t1[g]; o[32] = c.t2[g]; o[48] = c.t3[g];
+        }
     }
     if (tid == 0) { *cyc = t / reps; *badf = bad; }
 }
@@ -114,6 +160,21 @@ int main(int argc, char** argv) {
             if (fabs(O[i * n + j] + r) > err) { err = fabs(O[i * n + j] + r); wi = i; wj = j; }
         }
     printf("sweep64_blk: max |c + A^-1| / max |A^-1| = %.3e (at %d, %d), bad %d, %lld clock64 ticks per sweep (s_memtime, 100 MHz)\n", err / mx, wi, wj, bad, cyc);
+    {   // the chain-wave form (eight waves): bit-identical result expected
+        std::vector<double> O2(n * n);
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_probe_chain, dim3(1), dim3(512), 0, 0, dA, dO, dC, dB, pass ? 2000 : 1);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        hipMemcpy(O2.data(), dO, 8 * n * n, hipMemcpyDeviceToHost);
+        hipMemcpy(&cyc, dC, 8, hipMemcpyDeviceToHost); hipMemcpy(&bad, dB, 4, hipMemcpyDeviceToHost);
+        int ndiff = 0;
+        for (int i = 0; i < n * n; ++i) ndiff += O2[i] != O[i];
+        printf("sweep64_chain: %.2f us per {load block, sweep}, %lld ticks per sweep, bad %d, %d of %d entries differ from sweep64_blk\n", 1e3 * ms / 2000, cyc, bad, ndiff, n * n);
+    }
     // per 16 x 16 tile error map
     for (int ti = 0; ti < 4; ++ti) {
         for (int tj = 0; tj < 4; ++tj) {
